@@ -1,0 +1,194 @@
+/*
+ * sdhip.h -- C ABI of libsdhip.so: the MI355X (gfx950) implementation of SatDump's
+ * baseband -> soft symbols -> Viterbi -> deframe -> derand -> RS -> CADU hot path.
+ *
+ * This is the drop-in boundary. The thin C++ pipeline modules in plugin/ (subclasses of
+ * the reference's satdump::pipeline::ProcessingModule, src-core/pipeline/module.h:58-191)
+ * call ONLY these entry points; so does the Python binding used by tests/ and bench.py.
+ * Plain pointers and sizes, no C++ / torch types, int return codes (0 = ok, <0 = error,
+ * message via sdhip_last_error()), no exceptions cross this boundary.
+ *
+ * One handle = one stream. A handle is not thread safe; different handles may be used
+ * concurrently (one per GPU / per stream). The library owns all device memory.
+ *
+ * Every struct field mirrors a JSON key of the reference module it replaces:
+ *   sdhip_demod_cfg  <- "psk_demod"                 src-core/pipeline/modules/demod/module_psk_demod.cpp:12-84,
+ *                                                   module_demod_base.cpp:12-57, module_psk_demod.h:31-39
+ *   sdhip_fec_cfg    <- "ccsds_conv_concat_decoder" src-core/pipeline/modules/ccsds/module_ccsds_conv_concat_decoder.cpp:16-38
+ *                       "metop_ahrpt_decoder"       plugins/noaa_metop_support/metop/module_metop_ahrpt_decoder.cpp:17-28
+ */
+#ifndef SDHIP_H
+#define SDHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C"
+{
+#endif
+
+    /* ---- enums ---------------------------------------------------------------------- */
+    enum
+    {
+        SDHIP_BPSK = 0,    /* "bpsk"    */
+        SDHIP_BPSK_90 = 1, /* "bpsk_90" (decoder only) */
+        SDHIP_QPSK = 2,    /* "qpsk"    */
+        SDHIP_OQPSK = 3,   /* "oqpsk"   */
+        SDHIP_8PSK = 4     /* "8psk" (demod only) */
+    };
+    enum
+    {
+        SDHIP_RS_NONE = 0,
+        SDHIP_RS223 = 1, /* "rs223" */
+        SDHIP_RS239 = 2  /* "rs239" */
+    };
+    enum
+    {
+        SDHIP_FMT_CF32 = 0, /* baseband_format "cf32" / "f32" : raw read, baseband_interface.h:172-174 */
+        SDHIP_FMT_CS16 = 1, /* "cs16" / "s16" : x * (1/32767), baseband_interface.h:176-180 */
+        SDHIP_FMT_CS8 = 2,  /* "cs8"  / "s8"  : x * (1/127),   baseband_interface.h:181-185 */
+        SDHIP_FMT_CU8 = 3   /* "cu8"  / "u8"  : (x - 127.4) * (1/128), baseband_interface.h:191-199 */
+    };
+    enum
+    {
+        SDHIP_DEC_CONV_CONCAT = 0, /* ccsds_conv_concat_decoder: Viterbi1_2 r=1/2 */
+        SDHIP_DEC_METOP_AHRPT = 1  /* metop_ahrpt_decoder: Viterbi3_4 (MetOp puncture), deframer SYNCED=18, Viterbi watchdog */
+    };
+
+    /* ---- psk_demod ------------------------------------------------------------------- */
+    typedef struct sdhip_demod_cfg
+    {
+        /* reference json keys */
+        double samplerate;                /* "samplerate" (mandatory) */
+        double symbolrate;                /* "symbolrate" */
+        int constellation;                /* "constellation": SDHIP_BPSK / QPSK / OQPSK / 8PSK */
+        float rrc_alpha;                  /* "rrc_alpha" (mandatory) */
+        int rrc_taps;                     /* "rrc_taps", default 31 (forced odd, firdes.cpp:36) */
+        float pll_bw;                     /* "pll_bw" (mandatory) */
+        float agc_rate;                   /* "agc_rate", default 1e-2 */
+        int dc_block;                     /* "dc_block", default 0 */
+        int iq_swap;                      /* "iq_swap", default 0 */
+        float min_sps, max_sps;           /* "min_sps"/"max_sps", default 1.1 / 4.0 */
+        float clock_gain_omega;           /* default (8.7e-3)^2/4 */
+        float clock_mu;                   /* default 0.5 */
+        float clock_gain_mu;              /* default 8.7e-3 */
+        float clock_omega_relative_limit; /* default 0.005 */
+        float costas_max_offset_hz;       /* "costas_max_offset" in Hz; <=0 -> 1.0 rad/sample */
+        int buffer_size;                  /* "buffer_size"; <=0 -> reference default (module_demod_base.cpp:22-25) */
+        /* engine knobs (ours; no reference equivalent) */
+        int exact;     /* 1: one sequential lane per stream, bit-for-bit the reference schedule (slow; parity tests) */
+        int chunk_len; /* speculative chunk length in (resampled) samples; <=0 -> auto */
+        int warmup;    /* warm-up overlap per chunk in samples; <=0 -> auto */
+        int device;    /* HIP device ordinal */
+    } sdhip_demod_cfg;
+
+    typedef struct sdhip_demod_stats
+    {
+        uint64_t samples_in;   /* input samples consumed */
+        uint64_t symbols_out;  /* symbols produced */
+        float freq_hz;         /* Costas frequency, rad_to_hz(freq, final_samplerate) ("freq" stat) */
+        float final_sps;       /* samples per symbol after the resample decision */
+        float final_samplerate;
+        int buffer_size;       /* effective d_buffer_size */
+        int resample_interp, resample_decim; /* 0,0 when not resampling */
+        uint32_t chunks;        /* speculative chunks processed by the last call */
+        uint32_t chunks_fixed;  /* chunks re-run because the boundary certificate failed */
+        uint32_t chunks_rotated;/* chunks whose Costas quadrant was corrected against the left neighbour */
+    } sdhip_demod_stats;
+
+    void sdhip_demod_cfg_default(sdhip_demod_cfg *cfg);
+    /* returns NULL on error */
+    void *sdhip_demod_create(const sdhip_demod_cfg *cfg);
+    void sdhip_demod_destroy(void *h);
+    /* Host-buffer path: append nsamples complex samples in format fmt (SDHIP_FMT_*). Processing is
+       deferred until enough samples are pending or sdhip_demod_flush() is called. */
+    int sdhip_demod_push(void *h, const void *iq, size_t nsamples, int fmt);
+    /* Process everything pending, including the final partial chunk. */
+    int sdhip_demod_flush(void *h);
+    /* Pop up to cap soft-symbol BYTES (int8; BPSK 1 B/symbol = I*50, others 2 B/symbol = I*100,Q*100,
+       module_psk_demod.cpp:199-213). Returns the number of bytes written, <0 on error. */
+    int64_t sdhip_demod_pull(void *h, int8_t *soft, size_t cap);
+    /* Device-resident path: d_iq points to nsamples complex samples ALREADY IN HBM on cfg->device;
+       soft symbols are written to d_soft (device, capacity soft_cap bytes). If d_syms != NULL the float
+       symbols (2 floats each) are also written (capacity syms_cap symbols). `final` != 0 also drains the
+       tail. Returns soft bytes written, <0 on error. Stream state carries across calls. */
+    int64_t sdhip_demod_process_dev(void *h, const void *d_iq, size_t nsamples, int fmt, int8_t *d_soft, size_t soft_cap, float *d_syms, size_t syms_cap, int final);
+    int sdhip_demod_get_stats(void *h, sdhip_demod_stats *st);
+
+    /* ---- ccsds_conv_concat_decoder / metop_ahrpt_decoder ------------------------------ */
+    typedef struct sdhip_fec_cfg
+    {
+        int decoder;               /* SDHIP_DEC_* */
+        int constellation;         /* "constellation": bpsk / bpsk_90 / qpsk / oqpsk */
+        int iq_invert;             /* "iq_invert" */
+        int cadu_size;             /* "cadu_size" in BITS incl. ASM */
+        int viterbi_outsync_after; /* "viterbi_outsync_after" */
+        float viterbi_ber_thresold;/* "viterbi_ber_thresold" (sic) */
+        int nrzm;                  /* "nrzm" */
+        int derandomize;           /* "derandomize", default 1 */
+        int derand_after_rs;       /* "derand_after_rs", default 0 */
+        int derand_start;          /* "derand_start", default 4 */
+        int rs_i;                  /* "rs_i"; 0 disables RS */
+        int rs_fill_bytes;         /* "rs_fill_bytes", default -1 */
+        int rs_dualbasis;          /* "rs_dualbasis", default 1 */
+        int rs_type;               /* SDHIP_RS_* ("rs_type") */
+        int rs_usecheck;           /* "rs_usecheck" */
+        uint32_t asm_sync;         /* "asm", default 0x1ACFFC1D */
+        /* engine knobs */
+        int device;
+    } sdhip_fec_cfg;
+
+    typedef struct sdhip_fec_stats
+    {
+        uint64_t soft_in;        /* soft bytes consumed */
+        uint64_t blocks;         /* Viterbi blocks processed */
+        uint64_t bits_decoded;   /* Viterbi output bits fed to the deframer */
+        uint64_t frames_deframed;/* frames emitted by the deframer */
+        uint64_t frames_out;     /* frames written (after rs_usecheck) */
+        float viterbi_ber;       /* "viterbi_ber" */
+        int viterbi_lock;        /* "viterbi_lock": 0 NOSYNC, 1 SYNCED */
+        int deframer_state;      /* numeric threshold state: 2 NOSYNC, 6 SYNCING, 12/18 SYNCED */
+        int rs_errors[8];        /* last frame's per-codeword error counts (-1 = uncorrectable) */
+        uint32_t vit_respec;     /* Viterbi blocks re-decoded because the start-state speculation failed */
+        uint32_t tb_respec;      /* traceback segments re-run because the merge certificate failed */
+    } sdhip_fec_stats;
+
+    void sdhip_fec_cfg_default(sdhip_fec_cfg *cfg);
+    void *sdhip_fec_create(const sdhip_fec_cfg *cfg);
+    void sdhip_fec_destroy(void *h);
+    /* Host-buffer path: append n soft bytes (the .soft wire format). Whole Viterbi blocks
+       (max(cadu_size,8192) bytes, 16384 for MetOp) are decoded; the remainder stays pending. */
+    int sdhip_fec_push(void *h, const int8_t *soft, size_t n);
+    /* Pop up to cap_frames CADUs (ceil(cadu_size/8) bytes each) into cadu. Returns frame count. */
+    int64_t sdhip_fec_pull(void *h, uint8_t *cadu, size_t cap_frames);
+    /* Device-resident path: d_soft holds n soft bytes in HBM; CADUs are written to d_cadu (device,
+       capacity cap_frames frames). Returns frames written, <0 on error. */
+    int64_t sdhip_fec_process_dev(void *h, const int8_t *d_soft, size_t n, uint8_t *d_cadu, size_t cap_frames);
+    int sdhip_fec_get_stats(void *h, sdhip_fec_stats *st);
+    /* Optional per-block taps of the last process call (host arrays, may be NULL):
+       blk_ber[nblocks], blk_state[nblocks]. Returns number of blocks. */
+    int64_t sdhip_fec_get_block_taps(void *h, float *blk_ber, int *blk_state, size_t cap);
+
+    /* ---- kernel-level entry points (unit parity tests; each replaces one reference function) ---- */
+    /* viterbi::CCDecoder::work chained over nblocks (cc_decoder.cpp:295-302). d_syms: per block
+       2*(frame_bits+6) unsigned soft symbols (device). d_out: frame_bits bytes/block, one bit per byte. */
+    int sdhip_op_ccdecoder(int device, int frame_bits, const uint8_t *d_syms, int nblocks, uint8_t *d_out);
+    /* reedsolomon::ReedSolomon::decode_interlaved over nframes (reedsolomon.cpp:53-116). d_data points at
+       the first codeblock byte of frame 0 (cadu+4); errors: nframes*I ints (device). fill_bytes as in the reference. */
+    int sdhip_op_rs_decode(int device, uint8_t *d_data, int nframes, int frame_stride, int dualbasis, int I, int rs_type, int fill_bytes, int *d_errors);
+    /* dsp blocks over one stream, EXACT sequential semantics (single lane), for arithmetic parity:
+       kind 0 AGC(rate,ref,gain,max) agc.cpp:25-39 | 1 RRC FIR(fs,symrate,alpha,ntaps) fir.cpp:74-83 |
+       2 Costas(bw,order,limit) costas_loop.cpp:23-65 | 3 MM(omega,gw,mu,gmu,lim) clock_recovery_mm.cpp:52-121 |
+       4 rational resampler(interp,decim) rational_resampler.cpp:43-64. Returns output sample count. */
+    int64_t sdhip_op_block(int device, int kind, const float *params, const float *d_in, size_t n, float *d_out, size_t out_cap);
+
+    /* ---- misc ------------------------------------------------------------------------ */
+    const char *sdhip_last_error(void);
+    const char *sdhip_version(void);
+    int sdhip_device_count(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SDHIP_H */

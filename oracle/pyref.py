@@ -1,0 +1,227 @@
+"""ctypes loader for the CPU checkers under oracle/ -- TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+  * oracle/_ref/libsdref.so       = the reference's own sources compiled in place (oracle/Makefile `ref`)
+  * oracle/_build/libsdoracle.so  = our plain-C restatement (oracle/sd_oracle.c)
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+class DemodCfg(C.Structure):
+    _fields_ = [
+        ("samplerate", C.c_double), ("symbolrate", C.c_double), ("constellation", C.c_int), ("rrc_alpha", C.c_float),
+        ("rrc_taps", C.c_int), ("pll_bw", C.c_float), ("agc_rate", C.c_float), ("dc_block", C.c_int), ("iq_swap", C.c_int),
+        ("min_sps", C.c_float), ("max_sps", C.c_float), ("clock_gain_omega", C.c_float), ("clock_mu", C.c_float),
+        ("clock_gain_mu", C.c_float), ("clock_omega_relative_limit", C.c_float), ("costas_max_offset_hz", C.c_float),
+        ("buffer_size", C.c_int), ("exact", C.c_int), ("chunk_len", C.c_int), ("warmup", C.c_int), ("device", C.c_int),
+    ]
+
+
+class FecCfg(C.Structure):
+    _fields_ = [
+        ("decoder", C.c_int), ("constellation", C.c_int), ("iq_invert", C.c_int), ("cadu_size", C.c_int),
+        ("viterbi_outsync_after", C.c_int), ("viterbi_ber_thresold", C.c_float), ("nrzm", C.c_int), ("derandomize", C.c_int),
+        ("derand_after_rs", C.c_int), ("derand_start", C.c_int), ("rs_i", C.c_int), ("rs_fill_bytes", C.c_int),
+        ("rs_dualbasis", C.c_int), ("rs_type", C.c_int), ("rs_usecheck", C.c_int), ("asm_sync", C.c_uint32), ("device", C.c_int),
+    ]
+
+
+BPSK, BPSK_90, QPSK, OQPSK, PSK8 = 0, 1, 2, 3, 4
+RS_NONE, RS223, RS239 = 0, 1, 2
+
+
+def demod_cfg(**kw) -> DemodCfg:
+    c = DemodCfg()
+    c.samplerate = 6e6
+    c.symbolrate = 2333333
+    c.constellation = QPSK
+    c.rrc_alpha = 0.5
+    c.rrc_taps = 31
+    c.pll_bw = 0.003
+    c.agc_rate = 1e-2
+    c.min_sps, c.max_sps = 1.1, 4.0
+    c.clock_gain_omega = np.float32(8.7e-3 ** 2 / 4.0)
+    c.clock_mu = 0.5
+    c.clock_gain_mu = np.float32(8.7e-3)
+    c.clock_omega_relative_limit = 0.005
+    c.costas_max_offset_hz = 0.0
+    c.buffer_size = 0
+    for k, v in kw.items():
+        setattr(c, k, v)
+    return c
+
+
+def fec_cfg(**kw) -> FecCfg:
+    c = FecCfg()
+    c.decoder = 0
+    c.constellation = BPSK
+    c.cadu_size = 8192
+    c.viterbi_outsync_after = 20
+    c.viterbi_ber_thresold = 0.3
+    c.derandomize = 1
+    c.derand_start = 4
+    c.rs_i = 4
+    c.rs_fill_bytes = -1
+    c.rs_dualbasis = 1
+    c.rs_type = RS223
+    c.asm_sync = 0x1ACFFC1D
+    for k, v in kw.items():
+        setattr(c, k, v)
+    return c
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+class _Lib:
+    def __init__(self, path):
+        self.path = path
+        self.lib = C.CDLL(path)
+
+
+_ref = None
+
+
+def ref_available() -> bool:
+    return os.path.exists(os.path.join(_HERE, "_ref", "libsdref.so"))
+
+
+def ref():
+    """The compiled REFERENCE (oracle/_ref/libsdref.so)."""
+    global _ref
+    if _ref is None:
+        _ref = Ref(os.path.join(_HERE, "_ref", "libsdref.so"))
+    return _ref
+
+
+class Ref(_Lib):
+    def __init__(self, path):
+        super().__init__(path)
+        L = self.lib
+        L.sdref_concat_decode.restype = C.c_int64
+        L.sdref_metop_decode.restype = C.c_int64
+        L.sdref_block_run.restype = C.c_int64
+        L.sdref_psk_demod.restype = C.c_int64
+        L.sdref_metop_decode.argtypes = [C.c_float, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
+                                         C.c_void_p, C.c_void_p, C.c_void_p]
+        L.sdref_block_run.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_int64]
+        L.sdref_rrc_taps.argtypes = [C.c_double, C.c_double, C.c_double, C.c_double, C.c_int, C.c_void_p]
+        L.sdref_deframer.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_uint32, C.c_int, C.c_void_p, C.c_int64]
+
+    # ---- unit level
+    def ccdecoder(self, frame_bits: int, syms: np.ndarray) -> np.ndarray:
+        stride = 2 * (frame_bits + 6)
+        nb = len(syms) // stride
+        out = np.zeros(nb * frame_bits, dtype=np.uint8)
+        s = np.ascontiguousarray(syms, dtype=np.uint8)
+        self.lib.sdref_ccdecoder(C.c_int(frame_bits), _p(s), C.c_int(nb), _p(out))
+        return out
+
+    def ccencode(self, bits: np.ndarray) -> np.ndarray:
+        b = np.ascontiguousarray(bits, dtype=np.uint8)
+        out = np.zeros(2 * len(b), dtype=np.uint8)
+        self.lib.sdref_ccencode(_p(b), C.c_int(len(b)), _p(out))
+        return out
+
+    def rs_decode(self, frames: np.ndarray, I=4, dualbasis=True, rs239=False, fill_bytes=-1, offset=4):
+        """frames [n, bytes] uint8 -> (decoded copy, errors [n, I]). Codeblock starts at `offset`."""
+        f = np.ascontiguousarray(frames, dtype=np.uint8).copy()
+        n, stride = f.shape
+        pad = np.zeros((n, stride + 8), dtype=np.uint8)  # room for the fill_bytes=-1 overrun
+        pad[:, :stride] = f
+        err = np.zeros((n, I), dtype=np.int32)
+        base = pad.ctypes.data + offset
+        self.lib.sdref_rs_decode(C.c_void_p(base), C.c_int(n), C.c_int(stride + 8), C.c_int(int(dualbasis)), C.c_int(I),
+                                 C.c_int(int(rs239)), C.c_int(fill_bytes), _p(err))
+        return pad[:, :stride].copy(), err
+
+    def deframer(self, bits: np.ndarray, chunk=4096, cadu_size=8192, asm=0x1ACFFC1D, state_synced=12):
+        b = np.ascontiguousarray(bits, dtype=np.uint8)
+        cap = len(b) // cadu_size + 4
+        out = np.zeros((cap, (cadu_size + 7) // 8), dtype=np.uint8)
+        n = self.lib.sdref_deframer(_p(b), len(b), chunk, cadu_size, asm, state_synced, _p(out), cap)
+        return out[:n]
+
+    # ---- module level
+    def concat_decode(self, cfg: FecCfg, soft: np.ndarray, taps: bool = False):
+        s = np.ascontiguousarray(soft, dtype=np.int8)
+        cadu_bytes = (cfg.cadu_size + 7) // 8
+        bufsz = max(cfg.cadu_size, 8192)
+        nblk = len(s) // bufsz
+        cap = len(s) // cfg.cadu_size * 2 + 8
+        out = np.zeros((cap, cadu_bytes), dtype=np.uint8)
+        vb = np.zeros(nblk * bufsz + 8, dtype=np.uint8) if taps else None
+        nvb = C.c_int64(0)
+        ber = np.zeros(nblk, dtype=np.float32)
+        st = np.zeros(nblk, dtype=np.int32)
+        ferr = np.full((cap, max(cfg.rs_i, 1)), 0, dtype=np.int32)
+        ndef = C.c_int64(0)
+        n = self.lib.sdref_concat_decode(C.byref(cfg), _p(s), C.c_int64(len(s)), _p(out), C.c_int64(cap), _p(vb), C.byref(nvb),
+                                         _p(ber), _p(st), _p(ferr), C.byref(ndef))
+        res = {"cadu": out[:n], "ber": ber, "state": st, "frm_err": ferr[:ndef.value], "n_deframed": ndef.value}
+        if taps:
+            res["vit_bits"] = vb[:nvb.value]
+        return res
+
+    def metop_decode(self, soft: np.ndarray, ber_thr=0.17, outsync_after=5, taps=False):
+        s = np.ascontiguousarray(soft, dtype=np.int8)
+        nblk = len(s) // 16384
+        cap = len(s) * 3 // 4 // 8192 + 8
+        out = np.zeros((cap, 1024), dtype=np.uint8)
+        vb = np.zeros(nblk * 12288 + 8, dtype=np.uint8) if taps else None
+        nvb = C.c_int64(0)
+        ber = np.zeros(nblk, dtype=np.float32)
+        st = np.zeros(nblk, dtype=np.int32)
+        ferr = np.zeros((cap, 4), dtype=np.int32)
+        n = self.lib.sdref_metop_decode(C.c_float(ber_thr), C.c_int(outsync_after), _p(s), C.c_int64(len(s)), _p(out), C.c_int64(cap),
+                                        _p(vb), C.byref(nvb), _p(ber), _p(st), _p(ferr))
+        res = {"cadu": out[:n], "ber": ber, "state": st, "frm_err": ferr[:n]}
+        if taps:
+            res["vit_bits"] = vb[:nvb.value]
+        return res
+
+    # ---- dsp
+    def rrc_taps(self, fs, symrate, alpha, ntaps=31) -> np.ndarray:
+        out = np.zeros(ntaps | 1, dtype=np.float32)
+        n = self.lib.sdref_rrc_taps(1.0, float(fs), float(symrate), float(alpha), int(ntaps), _p(out))
+        return out[:n]
+
+    def mm_bank(self, nfilt=128, ntaps=8) -> np.ndarray:
+        out = np.zeros((nfilt, ntaps + 1), dtype=np.float32)
+        nt = self.lib.sdref_mm_bank(C.c_int(nfilt), C.c_int(ntaps), _p(out))
+        return out.reshape(-1)[: nfilt * nt].reshape(nfilt, nt)
+
+    def resamp_bank(self, interp, decim):
+        out = np.zeros(1 << 16, dtype=np.float32)
+        ir, dr = C.c_int(0), C.c_int(0)
+        nt = self.lib.sdref_resamp_bank(C.c_uint(interp), C.c_uint(decim), _p(out), C.c_int(len(out)), C.byref(ir), C.byref(dr))
+        return out[: ir.value * nt].reshape(ir.value, nt), ir.value, dr.value
+
+    def block(self, kind: int, params, x: np.ndarray, chunk=30000) -> np.ndarray:
+        xin = np.ascontiguousarray(x, dtype=np.complex64)
+        p = np.asarray(params, dtype=np.float32)
+        cap = len(xin) * 2 + 64
+        out = np.zeros(cap, dtype=np.complex64)
+        n = self.lib.sdref_block_run(kind, _p(p), _p(xin), len(xin), chunk, _p(out), cap)
+        return out[:n]
+
+    def psk_demod(self, cfg: DemodCfg, iq: np.ndarray, want_syms=True):
+        x = np.ascontiguousarray(iq, dtype=np.complex64)
+        cap = len(x) * 2 + 64
+        soft = np.zeros(cap, dtype=np.int8)
+        syms = np.zeros(cap // 2 + 8, dtype=np.complex64) if want_syms else None
+        bs, sps = C.c_int(0), C.c_float(0)
+        n = self.lib.sdref_psk_demod(C.byref(cfg), _p(x), C.c_int64(len(x)), _p(soft), C.c_int64(cap), _p(syms),
+                                     C.c_int64(len(syms) if syms is not None else 0), C.byref(bs), C.byref(sps))
+        if n < 0:
+            raise RuntimeError(f"sdref_psk_demod failed: {n}")
+        nsym = n if cfg.constellation == BPSK else n // 2
+        return {"soft": soft[:n], "syms": None if syms is None else syms[:nsym], "buffer_size": bs.value, "final_sps": sps.value}

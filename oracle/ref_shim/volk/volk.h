@@ -1,0 +1,78 @@
+// Minimal stand-in for <volk/volk.h> so that the reference's hot-path sources
+// (under /root/reference/src-core) compile unmodified in this container, which
+// has no libvolk. TEST INFRASTRUCTURE ONLY (oracle/_ref build) - never linked
+// into the product library.
+//
+// Every kernel here is the strict sequential ("_generic") accumulation order.
+// <math.h> is included on purpose: real VOLK's volk_common.h pulls it in, which
+// makes the unqualified sqrt(float) in common/dsp/utils/agc.cpp:32 resolve to
+// the float overload ("AGC sqrt overload trap").
+#pragma once
+#include <cstdlib>
+#include <cstddef>
+#include <cstdint>
+#include <complex>
+#include <cstring>
+#include <math.h>
+#define VOLK_VERSION 030200
+typedef std::complex<float> lv_32fc_t;
+static inline size_t volk_get_alignment() { return 32; }
+static inline void *volk_malloc(size_t size, size_t align)
+{
+    void *p = nullptr;
+    if (posix_memalign(&p, align < sizeof(void *) ? sizeof(void *) : align, size ? size : align))
+        return nullptr;
+    return p;
+}
+static inline void volk_free(void *p) { free(p); }
+static inline void volk_32fc_32f_dot_prod_32fc(lv_32fc_t *r, const lv_32fc_t *in, const float *t, unsigned n)
+{
+    float re = 0, im = 0;
+    const float *a = (const float *)in;
+    for (unsigned i = 0; i < n; i++)
+    {
+        re += a[2 * i] * t[i];
+        im += a[2 * i + 1] * t[i];
+    }
+    *r = lv_32fc_t(re, im);
+}
+#define volk_32fc_32f_dot_prod_32fc_a volk_32fc_32f_dot_prod_32fc
+static inline void volk_32f_x2_dot_prod_32f(float *r, const float *in, const float *t, unsigned n)
+{
+    float s = 0;
+    for (unsigned i = 0; i < n; i++)
+        s += in[i] * t[i];
+    *r = s;
+}
+#define volk_32f_x2_dot_prod_32f_a volk_32f_x2_dot_prod_32f
+static inline void volk_16i_s32f_convert_32f_u(float *o, const int16_t *in, float s, unsigned n)
+{
+    const float is = 1.0f / s;
+    for (unsigned i = 0; i < n; i++)
+        o[i] = (float)in[i] * is;
+}
+static inline void volk_8i_s32f_convert_32f_u(float *o, const int8_t *in, float s, unsigned n)
+{
+    const float is = 1.0f / s;
+    for (unsigned i = 0; i < n; i++)
+        o[i] = (float)in[i] * is;
+}
+static inline void volk_32i_s32f_convert_32f_u(float *o, const int32_t *in, float s, unsigned n)
+{
+    const float is = 1.0f / s;
+    for (unsigned i = 0; i < n; i++)
+        o[i] = (float)in[i] * is;
+}
+struct volk_func_desc
+{
+    const char **impl_names;
+    const int *impl_deps;
+    const bool *impl_alignment;
+    size_t n_impls;
+};
+static inline volk_func_desc volk_8u_x4_conv_k7_r2_8u_get_func_desc()
+{
+    static const char *names[] = {"generic"};
+    return volk_func_desc{names, nullptr, nullptr, 1};
+}
+static inline void volk_8u_x4_conv_k7_r2_8u_manual(unsigned char *, unsigned char *, unsigned char *, unsigned char *, unsigned, unsigned, unsigned char *, const char *) { abort(); }

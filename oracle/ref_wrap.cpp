@@ -1,0 +1,538 @@
+// oracle/ref_wrap.cpp -- TEST INFRASTRUCTURE ONLY.
+//
+// Thin C-ABI wrapper around the REFERENCE's own classes, compiled from the
+// sources where they lie under /root/reference/src-core (see oracle/Makefile).
+// Nothing in here is product code: only tests/, __graft_entry__.smoke() and
+// bench.py's cpu_baseline leg may load the resulting oracle/_ref/libsdref.so.
+//
+// The module-level orchestration (which the reference keeps inside ImGui-laden
+// module classes that do not compile standalone) is re-stated here, line for
+// line, from:
+//   pipeline/modules/demod/module_psk_demod.cpp:86-236      (psk_demod chain)
+//   pipeline/modules/demod/module_demod_base.cpp:59-208     (resample decision, AGC)
+//   pipeline/modules/ccsds/module_ccsds_conv_concat_decoder.cpp:140-200
+//   plugins/noaa_metop_support/metop/module_metop_ahrpt_decoder.cpp:34-90
+// DSP blocks are driven synchronously (producer swap -> block.work() -> ...),
+// which is arithmetically identical to the reference's thread-per-block
+// topology (dsp::stream is a strict hand-off, common/dsp/buffer.h:49-106).
+//
+// Built with -fno-access-control so Block::work() can be called directly.
+
+#include <cstdint>
+#include <cstring>
+#include <cmath>
+#include <memory>
+#include <vector>
+#include <new>
+
+#include "logger.h"
+std::shared_ptr<slog::Logger> logger = std::make_shared<slog::Logger>();
+
+#include "common/codings/viterbi/cc_decoder.h"
+#include "common/codings/viterbi/cc_encoder.h"
+#include "common/codings/viterbi/viterbi_1_2.h"
+#include "common/codings/viterbi/viterbi_3_4.h"
+#include "common/codings/rotation.h"
+#include "common/codings/randomization.h"
+#include "common/codings/differential/nrzm.h"
+#include "common/codings/deframing/bpsk_ccsds_deframer.h"
+#include "common/codings/reedsolomon/reedsolomon.h"
+
+#include "common/dsp/block.h"
+#include "common/dsp/utils/agc.h"
+#include "common/dsp/utils/correct_iq.h"
+#include "common/dsp/filter/fir.h"
+#include "common/dsp/filter/firdes.h"
+#include "common/dsp/pll/costas_loop.h"
+#include "common/dsp/clock_recovery/clock_recovery_mm.h"
+#include "common/dsp/resamp/rational_resampler.h"
+#include "common/dsp/window/window.h"
+#include "common/dsp/demod/delay_one_imag.h"
+
+#include "../include/sdhip.h" // plain-C config structs shared with the product ABI
+
+namespace
+{
+    // Allocate an object on zero-filled storage. Viterbi1_2/3_4 read a few bytes
+    // past ber_soft_buffer into ber_decoded_buffer (viterbi_1_2.cpp:68 with
+    // cc_decoder.cpp:295-297: 2*(1024+6)+shift symbols from a 2048-byte member),
+    // which is uninitialised in the reference. We pin that to zero.
+    template <class T, class... A>
+    T *zero_new(A... a)
+    {
+        void *p = calloc(1, sizeof(T));
+        return new (p) T(a...);
+    }
+    template <class T>
+    void zero_delete(T *p)
+    {
+        p->~T();
+        free(p);
+    }
+}
+
+extern "C"
+{
+    // ------------------------------------------------------------------ unit level
+    // Chained CCDecoder::work calls (cc_decoder.cpp:295-302). syms holds, per block,
+    // 2*(frame+6) unsigned soft symbols (caller provides the tail). out: frame bits/block.
+    void sdref_ccdecoder(int frame_bits, const uint8_t *syms, int nblocks, uint8_t *out)
+    {
+        viterbi::CCDecoder dec(frame_bits, 7, 2, {79, 109});
+        const size_t stride = 2 * (size_t)(frame_bits + 6);
+        std::vector<uint8_t> tmp(stride);
+        for (int b = 0; b < nblocks; b++)
+        {
+            memcpy(tmp.data(), syms + b * stride, stride);
+            dec.work(tmp.data(), out + (size_t)b * frame_bits);
+        }
+    }
+
+    // CCEncoder::work (cc_encoder.cpp:92-104), one call over nbits, start state 0.
+    void sdref_ccencode(const uint8_t *bits, int nbits, uint8_t *out)
+    {
+        viterbi::CCEncoder enc(nbits, 7, 2, {79, 109});
+        enc.work((uint8_t *)bits, out);
+    }
+
+    void sdref_derand(uint8_t *data, int len) { derand_ccsds(data, len); }
+
+    // ReedSolomon::encode_interlaved / decode_interlaved (reedsolomon.cpp:53-143)
+    void sdref_rs_encode(uint8_t *data, int nframes, int frame_stride, int dualbasis, int I, int rs239)
+    {
+        reedsolomon::ReedSolomon rs(rs239 ? reedsolomon::RS239 : reedsolomon::RS223);
+        for (int f = 0; f < nframes; f++)
+            rs.encode_interlaved(data + (size_t)f * frame_stride, dualbasis, I);
+    }
+    void sdref_rs_decode(uint8_t *data, int nframes, int frame_stride, int dualbasis, int I, int rs239, int fill_bytes, int *errors)
+    {
+        reedsolomon::ReedSolomon *rs = zero_new<reedsolomon::ReedSolomon>(rs239 ? reedsolomon::RS239 : reedsolomon::RS223, fill_bytes);
+        for (int f = 0; f < nframes; f++)
+            rs->decode_interlaved(data + (size_t)f * frame_stride, dualbasis, I, errors + (size_t)f * I);
+        zero_delete(rs);
+    }
+
+    // BPSK_CCSDS_Deframer::work (bpsk_ccsds_deframer.cpp:24-107), fed in `chunk`-bit calls.
+    int sdref_deframer(const uint8_t *bits, int64_t nbits, int chunk, int cadu_size, uint32_t asm_sync, int state_synced, uint8_t *out, int64_t out_cap_frames)
+    {
+        deframing::BPSK_CCSDS_Deframer def(cadu_size, asm_sync);
+        def.STATE_SYNCED = state_synced;
+        if (cadu_size % 8 != 0)
+            def.CADU_PADDING = cadu_size % 8;
+        const int cadu_bytes = (cadu_size + def.CADU_PADDING) / 8;
+        std::vector<uint8_t> fb((size_t)(chunk / cadu_size + 2) * cadu_bytes + 64);
+        int64_t nf = 0;
+        for (int64_t p = 0; p < nbits; p += chunk)
+        {
+            int n = (int)std::min<int64_t>(chunk, nbits - p);
+            int f = def.work((uint8_t *)bits + p, n, fb.data());
+            for (int i = 0; i < f && nf < out_cap_frames; i++, nf++)
+                memcpy(out + nf * cadu_bytes, fb.data() + (size_t)i * cadu_bytes, cadu_bytes);
+        }
+        return (int)nf;
+    }
+
+    // ------------------------------------------------------------------ FEC module level
+    // In-memory restatement of CCSDSConvConcatDecoderModule::process()
+    // (module_ccsds_conv_concat_decoder.cpp:140-200). Processes floor(n/buffer) blocks.
+    // Optional taps: vit_bits (1 bit/byte, concatenated viterbi output after NRZ-M),
+    // blk_ber/blk_state (per block, after work()), frm_err (rs_i ints per deframed frame,
+    // before the usecheck filter), frm_pre (deframed frames before derand/RS).
+    int64_t sdref_concat_decode(const sdhip_fec_cfg *c, const int8_t *soft, int64_t n, uint8_t *cadu_out, int64_t cadu_cap_frames,
+                                uint8_t *vit_bits, int64_t *vit_nbits, float *blk_ber, int *blk_state, int *frm_err, int64_t *n_deframed)
+    {
+        const int d_cadu_size = c->cadu_size;
+        const int d_cadu_bytes = (int)ceil(d_cadu_size / 8.0);
+        const int d_buffer_size = std::max<int>(d_cadu_size, 8192);
+        const bool bpsk = c->constellation == SDHIP_BPSK || c->constellation == SDHIP_BPSK_90;
+        const bool d_bpsk_90 = c->constellation == SDHIP_BPSK_90;
+        const bool d_oqpsk_mode = c->constellation == SDHIP_OQPSK;
+        std::vector<phase_t> d_phases;
+        if (bpsk && !d_bpsk_90)
+            d_phases = {PHASE_0};
+        else if (bpsk && d_bpsk_90)
+            d_phases = {PHASE_90};
+        else
+            d_phases = {PHASE_0, PHASE_90};
+
+        viterbi::Viterbi1_2 *vit = zero_new<viterbi::Viterbi1_2>(c->viterbi_ber_thresold, c->viterbi_outsync_after, d_buffer_size, d_phases, d_oqpsk_mode);
+        deframing::BPSK_CCSDS_Deframer deframer(d_cadu_size, c->asm_sync);
+        if (d_cadu_size % 8 != 0)
+            deframer.CADU_PADDING = d_cadu_size % 8;
+        reedsolomon::ReedSolomon *rs = nullptr;
+        if (c->rs_i != 0)
+            rs = zero_new<reedsolomon::ReedSolomon>(c->rs_type == SDHIP_RS239 ? reedsolomon::RS239 : reedsolomon::RS223, c->rs_fill_bytes);
+
+        std::vector<uint8_t> viterbi_out((size_t)d_buffer_size * 8, 0);
+        std::vector<int8_t> soft_buffer(d_buffer_size);
+        std::vector<uint8_t> frame_buffer((size_t)d_buffer_size * 8, 0);
+        int errors[16] = {0};
+        diff::NRZMDiff diff;
+
+        int64_t nout = 0, nvb = 0, ndef = 0;
+        const int64_t nblocks = n / d_buffer_size;
+        for (int64_t b = 0; b < nblocks; b++)
+        {
+            memcpy(soft_buffer.data(), soft + b * d_buffer_size, d_buffer_size);
+            if (d_bpsk_90 || c->iq_invert)
+                rotate_soft(soft_buffer.data(), d_buffer_size, PHASE_0, true);
+            int vitout = vit->work(soft_buffer.data(), d_buffer_size, viterbi_out.data());
+            if (blk_ber)
+                blk_ber[b] = vit->ber();
+            if (blk_state)
+                blk_state[b] = vit->getState();
+            if (c->nrzm)
+                diff.decode_bits(viterbi_out.data(), vitout);
+            if (vit_bits)
+                memcpy(vit_bits + nvb, viterbi_out.data(), vitout);
+            nvb += vitout;
+            int frames = deframer.work(viterbi_out.data(), vitout, frame_buffer.data());
+            for (int i = 0; i < frames; i++)
+            {
+                uint8_t *cadu = &frame_buffer[(size_t)i * d_cadu_bytes];
+                if (c->derandomize && !c->derand_after_rs)
+                    derand_ccsds(&cadu[c->derand_start], d_cadu_bytes - c->derand_start);
+                if (c->rs_i != 0)
+                    rs->decode_interlaved(&cadu[4], c->rs_dualbasis, c->rs_i, errors);
+                bool valid = true;
+                for (int k = 0; k < c->rs_i; k++)
+                    if (errors[k] == -1)
+                        valid = false;
+                if (frm_err)
+                    for (int k = 0; k < c->rs_i; k++)
+                        frm_err[ndef * c->rs_i + k] = errors[k];
+                ndef++;
+                if (c->derandomize && c->derand_after_rs)
+                    derand_ccsds(&cadu[c->derand_start], d_cadu_bytes - c->derand_start);
+                if (!c->rs_usecheck || valid)
+                {
+                    if (nout < cadu_cap_frames)
+                        memcpy(cadu_out + nout * d_cadu_bytes, cadu, d_cadu_bytes);
+                    nout++;
+                }
+            }
+        }
+        if (vit_nbits)
+            *vit_nbits = nvb;
+        if (n_deframed)
+            *n_deframed = ndef;
+        zero_delete(vit);
+        if (rs)
+            zero_delete(rs);
+        return nout;
+    }
+
+    // In-memory restatement of MetOpAHRPTDecoderModule::process()
+    // (plugins/noaa_metop_support/metop/module_metop_ahrpt_decoder.cpp:34-90).
+    int64_t sdref_metop_decode(float ber_thr, int outsync_after, const int8_t *soft, int64_t n, uint8_t *cadu_out, int64_t cadu_cap_frames,
+                               uint8_t *vit_bits, int64_t *vit_nbits, float *blk_ber, int *blk_state, int *frm_err)
+    {
+        const int BUFFER_SIZE = 8192 * 2;
+        viterbi::Viterbi3_4 *vit = zero_new<viterbi::Viterbi3_4>(ber_thr, outsync_after, BUFFER_SIZE, false);
+        deframing::BPSK_CCSDS_Deframer deframer;
+        deframer.STATE_SYNCED = 18;
+        reedsolomon::ReedSolomon *rs = zero_new<reedsolomon::ReedSolomon>(reedsolomon::RS223, 0);
+        std::vector<uint8_t> viterbi_out(BUFFER_SIZE * 2, 0);
+        std::vector<int8_t> soft_buffer(BUFFER_SIZE);
+        std::vector<uint8_t> frame_buffer(1024 * 10, 0);
+        int errors[4] = {0, 0, 0, 0};
+        int noSyncsRuns = 0;
+        int64_t nout = 0, nvb = 0;
+        const int64_t nblocks = n / BUFFER_SIZE;
+        for (int64_t b = 0; b < nblocks; b++)
+        {
+            memcpy(soft_buffer.data(), soft + b * BUFFER_SIZE, BUFFER_SIZE);
+            int num_samp = vit->work(soft_buffer.data(), BUFFER_SIZE, viterbi_out.data());
+            if (blk_ber)
+                blk_ber[b] = vit->ber();
+            if (blk_state)
+                blk_state[b] = vit->getState();
+            if (num_samp > 0)
+            {
+                if (vit_bits)
+                    memcpy(vit_bits + nvb, viterbi_out.data(), num_samp);
+                nvb += num_samp;
+                int frames = deframer.work(viterbi_out.data(), num_samp, frame_buffer.data());
+                if (deframer.getState() == deframer.STATE_NOSYNC)
+                {
+                    noSyncsRuns++;
+                    if (noSyncsRuns >= 10)
+                    {
+                        vit->reset();
+                        noSyncsRuns = 0;
+                    }
+                }
+                else
+                    noSyncsRuns = 0;
+                for (int i = 0; i < frames; i++)
+                {
+                    uint8_t *cadu = &frame_buffer[i * 1024];
+                    derand_ccsds(&cadu[4], 1024 - 4);
+                    rs->decode_interlaved(&cadu[4], true, 4, errors);
+                    if (frm_err)
+                        for (int k = 0; k < 4; k++)
+                            frm_err[nout * 4 + k] = errors[k];
+                    if (nout < cadu_cap_frames)
+                        memcpy(cadu_out + nout * 1024, cadu, 1024);
+                    nout++;
+                }
+            }
+        }
+        if (vit_nbits)
+            *vit_nbits = nvb;
+        zero_delete(vit);
+        zero_delete(rs);
+        return nout;
+    }
+
+    // ------------------------------------------------------------------ DSP unit level
+    int sdref_rrc_taps(double gain, double fs, double symrate, double alpha, int ntaps, float *out)
+    {
+        std::vector<float> t = dsp::firdes::root_raised_cosine(gain, fs, symrate, alpha, ntaps);
+        memcpy(out, t.data(), t.size() * sizeof(float));
+        return (int)t.size();
+    }
+    // MM interpolator bank (clock_recovery_mm.cpp:18, polyphase_bank.cpp:6-39): out[nfilt][ntaps]
+    int sdref_mm_bank(int nfilt, int ntaps, float *out)
+    {
+        dsp::PolyphaseBank pfb;
+        pfb.init(dsp::windowed_sinc(nfilt * ntaps, dsp::hz_to_rad(0.5 / (double)nfilt, 1.0), dsp::window::nuttall, nfilt), nfilt);
+        for (int i = 0; i < pfb.nfilt; i++)
+            memcpy(out + (size_t)i * pfb.ntaps, pfb.taps[i], pfb.ntaps * sizeof(float));
+        return pfb.ntaps;
+    }
+    // Rational resampler bank (rational_resampler.cpp:27-41): returns ntaps/phase, out[interp][ntaps]
+    int sdref_resamp_bank(unsigned interp, unsigned decim, float *out, int cap, int *interp_red, int *decim_red)
+    {
+        dsp::RationalResamplerBlock<complex_t> r(nullptr, interp, decim);
+        if (interp_red)
+            *interp_red = r.d_interpolation;
+        if (decim_red)
+            *decim_red = r.d_decimation;
+        if (r.pfb.nfilt * r.pfb.ntaps > cap)
+            return -r.pfb.ntaps;
+        for (int i = 0; i < r.pfb.nfilt; i++)
+            memcpy(out + (size_t)i * r.pfb.ntaps, r.pfb.taps[i], r.pfb.ntaps * sizeof(float));
+        return r.pfb.ntaps;
+    }
+
+    // Run ONE block type over a stream, fed in `chunk`-sample buffers. kind: see switch.
+    // p[] carries the constructor arguments. Returns output sample count.
+    int64_t sdref_block_run(int kind, const float *p, const float *in_c, int64_t n, int chunk, float *out_c, int64_t out_cap)
+    {
+        auto in = std::make_shared<dsp::stream<complex_t>>();
+        std::shared_ptr<dsp::Block<complex_t, complex_t>> blk;
+        std::shared_ptr<dsp::stream<complex_t>> outs;
+        std::shared_ptr<dsp::AGCBlock<complex_t>> agc;
+        std::shared_ptr<dsp::FIRBlock<complex_t>> fir;
+        std::shared_ptr<dsp::CostasLoopBlock> pll;
+        std::shared_ptr<dsp::MMClockRecoveryBlock<complex_t>> rec;
+        std::shared_ptr<dsp::RationalResamplerBlock<complex_t>> rr;
+        std::shared_ptr<dsp::CorrectIQBlock<complex_t>> dc;
+        std::shared_ptr<dsp::DelayOneImagBlock> dly;
+        switch (kind)
+        {
+        case 0: // AGC(rate, ref, gain, max_gain)
+            agc = std::make_shared<dsp::AGCBlock<complex_t>>(in, p[0], p[1], p[2], p[3]);
+            outs = agc->output_stream;
+            break;
+        case 1: // FIR RRC(fs, symrate, alpha, ntaps)
+            fir = std::make_shared<dsp::FIRBlock<complex_t>>(in, dsp::firdes::root_raised_cosine(1, p[0], p[1], p[2], (int)p[3]));
+            outs = fir->output_stream;
+            break;
+        case 2: // Costas(loop_bw, order, freq_limit)
+            pll = std::make_shared<dsp::CostasLoopBlock>(in, p[0], (unsigned)p[1], p[2]);
+            outs = pll->output_stream;
+            break;
+        case 3: // MM(omega, omega_gain, mu, mu_gain, omega_limit)
+            rec = std::make_shared<dsp::MMClockRecoveryBlock<complex_t>>(in, p[0], p[1], p[2], p[3], p[4]);
+            outs = rec->output_stream;
+            break;
+        case 4: // Rational resampler(interp, decim)
+            rr = std::make_shared<dsp::RationalResamplerBlock<complex_t>>(in, (unsigned)p[0], (unsigned)p[1]);
+            outs = rr->output_stream;
+            break;
+        case 5: // CorrectIQ (DC block)
+            dc = std::make_shared<dsp::CorrectIQBlock<complex_t>>(in);
+            outs = dc->output_stream;
+            break;
+        case 6: // DelayOneImag
+            dly = std::make_shared<dsp::DelayOneImagBlock>(in);
+            outs = dly->output_stream;
+            break;
+        default:
+            return -1;
+        }
+        int64_t no = 0;
+        for (int64_t pos = 0; pos < n; pos += chunk)
+        {
+            int m = (int)std::min<int64_t>(chunk, n - pos);
+            memcpy(in->writeBuf, in_c + 2 * pos, (size_t)m * sizeof(complex_t));
+            in->swap(m);
+            if (agc) agc->work();
+            if (fir) fir->work();
+            if (pll) pll->work();
+            if (rec) rec->work();
+            if (rr) rr->work();
+            if (dc) dc->work();
+            if (dly) dly->work();
+            int k = outs->read();
+            if (k > 0)
+            {
+                int64_t take = std::min<int64_t>(k, out_cap - no);
+                memcpy(out_c + 2 * no, outs->readBuf, (size_t)take * sizeof(complex_t));
+                no += take;
+            }
+            outs->flush();
+        }
+        return no;
+    }
+
+    // ------------------------------------------------------------------ demod module level
+    // In-memory restatement of PSKDemodModule init()/process() for cf32 input
+    // (module_psk_demod.cpp:86-236 + module_demod_base.cpp:59-208). Stream semantics:
+    // all n samples are consumed in buffer_size chunks (last one short); the file
+    // source's stale-tail quirk is NOT reproduced.
+    // Outputs: soft (int8; 1/sym BPSK, 2/sym otherwise), optional syms (float pairs).
+    int64_t sdref_psk_demod(const sdhip_demod_cfg *c, const float *iq, int64_t n, int8_t *soft, int64_t soft_cap, float *syms, int64_t syms_cap,
+                            int *buffer_size_out, float *final_sps_out)
+    {
+        // --- BaseDemodModule ctor + initb (module_demod_base.cpp:22-25, 59-89)
+        long d_samplerate = (long)c->samplerate;
+        int d_symbolrate = (int)c->symbolrate;
+        int d_buffer_size = c->buffer_size > 0 ? c->buffer_size : std::min<int>(dsp::STREAM_BUFFER_SIZE, std::max<int>(8192 + 1, d_samplerate / 200));
+        float MIN_SPS = c->min_sps, MAX_SPS = c->max_sps;
+        const bool is_bpsk = c->constellation == SDHIP_BPSK;
+        const bool is_oqpsk = c->constellation == SDHIP_OQPSK;
+        if (is_oqpsk)
+        {
+            MIN_SPS = 1.6;
+            MAX_SPS = 2.4;
+        }
+        float input_sps = (float)d_samplerate / (float)d_symbolrate;
+        bool resample = input_sps > MAX_SPS || input_sps < MIN_SPS;
+        int range = pow(10, (std::to_string(int(d_symbolrate)).size() - 1));
+        float final_samplerate = d_samplerate;
+        if (MAX_SPS == MIN_SPS)
+            final_samplerate = d_symbolrate * MAX_SPS;
+        else if (input_sps > MAX_SPS)
+            final_samplerate = resample ? (round(d_symbolrate / range) * range) * MAX_SPS : d_samplerate;
+        else if (input_sps < MIN_SPS)
+            final_samplerate = resample ? d_symbolrate * MIN_SPS : d_samplerate;
+        float decimation_factor = d_samplerate / final_samplerate;
+        if (resample)
+            d_buffer_size *= ceil(decimation_factor);
+        if (d_buffer_size > 8192 * 20)
+            d_buffer_size = 8192 * 20;
+        float final_sps = final_samplerate / (float)d_symbolrate;
+        if (buffer_size_out)
+            *buffer_size_out = d_buffer_size;
+        if (final_sps_out)
+            *final_sps_out = final_sps;
+
+        auto in = std::make_shared<dsp::stream<complex_t>>();
+        std::shared_ptr<dsp::stream<complex_t>> cur = in;
+        std::shared_ptr<dsp::CorrectIQBlock<complex_t>> dc_blocker;
+        if (c->dc_block)
+        {
+            dc_blocker = std::make_shared<dsp::CorrectIQBlock<complex_t>>(cur);
+            cur = dc_blocker->output_stream;
+        }
+        // SmartResamplerBlock(input, final_samplerate, d_samplerate) (module_demod_base.cpp:204):
+        // for 1 < decim/interp < 2 it reduces to a RationalResamplerBlock (smart_resampler.cpp:15-43).
+        std::shared_ptr<dsp::RationalResamplerBlock<complex_t>> rresamp;
+        if (resample)
+        {
+            unsigned interpolation = final_samplerate, decimation = d_samplerate;
+            if (decimation > interpolation)
+            {
+                int best_power = floor(log2(decimation / interpolation));
+                if (best_power > 0)
+                    return -2; // power-of-two pre-decimator: not covered by this oracle
+                double rsamp_in = decimation, fout = interpolation, t;
+                while (modf(rsamp_in, &t) != 0 || modf(fout, &t) != 0)
+                {
+                    rsamp_in *= 10;
+                    fout *= 10;
+                }
+                rresamp = std::make_shared<dsp::RationalResamplerBlock<complex_t>>(cur, fout, rsamp_in);
+            }
+            else
+                rresamp = std::make_shared<dsp::RationalResamplerBlock<complex_t>>(cur, interpolation, decimation);
+            cur = rresamp->output_stream;
+        }
+        auto agc = std::make_shared<dsp::AGCBlock<complex_t>>(cur, c->agc_rate, 1.0f, 1.0f, 65536);
+        // --- PSKDemodModule::init (module_psk_demod.cpp:86-136)
+        auto rrc = std::make_shared<dsp::FIRBlock<complex_t>>(agc->output_stream, dsp::firdes::root_raised_cosine(1, final_samplerate, d_symbolrate, c->rrc_alpha, c->rrc_taps));
+        float costas_max_offset = 1.0;
+        if (c->costas_max_offset_hz > 0)
+            costas_max_offset = dsp::hz_to_rad(c->costas_max_offset_hz, final_samplerate);
+        unsigned order = is_bpsk ? 2 : (c->constellation == SDHIP_8PSK ? 8 : 4);
+        auto pll = std::make_shared<dsp::CostasLoopBlock>(rrc->output_stream, c->pll_bw, order, costas_max_offset);
+        std::shared_ptr<dsp::DelayOneImagBlock> delay;
+        if (is_oqpsk)
+            delay = std::make_shared<dsp::DelayOneImagBlock>(pll->output_stream);
+        auto rec = std::make_shared<dsp::MMClockRecoveryBlock<complex_t>>(is_oqpsk ? delay->output_stream : pll->output_stream, final_sps, c->clock_gain_omega, c->clock_mu,
+                                                                           c->clock_gain_mu, c->clock_omega_relative_limit);
+
+        auto clampf = [](float x) -> int8_t { // module_demod_base.h:106-113
+            if (x < -128.0)
+                return -127;
+            if (x > 127.0)
+                return 127;
+            return x;
+        };
+
+        int64_t nsoft = 0, nsym = 0;
+        for (int64_t pos = 0; pos < n; pos += d_buffer_size)
+        {
+            int m = (int)std::min<int64_t>(d_buffer_size, n - pos);
+            if (c->iq_swap)
+            {
+                for (int i = 0; i < m; i++)
+                    in->writeBuf[i] = complex_t(iq[2 * (pos + i) + 1], iq[2 * (pos + i)]);
+            }
+            else
+                memcpy(in->writeBuf, iq + 2 * pos, (size_t)m * sizeof(complex_t));
+            in->swap(m);
+            if (dc_blocker) dc_blocker->work();
+            if (rresamp) rresamp->work();
+            agc->work();
+            rrc->work();
+            pll->work();
+            if (delay) delay->work();
+            rec->work();
+            int dat_size = rec->output_stream->read();
+            if (dat_size > 0)
+            {
+                complex_t *rb = rec->output_stream->readBuf;
+                for (int i = 0; i < dat_size; i++)
+                {
+                    if (syms && nsym < syms_cap)
+                    {
+                        syms[2 * nsym] = rb[i].real;
+                        syms[2 * nsym + 1] = rb[i].imag;
+                    }
+                    nsym++;
+                    if (is_bpsk)
+                    {
+                        if (nsoft < soft_cap)
+                            soft[nsoft] = clampf(rb[i].real * 50);
+                        nsoft++;
+                    }
+                    else
+                    {
+                        if (nsoft + 1 < soft_cap)
+                        {
+                            soft[nsoft] = clampf(rb[i].real * 100);
+                            soft[nsoft + 1] = clampf(rb[i].imag * 100);
+                        }
+                        nsoft += 2;
+                    }
+                }
+            }
+            rec->output_stream->flush();
+        }
+        return nsoft;
+    }
+}
