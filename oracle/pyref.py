@@ -88,6 +88,29 @@ class _Lib:
 
 
 _ref = None
+_port = None
+
+
+def port_available() -> bool:
+    return os.path.exists(os.path.join(_HERE, "_build", "libsdoracle.so"))
+
+
+def port():
+    """Our plain-C restatement (oracle/_build/libsdoracle.so) behind the same Python API as ref()."""
+    global _port
+    if _port is None:
+        _port = Ref(os.path.join(_HERE, "_build", "libsdoracle.so"), prefix="sdo_")
+        _port.raw.sdo_sinf.restype = C.c_float
+        _port.raw.sdo_cosf.restype = C.c_float
+        _port.raw.sdo_sinf.argtypes = [C.c_float]
+        _port.raw.sdo_cosf.argtypes = [C.c_float]
+    return _port
+
+
+def best():
+    """Prefer the compiled reference; fall back to the restatement (e.g. if _ref was not shipped)."""
+    return ref() if ref_available() else port()
+
 
 
 def ref_available() -> bool:
@@ -102,9 +125,24 @@ def ref():
     return _ref
 
 
+class _Pfx:
+    """Attribute proxy: L.sdref_x -> getattr(lib, prefix + 'x') so one wrapper serves both libraries."""
+
+    def __init__(self, lib, prefix):
+        object.__setattr__(self, "_lib", lib)
+        object.__setattr__(self, "_prefix", prefix)
+
+    def __getattr__(self, name):
+        if name.startswith("sdref_"):
+            name = self._prefix + name[len("sdref_"):]
+        return getattr(self._lib, name)
+
+
 class Ref(_Lib):
-    def __init__(self, path):
+    def __init__(self, path, prefix="sdref_"):
         super().__init__(path)
+        self.raw = self.lib
+        self.lib = _Pfx(self.raw, prefix)
         L = self.lib
         L.sdref_concat_decode.restype = C.c_int64
         L.sdref_metop_decode.restype = C.c_int64

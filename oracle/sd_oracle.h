@@ -1,0 +1,32 @@
+/* oracle/sd_oracle.h -- TEST INFRASTRUCTURE ONLY (see sd_oracle.c). */
+#ifndef SD_ORACLE_H
+#define SD_ORACLE_H
+#include <stdint.h>
+#include "../include/sdhip.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+void sdo_ccdecoder(int frame_bits, const uint8_t *syms, int nblocks, uint8_t *out);
+void sdo_ccencode(const uint8_t *bits, int nbits, uint8_t *out);
+void sdo_derand(uint8_t *data, int len);
+void sdo_rs_decode(uint8_t *data, int nframes, int frame_stride, int dualbasis, int I, int rs239, int fill_bytes, int *errors);
+int sdo_deframer(const uint8_t *bits, int64_t nbits, int chunk, int cadu_size, uint32_t asm_sync, int state_synced, uint8_t *out, int64_t out_cap_frames);
+int64_t sdo_concat_decode(const sdhip_fec_cfg *c, const int8_t *soft, int64_t n, uint8_t *cadu_out, int64_t cadu_cap_frames,
+                          uint8_t *vit_bits, int64_t *vit_nbits, float *blk_ber, int *blk_state, int *frm_err, int64_t *n_deframed);
+int64_t sdo_metop_decode(float ber_thr, int outsync_after, const int8_t *soft, int64_t n, uint8_t *cadu_out, int64_t cadu_cap_frames,
+                         uint8_t *vit_bits, int64_t *vit_nbits, float *blk_ber, int *blk_state, int *frm_err);
+
+int sdo_rrc_taps(double gain, double fs, double symrate, double alpha, int ntaps, float *out);
+int sdo_mm_bank(int nfilt, int ntaps, float *out);
+int sdo_resamp_bank(unsigned interp, unsigned decim, float *out, int cap, int *interp_red, int *decim_red);
+int64_t sdo_block_run(int kind, const float *p, const float *in_c, int64_t n, int chunk, float *out_c, int64_t out_cap);
+int64_t sdo_psk_demod(const sdhip_demod_cfg *c, const float *iq, int64_t n, int8_t *soft, int64_t soft_cap, float *syms, int64_t syms_cap,
+                      int *buffer_size_out, float *final_sps_out);
+/* glibc-2.35 sinf/cosf restatement (the device code must match this bit for bit) */
+float sdo_sinf(float x);
+float sdo_cosf(float x);
+#ifdef __cplusplus
+}
+#endif
+#endif
