@@ -1,0 +1,56 @@
+"""Build recipe for the native pieces (run by __graft_entry__.build(); hipcc cross-compiles gfx950 without a GPU).
+
+  satdump_amd/lib/libsdhip.so   the product: HIP kernels + host engines + C ABI (include/sdhip.h)
+  oracle/_build/libsdoracle.so  test oracle: plain-C restatement (building the checker is not using it)
+  oracle/_ref/libsdref.so       test oracle: the reference's own sources, only when /root/reference exists
+"""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "satdump_amd", "csrc")
+LIBDIR = os.path.join(ROOT, "satdump_amd", "lib")
+LIB = os.path.join(LIBDIR, "libsdhip.so")
+
+HIP_SOURCES = ["fec_kernels.hip", "fec_engine.hip", "demod_kernels.hip", "demod_engine.hip"]
+# -ffp-contract=off: the float chains must round exactly where the reference's x86-64 -O2 build rounds (no FMA)
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-Wno-unused-result"]
+
+
+def _newer(target: str, deps: list[str]) -> bool:
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+
+
+def build_lib(force: bool = False, verbose: bool = True) -> str:
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    srcs = [os.path.join(CSRC, s) for s in HIP_SOURCES if os.path.exists(os.path.join(CSRC, s))]
+    deps = srcs + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + [os.path.join(ROOT, "include", "sdhip.h")]
+    os.makedirs(LIBDIR, exist_ok=True)
+    if force or _newer(LIB, deps):
+        cmd = [hipcc] + HIPCC_FLAGS + srcs + ["-o", LIB]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd, cwd=ROOT)
+    return LIB
+
+
+def build_oracle(verbose: bool = True) -> None:
+    cmd = ["make", "-C", os.path.join(ROOT, "oracle"), "-j8", "all"]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+
+
+def build_all(force: bool = False) -> None:
+    build_lib(force=force)
+    build_oracle()
+
+
+if __name__ == "__main__":
+    build_all(force="--force" in sys.argv)

@@ -1,0 +1,222 @@
+"""ctypes binding of the C ABI in include/sdhip.h (libsdhip.so). Plumbing only: no compute happens here.
+
+The library is REQUIRED: importing this module on a machine without the built extension raises, and every
+call into it fails loudly when no HIP device is present -- there is no CPU fallback in the product path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libsdhip.so")
+
+BPSK, BPSK_90, QPSK, OQPSK, PSK8 = 0, 1, 2, 3, 4
+RS_NONE, RS223, RS239 = 0, 1, 2
+FMT_CF32, FMT_CS16, FMT_CS8, FMT_CU8 = 0, 1, 2, 3
+DEC_CONV_CONCAT, DEC_METOP_AHRPT = 0, 1
+CONSTELLATIONS = {"bpsk": BPSK, "bpsk_90": BPSK_90, "qpsk": QPSK, "oqpsk": OQPSK, "8psk": PSK8}
+
+
+class DemodCfg(C.Structure):
+    _fields_ = [
+        ("samplerate", C.c_double), ("symbolrate", C.c_double), ("constellation", C.c_int), ("rrc_alpha", C.c_float),
+        ("rrc_taps", C.c_int), ("pll_bw", C.c_float), ("agc_rate", C.c_float), ("dc_block", C.c_int), ("iq_swap", C.c_int),
+        ("min_sps", C.c_float), ("max_sps", C.c_float), ("clock_gain_omega", C.c_float), ("clock_mu", C.c_float),
+        ("clock_gain_mu", C.c_float), ("clock_omega_relative_limit", C.c_float), ("costas_max_offset_hz", C.c_float),
+        ("buffer_size", C.c_int), ("exact", C.c_int), ("chunk_len", C.c_int), ("warmup", C.c_int), ("device", C.c_int),
+    ]
+
+
+class DemodStats(C.Structure):
+    _fields_ = [
+        ("samples_in", C.c_uint64), ("symbols_out", C.c_uint64), ("freq_hz", C.c_float), ("final_sps", C.c_float),
+        ("final_samplerate", C.c_float), ("buffer_size", C.c_int), ("resample_interp", C.c_int), ("resample_decim", C.c_int),
+        ("chunks", C.c_uint32), ("chunks_fixed", C.c_uint32), ("chunks_rotated", C.c_uint32),
+    ]
+
+
+class FecCfg(C.Structure):
+    _fields_ = [
+        ("decoder", C.c_int), ("constellation", C.c_int), ("iq_invert", C.c_int), ("cadu_size", C.c_int),
+        ("viterbi_outsync_after", C.c_int), ("viterbi_ber_thresold", C.c_float), ("nrzm", C.c_int), ("derandomize", C.c_int),
+        ("derand_after_rs", C.c_int), ("derand_start", C.c_int), ("rs_i", C.c_int), ("rs_fill_bytes", C.c_int),
+        ("rs_dualbasis", C.c_int), ("rs_type", C.c_int), ("rs_usecheck", C.c_int), ("asm_sync", C.c_uint32), ("device", C.c_int),
+    ]
+
+
+class FecStats(C.Structure):
+    _fields_ = [
+        ("soft_in", C.c_uint64), ("blocks", C.c_uint64), ("bits_decoded", C.c_uint64), ("frames_deframed", C.c_uint64),
+        ("frames_out", C.c_uint64), ("viterbi_ber", C.c_float), ("viterbi_lock", C.c_int), ("deframer_state", C.c_int),
+        ("rs_errors", C.c_int * 8), ("vit_respec", C.c_uint32), ("tb_respec", C.c_uint32),
+    ]
+
+
+class SdhipError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise SdhipError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` (hipcc, gfx950). "
+                             "There is no CPU fallback.")
+        L = C.CDLL(LIB_PATH)
+        L.sdhip_last_error.restype = C.c_char_p
+        L.sdhip_version.restype = C.c_char_p
+        L.sdhip_fec_create.restype = C.c_void_p
+        L.sdhip_fec_create.argtypes = [C.POINTER(FecCfg)]
+        L.sdhip_fec_destroy.argtypes = [C.c_void_p]
+        L.sdhip_fec_push.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        L.sdhip_fec_pull.restype = C.c_int64
+        L.sdhip_fec_pull.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        L.sdhip_fec_process_dev.restype = C.c_int64
+        L.sdhip_fec_process_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+        L.sdhip_fec_get_stats.argtypes = [C.c_void_p, C.POINTER(FecStats)]
+        L.sdhip_fec_get_block_taps.restype = C.c_int64
+        L.sdhip_fec_get_block_taps.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+        L.sdhip_fec_cfg_default.argtypes = [C.POINTER(FecCfg)]
+        L.sdhip_op_ccdecoder.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+        L.sdhip_op_rs_decode.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        if hasattr(L, "sdhip_demod_create"):
+            L.sdhip_demod_create.restype = C.c_void_p
+            L.sdhip_demod_create.argtypes = [C.POINTER(DemodCfg)]
+            L.sdhip_demod_destroy.argtypes = [C.c_void_p]
+            L.sdhip_demod_cfg_default.argtypes = [C.POINTER(DemodCfg)]
+            L.sdhip_demod_push.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+            L.sdhip_demod_flush.argtypes = [C.c_void_p]
+            L.sdhip_demod_pull.restype = C.c_int64
+            L.sdhip_demod_pull.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+            L.sdhip_demod_process_dev.restype = C.c_int64
+            L.sdhip_demod_process_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int]
+            L.sdhip_demod_get_stats.argtypes = [C.c_void_p, C.POINTER(DemodStats)]
+            L.sdhip_op_block.restype = C.c_int64
+            L.sdhip_op_block.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+        _lib = L
+    return _lib
+
+
+def last_error() -> str:
+    return lib().sdhip_last_error().decode()
+
+
+def _check(rc, what):
+    if rc is None or (isinstance(rc, int) and rc < 0):
+        raise SdhipError(f"{what} failed: {last_error()}")
+    return rc
+
+
+def fec_cfg(**kw) -> FecCfg:
+    c = FecCfg()
+    lib().sdhip_fec_cfg_default(C.byref(c))
+    for k, v in kw.items():
+        if k == "constellation" and isinstance(v, str):
+            v = CONSTELLATIONS[v]
+        setattr(c, k, v)
+    return c
+
+
+def demod_cfg(**kw) -> DemodCfg:
+    c = DemodCfg()
+    lib().sdhip_demod_cfg_default(C.byref(c))
+    for k, v in kw.items():
+        if k == "constellation" and isinstance(v, str):
+            v = CONSTELLATIONS[v]
+        setattr(c, k, v)
+    return c
+
+
+class FecDecoder:
+    """ccsds_conv_concat_decoder / metop_ahrpt_decoder on one GPU stream (one handle = one stream)."""
+
+    def __init__(self, cfg: FecCfg):
+        self.cfg = cfg
+        self.h = lib().sdhip_fec_create(C.byref(cfg))
+        if not self.h:
+            raise SdhipError(f"sdhip_fec_create failed: {last_error()}")
+        self.cadu_bytes = 1024 if cfg.decoder == DEC_METOP_AHRPT else cfg.cadu_size // 8
+
+    def close(self):
+        if self.h:
+            lib().sdhip_fec_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def push(self, soft: np.ndarray):
+        s = np.ascontiguousarray(soft, dtype=np.int8)
+        _check(lib().sdhip_fec_push(self.h, s.ctypes.data_as(C.c_void_p), s.size), "sdhip_fec_push")
+
+    def pull(self, max_frames: int = 1 << 20) -> np.ndarray:
+        out = np.zeros((max_frames, self.cadu_bytes), dtype=np.uint8)
+        n = _check(lib().sdhip_fec_pull(self.h, out.ctypes.data_as(C.c_void_p), max_frames), "sdhip_fec_pull")
+        return out[:n].copy()
+
+    def process_dev(self, soft_ptr: int, n: int, cadu_ptr: int, cap_frames: int) -> int:
+        return _check(lib().sdhip_fec_process_dev(self.h, C.c_void_p(soft_ptr), n, C.c_void_p(cadu_ptr), cap_frames), "sdhip_fec_process_dev")
+
+    def stats(self) -> FecStats:
+        st = FecStats()
+        lib().sdhip_fec_get_stats(self.h, C.byref(st))
+        return st
+
+    def block_taps(self):
+        n = lib().sdhip_fec_get_block_taps(self.h, None, None, 0)
+        ber = np.zeros(n, dtype=np.float32)
+        st = np.zeros(n, dtype=np.int32)
+        lib().sdhip_fec_get_block_taps(self.h, ber.ctypes.data_as(C.c_void_p), st.ctypes.data_as(C.c_void_p), n)
+        return ber, st
+
+
+class PskDemod:
+    """psk_demod on one GPU stream."""
+
+    def __init__(self, cfg: DemodCfg):
+        self.cfg = cfg
+        self.h = lib().sdhip_demod_create(C.byref(cfg))
+        if not self.h:
+            raise SdhipError(f"sdhip_demod_create failed: {last_error()}")
+
+    def close(self):
+        if self.h:
+            lib().sdhip_demod_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def push(self, iq: np.ndarray, fmt: int = FMT_CF32):
+        a = np.ascontiguousarray(iq)
+        nsamp = a.size if a.dtype == np.complex64 else a.size // 2
+        _check(lib().sdhip_demod_push(self.h, a.ctypes.data_as(C.c_void_p), nsamp, fmt), "sdhip_demod_push")
+
+    def flush(self):
+        _check(lib().sdhip_demod_flush(self.h), "sdhip_demod_flush")
+
+    def pull(self, cap: int = 1 << 26) -> np.ndarray:
+        out = np.zeros(cap, dtype=np.int8)
+        n = _check(lib().sdhip_demod_pull(self.h, out.ctypes.data_as(C.c_void_p), cap), "sdhip_demod_pull")
+        return out[:n].copy()
+
+    def process_dev(self, iq_ptr: int, nsamples: int, fmt: int, soft_ptr: int, soft_cap: int, syms_ptr: int = 0, syms_cap: int = 0, final: bool = True) -> int:
+        return _check(lib().sdhip_demod_process_dev(self.h, C.c_void_p(iq_ptr), nsamples, fmt, C.c_void_p(soft_ptr), soft_cap,
+                                                    C.c_void_p(syms_ptr) if syms_ptr else None, syms_cap, int(final)), "sdhip_demod_process_dev")
+
+    def stats(self) -> DemodStats:
+        st = DemodStats()
+        lib().sdhip_demod_get_stats(self.h, C.byref(st))
+        return st

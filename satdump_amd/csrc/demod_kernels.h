@@ -1,0 +1,118 @@
+// demod_kernels.h -- psk_demod DSP chain on gfx950: launch-side declarations.
+//
+// Feed-forward stages (format convert, rational resampler, RRC FIR, quantiser) are plain data-parallel
+// kernels. The three feedback loops of the reference (AGC agc.cpp:25-39, Costas costas_loop.cpp:23-65,
+// M&M clock_recovery_mm.cpp:52-121) are nonlinear per-sample recurrences; they run CHUNK-SPECULATIVE:
+// one lane per chunk of the stream, every chunk but the first starting `warmup` samples early from a
+// default state, and a boundary certificate (state reached by the warm-up == state the previous chunk
+// ended in) decides whether the chunk's output stands or the chunk is re-run from the exact state.
+#pragma once
+#include "common.h"
+
+namespace sdhip
+{
+    struct cf32
+    {
+        float re, im;
+    };
+
+    constexpr int DEMOD_HIST = 64; // samples of history kept in front of every stage buffer
+
+    // chunk geometry of one speculative stage: chunk 0 = [0, L+W), chunk k>=1 = [W + k*L, W + (k+1)*L) (clipped to n)
+    struct ChunkGeom
+    {
+        long long n;
+        int L, W, K;
+    };
+    inline ChunkGeom make_geom(long long n, int L, int W)
+    {
+        ChunkGeom g{n, L, W, 1};
+        if (n > (long long)L + W)
+            g.K = 1 + (int)((n - (L + W) + L - 1) / L);
+        return g;
+    }
+    __host__ __device__ inline long long chunk_begin(const ChunkGeom &g, int k) { return k == 0 ? 0 : (long long)g.W + (long long)k * g.L; }
+    __host__ __device__ inline long long chunk_end(const ChunkGeom &g, int k)
+    {
+        const long long e = (long long)g.W + (long long)(k + 1) * g.L;
+        return e < g.n ? e : g.n;
+    }
+
+    // ---- format conversion (baseband_interface.h:172-199) + iq_swap --------------------------------
+    void launch_convert(const void *in, int fmt, int iq_swap, long long n, cf32 *out, hipStream_t st);
+
+    // ---- DC block -- not speculated yet: sequential single lane (correct_iq.cpp:27-31) ---------------
+    struct DcState
+    {
+        float acc_re, acc_im;
+    };
+    void launch_dcblock_seq(const cf32 *x, cf32 *y, long long n, DcState *state, hipStream_t st);
+
+    // ---- rational resampler (rational_resampler.cpp:43-64), fully parallel ---------------------------
+    // out[m] for m in [0, nout): global output index m0+m; input index/phase follow inc=(m*decim)/interp, ctr=(m*decim)%interp
+    struct ResampParams
+    {
+        int interp, decim, ntaps;
+        const float *bank; // [interp][ntaps] device
+    };
+    // x points at input sample 0 of this call (history at negative indices); phase0 = d_ctr, inc0 = carried inc
+    void launch_resample(const cf32 *x, long long nin, const ResampParams &p, int ctr0, int inc0, cf32 *y, long long nout, hipStream_t st);
+
+    // ---- AGC -----------------------------------------------------------------------------------------
+    struct AgcParams
+    {
+        float rate, reference, max_gain, init_gain;
+    };
+    struct AgcState
+    {
+        float gain;
+    };
+    // redo == nullptr: speculative pass over all chunks (spec/endst written). redo != nullptr: re-run chunks redo[0..nredo)
+    // from endst[k-1].
+    void launch_agc(const cf32 *x, cf32 *y, const ChunkGeom &g, const AgcParams &p, const AgcState *start0, AgcState *spec, AgcState *endst,
+                    const int *redo, int nredo, hipStream_t st);
+
+    // ---- RRC FIR (fir.cpp:74-83), fully parallel; taps reversed on the host, ntaps <= 361 ----------------
+    void launch_fir(const cf32 *x, cf32 *y, long long n, const float *rtaps_dev, int ntaps, hipStream_t st);
+
+    // ---- Costas loop ---------------------------------------------------------------------------------
+    struct CostasParams
+    {
+        float alpha, beta, fmin, fmax;
+        int order;
+        float init_freq; // warm-up start frequency
+    };
+    struct CostasState
+    {
+        float phase, freq;
+    };
+    void launch_costas(const cf32 *x, cf32 *y, const ChunkGeom &g, const CostasParams &p, const CostasState *start0, CostasState *spec, CostasState *endst,
+                       const int *redo, int nredo, hipStream_t st);
+
+    // ---- M&M clock recovery + quantiser ------------------------------------------------------------------
+    struct MmParams
+    {
+        float omega_gain, mu_gain, omega_mid, omega_limit, init_mu;
+        const float *bank; // [128][8] device
+        int oqpsk;         // DelayOneImag folded into the read (delay_one_imag.cpp:20-27)
+        // rotation of the Costas output per Costas chunk (quarter turns for order 4, half turns for order 2,
+        // eighth turns for order 8), indexed by the Costas stage's chunk geometry
+        ChunkGeom cg;
+        const int *rot;
+        int order;
+        int cap; // output capacity per chunk (symbols)
+    };
+    struct MmState
+    {
+        float mu, omega;
+        cf32 p_2T, p_1T, p_0T, c_2T, c_1T, c_0T;
+        long long inc; // position in this call's sample index space
+    };
+    void launch_mm(const cf32 *x, cf32 *sym_scratch, int *counts, const ChunkGeom &g, const MmParams &p, const MmState *start0, MmState *spec, MmState *endst,
+                   const int *redo, int nredo, hipStream_t st);
+    // compaction + quantiser (module_psk_demod.cpp:199-213): chunk k's counts[k] symbols go to offsets[k]
+    void launch_quantize(const cf32 *sym_scratch, const int *counts, const long long *offsets, int K, int cap, int bpsk, int8_t *soft, long long soft_cap,
+                         float *syms, long long syms_cap, hipStream_t st);
+    // rotated copy of the last `cnt` Costas outputs (history for the next call), incl. the per-chunk rotation
+    void launch_tail_copy(const cf32 *x, long long n, int cnt, const ChunkGeom &cg, const int *rot, int order, cf32 *out, hipStream_t st);
+} // namespace sdhip

@@ -1,0 +1,899 @@
+// fec_engine.hip -- host side of the FEC chain: replays the reference's small sequential state
+// machines (Viterbi lock FSM, ASM deframer FSM, MetOp watchdog) around the batch kernels of
+// fec_kernels.hip, verifies every speculation the kernels make, and exposes the C ABI of include/sdhip.h.
+//
+// What runs where:
+//   GPU : symbol rotation/conversion, depuncture, ACS, traceback, BER re-encode, lock-search decodes,
+//         NRZ-M, exact ASM search over every bit, frame extraction, derandomiser, Reed-Solomon.
+//   host: O(#blocks) Viterbi lock FSM (viterbi_1_2.cpp:52-117), O(#frames) deframer FSM
+//         (bpsk_ccsds_deframer.cpp:24-107) working on the packed bit stream, rs_usecheck filter.
+#include "fec_kernels.h"
+#include "../../include/sdhip.h"
+#include <algorithm>
+#include <cmath>
+#include <mutex>
+#include <vector>
+
+namespace sdhip
+{
+    static thread_local std::string g_last_error;
+    void set_error(const std::string &msg) { g_last_error = msg; }
+
+    __global__ void k_unpack_bits(const unsigned *vbits, int wpb, int F, int nblk, unsigned char *out)
+    {
+        const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+        if (i >= (long long)nblk * F)
+            return;
+        const int j = (int)(i / F), n = (int)(i % F);
+        out[i] = (unsigned char)((vbits[(size_t)j * wpb + (n >> 5)] >> (31 - (n & 31))) & 1u);
+    }
+
+    // raw (pre NRZ-M) bits [from, from + nbits) of a logical stream -> new carry buffer (word aligned at its start)
+    __global__ void k_make_carry(BitStream bs, long long from, int nwords, unsigned *out)
+    {
+        const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+        if (i >= nwords)
+            return;
+        // inline copy of stream_raw32 semantics via the public kernel helper is not visible here; re-implemented
+        long long g = from + (long long)i * 32;
+        unsigned o = 0;
+        for (int b = 0; b < 32; b++, g++)
+        {
+            unsigned bit = 0;
+            if (g >= 0 && g < bs.carry_bits)
+                bit = (bs.carry[g >> 5] >> (31 - (g & 31))) & 1u;
+            else if (g >= bs.carry_bits)
+            {
+                const long long g2 = g - bs.carry_bits;
+                const long long j = g2 / bs.F;
+                if (j < bs.nblk)
+                {
+                    const int n = (int)(g2 - j * bs.F);
+                    bit = (bs.vbits[(size_t)j * bs.wpb + (n >> 5)] >> (31 - (n & 31))) & 1u;
+                }
+            }
+            o |= bit << (31 - b);
+        }
+        out[i] = o;
+    }
+
+    struct DeframerState
+    {
+        int state = 2; // numeric thresholds as in bpsk_ccsds_deframer.h:33-35
+        int inv = 0;
+        int good = 0, invalid = 0;
+        int64_t next_check = 0;     // absolute bit position of the next state-machine evaluation
+        int64_t pending_start = -1; // absolute position of the first payload bit of a frame not yet emitted
+    };
+
+    struct FecEngine
+    {
+        sdhip_fec_cfg cfg;
+        hipStream_t stream = nullptr;
+        int B = 0, F = 0, nber = 0, cadu_bytes = 0, wpb = 0, dstride = 0;
+        VitCfg vc{};
+        int phases[4] = {0, 0, 0, 0};
+        int nphases = 1, n_swap = 1;
+        int st_synced = 12;
+        double ber_mult = 2.5;
+        int max_batch = 16384;
+
+        // Viterbi FSM (viterbi_1_2.h:25-31)
+        int vstate = 0, v_iq_swap = 0, v_phase = 0, v_shift = 0, v_invalid = 0;
+        float v_ber = 10;
+        float v_bers[2][4][2];
+        int dec_first = 1, dec_start = 0; // cc_decoder chaining
+        VitSearchState search{};          // cc_decoder_ber / cc_encoder_ber / ber_decoded_buffer
+        int metop_nosync_runs = 0;
+
+        // deframer
+        DeframerState def;
+        int64_t abs_bits = 0; // absolute index of the first bit AFTER everything handed to the deframer so far
+        std::vector<uint32_t> carry_host;
+        int carry_bits = 0;   // carry holds raw bits [abs_bits - carry_bits, abs_bits)
+
+        // RS bookkeeping
+        int last_errors[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+
+        // pending partial block (host copy) and output queue for the host path
+        std::vector<int8_t> pending;
+        std::vector<uint8_t> out_queue;
+        size_t out_queue_read = 0;
+
+        // taps of the last call
+        std::vector<float> tap_ber;
+        std::vector<int> tap_state;
+
+        sdhip_fec_stats stats{};
+
+        // device buffers
+        DevBuf<int8_t> d_stage;
+        DevBuf<VitBlockIO> d_io;
+        DevBuf<uint64_t> d_dec;
+        DevBuf<uint32_t> d_vbits;
+        DevBuf<uint32_t> d_carry[2];
+        int carry_sel = 0;
+        DevBuf<VitSearchState> d_search;
+        DevBuf<uint32_t> d_hits;
+        DevBuf<int> d_count;
+        DevBuf<uint8_t> d_packed;
+        DevBuf<FrameDesc> d_frames;
+        DevBuf<uint8_t> d_fbytes;
+        DevBuf<int> d_ferr;
+        DevBuf<int> d_dst;
+        DevBuf<uint8_t> d_out_tmp;
+        PinBuf<VitBlockIO> h_io;
+        PinBuf<uint8_t> h_packed;
+        PinBuf<uint32_t> h_hits;
+        PinBuf<int> h_ferr;
+        std::vector<FrameDesc> h_frames;
+        std::vector<int> h_dst;
+
+        explicit FecEngine(const sdhip_fec_cfg &c) : cfg(c)
+        {
+            SD_HIP(hipSetDevice(cfg.device));
+            SD_HIP(hipStreamCreate(&stream));
+            if (cfg.cadu_size <= 32 || cfg.cadu_size % 8 != 0)
+                throw HipError("cadu_size must be a multiple of 8 bits (padded frames are not supported by the HIP path)");
+            cadu_bytes = cfg.cadu_size / 8;
+            if (cfg.decoder == SDHIP_DEC_METOP_AHRPT)
+            {
+                // MetOpAHRPTDecoderModule: BUFFER_SIZE 16384, Viterbi3_4(thr, outsync, 16384), STATE_SYNCED = 18,
+                // derand from byte 4, RS223 dual basis I=4 fill 0, every frame written
+                // (plugins/noaa_metop_support/metop/module_metop_ahrpt_decoder.cpp:10-28,74-85)
+                B = 16384;
+                F = 12288;
+                nber = 1536;
+                ber_mult = 5;
+                vc.mode = 1;
+                vc.pre_swap = 0;
+                nphases = 2;
+                phases[0] = 0;
+                phases[1] = 1;
+                n_swap = 1;
+                st_synced = 18;
+                cfg.cadu_size = 8192;
+                cadu_bytes = 1024;
+                cfg.nrzm = 0;
+                cfg.derandomize = 1;
+                cfg.derand_after_rs = 0;
+                cfg.derand_start = 4;
+                cfg.rs_i = 4;
+                cfg.rs_fill_bytes = 0;
+                cfg.rs_dualbasis = 1;
+                cfg.rs_type = SDHIP_RS223;
+                cfg.rs_usecheck = 0;
+                cfg.asm_sync = 0x1ACFFC1D;
+            }
+            else
+            {
+                // CCSDSConvConcatDecoderModule ctor, module_ccsds_conv_concat_decoder.cpp:16-131
+                B = std::max(cfg.cadu_size, 8192);
+                if (B % 2)
+                    throw HipError("odd buffer size");
+                F = B / 2;
+                nber = 1024;
+                ber_mult = 2.5;
+                vc.mode = 0;
+                const bool bpsk = cfg.constellation == SDHIP_BPSK || cfg.constellation == SDHIP_BPSK_90;
+                const bool bpsk90 = cfg.constellation == SDHIP_BPSK_90;
+                if (bpsk && !bpsk90)
+                {
+                    nphases = 1;
+                    phases[0] = 0;
+                }
+                else if (bpsk90)
+                {
+                    nphases = 1;
+                    phases[0] = 1;
+                }
+                else if (cfg.constellation == SDHIP_QPSK || cfg.constellation == SDHIP_OQPSK)
+                {
+                    nphases = 2;
+                    phases[0] = 0;
+                    phases[1] = 1;
+                }
+                else
+                    throw HipError("CCSDS Concatenated 1/2 Decoder : invalid constellation type!");
+                n_swap = cfg.constellation == SDHIP_OQPSK ? 2 : 1;
+                vc.pre_swap = (bpsk90 || cfg.iq_invert) ? 1 : 0;
+                st_synced = 12;
+                if (cfg.rs_i != 0 && cfg.rs_type != SDHIP_RS223 && cfg.rs_type != SDHIP_RS239)
+                    throw HipError("CCSDS Concatenated 1/2 Decoder : invalid Reed-Solomon type!");
+                if (cfg.rs_i < 0 || cfg.rs_i > 8)
+                    throw HipError("rs_i out of range");
+                if (cfg.rs_i != 0 && 4 + 255 * cfg.rs_i - std::max(cfg.rs_fill_bytes, 0) * cfg.rs_i > cadu_bytes + 0 && cfg.rs_fill_bytes >= 0 && false)
+                    throw HipError("RS block does not fit the CADU");
+            }
+            vc.B = B;
+            vc.F = F;
+            vc.nber = nber;
+            wpb = vit_words_per_block(F);
+            dstride = (F + 6 + 63) / 64 * 64;
+            for (int s = 0; s < 2; s++)
+                for (int p = 0; p < 4; p++)
+                    for (int o = 0; o < 2; o++)
+                        v_bers[s][p][o] = 10;
+            memset(&search, 0, sizeof(search));
+            search.ber_first = 1;
+            // the deframer's shifter starts at 0: 64 zero bits of history
+            carry_bits = 64;
+            carry_host.assign(2, 0u);
+            def.next_check = 0;
+            abs_bits = 0;
+            d_search.reserve(1);
+            d_count.reserve(1);
+            upload_carry();
+        }
+        ~FecEngine()
+        {
+            if (stream)
+                (void)hipStreamDestroy(stream);
+        }
+
+        void upload_carry()
+        {
+            carry_sel ^= 1;
+            DevBuf<uint32_t> &c = d_carry[carry_sel];
+            c.reserve(carry_host.size() + 2);
+            SD_HIP(hipMemcpyAsync(c.p, carry_host.data(), carry_host.size() * 4, hipMemcpyHostToDevice, stream));
+            SD_HIP(hipMemsetAsync(c.p + carry_host.size(), 0, 8, stream));
+        }
+
+        // ------------------------------------------------------------------ Viterbi lock search on one block
+        void run_search(const int8_t *d_soft, int64_t block)
+        {
+            SD_HIP(hipMemcpyAsync(d_search.p, &search, sizeof(search), hipMemcpyHostToDevice, stream));
+            launch_vit_search(vc, d_soft, block, n_swap, phases, nphases, d_search.p, stream);
+            SD_HIP(hipMemcpyAsync(&search, d_search.p, sizeof(search), hipMemcpyDeviceToHost, stream));
+            SD_HIP(hipStreamSynchronize(stream));
+            // acceptance rule, viterbi_1_2.cpp:73-86 / viterbi_3_4.cpp:130-143
+            v_ber = 10;
+            int cand = 0;
+            const int nsw = vc.mode == 0 ? n_swap : 1;
+            const int nph = vc.mode == 0 ? nphases : 2;
+            for (int s = 0; s < nsw; s++)
+                for (int pi = 0; pi < nph; pi++)
+                    for (int shift = 0; shift < 2; shift++, cand++)
+                    {
+                        const int phase = vc.mode == 0 ? phases[pi] : pi;
+                        const float errors = (float)search.err[cand], total = (float)search.tot[cand];
+                        const float ber = (float)((errors / total) * ber_mult);
+                        v_bers[s][phase][shift] = ber;
+                        if ((v_ber == 10 && ber < cfg.viterbi_ber_thresold) || (v_ber < 10 && ber < v_ber))
+                        {
+                            v_ber = ber;
+                            v_iq_swap = s;
+                            vstate = 1;
+                            v_phase = phase;
+                            v_shift = shift;
+                            v_invalid = 0;
+                        }
+                    }
+        }
+
+        float current_ber() const
+        { // Viterbi1_2::ber(), viterbi_1_2.cpp:119-133
+            if (vstate == 1)
+                return v_ber;
+            float ber = 10;
+            const int nsw = vc.mode == 0 ? n_swap : 1;
+            const int nph = vc.mode == 0 ? nphases : 2;
+            for (int s = 0; s < nsw; s++)
+                for (int pi = 0; pi < nph; pi++)
+                    for (int o = 0; o < 2; o++)
+                    {
+                        const int phase = vc.mode == 0 ? phases[pi] : pi;
+                        if (ber > v_bers[s][phase][o])
+                            ber = v_bers[s][phase][o];
+                    }
+            return ber;
+        }
+
+        // ------------------------------------------------------------------ deframer FSM on the packed stream
+        struct WalkResult
+        {
+            DeframerState st;
+            std::vector<FrameDesc> frames; // pos relative to the call's logical stream
+            std::vector<int> state_at;     // deframer state after each block
+        };
+
+        static inline uint32_t window_at(const uint8_t *bytes, int64_t p)
+        { // 32 bits ending at stream-relative bit p (p >= 31)
+            const int64_t s = p - 31;
+            const int64_t byte = s >> 3;
+            const int sh = (int)(s & 7);
+            uint64_t v = 0;
+            for (int i = 0; i < 5; i++)
+                v = (v << 8) | bytes[byte + i];
+            return (uint32_t)((v << (24 + sh)) >> 32);
+        }
+
+        WalkResult walk(const DeframerState &in, const uint8_t *bytes, int64_t base_abs, int64_t total_rel, const std::vector<uint32_t> &hits, int nblk) const
+        {
+            // bytes: NRZ-M decoded logical stream of this call, relative index r <-> absolute base_abs + r
+            WalkResult R;
+            R.st = in;
+            DeframerState &s = R.st;
+            R.state_at.assign(nblk, s.state);
+            const int CADU = cfg.cadu_size;
+            const int64_t avail_end = base_abs + total_rel;
+            const uint32_t ASM = cfg.asm_sync, ASMI = ~cfg.asm_sync;
+            int blk_ptr = 0;
+            auto blk_end_abs = [&](int j) -> int64_t { return base_abs + carry_bits + (int64_t)(j + 1) * F - 1; };
+            auto settle_blocks = [&](int64_t upto_exclusive) {
+                while (blk_ptr < nblk && blk_end_abs(blk_ptr) < upto_exclusive)
+                    R.state_at[blk_ptr++] = s.state;
+            };
+            size_t hit_ptr = 0;
+            for (;;)
+            {
+                if (s.pending_start >= 0)
+                {
+                    const int64_t last = s.pending_start + (CADU - 32) - 1;
+                    if (last >= avail_end)
+                        break;
+                    FrameDesc d;
+                    d.pos = s.pending_start - base_abs;
+                    d.inv = s.inv;
+                    d.pad = 0;
+                    R.frames.push_back(d);
+                    s.pending_start = -1;
+                }
+                const int64_t p = s.next_check;
+                if (p >= avail_end)
+                    break;
+                settle_blocks(p);
+                if (s.state == 2)
+                {
+                    // exact ASM / ~ASM, bit by bit (bpsk_ccsds_deframer.cpp:49-67): jump to the next GPU-found hit
+                    const int64_t prel = p - base_abs;
+                    while (hit_ptr < hits.size() && (int64_t)(hits[hit_ptr] >> 1) < prel)
+                        hit_ptr++;
+                    if (hit_ptr >= hits.size())
+                    {
+                        s.next_check = avail_end;
+                        break;
+                    }
+                    const int64_t q = base_abs + (int64_t)(hits[hit_ptr] >> 1);
+                    settle_blocks(q);
+                    s.inv = (int)(hits[hit_ptr] & 1u);
+                    s.state = 6;
+                    s.good = s.invalid = 0;
+                    s.pending_start = q + 1;
+                    s.next_check = q + CADU;
+                }
+                else
+                {
+                    const uint32_t w = window_at(bytes, p - base_abs);
+                    const int dist = __builtin_popcount(w ^ (s.inv ? ASMI : ASM));
+                    if (s.state == 6)
+                    {
+                        if (dist < s.state)
+                        {
+                            s.pending_start = p + 1;
+                            s.next_check = p + CADU;
+                            s.invalid = 0;
+                            s.good++;
+                            if (s.good > 10)
+                                s.state = st_synced;
+                        }
+                        else
+                        {
+                            s.invalid++;
+                            s.good = 0;
+                            if (s.invalid > 2)
+                                s.state = 2;
+                            s.next_check = p + 1;
+                        }
+                    }
+                    else
+                    {
+                        if (dist < s.state)
+                        {
+                            s.pending_start = p + 1;
+                            s.next_check = p + CADU;
+                        }
+                        else
+                        {
+                            s.good = s.invalid = 0;
+                            s.state = 2;
+                            s.next_check = p + 1;
+                        }
+                    }
+                }
+            }
+            settle_blocks(avail_end);
+            while (blk_ptr < nblk)
+                R.state_at[blk_ptr++] = s.state;
+            return R;
+        }
+
+        // ------------------------------------------------------------------ one run of SYNCED blocks -> frames
+        // d_soft: device pointer to block 0 of the contiguous region; [blk0, blk0 + n) were decoded into d_vbits.
+        // Returns the number of blocks actually consumed by the deframer (may be < n for the MetOp watchdog).
+        int deframe_and_emit(int n, uint8_t *d_out, size_t out_cap_frames, size_t &out_written)
+        {
+            int n_eff = n;
+            bool watchdog_fired = false;
+            for (int attempt = 0; attempt < 3; attempt++)
+            {
+                BitStream bs;
+                bs.carry = d_carry[carry_sel].p;
+                bs.carry_bits = carry_bits;
+                bs.vbits = d_vbits.p;
+                bs.F = F;
+                bs.wpb = wpb;
+                bs.nblk = n_eff;
+                bs.nrzm = cfg.nrzm;
+                const int64_t total = carry_bits + (int64_t)n_eff * F;
+                const int64_t base_abs = abs_bits - carry_bits;
+                // exact hits are only needed from the first position the FSM may evaluate
+                const int hits_cap = (int)std::min<int64_t>(total / 64 + 1024, 1 << 26);
+                d_hits.reserve(hits_cap);
+                h_hits.reserve(hits_cap);
+                SD_HIP(hipMemsetAsync(d_count.p, 0, sizeof(int), stream));
+                int64_t from = std::max<int64_t>(def.next_check - base_abs, 32);
+                launch_sync_search(bs, from, cfg.asm_sync, d_hits.p, hits_cap, d_count.p, stream);
+                const size_t pbytes = (size_t)((total + 31) / 32) * 4 + 8;
+                d_packed.reserve(pbytes);
+                h_packed.reserve(pbytes);
+                launch_pack_stream(bs, d_packed.p, total, stream);
+                int count = 0;
+                SD_HIP(hipMemcpyAsync(&count, d_count.p, sizeof(int), hipMemcpyDeviceToHost, stream));
+                SD_HIP(hipMemcpyAsync(h_packed.p, d_packed.p, pbytes - 8, hipMemcpyDeviceToHost, stream));
+                SD_HIP(hipStreamSynchronize(stream));
+                if (count > hits_cap)
+                    throw HipError("ASM hit list overflow");
+                std::vector<uint32_t> hits(count);
+                if (count)
+                {
+                    SD_HIP(hipMemcpy(hits.data(), d_hits.p, (size_t)count * 4, hipMemcpyDeviceToHost));
+                    for (auto &h : hits)
+                        h += (uint32_t)(from << 1);
+                    std::sort(hits.begin(), hits.end());
+                }
+                memset(h_packed.p + pbytes - 8, 0, 8);
+                WalkResult W = walk(def, h_packed.p, base_abs, total, hits, n_eff);
+
+                if (cfg.decoder == SDHIP_DEC_METOP_AHRPT)
+                {
+                    // watchdog, module_metop_ahrpt_decoder.cpp:59-72: 10 consecutive calls ending in NOSYNC reset the Viterbi
+                    int runs = metop_nosync_runs, cut = -1;
+                    for (int j = 0; j < n_eff; j++)
+                    {
+                        if (W.state_at[j] == 2)
+                        {
+                            runs++;
+                            if (runs >= 10)
+                            {
+                                runs = 0;
+                                cut = j;
+                                break;
+                            }
+                        }
+                        else
+                            runs = 0;
+                    }
+                    if (cut >= 0 && cut + 1 < n_eff)
+                    {
+                        n_eff = cut + 1; // bits decoded after the reset must not reach the deframer: walk again, shorter
+                        continue;
+                    }
+                    metop_nosync_runs = runs;
+                    if (cut >= 0)
+                        watchdog_fired = true;
+                }
+
+                // ---- frames: extract + derand + RS on the GPU
+                const int nf = (int)W.frames.size();
+                stats.frames_deframed += nf;
+                if (nf > 0)
+                {
+                    d_frames.reserve(nf);
+                    d_fbytes.reserve((size_t)nf * cadu_bytes + 64);
+                    const int I = std::max(cfg.rs_i, 1);
+                    d_ferr.reserve((size_t)nf * I);
+                    h_ferr.reserve((size_t)nf * I);
+                    SD_HIP(hipMemcpyAsync(d_frames.p, W.frames.data(), (size_t)nf * sizeof(FrameDesc), hipMemcpyHostToDevice, stream));
+                    FrameCfg fc;
+                    fc.cadu_bits = cfg.cadu_size;
+                    fc.cadu_bytes = cadu_bytes;
+                    fc.asm_sync = cfg.asm_sync;
+                    fc.derand = cfg.derandomize;
+                    fc.derand_after_rs = cfg.derand_after_rs;
+                    fc.derand_start = cfg.derand_start;
+                    fc.rs_i = cfg.rs_i;
+                    fc.rs_fill_bytes = cfg.rs_fill_bytes;
+                    fc.rs_dualbasis = cfg.rs_dualbasis;
+                    fc.rs_nroots = cfg.rs_type == SDHIP_RS239 ? 16 : 32;
+                    launch_frames(bs, fc, d_frames.p, nf, d_fbytes.p, d_ferr.p, stream);
+                    h_dst.assign(nf, -1);
+                    size_t kept = 0;
+                    if (cfg.rs_i != 0)
+                    {
+                        SD_HIP(hipMemcpyAsync(h_ferr.p, d_ferr.p, (size_t)nf * I * sizeof(int), hipMemcpyDeviceToHost, stream));
+                        SD_HIP(hipStreamSynchronize(stream));
+                    }
+                    for (int f = 0; f < nf; f++)
+                    {
+                        bool valid = true;
+                        if (cfg.rs_i != 0)
+                        {
+                            for (int k = 0; k < cfg.rs_i; k++)
+                            {
+                                last_errors[k] = h_ferr.p[(size_t)f * I + k];
+                                if (last_errors[k] == -1)
+                                    valid = false;
+                            }
+                        }
+                        else
+                        { // errors[] keeps its previous content when RS is off (module_ccsds_conv_concat_decoder.cpp:183-186)
+                            for (int k = 0; k < 0; k++)
+                                (void)k;
+                        }
+                        if (!cfg.rs_usecheck || valid)
+                            h_dst[f] = (int)(out_written + kept++);
+                    }
+                    if (kept)
+                    {
+                        if (d_out)
+                        {
+                            if (out_written + kept > out_cap_frames)
+                                throw HipError("CADU output buffer too small");
+                            d_dst.reserve(nf);
+                            SD_HIP(hipMemcpyAsync(d_dst.p, h_dst.data(), (size_t)nf * sizeof(int), hipMemcpyHostToDevice, stream));
+                            launch_compact(d_fbytes.p, d_dst.p, nf, cadu_bytes, d_out, stream);
+                            SD_HIP(hipStreamSynchronize(stream));
+                        }
+                        else
+                        {
+                            std::vector<uint8_t> tmp((size_t)nf * cadu_bytes);
+                            SD_HIP(hipMemcpyAsync(tmp.data(), d_fbytes.p, tmp.size(), hipMemcpyDeviceToHost, stream));
+                            SD_HIP(hipStreamSynchronize(stream));
+                            for (int f = 0; f < nf; f++)
+                                if (h_dst[f] >= 0)
+                                    out_queue.insert(out_queue.end(), tmp.begin() + (size_t)f * cadu_bytes, tmp.begin() + (size_t)(f + 1) * cadu_bytes);
+                        }
+                        out_written += kept;
+                        stats.frames_out += kept;
+                    }
+                }
+
+                // ---- commit deframer state and build the next carry (raw bits) ----------------------------
+                def = W.st;
+                const int64_t avail_end = base_abs + total;
+                int64_t keep_from = avail_end - 64;
+                if (def.pending_start >= 0)
+                    keep_from = std::min(keep_from, def.pending_start - 34);
+                keep_from = std::min(keep_from, def.next_check - 34);
+                keep_from = std::max(keep_from, base_abs); // cannot keep more than we have
+                int new_bits = (int)(avail_end - keep_from);
+                const int nwords = (new_bits + 31) / 32;
+                const int pad = nwords * 32 - new_bits; // align the END of the carry to a word boundary: pad at the front
+                DevBuf<uint32_t> &nc = d_carry[carry_sel ^ 1];
+                nc.reserve(nwords + 2);
+                k_make_carry<<<dim3((nwords + 63) / 64), dim3(64), 0, stream>>>(bs, keep_from - pad - base_abs, nwords, nc.p);
+                SD_HIP(hipMemsetAsync(nc.p + nwords, 0, 8, stream));
+                SD_HIP(hipStreamSynchronize(stream));
+                carry_sel ^= 1;
+                carry_bits = nwords * 32;
+                abs_bits = avail_end;
+                stats.bits_decoded += (uint64_t)n_eff * F;
+                if (watchdog_fired)
+                    vstate = 0; // viterbi.reset()
+                return n_eff;
+            }
+            throw HipError("deframer walk did not converge");
+        }
+
+        // ------------------------------------------------------------------ main driver over whole blocks
+        void process_blocks(const int8_t *d_soft, int64_t nblocks, uint8_t *d_out, size_t out_cap_frames, size_t &out_written)
+        {
+            int64_t pos = 0;
+            tap_ber.reserve(tap_ber.size() + nblocks);
+            tap_state.reserve(tap_state.size() + nblocks);
+            while (pos < nblocks)
+            {
+                if (vstate == 0)
+                {
+                    run_search(d_soft, pos);
+                    if (vstate == 0)
+                    {
+                        tap_ber.push_back(current_ber());
+                        tap_state.push_back(0);
+                        pos++;
+                        stats.blocks++;
+                        continue;
+                    }
+                    stats.viterbi_lock = 1;
+                }
+                // ---- speculative SYNCED run
+                const int n = (int)std::min<int64_t>(nblocks - pos, max_batch);
+                vc.iq_swap = v_iq_swap;
+                vc.phase = v_phase;
+                vc.shift = v_shift;
+                d_io.reserve(n);
+                h_io.reserve(n);
+                d_dec.reserve((size_t)n * dstride);
+                d_vbits.reserve((size_t)n * wpb + 4);
+                for (int j = 0; j < n; j++)
+                {
+                    h_io.p[j] = VitBlockIO{};
+                    h_io.p[j].start_in = -1;
+                }
+                h_io.p[0].start_in = dec_first ? -2 : dec_start;
+                SD_HIP(hipMemcpyAsync(d_io.p, h_io.p, (size_t)n * sizeof(VitBlockIO), hipMemcpyHostToDevice, stream));
+                launch_vit_decode(vc, d_soft, pos, n, d_io.p, d_dec.p, d_vbits.p, stream);
+                SD_HIP(hipMemcpyAsync(h_io.p, d_io.p, (size_t)n * sizeof(VitBlockIO), hipMemcpyDeviceToHost, stream));
+                SD_HIP(hipStreamSynchronize(stream));
+                // verify the start-state chain; re-decode on a miss (exactness certificate)
+                for (int j = 1; j < n; j++)
+                {
+                    stats.tb_respec += h_io.p[j - 1].tb_fallback;
+                    if (h_io.p[j].start_used != h_io.p[j - 1].ret_state)
+                    {
+                        stats.vit_respec++;
+                        VitBlockIO one{};
+                        one.start_in = h_io.p[j - 1].ret_state;
+                        SD_HIP(hipMemcpyAsync(d_io.p + j, &one, sizeof(one), hipMemcpyHostToDevice, stream));
+                        launch_vit_decode(vc, d_soft, pos + j, 1, d_io.p + j, d_dec.p + (size_t)j * dstride, d_vbits.p + (size_t)j * wpb, stream);
+                        SD_HIP(hipMemcpyAsync(h_io.p + j, d_io.p + j, sizeof(one), hipMemcpyDeviceToHost, stream));
+                        SD_HIP(hipStreamSynchronize(stream));
+                    }
+                }
+                stats.tb_respec += h_io.p[n - 1].tb_fallback;
+                // BER estimate of every block, then the lock FSM (viterbi_1_2.cpp:101-113)
+                launch_vit_ber(vc, d_soft, pos, n, d_vbits.p, search.enc_state, d_io.p, stream);
+                SD_HIP(hipMemcpyAsync(h_io.p, d_io.p, (size_t)n * sizeof(VitBlockIO), hipMemcpyDeviceToHost, stream));
+                SD_HIP(hipStreamSynchronize(stream));
+                int accepted = n;
+                const size_t tap0 = tap_ber.size();
+                for (int j = 0; j < n; j++)
+                {
+                    const float errors = (float)h_io.p[j].ber_err, total = (float)h_io.p[j].ber_tot;
+                    v_ber = (float)((errors / total) * ber_mult);
+                    if (v_ber > cfg.viterbi_ber_thresold)
+                    {
+                        v_invalid++;
+                        if ((float)v_invalid > (float)cfg.viterbi_outsync_after)
+                            vstate = 0;
+                    }
+                    else
+                        v_invalid = 0;
+                    tap_ber.push_back(current_ber());
+                    tap_state.push_back(vstate);
+                    if (vstate == 0)
+                    {
+                        accepted = j + 1;
+                        break;
+                    }
+                }
+                // hand the accepted blocks to the deframer (the MetOp watchdog may cut the run shorter)
+                const int used = deframe_and_emit(accepted, d_out, out_cap_frames, out_written);
+                if (used < accepted)
+                { // MetOp watchdog reset the Viterbi after block used-1: the rest of the run is decoded again after re-lock
+                    accepted = used;
+                    tap_ber.resize(tap0 + accepted);
+                    tap_state.resize(tap0 + accepted);
+                }
+                dec_first = 0;
+                dec_start = h_io.p[accepted - 1].ret_state;
+                search.enc_state = (unsigned)h_io.p[accepted - 1].pad;
+                pos += accepted;
+                stats.blocks += accepted;
+            }
+            stats.viterbi_lock = vstate;
+            stats.viterbi_ber = current_ber();
+            stats.deframer_state = def.state;
+            for (int k = 0; k < 8; k++)
+                stats.rs_errors[k] = last_errors[k];
+        }
+
+        // ------------------------------------------------------------------ entry points
+        int64_t process_dev(const int8_t *d_soft, size_t n, uint8_t *d_out, size_t out_cap_frames)
+        {
+            SD_HIP(hipSetDevice(cfg.device));
+            tap_ber.clear();
+            tap_state.clear();
+            size_t out_written = 0;
+            size_t off = 0;
+            stats.soft_in += n;
+            if (!pending.empty())
+            {
+                const size_t need = (size_t)B - pending.size();
+                const size_t take = std::min(need, n);
+                const size_t old = pending.size();
+                pending.resize(old + take);
+                SD_HIP(hipMemcpy(pending.data() + old, d_soft, take, hipMemcpyDeviceToHost));
+                off = take;
+                if (pending.size() == (size_t)B)
+                {
+                    d_stage.reserve(B);
+                    SD_HIP(hipMemcpy(d_stage.p, pending.data(), B, hipMemcpyHostToDevice));
+                    pending.clear();
+                    process_blocks(d_stage.p, 1, d_out, out_cap_frames, out_written);
+                }
+            }
+            const size_t nb = (n - off) / B;
+            if (nb)
+                process_blocks(d_soft + off, (int64_t)nb, d_out, out_cap_frames, out_written);
+            off += nb * (size_t)B;
+            if (off < n)
+            {
+                const size_t old = pending.size();
+                pending.resize(old + (n - off));
+                SD_HIP(hipMemcpy(pending.data() + old, d_soft + off, n - off, hipMemcpyDeviceToHost));
+            }
+            return (int64_t)out_written;
+        }
+
+        DevBuf<int8_t> d_push;
+        int push_host(const int8_t *soft, size_t n)
+        {
+            SD_HIP(hipSetDevice(cfg.device));
+            // assemble pending + new data on the host, ship whole blocks
+            const size_t old = pending.size();
+            pending.insert(pending.end(), soft, soft + n);
+            stats.soft_in += n;
+            const size_t nb = pending.size() / B;
+            (void)old;
+            if (nb)
+            {
+                d_push.reserve(nb * (size_t)B);
+                SD_HIP(hipMemcpy(d_push.p, pending.data(), nb * (size_t)B, hipMemcpyHostToDevice));
+                size_t out_written = 0;
+                tap_ber.clear();
+                tap_state.clear();
+                process_blocks(d_push.p, (int64_t)nb, nullptr, 0, out_written);
+                pending.erase(pending.begin(), pending.begin() + nb * (size_t)B);
+            }
+            return 0;
+        }
+        int64_t pull(uint8_t *cadu, size_t cap_frames)
+        {
+            const size_t avail = (out_queue.size() - out_queue_read) / cadu_bytes;
+            const size_t take = std::min(avail, cap_frames);
+            memcpy(cadu, out_queue.data() + out_queue_read, take * cadu_bytes);
+            out_queue_read += take * cadu_bytes;
+            if (out_queue_read == out_queue.size())
+            {
+                out_queue.clear();
+                out_queue_read = 0;
+            }
+            return (int64_t)take;
+        }
+    };
+} // namespace sdhip
+
+using namespace sdhip;
+
+#define SD_GUARD_BEGIN try {
+#define SD_GUARD_END(ret)                \
+    }                                    \
+    catch (const std::exception &e)      \
+    {                                    \
+        sdhip::set_error(e.what());      \
+        return ret;                      \
+    }
+
+extern "C"
+{
+    const char *sdhip_last_error(void) { return g_last_error.c_str(); }
+    const char *sdhip_version(void) { return "sdhip 0.1 (gfx950)"; }
+    int sdhip_device_count(void)
+    {
+        int n = 0;
+        if (hipGetDeviceCount(&n) != hipSuccess)
+            return 0;
+        return n;
+    }
+
+    void sdhip_fec_cfg_default(sdhip_fec_cfg *c)
+    {
+        memset(c, 0, sizeof(*c));
+        c->decoder = SDHIP_DEC_CONV_CONCAT;
+        c->constellation = SDHIP_BPSK;
+        c->cadu_size = 8192;
+        c->viterbi_outsync_after = 20;
+        c->viterbi_ber_thresold = 0.3f;
+        c->derandomize = 1;
+        c->derand_start = 4;
+        c->rs_i = 0;
+        c->rs_fill_bytes = -1;
+        c->rs_dualbasis = 1;
+        c->rs_type = SDHIP_RS_NONE;
+        c->asm_sync = 0x1ACFFC1Du;
+    }
+
+    void *sdhip_fec_create(const sdhip_fec_cfg *cfg)
+    {
+        SD_GUARD_BEGIN
+        return new FecEngine(*cfg);
+        SD_GUARD_END(nullptr)
+    }
+    void sdhip_fec_destroy(void *h) { delete (FecEngine *)h; }
+    int sdhip_fec_push(void *h, const int8_t *soft, size_t n)
+    {
+        SD_GUARD_BEGIN
+        return ((FecEngine *)h)->push_host(soft, n);
+        SD_GUARD_END(-1)
+    }
+    int64_t sdhip_fec_pull(void *h, uint8_t *cadu, size_t cap_frames)
+    {
+        SD_GUARD_BEGIN
+        return ((FecEngine *)h)->pull(cadu, cap_frames);
+        SD_GUARD_END(-1)
+    }
+    int64_t sdhip_fec_process_dev(void *h, const int8_t *d_soft, size_t n, uint8_t *d_cadu, size_t cap_frames)
+    {
+        SD_GUARD_BEGIN
+        return ((FecEngine *)h)->process_dev(d_soft, n, d_cadu, cap_frames);
+        SD_GUARD_END(-1)
+    }
+    int sdhip_fec_get_stats(void *h, sdhip_fec_stats *st)
+    {
+        *st = ((FecEngine *)h)->stats;
+        return 0;
+    }
+    int64_t sdhip_fec_get_block_taps(void *h, float *blk_ber, int *blk_state, size_t cap)
+    {
+        FecEngine *e = (FecEngine *)h;
+        const size_t n = std::min(cap, e->tap_ber.size());
+        if (blk_ber)
+            memcpy(blk_ber, e->tap_ber.data(), n * sizeof(float));
+        if (blk_state)
+            memcpy(blk_state, e->tap_state.data(), n * sizeof(int));
+        return (int64_t)e->tap_ber.size();
+    }
+
+    int sdhip_op_ccdecoder(int device, int frame_bits, const uint8_t *d_syms, int nblocks, uint8_t *d_out)
+    {
+        SD_GUARD_BEGIN
+        SD_HIP(hipSetDevice(device));
+        VitCfg vc{};
+        vc.mode = 2; // raw unsigned symbols, 2*(F+6) per block, tail included
+        vc.F = frame_bits;
+        vc.B = 2 * (frame_bits + 6);
+        vc.nber = 0;
+        const int wpb = vit_words_per_block(frame_bits);
+        const int dstride = (frame_bits + 6 + 63) / 64 * 64;
+        DevBuf<VitBlockIO> d_io;
+        DevBuf<uint64_t> d_dec;
+        DevBuf<uint32_t> d_vb;
+        d_io.reserve(nblocks);
+        d_dec.reserve((size_t)nblocks * dstride);
+        d_vb.reserve((size_t)nblocks * wpb + 4);
+        std::vector<VitBlockIO> io(nblocks);
+        for (int j = 0; j < nblocks; j++)
+            io[j].start_in = -1;
+        io[0].start_in = -2;
+        SD_HIP(hipMemcpy(d_io.p, io.data(), io.size() * sizeof(VitBlockIO), hipMemcpyHostToDevice));
+        launch_vit_decode(vc, (const int8_t *)d_syms, 0, nblocks, d_io.p, d_dec.p, d_vb.p, nullptr);
+        SD_HIP(hipMemcpy(io.data(), d_io.p, io.size() * sizeof(VitBlockIO), hipMemcpyDeviceToHost));
+        for (int j = 1; j < nblocks; j++)
+            if (io[j].start_used != io[j - 1].ret_state)
+            {
+                VitBlockIO one{};
+                one.start_in = io[j - 1].ret_state;
+                SD_HIP(hipMemcpy(d_io.p + j, &one, sizeof(one), hipMemcpyHostToDevice));
+                launch_vit_decode(vc, (const int8_t *)d_syms, j, 1, d_io.p + j, d_dec.p + (size_t)j * dstride, d_vb.p + (size_t)j * wpb, nullptr);
+                SD_HIP(hipMemcpy(&io[j], d_io.p + j, sizeof(one), hipMemcpyDeviceToHost));
+            }
+        const long long nb = (long long)nblocks * frame_bits;
+        k_unpack_bits<<<dim3((unsigned)((nb + 255) / 256)), dim3(256)>>>(d_vb.p, wpb, frame_bits, nblocks, d_out);
+        SD_HIP(hipDeviceSynchronize());
+        return 0;
+        SD_GUARD_END(-1)
+    }
+
+    int sdhip_op_rs_decode(int device, uint8_t *d_data, int nframes, int frame_stride, int dualbasis, int I, int rs_type, int fill_bytes, int *d_errors)
+    {
+        SD_GUARD_BEGIN
+        SD_HIP(hipSetDevice(device));
+        launch_rs_only(d_data, nframes, frame_stride, dualbasis, I, rs_type == SDHIP_RS239 ? 16 : 32, fill_bytes, d_errors, nullptr);
+        SD_HIP(hipDeviceSynchronize());
+        return 0;
+        SD_GUARD_END(-1)
+    }
+}

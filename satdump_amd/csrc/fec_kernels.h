@@ -1,0 +1,114 @@
+// fec_kernels.h -- launch-side declarations of the CCSDS FEC kernels (gfx950).
+#pragma once
+#include "common.h"
+
+namespace sdhip
+{
+    // How the k=7 r=1/2 decoder's symbol stream is produced from a block of soft bytes.
+    //   mode 0 = viterbi::Viterbi1_2  (src-core/common/codings/viterbi/viterbi_1_2.cpp:92-98)
+    //   mode 1 = viterbi::Viterbi3_4 MetOp depuncture (viterbi_3_4.cpp:84-105,150-154)
+    struct VitCfg
+    {
+        int mode;
+        int B;        // soft bytes per block (d_buffer_size / BUFFER_SIZE)
+        int F;        // decoded bits per block (cc_decoder frame size)
+        int nber;     // bits re-encoded for the BER estimate (1024 / 1536)
+        int pre_swap; // module-level rotate_soft(.., PHASE_0, true) (module_ccsds_conv_concat_decoder.cpp:149-150)
+        int iq_swap;  // d_iq_swap
+        int phase;    // d_phase (0,1,2,3 = 0/90/180/270 deg)
+        int shift;    // d_shift
+    };
+
+    constexpr int VIT_PREPASS = 192;  // steps of the previous block replayed to speculate a start state
+    constexpr int VIT_TB_OVERLAP = 96; // extra traceback steps of a speculative traceback segment
+
+    // Per-block control / result words of k_vit_decode.
+    struct VitBlockIO
+    {
+        int start_in;   // >=0: start state to use; -1: speculate from the previous block's tail; -2: unbiased first block
+        int start_used; // start state actually used (or -2)
+        int ret_state;  // CCDecoder::work's chained start state for the NEXT block
+        int end_state;  // find_endstate()
+        int tb_fallback;// 1 if the segment-parallel traceback certificate failed and the serial path ran
+        int ber_err;    // BER estimate numerator  (filled by k_vit_ber)
+        int ber_tot;    // BER estimate denominator (non-erased symbols)
+        int pad;
+    };
+
+    // Decode `nblk` consecutive blocks: block j reads soft + (first_block + j) * cfg.B.
+    //   io[j]       : control/result words
+    //   decisions   : scratch, nblk * (F+6) * 8 bytes (lane-order ACS ballots)
+    //   vbits       : packed decoded bits, nblk * words_per_block(F) uint32 (MSB-first byte stream)
+    void launch_vit_decode(const VitCfg &cfg, const int8_t *soft, int64_t first_block, int nblk, VitBlockIO *io, uint64_t *decisions, uint32_t *vbits,
+                           hipStream_t st);
+
+    // BER estimate of every block (viterbi_1_2.cpp:101-102 / viterbi_3_4.cpp:156-157): re-encode the first
+    // nber decoded bits (encoder register chained through the previous block, enc_state_in for block 0) and
+    // compare with the hard decisions of the input symbols. Also returns the encoder register after the last block.
+    void launch_vit_ber(const VitCfg &cfg, const int8_t *soft, int64_t first_block, int nblk, const uint32_t *vbits, unsigned enc_state_in, VitBlockIO *io,
+                        hipStream_t st);
+
+    // Lock search on ONE block (Viterbi1_2::work IDLE branch, viterbi_1_2.cpp:54-88; Viterbi3_4: viterbi_3_4.cpp:112-148).
+    struct VitSearchState
+    {
+        // persistent state of cc_decoder_ber / cc_encoder_ber / ber_decoded_buffer
+        int ber_first;        // 1 until cc_decoder_ber has decoded once (unbiased metrics)
+        int ber_start;        // chained start state of cc_decoder_ber
+        unsigned enc_state;   // cc_encoder_ber shift register (low bits)
+        uint8_t tail[16];     // first 13 bytes of ber_decoded_buffer (mode 0 overrun source)
+        // results, one per candidate in reference order
+        int ncand;
+        int err[16], tot[16];
+    };
+    // candidates: mode 0: for s in [0, n_swap) for phase in phases[] for shift in {0,1}; mode 1: phase in {0,1} x shift in {0,1}
+    void launch_vit_search(const VitCfg &cfg, const int8_t *soft, int64_t block, int n_swap, const int *phases, int nphases, VitSearchState *d_state,
+                           hipStream_t st);
+
+    inline int vit_words_per_block(int F)
+    {
+        int L = (F + 63) / 64;
+        L = (L + 31) / 32 * 32; // bits per traceback lane, whole 32-bit words
+        return 64 * L / 32;
+    }
+
+    // ---- logical decoded bit stream ------------------------------------------------------------
+    // The deframer consumes [carry (carry_bits, raw Viterbi bits incl. >=33 bits of history)] ++ [blocks 0..nblk)
+    // where block j contributes F bits from vbits + j*wpb. NRZ-M (differential/nrzm.cpp:24-33) is applied on the fly.
+    struct BitStream
+    {
+        const uint32_t *carry; // packed MSB-first, carry_bits bits
+        int carry_bits;
+        const uint32_t *vbits;
+        int F, wpb;
+        int64_t nblk;
+        int nrzm;
+    };
+
+    // Exact ASM / ~ASM hits (bpsk_ccsds_deframer.cpp:51-66): appends (pos << 1 | inverted) for every logical bit
+    // position pos in [from, total) whose 32-bit window ENDING at pos equals asm / ~asm. count is a device counter.
+    void launch_sync_search(const BitStream &bs, int64_t from, uint32_t asm_sync, uint32_t *hits, int hits_cap, int *count, hipStream_t st);
+
+    // Copy the (NRZ-M decoded) logical stream [0,total) to a packed MSB-first byte buffer.
+    void launch_pack_stream(const BitStream &bs, uint8_t *out_bytes, int64_t total_bits, hipStream_t st);
+
+    // Frame extraction + derandomiser + Reed-Solomon (module_ccsds_conv_concat_decoder.cpp:173-195).
+    struct FrameCfg
+    {
+        int cadu_bits, cadu_bytes;
+        uint32_t asm_sync;
+        int derand, derand_after_rs, derand_start;
+        int rs_i, rs_fill_bytes, rs_dualbasis, rs_nroots; // rs_nroots 32 (rs223) / 16 (rs239); rs_i == 0 disables RS
+    };
+    struct FrameDesc
+    {
+        int64_t pos; // logical bit position of the first payload bit (the bit after the ASM)
+        int inv;     // bit_inversion
+        int pad;
+    };
+    // frames: nframes descriptors; out: nframes * cadu_bytes; errors: nframes * max(rs_i,1) ints (-1 = uncorrectable)
+    void launch_frames(const BitStream &bs, const FrameCfg &fc, const FrameDesc *frames, int nframes, uint8_t *out, int *errors, hipStream_t st);
+    // Unit entry: RS decode of frames already in memory (sdhip_op_rs_decode).
+    void launch_rs_only(uint8_t *data, int nframes, int frame_stride, int dualbasis, int I, int nroots, int fill_bytes, int *errors, hipStream_t st);
+    // Compaction: copy frames whose keep[i] != 0 to out in order. Returns nothing; count known to the host.
+    void launch_compact(const uint8_t *frames, const int *dst_index, int nframes, int cadu_bytes, uint8_t *out, hipStream_t st);
+} // namespace sdhip

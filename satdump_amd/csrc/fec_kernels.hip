@@ -1,0 +1,1194 @@
+// fec_kernels.hip -- CCSDS FEC chain on gfx950 (MI355X): k=7 r=1/2 Viterbi (ACS + traceback),
+// BER re-encode, lock search, ASM search, frame extraction, derandomiser, RS(255,223/239).
+//
+// Design:
+//  * Viterbi ACS: ONE WAVEFRONT PER BLOCK, lane = trellis state. The lane<->state map rotates every
+//    step (state held by lane l after t steps = rotl6(l, t)), so a butterfly needs ONE cross-lane
+//    exchange with lane l ^ (32 >> (t % 6)); new metric = min(mine, other) and the decision bits fall
+//    out of two v_cmp masks. Metrics are 8-bit values with the reference's wrap + per-step min
+//    renormalisation (volk_k7_r2_generic_fixed.h:95-163) reproduced exactly.
+//  * Decisions: one 64-bit lane-order ballot per step, gathered 64 steps at a time and written as one
+//    coalesced 512-byte store to an HBM scratch; traceback is segment-parallel (64 lanes x F/64 steps,
+//    each starting VIT_TB_OVERLAP steps early) with an exactness certificate and a serial fallback.
+//  * Block -> block start-state chaining (cc_decoder.cpp:295-302) is speculated by replaying the last
+//    VIT_PREPASS steps of the previous block; the host verifies and re-decodes on a miss.
+//  * RS: one thread per codeword, GF(256) log/exp tables in LDS; Berlekamp-Massey / Chien / Forney mirror
+//    libcorrect's control flow step for step (src-core/libs/correct/reed-solomon/decode.c).
+#include "fec_kernels.h"
+
+namespace sdhip
+{
+    // =============================================================================================
+    // Symbol fetch: rotate_soft (rotation.cpp:4-63) + signed_soft_to_unsigned (viterbi/utils.cpp:3-12)
+    // + the decoder's view of the buffer (viterbi_1_2.cpp:94-98) / MetOp depuncture (viterbi_3_4.cpp:84-105)
+    // =============================================================================================
+    struct SymFetch
+    {
+        VitCfg c;
+        const int8_t *blk;
+        int limit; // soft bytes visible to the decoder (B, or 2048 in the lock search)
+
+        __device__ __forceinline__ unsigned u_at(int j) const
+        {
+            if (j < 0 || j >= limit)
+                return 128u;
+            const int q = j & ~1;
+            int a = blk[q], b = blk[q + 1];
+            if (a == -128)
+                a = -127;
+            if (b == -128)
+                b = -127;
+            if (c.pre_swap)
+            {
+                int t = a;
+                a = b;
+                b = t;
+            }
+            if (c.iq_swap)
+            {
+                int t = a;
+                a = b;
+                b = t;
+            }
+            switch (c.phase)
+            {
+            case 1:
+            {
+                int t = a;
+                a = b;
+                b = -t;
+                break;
+            }
+            case 2:
+                a = -a;
+                b = -b;
+                break;
+            case 3:
+            {
+                int t = a;
+                a = -b;
+                b = t;
+                break;
+            }
+            default:
+                break;
+            }
+            const int v = (j & 1) ? b : a;
+            unsigned u = (unsigned)(v + 127) & 255u;
+            if (u == 128u)
+                u = 127u;
+            return u;
+        }
+
+        // symbol pair (s0 | s1 << 8) consumed by decoder step t; `tail` supplies symbols past `limit`
+        template <class Tail>
+        __device__ __forceinline__ unsigned pair(int t, const Tail &tail) const
+        {
+            unsigned s0, s1;
+            if (c.mode == 2)
+            { // raw unsigned symbols, tail included in the data (sdhip_op_ccdecoder)
+                const unsigned char *ub = (const unsigned char *)blk;
+                const int j = 2 * t;
+                s0 = (j < limit) ? ub[j] : 128u;
+                s1 = (j + 1 < limit) ? ub[j + 1] : 128u;
+            }
+            else if (c.mode == 0)
+            {
+                const int j = c.shift + 2 * t;
+                s0 = (j < limit) ? u_at(j) : tail(j - limit);
+                s1 = (j + 1 < limit) ? u_at(j + 1) : tail(j + 1 - limit);
+            }
+            else
+            {
+                const int m = t / 3, r = t - 3 * m;
+                const int base = 4 * m;
+                if (base >= limit) // past the depunctured data (limit is a multiple of 4)
+                {
+                    s0 = tail(0);
+                    s1 = tail(0);
+                }
+                else if (c.shift == 0)
+                {
+                    if (r == 0)
+                    {
+                        s0 = u_at(base);
+                        s1 = u_at(base + 1);
+                    }
+                    else if (r == 1)
+                    {
+                        s0 = 128u;
+                        s1 = u_at(base + 3);
+                    }
+                    else
+                    {
+                        s0 = u_at(base + 2);
+                        s1 = 128u;
+                    }
+                }
+                else
+                {
+                    if (r == 0)
+                    {
+                        s0 = 128u;
+                        s1 = u_at(base + 1);
+                    }
+                    else if (r == 1)
+                    {
+                        s0 = u_at(base);
+                        s1 = 128u;
+                    }
+                    else
+                    {
+                        s0 = u_at(base + 2);
+                        s1 = u_at(base + 3);
+                    }
+                }
+            }
+            return s0 | (s1 << 8);
+        }
+    };
+
+    struct TailErasure
+    {
+        __device__ __forceinline__ unsigned operator()(int) const { return 128u; }
+    };
+
+    // =============================================================================================
+    // ACS forward pass (one wave). X = this lane's path metric. Sink receives the ballot of each step.
+    // =============================================================================================
+    struct AcsConsts
+    {
+        unsigned m0[6], m1[6];        // per-lane branch masks (0 / 255) for the 6 layout phases
+        unsigned long long himask[6]; // wave masks: lane holds an "upper" old state (state >= 32)
+    };
+
+    __device__ __forceinline__ void acs_init_consts(AcsConsts &k)
+    {
+        const unsigned lane = (unsigned)lane_id();
+#pragma unroll
+        for (int p = 0; p < 6; p++)
+        {
+            const unsigned st = rotl6(lane, p);
+            const unsigned i = st & 31u;
+            // Branchtab, cc_decoder.cpp:116-123: polys {79, 109}
+            k.m0[p] = parity32((2u * i) & 79u) ? 255u : 0u;
+            k.m1[p] = parity32((2u * i) & 109u) ? 255u : 0u;
+            k.himask[p] = __ballot((st >> 5) != 0);
+        }
+    }
+
+    template <int P>
+    __device__ __forceinline__ unsigned acs_step(unsigned X, unsigned s0, unsigned s1, const AcsConsts &k, unsigned long long &ballot)
+    {
+        // BFLY, volk_k7_r2_generic_fixed.h:95-134 (both lanes of a butterfly share the same branch metric)
+        const unsigned metric = (1u + (s0 ^ k.m0[P]) + (s1 ^ k.m1[P])) >> 3;
+        const unsigned mine = (X + metric) & 255u;
+        const unsigned send = (X + 63u - metric) & 255u;
+        const unsigned other = (unsigned)__shfl_xor((int)send, 32 >> P);
+        const unsigned Y = min(mine, other);
+        const unsigned long long gt = __ballot(mine > other);
+        const unsigned long long eq = __ballot(mine == other);
+        ballot = eq | (gt ^ k.himask[P]);
+        // renormalize, volk_k7_r2_generic_fixed.h:80-92
+        return Y - wave_min_u32(Y);
+    }
+
+    template <class Fetch, class Sink>
+    __device__ __forceinline__ unsigned acs_forward(int nsteps, unsigned X, const AcsConsts &k, const Fetch &fetch, Sink &sink)
+    {
+        const int lane = lane_id();
+        unsigned pairs = 0;
+        int t = 0;
+#define SD_ACS_STEP(P)                                                                   \
+    {                                                                                    \
+        if ((t & 63) == 0)                                                               \
+            pairs = fetch(t + lane);                                                     \
+        const unsigned pr = (unsigned)__builtin_amdgcn_readlane((int)pairs, t & 63);     \
+        unsigned long long bal;                                                          \
+        X = acs_step<P>(X, pr & 255u, (pr >> 8) & 255u, k, bal);                         \
+        sink.put(t, bal);                                                                \
+        t++;                                                                             \
+    }
+        while (t + 6 <= nsteps)
+        {
+            SD_ACS_STEP(0)
+            SD_ACS_STEP(1)
+            SD_ACS_STEP(2)
+            SD_ACS_STEP(3)
+            SD_ACS_STEP(4)
+            SD_ACS_STEP(5)
+        }
+        const int rem = nsteps - t;
+        if (rem > 0) SD_ACS_STEP(0)
+        if (rem > 1) SD_ACS_STEP(1)
+        if (rem > 2) SD_ACS_STEP(2)
+        if (rem > 3) SD_ACS_STEP(3)
+        if (rem > 4) SD_ACS_STEP(4)
+#undef SD_ACS_STEP
+        sink.finish(nsteps);
+        return X;
+    }
+
+    // find_endstate (cc_decoder.cpp:192-209): first state index holding the minimum metric.
+    __device__ __forceinline__ unsigned acs_endstate(unsigned X, int nsteps)
+    {
+        const unsigned st = rotl6((unsigned)lane_id(), (unsigned)(nsteps % 6));
+        const unsigned mn = wave_min_u32(X);
+        return wave_min_u32(X == mn ? st : 64u);
+    }
+
+    // decision bit of `state` (the NEW state) at step t, ballots are in lane order
+    __device__ __forceinline__ unsigned dec_bit(unsigned long long ballot, int t, unsigned state)
+    {
+        const unsigned l = rotr6(state, (unsigned)((t + 1) % 6));
+        return (unsigned)(ballot >> l) & 1u;
+    }
+
+    // Sink: 64 ballots gathered in registers, one coalesced store per 64 steps
+    struct SinkGlobal
+    {
+        unsigned long long *dec;
+        unsigned long long rec;
+        __device__ __forceinline__ void put(int t, unsigned long long b)
+        {
+            if (lane_id() == (t & 63))
+                rec = b;
+            if ((t & 63) == 63)
+                dec[(t - 63) + lane_id()] = rec;
+        }
+        __device__ __forceinline__ void finish(int nsteps)
+        {
+            const int tail = nsteps & 63;
+            if (tail && lane_id() < tail)
+                dec[(nsteps - tail) + lane_id()] = rec;
+        }
+    };
+    struct SinkLds
+    {
+        unsigned long long *dec;
+        __device__ __forceinline__ void put(int t, unsigned long long b)
+        {
+            if (lane_id() == (t & 63))
+                dec[t] = b;
+        }
+        __device__ __forceinline__ void finish(int) {}
+    };
+
+    // =============================================================================================
+    // k_vit_decode
+    // =============================================================================================
+    constexpr int PRE_LDS = VIT_PREPASS + 8;
+
+    __global__ __launch_bounds__(256) void k_vit_decode(VitCfg c, const int8_t *__restrict__ soft, long long first_block, int nblk, VitBlockIO *io,
+                                                         unsigned long long *decisions, unsigned *vbits, int dstride, int wpb)
+    {
+        __shared__ unsigned long long pre_ballots[4][PRE_LDS];
+        const int wave = (int)(threadIdx.x >> 6);
+        const int lane = lane_id();
+        const int j = (int)blockIdx.x * 4 + wave;
+        if (j >= nblk)
+            return;
+        const int F = c.F, nsteps = F + 6;
+        AcsConsts k;
+        acs_init_consts(k);
+        const TailErasure erasure;
+
+        // ---- start state -------------------------------------------------------------------------
+        int start = io[j].start_in;
+        if (start == -1)
+        {
+            // speculate: replay the tail of the previous block from neutral metrics, take the state 6 steps
+            // before its end state (== CCDecoder::work's chained start state when survivor paths have merged)
+            SymFetch pf{c, soft + (first_block + j - 1) * (long long)c.B, c.B};
+            const int P = VIT_PREPASS < F ? VIT_PREPASS : F;
+            const int t0 = F - P, n = P + 6;
+            SinkLds sk{pre_ballots[wave]};
+            auto fetch = [&](int tt) -> unsigned { return pf.pair(t0 + tt, erasure); };
+            unsigned X = acs_forward(n, 0u, k, fetch, sk);
+            unsigned st = acs_endstate(X, n);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            for (int tt = n - 1; tt >= n - 6; tt--)
+            {
+                const unsigned kb = dec_bit(pre_ballots[wave][tt], tt, st);
+                st = (st >> 1) | (kb << 5);
+            }
+            start = (int)st;
+        }
+
+        // ---- forward pass over the block ------------------------------------------------------------
+        SymFetch f{c, soft + (first_block + j) * (long long)c.B, c.B};
+        unsigned long long *dec = decisions + (size_t)j * dstride;
+        unsigned X = (start == -2) ? 31u : ((lane == start) ? 0u : 63u); // init_viterbi(_unbiased), cc_decoder.cpp:159-190
+        {
+            SinkGlobal sk{dec, 0ull};
+            auto fetch = [&](int tt) -> unsigned { return f.pair(tt, erasure); };
+            X = acs_forward(nsteps, X, k, fetch, sk);
+        }
+        const unsigned endstate = acs_endstate(X, nsteps);
+        __threadfence(); // decisions written by other lanes of this wave are read below
+
+        // ---- chained start state for the next block: state after steps F+5..F (cc_decoder.cpp:250-260,275)
+        unsigned ret = endstate;
+        for (int t = F + 5; t >= F; t--)
+        {
+            const unsigned kb = dec_bit(dec[t], t, ret);
+            ret = (ret >> 1) | (kb << 5);
+        }
+
+        // ---- segment-parallel traceback ---------------------------------------------------------------
+        const int L = wpb / 2;                 // bits per lane = wpb*32/64
+        const int wpl = L / 32;                // words per lane
+        const int nseg = (F + L - 1) / L;
+        const int lo = 6 + lane * L;
+        int hi = 6 + (lane + 1) * L;
+        if (hi > F + 6)
+            hi = F + 6;
+        hi -= 1;
+        const bool active = lane < nseg;
+        int tstart = hi + VIT_TB_OVERLAP;
+        if (tstart > F + 5)
+            tstart = F + 5;
+        unsigned st = (tstart == F + 5) ? endstate : 0u;
+        unsigned entry = 0, exitst = 0;
+        unsigned *vb = vbits + (size_t)j * wpb + (size_t)lane * wpl;
+        if (active)
+        {
+            for (int t = tstart; t > hi; t--) // overlap: converge onto the survivor path
+            {
+                const unsigned kb = dec_bit(dec[t], t, st);
+                st = (st >> 1) | (kb << 5);
+            }
+            entry = st;
+            for (int w = wpl - 1; w >= 0; w--)
+            {
+                unsigned word = 0;
+                for (int b = 31; b >= 0; b--)
+                {
+                    const int n = lane * L + w * 32 + b;
+                    if (n < F)
+                    {
+                        const int t = n + 6;
+                        const unsigned kb = dec_bit(dec[t], t, st);
+                        st = (st >> 1) | (kb << 5);
+                        word |= kb << (31 - b);
+                    }
+                }
+                vb[w] = word;
+            }
+            exitst = st;
+        }
+        else
+        {
+            for (int w = 0; w < wpl; w++)
+                vb[w] = 0;
+        }
+        // certificate: every segment must end where the one below it assumed it starts
+        const unsigned exit_above = (unsigned)__shfl_down((int)exitst, 1);
+        // lane l's ENTRY state (top of its segment) must equal lane l+1's EXIT state
+        const bool mismatch = active && (lane + 1 < nseg) && (entry != exit_above);
+        int fallback = 0;
+        if (__ballot(mismatch) != 0ull)
+        {
+            fallback = 1;
+            if (lane == 0)
+            { // serial chainback, cc_decoder.cpp:228-276
+                unsigned s = endstate; // decoded bit n is the decision read at step n + 6, starting at step F + 5
+                unsigned *vball = vbits + (size_t)j * wpb;
+                unsigned word = 0;
+                for (int n = F - 1; n >= 0; n--)
+                {
+                    const int t = n + 6;
+                    const unsigned kb = dec_bit(dec[t], t, s);
+                    s = (s >> 1) | (kb << 5);
+                    word |= kb << (31 - (n & 31));
+                    if ((n & 31) == 0)
+                    {
+                        vball[n >> 5] = word;
+                        word = 0;
+                    }
+                }
+            }
+        }
+        if (lane == 0)
+        {
+            io[j].start_used = start;
+            io[j].ret_state = (int)ret;
+            io[j].end_state = (int)endstate;
+            io[j].tb_fallback = fallback;
+        }
+    }
+
+    void launch_vit_decode(const VitCfg &cfg, const int8_t *soft, int64_t first_block, int nblk, VitBlockIO *io, uint64_t *decisions, uint32_t *vbits,
+                           hipStream_t st)
+    {
+        if (nblk <= 0)
+            return;
+        const int dstride = (cfg.F + 6 + 63) / 64 * 64;
+        const int wpb = vit_words_per_block(cfg.F);
+        hipLaunchKernelGGL(k_vit_decode, dim3((nblk + 3) / 4), dim3(256), 0, st, cfg, soft, (long long)first_block, nblk, io,
+                           (unsigned long long *)decisions, vbits, dstride, wpb);
+    }
+
+    // =============================================================================================
+    // packed-bit helpers: bit n of a block lives in word n>>5 at position 31-(n&31)
+    // =============================================================================================
+    __device__ __forceinline__ unsigned getbit(const unsigned *w, int n) { return (w[n >> 5] >> (31 - (n & 31))) & 1u; }
+
+    // up to 32 bits starting at bit `off` (MSB-first), n in [1,32]; may read word (off>>5)+1
+    __device__ __forceinline__ unsigned peek_bits(const unsigned *w, long long off, int n)
+    {
+        const long long wi = off >> 5;
+        const int sh = (int)(off & 31);
+        const unsigned long long v = ((unsigned long long)w[wi] << 32) | (unsigned long long)w[wi + 1];
+        return (unsigned)((v << sh) >> (64 - n));
+    }
+
+    // =============================================================================================
+    // k_vit_ber: re-encode (cc_encoder.cpp:92-104) + get_ber (viterbi_1_2.cpp:37-50)
+    // =============================================================================================
+    __global__ __launch_bounds__(256) void k_vit_ber(VitCfg c, const int8_t *__restrict__ soft, long long first_block, int nblk, const unsigned *__restrict__ vbits,
+                                                      int wpb, unsigned enc_state_in, VitBlockIO *io)
+    {
+        const int wave = (int)(threadIdx.x >> 6);
+        const int lane = lane_id();
+        const int j = (int)blockIdx.x * 4 + wave;
+        if (j >= nblk)
+            return;
+        const int nber = c.nber;
+        const unsigned *vb = vbits + (size_t)j * wpb;
+        const unsigned *vprev = (j > 0) ? vbits + (size_t)(j - 1) * wpb : nullptr;
+        SymFetch f{c, soft + (first_block + j) * (long long)c.B, c.B};
+        const TailErasure erasure;
+        const int per = (nber + 63) / 64;
+        unsigned err = 0, tot = 0;
+        for (int q = 0; q < per; q++)
+        {
+            const int i = lane * per + q;
+            if (i >= nber)
+                break;
+            unsigned stw = 0; // bits i, i-1, ..., i-6 at positions 0..6
+#pragma unroll
+            for (int d = 0; d < 7; d++)
+            {
+                const int n = i - d;
+                unsigned bit;
+                if (n >= 0)
+                    bit = getbit(vb, n);
+                else if (vprev)
+                    bit = getbit(vprev, nber + n);
+                else
+                    bit = (enc_state_in >> (-n - 1)) & 1u;
+                stw |= bit << d;
+            }
+            const unsigned o0 = parity32(stw & 79u), o1 = parity32(stw & 109u);
+            const unsigned pr = f.pair(i, erasure);
+            const unsigned s0 = pr & 255u, s1 = pr >> 8;
+            if (s0 != 128u)
+            {
+                tot++;
+                err += ((s0 > 127u) ? 1u : 0u) != o0;
+            }
+            if (s1 != 128u)
+            {
+                tot++;
+                err += ((s1 > 127u) ? 1u : 0u) != o1;
+            }
+        }
+        err = wave_sum_u32(err);
+        tot = wave_sum_u32(tot);
+        if (lane == 0)
+        {
+            io[j].ber_err = (int)err;
+            io[j].ber_tot = (int)tot;
+            unsigned e = 0; // encoder register after this block: last 6 encoded bits, newest at bit 0
+            for (int d = 0; d < 6; d++)
+                e |= getbit(vb, nber - 1 - d) << d;
+            io[j].pad = (int)e;
+        }
+    }
+
+    void launch_vit_ber(const VitCfg &cfg, const int8_t *soft, int64_t first_block, int nblk, const uint32_t *vbits, unsigned enc_state_in, VitBlockIO *io,
+                        hipStream_t st)
+    {
+        if (nblk <= 0)
+            return;
+        hipLaunchKernelGGL(k_vit_ber, dim3((nblk + 3) / 4), dim3(256), 0, st, cfg, soft, (long long)first_block, nblk, vbits, vit_words_per_block(cfg.F),
+                           enc_state_in, io);
+    }
+
+    // =============================================================================================
+    // k_vit_search: the IDLE branch of Viterbi1_2::work / Viterbi3_4::work on one block (one wave)
+    // =============================================================================================
+    constexpr int SEARCH_MAX_BITS = 1536;
+
+    struct SearchCand
+    {
+        int s, phase, shift;
+    };
+
+    __global__ __launch_bounds__(64) void k_vit_search(VitCfg c, const int8_t *__restrict__ soft, long long block, int n_swap, int ph0, int ph1, int ph2, int ph3,
+                                                        int nphases, VitSearchState *S)
+    {
+        __shared__ unsigned long long ballots[SEARCH_MAX_BITS + 8];
+        __shared__ unsigned char bits[SEARCH_MAX_BITS];
+        __shared__ unsigned char tailb[16];
+        const int lane = lane_id();
+        const int nb = c.nber, nsteps = nb + 6;
+        const int phases[4] = {ph0, ph1, ph2, ph3};
+        AcsConsts k;
+        acs_init_consts(k);
+        int ber_first = S->ber_first, ber_start = S->ber_start;
+        unsigned enc = S->enc_state;
+        if (lane < 16)
+            tailb[lane] = S->tail[lane];
+        __syncthreads();
+        const int8_t *blk = soft + block * (long long)c.B;
+        int cand = 0;
+        const int nsw = (c.mode == 0) ? n_swap : 1;
+        const int nph = (c.mode == 0) ? nphases : 2;
+        for (int s = 0; s < nsw; s++)
+            for (int pi = 0; pi < nph; pi++)
+                for (int shift = 0; shift < 2; shift++)
+                {
+                    VitCfg cc = c;
+                    cc.iq_swap = (c.mode == 0) ? s : 0;
+                    cc.phase = (c.mode == 0) ? phases[pi] : pi;
+                    cc.shift = shift;
+                    SymFetch f{cc, blk, 2048};
+                    // mode 0: symbols past ber_soft_buffer come from ber_decoded_buffer (previous candidate's
+                    // decoded bits, viterbi_1_2.h:39-42); mode 1: never-written zero bytes of ber_depunc_buffer
+                    auto tail = [&](int idx) -> unsigned { return (cc.mode == 0) ? (unsigned)tailb[idx & 15] : 0u; };
+                    auto fetch = [&](int tt) -> unsigned { return f.pair(tt, tail); };
+                    unsigned X = ber_first ? 31u : ((lane == ber_start) ? 0u : 63u);
+                    SinkLds sk{ballots};
+                    X = acs_forward(nsteps, X, k, fetch, sk);
+                    unsigned st = acs_endstate(X, nsteps);
+                    __syncthreads();
+                    ber_first = 0;
+                    for (int n = nb - 1; n >= 0; n--) // chainback_viterbi, cc_decoder.cpp:228-276: bit n <- step n + 6
+                    {
+                        const int t = n + 6;
+                        const unsigned kb = dec_bit(ballots[t], t, st);
+                        st = (st >> 1) | (kb << 5);
+                        if (lane == 0)
+                            bits[n] = (unsigned char)kb;
+                        if (n == nb - 6)
+                            ber_start = (int)st; // chained start state of the next cc_decoder_ber.work
+                    }
+                    __syncthreads();
+                    if (lane < 16)
+                        tailb[lane] = bits[lane]; // ber_decoded_buffer now holds the new bits
+                    __syncthreads();
+                    // cc_encoder_ber.work + get_ber (the BER compare sees the UPDATED ber_decoded tail)
+                    const int per = (nb + 63) / 64;
+                    unsigned err = 0, tot = 0;
+                    for (int q = 0; q < per; q++)
+                    {
+                        const int i = lane * per + q;
+                        if (i >= nb)
+                            break;
+                        unsigned stw = 0;
+                        for (int d = 0; d < 7; d++)
+                        {
+                            const int n = i - d;
+                            const unsigned bit = (n >= 0) ? bits[n] : ((enc >> (-n - 1)) & 1u);
+                            stw |= bit << d;
+                        }
+                        const unsigned o0 = parity32(stw & 79u), o1 = parity32(stw & 109u);
+                        const unsigned pr = f.pair(i, tail);
+                        const unsigned s0 = pr & 255u, s1 = pr >> 8;
+                        if (s0 != 128u)
+                        {
+                            tot++;
+                            err += ((s0 > 127u) ? 1u : 0u) != o0;
+                        }
+                        if (s1 != 128u)
+                        {
+                            tot++;
+                            err += ((s1 > 127u) ? 1u : 0u) != o1;
+                        }
+                    }
+                    err = wave_sum_u32(err);
+                    tot = wave_sum_u32(tot);
+                    unsigned e = 0;
+                    for (int d = 0; d < 6; d++)
+                        e |= (unsigned)bits[nb - 1 - d] << d;
+                    enc = e;
+                    if (lane == 0)
+                    {
+                        S->err[cand] = (int)err;
+                        S->tot[cand] = (int)tot;
+                    }
+                    cand++;
+                    __syncthreads();
+                }
+        if (lane == 0)
+        {
+            S->ber_first = ber_first;
+            S->ber_start = ber_start;
+            S->enc_state = enc;
+            S->ncand = cand;
+        }
+        if (lane < 16)
+            S->tail[lane] = tailb[lane];
+    }
+
+    void launch_vit_search(const VitCfg &cfg, const int8_t *soft, int64_t block, int n_swap, const int *phases, int nphases, VitSearchState *d_state, hipStream_t st)
+    {
+        int ph[4] = {0, 0, 0, 0};
+        for (int i = 0; i < nphases && i < 4; i++)
+            ph[i] = phases[i];
+        hipLaunchKernelGGL(k_vit_search, dim3(1), dim3(64), 0, st, cfg, soft, (long long)block, n_swap, ph[0], ph[1], ph[2], ph[3], nphases, d_state);
+    }
+
+    // =============================================================================================
+    // Logical bit stream access
+    // =============================================================================================
+    __device__ __forceinline__ unsigned stream_raw32(const BitStream &bs, long long g)
+    {
+        unsigned out = 0;
+        int got = 0;
+        while (got < 32)
+        {
+            const unsigned *base = nullptr;
+            long long off = 0, avail = 32;
+            if (g < 0)
+            {
+                avail = -g;
+            }
+            else if (g < bs.carry_bits)
+            {
+                base = bs.carry;
+                off = g;
+                avail = bs.carry_bits - g;
+            }
+            else
+            {
+                const long long g2 = g - bs.carry_bits;
+                const long long j = g2 / bs.F;
+                if (j < bs.nblk)
+                {
+                    const long long o = g2 - j * bs.F;
+                    base = bs.vbits + (size_t)j * bs.wpb;
+                    off = o;
+                    avail = bs.F - o;
+                }
+            }
+            int take = 32 - got;
+            if (avail < take)
+                take = (int)avail;
+            const unsigned v = base ? peek_bits(base, off, take) : 0u;
+            out |= v << (32 - got - take);
+            got += take;
+            g += take;
+        }
+        return out;
+    }
+    // 32 bits of the stream the deframer sees, starting at logical bit g (NRZ-M: out = b ^ previous b)
+    __device__ __forceinline__ unsigned stream32(const BitStream &bs, long long g)
+    {
+        const unsigned r = stream_raw32(bs, g);
+        if (!bs.nrzm)
+            return r;
+        const unsigned prev = stream_raw32(bs, g - 1);
+        return r ^ prev;
+    }
+
+    // ---- exact ASM search ---------------------------------------------------------------------
+    __global__ __launch_bounds__(256) void k_sync_search(BitStream bs, long long from, long long total, unsigned asm_sync, unsigned *hits, int hits_cap, int *count)
+    {
+        // each thread owns 32 consecutive END positions p = from + 32*i + k
+        const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+        const long long p0 = from + 32 * i;
+        if (p0 >= total)
+            return;
+        const unsigned a = stream32(bs, p0 - 31); // bits p0-31 .. p0
+        const unsigned b = stream32(bs, p0 + 1);  // bits p0+1 .. p0+32
+        const unsigned long long v = ((unsigned long long)a << 32) | b;
+        const unsigned inv = ~asm_sync;
+#pragma unroll 4
+        for (int k2 = 0; k2 < 32; k2++)
+        {
+            const long long p = p0 + k2;
+            if (p >= total)
+                break;
+            const unsigned w = (unsigned)(v >> (32 - k2));
+            if (w == asm_sync || w == inv)
+            {
+                const int idx = atomicAdd(count, 1);
+                if (idx < hits_cap)
+                    hits[idx] = (unsigned)((p - from) << 1) | (w == inv ? 1u : 0u);
+            }
+        }
+    }
+
+    void launch_sync_search(const BitStream &bs, int64_t from, uint32_t asm_sync, uint32_t *hits, int hits_cap, int *count, hipStream_t st)
+    {
+        const int64_t total = bs.carry_bits + bs.nblk * (int64_t)bs.F;
+        const int64_t n = (total - from + 31) / 32;
+        if (n <= 0)
+            return;
+        hipLaunchKernelGGL(k_sync_search, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, bs, (long long)from, (long long)total, asm_sync, hits, hits_cap, count);
+    }
+
+    __global__ __launch_bounds__(256) void k_pack_stream(BitStream bs, unsigned char *out, long long total_bits)
+    {
+        const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+        if (i * 32 >= total_bits)
+            return;
+        const unsigned w = stream32(bs, i * 32);
+        out[i * 4 + 0] = (unsigned char)(w >> 24);
+        out[i * 4 + 1] = (unsigned char)(w >> 16);
+        out[i * 4 + 2] = (unsigned char)(w >> 8);
+        out[i * 4 + 3] = (unsigned char)(w);
+    }
+    void launch_pack_stream(const BitStream &bs, uint8_t *out_bytes, int64_t total_bits, hipStream_t st)
+    {
+        const int64_t n = (total_bits + 31) / 32;
+        if (n <= 0)
+            return;
+        hipLaunchKernelGGL(k_pack_stream, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, bs, out_bytes, (long long)total_bits);
+    }
+
+    // =============================================================================================
+    // GF(256) tables (libcorrect field.h:32-62, poly 0x187) + CCSDS tables, built once per device
+    // =============================================================================================
+    struct GfTables
+    {
+        unsigned char exp[512];
+        unsigned char log[256];
+        unsigned char to_dual[256];
+        unsigned char from_dual[256];
+        unsigned char pn[256]; // 255 used
+    };
+    static GfTables *g_tables_dev[16] = {nullptr};
+
+    static void build_tables_host(GfTables &t)
+    {
+        unsigned element = 1;
+        t.exp[0] = 1;
+        t.log[0] = 0;
+        for (unsigned i = 1; i < 512; i++)
+        {
+            element = element * 2;
+            element = (element > 255) ? (element ^ 0x187) : element;
+            t.exp[i] = (unsigned char)element;
+            if (i < 256)
+                t.log[element] = (unsigned char)i;
+        }
+        auto mul = [&](unsigned a, unsigned b) -> unsigned { return (a == 0 || b == 0) ? 0u : t.exp[t.log[a] + t.log[b]]; };
+        // CCSDS dual basis: z_j = Tr(x * beta^j), beta = alpha^117, z_0 = MSB (reedsolomon.cpp:6-28 tables)
+        for (unsigned x = 0; x < 256; x++)
+        {
+            unsigned z = 0;
+            for (unsigned j = 0; j < 8; j++)
+            {
+                unsigned y = mul(x, t.exp[(117 * j) % 255]), tr = 0;
+                for (int q = 0; q < 8; q++)
+                {
+                    tr ^= y;
+                    y = mul(y, y);
+                }
+                z |= (tr & 1u) << (7 - j);
+            }
+            t.to_dual[x] = (unsigned char)z;
+        }
+        for (unsigned x = 0; x < 256; x++)
+            t.from_dual[t.to_dual[x]] = (unsigned char)x;
+        // CCSDS pseudo-randomiser h(x) = x^8+x^7+x^5+x^3+1, all-ones seed (randomization.cpp:4-36)
+        unsigned char reg[8] = {1, 1, 1, 1, 1, 1, 1, 1};
+        for (int i = 0; i < 255; i++)
+        {
+            unsigned char byte = 0;
+            for (int b = 0; b < 8; b++)
+            {
+                byte = (unsigned char)(byte << 1 | reg[0]);
+                unsigned char nb = reg[0] ^ reg[3] ^ reg[5] ^ reg[7];
+                memmove(reg, reg + 1, 7);
+                reg[7] = nb;
+            }
+            t.pn[i] = byte;
+        }
+        t.pn[255] = 0;
+    }
+
+    static const GfTables *tables_for_current_device()
+    {
+        int dev = 0;
+        SD_HIP(hipGetDevice(&dev));
+        if (dev < 0 || dev >= 16)
+            throw HipError("device ordinal out of range");
+        if (!g_tables_dev[dev])
+        {
+            GfTables h;
+            build_tables_host(h);
+            GfTables *d = nullptr;
+            SD_HIP(hipMalloc((void **)&d, sizeof(GfTables)));
+            SD_HIP(hipMemcpy(d, &h, sizeof(GfTables), hipMemcpyHostToDevice));
+            g_tables_dev[dev] = d;
+        }
+        return g_tables_dev[dev];
+    }
+
+    // =============================================================================================
+    // Reed-Solomon, one thread per codeword. cw[] is this thread's 255-byte codeword held in LDS,
+    // transposed: byte k of thread `tid` at cw[k * nthr + tid].
+    // Mirrors correct_reed_solomon_decode (decode.c:299-379) with num_erasures = 0.
+    // =============================================================================================
+    struct GfLds
+    {
+        unsigned char exp[512];
+        unsigned char log[256];
+    };
+
+    struct RsCtx
+    {
+        const GfLds *gf;
+        int nroots, fcr, gap;
+        __device__ __forceinline__ unsigned mul(unsigned l, unsigned r) const { return (l == 0 || r == 0) ? 0u : gf->exp[gf->log[l] + gf->log[r]]; }
+        __device__ __forceinline__ unsigned div(unsigned l, unsigned r) const { return (l == 0 || r == 0) ? 0u : gf->exp[255u + gf->log[l] - gf->log[r]]; }
+        __device__ __forceinline__ unsigned pw(unsigned e, int p) const
+        {
+            int m = ((int)gf->log[e] * p) % 255;
+            if (m < 0)
+                m += 255;
+            return gf->exp[m];
+        }
+        __device__ __forceinline__ static unsigned mul_log(unsigned l, unsigned r)
+        {
+            const unsigned res = l + r;
+            return res > 255 ? res - 255 : res;
+        }
+    };
+
+    // returns -1 on failure, else msg_length; corrects cw in place (conventional basis, byte 0 = highest order)
+    __device__ int rs_decode_thread(const RsCtx &R, unsigned char *cw, int stride)
+    {
+        const int md = R.nroots;
+#define CW(k) cw[(k) * stride]
+        // syndromes: S_i = r(alpha_i) by Horner over the received polynomial (field arithmetic is exact, so this
+        // equals polynomial_eval_lut over generator_root_exp, decode.c:12-28)
+        unsigned char synd[32];
+        bool all_zero = true;
+        for (int i = 0; i < md; i++)
+        {
+            const unsigned lr = (unsigned)((R.gap * (i + R.fcr)) % 255); // log of generator root i (reed-solomon.c:9-11)
+            unsigned s = 0;
+            for (int k = 0; k < 255; k++)
+            {
+                if (s)
+                    s = R.gf->exp[R.gf->log[s] + lr];
+                s ^= CW(k);
+            }
+            synd[i] = (unsigned char)s;
+            if (s)
+                all_zero = false;
+        }
+        if (all_zero)
+            return 255 - md;
+
+        // Berlekamp-Massey, decode.c:32-118
+        unsigned char loc[40], last[40];
+        for (int i = 0; i < 40; i++)
+        {
+            loc[i] = 0;
+            last[i] = 0;
+        }
+        loc[0] = 1;
+        last[0] = 1;
+        unsigned loc_order = 0, last_order = 0, numerrors = 0;
+        unsigned last_disc = 1, delay = 1;
+        for (unsigned i = 0; i < (unsigned)md; i++)
+        {
+            unsigned disc = synd[i];
+            for (unsigned j = 1; j <= numerrors; j++)
+                disc ^= R.mul(loc[j], synd[i - j]);
+            if (!disc)
+            {
+                delay++;
+                continue;
+            }
+            if (2 * numerrors <= i)
+            {
+                for (int j = (int)last_order; j >= 0; j--)
+                {
+                    const unsigned idx = (unsigned)j + delay;
+                    const unsigned v = R.div(R.mul(last[j], disc), last_disc);
+                    if (idx < 40)
+                        last[idx] = (unsigned char)v;
+                }
+                for (int j = (int)delay - 1; j >= 0; j--)
+                    if (j < 40)
+                        last[j] = 0;
+                for (int j = 0; j <= (int)(last_order + delay) && j < 40; j++)
+                {
+                    const unsigned char tmp = loc[j];
+                    loc[j] = loc[j] ^ last[j];
+                    last[j] = tmp;
+                }
+                const unsigned tmp_order = loc_order;
+                loc_order = last_order + delay;
+                last_order = tmp_order;
+                numerrors = i + 1 - numerrors;
+                last_disc = disc;
+                delay = 1;
+                continue;
+            }
+            for (int j = (int)last_order; j >= 0; j--)
+            {
+                const unsigned idx = (unsigned)j + delay;
+                if (idx < 40)
+                    loc[idx] ^= (unsigned char)R.div(R.mul(last[j], disc), last_disc);
+            }
+            loc_order = (last_order + delay > loc_order) ? last_order + delay : loc_order;
+            delay++;
+        }
+        const unsigned order = loc_order;
+        if (order >= 40)
+            return -1; // outside the reference's own buffers (heap overrun there); cannot be mirrored
+        // Chien search over all 256 field elements, decode.c:122-145 (zero coefficients are skipped through the
+        // log(0) = 0 sentinel, polynomial.c:136-157)
+        unsigned char loc_log[40];
+        for (unsigned i = 0; i <= order; i++)
+            loc_log[i] = R.gf->log[loc[i]];
+        unsigned char roots[40];
+        for (unsigned i = 0; i < 40; i++)
+            roots[i] = 0;
+        unsigned nroot = 0;
+        for (unsigned e = 0; e < 256; e++)
+        {
+            unsigned res;
+            if (e == 0)
+                res = loc_log[0] == 0 ? 0u : R.gf->exp[loc_log[0]];
+            else
+            {
+                res = 0;
+                const unsigned le = R.gf->log[e];
+                unsigned ve = 255; // log[1]
+                for (unsigned i = 0; i <= order; i++)
+                {
+                    if (loc_log[i] != 0)
+                        res ^= R.gf->exp[(unsigned)loc_log[i] + ve];
+                    ve = RsCtx::mul_log(ve, le);
+                }
+            }
+            if (!res)
+            {
+                if (nroot < 40)
+                    roots[nroot] = (unsigned char)e;
+                nroot++;
+            }
+        }
+        if (nroot != order)
+            return -1;
+        // error locations, decode.c:198-222
+        unsigned char locs[40];
+        for (unsigned i = 0; i < order; i++)
+        {
+            locs[i] = 0;
+            if (roots[i] == 0)
+                continue;
+            const unsigned l = R.div(1, roots[i]);
+            for (unsigned j = 0; j < 256; j++)
+                if (R.pw(j, R.gap) == l)
+                {
+                    locs[i] = R.gf->log[j];
+                    break;
+                }
+        }
+        // Forney, decode.c:165-196: evaluator = locator * S mod x^md ; derivative of the locator
+        unsigned char ev[32];
+        for (int i = 0; i < md; i++)
+            ev[i] = 0;
+        for (unsigned i = 0; i <= order; i++)
+        {
+            if (i > (unsigned)md - 1)
+                continue;
+            const unsigned jl = (unsigned)md - 1 - i;
+            for (unsigned j = 0; j <= jl; j++)
+                ev[i + j] ^= (unsigned char)R.mul(loc[i], synd[j]);
+        }
+        for (unsigned i = 0; i < order; i++)
+        {
+            if (roots[i] == 0)
+                continue;
+            const unsigned le = R.gf->log[roots[i]];
+            // polynomial_eval_lut(evaluator) and (derivative) at the root (val_exp[0] = log[1] = 255 != 0)
+            unsigned num = 0, den = 0, ve = 255;
+            for (unsigned q = 0; q < (unsigned)md; q++)
+            {
+                if (ev[q] != 0)
+                    num ^= R.gf->exp[(unsigned)R.gf->log[ev[q]] + ve];
+                if (q + 1 <= order && q <= order - 1)
+                {
+                    const unsigned dc = ((q + 1) & 1u) ? loc[q + 1] : 0u; // formal derivative, polynomial.c:82-96
+                    if (dc != 0)
+                        den ^= R.gf->exp[(unsigned)R.gf->log[dc] + ve];
+                }
+                ve = RsCtx::mul_log(ve, le);
+            }
+            const unsigned val = R.mul(R.pw(roots[i], R.fcr - 1), R.div(num, den));
+            // received_polynomial.coeff[loc] ^= val ; coeff index i <-> codeword byte 254 - i
+            CW(254 - (int)locs[i]) ^= (unsigned char)val;
+        }
+#undef CW
+        return 255 - md;
+    }
+
+    // One thread per codeword. Frames live in global memory; codeword b of frame f is bytes data[f*stride + ii*I + b].
+    // Reproduces ReedSolomon::decode (reedsolomon.cpp:63-116) incl. fill_bytes handling and the error count.
+    constexpr int RS_THREADS = 64;
+    __global__ __launch_bounds__(RS_THREADS) void k_rs(unsigned char *data, int nframes, int frame_stride, int dualbasis, int I, int nroots, int fill_bytes,
+                                                        int *errors, const GfTables *tabs)
+    {
+        __shared__ GfLds gf;
+        __shared__ unsigned char dual[512]; // to_dual | from_dual
+        __shared__ unsigned char cwbuf[256 * RS_THREADS];
+        for (int i = (int)threadIdx.x; i < 512; i += RS_THREADS)
+        {
+            gf.exp[i] = tabs->exp[i];
+            if (i < 256)
+            {
+                gf.log[i] = tabs->log[i];
+                dual[i] = tabs->to_dual[i];
+                dual[256 + i] = tabs->from_dual[i];
+            }
+        }
+        __syncthreads();
+        const int tid = (int)threadIdx.x;
+        const long long cwid = (long long)blockIdx.x * RS_THREADS + tid;
+        if (cwid >= (long long)nframes * I)
+            return;
+        const int f = (int)(cwid / I), b = (int)(cwid % I);
+        unsigned char *base = data + (size_t)f * frame_stride;
+        unsigned char *cw = cwbuf + tid;
+        const int fb = fill_bytes < 0 ? 0 : fill_bytes; // fill_bytes == -1: no depuncture (the 256th-byte overrun is not reproduced)
+        const int coded = 255 - nroots;
+        // deinterleave + depuncture (reedsolomon.cpp:65-69,145-149) + dual->conventional
+        for (int k = 0; k < 255; k++)
+        {
+            unsigned v = (k < fb) ? 0u : base[(size_t)(k - fb) * I + b];
+            if (dualbasis && k >= fb)
+                v = dual[256 + v];
+            else if (dualbasis)
+                v = dual[256 + 0];
+            cw[k * RS_THREADS] = (unsigned char)v;
+        }
+        // keep a copy of the received message part for the error count
+        RsCtx R{&gf, nroots, nroots == 32 ? 112 : 120, 11};
+        // count differences while correcting: snapshot first `coded` bytes is expensive in registers, so
+        // recount by re-reading the input bytes after decode
+        const int res = rs_decode_thread(R, cw, RS_THREADS);
+        if (res < 0)
+        {
+            errors[cwid] = -1; // data left untouched (the reference restores it, reedsolomon.cpp:78-90)
+            return;
+        }
+        int err = 0;
+        for (int k = 0; k < 255; k++)
+        {
+            unsigned v = cw[k * RS_THREADS];
+            unsigned orig = (k < fb) ? 0u : base[(size_t)(k - fb) * I + b];
+            unsigned orig_conv = dualbasis ? dual[256 + orig] : orig;
+            if (k < coded)
+            {
+                if (v != orig_conv)
+                    err++;
+                // write back corrected message bytes (memcpy(data, odata, coded - fill) then ToDualBasis, :103-109;
+                // with fill_bytes > 0 the reference leaves the last fill_bytes message bytes uncorrected)
+                if (k >= fb && k < coded - fb)
+                    base[(size_t)(k - fb) * I + b] = (unsigned char)(dualbasis ? dual[v] : v);
+            }
+            // parity bytes: the reference converts the RECEIVED parity back unchanged -> no write needed
+        }
+        errors[cwid] = err;
+    }
+
+    void launch_rs_only(uint8_t *data, int nframes, int frame_stride, int dualbasis, int I, int nroots, int fill_bytes, int *errors, hipStream_t st)
+    {
+        const long long n = (long long)nframes * I;
+        if (n <= 0)
+            return;
+        const GfTables *tabs = tables_for_current_device();
+        hipLaunchKernelGGL(k_rs, dim3((unsigned)((n + RS_THREADS - 1) / RS_THREADS)), dim3(RS_THREADS), 0, st, data, nframes, frame_stride, dualbasis, I, nroots,
+                           fill_bytes, errors, tabs);
+    }
+
+    // ---- frame extraction + derandomiser -----------------------------------------------------------
+    __global__ __launch_bounds__(256) void k_extract(BitStream bs, FrameCfg fc, const FrameDesc *frames, int nframes, unsigned char *out, const GfTables *tabs)
+    {
+        const int f = (int)blockIdx.x;
+        if (f >= nframes)
+            return;
+        const FrameDesc d = frames[f];
+        unsigned char *o = out + (size_t)f * fc.cadu_bytes;
+        const int nwords = (fc.cadu_bytes + 3) / 4;
+        for (int w = (int)threadIdx.x; w < nwords; w += (int)blockDim.x)
+        {
+            unsigned v;
+            if (w == 0)
+                v = fc.asm_sync; // reset_frame writes the constant ASM, bpsk_ccsds_deframer.cpp:115-123
+            else
+            {
+                v = stream32(bs, d.pos + (long long)(w - 1) * 32);
+                if (d.inv)
+                    v = ~v;
+            }
+            for (int q = 0; q < 4; q++)
+            {
+                const int k = w * 4 + q;
+                if (k >= fc.cadu_bytes)
+                    break;
+                unsigned byte = (v >> (24 - 8 * q)) & 255u;
+                if (fc.derand && !fc.derand_after_rs && k >= fc.derand_start)
+                    byte ^= tabs->pn[(k - fc.derand_start) % 255];
+                o[k] = (unsigned char)byte;
+            }
+        }
+    }
+    __global__ __launch_bounds__(256) void k_derand(unsigned char *frames, int nframes, int cadu_bytes, int derand_start, const GfTables *tabs)
+    {
+        const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+        if (i >= (long long)nframes * cadu_bytes)
+            return;
+        const int k = (int)(i % cadu_bytes);
+        if (k >= derand_start)
+            frames[i] ^= tabs->pn[(k - derand_start) % 255];
+    }
+
+    void launch_frames(const BitStream &bs, const FrameCfg &fc, const FrameDesc *frames, int nframes, uint8_t *out, int *errors, hipStream_t st)
+    {
+        if (nframes <= 0)
+            return;
+        const GfTables *tabs = tables_for_current_device();
+        hipLaunchKernelGGL(k_extract, dim3(nframes), dim3(256), 0, st, bs, fc, frames, nframes, out, tabs);
+        if (fc.rs_i != 0)
+            launch_rs_only(out + 4, nframes, fc.cadu_bytes, fc.rs_dualbasis, fc.rs_i, fc.rs_nroots, fc.rs_fill_bytes, errors, st);
+        if (fc.derand && fc.derand_after_rs)
+        {
+            const long long n = (long long)nframes * fc.cadu_bytes;
+            hipLaunchKernelGGL(k_derand, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, out, nframes, fc.cadu_bytes, fc.derand_start, tabs);
+        }
+    }
+
+    __global__ __launch_bounds__(256) void k_compact(const unsigned char *frames, const int *dst_index, int nframes, int cadu_bytes, unsigned char *out)
+    {
+        const int f = (int)blockIdx.x;
+        if (f >= nframes)
+            return;
+        const int d = dst_index[f];
+        if (d < 0)
+            return;
+        const unsigned char *s = frames + (size_t)f * cadu_bytes;
+        unsigned char *o = out + (size_t)d * cadu_bytes;
+        for (int k = (int)threadIdx.x; k < cadu_bytes; k += (int)blockDim.x)
+            o[k] = s[k];
+    }
+    void launch_compact(const uint8_t *frames, const int *dst_index, int nframes, int cadu_bytes, uint8_t *out, hipStream_t st)
+    {
+        if (nframes <= 0)
+            return;
+        hipLaunchKernelGGL(k_compact, dim3(nframes), dim3(256), 0, st, frames, dst_index, nframes, cadu_bytes, out);
+    }
+} // namespace sdhip
