@@ -92,9 +92,10 @@ extern "C"
         float final_samplerate;
         int buffer_size;       /* effective d_buffer_size */
         int resample_interp, resample_decim; /* 0,0 when not resampling */
-        uint32_t chunks;        /* speculative chunks processed by the last call */
-        uint32_t chunks_fixed;  /* chunks re-run because the boundary certificate failed */
-        uint32_t chunks_rotated;/* chunks whose Costas quadrant was corrected against the left neighbour */
+        uint32_t chunks;        /* speculative chunks processed by the last call (all three loop stages) */
+        uint32_t chunks_fixed;  /* chunks re-run from the exact boundary state because the certificate failed */
+        uint32_t chunks_rotated;/* Costas chunks that locked on another constellation symmetry and were rotated back */
+        uint32_t chunks_inexact;/* chunks accepted by tolerance (boundary states equal to ~1e-6) rather than bit-for-bit */
     } sdhip_demod_stats;
 
     void sdhip_demod_cfg_default(sdhip_demod_cfg *cfg);

@@ -1,0 +1,768 @@
+// demod_engine.hip -- host side of psk_demod on the GPU: parameter derivation exactly as the reference
+// module does it (module_demod_base.cpp:12-89, module_psk_demod.cpp:12-136), stage sequencing, the
+// boundary certificates of the chunk-speculative loop stages, stream-state carry, and the C ABI.
+#include "demod_kernels.h"
+#include "dsp_design.h"
+#include "../../include/sdhip.h"
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+namespace sdhip
+{
+    // |x|^M frequency estimate for the very first warm-up frequency (parallel; the loops themselves are exact)
+    __global__ __launch_bounds__(256) void k_freq_est(const cf32 *x, long long n, int order, double *partial)
+    {
+        __shared__ double sre[256], sim[256];
+        const long long i0 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+        const long long stride = (long long)gridDim.x * blockDim.x;
+        double are = 0, aim = 0;
+        for (long long i = i0; i + 1 < n; i += stride)
+        {
+            double ar = x[i].re, ai = x[i].im, br = x[i + 1].re, bi = x[i + 1].im;
+            for (int m = 1; m < order; m <<= 1)
+            { // square log2(order) times: z^order
+                const double tr = ar * ar - ai * ai, ti = 2 * ar * ai;
+                ar = tr;
+                ai = ti;
+                const double ur = br * br - bi * bi, ui = 2 * br * bi;
+                br = ur;
+                bi = ui;
+            }
+            are += br * ar + bi * ai; // z[n+1] * conj(z[n])
+            aim += bi * ar - br * ai;
+        }
+        sre[threadIdx.x] = are;
+        sim[threadIdx.x] = aim;
+        __syncthreads();
+        for (int s = 128; s > 0; s >>= 1)
+        {
+            if ((int)threadIdx.x < s)
+            {
+                sre[threadIdx.x] += sre[threadIdx.x + s];
+                sim[threadIdx.x] += sim[threadIdx.x + s];
+            }
+            __syncthreads();
+        }
+        if (threadIdx.x == 0)
+        {
+            partial[2 * blockIdx.x] = sre[0];
+            partial[2 * blockIdx.x + 1] = sim[0];
+        }
+    }
+    __global__ __launch_bounds__(256) void k_mean_abs(const cf32 *x, long long n, double *partial)
+    {
+        __shared__ double acc[256];
+        const long long i0 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+        const long long stride = (long long)gridDim.x * blockDim.x;
+        double a = 0;
+        for (long long i = i0; i < n; i += stride)
+            a += sqrt((double)x[i].re * x[i].re + (double)x[i].im * x[i].im);
+        acc[threadIdx.x] = a;
+        __syncthreads();
+        for (int s = 128; s > 0; s >>= 1)
+        {
+            if ((int)threadIdx.x < s)
+                acc[threadIdx.x] += acc[threadIdx.x + s];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0)
+            partial[blockIdx.x] = acc[0];
+    }
+
+    struct DemodEngine
+    {
+        sdhip_demod_cfg cfg;
+        hipStream_t stream = nullptr;
+        // derived exactly like BaseDemodModule::initb / PSKDemodModule::init
+        int d_buffer_size = 0;
+        bool resample = false;
+        float final_samplerate = 0, final_sps = 0;
+        unsigned r_interp = 0, r_decim = 0;
+        int r_ntaps = 0;
+        bool is_bpsk = false, is_oqpsk = false;
+        int order = 4, rot_mod = 4;
+        double rot_unit = 0;
+        int rrc_ntaps = 31;
+        AgcParams agc_p{};
+        CostasParams cos_p{};
+        MmParams mm_p{};
+
+        // stream state
+        bool started = false;
+        int r_ctr = 0, r_inc = 0;
+        AgcState agc_s{1.0f};
+        CostasState cos_s{0.0f, 0.0f};
+        MmState mm_s{};
+        DcState dc_s{0, 0};
+        std::vector<cf32> hist_in, hist_agc, hist_cos; // DEMOD_HIST samples each (history in front of stage inputs)
+
+        // device
+        DevBuf<cf32> bufA, bufB, symbuf, d_hist;
+        DevBuf<float> d_rrc, d_mmbank, d_rbank;
+        DevBuf<AgcState> d_agc_spec, d_agc_end, d_agc_start;
+        DevBuf<CostasState> d_cos_spec, d_cos_end, d_cos_start;
+        DevBuf<MmState> d_mm_spec, d_mm_end, d_mm_start;
+        DevBuf<DcState> d_dc;
+        DevBuf<int> d_redo, d_rot, d_counts;
+        DevBuf<long long> d_offsets;
+        DevBuf<double> d_partial;
+        DevBuf<int8_t> d_soft_tmp;
+        DevBuf<uint8_t> d_in_tmp;
+
+        // host path
+        std::vector<uint8_t> pend_bytes;
+        int pend_fmt = 0;
+        std::vector<int8_t> out_queue;
+        size_t out_read = 0;
+
+        sdhip_demod_stats stats{};
+
+        static int fmt_bytes(int fmt) { return fmt == SDHIP_FMT_CF32 ? 8 : (fmt == SDHIP_FMT_CS16 ? 4 : 2); }
+
+        explicit DemodEngine(const sdhip_demod_cfg &c) : cfg(c)
+        {
+            SD_HIP(hipSetDevice(cfg.device));
+            SD_HIP(hipStreamCreate(&stream));
+            if (cfg.samplerate <= 0)
+                throw HipError("Samplerate parameter must be present!");
+            if (cfg.symbolrate <= 0)
+                throw HipError("symbolrate must be present");
+            // ---- BaseDemodModule ctor + initb (module_demod_base.cpp:22-25, 59-89)
+            const long d_samplerate = (long)cfg.samplerate;
+            const int d_symbolrate = (int)cfg.symbolrate;
+            d_buffer_size = cfg.buffer_size > 0 ? cfg.buffer_size : std::min<int>(1000000, std::max<int>(8192 + 1, (int)(d_samplerate / 200)));
+            float MIN_SPS = cfg.min_sps, MAX_SPS = cfg.max_sps;
+            is_bpsk = cfg.constellation == SDHIP_BPSK;
+            is_oqpsk = cfg.constellation == SDHIP_OQPSK;
+            if (cfg.constellation != SDHIP_BPSK && cfg.constellation != SDHIP_QPSK && cfg.constellation != SDHIP_OQPSK && cfg.constellation != SDHIP_8PSK)
+                throw HipError("Constellation type parameter must be present!");
+            if (is_oqpsk)
+            {
+                MIN_SPS = 1.6f;
+                MAX_SPS = 2.4f;
+            }
+            const float input_sps = (float)d_samplerate / (float)d_symbolrate;
+            resample = input_sps > MAX_SPS || input_sps < MIN_SPS;
+            const int range = (int)pow(10, (std::to_string(int(d_symbolrate)).size() - 1));
+            final_samplerate = d_samplerate;
+            if (MAX_SPS == MIN_SPS)
+                final_samplerate = d_symbolrate * MAX_SPS;
+            else if (input_sps > MAX_SPS)
+                final_samplerate = resample ? (round(d_symbolrate / range) * range) * MAX_SPS : d_samplerate;
+            else if (input_sps < MIN_SPS)
+                final_samplerate = resample ? d_symbolrate * MIN_SPS : d_samplerate;
+            const float decimation_factor = d_samplerate / final_samplerate;
+            if (resample)
+                d_buffer_size *= ceil(decimation_factor);
+            if (d_buffer_size > 8192 * 20)
+                d_buffer_size = 8192 * 20;
+            final_sps = final_samplerate / (float)d_symbolrate;
+            if (input_sps < 1.0)
+                throw HipError("Your sampling rate is too low!");
+
+            if (resample)
+            {
+                // SmartResamplerBlock(input, final_samplerate, d_samplerate), smart_resampler.cpp:8-61
+                unsigned interpolation = (unsigned)final_samplerate, decimation = (unsigned)d_samplerate;
+                if (decimation > interpolation)
+                {
+                    const int best_power = (int)floor(log2(decimation / interpolation));
+                    if (best_power > 0)
+                        throw HipError("input needs the power-of-two pre-decimator (samplerate >= 2x the target): not implemented in the HIP path");
+                    double rsamp_in = decimation, fout = interpolation, t;
+                    while (modf(rsamp_in, &t) != 0 || modf(fout, &t) != 0)
+                    {
+                        rsamp_in *= 10;
+                        fout *= 10;
+                    }
+                    interpolation = (unsigned)fout;
+                    decimation = (unsigned)rsamp_in;
+                }
+                std::vector<float> bank;
+                r_interp = interpolation;
+                r_decim = decimation;
+                r_ntaps = design::resampler_bank(r_interp, r_decim, bank);
+                if (r_ntaps > DEMOD_HIST)
+                    throw HipError("resampler filter longer than the history window");
+                d_rbank.reserve(bank.size());
+                SD_HIP(hipMemcpy(d_rbank.p, bank.data(), bank.size() * sizeof(float), hipMemcpyHostToDevice));
+            }
+            // AGC (module_demod_base.cpp:207)
+            agc_p.rate = cfg.agc_rate;
+            agc_p.reference = 1.0f;
+            agc_p.max_gain = 65536.0f;
+            agc_p.init_gain = 1.0f;
+            agc_s.gain = 1.0f;
+            // RRC (module_psk_demod.cpp:91)
+            std::vector<float> rrc = design::rrc(1, final_samplerate, d_symbolrate, cfg.rrc_alpha, cfg.rrc_taps);
+            rrc_ntaps = (int)rrc.size();
+            if (rrc_ntaps > DEMOD_HIST || rrc_ntaps > 384)
+                throw HipError("rrc_taps too large for the HIP path");
+            std::vector<float> rrev(rrc.size());
+            for (size_t j = 0; j < rrc.size(); j++)
+                rrev[j] = rrc[rrc.size() - 1 - j]; // FIRBlock reverses its taps, fir.cpp:30
+            d_rrc.reserve(rrev.size());
+            SD_HIP(hipMemcpy(d_rrc.p, rrev.data(), rrev.size() * sizeof(float), hipMemcpyHostToDevice));
+            // Costas (module_psk_demod.cpp:116-125)
+            float costas_max_offset = 1.0f;
+            if (cfg.costas_max_offset_hz > 0)
+                costas_max_offset = (float)(2.0 * design::PI * ((double)cfg.costas_max_offset_hz / (double)final_samplerate));
+            order = is_bpsk ? 2 : (cfg.constellation == SDHIP_8PSK ? 8 : 4);
+            rot_mod = order;
+            rot_unit = 2.0 * design::PI / order;
+            design::costas_gains(cfg.pll_bw, cos_p.alpha, cos_p.beta);
+            cos_p.fmin = -costas_max_offset;
+            cos_p.fmax = costas_max_offset;
+            cos_p.order = order;
+            cos_p.init_freq = 0.0f;
+            // M&M (module_psk_demod.cpp:134, clock_recovery_mm.cpp:10-27)
+            std::vector<float> mmb;
+            const int mmt = design::mm_bank(128, 8, mmb);
+            if (mmt != 8)
+                throw HipError("unexpected interpolator bank shape");
+            d_mmbank.reserve(mmb.size());
+            SD_HIP(hipMemcpy(d_mmbank.p, mmb.data(), mmb.size() * sizeof(float), hipMemcpyHostToDevice));
+            mm_p.omega_gain = cfg.clock_gain_omega;
+            mm_p.mu_gain = cfg.clock_gain_mu;
+            mm_p.omega_mid = final_sps;
+            mm_p.omega_limit = cfg.clock_omega_relative_limit * final_sps;
+            mm_p.init_mu = cfg.clock_mu;
+            mm_p.bank = d_mmbank.p;
+            mm_p.oqpsk = is_oqpsk ? 1 : 0;
+            mm_p.order = order;
+            memset(&mm_s, 0, sizeof(mm_s));
+            mm_s.mu = cfg.clock_mu;
+            mm_s.omega = final_sps;
+            mm_s.inc = 0;
+            hist_in.assign(DEMOD_HIST, cf32{0, 0});
+            hist_agc.assign(DEMOD_HIST, cf32{0, 0});
+            hist_cos.assign(DEMOD_HIST, cf32{0, 0});
+            d_hist.reserve(DEMOD_HIST);
+            d_agc_start.reserve(1);
+            d_cos_start.reserve(1);
+            d_mm_start.reserve(1);
+            d_dc.reserve(1);
+            d_partial.reserve(1024);
+            stats.final_sps = final_sps;
+            stats.final_samplerate = final_samplerate;
+            stats.buffer_size = d_buffer_size;
+            stats.resample_interp = resample ? (int)r_interp : 0;
+            stats.resample_decim = resample ? (int)r_decim : 0;
+        }
+        ~DemodEngine()
+        {
+            if (stream)
+                (void)hipStreamDestroy(stream);
+        }
+
+        void put_hist(cf32 *base, const std::vector<cf32> &h)
+        {
+            SD_HIP(hipMemcpyAsync(base - DEMOD_HIST, h.data(), DEMOD_HIST * sizeof(cf32), hipMemcpyHostToDevice, stream));
+        }
+        void get_hist(const cf32 *base, long long n, std::vector<cf32> &h)
+        { // last DEMOD_HIST samples of [hist | data(n)]
+            if (n >= DEMOD_HIST)
+                SD_HIP(hipMemcpyAsync(h.data(), base + n - DEMOD_HIST, DEMOD_HIST * sizeof(cf32), hipMemcpyDeviceToHost, stream));
+            else
+            {
+                std::vector<cf32> t(DEMOD_HIST);
+                SD_HIP(hipMemcpyAsync(t.data(), base - (DEMOD_HIST - n), DEMOD_HIST * sizeof(cf32), hipMemcpyDeviceToHost, stream));
+                SD_HIP(hipStreamSynchronize(stream));
+                h = t;
+                return;
+            }
+            SD_HIP(hipStreamSynchronize(stream));
+        }
+
+        int pick_L(long long n) const
+        {
+            if (cfg.exact)
+                return 1 << 30;
+            if (cfg.chunk_len > 0)
+                return cfg.chunk_len;
+            long long L = (n + 32767) / 32768;
+            L = (L + 255) / 256 * 256;
+            return (int)std::min<long long>(std::max<long long>(L, 4096), 1 << 20);
+        }
+
+        template <class S, class Accept, class Launch>
+        void verify_fix(const char *stage, int K, DevBuf<S> &d_spec, DevBuf<S> &d_end, std::vector<S> &spec, std::vector<S> &endst, Accept accept, Launch relaunch)
+        {
+            const unsigned fixed0 = stats.chunks_fixed, inexact0 = stats.chunks_inexact;
+            // certificate chain: chunk k stands iff the state its warm-up reached equals the state chunk k-1 ended in
+            spec.resize(K);
+            endst.resize(K);
+            SD_HIP(hipMemcpyAsync(spec.data(), d_spec.p, (size_t)K * sizeof(S), hipMemcpyDeviceToHost, stream));
+            SD_HIP(hipMemcpyAsync(endst.data(), d_end.p, (size_t)K * sizeof(S), hipMemcpyDeviceToHost, stream));
+            SD_HIP(hipStreamSynchronize(stream));
+            for (int k = 1; k < K; k++)
+            {
+                if (accept(k, spec[k], endst[k - 1]))
+                    continue;
+                // re-run chunk k from the exact boundary state; its new end state feeds the check of k+1
+                stats.chunks_fixed++;
+                d_redo.reserve(1);
+                SD_HIP(hipMemcpyAsync(d_redo.p, &k, sizeof(int), hipMemcpyHostToDevice, stream));
+                relaunch(d_redo.p, 1);
+                SD_HIP(hipMemcpyAsync(&endst[k], d_end.p + k, sizeof(S), hipMemcpyDeviceToHost, stream));
+                SD_HIP(hipStreamSynchronize(stream));
+                spec[k] = endst[k - 1];
+            }
+            if (getenv("SDHIP_DEBUG"))
+                fprintf(stderr, "[sdhip] %-6s chunks %d  re-run %u  accepted-by-tolerance %u\n", stage, K, stats.chunks_fixed - fixed0, stats.chunks_inexact - inexact0);
+        }
+
+        // Process n input samples resident on the device. Outputs go to d_soft / d_syms (device).
+        int64_t process(const void *d_in, size_t n_in, int fmt, int8_t *d_soft, size_t soft_cap, float *d_syms, size_t syms_cap)
+        {
+            SD_HIP(hipSetDevice(cfg.device));
+            stats.chunks = stats.chunks_fixed = stats.chunks_rotated = stats.chunks_inexact = 0;
+            if (n_in == 0)
+                return 0;
+            long long n = (long long)n_in;
+            const size_t need = (size_t)n + 2 * DEMOD_HIST + 64;
+            bufA.reserve(need);
+            bufB.reserve(need);
+            cf32 *A = bufA.p + DEMOD_HIST, *B = bufB.p + DEMOD_HIST;
+            stats.samples_in += n;
+
+            // ---- stage 0: format conversion (+ iq_swap)
+            launch_convert(d_in, fmt, cfg.iq_swap, n, A, stream);
+            if (cfg.dc_block)
+            {
+                SD_HIP(hipMemcpyAsync(d_dc.p, &dc_s, sizeof(dc_s), hipMemcpyHostToDevice, stream));
+                launch_dcblock_seq(A, B, n, d_dc.p, stream);
+                SD_HIP(hipMemcpyAsync(&dc_s, d_dc.p, sizeof(dc_s), hipMemcpyDeviceToHost, stream));
+                std::swap(A, B);
+            }
+            // ---- rational resampler
+            if (resample)
+            {
+                put_hist(A, hist_in);
+                // outputs m with inc0 + (ctr0 + m*decim)/interp < n
+                const long long lim = (n - r_inc) * (long long)r_interp - r_ctr;
+                const long long nout = lim > 0 ? (lim + r_decim - 1) / r_decim : 0;
+                ResampParams rp{(int)r_interp, (int)r_decim, r_ntaps, d_rbank.p};
+                launch_resample(A, n, rp, r_ctr, r_inc, B, nout, stream);
+                get_hist(A, n, hist_in);
+                const long long ph_end = r_ctr + nout * (long long)r_decim;
+                r_inc = (int)(r_inc + ph_end / r_interp - n);
+                r_ctr = (int)(ph_end % r_interp);
+                std::swap(A, B);
+                n = nout;
+                if (n == 0)
+                    return 0;
+            }
+            const int L = pick_L(n);
+
+            // ---- AGC (speculative)
+            {
+                // warm-up length ~ 24 time constants of the loop (tau = gain / rate samples), gain estimated from mean |x|
+                float g_est = agc_s.gain;
+                if (!started)
+                {
+                    const long long m = std::min<long long>(n, 1 << 16);
+                    hipLaunchKernelGGL(k_mean_abs, dim3(64), dim3(256), 0, stream, A, m, d_partial.p);
+                    double part[64];
+                    SD_HIP(hipMemcpyAsync(part, d_partial.p, sizeof(part), hipMemcpyDeviceToHost, stream));
+                    SD_HIP(hipStreamSynchronize(stream));
+                    double s = 0;
+                    for (double v : part)
+                        s += v;
+                    const double mean = s / (double)m;
+                    if (mean > 1e-12)
+                        g_est = (float)std::min(65536.0, 1.0 / mean);
+                }
+                long long W = cfg.warmup > 0 ? cfg.warmup : (long long)(24.0 * std::max(1.0f, g_est) / std::max(1e-6f, cfg.agc_rate));
+                W = std::min<long long>(std::max<long long>(W, 1024), 1 << 22);
+                W = (W + 255) / 256 * 256;
+                agc_p.init_gain = g_est;
+                const ChunkGeom g = make_geom(n, L, (int)W);
+                stats.chunks += g.K;
+                d_agc_spec.reserve(g.K);
+                d_agc_end.reserve(g.K);
+                SD_HIP(hipMemcpyAsync(d_agc_start.p, &agc_s, sizeof(agc_s), hipMemcpyHostToDevice, stream));
+                launch_agc(A, B, g, agc_p, d_agc_start.p, d_agc_spec.p, d_agc_end.p, nullptr, 0, stream);
+                std::vector<AgcState> spec, endst;
+                verify_fix(
+                    "agc", g.K, d_agc_spec, d_agc_end, spec, endst,
+                    [&](int, const AgcState &a, const AgcState &b) {
+                        if (memcmp(&a, &b, sizeof(a)) == 0)
+                            return true;
+                        if (std::fabs(a.gain - b.gain) <= 1e-6f * std::fabs(b.gain))
+                        {
+                            stats.chunks_inexact++;
+                            return true;
+                        }
+                        return false;
+                    },
+                    [&](const int *redo, int nr) { launch_agc(A, B, g, agc_p, d_agc_start.p, d_agc_spec.p, d_agc_end.p, redo, nr, stream); });
+                agc_s = endst[g.K - 1];
+                std::swap(A, B);
+            }
+            // ---- RRC FIR (parallel, exact)
+            put_hist(A, hist_agc);
+            launch_fir(A, B, n, d_rrc.p, rrc_ntaps, stream);
+            get_hist(A, n, hist_agc);
+            std::swap(A, B);
+
+            // ---- Costas (speculative, symmetry-corrected)
+            ChunkGeom cg;
+            std::vector<int> rot;
+            {
+                if (!started)
+                {
+                    // coarse carrier frequency for the warm-up start state: arg(sum z[n+1] conj(z[n])) / order, z = x^order
+                    const long long m = std::min<long long>(n, 1 << 18);
+                    hipLaunchKernelGGL(k_freq_est, dim3(64), dim3(256), 0, stream, A, m, order, d_partial.p);
+                    double part[128];
+                    SD_HIP(hipMemcpyAsync(part, d_partial.p, sizeof(part), hipMemcpyDeviceToHost, stream));
+                    SD_HIP(hipStreamSynchronize(stream));
+                    double sr = 0, si = 0;
+                    for (int i = 0; i < 64; i++)
+                    {
+                        sr += part[2 * i];
+                        si += part[2 * i + 1];
+                    }
+                    float f = (float)(std::atan2(si, sr) / order);
+                    f = std::min(std::max(f, cos_p.fmin), cos_p.fmax);
+                    cos_p.init_freq = f;
+                }
+                else
+                    cos_p.init_freq = cos_s.freq;
+                long long W = cfg.warmup > 0 ? cfg.warmup : (long long)std::max(8192.0, 100.0 / std::max(1e-5f, cos_p.alpha));
+                W = (std::min<long long>(W, 1 << 22) + 255) / 256 * 256;
+                cg = make_geom(n, L, (int)W);
+                stats.chunks += cg.K;
+                d_cos_spec.reserve(cg.K);
+                d_cos_end.reserve(cg.K);
+                SD_HIP(hipMemcpyAsync(d_cos_start.p, &cos_s, sizeof(cos_s), hipMemcpyHostToDevice, stream));
+                launch_costas(A, B, cg, cos_p, d_cos_start.p, d_cos_spec.p, d_cos_end.p, nullptr, 0, stream);
+                rot.assign(cg.K, 0);
+                std::vector<CostasState> spec, endst;
+                verify_fix(
+                    "costas", cg.K, d_cos_spec, d_cos_end, spec, endst,
+                    [&](int k, const CostasState &a, const CostasState &b) {
+                        if (memcmp(&a, &b, sizeof(a)) == 0)
+                        {
+                            rot[k] = rot[k - 1];
+                            return true;
+                        }
+                        // the loop's stable points are rot_unit apart: accept a lock on another one and rotate it back
+                        const double dphi = (double)a.phase - (double)b.phase;
+                        const double u = dphi / rot_unit;
+                        const long long d = llround(u);
+                        const double resid = dphi - (double)d * rot_unit;
+                        if (std::fabs(resid) < 2e-5 && std::fabs((double)a.freq - (double)b.freq) < 2e-7)
+                        {
+                            const int dm = (int)(((d % rot_mod) + rot_mod) % rot_mod);
+                            rot[k] = (rot[k - 1] + dm) % rot_mod;
+                            if (dm != 0)
+                                stats.chunks_rotated++;
+                            stats.chunks_inexact++;
+                            return true;
+                        }
+                        rot[k] = rot[k - 1]; // re-run continues in the previous chunk's frame
+                        return false;
+                    },
+                    [&](const int *redo, int nr) { launch_costas(A, B, cg, cos_p, d_cos_start.p, d_cos_spec.p, d_cos_end.p, redo, nr, stream); });
+                // chunk k's phase = true phase + rot[k]*unit; carry the loop state in the frame of the last chunk,
+                // re-expressed in the stream's frame (rot 0) so the next call starts unrotated
+                cos_s = endst[cg.K - 1];
+                if (rot[cg.K - 1] != 0)
+                {
+                    double ph = (double)cos_s.phase - rot[cg.K - 1] * rot_unit;
+                    while (ph > 2 * design::PI)
+                        ph -= 2 * design::PI;
+                    while (ph < -2 * design::PI)
+                        ph += 2 * design::PI;
+                    cos_s.phase = (float)ph;
+                }
+                stats.freq_hz = (float)(((double)cos_s.freq / (2.0 * design::PI)) * (double)final_samplerate);
+                std::swap(A, B);
+            }
+            // ---- M&M + quantiser
+            int64_t nsoft = 0;
+            {
+                d_rot.reserve(cg.K);
+                SD_HIP(hipMemcpyAsync(d_rot.p, rot.data(), (size_t)cg.K * sizeof(int), hipMemcpyHostToDevice, stream));
+                put_hist(A, hist_cos);
+                long long W = cfg.warmup > 0 ? cfg.warmup : 12288;
+                W = (W + 255) / 256 * 256;
+                const ChunkGeom g = make_geom(n, L, (int)W);
+                stats.chunks += g.K;
+                const double omin = (double)mm_p.omega_mid - (double)mm_p.omega_limit;
+                const long long span0 = std::min<long long>(n, (long long)L + W);
+                mm_p.cap = (int)(span0 / std::max(0.5, omin - 0.01)) + 16;
+                mm_p.cg = cg;
+                mm_p.rot = d_rot.p;
+                symbuf.reserve((size_t)g.K * mm_p.cap);
+                d_counts.reserve(g.K);
+                d_offsets.reserve(g.K);
+                d_mm_spec.reserve(g.K);
+                d_mm_end.reserve(g.K);
+                SD_HIP(hipMemcpyAsync(d_mm_start.p, &mm_s, sizeof(mm_s), hipMemcpyHostToDevice, stream));
+                launch_mm(A, symbuf.p, d_counts.p, g, mm_p, d_mm_start.p, d_mm_spec.p, d_mm_end.p, nullptr, 0, stream);
+                std::vector<MmState> spec, endst;
+                verify_fix(
+                    "mm", g.K, d_mm_spec, d_mm_end, spec, endst,
+                    [&](int, const MmState &a, const MmState &b) {
+                        if (memcmp(&a, &b, sizeof(a)) == 0)
+                            return true;
+                        // The M&M loop never re-merges bit for bit: its feedback is piecewise constant through the 128-arm
+                        // interpolator index rint(mu*128) (clock_recovery_mm.cpp:66), so independent trajectories hover
+                        // ~1e-4 apart in mu (tools/merge_study.py). Consistency is what is certified here: same sample
+                        // position (no duplicated / dropped symbol) and timing within ~1 interpolator arm.
+                        if (a.inc == b.inc && std::fabs(a.mu - b.mu) < 1e-2f && std::fabs(a.omega - b.omega) < 1e-4f * std::fabs(b.omega))
+                        {
+                            stats.chunks_inexact++;
+                            return true;
+                        }
+                        return false;
+                    },
+                    [&](const int *redo, int nr) { launch_mm(A, symbuf.p, d_counts.p, g, mm_p, d_mm_start.p, d_mm_spec.p, d_mm_end.p, redo, nr, stream); });
+                mm_s = endst[g.K - 1];
+                mm_s.inc -= n; // clock_recovery_mm.cpp:123-126
+                if (mm_s.inc < 0)
+                    mm_s.inc = 0;
+                // compaction offsets
+                std::vector<int> counts(g.K);
+                SD_HIP(hipMemcpyAsync(counts.data(), d_counts.p, (size_t)g.K * sizeof(int), hipMemcpyDeviceToHost, stream));
+                SD_HIP(hipStreamSynchronize(stream));
+                std::vector<long long> offs(g.K);
+                long long tot = 0;
+                for (int k = 0; k < g.K; k++)
+                {
+                    if (counts[k] > mm_p.cap)
+                        throw HipError("symbol scratch overflow");
+                    offs[k] = tot;
+                    tot += counts[k];
+                }
+                const long long need_soft = is_bpsk ? tot : 2 * tot;
+                if ((size_t)need_soft > soft_cap)
+                    throw HipError("soft output buffer too small");
+                SD_HIP(hipMemcpyAsync(d_offsets.p, offs.data(), (size_t)g.K * sizeof(long long), hipMemcpyHostToDevice, stream));
+                launch_quantize(symbuf.p, d_counts.p, d_offsets.p, g.K, mm_p.cap, is_bpsk ? 1 : 0, d_soft, (long long)soft_cap, d_syms, (long long)syms_cap, stream);
+                // history for the next call: last DEMOD_HIST de-rotated Costas outputs
+                launch_tail_copy(A, n, DEMOD_HIST, cg, d_rot.p, order, d_hist.p, stream);
+                SD_HIP(hipMemcpyAsync(hist_cos.data(), d_hist.p, DEMOD_HIST * sizeof(cf32), hipMemcpyDeviceToHost, stream));
+                SD_HIP(hipStreamSynchronize(stream));
+                stats.symbols_out += tot;
+                nsoft = need_soft;
+            }
+            started = true;
+            return nsoft;
+        }
+
+        // ---- host path
+        int push_host(const void *iq, size_t nsamples, int fmt)
+        {
+            if (!pend_bytes.empty() && fmt != pend_fmt)
+                throw HipError("baseband format changed mid-stream");
+            pend_fmt = fmt;
+            const size_t nb = nsamples * fmt_bytes(fmt);
+            pend_bytes.insert(pend_bytes.end(), (const uint8_t *)iq, (const uint8_t *)iq + nb);
+            if (pend_bytes.size() / fmt_bytes(fmt) >= (size_t)(32u << 20))
+                return flush_host();
+            return 0;
+        }
+        int flush_host()
+        {
+            const size_t ns = pend_bytes.size() / fmt_bytes(pend_fmt);
+            if (ns == 0)
+                return 0;
+            SD_HIP(hipSetDevice(cfg.device));
+            d_in_tmp.reserve(pend_bytes.size());
+            SD_HIP(hipMemcpy(d_in_tmp.p, pend_bytes.data(), pend_bytes.size(), hipMemcpyHostToDevice));
+            const size_t cap = 2 * ns + 64;
+            d_soft_tmp.reserve(cap);
+            const int64_t n = process(d_in_tmp.p, ns, pend_fmt, d_soft_tmp.p, cap, nullptr, 0);
+            const size_t old = out_queue.size();
+            out_queue.resize(old + (size_t)n);
+            SD_HIP(hipMemcpy(out_queue.data() + old, d_soft_tmp.p, (size_t)n, hipMemcpyDeviceToHost));
+            pend_bytes.clear();
+            return 0;
+        }
+        int64_t pull(int8_t *soft, size_t cap)
+        {
+            const size_t avail = out_queue.size() - out_read;
+            const size_t take = std::min(avail, cap);
+            memcpy(soft, out_queue.data() + out_read, take);
+            out_read += take;
+            if (out_read == out_queue.size())
+            {
+                out_queue.clear();
+                out_read = 0;
+            }
+            return (int64_t)take;
+        }
+    };
+} // namespace sdhip
+
+using namespace sdhip;
+
+#define SD_GUARD_BEGIN try {
+#define SD_GUARD_END(ret)           \
+    }                               \
+    catch (const std::exception &e) \
+    {                               \
+        sdhip::set_error(e.what()); \
+        return ret;                 \
+    }
+
+extern "C"
+{
+    void sdhip_demod_cfg_default(sdhip_demod_cfg *c)
+    {
+        memset(c, 0, sizeof(*c));
+        c->constellation = SDHIP_QPSK;
+        c->rrc_taps = 31;
+        c->agc_rate = 1e-2f;
+        c->min_sps = 1.1f;
+        c->max_sps = 4.0f;
+        c->clock_gain_omega = (float)(pow(8.7e-3, 2) / 4.0); // module_psk_demod.h:36-39
+        c->clock_mu = 0.5f;
+        c->clock_gain_mu = (float)8.7e-3;
+        c->clock_omega_relative_limit = 0.005f;
+    }
+    void *sdhip_demod_create(const sdhip_demod_cfg *cfg)
+    {
+        SD_GUARD_BEGIN
+        return new DemodEngine(*cfg);
+        SD_GUARD_END(nullptr)
+    }
+    void sdhip_demod_destroy(void *h) { delete (DemodEngine *)h; }
+    int sdhip_demod_push(void *h, const void *iq, size_t nsamples, int fmt)
+    {
+        SD_GUARD_BEGIN
+        return ((DemodEngine *)h)->push_host(iq, nsamples, fmt);
+        SD_GUARD_END(-1)
+    }
+    int sdhip_demod_flush(void *h)
+    {
+        SD_GUARD_BEGIN
+        return ((DemodEngine *)h)->flush_host();
+        SD_GUARD_END(-1)
+    }
+    int64_t sdhip_demod_pull(void *h, int8_t *soft, size_t cap)
+    {
+        SD_GUARD_BEGIN
+        return ((DemodEngine *)h)->pull(soft, cap);
+        SD_GUARD_END(-1)
+    }
+    int64_t sdhip_demod_process_dev(void *h, const void *d_iq, size_t nsamples, int fmt, int8_t *d_soft, size_t soft_cap, float *d_syms, size_t syms_cap, int final)
+    {
+        (void)final; // the demodulator has no block granularity: every call consumes all its samples
+        SD_GUARD_BEGIN
+        return ((DemodEngine *)h)->process(d_iq, nsamples, fmt, d_soft, soft_cap, d_syms, syms_cap);
+        SD_GUARD_END(-1)
+    }
+    int sdhip_demod_get_stats(void *h, sdhip_demod_stats *st)
+    {
+        *st = ((DemodEngine *)h)->stats;
+        return 0;
+    }
+
+    // single blocks, exact sequential semantics (one lane): arithmetic parity of each kernel body
+    int64_t sdhip_op_block(int device, int kind, const float *params, const float *d_in, size_t n, float *d_out, size_t out_cap)
+    {
+        SD_GUARD_BEGIN
+        SD_HIP(hipSetDevice(device));
+        const long long nn = (long long)n;
+        DevBuf<cf32> in;
+        in.reserve(n + 2 * DEMOD_HIST);
+        SD_HIP(hipMemset(in.p, 0, DEMOD_HIST * sizeof(cf32)));
+        cf32 *X = in.p + DEMOD_HIST;
+        SD_HIP(hipMemcpy(X, d_in, n * sizeof(cf32), hipMemcpyDeviceToDevice));
+        cf32 *Y = (cf32 *)d_out;
+        const ChunkGeom g = make_geom(nn, 1 << 30, 0);
+        int64_t nout = nn;
+        if (kind == 0)
+        {
+            if (out_cap < n)
+                throw HipError("output too small");
+            AgcParams p{params[0], params[1], params[3], params[2]};
+            AgcState s0{params[2]};
+            DevBuf<AgcState> st;
+            st.reserve(3);
+            SD_HIP(hipMemcpy(st.p, &s0, sizeof(s0), hipMemcpyHostToDevice));
+            launch_agc(X, Y, g, p, st.p, st.p + 1, st.p + 2, nullptr, 0, nullptr);
+        }
+        else if (kind == 1)
+        {
+            std::vector<float> t = design::rrc(1, params[0], params[1], params[2], (int)params[3]);
+            std::vector<float> r(t.rbegin(), t.rend());
+            DevBuf<float> dt;
+            dt.reserve(r.size());
+            SD_HIP(hipMemcpy(dt.p, r.data(), r.size() * sizeof(float), hipMemcpyHostToDevice));
+            launch_fir(X, Y, nn, dt.p, (int)r.size(), nullptr);
+        }
+        else if (kind == 2)
+        {
+            CostasParams p{};
+            design::costas_gains(params[0], p.alpha, p.beta);
+            p.order = (int)params[1];
+            p.fmin = -params[2];
+            p.fmax = params[2];
+            CostasState s0{0, 0};
+            DevBuf<CostasState> st;
+            st.reserve(3);
+            SD_HIP(hipMemcpy(st.p, &s0, sizeof(s0), hipMemcpyHostToDevice));
+            launch_costas(X, Y, g, p, st.p, st.p + 1, st.p + 2, nullptr, 0, nullptr);
+        }
+        else if (kind == 3)
+        {
+            std::vector<float> mmb;
+            design::mm_bank(128, 8, mmb);
+            DevBuf<float> db;
+            db.reserve(mmb.size());
+            SD_HIP(hipMemcpy(db.p, mmb.data(), mmb.size() * sizeof(float), hipMemcpyHostToDevice));
+            MmParams p{};
+            p.omega_gain = params[1];
+            p.mu_gain = params[3];
+            p.omega_mid = params[0];
+            p.omega_limit = params[4] * params[0];
+            p.init_mu = params[2];
+            p.bank = db.p;
+            p.cap = (int)out_cap;
+            p.cg = g;
+            p.rot = nullptr;
+            p.order = 4;
+            MmState s0{};
+            s0.mu = params[2];
+            s0.omega = params[0];
+            DevBuf<MmState> st;
+            st.reserve(3);
+            DevBuf<int> cnt;
+            cnt.reserve(1);
+            SD_HIP(hipMemcpy(st.p, &s0, sizeof(s0), hipMemcpyHostToDevice));
+            launch_mm(X, Y, cnt.p, g, p, st.p, st.p + 1, st.p + 2, nullptr, 0, nullptr);
+            int c = 0;
+            SD_HIP(hipMemcpy(&c, cnt.p, sizeof(int), hipMemcpyDeviceToHost));
+            nout = c;
+        }
+        else if (kind == 4)
+        {
+            unsigned ip = (unsigned)params[0], dc = (unsigned)params[1];
+            std::vector<float> bank;
+            const int nt = design::resampler_bank(ip, dc, bank);
+            DevBuf<float> db;
+            db.reserve(bank.size());
+            SD_HIP(hipMemcpy(db.p, bank.data(), bank.size() * sizeof(float), hipMemcpyHostToDevice));
+            const long long lim = nn * (long long)ip;
+            nout = (lim + dc - 1) / dc;
+            if ((size_t)nout > out_cap)
+                throw HipError("output too small");
+            ResampParams rp{(int)ip, (int)dc, nt, db.p};
+            launch_resample(X, nn, rp, 0, 0, Y, nout, nullptr);
+        }
+        else
+            throw HipError("unknown block kind");
+        SD_HIP(hipDeviceSynchronize());
+        return nout;
+        SD_GUARD_END(-1)
+    }
+}

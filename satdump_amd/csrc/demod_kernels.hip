@@ -1,0 +1,588 @@
+// demod_kernels.hip -- psk_demod DSP chain on gfx950 (see demod_kernels.h for the scheme).
+//
+// Arithmetic contract: every float operation rounds exactly where the reference's x86-64 -O2 build
+// rounds (separate mul / add, no FMA: the library is compiled with -ffp-contract=off), sqrt is the
+// IEEE correctly-rounded one, and sinf/cosf follow glibc 2.35's algorithm (sincosf.h) in double
+// precision with the same polynomial and reduction, so that a single sequential lane reproduces the
+// reference bit for bit (tests/test_demod_gpu.py, exact mode).
+#include "demod_kernels.h"
+
+namespace sdhip
+{
+    // =============================================================================================
+    // glibc 2.35 sinf / cosf (sysdeps/ieee754/flt-32/s_sincosf.h, x86-64 FMA build), |x| < 120
+    // =============================================================================================
+    struct SinCosTab
+    {
+        double c0, c1, c2, c3, c4, s1, s2, s3;
+    };
+    __device__ __forceinline__ float sd_sinf_poly(double x, double x2, bool neg_tab, int n)
+    {
+        // __sincosf_table[0] / [1]: table 1 negates the cosine coefficients
+        const double sgn = neg_tab ? -1.0 : 1.0;
+        if ((n & 1) == 0)
+        {
+            const double s1c = -0x1.555545995a603p-3, s2c = 0x1.1107605230bc4p-7, s3c = -0x1.994eb3774cf24p-13;
+            const double x3 = x * x2;
+            const double s1 = fma(x2, s3c, s2c);
+            const double x7 = x3 * x2;
+            const double s = fma(x3, s1c, x);
+            return (float)fma(x7, s1, s);
+        }
+        else
+        {
+            const double c0 = sgn * 0x1p0, c1c = sgn * -0x1.ffffffd0c621cp-2, c2c = sgn * 0x1.55553e1068f19p-5, c3c = sgn * -0x1.6c087e89a359dp-10,
+                         c4c = sgn * 0x1.99343027bf8c3p-16;
+            const double x4 = x2 * x2;
+            const double c2 = fma(x2, c4c, c3c);
+            const double c1 = fma(x2, c1c, c0);
+            const double x6 = x4 * x2;
+            const double c = fma(x4, c2c, c1);
+            return (float)fma(x6, c2, c);
+        }
+    }
+    __device__ __forceinline__ unsigned sd_abstop12(float x) { return (__float_as_uint(x) >> 20) & 0x7ffu; }
+    __device__ __forceinline__ double sd_reduce_fast(double x, int *np)
+    {
+        const double hpi_inv = 0x1.45F306DC9C883p+23, hpi = 0x1.921FB54442D18p0;
+        const double r = x * hpi_inv;
+        const int n = ((int)r + 0x800000) >> 24;
+        *np = n;
+        return fma(-(double)n, hpi, x);
+    }
+    __device__ __forceinline__ float sd_sinf(float y)
+    {
+        double x = (double)y;
+        if (sd_abstop12(y) < sd_abstop12(0x1.921FB6p-1f))
+        {
+            const double s = x * x;
+            if (sd_abstop12(y) < sd_abstop12(0x1p-12f))
+                return y;
+            return sd_sinf_poly(x, s, false, 0);
+        }
+        int n;
+        x = sd_reduce_fast(x, &n);
+        const double sgn = ((n & 3) == 1 || (n & 3) == 2) ? -1.0 : 1.0; // sign[] = {1,-1,-1,1}
+        return sd_sinf_poly(x * sgn, x * x, (n & 2) != 0, n);
+    }
+    __device__ __forceinline__ float sd_cosf(float y)
+    {
+        double x = (double)y;
+        if (sd_abstop12(y) < sd_abstop12(0x1.921FB6p-1f))
+        {
+            if (sd_abstop12(y) < sd_abstop12(0x1p-12f))
+                return 1.0f;
+            return sd_sinf_poly(x, x * x, false, 1);
+        }
+        int n;
+        x = sd_reduce_fast(x, &n);
+        const double sgn = ((n & 3) == 1 || (n & 3) == 2) ? -1.0 : 1.0;
+        return sd_sinf_poly(x * sgn, x * x, (n & 2) != 0, n ^ 1);
+    }
+
+    // =============================================================================================
+    // format conversion
+    // =============================================================================================
+    __global__ __launch_bounds__(256) void k_convert(const void *in, int fmt, int iq_swap, long long n, cf32 *out)
+    {
+        const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+        if (i >= n)
+            return;
+        float re, im;
+        if (fmt == 0)
+        {
+            const cf32 v = ((const cf32 *)in)[i];
+            re = v.re;
+            im = v.im;
+        }
+        else if (fmt == 1)
+        { // volk_16i_s32f_convert_32f(.., 32767): x * (1.0f / 32767)
+            const short2 v = ((const short2 *)in)[i];
+            const float s = 1.0f / 32767.0f;
+            re = (float)v.x * s;
+            im = (float)v.y * s;
+        }
+        else if (fmt == 2)
+        {
+            const char2 v = ((const char2 *)in)[i];
+            const float s = 1.0f / 127.0f;
+            re = (float)v.x * s;
+            im = (float)v.y * s;
+        }
+        else
+        { // cu8: (x - 127.4f) / 128.0f (baseband_interface.h:191-199)
+            const uchar2 v = ((const uchar2 *)in)[i];
+            re = ((float)v.x - 127.4f) / 128.0f;
+            im = ((float)v.y - 127.4f) / 128.0f;
+        }
+        if (iq_swap)
+        {
+            const float t = re;
+            re = im;
+            im = t;
+        }
+        out[i].re = re;
+        out[i].im = im;
+    }
+    void launch_convert(const void *in, int fmt, int iq_swap, long long n, cf32 *out, hipStream_t st)
+    {
+        if (n <= 0)
+            return;
+        hipLaunchKernelGGL(k_convert, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, in, fmt, iq_swap, n, out);
+    }
+
+    // =============================================================================================
+    // DC block (sequential; the option is off in every shipped PSK pipeline of BASELINE.json)
+    // =============================================================================================
+    __global__ void k_dcblock_seq(const cf32 *x, cf32 *y, long long n, DcState *state)
+    {
+        if (threadIdx.x != 0 || blockIdx.x != 0)
+            return;
+        const float alpha = 0.0001f, beta = 1.0f - 0.0001f;
+        float ar = state->acc_re, ai = state->acc_im;
+        for (long long i = 0; i < n; i++)
+        {
+            const float xr = x[i].re, xi = x[i].im;
+            ar = ar * beta + xr * alpha;
+            ai = ai * beta + xi * alpha;
+            y[i].re = xr - ar;
+            y[i].im = xi - ai;
+        }
+        state->acc_re = ar;
+        state->acc_im = ai;
+    }
+    void launch_dcblock_seq(const cf32 *x, cf32 *y, long long n, DcState *state, hipStream_t st)
+    {
+        hipLaunchKernelGGL(k_dcblock_seq, dim3(1), dim3(64), 0, st, x, y, n, state);
+    }
+
+    // =============================================================================================
+    // rational resampler: output m uses inputs [inc-(nt-1), inc] with phase ctr (sequential-order dot product)
+    // =============================================================================================
+    __global__ __launch_bounds__(256) void k_resample(const cf32 *x, ResampParams p, int ctr0, int inc0, cf32 *y, long long nout)
+    {
+        const long long m = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+        if (m >= nout)
+            return;
+        const long long ph = (long long)ctr0 + m * p.decim;
+        const long long inc = inc0 + ph / p.interp;
+        const int ctr = (int)(ph % p.interp);
+        const float *t = p.bank + (size_t)ctr * p.ntaps;
+        const cf32 *b = x + inc - (p.ntaps - 1);
+        float re = 0.0f, im = 0.0f;
+        for (int k = 0; k < p.ntaps; k++)
+        {
+            const cf32 v = b[k];
+            const float tk = t[k];
+            re = re + v.re * tk;
+            im = im + v.im * tk;
+        }
+        y[m].re = re;
+        y[m].im = im;
+    }
+    void launch_resample(const cf32 *x, long long nin, const ResampParams &p, int ctr0, int inc0, cf32 *y, long long nout, hipStream_t st)
+    {
+        (void)nin;
+        if (nout <= 0)
+            return;
+        hipLaunchKernelGGL(k_resample, dim3((unsigned)((nout + 255) / 256)), dim3(256), 0, st, x, p, ctr0, inc0, y, nout);
+    }
+
+    // =============================================================================================
+    // FIR: y[i] = sum_j x[i-(nt-1)+j] * rtaps[j], accumulated oldest sample first (volk generic order)
+    // =============================================================================================
+    constexpr int FIR_MAX_TAPS = 384;
+    __global__ __launch_bounds__(256) void k_fir(const cf32 *x, cf32 *y, long long n, const float *rtaps, int ntaps)
+    {
+        __shared__ float taps[FIR_MAX_TAPS];
+        for (int i = (int)threadIdx.x; i < ntaps; i += (int)blockDim.x)
+            taps[i] = rtaps[i];
+        __syncthreads();
+        const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+        if (i >= n)
+            return;
+        const cf32 *b = x + i - (ntaps - 1);
+        float re = 0.0f, im = 0.0f;
+        for (int j = 0; j < ntaps; j++)
+        {
+            const cf32 v = b[j];
+            const float t = taps[j];
+            re = re + v.re * t;
+            im = im + v.im * t;
+        }
+        y[i].re = re;
+        y[i].im = im;
+    }
+    void launch_fir(const cf32 *x, cf32 *y, long long n, const float *rtaps_dev, int ntaps, hipStream_t st)
+    {
+        if (n <= 0)
+            return;
+        hipLaunchKernelGGL(k_fir, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, y, n, rtaps_dev, ntaps);
+    }
+
+    // =============================================================================================
+    // chunk-speculative driver
+    // =============================================================================================
+    // Stage concept:  State init(P);  void step(State&, P, x, y, i, bool write)
+    struct AgcStage
+    {
+        using P = AgcParams;
+        using S = AgcState;
+        __device__ static __forceinline__ S init(const P &p) { return S{p.init_gain}; }
+        __device__ static __forceinline__ void step(S &s, const P &p, const cf32 *x, cf32 *y, long long i, bool write)
+        {
+            // AGCBlock<complex_t>::work, agc.cpp:25-39
+            const cf32 v = x[i];
+            const float ore = v.re * s.gain;
+            const float oim = v.im * s.gain;
+            const float mag = sqrtf(ore * ore + oim * oim) /* correctly rounded (default -fhip-fp32-correctly-rounded-divide-sqrt); __fsqrt_rn is the native approximation */;
+            s.gain = s.gain + p.rate * (p.reference - mag);
+            if (p.max_gain > 0.0f && s.gain > p.max_gain)
+                s.gain = p.max_gain;
+            if (write)
+            {
+                y[i].re = ore;
+                y[i].im = oim;
+            }
+        }
+    };
+
+    struct CostasStage
+    {
+        using P = CostasParams;
+        using S = CostasState;
+        __device__ static __forceinline__ S init(const P &p) { return S{0.0f, p.init_freq}; }
+        __device__ static __forceinline__ void step(S &s, const P &p, const cf32 *x, cf32 *y, long long i, bool write)
+        {
+            // CostasLoopBlock::work, costas_loop.cpp:23-65
+            const cf32 v = x[i];
+            const float cs = sd_cosf(-s.phase), sn = sd_sinf(-s.phase);
+            const float tr = (v.re * cs) - (v.im * sn);
+            const float ti = (v.im * cs) + (v.re * sn);
+            if (write)
+            {
+                y[i].re = tr;
+                y[i].im = ti;
+            }
+            float error;
+            if (p.order == 2)
+                error = tr * ti;
+            else if (p.order == 4)
+                error = (tr > 0.0f ? 1.0f : -1.0f) * ti - (ti > 0.0f ? 1.0f : -1.0f) * tr;
+            else
+            {
+                const float K = sqrtf(2.0f) - 1.0f; // (sqrtf(2.0) - 1)
+                if (fabsf(tr) >= fabsf(ti))
+                    error = ((tr > 0.0f ? 1.0f : -1.0f) * ti - (ti > 0.0f ? 1.0f : -1.0f) * tr * K);
+                else
+                    error = ((tr > 0.0f ? 1.0f : -1.0f) * ti * K - (ti > 0.0f ? 1.0f : -1.0f) * tr);
+            }
+            error = 0.5f * (fabsf(error + 1.0f) - fabsf(error - 1.0f)); // branchless_clip(error, 1.0), block.cpp:5
+            s.freq = s.freq + p.beta * error;
+            s.phase = s.phase + (s.freq + p.alpha * error);
+            const double twopi = 2 * 3.14159265358979323846;
+            while ((double)s.phase > twopi)
+                s.phase = (float)((double)s.phase - twopi);
+            while ((double)s.phase < -twopi)
+                s.phase = (float)((double)s.phase + twopi);
+            if (s.freq > p.fmax)
+                s.freq = p.fmax;
+            if (s.freq < p.fmin)
+                s.freq = p.fmin;
+        }
+    };
+
+    template <class Stage>
+    __global__ __launch_bounds__(64) void k_chunks(const cf32 *x, cf32 *y, ChunkGeom g, typename Stage::P p, const typename Stage::S *start0,
+                                                   typename Stage::S *spec, typename Stage::S *endst, const int *redo, int nredo)
+    {
+        const int idx = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+        int k;
+        typename Stage::S s;
+        if (redo)
+        {
+            if (idx >= nredo)
+                return;
+            k = redo[idx];
+            s = endst[k - 1]; // exact state at the chunk boundary
+        }
+        else
+        {
+            k = idx;
+            if (k >= g.K)
+                return;
+            if (k == 0)
+                s = *start0;
+            else
+            {
+                s = Stage::init(p);
+                const long long b = chunk_begin(g, k);
+                for (long long i = b - g.W; i < b; i++)
+                    Stage::step(s, p, x, y, i, false);
+                spec[k] = s;
+            }
+        }
+        const long long b = chunk_begin(g, k), e = chunk_end(g, k);
+        for (long long i = b; i < e; i++)
+            Stage::step(s, p, x, y, i, true);
+        endst[k] = s;
+    }
+
+    void launch_agc(const cf32 *x, cf32 *y, const ChunkGeom &g, const AgcParams &p, const AgcState *start0, AgcState *spec, AgcState *endst, const int *redo,
+                    int nredo, hipStream_t st)
+    {
+        const int n = redo ? nredo : g.K;
+        if (n <= 0)
+            return;
+        hipLaunchKernelGGL(k_chunks<AgcStage>, dim3((n + 63) / 64), dim3(64), 0, st, x, y, g, p, start0, spec, endst, redo, nredo);
+    }
+    void launch_costas(const cf32 *x, cf32 *y, const ChunkGeom &g, const CostasParams &p, const CostasState *start0, CostasState *spec, CostasState *endst,
+                       const int *redo, int nredo, hipStream_t st)
+    {
+        const int n = redo ? nredo : g.K;
+        if (n <= 0)
+            return;
+        hipLaunchKernelGGL(k_chunks<CostasStage>, dim3((n + 63) / 64), dim3(64), 0, st, x, y, g, p, start0, spec, endst, redo, nredo);
+    }
+
+    // =============================================================================================
+    // M&M clock recovery. Input = Costas output de-rotated per Costas chunk (+ OQPSK half-symbol delay).
+    // =============================================================================================
+    __device__ __forceinline__ cf32 rot_apply(cf32 v, int q, int order)
+    {
+        // multiply by exp(+j*q*unit): unit = pi/2 (order 4), pi (order 2), pi/4 (order 8)
+        if (order == 2)
+        {
+            if (q & 1)
+            {
+                v.re = -v.re;
+                v.im = -v.im;
+            }
+            return v;
+        }
+        int quarter = q, eighth = 0;
+        if (order == 8)
+        {
+            quarter = q >> 1;
+            eighth = q & 1;
+        }
+        switch (quarter & 3)
+        {
+        case 1:
+        {
+            const float t = v.re;
+            v.re = -v.im;
+            v.im = t;
+            break;
+        }
+        case 2:
+            v.re = -v.re;
+            v.im = -v.im;
+            break;
+        case 3:
+        {
+            const float t = v.re;
+            v.re = v.im;
+            v.im = -t;
+            break;
+        }
+        default:
+            break;
+        }
+        if (eighth)
+        {
+            const float c = 0.70710678118654752f;
+            const float r = (v.re - v.im) * c, i2 = (v.re + v.im) * c;
+            v.re = r;
+            v.im = i2;
+        }
+        return v;
+    }
+    __device__ __forceinline__ int costas_chunk_of(const ChunkGeom &g, long long i)
+    {
+        if (i < (long long)g.L + g.W)
+            return 0;
+        long long k = (i - g.W) / g.L;
+        if (k >= g.K)
+            k = g.K - 1;
+        return (int)k;
+    }
+    __device__ __forceinline__ cf32 mm_read(const cf32 *x, const MmParams &p, long long i)
+    {
+        // samples at negative indices are the carried history, already rotated by the previous call
+        cf32 v = x[i];
+        if (i >= 0 && p.rot)
+            v = rot_apply(v, p.rot[costas_chunk_of(p.cg, i)], p.order);
+        if (p.oqpsk)
+        {
+            cf32 w = x[i - 1];
+            if (i - 1 >= 0 && p.rot)
+                w = rot_apply(w, p.rot[costas_chunk_of(p.cg, i - 1)], p.order);
+            v.im = w.im;
+        }
+        return v;
+    }
+
+    // one iteration of MMClockRecoveryBlock<complex_t>::work's loop body, clock_recovery_mm.cpp:54-120
+    __device__ __forceinline__ cf32 mm_iter(MmState &s, const MmParams &p, const cf32 *x)
+    {
+        s.p_2T = s.p_1T;
+        s.p_1T = s.p_0T;
+        s.c_2T = s.c_1T;
+        s.c_1T = s.c_0T;
+        int imu = (int)rintf(s.mu * 128.0f);
+        if (imu < 0)
+            imu = 0;
+        if (imu >= 128)
+            imu = 127;
+        const float *t = p.bank + imu * 8;
+        float re = 0.0f, im = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+        {
+            const cf32 v = mm_read(x, p, s.inc - 7 + k);
+            re = re + v.re * t[k];
+            im = im + v.im * t[k];
+        }
+        s.p_0T.re = re;
+        s.p_0T.im = im;
+        s.c_0T.re = re > 0.0f ? 1.0f : 0.0f;
+        s.c_0T.im = im > 0.0f ? 1.0f : 0.0f;
+        const float ur = s.p_0T.re - s.p_2T.re, ui = s.p_0T.im - s.p_2T.im;
+        const float a_re = (ur * s.c_1T.re) - (ui * (-s.c_1T.im));
+        const float vr = s.c_0T.re - s.c_2T.re, vi = s.c_0T.im - s.c_2T.im;
+        const float b_re = (vr * s.p_1T.re) - (vi * (-s.p_1T.im));
+        float pe = a_re - b_re;
+        pe = pe < -1.0f ? -1.0f : (pe > 1.0f ? 1.0f : pe); // branched_clip(phase_error, 1.0)
+        const cf32 out = s.p_0T;
+        s.omega = s.omega + p.omega_gain * pe;
+        float d = s.omega - p.omega_mid;
+        d = d < -p.omega_limit ? -p.omega_limit : (d > p.omega_limit ? p.omega_limit : d);
+        s.omega = p.omega_mid + d;
+        s.mu = (s.mu + s.omega) + p.mu_gain * pe;
+        const float fl = floorf(s.mu);
+        s.inc += (long long)(int)fl;
+        s.mu = s.mu - fl;
+        if (s.inc < 0)
+            s.inc = 0;
+        return out;
+    }
+
+    __global__ __launch_bounds__(64) void k_mm(const cf32 *x, cf32 *sym, int *counts, ChunkGeom g, MmParams p, const MmState *start0, MmState *spec,
+                                               MmState *endst, const int *redo, int nredo)
+    {
+        const int idx = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+        int k;
+        MmState s;
+        if (redo)
+        {
+            if (idx >= nredo)
+                return;
+            k = redo[idx];
+            s = endst[k - 1];
+        }
+        else
+        {
+            k = idx;
+            if (k >= g.K)
+                return;
+            if (k == 0)
+                s = *start0;
+            else
+            {
+                const long long b = chunk_begin(g, k);
+                s.mu = p.init_mu;
+                s.omega = p.omega_mid;
+                s.p_2T = s.p_1T = s.p_0T = cf32{0.0f, 0.0f};
+                s.c_2T = s.c_1T = s.c_0T = cf32{0.0f, 0.0f};
+                s.inc = b - g.W;
+                while (s.inc < b)
+                    (void)mm_iter(s, p, x);
+                spec[k] = s;
+            }
+        }
+        const long long e = chunk_end(g, k);
+        cf32 *o = sym + (size_t)k * p.cap;
+        int cnt = 0;
+        while (s.inc < e)
+        {
+            const cf32 v = mm_iter(s, p, x);
+            if (cnt < p.cap)
+                o[cnt] = v;
+            cnt++;
+        }
+        counts[k] = cnt;
+        endst[k] = s;
+    }
+    void launch_mm(const cf32 *x, cf32 *sym_scratch, int *counts, const ChunkGeom &g, const MmParams &p, const MmState *start0, MmState *spec, MmState *endst,
+                   const int *redo, int nredo, hipStream_t st)
+    {
+        const int n = redo ? nredo : g.K;
+        if (n <= 0)
+            return;
+        hipLaunchKernelGGL(k_mm, dim3((n + 63) / 64), dim3(64), 0, st, x, sym_scratch, counts, g, p, start0, spec, endst, redo, nredo);
+    }
+
+    // quantiser, module_psk_demod.cpp:199-213 + clamp module_demod_base.h:106-113
+    __device__ __forceinline__ signed char sd_clamp8(float x)
+    {
+        if (x < -128.0f)
+            return -127;
+        if (x > 127.0f)
+            return 127;
+        return (signed char)(int)x;
+    }
+    __global__ __launch_bounds__(256) void k_quantize(const cf32 *sym, const int *counts, const long long *offsets, int K, int cap, int bpsk, int8_t *soft,
+                                                      long long soft_cap, float *syms, long long syms_cap)
+    {
+        const int k = (int)blockIdx.x;
+        if (k >= K)
+            return;
+        const int cnt = counts[k];
+        const long long off = offsets[k];
+        const cf32 *s = sym + (size_t)k * cap;
+        for (int j = (int)threadIdx.x; j < cnt; j += (int)blockDim.x)
+        {
+            const cf32 v = s[j];
+            const long long o = off + j;
+            if (syms && o < syms_cap)
+            {
+                syms[2 * o] = v.re;
+                syms[2 * o + 1] = v.im;
+            }
+            if (bpsk)
+            {
+                if (o < soft_cap)
+                    soft[o] = sd_clamp8(v.re * 50.0f);
+            }
+            else if (2 * o + 1 < soft_cap)
+            {
+                soft[2 * o] = sd_clamp8(v.re * 100.0f);
+                soft[2 * o + 1] = sd_clamp8(v.im * 100.0f);
+            }
+        }
+    }
+    void launch_quantize(const cf32 *sym_scratch, const int *counts, const long long *offsets, int K, int cap, int bpsk, int8_t *soft, long long soft_cap,
+                         float *syms, long long syms_cap, hipStream_t st)
+    {
+        if (K <= 0)
+            return;
+        hipLaunchKernelGGL(k_quantize, dim3(K), dim3(256), 0, st, sym_scratch, counts, offsets, K, cap, bpsk, soft, soft_cap, syms, syms_cap);
+    }
+
+    __global__ void k_tail_copy(const cf32 *x, long long n, int cnt, ChunkGeom cg, const int *rot, int order, cf32 *out)
+    {
+        const int j = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+        if (j >= cnt)
+            return;
+        const long long i = n - cnt + j; // may be negative: older history
+        cf32 v = x[i];
+        if (i >= 0 && rot)
+            v = rot_apply(v, rot[costas_chunk_of(cg, i)], order);
+        out[j] = v;
+    }
+    void launch_tail_copy(const cf32 *x, long long n, int cnt, const ChunkGeom &cg, const int *rot, int order, cf32 *out, hipStream_t st)
+    {
+        hipLaunchKernelGGL(k_tail_copy, dim3((cnt + 63) / 64), dim3(64), 0, st, x, n, cnt, cg, rot, order, out);
+    }
+} // namespace sdhip
