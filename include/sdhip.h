@@ -184,6 +184,14 @@ extern "C"
        4 rational resampler(interp,decim) rational_resampler.cpp:43-64. Returns output sample count. */
     int64_t sdhip_op_block(int device, int kind, const float *params, const float *d_in, size_t n, float *d_out, size_t out_cap);
 
+    /* ---- measurement ------------------------------------------------------------------ */
+    /* Per-kernel timing with HIP events recorded on the launch stream around every kernel launch of the
+       library (process-wide; off by default). sdhip_prof_get(idx, ...) returns the number of distinct kernels
+       seen and, for 0 <= idx < that number, the kernel's name, total milliseconds and launch count. */
+    void sdhip_prof_enable(int on);
+    void sdhip_prof_reset(void);
+    int sdhip_prof_get(int idx, char *name, size_t name_cap, double *total_ms, long long *launches);
+
     /* ---- misc ------------------------------------------------------------------------ */
     const char *sdhip_last_error(void);
     const char *sdhip_version(void);

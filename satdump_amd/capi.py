@@ -99,8 +99,31 @@ def lib():
             L.sdhip_demod_get_stats.argtypes = [C.c_void_p, C.POINTER(DemodStats)]
             L.sdhip_op_block.restype = C.c_int64
             L.sdhip_op_block.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+        L.sdhip_prof_enable.argtypes = [C.c_int]
+        L.sdhip_prof_get.argtypes = [C.c_int, C.c_char_p, C.c_size_t, C.POINTER(C.c_double), C.POINTER(C.c_longlong)]
         _lib = L
     return _lib
+
+
+def prof_enable(on: bool = True):
+    lib().sdhip_prof_enable(int(on))
+
+
+def prof_reset():
+    lib().sdhip_prof_reset()
+
+
+def prof_get() -> dict:
+    """{kernel name: (total ms, launches)} measured with HIP events on the launch stream (sdhip_prof_get)."""
+    L = lib()
+    n = L.sdhip_prof_get(-1, None, 0, None, None)
+    out = {}
+    for i in range(n):
+        buf = C.create_string_buffer(128)
+        ms, cnt = C.c_double(0), C.c_longlong(0)
+        L.sdhip_prof_get(i, buf, 128, C.byref(ms), C.byref(cnt))
+        out[buf.value.decode()] = (ms.value, cnt.value)
+    return out
 
 
 def last_error() -> str:

@@ -25,6 +25,16 @@ namespace sdhip
                                   std::to_string(__LINE__));                                                          \
     } while (0)
 
+    // Optional per-kernel timing (HIP events recorded on the launch stream, around every launch). Off by default;
+    // bench.py turns it on through sdhip_prof_enable() to get the roofline figures of the dominant kernel.
+    struct ProfScope
+    {
+        int idx;
+        hipStream_t st;
+        ProfScope(const char *name, hipStream_t stream);
+        ~ProfScope();
+    };
+
     // Simple owning device buffer (grow-only).
     template <class T>
     struct DevBuf

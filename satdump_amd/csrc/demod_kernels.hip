@@ -128,6 +128,7 @@ namespace sdhip
     {
         if (n <= 0)
             return;
+        ProfScope _ps("k_convert", st);
         hipLaunchKernelGGL(k_convert, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, in, fmt, iq_swap, n, out);
     }
 
@@ -153,6 +154,7 @@ namespace sdhip
     }
     void launch_dcblock_seq(const cf32 *x, cf32 *y, long long n, DcState *state, hipStream_t st)
     {
+        ProfScope _ps("k_dcblock_seq", st);
         hipLaunchKernelGGL(k_dcblock_seq, dim3(1), dim3(64), 0, st, x, y, n, state);
     }
 
@@ -185,6 +187,7 @@ namespace sdhip
         (void)nin;
         if (nout <= 0)
             return;
+        ProfScope _ps("k_resample", st);
         hipLaunchKernelGGL(k_resample, dim3((unsigned)((nout + 255) / 256)), dim3(256), 0, st, x, p, ctr0, inc0, y, nout);
     }
 
@@ -217,6 +220,7 @@ namespace sdhip
     {
         if (n <= 0)
             return;
+        ProfScope _ps("k_fir", st);
         hipLaunchKernelGGL(k_fir, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, y, n, rtaps_dev, ntaps);
     }
 
@@ -334,6 +338,7 @@ namespace sdhip
         const int n = redo ? nredo : g.K;
         if (n <= 0)
             return;
+        ProfScope _ps("k_chunks<AgcStage>", st);
         hipLaunchKernelGGL(k_chunks<AgcStage>, dim3((n + 63) / 64), dim3(64), 0, st, x, y, g, p, start0, spec, endst, redo, nredo);
     }
     void launch_costas(const cf32 *x, cf32 *y, const ChunkGeom &g, const CostasParams &p, const CostasState *start0, CostasState *spec, CostasState *endst,
@@ -342,6 +347,7 @@ namespace sdhip
         const int n = redo ? nredo : g.K;
         if (n <= 0)
             return;
+        ProfScope _ps("k_chunks<CostasStage>", st);
         hipLaunchKernelGGL(k_chunks<CostasStage>, dim3((n + 63) / 64), dim3(64), 0, st, x, y, g, p, start0, spec, endst, redo, nredo);
     }
 
@@ -511,8 +517,24 @@ namespace sdhip
                 o[cnt] = v;
             cnt++;
         }
-        counts[k] = cnt;
+        counts[2 * k] = cnt;
         endst[k] = s;
+        // Up to two symbols past the chunk end, from a COPY of the state: if the next chunk's own trajectory starts one
+        // symbol later than this one ends (timing within tolerance, boundary sample index on the other side of the
+        // mu wrap), the host hands these to the stream instead of re-running anything. Not part of the end state.
+        int nx = 0;
+        if (k + 1 < g.K)
+        {
+            MmState t = s;
+            for (int j = 0; j < 2 && t.inc < g.n; j++)
+            {
+                const cf32 v = mm_iter(t, p, x);
+                if (cnt + j < p.cap)
+                    o[cnt + j] = v;
+                nx++;
+            }
+        }
+        counts[2 * k + 1] = nx;
     }
     void launch_mm(const cf32 *x, cf32 *sym_scratch, int *counts, const ChunkGeom &g, const MmParams &p, const MmState *start0, MmState *spec, MmState *endst,
                    const int *redo, int nredo, hipStream_t st)
@@ -520,6 +542,7 @@ namespace sdhip
         const int n = redo ? nredo : g.K;
         if (n <= 0)
             return;
+        ProfScope _ps("k_mm", st);
         hipLaunchKernelGGL(k_mm, dim3((n + 63) / 64), dim3(64), 0, st, x, sym_scratch, counts, g, p, start0, spec, endst, redo, nredo);
     }
 
@@ -532,15 +555,15 @@ namespace sdhip
             return 127;
         return (signed char)(int)x;
     }
-    __global__ __launch_bounds__(256) void k_quantize(const cf32 *sym, const int *counts, const long long *offsets, int K, int cap, int bpsk, int8_t *soft,
+    __global__ __launch_bounds__(256) void k_quantize(const cf32 *sym, const int *seg, const long long *offsets, int K, int cap, int bpsk, int8_t *soft,
                                                       long long soft_cap, float *syms, long long syms_cap)
     {
         const int k = (int)blockIdx.x;
         if (k >= K)
             return;
-        const int cnt = counts[k];
+        const int cnt = seg[2 * k + 1];
         const long long off = offsets[k];
-        const cf32 *s = sym + (size_t)k * cap;
+        const cf32 *s = sym + (size_t)k * cap + seg[2 * k];
         for (int j = (int)threadIdx.x; j < cnt; j += (int)blockDim.x)
         {
             const cf32 v = s[j];
@@ -562,12 +585,13 @@ namespace sdhip
             }
         }
     }
-    void launch_quantize(const cf32 *sym_scratch, const int *counts, const long long *offsets, int K, int cap, int bpsk, int8_t *soft, long long soft_cap,
+    void launch_quantize(const cf32 *sym_scratch, const int *seg, const long long *offsets, int K, int cap, int bpsk, int8_t *soft, long long soft_cap,
                          float *syms, long long syms_cap, hipStream_t st)
     {
         if (K <= 0)
             return;
-        hipLaunchKernelGGL(k_quantize, dim3(K), dim3(256), 0, st, sym_scratch, counts, offsets, K, cap, bpsk, soft, soft_cap, syms, syms_cap);
+        ProfScope _ps("k_quantize", st);
+        hipLaunchKernelGGL(k_quantize, dim3(K), dim3(256), 0, st, sym_scratch, seg, offsets, K, cap, bpsk, soft, soft_cap, syms, syms_cap);
     }
 
     __global__ void k_tail_copy(const cf32 *x, long long n, int cnt, ChunkGeom cg, const int *rot, int order, cf32 *out)
@@ -583,6 +607,7 @@ namespace sdhip
     }
     void launch_tail_copy(const cf32 *x, long long n, int cnt, const ChunkGeom &cg, const int *rot, int order, cf32 *out, hipStream_t st)
     {
+        ProfScope _ps("k_tail_copy", st);
         hipLaunchKernelGGL(k_tail_copy, dim3((cnt + 63) / 64), dim3(64), 0, st, x, n, cnt, cg, rot, order, out);
     }
 } // namespace sdhip

@@ -11,6 +11,7 @@
 #include "../../include/sdhip.h"
 #include <algorithm>
 #include <cmath>
+#include <map>
 #include <mutex>
 #include <vector>
 
@@ -18,6 +19,64 @@ namespace sdhip
 {
     static thread_local std::string g_last_error;
     void set_error(const std::string &msg) { g_last_error = msg; }
+
+    // ---- per-kernel event timing (process-wide, off by default) ----------------------------------------
+    struct ProfRec
+    {
+        const char *name;
+        hipEvent_t a, b;
+    };
+    static std::mutex g_prof_mu;
+    static bool g_prof_on = false;
+    static std::vector<ProfRec> g_prof_pending;
+    static std::vector<hipEvent_t> g_prof_pool;
+    static std::map<std::string, std::pair<double, long long>> g_prof_acc;
+    static hipEvent_t prof_event()
+    {
+        if (!g_prof_pool.empty())
+        {
+            hipEvent_t e = g_prof_pool.back();
+            g_prof_pool.pop_back();
+            return e;
+        }
+        hipEvent_t e;
+        SD_HIP(hipEventCreate(&e));
+        return e;
+    }
+    ProfScope::ProfScope(const char *name, hipStream_t stream) : idx(-1), st(stream)
+    {
+        if (!g_prof_on)
+            return;
+        std::lock_guard<std::mutex> lk(g_prof_mu);
+        ProfRec r{name, prof_event(), prof_event()};
+        (void)hipEventRecord(r.a, st);
+        idx = (int)g_prof_pending.size();
+        g_prof_pending.push_back(r);
+    }
+    ProfScope::~ProfScope()
+    {
+        if (idx < 0)
+            return;
+        std::lock_guard<std::mutex> lk(g_prof_mu);
+        (void)hipEventRecord(g_prof_pending[idx].b, st);
+    }
+    static void prof_collect()
+    {
+        std::lock_guard<std::mutex> lk(g_prof_mu);
+        for (auto &r : g_prof_pending)
+        {
+            float ms = 0;
+            if (hipEventSynchronize(r.b) == hipSuccess && hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess)
+            {
+                auto &e = g_prof_acc[r.name];
+                e.first += ms;
+                e.second += 1;
+            }
+            g_prof_pool.push_back(r.a);
+            g_prof_pool.push_back(r.b);
+        }
+        g_prof_pending.clear();
+    }
 
     __global__ void k_unpack_bits(const unsigned *vbits, int wpb, int F, int nblk, unsigned char *out)
     {
@@ -787,6 +846,34 @@ extern "C"
         if (hipGetDeviceCount(&n) != hipSuccess)
             return 0;
         return n;
+    }
+
+    void sdhip_prof_enable(int on)
+    {
+        prof_collect();
+        g_prof_on = on != 0;
+    }
+    void sdhip_prof_reset(void)
+    {
+        prof_collect();
+        std::lock_guard<std::mutex> lk(g_prof_mu);
+        g_prof_acc.clear();
+    }
+    int sdhip_prof_get(int idx, char *name, size_t name_cap, double *total_ms, long long *launches)
+    {
+        prof_collect();
+        std::lock_guard<std::mutex> lk(g_prof_mu);
+        if (idx >= 0 && idx < (int)g_prof_acc.size() && name && name_cap)
+        {
+            auto it = g_prof_acc.begin();
+            std::advance(it, idx);
+            snprintf(name, name_cap, "%s", it->first.c_str());
+            if (total_ms)
+                *total_ms = it->second.first;
+            if (launches)
+                *launches = it->second.second;
+        }
+        return (int)g_prof_acc.size();
     }
 
     void sdhip_fec_cfg_default(sdhip_fec_cfg *c)

@@ -426,6 +426,7 @@ namespace sdhip
             return;
         const int dstride = (cfg.F + 6 + 63) / 64 * 64;
         const int wpb = vit_words_per_block(cfg.F);
+        ProfScope _ps("k_vit_decode", st);
         hipLaunchKernelGGL(k_vit_decode, dim3((nblk + 3) / 4), dim3(256), 0, st, cfg, soft, (long long)first_block, nblk, io,
                            (unsigned long long *)decisions, vbits, dstride, wpb);
     }
@@ -513,6 +514,7 @@ namespace sdhip
     {
         if (nblk <= 0)
             return;
+        ProfScope _ps("k_vit_ber", st);
         hipLaunchKernelGGL(k_vit_ber, dim3((nblk + 3) / 4), dim3(256), 0, st, cfg, soft, (long long)first_block, nblk, vbits, vit_words_per_block(cfg.F),
                            enc_state_in, io);
     }
@@ -639,6 +641,7 @@ namespace sdhip
         int ph[4] = {0, 0, 0, 0};
         for (int i = 0; i < nphases && i < 4; i++)
             ph[i] = phases[i];
+        ProfScope _ps("k_vit_search", st);
         hipLaunchKernelGGL(k_vit_search, dim3(1), dim3(64), 0, st, cfg, soft, (long long)block, n_swap, ph[0], ph[1], ph[2], ph[3], nphases, d_state);
     }
 
@@ -729,6 +732,7 @@ namespace sdhip
         const int64_t n = (total - from + 31) / 32;
         if (n <= 0)
             return;
+        ProfScope _ps("k_sync_search", st);
         hipLaunchKernelGGL(k_sync_search, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, bs, (long long)from, (long long)total, asm_sync, hits, hits_cap, count);
     }
 
@@ -748,6 +752,7 @@ namespace sdhip
         const int64_t n = (total_bits + 31) / 32;
         if (n <= 0)
             return;
+        ProfScope _ps("k_pack_stream", st);
         hipLaunchKernelGGL(k_pack_stream, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, bs, out_bytes, (long long)total_bits);
     }
 
@@ -1111,6 +1116,7 @@ namespace sdhip
         if (n <= 0)
             return;
         const GfTables *tabs = tables_for_current_device();
+        ProfScope _ps("k_rs", st);
         hipLaunchKernelGGL(k_rs, dim3((unsigned)((n + RS_THREADS - 1) / RS_THREADS)), dim3(RS_THREADS), 0, st, data, nframes, frame_stride, dualbasis, I, nroots,
                            fill_bytes, errors, tabs);
     }
@@ -1162,12 +1168,16 @@ namespace sdhip
         if (nframes <= 0)
             return;
         const GfTables *tabs = tables_for_current_device();
-        hipLaunchKernelGGL(k_extract, dim3(nframes), dim3(256), 0, st, bs, fc, frames, nframes, out, tabs);
+        {
+            ProfScope _ps("k_extract", st);
+            hipLaunchKernelGGL(k_extract, dim3(nframes), dim3(256), 0, st, bs, fc, frames, nframes, out, tabs);
+        }
         if (fc.rs_i != 0)
             launch_rs_only(out + 4, nframes, fc.cadu_bytes, fc.rs_dualbasis, fc.rs_i, fc.rs_nroots, fc.rs_fill_bytes, errors, st);
         if (fc.derand && fc.derand_after_rs)
         {
             const long long n = (long long)nframes * fc.cadu_bytes;
+            ProfScope _ps("k_derand", st);
             hipLaunchKernelGGL(k_derand, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, out, nframes, fc.cadu_bytes, fc.derand_start, tabs);
         }
     }
@@ -1189,6 +1199,7 @@ namespace sdhip
     {
         if (nframes <= 0)
             return;
+        ProfScope _ps("k_compact", st);
         hipLaunchKernelGGL(k_compact, dim3(nframes), dim3(256), 0, st, frames, dst_index, nframes, cadu_bytes, out);
     }
 } // namespace sdhip

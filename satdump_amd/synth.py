@@ -300,3 +300,70 @@ def soft_from_symbols(symbols: np.ndarray, spec: SynthSpec, sigma: float, seed: 
     # module_demod_base.h:106-113 clamp semantics
     out = np.where(v < -128.0, -127, np.where(v > 127.0, 127, np.trunc(v)))
     return out.astype(np.int8)
+
+
+# --------------------------------------------------------------------------- device-side modulator (bench inputs)
+def modulate_torch(symbols: np.ndarray, spec: SynthSpec, device, periodic: bool = True, noise_seed: int | None = None,
+                   chunk: int = 1 << 24):
+    """Same signal model as modulate(), evaluated with torch on `device` so that multi-GB inputs of BASELINE.json's
+    configs can be synthesised directly in HBM (float32 pulse shaping, float64 carrier phase). Returns
+    (torch.complex64 tensor [nout], cfo used). NOT on any timed path."""
+    import torch
+
+    ratio = Fraction(spec.samplerate / spec.symbolrate).limit_denominator(2000)
+    up, down = ratio.numerator, ratio.denominator
+    span = spec.span
+    hu = rrc_impulse(float(up), spec.rrc_alpha, span) * math.sqrt(up)
+    ntap = 2 * span
+    H = np.zeros((up, ntap), dtype=np.float64)
+    c = span * up
+    for j in range(ntap):
+        H[:, j] = hu[c + (j - span) * up + np.arange(up)]
+    nsym = len(symbols)
+    nout = (nsym * up) // down
+    is_real = np.isrealobj(symbols) or not np.any(np.imag(symbols))
+    a = np.asarray(symbols)
+    d_ar = torch.from_numpy(np.ascontiguousarray(a.real, dtype=np.float32)).to(device)
+    d_ai = None if is_real else torch.from_numpy(np.ascontiguousarray(a.imag, dtype=np.float32)).to(device)
+    d_H = torch.from_numpy(H.astype(np.float32)).to(device)
+    cfo = spec.cfo_hz
+    if periodic:
+        cyc = round(cfo * nout / spec.samplerate)
+        cfo = cyc * spec.samplerate / nout
+    w = 2 * math.pi * (cfo / spec.samplerate)
+    sps = up / down
+    sigma = math.sqrt(sps / (2.0 * 10 ** (spec.esn0_db / 10)))
+    gen = torch.Generator(device=device)
+    gen.manual_seed((spec.seed if noise_seed is None else noise_seed) + 7919)
+    out = torch.empty(nout, dtype=torch.complex64, device=device)
+    off = int(round(spec.timing_offset * up))
+    for m0 in range(0, nout, chunk):
+        m1 = min(nout, m0 + chunk)
+        m = torch.arange(m0, m1, dtype=torch.int64, device=device)
+        u = m * down + off
+        p = u % up
+        k0 = torch.div(u, up, rounding_mode="floor")
+        xr = torch.zeros(m1 - m0, dtype=torch.float32, device=device)
+        xi = None if is_real else torch.zeros(m1 - m0, dtype=torch.float32, device=device)
+        for j in range(ntap):
+            k = k0 - (j - span)
+            if periodic:
+                k = k % nsym
+                hj = d_H[p, j]
+            else:
+                valid = (k >= 0) & (k < nsym)
+                k = k.clamp(0, nsym - 1)
+                hj = d_H[p, j] * valid
+            xr += d_ar[k] * hj
+            if xi is not None:
+                xi += d_ai[k] * hj
+        ph = (m.to(torch.float64) * w + spec.phase0)
+        cs, sn = torch.cos(ph).to(torch.float32), torch.sin(ph).to(torch.float32)
+        if xi is None:
+            yr, yi = xr * cs, xr * sn
+        else:
+            yr, yi = xr * cs - xi * sn, xr * sn + xi * cs
+        yr += sigma * torch.randn(m1 - m0, dtype=torch.float32, device=device, generator=gen)
+        yi += sigma * torch.randn(m1 - m0, dtype=torch.float32, device=device, generator=gen)
+        out[m0:m1] = torch.complex(yr * spec.amplitude, yi * spec.amplitude)
+    return out, cfo
