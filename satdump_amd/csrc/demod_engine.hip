@@ -277,15 +277,24 @@ namespace sdhip
             SD_HIP(hipStreamSynchronize(stream));
         }
 
+        static long long env_int(const char *name, long long dflt)
+        { // tuning overrides (experiments only; defaults are what ships)
+            const char *v = getenv(name);
+            return (v && *v) ? atoll(v) : dflt;
+        }
         int pick_L(long long n) const
         {
             if (cfg.exact)
                 return 1 << 30;
+            if (cfg.chunk_len <= 0 && getenv("SDHIP_CHUNK"))
+                return (int)((env_int("SDHIP_CHUNK", 8192) + 7) / 8 * 8);
             if (cfg.chunk_len > 0)
-                return cfg.chunk_len;
-            long long L = (n + 32767) / 32768;
+                return (cfg.chunk_len + 7) / 8 * 8; // stage chunk boundaries stay multiples of 8 samples (64-byte blocks)
+            // one lane per chunk: aim at ~1.5 waves on each of the 1024 SIMDs, but keep chunks long enough that the
+            // warm-up overlap (a few thousand samples) does not dominate the work
+            long long L = (n + 98303) / 98304;
             L = (L + 255) / 256 * 256;
-            return (int)std::min<long long>(std::max<long long>(L, 4096), 1 << 20);
+            return (int)std::min<long long>(std::max<long long>(L, 2048), 1 << 20);
         }
 
         // Certificate chain of one speculative stage. Chunk k stands iff accept(k, state its warm-up reached, state chunk
@@ -337,7 +346,7 @@ namespace sdhip
             if (n_in == 0)
                 return 0;
             long long n = (long long)n_in;
-            const size_t need = (size_t)n + 2 * DEMOD_HIST + 64;
+            const size_t need = (size_t)n + 2 * DEMOD_HIST + 64; // 64 + 64 samples of slack behind the data: the lanes prefetch up to 32 past their range
             bufA.reserve(need);
             bufB.reserve(need);
             cf32 *A = bufA.p + DEMOD_HIST, *B = bufB.p + DEMOD_HIST;
@@ -392,6 +401,7 @@ namespace sdhip
                         g_est = (float)std::min(65536.0, 1.0 / mean);
                 }
                 long long W = cfg.warmup > 0 ? cfg.warmup : (long long)(24.0 * std::max(1.0f, g_est) / std::max(1e-6f, cfg.agc_rate));
+                W = env_int("SDHIP_W_AGC", W);
                 W = std::min<long long>(std::max<long long>(W, 1024), 1 << 22);
                 W = (W + 255) / 256 * 256;
                 agc_p.init_gain = g_est;
@@ -449,7 +459,10 @@ namespace sdhip
                 }
                 else
                     cos_p.init_freq = cos_s.freq;
-                long long W = cfg.warmup > 0 ? cfg.warmup : (long long)std::max(8192.0, 100.0 / std::max(1e-5f, cos_p.alpha));
+                // both loop modes decay like exp(-zeta*wn*t) with zeta*wn ~ 1.414*pll_bw per sample (unit detector gain after
+                // the AGC): 24 time constants from a phase error of up to pi/order bring the warm-up inside the tolerance
+                long long W = cfg.warmup > 0 ? cfg.warmup : (long long)std::max(512.0, 24.0 / (1.414 * std::max(1e-5f, cfg.pll_bw)));
+                W = env_int("SDHIP_W_COSTAS", W);
                 W = (std::min<long long>(W, 1 << 22) + 255) / 256 * 256;
                 cg = make_geom(n, L, (int)W);
                 stats.chunks += cg.K;
@@ -506,7 +519,10 @@ namespace sdhip
                 d_rot.reserve(cg.K);
                 SD_HIP(hipMemcpyAsync(d_rot.p, rot.data(), (size_t)cg.K * sizeof(int), hipMemcpyHostToDevice, stream));
                 put_hist(A, hist_cos);
-                long long W = cfg.warmup > 0 ? cfg.warmup : 12288;
+                // timing loop: ~2/(Kd*gain_mu) symbols per time constant with a detector gain Kd well below 1 at low Es/N0
+                // (measured: ~700 symbols at 7 dB BPSK with the default gains)
+                long long W = cfg.warmup > 0 ? cfg.warmup : (long long)(36.0 / std::max(1e-4f, cfg.clock_gain_mu) * final_sps);
+                W = env_int("SDHIP_W_MM", W);
                 W = (W + 255) / 256 * 256;
                 const ChunkGeom g = make_geom(n, L, (int)W);
                 stats.chunks += g.K;
@@ -530,7 +546,8 @@ namespace sdhip
                 // k-1 ended with. Equal within MM_TOL samples: chunk k stands. Exactly one or two symbol periods apart (the
                 // boundary fell between the two trajectories' sample indices, mu wrapping on opposite sides): the symbol(s) are
                 // taken from chunk k-1's look-ahead, or skipped at the head of chunk k. Anything else: re-run from the exact state.
-                const double MM_TOL = 0.02;
+                const double MM_TOL = env_int("SDHIP_MM_TOL_MILLI", 50) * 1e-3;
+                int dbg_left = getenv("SDHIP_DEBUG") ? 8 : 0;
                 std::vector<int> skip(g.K, 0), extra(g.K, 0), counts(2 * (size_t)g.K);
                 bool counts_fresh = false;
                 auto fetch_counts = [&]() {
@@ -569,6 +586,12 @@ namespace sdhip
                                 round_inexact++;
                                 return true;
                             }
+                        }
+                        if (dbg_left > 0)
+                        {
+                            dbg_left--;
+                            fprintf(stderr, "[sdhip] mm boundary %d rejected: dt %.5f samples = %lld symbols %+.5f, omega %.6f vs %.6f, look-ahead %d\n", k, d, r,
+                                    d - (double)r * om, a.omega, b.omega, counts[2 * (k - 1) + 1]);
                         }
                         return false;
                     },
@@ -729,7 +752,7 @@ extern "C"
         SD_HIP(hipSetDevice(device));
         const long long nn = (long long)n;
         DevBuf<cf32> in;
-        in.reserve(n + 2 * DEMOD_HIST);
+        in.reserve(n + 2 * DEMOD_HIST + 64);
         SD_HIP(hipMemset(in.p, 0, DEMOD_HIST * sizeof(cf32)));
         cf32 *X = in.p + DEMOD_HIST;
         SD_HIP(hipMemcpy(X, d_in, n * sizeof(cf32), hipMemcpyDeviceToDevice));

@@ -161,7 +161,66 @@ namespace sdhip
     // =============================================================================================
     // rational resampler: output m uses inputs [inc-(nt-1), inc] with phase ctr (sequential-order dot product)
     // =============================================================================================
-    __global__ __launch_bounds__(256) void k_resample(const cf32 *x, ResampParams p, int ctr0, int inc0, cf32 *y, long long nout)
+    typedef float v2f __attribute__((ext_vector_type(2))); // (re, im) pair: mul / add map to v_pk_mul_f32 / v_pk_add_f32
+
+    constexpr int RS_BLOCK = 256, RS_PER = 4;        // outputs per block = RS_BLOCK * RS_PER (thread t: m0 + t + RS_BLOCK*r)
+    constexpr int RS_MAX_BANK = 4096;                // floats of polyphase bank kept in LDS
+    constexpr int RS_MAX_TILE = 2560;                // input samples staged per block
+    // Block = 1024 consecutive outputs. Their input span (~1024*decim/interp + ntaps samples) and the whole polyphase bank
+    // are staged in LDS with coalesced loads; every thread then accumulates 4 independent outputs tap by tap, oldest
+    // sample first, mul and add rounded separately exactly like the scalar reference loop (rational_resampler.cpp:49-56 ->
+    // volk generic dot product).
+    __global__ __launch_bounds__(RS_BLOCK) void k_resample(const cf32 *x, ResampParams p, int ctr0, int inc0, cf32 *y, long long nout)
+    {
+        __shared__ float bank[RS_MAX_BANK];
+        __shared__ v2f tile[RS_MAX_TILE];
+        const long long m0 = (long long)blockIdx.x * (RS_BLOCK * RS_PER);
+        const int nb = p.interp * p.ntaps;
+        for (int i = (int)threadIdx.x; i < nb; i += RS_BLOCK)
+            bank[i] = p.bank[i];
+        long long mlast = m0 + RS_BLOCK * RS_PER - 1;
+        if (mlast >= nout)
+            mlast = nout - 1;
+        const long long first = inc0 + ((long long)ctr0 + m0 * p.decim) / p.interp - (p.ntaps - 1);
+        const long long last = inc0 + ((long long)ctr0 + mlast * p.decim) / p.interp;
+        const int span = (int)(last - first + 1);
+        const v2f *xs = reinterpret_cast<const v2f *>(x) + first;
+        for (int i = (int)threadIdx.x; i < span; i += RS_BLOCK)
+            tile[i] = xs[i];
+        __syncthreads();
+        v2f acc[RS_PER];
+        int off[RS_PER], row[RS_PER];
+#pragma unroll
+        for (int r = 0; r < RS_PER; r++)
+        {
+            long long m = m0 + (int)threadIdx.x + RS_BLOCK * r;
+            if (m >= nout)
+                m = nout - 1; // clamp: computed, not stored
+            const long long ph = (long long)ctr0 + m * p.decim;
+            off[r] = (int)(inc0 + ph / p.interp - (p.ntaps - 1) - first);
+            row[r] = (int)(ph % p.interp) * p.ntaps;
+            acc[r] = v2f{0.0f, 0.0f};
+        }
+        for (int k = 0; k < p.ntaps; k++)
+        {
+#pragma unroll
+            for (int r = 0; r < RS_PER; r++)
+            {
+                const float tk = bank[row[r] + k];
+                const v2f prod = tile[off[r] + k] * v2f{tk, tk};
+                acc[r] = acc[r] + prod;
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < RS_PER; r++)
+        {
+            const long long m = m0 + (int)threadIdx.x + RS_BLOCK * r;
+            if (m < nout)
+                reinterpret_cast<v2f *>(y)[m] = acc[r];
+        }
+    }
+    // fallback for banks / spans that do not fit the LDS budget (very large interpolation factors)
+    __global__ __launch_bounds__(256) void k_resample_big(const cf32 *x, ResampParams p, int ctr0, int inc0, cf32 *y, long long nout)
     {
         const long long m = (long long)blockIdx.x * blockDim.x + threadIdx.x;
         if (m >= nout)
@@ -187,41 +246,67 @@ namespace sdhip
         (void)nin;
         if (nout <= 0)
             return;
-        ProfScope _ps("k_resample", st);
-        hipLaunchKernelGGL(k_resample, dim3((unsigned)((nout + 255) / 256)), dim3(256), 0, st, x, p, ctr0, inc0, y, nout);
+        const long long span_max = ((long long)RS_BLOCK * RS_PER * p.decim) / p.interp + p.ntaps + 2;
+        if (p.interp * p.ntaps <= RS_MAX_BANK && span_max <= RS_MAX_TILE)
+        {
+            ProfScope _ps("k_resample", st);
+            hipLaunchKernelGGL(k_resample, dim3((unsigned)((nout + RS_BLOCK * RS_PER - 1) / (RS_BLOCK * RS_PER))), dim3(RS_BLOCK), 0, st, x, p, ctr0, inc0, y, nout);
+        }
+        else
+        {
+            ProfScope _ps("k_resample_big", st);
+            hipLaunchKernelGGL(k_resample_big, dim3((unsigned)((nout + 255) / 256)), dim3(256), 0, st, x, p, ctr0, inc0, y, nout);
+        }
     }
 
     // =============================================================================================
     // FIR: y[i] = sum_j x[i-(nt-1)+j] * rtaps[j], accumulated oldest sample first (volk generic order)
     // =============================================================================================
     constexpr int FIR_MAX_TAPS = 384;
-    __global__ __launch_bounds__(256) void k_fir(const cf32 *x, cf32 *y, long long n, const float *rtaps, int ntaps)
+    constexpr int FIR_BLOCK = 256, FIR_PER = 4; // outputs per block = 1024 (thread t: i0 + t + 256*r)
+    __global__ __launch_bounds__(FIR_BLOCK) void k_fir(const cf32 *x, cf32 *y, long long n, const float *__restrict__ rtaps, int ntaps)
     {
-        __shared__ float taps[FIR_MAX_TAPS];
-        for (int i = (int)threadIdx.x; i < ntaps; i += (int)blockDim.x)
-            taps[i] = rtaps[i];
+        __shared__ v2f tile[FIR_BLOCK * FIR_PER + FIR_MAX_TAPS];
+        const long long i0 = (long long)blockIdx.x * (FIR_BLOCK * FIR_PER);
+        long long cnt = n - i0;
+        if (cnt > FIR_BLOCK * FIR_PER)
+            cnt = FIR_BLOCK * FIR_PER;
+        const int span = (int)cnt + ntaps - 1;
+        const v2f *xs = reinterpret_cast<const v2f *>(x) + (i0 - (ntaps - 1));
+        for (int i = (int)threadIdx.x; i < span; i += FIR_BLOCK)
+            tile[i] = xs[i];
         __syncthreads();
-        const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-        if (i >= n)
-            return;
-        const cf32 *b = x + i - (ntaps - 1);
-        float re = 0.0f, im = 0.0f;
+        v2f acc[FIR_PER];
+#pragma unroll
+        for (int r = 0; r < FIR_PER; r++)
+            acc[r] = v2f{0.0f, 0.0f};
+        const int t0 = (int)threadIdx.x;
         for (int j = 0; j < ntaps; j++)
         {
-            const cf32 v = b[j];
-            const float t = taps[j];
-            re = re + v.re * t;
-            im = im + v.im * t;
+            const float t = rtaps[j]; // wave-uniform: scalar load
+            const v2f tt{t, t};
+#pragma unroll
+            for (int r = 0; r < FIR_PER; r++)
+            {
+                // rows past the end of a ragged last block read stale LDS: computed, never stored
+                const v2f prod = tile[t0 + FIR_BLOCK * r + j] * tt;
+                acc[r] = acc[r] + prod;
+            }
         }
-        y[i].re = re;
-        y[i].im = im;
+#pragma unroll
+        for (int r = 0; r < FIR_PER; r++)
+        {
+            const long long i = i0 + t0 + FIR_BLOCK * r;
+            if (i < n)
+                reinterpret_cast<v2f *>(y)[i] = acc[r];
+        }
     }
     void launch_fir(const cf32 *x, cf32 *y, long long n, const float *rtaps_dev, int ntaps, hipStream_t st)
     {
         if (n <= 0)
             return;
         ProfScope _ps("k_fir", st);
-        hipLaunchKernelGGL(k_fir, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, y, n, rtaps_dev, ntaps);
+        hipLaunchKernelGGL(k_fir, dim3((unsigned)((n + FIR_BLOCK * FIR_PER - 1) / (FIR_BLOCK * FIR_PER))), dim3(FIR_BLOCK), 0, st, x, y, n, rtaps_dev, ntaps);
     }
 
     // =============================================================================================
@@ -232,22 +317,18 @@ namespace sdhip
     {
         using P = AgcParams;
         using S = AgcState;
+        static constexpr int DEPTH = 6; // ~100 cycles per sample: 48 samples in flight cover the load latency
         __device__ static __forceinline__ S init(const P &p) { return S{p.init_gain}; }
-        __device__ static __forceinline__ void step(S &s, const P &p, const cf32 *x, cf32 *y, long long i, bool write)
+        __device__ static __forceinline__ cf32 step(S &s, const P &p, const cf32 v)
         {
             // AGCBlock<complex_t>::work, agc.cpp:25-39
-            const cf32 v = x[i];
             const float ore = v.re * s.gain;
             const float oim = v.im * s.gain;
             const float mag = sqrtf(ore * ore + oim * oim) /* correctly rounded (default -fhip-fp32-correctly-rounded-divide-sqrt); __fsqrt_rn is the native approximation */;
             s.gain = s.gain + p.rate * (p.reference - mag);
             if (p.max_gain > 0.0f && s.gain > p.max_gain)
                 s.gain = p.max_gain;
-            if (write)
-            {
-                y[i].re = ore;
-                y[i].im = oim;
-            }
+            return cf32{ore, oim};
         }
     };
 
@@ -255,19 +336,14 @@ namespace sdhip
     {
         using P = CostasParams;
         using S = CostasState;
+        static constexpr int DEPTH = 2; // ~400 cycles per sample (two double-precision sincos polynomials)
         __device__ static __forceinline__ S init(const P &p) { return S{0.0f, p.init_freq}; }
-        __device__ static __forceinline__ void step(S &s, const P &p, const cf32 *x, cf32 *y, long long i, bool write)
+        __device__ static __forceinline__ cf32 step(S &s, const P &p, const cf32 v)
         {
             // CostasLoopBlock::work, costas_loop.cpp:23-65
-            const cf32 v = x[i];
             const float cs = sd_cosf(-s.phase), sn = sd_sinf(-s.phase);
             const float tr = (v.re * cs) - (v.im * sn);
             const float ti = (v.im * cs) + (v.re * sn);
-            if (write)
-            {
-                y[i].re = tr;
-                y[i].im = ti;
-            }
             float error;
             if (p.order == 2)
                 error = tr * ti;
@@ -293,8 +369,81 @@ namespace sdhip
                 s.freq = p.fmax;
             if (s.freq < p.fmin)
                 s.freq = p.fmin;
+            return cf32{tr, ti};
         }
     };
+
+    // Run one lane over [i0, i1) of its chunk. The lane's samples are contiguous in memory, so they are moved in 64-byte
+    // blocks (8 samples = 4 x float4) through a register queue Stage::DEPTH blocks deep: the loads of block j+DEPTH are
+    // issued as soon as block j has been consumed, so the ~1.3 us latency of these chunk-strided HBM reads stays off the
+    // dependent recurrence (one lane per chunk means few waves per SIMD: nothing else would hide it).
+    // x + 8*m must be 16-byte aligned (stage buffers are).
+    struct Blk8
+    {
+        float4 a, b, c, d;
+    };
+    __device__ __forceinline__ Blk8 blk_load(const cf32 *x, long long i)
+    {
+        const float4 *xp = reinterpret_cast<const float4 *>(x + i);
+        return Blk8{xp[0], xp[1], xp[2], xp[3]};
+    }
+    template <class Stage>
+    __device__ __forceinline__ void blk_run(typename Stage::S &s, const typename Stage::P &p, const Blk8 &c, cf32 *y, long long i, bool write)
+    {
+        const cf32 a0 = Stage::step(s, p, cf32{c.a.x, c.a.y});
+        const cf32 a1 = Stage::step(s, p, cf32{c.a.z, c.a.w});
+        const cf32 a2 = Stage::step(s, p, cf32{c.b.x, c.b.y});
+        const cf32 a3 = Stage::step(s, p, cf32{c.b.z, c.b.w});
+        const cf32 a4 = Stage::step(s, p, cf32{c.c.x, c.c.y});
+        const cf32 a5 = Stage::step(s, p, cf32{c.c.z, c.c.w});
+        const cf32 a6 = Stage::step(s, p, cf32{c.d.x, c.d.y});
+        const cf32 a7 = Stage::step(s, p, cf32{c.d.z, c.d.w});
+        if (write)
+        {
+            float4 *yp = reinterpret_cast<float4 *>(y + i);
+            yp[0] = make_float4(a0.re, a0.im, a1.re, a1.im);
+            yp[1] = make_float4(a2.re, a2.im, a3.re, a3.im);
+            yp[2] = make_float4(a4.re, a4.im, a5.re, a5.im);
+            yp[3] = make_float4(a6.re, a6.im, a7.re, a7.im);
+        }
+    }
+    template <class Stage>
+    __device__ __forceinline__ void run_range(typename Stage::S &s, const typename Stage::P &p, const cf32 *x, cf32 *y, long long i0, long long i1, bool write)
+    {
+        constexpr int D = Stage::DEPTH;
+        long long i = i0;
+        for (; i < i1 && (i & 7); i++)
+        {
+            const cf32 o = Stage::step(s, p, x[i]);
+            if (write)
+                y[i] = o;
+        }
+        if (i + 8 * D <= i1)
+        {
+            Blk8 q[D];
+#pragma unroll
+            for (int d = 0; d < D; d++)
+                q[d] = blk_load(x, i + 8 * d);
+            for (; i + 8 * D <= i1; i += 8 * D)
+            {
+#pragma unroll
+                for (int d = 0; d < D; d++)
+                {
+                    const Blk8 cur = q[d];
+                    const long long nxt = i + 8 * (D + d);
+                    if (nxt + 8 <= i1)
+                        q[d] = blk_load(x, nxt);
+                    blk_run<Stage>(s, p, cur, y, i + 8 * d, write);
+                }
+            }
+        }
+        for (; i < i1; i++)
+        {
+            const cf32 o = Stage::step(s, p, x[i]);
+            if (write)
+                y[i] = o;
+        }
+    }
 
     template <class Stage>
     __global__ __launch_bounds__(64) void k_chunks(const cf32 *x, cf32 *y, ChunkGeom g, typename Stage::P p, const typename Stage::S *start0,
@@ -321,14 +470,12 @@ namespace sdhip
             {
                 s = Stage::init(p);
                 const long long b = chunk_begin(g, k);
-                for (long long i = b - g.W; i < b; i++)
-                    Stage::step(s, p, x, y, i, false);
+                run_range<Stage>(s, p, x, y, b - g.W, b, false);
                 spec[k] = s;
             }
         }
         const long long b = chunk_begin(g, k), e = chunk_end(g, k);
-        for (long long i = b; i < e; i++)
-            Stage::step(s, p, x, y, i, true);
+        run_range<Stage>(s, p, x, y, b, e, true);
         endst[k] = s;
     }
 
@@ -413,24 +560,97 @@ namespace sdhip
             k = g.K - 1;
         return (int)k;
     }
-    __device__ __forceinline__ cf32 mm_read(const cf32 *x, const MmParams &p, long long i)
+    // ---- per-lane sample window in LDS -------------------------------------------------------------------------
+    // A lane walks its own contiguous range of the Costas output. The last MM_RING samples it has fetched live in a
+    // private LDS ring (slot = index & (MM_RING-1)). The loop nest is BLOCK-outer / SYMBOL-inner: every outer step moves
+    // one 64-byte block (8 samples) from a statically named register queue MM_DEPTH blocks deep into the ring -- applying
+    // the per-Costas-chunk rotation and the OQPSK one-sample Q delay (delay_one_imag.cpp:20-27) on the way -- re-issues
+    // that queue slot's global loads for the block MM_DEPTH further on, and then runs every M&M iteration whose 8-tap
+    // window is now complete. The queue never shifts (a register move would have to wait for its load), so the compiler
+    // can count outstanding loads exactly and the ~1.3 us HBM latency of these chunk-strided reads stays off the timing
+    // recurrence; the interpolator reads samples and taps from LDS with lane-private addresses.
+    constexpr int MM_RING = 32;
+    constexpr int MM_RING_STRIDE = MM_RING + 1; // cf32 units; odd stride: lane rows start on different banks
+    constexpr int MM_DEPTH = 4;
+    __device__ __forceinline__ void mm_rot_cs(int q, int order, float &c, float &s)
     {
-        // samples at negative indices are the carried history, already rotated by the previous call
-        cf32 v = x[i];
-        if (i >= 0 && p.rot)
-            v = rot_apply(v, p.rot[costas_chunk_of(p.cg, i)], p.order);
+        // exp(+j*q*2pi/order) on the eighth-turn grid
+        const int e = (q * (8 / order)) & 7;
+        const float h = 0.70710678118654752f;
+        c = (e == 0) ? 1.0f : (e == 4) ? -1.0f : (e == 2 || e == 6) ? 0.0f : (e == 1 || e == 7) ? h : -h;
+        s = (e == 2) ? 1.0f : (e == 6) ? -1.0f : (e == 0 || e == 4) ? 0.0f : (e == 1 || e == 3) ? h : -h;
+    }
+    struct MmFeed
+    {
+        cf32 *ring;     // this lane's row
+        long long next; // first sample index not yet in the ring (multiple of 8)
+        long long cend; // first sample index of the NEXT Costas chunk (rotation changes there; multiple of 8)
+        int ck;         // Costas chunk of block `next`
+        float rc, rs;   // its rotation exp(+j*rot*unit) as (cos, sin): exactly 0 / +-1 for quarter and half turns
+        float prev_im;  // OQPSK: imaginary part of sample next-1 (after rotation)
+    };
+    // move one block into the ring. Stage chunk boundaries and 0 are multiples of 8, so a block never straddles a rotation
+    // change or the history/data boundary.
+    __device__ __forceinline__ void mm_feed_put(MmFeed &f, const MmParams &p, const Blk8 &c)
+    {
+        const long long i = f.next;
+        if (p.rot && i >= f.cend && f.ck + 1 < p.cg.K)
+        {
+            f.ck++;
+            f.cend += p.cg.L;
+            mm_rot_cs(p.rot[f.ck], p.order, f.rc, f.rs);
+        }
+        const bool dorot = p.rot && i >= 0; // history (negative indices) was rotated by the previous call
+        float re[8] = {c.a.x, c.a.z, c.b.x, c.b.z, c.c.x, c.c.z, c.d.x, c.d.z};
+        float im[8] = {c.a.y, c.a.w, c.b.y, c.b.w, c.c.y, c.c.w, c.d.y, c.d.w};
+        const int slot = (int)(i & (MM_RING - 1));
+#pragma unroll
+        for (int j = 0; j < 8; j++)
+        {
+            cf32 v{re[j], im[j]};
+            if (dorot) // branch-free: multiplications by 0 / +-1 are exact (only the sign of a zero can differ from a swap)
+                v = cf32{v.re * f.rc - v.im * f.rs, v.re * f.rs + v.im * f.rc};
+            if (p.oqpsk)
+            {
+                const float t = v.im;
+                v.im = f.prev_im;
+                f.prev_im = t;
+            }
+            f.ring[slot + j] = v;
+        }
+        f.next = i + 8;
+    }
+    // start the window so that samples [inc-7, inc] can be served
+    __device__ __forceinline__ void mm_feed_init(MmFeed &f, const MmParams &p, const cf32 *x, cf32 *ring, long long inc)
+    {
+        f.ring = ring;
+        long long first = inc - 7;
+        first = (first >= 0 ? first : first - 7) / 8 * 8; // floor to a multiple of 8 (also for negative indices)
+        f.next = first;
+        f.ck = 0;
+        f.rc = 1.0f;
+        f.rs = 0.0f;
+        f.cend = 0;
+        if (p.rot)
+        {
+            f.ck = first >= 0 ? costas_chunk_of(p.cg, first) : 0;
+            mm_rot_cs(p.rot[f.ck], p.order, f.rc, f.rs);
+            f.cend = chunk_end(p.cg, f.ck);
+        }
+        f.prev_im = 0.0f;
         if (p.oqpsk)
         {
-            cf32 w = x[i - 1];
-            if (i - 1 >= 0 && p.rot)
-                w = rot_apply(w, p.rot[costas_chunk_of(p.cg, i - 1)], p.order);
-            v.im = w.im;
+            // samples at negative indices are the carried history, already rotated by the previous call
+            cf32 v = x[first - 1];
+            if (first - 1 >= 0 && p.rot)
+                v = rot_apply(v, p.rot[costas_chunk_of(p.cg, first - 1)], p.order);
+            f.prev_im = v.im;
         }
-        return v;
     }
 
-    // one iteration of MMClockRecoveryBlock<complex_t>::work's loop body, clock_recovery_mm.cpp:54-120
-    __device__ __forceinline__ cf32 mm_iter(MmState &s, const MmParams &p, const cf32 *x)
+    // one iteration of MMClockRecoveryBlock<complex_t>::work's loop body, clock_recovery_mm.cpp:54-120; the window
+    // [inc-7, inc] must be in the ring
+    __device__ __forceinline__ cf32 mm_iter(MmState &s, const MmParams &p, const cf32 *ring, const float *bank)
     {
         s.p_2T = s.p_1T;
         s.p_1T = s.p_0T;
@@ -441,12 +661,15 @@ namespace sdhip
             imu = 0;
         if (imu >= 128)
             imu = 127;
-        const float *t = p.bank + imu * 8;
+        const float4 t0 = *reinterpret_cast<const float4 *>(bank + imu * 8);
+        const float4 t1 = *reinterpret_cast<const float4 *>(bank + imu * 8 + 4);
+        const float t[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
+        const int base = (int)((s.inc - 7) & (MM_RING - 1));
         float re = 0.0f, im = 0.0f;
 #pragma unroll
         for (int k = 0; k < 8; k++)
         {
-            const cf32 v = mm_read(x, p, s.inc - 7 + k);
+            const cf32 v = ring[(base + k) & (MM_RING - 1)];
             re = re + v.re * t[k];
             im = im + v.im * t[k];
         }
@@ -477,9 +700,15 @@ namespace sdhip
     __global__ __launch_bounds__(64) void k_mm(const cf32 *x, cf32 *sym, int *counts, ChunkGeom g, MmParams p, const MmState *start0, MmState *spec,
                                                MmState *endst, const int *redo, int nredo)
     {
+        __shared__ cf32 rings[64 * MM_RING_STRIDE];
+        __shared__ __attribute__((aligned(16))) float bank[128 * 8];
+        for (int i = (int)threadIdx.x; i < 128 * 8; i += 64)
+            bank[i] = p.bank[i];
+        __syncthreads();
         const int idx = (int)(blockIdx.x * blockDim.x + threadIdx.x);
         int k;
         MmState s;
+        bool warm = false;
         if (redo)
         {
             if (idx >= nredo)
@@ -496,42 +725,67 @@ namespace sdhip
                 s = *start0;
             else
             {
-                const long long b = chunk_begin(g, k);
                 s.mu = p.init_mu;
                 s.omega = p.omega_mid;
                 s.p_2T = s.p_1T = s.p_0T = cf32{0.0f, 0.0f};
                 s.c_2T = s.c_1T = s.c_0T = cf32{0.0f, 0.0f};
-                s.inc = b - g.W;
-                while (s.inc < b)
-                    (void)mm_iter(s, p, x);
-                spec[k] = s;
+                s.inc = chunk_begin(g, k) - g.W;
+                warm = true;
             }
         }
-        const long long e = chunk_end(g, k);
+        MmFeed f;
+        mm_feed_init(f, p, x, rings + (int)threadIdx.x * MM_RING_STRIDE, s.inc);
+        // Three phases: 0 = warm-up (nothing stored) until the chunk start, 1 = the chunk itself, 2 = up to two look-ahead
+        // symbols past the chunk end computed from the running state AFTER the end state has been saved: if the next
+        // chunk's own trajectory starts one symbol later than this one ends (timing within tolerance, boundary sample
+        // index on the other side of the mu wrap), the host hands these to the stream instead of re-running anything.
+        const long long b = chunk_begin(g, k), e = chunk_end(g, k);
         cf32 *o = sym + (size_t)k * p.cap;
-        int cnt = 0;
-        while (s.inc < e)
+        int phase = warm ? 0 : 1, cnt = 0, nx = 0;
+        bool done = false;
+        Blk8 q[MM_DEPTH];
+#pragma unroll
+        for (int d = 0; d < MM_DEPTH; d++)
+            q[d] = blk_load(x, f.next + 8 * d);
+        while (!done)
         {
-            const cf32 v = mm_iter(s, p, x);
-            if (cnt < p.cap)
-                o[cnt] = v;
-            cnt++;
-        }
-        counts[2 * k] = cnt;
-        endst[k] = s;
-        // Up to two symbols past the chunk end, from a COPY of the state: if the next chunk's own trajectory starts one
-        // symbol later than this one ends (timing within tolerance, boundary sample index on the other side of the
-        // mu wrap), the host hands these to the stream instead of re-running anything. Not part of the end state.
-        int nx = 0;
-        if (k + 1 < g.K)
-        {
-            MmState t = s;
-            for (int j = 0; j < 2 && t.inc < g.n; j++)
+#pragma unroll
+            for (int d = 0; d < MM_DEPTH; d++)
             {
-                const cf32 v = mm_iter(t, p, x);
-                if (cnt + j < p.cap)
-                    o[cnt + j] = v;
-                nx++;
+                const Blk8 cur = q[d];
+                q[d] = blk_load(x, f.next + 8 * MM_DEPTH); // at most 8*MM_DEPTH + 8 samples past the lane's last window
+                mm_feed_put(f, p, cur);
+                while (!done && s.inc < f.next)
+                {
+                    if (phase == 0 && s.inc >= b)
+                    {
+                        spec[k] = s;
+                        phase = 1;
+                    }
+                    if (phase == 1 && s.inc >= e)
+                    {
+                        counts[2 * k] = cnt;
+                        endst[k] = s;
+                        phase = 2;
+                        if (k + 1 >= g.K)
+                            done = true;
+                    }
+                    if (phase == 2 && (nx >= 2 || s.inc >= g.n))
+                        done = true;
+                    if (!done)
+                    {
+                        const cf32 v = mm_iter(s, p, f.ring, bank);
+                        if (phase != 0)
+                        {
+                            if (cnt + nx < p.cap)
+                                o[cnt + nx] = v;
+                            if (phase == 1)
+                                cnt++;
+                            else
+                                nx++;
+                        }
+                    }
+                }
             }
         }
         counts[2 * k + 1] = nx;
