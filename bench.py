@@ -197,13 +197,8 @@ def main():
     prof = capi.prof_get()
     last_nf = nf
 
-    tmax = torch.tensor([dt], dtype=torch.float64, device=device)
-    cnt = torch.tensor([float(n_in * args.steps), float(tot_frames)], dtype=torch.float64, device=device)
-    if world > 1:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
-    dt_all = float(tmax.item())
-    samples_all, frames_all = float(cnt[0].item()), float(cnt[1].item())
+    from satdump_amd import shard
+    dt_all, samples_all, frames_all = shard.reduce_metrics(dt, float(n_in * args.steps), float(tot_frames), device=device)
 
     # ---- correctness of what was timed: every CADU of the last step must be one of the transmitted frames
     check = None

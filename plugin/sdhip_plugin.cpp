@@ -1,0 +1,428 @@
+// sdhip_plugin.cpp -- SatDump plugin that puts the MI355X hot path behind the reference's own pipeline-module API.
+//
+// Built as plugins/libsdhip_support.so next to the reference's other plugins. It registers
+//   psk_demod_hip                  <- PSKDemodModule              (src-core/pipeline/modules/demod/module_psk_demod.{h,cpp})
+//   ccsds_conv_concat_decoder_hip  <- CCSDSConvConcatDecoderModule (src-core/pipeline/modules/ccsds/module_ccsds_conv_concat_decoder.{h,cpp})
+//   metop_ahrpt_decoder_hip        <- MetOpAHRPTDecoderModule      (plugins/noaa_metop_support/metop/module_metop_ahrpt_decoder.{h,cpp})
+// during RegisterModulesEvent (src-core/pipeline/module.h:213-216) and, when SDHIP_OVERRIDE=1 is set, re-points the
+// reference ids themselves at these classes from a SatDumpStartedEvent handler (src-core/core/plugin.h:21-23; the
+// registry lookup is first-match, src-core/pipeline/module.cpp:129-135), so existing pipelines run unchanged.
+//
+// The classes are thin: same JSON keys, same input/output types, same file extensions, same exceptions as the modules
+// they replace; every sample, soft symbol and frame goes through the C ABI of include/sdhip.h and nothing else.
+#include "core/exception.h"
+#include "core/plugin.h"
+#include "logger.h"
+#include "pipeline/module.h"
+#include "pipeline/modules/base/filestream_to_filestream.h"
+
+#include "../include/sdhip.h"
+
+#include <cstring>
+#include <fstream>
+#include <vector>
+
+namespace sdhip_plugin
+{
+    using namespace satdump::pipeline;
+
+    static int constellation_of(const std::string &s, bool demod)
+    {
+        if (s == "bpsk")
+            return SDHIP_BPSK;
+        if (s == "bpsk_90" && !demod)
+            return SDHIP_BPSK_90;
+        if (s == "qpsk")
+            return SDHIP_QPSK;
+        if (s == "oqpsk")
+            return SDHIP_OQPSK;
+        if (s == "8psk" && demod)
+            return SDHIP_8PSK;
+        return -1;
+    }
+
+    template <class T>
+    static void opt(const nlohmann::json &p, const char *key, T &dst)
+    {
+        if (p.count(key) > 0)
+            dst = p[key].get<T>();
+    }
+
+    // ------------------------------------------------------------------------------------------------ psk_demod
+    class PSKDemodHipModule : public ProcessingModule
+    {
+        sdhip_demod_cfg cfg;
+        void *h = nullptr;
+        std::string baseband_format = "cf32";
+        int fmt = SDHIP_FMT_CF32;
+        std::atomic<uint64_t> filesize{0}, progress{0};
+        std::atomic<float> display_freq{0};
+        std::atomic<bool> should_stop{false};
+        std::ofstream data_out;
+
+    public:
+        PSKDemodHipModule(std::string input_file, std::string output_file_hint, nlohmann::json parameters)
+            : ProcessingModule(input_file, output_file_hint, parameters)
+        {
+            sdhip_demod_cfg_default(&cfg);
+            // BaseDemodModule ctor (module_demod_base.cpp:12-57) + PSKDemodModule ctor (module_psk_demod.cpp:12-84)
+            if (parameters.count("samplerate") > 0)
+                cfg.samplerate = parameters["samplerate"].get<long>();
+            else
+                throw satdump_exception("Samplerate parameter must be present!");
+            opt(parameters, "buffer_size", cfg.buffer_size);
+            if (parameters.count("symbolrate") > 0)
+                cfg.symbolrate = parameters["symbolrate"].get<long>();
+            opt(parameters, "agc_rate", cfg.agc_rate);
+            bool b = false;
+            opt(parameters, "dc_block", b), cfg.dc_block = b;
+            b = false;
+            opt(parameters, "iq_swap", b), cfg.iq_swap = b;
+            opt(parameters, "min_sps", cfg.min_sps);
+            opt(parameters, "max_sps", cfg.max_sps);
+            if (parameters.count("freq_shift") > 0 && parameters["freq_shift"].get<long>() != 0)
+                throw satdump_exception("psk_demod_hip: freq_shift is not on the HIP path, use psk_demod");
+            if (parameters.count("constellation") > 0)
+                cfg.constellation = constellation_of(parameters["constellation"].get<std::string>(), true);
+            else
+                throw satdump_exception("Constellation type parameter must be present!");
+            if (cfg.constellation < 0)
+                throw satdump_exception("This Demodulator only supports BPSK, QPSK, OQPSK and 8PSK.");
+            if (parameters.count("rrc_alpha") > 0)
+                cfg.rrc_alpha = parameters["rrc_alpha"].get<float>();
+            else
+                throw satdump_exception("RRC Alpha parameter must be present!");
+            opt(parameters, "rrc_taps", cfg.rrc_taps);
+            if (parameters.count("pll_bw") > 0)
+                cfg.pll_bw = parameters["pll_bw"].get<float>();
+            else
+                throw satdump_exception("PLL BW parameter must be present!");
+            if (parameters.count("clock_alpha") > 0)
+            { // module_psk_demod.cpp:42-47
+                const float clock_alpha = parameters["clock_alpha"].get<float>();
+                cfg.clock_gain_omega = clock_alpha * clock_alpha / 4.0f;
+                cfg.clock_gain_mu = clock_alpha;
+            }
+            opt(parameters, "clock_gain_omega", cfg.clock_gain_omega);
+            opt(parameters, "clock_mu", cfg.clock_mu);
+            opt(parameters, "clock_gain_mu", cfg.clock_gain_mu);
+            opt(parameters, "clock_omega_relative_limit", cfg.clock_omega_relative_limit);
+            opt(parameters, "costas_max_offset", cfg.costas_max_offset_hz);
+            opt(parameters, "baseband_format", baseband_format);
+            // engine knobs of the HIP path (no reference equivalent)
+            opt(parameters, "hip_device", cfg.device);
+            opt(parameters, "hip_exact", cfg.exact);
+            if (baseband_format == "cf32" || baseband_format == "f32")
+                fmt = SDHIP_FMT_CF32;
+            else if (baseband_format == "cs16" || baseband_format == "s16")
+                fmt = SDHIP_FMT_CS16;
+            else if (baseband_format == "cs8" || baseband_format == "s8")
+                fmt = SDHIP_FMT_CS8;
+            else if (baseband_format == "cu8" || baseband_format == "u8")
+                fmt = SDHIP_FMT_CU8;
+            else
+                throw satdump_exception("psk_demod_hip: baseband_format " + baseband_format + " is not on the HIP path (cf32, cs16, cs8, cu8)");
+        }
+        ~PSKDemodHipModule()
+        {
+            if (h)
+                sdhip_demod_destroy(h);
+        }
+
+        std::vector<ModuleDataType> getInputTypes() { return {DATA_FILE, DATA_DSP_STREAM}; }
+        std::vector<ModuleDataType> getOutputTypes() { return {DATA_FILE, DATA_STREAM}; }
+
+        void init()
+        {
+            h = sdhip_demod_create(&cfg);
+            if (!h)
+                throw satdump_exception(std::string("psk_demod_hip: ") + sdhip_last_error());
+        }
+        void stop() { should_stop = true; }
+
+        void drain(std::vector<int8_t> &buf)
+        {
+            for (;;)
+            {
+                const int64_t n = sdhip_demod_pull(h, buf.data(), buf.size());
+                if (n < 0)
+                    throw satdump_exception(std::string("psk_demod_hip: ") + sdhip_last_error());
+                if (n == 0)
+                    break;
+                if (output_data_type == DATA_FILE)
+                    data_out.write((char *)buf.data(), n);
+                else
+                    output_fifo->write((uint8_t *)buf.data(), n);
+            }
+            sdhip_demod_stats st;
+            sdhip_demod_get_stats(h, &st);
+            display_freq = st.freq_hz;
+        }
+
+        void process()
+        {
+            if (output_data_type == DATA_FILE)
+            {
+                data_out = std::ofstream(d_output_file_hint + ".soft", std::ios::binary);
+                d_output_file = d_output_file_hint + ".soft";
+            }
+            logger->info("Using input baseband " + d_input_file);
+            logger->info("Demodulating to " + d_output_file_hint + ".soft (MI355X path)");
+            std::vector<int8_t> out(1 << 24);
+            static const int bps[4] = {8, 4, 2, 2};
+            if (input_data_type == DATA_FILE)
+            {
+                std::ifstream in(d_input_file, std::ios::binary);
+                in.seekg(0, std::ios::end);
+                filesize = (uint64_t)in.tellg();
+                in.seekg(0, std::ios::beg);
+                const size_t samples_per_read = 1 << 22;
+                std::vector<char> raw(samples_per_read * bps[fmt]);
+                while (!should_stop && in)
+                {
+                    in.read(raw.data(), raw.size());
+                    const size_t got = (size_t)in.gcount() / bps[fmt];
+                    if (got == 0)
+                        break;
+                    if (sdhip_demod_push(h, raw.data(), got, fmt) < 0)
+                        throw satdump_exception(std::string("psk_demod_hip: ") + sdhip_last_error());
+                    progress = progress + got * bps[fmt];
+                    drain(out);
+                }
+            }
+            else
+            {
+                // dsp::stream<complex_t> hand-off exactly as the reference's blocks consume it (common/dsp/buffer.h:28-151)
+                while (!should_stop && input_active.load())
+                {
+                    const int n = input_stream->read();
+                    if (n <= 0)
+                        continue;
+                    const int rc = sdhip_demod_push(h, input_stream->readBuf, (size_t)n, SDHIP_FMT_CF32);
+                    input_stream->flush();
+                    if (rc < 0)
+                        throw satdump_exception(std::string("psk_demod_hip: ") + sdhip_last_error());
+                    drain(out);
+                }
+            }
+            if (sdhip_demod_flush(h) < 0)
+                throw satdump_exception(std::string("psk_demod_hip: ") + sdhip_last_error());
+            drain(out);
+            if (output_data_type == DATA_FILE)
+                data_out.close();
+            logger->info("Demodulation finished");
+        }
+
+        void drawUI(bool) {}
+
+        nlohmann::json getModuleStats()
+        {
+            nlohmann::json v;
+            v["progress"] = filesize ? ((double)progress / (double)filesize) : 0.0;
+            v["freq"] = display_freq.load();
+            return v;
+        }
+
+        static std::string getID() { return "psk_demod_hip"; }
+        virtual std::string getIDM() { return getID(); }
+        static nlohmann::json getParams()
+        { // same advertised defaults as PSKDemodModule::getParams (module_psk_demod.cpp:330-338)
+            nlohmann::json v;
+            v["constellation"] = "bpsk";
+            v["rrc_alpha"] = 0.5;
+            v["rrc_taps"] = 31;
+            v["pll_bw"] = 0.01;
+            return v;
+        }
+        static std::shared_ptr<ProcessingModule> getInstance(std::string input_file, std::string output_file_hint, nlohmann::json parameters)
+        {
+            return std::make_shared<PSKDemodHipModule>(input_file, output_file_hint, parameters);
+        }
+    };
+
+    // ------------------------------------------------------------------------------- concatenated decoders
+    class FecHipModuleBase : public base::FileStreamToFileStreamModule
+    {
+    protected:
+        sdhip_fec_cfg cfg;
+        void *h = nullptr;
+        int block_bytes = 8192, cadu_bytes = 1024;
+        std::atomic<float> viterbi_ber{10};
+        std::atomic<int> viterbi_lock{0}, deframer_state{0};
+
+    public:
+        FecHipModuleBase(std::string input_file, std::string output_file_hint, nlohmann::json parameters)
+            : base::FileStreamToFileStreamModule(input_file, output_file_hint, parameters)
+        {
+            sdhip_fec_cfg_default(&cfg);
+            opt(parameters, "hip_device", cfg.device);
+        }
+        ~FecHipModuleBase()
+        {
+            if (h)
+                sdhip_fec_destroy(h);
+        }
+        void init()
+        {
+            base::FileStreamToFileStreamModule::init();
+            h = sdhip_fec_create(&cfg);
+            if (!h)
+                throw satdump_exception(std::string(getIDM()) + ": " + sdhip_last_error());
+        }
+        void process()
+        {
+            // batches of whole decoder buffers; the library keeps any remainder pending
+            const size_t batch = (size_t)block_bytes * 2048;
+            std::vector<int8_t> soft(batch);
+            std::vector<uint8_t> frames((size_t)cadu_bytes * 4096);
+            while (should_run())
+            {
+                const size_t want = input_data_type == DATA_FILE ? batch : (size_t)block_bytes; // streaming: stay close to real time
+                read_data((uint8_t *)soft.data(), want);
+                if (sdhip_fec_push(h, soft.data(), want) < 0)
+                    throw satdump_exception(std::string(getIDM()) + ": " + sdhip_last_error());
+                for (;;)
+                {
+                    const int64_t n = sdhip_fec_pull(h, frames.data(), frames.size() / cadu_bytes);
+                    if (n < 0)
+                        throw satdump_exception(std::string(getIDM()) + ": " + sdhip_last_error());
+                    if (n == 0)
+                        break;
+                    write_data(frames.data(), (size_t)n * cadu_bytes);
+                }
+                sdhip_fec_stats st;
+                sdhip_fec_get_stats(h, &st);
+                viterbi_ber = st.viterbi_ber;
+                viterbi_lock = st.viterbi_lock;
+                deframer_state = st.deframer_state;
+            }
+            cleanup();
+        }
+        void drawUI(bool) {}
+        nlohmann::json getModuleStats()
+        {
+            auto v = base::FileStreamToFileStreamModule::getModuleStats();
+            v["deframer_lock"] = deframer_state.load() >= 12;
+            v["viterbi_ber"] = viterbi_ber.load();
+            v["viterbi_lock"] = viterbi_lock.load();
+            return v;
+        }
+    };
+
+    class CCSDSConvConcatDecoderHipModule : public FecHipModuleBase
+    {
+    public:
+        CCSDSConvConcatDecoderHipModule(std::string input_file, std::string output_file_hint, nlohmann::json parameters)
+            : FecHipModuleBase(input_file, output_file_hint, parameters)
+        {
+            // CCSDSConvConcatDecoderModule ctor, module_ccsds_conv_concat_decoder.cpp:16-131
+            cfg.decoder = SDHIP_DEC_CONV_CONCAT;
+            cfg.constellation = constellation_of(parameters["constellation"].get<std::string>(), false);
+            if (cfg.constellation < 0)
+                throw satdump_exception("CCSDS Concatenated 1/2 Decoder : invalid constellation type!");
+            bool b = false;
+            opt(parameters, "iq_invert", b), cfg.iq_invert = b;
+            cfg.cadu_size = parameters["cadu_size"].get<int>();
+            cfg.viterbi_outsync_after = parameters["viterbi_outsync_after"].get<int>();
+            cfg.viterbi_ber_thresold = parameters["viterbi_ber_thresold"].get<float>();
+            cfg.nrzm = parameters.count("nrzm") > 0 ? parameters["nrzm"].get<bool>() : false;
+            cfg.derandomize = parameters.count("derandomize") > 0 ? parameters["derandomize"].get<bool>() : true;
+            cfg.derand_after_rs = parameters.count("derand_after_rs") > 0 ? parameters["derand_after_rs"].get<bool>() : false;
+            cfg.derand_start = parameters.count("derand_start") > 0 ? parameters["derand_start"].get<int>() : 4;
+            const std::string conv = parameters.count("conv_rate") > 0 ? parameters["conv_rate"].get<std::string>() : "1/2";
+            if (conv != "1/2")
+                throw satdump_exception("ccsds_conv_concat_decoder_hip: conv_rate " + conv + " is not on the HIP path yet, use ccsds_conv_concat_decoder");
+            cfg.rs_i = parameters["rs_i"].get<int>();
+            cfg.rs_fill_bytes = parameters.count("rs_fill_bytes") > 0 ? parameters["rs_fill_bytes"].get<int>() : -1;
+            cfg.rs_dualbasis = parameters.count("rs_dualbasis") > 0 ? parameters["rs_dualbasis"].get<bool>() : true;
+            const std::string rs_type = parameters.count("rs_type") > 0 ? parameters["rs_type"].get<std::string>() : "none";
+            if (cfg.rs_i != 0)
+            {
+                if (rs_type == "rs223")
+                    cfg.rs_type = SDHIP_RS223;
+                else if (rs_type == "rs239")
+                    cfg.rs_type = SDHIP_RS239;
+                else
+                    throw satdump_exception("CCSDS Concatenated 1/2 Decoder : invalid Reed-Solomon type!");
+            }
+            cfg.rs_usecheck = parameters.count("rs_usecheck") > 0 ? parameters["rs_usecheck"].get<bool>() : false;
+            if (parameters.count("asm") > 0)
+                cfg.asm_sync = (uint32_t)std::stoul(parameters["asm"].get<std::string>(), nullptr, 16);
+            const bool is_ccsds = parameters.count("ccsds") > 0 ? parameters["ccsds"].get<bool>() : true;
+            fsfsm_file_ext = is_ccsds ? ".cadu" : ".frm";
+            block_bytes = std::max(cfg.cadu_size, 8192);
+            cadu_bytes = cfg.cadu_size / 8;
+        }
+        static std::string getID() { return "ccsds_conv_concat_decoder_hip"; }
+        virtual std::string getIDM() { return getID(); }
+        static nlohmann::json getParams() { return {}; }
+        static std::shared_ptr<ProcessingModule> getInstance(std::string input_file, std::string output_file_hint, nlohmann::json parameters)
+        {
+            return std::make_shared<CCSDSConvConcatDecoderHipModule>(input_file, output_file_hint, parameters);
+        }
+    };
+
+    class MetOpAHRPTDecoderHipModule : public FecHipModuleBase
+    {
+    public:
+        MetOpAHRPTDecoderHipModule(std::string input_file, std::string output_file_hint, nlohmann::json parameters)
+            : FecHipModuleBase(input_file, output_file_hint, parameters)
+        {
+            // MetOpAHRPTDecoderModule ctor, plugins/noaa_metop_support/metop/module_metop_ahrpt_decoder.cpp:17-28
+            cfg.decoder = SDHIP_DEC_METOP_AHRPT;
+            cfg.viterbi_outsync_after = parameters["viterbi_outsync_after"].get<int>();
+            cfg.viterbi_ber_thresold = parameters["viterbi_ber_thresold"].get<float>();
+            fsfsm_file_ext = ".cadu";
+            block_bytes = 16384;
+            cadu_bytes = 1024;
+        }
+        static std::string getID() { return "metop_ahrpt_decoder_hip"; }
+        virtual std::string getIDM() { return getID(); }
+        static nlohmann::json getParams() { return {}; }
+        static std::shared_ptr<ProcessingModule> getInstance(std::string input_file, std::string output_file_hint, nlohmann::json parameters)
+        {
+            return std::make_shared<MetOpAHRPTDecoderHipModule>(input_file, output_file_hint, parameters);
+        }
+    };
+
+    // ------------------------------------------------------------------------------------------------ plugin
+    class SdhipSupport : public satdump::Plugin
+    {
+    public:
+        std::string getID() { return "sdhip_support"; }
+        void init()
+        {
+            satdump::eventBus->register_handler<RegisterModulesEvent>(registerModulesHandler);
+            satdump::eventBus->register_handler<satdump::SatDumpStartedEvent>(startedHandler);
+        }
+        static void registerModulesHandler(const RegisterModulesEvent &evt)
+        {
+            REGISTER_MODULE_EXTERNAL(evt.modules_registry, PSKDemodHipModule);
+            REGISTER_MODULE_EXTERNAL(evt.modules_registry, CCSDSConvConcatDecoderHipModule);
+            REGISTER_MODULE_EXTERNAL(evt.modules_registry, MetOpAHRPTDecoderHipModule);
+        }
+        static void startedHandler(const satdump::SatDumpStartedEvent &)
+        {
+            const char *ov = getenv("SDHIP_OVERRIDE");
+            if (!ov || std::string(ov) != "1")
+                return;
+            if (sdhip_device_count() <= 0)
+            {
+                logger->warn("sdhip_support: SDHIP_OVERRIDE=1 but no HIP device is visible, leaving the CPU modules in place");
+                return;
+            }
+            for (auto &e : modules_registry)
+            {
+                if (e.id == "psk_demod")
+                    e.inst = PSKDemodHipModule::getInstance;
+                else if (e.id == "ccsds_conv_concat_decoder")
+                    e.inst = CCSDSConvConcatDecoderHipModule::getInstance;
+                else if (e.id == "metop_ahrpt_decoder")
+                    e.inst = MetOpAHRPTDecoderHipModule::getInstance;
+            }
+            logger->info("sdhip_support: psk_demod / ccsds_conv_concat_decoder / metop_ahrpt_decoder now run on the MI355X path");
+        }
+    };
+} // namespace sdhip_plugin
+
+PLUGIN_LOADER(sdhip_plugin::SdhipSupport)

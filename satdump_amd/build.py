@@ -47,9 +47,21 @@ def build_oracle(verbose: bool = True) -> None:
     subprocess.check_call(cmd)
 
 
+def build_plugin_check(verbose: bool = True) -> None:
+    """Compile the SatDump plugin shim (plugin/sdhip_plugin.cpp) against the reference's own headers: a build check of the
+    drop-in boundary, only possible where the reference tree exists (not on the GPU box)."""
+    if not os.path.isdir("/root/reference/src-core"):
+        return
+    cmd = ["make", "-C", os.path.join(ROOT, "plugin"), "all"]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+
+
 def build_all(force: bool = False) -> None:
     build_lib(force=force)
     build_oracle()
+    build_plugin_check()
 
 
 if __name__ == "__main__":

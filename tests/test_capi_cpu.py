@@ -34,3 +34,20 @@ def test_fails_loudly_without_gpu():
         pytest.skip("GPU present")
     with pytest.raises(capi.SdhipError):
         capi.FecDecoder(capi.fec_cfg(constellation="bpsk"))
+
+
+def test_plugin_shim_builds_against_reference_headers():
+    """plugin/sdhip_plugin.cpp (the ProcessingModule subclasses above the C ABI) compiles against the reference's own
+    module.h / plugin.h and exports the plugin entry point `loader` (src-core/core/plugin.h:10-17); the only symbols it
+    needs besides SatDump's are the C ABI's."""
+    import subprocess
+    if not os.path.isdir("/root/reference/src-core"):
+        pytest.skip("reference tree not present (GPU box)")
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "plugin"), "all"], stdout=subprocess.DEVNULL)
+    so = os.path.join(ROOT, "plugin", "_build", "libsdhip_support.so")
+    defined = subprocess.check_output(["nm", "-D", "--defined-only", so], text=True)
+    assert " T loader" in defined
+    undefined = subprocess.check_output(["nm", "-D", "--undefined-only", so], text=True)
+    used = sorted(set(re.findall(r"\b(sdhip_[a-z0-9_]+)", undefined)))
+    assert "sdhip_demod_push" in used and "sdhip_fec_push" in used and "sdhip_fec_pull" in used
+    assert set(used) <= set(_declared_symbols())
