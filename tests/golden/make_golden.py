@@ -1,0 +1,138 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ from the REFERENCE ITSELF (oracle/_ref/libsdref.so = the
+reference's own sources compiled where they lie under /root/reference, see oracle/Makefile). The reference ships no
+golden vectors for this path, so these fixtures are how its behaviour is pinned where /root/reference
+does not exist (the GPU box): inputs are small and stored (or regenerated from a seed and hash-checked), outputs are
+what the reference produced here.
+
+    python tests/golden/make_golden.py          # needs oracle/_ref (make -C oracle ref)
+
+Fixtures (np.savez_compressed):
+  ccdecoder.npz   CCDecoder::work: uint8 symbols -> bits, several frame sizes / noise kinds
+  rs.npz          ReedSolomon::decode_interlaved on frames with 0..17 byte errors per codeword (+ the fill=-1 quirk)
+  concat_*.npz    CCSDSConvConcatDecoderModule loop: int8 soft -> CADUs, per-block BER/state, RS error counts
+  metop.npz       MetOpAHRPTDecoderModule loop (r=3/4 depuncture)
+  demod_*.npz     PSKDemodModule chain: cs16 IQ (stored) -> int8 soft symbols + float symbols
+  taps.npz        RRC / M&M interpolator bank / rational-resampler bank
+"""
+import hashlib
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+
+from oracle import pyref  # noqa: E402
+from satdump_amd import synth  # noqa: E402
+from tests import util  # noqa: E402
+
+
+def sha(a) -> str:
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def vit_symbols(rng, F, nb, kind):
+    """uint8 symbol blocks for CCDecoder (127 = 0, 128 = erasure), stride 2*(F+6)."""
+    stride = 2 * (F + 6)
+    bits = rng.integers(0, 2, nb * F + 64).astype(np.uint8)
+    coded = synth.conv_encode(bits)[: nb * 2 * F]
+    if kind == "noise":
+        soft = rng.integers(-127, 128, nb * 2 * F)
+    elif kind == "saturated":
+        soft = (coded.astype(np.int64) * 2 - 1) * 127
+        soft = np.where(rng.random(len(soft)) < 0.04, -soft, soft)
+    else:
+        amp, sig = {"clean": (60, 20), "noisy": (50, 45)}[kind]
+        soft = np.clip(np.rint((coded.astype(float) * 2 - 1) * amp + rng.standard_normal(len(coded)) * sig), -127, 127).astype(np.int64)
+    u = soft + 127
+    u[u == 128] = 127
+    if kind == "noisy":
+        u[rng.random(len(u)) < 0.1] = 128
+    syms = np.full(nb * stride, 128, dtype=np.uint8)
+    for b in range(nb):
+        syms[b * stride: b * stride + 2 * F] = u[b * 2 * F:(b + 1) * 2 * F]
+    return syms
+
+
+def main():
+    ref = pyref.ref()
+    out = {}
+
+    # ---- CCDecoder
+    d = {}
+    for i, (F, nb, kind) in enumerate([(4096, 3, "clean"), (4096, 3, "noisy"), (1024, 4, "noise"), (640, 5, "saturated"), (12288, 2, "noisy")]):
+        rng = np.random.default_rng(100 + i)
+        syms = vit_symbols(rng, F, nb, kind)
+        bits = ref.ccdecoder(F, syms)
+        d[f"c{i}_F"] = np.int32(F)
+        d[f"c{i}_syms"] = syms
+        d[f"c{i}_bits"] = np.packbits(bits)
+    out["ccdecoder"] = d
+
+    # ---- RS
+    rng = np.random.default_rng(7)
+    frames = synth.make_cadus(24, seed=7, derand=False)
+    bad = frames.copy()
+    for f in range(len(bad)):
+        for cw in range(4):
+            ne = (f + cw * 5) % 19  # 0..18 errors: beyond t=16 -> uncorrectable (-1)
+            pos = rng.choice(255, ne, replace=False)
+            for p in pos:
+                bad[f, 4 + p * 4 + cw] ^= rng.integers(1, 256)
+    dec, err = ref.rs_decode(bad, I=4, dualbasis=True, fill_bytes=-1)
+    dec0, err0 = ref.rs_decode(bad, I=4, dualbasis=True, fill_bytes=0)
+    out["rs"] = dict(frames=bad, dec=dec, err=err, dec_fill0=dec0, err_fill0=err0)
+
+    # ---- concatenated decoder, BPSK (GOES) and QPSK (NPP), incl. a polarity inversion + garbage gap (sync loss)
+    for name, const, oconst, sigma in [("bpsk", "bpsk", pyref.BPSK, 28.0), ("qpsk", "qpsk", pyref.QPSK, 55.0)]:
+        spec = synth.SynthSpec(constellation=const, samplerate=3e6, symbolrate=1e6, nrzm=True, seed=21)
+        cadus = synth.make_cadus(14, seed=21)
+        syms = synth.frames_to_symbols(cadus, spec)
+        soft = synth.soft_from_symbols(syms, spec, sigma=sigma, seed=21)
+        rng = np.random.default_rng(5)
+        gap = rng.integers(-127, 128, 3 * 8192).astype(np.int8)
+        half = (len(soft) // 2) // 8192 * 8192
+        soft = np.concatenate([soft[:half], gap, (-soft[half:].astype(np.int16)).clip(-127, 127).astype(np.int8)])
+        cfg = pyref.fec_cfg(constellation=oconst, nrzm=1, rs_usecheck=1)
+        r = ref.concat_decode(cfg, soft)
+        out[f"concat_{name}"] = dict(soft=soft, cadu=r["cadu"], ber=r["ber"], state=r["state"], frm_err=r["frm_err"])
+
+    # ---- MetOp r=3/4
+    spec, cadus, plain, syms = util.metop_case(nframes=12)
+    soft = synth.soft_from_symbols(syms, spec, sigma=40.0, seed=3)
+    r = ref.metop_decode(soft)
+    out["metop"] = dict(soft=soft, cadu=r["cadu"], ber=r["ber"], state=r["state"], frm_err=r["frm_err"])
+
+    # ---- psk_demod chain on cs16 input (the stored samples ARE the input: nothing depends on numpy's RNG)
+    for name, mk, ocfg, n in [
+        ("goes", lambda: util.goes_case(nframes=5), pyref.demod_cfg(samplerate=3e6, symbolrate=927000, constellation=pyref.BPSK, pll_bw=0.02, max_sps=3.0), 120000),
+        ("metop", lambda: util.metop_case(nframes=8), pyref.demod_cfg(), 120000),
+        ("npp", lambda: util.npp_case(nframes=8), pyref.demod_cfg(samplerate=30e6, symbolrate=15e6, constellation=pyref.QPSK, pll_bw=0.002), 120000),
+    ]:
+        spec, cadus, plain, syms = mk()
+        x, _ = synth.modulate(syms, spec)
+        cs16 = synth.to_cs16(x[:n])
+        xin = (cs16.astype(np.float32) * np.float32(1.0 / 32767.0)).view(np.complex64)  # baseband_interface.h:178 (volk_16i_s32f_convert_32f)
+        r = ref.psk_demod(ocfg, xin)
+        out[f"demod_{name}"] = dict(cs16=cs16, soft=r["soft"], syms=r["syms"], buffer_size=np.int32(r["buffer_size"]), final_sps=np.float32(r["final_sps"]))
+
+    # ---- filter designs
+    bank, ir, dr = ref.resamp_bank(2700000, 3000000)
+    out["taps"] = dict(rrc_goes=ref.rrc_taps(2.7e6, 927000, 0.5, 31), rrc_metop=ref.rrc_taps(6e6, 2333333, 0.5, 31), mm=ref.mm_bank(128, 8),
+                       resamp=bank, resamp_ratio=np.array([ir, dr], dtype=np.int32))
+
+    index = []
+    for name, d in out.items():
+        path = os.path.join(HERE, name + ".npz")
+        np.savez_compressed(path, **d)
+        index.append(f"{name}.npz  {os.path.getsize(path):8d} B  " + " ".join(f"{k}:{sha(v)[:12]}" for k, v in sorted(d.items())))
+    with open(os.path.join(HERE, "INDEX.txt"), "w") as f:
+        f.write("# produced by tests/golden/make_golden.py from oracle/_ref (the reference's own code); key:sha256[:12]\n" + "\n".join(index) + "\n")
+    print("\n".join(index))
+
+
+if __name__ == "__main__":
+    main()
