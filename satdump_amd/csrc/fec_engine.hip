@@ -169,6 +169,10 @@ namespace sdhip
         DevBuf<int8_t> d_stage;
         DevBuf<VitBlockIO> d_io;
         DevBuf<uint64_t> d_dec;
+        Vit2Work vit2;
+        std::vector<int> redo_list;
+        DevBuf<int> d_redo;
+        bool use_vit2 = !(getenv("SDHIP_VIT2") && atoi(getenv("SDHIP_VIT2")) == 0);
         DevBuf<uint32_t> d_vbits;
         DevBuf<uint32_t> d_carry[2];
         int carry_sel = 0;
@@ -674,7 +678,8 @@ namespace sdhip
                 vc.shift = v_shift;
                 d_io.reserve(n);
                 h_io.reserve(n);
-                d_dec.reserve((size_t)n * dstride);
+                if (!(use_vit2 && vit2_supported(vc)))
+                    d_dec.reserve((size_t)n * dstride);
                 d_vbits.reserve((size_t)n * wpb + 4);
                 for (int j = 0; j < n; j++)
                 {
@@ -683,25 +688,58 @@ namespace sdhip
                 }
                 h_io.p[0].start_in = dec_first ? -2 : dec_start;
                 SD_HIP(hipMemcpyAsync(d_io.p, h_io.p, (size_t)n * sizeof(VitBlockIO), hipMemcpyHostToDevice, stream));
-                launch_vit_decode(vc, d_soft, pos, n, d_io.p, d_dec.p, d_vbits.p, stream);
+                const bool v2 = use_vit2 && vit2_supported(vc);
+                if (v2)
+                    launch_vit_decode2(vc, d_soft, pos, n, d_io.p, d_vbits.p, vit2, stream);
+                else
+                    launch_vit_decode(vc, d_soft, pos, n, d_io.p, d_dec.p, d_vbits.p, stream);
                 SD_HIP(hipMemcpyAsync(h_io.p, d_io.p, (size_t)n * sizeof(VitBlockIO), hipMemcpyDeviceToHost, stream));
                 SD_HIP(hipStreamSynchronize(stream));
-                // verify the start-state chain; re-decode on a miss (exactness certificate)
-                for (int j = 1; j < n; j++)
+                // Certificates, in rounds (every failing block of a round is decoded again in ONE launch of the
+                // wave-per-block kernel, which is exact within a block given its start state): (1) segment certificate of
+                // the lane-per-segment kernel failed (tb_fallback == 2) -> again from the start state it used; (2) the
+                // start-state chain (cc_decoder.cpp:295-302): start used != state the previous block's chainback returned.
+                unsigned n_cert = 0, n_chain = 0, n_rounds = 0;
+                for (;;)
                 {
-                    stats.tb_respec += h_io.p[j - 1].tb_fallback;
-                    if (h_io.p[j].start_used != h_io.p[j - 1].ret_state)
+                    redo_list.clear();
+                    for (int j = 0; j < n; j++)
                     {
-                        stats.vit_respec++;
-                        VitBlockIO one{};
-                        one.start_in = h_io.p[j - 1].ret_state;
-                        SD_HIP(hipMemcpyAsync(d_io.p + j, &one, sizeof(one), hipMemcpyHostToDevice, stream));
-                        launch_vit_decode(vc, d_soft, pos + j, 1, d_io.p + j, d_dec.p + (size_t)j * dstride, d_vbits.p + (size_t)j * wpb, stream);
-                        SD_HIP(hipMemcpyAsync(h_io.p + j, d_io.p + j, sizeof(one), hipMemcpyDeviceToHost, stream));
-                        SD_HIP(hipStreamSynchronize(stream));
+                        if (j > 0 && h_io.p[j].start_used != h_io.p[j - 1].ret_state)
+                        {
+                            n_chain++;
+                            h_io.p[j].start_in = h_io.p[j - 1].ret_state;
+                            redo_list.push_back(j);
+                        }
+                        else if (h_io.p[j].tb_fallback == 2)
+                        {
+                            n_cert++;
+                            h_io.p[j].start_in = h_io.p[j].start_used;
+                            redo_list.push_back(j);
+                        }
                     }
+                    if (redo_list.empty())
+                        break;
+                    if (++n_rounds > (unsigned)n + 2)
+                        throw HipError("viterbi start-state chain does not converge");
+                    const int nr = (int)redo_list.size();
+                    d_redo.reserve(nr);
+                    d_dec.reserve((size_t)nr * dstride);
+                    SD_HIP(hipMemcpyAsync(d_redo.p, redo_list.data(), (size_t)nr * sizeof(int), hipMemcpyHostToDevice, stream));
+                    SD_HIP(hipMemcpyAsync(d_io.p, h_io.p, (size_t)n * sizeof(VitBlockIO), hipMemcpyHostToDevice, stream));
+                    launch_vit_decode(vc, d_soft, pos, nr, d_io.p, d_dec.p, d_vbits.p, stream, d_redo.p);
+                    SD_HIP(hipMemcpyAsync(h_io.p, d_io.p, (size_t)n * sizeof(VitBlockIO), hipMemcpyDeviceToHost, stream));
+                    SD_HIP(hipStreamSynchronize(stream));
                 }
-                stats.tb_respec += h_io.p[n - 1].tb_fallback;
+                stats.vit_respec += n_chain;
+                stats.tb_respec += n_cert;
+                unsigned n_tbfb = 0;
+                for (int j = 0; j < n; j++)
+                    n_tbfb += h_io.p[j].tb_fallback;
+                stats.tb_respec += n_tbfb;
+                if (getenv("SDHIP_DEBUG"))
+                    fprintf(stderr, "[sdhip] viterbi batch %d blocks (%s): segment-certificate re-decodes %u, start-state re-decodes %u in %u round(s), serial tracebacks %u\n", n,
+                            v2 ? "lane-per-segment" : "wave-per-block", n_cert, n_chain, n_rounds, n_tbfb);
                 // BER estimate of every block, then the lock FSM (viterbi_1_2.cpp:101-113)
                 launch_vit_ber(vc, d_soft, pos, n, d_vbits.p, search.enc_state, d_io.p, stream);
                 SD_HIP(hipMemcpyAsync(h_io.p, d_io.p, (size_t)n * sizeof(VitBlockIO), hipMemcpyDeviceToHost, stream));
@@ -956,17 +994,27 @@ extern "C"
             io[j].start_in = -1;
         io[0].start_in = -2;
         SD_HIP(hipMemcpy(d_io.p, io.data(), io.size() * sizeof(VitBlockIO), hipMemcpyHostToDevice));
-        launch_vit_decode(vc, (const int8_t *)d_syms, 0, nblocks, d_io.p, d_dec.p, d_vb.p, nullptr);
+        Vit2Work vit2;
+        const bool v2 = vit2_supported(vc) && !(getenv("SDHIP_VIT2") && atoi(getenv("SDHIP_VIT2")) == 0);
+        if (v2)
+            launch_vit_decode2(vc, (const int8_t *)d_syms, 0, nblocks, d_io.p, d_vb.p, vit2, nullptr);
+        else
+            launch_vit_decode(vc, (const int8_t *)d_syms, 0, nblocks, d_io.p, d_dec.p, d_vb.p, nullptr);
         SD_HIP(hipMemcpy(io.data(), d_io.p, io.size() * sizeof(VitBlockIO), hipMemcpyDeviceToHost));
-        for (int j = 1; j < nblocks; j++)
-            if (io[j].start_used != io[j - 1].ret_state)
-            {
-                VitBlockIO one{};
-                one.start_in = io[j - 1].ret_state;
-                SD_HIP(hipMemcpy(d_io.p + j, &one, sizeof(one), hipMemcpyHostToDevice));
-                launch_vit_decode(vc, (const int8_t *)d_syms, j, 1, d_io.p + j, d_dec.p + (size_t)j * dstride, d_vb.p + (size_t)j * wpb, nullptr);
-                SD_HIP(hipMemcpy(&io[j], d_io.p + j, sizeof(one), hipMemcpyDeviceToHost));
-            }
+        auto redo = [&](int j, int start) {
+            VitBlockIO one{};
+            one.start_in = start;
+            SD_HIP(hipMemcpy(d_io.p + j, &one, sizeof(one), hipMemcpyHostToDevice));
+            launch_vit_decode(vc, (const int8_t *)d_syms, j, 1, d_io.p + j, d_dec.p + (size_t)j * dstride, d_vb.p + (size_t)j * wpb, nullptr);
+            SD_HIP(hipMemcpy(&io[j], d_io.p + j, sizeof(one), hipMemcpyDeviceToHost));
+        };
+        for (int j = 0; j < nblocks; j++)
+        {
+            if (io[j].tb_fallback == 2)
+                redo(j, io[j].start_used);
+            if (j > 0 && io[j].start_used != io[j - 1].ret_state)
+                redo(j, io[j - 1].ret_state);
+        }
         const long long nb = (long long)nblocks * frame_bits;
         k_unpack_bits<<<dim3((unsigned)((nb + 255) / 256)), dim3(256)>>>(d_vb.p, wpb, frame_bits, nblocks, d_out);
         SD_HIP(hipDeviceSynchronize());

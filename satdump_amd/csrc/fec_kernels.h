@@ -39,8 +39,32 @@ namespace sdhip
     //   io[j]       : control/result words
     //   decisions   : scratch, nblk * (F+6) * 8 bytes (lane-order ACS ballots)
     //   vbits       : packed decoded bits, nblk * words_per_block(F) uint32 (MSB-first byte stream)
+    //   list        : optional device array of nblk block indices (relative to first_block) to decode instead of 0..nblk);
+    //                 io / vbits are indexed by block, the decision scratch by position in the launch
     void launch_vit_decode(const VitCfg &cfg, const int8_t *soft, int64_t first_block, int nblk, VitBlockIO *io, uint64_t *decisions, uint32_t *vbits,
-                           hipStream_t st);
+                           hipStream_t st, const int *list = nullptr);
+
+
+    // ---- packed lane-per-segment decoder (k_vit2_*) ----------------------------------------------------------
+    // Same contract as launch_vit_decode (io[] semantics, packed vbits), different mapping: every block is cut into
+    // segments of VIT2_SEG trellis steps and ONE LANE runs one segment with all 64 path metrics in 32 VGPRs
+    // (two 16-bit metrics per register, v_pk_add_u16 / v_pk_min_u16), see fec_kernels.hip. Segment g > 0 starts
+    // from neutral metrics VIT2_WARM steps early; its exactness certificate is "metric vector after the warm-up ==
+    // metric vector the previous segment ended with" (the decoder is a deterministic function of that vector).
+    // A block whose certificate fails comes back with io[j].tb_fallback == 2 and must be decoded again with
+    // launch_vit_decode(start_in = io[j].start_used).
+    constexpr int VIT2_SEG = 512;   // trellis steps per lane
+    constexpr int VIT2_WARM = 200;  // warm-up steps (multiple of 8)
+    struct Vit2Work
+    {
+        DevBuf<uint16_t> symu;      // per block: [VIT2_WARM prologue | F+6 steps | pad] unsigned symbol pairs (s0 | s1 << 8)
+        DevBuf<uint64_t> dec;       // decisions [step in segment][unit]
+        DevBuf<uint32_t> specx, endx; // 32 packed metric registers per unit
+        DevBuf<int> entry, exitst;  // traceback hand-off states per unit
+    };
+    inline bool vit2_supported(const VitCfg &cfg) { return cfg.F >= 2 * VIT2_SEG && cfg.F % VIT2_SEG == 0; }
+    void launch_vit_decode2(const VitCfg &cfg, const int8_t *soft, int64_t first_block, int nblk, VitBlockIO *io, uint32_t *vbits, Vit2Work &w,
+                            hipStream_t st);
 
     // BER estimate of every block (viterbi_1_2.cpp:101-102 / viterbi_3_4.cpp:156-157): re-encode the first
     // nber decoded bits (encoder register chained through the previous block, enc_state_in for block 0) and

@@ -279,15 +279,18 @@ namespace sdhip
     // =============================================================================================
     constexpr int PRE_LDS = VIT_PREPASS + 8;
 
+    // `list` (optional): the nblk blocks to decode are list[0..nblk) (indices relative to first_block) instead of 0..nblk;
+    // the decision scratch is always indexed by the position in the launch.
     __global__ __launch_bounds__(256) void k_vit_decode(VitCfg c, const int8_t *__restrict__ soft, long long first_block, int nblk, VitBlockIO *io,
-                                                         unsigned long long *decisions, unsigned *vbits, int dstride, int wpb)
+                                                         unsigned long long *decisions, unsigned *vbits, int dstride, int wpb, const int *__restrict__ list)
     {
         __shared__ unsigned long long pre_ballots[4][PRE_LDS];
         const int wave = (int)(threadIdx.x >> 6);
         const int lane = lane_id();
-        const int j = (int)blockIdx.x * 4 + wave;
-        if (j >= nblk)
+        const int slot = (int)blockIdx.x * 4 + wave;
+        if (slot >= nblk)
             return;
+        const int j = list ? list[slot] : slot;
         const int F = c.F, nsteps = F + 6;
         AcsConsts k;
         acs_init_consts(k);
@@ -318,7 +321,7 @@ namespace sdhip
 
         // ---- forward pass over the block ------------------------------------------------------------
         SymFetch f{c, soft + (first_block + j) * (long long)c.B, c.B};
-        unsigned long long *dec = decisions + (size_t)j * dstride;
+        unsigned long long *dec = decisions + (size_t)slot * dstride;
         unsigned X = (start == -2) ? 31u : ((lane == start) ? 0u : 63u); // init_viterbi(_unbiased), cc_decoder.cpp:159-190
         {
             SinkGlobal sk{dec, 0ull};
@@ -420,7 +423,7 @@ namespace sdhip
     }
 
     void launch_vit_decode(const VitCfg &cfg, const int8_t *soft, int64_t first_block, int nblk, VitBlockIO *io, uint64_t *decisions, uint32_t *vbits,
-                           hipStream_t st)
+                           hipStream_t st, const int *list)
     {
         if (nblk <= 0)
             return;
@@ -428,7 +431,414 @@ namespace sdhip
         const int wpb = vit_words_per_block(cfg.F);
         ProfScope _ps("k_vit_decode", st);
         hipLaunchKernelGGL(k_vit_decode, dim3((nblk + 3) / 4), dim3(256), 0, st, cfg, soft, (long long)first_block, nblk, io,
-                           (unsigned long long *)decisions, vbits, dstride, wpb);
+                           (unsigned long long *)decisions, vbits, dstride, wpb, list);
+    }
+
+    // =============================================================================================
+    // k_vit2_*: lane-per-segment decoder, 64 path metrics packed two per VGPR
+    // =============================================================================================
+    // Register r (0..31) holds the metrics of states r (low half) and 63-r (high half). This pairing is the one that is
+    // invariant under the trellis shift: butterfly i (inputs X[i], X[i+32]; outputs Y[2i], Y[2i+1]) and butterfly 31-i
+    // are evaluated by the same packed instructions, and their four outputs land again as (Y[s], Y[63-s]) pairs:
+    //   R1 = R[i]        = (X[i],    X[63-i]) = (A_i, B_i')        R2 = swap(R[31-i]) = (X[i+32], X[31-i]) = (B_i, A_i')
+    //   T1 = R1 + (M, M')       = (m0, m3')      T2 = R2 + (63-M, 63-M')   = (m1, m2')    E = min(T1,T2) = (Y[2i],   Y[63-2i])
+    //   T3 = R1 + (63-M, 63-M') = (m2, m1')      T4 = R2 + (M, M')         = (m3, m0')    O = min(T3,T4) = (Y[2i+1], Y[62-2i])
+    // (M, M' = branch metrics of butterflies i and 31-i; their branch-table bits are complements of each other.)
+    // Values are kept DOUBLED in the 16-bit fields (mask 0x1FE = the reference's uint8 wrap, volk_k7_r2_generic_fixed.h:118-121),
+    // which frees bit 0 as a tie-break tag: decision = (a >= b) is sign(b - a - tag) with the tag on the correct side, so
+    // one v_pk_sub_i16 yields both decisions of a packed pair (low half inverted). The per-step renormalisation
+    // (subtract the minimum, :80-92) is folded into the next step's branch-metric constants.
+    typedef unsigned short v2u16 __attribute__((ext_vector_type(2)));
+    __device__ __forceinline__ v2u16 v2v(unsigned x) { return __builtin_bit_cast(v2u16, x); }
+    __device__ __forceinline__ unsigned v2u(v2u16 x) { return __builtin_bit_cast(unsigned, x); }
+    __device__ __forceinline__ unsigned pk_add(unsigned a, unsigned b) { return v2u(v2v(a) + v2v(b)); }
+    __device__ __forceinline__ unsigned pk_sub(unsigned a, unsigned b) { return v2u(v2v(a) - v2v(b)); }
+    __device__ __forceinline__ unsigned pk_min(unsigned a, unsigned b) { return v2u(__builtin_elementwise_min(v2v(a), v2v(b))); }
+    __device__ __forceinline__ unsigned pk_swap(unsigned a)
+    {
+        const v2u16 v = v2v(a);
+        return v2u(__builtin_shufflevector(v, v, 1, 0));
+    }
+    constexpr unsigned V2_MASK = 0x01FE01FEu, V2_TAG = 0x00010000u;
+    // Constants that feed three-operand ops ((x & m) | y = one v_and_or_b32 / v_bitop3_b32) must live in registers: VOP3
+    // encodings take no literals on gfx9. The asm keeps the compiler from folding them back into literals.
+    struct V2Consts
+    {
+        unsigned tag;     // VGPR
+        unsigned mask;    // SGPR
+        unsigned dm[8];   // SGPR: 0x80808080 >> k
+    };
+    __device__ __forceinline__ void v2_consts(V2Consts &k)
+    {
+        asm volatile("v_mov_b32 %0, 0x10000" : "=v"(k.tag));
+        asm volatile("s_mov_b32 %0, 0x1fe01fe" : "=s"(k.mask));
+        asm volatile("s_mov_b32 %0, 0x80808080" : "=s"(k.dm[0]));
+        asm volatile("s_mov_b32 %0, 0x40404040" : "=s"(k.dm[1]));
+        asm volatile("s_mov_b32 %0, 0x20202020" : "=s"(k.dm[2]));
+        asm volatile("s_mov_b32 %0, 0x10101010" : "=s"(k.dm[3]));
+        asm volatile("s_mov_b32 %0, 0x08080808" : "=s"(k.dm[4]));
+        asm volatile("s_mov_b32 %0, 0x04040404" : "=s"(k.dm[5]));
+        asm volatile("s_mov_b32 %0, 0x02020202" : "=s"(k.dm[6]));
+        asm volatile("s_mov_b32 %0, 0x01010101" : "=s"(k.dm[7]));
+    }
+
+    struct V2State
+    {
+        unsigned R[32]; // (2*Y[r] | tag, 2*Y[63-r] | tag), not yet renormalised
+        unsigned C2;    // 2*min(Y) in both halves: true metric = ((half - C) & 0x1FE) >> 1
+    };
+    __device__ __forceinline__ void v2_init_neutral(V2State &s)
+    {
+#pragma unroll
+        for (int r = 0; r < 32; r++)
+            s.R[r] = 0u;
+        s.C2 = 0u;
+    }
+    // init_viterbi / init_viterbi_unbiased, cc_decoder.cpp:159-190
+    __device__ __forceinline__ void v2_init_start(V2State &s, int start)
+    {
+        const unsigned all = (start == -2) ? 62u : 126u;
+#pragma unroll
+        for (int r = 0; r < 32; r++)
+        {
+            unsigned lo = all, hi = all;
+            if (start == r)
+                lo = 0u;
+            if (start == 63 - r)
+                hi = 0u;
+            s.R[r] = lo | (hi << 16);
+        }
+        s.C2 = 0u;
+    }
+    // normalised packed metrics (for the certificate and the end state)
+    __device__ __forceinline__ unsigned v2_norm(const V2State &s, int r) { return pk_sub(s.R[r], s.C2) & V2_MASK; }
+
+    // find_endstate (cc_decoder.cpp:192-209): first state index holding the minimum metric
+    __device__ __forceinline__ unsigned v2_endstate(const V2State &s)
+    {
+        unsigned best = 0xFFFFu, idx = 0;
+#pragma unroll
+        for (int st = 0; st < 64; st++)
+        {
+            const int r = st < 32 ? st : 63 - st;
+            const unsigned v = v2_norm(s, r);
+            const unsigned x = st < 32 ? (v & 0xFFFFu) : (v >> 16);
+            if (x < best)
+            {
+                best = x;
+                idx = (unsigned)st;
+            }
+        }
+        return idx;
+    }
+
+    // decision bit of NEW state st in the two decision words of a step
+    __device__ __forceinline__ unsigned v2_dec_bit(unsigned w0, unsigned w1, unsigned st)
+    {
+        const unsigned r = st < 32u ? st : 63u - st;
+        const unsigned i = r >> 1;
+        const unsigned byte = (st < 32u ? 0u : 1u) + ((r & 1u) << 1);
+        const unsigned w = (i & 8u) ? w1 : w0;
+        return (w >> (byte * 8u + 7u - (i & 7u))) & 1u;
+    }
+
+    // one trellis step on symbol pair sym = s0 | s1 << 8
+    template <bool DEC>
+    __device__ __forceinline__ void v2_step(V2State &s, const V2Consts &kc, unsigned sym, unsigned &w0, unsigned &w1)
+    {
+        const unsigned s0 = sym & 255u, s1 = (sym >> 8) & 255u;
+        const unsigned a[2] = {s0, s0 ^ 255u}, c[2] = {s1, s1 ^ 255u};
+        // BFLY metric (volk_k7_r2_generic_fixed.h:110-113), doubled: class = b0*2 + b1 (Branchtab bits of the butterfly)
+        unsigned D[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            D[k] = ((a[k >> 1] + c[k & 1] + 1u) >> 2) & 0x7Eu;
+        const unsigned Q = pk_sub(0x007E007Eu, s.C2);
+        unsigned K1[4], K2[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+        {
+            const unsigned PD = D[k] | (D[3 - k] << 16); // (this butterfly's class, the complementary class of butterfly 31-i)
+            K1[k] = pk_sub(PD, s.C2);
+            K2[k] = pk_sub(Q, PD);
+        }
+        unsigned Rn[32];
+        unsigned mnA = 0xFFFFFFFFu, mnB = 0xFFFFFFFFu;
+        unsigned acc0 = 0u, acc1 = 0u;
+#pragma unroll
+        for (int i = 0; i < 16; i++)
+        {
+            // Branchtab (cc_decoder.cpp:116-123, polys 79 / 109): b0 = parity(2i & 79) = i0^i1^i2, b1 = parity(2i & 109) = i1^i2^i4
+            const int b0 = (i ^ (i >> 1) ^ (i >> 2)) & 1, b1 = ((i >> 1) ^ (i >> 2) ^ (i >> 4)) & 1;
+            const int k = b0 * 2 + b1;
+            const unsigned R1 = s.R[i], R2 = pk_swap(s.R[31 - i]);
+            const unsigned T1 = pk_add(R1, K1[k]) & V2_MASK;
+            const unsigned T2 = (pk_add(R2, K2[k]) & kc.mask) | kc.tag;
+            const unsigned T3 = pk_add(R1, K2[k]) & V2_MASK;
+            const unsigned T4 = (pk_add(R2, K1[k]) & kc.mask) | kc.tag;
+            const unsigned E = pk_min(T1, T2), O = pk_min(T3, T4);
+            Rn[2 * i] = E;
+            Rn[2 * i + 1] = O;
+            mnA = pk_min(mnA, E);
+            mnB = pk_min(mnB, O);
+            if (DEC)
+            {
+                const unsigned dE = pk_sub(T1, T2), dO = pk_sub(T3, T4);
+                // bytes: [dE.lo sign, dE.hi sign, dO.lo sign, dO.hi sign] in bit 7 of each byte
+                const unsigned p = __builtin_amdgcn_perm(dO, dE, 0x07050301u);
+                if (i < 8)
+                    acc0 = ((p >> (i & 7)) & kc.dm[i & 7]) | acc0;
+                else
+                    acc1 = ((p >> (i & 7)) & kc.dm[i & 7]) | acc1;
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 32; r++)
+            s.R[r] = Rn[r];
+        const unsigned mn = pk_min(mnA, mnB);
+        const unsigned m1 = min(mn & 0xFFFFu, mn >> 16) & 0xFFFEu;
+        s.C2 = m1 | (m1 << 16);
+        if (DEC)
+        {
+            w0 = acc0 ^ 0x00FF00FFu; // low-half signs are inverted decisions
+            w1 = acc1 ^ 0x00FF00FFu;
+        }
+    }
+
+    // ---- symbol staging: row j = [VIT2_WARM last steps of block j-1 | steps 0..F+5 of block j | erasures]
+    __global__ __launch_bounds__(256) void k_vit2_prep(VitCfg c, const int8_t *__restrict__ soft, long long first_block, int nblk, unsigned short *symu, int SU)
+    {
+        const int j = (int)blockIdx.y;
+        const int r = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+        if (j >= nblk || r >= SU)
+            return;
+        const TailErasure erasure;
+        const int nsteps = c.F + 6;
+        unsigned v = 128u | (128u << 8);
+        if (r < VIT2_WARM)
+        {
+            if (first_block + j > 0)
+            {
+                SymFetch pf{c, soft + (first_block + j - 1) * (long long)c.B, c.B};
+                v = pf.pair(nsteps - VIT2_WARM + r, erasure);
+            }
+        }
+        else if (r < VIT2_WARM + nsteps)
+        {
+            SymFetch f{c, soft + (first_block + j) * (long long)c.B, c.B};
+            v = f.pair(r - VIT2_WARM, erasure);
+        }
+        symu[(size_t)j * SU + r] = (unsigned short)v;
+    }
+
+    // ---- forward pass: one lane per (block, segment)
+    template <bool DEC>
+    __device__ __forceinline__ void v2_group(V2State &s, const V2Consts &kc, const uint4 q, unsigned (&w)[8][2])
+    {
+        const unsigned d[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+        {
+            const unsigned sym = (d[k >> 1] >> ((k & 1) * 16)) & 0xFFFFu;
+            v2_step<DEC>(s, kc, sym, w[k][0], w[k][1]);
+        }
+    }
+
+    #ifndef V2_WAVES
+#define V2_WAVES 2
+#endif
+    __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(V2_WAVES, V2_WAVES))) void k_vit2_acs(int F, int NSEG, int nblk, const unsigned short *__restrict__ symu, int SU, VitBlockIO *io,
+                                                      unsigned long long *dec, long long U64, unsigned *specx, unsigned *endx)
+    {
+        const int u = (int)(blockIdx.x * 64 + threadIdx.x);
+        if (u >= nblk * NSEG)
+            return;
+        const int j = u / NSEG, g = u - j * NSEG;
+        const int S = VIT2_SEG;
+        const uint4 *row = reinterpret_cast<const uint4 *>(symu + (size_t)j * SU + (size_t)g * S); // 8 steps per uint4
+        V2State s;
+        v2_init_neutral(s);
+        V2Consts kc;
+        v2_consts(kc);
+        unsigned w[8][2];
+        // ---- warm-up over the VIT2_WARM steps in front of the segment
+        constexpr int WG = VIT2_WARM / 8;
+        uint4 q = row[0];
+        for (int grp = 0; grp < WG - 1; grp++)
+        {
+            const uint4 nq = row[grp + 1];
+            v2_group<false>(s, kc, q, w);
+            q = nq;
+        }
+        {
+            const uint4 nq = row[WG];
+            v2_group<true>(s, kc, q, w); // the last 6 decisions are the chained start state's chainback (g == 0)
+            q = nq;
+        }
+        if (g == 0)
+        {
+            int start = io[j].start_in;
+            if (start == -1)
+            {
+                // state 6 steps before the end state of the previous block (cc_decoder.cpp:250-260, 295-302)
+                unsigned st = v2_endstate(s);
+#pragma unroll
+                for (int k = 7; k >= 2; k--)
+                {
+                    const unsigned kb = v2_dec_bit(w[k][0], w[k][1], st);
+                    st = (st >> 1) | (kb << 5);
+                }
+                start = (int)st;
+            }
+            v2_init_start(s, start);
+            io[j].start_used = start;
+        }
+        else
+        {
+#pragma unroll
+            for (int r = 0; r < 32; r++)
+                specx[(size_t)u * 32 + r] = v2_norm(s, r);
+        }
+        // ---- the segment itself: S steps (the last segment of a block: S + 6)
+        unsigned long long *d = dec + u;
+        for (int grp = 0; grp < S / 8; grp++)
+        {
+            const uint4 nq = row[WG + grp + 1];
+            v2_group<true>(s, kc, q, w);
+            q = nq;
+#pragma unroll
+            for (int k = 0; k < 8; k++)
+                d[(size_t)(grp * 8 + k) * U64] = (unsigned long long)w[k][0] | ((unsigned long long)w[k][1] << 32);
+        }
+        if (g == NSEG - 1)
+        {
+            unsigned wl[6][2];
+            const unsigned dd[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+            for (int k = 0; k < 6; k++)
+            {
+                const unsigned sym = (dd[k >> 1] >> ((k & 1) * 16)) & 0xFFFFu;
+                v2_step<true>(s, kc, sym, wl[k][0], wl[k][1]);
+                d[(size_t)(S + k) * U64] = (unsigned long long)wl[k][0] | ((unsigned long long)wl[k][1] << 32);
+            }
+            const unsigned endstate = v2_endstate(s);
+            unsigned ret = endstate; // chained start state for the next block: state after steps F+5..F (cc_decoder.cpp:250-260,275)
+#pragma unroll
+            for (int k = 5; k >= 0; k--)
+            {
+                const unsigned kb = v2_dec_bit(wl[k][0], wl[k][1], ret);
+                ret = (ret >> 1) | (kb << 5);
+            }
+            io[j].end_state = (int)endstate;
+            io[j].ret_state = (int)ret;
+        }
+        else
+        {
+#pragma unroll
+            for (int r = 0; r < 32; r++)
+                endx[(size_t)u * 32 + r] = v2_norm(s, r);
+        }
+    }
+
+    // ---- traceback: one lane per (block, segment); bits [g*S, (g+1)*S) <- decisions at steps n + 6
+    __global__ __launch_bounds__(64) void k_vit2_tb(int F, int NSEG, int nblk, const VitBlockIO *io, const unsigned long long *__restrict__ dec, long long U64,
+                                                     unsigned *vbits, int wpb, int *entry, int *exitst)
+    {
+        const int u = (int)(blockIdx.x * 64 + threadIdx.x);
+        if (u >= nblk * NSEG)
+            return;
+        const int j = u / NSEG, g = u - j * NSEG;
+        const int S = VIT2_SEG;
+        const int t_hi = (g + 1) * S + 5;
+        int tstart = t_hi + VIT_TB_OVERLAP;
+        if (tstart > F + 5)
+            tstart = F + 5;
+        unsigned st = (tstart == F + 5) ? (unsigned)io[j].end_state : 0u;
+        const long long ubase = (long long)j * NSEG;
+        auto rec = [&](int t) -> unsigned long long {
+            int gg = t / S;
+            if (gg > NSEG - 1)
+                gg = NSEG - 1;
+            return dec[(size_t)(t - gg * S) * U64 + ubase + gg];
+        };
+        for (int t = tstart; t > t_hi; t--) // overlap: converge onto the survivor path
+        {
+            const unsigned long long r = rec(t);
+            const unsigned kb = v2_dec_bit((unsigned)r, (unsigned)(r >> 32), st);
+            st = (st >> 1) | (kb << 5);
+        }
+        entry[u] = (int)st;
+        unsigned *vb = vbits + (size_t)j * wpb + (size_t)g * (S / 32);
+        for (int wd = S / 32 - 1; wd >= 0; wd--)
+        {
+            unsigned long long r[32];
+            const int tb = g * S + wd * 32 + 6;
+#pragma unroll
+            for (int b = 0; b < 32; b++)
+                r[b] = rec(tb + b);
+            unsigned word = 0;
+#pragma unroll
+            for (int b = 31; b >= 0; b--)
+            {
+                const unsigned kb = v2_dec_bit((unsigned)r[b], (unsigned)(r[b] >> 32), st);
+                st = (st >> 1) | (kb << 5);
+                word |= kb << (31 - b);
+            }
+            vb[wd] = word;
+        }
+        exitst[u] = (int)st;
+    }
+
+    // ---- certificates: segment g's warm-up metrics == segment g-1's end metrics; traceback entry[g] == exit[g+1]
+    __global__ __launch_bounds__(64) void k_vit2_cert(int NSEG, int nblk, const unsigned *__restrict__ specx, const unsigned *__restrict__ endx,
+                                                       const int *__restrict__ entry, const int *__restrict__ exitst, VitBlockIO *io)
+    {
+        const int j = (int)(blockIdx.x * 64 + threadIdx.x);
+        if (j >= nblk)
+            return;
+        int fail = 0;
+        for (int g = 1; g < NSEG; g++)
+        {
+            const size_t u = (size_t)j * NSEG + g;
+            for (int r = 0; r < 32; r++)
+                fail |= specx[u * 32 + r] != endx[(u - 1) * 32 + r];
+            fail |= entry[u - 1] != exitst[u];
+        }
+        io[j].tb_fallback = fail ? 2 : 0;
+    }
+
+    void launch_vit_decode2(const VitCfg &cfg, const int8_t *soft, int64_t first_block, int nblk, VitBlockIO *io, uint32_t *vbits, Vit2Work &w, hipStream_t st)
+    {
+        if (nblk <= 0)
+            return;
+        const int F = cfg.F, S = VIT2_SEG, NSEG = F / S;
+        const int SU = (VIT2_WARM + F + 6 + 8 + 7) / 8 * 8; // one spare group: the forward pass prefetches 8 steps ahead
+        const long long U = (long long)nblk * NSEG, U64 = (U + 63) / 64 * 64;
+        w.symu.reserve((size_t)nblk * SU + 64);
+        w.dec.reserve((size_t)(S + 8) * U64);
+        w.specx.reserve((size_t)U * 32);
+        w.endx.reserve((size_t)U * 32);
+        w.entry.reserve((size_t)U);
+        w.exitst.reserve((size_t)U);
+        const int wpb = vit_words_per_block(F);
+        {
+            ProfScope _ps("k_vit2_prep", st);
+            hipLaunchKernelGGL(k_vit2_prep, dim3((SU + 255) / 256, nblk), dim3(256), 0, st, cfg, soft, (long long)first_block, nblk, w.symu.p, SU);
+        }
+        {
+            ProfScope _ps("k_vit2_acs", st);
+            hipLaunchKernelGGL(k_vit2_acs, dim3((unsigned)(U64 / 64)), dim3(64), 0, st, F, NSEG, nblk, w.symu.p, SU, io, (unsigned long long *)w.dec.p, U64,
+                               w.specx.p, w.endx.p);
+        }
+        {
+            ProfScope _ps("k_vit2_tb", st);
+            hipLaunchKernelGGL(k_vit2_tb, dim3((unsigned)(U64 / 64)), dim3(64), 0, st, F, NSEG, nblk, io, (const unsigned long long *)w.dec.p, U64, vbits, wpb,
+                               w.entry.p, w.exitst.p);
+        }
+        {
+            ProfScope _ps("k_vit2_cert", st);
+            hipLaunchKernelGGL(k_vit2_cert, dim3((nblk + 63) / 64), dim3(64), 0, st, NSEG, nblk, w.specx.p, w.endx.p, w.entry.p, w.exitst.p, io);
+        }
     }
 
     // =============================================================================================
