@@ -100,7 +100,8 @@ namespace sdhip
         std::vector<cf32> hist_in, hist_agc, hist_cos; // DEMOD_HIST samples each (history in front of stage inputs)
 
         // device
-        DevBuf<cf32> bufA, bufB, symbuf, d_hist;
+        DevBuf<cf32> bufA, bufB, symbuf, d_hist, d_hist_in;
+        bool resample_sw_ok = false; // the static-window resampler (which can read the caller's buffer in place) covers this ratio
         DevBuf<float> d_rrc, d_mmbank, d_rbank;
         DevBuf<AgcState> d_agc_spec, d_agc_end, d_agc_start;
         DevBuf<CostasState> d_cos_spec, d_cos_end, d_cos_start;
@@ -241,6 +242,8 @@ namespace sdhip
             hist_agc.assign(DEMOD_HIST, cf32{0, 0});
             hist_cos.assign(DEMOD_HIST, cf32{0, 0});
             d_hist.reserve(DEMOD_HIST);
+            d_hist_in.reserve(DEMOD_HIST);
+            resample_sw_ok = resample && r_ntaps == 38 && r_decim == 10 && r_interp <= 64;
             d_agc_start.reserve(1);
             d_cos_start.reserve(1);
             d_mm_start.reserve(1);
@@ -352,8 +355,15 @@ namespace sdhip
             cf32 *A = bufA.p + DEMOD_HIST, *B = bufB.p + DEMOD_HIST;
             stats.samples_in += n;
 
-            // ---- stage 0: format conversion (+ iq_swap)
-            launch_convert(d_in, fmt, cfg.iq_swap, n, A, stream);
+            // ---- stage 0: format conversion (+ iq_swap). cf32 without swap is already the stage format: the first stage reads
+            // the caller's buffer in place (16-byte aligned pointers only: the lanes move float4 blocks).
+            const bool in_place = fmt == SDHIP_FMT_CF32 && !cfg.iq_swap && !cfg.dc_block && (reinterpret_cast<uintptr_t>(d_in) & 15) == 0 &&
+                                  !(resample && !resample_sw_ok);
+            const cf32 *SRC = A;
+            if (in_place)
+                SRC = reinterpret_cast<const cf32 *>(d_in);
+            else
+                launch_convert(d_in, fmt, cfg.iq_swap, n, A, stream);
             if (cfg.dc_block)
             {
                 SD_HIP(hipMemcpyAsync(d_dc.p, &dc_s, sizeof(dc_s), hipMemcpyHostToDevice, stream));
@@ -364,13 +374,30 @@ namespace sdhip
             // ---- rational resampler
             if (resample)
             {
-                put_hist(A, hist_in);
+                if (in_place)
+                    SD_HIP(hipMemcpyAsync(d_hist_in.p, hist_in.data(), DEMOD_HIST * sizeof(cf32), hipMemcpyHostToDevice, stream));
+                else
+                    put_hist(A, hist_in);
                 // outputs m with inc0 + (ctr0 + m*decim)/interp < n
                 const long long lim = (n - r_inc) * (long long)r_interp - r_ctr;
                 const long long nout = lim > 0 ? (lim + r_decim - 1) / r_decim : 0;
                 ResampParams rp{(int)r_interp, (int)r_decim, r_ntaps, d_rbank.p};
-                launch_resample(A, n, rp, r_ctr, r_inc, B, nout, stream);
-                get_hist(A, n, hist_in);
+                launch_resample(SRC, in_place ? d_hist_in.p : A - DEMOD_HIST, n, rp, r_ctr, r_inc, B, nout, stream);
+                if (in_place && n >= DEMOD_HIST)
+                {
+                    SD_HIP(hipMemcpyAsync(hist_in.data(), SRC + n - DEMOD_HIST, DEMOD_HIST * sizeof(cf32), hipMemcpyDeviceToHost, stream));
+                    SD_HIP(hipStreamSynchronize(stream));
+                }
+                else if (in_place)
+                { // short call: slide the host history
+                    std::vector<cf32> t(n);
+                    SD_HIP(hipMemcpyAsync(t.data(), SRC, (size_t)n * sizeof(cf32), hipMemcpyDeviceToHost, stream));
+                    SD_HIP(hipStreamSynchronize(stream));
+                    hist_in.erase(hist_in.begin(), hist_in.begin() + n);
+                    hist_in.insert(hist_in.end(), t.begin(), t.end());
+                }
+                else
+                    get_hist(A, n, hist_in);
                 const long long ph_end = r_ctr + nout * (long long)r_decim;
                 r_inc = (int)(r_inc + ph_end / r_interp - n);
                 r_ctr = (int)(ph_end % r_interp);
@@ -383,13 +410,14 @@ namespace sdhip
 
             // ---- AGC (speculative)
             {
+                const cf32 *AIN = (in_place && !resample) ? SRC : A; // k_chunks never loads outside [chunk begin - W, chunk end)
                 // warm-up length ~ 24 time constants of the loop (tau = gain / rate samples), gain estimated from mean |x|
                 float g_est = agc_s.gain;
                 if (!started)
                 {
                     const long long m = std::min<long long>(n, 1 << 16);
                     ProfScope _ps("k_mean_abs", stream);
-                    hipLaunchKernelGGL(k_mean_abs, dim3(64), dim3(256), 0, stream, A, m, d_partial.p);
+                    hipLaunchKernelGGL(k_mean_abs, dim3(64), dim3(256), 0, stream, AIN, m, d_partial.p);
                     double part[64];
                     SD_HIP(hipMemcpyAsync(part, d_partial.p, sizeof(part), hipMemcpyDeviceToHost, stream));
                     SD_HIP(hipStreamSynchronize(stream));
@@ -410,7 +438,7 @@ namespace sdhip
                 d_agc_spec.reserve(g.K);
                 d_agc_end.reserve(g.K);
                 SD_HIP(hipMemcpyAsync(d_agc_start.p, &agc_s, sizeof(agc_s), hipMemcpyHostToDevice, stream));
-                launch_agc(A, B, g, agc_p, d_agc_start.p, d_agc_spec.p, d_agc_end.p, nullptr, 0, stream);
+                launch_agc(AIN, B, g, agc_p, d_agc_start.p, d_agc_spec.p, d_agc_end.p, nullptr, 0, stream);
                 std::vector<AgcState> spec, endst;
                 verify_fix(
                     "agc", g.K, d_agc_spec, d_agc_end, spec, endst,
@@ -424,7 +452,7 @@ namespace sdhip
                         }
                         return false;
                     },
-                    [&](const int *redo, int nr) { launch_agc(A, B, g, agc_p, d_agc_start.p, d_agc_spec.p, d_agc_end.p, redo, nr, stream); });
+                    [&](const int *redo, int nr) { launch_agc(AIN, B, g, agc_p, d_agc_start.p, d_agc_spec.p, d_agc_end.p, redo, nr, stream); });
                 agc_s = endst[g.K - 1];
                 std::swap(A, B);
             }
@@ -521,7 +549,17 @@ namespace sdhip
                 put_hist(A, hist_cos);
                 // timing loop: ~2/(Kd*gain_mu) symbols per time constant with a detector gain Kd well below 1 at low Es/N0
                 // (measured: ~700 symbols at 7 dB BPSK with the default gains)
-                long long W = cfg.warmup > 0 ? cfg.warmup : (long long)(36.0 / std::max(1e-4f, cfg.clock_gain_mu) * final_sps);
+                // gear-shifted warm-up (tools/mm_gear_study.py): ~2.2/gain_mu symbols at 8x the timing gain (rate term frozen) pull the
+                // phase in, ~16/gain_mu symbols at the loop's own gains settle it onto the sequential trajectory
+                // (|dt| p99 < 0.03 sample at GOES' 7 dB, far less for the QPSK configs); 36/gain_mu without the fast gear
+                const double gmu = std::max(1e-4f, cfg.clock_gain_mu);
+                mm_p.fast_mult = (float)env_int("SDHIP_MM_FAST_MULT", 8);
+                mm_p.fast_syms = mm_p.fast_mult > 1.0f ? (int)env_int("SDHIP_MM_FAST_SYMS", (long long)(2.2 / gmu)) : 0;
+                // a re-run costs one lane the whole chunk, so long chunks (large batches) keep the conservative warm-up: it is a
+                // small fraction of L there anyway
+                const double w_full = 36.0 / gmu * final_sps;
+                const double w_gear = mm_p.fast_syms > 0 ? (mm_p.fast_syms + 16.0 / gmu) * final_sps : w_full;
+                long long W = cfg.warmup > 0 ? cfg.warmup : (long long)std::min(w_full, std::max(w_gear, 0.5 * L));
                 W = env_int("SDHIP_W_MM", W);
                 W = (W + 255) / 256 * 256;
                 const ChunkGeom g = make_geom(n, L, (int)W);
@@ -836,7 +874,7 @@ extern "C"
             if ((size_t)nout > out_cap)
                 throw HipError("output too small");
             ResampParams rp{(int)ip, (int)dc, nt, db.p};
-            launch_resample(X, nn, rp, 0, 0, Y, nout, nullptr);
+            launch_resample(X, X - DEMOD_HIST, nn, rp, 0, 0, Y, nout, nullptr);
         }
         else
             throw HipError("unknown block kind");

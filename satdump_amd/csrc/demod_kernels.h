@@ -56,7 +56,9 @@ namespace sdhip
         const float *bank; // [interp][ntaps] device
     };
     // x points at input sample 0 of this call (history at negative indices); phase0 = d_ctr, inc0 = carried inc
-    void launch_resample(const cf32 *x, long long nin, const ResampParams &p, int ctr0, int inc0, cf32 *y, long long nout, hipStream_t st);
+    // hist = the DEMOD_HIST samples preceding x[0]; x - DEMOD_HIST when the history sits in front of the buffer (the generic
+    // kernels require that), a separate buffer when x is the caller's own cf32 input (static-window kernel only)
+    void launch_resample(const cf32 *x, const cf32 *hist, long long nin, const ResampParams &p, int ctr0, int inc0, cf32 *y, long long nout, hipStream_t st);
 
     // ---- AGC -----------------------------------------------------------------------------------------
     struct AgcParams
@@ -101,6 +103,8 @@ namespace sdhip
         const int *rot;
         int order;
         int cap; // output capacity per chunk (symbols)
+        int fast_syms;   // warm-up gear shift: symbols run with mu_gain * fast_mult and the omega term frozen
+        float fast_mult;
     };
     struct MmState
     {

