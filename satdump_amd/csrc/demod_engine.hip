@@ -101,7 +101,6 @@ namespace sdhip
 
         // device
         DevBuf<cf32> bufA, bufB, symbuf, d_hist, d_hist_in;
-        bool resample_sw_ok = false; // the static-window resampler (which can read the caller's buffer in place) covers this ratio
         DevBuf<float> d_rrc, d_mmbank, d_rbank;
         DevBuf<AgcState> d_agc_spec, d_agc_end, d_agc_start;
         DevBuf<CostasState> d_cos_spec, d_cos_end, d_cos_start;
@@ -243,7 +242,6 @@ namespace sdhip
             hist_cos.assign(DEMOD_HIST, cf32{0, 0});
             d_hist.reserve(DEMOD_HIST);
             d_hist_in.reserve(DEMOD_HIST);
-            resample_sw_ok = resample && r_ntaps == 38 && r_decim == 10 && r_interp <= 64;
             d_agc_start.reserve(1);
             d_cos_start.reserve(1);
             d_mm_start.reserve(1);
@@ -357,8 +355,7 @@ namespace sdhip
 
             // ---- stage 0: format conversion (+ iq_swap). cf32 without swap is already the stage format: the first stage reads
             // the caller's buffer in place (16-byte aligned pointers only: the lanes move float4 blocks).
-            const bool in_place = fmt == SDHIP_FMT_CF32 && !cfg.iq_swap && !cfg.dc_block && (reinterpret_cast<uintptr_t>(d_in) & 15) == 0 &&
-                                  !(resample && !resample_sw_ok);
+            const bool in_place = fmt == SDHIP_FMT_CF32 && !cfg.iq_swap && !cfg.dc_block && (reinterpret_cast<uintptr_t>(d_in) & 15) == 0;
             const cf32 *SRC = A;
             if (in_place)
                 SRC = reinterpret_cast<const cf32 *>(d_in);

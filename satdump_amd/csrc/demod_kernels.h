@@ -56,8 +56,8 @@ namespace sdhip
         const float *bank; // [interp][ntaps] device
     };
     // x points at input sample 0 of this call (history at negative indices); phase0 = d_ctr, inc0 = carried inc
-    // hist = the DEMOD_HIST samples preceding x[0]; x - DEMOD_HIST when the history sits in front of the buffer (the generic
-    // kernels require that), a separate buffer when x is the caller's own cf32 input (static-window kernel only)
+    // hist = the DEMOD_HIST samples preceding x[0]: x - DEMOD_HIST when the history sits in front of a stage buffer, a separate
+    // buffer when x is the caller's own cf32 input read in place; nothing at or past x[nin] is read
     void launch_resample(const cf32 *x, const cf32 *hist, long long nin, const ResampParams &p, int ctr0, int inc0, cf32 *y, long long nout, hipStream_t st);
 
     // ---- AGC -----------------------------------------------------------------------------------------

@@ -170,7 +170,10 @@ namespace sdhip
     // are staged in LDS with coalesced loads; every thread then accumulates 4 independent outputs tap by tap, oldest
     // sample first, mul and add rounded separately exactly like the scalar reference loop (rational_resampler.cpp:49-56 ->
     // volk generic dot product).
-    __global__ __launch_bounds__(RS_BLOCK) void k_resample(const cf32 *x, ResampParams p, int ctr0, int inc0, cf32 *y, long long nout)
+    // x may be the caller's own cf32 buffer (read in place): samples at negative indices come from `hist` (the DEMOD_HIST
+    // samples preceding x[0]) and nothing at or past nin is touched.
+    __global__ __launch_bounds__(RS_BLOCK) void k_resample(const cf32 *x, const cf32 *hist, long long nin, ResampParams p, int ctr0, int inc0, cf32 *y,
+                                                           long long nout)
     {
         __shared__ float bank[RS_MAX_BANK];
         __shared__ v2f tile[RS_MAX_TILE];
@@ -184,9 +187,12 @@ namespace sdhip
         const long long first = inc0 + ((long long)ctr0 + m0 * p.decim) / p.interp - (p.ntaps - 1);
         const long long last = inc0 + ((long long)ctr0 + mlast * p.decim) / p.interp;
         const int span = (int)(last - first + 1);
-        const v2f *xs = reinterpret_cast<const v2f *>(x) + first;
         for (int i = (int)threadIdx.x; i < span; i += RS_BLOCK)
-            tile[i] = xs[i];
+        {
+            const long long idx = first + i;
+            const cf32 v = (idx < 0) ? hist[DEMOD_HIST + idx] : (idx < nin ? x[idx] : cf32{0.0f, 0.0f});
+            tile[i] = v2f{v.re, v.im};
+        }
         __syncthreads();
         v2f acc[RS_PER];
         int off[RS_PER], row[RS_PER];
@@ -219,69 +225,9 @@ namespace sdhip
                 reinterpret_cast<v2f *>(y)[m] = acc[r];
         }
     }
-    // Static-window variant for a known (taps per phase, decimation) pair. A thread computes J outputs of ONE polyphase
-    // arm (outputs interp apart; their input windows advance by exactly `decim` samples), so the arm's taps are read once
-    // per tap for J outputs and the NT + D*(J-1) input samples the J windows cover are read from LDS ONCE into registers:
-    // ~4x fewer LDS bytes per output than k_resample, which leaves the packed multiplies/adds as the bound. Same
-    // arithmetic: per output, taps oldest-first, mul and add rounded separately.
-    template <int NT, int D, int J>
-    __global__ __launch_bounds__(256) void k_resample_sw(const cf32 *x, const cf32 *hist, long long nin, ResampParams p, int ctr0, int inc0, cf32 *y,
-                                                          long long nout, int G, int span_max)
-    {
-        extern __shared__ float smem[];
-        float *bank = smem;                                            // interp * NT
-        v2f *tile = reinterpret_cast<v2f *>(smem + ((p.interp * NT + 1) & ~1)); // span_max samples
-        const int tile_out = p.interp * G * J;
-        const long long m0 = (long long)blockIdx.x * tile_out;
-        for (int i = (int)threadIdx.x; i < p.interp * NT; i += 256)
-            bank[i] = p.bank[i];
-        const long long first = inc0 + ((long long)ctr0 + m0 * p.decim) / p.interp - (NT - 1);
-        for (int i = (int)threadIdx.x; i < span_max; i += 256)
-        {
-            const long long idx = first + i;
-            const cf32 v = (idx < 0) ? hist[DEMOD_HIST + idx] : (idx < nin ? x[idx] : cf32{0.0f, 0.0f}); // x may be the caller's buffer: never read past it
-            tile[i] = v2f{v.re, v.im};
-        }
-        __syncthreads();
-        const int t = (int)threadIdx.x;
-        const int g = t / p.interp, slot = t - g * p.interp;
-        if (g >= G)
-            return;
-        const long long mfirst = m0 + slot + (long long)p.interp * (g * J);
-        const long long ph = (long long)ctr0 + mfirst * p.decim;
-        const int off = (int)(inc0 + ph / p.interp - (NT - 1) - first);
-        const float *row = bank + (int)(ph % p.interp) * NT;
-        v2f xw[NT + D * (J - 1)];
-#pragma unroll
-        for (int i = 0; i < NT + D * (J - 1); i++)
-            xw[i] = tile[off + i];
-        v2f acc[J];
-#pragma unroll
-        for (int j = 0; j < J; j++)
-            acc[j] = v2f{0.0f, 0.0f};
-#pragma unroll
-        for (int k = 0; k < NT; k++)
-        {
-            const float tk = row[k];
-            const v2f tt{tk, tk};
-#pragma unroll
-            for (int j = 0; j < J; j++)
-            {
-                const v2f prod = xw[D * j + k] * tt;
-                acc[j] = acc[j] + prod;
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < J; j++)
-        {
-            const long long m = mfirst + (long long)p.interp * j;
-            if (m < nout)
-                reinterpret_cast<v2f *>(y)[m] = acc[j];
-        }
-    }
-
     // fallback for banks / spans that do not fit the LDS budget (very large interpolation factors)
-    __global__ __launch_bounds__(256) void k_resample_big(const cf32 *x, ResampParams p, int ctr0, int inc0, cf32 *y, long long nout)
+    __global__ __launch_bounds__(256) void k_resample_big(const cf32 *x, const cf32 *hist, long long nin, ResampParams p, int ctr0, int inc0, cf32 *y,
+                                                           long long nout)
     {
         const long long m = (long long)blockIdx.x * blockDim.x + threadIdx.x;
         if (m >= nout)
@@ -290,11 +236,12 @@ namespace sdhip
         const long long inc = inc0 + ph / p.interp;
         const int ctr = (int)(ph % p.interp);
         const float *t = p.bank + (size_t)ctr * p.ntaps;
-        const cf32 *b = x + inc - (p.ntaps - 1);
+        const long long b = inc - (p.ntaps - 1);
         float re = 0.0f, im = 0.0f;
         for (int k = 0; k < p.ntaps; k++)
         {
-            const cf32 v = b[k];
+            const long long idx = b + k;
+            const cf32 v = (idx < 0) ? hist[DEMOD_HIST + idx] : (idx < nin ? x[idx] : cf32{0.0f, 0.0f});
             const float tk = t[k];
             re = re + v.re * tk;
             im = im + v.im * tk;
@@ -302,42 +249,21 @@ namespace sdhip
         y[m].re = re;
         y[m].im = im;
     }
-    template <int NT, int D, int J>
-    static bool try_resample_sw(const cf32 *x, const cf32 *hist, long long nin, const ResampParams &p, int ctr0, int inc0, cf32 *y, long long nout, hipStream_t st)
-    {
-        if (p.ntaps != NT || p.decim != D || p.interp > 64 || NT > DEMOD_HIST)
-            return false;
-        const int G = 256 / p.interp;
-        const int tile_out = p.interp * G * J;
-        const int span_max = (int)(((long long)tile_out * p.decim) / p.interp + NT + D * (J - 1) + 4);
-        const size_t lds = (size_t)(((p.interp * NT + 1) & ~1) + 2 * span_max) * sizeof(float);
-        if (lds > 60000)
-            return false;
-        ProfScope _ps("k_resample_sw", st);
-        hipLaunchKernelGGL((k_resample_sw<NT, D, J>), dim3((unsigned)((nout + tile_out - 1) / tile_out)), dim3(256), lds, st, x, hist, nin, p, ctr0, inc0, y, nout, G,
-                           span_max);
-        return true;
-    }
-
     void launch_resample(const cf32 *x, const cf32 *hist, long long nin, const ResampParams &p, int ctr0, int inc0, cf32 *y, long long nout, hipStream_t st)
     {
         if (nout <= 0)
             return;
-        // GOES HRIT 3 Msps -> 2.7 Msps: 9/10, 38 taps per arm (the ratio BASELINE.json configs[1] exercises)
-        if (try_resample_sw<38, 10, 4>(x, hist, nin, p, ctr0, inc0, y, nout, st))
-            return;
-        if (hist != x - DEMOD_HIST)
-            throw HipError("generic resampler needs the history in front of the input buffer");
+
         const long long span_max = ((long long)RS_BLOCK * RS_PER * p.decim) / p.interp + p.ntaps + 2;
         if (p.interp * p.ntaps <= RS_MAX_BANK && span_max <= RS_MAX_TILE)
         {
             ProfScope _ps("k_resample", st);
-            hipLaunchKernelGGL(k_resample, dim3((unsigned)((nout + RS_BLOCK * RS_PER - 1) / (RS_BLOCK * RS_PER))), dim3(RS_BLOCK), 0, st, x, p, ctr0, inc0, y, nout);
+            hipLaunchKernelGGL(k_resample, dim3((unsigned)((nout + RS_BLOCK * RS_PER - 1) / (RS_BLOCK * RS_PER))), dim3(RS_BLOCK), 0, st, x, hist, nin, p, ctr0, inc0, y, nout);
         }
         else
         {
             ProfScope _ps("k_resample_big", st);
-            hipLaunchKernelGGL(k_resample_big, dim3((unsigned)((nout + 255) / 256)), dim3(256), 0, st, x, p, ctr0, inc0, y, nout);
+            hipLaunchKernelGGL(k_resample_big, dim3((unsigned)((nout + 255) / 256)), dim3(256), 0, st, x, hist, nin, p, ctr0, inc0, y, nout);
         }
     }
 
@@ -383,72 +309,10 @@ namespace sdhip
                 reinterpret_cast<v2f *>(y)[i] = acc[r];
         }
     }
-    // Static-window variant: a thread computes J CONSECUTIVE outputs, whose NT + J - 1 input samples are read from LDS once
-    // into registers (k_fir reads NT samples per output). Same arithmetic and tap order.
-    template <int NT, int J>
-    __global__ __launch_bounds__(256) void k_fir_sw(const cf32 *x, cf32 *y, long long n, const float *__restrict__ rtaps)
-    {
-        constexpr int TILE = 256 * J;
-        __shared__ v2f tile[TILE + NT + 1];
-        const long long i0 = (long long)blockIdx.x * TILE;
-        long long cnt = n - i0;
-        if (cnt > TILE)
-            cnt = TILE;
-        const int span = (int)cnt + NT - 1;
-        const v2f *xs = reinterpret_cast<const v2f *>(x) + (i0 - (NT - 1));
-        for (int i = (int)threadIdx.x; i < span; i += 256)
-            tile[i] = xs[i];
-        __syncthreads();
-        // lane l of wave w handles outputs (w*64 + l)*J .. +J-1; rows past a ragged end compute on stale LDS, never stored
-        const int o = (int)threadIdx.x * J;
-        v2f xw[NT + J - 1];
-#pragma unroll
-        for (int i = 0; i < NT + J - 1; i++)
-            xw[i] = tile[o + i];
-        v2f acc[J];
-#pragma unroll
-        for (int j = 0; j < J; j++)
-            acc[j] = v2f{0.0f, 0.0f};
-#pragma unroll
-        for (int k = 0; k < NT; k++)
-        {
-            const float t = rtaps[k]; // wave-uniform: scalar load
-            const v2f tt{t, t};
-#pragma unroll
-            for (int j = 0; j < J; j++)
-            {
-                const v2f prod = xw[k + j] * tt;
-                acc[j] = acc[j] + prod;
-            }
-        }
-        const long long i = i0 + o;
-        if (i + J <= n && J % 2 == 0)
-        {
-            float4 *yp = reinterpret_cast<float4 *>(y + i);
-#pragma unroll
-            for (int j = 0; j < J; j += 2)
-                yp[j / 2] = make_float4(acc[j].x, acc[j].y, acc[j + 1].x, acc[j + 1].y);
-        }
-        else
-        {
-#pragma unroll
-            for (int j = 0; j < J; j++)
-                if (i + j < n)
-                    reinterpret_cast<v2f *>(y)[i + j] = acc[j];
-        }
-    }
-
     void launch_fir(const cf32 *x, cf32 *y, long long n, const float *rtaps_dev, int ntaps, hipStream_t st)
     {
         if (n <= 0)
             return;
-        if (ntaps == 31 && (reinterpret_cast<uintptr_t>(y) & 15) == 0)
-        { // the default rrc_taps of every shipped PSK pipeline (module_psk_demod.cpp:25)
-            constexpr int J = 8;
-            ProfScope _ps("k_fir_sw", st);
-            hipLaunchKernelGGL((k_fir_sw<31, J>), dim3((unsigned)((n + 256 * J - 1) / (256 * J))), dim3(256), 0, st, x, y, n, rtaps_dev);
-            return;
-        }
         ProfScope _ps("k_fir", st);
         hipLaunchKernelGGL(k_fir, dim3((unsigned)((n + FIR_BLOCK * FIR_PER - 1) / (FIR_BLOCK * FIR_PER))), dim3(FIR_BLOCK), 0, st, x, y, n, rtaps_dev, ntaps);
     }
