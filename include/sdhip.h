@@ -53,7 +53,9 @@ extern "C"
     enum
     {
         SDHIP_DEC_CONV_CONCAT = 0, /* ccsds_conv_concat_decoder: Viterbi1_2 r=1/2 */
-        SDHIP_DEC_METOP_AHRPT = 1  /* metop_ahrpt_decoder: Viterbi3_4 (MetOp puncture), deframer SYNCED=18, Viterbi watchdog */
+        SDHIP_DEC_METOP_AHRPT = 1, /* metop_ahrpt_decoder: Viterbi3_4 (MetOp puncture), deframer SYNCED=18, Viterbi watchdog */
+        SDHIP_DEC_SIMPLE_PSK = 2   /* ccsds_simple_psk_decoder: hard decisions (+NRZ-M / QPSK differential) -> deframer(s) -> derand -> RS
+                                      (src-core/pipeline/modules/ccsds/module_ccsds_simple_psk_decoder.cpp:16-296) */
     };
 
     /* ---- psk_demod ------------------------------------------------------------------- */
@@ -136,6 +138,12 @@ extern "C"
         int rs_type;               /* SDHIP_RS_* ("rs_type") */
         int rs_usecheck;           /* "rs_usecheck" */
         uint32_t asm_sync;         /* "asm", default 0x1ACFFC1D */
+        /* ccsds_simple_psk_decoder only (module_ccsds_simple_psk_decoder.cpp:25-29) */
+        int qpsk_swap_iq;          /* "qpsk_swap_iq", default 0 */
+        int qpsk_swap_diff;        /* "qpsk_swap_diff", default 1 */
+        int oqpsk_delay;           /* "oqpsk_delay", default 0 */
+        int oqpsk_method2;         /* "oqpsk_method2", default 0 */
+        int oqpsk_method3;         /* "oqpsk_method3", default 0 */
         /* engine knobs */
         int device;
     } sdhip_fec_cfg;

@@ -29,7 +29,9 @@ class FecCfg(C.Structure):
         ("decoder", C.c_int), ("constellation", C.c_int), ("iq_invert", C.c_int), ("cadu_size", C.c_int),
         ("viterbi_outsync_after", C.c_int), ("viterbi_ber_thresold", C.c_float), ("nrzm", C.c_int), ("derandomize", C.c_int),
         ("derand_after_rs", C.c_int), ("derand_start", C.c_int), ("rs_i", C.c_int), ("rs_fill_bytes", C.c_int),
-        ("rs_dualbasis", C.c_int), ("rs_type", C.c_int), ("rs_usecheck", C.c_int), ("asm_sync", C.c_uint32), ("device", C.c_int),
+        ("rs_dualbasis", C.c_int), ("rs_type", C.c_int), ("rs_usecheck", C.c_int), ("asm_sync", C.c_uint32),
+        ("qpsk_swap_iq", C.c_int), ("qpsk_swap_diff", C.c_int), ("oqpsk_delay", C.c_int), ("oqpsk_method2", C.c_int), ("oqpsk_method3", C.c_int),
+        ("device", C.c_int),
     ]
 
 
@@ -72,6 +74,7 @@ def fec_cfg(**kw) -> FecCfg:
     c.rs_dualbasis = 1
     c.rs_type = RS223
     c.asm_sync = 0x1ACFFC1D
+    c.qpsk_swap_diff = 1
     for k, v in kw.items():
         setattr(c, k, v)
     return c
@@ -148,6 +151,8 @@ class Ref(_Lib):
         L.sdref_metop_decode.restype = C.c_int64
         L.sdref_block_run.restype = C.c_int64
         L.sdref_psk_demod.restype = C.c_int64
+        L.sdref_simple_decode.restype = C.c_int64
+        L.sdref_simple_decode.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
         L.sdref_metop_decode.argtypes = [C.c_float, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
                                          C.c_void_p, C.c_void_p, C.c_void_p]
         L.sdref_block_run.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_int64]
@@ -208,6 +213,17 @@ class Ref(_Lib):
         if taps:
             res["vit_bits"] = vb[:nvb.value]
         return res
+
+    def simple_decode(self, cfg: FecCfg, soft: np.ndarray):
+        """ccsds_simple_psk_decoder: int8 soft -> CADUs (+ RS error counts of every deframed frame)."""
+        s = np.ascontiguousarray(soft, dtype=np.int8)
+        cadu_bytes = (cfg.cadu_size + 7) // 8
+        cap = len(s) // cfg.cadu_size * 4 + 8
+        out = np.zeros((cap, cadu_bytes), dtype=np.uint8)
+        ferr = np.zeros((cap, max(cfg.rs_i, 1)), dtype=np.int32)
+        ndef = C.c_int64(0)
+        n = self.lib.sdref_simple_decode(C.byref(cfg), _p(s), C.c_int64(len(s)), _p(out), C.c_int64(cap), _p(ferr), C.byref(ndef))
+        return {"cadu": out[:n], "frm_err": ferr[:ndef.value], "n_deframed": ndef.value}
 
     def metop_decode(self, soft: np.ndarray, ber_thr=0.17, outsync_after=5, taps=False):
         s = np.ascontiguousarray(soft, dtype=np.int8)

@@ -37,6 +37,8 @@ std::shared_ptr<slog::Logger> logger = std::make_shared<slog::Logger>();
 #include "common/codings/differential/nrzm.h"
 #include "common/codings/deframing/bpsk_ccsds_deframer.h"
 #include "common/codings/reedsolomon/reedsolomon.h"
+#include "common/codings/differential/qpsk_diff.h"
+#include "common/dsp/demod/constellation.h"
 
 #include "common/dsp/block.h"
 #include "common/dsp/utils/agc.h"
@@ -217,6 +219,141 @@ extern "C"
         if (n_deframed)
             *n_deframed = ndef;
         zero_delete(vit);
+        if (rs)
+            zero_delete(rs);
+        return nout;
+    }
+
+    // In-memory restatement of CCSDSSimplePSKDecoderModule::process()
+    // (pipeline/modules/ccsds/module_ccsds_simple_psk_decoder.cpp:104-296), soft symbols not "hard_symbols".
+    // frm_err: rs_i ints per deframed frame (before the usecheck filter).
+    int64_t sdref_simple_decode(const sdhip_fec_cfg *c, const int8_t *soft, int64_t n, uint8_t *cadu_out, int64_t cadu_cap_frames, int *frm_err,
+                                int64_t *n_deframed)
+    {
+        const int d_cadu_size = c->cadu_size;
+        const int d_cadu_bytes = (int)ceil(d_cadu_size / 8.0);
+        const int d_buffer_size = d_cadu_size;
+        const bool is_qpsk = c->constellation == SDHIP_QPSK;
+        const bool m23 = c->oqpsk_method2 || c->oqpsk_method3;
+        std::vector<uint8_t> bits_out((size_t)d_buffer_size * 2, 0); // indeterminate in the reference: taken as zero
+        std::vector<int8_t> soft_buffer(d_buffer_size), soft_buffer2(d_buffer_size);
+        std::vector<uint8_t> qpsk_diff_buffer((size_t)d_cadu_size * 2, 0);
+        std::vector<uint8_t> frame_buffer((size_t)d_cadu_size * 2 + 4 * d_cadu_bytes, 0);
+        deframing::BPSK_CCSDS_Deframer deframer(d_cadu_size, c->asm_sync), deframer_qpsk(d_cadu_size, c->asm_sync);
+        if (d_cadu_size % 8 != 0)
+        {
+            deframer.CADU_PADDING = d_cadu_size % 8;
+            deframer_qpsk.CADU_PADDING = d_cadu_size % 8;
+        }
+        reedsolomon::ReedSolomon *rs = nullptr;
+        if (c->rs_i != 0)
+            rs = zero_new<reedsolomon::ReedSolomon>(c->rs_type == SDHIP_RS239 ? reedsolomon::RS239 : reedsolomon::RS223, c->rs_fill_bytes);
+        int errors[16] = {0};
+        diff::NRZMDiff diff;
+        diff::QPSKDiff *qpsk_diff = zero_new<diff::QPSKDiff>(); // buffer[] is uninitialised in the reference; its first two symbols are skipped anyway
+        qpsk_diff->swap = c->qpsk_swap_diff;
+        dsp::constellation_t qpsk_const(dsp::QPSK);
+        int8_t last_oqpsk2 = 0, last_q_oqpsk = 0;
+        int64_t nout = 0, ndef = 0;
+        const int64_t nblocks = n / d_buffer_size;
+        for (int64_t b = 0; b < nblocks; b++)
+        {
+            int frames = 0;
+            memcpy(soft_buffer.data(), soft + b * d_buffer_size, d_buffer_size);
+            if (!is_qpsk)
+            {
+                for (int i = 0; i < d_buffer_size; i++)
+                    bits_out[i] = soft_buffer[i] > 0;
+                if (c->nrzm)
+                    diff.decode_bits(bits_out.data(), d_buffer_size);
+            }
+            else
+            {
+                if (c->oqpsk_delay)
+                    for (int i = 0; i < d_buffer_size / 2; i++)
+                    {
+                        int8_t back = soft_buffer[i * 2 + 0];
+                        soft_buffer[i * 2 + 0] = last_q_oqpsk;
+                        last_q_oqpsk = back;
+                    }
+                if (c->qpsk_swap_iq)
+                    rotate_soft(soft_buffer.data(), d_buffer_size, PHASE_0, true);
+                auto demod_to_bits = [&](int8_t *sb) {
+                    for (int i = 0; i < d_buffer_size / 2; i++)
+                    {
+                        uint8_t sym = qpsk_const.soft_demod(&sb[i * 2]);
+                        bits_out[i * 2 + 0] = sym >> 1;
+                        bits_out[i * 2 + 1] = sym & 1;
+                    }
+                };
+                auto delay2 = [&]() {
+                    memcpy(soft_buffer2.data(), soft_buffer.data(), d_buffer_size);
+                    for (int i = 0; i < d_buffer_size / 2; i++)
+                    {
+                        int8_t back = soft_buffer2[i * 2 + 0];
+                        soft_buffer2[i * 2 + 0] = last_oqpsk2;
+                        last_oqpsk2 = back;
+                    }
+                };
+                if (c->nrzm)
+                {
+                    for (int i = 0; i < d_buffer_size / 2; i++)
+                        qpsk_diff_buffer[i] = qpsk_const.soft_demod(&soft_buffer[i * 2]);
+                    qpsk_diff->work(qpsk_diff_buffer.data(), d_buffer_size / 2, bits_out.data());
+                }
+                else if (!m23)
+                {
+                    demod_to_bits(soft_buffer.data());
+                    frames += deframer_qpsk.work(bits_out.data(), d_buffer_size, &frame_buffer[(size_t)frames * d_cadu_bytes]);
+                    rotate_soft(soft_buffer.data(), d_buffer_size, PHASE_90, false);
+                    demod_to_bits(soft_buffer.data());
+                }
+                else if (!c->oqpsk_method3)
+                {
+                    delay2();
+                    demod_to_bits(soft_buffer2.data());
+                    frames += deframer_qpsk.work(bits_out.data(), d_buffer_size, &frame_buffer[(size_t)frames * d_cadu_bytes]);
+                    rotate_soft(soft_buffer.data(), d_buffer_size, PHASE_90, false);
+                    demod_to_bits(soft_buffer.data());
+                }
+                else
+                {
+                    delay2();
+                    rotate_soft(soft_buffer2.data(), d_buffer_size, PHASE_90, false);
+                    demod_to_bits(soft_buffer2.data());
+                    frames += deframer_qpsk.work(bits_out.data(), d_buffer_size, &frame_buffer[(size_t)frames * d_cadu_bytes]);
+                    demod_to_bits(soft_buffer.data());
+                }
+            }
+            frames += deframer.work(bits_out.data(), d_buffer_size, &frame_buffer[(size_t)frames * d_cadu_bytes]);
+            for (int i = 0; i < frames; i++)
+            {
+                uint8_t *cadu = &frame_buffer[(size_t)i * d_cadu_bytes];
+                if (c->derandomize && !c->derand_after_rs)
+                    derand_ccsds(&cadu[c->derand_start], d_cadu_bytes - c->derand_start);
+                if (c->rs_i != 0)
+                    rs->decode_interlaved(&cadu[4], c->rs_dualbasis, c->rs_i, errors);
+                bool valid = true;
+                for (int k = 0; k < c->rs_i; k++)
+                    if (errors[k] == -1)
+                        valid = false;
+                if (frm_err)
+                    for (int k = 0; k < c->rs_i; k++)
+                        frm_err[ndef * c->rs_i + k] = errors[k];
+                ndef++;
+                if (c->derandomize && c->derand_after_rs)
+                    derand_ccsds(&cadu[c->derand_start], d_cadu_bytes - c->derand_start);
+                if (!c->rs_usecheck || valid)
+                {
+                    if (nout < cadu_cap_frames)
+                        memcpy(cadu_out + nout * d_cadu_bytes, cadu, d_cadu_bytes);
+                    nout++;
+                }
+            }
+        }
+        if (n_deframed)
+            *n_deframed = ndef;
+        zero_delete(qpsk_diff);
         if (rs)
             zero_delete(rs);
         return nout;

@@ -362,6 +362,63 @@ namespace sdhip_plugin
         }
     };
 
+    class CCSDSSimplePSKDecoderHipModule : public FecHipModuleBase
+    {
+    public:
+        CCSDSSimplePSKDecoderHipModule(std::string input_file, std::string output_file_hint, nlohmann::json parameters)
+            : FecHipModuleBase(input_file, output_file_hint, parameters)
+        {
+            // CCSDSSimplePSKDecoderModule ctor, src-core/pipeline/modules/ccsds/module_ccsds_simple_psk_decoder.cpp:19-98
+            cfg.decoder = SDHIP_DEC_SIMPLE_PSK;
+            const std::string cs = parameters["constellation"].get<std::string>();
+            if (cs == "bpsk")
+                cfg.constellation = SDHIP_BPSK;
+            else if (cs == "qpsk")
+                cfg.constellation = SDHIP_QPSK;
+            else
+                throw satdump_exception("CCSDS Simple PSK Decoder : invalid constellation type!");
+            if (parameters.count("hard_symbols") > 0 && parameters["hard_symbols"].get<bool>())
+                throw satdump_exception("ccsds_simple_psk_decoder_hip: hard_symbols input is not on the HIP path, use ccsds_simple_psk_decoder");
+            cfg.cadu_size = parameters["cadu_size"].get<int>();
+            auto flag = [&](const char *key, bool dflt) { return parameters.count(key) > 0 ? parameters[key].get<bool>() : dflt; };
+            cfg.qpsk_swap_iq = flag("qpsk_swap_iq", false);
+            cfg.qpsk_swap_diff = flag("qpsk_swap_diff", true);
+            cfg.oqpsk_delay = flag("oqpsk_delay", false);
+            cfg.oqpsk_method2 = flag("oqpsk_method2", false);
+            cfg.oqpsk_method3 = flag("oqpsk_method3", false);
+            cfg.nrzm = flag("nrzm", false);
+            cfg.derandomize = flag("derandomize", true);
+            cfg.derand_after_rs = flag("derand_after_rs", false);
+            cfg.derand_start = parameters.count("derand_start") > 0 ? parameters["derand_start"].get<int>() : 4;
+            cfg.rs_i = parameters["rs_i"].get<int>();
+            cfg.rs_fill_bytes = parameters.count("rs_fill_bytes") > 0 ? parameters["rs_fill_bytes"].get<int>() : -1;
+            cfg.rs_dualbasis = flag("rs_dualbasis", true);
+            const std::string rs_type = parameters.count("rs_type") > 0 ? parameters["rs_type"].get<std::string>() : "none";
+            if (cfg.rs_i != 0)
+            {
+                if (rs_type == "rs223")
+                    cfg.rs_type = SDHIP_RS223;
+                else if (rs_type == "rs239")
+                    cfg.rs_type = SDHIP_RS239;
+                else
+                    throw satdump_exception("CCSDS Simple PSK Decoder : invalid Reed-Solomon type!");
+            }
+            cfg.rs_usecheck = flag("rs_usecheck", false);
+            if (parameters.count("asm") > 0)
+                cfg.asm_sync = (uint32_t)std::stoul(parameters["asm"].get<std::string>(), nullptr, 16);
+            fsfsm_file_ext = flag("ccsds", true) ? ".cadu" : ".frm";
+            block_bytes = cfg.cadu_size; // d_buffer_size = d_cadu_size soft bytes
+            cadu_bytes = cfg.cadu_size / 8;
+        }
+        static std::string getID() { return "ccsds_simple_psk_decoder_hip"; }
+        virtual std::string getIDM() { return getID(); }
+        static nlohmann::json getParams() { return {}; }
+        static std::shared_ptr<ProcessingModule> getInstance(std::string input_file, std::string output_file_hint, nlohmann::json parameters)
+        {
+            return std::make_shared<CCSDSSimplePSKDecoderHipModule>(input_file, output_file_hint, parameters);
+        }
+    };
+
     class MetOpAHRPTDecoderHipModule : public FecHipModuleBase
     {
     public:
@@ -400,6 +457,7 @@ namespace sdhip_plugin
             REGISTER_MODULE_EXTERNAL(evt.modules_registry, PSKDemodHipModule);
             REGISTER_MODULE_EXTERNAL(evt.modules_registry, CCSDSConvConcatDecoderHipModule);
             REGISTER_MODULE_EXTERNAL(evt.modules_registry, MetOpAHRPTDecoderHipModule);
+            REGISTER_MODULE_EXTERNAL(evt.modules_registry, CCSDSSimplePSKDecoderHipModule);
         }
         static void startedHandler(const satdump::SatDumpStartedEvent &)
         {
@@ -419,8 +477,18 @@ namespace sdhip_plugin
                     e.inst = CCSDSConvConcatDecoderHipModule::getInstance;
                 else if (e.id == "metop_ahrpt_decoder")
                     e.inst = MetOpAHRPTDecoderHipModule::getInstance;
+                else if (e.id == "ccsds_simple_psk_decoder")
+                {
+                    // hard_symbols input (soft_reader.h:49-58) stays on the CPU module
+                    auto cpu = e.inst;
+                    e.inst = [cpu](std::string in, std::string out, nlohmann::json p) -> std::shared_ptr<ProcessingModule> {
+                        if (p.count("hard_symbols") > 0 && p["hard_symbols"].get<bool>())
+                            return cpu(in, out, p);
+                        return CCSDSSimplePSKDecoderHipModule::getInstance(in, out, p);
+                    };
+                }
             }
-            logger->info("sdhip_support: psk_demod / ccsds_conv_concat_decoder / metop_ahrpt_decoder now run on the MI355X path");
+            logger->info("sdhip_support: psk_demod / ccsds_conv_concat_decoder / metop_ahrpt_decoder / ccsds_simple_psk_decoder now run on the MI355X path");
         }
     };
 } // namespace sdhip_plugin

@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libsdhip.so")
 BPSK, BPSK_90, QPSK, OQPSK, PSK8 = 0, 1, 2, 3, 4
 RS_NONE, RS223, RS239 = 0, 1, 2
 FMT_CF32, FMT_CS16, FMT_CS8, FMT_CU8 = 0, 1, 2, 3
-DEC_CONV_CONCAT, DEC_METOP_AHRPT = 0, 1
+DEC_CONV_CONCAT, DEC_METOP_AHRPT, DEC_SIMPLE_PSK = 0, 1, 2
 CONSTELLATIONS = {"bpsk": BPSK, "bpsk_90": BPSK_90, "qpsk": QPSK, "oqpsk": OQPSK, "8psk": PSK8}
 
 
@@ -43,7 +43,9 @@ class FecCfg(C.Structure):
         ("decoder", C.c_int), ("constellation", C.c_int), ("iq_invert", C.c_int), ("cadu_size", C.c_int),
         ("viterbi_outsync_after", C.c_int), ("viterbi_ber_thresold", C.c_float), ("nrzm", C.c_int), ("derandomize", C.c_int),
         ("derand_after_rs", C.c_int), ("derand_start", C.c_int), ("rs_i", C.c_int), ("rs_fill_bytes", C.c_int),
-        ("rs_dualbasis", C.c_int), ("rs_type", C.c_int), ("rs_usecheck", C.c_int), ("asm_sync", C.c_uint32), ("device", C.c_int),
+        ("rs_dualbasis", C.c_int), ("rs_type", C.c_int), ("rs_usecheck", C.c_int), ("asm_sync", C.c_uint32),
+        ("qpsk_swap_iq", C.c_int), ("qpsk_swap_diff", C.c_int), ("oqpsk_delay", C.c_int), ("oqpsk_method2", C.c_int), ("oqpsk_method3", C.c_int),
+        ("device", C.c_int),
     ]
 
 

@@ -6,6 +6,7 @@
 #include <cstring>
 #include <stdexcept>
 #include <string>
+#include <utility>
 
 namespace sdhip
 {
@@ -57,6 +58,11 @@ namespace sdhip
             size_t want = n + n / 8 + 64;
             SD_HIP(hipMalloc((void **)&p, want * sizeof(T)));
             cap = want;
+        }
+        void swap(DevBuf &o)
+        {
+            std::swap(p, o.p);
+            std::swap(cap, o.cap);
         }
         DevBuf() = default;
         DevBuf(const DevBuf &) = delete;

@@ -151,6 +151,42 @@ namespace sdhip
         std::vector<uint32_t> carry_host;
         int carry_bits = 0;   // carry holds raw bits [abs_bits - carry_bits, abs_bits)
 
+        // ccsds_simple_psk_decoder runs two deframers on QPSK without NRZ-M (module_ccsds_simple_psk_decoder.cpp:79-80): the
+        // members above/below are the ACTIVE deframer context, the other one is parked here (swap_ctx)
+        struct DefCtx
+        {
+            DeframerState def;
+            int64_t abs_bits = 0;
+            std::vector<uint32_t> carry_host;
+            int carry_bits = 0;
+            DevBuf<uint32_t> d_carry[2];
+            int carry_sel = 0;
+            DevBuf<uint32_t> d_vbits;
+            DevBuf<uint8_t> d_fbytes;
+        } parked;
+        void swap_ctx()
+        {
+            std::swap(def, parked.def);
+            std::swap(abs_bits, parked.abs_bits);
+            carry_host.swap(parked.carry_host);
+            std::swap(carry_bits, parked.carry_bits);
+            d_carry[0].swap(parked.d_carry[0]);
+            d_carry[1].swap(parked.d_carry[1]);
+            std::swap(carry_sel, parked.carry_sel);
+            d_vbits.swap(parked.d_vbits);
+            d_fbytes.swap(parked.d_fbytes);
+        }
+        // frames of one deframer over one batch, kept on the device until the caller has merged the two streams' order
+        struct FrameBatch
+        {
+            int nf = 0;
+            std::vector<int> keep;         // passes the rs_usecheck filter
+            std::vector<int64_t> done_blk; // absolute index of the block in which the reference's deframer->work() returns the frame
+        };
+        HardCfg hard{};
+        long long simple_blocks_done = 0;
+        int n_streams = 1;
+
         // RS bookkeeping
         int last_errors[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 
@@ -228,6 +264,29 @@ namespace sdhip
                 cfg.rs_usecheck = 0;
                 cfg.asm_sync = 0x1ACFFC1D;
             }
+            else if (cfg.decoder == SDHIP_DEC_SIMPLE_PSK)
+            {
+                // CCSDSSimplePSKDecoderModule ctor, module_ccsds_simple_psk_decoder.cpp:19-98: d_buffer_size = d_cadu_size soft bytes
+                if (cfg.constellation != SDHIP_BPSK && cfg.constellation != SDHIP_QPSK)
+                    throw HipError("CCSDS Simple PSK Decoder : invalid constellation type!");
+                if (cfg.rs_i != 0 && cfg.rs_type != SDHIP_RS223 && cfg.rs_type != SDHIP_RS239)
+                    throw HipError("CCSDS Simple PSK Decoder : invalid Reed-Solomon type!");
+                if (cfg.rs_i < 0 || cfg.rs_i > 8)
+                    throw HipError("rs_i out of range");
+                B = F = cfg.cadu_size;
+                st_synced = 12;
+                hard.qpsk = cfg.constellation == SDHIP_QPSK;
+                hard.nrzm = cfg.nrzm;
+                hard.swap_iq = cfg.qpsk_swap_iq;
+                hard.swap_diff = cfg.qpsk_swap_diff;
+                hard.oqpsk_delay = cfg.oqpsk_delay;
+                hard.method2 = cfg.oqpsk_method2;
+                hard.method3 = cfg.oqpsk_method3;
+                hard.F = F;
+                n_streams = (hard.qpsk && !cfg.nrzm) ? 2 : 1;
+                if (hard.qpsk)
+                    cfg.nrzm = 0; // QPSK: the differential decoder is part of the bit slicer (QPSKDiff), not NRZ-M on the bit stream
+            }
             else
             {
                 // CCSDSConvConcatDecoderModule ctor, module_ccsds_conv_concat_decoder.cpp:16-131
@@ -271,7 +330,7 @@ namespace sdhip
             vc.B = B;
             vc.F = F;
             vc.nber = nber;
-            wpb = vit_words_per_block(F);
+            wpb = cfg.decoder == SDHIP_DEC_SIMPLE_PSK ? (F + 31) / 32 : vit_words_per_block(F);
             dstride = (F + 6 + 63) / 64 * 64;
             for (int s = 0; s < 2; s++)
                 for (int p = 0; p < 4; p++)
@@ -287,6 +346,14 @@ namespace sdhip
             d_search.reserve(1);
             d_count.reserve(1);
             upload_carry();
+            if (n_streams == 2)
+            { // second deframer: same initial state
+                parked.carry_bits = 64;
+                parked.carry_host.assign(2, 0u);
+                swap_ctx();
+                upload_carry();
+                swap_ctx();
+            }
         }
         ~FecEngine()
         {
@@ -475,7 +542,8 @@ namespace sdhip
         // ------------------------------------------------------------------ one run of SYNCED blocks -> frames
         // d_soft: device pointer to block 0 of the contiguous region; [blk0, blk0 + n) were decoded into d_vbits.
         // Returns the number of blocks actually consumed by the deframer (may be < n for the MetOp watchdog).
-        int deframe_and_emit(int n, uint8_t *d_out, size_t out_cap_frames, size_t &out_written)
+        // collect != nullptr: do not emit; report the frames (left in d_fbytes) and where the reference would have returned them
+        int deframe_and_emit(int n, uint8_t *d_out, size_t out_cap_frames, size_t &out_written, FrameBatch *collect = nullptr)
         {
             int n_eff = n;
             bool watchdog_fired = false;
@@ -551,6 +619,14 @@ namespace sdhip
                 // ---- frames: extract + derand + RS on the GPU
                 const int nf = (int)W.frames.size();
                 stats.frames_deframed += nf;
+                if (collect)
+                {
+                    collect->nf = nf;
+                    collect->keep.assign(nf, 1);
+                    collect->done_blk.resize(nf);
+                    for (int f = 0; f < nf; f++)
+                        collect->done_blk[f] = (base_abs + W.frames[f].pos + (cfg.cadu_size - 32) - 1) / F;
+                }
                 if (nf > 0)
                 {
                     d_frames.reserve(nf);
@@ -595,7 +671,9 @@ namespace sdhip
                             for (int k = 0; k < 0; k++)
                                 (void)k;
                         }
-                        if (!cfg.rs_usecheck || valid)
+                        if (collect)
+                            collect->keep[f] = (!cfg.rs_usecheck || valid) ? 1 : 0;
+                        else if (!cfg.rs_usecheck || valid)
                             h_dst[f] = (int)(out_written + kept++);
                     }
                     if (kept)
@@ -651,8 +729,108 @@ namespace sdhip
         }
 
         // ------------------------------------------------------------------ main driver over whole blocks
+        // ------------------------------------------------------------------ ccsds_simple_psk_decoder: slicer -> deframer(s) -> derand -> RS
+        void emit_frames(const DevBuf<uint8_t> &fbytes, const std::vector<int> &dst, int nf, size_t kept, uint8_t *d_out, size_t out_cap_frames, size_t out_base)
+        {
+            if (!kept)
+                return;
+            if (d_out)
+            {
+                if (out_base + kept > out_cap_frames)
+                    throw HipError("CADU output buffer too small");
+                d_dst.reserve(nf);
+                SD_HIP(hipMemcpyAsync(d_dst.p, dst.data(), (size_t)nf * sizeof(int), hipMemcpyHostToDevice, stream));
+                launch_compact(fbytes.p, d_dst.p, nf, cadu_bytes, d_out, stream);
+                SD_HIP(hipStreamSynchronize(stream));
+            }
+        }
+        void process_blocks_simple(const int8_t *d_soft, int64_t nblocks, uint8_t *d_out, size_t out_cap_frames, size_t &out_written)
+        {
+            int64_t pos = 0;
+            while (pos < nblocks)
+            {
+                const int n = (int)std::min<int64_t>(nblocks - pos, max_batch);
+                hard.blocks_done = simple_blocks_done;
+                const int8_t *blk = d_soft + pos * (int64_t)B;
+                FrameBatch fb[2];
+                // stream order of the reference inside one buffer: deframer_qpsk first, then deframer (:185, :264)
+                for (int sidx = 0; sidx < n_streams; sidx++)
+                {
+                    const int which = (n_streams == 2) ? (sidx == 0 ? 1 : 0) : 0;
+                    if (sidx == 1)
+                        swap_ctx();
+                    d_vbits.reserve((size_t)n * wpb + 4);
+                    launch_hard_bits(hard, blk, n, which, d_vbits.p, wpb, stream);
+                    if (n_streams == 1)
+                        deframe_and_emit(n, d_out, out_cap_frames, out_written);
+                    else
+                        deframe_and_emit(n, d_out, out_cap_frames, out_written, &fb[sidx]);
+                    if (sidx == 1)
+                        swap_ctx();
+                }
+                if (n_streams == 2)
+                {
+                    // merge: per block, deframer_qpsk's frames, then the main deframer's
+                    std::vector<int> dst[2] = {std::vector<int>(fb[0].nf, -1), std::vector<int>(fb[1].nf, -1)};
+                    size_t i0 = 0, i1 = 0, kept = 0, kept_s[2] = {0, 0};
+                    while (i0 < (size_t)fb[0].nf || i1 < (size_t)fb[1].nf)
+                    {
+                        const bool take0 = i1 >= (size_t)fb[1].nf || (i0 < (size_t)fb[0].nf && fb[0].done_blk[i0] <= fb[1].done_blk[i1]);
+                        const int sx = take0 ? 0 : 1;
+                        size_t &ix = take0 ? i0 : i1;
+                        if (fb[sx].keep[ix])
+                        {
+                            dst[sx][ix] = (int)(out_written + kept++);
+                            kept_s[sx]++;
+                        }
+                        ix++;
+                    }
+                    if (d_out)
+                    {
+                        emit_frames(d_fbytes, dst[0], fb[0].nf, kept_s[0], d_out, out_cap_frames, out_written);
+                        emit_frames(parked.d_fbytes, dst[1], fb[1].nf, kept_s[1], d_out, out_cap_frames, out_written);
+                    }
+                    else if (kept)
+                    {
+                        std::vector<uint8_t> t0((size_t)fb[0].nf * cadu_bytes), t1((size_t)fb[1].nf * cadu_bytes);
+                        if (fb[0].nf)
+                            SD_HIP(hipMemcpyAsync(t0.data(), d_fbytes.p, t0.size(), hipMemcpyDeviceToHost, stream));
+                        if (fb[1].nf)
+                            SD_HIP(hipMemcpyAsync(t1.data(), parked.d_fbytes.p, t1.size(), hipMemcpyDeviceToHost, stream));
+                        SD_HIP(hipStreamSynchronize(stream));
+                        const size_t base = out_queue.size();
+                        out_queue.resize(base + kept * cadu_bytes);
+                        for (int sx = 0; sx < 2; sx++)
+                            for (int f = 0; f < fb[sx].nf; f++)
+                                if (dst[sx][f] >= 0)
+                                    memcpy(out_queue.data() + base + (size_t)(dst[sx][f] - (int)out_written) * cadu_bytes,
+                                           (sx ? t1 : t0).data() + (size_t)f * cadu_bytes, cadu_bytes);
+                    }
+                    out_written += kept;
+                    stats.frames_out += kept;
+                }
+                // the two symbols in front of the next call's first soft byte
+                if ((size_t)n * B >= 4)
+                {
+                    int8_t t[4];
+                    SD_HIP(hipMemcpyAsync(t, blk + (size_t)n * B - 4, 4, hipMemcpyDeviceToHost, stream));
+                    SD_HIP(hipStreamSynchronize(stream));
+                    for (int k = 0; k < 4; k++)
+                        hard.tail[k] = t[k];
+                }
+                simple_blocks_done += n;
+                pos += n;
+                stats.blocks += n;
+            }
+            stats.deframer_state = std::max(def.state, n_streams == 2 ? parked.def.state : 0);
+            for (int k = 0; k < 8; k++)
+                stats.rs_errors[k] = last_errors[k];
+        }
+
         void process_blocks(const int8_t *d_soft, int64_t nblocks, uint8_t *d_out, size_t out_cap_frames, size_t &out_written)
         {
+            if (cfg.decoder == SDHIP_DEC_SIMPLE_PSK)
+                return process_blocks_simple(d_soft, nblocks, d_out, out_cap_frames, out_written);
             int64_t pos = 0;
             tap_ber.reserve(tap_ber.size() + nblocks);
             tap_state.reserve(tap_state.size() + nblocks);
@@ -929,6 +1107,7 @@ extern "C"
         c->rs_dualbasis = 1;
         c->rs_type = SDHIP_RS_NONE;
         c->asm_sync = 0x1ACFFC1Du;
+        c->qpsk_swap_diff = 1;
     }
 
     void *sdhip_fec_create(const sdhip_fec_cfg *cfg)

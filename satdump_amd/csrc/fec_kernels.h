@@ -95,6 +95,18 @@ namespace sdhip
         return 64 * L / 32;
     }
 
+    // ---- ccsds_simple_psk_decoder: hard decisions of the .soft stream, packed like the Viterbi output --------------
+    // (module_ccsds_simple_psk_decoder.cpp:141-262). One block = cadu_bits soft bytes = cadu_bits bits. which: 0 = the bits the
+    // module's main `deframer` sees, 1 = the bits `deframer_qpsk` sees (QPSK without NRZ-M only).
+    struct HardCfg
+    {
+        int qpsk, nrzm, swap_iq, swap_diff, oqpsk_delay, method2, method3;
+        int F;                 // bits (= soft bytes) per block
+        long long blocks_done; // blocks consumed by earlier calls (QPSKDiff swallows the first two symbols of the stream)
+        int tail[4];           // the two symbols (I,Q,I,Q) preceding this call's first soft byte; zeros at the stream start
+    };
+    void launch_hard_bits(const HardCfg &hc, const int8_t *soft, int nblk, int which, uint32_t *vbits, int wpb, hipStream_t st);
+
     // ---- logical decoded bit stream ------------------------------------------------------------
     // The deframer consumes [carry (carry_bits, raw Viterbi bits incl. >=33 bits of history)] ++ [blocks 0..nblk)
     // where block j contributes F bits from vbits + j*wpb. NRZ-M (differential/nrzm.cpp:24-33) is applied on the fly.

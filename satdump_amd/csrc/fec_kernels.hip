@@ -1056,6 +1056,132 @@ namespace sdhip
     }
 
     // =============================================================================================
+    // k_hard_bits: ccsds_simple_psk_decoder's bit slicers (module_ccsds_simple_psk_decoder.cpp:141-262)
+    // =============================================================================================
+    // All of the module's per-buffer transformations have a memory of at most two symbols (OQPSK one-symbol I delay,
+    // delay_one of method 2/3, the differential decoder), so every output bit is a function of at most three
+    // consecutive symbols of the raw stream: data-parallel, thread per 32-bit output word.
+    struct HardSym
+    {
+        int a, b; // soft_buffer[2i], soft_buffer[2i+1] after the optional OQPSK delay and I/Q swap
+    };
+    __device__ __forceinline__ int hard_raw(const HardCfg &hc, const int8_t *soft, long long k)
+    { // soft byte k of this call; k in [-4, 0) = the carried tail
+        return k >= 0 ? (int)soft[k] : hc.tail[4 + k];
+    }
+    __device__ __forceinline__ HardSym hard_sym(const HardCfg &hc, const int8_t *soft, long long i)
+    { // symbol i of this call (i >= -1)
+        int I = hc.oqpsk_delay ? hard_raw(hc, soft, 2 * (i - 1)) : hard_raw(hc, soft, 2 * i); // :151-160
+        int Q = hard_raw(hc, soft, 2 * i + 1);
+        if (hc.swap_iq) // rotate_soft(.., PHASE_0, true), :162-163
+        {
+            const int t = I;
+            I = Q;
+            Q = t;
+        }
+        return HardSym{I, Q};
+    }
+    __global__ __launch_bounds__(256) void k_hard_bits(HardCfg hc, const int8_t *__restrict__ soft, int nblk, int which, unsigned *vbits, int wpb)
+    {
+        const int j = (int)blockIdx.y;
+        const int w = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+        if (j >= nblk || w >= wpb)
+            return;
+        const int F = hc.F;
+        unsigned word = 0;
+        for (int bb = 0; bb < 32; bb++)
+        {
+            const int n = w * 32 + bb;
+            if (n >= F)
+                break;
+            unsigned bit;
+            if (!hc.qpsk)
+                bit = soft[(long long)j * F + n] > 0; // :143-144 (NRZ-M is applied by the stream reader)
+            else
+            {
+                const long long i = (long long)j * (F / 2) + (n >> 1); // symbol of this call holding output bit n
+                const int second = n & 1;
+                if (hc.nrzm)
+                { // soft_demod + QPSKDiff (qpsk_diff.cpp:5-55): the very first two symbols of the stream produce nothing, so
+                  // block 0 of the stream holds F-4 decoded bits followed by 4 never-written (zero) entries of bits_out
+                    long long cur = i;
+                    bool valid = true;
+                    if (hc.blocks_done == 0 && j == 0)
+                    {
+                        cur = i + 2;
+                        valid = n < F - 4;
+                    }
+                    bit = 0;
+                    if (valid)
+                    {
+                        const HardSym p = hard_sym(hc, soft, cur - 1), c = hard_sym(hc, soft, cur);
+                        const unsigned Xin_1 = p.b > 0, Yin_1 = p.a > 0, Xin = c.b > 0, Yin = c.a > 0;
+                        unsigned ou;
+                        if ((Xin ^ Yin) == 1u)
+                            ou = ((Yin_1 ^ Yin) << 1) + (Xin_1 ^ Xin);
+                        else
+                            ou = ((Xin_1 ^ Xin) << 1) + (Yin_1 ^ Yin);
+                        const unsigned first = hc.swap_diff ? (ou & 1u) : (ou >> 1), sec = hc.swap_diff ? (ou >> 1) : (ou & 1u);
+                        bit = second ? sec : first;
+                    }
+                }
+                else
+                {
+                    const HardSym c = hard_sym(hc, soft, i);
+                    // bits_out[2i] = sym >> 1 = (sample[1] > 0), bits_out[2i+1] = sym & 1 = (sample[0] > 0); PHASE_90: (a, b) -> (b, -a)
+                    unsigned b0, b1;
+                    const bool m23 = hc.method2 || hc.method3;
+                    if (which == 0)
+                    { // main deframer
+                        if (m23 && hc.method3)
+                        { // unrotated soft_buffer, :236-241
+                            b0 = c.b > 0;
+                            b1 = c.a > 0;
+                        }
+                        else
+                        { // soft_buffer rotated by 90 degrees, :186-193 / :213-220
+                            b0 = c.a < 0;
+                            b1 = c.b > 0;
+                        }
+                    }
+                    else
+                    { // deframer_qpsk
+                        if (!m23)
+                        { // 0 degrees, :176-183
+                            b0 = c.b > 0;
+                            b1 = c.a > 0;
+                        }
+                        else
+                        {
+                            const int ad = hard_sym(hc, soft, i - 1).a; // soft_buffer2: I delayed by one symbol, :197-203
+                            if (!hc.method3)
+                            {
+                                b0 = c.b > 0;
+                                b1 = ad > 0;
+                            }
+                            else
+                            { // delayed copy rotated by 90 degrees: (ad, b) -> (b, -ad), :231-232
+                                b0 = ad < 0;
+                                b1 = c.b > 0;
+                            }
+                        }
+                    }
+                    bit = second ? b1 : b0;
+                }
+            }
+            word |= bit << (31 - bb);
+        }
+        vbits[(size_t)j * wpb + w] = word;
+    }
+    void launch_hard_bits(const HardCfg &hc, const int8_t *soft, int nblk, int which, uint32_t *vbits, int wpb, hipStream_t st)
+    {
+        if (nblk <= 0)
+            return;
+        ProfScope _ps("k_hard_bits", st);
+        hipLaunchKernelGGL(k_hard_bits, dim3((wpb + 255) / 256, nblk), dim3(256), 0, st, hc, soft, nblk, which, vbits, wpb);
+    }
+
+    // =============================================================================================
     // Logical bit stream access
     // =============================================================================================
     __device__ __forceinline__ unsigned stream_raw32(const BitStream &bs, long long g)

@@ -194,3 +194,27 @@ def test_sync_loss_and_inversion(torch_cuda, capi, orc):
     assert np.array_equal(state, want["state"])
     assert got.shape == want["cadu"].shape and np.array_equal(got, want["cadu"])
     assert len(got) > 25
+
+
+@pytest.mark.parametrize("name", [c[0] for c in util.SIMPLE_CASES])
+@pytest.mark.parametrize("sigma,usecheck", [(15.0, 1), (28.0, 0)])
+def test_simple_psk_decoder(torch_cuda, capi, orc, name, sigma, usecheck):
+    """ccsds_simple_psk_decoder on the GPU (bit slicers, one or two deframers, derand, RS) == the reference module loop,
+    frame for frame and in the reference's output order (deframer_qpsk's frames of a buffer before the main deframer's)."""
+    ck, soft, plain = util.simple_case(name, sigma=sigma, nframes=16)
+    ock = dict(ck)
+    ock["constellation"] = {"bpsk": pyref.BPSK, "qpsk": pyref.QPSK}[ck["constellation"]]
+    want = orc.simple_decode(pyref.fec_cfg(decoder=2, rs_usecheck=usecheck, **ock), soft)
+    cfg = capi.fec_cfg(decoder=capi.DEC_SIMPLE_PSK, rs_i=4, rs_type=capi.RS223, rs_usecheck=usecheck, **ck)
+    got, _, _, st = _run_dev(torch_cuda, capi, cfg, soft)
+    assert st.frames_deframed == want["n_deframed"]
+    assert got.shape == want["cadu"].shape and np.array_equal(got, want["cadu"])
+    # ragged calls (partial buffers, an empty call) and the host push/pull path give the same stream
+    n = len(soft)
+    bounds = [0, 1001, 1001, 8192 * 2 + 18, 8192 * 5, 8192 * 5 + 6, n]
+    got2, _, _, _ = _run_dev(torch_cuda, capi, cfg, soft, chunks=bounds)
+    assert np.array_equal(got2, want["cadu"])
+    dec = capi.FecDecoder(cfg)
+    for a, b in zip(bounds[:-1], bounds[1:]):
+        dec.push(soft[a:b])
+    assert np.array_equal(dec.pull(), want["cadu"])
