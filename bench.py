@@ -86,6 +86,7 @@ def algorithmic_bytes(wl, n_in, n_rs, nsym, nsoft, nblk_bytes, cadu_bytes_out, i
         "k_mm": n_rs * 8 + nsym * 8,
         "k_quantize": nsym * (8 + q),
         "k_vit_decode": nsoft + nsoft * wl["conv_rate"] / 8.0,
+        "k_vit2_acs": nsoft + nsoft * wl["conv_rate"] / 8.0,  # the Viterbi stage as a whole (prep/acs/tb/cert); SURVEY 8(d) keeps decisions on chip
         "k_vit_ber": nsoft + nsoft * wl["conv_rate"] / 8.0,
         "k_sync_search": nsoft * wl["conv_rate"] / 8.0,
         "k_pack_stream": 2 * nsoft * wl["conv_rate"] / 8.0,
@@ -93,6 +94,25 @@ def algorithmic_bytes(wl, n_in, n_rs, nsym, nsoft, nblk_bytes, cadu_bytes_out, i
         "k_rs": 2 * cadu_bytes_out,
         "k_compact": 2 * cadu_bytes_out,
     }
+
+
+def pmc_traffic(workload, kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (profiles/r*_<wl>_pmc.csv,
+    produced by tools/gpu_round.sh + tools/pmc_summary.py with the guide's gfx950 x2 correction on FETCH_SIZE). PMC passes cannot
+    run inside this process, so the figure is the one of the most recent committed profile of this workload; None if there is none."""
+    import csv
+    import glob
+    short = {"goes_hrit": "goes", "metop_ahrpt": "metop", "npp_hrd": "npp"}[workload]
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_{short}_pmc.csv")))
+    if not files:
+        return None, None
+    with open(files[-1]) as f:
+        rows = [r for r in csv.reader(l for l in f if not l.startswith("#"))]
+    hdr, rows = rows[0], rows[1:]
+    for r in rows:
+        if r and r[0] == kernel:
+            return float(r[hdr.index("traffic_bytes_per_dispatch")]), os.path.basename(files[-1])
+    return None, os.path.basename(files[-1])
 
 
 def cpu_baseline(wl, x_host, max_seconds_hint=20.0):
@@ -205,8 +225,11 @@ def main():
     if not args.no_check:
         got = d_cadu[:last_nf].cpu().numpy()
         want = {bytes(p) for p in plain}
+        want_payload = {bytes(p[4:]) for p in plain}
         ok = sum(1 for g in got if bytes(g) in want)
-        check = {"cadus_last_step": int(last_nf), "cadus_matching_transmitted": int(ok), "transmitted": int(frames)}
+        ok_payload = sum(1 for g in got if bytes(g[4:]) in want_payload)  # the 4-byte ASM is not RS protected: channel errors stay in it
+        check = {"cadus_last_step": int(last_nf), "cadus_matching_transmitted": int(ok), "payload_matching_transmitted": int(ok_payload),
+                 "transmitted": int(frames)}
 
     if rank == 0:
         dst = dem.stats()
@@ -227,8 +250,9 @@ def main():
             launches = prof[dom][1] / steps
             bytes_step = algo.get(dom, 0.0)
             achieved = bytes_step / (ms_step * 1e-3) / 1e9 if ms_step > 0 else 0.0
+            traffic, traffic_src = pmc_traffic(args.workload, dom)
             roof = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
+                    "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": traffic_src,
                     "algo_bytes_per_launch": round(bytes_step / max(launches, 1e-9)), "avg_launch_ms": round(ms_step / max(launches, 1e-9), 4),
                     "launches_per_step": round(launches, 2), "kernel_time_frac_of_step": round(ms_step / (dt / steps * 1e3), 4)}
         cpu = None
