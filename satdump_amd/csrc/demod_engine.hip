@@ -425,7 +425,11 @@ namespace sdhip
                     if (mean > 1e-12)
                         g_est = (float)std::min(65536.0, 1.0 / mean);
                 }
-                long long W = cfg.warmup > 0 ? cfg.warmup : (long long)(24.0 * std::max(1.0f, g_est) / std::max(1e-6f, cfg.agc_rate));
+                // tau = gain / rate samples; 24 tau of warm-up from the mean-based gain merge bit for bit with the previous chunk's
+                // trajectory (13 tau would do within the 1e-6 tolerance; measured: the lane kernels are bound by their strided
+                // HBM traffic, not by the chain -- a parallel-scan start value that cut W to 6 tau bought nothing net)
+                const double tau = std::max(1.0f, g_est) / std::max(1e-6f, cfg.agc_rate);
+                long long W = cfg.warmup > 0 ? cfg.warmup : (long long)(24.0 * tau);
                 W = env_int("SDHIP_W_AGC", W);
                 W = std::min<long long>(std::max<long long>(W, 1024), 1 << 22);
                 W = (W + 255) / 256 * 256;
@@ -489,6 +493,7 @@ namespace sdhip
                 long long W = cfg.warmup > 0 ? cfg.warmup : (long long)std::max(512.0, 24.0 / (1.414 * std::max(1e-5f, cfg.pll_bw)));
                 W = env_int("SDHIP_W_COSTAS", W);
                 W = (std::min<long long>(W, 1 << 22) + 255) / 256 * 256;
+                cos_p.est_len = (int)std::min<long long>(env_int("SDHIP_COSTAS_EST", 256), W / 2);
                 cg = make_geom(n, L, (int)W);
                 stats.chunks += cg.K;
                 d_cos_spec.reserve(cg.K);
@@ -496,6 +501,7 @@ namespace sdhip
                 SD_HIP(hipMemcpyAsync(d_cos_start.p, &cos_s, sizeof(cos_s), hipMemcpyHostToDevice, stream));
                 launch_costas(A, B, cg, cos_p, d_cos_start.p, d_cos_spec.p, d_cos_end.p, nullptr, 0, stream);
                 rot.assign(cg.K, 0);
+                int cdbg_left = getenv("SDHIP_DEBUG") ? 12 : 0;
                 std::vector<CostasState> spec, endst;
                 verify_fix(
                     "costas", cg.K, d_cos_spec, d_cos_end, spec, endst,
@@ -520,6 +526,12 @@ namespace sdhip
                             return true;
                         }
                         rot[k] = rot[k - 1]; // re-run continues in the previous chunk's frame
+                        if (cdbg_left > 0)
+                        {
+                            cdbg_left--;
+                            fprintf(stderr, "[sdhip] costas boundary %d rejected: dphi %.6f = %lld units %+.6f, freq %.9f vs %.9f (d %.3g)\n", k, dphi, d, resid,
+                                    a.freq, b.freq, (double)a.freq - (double)b.freq);
+                        }
                         return false;
                     },
                     [&](const int *redo, int nr) { launch_costas(A, B, cg, cos_p, d_cos_start.p, d_cos_spec.p, d_cos_end.p, redo, nr, stream); });

@@ -83,6 +83,7 @@ namespace sdhip
         float alpha, beta, fmin, fmax;
         int order;
         float init_freq; // warm-up start frequency
+        int est_len;     // samples of the feed-forward start-phase estimate of a warm-up (0 = start at phase 0)
     };
     struct CostasState
     {

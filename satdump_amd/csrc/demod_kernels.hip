@@ -327,6 +327,7 @@ namespace sdhip
         using S = AgcState;
         static constexpr int DEPTH = 6; // ~100 cycles per sample: 48 samples in flight cover the load latency
         __device__ static __forceinline__ S init(const P &p) { return S{p.init_gain}; }
+        __device__ static __forceinline__ void prewarm(S &, const P &, const cf32 *, long long) {}
         __device__ static __forceinline__ cf32 step(S &s, const P &p, const cf32 v)
         {
             // AGCBlock<complex_t>::work, agc.cpp:25-39
@@ -346,6 +347,38 @@ namespace sdhip
         using S = CostasState;
         static constexpr int DEPTH = 2; // ~400 cycles per sample (two double-precision sincos polynomials)
         __device__ static __forceinline__ S init(const P &p) { return S{0.0f, p.init_freq}; }
+        // Start phase of a warm-up from a feed-forward M-th power estimate over its first est_len samples, so that the loop
+        // starts next to one of its `order` stable points instead of anywhere in between: a restart that lands near the
+        // unstable point half way hangs there for many time constants (the cause of nearly all Costas re-runs at pll_bw
+        // 0.002-0.003). Speculation only -- the boundary certificate decides.
+        __device__ static __forceinline__ void prewarm(S &s, const P &p, const cf32 *x, long long i0)
+        {
+            if (p.est_len <= 0 || p.order > 4)
+                return;
+            const int M = p.order;
+            float rc, rs; // exp(-j*M*freq*n), advanced by recurrence
+            __sincosf(-(float)M * s.freq, &rs, &rc);
+            float cr = 1.0f, ci = 0.0f, ar = 0.0f, ai = 0.0f;
+            for (int n = 0; n < p.est_len; n++)
+            {
+                const cf32 v = x[i0 + n];
+                float zr = v.re * v.re - v.im * v.im, zi = 2.0f * v.re * v.im; // x^2
+                if (M == 4)
+                {
+                    const float tr = zr * zr - zi * zi, ti = 2.0f * zr * zi;
+                    zr = tr;
+                    zi = ti;
+                }
+                ar += zr * cr - zi * ci;
+                ai += zr * ci + zi * cr;
+                const float nr = cr * rc - ci * rs, ni = cr * rs + ci * rc;
+                cr = nr;
+                ci = ni;
+            }
+            // BPSK symbols sit on the real axis (x^2 -> +1), QPSK symbols on the diagonals (x^4 -> -1)
+            const float ang = (M == 4) ? atan2f(-ai, -ar) : atan2f(ai, ar);
+            s.phase = ang / (float)M;
+        }
         __device__ static __forceinline__ cf32 step(S &s, const P &p, const cf32 v)
         {
             // CostasLoopBlock::work, costas_loop.cpp:23-65
@@ -478,6 +511,7 @@ namespace sdhip
             {
                 s = Stage::init(p);
                 const long long b = chunk_begin(g, k);
+                Stage::prewarm(s, p, x, b - g.W);
                 run_range<Stage>(s, p, x, y, b - g.W, b, false);
                 spec[k] = s;
             }
