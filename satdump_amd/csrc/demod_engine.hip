@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
 #include <vector>
 
@@ -105,8 +106,10 @@ namespace sdhip
         DevBuf<AgcState> d_agc_spec, d_agc_end, d_agc_start;
         DevBuf<CostasState> d_cos_spec, d_cos_end, d_cos_start;
         DevBuf<MmState> d_mm_spec, d_mm_end, d_mm_start;
+        DevBuf<MmCert> d_mm_spec_c, d_mm_end_c; // what the host certificate reads (16 B per chunk instead of the 72-byte state)
         DevBuf<DcState> d_dc;
         DevBuf<int> d_redo, d_rot, d_counts, d_seg;
+        PinBuf<int> h_counts;
         DevBuf<long long> d_offsets;
         DevBuf<double> d_partial;
         DevBuf<int8_t> d_soft_tmp;
@@ -303,17 +306,21 @@ namespace sdhip
         // chunks of a round in ONE launch -- and the chain is evaluated again (a re-run changes that chunk's end state,
         // which its successor is then checked against), until nothing fails. accept() is evaluated for k ascending and
         // may fill per-chunk side information derived from chunk k-1's (rotation, symbol hand-off).
+        // (states travel through pinned host buffers: a pageable destination costs ~1 ms per stage at ~10^5 chunks)
+        PinBuf<uint8_t> h_vf_spec, h_vf_end;
         template <class S, class Accept, class Launch>
-        void verify_fix(const char *stage, int K, DevBuf<S> &d_spec, DevBuf<S> &d_end, std::vector<S> &spec, std::vector<S> &endst, Accept accept, Launch relaunch)
+        void verify_fix(const char *stage, int K, DevBuf<S> &d_spec, DevBuf<S> &d_end, S *&spec, S *&endst, Accept accept, Launch relaunch)
         {
-            spec.resize(K);
-            endst.resize(K);
-            SD_HIP(hipMemcpyAsync(spec.data(), d_spec.p, (size_t)K * sizeof(S), hipMemcpyDeviceToHost, stream));
+            h_vf_spec.reserve((size_t)K * sizeof(S));
+            h_vf_end.reserve((size_t)K * sizeof(S));
+            spec = reinterpret_cast<S *>(h_vf_spec.p);
+            endst = reinterpret_cast<S *>(h_vf_end.p);
+            SD_HIP(hipMemcpyAsync(spec, d_spec.p, (size_t)K * sizeof(S), hipMemcpyDeviceToHost, stream));
             unsigned reruns = 0, rounds = 0;
             std::vector<int> fails;
             for (;;)
             {
-                SD_HIP(hipMemcpyAsync(endst.data(), d_end.p, (size_t)K * sizeof(S), hipMemcpyDeviceToHost, stream));
+                SD_HIP(hipMemcpyAsync(endst, d_end.p, (size_t)K * sizeof(S), hipMemcpyDeviceToHost, stream));
                 SD_HIP(hipStreamSynchronize(stream));
                 fails.clear();
                 round_inexact = round_rotated = 0;
@@ -343,6 +350,17 @@ namespace sdhip
         int64_t process(const void *d_in, size_t n_in, int fmt, int8_t *d_soft, size_t soft_cap, float *d_syms, size_t syms_cap)
         {
             SD_HIP(hipSetDevice(cfg.device));
+            // SDHIP_DEBUG: host wall-clock of every stage incl. its certificate round trips
+            const bool tdbg = getenv("SDHIP_DEBUG") != nullptr;
+            auto tnow = [] { return std::chrono::steady_clock::now(); };
+            auto t_prev = tnow();
+            auto tick = [&](const char *what) {
+                if (!tdbg)
+                    return;
+                const auto t = tnow();
+                fprintf(stderr, "[sdhip] demod %-10s %7.3f ms (host wall)\n", what, std::chrono::duration<double, std::milli>(t - t_prev).count());
+                t_prev = t;
+            };
             stats.chunks = stats.chunks_fixed = stats.chunks_rotated = stats.chunks_inexact = 0;
             if (n_in == 0)
                 return 0;
@@ -403,6 +421,7 @@ namespace sdhip
                 if (n == 0)
                     return 0;
             }
+            tick("resample");
             const int L = pick_L(n);
 
             // ---- AGC (speculative)
@@ -440,7 +459,7 @@ namespace sdhip
                 d_agc_end.reserve(g.K);
                 SD_HIP(hipMemcpyAsync(d_agc_start.p, &agc_s, sizeof(agc_s), hipMemcpyHostToDevice, stream));
                 launch_agc(AIN, B, g, agc_p, d_agc_start.p, d_agc_spec.p, d_agc_end.p, nullptr, 0, stream);
-                std::vector<AgcState> spec, endst;
+                AgcState *spec = nullptr, *endst = nullptr;
                 verify_fix(
                     "agc", g.K, d_agc_spec, d_agc_end, spec, endst,
                     [&](int, const AgcState &a, const AgcState &b) {
@@ -457,12 +476,14 @@ namespace sdhip
                 agc_s = endst[g.K - 1];
                 std::swap(A, B);
             }
+            tick("agc");
             // ---- RRC FIR (parallel, exact)
             put_hist(A, hist_agc);
             launch_fir(A, B, n, d_rrc.p, rrc_ntaps, stream);
             get_hist(A, n, hist_agc);
             std::swap(A, B);
 
+            tick("fir");
             // ---- Costas (speculative, symmetry-corrected)
             ChunkGeom cg;
             std::vector<int> rot;
@@ -502,7 +523,7 @@ namespace sdhip
                 launch_costas(A, B, cg, cos_p, d_cos_start.p, d_cos_spec.p, d_cos_end.p, nullptr, 0, stream);
                 rot.assign(cg.K, 0);
                 int cdbg_left = getenv("SDHIP_DEBUG") ? 12 : 0;
-                std::vector<CostasState> spec, endst;
+                CostasState *spec = nullptr, *endst = nullptr;
                 verify_fix(
                     "costas", cg.K, d_cos_spec, d_cos_end, spec, endst,
                     [&](int k, const CostasState &a, const CostasState &b) {
@@ -550,6 +571,7 @@ namespace sdhip
                 stats.freq_hz = (float)(((double)cos_s.freq / (2.0 * design::PI)) * (double)final_samplerate);
                 std::swap(A, B);
             }
+            tick("costas");
             // ---- M&M + quantiser
             int64_t nsoft = 0;
             {
@@ -583,9 +605,11 @@ namespace sdhip
                 d_offsets.reserve(g.K);
                 d_mm_spec.reserve(g.K);
                 d_mm_end.reserve(g.K);
+                d_mm_spec_c.reserve(g.K);
+                d_mm_end_c.reserve(g.K);
                 SD_HIP(hipMemcpyAsync(d_mm_start.p, &mm_s, sizeof(mm_s), hipMemcpyHostToDevice, stream));
-                launch_mm(A, symbuf.p, d_counts.p, g, mm_p, d_mm_start.p, d_mm_spec.p, d_mm_end.p, nullptr, 0, stream);
-                std::vector<MmState> spec, endst;
+                launch_mm(A, symbuf.p, d_counts.p, g, mm_p, d_mm_start.p, d_mm_spec.p, d_mm_end.p, d_mm_spec_c.p, d_mm_end_c.p, nullptr, 0, stream);
+                MmCert *spec = nullptr, *endst = nullptr;
                 // Symbol hand-off at chunk boundaries. The M&M loop never re-merges bit for bit: its feedback is piecewise
                 // constant through the 128-arm interpolator index rint(mu*128) (clock_recovery_mm.cpp:66), so independent
                 // trajectories hover a fraction of an arm apart (tools/merge_study.py). What is certified is CONSISTENCY in
@@ -595,16 +619,18 @@ namespace sdhip
                 // taken from chunk k-1's look-ahead, or skipped at the head of chunk k. Anything else: re-run from the exact state.
                 const double MM_TOL = env_int("SDHIP_MM_TOL_MILLI", 50) * 1e-3;
                 int dbg_left = getenv("SDHIP_DEBUG") ? 8 : 0;
-                std::vector<int> skip(g.K, 0), extra(g.K, 0), counts(2 * (size_t)g.K);
+                std::vector<int> skip(g.K, 0), extra(g.K, 0);
+                h_counts.reserve(2 * (size_t)g.K);
+                int *counts = h_counts.p;
                 bool counts_fresh = false;
                 auto fetch_counts = [&]() {
-                    SD_HIP(hipMemcpyAsync(counts.data(), d_counts.p, counts.size() * sizeof(int), hipMemcpyDeviceToHost, stream));
+                    SD_HIP(hipMemcpyAsync(counts, d_counts.p, 2 * (size_t)g.K * sizeof(int), hipMemcpyDeviceToHost, stream));
                     SD_HIP(hipStreamSynchronize(stream));
                     counts_fresh = true;
                 };
                 verify_fix(
-                    "mm", g.K, d_mm_spec, d_mm_end, spec, endst,
-                    [&](int k, const MmState &a, const MmState &b) {
+                    "mm", g.K, d_mm_spec_c, d_mm_end_c, spec, endst,
+                    [&](int k, const MmCert &a, const MmCert &b) {
                         if (!counts_fresh)
                             fetch_counts();
                         skip[k] = 0;
@@ -643,12 +669,13 @@ namespace sdhip
                         return false;
                     },
                     [&](const int *redo, int nr) {
-                        launch_mm(A, symbuf.p, d_counts.p, g, mm_p, d_mm_start.p, d_mm_spec.p, d_mm_end.p, redo, nr, stream);
+                        launch_mm(A, symbuf.p, d_counts.p, g, mm_p, d_mm_start.p, d_mm_spec.p, d_mm_end.p, d_mm_spec_c.p, d_mm_end_c.p, redo, nr, stream);
                         counts_fresh = false;
                     });
                 if (!counts_fresh)
                     fetch_counts();
-                mm_s = endst[g.K - 1];
+                SD_HIP(hipMemcpyAsync(&mm_s, d_mm_end.p + (g.K - 1), sizeof(mm_s), hipMemcpyDeviceToHost, stream));
+                SD_HIP(hipStreamSynchronize(stream));
                 mm_s.inc -= n; // clock_recovery_mm.cpp:123-126
                 if (mm_s.inc < 0)
                     mm_s.inc = 0;
@@ -679,6 +706,7 @@ namespace sdhip
                 stats.symbols_out += tot;
                 nsoft = need_soft;
             }
+            tick("mm+quant");
             started = true;
             return nsoft;
         }
@@ -865,7 +893,9 @@ extern "C"
             DevBuf<int> cnt;
             cnt.reserve(2);
             SD_HIP(hipMemcpy(st.p, &s0, sizeof(s0), hipMemcpyHostToDevice));
-            launch_mm(X, Y, cnt.p, g, p, st.p, st.p + 1, st.p + 2, nullptr, 0, nullptr);
+            DevBuf<MmCert> cc;
+            cc.reserve(2);
+            launch_mm(X, Y, cnt.p, g, p, st.p, st.p + 1, st.p + 2, cc.p, cc.p + 1, nullptr, 0, nullptr);
             int c = 0;
             SD_HIP(hipMemcpy(&c, cnt.p, sizeof(int), hipMemcpyDeviceToHost));
             nout = c;

@@ -113,9 +113,16 @@ namespace sdhip
         cf32 p_2T, p_1T, p_0T, c_2T, c_1T, c_0T;
         long long inc; // position in this call's sample index space
     };
+    // what the boundary certificate compares: the timing state (the delay lines follow from it and the data)
+    struct MmCert
+    {
+        float mu, omega;
+        long long inc;
+    };
     // counts: 2 ints per chunk = {symbols emitted inside the chunk, extra symbols computed past its end (0..2, stored right after)}
+    // spec_c / end_c: compact copies of spec / endst for the host
     void launch_mm(const cf32 *x, cf32 *sym_scratch, int *counts, const ChunkGeom &g, const MmParams &p, const MmState *start0, MmState *spec, MmState *endst,
-                   const int *redo, int nredo, hipStream_t st);
+                   MmCert *spec_c, MmCert *end_c, const int *redo, int nredo, hipStream_t st);
     // compaction + quantiser (module_psk_demod.cpp:199-213): seg = 2 ints per chunk {first, count}: chunk k's symbols
     // [first, first+count) of its scratch row go to offsets[k]
     void launch_quantize(const cf32 *sym_scratch, const int *seg, const long long *offsets, int K, int cap, int bpsk, int8_t *soft, long long soft_cap,

@@ -740,7 +740,7 @@ namespace sdhip
     }
 
     __global__ __launch_bounds__(64) void k_mm(const cf32 *x, cf32 *sym, int *counts, ChunkGeom g, MmParams p, const MmState *start0, MmState *spec,
-                                               MmState *endst, const int *redo, int nredo)
+                                               MmState *endst, MmCert *spec_c, MmCert *end_c, const int *redo, int nredo)
     {
         __shared__ cf32 rings[64 * MM_RING_STRIDE];
         __shared__ __attribute__((aligned(16))) float bank[128 * 8];
@@ -802,12 +802,14 @@ namespace sdhip
                     if (phase == 0 && s.inc >= b)
                     {
                         spec[k] = s;
+                        spec_c[k] = MmCert{s.mu, s.omega, s.inc};
                         phase = 1;
                     }
                     if (phase == 1 && s.inc >= e)
                     {
                         counts[2 * k] = cnt;
                         endst[k] = s;
+                        end_c[k] = MmCert{s.mu, s.omega, s.inc};
                         phase = 2;
                         if (k + 1 >= g.K)
                             done = true;
@@ -838,13 +840,13 @@ namespace sdhip
         counts[2 * k + 1] = nx;
     }
     void launch_mm(const cf32 *x, cf32 *sym_scratch, int *counts, const ChunkGeom &g, const MmParams &p, const MmState *start0, MmState *spec, MmState *endst,
-                   const int *redo, int nredo, hipStream_t st)
+                   MmCert *spec_c, MmCert *end_c, const int *redo, int nredo, hipStream_t st)
     {
         const int n = redo ? nredo : g.K;
         if (n <= 0)
             return;
         ProfScope _ps("k_mm", st);
-        hipLaunchKernelGGL(k_mm, dim3((n + 63) / 64), dim3(64), 0, st, x, sym_scratch, counts, g, p, start0, spec, endst, redo, nredo);
+        hipLaunchKernelGGL(k_mm, dim3((n + 63) / 64), dim3(64), 0, st, x, sym_scratch, counts, g, p, start0, spec, endst, spec_c, end_c, redo, nredo);
     }
 
     // quantiser, module_psk_demod.cpp:199-213 + clamp module_demod_base.h:106-113

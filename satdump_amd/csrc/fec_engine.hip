@@ -10,6 +10,7 @@
 #include "fec_kernels.h"
 #include "../../include/sdhip.h"
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <map>
 #include <mutex>
@@ -850,6 +851,15 @@ namespace sdhip
                     stats.viterbi_lock = 1;
                 }
                 // ---- speculative SYNCED run
+                const bool tdbg = getenv("SDHIP_DEBUG") != nullptr;
+                auto t_prev = std::chrono::steady_clock::now();
+                auto tick = [&](const char *what) {
+                    if (!tdbg)
+                        return;
+                    const auto t = std::chrono::steady_clock::now();
+                    fprintf(stderr, "[sdhip] fec   %-10s %7.3f ms (host wall)\n", what, std::chrono::duration<double, std::milli>(t - t_prev).count());
+                    t_prev = t;
+                };
                 const int n = (int)std::min<int64_t>(nblocks - pos, max_batch);
                 vc.iq_swap = v_iq_swap;
                 vc.phase = v_phase;
@@ -918,6 +928,7 @@ namespace sdhip
                 if (getenv("SDHIP_DEBUG"))
                     fprintf(stderr, "[sdhip] viterbi batch %d blocks (%s): segment-certificate re-decodes %u, start-state re-decodes %u in %u round(s), serial tracebacks %u\n", n,
                             v2 ? "lane-per-segment" : "wave-per-block", n_cert, n_chain, n_rounds, n_tbfb);
+                tick("viterbi");
                 // BER estimate of every block, then the lock FSM (viterbi_1_2.cpp:101-113)
                 launch_vit_ber(vc, d_soft, pos, n, d_vbits.p, search.enc_state, d_io.p, stream);
                 SD_HIP(hipMemcpyAsync(h_io.p, d_io.p, (size_t)n * sizeof(VitBlockIO), hipMemcpyDeviceToHost, stream));
@@ -944,8 +955,10 @@ namespace sdhip
                         break;
                     }
                 }
+                tick("ber+fsm");
                 // hand the accepted blocks to the deframer (the MetOp watchdog may cut the run shorter)
                 const int used = deframe_and_emit(accepted, d_out, out_cap_frames, out_written);
+                tick("deframe+rs");
                 if (used < accepted)
                 { // MetOp watchdog reset the Viterbi after block used-1: the rest of the run is decoded again after re-lock
                     accepted = used;
