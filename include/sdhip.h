@@ -189,7 +189,8 @@ extern "C"
     /* dsp blocks over one stream, EXACT sequential semantics (single lane), for arithmetic parity:
        kind 0 AGC(rate,ref,gain,max) agc.cpp:25-39 | 1 RRC FIR(fs,symrate,alpha,ntaps) fir.cpp:74-83 |
        2 Costas(bw,order,limit) costas_loop.cpp:23-65 | 3 MM(omega,gw,mu,gmu,lim) clock_recovery_mm.cpp:52-121 |
-       4 rational resampler(interp,decim) rational_resampler.cpp:43-64. Returns output sample count. */
+       4 rational resampler(interp,decim) rational_resampler.cpp:43-64 | 5 DC block correct_iq.cpp:18-35 |
+       7 Gardner(omega,gw,mu,gmu,lim) clock_recovery_gardner.cpp:33-124. Returns output sample count. */
     int64_t sdhip_op_block(int device, int kind, const float *params, const float *d_in, size_t n, float *d_out, size_t out_cap);
 
     /* ---- measurement ------------------------------------------------------------------ */

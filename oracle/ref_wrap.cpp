@@ -47,6 +47,7 @@ std::shared_ptr<slog::Logger> logger = std::make_shared<slog::Logger>();
 #include "common/dsp/filter/firdes.h"
 #include "common/dsp/pll/costas_loop.h"
 #include "common/dsp/clock_recovery/clock_recovery_mm.h"
+#include "common/dsp/clock_recovery/clock_recovery_gardner.h"
 #include "common/dsp/resamp/rational_resampler.h"
 #include "common/dsp/window/window.h"
 #include "common/dsp/demod/delay_one_imag.h"
@@ -467,6 +468,7 @@ extern "C"
         std::shared_ptr<dsp::RationalResamplerBlock<complex_t>> rr;
         std::shared_ptr<dsp::CorrectIQBlock<complex_t>> dc;
         std::shared_ptr<dsp::DelayOneImagBlock> dly;
+        std::shared_ptr<dsp::GardnerClockRecoveryBlock<complex_t>> gar;
         switch (kind)
         {
         case 0: // AGC(rate, ref, gain, max_gain)
@@ -497,6 +499,12 @@ extern "C"
             dly = std::make_shared<dsp::DelayOneImagBlock>(in);
             outs = dly->output_stream;
             break;
+        case 7: // Gardner(omega, omega_gain, mu, mu_gain, omega_limit)
+            gar = std::make_shared<dsp::GardnerClockRecoveryBlock<complex_t>>(in, p[0], p[1], p[2], p[3], p[4]);
+            memset(gar->buffer, 0, sizeof(complex_t) * 64); // volk_malloc'ed, read before written: taken as zero history
+            gar->sample = gar->zc_sample = gar->last_sample = complex_t(0, 0); // uninitialised members in the reference
+            outs = gar->output_stream;
+            break;
         default:
             return -1;
         }
@@ -513,6 +521,7 @@ extern "C"
             if (rr) rr->work();
             if (dc) dc->work();
             if (dly) dly->work();
+            if (gar) gar->work();
             int k = outs->read();
             if (k > 0)
             {

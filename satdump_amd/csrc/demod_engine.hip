@@ -915,6 +915,31 @@ extern "C"
             ResampParams rp{(int)ip, (int)dc, nt, db.p};
             launch_resample(X, X - DEMOD_HIST, nn, rp, 0, 0, Y, nout, nullptr);
         }
+        else if (kind == 5)
+        { // CorrectIQBlock (DC block), correct_iq.cpp:18-35
+            if (out_cap < n)
+                throw HipError("output too small");
+            DcState s0{0, 0};
+            DevBuf<DcState> st;
+            st.reserve(1);
+            SD_HIP(hipMemcpy(st.p, &s0, sizeof(s0), hipMemcpyHostToDevice));
+            launch_dcblock_seq(X, Y, nn, st.p, nullptr);
+        }
+        else if (kind == 7)
+        { // GardnerClockRecoveryBlock(omega, omega_gain, mu, mu_gain, omega_limit), clock_recovery_gardner.cpp:10-24
+            std::vector<float> mmb;
+            design::mm_bank(128, 8, mmb);
+            DevBuf<float> db;
+            db.reserve(mmb.size());
+            SD_HIP(hipMemcpy(db.p, mmb.data(), mmb.size() * sizeof(float), hipMemcpyHostToDevice));
+            GardnerParams p{params[1], params[3], params[0], params[4] * params[0], params[2], db.p};
+            DevBuf<long long> cnt;
+            cnt.reserve(1);
+            launch_gardner_seq(X, nn, p, Y, (long long)out_cap, cnt.p, nullptr);
+            long long c = 0;
+            SD_HIP(hipMemcpy(&c, cnt.p, sizeof(c), hipMemcpyDeviceToHost));
+            nout = c;
+        }
         else
             throw HipError("unknown block kind");
         SD_HIP(hipDeviceSynchronize());

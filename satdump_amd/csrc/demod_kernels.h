@@ -123,6 +123,13 @@ namespace sdhip
     // spec_c / end_c: compact copies of spec / endst for the host
     void launch_mm(const cf32 *x, cf32 *sym_scratch, int *counts, const ChunkGeom &g, const MmParams &p, const MmState *start0, MmState *spec, MmState *endst,
                    MmCert *spec_c, MmCert *end_c, const int *redo, int nredo, hipStream_t st);
+    // ---- Gardner clock recovery (clock_recovery_gardner.cpp:33-124), sequential lane; x must have >= 32 samples of history in front
+    struct GardnerParams
+    {
+        float omega_gain, mu_gain, omega_mid, omega_limit, init_mu;
+        const float *bank; // [128][8] device, same interpolator bank as the M&M loop
+    };
+    void launch_gardner_seq(const cf32 *x, long long n, const GardnerParams &p, cf32 *out, long long out_cap, long long *count, hipStream_t st);
     // compaction + quantiser (module_psk_demod.cpp:199-213): seg = 2 ints per chunk {first, count}: chunk k's symbols
     // [first, first+count) of its scratch row go to offsets[k]
     void launch_quantize(const cf32 *sym_scratch, const int *seg, const long long *offsets, int K, int cap, int bpsk, int8_t *soft, long long soft_cap,

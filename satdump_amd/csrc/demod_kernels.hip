@@ -849,6 +849,67 @@ namespace sdhip
         hipLaunchKernelGGL(k_mm, dim3((n + 63) / 64), dim3(64), 0, st, x, sym_scratch, counts, g, p, start0, spec, endst, spec_c, end_c, redo, nredo);
     }
 
+    // =============================================================================================
+    // Gardner clock recovery (clock_recovery_gardner.cpp:33-124): sibling of the M&M loop, used by xfsk_burst_demod, not by
+    // psk_demod. One sequential lane, the reference's float/double operations in the reference's order (the two
+    // BRANCHLESS_CLIPs and the zero-crossing phase are evaluated in double exactly where C++'s promotions put them).
+    // =============================================================================================
+    __global__ void k_gardner_seq(const cf32 *x, long long n, GardnerParams p, cf32 *out, long long out_cap, long long *count)
+    {
+        if (threadIdx.x != 0 || blockIdx.x != 0)
+            return;
+        float mu = p.init_mu, omega = p.omega_mid;
+        cf32 last{0.0f, 0.0f};
+        long long inc = 0, ouc = 0;
+        while (inc < n && ouc < out_cap)
+        {
+            const float muz = (float)((double)mu - ((double)omega / 2.0));
+            int offzc = (int)floor((double)omega / 2.0);
+            float mupos = (float)fmod((double)(muz + (float)offzc), 1.0);
+            if (mupos < 0)
+            {
+                mupos = 1 + mupos;
+                offzc += 1;
+            }
+            int imuz = (int)rint((double)(mupos * 128.0f));
+            imuz = imuz < 0 ? 0 : (imuz >= 128 ? 127 : imuz);
+            int imu = (int)rint((double)(mu * 128.0f));
+            imu = imu < 0 ? 0 : (imu >= 128 ? 127 : imu);
+            const float *tz = p.bank + imuz * 8, *t = p.bank + imu * 8;
+            const cf32 *bz = x + inc - offzc - 7, *b = x + inc - 7;
+            float zr = 0.0f, zi = 0.0f, sr = 0.0f, si = 0.0f;
+            for (int k = 0; k < 8; k++)
+            {
+                zr = zr + bz[k].re * tz[k];
+                zi = zi + bz[k].im * tz[k];
+            }
+            for (int k = 0; k < 8; k++)
+            {
+                sr = sr + b[k].re * t[k];
+                si = si + b[k].im * t[k];
+            }
+            float pe = zr * (last.re - sr) + zi * (last.im - si);
+            pe = (float)(0.5 * (fabs((double)pe + 1.0) - fabs((double)pe - 1.0)));
+            last = cf32{sr, si};
+            out[ouc++] = last;
+            omega = omega + p.omega_gain * pe;
+            const float d = omega - p.omega_mid;
+            omega = (float)((double)p.omega_mid + 0.5 * (double)(fabsf(d + p.omega_limit) - fabsf(d - p.omega_limit)));
+            mu = mu + omega + p.mu_gain * pe;
+            const float fl = floorf(mu);
+            inc += (long long)(int)fl;
+            mu = mu - fl;
+            if (inc < 0)
+                inc = 0;
+        }
+        *count = ouc;
+    }
+    void launch_gardner_seq(const cf32 *x, long long n, const GardnerParams &p, cf32 *out, long long out_cap, long long *count, hipStream_t st)
+    {
+        ProfScope _ps("k_gardner_seq", st);
+        hipLaunchKernelGGL(k_gardner_seq, dim3(1), dim3(64), 0, st, x, n, p, out, out_cap, count);
+    }
+
     // quantiser, module_psk_demod.cpp:199-213 + clamp module_demod_base.h:106-113
     __device__ __forceinline__ signed char sd_clamp8(float x)
     {

@@ -41,7 +41,8 @@ def _dev(torch, a):
 
 
 BLOCKS = [(0, [1e-2, 1, 1, 65536]), (1, [6e6, 2333333, 0.5, 31]), (2, [0.003, 4, 1.0]), (2, [0.02, 2, 1.0]), (2, [0.003, 8, 1.0]),
-          (3, [2.5714, (8.7e-3) ** 2 / 4, 0.5, 8.7e-3, 0.005]), (4, [2700000, 3000000])]
+          (3, [2.5714, (8.7e-3) ** 2 / 4, 0.5, 8.7e-3, 0.005]), (4, [2700000, 3000000]), (5, [0.0]),
+          (7, [2.5714, (8.7e-3) ** 2 / 4, 0.5, 8.7e-3, 0.005]), (7, [2.0, (8.7e-3) ** 2 / 4, 0.5, 8.7e-3, 0.005])]
 
 
 @pytest.mark.parametrize("kind,params", BLOCKS)
