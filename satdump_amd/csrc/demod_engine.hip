@@ -73,6 +73,171 @@ namespace sdhip
             partial[blockIdx.x] = acc[0];
     }
 
+    // =============================================================================================
+    // Boundary certificates on the device. Every boundary k is judged from (state chunk k's warm-up reached, state chunk
+    // k-1 ended in) alone, so the verdicts are one thread per boundary; what the sequential host loop carried along
+    // (Costas frame rotation, symbol offsets) is a prefix sum. The host reads back four counters per round.
+    // =============================================================================================
+    struct VerdictOut
+    {
+        int nfail, inexact, rotated, overflow;
+        long long total;
+    };
+    template <class S>
+    __global__ void k_spec_from_prev(const int *list, int n, S *spec, const S *endst)
+    { // a re-run chunk starts from the exact end state of its predecessor: that is the state its certificate holds now
+        const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+        if (i < n)
+            spec[list[i]] = endst[list[i] - 1];
+    }
+    __device__ __forceinline__ void verdict_fail(VerdictOut *vo, int *fails, int k) { fails[atomicAdd(&vo->nfail, 1)] = k; }
+
+    __global__ void k_agc_verdict(int K, const AgcState *spec, const AgcState *endst, VerdictOut *vo, int *fails)
+    {
+        const int k = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+        if (k < 1 || k >= K)
+            return;
+        const float a = spec[k].gain, b = endst[k - 1].gain;
+        if (__float_as_uint(a) == __float_as_uint(b))
+            return;
+        if (fabsf(a - b) <= 1e-6f * fabsf(b))
+            atomicAdd(&vo->inexact, 1);
+        else
+            verdict_fail(vo, fails, k);
+    }
+    // dm[k] = quarter/half/eighth turns chunk k's frame is ahead of chunk k-1's (0 for a bit-exact or re-run boundary)
+    __global__ void k_costas_verdict(int K, const CostasState *spec, const CostasState *endst, double rot_unit, int rot_mod, int *dm, VerdictOut *vo,
+                                     int *fails)
+    {
+        const int k = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+        if (k >= K)
+            return;
+        int d_out = 0;
+        if (k >= 1)
+        {
+            const CostasState a = spec[k], b = endst[k - 1];
+            if (!(__float_as_uint(a.phase) == __float_as_uint(b.phase) && __float_as_uint(a.freq) == __float_as_uint(b.freq)))
+            {
+                // the loop's stable points are rot_unit apart: accept a lock on another one and rotate it back
+                const double dphi = (double)a.phase - (double)b.phase;
+                const long long d = llround(dphi / rot_unit);
+                const double resid = dphi - (double)d * rot_unit;
+                if (fabs(resid) < 2e-5 && fabs((double)a.freq - (double)b.freq) < 2e-7)
+                {
+                    d_out = (int)(((d % rot_mod) + rot_mod) % rot_mod);
+                    if (d_out != 0)
+                        atomicAdd(&vo->rotated, 1);
+                    atomicAdd(&vo->inexact, 1);
+                }
+                else
+                    verdict_fail(vo, fails, k); // re-run continues in the previous chunk's frame: dm = 0
+            }
+        }
+        dm[k] = d_out;
+    }
+    // symbol hand-off at an M&M boundary (see DemodEngine::process): skip[k] symbols dropped at the head of chunk k, extra[k-1]
+    // look-ahead symbols of chunk k-1 appended
+    __global__ void k_mm_verdict(int K, const MmCert *spec, const MmCert *endst, const int *counts, double tol, int *skip, int *extra, VerdictOut *vo,
+                                 int *fails)
+    {
+        const int k = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+        if (k >= K)
+            return;
+        if (k == 0)
+        {
+            skip[0] = 0;
+            extra[K - 1] = 0;
+            return;
+        }
+        int sk = 0, ex = 0;
+        const MmCert a = spec[k], b = endst[k - 1];
+        const bool same = __float_as_uint(a.mu) == __float_as_uint(b.mu) && __float_as_uint(a.omega) == __float_as_uint(b.omega) && a.inc == b.inc;
+        if (!same)
+        {
+            bool ok = false;
+            const double d = (double)(a.inc - b.inc) + ((double)a.mu - (double)b.mu);
+            const double om = (double)b.omega;
+            const long long r = llround(d / om);
+            if (fabs(d - (double)r * om) < tol && fabsf(a.omega - b.omega) < 1e-3f * fabsf(b.omega))
+            {
+                if (r == 0)
+                    ok = true;
+                else if (r > 0 && r <= counts[2 * (k - 1) + 1])
+                { // chunk k starts r symbols late: chunk k-1's look-ahead fills the gap
+                    ex = (int)r;
+                    ok = true;
+                }
+                else if (r < 0 && -r <= 2 && -r < counts[2 * k])
+                { // chunk k starts r symbols early: its first symbols duplicate chunk k-1's last ones
+                    sk = (int)-r;
+                    ok = true;
+                }
+            }
+            if (ok)
+                atomicAdd(&vo->inexact, 1);
+            else
+                verdict_fail(vo, fails, k);
+        }
+        skip[k] = sk;
+        extra[k - 1] = ex;
+    }
+    // one block: exclusive prefix sums over K chunks. mode 0: rot[k] = (sum of dm[0..k]) mod rot_mod (inclusive);
+    // mode 1: seg = {skip, count}, offs[k] = symbols in front of chunk k, vo->total, vo->overflow
+    __global__ __launch_bounds__(1024) void k_chunk_scan(int K, int mode, const int *dm, int rot_mod, int *rot, const int *counts, const int *skip, const int *extra,
+                                                          int cap, int *seg, long long *offs, VerdictOut *vo)
+    {
+        __shared__ long long part[1024];
+        const int t = (int)threadIdx.x;
+        const int per = (K + 1023) / 1024;
+        const int k0 = t * per, k1 = min(K, k0 + per);
+        long long s = 0;
+        int ovf = 0;
+        for (int k = k0; k < k1; k++)
+        {
+            if (mode == 0)
+                s += dm[k];
+            else
+            {
+                if (counts[2 * k] + 2 > cap)
+                    ovf = 1;
+                s += counts[2 * k] - skip[k] + extra[k];
+            }
+        }
+        part[t] = s;
+        __syncthreads();
+        for (int d = 1; d < 1024; d <<= 1)
+        {
+            const long long v = t >= d ? part[t - d] : 0;
+            __syncthreads();
+            part[t] += v;
+            __syncthreads();
+        }
+        long long run = t ? part[t - 1] : 0;
+        for (int k = k0; k < k1; k++)
+        {
+            if (mode == 0)
+            {
+                run += dm[k];
+                rot[k] = (int)(run % rot_mod);
+            }
+            else
+            {
+                const int c = counts[2 * k] - skip[k] + extra[k];
+                seg[2 * k] = skip[k];
+                seg[2 * k + 1] = c;
+                offs[k] = run;
+                run += c;
+            }
+        }
+        if (mode == 1)
+        {
+            if (ovf)
+                atomicExch(&vo->overflow, 1);
+            if (t == 1023)
+                vo->total = part[1023];
+        }
+    }
+
     struct DemodEngine
     {
         sdhip_demod_cfg cfg;
@@ -108,8 +273,7 @@ namespace sdhip
         DevBuf<MmState> d_mm_spec, d_mm_end, d_mm_start;
         DevBuf<MmCert> d_mm_spec_c, d_mm_end_c; // what the host certificate reads (16 B per chunk instead of the 72-byte state)
         DevBuf<DcState> d_dc;
-        DevBuf<int> d_redo, d_rot, d_counts, d_seg;
-        PinBuf<int> h_counts;
+        DevBuf<int> d_redo, d_rot, d_dm, d_counts, d_seg, d_skip, d_extra;
         DevBuf<long long> d_offsets;
         DevBuf<double> d_partial;
         DevBuf<int8_t> d_soft_tmp;
@@ -301,50 +465,42 @@ namespace sdhip
             return (int)std::min<long long>(std::max<long long>(L, 2048), 1 << 20);
         }
 
-        // Certificate chain of one speculative stage. Chunk k stands iff accept(k, state its warm-up reached, state chunk
-        // k-1 ended in). Every chunk that fails is re-run from the exact end state of its predecessor -- all failing
-        // chunks of a round in ONE launch -- and the chain is evaluated again (a re-run changes that chunk's end state,
-        // which its successor is then checked against), until nothing fails. accept() is evaluated for k ascending and
-        // may fill per-chunk side information derived from chunk k-1's (rotation, symbol hand-off).
-        // (states travel through pinned host buffers: a pageable destination costs ~1 ms per stage at ~10^5 chunks)
-        PinBuf<uint8_t> h_vf_spec, h_vf_end;
-        template <class S, class Accept, class Launch>
-        void verify_fix(const char *stage, int K, DevBuf<S> &d_spec, DevBuf<S> &d_end, S *&spec, S *&endst, Accept accept, Launch relaunch)
+        // Certificate chain of one speculative stage. Chunk k stands iff its verdict kernel accepts (state its warm-up reached,
+        // state chunk k-1 ended in). Every chunk that fails is re-run from the exact end state of its predecessor -- all failing
+        // chunks of a round in ONE launch -- and the chain is judged again (a re-run changes that chunk's end state, which its
+        // successor is then checked against), until nothing fails. Only the four counters of VerdictOut cross PCIe.
+        DevBuf<VerdictOut> d_vout;
+        PinBuf<VerdictOut> h_vout;
+        DevBuf<int> d_fails;
+        template <class Verdict, class SpecFix, class Launch>
+        VerdictOut verify_fix(const char *stage, int K, Verdict verdict, SpecFix specfix, Launch relaunch)
         {
-            h_vf_spec.reserve((size_t)K * sizeof(S));
-            h_vf_end.reserve((size_t)K * sizeof(S));
-            spec = reinterpret_cast<S *>(h_vf_spec.p);
-            endst = reinterpret_cast<S *>(h_vf_end.p);
-            SD_HIP(hipMemcpyAsync(spec, d_spec.p, (size_t)K * sizeof(S), hipMemcpyDeviceToHost, stream));
+            d_vout.reserve(1);
+            h_vout.reserve(1);
+            d_fails.reserve((size_t)K + 1);
             unsigned reruns = 0, rounds = 0;
-            std::vector<int> fails;
             for (;;)
             {
-                SD_HIP(hipMemcpyAsync(endst, d_end.p, (size_t)K * sizeof(S), hipMemcpyDeviceToHost, stream));
+                SD_HIP(hipMemsetAsync(d_vout.p, 0, sizeof(VerdictOut), stream));
+                verdict(d_vout.p, d_fails.p);
+                SD_HIP(hipMemcpyAsync(h_vout.p, d_vout.p, sizeof(VerdictOut), hipMemcpyDeviceToHost, stream));
                 SD_HIP(hipStreamSynchronize(stream));
-                fails.clear();
-                round_inexact = round_rotated = 0;
-                for (int k = 1; k < K; k++)
-                    if (!accept(k, spec[k], endst[k - 1]))
-                        fails.push_back(k);
-                if (fails.empty())
+                const int nf = h_vout.p->nfail;
+                if (nf == 0)
                     break;
                 if (++rounds > (unsigned)K + 1)
                     throw HipError(std::string(stage) + ": boundary certificates do not converge");
-                reruns += (unsigned)fails.size();
-                d_redo.reserve(fails.size());
-                SD_HIP(hipMemcpyAsync(d_redo.p, fails.data(), fails.size() * sizeof(int), hipMemcpyHostToDevice, stream));
-                relaunch(d_redo.p, (int)fails.size());
-                for (int k : fails)
-                    spec[k] = endst[k - 1]; // the state the re-run started from
+                reruns += (unsigned)nf;
+                specfix(d_fails.p, nf);
+                relaunch(d_fails.p, nf);
             }
             stats.chunks_fixed += reruns;
-            stats.chunks_inexact += round_inexact;
-            stats.chunks_rotated += round_rotated;
+            stats.chunks_inexact += (unsigned)h_vout.p->inexact;
+            stats.chunks_rotated += (unsigned)h_vout.p->rotated;
             if (getenv("SDHIP_DEBUG"))
-                fprintf(stderr, "[sdhip] %-6s chunks %d  re-run %u in %u round(s)  accepted-by-tolerance %u\n", stage, K, reruns, rounds, round_inexact);
+                fprintf(stderr, "[sdhip] %-6s chunks %d  re-run %u in %u round(s)  accepted-by-tolerance %d\n", stage, K, reruns, rounds, h_vout.p->inexact);
+            return *h_vout.p;
         }
-        unsigned round_inexact = 0, round_rotated = 0;
 
         // Process n input samples resident on the device. Outputs go to d_soft / d_syms (device).
         int64_t process(const void *d_in, size_t n_in, int fmt, int8_t *d_soft, size_t soft_cap, float *d_syms, size_t syms_cap)
@@ -459,21 +615,16 @@ namespace sdhip
                 d_agc_end.reserve(g.K);
                 SD_HIP(hipMemcpyAsync(d_agc_start.p, &agc_s, sizeof(agc_s), hipMemcpyHostToDevice, stream));
                 launch_agc(AIN, B, g, agc_p, d_agc_start.p, d_agc_spec.p, d_agc_end.p, nullptr, 0, stream);
-                AgcState *spec = nullptr, *endst = nullptr;
+                const int vb = (g.K + 255) / 256;
                 verify_fix(
-                    "agc", g.K, d_agc_spec, d_agc_end, spec, endst,
-                    [&](int, const AgcState &a, const AgcState &b) {
-                        if (memcmp(&a, &b, sizeof(a)) == 0)
-                            return true;
-                        if (std::fabs(a.gain - b.gain) <= 1e-6f * std::fabs(b.gain))
-                        {
-                            round_inexact++;
-                            return true;
-                        }
-                        return false;
+                    "agc", g.K,
+                    [&](VerdictOut *vo, int *fails) { hipLaunchKernelGGL(k_agc_verdict, dim3(vb), dim3(256), 0, stream, g.K, d_agc_spec.p, d_agc_end.p, vo, fails); },
+                    [&](const int *list, int nr) {
+                        hipLaunchKernelGGL(k_spec_from_prev<AgcState>, dim3((nr + 255) / 256), dim3(256), 0, stream, list, nr, d_agc_spec.p, d_agc_end.p);
                     },
                     [&](const int *redo, int nr) { launch_agc(AIN, B, g, agc_p, d_agc_start.p, d_agc_spec.p, d_agc_end.p, redo, nr, stream); });
-                agc_s = endst[g.K - 1];
+                SD_HIP(hipMemcpyAsync(&agc_s, d_agc_end.p + (g.K - 1), sizeof(agc_s), hipMemcpyDeviceToHost, stream));
+                SD_HIP(hipStreamSynchronize(stream));
                 std::swap(A, B);
             }
             tick("agc");
@@ -486,7 +637,6 @@ namespace sdhip
             tick("fir");
             // ---- Costas (speculative, symmetry-corrected)
             ChunkGeom cg;
-            std::vector<int> rot;
             {
                 if (!started)
                 {
@@ -521,47 +671,29 @@ namespace sdhip
                 d_cos_end.reserve(cg.K);
                 SD_HIP(hipMemcpyAsync(d_cos_start.p, &cos_s, sizeof(cos_s), hipMemcpyHostToDevice, stream));
                 launch_costas(A, B, cg, cos_p, d_cos_start.p, d_cos_spec.p, d_cos_end.p, nullptr, 0, stream);
-                rot.assign(cg.K, 0);
-                int cdbg_left = getenv("SDHIP_DEBUG") ? 12 : 0;
-                CostasState *spec = nullptr, *endst = nullptr;
+                d_rot.reserve(cg.K);
+                d_dm.reserve(cg.K);
+                const int vb = (cg.K + 255) / 256;
                 verify_fix(
-                    "costas", cg.K, d_cos_spec, d_cos_end, spec, endst,
-                    [&](int k, const CostasState &a, const CostasState &b) {
-                        if (memcmp(&a, &b, sizeof(a)) == 0)
-                        {
-                            rot[k] = rot[k - 1];
-                            return true;
-                        }
-                        // the loop's stable points are rot_unit apart: accept a lock on another one and rotate it back
-                        const double dphi = (double)a.phase - (double)b.phase;
-                        const double u = dphi / rot_unit;
-                        const long long d = llround(u);
-                        const double resid = dphi - (double)d * rot_unit;
-                        if (std::fabs(resid) < 2e-5 && std::fabs((double)a.freq - (double)b.freq) < 2e-7)
-                        {
-                            const int dm = (int)(((d % rot_mod) + rot_mod) % rot_mod);
-                            rot[k] = (rot[k - 1] + dm) % rot_mod;
-                            if (dm != 0)
-                                round_rotated++;
-                            round_inexact++;
-                            return true;
-                        }
-                        rot[k] = rot[k - 1]; // re-run continues in the previous chunk's frame
-                        if (cdbg_left > 0)
-                        {
-                            cdbg_left--;
-                            fprintf(stderr, "[sdhip] costas boundary %d rejected: dphi %.6f = %lld units %+.6f, freq %.9f vs %.9f (d %.3g)\n", k, dphi, d, resid,
-                                    a.freq, b.freq, (double)a.freq - (double)b.freq);
-                        }
-                        return false;
+                    "costas", cg.K,
+                    [&](VerdictOut *vo, int *fails) {
+                        hipLaunchKernelGGL(k_costas_verdict, dim3(vb), dim3(256), 0, stream, cg.K, d_cos_spec.p, d_cos_end.p, rot_unit, rot_mod, d_dm.p, vo, fails);
+                    },
+                    [&](const int *list, int nr) {
+                        hipLaunchKernelGGL(k_spec_from_prev<CostasState>, dim3((nr + 255) / 256), dim3(256), 0, stream, list, nr, d_cos_spec.p, d_cos_end.p);
                     },
                     [&](const int *redo, int nr) { launch_costas(A, B, cg, cos_p, d_cos_start.p, d_cos_spec.p, d_cos_end.p, redo, nr, stream); });
+                // rot[k] = frame of chunk k relative to the stream's (prefix sum of the per-boundary turns)
+                hipLaunchKernelGGL(k_chunk_scan, dim3(1), dim3(1024), 0, stream, cg.K, 0, d_dm.p, rot_mod, d_rot.p, nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr);
+                int rot_last = 0;
+                SD_HIP(hipMemcpyAsync(&cos_s, d_cos_end.p + (cg.K - 1), sizeof(cos_s), hipMemcpyDeviceToHost, stream));
+                SD_HIP(hipMemcpyAsync(&rot_last, d_rot.p + (cg.K - 1), sizeof(int), hipMemcpyDeviceToHost, stream));
+                SD_HIP(hipStreamSynchronize(stream));
                 // chunk k's phase = true phase + rot[k]*unit; carry the loop state in the frame of the last chunk,
                 // re-expressed in the stream's frame (rot 0) so the next call starts unrotated
-                cos_s = endst[cg.K - 1];
-                if (rot[cg.K - 1] != 0)
+                if (rot_last != 0)
                 {
-                    double ph = (double)cos_s.phase - rot[cg.K - 1] * rot_unit;
+                    double ph = (double)cos_s.phase - rot_last * rot_unit;
                     while (ph > 2 * design::PI)
                         ph -= 2 * design::PI;
                     while (ph < -2 * design::PI)
@@ -575,8 +707,6 @@ namespace sdhip
             // ---- M&M + quantiser
             int64_t nsoft = 0;
             {
-                d_rot.reserve(cg.K);
-                SD_HIP(hipMemcpyAsync(d_rot.p, rot.data(), (size_t)cg.K * sizeof(int), hipMemcpyHostToDevice, stream));
                 put_hist(A, hist_cos);
                 // timing loop: ~2/(Kd*gain_mu) symbols per time constant with a detector gain Kd well below 1 at low Es/N0
                 // (measured: ~700 symbols at 7 dB BPSK with the default gains)
@@ -609,7 +739,6 @@ namespace sdhip
                 d_mm_end_c.reserve(g.K);
                 SD_HIP(hipMemcpyAsync(d_mm_start.p, &mm_s, sizeof(mm_s), hipMemcpyHostToDevice, stream));
                 launch_mm(A, symbuf.p, d_counts.p, g, mm_p, d_mm_start.p, d_mm_spec.p, d_mm_end.p, d_mm_spec_c.p, d_mm_end_c.p, nullptr, 0, stream);
-                MmCert *spec = nullptr, *endst = nullptr;
                 // Symbol hand-off at chunk boundaries. The M&M loop never re-merges bit for bit: its feedback is piecewise
                 // constant through the 128-arm interpolator index rint(mu*128) (clock_recovery_mm.cpp:66), so independent
                 // trajectories hover a fraction of an arm apart (tools/merge_study.py). What is certified is CONSISTENCY in
@@ -617,87 +746,40 @@ namespace sdhip
                 // k-1 ended with. Equal within MM_TOL samples: chunk k stands. Exactly one or two symbol periods apart (the
                 // boundary fell between the two trajectories' sample indices, mu wrapping on opposite sides): the symbol(s) are
                 // taken from chunk k-1's look-ahead, or skipped at the head of chunk k. Anything else: re-run from the exact state.
+                // (k_mm_verdict; the compaction segments and offsets are a prefix sum on the device, k_chunk_scan.)
                 const double MM_TOL = env_int("SDHIP_MM_TOL_MILLI", 50) * 1e-3;
-                int dbg_left = getenv("SDHIP_DEBUG") ? 8 : 0;
-                std::vector<int> skip(g.K, 0), extra(g.K, 0);
-                h_counts.reserve(2 * (size_t)g.K);
-                int *counts = h_counts.p;
-                bool counts_fresh = false;
-                auto fetch_counts = [&]() {
-                    SD_HIP(hipMemcpyAsync(counts, d_counts.p, 2 * (size_t)g.K * sizeof(int), hipMemcpyDeviceToHost, stream));
-                    SD_HIP(hipStreamSynchronize(stream));
-                    counts_fresh = true;
-                };
+                d_skip.reserve(g.K);
+                d_extra.reserve(g.K);
+                d_seg.reserve(2 * (size_t)g.K);
+                const int vb = (g.K + 255) / 256;
                 verify_fix(
-                    "mm", g.K, d_mm_spec_c, d_mm_end_c, spec, endst,
-                    [&](int k, const MmCert &a, const MmCert &b) {
-                        if (!counts_fresh)
-                            fetch_counts();
-                        skip[k] = 0;
-                        extra[k - 1] = 0;
-                        if (memcmp(&a, &b, sizeof(a)) == 0)
-                            return true;
-                        const double d = (double)(a.inc - b.inc) + ((double)a.mu - (double)b.mu);
-                        const double om = (double)b.omega;
-                        const long long r = llround(d / om);
-                        if (std::fabs(d - (double)r * om) < MM_TOL && std::fabs(a.omega - b.omega) < 1e-3f * std::fabs(b.omega))
-                        {
-                            if (r == 0)
-                            {
-                                round_inexact++;
-                                return true;
-                            }
-                            if (r > 0 && r <= counts[2 * (k - 1) + 1])
-                            { // chunk k starts r symbols late: chunk k-1's look-ahead fills the gap
-                                extra[k - 1] = (int)r;
-                                round_inexact++;
-                                return true;
-                            }
-                            if (r < 0 && -r <= 2 && -r < counts[2 * k])
-                            { // chunk k starts r symbols early: its first symbols duplicate chunk k-1's last ones
-                                skip[k] = (int)-r;
-                                round_inexact++;
-                                return true;
-                            }
-                        }
-                        if (dbg_left > 0)
-                        {
-                            dbg_left--;
-                            fprintf(stderr, "[sdhip] mm boundary %d rejected: dt %.5f samples = %lld symbols %+.5f, omega %.6f vs %.6f, look-ahead %d\n", k, d, r,
-                                    d - (double)r * om, a.omega, b.omega, counts[2 * (k - 1) + 1]);
-                        }
-                        return false;
+                    "mm", g.K,
+                    [&](VerdictOut *vo, int *fails) {
+                        hipLaunchKernelGGL(k_mm_verdict, dim3(vb), dim3(256), 0, stream, g.K, d_mm_spec_c.p, d_mm_end_c.p, d_counts.p, MM_TOL, d_skip.p, d_extra.p, vo,
+                                           fails);
+                    },
+                    [&](const int *list, int nr) {
+                        hipLaunchKernelGGL(k_spec_from_prev<MmCert>, dim3((nr + 255) / 256), dim3(256), 0, stream, list, nr, d_mm_spec_c.p, d_mm_end_c.p);
                     },
                     [&](const int *redo, int nr) {
                         launch_mm(A, symbuf.p, d_counts.p, g, mm_p, d_mm_start.p, d_mm_spec.p, d_mm_end.p, d_mm_spec_c.p, d_mm_end_c.p, redo, nr, stream);
-                        counts_fresh = false;
                     });
-                if (!counts_fresh)
-                    fetch_counts();
+                // compaction segments + offsets + total
+                SD_HIP(hipMemsetAsync(d_vout.p, 0, sizeof(VerdictOut), stream));
+                hipLaunchKernelGGL(k_chunk_scan, dim3(1), dim3(1024), 0, stream, g.K, 1, nullptr, 1, nullptr, d_counts.p, d_skip.p, d_extra.p, mm_p.cap, d_seg.p,
+                                   d_offsets.p, d_vout.p);
+                SD_HIP(hipMemcpyAsync(h_vout.p, d_vout.p, sizeof(VerdictOut), hipMemcpyDeviceToHost, stream));
                 SD_HIP(hipMemcpyAsync(&mm_s, d_mm_end.p + (g.K - 1), sizeof(mm_s), hipMemcpyDeviceToHost, stream));
                 SD_HIP(hipStreamSynchronize(stream));
                 mm_s.inc -= n; // clock_recovery_mm.cpp:123-126
                 if (mm_s.inc < 0)
                     mm_s.inc = 0;
-                // compaction segments + offsets
-                std::vector<int> seg(2 * (size_t)g.K);
-                std::vector<long long> offs(g.K);
-                long long tot = 0;
-                for (int k = 0; k < g.K; k++)
-                {
-                    if (counts[2 * k] + 2 > mm_p.cap)
-                        throw HipError("symbol scratch overflow");
-                    seg[2 * k] = skip[k];
-                    seg[2 * k + 1] = counts[2 * k] - skip[k] + extra[k];
-                    offs[k] = tot;
-                    tot += seg[2 * k + 1];
-                }
+                if (h_vout.p->overflow)
+                    throw HipError("symbol scratch overflow");
+                const long long tot = h_vout.p->total;
                 const long long need_soft = is_bpsk ? tot : 2 * tot;
                 if ((size_t)need_soft > soft_cap)
                     throw HipError("soft output buffer too small");
-                d_seg.reserve(seg.size());
-                SD_HIP(hipMemcpyAsync(d_seg.p, seg.data(), seg.size() * sizeof(int), hipMemcpyHostToDevice, stream));
-                SD_HIP(hipMemcpyAsync(d_offsets.p, offs.data(), (size_t)g.K * sizeof(long long), hipMemcpyHostToDevice, stream));
                 launch_quantize(symbuf.p, d_seg.p, d_offsets.p, g.K, mm_p.cap, is_bpsk ? 1 : 0, d_soft, (long long)soft_cap, d_syms, (long long)syms_cap, stream);
                 // history for the next call: last DEMOD_HIST de-rotated Costas outputs
                 launch_tail_copy(A, n, DEMOD_HIST, cg, d_rot.p, order, d_hist.p, stream);
