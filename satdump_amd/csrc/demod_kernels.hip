@@ -225,6 +225,68 @@ namespace sdhip
                 reinterpret_cast<v2f *>(y)[m] = acc[r];
         }
     }
+    // Decimating ratios close to 1 (GOES: 9/10): consecutive outputs start 1 or 2 input samples apart, so the 32 lanes of an
+    // LDS access group span more than 32 tile slots and every tile read of k_resample takes two passes (SQ: bank-conflict
+    // cycles ~3x the active LDS cycles). Here a lane owns an INPUT OFFSET instead: the one output (if any) whose window ends
+    // at that sample. Lanes then read stride-1 tile slots -- conflict free -- at the price of decim-interp idle lanes in decim.
+    // Same arithmetic per output (taps oldest first, mul and add rounded separately).
+    // A thread's RS_PER offsets are `stride` = (256 / decim) * decim apart: same polyphase arm (the hit/miss pattern and the
+    // arm repeat every decim offsets), so the tap is read once per k for all of them.
+    __global__ __launch_bounds__(RS_BLOCK) void k_resample_byoffset(const cf32 *x, const cf32 *hist, long long nin, ResampParams p, int ctr0, int inc0, cf32 *y,
+                                                                    long long nout, long long o_first, int stride)
+    {
+        __shared__ float bank[RS_MAX_BANK];
+        __shared__ v2f tile[RS_BLOCK * RS_PER + 64];
+        const int nb = p.interp * p.ntaps;
+        for (int i = (int)threadIdx.x; i < nb; i += RS_BLOCK)
+            bank[i] = p.bank[i];
+        const long long o_base = o_first + (long long)blockIdx.x * (stride * RS_PER); // window-end offsets [o_base, o_base + RS_PER*stride)
+        const long long first = o_base - (p.ntaps - 1);
+        const int span = stride * RS_PER + p.ntaps - 1;
+        for (int i = (int)threadIdx.x; i < span; i += RS_BLOCK)
+        {
+            const long long idx = first + i;
+            const cf32 v = (idx < 0) ? hist[DEMOD_HIST + idx] : (idx < nin ? x[idx] : cf32{0.0f, 0.0f});
+            tile[i] = v2f{v.re, v.im};
+        }
+        __syncthreads();
+        const int t0 = (int)threadIdx.x;
+        if (t0 >= stride)
+            return;
+        v2f acc[RS_PER];
+        long long mm[RS_PER];
+        int row = 0;
+#pragma unroll
+        for (int r = 0; r < RS_PER; r++)
+        {
+            const long long o = o_base + t0 + stride * r;
+            // smallest m with inc0 + (ctr0 + m*decim)/interp >= o; it is THE output of offset o iff equality holds
+            const long long need = (o - inc0) * p.interp - ctr0;
+            const long long m = need <= 0 ? 0 : (need + p.decim - 1) / p.decim;
+            const long long ph = (long long)ctr0 + m * p.decim;
+            const bool hit = m < nout && inc0 + ph / p.interp == o;
+            mm[r] = hit ? m : -1;
+            if (r == 0)
+                row = (int)(ph % p.interp) * p.ntaps; // a miss at r = 0 is a miss at every r (or past the end): row is unused then
+            acc[r] = v2f{0.0f, 0.0f};
+        }
+        for (int k = 0; k < p.ntaps; k++)
+        {
+            const float tk = bank[row + k];
+            const v2f tt{tk, tk};
+#pragma unroll
+            for (int r = 0; r < RS_PER; r++)
+            {
+                const v2f prod = tile[t0 + stride * r + k] * tt;
+                acc[r] = acc[r] + prod;
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < RS_PER; r++)
+            if (mm[r] >= 0)
+                reinterpret_cast<v2f *>(y)[mm[r]] = acc[r];
+    }
+
     // fallback for banks / spans that do not fit the LDS budget (very large interpolation factors)
     __global__ __launch_bounds__(256) void k_resample_big(const cf32 *x, const cf32 *hist, long long nin, ResampParams p, int ctr0, int inc0, cf32 *y,
                                                            long long nout)
@@ -255,7 +317,16 @@ namespace sdhip
             return;
 
         const long long span_max = ((long long)RS_BLOCK * RS_PER * p.decim) / p.interp + p.ntaps + 2;
-        if (p.interp * p.ntaps <= RS_MAX_BANK && span_max <= RS_MAX_TILE)
+        if (p.interp * p.ntaps <= RS_MAX_BANK && p.ntaps <= 64 && p.decim > p.interp && 4 * p.decim <= 5 * p.interp && p.decim <= 64)
+        {
+            const long long o_first = inc0 + (long long)ctr0 / p.interp;                              // window end of output 0
+            const long long o_last = inc0 + ((long long)ctr0 + (nout - 1) * (long long)p.decim) / p.interp; // ... of the last output
+            const int stride = (RS_BLOCK / p.decim) * p.decim;
+            ProfScope _ps("k_resample_byoffset", st);
+            hipLaunchKernelGGL(k_resample_byoffset, dim3((unsigned)((o_last - o_first + stride * RS_PER) / (stride * RS_PER))), dim3(RS_BLOCK), 0, st, x, hist, nin, p,
+                               ctr0, inc0, y, nout, o_first, stride);
+        }
+        else if (p.interp * p.ntaps <= RS_MAX_BANK && span_max <= RS_MAX_TILE)
         {
             ProfScope _ps("k_resample", st);
             hipLaunchKernelGGL(k_resample, dim3((unsigned)((nout + RS_BLOCK * RS_PER - 1) / (RS_BLOCK * RS_PER))), dim3(RS_BLOCK), 0, st, x, hist, nin, p, ctr0, inc0, y, nout);
