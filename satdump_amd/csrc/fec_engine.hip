@@ -136,7 +136,7 @@ namespace sdhip
         int nphases = 1, n_swap = 1;
         int st_synced = 12;
         double ber_mult = 2.5;
-        int max_batch = 16384;
+        int max_batch = 65536; // blocks per Viterbi launch (decision scratch: 8 B per trellis step, ~2.2 GB at F = 4096)
 
         // Viterbi FSM (viterbi_1_2.h:25-31)
         int vstate = 0, v_iq_swap = 0, v_phase = 0, v_shift = 0, v_invalid = 0;

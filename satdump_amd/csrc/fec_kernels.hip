@@ -647,14 +647,13 @@ namespace sdhip
     #ifndef V2_WAVES
 #define V2_WAVES 2
 #endif
-    __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(V2_WAVES, V2_WAVES))) void k_vit2_acs(int F, int NSEG, int nblk, const unsigned short *__restrict__ symu, int SU, VitBlockIO *io,
+    __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(V2_WAVES, V2_WAVES))) void k_vit2_acs(int F, int S, int NSEG, int nblk, const unsigned short *__restrict__ symu, int SU, VitBlockIO *io,
                                                       unsigned long long *dec, long long U64, unsigned *specx, unsigned *endx)
     {
         const int u = (int)(blockIdx.x * 64 + threadIdx.x);
         if (u >= nblk * NSEG)
             return;
         const int j = u / NSEG, g = u - j * NSEG;
-        const int S = VIT2_SEG;
         const uint4 *row = reinterpret_cast<const uint4 *>(symu + (size_t)j * SU + (size_t)g * S); // 8 steps per uint4
         V2State s;
         v2_init_neutral(s);
@@ -741,14 +740,13 @@ namespace sdhip
     }
 
     // ---- traceback: one lane per (block, segment); bits [g*S, (g+1)*S) <- decisions at steps n + 6
-    __global__ __launch_bounds__(64) void k_vit2_tb(int F, int NSEG, int nblk, const VitBlockIO *io, const unsigned long long *__restrict__ dec, long long U64,
+    __global__ __launch_bounds__(64) void k_vit2_tb(int F, int S, int NSEG, int nblk, const VitBlockIO *io, const unsigned long long *__restrict__ dec, long long U64,
                                                      unsigned *vbits, int wpb, int *entry, int *exitst)
     {
         const int u = (int)(blockIdx.x * 64 + threadIdx.x);
         if (u >= nblk * NSEG)
             return;
         const int j = u / NSEG, g = u - j * NSEG;
-        const int S = VIT2_SEG;
         const int t_hi = (g + 1) * S + 5;
         int tstart = t_hi + VIT_TB_OVERLAP;
         if (tstart > F + 5)
@@ -811,7 +809,18 @@ namespace sdhip
     {
         if (nblk <= 0)
             return;
-        const int F = cfg.F, S = VIT2_SEG, NSEG = F / S;
+        // segment length: 512 steps; twice that when the batch still fills the chip with >= 2 waves per SIMD (the 200-step
+        // warm-up then costs 20 % instead of 39 %)
+        const int F = cfg.F;
+        int S = VIT2_SEG;
+        {
+            const char *e = getenv("SDHIP_VIT2_SEG");
+            if (e && atoi(e) >= 512 && F % atoi(e) == 0 && F / atoi(e) >= 2)
+                S = atoi(e);
+            else if (F % (2 * VIT2_SEG) == 0 && F / (2 * VIT2_SEG) >= 2 && (long long)nblk * (F / (2 * VIT2_SEG)) >= 2 * 65536)
+                S = 2 * VIT2_SEG;
+        }
+        const int NSEG = F / S;
         const int SU = (VIT2_WARM + F + 6 + 8 + 7) / 8 * 8; // one spare group: the forward pass prefetches 8 steps ahead
         const long long U = (long long)nblk * NSEG, U64 = (U + 63) / 64 * 64;
         w.symu.reserve((size_t)nblk * SU + 64);
@@ -827,12 +836,12 @@ namespace sdhip
         }
         {
             ProfScope _ps("k_vit2_acs", st);
-            hipLaunchKernelGGL(k_vit2_acs, dim3((unsigned)(U64 / 64)), dim3(64), 0, st, F, NSEG, nblk, w.symu.p, SU, io, (unsigned long long *)w.dec.p, U64,
+            hipLaunchKernelGGL(k_vit2_acs, dim3((unsigned)(U64 / 64)), dim3(64), 0, st, F, S, NSEG, nblk, w.symu.p, SU, io, (unsigned long long *)w.dec.p, U64,
                                w.specx.p, w.endx.p);
         }
         {
             ProfScope _ps("k_vit2_tb", st);
-            hipLaunchKernelGGL(k_vit2_tb, dim3((unsigned)(U64 / 64)), dim3(64), 0, st, F, NSEG, nblk, io, (const unsigned long long *)w.dec.p, U64, vbits, wpb,
+            hipLaunchKernelGGL(k_vit2_tb, dim3((unsigned)(U64 / 64)), dim3(64), 0, st, F, S, NSEG, nblk, io, (const unsigned long long *)w.dec.p, U64, vbits, wpb,
                                w.entry.p, w.exitst.p);
         }
         {
