@@ -106,8 +106,8 @@ namespace sdhip
             verdict_fail(vo, fails, k);
     }
     // dm[k] = quarter/half/eighth turns chunk k's frame is ahead of chunk k-1's (0 for a bit-exact or re-run boundary)
-    __global__ void k_costas_verdict(int K, const CostasState *spec, const CostasState *endst, double rot_unit, int rot_mod, int *dm, VerdictOut *vo,
-                                     int *fails)
+    __global__ void k_costas_verdict(int K, const CostasState *spec, const CostasState *endst, double rot_unit, int rot_mod, double tol_phase, double tol_freq,
+                                     int *dm, VerdictOut *vo, int *fails)
     {
         const int k = (int)(blockIdx.x * blockDim.x + threadIdx.x);
         if (k >= K)
@@ -122,7 +122,7 @@ namespace sdhip
                 const double dphi = (double)a.phase - (double)b.phase;
                 const long long d = llround(dphi / rot_unit);
                 const double resid = dphi - (double)d * rot_unit;
-                if (fabs(resid) < 2e-5 && fabs((double)a.freq - (double)b.freq) < 2e-7)
+                if (fabs(resid) < tol_phase && fabs((double)a.freq - (double)b.freq) < tol_freq)
                 {
                     d_out = (int)(((d % rot_mod) + rot_mod) % rot_mod);
                     if (d_out != 0)
@@ -673,11 +673,18 @@ namespace sdhip
                 launch_costas(A, B, cg, cos_p, d_cos_start.p, d_cos_spec.p, d_cos_end.p, nullptr, 0, stream);
                 d_rot.reserve(cg.K);
                 d_dm.reserve(cg.K);
+                // Acceptance window of a Costas boundary. Two trajectories of this loop on the same samples contract onto each other
+                // only until a sample lands within their distance of a slicer threshold: the sign detectors then disagree and the
+                // trajectories are kicked ~alpha apart again (and re-converge). A long chunk therefore ends, with probability ~1e-3,
+                // a few 1e-4 rad / 1e-6 rad/sample away from where the next chunk's warm-up arrived although both are "the" loop
+                // trajectory to float noise; such boundaries are accepted (the residual decays within a few hundred samples).
+                const double tol_phase = env_int("SDHIP_COSTAS_TOL_URAD", 500) * 1e-6, tol_freq = env_int("SDHIP_COSTAS_TOL_NFREQ", 3000) * 1e-9;
                 const int vb = (cg.K + 255) / 256;
                 verify_fix(
                     "costas", cg.K,
                     [&](VerdictOut *vo, int *fails) {
-                        hipLaunchKernelGGL(k_costas_verdict, dim3(vb), dim3(256), 0, stream, cg.K, d_cos_spec.p, d_cos_end.p, rot_unit, rot_mod, d_dm.p, vo, fails);
+                        hipLaunchKernelGGL(k_costas_verdict, dim3(vb), dim3(256), 0, stream, cg.K, d_cos_spec.p, d_cos_end.p, rot_unit, rot_mod, tol_phase, tol_freq,
+                                           d_dm.p, vo, fails);
                     },
                     [&](const int *list, int nr) {
                         hipLaunchKernelGGL(k_spec_from_prev<CostasState>, dim3((nr + 255) / 256), dim3(256), 0, stream, list, nr, d_cos_spec.p, d_cos_end.p);
