@@ -181,60 +181,74 @@ namespace sdhip
         skip[k] = sk;
         extra[k - 1] = ex;
     }
-    // one block: exclusive prefix sums over K chunks. mode 0: rot[k] = (sum of dm[0..k]) mod rot_mod (inclusive);
-    // mode 1: seg = {skip, count}, offs[k] = symbols in front of chunk k, vo->total, vo->overflow
-    __global__ __launch_bounds__(1024) void k_chunk_scan(int K, int mode, const int *dm, int rot_mod, int *rot, const int *counts, const int *skip, const int *extra,
-                                                          int cap, int *seg, long long *offs, VerdictOut *vo)
+    // Prefix sums over the K chunks, two launches of K/1024 blocks: tile sums, then every block adds the sums of the tiles in front
+    // of it to its own scan. mode 0: rot[k] = (sum of dm[0..k]) mod rot_mod; mode 1: seg = {skip, count}, offs[k] = symbols in
+    // front of chunk k, vo->total, vo->overflow.
+    __device__ __forceinline__ long long chunk_scan_value(int mode, int k, const int *dm, const int *counts, const int *skip, const int *extra)
     {
-        __shared__ long long part[1024];
+        return mode == 0 ? (long long)dm[k] : (long long)(counts[2 * k] - skip[k] + extra[k]);
+    }
+    __device__ __forceinline__ long long block_scan_incl(long long v, long long *sh)
+    { // inclusive scan over the 1024 threads of the block
         const int t = (int)threadIdx.x;
-        const int per = (K + 1023) / 1024;
-        const int k0 = t * per, k1 = min(K, k0 + per);
-        long long s = 0;
-        int ovf = 0;
-        for (int k = k0; k < k1; k++)
-        {
-            if (mode == 0)
-                s += dm[k];
-            else
-            {
-                if (counts[2 * k] + 2 > cap)
-                    ovf = 1;
-                s += counts[2 * k] - skip[k] + extra[k];
-            }
-        }
-        part[t] = s;
+        sh[t] = v;
         __syncthreads();
         for (int d = 1; d < 1024; d <<= 1)
         {
-            const long long v = t >= d ? part[t - d] : 0;
+            const long long o = t >= d ? sh[t - d] : 0;
             __syncthreads();
-            part[t] += v;
+            sh[t] += o;
             __syncthreads();
         }
-        long long run = t ? part[t - 1] : 0;
-        for (int k = k0; k < k1; k++)
+        return sh[t];
+    }
+    __global__ __launch_bounds__(1024) void k_chunk_scan_sums(int K, int mode, const int *dm, const int *counts, const int *skip, const int *extra, int cap,
+                                                               long long *tile_sums, VerdictOut *vo)
+    {
+        __shared__ long long sh[1024];
+        const int k = (int)(blockIdx.x * 1024 + threadIdx.x);
+        long long v = 0;
+        if (k < K)
+        {
+            v = chunk_scan_value(mode, k, dm, counts, skip, extra);
+            if (mode == 1 && counts[2 * k] + 2 > cap)
+                atomicExch(&vo->overflow, 1);
+        }
+        const long long incl = block_scan_incl(v, sh);
+        if (threadIdx.x == 1023)
+            tile_sums[blockIdx.x] = incl;
+    }
+    __global__ __launch_bounds__(1024) void k_chunk_scan_apply(int K, int mode, const int *dm, int rot_mod, int *rot, const int *counts, const int *skip,
+                                                                const int *extra, const long long *tile_sums, int *seg, long long *offs, VerdictOut *vo)
+    {
+        __shared__ long long sh[1024];
+        __shared__ long long base_sh;
+        const int t = (int)threadIdx.x;
+        // sum of the tiles in front of this one (a few hundred at most)
+        long long part = 0;
+        for (int b = t; b < (int)blockIdx.x; b += 1024)
+            part += tile_sums[b];
+        const long long all = block_scan_incl(part, sh);
+        if (t == 1023)
+            base_sh = all;
+        __syncthreads();
+        const long long base = base_sh;
+        __syncthreads();
+        const int k = (int)(blockIdx.x * 1024 + t);
+        const long long v = k < K ? chunk_scan_value(mode, k, dm, counts, skip, extra) : 0;
+        const long long incl = block_scan_incl(v, sh) + base;
+        if (k < K)
         {
             if (mode == 0)
-            {
-                run += dm[k];
-                rot[k] = (int)(run % rot_mod);
-            }
+                rot[k] = (int)(incl % rot_mod);
             else
             {
-                const int c = counts[2 * k] - skip[k] + extra[k];
                 seg[2 * k] = skip[k];
-                seg[2 * k + 1] = c;
-                offs[k] = run;
-                run += c;
+                seg[2 * k + 1] = (int)v;
+                offs[k] = incl - v;
+                if (k == K - 1)
+                    vo->total = incl;
             }
-        }
-        if (mode == 1)
-        {
-            if (ovf)
-                atomicExch(&vo->overflow, 1);
-            if (t == 1023)
-                vo->total = part[1023];
         }
     }
 
@@ -274,7 +288,7 @@ namespace sdhip
         DevBuf<MmCert> d_mm_spec_c, d_mm_end_c; // what the host certificate reads (16 B per chunk instead of the 72-byte state)
         DevBuf<DcState> d_dc;
         DevBuf<int> d_redo, d_rot, d_dm, d_counts, d_seg, d_skip, d_extra;
-        DevBuf<long long> d_offsets;
+        DevBuf<long long> d_offsets, d_tile_sums;
         DevBuf<double> d_partial;
         DevBuf<int8_t> d_soft_tmp;
         DevBuf<uint8_t> d_in_tmp;
@@ -691,7 +705,13 @@ namespace sdhip
                     },
                     [&](const int *redo, int nr) { launch_costas(A, B, cg, cos_p, d_cos_start.p, d_cos_spec.p, d_cos_end.p, redo, nr, stream); });
                 // rot[k] = frame of chunk k relative to the stream's (prefix sum of the per-boundary turns)
-                hipLaunchKernelGGL(k_chunk_scan, dim3(1), dim3(1024), 0, stream, cg.K, 0, d_dm.p, rot_mod, d_rot.p, nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr);
+                {
+                    const int nt = (cg.K + 1023) / 1024;
+                    d_tile_sums.reserve(nt);
+                    hipLaunchKernelGGL(k_chunk_scan_sums, dim3(nt), dim3(1024), 0, stream, cg.K, 0, d_dm.p, nullptr, nullptr, nullptr, 0, d_tile_sums.p, nullptr);
+                    hipLaunchKernelGGL(k_chunk_scan_apply, dim3(nt), dim3(1024), 0, stream, cg.K, 0, d_dm.p, rot_mod, d_rot.p, nullptr, nullptr, nullptr, d_tile_sums.p,
+                                       nullptr, nullptr, nullptr);
+                }
                 int rot_last = 0;
                 SD_HIP(hipMemcpyAsync(&cos_s, d_cos_end.p + (cg.K - 1), sizeof(cos_s), hipMemcpyDeviceToHost, stream));
                 SD_HIP(hipMemcpyAsync(&rot_last, d_rot.p + (cg.K - 1), sizeof(int), hipMemcpyDeviceToHost, stream));
@@ -773,8 +793,14 @@ namespace sdhip
                     });
                 // compaction segments + offsets + total
                 SD_HIP(hipMemsetAsync(d_vout.p, 0, sizeof(VerdictOut), stream));
-                hipLaunchKernelGGL(k_chunk_scan, dim3(1), dim3(1024), 0, stream, g.K, 1, nullptr, 1, nullptr, d_counts.p, d_skip.p, d_extra.p, mm_p.cap, d_seg.p,
-                                   d_offsets.p, d_vout.p);
+                {
+                    const int nt = (g.K + 1023) / 1024;
+                    d_tile_sums.reserve(nt);
+                    hipLaunchKernelGGL(k_chunk_scan_sums, dim3(nt), dim3(1024), 0, stream, g.K, 1, nullptr, d_counts.p, d_skip.p, d_extra.p, mm_p.cap, d_tile_sums.p,
+                                       d_vout.p);
+                    hipLaunchKernelGGL(k_chunk_scan_apply, dim3(nt), dim3(1024), 0, stream, g.K, 1, nullptr, 1, nullptr, d_counts.p, d_skip.p, d_extra.p, d_tile_sums.p,
+                                       d_seg.p, d_offsets.p, d_vout.p);
+                }
                 SD_HIP(hipMemcpyAsync(h_vout.p, d_vout.p, sizeof(VerdictOut), hipMemcpyDeviceToHost, stream));
                 SD_HIP(hipMemcpyAsync(&mm_s, d_mm_end.p + (g.K - 1), sizeof(mm_s), hipMemcpyDeviceToHost, stream));
                 SD_HIP(hipStreamSynchronize(stream));
