@@ -396,7 +396,7 @@ namespace sdhip
     {
         using P = AgcParams;
         using S = AgcState;
-        static constexpr int DEPTH = 6; // ~100 cycles per sample: 48 samples in flight cover the load latency
+        static constexpr int DEPTH = 4; // blocks per load group (256 bytes); two groups in flight
         __device__ static __forceinline__ S init(const P &p) { return S{p.init_gain}; }
         __device__ static __forceinline__ void prewarm(S &, const P &, const cf32 *, long long) {}
         __device__ static __forceinline__ cf32 step(S &s, const P &p, const cf32 v)
@@ -416,7 +416,7 @@ namespace sdhip
     {
         using P = CostasParams;
         using S = CostasState;
-        static constexpr int DEPTH = 2; // ~400 cycles per sample (two double-precision sincos polynomials)
+        static constexpr int DEPTH = 2; // blocks per load group (one 128-byte line); two groups in flight
         __device__ static __forceinline__ S init(const P &p) { return S{0.0f, p.init_freq}; }
         // Start phase of a warm-up from a feed-forward M-th power estimate over its first est_len samples, so that the loop
         // starts next to one of its `order` stable points instead of anywhere in between: a restart that lands near the
@@ -519,6 +519,9 @@ namespace sdhip
             yp[3] = make_float4(a6.re, a6.im, a7.re, a7.im);
         }
     }
+    // Groups of Stage::DEPTH blocks, double buffered: all loads of group j+1 (DEPTH * 64 contiguous bytes of this lane's stream,
+    // whole 128-byte lines when DEPTH is even and the range starts on a 16-sample boundary) are issued together before group
+    // j is consumed, instead of one 64-byte block at a time.
     template <class Stage>
     __device__ __forceinline__ void run_range(typename Stage::S &s, const typename Stage::P &p, const cf32 *x, cf32 *y, long long i0, long long i1, bool write)
     {
@@ -532,21 +535,38 @@ namespace sdhip
         }
         if (i + 8 * D <= i1)
         {
-            Blk8 q[D];
+            Blk8 qa[D], qb[D];
 #pragma unroll
             for (int d = 0; d < D; d++)
-                q[d] = blk_load(x, i + 8 * d);
-            for (; i + 8 * D <= i1; i += 8 * D)
+                qa[d] = blk_load(x, i + 8 * d);
+            for (;;)
             {
+                const bool more_b = i + 16 * D <= i1;
+                if (more_b)
+                {
+#pragma unroll
+                    for (int d = 0; d < D; d++)
+                        qb[d] = blk_load(x, i + 8 * (D + d));
+                }
 #pragma unroll
                 for (int d = 0; d < D; d++)
+                    blk_run<Stage>(s, p, qa[d], y, i + 8 * d, write);
+                i += 8 * D;
+                if (!more_b)
+                    break;
+                const bool more_a = i + 16 * D <= i1;
+                if (more_a)
                 {
-                    const Blk8 cur = q[d];
-                    const long long nxt = i + 8 * (D + d);
-                    if (nxt + 8 <= i1)
-                        q[d] = blk_load(x, nxt);
-                    blk_run<Stage>(s, p, cur, y, i + 8 * d, write);
+#pragma unroll
+                    for (int d = 0; d < D; d++)
+                        qa[d] = blk_load(x, i + 8 * (D + d));
                 }
+#pragma unroll
+                for (int d = 0; d < D; d++)
+                    blk_run<Stage>(s, p, qb[d], y, i + 8 * d, write);
+                i += 8 * D;
+                if (!more_a)
+                    break;
             }
         }
         for (; i < i1; i++)
@@ -683,7 +703,10 @@ namespace sdhip
     // can count outstanding loads exactly and the ~1.3 us HBM latency of these chunk-strided reads stays off the timing
     // recurrence; the interpolator reads samples and taps from LDS with lane-private addresses.
     constexpr int MM_RING = 32;
-    constexpr int MM_RING_STRIDE = MM_RING + 1; // cf32 units; odd stride: lane rows start on different banks
+    // ring[slot][lane]: slot-major, so lane l of a 32-lane LDS access group always owns 8-byte bank pair l whatever slot it
+    // addresses -- the lanes' windows sit at unrelated ring positions, and a lane-major layout made them collide at random
+    // (SQ: bank-conflict cycles were twice the active LDS cycles)
+    constexpr int MM_RING_STRIDE = 64; // cf32 units between consecutive slots of one lane
     constexpr int MM_DEPTH = 4;
     __device__ __forceinline__ void mm_rot_cs(int q, int order, float &c, float &s)
     {
@@ -729,7 +752,7 @@ namespace sdhip
                 v.im = f.prev_im;
                 f.prev_im = t;
             }
-            f.ring[slot + j] = v;
+            f.ring[(slot + j) * MM_RING_STRIDE] = v;
         }
         f.next = i + 8;
     }
@@ -782,7 +805,7 @@ namespace sdhip
 #pragma unroll
         for (int k = 0; k < 8; k++)
         {
-            const cf32 v = ring[(base + k) & (MM_RING - 1)];
+            const cf32 v = ring[((base + k) & (MM_RING - 1)) * MM_RING_STRIDE];
             re = re + v.re * t[k];
             im = im + v.im * t[k];
         }
@@ -813,7 +836,7 @@ namespace sdhip
     __global__ __launch_bounds__(64) void k_mm(const cf32 *x, cf32 *sym, int *counts, ChunkGeom g, MmParams p, const MmState *start0, MmState *spec,
                                                MmState *endst, MmCert *spec_c, MmCert *end_c, const int *redo, int nredo)
     {
-        __shared__ cf32 rings[64 * MM_RING_STRIDE];
+        __shared__ cf32 rings[MM_RING * MM_RING_STRIDE];
         __shared__ __attribute__((aligned(16))) float bank[128 * 8];
         for (int i = (int)threadIdx.x; i < 128 * 8; i += 64)
             bank[i] = p.bank[i];
@@ -847,7 +870,7 @@ namespace sdhip
             }
         }
         MmFeed f;
-        mm_feed_init(f, p, x, rings + (int)threadIdx.x * MM_RING_STRIDE, s.inc);
+        mm_feed_init(f, p, x, rings + (int)threadIdx.x, s.inc);
         // Three phases: 0 = warm-up (nothing stored) until the chunk start, 1 = the chunk itself, 2 = up to two look-ahead
         // symbols past the chunk end computed from the running state AFTER the end state has been saved: if the next
         // chunk's own trajectory starts one symbol later than this one ends (timing within tolerance, boundary sample
