@@ -11,7 +11,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libsdhip.so")
+LIB_PATH = os.environ.get("SDHIP_LIB") or os.path.join(_HERE, "lib", "libsdhip.so")  # SDHIP_LIB: experiment builds only
 
 BPSK, BPSK_90, QPSK, OQPSK, PSK8 = 0, 1, 2, 3, 4
 RS_NONE, RS223, RS239 = 0, 1, 2

@@ -737,12 +737,12 @@ namespace sdhip
                 put_hist(A, hist_cos);
                 // timing loop: ~2/(Kd*gain_mu) symbols per time constant with a detector gain Kd well below 1 at low Es/N0
                 // (measured: ~700 symbols at 7 dB BPSK with the default gains)
-                // gear-shifted warm-up (tools/mm_gear_study.py): ~2.2/gain_mu symbols at 8x the timing gain (rate term frozen) pull the
+                // gear-shifted warm-up (tools/mm_gear_study.py): ~2.75/gain_mu symbols at 8x the timing gain (rate term frozen) pull the
                 // phase in, ~16/gain_mu symbols at the loop's own gains settle it onto the sequential trajectory
                 // (|dt| p99 < 0.03 sample at GOES' 7 dB, far less for the QPSK configs); 36/gain_mu without the fast gear
                 const double gmu = std::max(1e-4f, cfg.clock_gain_mu);
                 mm_p.fast_mult = (float)env_int("SDHIP_MM_FAST_MULT", 8);
-                mm_p.fast_syms = mm_p.fast_mult > 1.0f ? (int)env_int("SDHIP_MM_FAST_SYMS", (long long)(2.2 / gmu)) : 0;
+                mm_p.fast_syms = mm_p.fast_mult > 1.0f ? (int)env_int("SDHIP_MM_FAST_SYMS", (long long)(2.75 / gmu)) : 0;
                 // a re-run costs one lane the whole chunk, so long chunks (large batches) keep the conservative warm-up: it is a
                 // small fraction of L there anyway
                 const double w_full = 36.0 / gmu * final_sps;
@@ -774,7 +774,7 @@ namespace sdhip
                 // boundary fell between the two trajectories' sample indices, mu wrapping on opposite sides): the symbol(s) are
                 // taken from chunk k-1's look-ahead, or skipped at the head of chunk k. Anything else: re-run from the exact state.
                 // (k_mm_verdict; the compaction segments and offsets are a prefix sum on the device, k_chunk_scan.)
-                const double MM_TOL = env_int("SDHIP_MM_TOL_MILLI", 50) * 1e-3;
+                const double MM_TOL = env_int("SDHIP_MM_TOL_MILLI", 80) * 1e-3;
                 d_skip.reserve(g.K);
                 d_extra.reserve(g.K);
                 d_seg.reserve(2 * (size_t)g.K);

@@ -499,6 +499,41 @@ namespace sdhip
         const float4 *xp = reinterpret_cast<const float4 *>(x + i);
         return Blk8{xp[0], xp[1], xp[2], xp[3]};
     }
+    // run one block, results returned (stored later, a whole load group's worth at a time: 128/256 contiguous bytes per lane)
+    template <class Stage>
+    __device__ __forceinline__ Blk8 blk_step(typename Stage::S &s, const typename Stage::P &p, const Blk8 &c)
+    {
+        const cf32 a0 = Stage::step(s, p, cf32{c.a.x, c.a.y});
+        const cf32 a1 = Stage::step(s, p, cf32{c.a.z, c.a.w});
+        const cf32 a2 = Stage::step(s, p, cf32{c.b.x, c.b.y});
+        const cf32 a3 = Stage::step(s, p, cf32{c.b.z, c.b.w});
+        const cf32 a4 = Stage::step(s, p, cf32{c.c.x, c.c.y});
+        const cf32 a5 = Stage::step(s, p, cf32{c.c.z, c.c.w});
+        const cf32 a6 = Stage::step(s, p, cf32{c.d.x, c.d.y});
+        const cf32 a7 = Stage::step(s, p, cf32{c.d.z, c.d.w});
+        return Blk8{make_float4(a0.re, a0.im, a1.re, a1.im), make_float4(a2.re, a2.im, a3.re, a3.im), make_float4(a4.re, a4.im, a5.re, a5.im),
+                    make_float4(a6.re, a6.im, a7.re, a7.im)};
+    }
+    template <class Stage, int D>
+    __device__ __forceinline__ void group_run(typename Stage::S &s, const typename Stage::P &p, const Blk8 (&q)[D], cf32 *y, long long i, bool write)
+    {
+        Blk8 o[D];
+#pragma unroll
+        for (int d = 0; d < D; d++)
+            o[d] = blk_step<Stage>(s, p, q[d]);
+        if (write)
+        {
+            float4 *yp = reinterpret_cast<float4 *>(y + i);
+#pragma unroll
+            for (int d = 0; d < D; d++)
+            {
+                yp[4 * d + 0] = o[d].a;
+                yp[4 * d + 1] = o[d].b;
+                yp[4 * d + 2] = o[d].c;
+                yp[4 * d + 3] = o[d].d;
+            }
+        }
+    }
     template <class Stage>
     __device__ __forceinline__ void blk_run(typename Stage::S &s, const typename Stage::P &p, const Blk8 &c, cf32 *y, long long i, bool write)
     {
@@ -548,9 +583,7 @@ namespace sdhip
                     for (int d = 0; d < D; d++)
                         qb[d] = blk_load(x, i + 8 * (D + d));
                 }
-#pragma unroll
-                for (int d = 0; d < D; d++)
-                    blk_run<Stage>(s, p, qa[d], y, i + 8 * d, write);
+                group_run<Stage, D>(s, p, qa, y, i, write);
                 i += 8 * D;
                 if (!more_b)
                     break;
@@ -561,9 +594,7 @@ namespace sdhip
                     for (int d = 0; d < D; d++)
                         qa[d] = blk_load(x, i + 8 * (D + d));
                 }
-#pragma unroll
-                for (int d = 0; d < D; d++)
-                    blk_run<Stage>(s, p, qb[d], y, i + 8 * d, write);
+                group_run<Stage, D>(s, p, qb, y, i, write);
                 i += 8 * D;
                 if (!more_a)
                     break;
