@@ -215,3 +215,47 @@ def test_cs16_input(torch_cuda, capi, orc):
     d_soft = torch_cuda.zeros(2 * n, dtype=torch_cuda.int8, device="cuda")
     ns = dem.process_dev(d_x.data_ptr(), n, capi.FMT_CS16, d_soft.data_ptr(), 2 * n)
     assert np.array_equal(d_soft[:ns].cpu().numpy(), want["soft"])
+
+
+def test_empty_and_tiny_calls(torch_cuda, capi, orc):
+    """Zero-length and very short calls (shorter than any filter history) leave the stream state intact: the concatenation of
+    ragged calls equals one call (exact mode: bit for bit)."""
+    spec, plain, x, ocfg, kw, fec, ofec = _case("metop")
+    x = x[:60000]
+    want = orc.psk_demod(ocfg, x)
+    bounds = [0, 0, 5, 5, 36, 100, 101, 4096, 4096 + 63, 30011, 60000, 60000]
+    soft, syms, st = _run_demod(torch_cuda, capi, kw, x, chunks=bounds, exact=1)
+    assert np.array_equal(soft, want["soft"])
+    assert np.array_equal(syms.view(np.uint32), want["syms"].view(np.uint32))
+    soft2, _, _ = _run_demod(torch_cuda, capi, kw, x, chunks=bounds)  # chunk-speculative engine on the same ragged calls
+    assert len(soft2) == len(want["soft"])
+    assert np.mean(soft2 != want["soft"]) < 0.05
+
+
+def test_full_size_goes_round_trip(torch_cuda, capi):
+    """BASELINE.json configs[1] at FULL size (262 144 000 cf32 samples, 2.1 GB) through the C ABI, checked by the size-independent
+    property the domain offers: every CADU that comes out is one of the 4944 transmitted frames (RS-protected payload compared;
+    the 4-byte ASM is outside the code), none is missing after the first step's lock-in, and a second pass over the periodic
+    stream returns the same frames."""
+    import bench
+    wl = bench.WORKLOADS["goes_hrit"]
+    dev = torch_cuda.device("cuda", 0)
+    x, plain, spec = bench.make_input(wl, dev, seed_offset=0, frames=wl["frames"])
+    n_in = x.numel()
+    dem = capi.PskDemod(capi.demod_cfg(**wl["demod"]))
+    fec = capi.FecDecoder(capi.fec_cfg(**wl["fec"]))
+    d_soft = torch_cuda.empty(2 * n_in + 64, dtype=torch_cuda.int8, device=dev)
+    d_cadu = torch_cuda.empty((wl["frames"] + 64, 1024), dtype=torch_cuda.uint8, device=dev)
+    want = {bytes(p[4:]) for p in plain}
+    outs = []
+    for step in range(2):
+        ns = dem.process_dev(x.data_ptr(), n_in, capi.FMT_CF32, d_soft.data_ptr(), 2 * n_in + 64)
+        nf = fec.process_dev(d_soft.data_ptr(), ns, d_cadu.data_ptr(), wl["frames"] + 64)
+        got = d_cadu[:nf].cpu().numpy()
+        assert all(bytes(g[4:]) in want for g in got), "a decoded CADU is not one of the transmitted frames"
+        outs.append(got)
+    assert len(outs[0]) >= wl["frames"] - 8          # first pass: loops and decoders lock within the first few frames
+    assert len(outs[1]) == wl["frames"]              # steady state: every frame, once
+    assert len({bytes(g[4:]) for g in outs[1]}) == wl["frames"]
+    st = dem.stats()
+    assert st.chunks > 100000 and st.chunks_fixed < st.chunks // 100
