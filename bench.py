@@ -155,8 +155,9 @@ def main():
     ap.add_argument("--chunk-len", type=int, default=0)
     ap.add_argument("--exact", type=int, default=0)
     ap.add_argument("--no-check", action="store_true")
-    ap.add_argument("--no-pipeline", action="store_true",
-                    help="run the two modules of a step back to back instead of overlapping the decoder of step i with the demodulator of step i+1")
+    ap.add_argument("--pipeline", action="store_true",
+                    help="overlap the decoder of step i with the demodulator of step i+1 (two host threads, two HIP streams) like the reference's "
+                         "thread-per-module pipeline; off by default: the per-kernel HIP-event times of the roofline need the kernels un-overlapped")
     args = ap.parse_args()
 
     import torch
@@ -209,7 +210,7 @@ def main():
     capi.prof_enable(True)
     tot_frames = 0
     tot_soft = 0
-    pipelined = not args.no_pipeline and args.steps > 1
+    pipelined = args.pipeline and args.steps > 1
     t0 = time.perf_counter()
     if not pipelined:
         for _ in range(args.steps):

@@ -216,7 +216,7 @@ namespace sdhip
         DevBuf<VitSearchState> d_search;
         DevBuf<uint32_t> d_hits;
         DevBuf<int> d_count;
-        DevBuf<uint8_t> d_packed;
+        DevBuf<uint8_t> d_packed, d_rs_clean;
         DevBuf<FrameDesc> d_frames;
         DevBuf<uint8_t> d_fbytes;
         DevBuf<int> d_ferr;
@@ -647,7 +647,8 @@ namespace sdhip
                     fc.rs_fill_bytes = cfg.rs_fill_bytes;
                     fc.rs_dualbasis = cfg.rs_dualbasis;
                     fc.rs_nroots = cfg.rs_type == SDHIP_RS239 ? 16 : 32;
-                    launch_frames(bs, fc, d_frames.p, nf, d_fbytes.p, d_ferr.p, stream);
+                    d_rs_clean.reserve((size_t)nf * I + 8);
+                    launch_frames(bs, fc, d_frames.p, nf, d_fbytes.p, d_ferr.p, stream, d_rs_clean.p);
                     h_dst.assign(nf, -1);
                     size_t kept = 0;
                     if (cfg.rs_i != 0)
@@ -1218,7 +1219,9 @@ extern "C"
     {
         SD_GUARD_BEGIN
         SD_HIP(hipSetDevice(device));
-        launch_rs_only(d_data, nframes, frame_stride, dualbasis, I, rs_type == SDHIP_RS239 ? 16 : 32, fill_bytes, d_errors, nullptr);
+        DevBuf<uint8_t> clean;
+        clean.reserve((size_t)nframes * I + 8);
+        launch_rs_only(d_data, nframes, frame_stride, dualbasis, I, rs_type == SDHIP_RS239 ? 16 : 32, fill_bytes, d_errors, nullptr, clean.p);
         SD_HIP(hipDeviceSynchronize());
         return 0;
         SD_GUARD_END(-1)

@@ -142,9 +142,12 @@ namespace sdhip
         int pad;
     };
     // frames: nframes descriptors; out: nframes * cadu_bytes; errors: nframes * max(rs_i,1) ints (-1 = uncorrectable)
-    void launch_frames(const BitStream &bs, const FrameCfg &fc, const FrameDesc *frames, int nframes, uint8_t *out, int *errors, hipStream_t st);
+    // clean_scratch (optional, nframes * rs_i bytes): enables the syndrome screen in front of the thread-per-codeword decoder
+    void launch_frames(const BitStream &bs, const FrameCfg &fc, const FrameDesc *frames, int nframes, uint8_t *out, int *errors, hipStream_t st,
+                       uint8_t *clean_scratch = nullptr);
     // Unit entry: RS decode of frames already in memory (sdhip_op_rs_decode).
-    void launch_rs_only(uint8_t *data, int nframes, int frame_stride, int dualbasis, int I, int nroots, int fill_bytes, int *errors, hipStream_t st);
+    void launch_rs_only(uint8_t *data, int nframes, int frame_stride, int dualbasis, int I, int nroots, int fill_bytes, int *errors, hipStream_t st,
+                        uint8_t *clean_scratch = nullptr);
     // Compaction: copy frames whose keep[i] != 0 to out in order. Returns nothing; count known to the host.
     void launch_compact(const uint8_t *frames, const int *dst_index, int nframes, int cadu_bytes, uint8_t *out, hipStream_t st);
 } // namespace sdhip

@@ -1590,7 +1590,7 @@ namespace sdhip
     // Reproduces ReedSolomon::decode (reedsolomon.cpp:63-116) incl. fill_bytes handling and the error count.
     constexpr int RS_THREADS = 64;
     __global__ __launch_bounds__(RS_THREADS) void k_rs(unsigned char *data, int nframes, int frame_stride, int dualbasis, int I, int nroots, int fill_bytes,
-                                                        int *errors, const GfTables *tabs)
+                                                        int *errors, const GfTables *tabs, const unsigned char *__restrict__ clean)
     {
         __shared__ GfLds gf;
         __shared__ unsigned char dual[512]; // to_dual | from_dual
@@ -1610,6 +1610,11 @@ namespace sdhip
         const long long cwid = (long long)blockIdx.x * RS_THREADS + tid;
         if (cwid >= (long long)nframes * I)
             return;
+        if (clean && clean[cwid])
+        { // all syndromes zero (k_rs_screen): nothing to correct, nothing to write
+            errors[cwid] = 0;
+            return;
+        }
         const int f = (int)(cwid / I), b = (int)(cwid % I);
         unsigned char *base = data + (size_t)f * frame_stride;
         unsigned char *cw = cwbuf + tid;
@@ -1655,15 +1660,83 @@ namespace sdhip
         errors[cwid] = err;
     }
 
-    void launch_rs_only(uint8_t *data, int nframes, int frame_stride, int dualbasis, int I, int nroots, int fill_bytes, int *errors, hipStream_t st)
+    // Syndrome screen: 32 lanes per codeword, one generator root each (the same Horner evaluation as rs_decode_thread). A
+    // codeword whose syndromes are all zero is what the decoder leaves untouched with an error count of 0 (decode.c:335-342),
+    // so k_rs skips it; on a clean link that is every codeword and the thread-per-codeword kernel (255 x 32 dependent table
+    // look-ups per thread before it can tell) has nothing left to do.
+    constexpr int RSS_CW = 8;
+    __global__ __launch_bounds__(32 * RSS_CW) void k_rs_screen(const unsigned char *__restrict__ data, int nframes, int frame_stride, int dualbasis, int I, int nroots,
+                                                                int fill_bytes, unsigned char *clean, const GfTables *tabs)
+    {
+        __shared__ GfLds gf;
+        __shared__ unsigned char from_dual[256];
+        __shared__ unsigned char cw[RSS_CW][256];
+        __shared__ int nz[RSS_CW];
+        const int tid = (int)threadIdx.x;
+        for (int i = tid; i < 512; i += 32 * RSS_CW)
+        {
+            gf.exp[i] = tabs->exp[i];
+            if (i < 256)
+            {
+                gf.log[i] = tabs->log[i];
+                from_dual[i] = tabs->from_dual[i];
+            }
+        }
+        if (tid < RSS_CW)
+            nz[tid] = 0;
+        const long long cw0 = (long long)blockIdx.x * RSS_CW, ncw = (long long)nframes * I;
+        const int fb = fill_bytes < 0 ? 0 : fill_bytes;
+        __syncthreads();
+        for (int idx = tid; idx < RSS_CW * 255; idx += 32 * RSS_CW)
+        {
+            const int c = idx / 255, k = idx - c * 255;
+            const long long cwid = cw0 + c;
+            unsigned v = 0;
+            if (cwid < ncw)
+            {
+                const int f = (int)(cwid / I), b = (int)(cwid % I);
+                v = (k < fb) ? 0u : data[(size_t)f * frame_stride + (size_t)(k - fb) * I + b];
+                if (dualbasis)
+                    v = from_dual[v];
+            }
+            cw[c][k] = (unsigned char)v;
+        }
+        __syncthreads();
+        const int c = tid >> 5, r = tid & 31;
+        if (r < nroots && cw0 + c < ncw)
+        {
+            const int fcr = nroots == 32 ? 112 : 120, gap = 11;
+            const unsigned lr = (unsigned)((gap * (r + fcr)) % 255); // log of generator root r (reed-solomon.c:9-11)
+            unsigned sy = 0;
+            for (int k = 0; k < 255; k++)
+            {
+                if (sy)
+                    sy = gf.exp[gf.log[sy] + lr];
+                sy ^= cw[c][k];
+            }
+            if (sy)
+                nz[c] = 1;
+        }
+        __syncthreads();
+        if (tid < RSS_CW && cw0 + tid < ncw)
+            clean[cw0 + tid] = nz[tid] ? 0 : 1;
+    }
+
+    void launch_rs_only(uint8_t *data, int nframes, int frame_stride, int dualbasis, int I, int nroots, int fill_bytes, int *errors, hipStream_t st, uint8_t *clean_scratch)
     {
         const long long n = (long long)nframes * I;
         if (n <= 0)
             return;
         const GfTables *tabs = tables_for_current_device();
+        if (clean_scratch)
+        {
+            ProfScope _ps("k_rs_screen", st);
+            hipLaunchKernelGGL(k_rs_screen, dim3((unsigned)((n + RSS_CW - 1) / RSS_CW)), dim3(32 * RSS_CW), 0, st, data, nframes, frame_stride, dualbasis, I, nroots, fill_bytes,
+                               clean_scratch, tabs);
+        }
         ProfScope _ps("k_rs", st);
         hipLaunchKernelGGL(k_rs, dim3((unsigned)((n + RS_THREADS - 1) / RS_THREADS)), dim3(RS_THREADS), 0, st, data, nframes, frame_stride, dualbasis, I, nroots,
-                           fill_bytes, errors, tabs);
+                           fill_bytes, errors, tabs, clean_scratch);
     }
 
     // ---- frame extraction + derandomiser -----------------------------------------------------------
@@ -1708,7 +1781,7 @@ namespace sdhip
             frames[i] ^= tabs->pn[(k - derand_start) % 255];
     }
 
-    void launch_frames(const BitStream &bs, const FrameCfg &fc, const FrameDesc *frames, int nframes, uint8_t *out, int *errors, hipStream_t st)
+    void launch_frames(const BitStream &bs, const FrameCfg &fc, const FrameDesc *frames, int nframes, uint8_t *out, int *errors, hipStream_t st, uint8_t *clean_scratch)
     {
         if (nframes <= 0)
             return;
@@ -1718,7 +1791,7 @@ namespace sdhip
             hipLaunchKernelGGL(k_extract, dim3(nframes), dim3(256), 0, st, bs, fc, frames, nframes, out, tabs);
         }
         if (fc.rs_i != 0)
-            launch_rs_only(out + 4, nframes, fc.cadu_bytes, fc.rs_dualbasis, fc.rs_i, fc.rs_nroots, fc.rs_fill_bytes, errors, st);
+            launch_rs_only(out + 4, nframes, fc.cadu_bytes, fc.rs_dualbasis, fc.rs_i, fc.rs_nroots, fc.rs_fill_bytes, errors, st, clean_scratch);
         if (fc.derand && fc.derand_after_rs)
         {
             const long long n = (long long)nframes * fc.cadu_bytes;
