@@ -608,27 +608,39 @@ namespace sdhip
     // ---- symbol staging: row j = [VIT2_WARM last steps of block j-1 | steps 0..F+5 of block j | erasures]
     __global__ __launch_bounds__(256) void k_vit2_prep(VitCfg c, const int8_t *__restrict__ soft, long long first_block, int nblk, unsigned short *symu, int SU)
     {
-        const int j = (int)blockIdx.y;
-        const int r = (int)(blockIdx.x * blockDim.x + threadIdx.x);
-        if (j >= nblk || r >= SU)
+        // thread = 8 consecutive steps of one row (one 16-byte store); 1-D grid: block index = j * tiles + tile (grid.y is
+        // limited to 65535 blocks)
+        const int groups = SU / 8, tiles = (groups + 255) / 256;
+        const int j = (int)(blockIdx.x / tiles);
+        const int gi = (int)((blockIdx.x % tiles) * blockDim.x + threadIdx.x);
+        if (j >= nblk || gi >= groups)
             return;
         const TailErasure erasure;
         const int nsteps = c.F + 6;
-        unsigned v = 128u | (128u << 8);
-        if (r < VIT2_WARM)
+        const SymFetch pf{c, soft + (first_block + j - 1) * (long long)c.B, c.B};
+        const SymFetch f{c, soft + (first_block + j) * (long long)c.B, c.B};
+        const bool have_prev = first_block + j > 0;
+        unsigned v[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++)
         {
-            if (first_block + j > 0)
+            const int r = gi * 8 + q;
+            unsigned x = 128u | (128u << 8);
+            if (r < VIT2_WARM)
             {
-                SymFetch pf{c, soft + (first_block + j - 1) * (long long)c.B, c.B};
-                v = pf.pair(nsteps - VIT2_WARM + r, erasure);
+                if (have_prev)
+                    x = pf.pair(nsteps - VIT2_WARM + r, erasure);
             }
+            else if (r < VIT2_WARM + nsteps)
+                x = f.pair(r - VIT2_WARM, erasure);
+            v[q] = x & 0xFFFFu;
         }
-        else if (r < VIT2_WARM + nsteps)
-        {
-            SymFetch f{c, soft + (first_block + j) * (long long)c.B, c.B};
-            v = f.pair(r - VIT2_WARM, erasure);
-        }
-        symu[(size_t)j * SU + r] = (unsigned short)v;
+        uint4 o;
+        o.x = v[0] | (v[1] << 16);
+        o.y = v[2] | (v[3] << 16);
+        o.z = v[4] | (v[5] << 16);
+        o.w = v[6] | (v[7] << 16);
+        *reinterpret_cast<uint4 *>(symu + (size_t)j * SU + (size_t)gi * 8) = o;
     }
 
     // ---- forward pass: one lane per (block, segment)
@@ -832,7 +844,7 @@ namespace sdhip
         const int wpb = vit_words_per_block(F);
         {
             ProfScope _ps("k_vit2_prep", st);
-            hipLaunchKernelGGL(k_vit2_prep, dim3((SU + 255) / 256, nblk), dim3(256), 0, st, cfg, soft, (long long)first_block, nblk, w.symu.p, SU);
+            hipLaunchKernelGGL(k_vit2_prep, dim3((unsigned)(((SU / 8 + 255) / 256) * (long long)nblk)), dim3(256), 0, st, cfg, soft, (long long)first_block, nblk, w.symu.p, SU);
         }
         {
             ProfScope _ps("k_vit2_acs", st);
@@ -1092,8 +1104,9 @@ namespace sdhip
     }
     __global__ __launch_bounds__(256) void k_hard_bits(HardCfg hc, const int8_t *__restrict__ soft, int nblk, int which, unsigned *vbits, int wpb)
     {
-        const int j = (int)blockIdx.y;
-        const int w = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+        const int tiles = (wpb + 255) / 256; // 1-D grid (grid.y is limited to 65535 blocks)
+        const int j = (int)(blockIdx.x / tiles);
+        const int w = (int)((blockIdx.x % tiles) * blockDim.x + threadIdx.x);
         if (j >= nblk || w >= wpb)
             return;
         const int F = hc.F;
@@ -1187,7 +1200,7 @@ namespace sdhip
         if (nblk <= 0)
             return;
         ProfScope _ps("k_hard_bits", st);
-        hipLaunchKernelGGL(k_hard_bits, dim3((wpb + 255) / 256, nblk), dim3(256), 0, st, hc, soft, nblk, which, vbits, wpb);
+        hipLaunchKernelGGL(k_hard_bits, dim3((unsigned)(((wpb + 255) / 256) * (long long)nblk)), dim3(256), 0, st, hc, soft, nblk, which, vbits, wpb);
     }
 
     // =============================================================================================
