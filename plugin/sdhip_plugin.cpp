@@ -128,6 +128,33 @@ namespace sdhip_plugin
             if (h)
                 sdhip_demod_destroy(h);
         }
+        // Can the HIP path run this parameter set? (The override keeps the CPU module for what it does not cover: frequency
+        // shift / Doppler front-ends, wav/ziq/cs32 containers, ratios that need SmartResampler's power-of-two pre-decimator.)
+        static bool covers(const std::string &input_file, const std::string &output_file_hint, const nlohmann::json &parameters, std::string &why)
+        {
+            if (parameters.count("enable_doppler") > 0 && parameters["enable_doppler"].get<bool>())
+            {
+                why = "enable_doppler";
+                return false;
+            }
+            try
+            {
+                PSKDemodHipModule probe(input_file, output_file_hint, parameters);
+                void *e = sdhip_demod_create(&probe.cfg);
+                if (!e)
+                {
+                    why = sdhip_last_error();
+                    return false;
+                }
+                sdhip_demod_destroy(e);
+                return true;
+            }
+            catch (const std::exception &ex)
+            {
+                why = ex.what();
+                return false;
+            }
+        }
 
         std::vector<ModuleDataType> getInputTypes() { return {DATA_FILE, DATA_DSP_STREAM}; }
         std::vector<ModuleDataType> getOutputTypes() { return {DATA_FILE, DATA_STREAM}; }
@@ -472,9 +499,30 @@ namespace sdhip_plugin
             for (auto &e : modules_registry)
             {
                 if (e.id == "psk_demod")
-                    e.inst = PSKDemodHipModule::getInstance;
+                {
+                    auto cpu = e.inst;
+                    e.inst = [cpu](std::string in, std::string out, nlohmann::json p) -> std::shared_ptr<ProcessingModule> {
+                        std::string why;
+                        if (!PSKDemodHipModule::covers(in, out, p, why))
+                        {
+                            logger->info("sdhip_support: psk_demod stays on the CPU module for this run (" + why + ")");
+                            return cpu(in, out, p);
+                        }
+                        return PSKDemodHipModule::getInstance(in, out, p);
+                    };
+                }
                 else if (e.id == "ccsds_conv_concat_decoder")
-                    e.inst = CCSDSConvConcatDecoderHipModule::getInstance;
+                {
+                    // punctured rates (conv_rate != "1/2", viterbi_punc.cpp) and padded frames stay on the CPU module
+                    auto cpu = e.inst;
+                    e.inst = [cpu](std::string in, std::string out, nlohmann::json p) -> std::shared_ptr<ProcessingModule> {
+                        const std::string conv = p.count("conv_rate") > 0 ? p["conv_rate"].get<std::string>() : "1/2";
+                        const bool padded = p.count("cadu_size") > 0 && p["cadu_size"].get<int>() % 8 != 0;
+                        if (conv != "1/2" || padded)
+                            return cpu(in, out, p);
+                        return CCSDSConvConcatDecoderHipModule::getInstance(in, out, p);
+                    };
+                }
                 else if (e.id == "metop_ahrpt_decoder")
                     e.inst = MetOpAHRPTDecoderHipModule::getInstance;
                 else if (e.id == "ccsds_simple_psk_decoder")
@@ -482,7 +530,7 @@ namespace sdhip_plugin
                     // hard_symbols input (soft_reader.h:49-58) stays on the CPU module
                     auto cpu = e.inst;
                     e.inst = [cpu](std::string in, std::string out, nlohmann::json p) -> std::shared_ptr<ProcessingModule> {
-                        if (p.count("hard_symbols") > 0 && p["hard_symbols"].get<bool>())
+                        if ((p.count("hard_symbols") > 0 && p["hard_symbols"].get<bool>()) || (p.count("cadu_size") > 0 && p["cadu_size"].get<int>() % 8 != 0))
                             return cpu(in, out, p);
                         return CCSDSSimplePSKDecoderHipModule::getInstance(in, out, p);
                     };

@@ -827,7 +827,7 @@ namespace sdhip
         int S = VIT2_SEG;
         {
             const char *e = getenv("SDHIP_VIT2_SEG");
-            if (e && atoi(e) >= 512 && F % atoi(e) == 0 && F / atoi(e) >= 2)
+            if (e && atoi(e) >= 128 && atoi(e) % 32 == 0 && F % atoi(e) == 0 && F / atoi(e) >= 2)
                 S = atoi(e);
             else if (F % (2 * VIT2_SEG) == 0 && F / (2 * VIT2_SEG) >= 2 && (long long)nblk * (F / (2 * VIT2_SEG)) >= 2 * 65536)
                 S = 2 * VIT2_SEG;
