@@ -48,7 +48,8 @@ extern "C"
         SDHIP_FMT_CF32 = 0, /* baseband_format "cf32" / "f32" : raw read, baseband_interface.h:172-174 */
         SDHIP_FMT_CS16 = 1, /* "cs16" / "s16" : x * (1/32767), baseband_interface.h:176-180 */
         SDHIP_FMT_CS8 = 2,  /* "cs8"  / "s8"  : x * (1/127),   baseband_interface.h:181-185 */
-        SDHIP_FMT_CU8 = 3   /* "cu8"  / "u8"  : (x - 127.4) * (1/128), baseband_interface.h:191-199 */
+        SDHIP_FMT_CU8 = 3,  /* "cu8"  / "u8"  : (x - 127) * (1.0/127.0) in double, baseband_interface.h:190-198 */
+        SDHIP_FMT_CS32 = 4  /* "cs32" / "s32" : x * (1/2147483647), baseband_interface.h:175-178 */
     };
     enum
     {

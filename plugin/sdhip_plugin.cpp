@@ -120,8 +120,10 @@ namespace sdhip_plugin
                 fmt = SDHIP_FMT_CS8;
             else if (baseband_format == "cu8" || baseband_format == "u8")
                 fmt = SDHIP_FMT_CU8;
+            else if (baseband_format == "cs32" || baseband_format == "s32")
+                fmt = SDHIP_FMT_CS32;
             else
-                throw satdump_exception("psk_demod_hip: baseband_format " + baseband_format + " is not on the HIP path (cf32, cs16, cs8, cu8)");
+                throw satdump_exception("psk_demod_hip: baseband_format " + baseband_format + " is not on the HIP path (cf32, cs32, cs16, cs8, cu8)");
         }
         ~PSKDemodHipModule()
         {

@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("SDHIP_LIB") or os.path.join(_HERE, "lib", "libsdhip.s
 
 BPSK, BPSK_90, QPSK, OQPSK, PSK8 = 0, 1, 2, 3, 4
 RS_NONE, RS223, RS239 = 0, 1, 2
-FMT_CF32, FMT_CS16, FMT_CS8, FMT_CU8 = 0, 1, 2, 3
+FMT_CF32, FMT_CS16, FMT_CS8, FMT_CU8, FMT_CS32 = 0, 1, 2, 3, 4
 DEC_CONV_CONCAT, DEC_METOP_AHRPT, DEC_SIMPLE_PSK = 0, 1, 2
 CONSTELLATIONS = {"bpsk": BPSK, "bpsk_90": BPSK_90, "qpsk": QPSK, "oqpsk": OQPSK, "8psk": PSK8}
 

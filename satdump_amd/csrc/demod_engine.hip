@@ -301,7 +301,7 @@ namespace sdhip
 
         sdhip_demod_stats stats{};
 
-        static int fmt_bytes(int fmt) { return fmt == SDHIP_FMT_CF32 ? 8 : (fmt == SDHIP_FMT_CS16 ? 4 : 2); }
+        static int fmt_bytes(int fmt) { return (fmt == SDHIP_FMT_CF32 || fmt == SDHIP_FMT_CS32) ? 8 : (fmt == SDHIP_FMT_CS16 ? 4 : 2); }
 
         explicit DemodEngine(const sdhip_demod_cfg &c) : cfg(c)
         {

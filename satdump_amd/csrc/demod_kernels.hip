@@ -109,11 +109,18 @@ namespace sdhip
             re = (float)v.x * s;
             im = (float)v.y * s;
         }
-        else
-        { // cu8: (x - 127.4f) / 128.0f (baseband_interface.h:191-199)
+        else if (fmt == 3)
+        { // cu8: (x - 127) * (1.0 / 127.0), the product taken in double and rounded once (baseband_interface.h:190-198)
             const uchar2 v = ((const uchar2 *)in)[i];
-            re = ((float)v.x - 127.4f) / 128.0f;
-            im = ((float)v.y - 127.4f) / 128.0f;
+            re = (float)((double)((int)v.x - 127) * (1.0 / 127.0));
+            im = (float)((double)((int)v.y - 127) * (1.0 / 127.0));
+        }
+        else
+        { // cs32: volk_32i_s32f_convert_32f(.., 2147483647): (float)x * (1.0f / 2147483647) (baseband_interface.h:175-178)
+            const int2 v = ((const int2 *)in)[i];
+            const float sc = 1.0f / 2147483647.0f;
+            re = (float)v.x * sc;
+            im = (float)v.y * sc;
         }
         if (iq_swap)
         {

@@ -259,3 +259,31 @@ def test_full_size_goes_round_trip(torch_cuda, capi):
     assert len({bytes(g[4:]) for g in outs[1]}) == wl["frames"]
     st = dem.stats()
     assert st.chunks > 100000 and st.chunks_fixed < st.chunks // 100
+
+
+@pytest.mark.parametrize("fmt", ["cs8", "cu8", "cs32"])
+def test_integer_input_formats(torch_cuda, capi, orc, fmt):
+    """The other integer containers of BasebandReader::read_samples (baseband_interface.h:175-198): cs8 x * (1/127) in float, cu8
+    (x - 127) * (1.0/127.0) in double, cs32 x * (1/2147483647) in float; exact mode, soft symbols bit-identical."""
+    spec, plain, x, ocfg, kw, fec, ofec = _case("metop")
+    x = x[:120000]
+    iq = np.stack([x.real, x.imag], axis=1).reshape(-1) / np.abs(x).max()
+    if fmt == "cs8":
+        raw = np.clip(np.rint(iq * 120), -127, 127).astype(np.int8)
+        xf = raw.astype(np.float32) * np.float32(1.0 / 127.0)
+        code = capi.FMT_CS8
+    elif fmt == "cu8":
+        raw = np.clip(np.rint(iq * 120) + 127, 0, 255).astype(np.uint8)
+        xf = ((raw.astype(np.int64) - 127).astype(np.float64) * (1.0 / 127.0)).astype(np.float32)
+        code = capi.FMT_CU8
+    else:
+        raw = np.rint(iq * 2.0e9).astype(np.int32)
+        xf = raw.astype(np.float32) * np.float32(1.0 / 2147483647.0)
+        code = capi.FMT_CS32
+    want = orc.psk_demod(ocfg, np.ascontiguousarray(xf).view(np.complex64))
+    dem = capi.PskDemod(capi.demod_cfg(**kw, exact=1))
+    d_x = _dev(torch_cuda, raw)
+    n = len(x)
+    d_soft = torch_cuda.zeros(2 * n, dtype=torch_cuda.int8, device="cuda")
+    ns = dem.process_dev(d_x.data_ptr(), n, code, d_soft.data_ptr(), 2 * n)
+    assert np.array_equal(d_soft[:ns].cpu().numpy(), want["soft"])
