@@ -82,6 +82,11 @@ namespace sdhip_plugin
             opt(parameters, "max_sps", cfg.max_sps);
             if (parameters.count("freq_shift") > 0 && parameters["freq_shift"].get<long>() != 0)
                 throw satdump_exception("psk_demod_hip: freq_shift is not on the HIP path, use psk_demod");
+            // carrier-tracking front-end and post-Costas DC block (module_psk_demod.cpp:36-40, 93-113, 127-128): CPU module only
+            if (parameters.count("has_carrier") > 0 && parameters["has_carrier"].get<bool>())
+                throw satdump_exception("psk_demod_hip: has_carrier is not on the HIP path, use psk_demod");
+            if (parameters.count("post_costas_dc") > 0 && parameters["post_costas_dc"].get<bool>())
+                throw satdump_exception("psk_demod_hip: post_costas_dc is not on the HIP path, use psk_demod");
             if (parameters.count("constellation") > 0)
                 cfg.constellation = constellation_of(parameters["constellation"].get<std::string>(), true);
             else
