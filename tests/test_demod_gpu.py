@@ -287,3 +287,22 @@ def test_integer_input_formats(torch_cuda, capi, orc, fmt):
     d_soft = torch_cuda.zeros(2 * n, dtype=torch_cuda.int8, device="cuda")
     ns = dem.process_dev(d_x.data_ptr(), n, code, d_soft.data_ptr(), 2 * n)
     assert np.array_equal(d_soft[:ns].cpu().numpy(), want["soft"])
+
+
+@pytest.mark.parametrize("const", ["oqpsk", "8psk"])
+def test_exact_mode_other_constellations(torch_cuda, capi, orc, const):
+    """OQPSK (Costas order 4 + DelayOneImag in front of the M&M loop, resample decision with the 1.6..2.4 sps window) and 8PSK
+    (Costas order 8): arithmetic parity of the whole chain in exact mode, and the chunk-speculative engine delivers the same
+    number of symbols (8PSK runs on a QPSK signal, whose points are a subset of the 8PSK ones)."""
+    spec, plain, x, ocfg, kw, fec, ofec = _case("npp")
+    x = x[:300000]
+    if const == "oqpsk":  # offset the Q rail by half a symbol (= one sample at 2 sps): a genuine OQPSK waveform
+        x = (x.real + 1j * np.concatenate([[0.0], x.imag[:-1]])).astype(np.complex64)
+    oc = pyref.demod_cfg(samplerate=30e6, symbolrate=15e6, constellation={"oqpsk": pyref.OQPSK, "8psk": pyref.PSK8}[const], pll_bw=0.004)
+    kw = dict(samplerate=30e6, symbolrate=15e6, constellation=const, rrc_alpha=0.5, pll_bw=0.004)
+    want = orc.psk_demod(oc, x)
+    soft, syms, st = _run_demod(torch_cuda, capi, kw, x, exact=1)
+    assert np.array_equal(syms.view(np.uint32), want["syms"].view(np.uint32))
+    assert np.array_equal(soft, want["soft"])
+    soft2, syms2, st2 = _run_demod(torch_cuda, capi, kw, x, chunk_len=8192)
+    assert len(soft2) == len(want["soft"]) and st2.chunks > 30
