@@ -313,7 +313,7 @@ def main():
             "whole_path_GBps": round(samples_all * algo_per_sample / dt_all / 1e9, 3),
             "roofline": roof, "cpu_baseline": cpu, "check": check,
             "demod_stats": {"chunks": dst.chunks, "chunks_fixed": dst.chunks_fixed, "chunks_rotated": dst.chunks_rotated,
-                            "chunks_inexact": dst.chunks_inexact, "freq_hz": round(dst.freq_hz, 2)},
+                            "chunks_inexact": dst.chunks_inexact, "chunks_forced": dst.chunks_forced, "freq_hz": round(dst.freq_hz, 2)},
             "fec_stats": {"vit_respec": fst.vit_respec, "tb_respec": fst.tb_respec, "viterbi_ber": round(fst.viterbi_ber, 4),
                           "blocks": fst.blocks, "frames_out": fst.frames_out},
             "kernels": kernels, "input_gen_s": round(t_gen, 2),

@@ -99,6 +99,7 @@ extern "C"
         uint32_t chunks_fixed;  /* chunks re-run from the exact boundary state because the certificate failed */
         uint32_t chunks_rotated;/* Costas chunks that locked on another constellation symmetry and were rotated back */
         uint32_t chunks_inexact;/* chunks accepted by tolerance (boundary states equal to ~1e-6) rather than bit-for-bit */
+        uint32_t chunks_forced; /* boundaries let through after the re-run round limit: the signal was not locked there (noise) */
     } sdhip_demod_stats;
 
     void sdhip_demod_cfg_default(sdhip_demod_cfg *cfg);

@@ -35,6 +35,7 @@ class DemodStats(C.Structure):
         ("samples_in", C.c_uint64), ("symbols_out", C.c_uint64), ("freq_hz", C.c_float), ("final_sps", C.c_float),
         ("final_samplerate", C.c_float), ("buffer_size", C.c_int), ("resample_interp", C.c_int), ("resample_decim", C.c_int),
         ("chunks", C.c_uint32), ("chunks_fixed", C.c_uint32), ("chunks_rotated", C.c_uint32), ("chunks_inexact", C.c_uint32),
+        ("chunks_forced", C.c_uint32),
     ]
 
 

@@ -305,4 +305,31 @@ def test_exact_mode_other_constellations(torch_cuda, capi, orc, const):
     assert np.array_equal(syms.view(np.uint32), want["syms"].view(np.uint32))
     assert np.array_equal(soft, want["soft"])
     soft2, syms2, st2 = _run_demod(torch_cuda, capi, kw, x, chunk_len=8192)
-    assert len(soft2) == len(want["soft"]) and st2.chunks > 30
+    assert st2.chunks > 30
+    if const == "8psk":
+        assert len(soft2) == len(want["soft"]) and st2.chunks_forced <= st2.chunks // 10
+    else:
+        # the reference's M&M loop does not lock on this waveform (its timing wanders by tenths of a symbol between any two
+        # trajectories): the engine must notice (boundaries let through after the round limit), not loop chunk by chunk
+        assert abs(len(soft2) - len(want["soft"])) < 0.01 * len(soft2) and st2.chunks_forced > 0
+
+
+def test_noise_only_input_is_bounded(torch_cuda, capi):
+    """Noise before / after a pass: no loop is locked, every boundary certificate fails. The engine must not degrade into one
+    launch per chunk: after the round limit the remaining boundaries are let through and counted."""
+    import time
+    n = 4_000_000
+    g = torch_cuda.Generator(device="cuda")
+    g.manual_seed(1)
+    x = (torch_cuda.randn(2 * n, device="cuda", generator=g) * 0.3).contiguous()
+    dem = capi.PskDemod(capi.demod_cfg(samplerate=6e6, symbolrate=2333333, constellation="qpsk", rrc_alpha=0.5, pll_bw=0.003))
+    d_soft = torch_cuda.zeros(2 * n + 64, dtype=torch_cuda.int8, device="cuda")
+    dem.process_dev(x.data_ptr(), n, capi.FMT_CF32, d_soft.data_ptr(), 2 * n + 64)
+    t0 = time.time()
+    ns = dem.process_dev(x.data_ptr(), n, capi.FMT_CF32, d_soft.data_ptr(), 2 * n + 64)
+    torch_cuda.cuda.synchronize()
+    dt = time.time() - t0
+    st = dem.stats()
+    assert abs(ns / 2 - n / (6e6 / 2333333)) < 0.01 * n          # about one symbol pair per symbol period
+    assert st.chunks_forced > 0 and st.chunks_fixed < 6 * st.chunks  # a handful of rounds, not one per chunk
+    assert dt < 1.0
