@@ -541,26 +541,6 @@ namespace sdhip
             }
         }
     }
-    template <class Stage>
-    __device__ __forceinline__ void blk_run(typename Stage::S &s, const typename Stage::P &p, const Blk8 &c, cf32 *y, long long i, bool write)
-    {
-        const cf32 a0 = Stage::step(s, p, cf32{c.a.x, c.a.y});
-        const cf32 a1 = Stage::step(s, p, cf32{c.a.z, c.a.w});
-        const cf32 a2 = Stage::step(s, p, cf32{c.b.x, c.b.y});
-        const cf32 a3 = Stage::step(s, p, cf32{c.b.z, c.b.w});
-        const cf32 a4 = Stage::step(s, p, cf32{c.c.x, c.c.y});
-        const cf32 a5 = Stage::step(s, p, cf32{c.c.z, c.c.w});
-        const cf32 a6 = Stage::step(s, p, cf32{c.d.x, c.d.y});
-        const cf32 a7 = Stage::step(s, p, cf32{c.d.z, c.d.w});
-        if (write)
-        {
-            float4 *yp = reinterpret_cast<float4 *>(y + i);
-            yp[0] = make_float4(a0.re, a0.im, a1.re, a1.im);
-            yp[1] = make_float4(a2.re, a2.im, a3.re, a3.im);
-            yp[2] = make_float4(a4.re, a4.im, a5.re, a5.im);
-            yp[3] = make_float4(a6.re, a6.im, a7.re, a7.im);
-        }
-    }
     // Groups of Stage::DEPTH blocks, double buffered: all loads of group j+1 (DEPTH * 64 contiguous bytes of this lane's stream,
     // whole 128-byte lines when DEPTH is even and the range starts on a 16-sample boundary) are issued together before group
     // j is consumed, instead of one 64-byte block at a time.

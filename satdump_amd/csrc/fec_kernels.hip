@@ -343,7 +343,6 @@ namespace sdhip
         const int L = wpb / 2;                 // bits per lane = wpb*32/64
         const int wpl = L / 32;                // words per lane
         const int nseg = (F + L - 1) / L;
-        const int lo = 6 + lane * L;
         int hi = 6 + (lane + 1) * L;
         if (hi > F + 6)
             hi = F + 6;
@@ -459,7 +458,7 @@ namespace sdhip
         const v2u16 v = v2v(a);
         return v2u(__builtin_shufflevector(v, v, 1, 0));
     }
-    constexpr unsigned V2_MASK = 0x01FE01FEu, V2_TAG = 0x00010000u;
+    constexpr unsigned V2_MASK = 0x01FE01FEu; // (the tie-break tag 0x00010000 lives in V2Consts::tag)
     // Constants that feed three-operand ops ((x & m) | y = one v_and_or_b32 / v_bitop3_b32) must live in registers: VOP3
     // encodings take no literals on gfx9. The asm keeps the compiler from folding them back into literals.
     struct V2Consts
