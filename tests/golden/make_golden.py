@@ -13,6 +13,8 @@ Fixtures (np.savez_compressed):
   concat_*.npz    CCSDSConvConcatDecoderModule loop: int8 soft -> CADUs, per-block BER/state, RS error counts
   metop.npz       MetOpAHRPTDecoderModule loop (r=3/4 depuncture)
   demod_*.npz     PSKDemodModule chain: cs16 IQ (stored) -> int8 soft symbols + float symbols
+  simple_*.npz    CCSDSSimplePSKDecoderModule loop: int8 soft -> CADUs + RS error counts (three slicer modes)
+  gardner.npz     GardnerClockRecoveryBlock on stored cs16 samples
   taps.npz        RRC / M&M interpolator bank / rational-resampler bank
 """
 import hashlib
@@ -118,6 +120,22 @@ def main():
         xin = (cs16.astype(np.float32) * np.float32(1.0 / 32767.0)).view(np.complex64)  # baseband_interface.h:178 (volk_16i_s32f_convert_32f)
         r = ref.psk_demod(ocfg, xin)
         out[f"demod_{name}"] = dict(cs16=cs16, soft=r["soft"], syms=r["syms"], buffer_size=np.int32(r["buffer_size"]), final_sps=np.float32(r["final_sps"]))
+
+    # ---- ccsds_simple_psk_decoder: BPSK + NRZ-M, QPSK differential, QPSK two-deframer case (90 degree stream)
+    for name in ("bpsk_nrzm", "qpsk_diff_swap", "qpsk_90deg"):
+        ck, soft, plain = util.simple_case(name, sigma=18.0, nframes=8, seed=31)
+        ock = dict(ck)
+        ock["constellation"] = {"bpsk": pyref.BPSK, "qpsk": pyref.QPSK}[ck["constellation"]]
+        r = ref.simple_decode(pyref.fec_cfg(decoder=2, rs_usecheck=0, **ock), soft)
+        out[f"simple_{name}"] = dict(soft=soft, cadu=r["cadu"], frm_err=r["frm_err"])
+
+    # ---- Gardner clock recovery block (clock_recovery_gardner.cpp) on a QPSK baseband
+    spec, cadus, plain, syms = util.metop_case(nframes=3)
+    x, _ = synth.modulate(syms, spec)
+    cs16 = synth.to_cs16(x[:40000])
+    xin = (cs16.astype(np.float32) * np.float32(1.0 / 32767.0)).view(np.complex64)
+    gp = np.array([2.5714, (8.7e-3) ** 2 / 4, 0.5, 8.7e-3, 0.005], dtype=np.float32)
+    out["gardner"] = dict(cs16=cs16, params=gp, syms=ref.block(7, gp, xin))
 
     # ---- filter designs
     bank, ir, dr = ref.resamp_bank(2700000, 3000000)

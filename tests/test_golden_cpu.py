@@ -76,3 +76,21 @@ def test_taps_golden(port):
     assert np.array_equal(port.mm_bank(128, 8).view(np.uint32), d["mm"].view(np.uint32))
     bank, ir, dr = port.resamp_bank(2700000, 3000000)
     assert [ir, dr] == list(d["resamp_ratio"]) and np.array_equal(bank.view(np.uint32), d["resamp"].view(np.uint32))
+
+
+@pytest.mark.parametrize("name", ["bpsk_nrzm", "qpsk_diff_swap", "qpsk_90deg"])
+def test_simple_decoder_golden(port, name):
+    from tests import util
+    d = load("simple_" + name)
+    ck = dict(next(c for c in util.SIMPLE_CASES if c[0] == name)[1])
+    ck["constellation"] = {"bpsk": pyref.BPSK, "qpsk": pyref.QPSK}[ck["constellation"]]
+    r = port.simple_decode(pyref.fec_cfg(decoder=2, rs_usecheck=0, **ck), d["soft"])
+    assert np.array_equal(r["cadu"], d["cadu"]) and len(d["cadu"]) >= 6
+    assert np.array_equal(r["frm_err"], d["frm_err"])
+
+
+def test_gardner_golden(port):
+    d = load("gardner")
+    x = (d["cs16"].astype(np.float32) * np.float32(1.0 / 32767.0)).view(np.complex64)
+    got = port.block(7, d["params"], x)
+    assert np.array_equal(got.view(np.uint32), d["syms"].view(np.uint32)) and len(got) > 10000

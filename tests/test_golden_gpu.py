@@ -104,3 +104,24 @@ def test_demod_golden_exact_cs16(torch_cuda, capi, name, kw):
     assert np.array_equal(d_soft[:ns].cpu().numpy(), d["soft"])
     nsym = len(d["syms"])
     assert np.array_equal(d_syms[: 2 * nsym].cpu().numpy().view(np.uint32), d["syms"].view(np.uint32).reshape(-1))
+
+
+@pytest.mark.parametrize("name", ["bpsk_nrzm", "qpsk_diff_swap", "qpsk_90deg"])
+def test_simple_decoder_golden(torch_cuda, capi, name):
+    from tests import util
+    d = load("simple_" + name)
+    ck = dict(next(c for c in util.SIMPLE_CASES if c[0] == name)[1])
+    got, _, _ = _fec(torch_cuda, capi, capi.fec_cfg(decoder=capi.DEC_SIMPLE_PSK, rs_i=4, rs_type=capi.RS223, rs_usecheck=0, **ck), d["soft"])
+    assert np.array_equal(got, d["cadu"])
+
+
+def test_gardner_golden(torch_cuda, capi):
+    d = load("gardner")
+    x = (d["cs16"].astype(np.float32) * np.float32(1.0 / 32767.0))
+    n = len(x) // 2
+    d_x = _dev(torch_cuda, x)
+    d_y = torch_cuda.zeros(2 * (n + 64), dtype=torch_cuda.float32, device="cuda")
+    p = np.asarray(d["params"], dtype=np.float32)
+    nout = capi.lib().sdhip_op_block(0, 7, p.ctypes.data_as(C.c_void_p), C.c_void_p(d_x.data_ptr()), n, C.c_void_p(d_y.data_ptr()), n + 64)
+    assert nout == len(d["syms"]), capi.last_error()
+    assert np.array_equal(d_y[: 2 * nout].cpu().numpy().view(np.uint32), d["syms"].view(np.uint32).reshape(-1))
