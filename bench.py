@@ -169,11 +169,18 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the product path has no CPU fallback")
+    # plumbing check on a 1-GPU box only: SDHIP_BENCH_SHARE_GPU=1 puts every rank on device 0 and reduces over gloo
+    share_gpu = os.environ.get("SDHIP_BENCH_SHARE_GPU") == "1"
+    if share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if share_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     wl = WORKLOADS[args.workload]
     frames = args.frames or wl["frames"]
@@ -252,7 +259,7 @@ def main():
     last_nf = nf
 
     from satdump_amd import shard
-    dt_all, samples_all, frames_all = shard.reduce_metrics(dt, float(n_in * args.steps), float(tot_frames), device=device)
+    dt_all, samples_all, frames_all = shard.reduce_metrics(dt, float(n_in * args.steps), float(tot_frames), device=None if share_gpu else device)
 
     # ---- correctness of what was timed: every CADU of the last step must be one of the transmitted frames
     check = None
