@@ -303,7 +303,10 @@ namespace sdhip
         DevBuf<uint8_t> d_in_tmp;
 
         // host path
-        std::vector<uint8_t> pend_bytes;
+        static constexpr size_t HOST_BATCH = (size_t)64u << 20; // samples per shipped batch
+        PinBuf<uint8_t> h_in;
+        PinBuf<int8_t> h_out;
+        size_t pend_size = 0; // bytes gathered in h_in
         int pend_fmt = 0;
         std::vector<int8_t> out_queue;
         size_t out_read = 0;
@@ -866,30 +869,52 @@ namespace sdhip
         // ---- host path
         int push_host(const void *iq, size_t nsamples, int fmt)
         {
-            if (!pend_bytes.empty() && fmt != pend_fmt)
+            if (pend_size != 0 && fmt != pend_fmt)
                 throw HipError("baseband format changed mid-stream");
             pend_fmt = fmt;
-            const size_t nb = nsamples * fmt_bytes(fmt);
-            pend_bytes.insert(pend_bytes.end(), (const uint8_t *)iq, (const uint8_t *)iq + nb);
-            if (pend_bytes.size() / fmt_bytes(fmt) >= (size_t)(32u << 20))
-                return flush_host();
+            // samples are gathered in a PINNED staging buffer (one copy on the host, H2D at PCIe rate) and shipped in batches
+            // of HOST_BATCH samples: large enough to fill the lanes, small enough for a live stream's latency
+            const size_t bps = (size_t)fmt_bytes(fmt);
+            const uint8_t *src = (const uint8_t *)iq;
+            size_t left = nsamples;
+            while (left)
+            {
+                const size_t have = pend_size / bps;
+                const size_t take = std::min(left, HOST_BATCH - have);
+                if (pend_size + take * bps > h_in.cap)
+                { // grow the staging buffer, keeping what is gathered (PinBuf::reserve does not preserve content)
+                    PinBuf<uint8_t> bigger;
+                    bigger.reserve(std::min(HOST_BATCH * bps, std::max<size_t>(2 * (pend_size + take * bps), (size_t)1 << 22)));
+                    if (pend_size)
+                        memcpy(bigger.p, h_in.p, pend_size);
+                    std::swap(bigger.p, h_in.p);
+                    std::swap(bigger.cap, h_in.cap);
+                }
+                memcpy(h_in.p + pend_size, src, take * bps);
+                pend_size += take * bps;
+                src += take * bps;
+                left -= take;
+                if (pend_size / bps >= HOST_BATCH)
+                    flush_host();
+            }
             return 0;
         }
         int flush_host()
         {
-            const size_t ns = pend_bytes.size() / fmt_bytes(pend_fmt);
+            const size_t ns = pend_size / fmt_bytes(pend_fmt);
             if (ns == 0)
                 return 0;
             SD_HIP(hipSetDevice(cfg.device));
-            d_in_tmp.reserve(pend_bytes.size());
-            SD_HIP(hipMemcpy(d_in_tmp.p, pend_bytes.data(), pend_bytes.size(), hipMemcpyHostToDevice));
+            d_in_tmp.reserve(pend_size);
+            SD_HIP(hipMemcpyAsync(d_in_tmp.p, h_in.p, pend_size, hipMemcpyHostToDevice, stream));
             const size_t cap = 2 * ns + 64;
             d_soft_tmp.reserve(cap);
             const int64_t n = process(d_in_tmp.p, ns, pend_fmt, d_soft_tmp.p, cap, nullptr, 0);
-            const size_t old = out_queue.size();
-            out_queue.resize(old + (size_t)n);
-            SD_HIP(hipMemcpy(out_queue.data() + old, d_soft_tmp.p, (size_t)n, hipMemcpyDeviceToHost));
-            pend_bytes.clear();
+            h_out.reserve((size_t)n + 1);
+            SD_HIP(hipMemcpyAsync(h_out.p, d_soft_tmp.p, (size_t)n, hipMemcpyDeviceToHost, stream));
+            SD_HIP(hipStreamSynchronize(stream));
+            out_queue.insert(out_queue.end(), h_out.p, h_out.p + n);
+            pend_size = 0;
             return 0;
         }
         int64_t pull(int8_t *soft, size_t cap)

@@ -333,3 +333,30 @@ def test_noise_only_input_is_bounded(torch_cuda, capi):
     assert abs(ns / 2 - n / (6e6 / 2333333)) < 0.01 * n          # about one symbol pair per symbol period
     assert st.chunks_forced > 0 and st.chunks_fixed < 6 * st.chunks  # a handful of rounds, not one per chunk
     assert dt < 1.0
+
+
+def test_host_push_pull_path(torch_cuda, capi, orc):
+    """The host-buffer entry points the C++ modules call (sdhip_demod_push / flush / pull): ragged pushes in the file's own
+    sample format, one flush at the end; soft symbols identical to the reference chain (exact mode) and CADUs identical after
+    the chunk-parallel engine."""
+    spec, plain, x, ocfg, kw, fec, ofec = _case("metop")
+    x = x[:400000]
+    s16 = synth.to_cs16(x)
+    xf = (s16.astype(np.float32) * np.float32(1.0 / 32767.0)).view(np.complex64)
+    want = orc.psk_demod(ocfg, xf)
+    for exact in (1, 0):
+        dem = capi.PskDemod(capi.demod_cfg(**kw, exact=exact))
+        bounds = [0, 7, 7, 30000, 30001, 123456, 400000]
+        for a, b in zip(bounds[:-1], bounds[1:]):
+            dem.push(s16[2 * a: 2 * b], capi.FMT_CS16)
+        dem.flush()
+        soft = dem.pull()
+        assert len(soft) == len(want["soft"])
+        if exact:
+            assert np.array_equal(soft, want["soft"])
+        else:
+            dec = capi.FecDecoder(capi.fec_cfg(**fec))
+            dec.push(soft)
+            got = dec.pull()
+            wantc = orc.metop_decode(want["soft"])["cadu"]
+            assert got.shape == wantc.shape and np.array_equal(got, wantc)
