@@ -80,6 +80,7 @@ def algorithmic_bytes(wl, n_in, n_rs, nsym, nsoft, nblk_bytes, cadu_bytes_out, i
     return {
         "k_convert": n_in * (in_bytes_per_sample + 8),
         "k_resample": n_in * 8 + n_rs * 8,
+        "k_resample_byoffset": n_in * 8 + n_rs * 8,
         "k_chunks<AgcStage>": n_rs * 16,
         "k_fir": n_rs * 16,
         "k_chunks<CostasStage>": n_rs * 16,
@@ -92,6 +93,7 @@ def algorithmic_bytes(wl, n_in, n_rs, nsym, nsoft, nblk_bytes, cadu_bytes_out, i
         "k_pack_stream": 2 * nsoft * wl["conv_rate"] / 8.0,
         "k_extract": 2 * cadu_bytes_out,
         "k_rs": 2 * cadu_bytes_out,
+        "k_rs_screen": cadu_bytes_out,
         "k_compact": 2 * cadu_bytes_out,
     }
 

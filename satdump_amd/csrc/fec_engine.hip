@@ -546,6 +546,15 @@ namespace sdhip
         // collect != nullptr: do not emit; report the frames (left in d_fbytes) and where the reference would have returned them
         int deframe_and_emit(int n, uint8_t *d_out, size_t out_cap_frames, size_t &out_written, FrameBatch *collect = nullptr)
         {
+            const bool tdbg = getenv("SDHIP_DEBUG") != nullptr;
+            auto t_prev = std::chrono::steady_clock::now();
+            auto tick = [&](const char *what) {
+                if (!tdbg)
+                    return;
+                const auto t = std::chrono::steady_clock::now();
+                fprintf(stderr, "[sdhip] fec     . %-12s %7.3f ms (host wall)\n", what, std::chrono::duration<double, std::milli>(t - t_prev).count());
+                t_prev = t;
+            };
             int n_eff = n;
             bool watchdog_fired = false;
             for (int attempt = 0; attempt < 3; attempt++)
@@ -586,7 +595,9 @@ namespace sdhip
                     std::sort(hits.begin(), hits.end());
                 }
                 memset(h_packed.p + pbytes - 8, 0, 8);
+                tick("search+pack");
                 WalkResult W = walk(def, h_packed.p, base_abs, total, hits, n_eff);
+                tick("walk");
 
                 if (cfg.decoder == SDHIP_DEC_METOP_AHRPT)
                 {
@@ -703,6 +714,7 @@ namespace sdhip
                     }
                 }
 
+                tick("frames+rs");
                 // ---- commit deframer state and build the next carry (raw bits) ----------------------------
                 def = W.st;
                 const int64_t avail_end = base_abs + total;
@@ -725,6 +737,7 @@ namespace sdhip
                 stats.bits_decoded += (uint64_t)n_eff * F;
                 if (watchdog_fired)
                     vstate = 0; // viterbi.reset()
+                tick("carry");
                 return n_eff;
             }
             throw HipError("deframer walk did not converge");

@@ -51,3 +51,19 @@ def test_plugin_shim_builds_against_reference_headers():
     used = sorted(set(re.findall(r"\b(sdhip_[a-z0-9_]+)", undefined)))
     assert "sdhip_demod_push" in used and "sdhip_fec_push" in used and "sdhip_fec_pull" in used
     assert set(used) <= set(_declared_symbols())
+
+
+def test_bench_reads_committed_pmc_traffic():
+    """bench.py's roofline.traffic comes from the committed rocprofv3 --pmc summaries (profiles/r*_goes_pmc.csv): the parser
+    must find the dominant kernels there, and the algorithmic byte model must know every kernel it may name."""
+    import bench
+    for k in ("k_mm", "k_chunks<AgcStage>", "k_chunks<CostasStage>", "k_vit2_acs"):
+        traffic, src = bench.pmc_traffic("goes_hrit", k)
+        assert src is not None and src.startswith("r01_") and traffic and traffic > 1e6, (k, traffic, src)
+    wl = bench.WORKLOADS["goes_hrit"]
+    algo = bench.algorithmic_bytes(wl, 262144000, 235929600, 81000000, 81000000, 0, 4944 * 1024, 8)
+    for k in ("k_mm", "k_chunks<AgcStage>", "k_chunks<CostasStage>", "k_resample", "k_resample_byoffset", "k_fir", "k_vit2_acs", "k_rs", "k_rs_screen"):
+        assert algo[k] > 0
+    # SURVEY 8(d): 8 + 2q/S + c/S bytes per input sample for GOES
+    q, sps_in = wl["soft_per_sym"], wl["spec"]["samplerate"] / wl["spec"]["symbolrate"]
+    assert abs(8 + 2 * q / sps_in + (q * wl["conv_rate"] / 8.0) / sps_in - 8.637) < 1e-3
