@@ -81,8 +81,10 @@ def algorithmic_bytes(wl, n_in, n_rs, nsym, nsoft, nblk_bytes, cadu_bytes_out, i
         "k_convert": n_in * (in_bytes_per_sample + 8),
         "k_resample": n_in * 8 + n_rs * 8,
         "k_resample_byoffset": n_in * 8 + n_rs * 8,
+        "k_resample_period": n_in * 8 + n_rs * 8,
         "k_chunks<AgcStage>": n_rs * 16,
         "k_fir": n_rs * 16,
+        "k_fir_window": n_rs * 16,
         "k_chunks<CostasStage>": n_rs * 16,
         "k_mm": n_rs * 8 + nsym * 8,
         "k_quantize": nsym * (8 + q),

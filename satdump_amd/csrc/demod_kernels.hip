@@ -232,6 +232,12 @@ namespace sdhip
                 reinterpret_cast<v2f *>(y)[m] = acc[r];
         }
     }
+    struct ResampIndex
+    {
+        long long o_first, inc0; // first window-end offset of the launch; carried input index of the stream
+        long long qb0, qi0;      // output index / input-index quotient belonging to o_first
+        int rb, ri;              // and their remainders (constant over the launch)
+    };
     // Decimating ratios close to 1 (GOES: 9/10): consecutive outputs start 1 or 2 input samples apart, so the 32 lanes of an
     // LDS access group span more than 32 tile slots and every tile read of k_resample takes two passes (SQ: bank-conflict
     // cycles ~3x the active LDS cycles). Here a lane owns an INPUT OFFSET instead: the one output (if any) whose window ends
@@ -239,15 +245,21 @@ namespace sdhip
     // Same arithmetic per output (taps oldest first, mul and add rounded separately).
     // A thread's RS_PER offsets are `stride` = (256 / decim) * decim apart: same polyphase arm (the hit/miss pattern and the
     // arm repeat every decim offsets), so the tap is read once per k for all of them.
-    __global__ __launch_bounds__(RS_BLOCK) void k_resample_byoffset(const cf32 *x, const cf32 *hist, long long nin, ResampParams p, int ctr0, int inc0, cf32 *y,
-                                                                    long long nout, long long o_first, int stride)
+    // Index arithmetic: offset o is the window end of output m iff inc0 + (ctr0 + m*decim)/interp == o with
+    // m = ceil(((o - inc0)*interp - ctr0) / decim). Done naively that is three 64-bit divisions per output (~2000 VALU
+    // instructions per thread against ~500 useful ones: the first version of this kernel ran at 72 % VALU issue doing mostly
+    // that). A block covers RS_PER*stride offsets = a whole number of decim-periods, so the 64-bit quotients advance by a
+    // constant per block and per r; the host divides once (ResampIndex), a thread is left with three small 32-bit divisions.
+    __global__ __launch_bounds__(RS_BLOCK) void k_resample_byoffset(const cf32 *x, const cf32 *hist, long long nin, ResampParams p, ResampIndex ix, cf32 *y,
+                                                                    long long nout, int stride)
     {
         __shared__ float bank[RS_MAX_BANK];
         __shared__ v2f tile[RS_BLOCK * RS_PER + 64];
         const int nb = p.interp * p.ntaps;
         for (int i = (int)threadIdx.x; i < nb; i += RS_BLOCK)
             bank[i] = p.bank[i];
-        const long long o_base = o_first + (long long)blockIdx.x * (stride * RS_PER); // window-end offsets [o_base, o_base + RS_PER*stride)
+        const long long blk = (long long)blockIdx.x;
+        const long long o_base = ix.o_first + blk * (stride * RS_PER); // window-end offsets [o_base, o_base + RS_PER*stride)
         const long long first = o_base - (p.ntaps - 1);
         const int span = stride * RS_PER + p.ntaps - 1;
         for (int i = (int)threadIdx.x; i < span; i += RS_BLOCK)
@@ -260,31 +272,34 @@ namespace sdhip
         const int t0 = (int)threadIdx.x;
         if (t0 >= stride)
             return;
+        const int per_dec = stride / p.decim;                      // decim-periods per stride
+        const long long qb = ix.qb0 + blk * (long long)(RS_PER * per_dec * p.interp); // outputs in front of this block's first candidate
+        const long long qi = ix.qi0 + blk * (long long)(RS_PER * stride);
+        const unsigned u = (unsigned)ix.rb + (unsigned)t0 * (unsigned)p.interp;
+        const unsigned mv0 = u / (unsigned)p.decim;
+        const unsigned t2 = (unsigned)ix.ri + mv0 * (unsigned)p.decim;
+        const unsigned a0 = t2 / (unsigned)p.interp, arm = t2 - a0 * (unsigned)p.interp;
+        const bool hit0 = ix.inc0 + qi + (long long)a0 == o_base + t0; // the same for every r (offsets a whole number of periods apart)
+        const int row = (int)arm * p.ntaps;
         v2f acc[RS_PER];
         long long mm[RS_PER];
-        int row = 0;
 #pragma unroll
         for (int r = 0; r < RS_PER; r++)
         {
-            const long long o = o_base + t0 + stride * r;
-            // smallest m with inc0 + (ctr0 + m*decim)/interp >= o; it is THE output of offset o iff equality holds
-            const long long need = (o - inc0) * p.interp - ctr0;
-            const long long m = need <= 0 ? 0 : (need + p.decim - 1) / p.decim;
-            const long long ph = (long long)ctr0 + m * p.decim;
-            const bool hit = m < nout && inc0 + ph / p.interp == o;
-            mm[r] = hit ? m : -1;
-            if (r == 0)
-                row = (int)(ph % p.interp) * p.ntaps; // a miss at r = 0 is a miss at every r (or past the end): row is unused then
+            const long long m = qb + (long long)mv0 + (long long)r * (per_dec * p.interp);
+            mm[r] = (hit0 && m < nout) ? m : -1;
             acc[r] = v2f{0.0f, 0.0f};
         }
+        const float *brow = bank + row;
+        const v2f *trow = tile + t0;
         for (int k = 0; k < p.ntaps; k++)
         {
-            const float tk = bank[row + k];
+            const float tk = brow[k];
             const v2f tt{tk, tk};
 #pragma unroll
             for (int r = 0; r < RS_PER; r++)
             {
-                const v2f prod = tile[t0 + stride * r + k] * tt;
+                const v2f prod = trow[stride * r + k] * tt;
                 acc[r] = acc[r] + prod;
             }
         }
@@ -292,6 +307,76 @@ namespace sdhip
         for (int r = 0; r < RS_PER; r++)
             if (mm[r] >= 0)
                 reinterpret_cast<v2f *>(y)[mm[r]] = acc[r];
+    }
+
+    // Register-window variant for a ratio known at compile time (GOES HRIT: 9/10, 38 taps per arm). k_resample_byoffset reads
+    // every sample of every window from LDS (ntaps * 8 B per output: the LDS pipe, not HBM, bounds it). Here a thread owns one
+    // whole decim-period starting at an output of arm 0: D consecutive window-end offsets -> I outputs whose (offset, arm)
+    // pattern (j*D/I, j*D%I) is the same for every thread. It pulls its NT + EMAX samples into registers once (8x fewer LDS
+    // bytes per output for 9/10), the arm of output j is wave-uniform so the taps arrive through scalar loads, and the
+    // outputs go back through LDS so that the global stores are contiguous. Accumulation order per output is unchanged.
+    constexpr int RSP_BLOCK = 256;
+    template <int I, int D, int NT>
+    __global__ __launch_bounds__(RSP_BLOCK) void k_resample_period(const cf32 *x, const cf32 *hist, long long nin, const float *__restrict__ bank,
+                                                                    long long off0, long long m_start, cf32 *y, long long nout)
+    {
+        constexpr int EMAX = ((I - 1) * D) / I;   // largest window-end offset inside a period
+        constexpr int WIN = NT + EMAX;            // samples one thread touches
+        constexpr int SPAN = (RSP_BLOCK - 1) * D + WIN;
+        static_assert(RSP_BLOCK * I <= SPAN, "output staging reuses the input tile");
+        __shared__ v2f tile[SPAN];
+        const long long blk = (long long)blockIdx.x;
+        const long long first = off0 + blk * (RSP_BLOCK * D) - (NT - 1); // input index of tile[0]
+        for (int i = (int)threadIdx.x; i < SPAN; i += RSP_BLOCK)
+        {
+            const long long idx = first + i;
+            cf32 v{0.0f, 0.0f};
+            if (idx >= 0)
+            {
+                if (idx < nin)
+                    v = x[idx];
+            }
+            else if (idx >= -DEMOD_HIST)
+                v = hist[DEMOD_HIST + idx];
+            tile[i] = v2f{v.re, v.im};
+        }
+        __syncthreads();
+        const int t = (int)threadIdx.x;
+        v2f s[WIN];
+#pragma unroll
+        for (int i = 0; i < WIN; i++)
+            s[i] = tile[t * D + i];
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < I; j++)
+        {
+            const int e = (j * D) / I, a = (j * D) % I;
+            v2f acc{0.0f, 0.0f};
+#pragma unroll
+            for (int k = 0; k < NT; k++)
+            {
+                const float tk = bank[a * NT + k];
+                const v2f prod = s[e + k] * v2f{tk, tk};
+                acc = acc + prod;
+            }
+            tile[t * I + j] = acc;
+        }
+        __syncthreads();
+        const long long mb = m_start + blk * (RSP_BLOCK * I); // output index of tile[0]
+        for (int i = (int)threadIdx.x; i < RSP_BLOCK * I; i += RSP_BLOCK)
+        {
+            const long long m = mb + i;
+            if (m >= 0 && m < nout)
+                reinterpret_cast<v2f *>(y)[m] = tile[i];
+        }
+    }
+    static bool resample_period_enabled()
+    {
+        static const bool on = [] {
+            const char *e = getenv("SDHIP_RESAMP_PERIOD");
+            return !(e && e[0] == '0');
+        }();
+        return on;
     }
 
     // fallback for banks / spans that do not fit the LDS budget (very large interpolation factors)
@@ -324,14 +409,37 @@ namespace sdhip
             return;
 
         const long long span_max = ((long long)RS_BLOCK * RS_PER * p.decim) / p.interp + p.ntaps + 2;
-        if (p.interp * p.ntaps <= RS_MAX_BANK && p.ntaps <= 64 && p.decim > p.interp && 4 * p.decim <= 5 * p.interp && p.decim <= 64)
+        if (p.interp == 9 && p.decim == 10 && p.ntaps == 38 && resample_period_enabled())
+        {
+            // first output whose arm is 0, then one period back so that outputs 0 .. m_first-1 are covered (m < 0 is masked)
+            long long m_first = 0;
+            while (((long long)ctr0 + m_first * p.decim) % p.interp != 0)
+                m_first++;
+            const long long m_start = m_first - p.interp;
+            const long long off0 = inc0 + ((long long)ctr0 + m_start * p.decim) / p.interp; // exact division
+            const long long nper = (nout - m_start + p.interp - 1) / p.interp;
+            ProfScope _ps("k_resample_period", st);
+            hipLaunchKernelGGL((k_resample_period<9, 10, 38>), dim3((unsigned)((nper + RSP_BLOCK - 1) / RSP_BLOCK)), dim3(RSP_BLOCK), 0, st, x, hist, nin, p.bank,
+                               off0, m_start, y, nout);
+        }
+        else if (p.interp * p.ntaps <= RS_MAX_BANK && p.ntaps <= 64 && p.decim > p.interp && 4 * p.decim <= 5 * p.interp && p.decim <= 64)
         {
             const long long o_first = inc0 + (long long)ctr0 / p.interp;                              // window end of output 0
             const long long o_last = inc0 + ((long long)ctr0 + (nout - 1) * (long long)p.decim) / p.interp; // ... of the last output
             const int stride = (RS_BLOCK / p.decim) * p.decim;
+            // m(o) = floor((N0 + (o - o_first)*interp) / decim), N0 = (o_first - inc0)*interp - ctr0 + decim - 1 >= 0
+            ResampIndex ix;
+            ix.o_first = o_first;
+            ix.inc0 = inc0;
+            const long long N0 = (o_first - inc0) * (long long)p.interp - ctr0 + p.decim - 1;
+            ix.qb0 = N0 / p.decim;
+            ix.rb = (int)(N0 % p.decim);
+            const long long PH0 = (long long)ctr0 + ix.qb0 * p.decim; // phase counter of output qb0
+            ix.qi0 = PH0 / p.interp;
+            ix.ri = (int)(PH0 % p.interp);
             ProfScope _ps("k_resample_byoffset", st);
             hipLaunchKernelGGL(k_resample_byoffset, dim3((unsigned)((o_last - o_first + stride * RS_PER) / (stride * RS_PER))), dim3(RS_BLOCK), 0, st, x, hist, nin, p,
-                               ctr0, inc0, y, nout, o_first, stride);
+                               ix, y, nout, stride);
         }
         else if (p.interp * p.ntaps <= RS_MAX_BANK && span_max <= RS_MAX_TILE)
         {
@@ -387,10 +495,72 @@ namespace sdhip
                 reinterpret_cast<v2f *>(y)[i] = acc[r];
         }
     }
+    // Register-window variant for a tap count known at compile time (the 31-tap RRC every pipeline of the path uses): a thread
+    // pulls NT + R - 1 samples into registers once and produces R consecutive outputs from them (k_fir reads every sample of
+    // every window from LDS: NT * 8 B per output, enough to keep the LDS pipe as busy as HBM). R = 10: the 16-byte LDS reads of
+    // 16 consecutive lanes (20 dwords apart) fall on 16 distinct bank quads. Outputs return through LDS for contiguous stores.
+    // Same accumulation order per output as k_fir.
+    constexpr int FIRW_BLOCK = 256, FIRW_R = 10;
+    template <int NT>
+    __global__ __launch_bounds__(FIRW_BLOCK) void k_fir_window(const cf32 *x, cf32 *y, long long n, const float *__restrict__ rtaps)
+    {
+        constexpr int OUTS = FIRW_BLOCK * FIRW_R;
+        constexpr int SPAN = OUTS + NT - 1;
+        __shared__ v2f tile[SPAN];
+        const long long i0 = (long long)blockIdx.x * OUTS;
+        const v2f *xs = reinterpret_cast<const v2f *>(x) + (i0 - (NT - 1));
+        const long long lim = n - i0 + (NT - 1); // tile entries backed by input samples
+        for (int i = (int)threadIdx.x; i < SPAN; i += FIRW_BLOCK)
+            tile[i] = (i < lim) ? xs[i] : v2f{0.0f, 0.0f};
+        __syncthreads();
+        const int t = (int)threadIdx.x;
+        v2f s[NT + FIRW_R - 1];
+#pragma unroll
+        for (int i = 0; i < NT + FIRW_R - 1; i++)
+            s[i] = tile[t * FIRW_R + i];
+        __syncthreads();
+        v2f acc[FIRW_R];
+#pragma unroll
+        for (int r = 0; r < FIRW_R; r++)
+            acc[r] = v2f{0.0f, 0.0f};
+#pragma unroll
+        for (int j = 0; j < NT; j++)
+        {
+            const float tk = rtaps[j]; // wave-uniform: scalar load, one tap live at a time
+            const v2f tt{tk, tk};
+#pragma unroll
+            for (int r = 0; r < FIRW_R; r++)
+            {
+                const v2f prod = s[r + j] * tt;
+                acc[r] = acc[r] + prod;
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < FIRW_R; r++)
+            tile[t * FIRW_R + r] = acc[r];
+        __syncthreads();
+        for (int i = (int)threadIdx.x; i < OUTS; i += FIRW_BLOCK)
+            if (i0 + i < n)
+                reinterpret_cast<v2f *>(y)[i0 + i] = tile[i];
+    }
+    static bool fir_window_enabled()
+    {
+        static const bool on = [] {
+            const char *e = getenv("SDHIP_FIR_WINDOW");
+            return !(e && e[0] == '0');
+        }();
+        return on;
+    }
     void launch_fir(const cf32 *x, cf32 *y, long long n, const float *rtaps_dev, int ntaps, hipStream_t st)
     {
         if (n <= 0)
             return;
+        if (ntaps == 31 && fir_window_enabled())
+        {
+            ProfScope _ps("k_fir_window", st);
+            hipLaunchKernelGGL((k_fir_window<31>), dim3((unsigned)((n + FIRW_BLOCK * FIRW_R - 1) / (FIRW_BLOCK * FIRW_R))), dim3(FIRW_BLOCK), 0, st, x, y, n, rtaps_dev);
+            return;
+        }
         ProfScope _ps("k_fir", st);
         hipLaunchKernelGGL(k_fir, dim3((unsigned)((n + FIR_BLOCK * FIR_PER - 1) / (FIR_BLOCK * FIR_PER))), dim3(FIR_BLOCK), 0, st, x, y, n, rtaps_dev, ntaps);
     }

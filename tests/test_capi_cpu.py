@@ -62,7 +62,7 @@ def test_bench_reads_committed_pmc_traffic():
         assert src is not None and src.startswith("r01_") and traffic and traffic > 1e6, (k, traffic, src)
     wl = bench.WORKLOADS["goes_hrit"]
     algo = bench.algorithmic_bytes(wl, 262144000, 235929600, 81000000, 81000000, 0, 4944 * 1024, 8)
-    for k in ("k_mm", "k_chunks<AgcStage>", "k_chunks<CostasStage>", "k_resample", "k_resample_byoffset", "k_fir", "k_vit2_acs", "k_rs", "k_rs_screen"):
+    for k in ("k_mm", "k_chunks<AgcStage>", "k_chunks<CostasStage>", "k_resample", "k_resample_byoffset", "k_resample_period", "k_fir", "k_fir_window", "k_vit2_acs", "k_rs", "k_rs_screen"):
         assert algo[k] > 0
     # 8 + 2q/S + c/S bytes per input sample for GOES
     q, sps_in = wl["soft_per_sym"], wl["spec"]["samplerate"] / wl["spec"]["symbolrate"]
