@@ -316,58 +316,90 @@ namespace sdhip
     // bytes per output for 9/10), the arm of output j is wave-uniform so the taps arrive through scalar loads, and the
     // outputs go back through LDS so that the global stores are contiguous. Accumulation order per output is unchanged.
     constexpr int RSP_BLOCK = 256;
+    // grid of a persistent kernel: exactly the blocks that are resident at once (CUs x occupancy), see k_resample_period
+    template <class K>
+    static int resident_grid(K kernel, int block)
+    {
+        int occ = 0, dev = 0, cus = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kernel, block, 0) != hipSuccess || occ < 1)
+            occ = 2;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1)
+            cus = 256;
+        return occ * cus;
+    }
+    // Persistent blocks walk over the tiles with stride gridDim.x and fetch the NEXT tile's samples into registers before
+    // they compute the current one: with one tile per block the loads of a block only overlap other blocks' compute, and
+    // at 3-4 resident blocks per CU that left HBM at ~3.5 TB/s.
     template <int I, int D, int NT>
     __global__ __launch_bounds__(RSP_BLOCK) void k_resample_period(const cf32 *x, const cf32 *hist, long long nin, const float *__restrict__ bank,
-                                                                    long long off0, long long m_start, cf32 *y, long long nout)
+                                                                    long long off0, long long m_start, cf32 *y, long long nout, long long ntiles)
     {
         constexpr int EMAX = ((I - 1) * D) / I;   // largest window-end offset inside a period
         constexpr int WIN = NT + EMAX;            // samples one thread touches
         constexpr int SPAN = (RSP_BLOCK - 1) * D + WIN;
+        constexpr int LOADS = (SPAN + RSP_BLOCK - 1) / RSP_BLOCK;
         static_assert(RSP_BLOCK * I <= SPAN, "output staging reuses the input tile");
         __shared__ v2f tile[SPAN];
-        const long long blk = (long long)blockIdx.x;
-        const long long first = off0 + blk * (RSP_BLOCK * D) - (NT - 1); // input index of tile[0]
-        for (int i = (int)threadIdx.x; i < SPAN; i += RSP_BLOCK)
-        {
-            const long long idx = first + i;
-            cf32 v{0.0f, 0.0f};
-            if (idx >= 0)
-            {
-                if (idx < nin)
-                    v = x[idx];
-            }
-            else if (idx >= -DEMOD_HIST)
-                v = hist[DEMOD_HIST + idx];
-            tile[i] = v2f{v.re, v.im};
-        }
-        __syncthreads();
         const int t = (int)threadIdx.x;
-        v2f s[WIN];
+        v2f pre[LOADS];
+        unsigned ok = 0; // bit l: pre[l] is a real sample (not clamped)
+        auto fetch = [&](long long blk) {
+            ok = 0;
+            const long long first = off0 + blk * (RSP_BLOCK * D) - (NT - 1); // input index of tile[0]
 #pragma unroll
-        for (int i = 0; i < WIN; i++)
-            s[i] = tile[t * D + i];
-        __syncthreads();
-#pragma unroll
-        for (int j = 0; j < I; j++)
-        {
-            const int e = (j * D) / I, a = (j * D) % I;
-            v2f acc{0.0f, 0.0f};
-#pragma unroll
-            for (int k = 0; k < NT; k++)
+            for (int l = 0; l < LOADS; l++)
             {
-                const float tk = bank[a * NT + k];
-                const v2f prod = s[e + k] * v2f{tk, tk};
-                acc = acc + prod;
+                // branch-free: always load from a clamped (valid) address, zero what lies outside [-DEMOD_HIST, nin)
+                const long long idx = first + t + RSP_BLOCK * l;
+                long long c = idx < nin - 1 ? idx : nin - 1;
+                c = c > -DEMOD_HIST ? c : -DEMOD_HIST;
+                const v2f *src = c >= 0 ? reinterpret_cast<const v2f *>(x) + c : reinterpret_cast<const v2f *>(hist) + (DEMOD_HIST + c);
+                pre[l] = *src; // masked when it is written to LDS: a select here would make the compiler wait for each load in turn
+                ok |= (c == idx ? 1u : 0u) << l;
             }
-            tile[t * I + j] = acc;
-        }
-        __syncthreads();
-        const long long mb = m_start + blk * (RSP_BLOCK * I); // output index of tile[0]
-        for (int i = (int)threadIdx.x; i < RSP_BLOCK * I; i += RSP_BLOCK)
+        };
+        long long blk = (long long)blockIdx.x;
+        if (blk < ntiles)
+            fetch(blk);
+        for (; blk < ntiles; blk += gridDim.x)
         {
-            const long long m = mb + i;
-            if (m >= 0 && m < nout)
-                reinterpret_cast<v2f *>(y)[m] = tile[i];
+#pragma unroll
+            for (int l = 0; l < LOADS; l++)
+                if (t + RSP_BLOCK * l < SPAN)
+                    tile[t + RSP_BLOCK * l] = ((ok >> l) & 1u) ? pre[l] : v2f{0.0f, 0.0f};
+            __syncthreads();
+            v2f s[WIN];
+#pragma unroll
+            for (int i = 0; i < WIN; i++)
+                s[i] = tile[t * D + i];
+            __syncthreads();
+            if (blk + gridDim.x < ntiles)
+                fetch(blk + gridDim.x);
+            int z = 0;
+            asm volatile("" : "+s"(z)); // opaque zero: keeps the (loop-invariant) scalar tap loads inside the tile loop; hoisted they spill ~340 SGPRs
+#pragma unroll
+            for (int j = 0; j < I; j++)
+            {
+                const int e = (j * D) / I, a = (j * D) % I;
+                v2f acc{0.0f, 0.0f};
+#pragma unroll
+                for (int k = 0; k < NT; k++)
+                {
+                    const float tk = bank[z + a * NT + k];
+                    const v2f prod = s[e + k] * v2f{tk, tk};
+                    acc = acc + prod;
+                }
+                tile[t * I + j] = acc;
+            }
+            __syncthreads();
+            const long long mb = m_start + blk * (RSP_BLOCK * I); // output index of tile[0]
+            for (int i = t; i < RSP_BLOCK * I; i += RSP_BLOCK)
+            {
+                const long long m = mb + i;
+                if (m >= 0 && m < nout)
+                    reinterpret_cast<v2f *>(y)[m] = tile[i];
+            }
+            __syncthreads();
         }
     }
     static bool resample_period_enabled()
@@ -419,8 +451,10 @@ namespace sdhip
             const long long off0 = inc0 + ((long long)ctr0 + m_start * p.decim) / p.interp; // exact division
             const long long nper = (nout - m_start + p.interp - 1) / p.interp;
             ProfScope _ps("k_resample_period", st);
-            hipLaunchKernelGGL((k_resample_period<9, 10, 38>), dim3((unsigned)((nper + RSP_BLOCK - 1) / RSP_BLOCK)), dim3(RSP_BLOCK), 0, st, x, hist, nin, p.bank,
-                               off0, m_start, y, nout);
+            const long long ntiles = (nper + RSP_BLOCK - 1) / RSP_BLOCK;
+            static const int grid = resident_grid(k_resample_period<9, 10, 38>, RSP_BLOCK);
+            hipLaunchKernelGGL((k_resample_period<9, 10, 38>), dim3((unsigned)(ntiles < grid ? ntiles : grid)), dim3(RSP_BLOCK), 0, st, x, hist, nin,
+                               p.bank, off0, m_start, y, nout, ntiles);
         }
         else if (p.interp * p.ntaps <= RS_MAX_BANK && p.ntaps <= 64 && p.decim > p.interp && 4 * p.decim <= 5 * p.interp && p.decim <= 64)
         {
@@ -502,46 +536,74 @@ namespace sdhip
     // Same accumulation order per output as k_fir.
     constexpr int FIRW_BLOCK = 256, FIRW_R = 10;
     template <int NT>
-    __global__ __launch_bounds__(FIRW_BLOCK) void k_fir_window(const cf32 *x, cf32 *y, long long n, const float *__restrict__ rtaps)
+    __global__ __launch_bounds__(FIRW_BLOCK) void k_fir_window(const cf32 *x, cf32 *y, long long n, const float *__restrict__ rtaps, long long ntiles)
     {
         constexpr int OUTS = FIRW_BLOCK * FIRW_R;
         constexpr int SPAN = OUTS + NT - 1;
+        constexpr int LOADS = (SPAN + FIRW_BLOCK - 1) / FIRW_BLOCK;
         __shared__ v2f tile[SPAN];
-        const long long i0 = (long long)blockIdx.x * OUTS;
-        const v2f *xs = reinterpret_cast<const v2f *>(x) + (i0 - (NT - 1));
-        const long long lim = n - i0 + (NT - 1); // tile entries backed by input samples
-        for (int i = (int)threadIdx.x; i < SPAN; i += FIRW_BLOCK)
-            tile[i] = (i < lim) ? xs[i] : v2f{0.0f, 0.0f};
-        __syncthreads();
         const int t = (int)threadIdx.x;
-        v2f s[NT + FIRW_R - 1];
+        v2f pre[LOADS];
+        unsigned ok = 0;
+        auto fetch = [&](long long blk) {
+            ok = 0;
+            const long long i0 = blk * OUTS;
+            const v2f *xs = reinterpret_cast<const v2f *>(x) + (i0 - (NT - 1));
+            const long long lim = n - i0 + (NT - 1); // tile entries backed by input samples
 #pragma unroll
-        for (int i = 0; i < NT + FIRW_R - 1; i++)
-            s[i] = tile[t * FIRW_R + i];
-        __syncthreads();
-        v2f acc[FIRW_R];
-#pragma unroll
-        for (int r = 0; r < FIRW_R; r++)
-            acc[r] = v2f{0.0f, 0.0f};
-#pragma unroll
-        for (int j = 0; j < NT; j++)
+            for (int l = 0; l < LOADS; l++)
+            {
+                const int i = t + FIRW_BLOCK * l; // branch-free: clamped address, zero past the end of the input
+                const long long c = i < lim - 1 ? i : lim - 1;
+                pre[l] = xs[c]; // masked when it is written to LDS (see k_resample_period)
+                ok |= (c == i ? 1u : 0u) << l;
+            }
+        };
+        long long blk = (long long)blockIdx.x;
+        if (blk < ntiles)
+            fetch(blk); // persistent blocks, next tile prefetched during compute: see k_resample_period
+        for (; blk < ntiles; blk += gridDim.x)
         {
-            const float tk = rtaps[j]; // wave-uniform: scalar load, one tap live at a time
-            const v2f tt{tk, tk};
+#pragma unroll
+            for (int l = 0; l < LOADS; l++)
+                if (t + FIRW_BLOCK * l < SPAN)
+                    tile[t + FIRW_BLOCK * l] = ((ok >> l) & 1u) ? pre[l] : v2f{0.0f, 0.0f};
+            __syncthreads();
+            v2f s[NT + FIRW_R - 1];
+#pragma unroll
+            for (int i = 0; i < NT + FIRW_R - 1; i++)
+                s[i] = tile[t * FIRW_R + i];
+            __syncthreads();
+            if (blk + gridDim.x < ntiles)
+                fetch(blk + gridDim.x);
+            v2f acc[FIRW_R];
 #pragma unroll
             for (int r = 0; r < FIRW_R; r++)
-            {
-                const v2f prod = s[r + j] * tt;
-                acc[r] = acc[r] + prod;
-            }
-        }
+                acc[r] = v2f{0.0f, 0.0f};
+            int z = 0;
+            asm volatile("" : "+s"(z)); // opaque zero: keeps the scalar tap loads inside the tile loop
 #pragma unroll
-        for (int r = 0; r < FIRW_R; r++)
-            tile[t * FIRW_R + r] = acc[r];
-        __syncthreads();
-        for (int i = (int)threadIdx.x; i < OUTS; i += FIRW_BLOCK)
-            if (i0 + i < n)
-                reinterpret_cast<v2f *>(y)[i0 + i] = tile[i];
+            for (int j = 0; j < NT; j++)
+            {
+                const float tk = rtaps[z + j]; // wave-uniform: scalar load
+                const v2f tt{tk, tk};
+#pragma unroll
+                for (int r = 0; r < FIRW_R; r++)
+                {
+                    const v2f prod = s[r + j] * tt;
+                    acc[r] = acc[r] + prod;
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < FIRW_R; r++)
+                tile[t * FIRW_R + r] = acc[r];
+            __syncthreads();
+            const long long i0 = blk * OUTS;
+            for (int i = t; i < OUTS; i += FIRW_BLOCK)
+                if (i0 + i < n)
+                    reinterpret_cast<v2f *>(y)[i0 + i] = tile[i];
+            __syncthreads();
+        }
     }
     static bool fir_window_enabled()
     {
@@ -558,7 +620,9 @@ namespace sdhip
         if (ntaps == 31 && fir_window_enabled())
         {
             ProfScope _ps("k_fir_window", st);
-            hipLaunchKernelGGL((k_fir_window<31>), dim3((unsigned)((n + FIRW_BLOCK * FIRW_R - 1) / (FIRW_BLOCK * FIRW_R))), dim3(FIRW_BLOCK), 0, st, x, y, n, rtaps_dev);
+            const long long ntiles = (n + FIRW_BLOCK * FIRW_R - 1) / (FIRW_BLOCK * FIRW_R);
+            static const int grid = resident_grid(k_fir_window<31>, FIRW_BLOCK);
+            hipLaunchKernelGGL((k_fir_window<31>), dim3((unsigned)(ntiles < grid ? ntiles : grid)), dim3(FIRW_BLOCK), 0, st, x, y, n, rtaps_dev, ntiles);
             return;
         }
         ProfScope _ps("k_fir", st);
