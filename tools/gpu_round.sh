@@ -13,6 +13,6 @@ done
 find $OUT -name "*.csv" | head -20
 f=$(find $OUT/prof_$WL -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && python tools/rocprof_summary.py $f "python bench.py --workload $WL --steps 3 --warmup 1 --cpu-samples 0" > $OUT/${WL}_kernel_stats.csv && head -12 $OUT/${WL}_kernel_stats.csv
 python tools/pmc_summary.py $OUT $WL > $OUT/${WL}_pmc.csv 2>&1; head -30 $OUT/${WL}_pmc.csv
-tools/gpu_sq.sh $TAG $WL > /dev/null 2>&1; head -12 $OUT/${WL}_sq.csv
+[ -z "$NO_SQ" ] && { tools/gpu_sq.sh $TAG $WL > /dev/null 2>&1; head -12 $OUT/${WL}_sq.csv; }
 # keep only the small summaries in the merge-back
 find $OUT -name "*kernel_trace.csv" -size +20M -delete
