@@ -476,7 +476,14 @@ namespace sdhip
             const char *v = getenv(name);
             return (v && *v) ? atoll(v) : dflt;
         }
-        int pick_L(long long n) const
+        // Chunk length of one speculative stage: one lane per chunk, `lanes` lanes wanted. Measured (tools/sweep.sh, sweep_wl.sh,
+        // DESIGN.md 5): the M&M lane is issue-bound (a wave alone on a SIMD runs ~2x faster per sample than two sharing one) and
+        // the AGC lane HBM-bound with a long warm-up, so both want ONE wave per SIMD (1024 SIMDs x 64 lanes, a little less so
+        // that no SIMD gets two) and the longest chunks that allows; the Costas lane is latency-bound (sincos chain) and gains
+        // from two to three waves per SIMD. Chunks stay long enough (2048) that the warm-up overlap does not dominate.
+        // SDHIP_LANES_AGC / _COSTAS / _MM override the targets (experiments only).
+        enum StageKind { ST_AGC = 0, ST_COSTAS = 1, ST_MM = 2 };
+        int pick_L(long long n, StageKind st) const
         {
             if (cfg.exact)
                 return 1 << 30;
@@ -484,11 +491,13 @@ namespace sdhip
                 return (int)((env_int("SDHIP_CHUNK", 8192) + 7) / 8 * 8);
             if (cfg.chunk_len > 0)
                 return (cfg.chunk_len + 7) / 8 * 8; // stage chunk boundaries stay multiples of 8 samples (64-byte blocks)
-            // one lane per chunk: aim at ~1.5 waves on each of the 1024 SIMDs, but keep chunks long enough that the
-            // warm-up overlap (a few thousand samples) does not dominate the work
-            long long L = (n + 98303) / 98304;
-            L = (L + 255) / 256 * 256;
-            return (int)std::min<long long>(std::max<long long>(L, 2048), 1 << 20);
+            static const char *names[3] = {"SDHIP_LANES_AGC", "SDHIP_LANES_COSTAS", "SDHIP_LANES_MM"};
+            static const long long dflt[3] = {65280, 196608, 65280};
+            static const long long min_len[3] = {2048, 2048, 2048};
+            const long long lanes = std::max<long long>(64, env_int(names[st], dflt[st]));
+            long long L = (n + lanes - 1) / lanes;
+            L = (L + 63) / 64 * 64;
+            return (int)std::min<long long>(std::max<long long>(L, min_len[st]), 1 << 20);
         }
 
         // Certificate chain of one speculative stage. Chunk k stands iff its verdict kernel accepts (state its warm-up reached,
@@ -611,7 +620,6 @@ namespace sdhip
                     return 0;
             }
             tick("resample");
-            const int L = pick_L(n);
 
             // ---- AGC (speculative)
             {
@@ -642,6 +650,7 @@ namespace sdhip
                 W = std::min<long long>(std::max<long long>(W, 1024), 1 << 22);
                 W = (W + 255) / 256 * 256;
                 agc_p.init_gain = g_est;
+                const int L = pick_L(n, ST_AGC);
                 const ChunkGeom g = make_geom(n, L, (int)W);
                 stats.chunks += g.K;
                 d_agc_spec.reserve(g.K);
@@ -700,6 +709,7 @@ namespace sdhip
                 W = env_int("SDHIP_W_COSTAS", W);
                 W = (std::min<long long>(W, 1 << 22) + 255) / 256 * 256;
                 cos_p.est_len = (int)std::min<long long>(env_int("SDHIP_COSTAS_EST", 256), W / 2);
+                const int L = pick_L(n, ST_COSTAS);
                 cg = make_geom(n, L, (int)W);
                 stats.chunks += cg.K;
                 d_cos_spec.reserve(cg.K);
@@ -771,6 +781,7 @@ namespace sdhip
                 mm_p.fast_syms = mm_p.fast_mult > 1.0f ? (int)env_int("SDHIP_MM_FAST_SYMS", (long long)(2.75 / gmu)) : 0;
                 // a re-run costs one lane the whole chunk, so long chunks (large batches) keep the conservative warm-up: it is a
                 // small fraction of L there anyway
+                const int L = pick_L(n, ST_MM);
                 const double w_full = 36.0 / gmu * final_sps;
                 const double w_gear = mm_p.fast_syms > 0 ? (mm_p.fast_syms + 16.0 / gmu) * final_sps : w_full;
                 long long W = cfg.warmup > 0 ? cfg.warmup : (long long)std::min(w_full, std::max(w_gear, 0.5 * L));
