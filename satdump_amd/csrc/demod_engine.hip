@@ -295,6 +295,7 @@ namespace sdhip
         DevBuf<CostasState> d_cos_spec, d_cos_end, d_cos_start;
         DevBuf<MmState> d_mm_spec, d_mm_end, d_mm_start;
         DevBuf<MmCert> d_mm_spec_c, d_mm_end_c; // what the host certificate reads (16 B per chunk instead of the 72-byte state)
+        DevBuf<MmCert> d_mm_ck;                 // experimental: per-chunk checkpoints for the early exit of re-run lanes (SDHIP_MM_CKPT)
         DevBuf<DcState> d_dc;
         DevBuf<int> d_redo, d_rot, d_dm, d_counts, d_seg, d_skip, d_extra;
         DevBuf<long long> d_offsets, d_tile_sums;
@@ -802,7 +803,17 @@ namespace sdhip
                 d_mm_spec_c.reserve(g.K);
                 d_mm_end_c.reserve(g.K);
                 SD_HIP(hipMemcpyAsync(d_mm_start.p, &mm_s, sizeof(mm_s), hipMemcpyHostToDevice, stream));
-                launch_mm(A, symbuf.p, d_counts.p, g, mm_p, d_mm_start.p, d_mm_spec.p, d_mm_end.p, d_mm_spec_c.p, d_mm_end_c.p, nullptr, 0, stream);
+                const double MM_TOL = env_int("SDHIP_MM_TOL_MILLI", 80) * 1e-3;
+                // experimental (off): checkpoints for the early exit of re-run lanes, k_mm<true>
+                MmCert *ckp = nullptr;
+                const int ck_per_chunk = mm_p.cap / MM_CKPT_SYMS + 1;
+                if (env_int("SDHIP_MM_CKPT", 0))
+                {
+                    d_mm_ck.reserve((size_t)g.K * ck_per_chunk);
+                    ckp = d_mm_ck.p;
+                }
+                launch_mm(A, symbuf.p, d_counts.p, g, mm_p, d_mm_start.p, d_mm_spec.p, d_mm_end.p, d_mm_spec_c.p, d_mm_end_c.p, nullptr, 0, stream, ckp, ck_per_chunk,
+                          (float)MM_TOL);
                 // Symbol hand-off at chunk boundaries. The M&M loop never re-merges bit for bit: its feedback is piecewise
                 // constant through the 128-arm interpolator index rint(mu*128) (clock_recovery_mm.cpp:66), so independent
                 // trajectories hover a fraction of an arm apart (tools/merge_study.py). What is certified is CONSISTENCY in
@@ -811,7 +822,6 @@ namespace sdhip
                 // boundary fell between the two trajectories' sample indices, mu wrapping on opposite sides): the symbol(s) are
                 // taken from chunk k-1's look-ahead, or skipped at the head of chunk k. Anything else: re-run from the exact state.
                 // (k_mm_verdict; the compaction segments and offsets are a prefix sum on the device, k_chunk_scan.)
-                const double MM_TOL = env_int("SDHIP_MM_TOL_MILLI", 80) * 1e-3;
                 d_skip.reserve(g.K);
                 d_extra.reserve(g.K);
                 d_seg.reserve(2 * (size_t)g.K);
@@ -840,7 +850,8 @@ namespace sdhip
                         hipLaunchKernelGGL(k_spec_from_prev<MmCert>, dim3((nr + 255) / 256), dim3(256), 0, stream, list, nr, d_mm_spec_c.p, d_mm_end_c.p);
                     },
                     [&](const int *redo, int nr) {
-                        launch_mm(A, symbuf.p, d_counts.p, g, mm_p, d_mm_start.p, d_mm_spec.p, d_mm_end.p, d_mm_spec_c.p, d_mm_end_c.p, redo, nr, stream);
+                        launch_mm(A, symbuf.p, d_counts.p, g, mm_p, d_mm_start.p, d_mm_spec.p, d_mm_end.p, d_mm_spec_c.p, d_mm_end_c.p, redo, nr, stream, ckp,
+                                  ck_per_chunk, (float)MM_TOL);
                     });
                 // compaction segments + offsets + total
                 SD_HIP(hipMemsetAsync(d_vout.p, 0, sizeof(VerdictOut), stream));

@@ -122,7 +122,9 @@ namespace sdhip
     // counts: 2 ints per chunk = {symbols emitted inside the chunk, extra symbols computed past its end (0..2, stored right after)}
     // spec_c / end_c: compact copies of spec / endst for the host
     void launch_mm(const cf32 *x, cf32 *sym_scratch, int *counts, const ChunkGeom &g, const MmParams &p, const MmState *start0, MmState *spec, MmState *endst,
-                   MmCert *spec_c, MmCert *end_c, const int *redo, int nredo, hipStream_t st);
+                   MmCert *spec_c, MmCert *end_c, const int *redo, int nredo, hipStream_t st, MmCert *ck = nullptr, int ck_per_chunk = 0,
+                   float ck_tol = 0.0f); // ck: optional per-chunk checkpoint rows (experimental early exit of re-run lanes, see k_mm)
+    constexpr int MM_CKPT_SYMS = 64;      // symbols between checkpoints (= MM_CK_SYMS of the kernel)
     // ---- Gardner clock recovery (clock_recovery_gardner.cpp:33-124), sequential lane; x must have >= 32 samples of history in front
     struct GardnerParams
     {

@@ -1085,8 +1085,17 @@ namespace sdhip
         return out;
     }
 
+    // CKPT (experimental, SDHIP_MM_CKPT=1, not yet validated on the GPU -- DESIGN.md 6b): every MM_CK_SYMS symbols of its chunk a
+    // lane leaves a checkpoint {mu, omega, inc} of the state that is about to produce that symbol. A re-run lane (exact start
+    // state) compares itself with the checkpoint of the same symbol index and stops as soon as it is inside the boundary
+    // tolerance: from there on the speculative output, count and end state of the chunk stand under the very rule that accepts a
+    // chunk boundary. A lane that does not merge overwrites the checkpoints, so they always describe the trajectory whose
+    // symbols are in the scratch rows.
+    constexpr int MM_CK_SYMS = 64;
+    template <bool CKPT>
     __global__ __launch_bounds__(64) void k_mm(const cf32 *x, cf32 *sym, int *counts, ChunkGeom g, MmParams p, const MmState *start0, MmState *spec,
-                                               MmState *endst, MmCert *spec_c, MmCert *end_c, const int *redo, int nredo)
+                                               MmState *endst, MmCert *spec_c, MmCert *end_c, const int *redo, int nredo, MmCert *ck, int ck_per_chunk,
+                                               float ck_tol)
     {
         __shared__ cf32 rings[MM_RING * MM_RING_STRIDE];
         __shared__ __attribute__((aligned(16))) float bank[128 * 8];
@@ -1130,7 +1139,7 @@ namespace sdhip
         const long long b = chunk_begin(g, k), e = chunk_end(g, k);
         cf32 *o = sym + (size_t)k * p.cap;
         int phase = warm ? 0 : 1, cnt = 0, nx = 0, wsym = 0;
-        bool done = false;
+        bool done = false, merged = false;
         Blk8 q[MM_DEPTH];
 #pragma unroll
         for (int d = 0; d < MM_DEPTH; d++)
@@ -1162,6 +1171,22 @@ namespace sdhip
                     }
                     if (phase == 2 && (nx >= 2 || s.inc >= g.n))
                         done = true;
+                    if constexpr (CKPT)
+                    {
+                        if (!done && phase == 1 && cnt > 0 && (cnt & (MM_CK_SYMS - 1)) == 0 && cnt / MM_CK_SYMS <= ck_per_chunk)
+                        {
+                            MmCert *c = ck + (size_t)k * ck_per_chunk + (cnt / MM_CK_SYMS - 1);
+                            if (redo)
+                            {
+                                const MmCert o = *c;
+                                const double dt = (double)(s.inc - o.inc) + ((double)s.mu - (double)o.mu);
+                                if (fabs(dt) < (double)ck_tol && fabsf(s.omega - o.omega) < 1e-3f * fabsf(o.omega))
+                                    merged = done = true;
+                            }
+                            if (!merged)
+                                *c = MmCert{s.mu, s.omega, s.inc};
+                        }
+                    }
                     if (!done)
                     {
                         // warm-up gear shift: the first fast_syms symbols of a warm-up run with the timing gain raised and the
@@ -1183,16 +1208,22 @@ namespace sdhip
                 }
             }
         }
-        counts[2 * k + 1] = nx;
+        if (!merged) // a merged re-run leaves the chunk's count, look-ahead and end state as the speculative run wrote them
+            counts[2 * k + 1] = nx;
     }
     void launch_mm(const cf32 *x, cf32 *sym_scratch, int *counts, const ChunkGeom &g, const MmParams &p, const MmState *start0, MmState *spec, MmState *endst,
-                   MmCert *spec_c, MmCert *end_c, const int *redo, int nredo, hipStream_t st)
+                   MmCert *spec_c, MmCert *end_c, const int *redo, int nredo, hipStream_t st, MmCert *ck, int ck_per_chunk, float ck_tol)
     {
         const int n = redo ? nredo : g.K;
         if (n <= 0)
             return;
         ProfScope _ps("k_mm", st);
-        hipLaunchKernelGGL(k_mm, dim3((n + 63) / 64), dim3(64), 0, st, x, sym_scratch, counts, g, p, start0, spec, endst, spec_c, end_c, redo, nredo);
+        if (ck)
+            hipLaunchKernelGGL(k_mm<true>, dim3((n + 63) / 64), dim3(64), 0, st, x, sym_scratch, counts, g, p, start0, spec, endst, spec_c, end_c, redo, nredo, ck,
+                               ck_per_chunk, ck_tol);
+        else
+            hipLaunchKernelGGL(k_mm<false>, dim3((n + 63) / 64), dim3(64), 0, st, x, sym_scratch, counts, g, p, start0, spec, endst, spec_c, end_c, redo, nredo,
+                               (MmCert *)nullptr, 0, 0.0f);
     }
 
     // =============================================================================================
