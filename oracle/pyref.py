@@ -214,6 +214,27 @@ class Ref(_Lib):
             res["vit_bits"] = vb[:nvb.value]
         return res
 
+    def concat_decode_punc(self, cfg: FecCfg, rate: int, soft: np.ndarray, taps: bool = False):
+        """ccsds_conv_concat_decoder with conv_rate != "1/2" (Viterbi_Depunc). rate: 1 = 2/3, 2 = 3/4, 3 = 5/6, 4 = 7/8."""
+        s = np.ascontiguousarray(soft, dtype=np.int8)
+        cadu_bytes = (cfg.cadu_size + 7) // 8
+        bufsz = max(cfg.cadu_size, 8192)
+        nblk = len(s) // bufsz
+        cap = len(s) // cfg.cadu_size * 2 + 8
+        out = np.zeros((cap, cadu_bytes), dtype=np.uint8)
+        vb = np.zeros(nblk * bufsz * 2 + 8, dtype=np.uint8) if taps else None
+        nvb = C.c_int64(0)
+        ber = np.zeros(nblk, dtype=np.float32)
+        st = np.zeros(nblk, dtype=np.int32)
+        ferr = np.full((cap, max(cfg.rs_i, 1)), 0, dtype=np.int32)
+        ndef = C.c_int64(0)
+        n = self.lib.sdref_concat_decode_punc(C.byref(cfg), C.c_int(rate), _p(s), C.c_int64(len(s)), _p(out), C.c_int64(cap), _p(vb), C.byref(nvb),
+                                              _p(ber), _p(st), _p(ferr), C.byref(ndef))
+        res = {"cadu": out[:n], "ber": ber, "state": st, "frm_err": ferr[:ndef.value], "n_deframed": ndef.value}
+        if taps:
+            res["vit_bits"] = vb[:nvb.value]
+        return res
+
     def simple_decode(self, cfg: FecCfg, soft: np.ndarray):
         """ccsds_simple_psk_decoder: int8 soft -> CADUs (+ RS error counts of every deframed frame)."""
         s = np.ascontiguousarray(soft, dtype=np.int8)

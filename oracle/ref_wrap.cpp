@@ -32,6 +32,7 @@ std::shared_ptr<slog::Logger> logger = std::make_shared<slog::Logger>();
 #include "common/codings/viterbi/cc_encoder.h"
 #include "common/codings/viterbi/viterbi_1_2.h"
 #include "common/codings/viterbi/viterbi_3_4.h"
+#include "common/codings/viterbi/viterbi_punc.h"
 #include "common/codings/rotation.h"
 #include "common/codings/randomization.h"
 #include "common/codings/differential/nrzm.h"
@@ -159,6 +160,108 @@ extern "C"
             d_phases = {PHASE_0, PHASE_90};
 
         viterbi::Viterbi1_2 *vit = zero_new<viterbi::Viterbi1_2>(c->viterbi_ber_thresold, c->viterbi_outsync_after, d_buffer_size, d_phases, d_oqpsk_mode);
+        deframing::BPSK_CCSDS_Deframer deframer(d_cadu_size, c->asm_sync);
+        if (d_cadu_size % 8 != 0)
+            deframer.CADU_PADDING = d_cadu_size % 8;
+        reedsolomon::ReedSolomon *rs = nullptr;
+        if (c->rs_i != 0)
+            rs = zero_new<reedsolomon::ReedSolomon>(c->rs_type == SDHIP_RS239 ? reedsolomon::RS239 : reedsolomon::RS223, c->rs_fill_bytes);
+
+        std::vector<uint8_t> viterbi_out((size_t)d_buffer_size * 8, 0);
+        std::vector<int8_t> soft_buffer(d_buffer_size);
+        std::vector<uint8_t> frame_buffer((size_t)d_buffer_size * 8, 0);
+        int errors[16] = {0};
+        diff::NRZMDiff diff;
+
+        int64_t nout = 0, nvb = 0, ndef = 0;
+        const int64_t nblocks = n / d_buffer_size;
+        for (int64_t b = 0; b < nblocks; b++)
+        {
+            memcpy(soft_buffer.data(), soft + b * d_buffer_size, d_buffer_size);
+            if (d_bpsk_90 || c->iq_invert)
+                rotate_soft(soft_buffer.data(), d_buffer_size, PHASE_0, true);
+            int vitout = vit->work(soft_buffer.data(), d_buffer_size, viterbi_out.data());
+            if (blk_ber)
+                blk_ber[b] = vit->ber();
+            if (blk_state)
+                blk_state[b] = vit->getState();
+            if (c->nrzm)
+                diff.decode_bits(viterbi_out.data(), vitout);
+            if (vit_bits)
+                memcpy(vit_bits + nvb, viterbi_out.data(), vitout);
+            nvb += vitout;
+            int frames = deframer.work(viterbi_out.data(), vitout, frame_buffer.data());
+            for (int i = 0; i < frames; i++)
+            {
+                uint8_t *cadu = &frame_buffer[(size_t)i * d_cadu_bytes];
+                if (c->derandomize && !c->derand_after_rs)
+                    derand_ccsds(&cadu[c->derand_start], d_cadu_bytes - c->derand_start);
+                if (c->rs_i != 0)
+                    rs->decode_interlaved(&cadu[4], c->rs_dualbasis, c->rs_i, errors);
+                bool valid = true;
+                for (int k = 0; k < c->rs_i; k++)
+                    if (errors[k] == -1)
+                        valid = false;
+                if (frm_err)
+                    for (int k = 0; k < c->rs_i; k++)
+                        frm_err[ndef * c->rs_i + k] = errors[k];
+                ndef++;
+                if (c->derandomize && c->derand_after_rs)
+                    derand_ccsds(&cadu[c->derand_start], d_cadu_bytes - c->derand_start);
+                if (!c->rs_usecheck || valid)
+                {
+                    if (nout < cadu_cap_frames)
+                        memcpy(cadu_out + nout * d_cadu_bytes, cadu, d_cadu_bytes);
+                    nout++;
+                }
+            }
+        }
+        if (vit_nbits)
+            *vit_nbits = nvb;
+        if (n_deframed)
+            *n_deframed = ndef;
+        zero_delete(vit);
+        if (rs)
+            zero_delete(rs);
+        return nout;
+    }
+
+    // CCSDSConvConcatDecoderModule::process() with conv_rate != "1/2" (module_ccsds_conv_concat_decoder.cpp:107-119,140-200):
+    // the same loop around viterbi::Viterbi_Depunc. rate: 1 = 2/3, 2 = 3/4, 3 = 5/6, 4 = 7/8.
+    // The decoder's heap buffers are uninitialised in the reference (new uint8_t[]); they are pinned to zero here like the
+    // object storage itself (zero_new) -- with these rates the first decode already finds > buffer_size + 12 valid symbols in
+    // the sliding buffer, so no uninitialised byte reaches the trellis anyway.
+    int64_t sdref_concat_decode_punc(const sdhip_fec_cfg *c, int rate, const int8_t *soft, int64_t n, uint8_t *cadu_out, int64_t cadu_cap_frames,
+                                     uint8_t *vit_bits, int64_t *vit_nbits, float *blk_ber, int *blk_state, int *frm_err, int64_t *n_deframed)
+    {
+        const int d_cadu_size = c->cadu_size;
+        const int d_cadu_bytes = (int)ceil(d_cadu_size / 8.0);
+        const int d_buffer_size = std::max<int>(d_cadu_size, 8192);
+        const bool bpsk = c->constellation == SDHIP_BPSK || c->constellation == SDHIP_BPSK_90;
+        const bool d_bpsk_90 = c->constellation == SDHIP_BPSK_90;
+        const bool d_oqpsk_mode = c->constellation == SDHIP_OQPSK;
+        std::vector<phase_t> d_phases;
+        if (bpsk && !d_bpsk_90)
+            d_phases = {PHASE_0};
+        else if (bpsk && d_bpsk_90)
+            d_phases = {PHASE_90};
+        else
+            d_phases = {PHASE_0, PHASE_90};
+
+        std::shared_ptr<viterbi::puncturing::GenericDepunc> dp;
+        if (rate == 1)
+            dp = std::make_shared<viterbi::puncturing::Depunc23>();
+        else if (rate == 2)
+            dp = std::make_shared<viterbi::puncturing::Depunc34>();
+        else if (rate == 3)
+            dp = std::make_shared<viterbi::puncturing::Depunc56>();
+        else
+            dp = std::make_shared<viterbi::puncturing::Depunc78>();
+        viterbi::Viterbi_Depunc *vit = zero_new<viterbi::Viterbi_Depunc>(dp, c->viterbi_ber_thresold, c->viterbi_outsync_after, d_buffer_size, d_phases, d_oqpsk_mode);
+        memset(vit->soft_buffer, 0, (size_t)d_buffer_size * 8);
+        memset(vit->depunc_buffer, 0, (size_t)d_buffer_size * 8);
+        memset(vit->output_buffer, 0, (size_t)d_buffer_size * 8);
+        memset(vit->vit_buffer.buffer_ptr, 0, (size_t)d_buffer_size * 4);
         deframing::BPSK_CCSDS_Deframer deframer(d_cadu_size, c->asm_sync);
         if (d_cadu_size % 8 != 0)
             deframer.CADU_PADDING = d_cadu_size % 8;

@@ -14,6 +14,10 @@ void sdo_rs_decode(uint8_t *data, int nframes, int frame_stride, int dualbasis, 
 int sdo_deframer(const uint8_t *bits, int64_t nbits, int chunk, int cadu_size, uint32_t asm_sync, int state_synced, uint8_t *out, int64_t out_cap_frames);
 int64_t sdo_concat_decode(const sdhip_fec_cfg *c, const int8_t *soft, int64_t n, uint8_t *cadu_out, int64_t cadu_cap_frames,
                           uint8_t *vit_bits, int64_t *vit_nbits, float *blk_ber, int *blk_state, int *frm_err, int64_t *n_deframed);
+/* conv_rate of ccsds_conv_concat_decoder other than "1/2" (Viterbi_Depunc, SURVEY.md 8 row a13'); rate = SDO_RATE_* */
+enum { SDO_RATE_2_3 = 1, SDO_RATE_3_4 = 2, SDO_RATE_5_6 = 3, SDO_RATE_7_8 = 4 };
+int64_t sdo_concat_decode_punc(const sdhip_fec_cfg *c, int rate, const int8_t *soft, int64_t n, uint8_t *cadu_out, int64_t cadu_cap_frames,
+                               uint8_t *vit_bits, int64_t *vit_nbits, float *blk_ber, int *blk_state, int *frm_err, int64_t *n_deframed);
 int64_t sdo_simple_decode(const sdhip_fec_cfg *c, const int8_t *soft, int64_t n, uint8_t *cadu_out, int64_t cadu_cap_frames, int *frm_err, int64_t *n_deframed);
 int64_t sdo_metop_decode(float ber_thr, int outsync_after, const int8_t *soft, int64_t n, uint8_t *cadu_out, int64_t cadu_cap_frames,
                          uint8_t *vit_bits, int64_t *vit_nbits, float *blk_ber, int *blk_state, int *frm_err);

@@ -176,6 +176,23 @@ def puncture_metop(coded: np.ndarray) -> np.ndarray:
 
 
 # --------------------------------------------------------------------------- modulation
+# transmit masks over the r=1/2 coded stream (c0,c1 per bit) of the DVB-style punctured rates the reference's
+# viterbi::puncturing::Depunc23/34/56/78 undo (src-core/common/codings/viterbi/depunc.h): rate code 1 = 2/3, 2 = 3/4, 3 = 5/6, 4 = 7/8
+PUNCTURE_MASKS = {
+    1: [1, 1, 0, 1],
+    2: [1, 1, 0, 1, 1, 0],
+    3: [1, 1, 0, 1, 1, 0, 0, 1, 1, 0],
+    4: [1, 1, 0, 1, 0, 1, 0, 1, 1, 0, 0, 1, 1, 0],
+}
+
+
+def puncture(coded: np.ndarray, rate: int) -> np.ndarray:
+    """Drop the punctured positions of an r=1/2 coded bit stream (rate code as in PUNCTURE_MASKS)."""
+    m = np.asarray(PUNCTURE_MASKS[rate], dtype=bool)
+    n = len(coded) // len(m) * len(m)
+    return coded[:n].reshape(-1, len(m))[:, m].reshape(-1)
+
+
 def rrc_impulse(sps: float, alpha: float, span: int) -> np.ndarray:
     """Root-raised-cosine impulse response sampled at `sps` samples/symbol, unit energy."""
     n = int(round(span * sps))

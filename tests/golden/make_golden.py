@@ -14,6 +14,7 @@ Fixtures (np.savez_compressed):
   metop.npz       MetOpAHRPTDecoderModule loop (r=3/4 depuncture)
   demod_*.npz     PSKDemodModule chain: cs16 IQ (stored) -> int8 soft symbols + float symbols
   simple_*.npz    CCSDSSimplePSKDecoderModule loop: int8 soft -> CADUs + RS error counts (three slicer modes)
+  punct_*.npz     concatenated decoder with conv_rate 3/4 and 7/8 (Viterbi_Depunc): int8 soft -> CADUs, per-block BER/state
   gardner.npz     GardnerClockRecoveryBlock on stored cs16 samples
   taps.npz        RRC / M&M interpolator bank / rational-resampler bank
 """
@@ -128,6 +129,12 @@ def main():
         ock["constellation"] = {"bpsk": pyref.BPSK, "qpsk": pyref.QPSK}[ck["constellation"]]
         r = ref.simple_decode(pyref.fec_cfg(decoder=2, rs_usecheck=0, **ock), soft)
         out[f"simple_{name}"] = dict(soft=soft, cadu=r["cadu"], frm_err=r["frm_err"])
+
+    # ---- conv_rate != 1/2: Viterbi_Depunc behind the concatenated decoder's loop (SURVEY.md 8 row a13'), 3/4 and 7/8, with a noise gap
+    for rate, name, sig in [(2, "r34", 20.0), (4, "r78", 11.0)]:
+        soft, plain = util.punctured_case(rate, nframes=8, sigma=sig, seed=40 + rate, gap=(rate == 2))
+        r = ref.concat_decode_punc(pyref.fec_cfg(constellation=pyref.QPSK, nrzm=0, rs_usecheck=1), rate, soft)
+        out[f"punct_{name}"] = dict(soft=soft, rate=np.int32(rate), cadu=r["cadu"], ber=r["ber"], state=r["state"], frm_err=r["frm_err"])
 
     # ---- Gardner clock recovery block (clock_recovery_gardner.cpp) on a QPSK baseband
     spec, cadus, plain, syms = util.metop_case(nframes=3)

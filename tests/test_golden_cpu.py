@@ -94,3 +94,12 @@ def test_gardner_golden(port):
     x = (d["cs16"].astype(np.float32) * np.float32(1.0 / 32767.0)).view(np.complex64)
     got = port.block(7, d["params"], x)
     assert np.array_equal(got.view(np.uint32), d["syms"].view(np.uint32)) and len(got) > 10000
+
+
+@pytest.mark.parametrize("name", ["punct_r34", "punct_r78"])
+def test_punctured_decoder_golden(port, name):
+    g = load(name)
+    r = port.concat_decode_punc(pyref.fec_cfg(constellation=pyref.QPSK, nrzm=0, rs_usecheck=1), int(g["rate"]), g["soft"])
+    assert len(g["cadu"]) >= 4
+    for k in ("cadu", "ber", "state", "frm_err"):
+        assert np.array_equal(r[k], g[k]), k

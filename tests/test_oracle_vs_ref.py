@@ -177,3 +177,20 @@ def test_simple_psk_decoder_port_equals_ref(ref, port, name, sigma, usecheck):
         # the last byte of each codeword uncorrected: allow a few bytes)
         near = [min(int(np.sum(f[4:] != p[4:])) for p in plain) for f in a["cadu"]]
         assert len(near) >= 9 and sum(d <= 4 for d in near) >= len(near) - 2
+
+
+# ---- conv_rate != "1/2": Viterbi_Depunc + Depunc23/34/56/78 (SURVEY.md 8 row a13'), oracle only so far
+@pytest.mark.parametrize("rate", [1, 2, 3, 4])
+@pytest.mark.parametrize("const,sigma,nrzm,gap", [(pyref.QPSK, 20.0, 0, False), (pyref.BPSK, 32.0, 1, False), (pyref.OQPSK, 26.0, 0, True)])
+def test_punctured_concat_decoder_port_equals_ref(ref, port, rate, const, sigma, nrzm, gap):
+    sigma *= {1: 1.0, 2: 0.85, 3: 0.55, 4: 0.45}[rate]  # the weaker codes need the better channel to deliver frames at all
+    soft, plain = util.punctured_case(rate, nframes=12, sigma=sigma, seed=11 + rate, nrzm=bool(nrzm), gap=gap)
+    cfg = pyref.fec_cfg(constellation=const, nrzm=nrzm, rs_usecheck=1)
+    a = ref.concat_decode_punc(cfg, rate, soft, taps=True)
+    b = port.concat_decode_punc(cfg, rate, soft, taps=True)
+    for k in ("cadu", "ber", "state", "frm_err", "vit_bits"):
+        assert np.array_equal(a[k], b[k]), k
+    assert a["state"].max() == 1  # the stream locks ...
+    ids = [i for i in util.frame_ids(a["cadu"], plain) if i >= 0]
+    if not gap:  # ... and delivers the transmitted frames (behind a noise gap the reference keeps its stale puncture phase: BER*5 stays
+        assert len(ids) >= 10  # under the threshold on noise, so what it delivers there is whatever it delivers -- parity only)

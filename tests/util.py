@@ -112,3 +112,26 @@ def simple_case(name, sigma=15.0, nframes=12, seed=5, prefix=3000):
     soft = simple_soft(cadus, sigma=sigma, seed=seed + 1, **sk)
     junk = np.random.default_rng(seed + 2).integers(-90, 90, prefix).astype(np.int8)
     return dict(ck), np.concatenate([junk, soft]), plain
+
+
+# ---------------------------------------------------------------- conv_rate != 1/2 (Viterbi_Depunc) inputs
+def punctured_case(rate, nframes=10, sigma=20.0, seed=3, prefix=777, nrzm=False, gap=False):
+    """int8 soft stream of a punctured (rate code 1 = 2/3, 2 = 3/4, 3 = 5/6, 4 = 7/8) r=1/2 k=7 stream carrying `nframes` CADUs,
+    behind `prefix` garbage symbols; gap=True inserts 5 blocks of noise in the middle (loss of lock + re-lock at another shift).
+    Returns (soft, plain frames as the decoder should deliver them)."""
+    from satdump_amd import synth
+    cadus = synth.make_cadus(nframes, seed=seed)
+    plain = synth.make_cadus(nframes, seed=seed, derand=False)
+    bits = np.unpackbits(cadus.reshape(-1))
+    if nrzm:
+        bits = synth.nrzm_encode(bits)
+    tx = synth.puncture(synth.conv_encode(bits), rate)
+    rng = np.random.default_rng(seed + 100 * rate)
+    soft = np.clip(np.rint((tx.astype(float) * 2 - 1) * 60 + rng.standard_normal(len(tx)) * sigma), -127, 127).astype(np.int8)
+    if gap:
+        h = len(soft) // 2 + 3
+        soft = np.concatenate([soft[:h], rng.integers(-127, 128, 5 * 8192 + 1).astype(np.int8), soft[h:]])
+    soft = np.concatenate([rng.integers(-127, 128, prefix).astype(np.int8), soft])
+    pad = (-len(soft)) % 8192
+    soft = np.concatenate([soft, rng.integers(-127, 128, pad + 8192).astype(np.int8)])
+    return soft, plain
