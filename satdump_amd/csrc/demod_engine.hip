@@ -848,6 +848,7 @@ namespace sdhip
                             }
                         }
                         hipLaunchKernelGGL(k_spec_from_prev<MmCert>, dim3((nr + 255) / 256), dim3(256), 0, stream, list, nr, d_mm_spec_c.p, d_mm_end_c.p);
+                        hipLaunchKernelGGL(k_spec_from_prev<MmState>, dim3((nr + 255) / 256), dim3(256), 0, stream, list, nr, d_mm_spec.p, d_mm_end.p);
                     },
                     [&](const int *redo, int nr) {
                         launch_mm(A, symbuf.p, d_counts.p, g, mm_p, d_mm_start.p, d_mm_spec.p, d_mm_end.p, d_mm_spec_c.p, d_mm_end_c.p, redo, nr, stream, ckp,

@@ -841,7 +841,10 @@ namespace sdhip
             if (idx >= nredo)
                 return;
             k = redo[idx];
-            s = endst[k - 1]; // exact state at the chunk boundary
+            // exact state at the chunk boundary: the SNAPSHOT of endst[k-1] the engine put into spec[k] before this launch
+            // (k_spec_from_prev), not endst[k-1] itself -- the predecessor may be re-run in this very launch and overwrite it,
+            // and the certificate of this chunk is judged against the snapshot
+            s = spec[k];
         }
         else
         {
@@ -1111,7 +1114,7 @@ namespace sdhip
             if (idx >= nredo)
                 return;
             k = redo[idx];
-            s = endst[k - 1];
+            s = spec[k]; // snapshot of endst[k-1] taken before the launch (see k_chunks)
         }
         else
         {

@@ -1,0 +1,37 @@
+"""tests/emu/build.py -- TEST INFRASTRUCTURE ONLY: builds the HOST TWIN of the demodulator (tests/emu/_build/libsdhip_emu.so)
+from the unchanged HIP sources satdump_amd/csrc/demod_{kernels,engine}.hip and the stand-in runtime in this directory.
+The only textual change: the two `asm volatile("" : "+s"(z))` scheduling barriers (an AMDGPU register constraint) are dropped."""
+import os
+import re
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+CSRC = os.path.join(ROOT, "satdump_amd", "csrc")
+OUT = os.path.join(HERE, "_build")
+LIB = os.path.join(OUT, "libsdhip_emu.so")
+CLANG = "/opt/rocm/lib/llvm/bin/clang++"
+SOURCES = ["demod_kernels.hip", "demod_engine.hip"]
+
+
+def build(force: bool = False) -> str:
+    os.makedirs(OUT, exist_ok=True)
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, "emu_runtime.cpp"), os.path.join(HERE, "hip", "hip_runtime.h"),
+                                                                  os.path.join(ROOT, "include", "sdhip.h"), os.path.abspath(__file__)]
+    if not force and os.path.exists(LIB) and all(os.path.getmtime(LIB) >= os.path.getmtime(d) for d in deps):
+        return LIB
+    gen = []
+    for f in SOURCES:
+        src = open(os.path.join(CSRC, f)).read()
+        src = re.sub(r'asm volatile\("" : "\+s"\(\w+\)\);', "", src)
+        dst = os.path.join(OUT, f.replace(".hip", "_emu.cpp"))
+        open(dst, "w").write(src)
+        gen.append(dst)
+    cmd = [CLANG, "-x", "c++", "-std=c++17", "-O1", "-g", "-ffp-contract=off", "-fPIC", "-shared", "-Wno-unknown-attributes", "-Wno-unused-value",
+           "-I", HERE, "-I", CSRC, "-I", os.path.join(ROOT, "include"), "-o", LIB] + gen + [os.path.join(HERE, "emu_runtime.cpp"), "-lm"]
+    subprocess.run(cmd, check=True)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force=True))
