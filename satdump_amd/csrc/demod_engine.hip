@@ -13,16 +13,25 @@
 
 namespace sdhip
 {
-    // |x|^M frequency estimate for the very first warm-up frequency (parallel; the loops themselves are exact)
-    __global__ __launch_bounds__(256) void k_freq_est(const cf32 *x, long long n, int order, double *partial)
+    // |x|^M frequency estimate for the very first warm-up frequency (parallel; the loops themselves are exact and the boundary
+    // certificates decide what stands: this only seeds the speculation). Two autocorrelation lags of z = x^order in one pass:
+    // lag 1 is unambiguous over +-pi/order rad/sample but, on the matched filter's output, noisy and biased by the pulse shape
+    // (NPP QPSK, 2 samples/symbol, 2^18 samples: 3e-3 rad/sample of spread against a loop bandwidth of 2e-3); lag ~2 symbols is
+    // 5-10x tighter (4e-4) but ambiguous, so the host takes its branch next to the lag-1 value. partial: 4 doubles per block.
+    __global__ __launch_bounds__(256) void k_freq_est(const cf32 *x, long long n, int order, int lag, double *partial)
     {
-        __shared__ double sre[256], sim[256];
+        __shared__ double sre[256], sim[256], lre[256], lim[256];
         const long long i0 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
         const long long stride = (long long)gridDim.x * blockDim.x;
-        double are = 0, aim = 0;
-        for (long long i = i0; i + 1 < n; i += stride)
+        double are = 0, aim = 0, bre = 0, bim = 0;
+        for (long long i = i0; i + lag < n; i += stride)
         {
-            double ar = x[i].re, ai = x[i].im, br = x[i + 1].re, bi = x[i + 1].im;
+            double ar = x[i].re, ai = x[i].im, br = x[i + 1].re, bi = x[i + 1].im, cr = x[i + lag].re, ci = x[i + lag].im;
+            // z = (x/|x|)^order * min(|x|, 2): the phase raised to the order, weighted by the (clamped) magnitude. Weighting by
+            // |x|^order lets a few hundred over-sized samples (the AGC's transient after a level step) outvote a million others.
+            const double ma = sqrt(ar * ar + ai * ai), mb = sqrt(br * br + bi * bi), mc = sqrt(cr * cr + ci * ci);
+            const double ia = ma > 1e-30 ? 1.0 / ma : 0.0, ib = mb > 1e-30 ? 1.0 / mb : 0.0, ic = mc > 1e-30 ? 1.0 / mc : 0.0;
+            ar *= ia, ai *= ia, br *= ib, bi *= ib, cr *= ic, ci *= ic;
             for (int m = 1; m < order; m <<= 1)
             { // square log2(order) times: z^order
                 const double tr = ar * ar - ai * ai, ti = 2 * ar * ai;
@@ -31,12 +40,20 @@ namespace sdhip
                 const double ur = br * br - bi * bi, ui = 2 * br * bi;
                 br = ur;
                 bi = ui;
+                const double vr = cr * cr - ci * ci, vi = 2 * cr * ci;
+                cr = vr;
+                ci = vi;
             }
-            are += br * ar + bi * ai; // z[n+1] * conj(z[n])
-            aim += bi * ar - br * ai;
+            const double wa = ma < 2.0 ? ma : 2.0, wb = mb < 2.0 ? mb : 2.0, wc = mc < 2.0 ? mc : 2.0;
+            are += (br * ar + bi * ai) * (wa * wb); // z[n+1] * conj(z[n])
+            aim += (bi * ar - br * ai) * (wa * wb);
+            bre += (cr * ar + ci * ai) * (wa * wc); // z[n+lag] * conj(z[n])
+            bim += (ci * ar - cr * ai) * (wa * wc);
         }
         sre[threadIdx.x] = are;
         sim[threadIdx.x] = aim;
+        lre[threadIdx.x] = bre;
+        lim[threadIdx.x] = bim;
         __syncthreads();
         for (int s = 128; s > 0; s >>= 1)
         {
@@ -44,13 +61,17 @@ namespace sdhip
             {
                 sre[threadIdx.x] += sre[threadIdx.x + s];
                 sim[threadIdx.x] += sim[threadIdx.x + s];
+                lre[threadIdx.x] += lre[threadIdx.x + s];
+                lim[threadIdx.x] += lim[threadIdx.x + s];
             }
             __syncthreads();
         }
         if (threadIdx.x == 0)
         {
-            partial[2 * blockIdx.x] = sre[0];
-            partial[2 * blockIdx.x + 1] = sim[0];
+            partial[4 * blockIdx.x] = sre[0];
+            partial[4 * blockIdx.x + 1] = sim[0];
+            partial[4 * blockIdx.x + 2] = lre[0];
+            partial[4 * blockIdx.x + 3] = lim[0];
         }
     }
     __global__ __launch_bounds__(256) void k_mean_abs(const cf32 *x, long long n, double *partial)
@@ -685,20 +706,34 @@ namespace sdhip
             {
                 if (!started)
                 {
-                    // coarse carrier frequency for the warm-up start state: arg(sum z[n+1] conj(z[n])) / order, z = x^order
-                    const long long m = std::min<long long>(n, 1 << 18);
+                    // carrier frequency for the warm-up start state: arg(sum z[n+L] conj(z[n])) / (order L), z = x^order, L ~ two
+                    // symbols, on the branch next to the (unambiguous, coarse) lag-1 value -- see k_freq_est
+                    const long long m = std::min<long long>(n, 1 << 20);
+                    const int lag = (int)std::min(16.0, std::max(2.0, std::floor(2.0 * final_sps + 0.5)));
                     ProfScope _ps("k_freq_est", stream);
-                    hipLaunchKernelGGL(k_freq_est, dim3(64), dim3(256), 0, stream, A, m, order, d_partial.p);
-                    double part[128];
+                    hipLaunchKernelGGL(k_freq_est, dim3(64), dim3(256), 0, stream, A, m, order, lag, d_partial.p);
+                    double part[256];
                     SD_HIP(hipMemcpyAsync(part, d_partial.p, sizeof(part), hipMemcpyDeviceToHost, stream));
                     SD_HIP(hipStreamSynchronize(stream));
-                    double sr = 0, si = 0;
+                    double sr = 0, si = 0, lr = 0, li = 0;
                     for (int i = 0; i < 64; i++)
                     {
-                        sr += part[2 * i];
-                        si += part[2 * i + 1];
+                        sr += part[4 * i];
+                        si += part[4 * i + 1];
+                        lr += part[4 * i + 2];
+                        li += part[4 * i + 3];
                     }
-                    float f = (float)(std::atan2(si, sr) / order);
+                    const double coarse = std::atan2(si, sr) / order;
+                    double fine = coarse;
+                    if (m > 4 * lag && (lr != 0 || li != 0))
+                    {
+                        const double step = 2.0 * design::PI / ((double)order * lag); // spacing of the lag-L branches
+                        const double base = std::atan2(li, lr) / ((double)order * lag);
+                        fine = base + step * std::floor((coarse - base) / step + 0.5);
+                    }
+                    if (getenv("SDHIP_DEBUG"))
+                        fprintf(stderr, "[sdhip] costas start frequency: lag-1 %.6f, lag-%d %.6f rad/sample (%lld samples)\n", coarse, lag, fine, m);
+                    float f = (float)fine;
                     f = std::min(std::max(f, cos_p.fmin), cos_p.fmax);
                     cos_p.init_freq = f;
                 }

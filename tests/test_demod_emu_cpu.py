@@ -177,3 +177,38 @@ def test_auto_geometry_per_stage(twin, orc, monkeypatch):
     assert len(syms) == len(want["syms"])
     got, wantc = _cadus(orc, "metop", None, soft), _cadus(orc, "metop", None, want["soft"])
     assert got.shape == wantc.shape and np.array_equal(got, wantc)
+
+
+def _noise(rng, m, sig):
+    return ((rng.standard_normal(m) + 1j * rng.standard_normal(m)) * sig / np.sqrt(2)).astype(np.complex64)
+
+
+@pytest.mark.parametrize("scenario", ["noise_first", "amplitude_step", "noise_gap", "frequency_step"])
+def test_disturbed_streams_deliver_the_reference_frames(twin, orc, scenario):
+    """Streams that are not stationary (NPP: the narrowest carrier loop of the three configs, so the one that depends most on the
+    warm-up start values). Found with this twin and fixed: a start-frequency estimate weighted by |x|^order let the AGC transient
+    after a level step, or 100 k samples of leading noise, throw every chunk's warm-up off (0 of 48 / 58 frames).
+    Where the loops are unlocked both decoders deliver nothing, so the frame sets are compared."""
+    plain, x, ocfg, kw, ofec = _case("npp", 60)
+    n, sig = len(x), float(np.std(x))
+    rng = np.random.default_rng(4)
+    if scenario == "noise_first":
+        x = np.concatenate([_noise(rng, 100000, sig), x])
+    elif scenario == "amplitude_step":
+        x = x.copy()
+        x[n // 3: 2 * n // 3] *= 4
+    elif scenario == "noise_gap":
+        x = np.concatenate([x[: n // 2], _noise(rng, 150000, sig), x[n // 2:]])
+    else:
+        x = x.copy()
+        x[n // 2:] *= np.exp(1j * 0.002 * np.arange(n - n // 2)).astype(np.complex64)
+    want = orc.psk_demod(ocfg, x)
+    soft, syms, st = _run(twin, kw, x, chunk_len=4096)
+    got, wantc = _cadus(orc, "npp", ofec, soft), _cadus(orc, "npp", ofec, want["soft"])
+    ws, gs = {bytes(c) for c in wantc}, {bytes(c) for c in got}
+    assert len(ws) >= 40
+    # around an unlocked stretch the two re-acquire at their own pace (there is no sequential trajectory to be faithful to there)
+    slack = 3 if scenario in ("noise_first", "noise_gap") else 0
+    assert len(ws - gs) <= slack and len(gs - ws) <= slack
+    if scenario in ("amplitude_step", "frequency_step"):
+        assert st.chunks_forced == 0 and len(syms) == len(want["syms"])
