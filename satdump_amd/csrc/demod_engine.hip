@@ -18,7 +18,9 @@ namespace sdhip
     // lag 1 is unambiguous over +-pi/order rad/sample but, on the matched filter's output, noisy and biased by the pulse shape
     // (NPP QPSK, 2 samples/symbol, 2^18 samples: 3e-3 rad/sample of spread against a loop bandwidth of 2e-3); lag ~2 symbols is
     // 5-10x tighter (4e-4) but ambiguous, so the host takes its branch next to the lag-1 value. partial: 4 doubles per block.
-    __global__ __launch_bounds__(256) void k_freq_est(const cf32 *x, long long n, int order, int lag, double *partial)
+    // classic = 1: the plain x^order weighting (kept for order 8, where the 8th power is so noisy at working SNRs that neither
+    // the longer lag nor the clamp buys accuracy -- measured -- and the start value is refined from the lanes' own loops instead).
+    __global__ __launch_bounds__(256) void k_freq_est(const cf32 *x, long long n, int order, int lag, int classic, double *partial)
     {
         __shared__ double sre[256], sim[256], lre[256], lim[256];
         const long long i0 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -31,7 +33,8 @@ namespace sdhip
             // |x|^order lets a few hundred over-sized samples (the AGC's transient after a level step) outvote a million others.
             const double ma = sqrt(ar * ar + ai * ai), mb = sqrt(br * br + bi * bi), mc = sqrt(cr * cr + ci * ci);
             const double ia = ma > 1e-30 ? 1.0 / ma : 0.0, ib = mb > 1e-30 ? 1.0 / mb : 0.0, ic = mc > 1e-30 ? 1.0 / mc : 0.0;
-            ar *= ia, ai *= ia, br *= ib, bi *= ib, cr *= ic, ci *= ic;
+            if (!classic)
+                ar *= ia, ai *= ia, br *= ib, bi *= ib, cr *= ic, ci *= ic;
             for (int m = 1; m < order; m <<= 1)
             { // square log2(order) times: z^order
                 const double tr = ar * ar - ai * ai, ti = 2 * ar * ai;
@@ -44,7 +47,7 @@ namespace sdhip
                 cr = vr;
                 ci = vi;
             }
-            const double wa = ma < 2.0 ? ma : 2.0, wb = mb < 2.0 ? mb : 2.0, wc = mc < 2.0 ? mc : 2.0;
+            const double wa = classic ? 1.0 : (ma < 2.0 ? ma : 2.0), wb = classic ? 1.0 : (mb < 2.0 ? mb : 2.0), wc = classic ? 1.0 : (mc < 2.0 ? mc : 2.0);
             are += (br * ar + bi * ai) * (wa * wb); // z[n+1] * conj(z[n])
             aim += (bi * ar - br * ai) * (wa * wb);
             bre += (cr * ar + ci * ai) * (wa * wc); // z[n+lag] * conj(z[n])
@@ -532,6 +535,15 @@ namespace sdhip
         template <class Verdict, class SpecFix, class Launch>
         VerdictOut verify_fix(const char *stage, int K, Verdict verdict, SpecFix specfix, Launch relaunch)
         {
+            return verify_fix(stage, K, verdict, specfix, relaunch, [](int) { return false; });
+        }
+        // respec(nfail): called once, when the FIRST judgement of the stage fails for more than an eighth of the chunks -- the
+        // speculation's start values were off, not a few boundaries. It may re-launch the whole stage with better ones (true = it
+        // did: judge again from scratch).
+        template <class Verdict, class SpecFix, class Launch, class Respec>
+        VerdictOut verify_fix(const char *stage, int K, Verdict verdict, SpecFix specfix, Launch relaunch, Respec respec)
+        {
+            bool respecced = false;
             d_vout.reserve(1);
             h_vout.reserve(1);
             d_fails.reserve((size_t)K + 1);
@@ -551,6 +563,16 @@ namespace sdhip
                 const int nf = h_vout.p->nfail;
                 if (nf == 0)
                     break;
+                if (rounds == 0 && !respecced && nf > std::max(4, K / 8))
+                {
+                    respecced = true;
+                    if (respec(nf))
+                    {
+                        if (getenv("SDHIP_DEBUG"))
+                            fprintf(stderr, "[sdhip] %-6s %d of %d boundaries failed at first sight: stage re-launched with refined start values\n", stage, nf, K);
+                        continue;
+                    }
+                }
                 ++rounds;
                 reruns += (unsigned)nf;
                 specfix(d_fails.p, nf);
@@ -708,10 +730,11 @@ namespace sdhip
                 {
                     // carrier frequency for the warm-up start state: arg(sum z[n+L] conj(z[n])) / (order L), z = x^order, L ~ two
                     // symbols, on the branch next to the (unambiguous, coarse) lag-1 value -- see k_freq_est
-                    const long long m = std::min<long long>(n, 1 << 20);
+                    const int classic = order > 4 ? 1 : 0;
+                    const long long m = std::min<long long>(n, classic ? 1 << 18 : 1 << 20);
                     const int lag = (int)std::min(16.0, std::max(2.0, std::floor(2.0 * final_sps + 0.5)));
                     ProfScope _ps("k_freq_est", stream);
-                    hipLaunchKernelGGL(k_freq_est, dim3(64), dim3(256), 0, stream, A, m, order, lag, d_partial.p);
+                    hipLaunchKernelGGL(k_freq_est, dim3(64), dim3(256), 0, stream, A, m, order, lag, classic, d_partial.p);
                     double part[256];
                     SD_HIP(hipMemcpyAsync(part, d_partial.p, sizeof(part), hipMemcpyDeviceToHost, stream));
                     SD_HIP(hipStreamSynchronize(stream));
@@ -725,7 +748,7 @@ namespace sdhip
                     }
                     const double coarse = std::atan2(si, sr) / order;
                     double fine = coarse;
-                    if (m > 4 * lag && (lr != 0 || li != 0))
+                    if (!classic && m > 4 * lag && (lr != 0 || li != 0))
                     {
                         const double step = 2.0 * design::PI / ((double)order * lag); // spacing of the lag-L branches
                         const double base = std::atan2(li, lr) / ((double)order * lag);
@@ -775,7 +798,25 @@ namespace sdhip
                     [&](const int *list, int nr) {
                         hipLaunchKernelGGL(k_spec_from_prev<CostasState>, dim3((nr + 255) / 256), dim3(256), 0, stream, list, nr, d_cos_spec.p, d_cos_end.p);
                     },
-                    [&](const int *redo, int nr) { launch_costas(A, B, cg, cos_p, d_cos_start.p, d_cos_spec.p, d_cos_end.p, redo, nr, stream); });
+                    [&](const int *redo, int nr) { launch_costas(A, B, cg, cos_p, d_cos_start.p, d_cos_spec.p, d_cos_end.p, redo, nr, stream); },
+                    [&](int) {
+                        // Many warm-ups missed: the start frequency was off (the M-th-power estimate is weak for order 8 and at low
+                        // SNR; a call may also begin in noise with the carried loop state meaningless). Every lane has meanwhile run a
+                        // real loop over W + L samples: the median of their end frequencies is a far better start value. One extra pass.
+                        std::vector<CostasState> es((size_t)cg.K);
+                        SD_HIP(hipMemcpyAsync(es.data(), d_cos_end.p, es.size() * sizeof(CostasState), hipMemcpyDeviceToHost, stream));
+                        SD_HIP(hipStreamSynchronize(stream));
+                        std::vector<float> fr(es.size());
+                        for (size_t i = 0; i < es.size(); i++)
+                            fr[i] = es[i].freq;
+                        std::nth_element(fr.begin(), fr.begin() + fr.size() / 2, fr.end());
+                        const float med = fr[fr.size() / 2];
+                        if (!(std::fabs(med - cos_p.init_freq) > 0.05f * cfg.pll_bw))
+                            return false;
+                        cos_p.init_freq = med;
+                        launch_costas(A, B, cg, cos_p, d_cos_start.p, d_cos_spec.p, d_cos_end.p, nullptr, 0, stream);
+                        return true;
+                    });
                 // rot[k] = frame of chunk k relative to the stream's (prefix sum of the per-boundary turns)
                 {
                     const int nt = (cg.K + 1023) / 1024;

@@ -7,8 +7,9 @@ import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
-CSRC = os.path.join(ROOT, "satdump_amd", "csrc")
-OUT = os.path.join(HERE, "_build")
+# EMU_CSRC / EMU_TAG: build a twin of ANOTHER copy of the sources (e.g. an older commit, for A/B on the CPU) next to the default one
+CSRC = os.environ.get("EMU_CSRC") or os.path.join(ROOT, "satdump_amd", "csrc")
+OUT = os.path.join(HERE, "_build" + os.environ.get("EMU_TAG", ""))
 LIB = os.path.join(OUT, "libsdhip_emu.so")
 CLANG = "/opt/rocm/lib/llvm/bin/clang++"
 SOURCES = ["demod_kernels.hip", "demod_engine.hip"]
