@@ -627,6 +627,7 @@ namespace sdhip
                 launch_dcblock_seq(A, B, n, d_dc.p, stream);
                 SD_HIP(hipMemcpyAsync(&dc_s, d_dc.p, sizeof(dc_s), hipMemcpyDeviceToHost, stream));
                 std::swap(A, B);
+                SRC = A; // the resampler reads the DC-blocked samples (found by the fuzz on the host twin: it read the stage's input)
             }
             // ---- rational resampler
             if (resample)

@@ -212,3 +212,33 @@ def test_disturbed_streams_deliver_the_reference_frames(twin, orc, scenario):
     assert len(ws - gs) <= slack and len(gs - ws) <= slack
     if scenario in ("amplitude_step", "frequency_step"):
         assert st.chunks_forced == 0 and len(syms) == len(want["syms"])
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_random_configurations_exact_mode(twin, orc, seed):
+    """Differential fuzz: random sample/symbol rates (with and without the rational resampler), tap counts, loop gains, dc_block,
+    iq_swap and call boundaries -- exact mode must reproduce the reference chain bit for bit. (How dc_block + resampler reading
+    the wrong buffer was found.)"""
+    rng = np.random.default_rng(1000 + seed)
+    const = str(rng.choice(["bpsk", "qpsk", "qpsk", "oqpsk", "8psk"]))
+    symrate = float(rng.choice([927000, 2333333, 665400, 3.5e6]))
+    fs = round(symrate * float(rng.uniform(1.3, 7.0)) / 1000) * 1000.0
+    kw = dict(samplerate=fs, symbolrate=symrate, rrc_alpha=float(rng.choice([0.35, 0.5, 0.6])), rrc_taps=int(rng.choice([31, 51, 21])),
+              pll_bw=float(rng.choice([0.002, 0.006, 0.02])), agc_rate=float(rng.choice([1e-2, 1e-3])), dc_block=int(seed % 3 == 0), iq_swap=int(seed % 4 == 1))
+    n = int(rng.integers(20000, 60000))
+    x = ((rng.standard_normal(n) + 1j * rng.standard_normal(n)) * 0.3).astype(np.complex64)
+    cn = {"bpsk": pyref.BPSK, "qpsk": pyref.QPSK, "oqpsk": pyref.OQPSK, "8psk": pyref.PSK8}[const]
+    try:
+        want = orc.psk_demod(pyref.demod_cfg(constellation=cn, **kw), x)
+    except Exception:
+        pytest.skip("ratio needs the power-of-two pre-decimator (not built, DESIGN.md 7)")
+    cuts = sorted(set([0, n] + rng.integers(0, n, 3).tolist()))
+    try:
+        soft, syms, st = _run(twin, dict(constellation=const, **kw), x, chunks=cuts, exact=1)
+    except Exception as e:
+        if "longer than the history" in str(e):
+            pytest.skip("resampler bank longer than the 64-sample history window (engine refuses, plugin keeps the CPU module)")
+        raise
+    assert st.buffer_size == want["buffer_size"]
+    assert np.array_equal(syms.view(np.uint32), want["syms"].view(np.uint32))
+    assert np.array_equal(soft, want["soft"])
