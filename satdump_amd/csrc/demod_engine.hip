@@ -115,6 +115,27 @@ namespace sdhip
         if (i < n)
             spec[list[i]] = endst[list[i] - 1];
     }
+    // CKPT mode: a Costas re-run starts from the predecessor's end state expressed in the frame the chunk's earlier run locked on
+    // (phase + d * rot_unit), so that the re-run can merge with that run's checkpoints; the verdict then books the boundary as a
+    // frame change of d like any accepted rotated boundary.
+    __global__ void k_costas_spec_aligned(const int *list, int n, CostasState *spec, const CostasState *endst, double rot_unit)
+    {
+        const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+        if (i >= n)
+            return;
+        const int k = list[i];
+        const CostasState a = spec[k], b = endst[k - 1];
+        const long long d = llround(((double)a.phase - (double)b.phase) / rot_unit);
+        CostasState ns = b;
+        double ph = (double)b.phase + (double)d * rot_unit;
+        const double twopi = 2 * 3.14159265358979323846;
+        while (ph > twopi)
+            ph -= twopi;
+        while (ph < -twopi)
+            ph += twopi;
+        ns.phase = (float)ph;
+        spec[k] = ns;
+    }
     // force: the round limit is reached (unlocked signal: every trajectory is noise-driven, there is no sequential one to be
     // faithful to): the boundary is let through as it is and counted
     __device__ __forceinline__ void verdict_fail(VerdictOut *vo, int *fails, int k, int force)
@@ -320,6 +341,17 @@ namespace sdhip
         DevBuf<MmState> d_mm_spec, d_mm_end, d_mm_start;
         DevBuf<MmCert> d_mm_spec_c, d_mm_end_c; // what the host certificate reads (16 B per chunk instead of the 72-byte state)
         DevBuf<MmCert> d_mm_ck;                 // experimental: per-chunk checkpoints for the early exit of re-run lanes (SDHIP_MM_CKPT)
+        DevBuf<AgcState> d_agc_ck;              // ... of the AGC and Costas lanes (SDHIP_CKPT)
+        DevBuf<CostasState> d_cos_ck;
+        const bool use_ckpt = env_int("SDHIP_CKPT", 0) != 0;
+        DevBuf<unsigned long long> d_ck_work;   // {lanes, pieces run, pieces of full chunks} x {agc, costas}, SDHIP_DEBUG only
+        void ck_report(const char *stage, int slot)
+        {
+            unsigned long long w[3];
+            SD_HIP(hipMemcpy(w, d_ck_work.p + 3 * slot, sizeof(w), hipMemcpyDeviceToHost));
+            if (w[0])
+                fprintf(stderr, "[sdhip] %-6s early exit: %llu re-run lanes ran %llu of %llu pieces (%.0f %%)\n", stage, w[0], w[1], w[2], 100.0 * (double)w[1] / (double)w[2]);
+        }
         DevBuf<DcState> d_dc;
         DevBuf<int> d_redo, d_rot, d_dm, d_counts, d_seg, d_skip, d_extra;
         DevBuf<long long> d_offsets, d_tile_sums;
@@ -701,7 +733,22 @@ namespace sdhip
                 d_agc_spec.reserve(g.K);
                 d_agc_end.reserve(g.K);
                 SD_HIP(hipMemcpyAsync(d_agc_start.p, &agc_s, sizeof(agc_s), hipMemcpyHostToDevice, stream));
-                launch_agc(AIN, B, g, agc_p, d_agc_start.p, d_agc_spec.p, d_agc_end.p, nullptr, 0, stream);
+                ChunkCkpt agc_ck;
+                if (use_ckpt)
+                {
+                    agc_ck.len = 512;
+                    agc_ck.per_chunk = L / agc_ck.len + 1;
+                    d_agc_ck.reserve((size_t)g.K * agc_ck.per_chunk);
+                    agc_ck.ck = d_agc_ck.p;
+                    agc_ck.tol_a = 1e-6f;
+                    if (getenv("SDHIP_DEBUG"))
+                    {
+                        d_ck_work.reserve(6);
+                        SD_HIP(hipMemsetAsync(d_ck_work.p, 0, 6 * sizeof(unsigned long long), stream));
+                        agc_ck.work = d_ck_work.p;
+                    }
+                }
+                launch_agc(AIN, B, g, agc_p, d_agc_start.p, d_agc_spec.p, d_agc_end.p, nullptr, 0, stream, agc_ck);
                 const int vb = (g.K + 255) / 256;
                 verify_fix(
                     "agc", g.K,
@@ -711,7 +758,9 @@ namespace sdhip
                     [&](const int *list, int nr) {
                         hipLaunchKernelGGL(k_spec_from_prev<AgcState>, dim3((nr + 255) / 256), dim3(256), 0, stream, list, nr, d_agc_spec.p, d_agc_end.p);
                     },
-                    [&](const int *redo, int nr) { launch_agc(AIN, B, g, agc_p, d_agc_start.p, d_agc_spec.p, d_agc_end.p, redo, nr, stream); });
+                    [&](const int *redo, int nr) { launch_agc(AIN, B, g, agc_p, d_agc_start.p, d_agc_spec.p, d_agc_end.p, redo, nr, stream, agc_ck); });
+                if (agc_ck.work)
+                    ck_report("agc", 0);
                 SD_HIP(hipMemcpyAsync(&agc_s, d_agc_end.p + (g.K - 1), sizeof(agc_s), hipMemcpyDeviceToHost, stream));
                 SD_HIP(hipStreamSynchronize(stream));
                 std::swap(A, B);
@@ -775,7 +824,22 @@ namespace sdhip
                 d_cos_spec.reserve(cg.K);
                 d_cos_end.reserve(cg.K);
                 SD_HIP(hipMemcpyAsync(d_cos_start.p, &cos_s, sizeof(cos_s), hipMemcpyHostToDevice, stream));
-                launch_costas(A, B, cg, cos_p, d_cos_start.p, d_cos_spec.p, d_cos_end.p, nullptr, 0, stream);
+                const bool long_chunks = L >= 8192; // acceptance windows: see below
+                const double tol_phase = env_int("SDHIP_COSTAS_TOL_URAD", long_chunks ? 50000 : 500) * 1e-6,
+                             tol_freq = env_int("SDHIP_COSTAS_TOL_NFREQ", long_chunks ? 100000 : 3000) * 1e-9;
+                ChunkCkpt cos_ck;
+                if (use_ckpt)
+                {
+                    cos_ck.len = 512;
+                    cos_ck.per_chunk = L / cos_ck.len + 1;
+                    d_cos_ck.reserve((size_t)cg.K * cos_ck.per_chunk);
+                    cos_ck.ck = d_cos_ck.p;
+                    cos_ck.tol_a = (float)tol_phase;
+                    cos_ck.tol_b = (float)tol_freq;
+                    if (getenv("SDHIP_DEBUG"))
+                        cos_ck.work = d_ck_work.p + 3;
+                }
+                launch_costas(A, B, cg, cos_p, d_cos_start.p, d_cos_spec.p, d_cos_end.p, nullptr, 0, stream, cos_ck);
                 d_rot.reserve(cg.K);
                 d_dm.reserve(cg.K);
                 // Acceptance window of a Costas boundary. Two trajectories of this loop on the same samples contract onto each other
@@ -786,9 +850,6 @@ namespace sdhip
                 // Long chunks (large batches, L >= 8192): one lane re-running a whole chunk costs as much as the stage itself, while the
                 // few boundaries per 10^5 that miss the tight window are real but small transients (<= a few 1e-2 rad: inside the
                 // loop's own phase jitter at these SNRs) that have decayed after ~2 % of the chunk; they are accepted as well.
-                const bool long_chunks = L >= 8192;
-                const double tol_phase = env_int("SDHIP_COSTAS_TOL_URAD", long_chunks ? 50000 : 500) * 1e-6,
-                             tol_freq = env_int("SDHIP_COSTAS_TOL_NFREQ", long_chunks ? 100000 : 3000) * 1e-9;
                 const int vb = (cg.K + 255) / 256;
                 verify_fix(
                     "costas", cg.K,
@@ -797,9 +858,12 @@ namespace sdhip
                                            d_dm.p, vo, fails, force);
                     },
                     [&](const int *list, int nr) {
-                        hipLaunchKernelGGL(k_spec_from_prev<CostasState>, dim3((nr + 255) / 256), dim3(256), 0, stream, list, nr, d_cos_spec.p, d_cos_end.p);
+                        if (use_ckpt)
+                            hipLaunchKernelGGL(k_costas_spec_aligned, dim3((nr + 255) / 256), dim3(256), 0, stream, list, nr, d_cos_spec.p, d_cos_end.p, rot_unit);
+                        else
+                            hipLaunchKernelGGL(k_spec_from_prev<CostasState>, dim3((nr + 255) / 256), dim3(256), 0, stream, list, nr, d_cos_spec.p, d_cos_end.p);
                     },
-                    [&](const int *redo, int nr) { launch_costas(A, B, cg, cos_p, d_cos_start.p, d_cos_spec.p, d_cos_end.p, redo, nr, stream); },
+                    [&](const int *redo, int nr) { launch_costas(A, B, cg, cos_p, d_cos_start.p, d_cos_spec.p, d_cos_end.p, redo, nr, stream, cos_ck); },
                     [&](int) {
                         // Many warm-ups missed: the start frequency was off (the M-th-power estimate is weak for order 8 and at low
                         // SNR; a call may also begin in noise with the carried loop state meaningless). Every lane has meanwhile run a
@@ -815,9 +879,11 @@ namespace sdhip
                         if (!(std::fabs(med - cos_p.init_freq) > 0.05f * cfg.pll_bw))
                             return false;
                         cos_p.init_freq = med;
-                        launch_costas(A, B, cg, cos_p, d_cos_start.p, d_cos_spec.p, d_cos_end.p, nullptr, 0, stream);
+                        launch_costas(A, B, cg, cos_p, d_cos_start.p, d_cos_spec.p, d_cos_end.p, nullptr, 0, stream, cos_ck);
                         return true;
                     });
+                if (cos_ck.work)
+                    ck_report("costas", 1);
                 // rot[k] = frame of chunk k relative to the stream's (prefix sum of the per-boundary turns)
                 {
                     const int nt = (cg.K + 1023) / 1024;
@@ -884,7 +950,7 @@ namespace sdhip
                 // experimental (off): checkpoints for the early exit of re-run lanes, k_mm<true>
                 MmCert *ckp = nullptr;
                 const int ck_per_chunk = mm_p.cap / MM_CKPT_SYMS + 1;
-                if (env_int("SDHIP_MM_CKPT", 0))
+                if (use_ckpt || env_int("SDHIP_MM_CKPT", 0))
                 {
                     d_mm_ck.reserve((size_t)g.K * ck_per_chunk);
                     ckp = d_mm_ck.p;

@@ -71,8 +71,16 @@ namespace sdhip
     };
     // redo == nullptr: speculative pass over all chunks (spec/endst written). redo != nullptr: re-run chunks redo[0..nredo)
     // from endst[k-1].
+    // optional checkpoint rows of a chunk stage (experimental early exit of re-run lanes, see k_chunks): ck = K * per_chunk states
+    struct ChunkCkpt
+    {
+        void *ck = nullptr;
+        int per_chunk = 0, len = 0; // checkpoints per chunk, samples between them (multiple of 8)
+        float tol_a = 0, tol_b = 0; // Stage::close() windows
+        unsigned long long *work = nullptr; // optional device counters {re-run lanes, pieces run, pieces of the full chunks}
+    };
     void launch_agc(const cf32 *x, cf32 *y, const ChunkGeom &g, const AgcParams &p, const AgcState *start0, AgcState *spec, AgcState *endst,
-                    const int *redo, int nredo, hipStream_t st);
+                    const int *redo, int nredo, hipStream_t st, const ChunkCkpt &ck = ChunkCkpt());
 
     // ---- RRC FIR (fir.cpp:74-83), fully parallel; taps reversed on the host, ntaps <= 361 ----------------
     void launch_fir(const cf32 *x, cf32 *y, long long n, const float *rtaps_dev, int ntaps, hipStream_t st);
@@ -90,7 +98,7 @@ namespace sdhip
         float phase, freq;
     };
     void launch_costas(const cf32 *x, cf32 *y, const ChunkGeom &g, const CostasParams &p, const CostasState *start0, CostasState *spec, CostasState *endst,
-                       const int *redo, int nredo, hipStream_t st);
+                       const int *redo, int nredo, hipStream_t st, const ChunkCkpt &ck = ChunkCkpt());
 
     // ---- M&M clock recovery + quantiser ------------------------------------------------------------------
     struct MmParams

@@ -639,6 +639,8 @@ namespace sdhip
         using S = AgcState;
         static constexpr int DEPTH = 4; // blocks per load group (256 bytes); two groups in flight
         __device__ static __forceinline__ S init(const P &p) { return S{p.init_gain}; }
+        // early exit of a re-run lane (CKPT): is state a on the trajectory that left checkpoint b? (the AGC certificate's own rule)
+        __device__ static __forceinline__ bool close(const S &a, const S &b, float tol_a, float) { return fabsf(a.gain - b.gain) <= tol_a * fabsf(b.gain); }
         __device__ static __forceinline__ void prewarm(S &, const P &, const cf32 *, long long) {}
         __device__ static __forceinline__ cf32 step(S &s, const P &p, const cf32 v)
         {
@@ -659,6 +661,15 @@ namespace sdhip
         using S = CostasState;
         static constexpr int DEPTH = 2; // blocks per load group (one 128-byte line); two groups in flight
         __device__ static __forceinline__ S init(const P &p) { return S{0.0f, p.init_freq}; }
+        // early exit of a re-run lane (CKPT): same frame (the engine aligns a re-run with the speculative run's frame), phase
+        // compared modulo the loop's own 2 pi wrap, the Costas certificate's windows
+        __device__ static __forceinline__ bool close(const S &a, const S &b, float tol_phase, float tol_freq)
+        {
+            const float twopi = 6.28318530717958647692f;
+            float d = a.phase - b.phase;
+            d -= twopi * rintf(d / twopi);
+            return fabsf(d) < tol_phase && fabsf(a.freq - b.freq) < tol_freq;
+        }
         // Start phase of a warm-up from a feed-forward M-th power estimate over its first est_len samples, so that the loop
         // starts next to one of its `order` stable points instead of anywhere in between: a restart that lands near the
         // unstable point half way hangs there for many time constants (the cause of nearly all Costas re-runs at pll_bw
@@ -829,9 +840,15 @@ namespace sdhip
         }
     }
 
-    template <class Stage>
+    // CKPT (experimental, SDHIP_CKPT=1, validated on the host twin only): the chunk is run in pieces of ck_len samples and the
+    // state after every piece is left in ck[k][*]. A re-run lane compares itself with the checkpoint at the same sample index
+    // and stops as soon as Stage::close() holds: from there on the output and the end state of the earlier run stand, under the
+    // rule that accepts a chunk boundary. A lane that does not merge overwrites the checkpoints (they always describe the
+    // trajectory whose samples are in y).
+    template <class Stage, bool CKPT>
     __global__ __launch_bounds__(64) void k_chunks(const cf32 *x, cf32 *y, ChunkGeom g, typename Stage::P p, const typename Stage::S *start0,
-                                                   typename Stage::S *spec, typename Stage::S *endst, const int *redo, int nredo)
+                                                   typename Stage::S *spec, typename Stage::S *endst, const int *redo, int nredo, typename Stage::S *ck,
+                                                   int ck_per_chunk, int ck_len, float tol_a, float tol_b, unsigned long long *ck_work)
     {
         const int idx = (int)(blockIdx.x * blockDim.x + threadIdx.x);
         int k;
@@ -863,27 +880,70 @@ namespace sdhip
             }
         }
         const long long b = chunk_begin(g, k), e = chunk_end(g, k);
-        run_range<Stage>(s, p, x, y, b, e, true);
-        endst[k] = s;
+        if constexpr (!CKPT)
+        {
+            run_range<Stage>(s, p, x, y, b, e, true);
+            endst[k] = s;
+        }
+        else
+        {
+            bool merged = false;
+            int j = 0;
+            for (long long pos = b; pos < e;)
+            {
+                const long long nxt = pos + ck_len < e ? pos + ck_len : e;
+                run_range<Stage>(s, p, x, y, pos, nxt, true);
+                pos = nxt;
+                if (pos < e && j < ck_per_chunk)
+                {
+                    typename Stage::S *c = ck + (size_t)k * ck_per_chunk + j;
+                    if (redo && Stage::close(s, *c, tol_a, tol_b))
+                    {
+                        merged = true;
+                        break;
+                    }
+                    *c = s;
+                    j++;
+                }
+            }
+            if (!merged)
+                endst[k] = s;
+            if (redo && ck_work)
+            { // statistics of the experiment: re-run lanes, pieces they ran, pieces a full re-run would have run
+                atomicAdd(ck_work, 1ull);
+                atomicAdd(ck_work + 1, (unsigned long long)(j + 1));
+                atomicAdd(ck_work + 2, (unsigned long long)((e - b + ck_len - 1) / ck_len));
+            }
+        }
     }
 
     void launch_agc(const cf32 *x, cf32 *y, const ChunkGeom &g, const AgcParams &p, const AgcState *start0, AgcState *spec, AgcState *endst, const int *redo,
-                    int nredo, hipStream_t st)
+                    int nredo, hipStream_t st, const ChunkCkpt &ck)
     {
         const int n = redo ? nredo : g.K;
         if (n <= 0)
             return;
         ProfScope _ps("k_chunks<AgcStage>", st);
-        hipLaunchKernelGGL(k_chunks<AgcStage>, dim3((n + 63) / 64), dim3(64), 0, st, x, y, g, p, start0, spec, endst, redo, nredo);
+        if (ck.ck)
+            hipLaunchKernelGGL((k_chunks<AgcStage, true>), dim3((n + 63) / 64), dim3(64), 0, st, x, y, g, p, start0, spec, endst, redo, nredo, (AgcState *)ck.ck,
+                               ck.per_chunk, ck.len, ck.tol_a, ck.tol_b, ck.work);
+        else
+            hipLaunchKernelGGL((k_chunks<AgcStage, false>), dim3((n + 63) / 64), dim3(64), 0, st, x, y, g, p, start0, spec, endst, redo, nredo, (AgcState *)nullptr, 0,
+                               0, 0.0f, 0.0f, (unsigned long long *)nullptr);
     }
     void launch_costas(const cf32 *x, cf32 *y, const ChunkGeom &g, const CostasParams &p, const CostasState *start0, CostasState *spec, CostasState *endst,
-                       const int *redo, int nredo, hipStream_t st)
+                       const int *redo, int nredo, hipStream_t st, const ChunkCkpt &ck)
     {
         const int n = redo ? nredo : g.K;
         if (n <= 0)
             return;
         ProfScope _ps("k_chunks<CostasStage>", st);
-        hipLaunchKernelGGL(k_chunks<CostasStage>, dim3((n + 63) / 64), dim3(64), 0, st, x, y, g, p, start0, spec, endst, redo, nredo);
+        if (ck.ck)
+            hipLaunchKernelGGL((k_chunks<CostasStage, true>), dim3((n + 63) / 64), dim3(64), 0, st, x, y, g, p, start0, spec, endst, redo, nredo,
+                               (CostasState *)ck.ck, ck.per_chunk, ck.len, ck.tol_a, ck.tol_b, ck.work);
+        else
+            hipLaunchKernelGGL((k_chunks<CostasStage, false>), dim3((n + 63) / 64), dim3(64), 0, st, x, y, g, p, start0, spec, endst, redo, nredo,
+                               (CostasState *)nullptr, 0, 0, 0.0f, 0.0f, (unsigned long long *)nullptr);
     }
 
     // =============================================================================================
@@ -1168,6 +1228,13 @@ namespace sdhip
                         counts[2 * k] = cnt;
                         endst[k] = s;
                         end_c[k] = MmCert{s.mu, s.omega, s.inc};
+                        if constexpr (CKPT)
+                        { // the slot behind this run's last checkpoint may hold one of an earlier call: it must never match
+                            // (slots 0 .. (cnt-1)/64 - 1 were written: a checkpoint exists for every symbol index 64 m < cnt)
+                            const int nxt = cnt > 0 ? (cnt - 1) / MM_CK_SYMS : 0;
+                            if (nxt < ck_per_chunk)
+                                ck[(size_t)k * ck_per_chunk + nxt] = MmCert{0.0f, 0.0f, -(1ll << 60)};
+                        }
                         phase = 2;
                         if (k + 1 >= g.K)
                             done = true;
@@ -1185,6 +1252,7 @@ namespace sdhip
                                 const double dt = (double)(s.inc - o.inc) + ((double)s.mu - (double)o.mu);
                                 if (fabs(dt) < (double)ck_tol && fabsf(s.omega - o.omega) < 1e-3f * fabsf(o.omega))
                                     merged = done = true;
+
                             }
                             if (!merged)
                                 *c = MmCert{s.mu, s.omega, s.inc};
