@@ -728,7 +728,7 @@ namespace sdhip
                 const int pad = nwords * 32 - new_bits; // align the END of the carry to a word boundary: pad at the front
                 DevBuf<uint32_t> &nc = d_carry[carry_sel ^ 1];
                 nc.reserve(nwords + 2);
-                k_make_carry<<<dim3((nwords + 63) / 64), dim3(64), 0, stream>>>(bs, keep_from - pad - base_abs, nwords, nc.p);
+                hipLaunchKernelGGL(k_make_carry, dim3((nwords + 63) / 64), dim3(64), 0, stream, bs, keep_from - pad - base_abs, nwords, nc.p);
                 SD_HIP(hipMemsetAsync(nc.p + nwords, 0, 8, stream));
                 SD_HIP(hipStreamSynchronize(stream));
                 carry_sel ^= 1;
@@ -1222,7 +1222,7 @@ extern "C"
                 redo(j, io[j - 1].ret_state);
         }
         const long long nb = (long long)nblocks * frame_bits;
-        k_unpack_bits<<<dim3((unsigned)((nb + 255) / 256)), dim3(256)>>>(d_vb.p, wpb, frame_bits, nblocks, d_out);
+        hipLaunchKernelGGL(k_unpack_bits, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, nullptr, d_vb.p, wpb, frame_bits, nblocks, d_out);
         SD_HIP(hipDeviceSynchronize());
         return 0;
         SD_GUARD_END(-1)

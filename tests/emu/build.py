@@ -12,7 +12,7 @@ CSRC = os.environ.get("EMU_CSRC") or os.path.join(ROOT, "satdump_amd", "csrc")
 OUT = os.path.join(HERE, "_build" + os.environ.get("EMU_TAG", ""))
 LIB = os.path.join(OUT, "libsdhip_emu.so")
 CLANG = "/opt/rocm/lib/llvm/bin/clang++"
-SOURCES = ["demod_kernels.hip", "demod_engine.hip"]
+SOURCES = ["demod_kernels.hip", "demod_engine.hip", "fec_kernels.hip", "fec_engine.hip"]
 
 
 def build(force: bool = False) -> str:
@@ -25,10 +25,13 @@ def build(force: bool = False) -> str:
     for f in SOURCES:
         src = open(os.path.join(CSRC, f)).read()
         src = re.sub(r'asm volatile\("" : "\+s"\(\w+\)\);', "", src)
+        src = re.sub(r'__attribute__\(\(amdgpu_waves_per_eu\([^)]*\)\)\)', "", src)
+        # constants pinned into registers with v_mov / s_mov: plain assignments here
+        src = re.sub(r'asm volatile\("[sv]_mov_b32 %0, (0x[0-9a-fA-F]+)" : "=[sv]"\(([^;]+?)\)\);', r"\2 = \1;", src)
         dst = os.path.join(OUT, f.replace(".hip", "_emu.cpp"))
         open(dst, "w").write(src)
         gen.append(dst)
-    cmd = [CLANG, "-x", "c++", "-std=c++17", "-O1", "-g", "-ffp-contract=off", "-fPIC", "-shared", "-Wno-unknown-attributes", "-Wno-unused-value",
+    cmd = [CLANG, "-x", "c++", "-std=c++17", "-O1", "-g", "-ffp-contract=off", "-fPIC", "-shared", "-Wno-unknown-attributes", "-D__HIPCC__", "-DSDHIP_HOST_TWIN", "-Wno-unused-value",
            "-I", HERE, "-I", CSRC, "-I", os.path.join(ROOT, "include"), "-o", LIB] + gen + [os.path.join(HERE, "emu_runtime.cpp"), "-lm"]
     subprocess.run(cmd, check=True)
     return LIB

@@ -4,6 +4,7 @@
 #include "hip/hip_runtime.h"
 #include "common.h"
 #include "../../include/sdhip.h"
+#include <cstdio>
 #include <string>
 #include <ucontext.h>
 #include <vector>
@@ -15,6 +16,7 @@ dim3 blockDim, gridDim;
 namespace
 {
     constexpr size_t STACK = 256 * 1024;
+    constexpr int MAXW = 16; // waves per block (1024 threads)
     struct Fiber
     {
         ucontext_t ctx;
@@ -25,23 +27,94 @@ namespace
     ucontext_t sched_ctx;
     int current = -1;
     const std::function<void()> *body = nullptr;
+    // barrier state of the running block: block-wide (__syncthreads) and per wave (collectives)
+    int live_block = 0, barr_arrived = 0;
+    unsigned bgen = 0;
+    int live_wave[MAXW], w_arrived[MAXW];
+    unsigned wgen[MAXW];
+    unsigned long long xchg[MAXW][64];
+    unsigned long long spins = 0;
 
+    void yield() { swapcontext(&fibers[current].ctx, &sched_ctx); }
+    void release_if_complete(int w)
+    { // called when an arrival OR an exit may have completed a rendezvous
+        if (live_block > 0 && barr_arrived == live_block)
+        {
+            barr_arrived = 0;
+            bgen++;
+        }
+        if (w >= 0 && live_wave[w] > 0 && w_arrived[w] == live_wave[w])
+        {
+            w_arrived[w] = 0;
+            wgen[w]++;
+        }
+    }
     void fiber_main()
     {
         (*body)();
         fibers[current].done = true;
+        live_block--;
+        live_wave[current / 64]--;
+        release_if_complete(current / 64); // threads that have left do not take part in later barriers (s_barrier semantics)
         swapcontext(&fibers[current].ctx, &sched_ctx);
+    }
+    void wave_sync()
+    {
+        const int w = current / 64;
+        const unsigned g = wgen[w];
+        w_arrived[w]++;
+        release_if_complete(w);
+        while (wgen[w] == g)
+        {
+            if (++spins > 400000000ull)
+            {
+                fprintf(stderr, "host twin: wave collective never completed (divergent call?)\n");
+                abort();
+            }
+            yield();
+        }
+        spins = 0;
     }
 }
 
 void __syncthreads()
-{ // back to the scheduler; it resumes this fiber once every live fiber of the block has arrived (or finished)
-    swapcontext(&fibers[current].ctx, &sched_ctx);
+{
+    const unsigned g = bgen;
+    barr_arrived++;
+    release_if_complete(-1);
+    while (bgen == g)
+        yield();
+}
+unsigned long long emu_wave_xchg(unsigned long long v, int src_lane)
+{
+    const int w = current / 64;
+    xchg[w][current % 64] = v;
+    wave_sync();
+    const unsigned long long r = xchg[w][src_lane & 63];
+    wave_sync(); // nobody overwrites a slot before everybody has read
+    return r;
+}
+unsigned long long emu_ballot(int pred)
+{
+    const int w = current / 64;
+    xchg[w][current % 64] = pred ? 1 : 0;
+    wave_sync();
+    unsigned long long m = 0;
+    for (int l = 0; l < 64; l++)
+    {
+        const size_t t = (size_t)w * 64 + l;
+        if (t < fibers.size() && t < (size_t)(blockDim.x * blockDim.y * blockDim.z) && !fibers[t].done && xchg[w][l])
+            m |= 1ull << l;
+    }
+    wave_sync();
+    return m;
 }
 
 void emu_launch(dim3 grid, dim3 block, const std::function<void()> &thread_body)
 {
     const unsigned nt = block.x * block.y * block.z;
+    if (nt > 64 * MAXW)
+        abort();
     if (fibers.size() < nt)
         fibers.resize(nt);
     for (unsigned t = 0; t < nt; t++)
@@ -51,6 +124,7 @@ void emu_launch(dim3 grid, dim3 block, const std::function<void()> &thread_body)
             if (fibers[t].stack == (char *)MAP_FAILED)
                 abort();
         }
+    const std::function<void()> *outer = body; // (kernels do not launch kernels; kept simple)
     body = &thread_body;
     blockDim = block;
     gridDim = grid;
@@ -58,6 +132,14 @@ void emu_launch(dim3 grid, dim3 block, const std::function<void()> &thread_body)
         for (unsigned by = 0; by < grid.y; by++)
             for (unsigned bx = 0; bx < grid.x; bx++)
             {
+                live_block = (int)nt;
+                barr_arrived = 0;
+                for (int w = 0; w < MAXW; w++)
+                {
+                    const int lo = w * 64, hi = std::min<int>((w + 1) * 64, (int)nt);
+                    live_wave[w] = hi > lo ? hi - lo : 0;
+                    w_arrived[w] = 0;
+                }
                 for (unsigned t = 0; t < nt; t++)
                 {
                     Fiber &f = fibers[t];
@@ -68,9 +150,8 @@ void emu_launch(dim3 grid, dim3 block, const std::function<void()> &thread_body)
                     f.ctx.uc_link = nullptr;
                     makecontext(&f.ctx, fiber_main, 0);
                 }
-                unsigned live = nt;
-                while (live)
-                { // one pass = every live fiber runs up to its next barrier (or to its end)
+                while (live_block > 0)
+                { // round robin: every live fiber runs until it blocks in a rendezvous (it re-checks when resumed) or ends
                     for (unsigned t = 0; t < nt; t++)
                     {
                         if (fibers[t].done)
@@ -79,43 +160,11 @@ void emu_launch(dim3 grid, dim3 block, const std::function<void()> &thread_body)
                         threadIdx = emu_idx{t % block.x, (t / block.x) % block.y, t / (block.x * block.y)};
                         current = (int)t;
                         swapcontext(&sched_ctx, &fibers[t].ctx);
-                        if (fibers[t].done)
-                            live--;
                     }
                 }
             }
-    body = nullptr;
+    body = outer;
     current = -1;
 }
 
-namespace sdhip
-{
-    static std::string g_last_error;
-    void set_error(const std::string &msg) { g_last_error = msg; }
-    ProfScope::ProfScope(const char *, hipStream_t stream) : idx(-1), st(stream) {}
-    ProfScope::~ProfScope() {}
-}
-
-extern "C"
-{
-    const char *sdhip_last_error(void) { return sdhip::g_last_error.c_str(); }
-    const char *sdhip_version(void) { return "sdhip host twin (tests only)"; }
-    void sdhip_prof_enable(int) {}
-    void sdhip_prof_reset(void) {}
-    int sdhip_prof_get(int, char *, size_t, double *, long long *) { return 0; }
-    static void *no_fec(void)
-    {
-        sdhip::set_error("the host twin covers the demodulator only");
-        return nullptr;
-    }
-    void sdhip_fec_cfg_default(sdhip_fec_cfg *c) { memset(c, 0, sizeof(*c)); }
-    void *sdhip_fec_create(const sdhip_fec_cfg *) { return no_fec(); }
-    void sdhip_fec_destroy(void *) {}
-    int sdhip_fec_push(void *, const int8_t *, size_t) { return no_fec(), -1; }
-    int64_t sdhip_fec_pull(void *, uint8_t *, size_t) { return no_fec(), -1; }
-    int64_t sdhip_fec_process_dev(void *, const int8_t *, size_t, uint8_t *, size_t) { return no_fec(), -1; }
-    int sdhip_fec_get_stats(void *, sdhip_fec_stats *) { return no_fec(), -1; }
-    int64_t sdhip_fec_get_block_taps(void *, float *, int *, size_t) { return no_fec(), -1; }
-    int sdhip_op_ccdecoder(int, int, const uint8_t *, int, uint8_t *) { return no_fec(), -1; }
-    int sdhip_op_rs_decode(int, uint8_t *, int, int, int, int, int, int, int *) { return no_fec(), -1; }
-}
+// (error string, profiling scope and the C ABI's FEC half come from fec_engine.hip itself)

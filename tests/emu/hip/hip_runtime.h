@@ -131,6 +131,85 @@ inline hipError_t hipOccupancyMaxActiveBlocksPerMultiprocessor(int *occ, K, int,
     return 0;
 }
 
+// events (the library's profiling scope): no clock here
+typedef void *hipEvent_t;
+inline hipError_t hipEventCreate(hipEvent_t *e)
+{
+    *e = nullptr;
+    return 0;
+}
+inline hipError_t hipEventRecord(hipEvent_t, hipStream_t = nullptr) { return 0; }
+inline hipError_t hipEventSynchronize(hipEvent_t) { return 0; }
+inline hipError_t hipEventElapsedTime(float *ms, hipEvent_t, hipEvent_t)
+{
+    *ms = 0.0f;
+    return 0;
+}
+inline hipError_t hipEventDestroy(hipEvent_t) { return 0; }
+inline hipError_t hipGetDeviceCount(int *n)
+{
+    *n = 1;
+    return 0;
+}
+
+// ---- wave-level operations (the FEC kernels): the 64 fibers of a wave meet at every collective (emu_runtime.cpp). All live
+// lanes of the wave must call the same collectives in the same order (true for convergent code, which is what the kernels have).
+unsigned long long emu_wave_xchg(unsigned long long v, int src_lane); // value lane src_lane passed to the same call
+unsigned long long emu_ballot(int pred);
+inline int emu_lane() { return (int)((threadIdx.x + blockDim.x * (threadIdx.y + blockDim.y * threadIdx.z)) & 63u); }
+inline unsigned long long __ballot(int pred) { return emu_ballot(pred); }
+inline int __shfl_xor(int v, int mask) { return (int)(unsigned)emu_wave_xchg((unsigned)v, emu_lane() ^ mask); }
+inline int __shfl_down(int v, int d) { return (int)(unsigned)emu_wave_xchg((unsigned)v, emu_lane() + d < 64 ? emu_lane() + d : emu_lane()); }
+inline int __shfl(int v, int lane) { return (int)(unsigned)emu_wave_xchg((unsigned)v, lane & 63); }
+inline int emu_readlane(int v, int lane) { return (int)(unsigned)emu_wave_xchg((unsigned)v, lane & 63); }
+inline int emu_update_dpp(int, int src, int ctrl, int, int, bool)
+{ // the four controls common.h uses: all of them are permutations inside a row of 16 lanes
+    const int l = emu_lane();
+    int from = l;
+    if (ctrl == 0xB1)
+        from = l ^ 1; // quad_perm [1,0,3,2]
+    else if (ctrl == 0x4E)
+        from = l ^ 2; // quad_perm [2,3,0,1]
+    else if (ctrl == 0x141)
+        from = (l & ~7) | (7 - (l & 7)); // row_half_mirror
+    else if (ctrl == 0x140)
+        from = (l & ~15) | (15 - (l & 15)); // row_mirror
+    else
+        abort();
+    return (int)(unsigned)emu_wave_xchg((unsigned)src, from);
+}
+inline unsigned emu_perm(unsigned s0, unsigned s1, unsigned sel)
+{ // v_perm_b32: selector 0-3 = bytes of s1, 4-7 = bytes of s0, 12 = 0x00, >= 13 = 0xff
+    const unsigned long long c = ((unsigned long long)s0 << 32) | s1;
+    unsigned r = 0;
+    for (int i = 0; i < 4; i++)
+    {
+        const unsigned k = (sel >> (8 * i)) & 0xff;
+        const unsigned b = k < 8 ? (unsigned)((c >> (8 * k)) & 0xff) : (k == 12 ? 0u : (k >= 13 ? 0xffu : 0u));
+        r |= b << (8 * i);
+    }
+    return r;
+}
+#define __builtin_amdgcn_readlane emu_readlane
+#define __builtin_amdgcn_update_dpp emu_update_dpp
+#define __builtin_amdgcn_perm emu_perm
+#define __builtin_amdgcn_wave_barrier() ((void)0)
+#define __builtin_amdgcn_fence(...) ((void)0)
+inline void __threadfence() {}
+inline void __threadfence_block() {}
+inline int __popc(unsigned v) { return __builtin_popcount(v); }
+inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
+inline int __clz(int v) { return v ? __builtin_clz((unsigned)v) : 32; }
+inline int __ffs(int v) { return __builtin_ffs(v); }
+inline int __ffsll(long long v) { return __builtin_ffsll(v); }
+inline unsigned __brev(unsigned v)
+{
+    unsigned r = 0;
+    for (int i = 0; i < 32; i++)
+        r |= ((v >> i) & 1u) << (31 - i);
+    return r;
+}
+
 // ---- kernel launch: blocks one after the other, the threads of a block as fibers (emu_runtime.cpp)
 void emu_launch(dim3 grid, dim3 block, const std::function<void()> &thread_body);
 void __syncthreads();
