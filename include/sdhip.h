@@ -58,6 +58,14 @@ extern "C"
         SDHIP_DEC_SIMPLE_PSK = 2   /* ccsds_simple_psk_decoder: hard decisions (+NRZ-M / QPSK differential) -> deframer(s) -> derand -> RS
                                       (src-core/pipeline/modules/ccsds/module_ccsds_simple_psk_decoder.cpp:16-296) */
     };
+    enum
+    {
+        SDHIP_RATE_1_2 = 0,
+        SDHIP_RATE_2_3 = 1,
+        SDHIP_RATE_3_4 = 2,
+        SDHIP_RATE_5_6 = 3,
+        SDHIP_RATE_7_8 = 4
+    };
 
     /* ---- psk_demod ------------------------------------------------------------------- */
     typedef struct sdhip_demod_cfg
@@ -146,6 +154,9 @@ extern "C"
         int oqpsk_delay;           /* "oqpsk_delay", default 0 */
         int oqpsk_method2;         /* "oqpsk_method2", default 0 */
         int oqpsk_method3;         /* "oqpsk_method3", default 0 */
+        /* ccsds_conv_concat_decoder only: "conv_rate" (module_ccsds_conv_concat_decoder.cpp:33,93-119). 0 = "1/2" (Viterbi1_2);
+           SDHIP_RATE_2_3 .. SDHIP_RATE_7_8 = the punctured rates of viterbi::Viterbi_Depunc (viterbi_punc.cpp, depunc.h) */
+        int conv_rate;
         /* engine knobs */
         int device;
     } sdhip_fec_cfg;

@@ -364,8 +364,19 @@ namespace sdhip_plugin
             cfg.derand_after_rs = parameters.count("derand_after_rs") > 0 ? parameters["derand_after_rs"].get<bool>() : false;
             cfg.derand_start = parameters.count("derand_start") > 0 ? parameters["derand_start"].get<int>() : 4;
             const std::string conv = parameters.count("conv_rate") > 0 ? parameters["conv_rate"].get<std::string>() : "1/2";
-            if (conv != "1/2")
-                throw satdump_exception("ccsds_conv_concat_decoder_hip: conv_rate " + conv + " is not on the HIP path yet, use ccsds_conv_concat_decoder");
+            // module_ccsds_conv_concat_decoder.cpp:93-119: Viterbi1_2 for "1/2", Viterbi_Depunc + Depunc23/34/56/78 for the others
+            if (conv == "1/2")
+                cfg.conv_rate = SDHIP_RATE_1_2;
+            else if (conv == "2/3")
+                cfg.conv_rate = SDHIP_RATE_2_3;
+            else if (conv == "3/4")
+                cfg.conv_rate = SDHIP_RATE_3_4;
+            else if (conv == "5/6")
+                cfg.conv_rate = SDHIP_RATE_5_6;
+            else if (conv == "7/8")
+                cfg.conv_rate = SDHIP_RATE_7_8;
+            else
+                throw satdump_exception("ccsds_conv_concat_decoder_hip: invalid conv_rate " + conv);
             cfg.rs_i = parameters["rs_i"].get<int>();
             cfg.rs_fill_bytes = parameters.count("rs_fill_bytes") > 0 ? parameters["rs_fill_bytes"].get<int>() : -1;
             cfg.rs_dualbasis = parameters.count("rs_dualbasis") > 0 ? parameters["rs_dualbasis"].get<bool>() : true;
@@ -520,7 +531,9 @@ namespace sdhip_plugin
                 }
                 else if (e.id == "ccsds_conv_concat_decoder")
                 {
-                    // punctured rates (conv_rate != "1/2", viterbi_punc.cpp) and padded frames stay on the CPU module
+                    // punctured rates (conv_rate != "1/2", viterbi_punc.cpp) stay on the CPU module under the OVERRIDE until the HIP
+                    // path for them (sequential first cut, validated on the host twin) has been through the GPU suite; the explicit
+                    // ccsds_conv_concat_decoder_hip module takes them. Padded frames stay on the CPU module.
                     auto cpu = e.inst;
                     e.inst = [cpu](std::string in, std::string out, nlohmann::json p) -> std::shared_ptr<ProcessingModule> {
                         const std::string conv = p.count("conv_rate") > 0 ? p["conv_rate"].get<std::string>() : "1/2";

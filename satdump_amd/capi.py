@@ -15,6 +15,7 @@ LIB_PATH = os.environ.get("SDHIP_LIB") or os.path.join(_HERE, "lib", "libsdhip.s
 
 BPSK, BPSK_90, QPSK, OQPSK, PSK8 = 0, 1, 2, 3, 4
 RS_NONE, RS223, RS239 = 0, 1, 2
+RATE_1_2, RATE_2_3, RATE_3_4, RATE_5_6, RATE_7_8 = 0, 1, 2, 3, 4
 FMT_CF32, FMT_CS16, FMT_CS8, FMT_CU8, FMT_CS32 = 0, 1, 2, 3, 4
 DEC_CONV_CONCAT, DEC_METOP_AHRPT, DEC_SIMPLE_PSK = 0, 1, 2
 CONSTELLATIONS = {"bpsk": BPSK, "bpsk_90": BPSK_90, "qpsk": QPSK, "oqpsk": OQPSK, "8psk": PSK8}
@@ -46,7 +47,7 @@ class FecCfg(C.Structure):
         ("derand_after_rs", C.c_int), ("derand_start", C.c_int), ("rs_i", C.c_int), ("rs_fill_bytes", C.c_int),
         ("rs_dualbasis", C.c_int), ("rs_type", C.c_int), ("rs_usecheck", C.c_int), ("asm_sync", C.c_uint32),
         ("qpsk_swap_iq", C.c_int), ("qpsk_swap_diff", C.c_int), ("oqpsk_delay", C.c_int), ("oqpsk_method2", C.c_int), ("oqpsk_method3", C.c_int),
-        ("device", C.c_int),
+        ("conv_rate", C.c_int), ("device", C.c_int),
     ]
 
 

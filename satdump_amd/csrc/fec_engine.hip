@@ -146,6 +146,28 @@ namespace sdhip
         VitSearchState search{};          // cc_decoder_ber / cc_encoder_ber / ber_decoded_buffer
         int metop_nosync_runs = 0;
 
+        // conv_rate != 1/2: viterbi::Viterbi_Depunc (viterbi_punc.{h,cpp}) in front of the same decoder kernels. Host = the reference's
+        // state machine call by call (one 8192-symbol block per work()), device = depuncturing, the sliding symbol buffer
+        // (ViterbiSlidingBuffer), the decodes and the BER sums. Sequential first cut: coverage of the mode, not speed.
+        struct Punc
+        {
+            int rate = 0;
+            PuncPat pat{};
+            int is_first = 0, got_extra = 0, changing_shift = 0; // GenericDepunc state (the carried byte lives in d_carry)
+            int in_buffer = 0;                                   // ViterbiSlidingBuffer::in_buffer
+            int test_bit_len = 0;
+            float bers[48];                                      // d_bers[2][12][2], flat (written [s][phase][shift], read [s][o][phase])
+            float ber = 10;                                      // d_ber
+            int state = 0, iq_swap = 0, phase = 0, shift = 0, invalid = 0;
+            int ber_first = 1, ber_start = 0;                    // cc_decoder_ber chaining
+            int dec_first = 1, dec_start = 0;                    // cc_decoder chaining
+            unsigned enc_state = 0;                              // cc_encoder_ber register
+            DevBuf<uint8_t> d_berdep, d_slide, d_tmp, d_carry;
+            DevBuf<VitBlockIO> d_io;
+            DevBuf<uint64_t> d_dec;
+            DevBuf<uint32_t> d_vb_ber;
+        } punc;
+
         // deframer
         DeframerState def;
         int64_t abs_bits = 0; // absolute index of the first bit AFTER everything handed to the deframer so far
@@ -298,6 +320,15 @@ namespace sdhip
                 nber = 1024;
                 ber_mult = 2.5;
                 vc.mode = 0;
+                if (cfg.conv_rate < 0 || cfg.conv_rate > SDHIP_RATE_7_8)
+                    throw HipError("CCSDS Concatenated Decoder : invalid convolutional rate");
+                if (cfg.conv_rate != SDHIP_RATE_1_2)
+                {
+                    punc.rate = cfg.conv_rate;
+                    punc.pat = punc_pattern(cfg.conv_rate);
+                    for (float &b : punc.bers)
+                        b = 10;
+                }
                 const bool bpsk = cfg.constellation == SDHIP_BPSK || cfg.constellation == SDHIP_BPSK_90;
                 const bool bpsk90 = cfg.constellation == SDHIP_BPSK_90;
                 if (bpsk && !bpsk90)
@@ -842,10 +873,189 @@ namespace sdhip
                 stats.rs_errors[k] = last_errors[k];
         }
 
+        // ------------------------------------------------------------------ conv_rate != 1/2 (Viterbi_Depunc)
+        float punc_ber() const
+        { // Viterbi_Depunc::ber(), viterbi_punc.cpp:151-167 (reads d_bers transposed: [s][o][phase])
+            if (punc.state == 1)
+                return punc.ber;
+            float ber = 10;
+            for (int s = 0; s < n_swap; s++)
+                for (int pi = 0; pi < nphases; pi++)
+                    for (int o = 0; o < 12; o++)
+                        if (ber > punc.bers[s * 24 + o * 2 + phases[pi]])
+                            ber = punc.bers[s * 24 + o * 2 + phases[pi]];
+            return ber;
+        }
+        // one CCDecoder::work on raw unsigned symbols (cc_decoder.cpp:295-302): frame_bits bits from 2*(frame_bits+6) symbols at d_syms
+        VitBlockIO punc_decode(const uint8_t *d_syms, int frame_bits, int &first, int &start, uint32_t *d_vb_out)
+        {
+            VitCfg v{};
+            v.mode = 2;
+            v.F = frame_bits;
+            v.B = 2 * (frame_bits + 6);
+            VitBlockIO one{};
+            one.start_in = first ? -2 : start;
+            punc.d_io.reserve(1);
+            punc.d_dec.reserve((size_t)(frame_bits + 6 + 63) / 64 * 64);
+            SD_HIP(hipMemcpyAsync(punc.d_io.p, &one, sizeof(one), hipMemcpyHostToDevice, stream));
+            launch_vit_decode(v, (const int8_t *)d_syms, 0, 1, punc.d_io.p, punc.d_dec.p, d_vb_out, stream);
+            SD_HIP(hipMemcpyAsync(&one, punc.d_io.p, sizeof(one), hipMemcpyDeviceToHost, stream));
+            SD_HIP(hipStreamSynchronize(stream));
+            first = 0;
+            start = one.ret_state;
+            return one;
+        }
+        // get_ber over the first nsyms symbols at d_syms against the re-encoded first nsyms/2 bits of d_vb (encoder register enc_in)
+        VitBlockIO punc_ber_sums(const uint8_t *d_syms, int frame_bits, int nsyms, const uint32_t *d_vb, unsigned enc_in)
+        {
+            VitCfg v{};
+            v.mode = 2;
+            v.F = frame_bits;
+            v.B = 2 * (frame_bits + 6);
+            v.nber = nsyms / 2;
+            VitBlockIO one{};
+            launch_vit_ber(v, (const int8_t *)d_syms, 0, 1, d_vb, enc_in, punc.d_io.p, stream);
+            SD_HIP(hipMemcpyAsync(&one, punc.d_io.p, sizeof(one), hipMemcpyDeviceToHost, stream));
+            SD_HIP(hipStreamSynchronize(stream));
+            return one;
+        }
+        void process_blocks_punctured(const int8_t *d_soft, int64_t nblocks, uint8_t *d_out, size_t out_cap_frames, size_t &out_written)
+        {
+            const int TEST = 2048; // TEST_BITS_LENGTH, viterbi_punc.h:4
+            Punc &P = punc;
+            if (!P.d_slide.p)
+            {
+                P.d_berdep.reserve((size_t)TEST * 4 + 64);
+                P.d_slide.reserve((size_t)B * 4 + 64);
+                P.d_tmp.reserve((size_t)B * 4 + 64);
+                P.d_carry.reserve(4);
+                P.d_vb_ber.reserve(vit_words_per_block(TEST) + 4);
+                // members / heap buffers the reference leaves uninitialised are pinned to zero like in the oracle's wrapper; the
+                // depuncturer's carried byte starts as an erasure (depunc.h: buf = 128)
+                SD_HIP(hipMemsetAsync(P.d_berdep.p, 0, (size_t)TEST * 4 + 64, stream));
+                SD_HIP(hipMemsetAsync(P.d_slide.p, 0, (size_t)B * 4 + 64, stream));
+                SD_HIP(hipMemsetAsync(P.d_carry.p, 128, 4, stream));
+            }
+            tap_ber.reserve(tap_ber.size() + nblocks);
+            tap_state.reserve(tap_state.size() + nblocks);
+            VitCfg rot = vc; // rotation / swap parameters of SymFetch::u_at
+            rot.mode = 0;
+            int64_t pos = 0;
+            while (pos < nblocks)
+            {
+                // decoded 4096-bit blocks of this batch go to d_vbits like the rate 1/2 engine's, then to the same deframer
+                const int64_t batch = std::min<int64_t>(nblocks - pos, 4096);
+                d_vbits.reserve((size_t)(2 * batch + 2) * wpb + 4);
+                int nout = 0;
+                for (int64_t b = pos; b < pos + batch; b++)
+                {
+                    const int8_t *blk = d_soft + b * (int64_t)B;
+                    if (P.state == 0)
+                    { // IDLE: viterbi_punc.cpp:55-99
+                        P.ber = 10;
+                        for (int s = 0; s < n_swap; s++)
+                            for (int pi = 0; pi < nphases; pi++)
+                            {
+                                const int phase = phases[pi];
+                                rot.iq_swap = s;
+                                rot.phase = phase;
+                                for (int shift = 0; shift < P.pat.n * 2; shift++)
+                                {
+                                    int lenp = (shift > P.pat.n - 1 ? 1 : 0) + punc_count(P.pat, shift % P.pat.n, TEST);
+                                    launch_punc_static(rot, blk, P.pat, shift, TEST, P.d_berdep.p, stream);
+                                    if (lenp % 2)
+                                        lenp--;
+                                    punc_decode(P.d_berdep.p, TEST, P.ber_first, P.ber_start, P.d_vb_ber.p);
+                                    const VitBlockIO r = punc_ber_sums(P.d_berdep.p, TEST, lenp, P.d_vb_ber.p, P.enc_state);
+                                    P.enc_state = (unsigned)r.pad; // the encoder ran lenp/2 bits
+                                    P.test_bit_len = lenp;
+                                    const float errors = (float)r.ber_err, total = (float)r.ber_tot;
+                                    const float ber = (errors / total) * P.pat.berscale;
+                                    P.bers[s * 24 + phase * 2 + shift] = ber;
+                                    if (ber < cfg.viterbi_ber_thresold && ber < P.ber)
+                                    {
+                                        P.ber = ber;
+                                        P.iq_swap = s;
+                                        P.state = 1;
+                                        P.phase = phase;
+                                        P.shift = shift;
+                                        P.invalid = 0;
+                                        P.changing_shift = shift; // depunc->set_shift
+                                        P.is_first = shift > P.pat.n - 1;
+                                    }
+                                }
+                            }
+                    }
+                    if (P.state == 1)
+                    { // SYNCED: viterbi_punc.cpp:103-142
+                        rot.iq_swap = P.iq_swap;
+                        rot.phase = P.phase;
+                        const int lead = (P.is_first || P.got_extra) ? 1 : 0;
+                        P.is_first = 0;
+                        P.got_extra = 0;
+                        P.changing_shift %= P.pat.n;
+                        int sz = lead + punc_count(P.pat, P.changing_shift, B);
+                        launch_punc_cont(rot, blk, B, P.pat, P.changing_shift, lead, P.d_carry.p, P.d_slide.p + P.in_buffer, stream);
+                        P.changing_shift += B;
+                        if (sz % 2)
+                        {
+                            sz--;
+                            P.got_extra = 1;
+                        }
+                        P.in_buffer += sz; // ViterbiSlidingBuffer::add
+                        while (P.in_buffer > B)
+                        {
+                            uint32_t *vb = d_vbits.p + (size_t)nout * wpb;
+                            punc_decode(P.d_slide.p, F, P.dec_first, P.dec_start, vb);
+                            // cc_encoder_ber.work(output): TEST bits; get_ber over test_bit_len symbols, scale 5 (viterbi_punc.cpp:126-127)
+                            const VitBlockIO r = punc_ber_sums(P.d_slide.p, F, P.test_bit_len, vb, P.enc_state);
+                            const float errors = (float)r.ber_err, total = (float)r.ber_tot;
+                            P.ber = (errors / total) * 5;
+                            uint32_t w[2]; // encoder register after the TEST encoded bits: bits TEST-6 .. TEST-1 of the block
+                            SD_HIP(hipMemcpyAsync(w, vb + (TEST - 32) / 32, 4, hipMemcpyDeviceToHost, stream));
+                            SD_HIP(hipStreamSynchronize(stream));
+                            unsigned e = 0;
+                            for (int d = 0; d < 6; d++)
+                                e |= ((w[0] >> d) & 1u) << d; // bit TEST-1-d sits at position d of the word that ends at bit TEST-1
+                            P.enc_state = e;
+                            nout++;
+                            // ViterbiSlidingBuffer::del(B), viterbi_buffer.h:32-37
+                            const int rest = P.in_buffer - B;
+                            SD_HIP(hipMemcpyAsync(P.d_tmp.p, P.d_slide.p + B, (size_t)rest, hipMemcpyDeviceToDevice, stream));
+                            SD_HIP(hipMemcpyAsync(P.d_slide.p, P.d_tmp.p, (size_t)rest, hipMemcpyDeviceToDevice, stream));
+                            P.in_buffer = rest;
+                            SD_HIP(hipMemsetAsync(P.d_slide.p + P.in_buffer, 128, 100, stream));
+                        }
+                        if (P.ber > cfg.viterbi_ber_thresold)
+                        {
+                            P.invalid++;
+                            if ((float)P.invalid > (float)cfg.viterbi_outsync_after)
+                                P.state = 0;
+                        }
+                        else
+                            P.invalid = 0;
+                    }
+                    tap_ber.push_back(punc_ber());
+                    tap_state.push_back(P.state);
+                    stats.blocks++;
+                }
+                if (nout > 0)
+                    deframe_and_emit(nout, d_out, out_cap_frames, out_written);
+                pos += batch;
+            }
+            stats.viterbi_lock = P.state;
+            stats.viterbi_ber = punc_ber();
+            stats.deframer_state = def.state;
+            for (int k = 0; k < 8; k++)
+                stats.rs_errors[k] = last_errors[k];
+        }
+
         void process_blocks(const int8_t *d_soft, int64_t nblocks, uint8_t *d_out, size_t out_cap_frames, size_t &out_written)
         {
             if (cfg.decoder == SDHIP_DEC_SIMPLE_PSK)
                 return process_blocks_simple(d_soft, nblocks, d_out, out_cap_frames, out_written);
+            if (punc.rate != 0)
+                return process_blocks_punctured(d_soft, nblocks, d_out, out_cap_frames, out_written);
             int64_t pos = 0;
             tap_ber.reserve(tap_ber.size() + nblocks);
             tap_state.reserve(tap_state.size() + nblocks);

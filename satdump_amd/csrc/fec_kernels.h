@@ -88,6 +88,42 @@ namespace sdhip
     void launch_vit_search(const VitCfg &cfg, const int8_t *soft, int64_t block, int n_swap, const int *phases, int nphases, VitSearchState *d_state,
                            hipStream_t st);
 
+    // ---- generic punctured rates (depunc.h): per input position of the period, one or two depunctured symbols
+    struct PuncPat
+    {
+        int n;            // period = numstates
+        unsigned two;     // bit p: position p emits two symbols (the received one and an erasure)
+        unsigned lead128; // bit p: the erasure comes first
+        float berscale;   // get_berscale()
+    };
+    inline PuncPat punc_pattern(int rate)
+    { // Depunc23 "a b a", Depunc34 "a b a b", Depunc56 "a b a b c b", Depunc78 "a b b b a b c b" (a: in | b: in,128 | c: 128,in)
+        switch (rate)
+        {
+        case 1:
+            return PuncPat{3, 0x02u, 0u, 3.5f};
+        case 2:
+            return PuncPat{4, 0x0Au, 0u, 5.0f};
+        case 3:
+            return PuncPat{6, 0x3Au, 0x10u, 8.0f};
+        default:
+            return PuncPat{8, 0xEEu, 0x40u, 10.0f};
+        }
+    }
+    inline int punc_count(const PuncPat &p, int pos0, int n_in)
+    { // symbols n_in inputs expand to, starting at pattern position pos0
+        int oo = 0, pos = pos0;
+        for (int i = 0; i < n_in; i++)
+        {
+            oo += ((p.two >> pos) & 1u) ? 2 : 1;
+            pos = pos + 1 == p.n ? 0 : pos + 1;
+        }
+        return oo;
+    }
+    void launch_punc_static(const VitCfg &c, const int8_t *blk, const PuncPat &pat, int shift, int n_in, unsigned char *out, hipStream_t st);
+    void launch_punc_cont(const VitCfg &c, const int8_t *blk, int n_in, const PuncPat &pat, int pos0, int lead, unsigned char *carry, unsigned char *dst,
+                          hipStream_t st);
+
     inline int vit_words_per_block(int F)
     {
         int L = (F + 63) / 64;

@@ -950,6 +950,71 @@ namespace sdhip
     }
 
     // =============================================================================================
+    // Generic punctured rates (conv_rate 2/3 .. 7/8): viterbi::puncturing::Depunc23/34/56/78, depunc.h:21-430.
+    // First cut: one sequential lane per call (8192 symbols), exactly the reference's loops -- this mode is one pipeline step
+    // of 76 and is built for coverage, not speed (the decoder behind it is the batch engine's own kernel).
+    // =============================================================================================
+    __device__ __forceinline__ int punc_emit(const PuncPat &pat, int pos, unsigned u, unsigned char *out, int oo)
+    {
+        if (!((pat.two >> pos) & 1u))
+            out[oo++] = (unsigned char)u;
+        else if ((pat.lead128 >> pos) & 1u)
+        {
+            out[oo++] = 128;
+            out[oo++] = (unsigned char)u;
+        }
+        else
+        {
+            out[oo++] = (unsigned char)u;
+            out[oo++] = 128;
+        }
+        return oo;
+    }
+    // depunc_static(in, out, n_in, shift) on the rotated / converted first n_in symbols of a block (lock search)
+    __global__ void k_punc_static(VitCfg c, const int8_t *blk, PuncPat pat, int shift, int n_in, unsigned char *out)
+    {
+        if (threadIdx.x != 0 || blockIdx.x != 0)
+            return;
+        const SymFetch f{c, blk, n_in};
+        int oo = 0;
+        const int actual = shift % pat.n;
+        if (shift > pat.n - 1)
+            out[oo++] = 128;
+        for (int i = 0; i < n_in; i++)
+            oo = punc_emit(pat, (i + actual) % pat.n, f.u_at(i), out, oo);
+    }
+    // depunc_cont: appended at dst; `lead` = is_first || got_extra (the carried byte goes first), pos0 = changing_shift % n.
+    // An odd count leaves its last symbol in *carry (the host knows the count: it is a function of the pattern alone).
+    __global__ void k_punc_cont(VitCfg c, const int8_t *blk, int n_in, PuncPat pat, int pos0, int lead, unsigned char *carry, unsigned char *dst)
+    {
+        if (threadIdx.x != 0 || blockIdx.x != 0)
+            return;
+        const SymFetch f{c, blk, n_in};
+        int oo = 0;
+        if (lead)
+            dst[oo++] = *carry;
+        int pos = pos0;
+        for (int i = 0; i < n_in; i++)
+        {
+            oo = punc_emit(pat, pos, f.u_at(i), dst, oo);
+            pos = pos + 1 == pat.n ? 0 : pos + 1;
+        }
+        if (oo & 1)
+            *carry = dst[oo - 1];
+    }
+    void launch_punc_static(const VitCfg &c, const int8_t *blk, const PuncPat &pat, int shift, int n_in, unsigned char *out, hipStream_t st)
+    {
+        ProfScope _ps("k_punc_static", st);
+        hipLaunchKernelGGL(k_punc_static, dim3(1), dim3(64), 0, st, c, blk, pat, shift, n_in, out);
+    }
+    void launch_punc_cont(const VitCfg &c, const int8_t *blk, int n_in, const PuncPat &pat, int pos0, int lead, unsigned char *carry, unsigned char *dst,
+                          hipStream_t st)
+    {
+        ProfScope _ps("k_punc_cont", st);
+        hipLaunchKernelGGL(k_punc_cont, dim3(1), dim3(64), 0, st, c, blk, n_in, pat, pos0, lead, carry, dst);
+    }
+
+    // =============================================================================================
     // k_vit_search: the IDLE branch of Viterbi1_2::work / Viterbi3_4::work on one block (one wave)
     // =============================================================================================
     constexpr int SEARCH_MAX_BITS = 1536;

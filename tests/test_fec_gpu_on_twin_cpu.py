@@ -11,6 +11,7 @@ import pytest
 from oracle import pyref
 from tests import test_fec_gpu as F
 from tests import test_golden_gpu as GG
+from tests import test_zz_punctured_gpu as PG
 from tests.emu import build as emu_build
 from tests.emu import fake_torch
 
@@ -48,7 +49,7 @@ def orc():
     return pyref.best()
 
 
-for _mod, _pfx in ((F, ""), (GG, "")):
+for _mod, _pfx in ((F, ""), (GG, ""), (PG, "")):
     for _name in dir(_mod):
         if _name.startswith("test_") and _name not in globals():
             globals()[_name] = getattr(_mod, _name)

@@ -1,0 +1,55 @@
+"""conv_rate != "1/2" of ccsds_conv_concat_decoder (viterbi::Viterbi_Depunc + Depunc23/34/56/78, SURVEY.md 8 row a13') through the C ABI
+against the oracle (which is pinned to the compiled reference, tests/test_oracle_vs_ref.py). CADUs, per-block BER and lock state
+bit-identical, incl. a loss of lock with re-lock at a stale puncture phase, NRZ-M, the OQPSK IQ-swap search and ragged pushes.
+The file sorts last on purpose: this path was written after the round's GPU budget was spent and has so far been validated on the
+host twin only (tests/test_fec_gpu_on_twin_cpu.py collects these tests too)."""
+import numpy as np
+import pytest
+
+from oracle import pyref
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a GPU (no CPU fallback exists)"
+    return torch
+
+
+@pytest.fixture(scope="module")
+def capi():
+    from satdump_amd import capi as c
+    c.lib()
+    return c
+
+
+@pytest.fixture(scope="module")
+def orc():
+    return pyref.best()
+
+
+CASES = [("qpsk", pyref.QPSK, 20.0, 0, False), ("bpsk", pyref.BPSK, 32.0, 1, False), ("oqpsk", pyref.OQPSK, 26.0, 0, True)]
+
+
+@pytest.mark.parametrize("rate", [1, 2, 3, 4])
+@pytest.mark.parametrize("const,oconst,sigma,nrzm,gap", CASES)
+def test_punctured_concat_decoder(torch_cuda, capi, orc, rate, const, oconst, sigma, nrzm, gap):
+    sigma *= {1: 1.0, 2: 0.85, 3: 0.55, 4: 0.45}[rate]
+    soft, plain = util.punctured_case(rate, nframes=8, sigma=sigma, seed=11 + rate, nrzm=bool(nrzm), gap=gap)
+    want = orc.concat_decode_punc(pyref.fec_cfg(constellation=oconst, nrzm=nrzm, rs_usecheck=1), rate, soft)
+    dec = capi.FecDecoder(capi.fec_cfg(constellation=const, nrzm=nrzm, rs_i=4, rs_type=1, rs_usecheck=1, conv_rate=rate))
+    cuts = [0, len(soft) // 3 // 8192 * 8192 + 777, len(soft)]  # ragged pushes: whole blocks are decoded, the rest stays pending
+    got = []
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        dec.push(soft[a:b])
+        got.append(dec.pull())
+    got = np.concatenate(got)
+    assert got.shape == want["cadu"].shape and np.array_equal(got, want["cadu"])
+    if not gap:
+        assert len(got) >= 6 and sum(i >= 0 for i in util.frame_ids(got, plain)) >= len(got) - 1  # (the 4 ASM bytes are outside the RS code)
+    st = dec.stats()
+    assert st.viterbi_lock == int(want["state"][-1])
+    assert np.float32(st.viterbi_ber) == want["ber"][-1]
