@@ -25,6 +25,31 @@ def test_version_and_defaults():
     assert b"gfx950" in capi.lib().sdhip_version()
     c = capi.fec_cfg(constellation="qpsk", rs_i=4)
     assert c.constellation == capi.QPSK and c.asm_sync == 0x1ACFFC1D and c.rs_fill_bytes == -1 and c.derand_start == 4
+    assert c.qpsk_swap_diff == 1 and c.conv_rate == capi.RATE_1_2 and c.device == 0
+
+
+def test_struct_mirrors_match_the_header():
+    """The ctypes mirrors (satdump_amd/capi.py and oracle/pyref.py) against include/sdhip.h: same field names in the same order
+    (the structs are plain ints / floats / doubles, so order + count pins the layout)."""
+    import re
+    from satdump_amd import capi
+    from oracle import pyref
+    hdr = open(os.path.join(ROOT, "include", "sdhip.h")).read()
+
+    def fields(name):
+        body = re.search(r"typedef struct " + name + r"\s*\{(.*?)\}\s*" + name + ";", hdr, re.S).group(1)
+        body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+        out = []
+        for d in body.split(";"):
+            if d.strip():
+                names = d.strip().split(None, 1)[1] if not d.strip().startswith("unsigned") else d.strip().split(None, 2)[2]
+                out += [re.sub(r"\[.*\]", "", n.strip()) for n in names.split(",")]
+        return out
+
+    assert [f for f, _ in capi.FecCfg._fields_] == fields("sdhip_fec_cfg")
+    assert [f for f, _ in pyref.FecCfg._fields_] == fields("sdhip_fec_cfg")
+    assert [f for f, _ in capi.DemodCfg._fields_] == fields("sdhip_demod_cfg")
+    assert [f for f, _ in pyref.DemodCfg._fields_] == fields("sdhip_demod_cfg")
 
 
 def test_fails_loudly_without_gpu():
