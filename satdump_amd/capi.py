@@ -72,6 +72,8 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise SdhipError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` (hipcc, gfx950). "
                              "There is no CPU fallback.")
+        if "libsdhip_emu" in os.path.basename(LIB_PATH) and os.environ.get("SDHIP_TESTING_TWIN") != "1":
+            raise SdhipError("the host twin (tests/emu) is test infrastructure, not a backend: there is no CPU fallback")
         L = C.CDLL(LIB_PATH)
         L.sdhip_last_error.restype = C.c_char_p
         L.sdhip_version.restype = C.c_char_p

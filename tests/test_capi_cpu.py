@@ -92,3 +92,18 @@ def test_bench_reads_committed_pmc_traffic():
     # 8 + 2q/S + c/S bytes per input sample for GOES
     q, sps_in = wl["soft_per_sym"], wl["spec"]["samplerate"] / wl["spec"]["symbolrate"]
     assert abs(8 + 2 * q / sps_in + (q * wl["conv_rate"] / 8.0) / sps_in - 8.637) < 1e-3
+
+
+def test_binding_refuses_the_host_twin(monkeypatch):
+    """The host twin is for the test modules that open it explicitly; the binding does not take it as a backend."""
+    import importlib.util
+    from tests.emu import build as emu_build
+    if not os.path.exists(emu_build.CLANG):
+        pytest.skip("no host clang++")
+    monkeypatch.setenv("SDHIP_LIB", emu_build.build())
+    monkeypatch.delenv("SDHIP_TESTING_TWIN", raising=False)
+    spec = importlib.util.spec_from_file_location("capi_refuse", os.path.join(ROOT, "satdump_amd", "capi.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    with pytest.raises(m.SdhipError):
+        m.lib()

@@ -62,10 +62,12 @@ def capi():
     m = importlib.util.module_from_spec(spec)
     old = os.environ.get("SDHIP_LIB")
     os.environ["SDHIP_LIB"] = lib
+    os.environ["SDHIP_TESTING_TWIN"] = "1"  # capi refuses the twin without it
     try:
         spec.loader.exec_module(m)
         m.lib()
     finally:
+        del os.environ["SDHIP_TESTING_TWIN"]
         if old is None:
             del os.environ["SDHIP_LIB"]
         else:
