@@ -281,6 +281,30 @@ namespace sdhip_plugin
         sdhip_fec_cfg cfg;
         void *h = nullptr;
         int block_bytes = 8192, cadu_bytes = 1024;
+        // "hard_symbols" input (satdump::SoftSymbolReader, src-core/common/codings/soft_reader.h:29-57): the input holds packed hard bits,
+        // MSB first, one soft symbol of +-70 each; 1024 bytes are fetched whenever the previous 8192 bits are used up. The reference
+        // never fetches before its FIRST 8192 symbols (it reads them out of a fresh `new uint8_t[1024]`): that buffer is zeros here.
+        bool hard_symbols = false;
+        std::vector<uint8_t> hard_buf = std::vector<uint8_t>(1024, 0);
+        int hard_pos = 0;
+        void read_soft(int8_t *buf, size_t n)
+        {
+            if (!hard_symbols)
+            {
+                read_data((uint8_t *)buf, n);
+                return;
+            }
+            for (size_t i = 0; i < n; i++)
+            {
+                const uint8_t bit = (hard_buf[hard_pos / 8] >> (7 - (hard_pos % 8))) & 1;
+                buf[i] = bit ? 70 : -70;
+                if (++hard_pos == 1024 * 8)
+                {
+                    read_data(hard_buf.data(), 1024);
+                    hard_pos = 0;
+                }
+            }
+        }
         std::atomic<float> viterbi_ber{10};
         std::atomic<int> viterbi_lock{0}, deframer_state{0};
 
@@ -312,7 +336,7 @@ namespace sdhip_plugin
             while (should_run())
             {
                 const size_t want = input_data_type == DATA_FILE ? batch : (size_t)block_bytes; // streaming: stay close to real time
-                read_data((uint8_t *)soft.data(), want);
+                read_soft(soft.data(), want);
                 if (sdhip_fec_push(h, soft.data(), want) < 0)
                     throw satdump_exception(std::string(getIDM()) + ": " + sdhip_last_error());
                 for (;;)
@@ -422,8 +446,7 @@ namespace sdhip_plugin
                 cfg.constellation = SDHIP_QPSK;
             else
                 throw satdump_exception("CCSDS Simple PSK Decoder : invalid constellation type!");
-            if (parameters.count("hard_symbols") > 0 && parameters["hard_symbols"].get<bool>())
-                throw satdump_exception("ccsds_simple_psk_decoder_hip: hard_symbols input is not on the HIP path, use ccsds_simple_psk_decoder");
+            hard_symbols = parameters.count("hard_symbols") > 0 && parameters["hard_symbols"].get<bool>();
             cfg.cadu_size = parameters["cadu_size"].get<int>();
             auto flag = [&](const char *key, bool dflt) { return parameters.count(key) > 0 ? parameters[key].get<bool>() : dflt; };
             cfg.qpsk_swap_iq = flag("qpsk_swap_iq", false);
