@@ -314,20 +314,6 @@ def test_exact_mode_other_constellations(torch_cuda, capi, orc, const):
         assert abs(len(soft2) - len(want["soft"])) < 0.01 * len(soft2) and st2.chunks_forced > 0
 
 
-def test_dc_block_in_front_of_the_resampler(torch_cuda, capi, orc):
-    """dc_block=1 together with the rational resampler (samplerate / symbolrate above max_sps): the resampler must read the DC-blocked
-    samples. (It read the stage's input: found by the differential fuzz on the host twin, tests/test_demod_emu_cpu.py.)"""
-    rng = np.random.default_rng(77)
-    n = 60000
-    x = ((rng.standard_normal(n) + 1j * rng.standard_normal(n)) * 0.3 + (0.05 - 0.02j)).astype(np.complex64)
-    kw = dict(samplerate=19153000.0, symbolrate=3.5e6, rrc_alpha=0.5, rrc_taps=21, pll_bw=0.006, dc_block=1)
-    want = orc.psk_demod(pyref.demod_cfg(constellation=pyref.QPSK, **kw), x)
-    soft, syms, st = _run_demod(torch_cuda, capi, dict(constellation="qpsk", **kw), x, chunks=[0, 12345, n], exact=1)
-    assert st.final_sps == np.float32(want["final_sps"]) and want["final_sps"] < 4.0
-    assert np.array_equal(syms.view(np.uint32), want["syms"].view(np.uint32))
-    assert np.array_equal(soft, want["soft"])
-
-
 def test_noise_only_input_is_bounded(torch_cuda, capi):
     """Noise before / after a pass: no loop is locked, every boundary certificate fails. The engine must not degrade into one
     launch per chunk: after the round limit the remaining boundaries are let through and counted."""

@@ -10,6 +10,7 @@ import pytest
 
 from oracle import pyref
 from tests import test_demod_gpu as G
+from tests import test_zy_demod_additions_gpu as G2
 from tests.emu import build as emu_build
 from tests.emu import fake_torch
 
@@ -109,4 +110,4 @@ def test_noise_only_input_is_bounded(torch_cuda, capi):
 
 
 test_host_push_pull_path = G.test_host_push_pull_path
-test_dc_block_in_front_of_the_resampler = G.test_dc_block_in_front_of_the_resampler
+test_dc_block_in_front_of_the_resampler = G2.test_dc_block_in_front_of_the_resampler

@@ -1,0 +1,23 @@
+"""Demodulator GPU tests added after the last GPU visit of round 1 (validated on the host twin only so far, tests/test_demod_gpu_on_twin_cpu.py
+collects them too). The file sorts behind the long-standing GPU tests on purpose."""
+import numpy as np
+import pytest
+
+from oracle import pyref
+from tests.test_demod_gpu import _run_demod, capi, orc, torch_cuda  # noqa: F401  (fixtures)
+
+pytestmark = pytest.mark.gpu
+
+
+def test_dc_block_in_front_of_the_resampler(torch_cuda, capi, orc):
+    """dc_block=1 together with the rational resampler (samplerate / symbolrate above max_sps): the resampler must read the DC-blocked
+    samples. (It read the stage's input: found by the differential fuzz on the host twin, tests/test_demod_emu_cpu.py.)"""
+    rng = np.random.default_rng(77)
+    n = 60000
+    x = ((rng.standard_normal(n) + 1j * rng.standard_normal(n)) * 0.3 + (0.05 - 0.02j)).astype(np.complex64)
+    kw = dict(samplerate=19153000.0, symbolrate=3.5e6, rrc_alpha=0.5, rrc_taps=21, pll_bw=0.006, dc_block=1)
+    want = orc.psk_demod(pyref.demod_cfg(constellation=pyref.QPSK, **kw), x)
+    soft, syms, st = _run_demod(torch_cuda, capi, dict(constellation="qpsk", **kw), x, chunks=[0, 12345, n], exact=1)
+    assert st.final_sps == np.float32(want["final_sps"]) and want["final_sps"] < 4.0
+    assert np.array_equal(syms.view(np.uint32), want["syms"].view(np.uint32))
+    assert np.array_equal(soft, want["soft"])
