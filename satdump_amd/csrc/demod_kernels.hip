@@ -1155,7 +1155,10 @@ namespace sdhip
     // chunk boundary. A lane that does not merge overwrites the checkpoints, so they always describe the trajectory whose
     // symbols are in the scratch rows.
     constexpr int MM_CK_SYMS = 64;
-    template <bool CKPT>
+    // SPLIT (experimental, SDHIP_MM_SPLIT=1, same results bit for bit -- checked on the host twin; not yet measured): the symbol loop
+    // as three plain loops, one per phase, each bounded by a single sample-index test, instead of one loop that re-evaluates the
+    // warm-up / chunk / look-ahead bookkeeping (~45 of its ~200 instructions) on every symbol. The lane is issue-bound.
+    template <bool CKPT, bool SPLIT>
     __global__ __launch_bounds__(64) void k_mm(const cf32 *x, cf32 *sym, int *counts, ChunkGeom g, MmParams p, const MmState *start0, MmState *spec,
                                                MmState *endst, MmCert *spec_c, MmCert *end_c, const int *redo, int nredo, MmCert *ck, int ck_per_chunk,
                                                float ck_tol)
@@ -1215,6 +1218,63 @@ namespace sdhip
                 const Blk8 cur = q[d];
                 q[d] = blk_load(x, f.next + 8 * MM_DEPTH); // at most 8*MM_DEPTH + 8 samples past the lane's last window
                 mm_feed_put(f, p, cur);
+                if constexpr (SPLIT && !CKPT)
+                {
+                    while (!done && s.inc < f.next)
+                    {
+                        if (phase == 0)
+                        {
+                            if (s.inc >= b)
+                            {
+                                spec[k] = s;
+                                spec_c[k] = MmCert{s.mu, s.omega, s.inc};
+                                phase = 1;
+                                continue;
+                            }
+                            const long long lim = f.next < b ? f.next : b;
+                            do
+                            { // warm-up symbols: nothing stored (gear shift: see below)
+                                const bool fast = wsym < p.fast_syms;
+                                wsym++;
+                                (void)mm_iter(s, p, f.ring, bank, fast ? 0.0f : p.omega_gain, fast ? p.mu_gain * p.fast_mult : p.mu_gain);
+                            } while (s.inc < lim);
+                        }
+                        else if (phase == 1)
+                        {
+                            if (s.inc >= e)
+                            {
+                                counts[2 * k] = cnt;
+                                endst[k] = s;
+                                end_c[k] = MmCert{s.mu, s.omega, s.inc};
+                                phase = 2;
+                                if (k + 1 >= g.K)
+                                    done = true;
+                                continue;
+                            }
+                            const long long lim = f.next < e ? f.next : e;
+                            do
+                            {
+                                const cf32 v = mm_iter(s, p, f.ring, bank, p.omega_gain, p.mu_gain);
+                                if (cnt < p.cap)
+                                    o[cnt] = v;
+                                cnt++;
+                            } while (s.inc < lim);
+                        }
+                        else
+                        {
+                            if (nx >= 2 || s.inc >= g.n)
+                            {
+                                done = true;
+                                break;
+                            }
+                            const cf32 v = mm_iter(s, p, f.ring, bank, p.omega_gain, p.mu_gain);
+                            if (cnt + nx < p.cap)
+                                o[cnt + nx] = v;
+                            nx++;
+                        }
+                    }
+                    continue;
+                }
                 while (!done && s.inc < f.next)
                 {
                     if (phase == 0 && s.inc >= b)
@@ -1289,12 +1349,17 @@ namespace sdhip
         if (n <= 0)
             return;
         ProfScope _ps("k_mm", st);
+        const char *split_env = getenv("SDHIP_MM_SPLIT");
+        const bool split = split_env && split_env[0] == '1';
         if (ck)
-            hipLaunchKernelGGL(k_mm<true>, dim3((n + 63) / 64), dim3(64), 0, st, x, sym_scratch, counts, g, p, start0, spec, endst, spec_c, end_c, redo, nredo, ck,
-                               ck_per_chunk, ck_tol);
+            hipLaunchKernelGGL((k_mm<true, false>), dim3((n + 63) / 64), dim3(64), 0, st, x, sym_scratch, counts, g, p, start0, spec, endst, spec_c, end_c, redo,
+                               nredo, ck, ck_per_chunk, ck_tol);
+        else if (split)
+            hipLaunchKernelGGL((k_mm<false, true>), dim3((n + 63) / 64), dim3(64), 0, st, x, sym_scratch, counts, g, p, start0, spec, endst, spec_c, end_c, redo,
+                               nredo, (MmCert *)nullptr, 0, 0.0f);
         else
-            hipLaunchKernelGGL(k_mm<false>, dim3((n + 63) / 64), dim3(64), 0, st, x, sym_scratch, counts, g, p, start0, spec, endst, spec_c, end_c, redo, nredo,
-                               (MmCert *)nullptr, 0, 0.0f);
+            hipLaunchKernelGGL((k_mm<false, false>), dim3((n + 63) / 64), dim3(64), 0, st, x, sym_scratch, counts, g, p, start0, spec, endst, spec_c, end_c, redo,
+                               nredo, (MmCert *)nullptr, 0, 0.0f);
     }
 
     // =============================================================================================

@@ -265,3 +265,16 @@ def test_experimental_early_exit_of_rerun_lanes(twin, orc, monkeypatch, case, ch
     assert len(syms) == len(want["syms"])
     got, wantc = _cadus(orc, case, ofec, soft), _cadus(orc, case, ofec, want["soft"])
     assert len(wantc) >= 30 and got.shape == wantc.shape and np.array_equal(got, wantc)
+
+
+@pytest.mark.parametrize("case,extra,env", [("goes", dict(chunk_len=4096), {}), ("npp", dict(chunk_len=2048), {"SDHIP_W_MM": "512"}), ("metop", dict(exact=1), {})])
+def test_experimental_split_symbol_loop_is_bit_identical(twin, monkeypatch, case, extra, env):
+    """SDHIP_MM_SPLIT=1 (off by default, not yet measured): the M&M symbol loop as one plain loop per phase. Same soft and float symbols, bit for bit."""
+    plain, x, ocfg, kw, ofec = _case(case, 24)
+    n = len(x)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    a = _run(twin, kw, x, chunks=[0, n // 3 + 5, n], **extra)
+    monkeypatch.setenv("SDHIP_MM_SPLIT", "1")
+    b = _run(twin, kw, x, chunks=[0, n // 3 + 5, n], **extra)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1].view(np.uint32), b[1].view(np.uint32))
