@@ -16,7 +16,7 @@ namespace sdhip
         float re, im;
     };
 
-    constexpr int DEMOD_HIST = 64; // samples of history kept in front of every stage buffer
+    constexpr int DEMOD_HIST = 128; // samples of history kept in front of every stage buffer (>= the longest resampler arm: 34 / rate taps, rate > 0.5)
 
     // chunk geometry of one speculative stage: chunk 0 = [0, L+W), chunk k>=1 = [W + k*L, W + (k+1)*L) (clipped to n)
     struct ChunkGeom
