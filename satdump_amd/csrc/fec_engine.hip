@@ -995,7 +995,7 @@ namespace sdhip
                         P.got_extra = 0;
                         P.changing_shift %= P.pat.n;
                         int sz = lead + punc_count(P.pat, P.changing_shift, B);
-                        launch_punc_cont(rot, blk, B, P.pat, P.changing_shift, lead, P.d_carry.p, P.d_slide.p + P.in_buffer, stream);
+                        launch_punc_cont(rot, blk, B, P.pat, P.changing_shift, lead, sz, P.d_carry.p, P.d_slide.p + P.in_buffer, stream);
                         P.changing_shift += B;
                         if (sz % 2)
                         {

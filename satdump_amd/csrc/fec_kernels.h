@@ -121,8 +121,8 @@ namespace sdhip
         return oo;
     }
     void launch_punc_static(const VitCfg &c, const int8_t *blk, const PuncPat &pat, int shift, int n_in, unsigned char *out, hipStream_t st);
-    void launch_punc_cont(const VitCfg &c, const int8_t *blk, int n_in, const PuncPat &pat, int pos0, int lead, unsigned char *carry, unsigned char *dst,
-                          hipStream_t st);
+    void launch_punc_cont(const VitCfg &c, const int8_t *blk, int n_in, const PuncPat &pat, int pos0, int lead, int total, unsigned char *carry,
+                          unsigned char *dst, hipStream_t st);
 
     inline int vit_words_per_block(int F)
     {

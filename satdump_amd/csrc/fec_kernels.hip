@@ -951,67 +951,71 @@ namespace sdhip
 
     // =============================================================================================
     // Generic punctured rates (conv_rate 2/3 .. 7/8): viterbi::puncturing::Depunc23/34/56/78, depunc.h:21-430.
-    // First cut: one sequential lane per call (8192 symbols), exactly the reference's loops -- this mode is one pipeline step
-    // of 76 and is built for coverage, not speed (the decoder behind it is the batch engine's own kernel).
+    // First cut: one call (8192 symbols) per launch, blocks decoded one after the other -- this mode is one pipeline step of 76
+    // and is built for coverage, not speed (the decoder behind it is the batch engine's own kernel).
     // =============================================================================================
-    __device__ __forceinline__ int punc_emit(const PuncPat &pat, int pos, unsigned u, unsigned char *out, int oo)
+    // Output index of input i is a closed form of the pattern: j = i + pos0 inputs from a period start, q = j / n whole periods of
+    // P = n + popcount(two) outputs, plus what positions pos0 .. (j % n) - 1 of the current period emit. One block, a thread per
+    // input (strided): the same bytes the reference's sequential loops write.
+    __device__ __forceinline__ int punc_pre(const PuncPat &pat, int r)
+    { // outputs of pattern positions 0 .. r-1
+        return r + __popc(pat.two & ((1u << r) - 1u));
+    }
+    __device__ __forceinline__ void punc_scatter(const PuncPat &pat, const SymFetch &f, int n_in, int pos0, int lead, unsigned char *dst)
     {
-        if (!((pat.two >> pos) & 1u))
-            out[oo++] = (unsigned char)u;
-        else if ((pat.lead128 >> pos) & 1u)
+        const int P = pat.n + __popc(pat.two);
+        const int base = lead - punc_pre(pat, pos0);
+        for (int i = (int)threadIdx.x; i < n_in; i += (int)blockDim.x)
         {
-            out[oo++] = 128;
-            out[oo++] = (unsigned char)u;
+            const int j = i + pos0, q = j / pat.n, r = j - q * pat.n;
+            int oo = base + q * P + punc_pre(pat, r);
+            const unsigned u = f.u_at(i);
+            if (!((pat.two >> r) & 1u))
+                dst[oo] = (unsigned char)u;
+            else if ((pat.lead128 >> r) & 1u)
+            {
+                dst[oo] = 128;
+                dst[oo + 1] = (unsigned char)u;
+            }
+            else
+            {
+                dst[oo] = (unsigned char)u;
+                dst[oo + 1] = 128;
+            }
         }
-        else
-        {
-            out[oo++] = (unsigned char)u;
-            out[oo++] = 128;
-        }
-        return oo;
     }
     // depunc_static(in, out, n_in, shift) on the rotated / converted first n_in symbols of a block (lock search)
-    __global__ void k_punc_static(VitCfg c, const int8_t *blk, PuncPat pat, int shift, int n_in, unsigned char *out)
+    __global__ __launch_bounds__(256) void k_punc_static(VitCfg c, const int8_t *blk, PuncPat pat, int shift, int n_in, unsigned char *out)
     {
-        if (threadIdx.x != 0 || blockIdx.x != 0)
-            return;
         const SymFetch f{c, blk, n_in};
-        int oo = 0;
-        const int actual = shift % pat.n;
-        if (shift > pat.n - 1)
-            out[oo++] = 128;
-        for (int i = 0; i < n_in; i++)
-            oo = punc_emit(pat, (i + actual) % pat.n, f.u_at(i), out, oo);
+        const int lead = shift > pat.n - 1 ? 1 : 0;
+        if (lead && threadIdx.x == 0)
+            out[0] = 128;
+        punc_scatter(pat, f, n_in, shift % pat.n, lead, out);
     }
     // depunc_cont: appended at dst; `lead` = is_first || got_extra (the carried byte goes first), pos0 = changing_shift % n.
-    // An odd count leaves its last symbol in *carry (the host knows the count: it is a function of the pattern alone).
-    __global__ void k_punc_cont(VitCfg c, const int8_t *blk, int n_in, PuncPat pat, int pos0, int lead, unsigned char *carry, unsigned char *dst)
+    // An odd count (total: the host computes it, it is a function of the pattern alone) leaves its last symbol in *carry.
+    __global__ __launch_bounds__(256) void k_punc_cont(VitCfg c, const int8_t *blk, int n_in, PuncPat pat, int pos0, int lead, int total, unsigned char *carry,
+                                                       unsigned char *dst)
     {
-        if (threadIdx.x != 0 || blockIdx.x != 0)
-            return;
         const SymFetch f{c, blk, n_in};
-        int oo = 0;
-        if (lead)
-            dst[oo++] = *carry;
-        int pos = pos0;
-        for (int i = 0; i < n_in; i++)
-        {
-            oo = punc_emit(pat, pos, f.u_at(i), dst, oo);
-            pos = pos + 1 == pat.n ? 0 : pos + 1;
-        }
-        if (oo & 1)
-            *carry = dst[oo - 1];
+        if (lead && threadIdx.x == 0)
+            dst[0] = *carry;
+        punc_scatter(pat, f, n_in, pos0, lead, dst);
+        __syncthreads();
+        if ((total & 1) && threadIdx.x == 0)
+            *carry = dst[total - 1];
     }
     void launch_punc_static(const VitCfg &c, const int8_t *blk, const PuncPat &pat, int shift, int n_in, unsigned char *out, hipStream_t st)
     {
         ProfScope _ps("k_punc_static", st);
-        hipLaunchKernelGGL(k_punc_static, dim3(1), dim3(64), 0, st, c, blk, pat, shift, n_in, out);
+        hipLaunchKernelGGL(k_punc_static, dim3(1), dim3(256), 0, st, c, blk, pat, shift, n_in, out);
     }
-    void launch_punc_cont(const VitCfg &c, const int8_t *blk, int n_in, const PuncPat &pat, int pos0, int lead, unsigned char *carry, unsigned char *dst,
-                          hipStream_t st)
+    void launch_punc_cont(const VitCfg &c, const int8_t *blk, int n_in, const PuncPat &pat, int pos0, int lead, int total, unsigned char *carry,
+                          unsigned char *dst, hipStream_t st)
     {
         ProfScope _ps("k_punc_cont", st);
-        hipLaunchKernelGGL(k_punc_cont, dim3(1), dim3(64), 0, st, c, blk, n_in, pat, pos0, lead, carry, dst);
+        hipLaunchKernelGGL(k_punc_cont, dim3(1), dim3(256), 0, st, c, blk, n_in, pat, pos0, lead, total, carry, dst);
     }
 
     // =============================================================================================
