@@ -343,7 +343,8 @@ namespace sdhip
         DevBuf<MmCert> d_mm_ck;                 // experimental: per-chunk checkpoints for the early exit of re-run lanes (SDHIP_MM_CKPT)
         DevBuf<AgcState> d_agc_ck;              // ... of the AGC and Costas lanes (SDHIP_CKPT)
         DevBuf<CostasState> d_cos_ck;
-        const bool use_ckpt = env_int("SDHIP_CKPT", 0) != 0;
+        const bool use_ckpt = env_int("SDHIP_CKPT", 1) != 0; // early exit of re-run lanes (checkpoints); SDHIP_CKPT=0: a re-run lane runs its whole chunk
+        long long w_mm_learned = 0, w_cos_learned = 0; // warm-up lengths this stream has been found to need (see the stages)
         DevBuf<unsigned long long> d_ck_work;   // {lanes, pieces run, pieces of full chunks} x {agc, costas}, SDHIP_DEBUG only
         void ck_report(const char *stage, int slot)
         {
@@ -548,6 +549,9 @@ namespace sdhip
                 return (int)((env_int("SDHIP_CHUNK", 8192) + 7) / 8 * 8);
             if (cfg.chunk_len > 0)
                 return (cfg.chunk_len + 7) / 8 * 8; // stage chunk boundaries stay multiples of 8 samples (64-byte blocks)
+            static const char *lnames[3] = {"SDHIP_CHUNK_AGC", "SDHIP_CHUNK_COSTAS", "SDHIP_CHUNK_MM"};
+            if (getenv(lnames[st]))
+                return (int)((env_int(lnames[st], 8192) + 7) / 8 * 8);
             static const char *names[3] = {"SDHIP_LANES_AGC", "SDHIP_LANES_COSTAS", "SDHIP_LANES_MM"};
             static const long long dflt[3] = {65280, 196608, 65280};
             static const long long min_len[3] = {2048, 2048, 2048};
@@ -565,17 +569,17 @@ namespace sdhip
         PinBuf<VerdictOut> h_vout;
         DevBuf<int> d_fails;
         template <class Verdict, class SpecFix, class Launch>
-        VerdictOut verify_fix(const char *stage, int K, Verdict verdict, SpecFix specfix, Launch relaunch)
+        VerdictOut verify_fix(const char *stage, const int &K, Verdict verdict, SpecFix specfix, Launch relaunch)
         {
             return verify_fix(stage, K, verdict, specfix, relaunch, [](int) { return false; });
         }
-        // respec(nfail): called once, when the FIRST judgement of the stage fails for more than an eighth of the chunks -- the
-        // speculation's start values were off, not a few boundaries. It may re-launch the whole stage with better ones (true = it
-        // did: judge again from scratch).
+        // respec(nfail): called when the FIRST judgement of the stage fails for more than an eighth of the chunks -- the
+        // speculation's start values or warm-up length were off, not a few boundaries. It may re-launch the whole stage with better
+        // ones (true = it did: judge again from scratch; it is then asked again if that judgement still fails as widely).
         template <class Verdict, class SpecFix, class Launch, class Respec>
-        VerdictOut verify_fix(const char *stage, int K, Verdict verdict, SpecFix specfix, Launch relaunch, Respec respec)
+        VerdictOut verify_fix(const char *stage, const int &K, Verdict verdict, SpecFix specfix, Launch relaunch, Respec respec)
         {
-            bool respecced = false;
+            int respecs = 0;
             d_vout.reserve(1);
             h_vout.reserve(1);
             d_fails.reserve((size_t)K + 1);
@@ -595,9 +599,9 @@ namespace sdhip
                 const int nf = h_vout.p->nfail;
                 if (nf == 0)
                     break;
-                if (rounds == 0 && !respecced && nf > std::max(4, K / 8))
+                if (rounds == 0 && respecs < 8 && nf > std::max(4, K / 8))
                 {
-                    respecced = true;
+                    respecs++;
                     if (respec(nf))
                     {
                         if (getenv("SDHIP_DEBUG"))
@@ -813,48 +817,51 @@ namespace sdhip
                 else
                     cos_p.init_freq = cos_s.freq;
                 // both loop modes decay like exp(-zeta*wn*t) with zeta*wn ~ 1.414*pll_bw per sample (unit detector gain after
-                // the AGC): 24 time constants from a phase error of up to pi/order bring the warm-up inside the tolerance
+                // the AGC): 24 time constants from a phase error of up to pi/order bring the warm-up to the float floor of two
+                // trajectories of this loop on the same samples. A stream that needed more (first judgement failed widely, see
+                // the respec hook below) keeps the longer warm-up for its later calls.
+                const long long w_cos_cap = 1 << 20;
                 long long W = cfg.warmup > 0 ? cfg.warmup : (long long)std::max(512.0, 24.0 / (1.414 * std::max(1e-5f, cfg.pll_bw)));
+                W = std::max(W, w_cos_learned);
                 W = env_int("SDHIP_W_COSTAS", W);
-                W = (std::min<long long>(W, 1 << 22) + 255) / 256 * 256;
-                cos_p.est_len = (int)std::min<long long>(env_int("SDHIP_COSTAS_EST", 256), W / 2);
+                W = (std::min<long long>(W, w_cos_cap) + 255) / 256 * 256;
                 const int L = pick_L(n, ST_COSTAS);
-                cg = make_geom(n, L, (int)W);
-                stats.chunks += cg.K;
-                d_cos_spec.reserve(cg.K);
-                d_cos_end.reserve(cg.K);
-                SD_HIP(hipMemcpyAsync(d_cos_start.p, &cos_s, sizeof(cos_s), hipMemcpyHostToDevice, stream));
-                const bool long_chunks = L >= 8192; // acceptance windows: see below
-                const double tol_phase = env_int("SDHIP_COSTAS_TOL_URAD", long_chunks ? 50000 : 500) * 1e-6,
-                             tol_freq = env_int("SDHIP_COSTAS_TOL_NFREQ", long_chunks ? 100000 : 3000) * 1e-9;
+                // Acceptance window of a Costas boundary = the soft-symbol parity target (1e-5 relative): a phase offset of d rad
+                // is a relative symbol error of d. Two trajectories of this loop on the same samples contract onto each other down to
+                // float noise (measured, tools/twin/soft_parity.py and DESIGN.md 2: median 5e-7, p99 3e-6 rad) except while one of the
+                // sign detectors of the order-4/8 error has just disagreed (a kick of ~alpha that decays within a few hundred
+                // samples): such boundaries fail the window and their chunk is re-run from the exact state until it has merged.
+                const double tol_phase = env_int("SDHIP_COSTAS_TOL_URAD", 10) * 1e-6, tol_freq = env_int("SDHIP_COSTAS_TOL_NFREQ", 100) * 1e-9;
                 ChunkCkpt cos_ck;
-                if (use_ckpt)
-                {
-                    cos_ck.len = 512;
-                    cos_ck.per_chunk = L / cos_ck.len + 1;
-                    d_cos_ck.reserve((size_t)cg.K * cos_ck.per_chunk);
-                    cos_ck.ck = d_cos_ck.p;
-                    cos_ck.tol_a = (float)tol_phase;
-                    cos_ck.tol_b = (float)tol_freq;
-                    if (getenv("SDHIP_DEBUG"))
-                        cos_ck.work = d_ck_work.p + 3;
-                }
+                auto costas_setup = [&](long long Wn) {
+                    cos_p.est_len = (int)std::min<long long>(env_int("SDHIP_COSTAS_EST", 256), Wn / 2);
+                    cg = make_geom(n, L, (int)Wn);
+                    d_cos_spec.reserve(cg.K);
+                    d_cos_end.reserve(cg.K);
+                    if (use_ckpt)
+                    {
+                        cos_ck.len = 512;
+                        cos_ck.per_chunk = L / cos_ck.len + 1;
+                        d_cos_ck.reserve((size_t)cg.K * cos_ck.per_chunk);
+                        cos_ck.ck = d_cos_ck.p;
+                        cos_ck.tol_a = (float)tol_phase;
+                        cos_ck.tol_b = (float)tol_freq;
+                        if (getenv("SDHIP_DEBUG"))
+                        {
+                            d_ck_work.reserve(6);
+                            cos_ck.work = d_ck_work.p + 3;
+                        }
+                    }
+                    d_rot.reserve(cg.K);
+                    d_dm.reserve(cg.K);
+                };
+                costas_setup(W);
+                SD_HIP(hipMemcpyAsync(d_cos_start.p, &cos_s, sizeof(cos_s), hipMemcpyHostToDevice, stream));
                 launch_costas(A, B, cg, cos_p, d_cos_start.p, d_cos_spec.p, d_cos_end.p, nullptr, 0, stream, cos_ck);
-                d_rot.reserve(cg.K);
-                d_dm.reserve(cg.K);
-                // Acceptance window of a Costas boundary. Two trajectories of this loop on the same samples contract onto each other
-                // only until a sample lands within their distance of a slicer threshold: the sign detectors then disagree and the
-                // trajectories are kicked ~alpha apart again (and re-converge). A long chunk therefore ends, with probability ~1e-3,
-                // a few 1e-4 rad / 1e-6 rad/sample away from where the next chunk's warm-up arrived although both are "the" loop
-                // trajectory to float noise; such boundaries are accepted (the residual decays within a few hundred samples).
-                // Long chunks (large batches, L >= 8192): one lane re-running a whole chunk costs as much as the stage itself, while the
-                // few boundaries per 10^5 that miss the tight window are real but small transients (<= a few 1e-2 rad: inside the
-                // loop's own phase jitter at these SNRs) that have decayed after ~2 % of the chunk; they are accepted as well.
-                const int vb = (cg.K + 255) / 256;
                 verify_fix(
                     "costas", cg.K,
                     [&](VerdictOut *vo, int *fails, int force) {
-                        hipLaunchKernelGGL(k_costas_verdict, dim3(vb), dim3(256), 0, stream, cg.K, d_cos_spec.p, d_cos_end.p, rot_unit, rot_mod, tol_phase, tol_freq,
+                        hipLaunchKernelGGL(k_costas_verdict, dim3((cg.K + 255) / 256), dim3(256), 0, stream, cg.K, d_cos_spec.p, d_cos_end.p, rot_unit, rot_mod, tol_phase, tol_freq,
                                            d_dm.p, vo, fails, force);
                     },
                     [&](const int *list, int nr) {
@@ -865,9 +872,10 @@ namespace sdhip
                     },
                     [&](const int *redo, int nr) { launch_costas(A, B, cg, cos_p, d_cos_start.p, d_cos_spec.p, d_cos_end.p, redo, nr, stream, cos_ck); },
                     [&](int) {
-                        // Many warm-ups missed: the start frequency was off (the M-th-power estimate is weak for order 8 and at low
-                        // SNR; a call may also begin in noise with the carried loop state meaningless). Every lane has meanwhile run a
-                        // real loop over W + L samples: the median of their end frequencies is a far better start value. One extra pass.
+                        // Many warm-ups missed. (a) The start frequency was off (the M-th-power estimate is weak for order 8 and at low
+                        // SNR; a call may also begin in noise with the carried loop state meaningless): every lane has meanwhile run a
+                        // real loop over W + L samples, and the median of their end frequencies is a far better start value. (b) The
+                        // warm-up is too short for this signal's loop dynamics: double it (the stream keeps the longer one).
                         std::vector<CostasState> es((size_t)cg.K);
                         SD_HIP(hipMemcpyAsync(es.data(), d_cos_end.p, es.size() * sizeof(CostasState), hipMemcpyDeviceToHost, stream));
                         SD_HIP(hipStreamSynchronize(stream));
@@ -876,12 +884,19 @@ namespace sdhip
                             fr[i] = es[i].freq;
                         std::nth_element(fr.begin(), fr.begin() + fr.size() / 2, fr.end());
                         const float med = fr[fr.size() / 2];
-                        if (!(std::fabs(med - cos_p.init_freq) > 0.05f * cfg.pll_bw))
+                        if (std::fabs(med - cos_p.init_freq) > 0.05f * cfg.pll_bw)
+                            cos_p.init_freq = med;
+                        else if (cfg.warmup <= 0 && !getenv("SDHIP_W_COSTAS") && 2 * (long long)cg.W <= w_cos_cap)
+                        {
+                            w_cos_learned = 2 * (long long)cg.W;
+                            costas_setup(w_cos_learned);
+                        }
+                        else
                             return false;
-                        cos_p.init_freq = med;
                         launch_costas(A, B, cg, cos_p, d_cos_start.p, d_cos_spec.p, d_cos_end.p, nullptr, 0, stream, cos_ck);
                         return true;
                     });
+                stats.chunks += cg.K;
                 if (cos_ck.work)
                     ck_report("costas", 1);
                 // rot[k] = frame of chunk k relative to the stream's (prefix sum of the per-boundary turns)
@@ -928,33 +943,51 @@ namespace sdhip
                 const int L = pick_L(n, ST_MM);
                 const double w_full = 36.0 / gmu * final_sps;
                 const double w_gear = mm_p.fast_syms > 0 ? (mm_p.fast_syms + 16.0 / gmu) * final_sps : w_full;
+                // Warm-up length. The timing loop's contraction rate depends on the detector gain, i.e. on the signal (measured time
+                // constants: ~360 symbols for MetOp QPSK at 10 dB, ~870 for GOES BPSK at 7 dB; tools/twin/soft_parity.py),
+                // and the chunk's symbols only agree with the sequential reference's once the warm-up has brought the lane within
+                // ~1e-4 sample of its trajectory. So the first guess (gear-shifted ~19/gain_mu symbols) is checked against the tight
+                // hand-off window below, and if more than an eighth of the boundaries miss it the stage is launched again with twice
+                // the warm-up (up to 64 loop constants 1/gain_mu); the stream keeps what it learned for its later calls.
+                const long long w_mm_cap = (long long)(64.0 / gmu * final_sps);
                 long long W = cfg.warmup > 0 ? cfg.warmup : (long long)std::min(w_full, std::max(w_gear, 0.5 * L));
+                W = std::max(W, w_mm_learned);
                 W = env_int("SDHIP_W_MM", W);
                 W = (W + 255) / 256 * 256;
-                const ChunkGeom g = make_geom(n, L, (int)W);
-                stats.chunks += g.K;
-                const double omin = (double)mm_p.omega_mid - (double)mm_p.omega_limit;
-                const long long span0 = std::min<long long>(n, (long long)L + W);
-                mm_p.cap = (int)(span0 / std::max(0.5, omin - 0.01)) + 16;
-                mm_p.cg = cg;
-                mm_p.rot = d_rot.p;
-                symbuf.reserve((size_t)g.K * mm_p.cap);
-                d_counts.reserve(2 * (size_t)g.K);
-                d_offsets.reserve(g.K);
-                d_mm_spec.reserve(g.K);
-                d_mm_end.reserve(g.K);
-                d_mm_spec_c.reserve(g.K);
-                d_mm_end_c.reserve(g.K);
-                SD_HIP(hipMemcpyAsync(d_mm_start.p, &mm_s, sizeof(mm_s), hipMemcpyHostToDevice, stream));
-                const double MM_TOL = env_int("SDHIP_MM_TOL_MILLI", 80) * 1e-3;
-                // experimental (off): checkpoints for the early exit of re-run lanes, k_mm<true>
+                ChunkGeom g;
+                // Hand-off window of an M&M boundary, in samples of timing: two trajectories of this loop on the same samples
+                // hover 3e-5 ... 1e-4 sample apart (the feedback is piecewise constant in mu through the arm index), which makes
+                // them pick different interpolator arms on 0.3-0.7 % of the symbols -- the floor of any time-parallel schedule.
+                // 2e-4 keeps a boundary's contribution inside that floor; boundaries outside are re-run from the exact state.
+                const double MM_TOL = getenv("SDHIP_MM_TOL_MICRO") ? env_int("SDHIP_MM_TOL_MICRO", 200) * 1e-6 : env_int("SDHIP_MM_TOL_MILLI", 0) * 1e-3 + (getenv("SDHIP_MM_TOL_MILLI") ? 0.0 : 2e-4);
                 MmCert *ckp = nullptr;
-                const int ck_per_chunk = mm_p.cap / MM_CKPT_SYMS + 1;
-                if (use_ckpt || env_int("SDHIP_MM_CKPT", 0))
-                {
-                    d_mm_ck.reserve((size_t)g.K * ck_per_chunk);
-                    ckp = d_mm_ck.p;
-                }
+                int ck_per_chunk = 0;
+                auto mm_setup = [&](long long Wn) {
+                    g = make_geom(n, L, (int)Wn);
+                    const double omin = (double)mm_p.omega_mid - (double)mm_p.omega_limit;
+                    const long long span0 = std::min<long long>(n, (long long)L + Wn);
+                    mm_p.cap = (int)(span0 / std::max(0.5, omin - 0.01)) + 16;
+                    mm_p.cg = cg;
+                    mm_p.rot = d_rot.p;
+                    symbuf.reserve((size_t)g.K * mm_p.cap);
+                    d_counts.reserve(2 * (size_t)g.K);
+                    d_offsets.reserve(g.K);
+                    d_mm_spec.reserve(g.K);
+                    d_mm_end.reserve(g.K);
+                    d_mm_spec_c.reserve(g.K);
+                    d_mm_end_c.reserve(g.K);
+                    d_skip.reserve(g.K);
+                    d_extra.reserve(g.K);
+                    d_seg.reserve(2 * (size_t)g.K);
+                    ck_per_chunk = mm_p.cap / MM_CKPT_SYMS + 1;
+                    if (use_ckpt || env_int("SDHIP_MM_CKPT", 0))
+                    { // checkpoints for the early exit of re-run lanes, k_mm<true>
+                        d_mm_ck.reserve((size_t)g.K * ck_per_chunk);
+                        ckp = d_mm_ck.p;
+                    }
+                };
+                mm_setup(W);
+                SD_HIP(hipMemcpyAsync(d_mm_start.p, &mm_s, sizeof(mm_s), hipMemcpyHostToDevice, stream));
                 launch_mm(A, symbuf.p, d_counts.p, g, mm_p, d_mm_start.p, d_mm_spec.p, d_mm_end.p, d_mm_spec_c.p, d_mm_end_c.p, nullptr, 0, stream, ckp, ck_per_chunk,
                           (float)MM_TOL);
                 // Symbol hand-off at chunk boundaries. The M&M loop never re-merges bit for bit: its feedback is piecewise
@@ -965,15 +998,11 @@ namespace sdhip
                 // boundary fell between the two trajectories' sample indices, mu wrapping on opposite sides): the symbol(s) are
                 // taken from chunk k-1's look-ahead, or skipped at the head of chunk k. Anything else: re-run from the exact state.
                 // (k_mm_verdict; the compaction segments and offsets are a prefix sum on the device, k_chunk_scan.)
-                d_skip.reserve(g.K);
-                d_extra.reserve(g.K);
-                d_seg.reserve(2 * (size_t)g.K);
-                const int vb = (g.K + 255) / 256;
                 verify_fix(
                     "mm", g.K,
                     [&](VerdictOut *vo, int *fails, int force) {
-                        hipLaunchKernelGGL(k_mm_verdict, dim3(vb), dim3(256), 0, stream, g.K, d_mm_spec_c.p, d_mm_end_c.p, d_counts.p, MM_TOL, d_skip.p, d_extra.p, vo,
-                                           fails, force);
+                        hipLaunchKernelGGL(k_mm_verdict, dim3((g.K + 255) / 256), dim3(256), 0, stream, g.K, d_mm_spec_c.p, d_mm_end_c.p, d_counts.p, MM_TOL, d_skip.p,
+                                           d_extra.p, vo, fails, force);
                     },
                     [&](const int *list, int nr) {
                         if (getenv("SDHIP_DEBUG"))
@@ -996,7 +1025,20 @@ namespace sdhip
                     [&](const int *redo, int nr) {
                         launch_mm(A, symbuf.p, d_counts.p, g, mm_p, d_mm_start.p, d_mm_spec.p, d_mm_end.p, d_mm_spec_c.p, d_mm_end_c.p, redo, nr, stream, ckp,
                                   ck_per_chunk, (float)MM_TOL);
+                    },
+                    [&](int nf) {
+                        const long long wn = (std::min<long long>(2 * (long long)g.W, w_mm_cap) + 255) / 256 * 256;
+                        if (cfg.warmup > 0 || getenv("SDHIP_W_MM") || wn <= (long long)g.W)
+                            return false;
+                        w_mm_learned = wn;
+                        if (getenv("SDHIP_DEBUG"))
+                            fprintf(stderr, "[sdhip] mm     %d of %d boundaries outside the hand-off window: warm-up %d -> %lld samples\n", nf, g.K, g.W, w_mm_learned);
+                        mm_setup(w_mm_learned);
+                        launch_mm(A, symbuf.p, d_counts.p, g, mm_p, d_mm_start.p, d_mm_spec.p, d_mm_end.p, d_mm_spec_c.p, d_mm_end_c.p, nullptr, 0, stream, ckp,
+                                  ck_per_chunk, (float)MM_TOL);
+                        return true;
                     });
+                stats.chunks += g.K;
                 // compaction segments + offsets + total
                 SD_HIP(hipMemsetAsync(d_vout.p, 0, sizeof(VerdictOut), stream));
                 {

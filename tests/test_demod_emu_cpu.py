@@ -142,10 +142,10 @@ def test_chunked_mode_against_reference(twin, orc, case, chunk):
     ref = want["syms"]
     err = np.abs(syms - ref) / np.sqrt(np.mean(np.abs(ref) ** 2))
     assert np.median(err) < 1e-6
-    assert np.mean(err > REL_TOL) < (0.25 if case == "goes" else 0.03)
-    assert err.max() < 0.15
+    assert np.mean(err > REL_TOL) < (0.012 if case == "goes" else 0.007)  # measured 0.006-0.008 / 0.003-0.004 (tools/twin/soft_parity.py)
+    assert err.max() < 0.08
     d = soft.astype(np.int32) - want["soft"].astype(np.int32)
-    assert np.abs(d).max() <= 8 and np.mean(d != 0) < 0.04
+    assert np.abs(d).max() <= 4 and np.mean(d != 0) < 0.004
     assert st.chunks_fixed <= st.chunks // 10
     got, wantc = _cadus(orc, case, ofec, soft), _cadus(orc, case, ofec, want["soft"])
     assert len(wantc) >= 8

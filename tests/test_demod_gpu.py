@@ -146,15 +146,16 @@ def test_exact_mode_streaming(torch_cuda, capi, orc, case):
 
 @pytest.mark.parametrize("case", ["goes", "metop", "npp"])
 def test_chunked_mode_symbols_and_cadus(torch_cuda, capi, orc, case):
-    """Default (chunk-speculative) mode against the sequential reference.
+    """Default (chunk-parallel) mode against the sequential reference.
 
-    What is guaranteed and asserted: the same NUMBER of symbols (no duplicated / dropped symbol at any chunk boundary),
-    CADUs decoded from the HIP soft symbols bit-identical to the reference's, and float symbols within 1e-5 relative for
-    the bulk of the stream. What cannot be guaranteed by ANY time-parallel schedule: the reference's M&M loop feeds back
-    through a 128-arm interpolator index rint(mu*128) (clock_recovery_mm.cpp:66), so two trajectories that differ in the
-    last bits of mu pick neighbouring arms on a small fraction of symbols (tools/merge_study.py: the loop never re-merges
-    bit for bit; the same happens between two VOLK machine variants of the reference itself). Those symbols differ by one
-    interpolator step (<~2e-2 relative), i.e. at most a couple of int8 LSBs."""
+    Asserted: the same NUMBER of symbols (no duplicated / dropped symbol at any chunk boundary), CADUs decoded from the HIP
+    soft symbols bit-identical to the reference's, and >= 99 % of the float symbols within 1e-5 relative of the reference's
+    (measured on the host twin and on the GPU, chunk_len 8192: GOES 7 dB 99.26 %, MetOp 99.64 %, NPP 99.61 %; the bounds
+    below are those figures with a small margin). The remainder is the floor of ANY time-parallel schedule: the reference's
+    M&M loop feeds back through a 128-arm interpolator index rint(mu*128) (clock_recovery_mm.cpp:66), so two trajectories of
+    the loop on the same samples hover 3e-5..1e-4 sample apart and pick neighbouring arms on 0.3-0.7 % of the symbols
+    (tools/twin/soft_parity.py; the same happens between two VOLK machine variants of the reference itself).
+    Those symbols differ by one interpolator step (<~3e-2 relative), i.e. at most a couple of int8 LSBs."""
     spec, plain, x, ocfg, kw, fec, ofec = _case(case)
     want = orc.psk_demod(ocfg, x)
     soft, syms, st = _run_demod(torch_cuda, capi, kw, x, chunk_len=8192)
@@ -165,10 +166,10 @@ def test_chunked_mode_symbols_and_cadus(torch_cuda, capi, orc, case):
     err = np.abs(syms - ref) / scale
     frac_bad = np.mean(err > REL_TOL)
     assert np.median(err) < 1e-6
-    assert frac_bad < (0.20 if case == "goes" else 0.02), f"{frac_bad:.4f} of the symbols beyond 1e-5"
-    assert err.max() < 0.15, f"max rel err {err.max():.3g}"
+    assert frac_bad < (0.010 if case == "goes" else 0.006), f"{frac_bad:.4f} of the symbols beyond 1e-5"
+    assert err.max() < 0.08, f"max rel err {err.max():.3g}"
     d = soft.astype(np.int32) - want["soft"].astype(np.int32)
-    assert np.abs(d).max() <= 8 and np.mean(d != 0) < 0.03
+    assert np.abs(d).max() <= 4 and np.mean(d != 0) < 0.003
     # the loops ran chunk-parallel for real, and almost nothing had to be re-run sequentially
     assert st.chunks_fixed <= st.chunks // 10
     # CADU parity: HIP demod -> HIP FEC vs reference demod -> reference FEC
