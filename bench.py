@@ -2,16 +2,23 @@
 """bench.py -- Msamples/s of IQ through psk_demod -> Viterbi -> deframe -> derand -> RS on MI355X.
 
 One "step" = one pass of the whole hot path (sdhip_demod_process_dev + sdhip_fec_process_dev, include/sdhip.h) over
-one batch of synthetic IQ that is ALREADY RESIDENT IN HBM when the timed region starts; soft symbols and CADUs
-stay in HBM too. The workload is BASELINE.json configs[1] (GOES HRIT: BPSK 927 ksym/s @ 3 Msps cf32, r=1/2
-Viterbi + RS(255,223) I=4, ~2 GB) unless --workload selects another config. N>1 (torchrun, one rank per GPU):
-every rank demodulates/decodes its own independent baseband stream of the same size -- the path shards
-stream-parallel with no data-path collective -- so scaling is "weak" and value = samples of all
-ranks / max-over-ranks time.
+one batch of synthetic IQ that is ALREADY RESIDENT IN HBM when the timed region starts; soft symbols and CADUs stay in
+HBM too. Default workload = BASELINE.json configs[2], the largest single-GPU configuration (MetOp AHRPT: QPSK 2.33 Msym/s @
+6 Msps cf32, punctured r=3/4 Viterbi + RS(255,223) I=4, 16 GiB of IQ); --workload selects goes_hrit (configs[1]) or
+npp_hrd (configs[3]'s per-GPU share).
 
-Prints ONE JSON line on rank 0. Extra objects: "roofline" (dominant kernel, HIP-event timed on the launch stream
-via sdhip_prof_*), "cpu_baseline" (the compiled reference oracle/_ref -- or the restatement -- on a bounded sample of
-the same workload, rank 0 / N=1 only), "cadu_per_s", "kernels" (per-kernel ms/step).
+N=1: the engines are stateful and the recording tiles seamlessly in time, so consecutive steps are one continuous stream.
+N>1 (torchrun, one rank per GPU): ONE recording of N x (the per-GPU share) samples is cut into contiguous per-rank chunks
+(satdump_amd/shard.py: rank r reads from `overlap` samples before its range so that its loops, Viterbi and deframer are locked
+when its own range begins); every step each rank starts cold (fresh handles), demodulates and decodes its chunk, and rank 0
+stitches the per-rank CADU lists on the host from the boundary frames (no data-path collective); value =
+samples of the recording / max-over-ranks time, scaling "weak" (the share per GPU is fixed).
+
+Prints ONE JSON line on rank 0. Extra objects: "roofline" (dominant kernel, HIP-event timed on the launch stream via
+sdhip_prof_*), "cpu_baseline" (the compiled reference oracle/_ref in its own thread-per-block topology, plus single-thread and
+all-cores legs, on a bounded sample of the same stream; rank 0 / N=1 only), "soft_parity" / "cadu_parity" (the first pass of
+fresh handles over the FULL-SIZE stream compared with the reference's output on the stream's first --cpu-samples samples:
+CADUs must be byte-identical -- hard failure otherwise), "cadu_per_s", "kernels" (per-kernel ms/step).
 """
 from __future__ import annotations
 
@@ -36,14 +43,14 @@ WORKLOADS = {
         demod=dict(samplerate=3e6, symbolrate=927000, constellation="bpsk", rrc_alpha=0.5, pll_bw=0.02, max_sps=3.0),
         fec=dict(constellation="bpsk", cadu_size=8192, viterbi_ber_thresold=0.3, viterbi_outsync_after=20, derandomize=1, nrzm=1, rs_i=4,
                  rs_type=1, rs_usecheck=1),
-        frames_quantum=309, frames=16 * 309, q=1, soft_per_sym=1, conv_rate=0.5),
+        frames_quantum=309, frames=16 * 309, q=1, soft_per_sym=1, conv_rate=0.5, baseline="configs[1]"),
     # BASELINE.json configs[2]: MetOp AHRPT QPSK + punctured r=3/4 + RS, 16 GB cf32 @ 6 Msps
     "metop_ahrpt": dict(
         spec=dict(constellation="qpsk", samplerate=6e6, symbolrate=2333333, conv="3/4-metop", nrzm=False, esn0_db=10.0, amplitude=0.25,
                   cfo_hz=3000.0, seed=3),
         demod=dict(samplerate=6e6, symbolrate=2333333, constellation="qpsk", rrc_alpha=0.5, pll_bw=0.003),
         fec=dict(decoder=1, viterbi_ber_thresold=0.28, viterbi_outsync_after=10),
-        frames_quantum=21, frames=21 * 7280, q=2, soft_per_sym=2, conv_rate=0.75),
+        frames_quantum=21, frames=21 * 7280, q=2, soft_per_sym=2, conv_rate=0.75, baseline="configs[2]"),
     # BASELINE.json configs[3] per-GPU share: JPSS HRD QPSK 15 Msym/s @ 30 Msps, 16 GB cf32 per GPU
     "npp_hrd": dict(
         spec=dict(constellation="qpsk", samplerate=30e6, symbolrate=15e6, conv="1/2", nrzm=True, esn0_db=8.0, amplitude=0.4, cfo_hz=20000.0,
@@ -51,30 +58,11 @@ WORKLOADS = {
         demod=dict(samplerate=30e6, symbolrate=15e6, constellation="qpsk", rrc_alpha=0.5, pll_bw=0.002),
         fec=dict(constellation="qpsk", cadu_size=8192, viterbi_ber_thresold=0.3, viterbi_outsync_after=20, derandomize=1, nrzm=1, rs_i=4,
                  rs_type=1, rs_usecheck=1),
-        frames_quantum=1, frames=131072, q=2, soft_per_sym=2, conv_rate=0.5),
+        frames_quantum=1, frames=131072, q=2, soft_per_sym=2, conv_rate=0.5, baseline="configs[3] (per-GPU share)"),
 }
 
 
-def make_input(wl, device, seed_offset, frames):
-    """Synthesise the rank's baseband stream in HBM (periodic: symbol sequence and carrier wrap seamlessly, so
-    consecutive steps look like one continuous stream to the stateful engines)."""
-    from satdump_amd import synth
-    spec = synth.SynthSpec(**wl["spec"])
-    spec.seed += seed_offset
-    seed = spec.seed
-    while True:
-        cadus = synth.make_cadus(frames, seed=seed)
-        bits = np.unpackbits(cadus.reshape(-1))
-        if not spec.nrzm or int(bits.sum()) % 2 == 0:  # NRZ-M level must wrap too
-            break
-        seed += 1000
-    plain = synth.make_cadus(frames, seed=seed, derand=False)
-    syms = synth.frames_to_symbols(cadus, spec, circular=True)
-    x, cfo = synth.modulate_torch(syms, spec, device, periodic=True)
-    return x, plain, spec
-
-
-def algorithmic_bytes(wl, n_in, n_rs, nsym, nsoft, nblk_bytes, cadu_bytes_out, in_bytes_per_sample):
+def algorithmic_bytes(wl, n_in, n_rs, nsym, nsoft, cadu_bytes_out, in_bytes_per_sample):
     """Per-step minimal HBM traffic of each kernel when stages are NOT fused: read + write once."""
     q = wl["soft_per_sym"]
     return {
@@ -102,50 +90,114 @@ def algorithmic_bytes(wl, n_in, n_rs, nsym, nsoft, nblk_bytes, cadu_bytes_out, i
 
 def pmc_traffic(workload, kernel):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (profiles/r*_<wl>_pmc.csv,
-    produced by tools/gpu_round.sh + tools/pmc_summary.py with the guide's gfx950 x2 correction on FETCH_SIZE). PMC passes cannot
-    run inside this process, so the figure is the one of the most recent committed profile of this workload; None if there is none."""
+    produced by tools/gpu_round.sh + tools/pmc_summary.py with the guide's gfx950 x2 correction on FETCH_SIZE). The PMC passes cannot
+    run inside this process, so the figure is read from the most recent committed profile of this workload -- and only if that
+    profile was taken with the kernel sources this library was built from (its `# source_hash:` line against
+    satdump_amd.build.source_hash()); a profile of other sources yields traffic = null and says so in traffic_source."""
     import csv
     import glob
+    from satdump_amd import build as sd_build
     short = {"goes_hrit": "goes", "metop_ahrpt": "metop", "npp_hrd": "npp"}[workload]
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_{short}_pmc.csv")))
     if not files:
         return None, None
+    name = os.path.basename(files[-1])
     with open(files[-1]) as f:
-        rows = [r for r in csv.reader(l for l in f if not l.startswith("#"))]
+        lines = f.read().splitlines()
+    prof_hash = next((ln.split(":", 1)[1].strip() for ln in lines if ln.startswith("# source_hash:")), None)
+    if prof_hash != sd_build.source_hash():
+        return None, f"{name} (stale: taken with kernel sources {prof_hash}, this library is {sd_build.source_hash()})"
+    rows = [r for r in csv.reader(ln for ln in lines if not ln.startswith("#"))]
     hdr, rows = rows[0], rows[1:]
     for r in rows:
-        if r and r[0] == kernel:
-            return float(r[hdr.index("traffic_bytes_per_dispatch")]), os.path.basename(files[-1])
-    return None, os.path.basename(files[-1])
+        if r and r[0].split("<")[0] == kernel.split("<")[0] and (("<" not in kernel) or kernel.split("<")[1].split(">")[0].split(",")[0] in r[0]):
+            return float(r[hdr.index("traffic_bytes_per_dispatch")]), name
+    return None, name
 
 
-def cpu_baseline(wl, x_host, max_seconds_hint=20.0):
-    """The reference's own code (oracle/_ref, else the restatement) on a bounded sample of the same stream, one host thread."""
+def ref_cfgs(wl):
     from oracle import pyref
-    kind = "reference" if pyref.ref_available() else "port"
-    orc = pyref.best()
-    d = wl["demod"]
+    d, f = wl["demod"], wl["fec"]
     cons = {"bpsk": pyref.BPSK, "qpsk": pyref.QPSK}[d["constellation"]]
     ocfg = pyref.demod_cfg(samplerate=d["samplerate"], symbolrate=d["symbolrate"], constellation=cons, rrc_alpha=d["rrc_alpha"], pll_bw=d["pll_bw"],
                            max_sps=d.get("max_sps", 4.0))
-    t0 = time.perf_counter()
-    r = orc.psk_demod(ocfg, x_host, want_syms=False)
-    t1 = time.perf_counter()
-    f = wl["fec"]
-    if f.get("decoder", 0) == 1:
-        out = orc.metop_decode(r["soft"], ber_thr=f["viterbi_ber_thresold"], outsync_after=f["viterbi_outsync_after"])
+    metop = f.get("decoder", 0) == 1
+    if metop:
+        ofec = pyref.fec_cfg(viterbi_ber_thresold=f["viterbi_ber_thresold"], viterbi_outsync_after=f["viterbi_outsync_after"])
     else:
         ofec = pyref.fec_cfg(constellation=cons, nrzm=f["nrzm"], rs_usecheck=f["rs_usecheck"], viterbi_ber_thresold=f["viterbi_ber_thresold"],
                              viterbi_outsync_after=f["viterbi_outsync_after"])
+    return ocfg, ofec, metop
+
+
+def ref_decode(orc, wl, x_host, want_syms):
+    ocfg, ofec, metop = ref_cfgs(wl)
+    t0 = time.perf_counter()
+    r = orc.psk_demod(ocfg, x_host, want_syms=want_syms)
+    t1 = time.perf_counter()
+    if metop:
+        out = orc.metop_decode(r["soft"], ber_thr=ofec.viterbi_ber_thresold, outsync_after=ofec.viterbi_outsync_after)
+    else:
         out = orc.concat_decode(ofec, r["soft"])
     t2 = time.perf_counter()
+    return r, out["cadu"], t1 - t0, t2 - t1
+
+
+def cpu_baseline(wl, x_host):
+    """The reference's own code (oracle/_ref; the restatement if it is not there) on a bounded sample of the same stream:
+    (i) in the reference's run-time topology -- a thread per DSP block, the module thread, the decoder module's thread
+        (pipeline_run.cpp:72-104, block.h:49-53) -- which is `value`;
+    (ii) one thread (the same calls back to back; also what the parity leg compares against);
+    (iii) all host cores: one independent reference instance per core on its own slice of the sample."""
+    import threading
+    from oracle import pyref
+    kind = "reference" if pyref.ref_available() else "port"
+    orc = pyref.best()
     n = len(x_host)
-    return {
-        "value": round(n / (t2 - t0) / 1e6, 3), "unit": "Msamples/s", "cores": 1, "kind": kind,
-        "sample": f"first {n} samples of rank 0's stream, demod {t1 - t0:.2f}s + FEC {t2 - t1:.2f}s, {len(out['cadu'])} CADUs, single thread "
-                  f"(generic-order VOLK shim, gcc -O2)",
-        "cadus": int(len(out["cadu"])),
-    }
+    ncores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    r, cadus, t_dem, t_fec = ref_decode(orc, wl, x_host, want_syms=True)
+    single = {"value": round(n / (t_dem + t_fec) / 1e6, 3), "cores": 1, "demod_s": round(t_dem, 2), "fec_s": round(t_fec, 2)}
+    res = {"unit": "Msamples/s", "kind": kind, "host_cores": ncores, "single_thread": single,
+           "volk": "generic-order shim (oracle/ref_shim), gcc -O2, no libvolk on the box"}
+    if kind == "reference":
+        ocfg, ofec, metop = ref_cfgs(wl)
+        th = pyref.ref().pipeline_threaded(ocfg, ofec, 1 if metop else 0, x_host)
+        res.update({"value": round(n / th["seconds"] / 1e6, 3), "cores": int(th["threads"]),
+                    "sample": f"first {n} samples of rank 0's stream; reference topology: {th['threads']} threads (one per DSP block + source + module + decoder), "
+                              f"{len(th['cadu'])} CADUs in {th['seconds']:.2f} s"})
+    else:
+        res.update({"value": single["value"], "cores": 1, "sample": f"first {n} samples of rank 0's stream, one thread"})
+    # all cores: one instance per core, each on its own slice
+    per = max(1_000_000, min(n // 4, 400_000_000 // max(1, ncores)))
+    k = min(ncores, max(1, n // per))
+    if k > 1:
+        outs = [None] * k
+
+        def work(i):
+            outs[i] = ref_decode(orc, wl, x_host[i * per:(i + 1) * per], want_syms=False)[1]
+
+        ths = [threading.Thread(target=work, args=(i,)) for i in range(k)]
+        t0 = time.perf_counter()
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join()
+        dt = time.perf_counter() - t0
+        res["all_cores"] = {"value": round(k * per / dt / 1e6, 3), "cores": k, "sample": f"{k} independent instances x {per} samples in {dt:.2f} s"}
+    return res, r, cadus
+
+
+def soft_parity(gpu_syms, gpu_soft, ref):
+    """Soft-symbol agreement of the chunk-parallel GPU pass with the sequential reference over the compared prefix."""
+    rs, rq = ref["syms"], ref["soft"]
+    n = min(len(rs), len(gpu_syms))
+    scale = float(np.sqrt(np.mean(np.abs(rs[:n]) ** 2)))
+    err = np.abs(gpu_syms[:n] - rs[:n]) / scale
+    m = min(len(rq), len(gpu_soft))
+    d = gpu_soft[:m].astype(np.int32) - rq[:m].astype(np.int32)
+    return {"symbols_compared": int(n), "frac_within_1e-5": round(float(np.mean(err <= 1e-5)), 6), "frac_bit_identical": round(float(np.mean(err == 0)), 6),
+            "median_rel": float(np.median(err)), "max_rel": float(err.max()), "frac_int8_equal": round(float(np.mean(d == 0)), 6),
+            "max_lsb": int(np.abs(d).max())}
 
 
 def main():
@@ -153,20 +205,24 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="goes_hrit", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default="metop_ahrpt", choices=sorted(WORKLOADS))
     ap.add_argument("--frames", type=int, default=0, help="CADUs per step per GPU (0 = the config's full size)")
-    ap.add_argument("--cpu-samples", type=int, default=40_000_000, help="samples of the CPU-baseline leg (0 = skip)")
+    ap.add_argument("--cpu-samples", type=int, default=40_000_000, help="samples of the CPU-baseline / parity leg (0 = skip)")
     ap.add_argument("--chunk-len", type=int, default=0)
     ap.add_argument("--exact", type=int, default=0)
     ap.add_argument("--no-check", action="store_true")
+    ap.add_argument("--blocks", type=int, default=0,
+                    help="blocks of --frames CADUs the recording consists of (default: one per GPU); --gpus 1 --blocks N decodes on one GPU the very "
+                         "recording that --gpus N shards")
+    ap.add_argument("--dump", default="", help="write the last step's CADUs of every rank to <prefix>.rank<r>.npy (+ <prefix>.json on rank 0): tests")
     ap.add_argument("--pipeline", action="store_true",
-                    help="overlap the decoder of step i with the demodulator of step i+1 (two host threads, two HIP streams) like the reference's "
+                    help="N=1: overlap the decoder of step i with the demodulator of step i+1 (two host threads, two HIP streams) like the reference's "
                          "thread-per-module pipeline; off by default: the per-kernel HIP-event times of the roofline need the kernels un-overlapped")
     args = ap.parse_args()
 
     import torch
     import torch.distributed as dist
-    from satdump_amd import capi
+    from satdump_amd import capi, shard, synth
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -185,23 +241,33 @@ def main():
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+    coll_dev = torch.device("cpu") if share_gpu else device
 
     wl = WORKLOADS[args.workload]
     frames = args.frames or wl["frames"]
     frames = max(wl["frames_quantum"], frames // wl["frames_quantum"] * wl["frames_quantum"])
+    spec = synth.SynthSpec(**wl["spec"])
+    blocks = args.blocks or world
+    if blocks % world:
+        raise SystemExit("--blocks must be a multiple of the number of GPUs")
+    bpr = blocks // world  # blocks per rank
+    rec = synth.Recording(spec, frames, blocks=blocks)
+    share = rec.samples_per_block * bpr
+    dcfg_kw = dict(**wl["demod"], device=local_rank, chunk_len=args.chunk_len, exact=args.exact)
+    fcfg_kw = dict(**wl["fec"], device=local_rank)
+    overlap = shard.lockin_overlap(wl["demod"], wl["fec"]) if world > 1 else 0
+    plan = shard.plan_chunks(rec.n_samples, world, overlap)[rank]
     t_gen = time.perf_counter()
-    x, plain, spec = make_input(wl, device, seed_offset=100 * rank, frames=frames)
+    x = rec.synth_range(plan["read_start"], plan["stop"], device=device)
     torch.cuda.synchronize()
     t_gen = time.perf_counter() - t_gen
     n_in = x.numel()
+    cadu_bytes = 1024
 
-    dem = capi.PskDemod(capi.demod_cfg(**wl["demod"], device=local_rank, chunk_len=args.chunk_len, exact=args.exact))
-    fec = capi.FecDecoder(capi.fec_cfg(**wl["fec"], device=local_rank))
     soft_cap = 2 * n_in + 64
     d_soft = torch.empty(soft_cap, dtype=torch.int8, device=device)
-    d_soft2 = torch.empty(soft_cap, dtype=torch.int8, device=device)  # second .soft buffer of the two-stage pipeline
-    cap_frames = frames + 64
-    d_cadu = torch.empty((cap_frames, 1024), dtype=torch.uint8, device=device)
+    cap_frames = frames * bpr + 256
+    d_cadu = torch.empty((cap_frames, cadu_bytes), dtype=torch.uint8, device=device)
 
     def barrier():
         torch.cuda.synchronize()
@@ -209,23 +275,80 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def step():
-        ns = dem.process_dev(x.data_ptr(), n_in, capi.FMT_CF32, d_soft.data_ptr(), soft_cap)
-        nf = fec.process_dev(d_soft.data_ptr(), ns, d_cadu.data_ptr(), cap_frames)
-        return ns, nf
+    dem = capi.PskDemod(capi.demod_cfg(**dcfg_kw))
+    fec = capi.FecDecoder(capi.fec_cfg(**fcfg_kw))
 
+    # ---- parity leg, part 1 (rank 0, N=1): the FIRST pass of fresh handles over the full-size stream, with the float symbols of
+    # the prefix the CPU leg will cover. Untimed; it also is the pass that allocates and acquires lock.
+    do_cpu = world == 1 and args.cpu_samples > 0 and not args.exact
+    parity_gpu = None
     warmup_ms = []
+    if do_cpu:
+        ncpu = min(n_in, args.cpu_samples)
+        sps_in = wl["spec"]["samplerate"] / wl["spec"]["symbolrate"]
+        syms_cap = int(ncpu / sps_in * 1.02) + 4096
+        d_syms = torch.empty(2 * syms_cap, dtype=torch.float32, device=device)
+        tw = time.perf_counter()
+        ns0 = dem.process_dev(x.data_ptr(), n_in, capi.FMT_CF32, d_soft.data_ptr(), soft_cap, d_syms.data_ptr(), syms_cap)
+        nf0 = fec.process_dev(d_soft.data_ptr(), ns0, d_cadu.data_ptr(), cap_frames)
+        torch.cuda.synchronize()
+        warmup_ms.append(round((time.perf_counter() - tw) * 1e3, 2))
+        q = wl["soft_per_sym"]
+        parity_gpu = {"syms": d_syms[: 2 * min(syms_cap, ns0 // q)].cpu().numpy().view(np.complex64),
+                      "soft": d_soft[: min(ns0, syms_cap * q)].cpu().numpy(),
+                      "cadus": d_cadu[: min(nf0, int(ncpu / share * frames * bpr) + 64)].cpu().numpy(), "first_pass_stats": dem.stats()}
+        del d_syms
+
+    tot_frames = 0
+    tot_soft = 0
+    stitched_total = None
+    if world == 1:
+        def step():
+            ns = dem.process_dev(x.data_ptr(), n_in, capi.FMT_CF32, d_soft.data_ptr(), soft_cap)
+            nf = fec.process_dev(d_soft.data_ptr(), ns, d_cadu.data_ptr(), cap_frames)
+            return ns, nf
+    else:
+        # one cold start per step: fresh handles, their device blocks recycled through the library's pool
+        capi.pool_enable(True)
+        EDGE = 64  # boundary frames each rank contributes to the stitch
+        state = {}
+
+        def step():
+            nonlocal dem, fec
+            dem.close()
+            fec.close()
+            dem = capi.PskDemod(capi.demod_cfg(**dcfg_kw))
+            fec = capi.FecDecoder(capi.fec_cfg(**fcfg_kw))
+            ns = dem.process_dev(x.data_ptr(), n_in, capi.FMT_CF32, d_soft.data_ptr(), soft_cap)
+            nf = fec.process_dev(d_soft.data_ptr(), ns, d_cadu.data_ptr(), cap_frames)
+            # stitch on the host from the boundary frames only (the CADU lists themselves stay with their ranks, like the
+            # per-module output files of the reference): [count | first EDGE frames | last EDGE frames] per rank
+            edge = torch.zeros((2 * EDGE + 1, cadu_bytes), dtype=torch.uint8, device=device)
+            edge[0, :8] = torch.tensor(list(int(nf).to_bytes(8, "little")), dtype=torch.uint8, device=device)
+            h = min(EDGE, nf)
+            edge[1:1 + h] = d_cadu[:h]
+            edge[1 + EDGE:1 + EDGE + h] = d_cadu[nf - h:nf]
+            edge = edge.to(coll_dev)
+            allv = [torch.empty_like(edge) for _ in range(world)]
+            dist.all_gather(allv, edge)
+            if rank == 0:
+                hv = [a.cpu().numpy() for a in allv]
+                counts = [int.from_bytes(bytes(a[0, :8]), "little") for a in hv]
+                heads = [a[1:1 + min(EDGE, c)] for a, c in zip(hv, counts)]
+                tails = [a[1 + EDGE:1 + EDGE + min(EDGE, c)] for a, c in zip(hv, counts)]
+                state["drops"] = shard.stitch_plan(heads, tails, counts)
+                state["counts"] = counts
+            return ns, nf
+
     for _ in range(args.warmup):
         tw = time.perf_counter()
         step()
         torch.cuda.synchronize()
-        warmup_ms.append(round((time.perf_counter() - tw) * 1e3, 2))  # the first call also allocates and acquires lock (untimed)
+        warmup_ms.append(round((time.perf_counter() - tw) * 1e3, 2))
     barrier()
     capi.prof_reset()
     capi.prof_enable(True)
-    tot_frames = 0
-    tot_soft = 0
-    pipelined = args.pipeline and args.steps > 1
+    pipelined = args.pipeline and args.steps > 1 and world == 1
     t0 = time.perf_counter()
     if not pipelined:
         for _ in range(args.steps):
@@ -238,7 +361,7 @@ def main():
         # releases the GIL), each engine on its own HIP stream, two .soft buffers. All K demodulator passes and all K decoder
         # passes lie inside the timed region.
         import threading
-        bufs = [d_soft, d_soft2]
+        bufs = [d_soft, torch.empty(soft_cap, dtype=torch.int8, device=device)]
         res = {}
 
         def run_dem(i):
@@ -266,28 +389,57 @@ def main():
     prof = capi.prof_get()
     last_nf = nf
 
-    from satdump_amd import shard
-    dt_all, samples_all, frames_all = shard.reduce_metrics(dt, float(n_in * args.steps), float(tot_frames), device=None if share_gpu else device)
+    # samples of the recording each rank OWNS (the overlap is re-processed work, not throughput)
+    own = float((plan["stop"] - plan["own_start"]) * args.steps)
+    dt_all, samples_all, frames_all = shard.reduce_metrics(dt, own, float(tot_frames), device=None if share_gpu else device)
 
-    # ---- correctness of what was timed: every CADU of the last step must be one of the transmitted frames
+    # ---- correctness of what was timed: every CADU of the last step must be one of the transmitted frames of this rank's
+    # range (its block plus, with N>1, the overlap frames in front of it); N>1: the stitched list has no duplicates and no gaps
     check = None
     if not args.no_check:
         got = d_cadu[:last_nf].cpu().numpy()
-        want = {bytes(p) for p in plain}
-        want_payload = {bytes(p[4:]) for p in plain}
+        want, want_payload = set(), set()
+        for b in range(rank * bpr, (rank + 1) * bpr):
+            plain = rec.plain_cadus(b)
+            want |= {bytes(p) for p in plain}
+            want_payload |= {bytes(p[4:]) for p in plain}
+        if args.dump:
+            np.save(f"{args.dump}.rank{rank}.npy", got)
+        if world > 1:
+            lead = -(-overlap // (rec.samples_per_block // frames)) + 2
+            pn = np.resize(synth._PN, 255 * spec.rs_i)
+            for p in rec.frames(rank * bpr * frames - lead, rank * bpr * frames):
+                p = p.copy()
+                if spec.derand:
+                    p[4:] ^= pn
+                want.add(bytes(p))
+                want_payload.add(bytes(p[4:]))
         ok = sum(1 for g in got if bytes(g) in want)
         ok_payload = sum(1 for g in got if bytes(g[4:]) in want_payload)  # the 4-byte ASM is not RS protected: channel errors stay in it
         check = {"cadus_last_step": int(last_nf), "cadus_matching_transmitted": int(ok), "payload_matching_transmitted": int(ok_payload),
-                 "transmitted": int(frames)}
+                 "transmitted": int(frames * bpr)}
+        if world > 1:
+            c = torch.tensor([float(last_nf), float(ok), float(ok_payload)], dtype=torch.float64, device=coll_dev)
+            dist.all_reduce(c)
+            if rank == 0:
+                drops, counts = state["drops"], state["counts"]
+                stitched_total = int(sum(counts) - sum(drops))
+                check = {"cadus_last_step_all_ranks": int(c[0].item()), "cadus_matching_transmitted": int(c[1].item()),
+                         "payload_matching_transmitted": int(c[2].item()), "transmitted": int(frames * blocks),
+                         "stitched": stitched_total, "dropped_as_decoded_twice": [int(d) for d in drops]}
+                if args.dump:
+                    with open(args.dump + ".json", "w") as fh:
+                        json.dump({"drops": [int(d) for d in drops], "counts": [int(c) for c in counts]}, fh)
 
     if rank == 0:
         dst = dem.stats()
         fst = fec.stats()
         steps = args.steps
-        nsym = dst.symbols_out // max(1, (args.warmup + steps))
+        passes = max(1, args.warmup + steps + (1 if do_cpu else 0)) if world == 1 else 1
+        nsym = dst.symbols_out // passes
         n_rs = n_in if not dst.resample_interp else (n_in * dst.resample_interp) // dst.resample_decim
         nsoft = tot_soft // steps
-        algo = algorithmic_bytes(wl, n_in, n_rs, nsym, nsoft, 0, (tot_frames // steps) * 1024, 8)
+        algo = algorithmic_bytes(wl, n_in, n_rs, nsym, nsoft, (tot_frames // steps) * cadu_bytes, 8)
         kernels = {k: {"ms_per_step": round(v[0] / steps, 4), "launches_per_step": round(v[1] / steps, 2)} for k, v in prof.items()}
         for k, v in kernels.items():
             if k in algo and v["ms_per_step"] > 0:
@@ -305,28 +457,42 @@ def main():
                     "algo_bytes_per_launch": round(bytes_step / max(launches, 1e-9)), "avg_launch_ms": round(ms_step / max(launches, 1e-9), 4),
                     "launches_per_step": round(launches, 2), "kernel_time_frac_of_step": round(ms_step / (dt / steps * 1e3), 4)}
         cpu = None
-        if world == 1 and args.cpu_samples > 0:
-            ncpu = min(n_in, args.cpu_samples)
+        sparity = None
+        cparity = None
+        if do_cpu:
             xh = x[:ncpu].cpu().numpy()
-            cpu = cpu_baseline(wl, xh)
+            cpu, ref, ref_cadus = cpu_baseline(wl, xh)
+            sparity = soft_parity(parity_gpu["syms"], parity_gpu["soft"], ref)
+            fp = parity_gpu["first_pass_stats"]
+            sparity["what"] = (f"first pass of fresh handles over the full {n_in}-sample stream (chunk-parallel mode) against the sequential reference on its first "
+                               f"{ncpu} samples")
+            sparity["first_pass_chunks"] = {"chunks": fp.chunks, "re_run": fp.chunks_fixed, "accepted_by_tolerance": fp.chunks_inexact, "let_through": fp.chunks_forced}
+            m = min(len(ref_cadus), len(parity_gpu["cadus"]))
+            same = bool(m > 0 and np.array_equal(ref_cadus[:m], parity_gpu["cadus"][:m]))
+            cparity = {"reference_cadus": int(len(ref_cadus)), "compared": int(m), "byte_identical": same}
         q = wl["soft_per_sym"]
         sps_in = wl["spec"]["samplerate"] / wl["spec"]["symbolrate"]
         algo_per_sample = 8 + 2 * q / sps_in + (q * wl["conv_rate"] / 8.0) / sps_in
+        if world == 1:
+            sharding = "one continuous stream on one GPU"
+        else:
+            sharding = (f"ONE recording of {rec.n_samples} samples cut into {world} contiguous chunks, one per GPU, each read from {overlap} samples early "
+                        f"(lock-in overlap), cold start per step, per-rank CADU lists stitched on the host from the boundary frames; no data-path collective")
         out = {
             "metric": "Msamples/s IQ through PSK demod -> Viterbi -> RS (HBM-resident cf32)",
             "value": round(samples_all / dt_all / 1e6, 3), "unit": "Msamples/s", "n_gpus": world, "steps": steps, "warmup": args.warmup,
             "ms_per_step": round(dt_all / steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": f"{args.workload}: {wl['spec']['constellation'].upper()} {wl['spec']['symbolrate']:.0f} sym/s @ "
-                                   f"{wl['spec']['samplerate'] / 1e6:g} Msps cf32, conv {wl['spec']['conv']}, RS(255,223) I=4, {frames} CADUs = "
-                                   f"{n_in} samples ({n_in * 8 / 1e9:.3f} GB) per GPU per step",
-                       "mode": "exact" if args.exact else "chunk-speculative", "sharding": f"{world} independent stream(s), one per GPU",
+            "config": {"workload": f"{args.workload} (BASELINE {wl['baseline']}): {wl['spec']['constellation'].upper()} {wl['spec']['symbolrate']:.0f} sym/s @ "
+                                   f"{wl['spec']['samplerate'] / 1e6:g} Msps cf32, conv {wl['spec']['conv']}, RS(255,223) I=4, {frames * bpr} CADUs = "
+                                   f"{share} samples ({share * 8 / 1e9:.3f} GB) per GPU per step",
+                       "mode": "exact" if args.exact else "chunk-parallel (speculate + certify)", "sharding": sharding,
                        "module_overlap": "decoder of step i overlaps the demodulator of step i+1 (two host threads, two HIP streams)" if pipelined
                        else "none (modules back to back)"},
-            "cadu_per_s": round(frames_all / dt_all, 1),
+            "cadu_per_s": round((stitched_total * steps if stitched_total is not None else frames_all) / dt_all, 1),
             "algo_bytes_per_sample": round(algo_per_sample, 3),
             "whole_path_GBps": round(samples_all * algo_per_sample / dt_all / 1e9, 3),
-            "roofline": roof, "cpu_baseline": cpu, "check": check,
+            "roofline": roof, "cpu_baseline": cpu, "soft_parity": sparity, "cadu_parity": cparity, "check": check,
             "demod_stats": {"chunks": dst.chunks, "chunks_fixed": dst.chunks_fixed, "chunks_rotated": dst.chunks_rotated,
                             "chunks_inexact": dst.chunks_inexact, "chunks_forced": dst.chunks_forced, "freq_hz": round(dst.freq_hz, 2)},
             "fec_stats": {"vit_respec": fst.vit_respec, "tb_respec": fst.tb_respec, "viterbi_ber": round(fst.viterbi_ber, 4),
@@ -334,6 +500,9 @@ def main():
             "kernels": kernels, "input_gen_s": round(t_gen, 2), "warmup_ms": warmup_ms,
         }
         print(json.dumps(out), flush=True)
+        if cparity is not None and not cparity["byte_identical"]:
+            print("bench.py: CADUs of the GPU pass differ from the reference's on the same IQ", file=sys.stderr)
+            sys.exit(3)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

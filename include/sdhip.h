@@ -214,6 +214,14 @@ extern "C"
     void sdhip_prof_reset(void);
     int sdhip_prof_get(int idx, char *name, size_t name_cap, double *total_ms, long long *launches);
 
+    /* ---- memory ----------------------------------------------------------------------- */
+    /* Park the device / pinned blocks of destroyed handles (per device and size) and hand them to later handles instead of
+       returning them to the driver: a caller that starts every recording (or every chunk of a sharded recording) with fresh
+       handles -- the reference constructs new module instances per pipeline run, src-core/pipeline/pipeline_run.cpp:40-70 -- then
+       allocates once. Off by default; sdhip_pool_enable(0) and sdhip_pool_trim() release what is parked. Process-wide. */
+    void sdhip_pool_enable(int on);
+    void sdhip_pool_trim(void);
+
     /* ---- misc ------------------------------------------------------------------------ */
     const char *sdhip_last_error(void);
     const char *sdhip_version(void);

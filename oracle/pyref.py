@@ -300,3 +300,19 @@ class Ref(_Lib):
             raise RuntimeError(f"sdref_psk_demod failed: {n}")
         nsym = n if cfg.constellation == BPSK else n // 2
         return {"soft": soft[:n], "syms": None if syms is None else syms[:nsym], "buffer_size": bs.value, "final_sps": sps.value}
+
+    def pipeline_threaded(self, dcfg: DemodCfg, fcfg: FecCfg, decoder: int, iq: np.ndarray):
+        """psk_demod + decoder in the reference's own run-time topology (a thread per DSP block, module thread, decoder
+        thread; oracle/ref_wrap.cpp sdref_pipeline_threaded). Compiled reference only. -> dict(cadu, seconds, threads, nsoft)"""
+        x = np.ascontiguousarray(iq, dtype=np.complex64)
+        cap = len(x) // 2048 + 64
+        out = np.zeros((cap, 1024), dtype=np.uint8)
+        sec, thr, nsoft = C.c_double(0), C.c_int(0), C.c_int64(0)
+        fn = self.lib.sdref_pipeline_threaded
+        fn.restype = C.c_int64
+        fn.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
+        n = fn(C.byref(dcfg), C.byref(fcfg), decoder, _p(x), len(x), _p(out), cap, C.byref(sec), C.byref(thr), C.byref(nsoft))
+        if n < 0:
+            raise RuntimeError(f"sdref_pipeline_threaded failed: {n}")
+        return {"cadu": out[:min(n, cap)], "seconds": sec.value, "threads": thr.value, "nsoft": nsoft.value}
+

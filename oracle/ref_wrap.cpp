@@ -24,6 +24,9 @@
 #include <memory>
 #include <vector>
 #include <new>
+#include <atomic>
+#include <chrono>
+#include <thread>
 
 #include "logger.h"
 std::shared_ptr<slog::Logger> logger = std::make_shared<slog::Logger>();
@@ -73,6 +76,25 @@ namespace
         p->~T();
         free(p);
     }
+
+    // sdref_pipeline_threaded: the decoder loops below run on their own thread and take their soft symbols from an array
+    // the demodulator's consumer thread is still filling (the role of the module's output_fifo, pipeline_run.cpp:72-104).
+    struct SoftFeed
+    {
+        std::atomic<int64_t> avail{0};
+        std::atomic<bool> done{false};
+        bool wait(int64_t need)
+        {
+            while (avail.load(std::memory_order_acquire) < need)
+            {
+                if (done.load(std::memory_order_acquire))
+                    return avail.load(std::memory_order_acquire) >= need;
+                std::this_thread::sleep_for(std::chrono::microseconds(50));
+            }
+            return true;
+        }
+    };
+    thread_local SoftFeed *tl_feed = nullptr;
 }
 
 extern "C"
@@ -177,6 +199,8 @@ extern "C"
         const int64_t nblocks = n / d_buffer_size;
         for (int64_t b = 0; b < nblocks; b++)
         {
+            if (tl_feed && !tl_feed->wait((b + 1) * (int64_t)d_buffer_size))
+                break;
             memcpy(soft_buffer.data(), soft + b * d_buffer_size, d_buffer_size);
             if (d_bpsk_90 || c->iq_invert)
                 rotate_soft(soft_buffer.data(), d_buffer_size, PHASE_0, true);
@@ -482,6 +506,8 @@ extern "C"
         const int64_t nblocks = n / BUFFER_SIZE;
         for (int64_t b = 0; b < nblocks; b++)
         {
+            if (tl_feed && !tl_feed->wait((b + 1) * (int64_t)BUFFER_SIZE))
+                break;
             memcpy(soft_buffer.data(), soft + b * BUFFER_SIZE, BUFFER_SIZE);
             int num_samp = vit->work(soft_buffer.data(), BUFFER_SIZE, viterbi_out.data());
             if (blk_ber)
@@ -637,6 +663,97 @@ extern "C"
         return no;
     }
 
+    // The psk_demod block chain, built exactly as BaseDemodModule::initb + PSKDemodModule::init build it.
+    struct RefDemodChain
+    {
+        int d_buffer_size = 0;
+        float final_sps = 0;
+        bool is_bpsk = false, is_oqpsk = false, ok = true;
+        std::shared_ptr<dsp::stream<complex_t>> in;
+        std::shared_ptr<dsp::CorrectIQBlock<complex_t>> dc_blocker;
+        std::shared_ptr<dsp::RationalResamplerBlock<complex_t>> rresamp;
+        std::shared_ptr<dsp::AGCBlock<complex_t>> agc;
+        std::shared_ptr<dsp::FIRBlock<complex_t>> rrc;
+        std::shared_ptr<dsp::CostasLoopBlock> pll;
+        std::shared_ptr<dsp::DelayOneImagBlock> delay;
+        std::shared_ptr<dsp::MMClockRecoveryBlock<complex_t>> rec;
+        explicit RefDemodChain(const sdhip_demod_cfg *c)
+        {
+            // --- BaseDemodModule ctor + initb (module_demod_base.cpp:22-25, 59-89)
+            long d_samplerate = (long)c->samplerate;
+            int d_symbolrate = (int)c->symbolrate;
+            d_buffer_size = c->buffer_size > 0 ? c->buffer_size : std::min<int>(dsp::STREAM_BUFFER_SIZE, std::max<int>(8192 + 1, d_samplerate / 200));
+            float MIN_SPS = c->min_sps, MAX_SPS = c->max_sps;
+            is_bpsk = c->constellation == SDHIP_BPSK;
+            is_oqpsk = c->constellation == SDHIP_OQPSK;
+            if (is_oqpsk)
+            {
+                MIN_SPS = 1.6;
+                MAX_SPS = 2.4;
+            }
+            float input_sps = (float)d_samplerate / (float)d_symbolrate;
+            bool resample = input_sps > MAX_SPS || input_sps < MIN_SPS;
+            int range = pow(10, (std::to_string(int(d_symbolrate)).size() - 1));
+            float final_samplerate = d_samplerate;
+            if (MAX_SPS == MIN_SPS)
+                final_samplerate = d_symbolrate * MAX_SPS;
+            else if (input_sps > MAX_SPS)
+                final_samplerate = resample ? (round(d_symbolrate / range) * range) * MAX_SPS : d_samplerate;
+            else if (input_sps < MIN_SPS)
+                final_samplerate = resample ? d_symbolrate * MIN_SPS : d_samplerate;
+            float decimation_factor = d_samplerate / final_samplerate;
+            if (resample)
+                d_buffer_size *= ceil(decimation_factor);
+            if (d_buffer_size > 8192 * 20)
+                d_buffer_size = 8192 * 20;
+            final_sps = final_samplerate / (float)d_symbolrate;
+            in = std::make_shared<dsp::stream<complex_t>>();
+            std::shared_ptr<dsp::stream<complex_t>> cur = in;
+            if (c->dc_block)
+            {
+                dc_blocker = std::make_shared<dsp::CorrectIQBlock<complex_t>>(cur);
+                cur = dc_blocker->output_stream;
+            }
+            // SmartResamplerBlock(input, final_samplerate, d_samplerate) (module_demod_base.cpp:204):
+            // for 1 < decim/interp < 2 it reduces to a RationalResamplerBlock (smart_resampler.cpp:15-43).
+            if (resample)
+            {
+                unsigned interpolation = final_samplerate, decimation = d_samplerate;
+                if (decimation > interpolation)
+                {
+                    int best_power = floor(log2(decimation / interpolation));
+                    if (best_power > 0)
+                    {
+                        ok = false; // power-of-two pre-decimator: not covered by this oracle
+                        return;
+                    }
+                    double rsamp_in = decimation, fout = interpolation, t;
+                    while (modf(rsamp_in, &t) != 0 || modf(fout, &t) != 0)
+                    {
+                        rsamp_in *= 10;
+                        fout *= 10;
+                    }
+                    rresamp = std::make_shared<dsp::RationalResamplerBlock<complex_t>>(cur, fout, rsamp_in);
+                }
+                else
+                    rresamp = std::make_shared<dsp::RationalResamplerBlock<complex_t>>(cur, interpolation, decimation);
+                cur = rresamp->output_stream;
+            }
+            agc = std::make_shared<dsp::AGCBlock<complex_t>>(cur, c->agc_rate, 1.0f, 1.0f, 65536);
+            // --- PSKDemodModule::init (module_psk_demod.cpp:86-136)
+            rrc = std::make_shared<dsp::FIRBlock<complex_t>>(agc->output_stream, dsp::firdes::root_raised_cosine(1, final_samplerate, d_symbolrate, c->rrc_alpha, c->rrc_taps));
+            float costas_max_offset = 1.0;
+            if (c->costas_max_offset_hz > 0)
+                costas_max_offset = dsp::hz_to_rad(c->costas_max_offset_hz, final_samplerate);
+            unsigned order = is_bpsk ? 2 : (c->constellation == SDHIP_8PSK ? 8 : 4);
+            pll = std::make_shared<dsp::CostasLoopBlock>(rrc->output_stream, c->pll_bw, order, costas_max_offset);
+            if (is_oqpsk)
+                delay = std::make_shared<dsp::DelayOneImagBlock>(pll->output_stream);
+            rec = std::make_shared<dsp::MMClockRecoveryBlock<complex_t>>(is_oqpsk ? delay->output_stream : pll->output_stream, final_sps, c->clock_gain_omega, c->clock_mu,
+                                                                               c->clock_gain_mu, c->clock_omega_relative_limit);
+        }
+    };
+
     // ------------------------------------------------------------------ demod module level
     // In-memory restatement of PSKDemodModule init()/process() for cf32 input
     // (module_psk_demod.cpp:86-236 + module_demod_base.cpp:59-208). Stream semantics:
@@ -646,83 +763,23 @@ extern "C"
     int64_t sdref_psk_demod(const sdhip_demod_cfg *c, const float *iq, int64_t n, int8_t *soft, int64_t soft_cap, float *syms, int64_t syms_cap,
                             int *buffer_size_out, float *final_sps_out)
     {
-        // --- BaseDemodModule ctor + initb (module_demod_base.cpp:22-25, 59-89)
-        long d_samplerate = (long)c->samplerate;
-        int d_symbolrate = (int)c->symbolrate;
-        int d_buffer_size = c->buffer_size > 0 ? c->buffer_size : std::min<int>(dsp::STREAM_BUFFER_SIZE, std::max<int>(8192 + 1, d_samplerate / 200));
-        float MIN_SPS = c->min_sps, MAX_SPS = c->max_sps;
-        const bool is_bpsk = c->constellation == SDHIP_BPSK;
-        const bool is_oqpsk = c->constellation == SDHIP_OQPSK;
-        if (is_oqpsk)
-        {
-            MIN_SPS = 1.6;
-            MAX_SPS = 2.4;
-        }
-        float input_sps = (float)d_samplerate / (float)d_symbolrate;
-        bool resample = input_sps > MAX_SPS || input_sps < MIN_SPS;
-        int range = pow(10, (std::to_string(int(d_symbolrate)).size() - 1));
-        float final_samplerate = d_samplerate;
-        if (MAX_SPS == MIN_SPS)
-            final_samplerate = d_symbolrate * MAX_SPS;
-        else if (input_sps > MAX_SPS)
-            final_samplerate = resample ? (round(d_symbolrate / range) * range) * MAX_SPS : d_samplerate;
-        else if (input_sps < MIN_SPS)
-            final_samplerate = resample ? d_symbolrate * MIN_SPS : d_samplerate;
-        float decimation_factor = d_samplerate / final_samplerate;
-        if (resample)
-            d_buffer_size *= ceil(decimation_factor);
-        if (d_buffer_size > 8192 * 20)
-            d_buffer_size = 8192 * 20;
-        float final_sps = final_samplerate / (float)d_symbolrate;
+        RefDemodChain ch(c);
+        if (!ch.ok)
+            return -2;
+        const int d_buffer_size = ch.d_buffer_size;
+        const bool is_bpsk = ch.is_bpsk;
         if (buffer_size_out)
             *buffer_size_out = d_buffer_size;
         if (final_sps_out)
-            *final_sps_out = final_sps;
-
-        auto in = std::make_shared<dsp::stream<complex_t>>();
-        std::shared_ptr<dsp::stream<complex_t>> cur = in;
-        std::shared_ptr<dsp::CorrectIQBlock<complex_t>> dc_blocker;
-        if (c->dc_block)
-        {
-            dc_blocker = std::make_shared<dsp::CorrectIQBlock<complex_t>>(cur);
-            cur = dc_blocker->output_stream;
-        }
-        // SmartResamplerBlock(input, final_samplerate, d_samplerate) (module_demod_base.cpp:204):
-        // for 1 < decim/interp < 2 it reduces to a RationalResamplerBlock (smart_resampler.cpp:15-43).
-        std::shared_ptr<dsp::RationalResamplerBlock<complex_t>> rresamp;
-        if (resample)
-        {
-            unsigned interpolation = final_samplerate, decimation = d_samplerate;
-            if (decimation > interpolation)
-            {
-                int best_power = floor(log2(decimation / interpolation));
-                if (best_power > 0)
-                    return -2; // power-of-two pre-decimator: not covered by this oracle
-                double rsamp_in = decimation, fout = interpolation, t;
-                while (modf(rsamp_in, &t) != 0 || modf(fout, &t) != 0)
-                {
-                    rsamp_in *= 10;
-                    fout *= 10;
-                }
-                rresamp = std::make_shared<dsp::RationalResamplerBlock<complex_t>>(cur, fout, rsamp_in);
-            }
-            else
-                rresamp = std::make_shared<dsp::RationalResamplerBlock<complex_t>>(cur, interpolation, decimation);
-            cur = rresamp->output_stream;
-        }
-        auto agc = std::make_shared<dsp::AGCBlock<complex_t>>(cur, c->agc_rate, 1.0f, 1.0f, 65536);
-        // --- PSKDemodModule::init (module_psk_demod.cpp:86-136)
-        auto rrc = std::make_shared<dsp::FIRBlock<complex_t>>(agc->output_stream, dsp::firdes::root_raised_cosine(1, final_samplerate, d_symbolrate, c->rrc_alpha, c->rrc_taps));
-        float costas_max_offset = 1.0;
-        if (c->costas_max_offset_hz > 0)
-            costas_max_offset = dsp::hz_to_rad(c->costas_max_offset_hz, final_samplerate);
-        unsigned order = is_bpsk ? 2 : (c->constellation == SDHIP_8PSK ? 8 : 4);
-        auto pll = std::make_shared<dsp::CostasLoopBlock>(rrc->output_stream, c->pll_bw, order, costas_max_offset);
-        std::shared_ptr<dsp::DelayOneImagBlock> delay;
-        if (is_oqpsk)
-            delay = std::make_shared<dsp::DelayOneImagBlock>(pll->output_stream);
-        auto rec = std::make_shared<dsp::MMClockRecoveryBlock<complex_t>>(is_oqpsk ? delay->output_stream : pll->output_stream, final_sps, c->clock_gain_omega, c->clock_mu,
-                                                                           c->clock_gain_mu, c->clock_omega_relative_limit);
+            *final_sps_out = ch.final_sps;
+        auto &in = ch.in;
+        auto &dc_blocker = ch.dc_blocker;
+        auto &rresamp = ch.rresamp;
+        auto &agc = ch.agc;
+        auto &rrc = ch.rrc;
+        auto &pll = ch.pll;
+        auto &delay = ch.delay;
+        auto &rec = ch.rec;
 
         auto clampf = [](float x) -> int8_t { // module_demod_base.h:106-113
             if (x < -128.0)
@@ -783,5 +840,115 @@ extern "C"
             rec->output_stream->flush();
         }
         return nsoft;
+    }
+
+    // ------------------------------------------------------------------ the reference's own run-time topology (CPU baseline)
+    // psk_demod and the decoder as the pipeline runs them (pipeline_run.cpp:72-104, block.h:49-53): every DSP block on its own
+    // thread (Block::start), joined by dsp::stream hand-offs; the module thread drains the clock-recovery output, quantises
+    // (module_psk_demod.cpp:199-220) and hands the int8 symbols to the decoder module on its own thread through a FIFO; the
+    // calling thread plays the file source. decoder: 0 = ccsds_conv_concat_decoder, 1 = metop_ahrpt_decoder.
+    // Returns CADUs decoded; *seconds = wall clock from the first buffer fed to the decoder's last frame; *threads = threads
+    // that carried work (blocks + source + module + decoder). The tail of the stream that is still inside the block
+    // hand-offs when the source ends is dropped by stop(), as in the reference: throughput, not parity, is what
+    // this entry is for.
+    int64_t sdref_pipeline_threaded(const sdhip_demod_cfg *c, const sdhip_fec_cfg *f, int decoder, const float *iq, int64_t n, uint8_t *cadu_out,
+                                    int64_t cadu_cap_frames, double *seconds, int *threads, int64_t *nsoft_out)
+    {
+        RefDemodChain ch(c);
+        if (!ch.ok)
+            return -2;
+        const bool is_bpsk = ch.is_bpsk;
+        std::vector<int8_t> soft((size_t)(2 * n + 64));
+        SoftFeed feed;
+        auto clampf = [](float x) -> int8_t {
+            if (x < -128.0)
+                return -127;
+            if (x > 127.0)
+                return 127;
+            return x;
+        };
+        int nthreads = 3; // source (caller) + module thread + decoder thread
+        const auto t0 = std::chrono::steady_clock::now();
+        if (ch.dc_blocker) ch.dc_blocker->start(), nthreads++;
+        if (ch.rresamp) ch.rresamp->start(), nthreads++;
+        ch.agc->start(), nthreads++;
+        ch.rrc->start(), nthreads++;
+        ch.pll->start(), nthreads++;
+        if (ch.delay) ch.delay->start(), nthreads++;
+        ch.rec->start(), nthreads++;
+        std::atomic<bool> module_run{true};
+        std::atomic<int64_t> last_progress_us{0};
+        std::thread module_thread([&] {
+            int64_t nsoft = 0;
+            while (module_run.load())
+            {
+                int dat_size = ch.rec->output_stream->read();
+                if (dat_size <= 0)
+                    continue;
+                complex_t *rb = ch.rec->output_stream->readBuf;
+                if (is_bpsk)
+                    for (int i = 0; i < dat_size; i++)
+                        soft[nsoft++] = clampf(rb[i].real * 50);
+                else
+                    for (int i = 0; i < dat_size; i++)
+                    {
+                        soft[nsoft++] = clampf(rb[i].real * 100);
+                        soft[nsoft++] = clampf(rb[i].imag * 100);
+                    }
+                ch.rec->output_stream->flush();
+                feed.avail.store(nsoft, std::memory_order_release);
+                last_progress_us.store(std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count());
+            }
+        });
+        int64_t ncadu = 0;
+        std::chrono::steady_clock::time_point t_dec_end = t0;
+        std::thread decoder_thread([&] {
+            tl_feed = &feed;
+            if (decoder == 1)
+                ncadu = sdref_metop_decode(f->viterbi_ber_thresold, f->viterbi_outsync_after, soft.data(), (int64_t)soft.size(), cadu_out, cadu_cap_frames, nullptr, nullptr,
+                                           nullptr, nullptr, nullptr);
+            else
+                ncadu = sdref_concat_decode(f, soft.data(), (int64_t)soft.size(), cadu_out, cadu_cap_frames, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+            tl_feed = nullptr;
+            t_dec_end = std::chrono::steady_clock::now();
+        });
+        // file source
+        for (int64_t pos = 0; pos < n; pos += ch.d_buffer_size)
+        {
+            const int m = (int)std::min<int64_t>(ch.d_buffer_size, n - pos);
+            if (c->iq_swap)
+                for (int i = 0; i < m; i++)
+                    ch.in->writeBuf[i] = complex_t(iq[2 * (pos + i) + 1], iq[2 * (pos + i)]);
+            else
+                memcpy(ch.in->writeBuf, iq + 2 * pos, (size_t)m * sizeof(complex_t));
+            ch.in->swap(m);
+        }
+        // let the hand-offs drain: stop once the module thread has seen nothing new for 20 ms
+        for (;;)
+        {
+            const int64_t now_us = std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count();
+            if (now_us - last_progress_us.load() > 20000)
+                break;
+            std::this_thread::sleep_for(std::chrono::milliseconds(2));
+        }
+        module_run.store(false);
+        if (ch.dc_blocker) ch.dc_blocker->stop();
+        if (ch.rresamp) ch.rresamp->stop();
+        ch.agc->stop();
+        ch.rrc->stop();
+        ch.pll->stop();
+        if (ch.delay) ch.delay->stop();
+        ch.rec->stop();
+        ch.rec->output_stream->stopReader();
+        module_thread.join();
+        feed.done.store(true, std::memory_order_release);
+        decoder_thread.join();
+        if (seconds)
+            *seconds = std::chrono::duration<double>(t_dec_end - t0).count() - 0.020; // minus the idle time of the drain rule above
+        if (threads)
+            *threads = nthreads;
+        if (nsoft_out)
+            *nsoft_out = feed.avail.load();
+        return ncadu;
     }
 }

@@ -40,6 +40,21 @@ def build_lib(force: bool = False, verbose: bool = True) -> str:
     return LIB
 
 
+def source_hash() -> str:
+    """Fingerprint of the kernel sources libsdhip.so is built from (csrc/*.hip, csrc/*.h, include/sdhip.h, the hipcc flags):
+    tools/pmc_summary.py stamps it into profiles/*_pmc.csv and bench.py only quotes a PMC traffic figure whose stamp matches."""
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(f for f in os.listdir(CSRC) if f.endswith((".hip", ".h"))) 
+    for f in files:
+        with open(os.path.join(CSRC, f), "rb") as fh:
+            h.update(f.encode() + b"\0" + fh.read())
+    with open(os.path.join(ROOT, "include", "sdhip.h"), "rb") as fh:
+        h.update(fh.read())
+    h.update(" ".join(HIPCC_FLAGS).encode())
+    return h.hexdigest()[:16]
+
+
 def build_oracle(verbose: bool = True) -> None:
     cmd = ["make", "-C", os.path.join(ROOT, "oracle"), "-j8", "all"]
     if verbose:

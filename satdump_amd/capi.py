@@ -106,9 +106,15 @@ def lib():
             L.sdhip_op_block.restype = C.c_int64
             L.sdhip_op_block.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
         L.sdhip_prof_enable.argtypes = [C.c_int]
+        L.sdhip_pool_enable.argtypes = [C.c_int]
         L.sdhip_prof_get.argtypes = [C.c_int, C.c_char_p, C.c_size_t, C.POINTER(C.c_double), C.POINTER(C.c_longlong)]
         _lib = L
     return _lib
+
+
+def pool_enable(on: bool = True):
+    """Park the device / pinned blocks of destroyed handles for the next handles (sdhip_pool_enable)."""
+    lib().sdhip_pool_enable(int(on))
 
 
 def prof_enable(on: bool = True):

@@ -36,6 +36,15 @@ namespace sdhip
         ~ProfScope();
     };
 
+    // Device / pinned-host memory of the buffers below. With the pool off (default) these are hipMalloc / hipFree and
+    // hipHostMalloc / hipHostFree. With it on (sdhip_pool_enable), freed blocks are parked per (device, size) and handed to
+    // the next request of the same size: a caller that destroys and re-creates handles for every recording (one cold start
+    // per chunk, bench.py --gpus N) then pays no allocation after the first one. sdhip_pool_trim() releases what is parked.
+    void *dev_alloc(size_t bytes);
+    void dev_free(void *p, size_t bytes);
+    void *pin_alloc(size_t bytes);
+    void pin_free(void *p, size_t bytes);
+
     // Simple owning device buffer (grow-only).
     template <class T>
     struct DevBuf
@@ -46,7 +55,7 @@ namespace sdhip
         void release()
         {
             if (p)
-                (void)hipFree(p);
+                dev_free(p, cap * sizeof(T));
             p = nullptr;
             cap = 0;
         }
@@ -56,7 +65,7 @@ namespace sdhip
                 return;
             release();
             size_t want = n + n / 8 + 64;
-            SD_HIP(hipMalloc((void **)&p, want * sizeof(T)));
+            p = (T *)dev_alloc(want * sizeof(T));
             cap = want;
         }
         void swap(DevBuf &o)
@@ -78,17 +87,18 @@ namespace sdhip
         ~PinBuf()
         {
             if (p)
-                (void)hipHostFree(p);
+                pin_free(p, cap * sizeof(T));
         }
         void reserve(size_t n)
         {
             if (n <= cap)
                 return;
             if (p)
-                (void)hipHostFree(p);
+                pin_free(p, cap * sizeof(T));
             p = nullptr;
+            cap = 0;
             size_t want = n + n / 8 + 64;
-            SD_HIP(hipHostMalloc((void **)&p, want * sizeof(T), hipHostMallocDefault));
+            p = (T *)pin_alloc(want * sizeof(T));
             cap = want;
         }
         PinBuf() = default;

@@ -21,6 +21,91 @@ namespace sdhip
     static thread_local std::string g_last_error;
     void set_error(const std::string &msg) { g_last_error = msg; }
 
+    // ---- block pool behind DevBuf / PinBuf (common.h) ----
+    static std::mutex g_pool_mu;
+    static bool g_pool_on = false;
+    static std::multimap<std::pair<int, size_t>, void *> g_pool_dev; // (device, bytes) -> parked block
+    static std::multimap<size_t, void *> g_pool_pin;
+    static std::map<void *, int> g_dev_of; // device a live block was allocated on
+    void *dev_alloc(size_t bytes)
+    {
+        int dev = 0;
+        SD_HIP(hipGetDevice(&dev));
+        {
+            std::lock_guard<std::mutex> lk(g_pool_mu);
+            auto it = g_pool_dev.find({dev, bytes});
+            if (it != g_pool_dev.end())
+            {
+                void *p = it->second;
+                g_pool_dev.erase(it);
+                return p;
+            }
+        }
+        void *p = nullptr;
+        SD_HIP(hipMalloc(&p, bytes));
+        std::lock_guard<std::mutex> lk(g_pool_mu);
+        g_dev_of[p] = dev;
+        return p;
+    }
+    void dev_free(void *p, size_t bytes)
+    {
+        if (!p)
+            return;
+        {
+            std::lock_guard<std::mutex> lk(g_pool_mu);
+            if (g_pool_on)
+            {
+                g_pool_dev.insert({{g_dev_of[p], bytes}, p});
+                return;
+            }
+            g_dev_of.erase(p);
+        }
+        (void)hipFree(p);
+    }
+    void *pin_alloc(size_t bytes)
+    {
+        {
+            std::lock_guard<std::mutex> lk(g_pool_mu);
+            auto it = g_pool_pin.find(bytes);
+            if (it != g_pool_pin.end())
+            {
+                void *p = it->second;
+                g_pool_pin.erase(it);
+                return p;
+            }
+        }
+        void *p = nullptr;
+        SD_HIP(hipHostMalloc(&p, bytes, hipHostMallocDefault));
+        return p;
+    }
+    void pin_free(void *p, size_t bytes)
+    {
+        if (!p)
+            return;
+        {
+            std::lock_guard<std::mutex> lk(g_pool_mu);
+            if (g_pool_on)
+            {
+                g_pool_pin.insert({bytes, p});
+                return;
+            }
+        }
+        (void)hipHostFree(p);
+    }
+    static void pool_trim()
+    {
+        std::lock_guard<std::mutex> lk(g_pool_mu);
+        for (auto &kv : g_pool_dev)
+        {
+            g_dev_of.erase(kv.second);
+            (void)hipFree(kv.second);
+        }
+        g_pool_dev.clear();
+        for (auto &kv : g_pool_pin)
+            (void)hipHostFree(kv.second);
+        g_pool_pin.clear();
+    }
+
     // ---- per-kernel event timing (process-wide, off by default) ----------------------------------------
     struct ProfRec
     {
@@ -1300,6 +1385,17 @@ extern "C"
             return 0;
         return n;
     }
+
+    void sdhip_pool_enable(int on)
+    {
+        {
+            std::lock_guard<std::mutex> lk(sdhip::g_pool_mu);
+            sdhip::g_pool_on = on != 0;
+        }
+        if (!on)
+            sdhip::pool_trim();
+    }
+    void sdhip_pool_trim(void) { sdhip::pool_trim(); }
 
     void sdhip_prof_enable(int on)
     {

@@ -23,38 +23,89 @@ def plan_chunks(n_samples: int, world: int, overlap: int, align: int = 8):
     return plan
 
 
+def lockin_overlap(demod: dict, fec: dict) -> int:
+    """Samples a rank reads in front of its own range so that a cold-started chain is producing the reference's frames when the
+    range begins. Sum of the lock-in times of the stages, from the loop constants the modules are configured with:
+      AGC 8/agc_rate samples, Costas 16/pll_bw samples, M&M 40/clock_gain_mu symbols; viterbi_outsync_after + 2 Viterbi blocks
+      (the lock search runs on the first block, viterbi_1_2.cpp:52-92 -- and when it runs while the loops are still settling it
+      can lock on a wrong phase with a BER just under the threshold, which the decoder only gives up after outsync_after bad
+      blocks, :104-113; measured on a cold-started NPP chunk: first good frame 11 CADUs in with an unlucky start, 1 CADU in
+      otherwise), for MetOp 10 more (the module's own no-sync watchdog, module_metop_ahrpt_decoder.cpp:58-66); and four CADUs
+      (the deframer needs consecutive ASMs before it reports SYNCED, bpsk_ccsds_deframer.cpp:47-107; one more frame straddles the
+      boundary)."""
+    sps = float(demod["samplerate"]) / float(demod["symbolrate"])
+    q = 1 if demod.get("constellation", "qpsk") == "bpsk" else 2
+    metop = fec.get("decoder", 0) == 1
+    cadu_bits = 8192 if metop else int(fec.get("cadu_size", 8192))
+    conv_rate = 0.75 if metop else {0: 0.5, 1: 2 / 3, 2: 0.75, 3: 5 / 6, 4: 7 / 8}[int(fec.get("conv_rate", 0))]
+    block_syms = (16384 if metop else max(cadu_bits, 8192)) / q
+    cadu_syms = cadu_bits / conv_rate / q
+    gmu = float(demod.get("clock_gain_mu", 8.7e-3))
+    relock_blocks = int(fec.get("viterbi_outsync_after", 10 if metop else 20)) + 2 + (10 if metop else 0)
+    n = 8.0 / float(demod.get("agc_rate", 1e-2)) + 16.0 / float(demod["pll_bw"]) + (40.0 / gmu + relock_blocks * block_syms + 4 * cadu_syms) * sps
+    return int(n + 7) // 8 * 8
+
+
+def overlap_drop(tail_prev: np.ndarray, head: np.ndarray) -> int:
+    """Leading frames of `head` (first frames a rank decoded) that repeat the end of `tail_prev` (last frames of everything in
+    front of it): the largest m with head[:m] == tail_prev[-m:]; if there is none, the first frames of head that occur anywhere
+    in tail_prev (the rank's re-lock began in the middle of the overlap). Frames are compared behind their 4-byte sync marker:
+    the marker is not RS protected, so two decodes of the same frame from differently started loops may differ in it, while the
+    RS-corrected code block is the transmitted one in both. CADUs of a real recording carry counters, so genuine repeats do not occur."""
+    tail_prev = np.asarray(tail_prev, dtype=np.uint8)
+    head = np.asarray(head, dtype=np.uint8)
+    if len(tail_prev) == 0 or len(head) == 0:
+        return 0
+    if tail_prev.shape[1] > 8:
+        tail_prev, head = tail_prev[:, 4:], head[:, 4:]
+    # candidates: positions of head[0] in tail_prev
+    pos = np.flatnonzero((tail_prev == head[0][None, :]).all(axis=1))
+    for p in pos:  # earliest position = largest overlap first
+        m = len(tail_prev) - int(p)
+        if m <= len(head) and np.array_equal(tail_prev[p:], head[:m]):
+            return m
+    seen = {bytes(r) for r in tail_prev}
+    j = 0
+    while j < len(head) and bytes(head[j]) in seen:
+        j += 1
+    return j
+
+
+def stitch_plan(heads, tails, counts, edge: int = 64):
+    """Frames to drop at the head of every rank's CADU list, from the boundary frames alone: heads[r] / tails[r] = the first / last
+    (up to `edge`) frames rank r decoded, counts[r] = how many it decoded. The running tail of the stitched stream is kept so that
+    a rank that decoded fewer than `edge` frames does not hide its predecessor's."""
+    drops = [0] * len(counts)
+    run = np.zeros((0, 0), dtype=np.uint8)
+    for r in range(len(counts)):
+        h = np.asarray(heads[r], dtype=np.uint8)
+        t = np.asarray(tails[r], dtype=np.uint8)
+        c = int(counts[r])
+        if c == 0:
+            continue
+        if run.size:
+            drops[r] = overlap_drop(run, h)
+        if c - drops[r] >= len(t) or not run.size:
+            kept_tail = t if c - drops[r] >= len(t) else t[len(t) - (c - drops[r]):]
+            run = kept_tail[-edge:] if c - drops[r] >= edge or not run.size else np.concatenate([run, kept_tail], axis=0)[-edge:]
+        else:
+            run = np.concatenate([run, t[len(t) - (c - drops[r]):]], axis=0)[-edge:]
+    return drops
+
+
 def stitch_cadus(per_rank_frames):
-    """Concatenate per-rank CADU arrays [n_r, cadu_bytes] in rank order. A frame transmitted inside the overlap region may be
-    decoded by both neighbours: the leading frames of rank r that repeat the tail of what is already stitched are dropped
-    (byte comparison of whole frames; CADU payloads of real missions carry counters, so genuine repeats do not occur)."""
-    out = None
-    for f in per_rank_frames:
-        f = np.asarray(f, dtype=np.uint8)
+    """Concatenate per-rank CADU arrays [n_r, cadu_bytes] in rank order, dropping the leading frames of rank r that repeat the
+    tail of what is already stitched (a frame transmitted inside the overlap region is decoded by both neighbours)."""
+    fr = [np.asarray(f, dtype=np.uint8) for f in per_rank_frames]
+    for f in fr:
         if f.ndim != 2:
             raise ValueError("frames must be [n, cadu_bytes]")
-        if out is None or len(out) == 0:
-            out = f.copy()
-            continue
-        if len(f) == 0:
-            continue
-        # longest m such that f[:m] == out[-m:], searched from the largest plausible overlap down
-        drop = 0
-        max_m = min(len(f), len(out))
-        tail_keys = [bytes(r) for r in out[-max_m:]]
-        head_keys = [bytes(r) for r in f[:max_m]]
-        for m in range(max_m, 0, -1):
-            if tail_keys[-m:] == head_keys[:m]:
-                drop = m
-                break
-        if drop == 0:
-            # the overlap may also start in the MIDDLE of rank r's re-lock: find the first frame of f that continues `out`
-            seen = {k: i for i, k in enumerate(tail_keys)}
-            j = 0
-            while j < len(head_keys) and head_keys[j] in seen:
-                j += 1
-            drop = j
-        out = np.concatenate([out, f[drop:]], axis=0)
-    return out if out is not None else np.zeros((0, 0), dtype=np.uint8)
+    edge = 64
+    drops = stitch_plan([f[:edge] for f in fr], [f[-edge:] if len(f) else f for f in fr], [len(f) for f in fr], edge)
+    parts = [f[d:] for f, d in zip(fr, drops) if len(f) - d > 0]
+    if not parts:
+        return np.zeros((0, 0), dtype=np.uint8)
+    return np.concatenate(parts, axis=0)
 
 
 def reduce_metrics(dt_s: float, samples: float, frames: float, device=None):

@@ -118,11 +118,19 @@ _PN = ccsds_pn_table()
 
 
 def make_cadus(nframes: int, seed: int, rs_i: int = 4, dualbasis: bool = True, derand: bool = True, asm: int = ASM,
-               nroots: int = 32) -> np.ndarray:
-    """Random-payload CADUs: 4-byte ASM + rs_i*255 bytes (interleaved codeblock, randomised)."""
-    rng = np.random.default_rng(seed)
+               nroots: int = 32, subset=None, payload=None) -> np.ndarray:
+    """Random-payload CADUs: 4-byte ASM + rs_i*255 bytes (interleaved codeblock, randomised).
+    subset: frame indices to build (the payload of ALL nframes is drawn, so frame i is the same whichever subset asks for it).
+    payload: [n, rs_i, k] bytes to use instead of drawing them."""
     k = 255 - nroots
-    data = rng.integers(0, 256, size=(nframes, rs_i, k), dtype=np.uint8)
+    if payload is not None:
+        data = np.asarray(payload, dtype=np.uint8)
+    else:
+        rng = np.random.default_rng(seed)
+        data = rng.integers(0, 256, size=(nframes, rs_i, k), dtype=np.uint8)
+        if subset is not None:
+            data = data[np.asarray(subset, dtype=np.int64)]
+    nframes = len(data)
     if dualbasis:
         conv = _FROM_DUAL[data]
     else:
@@ -384,3 +392,218 @@ def modulate_torch(symbols: np.ndarray, spec: SynthSpec, device, periodic: bool 
         yi += sigma * torch.randn(m1 - m0, dtype=torch.float32, device=device, generator=gen)
         out[m0:m1] = torch.complex(yr * spec.amplitude, yi * spec.amplitude)
     return out, cfo
+
+
+# --------------------------------------------------------------------------- one long recording, synthesised slice by slice
+def _splitmix64(z):
+    """splitmix64 finaliser on int64 arrays (numpy or torch; two's-complement wrap-around, logical shifts by masking)."""
+    m30, m27, m31 = (1 << 34) - 1, (1 << 37) - 1, (1 << 33) - 1
+    z = (z ^ ((z >> 30) & m30)) * (-0x40A7B892E31B1A47)  # 0xBF58476D1CE4E5B9
+    z = (z ^ ((z >> 27) & m27)) * (-0x6B2FB644ECCEEE15)  # 0x94D049BB133111EB
+    return z ^ ((z >> 31) & m31)
+
+
+class Recording:
+    """ONE synthetic recording of `blocks` x `frames_per_block` CADUs whose samples are a pure function of the absolute
+    sample index, so that any rank can synthesise any range [a, b) of it without the rest (bench.py shards one recording over
+    the GPUs of a node; tests cut it at arbitrary places).
+
+    Block r holds frames_per_block CADUs drawn from seed + 100 r. With NRZ-M the payload of its frame 1 is re-drawn until the
+    block's bit parity is even, so the differential encoder's level is 0 at every block boundary: the level anywhere in the
+    last frames of a block follows backwards from its end, without the frames in front. The convolutional encoder runs
+    through (a slice is encoded from one frame early and that frame's symbols are dropped). The block sequence is periodic
+    (block `blocks` = block 0), the carrier makes a whole number of turns over the recording, and the noise of sample m is a
+    hash of m -- so the recording also tiles seamlessly in time, which lets a stateful engine process it step after step."""
+
+    def __init__(self, spec: SynthSpec, frames_per_block: int, blocks: int = 1):
+        self.spec = spec
+        self.P = int(frames_per_block)
+        self.blocks = int(blocks)
+        ratio = Fraction(spec.samplerate / spec.symbolrate).limit_denominator(2000)
+        self.up, self.down = ratio.numerator, ratio.denominator
+        bits = 8 * (4 + 255 * spec.rs_i)
+        # frames per whole puncture / symbol period: MetOp's 3/4 pattern consumes 6 mother-code bits per 3 information bits and
+        # a frame is 8192 bits, so symbol boundaries and frame boundaries only coincide every 3 frames
+        self.group = 1 if spec.conv == "1/2" else 3
+        coded_bits = self.group * (2 * bits if spec.conv == "1/2" else bits * 4 // 3)
+        self.syms_per_group = coded_bits if spec.constellation == "bpsk" else coded_bits // 2
+        if self.P % self.group:
+            raise ValueError(f"frames_per_block must be a multiple of {self.group}")
+        nsym_block = self.P // self.group * self.syms_per_group
+        if (nsym_block * self.up) % self.down:
+            raise ValueError("frames_per_block does not give a whole number of samples")
+        self.nsym_block = nsym_block
+        self.samples_per_block = nsym_block * self.up // self.down
+        self.n_samples = self.samples_per_block * self.blocks
+        cyc = round(spec.cfo_hz * self.n_samples / spec.samplerate)
+        self.cfo = cyc * spec.samplerate / self.n_samples
+        self._full = {}
+
+    # ---- frames
+    def _seed(self, b):
+        return self.spec.seed + 100 * (b % self.blocks)
+
+    def _kw(self):
+        return dict(rs_i=self.spec.rs_i, dualbasis=self.spec.dualbasis, derand=self.spec.derand)
+
+    def block_cadus(self, b):
+        """All CADUs of block b as transmitted (frame 1 adjusted for even block parity when NRZ-M is on)."""
+        b %= self.blocks
+        if b not in self._full:
+            cad = make_cadus(self.P, self._seed(b), **self._kw())
+            if self.spec.nrzm and self.P >= 2:
+                par = int(np.unpackbits(cad.reshape(-1)).sum()) & 1
+                t = 0
+                while par:
+                    rng = np.random.default_rng(self._seed(b) + 7777 + t)
+                    pl = rng.integers(0, 256, size=(1, self.spec.rs_i, 223), dtype=np.uint8)
+                    new = make_cadus(1, 0, payload=pl, **self._kw())[0]
+                    par ^= (int(np.unpackbits(cad[1]).sum()) ^ int(np.unpackbits(new).sum())) & 1
+                    cad[1] = new
+                    t += 1
+            self._full = {b: cad}  # one block cached at a time (a block is ~134 MB at the bench sizes)
+        return self._full[b]
+
+    def plain_cadus(self, b):
+        """Block b's CADUs as a decoder outputs them (de-randomised)."""
+        cad = self.block_cadus(b)
+        if not self.spec.derand:
+            return cad.copy()
+        pn = np.resize(_PN, 255 * self.spec.rs_i)
+        out = cad.copy()
+        out[:, 4:] ^= pn[None, :]
+        return out
+
+    def frames(self, f0, f1):
+        """Transmitted CADUs of absolute frame indices [f0, f1) (periodic). Whole blocks come from block_cadus(); partial
+        ones are built frame by frame -- valid for any frame but frame 1 of a block with NRZ-M, which needs the whole block."""
+        out = []
+        f = f0
+        T = self.P * self.blocks
+        while f < f1:
+            b, i0 = divmod(f % T, self.P)
+            i1 = min(self.P, i0 + (f1 - f))
+            if (b in self._full) or (i0 == 0 and i1 == self.P) or (self.spec.nrzm and i0 <= 1 < i1):
+                out.append(self.block_cadus(b)[i0:i1])
+            else:
+                out.append(make_cadus(self.P, self._seed(b), subset=np.arange(i0, i1), **self._kw()))
+            f += i1 - i0
+        return np.concatenate(out, axis=0) if out else np.zeros((0, 4 + 255 * self.spec.rs_i), dtype=np.uint8)
+
+    def symbols(self, g0, g1):
+        """Symbols of frame groups [g0, g1) (group = self.group frames); first symbol has absolute index g0 * syms_per_group."""
+        G = self.group
+        fr = self.frames(g0 * G - 1, g1 * G)  # one frame early: convolutional encoder state
+        bits = np.unpackbits(fr.reshape(-1))
+        fb = fr.shape[1] * 8
+        if self.spec.nrzm:
+            # level just before the first bit: 0 at every block boundary; backwards from the next boundary otherwise
+            first = (g0 * G - 1) % (self.P * self.blocks)
+            to_boundary = (self.P - first % self.P) % self.P  # frames from `first` to the next block boundary
+            lvl = int(bits[: to_boundary * fb].sum()) & 1 if to_boundary * fb <= len(bits) else None
+            if lvl is None:
+                raise ValueError("slice does not reach a block boundary: cannot anchor the NRZ-M level")
+            bits = ((np.cumsum(bits.astype(np.int64)) + lvl) & 1).astype(np.uint8)
+        coded = conv_encode(bits)
+        coded = coded[2 * fb:]  # drop the lead-in frame (its last 6 bits set the encoder state)
+        if self.spec.conv == "3/4-metop":
+            coded = puncture_metop(coded)
+        lv = coded.astype(np.float32) * 2.0 - 1.0
+        if self.spec.constellation == "bpsk":
+            return lv.astype(np.complex64)
+        return ((lv[0::2] + 1j * lv[1::2]) / np.float32(math.sqrt(2.0))).astype(np.complex64)
+
+    # ---- samples
+    def _bank(self):
+        span = self.spec.span
+        hu = rrc_impulse(float(self.up), self.spec.rrc_alpha, span) * math.sqrt(self.up)
+        ntap = 2 * span
+        H = np.zeros((self.up, ntap), dtype=np.float64)
+        c = span * self.up
+        for j in range(ntap):
+            H[:, j] = hu[c + (j - span) * self.up + np.arange(self.up)]
+        return H
+
+    def synth_range(self, a: int, b: int, device=None, chunk: int = 1 << 24):
+        """Samples [a, b) of the recording (0 <= a < b; b may exceed n_samples: the recording repeats). device=None: numpy
+        complex64; else a torch.complex64 tensor on `device`."""
+        span = self.spec.span
+        spg = self.syms_per_group
+        k_lo = (a * self.down) // self.up - span - 1
+        k_hi = ((b - 1) * self.down) // self.up + span + 1
+        g0 = k_lo // spg
+        g1 = k_hi // spg + 1
+        sy = self.symbols(g0, g1)
+        ks = g0 * spg  # absolute index of sy[0]
+        H = self._bank()
+        ntap = 2 * span
+        sps = self.up / self.down
+        sigma = math.sqrt(sps / (2.0 * 10 ** (self.spec.esn0_db / 10)))
+        w = 2 * math.pi * (self.cfo / self.spec.samplerate)
+        key = (self.spec.seed * 0x9E3779B97F4A7C15 + 0x1234567) & ((1 << 63) - 1)
+        off = int(round(self.spec.timing_offset * self.up))
+        is_real = self.spec.constellation == "bpsk"
+        if device is None:
+            out = np.empty(b - a, dtype=np.complex64)
+            Hf = H.astype(np.float32)
+            for m0 in range(a, b, chunk):
+                m1 = min(b, m0 + chunk)
+                m = np.arange(m0, m1, dtype=np.int64)
+                u = m * self.down + off
+                p = u % self.up
+                k0 = u // self.up - ks
+                xr = np.zeros(m1 - m0, dtype=np.float32)
+                xi = None if is_real else np.zeros(m1 - m0, dtype=np.float32)
+                for j in range(ntap):
+                    k = k0 - (j - span)
+                    hj = Hf[p, j]
+                    xr += sy.real[k] * hj
+                    if xi is not None:
+                        xi += sy.imag[k] * hj
+                ph = m.astype(np.float64) * w + self.spec.phase0
+                cs, sn = np.cos(ph).astype(np.float32), np.sin(ph).astype(np.float32)
+                if xi is None:
+                    yr, yi = xr * cs, xr * sn
+                else:
+                    yr, yi = xr * cs - xi * sn, xr * sn + xi * cs
+                with np.errstate(over="ignore"):
+                    z = _splitmix64((m % self.n_samples) ^ np.int64(key))
+                u1 = (((z & 0xFFFFFF).astype(np.float32)) + np.float32(0.5)) * np.float32(2.0 ** -24)
+                u2 = ((((z >> 24) & 0xFFFFFF).astype(np.float32)) + np.float32(0.5)) * np.float32(2.0 ** -24)
+                r = np.sqrt(np.float32(-2.0) * np.log(u1)) * np.float32(sigma)
+                t = np.float32(2 * math.pi) * u2
+                out[m0 - a:m1 - a] = ((yr + r * np.cos(t)) * np.float32(self.spec.amplitude)) + 1j * ((yi + r * np.sin(t)) * np.float32(self.spec.amplitude))
+            return out
+        import torch
+        d_ar = torch.from_numpy(np.ascontiguousarray(sy.real)).to(device)
+        d_ai = None if is_real else torch.from_numpy(np.ascontiguousarray(sy.imag)).to(device)
+        d_H = torch.from_numpy(H.astype(np.float32)).to(device)
+        out = torch.empty(b - a, dtype=torch.complex64, device=device)
+        for m0 in range(a, b, chunk):
+            m1 = min(b, m0 + chunk)
+            m = torch.arange(m0, m1, dtype=torch.int64, device=device)
+            u = m * self.down + off
+            p = u % self.up
+            k0 = torch.div(u, self.up, rounding_mode="floor") - ks
+            xr = torch.zeros(m1 - m0, dtype=torch.float32, device=device)
+            xi = None if is_real else torch.zeros(m1 - m0, dtype=torch.float32, device=device)
+            for j in range(ntap):
+                k = k0 - (j - span)
+                hj = d_H[p, j]
+                xr += d_ar[k] * hj
+                if xi is not None:
+                    xi += d_ai[k] * hj
+            ph = m.to(torch.float64) * w + self.spec.phase0
+            cs, sn = torch.cos(ph).to(torch.float32), torch.sin(ph).to(torch.float32)
+            if xi is None:
+                yr, yi = xr * cs, xr * sn
+            else:
+                yr, yi = xr * cs - xi * sn, xr * sn + xi * cs
+            z = _splitmix64((m % self.n_samples) ^ key)
+            u1 = ((z & 0xFFFFFF).to(torch.float32) + 0.5) * (2.0 ** -24)
+            u2 = (((z >> 24) & 0xFFFFFF).to(torch.float32) + 0.5) * (2.0 ** -24)
+            r = torch.sqrt(-2.0 * torch.log(u1)) * sigma
+            t = (2 * math.pi) * u2
+            out[m0 - a:m1 - a] = torch.complex((yr + r * torch.cos(t)) * self.spec.amplitude, (yi + r * torch.sin(t)) * self.spec.amplitude)
+        return out
+

@@ -78,15 +78,28 @@ def test_plugin_shim_builds_against_reference_headers():
     assert set(used) <= set(_declared_symbols())
 
 
-def test_bench_reads_committed_pmc_traffic():
-    """bench.py's roofline.traffic comes from the committed rocprofv3 --pmc summaries (profiles/r*_goes_pmc.csv): the parser
-    must find the dominant kernels there, and the algorithmic byte model must know every kernel it may name."""
+def test_bench_reads_committed_pmc_traffic(tmp_path, monkeypatch):
+    """bench.py's roofline.traffic comes from the committed rocprofv3 --pmc summaries (profiles/r*_<wl>_pmc.csv), and only from a
+    summary stamped with the hash of the kernel sources the library is built from: a stale profile yields traffic = None and says
+    so. The algorithmic byte model must know every kernel the roofline may name."""
+    import shutil
     import bench
+    from satdump_amd import build as sd_build
+    prof = tmp_path / "profiles"
+    prof.mkdir()
+    src = os.path.join(ROOT, "profiles", "r01_j_goes_pmc.csv")  # an unstamped round-1 profile
+    shutil.copy(src, prof / "r90_goes_pmc.csv")
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    traffic, name = bench.pmc_traffic("goes_hrit", "k_mm")
+    assert traffic is None and "stale" in name
+    body = open(src).read().splitlines()
+    (prof / "r91_goes_pmc.csv").write_text("\n".join([body[0], f"# source_hash: {sd_build.source_hash()}"] + body[1:]) + "\n")
     for k in ("k_mm", "k_chunks<AgcStage>", "k_chunks<CostasStage>", "k_vit2_acs"):
-        traffic, src = bench.pmc_traffic("goes_hrit", k)
-        assert src is not None and src.startswith("r01_") and traffic and traffic > 1e6, (k, traffic, src)
+        traffic, name = bench.pmc_traffic("goes_hrit", k)
+        assert name == "r91_goes_pmc.csv" and traffic and traffic > 1e6, (k, traffic, name)
+    assert bench.pmc_traffic("goes_hrit", "k_chunks<AgcStage>")[0] != bench.pmc_traffic("goes_hrit", "k_chunks<CostasStage>")[0]
     wl = bench.WORKLOADS["goes_hrit"]
-    algo = bench.algorithmic_bytes(wl, 262144000, 235929600, 81000000, 81000000, 0, 4944 * 1024, 8)
+    algo = bench.algorithmic_bytes(wl, 262144000, 235929600, 81000000, 81000000, 4944 * 1024, 8)
     for k in ("k_mm", "k_chunks<AgcStage>", "k_chunks<CostasStage>", "k_resample", "k_resample_byoffset", "k_resample_period", "k_fir", "k_fir_window", "k_vit2_acs", "k_rs", "k_rs_screen"):
         assert algo[k] > 0
     # SURVEY 8(d): 8 + 2q/S + c/S bytes per input sample for GOES

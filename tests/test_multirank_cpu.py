@@ -1,6 +1,7 @@
-"""N>1 path on CPU: world_size-2 gloo processes run the sharding plan of satdump_amd/shard.py on ONE synthetic recording,
-each rank decoding its chunk with the ORACLE standing in for the GPU engines (test infrastructure: there is no GPU here
-and the product has no CPU path), rank 0 gathers and stitches. The stitched CADU list must equal what the sequential
+"""N>1 path on CPU: world_size-2 gloo processes run the sharding plan of satdump_amd/shard.py on ONE synthetic recording
+(every rank synthesises its own range of it, as bench.py does), each rank decoding its chunk with the ORACLE standing in for the
+GPU engines (test infrastructure: there is no GPU here and the product has no CPU path; tests/test_multirank_gpu.py is the
+same run on the engines), rank 0 stitches from the boundary frames. The stitched CADU list must equal what the sequential
 reference decodes from the whole recording (minus the frames lost while the very first rank locks, which the sequential
 run loses too), and the timing/counter reduction must be max / sum over ranks."""
 import os
@@ -45,47 +46,76 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, x_path, n, overlap, out_dir):
+DEMOD = dict(samplerate=30e6, symbolrate=15e6, constellation="qpsk", pll_bw=0.002)
+FEC = dict(constellation="qpsk", cadu_size=8192, nrzm=1, rs_usecheck=1)
+SPEC = dict(constellation="qpsk", samplerate=30e6, symbolrate=15e6, conv="1/2", nrzm=True, esn0_db=8.0, amplitude=0.4, cfo_hz=20000.0, seed=4)
+FRAMES = 48
+
+
+def _decode(x):
+    from oracle import pyref
+    orc = pyref.best()
+    soft = orc.psk_demod(pyref.demod_cfg(samplerate=30e6, symbolrate=15e6, constellation=pyref.QPSK, pll_bw=0.002), x, want_syms=False)["soft"]
+    return orc.concat_decode(pyref.fec_cfg(constellation=pyref.QPSK, nrzm=1, rs_usecheck=1), soft)["cadu"]
+
+
+def _worker(rank, world, port, out_dir):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    from oracle import pyref
-    x = np.load(x_path, mmap_mode="r")
-    me = shard.plan_chunks(n, world, overlap)[rank]
-    chunk = np.ascontiguousarray(x[me["read_start"]:me["stop"]])
-    orc = pyref.best()
-    soft = orc.psk_demod(pyref.demod_cfg(samplerate=3e6, symbolrate=927000, constellation=pyref.BPSK, pll_bw=0.02, max_sps=3.0), chunk,
-                         want_syms=False)["soft"]
-    cadu = orc.concat_decode(pyref.fec_cfg(constellation=pyref.BPSK, nrzm=1, rs_usecheck=1), soft)["cadu"]
+    from satdump_amd import synth
+    # every rank synthesises ITS range of the one recording (a pure function of the absolute sample index)
+    rec = synth.Recording(synth.SynthSpec(**SPEC), FRAMES, blocks=world)
+    me = shard.plan_chunks(rec.n_samples, world, shard.lockin_overlap(DEMOD, FEC))[rank]
+    cadu = _decode(rec.synth_range(me["read_start"], me["stop"]))
+    # the boundary exchange bench.py does: [count | first EDGE | last EDGE] frames per rank
+    EDGE = 64
+    edge = torch.zeros((2 * EDGE + 1, 1024), dtype=torch.uint8)
+    edge[0, :8] = torch.tensor(list(len(cadu).to_bytes(8, "little")), dtype=torch.uint8)
+    h = min(EDGE, len(cadu))
+    edge[1:1 + h] = torch.from_numpy(cadu[:h])
+    edge[1 + EDGE:1 + EDGE + h] = torch.from_numpy(cadu[len(cadu) - h:])
+    allv = [torch.empty_like(edge) for _ in range(world)]
+    dist.all_gather(allv, edge)
     gathered = [None] * world
     dist.all_gather_object(gathered, cadu)
     dt, ns, nf = shard.reduce_metrics(1.0 + rank, float(me["stop"] - me["own_start"]), float(len(cadu)))
     if rank == 0:
-        np.save(os.path.join(out_dir, "stitched.npy"), shard.stitch_cadus(gathered))
-        np.save(os.path.join(out_dir, "metrics.npy"), np.array([dt, ns, nf, sum(len(g) for g in gathered)]))
+        hv = [a.numpy() for a in allv]
+        counts = [int.from_bytes(bytes(a[0, :8]), "little") for a in hv]
+        drops = shard.stitch_plan([a[1:1 + min(EDGE, c)] for a, c in zip(hv, counts)], [a[1 + EDGE:1 + EDGE + min(EDGE, c)] for a, c in zip(hv, counts)], counts)
+        np.save(os.path.join(out_dir, "stitched.npy"), np.concatenate([g[d:] for g, d in zip(gathered, drops)], axis=0))
+        np.save(os.path.join(out_dir, "stitched_full.npy"), shard.stitch_cadus(gathered))
+        np.save(os.path.join(out_dir, "metrics.npy"), np.array([dt, ns, nf, sum(len(g) for g in gathered)] + drops))
     dist.barrier()
     dist.destroy_process_group()
 
 
 def test_two_ranks_shard_one_recording(tmp_path):
-    from oracle import pyref
     from satdump_amd import synth
     from tests import util
-    spec, cadus, plain, syms = util.goes_case(nframes=60)
-    x, _ = synth.modulate(syms, spec)
-    n = len(x)
-    x_path = str(tmp_path / "x.npy")
-    np.save(x_path, x)
-    orc = pyref.best()
-    soft = orc.psk_demod(pyref.demod_cfg(samplerate=3e6, symbolrate=927000, constellation=pyref.BPSK, pll_bw=0.02, max_sps=3.0), x, want_syms=False)["soft"]
-    want = orc.concat_decode(pyref.fec_cfg(constellation=pyref.BPSK, nrzm=1, rs_usecheck=1), soft)["cadu"]
     world = 2
-    overlap = 6 * 53023  # six CADUs of lead-in: loops + Viterbi + deframer (needs ~3 consecutive ASMs) lock before the owned range
-    mp.spawn(_worker, args=(world, _free_port(), x_path, n, overlap, str(tmp_path)), nprocs=world, join=True)
+    rec = synth.Recording(synth.SynthSpec(**SPEC), FRAMES, blocks=world)
+    want = _decode(rec.synth_range(0, rec.n_samples))
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
     got = np.load(str(tmp_path / "stitched.npy"))
-    dt, ns, nf, ntot = np.load(str(tmp_path / "metrics.npy"))
-    assert dt == 2.0 and ns == float(n) and nf == ntot  # max over ranks / sums over ranks
-    # identical frame list (the sharded run may only differ by frames around the chunk boundary that BOTH decoded: stitched away)
-    assert got.shape == want.shape and np.array_equal(got, want)
+    m = np.load(str(tmp_path / "metrics.npy"))
+    dt, ns, nf, ntot, drops = m[0], m[1], m[2], m[3], m[4:]
+    assert dt == 2.0 and ns == float(rec.n_samples) and nf == ntot  # max over ranks / sums over ranks
+    assert drops[0] == 0 and drops[1] >= 1  # the overlap was decoded by both ranks and stitched away
+    # identical frame list (sync marker aside: it is not RS protected)
+    assert got.shape == want.shape and np.array_equal(got[:, 4:], want[:, 4:])
+    assert np.array_equal(np.load(str(tmp_path / "stitched_full.npy")), got)
+    plain = np.concatenate([rec.plain_cadus(b) for b in range(world)])
     ids = util.frame_ids(got, plain)
     assert all(i >= 0 for i in ids[2:]) and len(set(ids[2:])) == len(ids[2:])
+    assert len(got) >= world * FRAMES - 4
+
+
+def test_lockin_overlap_follows_the_loop_constants():
+    a = shard.lockin_overlap(DEMOD, FEC)
+    assert a % 8 == 0 and 200_000 < a < 400_000
+    assert shard.lockin_overlap(dict(DEMOD, pll_bw=0.001), FEC) > a
+    assert shard.lockin_overlap(dict(DEMOD, clock_gain_mu=4e-3), FEC) > a
+    assert shard.lockin_overlap(dict(DEMOD), dict(FEC, viterbi_outsync_after=40)) > a
+    assert shard.lockin_overlap(dict(samplerate=6e6, symbolrate=2333333, constellation="qpsk", pll_bw=0.003), dict(decoder=1)) > 400_000

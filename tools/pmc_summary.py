@@ -5,8 +5,12 @@ TCC pass on gfx950). Units as rocprofv3 reports them (KB on gfx94x formulas); th
 in the `fetch_bytes_corrected` column. Usage: pmc_summary.py <outdir> <workload>"""
 import csv
 import glob
+import os
 import sys
 from collections import defaultdict
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from satdump_amd import build as sd_build  # noqa: E402
 
 
 def collect(outdir, counter, wl):
@@ -30,6 +34,7 @@ def main():
     fe = collect(outdir, "FETCH_SIZE", wl)
     wr = collect(outdir, "WRITE_SIZE", wl)
     print("# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), bench.py --steps 1 --warmup 1; counter unit = KB")
+    print(f"# source_hash: {sd_build.source_hash()}")
     print("kernel,dispatches,fetch_KB_per_dispatch,fetch_bytes_corrected_x2,write_KB_per_dispatch,traffic_bytes_per_dispatch")
     for k in sorted(set(fe) | set(wr), key=lambda k: -(fe.get(k, [0, 0])[1] + wr.get(k, [0, 0])[1])):
         nf, f = fe.get(k, [0, 0.0])
