@@ -18,6 +18,8 @@
 
 #include "../include/sdhip.h"
 
+#include <algorithm>
+#include <cmath>
 #include <cstring>
 #include <fstream>
 #include <vector>
@@ -56,9 +58,30 @@ namespace sdhip_plugin
         std::string baseband_format = "cf32";
         int fmt = SDHIP_FMT_CF32;
         std::atomic<uint64_t> filesize{0}, progress{0};
-        std::atomic<float> display_freq{0};
+        std::atomic<float> display_freq{0}, snr{0}, peak_snr{0};
         std::atomic<bool> should_stop{false};
         std::ofstream data_out;
+        // M2M4 estimate over the soft symbols handed on (the reference runs M2M4SNREstimator on the float symbols,
+        // module_psk_demod.cpp:190-194, snr_estimator.cpp:16-41; the int8 symbols are those scaled by 50 / 100 and clamped:
+        // a statistic for the UI and the logger, not part of the data path)
+        float snr_y1 = 0, snr_y2 = 0;
+        void snr_update(const int8_t *soft, size_t n)
+        {
+            const bool bpsk = cfg.constellation == SDHIP_BPSK;
+            const float sc = bpsk ? 1.0f / 50.0f : 1.0f / 100.0f, alpha = 0.001f, beta = 1.0f - alpha;
+            for (size_t i = 0; i + (bpsk ? 0 : 1) < n; i += bpsk ? 1 : 2)
+            {
+                const float re = soft[i] * sc, im = bpsk ? 0.0f : soft[i + 1] * sc;
+                const float m2 = re * re + im * im;
+                snr_y1 = alpha * m2 + beta * snr_y1;
+                snr_y2 = alpha * m2 * m2 + beta * snr_y2;
+            }
+            const float y1_2 = snr_y1 * snr_y1, sig = std::sqrt(std::max(0.0f, 2 * y1_2 - snr_y2)), noise = snr_y1 - sig;
+            const float v = (sig > 0 && noise > 0) ? std::max(0.0f, 10.0f * std::log10(sig / noise)) : 0.0f;
+            snr = v;
+            if (v > peak_snr)
+                peak_snr = v;
+        }
 
     public:
         PSKDemodHipModule(std::string input_file, std::string output_file_hint, nlohmann::json parameters)
@@ -82,6 +105,9 @@ namespace sdhip_plugin
             opt(parameters, "max_sps", cfg.max_sps);
             if (parameters.count("freq_shift") > 0 && parameters["freq_shift"].get<long>() != 0)
                 throw satdump_exception("psk_demod_hip: freq_shift is not on the HIP path, use psk_demod");
+            // custom_samplerate overrides the resample decision (module_demod_base.cpp:73-74): not a field of the C ABI
+            if (parameters.count("custom_samplerate") > 0)
+                throw satdump_exception("psk_demod_hip: custom_samplerate is not on the HIP path, use psk_demod");
             // carrier-tracking front-end and post-Costas DC block (module_psk_demod.cpp:36-40, 93-113, 127-128): CPU module only
             if (parameters.count("has_carrier") > 0 && parameters["has_carrier"].get<bool>())
                 throw satdump_exception("psk_demod_hip: has_carrier is not on the HIP path, use psk_demod");
@@ -187,6 +213,7 @@ namespace sdhip_plugin
                     data_out.write((char *)buf.data(), n);
                 else
                     output_fifo->write((uint8_t *)buf.data(), n);
+                snr_update(buf.data(), (size_t)n);
             }
             sdhip_demod_stats st;
             sdhip_demod_get_stats(h, &st);
@@ -203,7 +230,7 @@ namespace sdhip_plugin
             logger->info("Using input baseband " + d_input_file);
             logger->info("Demodulating to " + d_output_file_hint + ".soft (MI355X path)");
             std::vector<int8_t> out(1 << 24);
-            static const int bps[4] = {8, 4, 2, 2};
+            static const int bps[5] = {8, 4, 2, 2, 8}; // bytes per complex sample, indexed by SDHIP_FMT_* (cf32, cs16, cs8, cu8, cs32)
             if (input_data_type == DATA_FILE)
             {
                 std::ifstream in(d_input_file, std::ios::binary);
@@ -226,7 +253,13 @@ namespace sdhip_plugin
             }
             else
             {
-                // dsp::stream<complex_t> hand-off exactly as the reference's blocks consume it (common/dsp/buffer.h:28-151)
+                // dsp::stream<complex_t> hand-off exactly as the reference's blocks consume it (common/dsp/buffer.h:28-151).
+                // A live source must see its symbols soon: the library gathers host samples into large batches (file input), so here
+                // everything pending is processed as soon as an eighth of a second of samples has arrived (the reference emits every
+                // d_buffer_size = samplerate / 200 samples; the decoder behind the FIFO, the UI and the Viterbi lock do not care about
+                // 125 ms, they do about the tens of seconds a 64 Mi-sample batch is at a few Msps).
+                const size_t flush_every = std::max<size_t>(8192, (size_t)(cfg.samplerate / 8.0));
+                size_t since_flush = 0;
                 while (!should_stop && input_active.load())
                 {
                     const int n = input_stream->read();
@@ -236,6 +269,13 @@ namespace sdhip_plugin
                     input_stream->flush();
                     if (rc < 0)
                         throw satdump_exception(std::string("psk_demod_hip: ") + sdhip_last_error());
+                    since_flush += (size_t)n;
+                    if (since_flush >= flush_every)
+                    {
+                        if (sdhip_demod_flush(h) < 0)
+                            throw satdump_exception(std::string("psk_demod_hip: ") + sdhip_last_error());
+                        since_flush = 0;
+                    }
                     drain(out);
                 }
             }
@@ -253,6 +293,8 @@ namespace sdhip_plugin
         {
             nlohmann::json v;
             v["progress"] = filesize ? ((double)progress / (double)filesize) : 0.0;
+            v["snr"] = snr.load();
+            v["peak_snr"] = peak_snr.load();
             v["freq"] = display_freq.load();
             return v;
         }
@@ -306,7 +348,8 @@ namespace sdhip_plugin
             }
         }
         std::atomic<float> viterbi_ber{10};
-        std::atomic<int> viterbi_lock{0}, deframer_state{0};
+        std::atomic<int> viterbi_lock{0}, deframer_state{0}, rs_avg{0};
+        bool has_viterbi = true;
 
     public:
         FecHipModuleBase(std::string input_file, std::string output_file_hint, nlohmann::json parameters)
@@ -329,15 +372,30 @@ namespace sdhip_plugin
         }
         void process()
         {
-            // batches of whole decoder buffers; the library keeps any remainder pending
-            const size_t batch = (size_t)block_bytes * 2048;
-            std::vector<int8_t> soft(batch);
+            // The reference decoders read ONE decoder buffer (block_bytes) per loop iteration into the same array and test
+            // should_run() = !eof in between (module_ccsds_conv_concat_decoder.cpp:140-146, filestream_to_filestream.cpp:46-88): a
+            // short last read leaves the tail of the array as the previous buffer left it, and a file that ends exactly on a buffer
+            // boundary is followed by one more iteration that decodes the previous buffer again. Same reads here, block by block
+            // with the same stale-tail content, but gathered into batches of up to 2048 buffers per push so that a file is decoded
+            // at the GPU's rate; a FIFO input is pushed buffer by buffer (stay close to real time).
+            const size_t max_blocks = input_data_type == DATA_FILE ? 2048 : 1;
+            std::vector<int8_t> soft((size_t)block_bytes * max_blocks, 0);
             std::vector<uint8_t> frames((size_t)cadu_bytes * 4096);
+            std::vector<int8_t> last((size_t)block_bytes, 0); // what the reference's soft_buffer holds before a read
             while (should_run())
             {
-                const size_t want = input_data_type == DATA_FILE ? batch : (size_t)block_bytes; // streaming: stay close to real time
-                read_soft(soft.data(), want);
-                if (sdhip_fec_push(h, soft.data(), want) < 0)
+                size_t nb = 0;
+                while (nb < max_blocks && should_run())
+                {
+                    int8_t *slot = soft.data() + nb * (size_t)block_bytes;
+                    memcpy(slot, last.data(), (size_t)block_bytes);
+                    read_soft(slot, (size_t)block_bytes);
+                    memcpy(last.data(), slot, (size_t)block_bytes);
+                    nb++;
+                }
+                if (nb == 0)
+                    break;
+                if (sdhip_fec_push(h, soft.data(), nb * (size_t)block_bytes) < 0)
                     throw satdump_exception(std::string(getIDM()) + ": " + sdhip_last_error());
                 for (;;)
                 {
@@ -353,16 +411,29 @@ namespace sdhip_plugin
                 viterbi_ber = st.viterbi_ber;
                 viterbi_lock = st.viterbi_lock;
                 deframer_state = st.deframer_state;
+                rs_avg = (st.rs_errors[0] + st.rs_errors[1] + st.rs_errors[2] + st.rs_errors[3]) / 4;
             }
             cleanup();
         }
         void drawUI(bool) {}
         nlohmann::json getModuleStats()
         {
-            auto v = base::FileStreamToFileStreamModule::getModuleStats();
-            v["deframer_lock"] = deframer_state.load() >= 12;
-            v["viterbi_ber"] = viterbi_ber.load();
-            v["viterbi_lock"] = viterbi_lock.load();
+            // same keys as the modules replaced (module_ccsds_conv_concat_decoder.cpp:202-215, module_metop_ahrpt_decoder.cpp:92-104,
+            // module_ccsds_simple_psk_decoder.cpp:304-317)
+            nlohmann::json v;
+            if (has_viterbi)
+                v = base::FileStreamToFileStreamModule::getModuleStats();
+            const int ds = deframer_state.load();
+            v["deframer_lock"] = ds >= 12;
+            if (has_viterbi)
+            {
+                v["viterbi_ber"] = viterbi_ber.load();
+                v["viterbi_lock"] = viterbi_lock.load();
+                v["viterbi_state"] = viterbi_lock.load() == 0 ? "NOSYNC" : "SYNCED";
+            }
+            if (cfg.rs_i != 0)
+                v["rs_avg"] = rs_avg.load();
+            v["deframer_state"] = ds <= 2 ? "NOSYNC" : (ds < 12 ? "SYNCING" : "SYNCED");
             return v;
         }
     };
@@ -439,6 +510,7 @@ namespace sdhip_plugin
         {
             // CCSDSSimplePSKDecoderModule ctor, src-core/pipeline/modules/ccsds/module_ccsds_simple_psk_decoder.cpp:19-98
             cfg.decoder = SDHIP_DEC_SIMPLE_PSK;
+            has_viterbi = false;
             const std::string cs = parameters["constellation"].get<std::string>();
             if (cs == "bpsk")
                 cfg.constellation = SDHIP_BPSK;

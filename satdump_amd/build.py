@@ -67,10 +67,11 @@ def build_plugin_check(verbose: bool = True) -> None:
     drop-in boundary, only possible where the reference tree exists (not on the GPU box)."""
     if not os.path.isdir("/root/reference/src-core"):
         return
-    cmd = ["make", "-C", os.path.join(ROOT, "plugin"), "all"]
-    if verbose:
-        print(" ".join(cmd), flush=True)
-    subprocess.check_call(cmd)
+    for d in (os.path.join(ROOT, "plugin"), os.path.join(ROOT, "tests", "minihost")):  # the plugin, and the test host that runs it
+        cmd = ["make", "-C", d, "all"]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
 
 
 def build_all(force: bool = False) -> None:

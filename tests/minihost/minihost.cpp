@@ -1,0 +1,262 @@
+// tests/minihost/minihost.cpp -- TEST INFRASTRUCTURE: the smallest host that can load a SatDump plugin and run its modules.
+//
+// Full SatDump cannot be built in this repository's environment (no volk / fftw3 / nng / ... SURVEY.md 8c), so the plugin
+// of plugin/sdhip_plugin.cpp would never execute. This program is the part of SatDump the plugin touches, and nothing else:
+//   * it includes the reference's REAL headers (pipeline/module.h, core/plugin.h, utils/event_bus.h, common/dsp/buffer.h) and
+//     compiles the reference's own FileStreamToFileStreamModule and dsp buffer constants where they lie (tests/minihost/Makefile);
+//   * it defines what libsatdump_core defines for those headers: satdump::eventBus, satdump::pipeline::modules_registry, the
+//     handful of ProcessingModule members of src-core/pipeline/module.cpp:36-84 and the registry lookup :123-135 (that file
+//     includes every module of SatDump and cannot be compiled alone);
+//   * it loads the plugin the way src-core/core/plugin.cpp:15-58 does (dlopen, `loader`, init()), registers stand-ins for the
+//     CPU modules under the stock ids, fires RegisterModulesEvent (module.cpp:121) and SatDumpStartedEvent (init.cpp:163), and
+//     runs two modules the way Pipeline::run does: one after the other through a file (pipeline_run.cpp:121-180), or both at
+//     once joined by a FIFO (pipeline_run.cpp:44-104), or -- as the live pipeline does -- the demodulator fed from a
+//     dsp::stream<complex_t> (live_pipeline.cpp:45-105).
+// Usage: minihost <libsdhip.so> <plugin.so> list | run <job.json>
+#include "core/exception.h"
+#include "core/plugin.h"
+#include "logger.h"
+#include "pipeline/module.h"
+#include "pipeline/modules/base/filestream_to_filestream.h"
+
+#include <dlfcn.h>
+#include <filesystem>
+#include <fstream>
+#include <iostream>
+#include <thread>
+
+std::shared_ptr<slog::Logger> logger = std::make_shared<slog::Logger>();
+
+// ---- what libsatdump_core provides for the headers above
+float ui_scale = 1.0f;
+namespace ImGui
+{
+    ImVec2 GetContentRegionAvail() { return ImVec2(0, 0); }
+    void ProgressBar(float, const ImVec2 &, const char *) {}
+}
+namespace satdump
+{
+    uint64_t getFilesize(std::string filepath) { return std::filesystem::exists(filepath) ? (uint64_t)std::filesystem::file_size(filepath) : 0; }
+    std::map<std::string, std::shared_ptr<satdump::Plugin>> loaded_plugins;
+    std::shared_ptr<EventBus> eventBus = std::make_shared<EventBus>();
+    std::shared_ptr<TaskScheduler> taskScheduler;
+    namespace pipeline
+    {
+        // src-core/pipeline/module.cpp:36-84
+        ProcessingModule::ProcessingModule(std::string input_file, std::string output_file_hint, nlohmann::json parameters)
+            : d_parameters(parameters), d_input_file(input_file), d_output_file_hint(output_file_hint)
+        {
+            input_active = false;
+            d_is_streaming_input = false;
+        }
+        std::string ProcessingModule::getOutput() { return d_output_file; }
+        void ProcessingModule::setInputType(ModuleDataType type)
+        {
+            input_data_type = type;
+            d_is_streaming_input = type != DATA_FILE;
+            bool found = false;
+            for (auto &t : getInputTypes())
+                found |= t == type;
+            if (!found)
+                throw satdump_exception("Module input type not supported! (" + getIDM() + ") : " + std::to_string(type));
+        }
+        void ProcessingModule::setOutputType(ModuleDataType type)
+        {
+            output_data_type = type;
+            bool found = false;
+            for (auto &t : getOutputTypes())
+                found |= t == type;
+            if (!found)
+                throw satdump_exception("Module output type not supported!");
+        }
+        ModuleDataType ProcessingModule::getInputType() { return input_data_type; }
+        ModuleDataType ProcessingModule::getOutputType() { return output_data_type; }
+        void ProcessingModule::init() {}
+        void ProcessingModule::stop() {}
+        void ProcessingModule::drawUI(bool) {}
+        std::vector<ModuleEntry> modules_registry;
+        std::shared_ptr<ProcessingModule> getModuleInstance(std::string id, std::string input_file, std::string output_file_hint, nlohmann::json parameters)
+        { // module.cpp:123-129: first match
+            for (auto &m : modules_registry)
+                if (m.id == id)
+                    return m.inst(input_file, output_file_hint, parameters);
+            throw satdump_exception("Could not find module " + id);
+        }
+    }
+}
+
+using namespace satdump::pipeline;
+
+// Stand-in for a CPU module of the stock registry (psk_demod & co. are registered before the plugins' handlers fire,
+// module.cpp:91-121). It only says who it is: a job that ends up here was NOT taken over by the plugin.
+template <int WHICH>
+class CpuStandIn : public ProcessingModule
+{
+public:
+    CpuStandIn(std::string i, std::string o, nlohmann::json p) : ProcessingModule(i, o, p) {}
+    std::vector<ModuleDataType> getInputTypes() { return {DATA_FILE, DATA_STREAM, DATA_DSP_STREAM}; }
+    std::vector<ModuleDataType> getOutputTypes() { return {DATA_FILE, DATA_STREAM}; }
+    void process() { throw satdump_exception("cpu stand-in invoked"); }
+    void drawUI(bool) {}
+    static const char *name()
+    {
+        static const char *n[4] = {"psk_demod", "ccsds_conv_concat_decoder", "metop_ahrpt_decoder", "ccsds_simple_psk_decoder"};
+        return n[WHICH];
+    }
+    static std::string getID() { return name(); }
+    std::string getIDM() { return std::string("cpu:") + name(); }
+    static nlohmann::json getParams() { return {}; }
+    static std::shared_ptr<ProcessingModule> getInstance(std::string i, std::string o, nlohmann::json p) { return std::make_shared<CpuStandIn<WHICH>>(i, o, p); }
+};
+
+static int fail(const std::string &m)
+{
+    std::cerr << "minihost: " << m << std::endl;
+    return 2;
+}
+
+int main(int argc, char **argv)
+{
+    if (argc < 4)
+        return fail("usage: minihost <libsdhip.so> <plugin.so> list | run <job.json>");
+    // the C-ABI library first, globally, so that the plugin's sdhip_* references resolve (in a SatDump tree the plugin links it)
+    if (!dlopen(argv[1], RTLD_NOW | RTLD_GLOBAL))
+        return fail(std::string("dlopen ") + argv[1] + ": " + dlerror());
+    // src-core/core/plugin.cpp:15-35
+    void *dyn = dlopen(argv[2], RTLD_LAZY);
+    if (!dyn)
+        return fail(std::string("dlopen ") + argv[2] + ": " + dlerror());
+    void *create = dlsym(dyn, "loader");
+    if (!create)
+        return fail("plugin has no loader()");
+    std::shared_ptr<satdump::Plugin> plugin(reinterpret_cast<satdump::Plugin *(*)()>(create)());
+    plugin->init();
+    satdump::loaded_plugins[plugin->getID()] = plugin;
+    // module.cpp:91-121: core modules, then the plugins'
+    REGISTER_MODULE(CpuStandIn<0>);
+    REGISTER_MODULE(CpuStandIn<1>);
+    REGISTER_MODULE(CpuStandIn<3>);
+    satdump::eventBus->fire_event<RegisterModulesEvent>({modules_registry});
+    REGISTER_MODULE(CpuStandIn<2>); // metop_ahrpt_decoder comes from ANOTHER plugin, possibly loaded after ours (SURVEY 8b ordering caveat)
+    satdump::eventBus->fire_event<satdump::SatDumpStartedEvent>({}); // init.cpp:163
+
+    const std::string cmd = argv[3];
+    if (cmd == "list")
+    {
+        std::cout << plugin->getID();
+        for (auto &m : modules_registry)
+            std::cout << " " << m.id;
+        std::cout << std::endl;
+        return 0;
+    }
+    if (cmd != "run" || argc < 5)
+        return fail("unknown command");
+    nlohmann::json job;
+    {
+        std::ifstream f(argv[4]);
+        f >> job;
+    }
+    try
+    {
+        const std::string mode = job["mode"], input = job["input"], hint = job["output_hint"];
+        auto m1 = getModuleInstance(job["demod"]["module"], input, hint, job["demod"]["parameters"]);
+        nlohmann::json report;
+        report["demod_class"] = m1->getIDM();
+        std::shared_ptr<ProcessingModule> m2;
+        if (job.contains("decoder"))
+        {
+            m2 = getModuleInstance(job["decoder"]["module"], input, hint, job["decoder"]["parameters"]);
+            report["decoder_class"] = m2->getIDM();
+        }
+        if (job.value("instantiate_only", false))
+        {
+            std::cout << report.dump() << std::endl;
+            return 0;
+        }
+        if (mode == "file")
+        { // pipeline_run.cpp:121-180: one module after the other, the output file of one is the input of the next
+            m1->setInputType(DATA_FILE);
+            m1->setOutputType(DATA_FILE);
+            m1->init();
+            m1->process();
+            report["soft"] = m1->getOutput();
+            report["demod_stats"] = m1->getModuleStats();
+            if (m2)
+            {
+                m2 = getModuleInstance(job["decoder"]["module"], m1->getOutput(), hint, job["decoder"]["parameters"]);
+                m2->setInputType(DATA_FILE);
+                m2->setOutputType(DATA_FILE);
+                m2->init();
+                m2->process();
+                report["cadu"] = m2->getOutput();
+                report["decoder_stats"] = m2->getModuleStats();
+            }
+        }
+        else if (mode == "fifo" || mode == "dsp_stream")
+        {
+            if (!m2)
+                return fail("fifo / dsp_stream need a decoder");
+            std::thread feeder;
+            if (mode == "fifo")
+                m1->setInputType(DATA_FILE);
+            else
+            { // live_pipeline.cpp: the source's dsp::stream is the demodulator's input
+                m1->setInputType(DATA_DSP_STREAM);
+                m1->input_stream = std::make_shared<dsp::stream<complex_t>>();
+                m1->input_active = true;
+            }
+            // pipeline_run.cpp:72-104
+            m1->setOutputType(DATA_STREAM);
+            m1->output_fifo = std::make_shared<dsp::RingBuffer<uint8_t>>(1000000);
+            m2->input_fifo = m1->output_fifo;
+            m2->setInputType(DATA_STREAM);
+            m2->setOutputType(DATA_FILE);
+            m2->input_active = true;
+            m1->init();
+            m2->init();
+            std::thread module1_thread([&m1]() { m1->process(); });
+            std::thread module2_thread([&m2]() { m2->process(); });
+            if (mode == "dsp_stream")
+            {
+                const int chunk = job.value("source_buffer", 8192);
+                std::ifstream f(input, std::ios::binary);
+                while (f)
+                {
+                    f.read((char *)m1->input_stream->writeBuf, (std::streamsize)chunk * sizeof(complex_t));
+                    const int got = (int)(f.gcount() / sizeof(complex_t));
+                    if (got <= 0)
+                        break;
+                    if (!m1->input_stream->swap(got))
+                        break;
+                }
+                // let the demodulator take the last buffer, then end the stream like a stopped source does
+                std::this_thread::sleep_for(std::chrono::milliseconds(200));
+                m1->input_active = false;
+                m1->input_stream->stopWriter();
+                m1->input_stream->stopReader();
+                m1->stop();
+            }
+            if (module1_thread.joinable())
+                module1_thread.join();
+            while (m2->input_fifo->getReadable() > 0)
+                std::this_thread::sleep_for(std::chrono::milliseconds(10));
+            m2->input_active = false;
+            m2->input_fifo->stopReader();
+            m2->input_fifo->stopWriter();
+            m2->stop();
+            if (module2_thread.joinable())
+                module2_thread.join();
+            report["cadu"] = m2->getOutput();
+            report["demod_stats"] = m1->getModuleStats();
+            report["decoder_stats"] = m2->getModuleStats();
+        }
+        else
+            return fail("unknown mode " + mode);
+        std::cout << report.dump() << std::endl;
+    }
+    catch (const std::exception &e)
+    {
+        return fail(std::string("exception: ") + e.what());
+    }
+    return 0;
+}

@@ -1,0 +1,66 @@
+"""The plugin of plugin/sdhip_plugin.cpp EXECUTED by a host built from the reference's own headers (tests/minihost): loader(),
+init(), the RegisterModulesEvent / SatDumpStartedEvent handlers, the registry entries. No GPU here, so no process() call: the
+override must notice that there is no HIP device and leave the CPU modules in place (tests/test_plugin_minihost_gpu.py runs
+the modules)."""
+import json
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HOST = os.path.join(ROOT, "tests", "minihost", "_build", "minihost")
+PLUGIN = os.path.join(ROOT, "plugin", "_build", "libsdhip_support.so")
+LIB = os.path.join(ROOT, "satdump_amd", "lib", "libsdhip.so")
+
+
+@pytest.fixture(scope="module")
+def host():
+    if os.path.isdir("/root/reference/src-core"):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "plugin"), "all"], stdout=subprocess.DEVNULL)
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "tests", "minihost"), "all"], stdout=subprocess.DEVNULL)
+    if not (os.path.exists(HOST) and os.path.exists(PLUGIN)):
+        pytest.skip("minihost / plugin not built (needs the reference tree)")
+    return HOST
+
+
+def _run(host, *args, env=None):
+    e = dict(os.environ)
+    e.update(env or {})
+    return subprocess.run([host, LIB, PLUGIN, *args], capture_output=True, text=True, env=e, timeout=120)
+
+
+def test_plugin_loads_and_registers_its_modules(host):
+    p = _run(host, "list")
+    assert p.returncode == 0, p.stderr
+    ids = p.stdout.split()
+    assert ids[0] == "sdhip_support"
+    for m in ("psk_demod_hip", "ccsds_conv_concat_decoder_hip", "metop_ahrpt_decoder_hip", "ccsds_simple_psk_decoder_hip"):
+        assert m in ids[1:]
+    # new ids are appended behind the core modules, the stock ids stay first (first-match lookup, module.cpp:123-129)
+    assert ids.index("psk_demod") < ids.index("psk_demod_hip")
+
+
+def test_override_without_a_device_leaves_the_cpu_modules(host, tmp_path):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    job = {"mode": "file", "input": str(tmp_path / "x.cf32"), "output_hint": str(tmp_path / "out"), "instantiate_only": True,
+           "demod": {"module": "psk_demod", "parameters": {"samplerate": 6000000, "symbolrate": 2333333, "constellation": "qpsk", "rrc_alpha": 0.5, "pll_bw": 0.003}},
+           "decoder": {"module": "metop_ahrpt_decoder", "parameters": {"viterbi_outsync_after": 10, "viterbi_ber_thresold": 0.28}}}
+    jp = tmp_path / "job.json"
+    jp.write_text(json.dumps(job))
+    p = _run(host, "run", str(jp), env={"SDHIP_OVERRIDE": "1"})
+    assert p.returncode == 0, p.stderr
+    rep = json.loads(p.stdout.strip().splitlines()[-1])
+    assert rep["demod_class"] == "cpu:psk_demod" and rep["decoder_class"] == "cpu:metop_ahrpt_decoder"
+    # the explicit ids instantiate (constructor = parameter parsing only; init() is what needs the device)
+    job["demod"]["module"], job["decoder"]["module"] = "psk_demod_hip", "metop_ahrpt_decoder_hip"
+    jp.write_text(json.dumps(job))
+    rep = json.loads(_run(host, "run", str(jp)).stdout.strip().splitlines()[-1])
+    assert rep["demod_class"] == "psk_demod_hip" and rep["decoder_class"] == "metop_ahrpt_decoder_hip"
+    # mandatory keys raise the reference's own messages
+    del job["demod"]["parameters"]["pll_bw"]
+    jp.write_text(json.dumps(job))
+    p = _run(host, "run", str(jp))
+    assert p.returncode != 0 and "PLL BW parameter must be present!" in p.stderr
