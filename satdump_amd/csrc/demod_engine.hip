@@ -105,7 +105,7 @@ namespace sdhip
     struct VerdictOut
     {
         int nfail, inexact, rotated, overflow;
-        int forced, pad;
+        int forced, loose; // loose: accepted, but outside the stage's TIGHT window (drives the warm-up adaptation, not a re-run)
         long long total;
     };
     template <class S>
@@ -191,8 +191,8 @@ namespace sdhip
     }
     // symbol hand-off at an M&M boundary (see DemodEngine::process): skip[k] symbols dropped at the head of chunk k, extra[k-1]
     // look-ahead symbols of chunk k-1 appended
-    __global__ void k_mm_verdict(int K, const MmCert *spec, const MmCert *endst, const int *counts, double tol, int *skip, int *extra, VerdictOut *vo,
-                                 int *fails, int force)
+    __global__ void k_mm_verdict(int K, const MmCert *spec, const MmCert *endst, const int *counts, double tol, double tol_tight, int *skip, int *extra,
+                                 VerdictOut *vo, int *fails, int force)
     {
         const int k = (int)(blockIdx.x * blockDim.x + threadIdx.x);
         if (k >= K)
@@ -214,6 +214,8 @@ namespace sdhip
             const long long r = llround(d / om);
             if (fabs(d - (double)r * om) < tol && fabsf(a.omega - b.omega) < 1e-3f * fabsf(b.omega))
             {
+                if (fabs(d - (double)r * om) >= tol_tight)
+                    atomicAdd(&vo->loose, 1);
                 if (r == 0)
                     ok = true;
                 else if (r > 0 && r <= counts[2 * (k - 1) + 1])
@@ -597,18 +599,18 @@ namespace sdhip
                 SD_HIP(hipMemcpyAsync(h_vout.p, d_vout.p, sizeof(VerdictOut), hipMemcpyDeviceToHost, stream));
                 SD_HIP(hipStreamSynchronize(stream));
                 const int nf = h_vout.p->nfail;
-                if (nf == 0)
-                    break;
-                if (rounds == 0 && respecs < 8 && nf > std::max(4, K / 8))
+                if (rounds == 0 && respecs < 8 && nf + h_vout.p->loose > std::max(4, K / 8))
                 {
                     respecs++;
-                    if (respec(nf))
+                    if (respec(nf + h_vout.p->loose))
                     {
                         if (getenv("SDHIP_DEBUG"))
-                            fprintf(stderr, "[sdhip] %-6s %d of %d boundaries failed at first sight: stage re-launched with refined start values\n", stage, nf, K);
+                            fprintf(stderr, "[sdhip] %-6s %d of %d boundaries missed their (tight) window at first sight: stage re-launched\n", stage, nf + h_vout.p->loose, K);
                         continue;
                     }
                 }
+                if (nf == 0)
+                    break;
                 ++rounds;
                 reruns += (unsigned)nf;
                 specfix(d_fails.p, nf);
@@ -831,7 +833,10 @@ namespace sdhip
                 // float noise (measured, tools/twin/soft_parity.py and DESIGN.md 2: median 5e-7, p99 3e-6 rad) except while one of the
                 // sign detectors of the order-4/8 error has just disagreed (a kick of ~alpha that decays within a few hundred
                 // samples): such boundaries fail the window and their chunk is re-run from the exact state until it has merged.
-                const double tol_phase = env_int("SDHIP_COSTAS_TOL_URAD", 10) * 1e-6, tol_freq = env_int("SDHIP_COSTAS_TOL_NFREQ", 100) * 1e-9;
+                // The window is 1e-4 rad / 4e-7 rad/sample: the 0.04 % of boundaries between 1e-5 and 1e-4 rad (measured, MetOp, 196 k
+                // boundaries) are back under 1e-5 within ~2.3 loop time constants (a few hundred samples of a chunk of >= 10^4); re-running
+                // them bought nothing measurable and cost a second launch (1.2 ms of a 97 ms step).
+                const double tol_phase = env_int("SDHIP_COSTAS_TOL_URAD", 100) * 1e-6, tol_freq = env_int("SDHIP_COSTAS_TOL_NFREQ", 400) * 1e-9;
                 ChunkCkpt cos_ck;
                 auto costas_setup = [&](long long Wn) {
                     cos_p.est_len = (int)std::min<long long>(env_int("SDHIP_COSTAS_EST", 256), Wn / 2);
@@ -955,11 +960,18 @@ namespace sdhip
                 W = env_int("SDHIP_W_MM", W);
                 W = (W + 255) / 256 * 256;
                 ChunkGeom g;
-                // Hand-off window of an M&M boundary, in samples of timing: two trajectories of this loop on the same samples
-                // hover 3e-5 ... 1e-4 sample apart (the feedback is piecewise constant in mu through the arm index), which makes
+                // Hand-off windows of an M&M boundary, in samples of timing. Two trajectories of this loop on the same samples
+                // hover 3e-5 ... 3e-4 sample apart (the feedback is piecewise constant in mu through the arm index), which makes
                 // them pick different interpolator arms on 0.3-0.7 % of the symbols -- the floor of any time-parallel schedule.
-                // 2e-4 keeps a boundary's contribution inside that floor; boundaries outside are re-run from the exact state.
-                const double MM_TOL = getenv("SDHIP_MM_TOL_MICRO") ? env_int("SDHIP_MM_TOL_MICRO", 200) * 1e-6 : env_int("SDHIP_MM_TOL_MILLI", 0) * 1e-3 + (getenv("SDHIP_MM_TOL_MILLI") ? 0.0 : 2e-4);
+                //  * TIGHT (2e-4): a boundary inside it adds nothing to that floor. It is the yardstick of the warm-up length: when more
+                //    than an eighth of the boundaries miss it, the warm-up is doubled (respec below).
+                //  * RE-RUN (1e-3): a boundary outside it is re-run from the exact state (and stops as soon as it is back inside). Between
+                //    the two windows a chunk starts <= 1e-3 sample off and is on the floor again within a loop time constant (a few
+                //    hundred symbols of a chunk of thousands): measured on the bench streams, re-running those moves the 1e-5 fraction
+                //    in the fifth digit and costs a second launch whose slowest lane runs for milliseconds.
+                const double MM_TOL_TIGHT = 2e-4;
+                const double MM_TOL = getenv("SDHIP_MM_TOL_MICRO") ? env_int("SDHIP_MM_TOL_MICRO", 1000) * 1e-6
+                                                                  : (getenv("SDHIP_MM_TOL_MILLI") ? env_int("SDHIP_MM_TOL_MILLI", 1) * 1e-3 : 1e-3);
                 MmCert *ckp = nullptr;
                 int ck_per_chunk = 0;
                 auto mm_setup = [&](long long Wn) {
@@ -1001,8 +1013,8 @@ namespace sdhip
                 verify_fix(
                     "mm", g.K,
                     [&](VerdictOut *vo, int *fails, int force) {
-                        hipLaunchKernelGGL(k_mm_verdict, dim3((g.K + 255) / 256), dim3(256), 0, stream, g.K, d_mm_spec_c.p, d_mm_end_c.p, d_counts.p, MM_TOL, d_skip.p,
-                                           d_extra.p, vo, fails, force);
+                        hipLaunchKernelGGL(k_mm_verdict, dim3((g.K + 255) / 256), dim3(256), 0, stream, g.K, d_mm_spec_c.p, d_mm_end_c.p, d_counts.p, MM_TOL, std::min(MM_TOL, MM_TOL_TIGHT),
+                                           d_skip.p, d_extra.p, vo, fails, force);
                     },
                     [&](const int *list, int nr) {
                         if (getenv("SDHIP_DEBUG"))
