@@ -206,6 +206,14 @@ extern "C"
        7 Gardner(omega,gw,mu,gmu,lim) clock_recovery_gardner.cpp:33-124. Returns output sample count. */
     int64_t sdhip_op_block(int device, int kind, const float *params, const float *d_in, size_t n, float *d_out, size_t out_cap);
 
+    /* The coefficient tables the modules' blocks are constructed with, designed on the host exactly as the reference designs them
+       (double precision, float taps): kind 0 = dsp::firdes::root_raised_cosine(gain, fs, symrate, alpha, ntaps) firdes.cpp:34-78,
+       params[5]; kind 1 = the M&M interpolator bank, windowed_sinc + nuttall split over nfilt arms (clock_recovery_mm.cpp:22-24,
+       window.cpp:9-50, polyphase_bank.cpp:6-39), params {nfilt, ntaps}, dims = {nfilt, taps per arm}; kind 2 = the rational
+       resampler's bank (design_resampler_filter_float, firdes.cpp:276-301), params {interp, decim}, dims = {interp and decim
+       reduced by their gcd, taps per arm}. No device is touched. Returns the number of floats written, <0 on error. */
+    int64_t sdhip_design(int kind, const double *params, float *out, size_t cap, int *dims);
+
     /* ---- measurement ------------------------------------------------------------------ */
     /* Per-kernel timing with HIP events recorded on the launch stream around every kernel launch of the
        library (process-wide; off by default). sdhip_prof_get(idx, ...) returns the number of distinct kernels

@@ -1217,6 +1217,45 @@ extern "C"
         return 0;
     }
 
+    // the coefficient tables the modules are built with (host only: no device involved)
+    int64_t sdhip_design(int kind, const double *params, float *out, size_t cap, int *dims)
+    {
+        SD_GUARD_BEGIN
+        std::vector<float> t;
+        int d0 = 0, d1 = 0;
+        if (kind == 0)
+        {
+            t = design::rrc(params[0], params[1], params[2], params[3], (int)params[4]);
+            d0 = (int)t.size();
+        }
+        else if (kind == 1)
+        {
+            d0 = (int)params[0];
+            d1 = design::mm_bank((int)params[0], (int)params[1], t);
+        }
+        else if (kind == 2)
+        {
+            unsigned ip = (unsigned)params[0], dc = (unsigned)params[1];
+            const int nt = design::resampler_bank(ip, dc, t);
+            d0 = (int)ip;
+            d1 = (int)dc;
+            if (dims)
+                dims[2] = nt;
+        }
+        else
+            throw HipError("unknown table kind");
+        if (t.size() > cap)
+            throw HipError("output too small");
+        memcpy(out, t.data(), t.size() * sizeof(float));
+        if (dims)
+        {
+            dims[0] = d0;
+            dims[1] = d1;
+        }
+        return (int64_t)t.size();
+        SD_GUARD_END(-1)
+    }
+
     // single blocks, exact sequential semantics (one lane): arithmetic parity of each kernel body
     int64_t sdhip_op_block(int device, int kind, const float *params, const float *d_in, size_t n, float *d_out, size_t out_cap)
     {

@@ -17,47 +17,63 @@ namespace sdhip
     {
         constexpr double PI = 3.14159265358979323846;
 
+        // ---- root-raised-cosine matched filter -----------------------------------------------------------------
+        // The pulse h(t) = [cos((1+a) pi t) + sin((1-a) pi t) / (4 a t)] * 4a / (pi ((4 a t)^2 - 1)), t in symbols, sampled at
+        // t = k / sps for k = -(n-1)/2 .. (n-1)/2, each tap rounded to float, then all of them scaled to unit sum. The reference
+        // evaluates it in double in one particular operand order (firdes.cpp:34-78); the taps here must be those floats bit for
+        // bit, so each sub-expression below keeps the reference's association -- e.g. (pi * k) / sps, never pi * (k / sps) --
+        // while the organisation is ours: one function per branch of the formula, the pulse's even symmetry used to evaluate
+        // only one half (sin and cos are odd / even to the last bit, so the mirrored tap is the same float), the centre tap on
+        // its own.
+        struct RrcPulse
+        {
+            double sps, a; // samples per symbol, roll-off
+            // regular point k != 0 (the denominator (4 a k / sps)^2 - 1 is away from zero)
+            double regular(double k, double pole_term) const
+            {
+                const double ph = PI * k / sps;
+                const double top = std::cos((1 + a) * ph) + std::sin((1 - a) * ph) / (4 * a * k / sps);
+                return 4 * a * top / (pole_term * PI);
+            }
+            // centre: sin(x)/x -> its limit
+            double centre(double pole_term) const
+            {
+                const double ph = PI * 0.0 / sps;
+                const double top = std::cos((1 + a) * ph) + (1 - a) * PI / (4 * a);
+                return 4 * a * top / (pole_term * PI);
+            }
+            // on the pole 4 a k / sps = +-1 the closed form is 0/0: l'Hopital's form, as the reference writes it
+            double on_pole(double k) const
+            {
+                const double ph = PI * k / sps;
+                const double lo = (1 - a) * ph, hi = (1 + a) * ph;
+                const double top = std::sin(hi) * (1 + a) * PI - std::cos(lo) * ((1 - a) * PI * sps) / (4 * a * k) + std::sin(lo) * sps * sps / (4 * a * k * k);
+                return 4 * a * top / (-32 * PI * a * a * k / sps);
+            }
+            float tap(int k) const
+            {
+                const double kk = (double)k;
+                const double q = 4 * a * kk / sps;
+                const double pole_term = q * q - 1;
+                if (std::fabs(pole_term) < 0.000001)
+                    return a == 1 ? -1.0f : (float)on_pole(kk);
+                return (float)(k == 0 ? centre(pole_term) : regular(kk, pole_term));
+            }
+        };
         inline std::vector<float> rrc(double gain, double fs, double symrate, double alpha, int ntaps)
         {
-            ntaps |= 1;
-            const double spb = fs / symrate;
-            std::vector<float> taps(ntaps);
-            double scale = 0;
-            for (int i = 0; i < ntaps; i++)
-            {
-                double x1, x2, x3, num, den;
-                const double xindx = i - ntaps / 2;
-                x1 = PI * xindx / spb;
-                x2 = 4 * alpha * xindx / spb;
-                x3 = x2 * x2 - 1;
-                if (std::fabs(x3) >= 0.000001)
-                {
-                    if (i != ntaps / 2)
-                        num = std::cos((1 + alpha) * x1) + std::sin((1 - alpha) * x1) / (4 * alpha * xindx / spb);
-                    else
-                        num = std::cos((1 + alpha) * x1) + (1 - alpha) * PI / (4 * alpha);
-                    den = x3 * PI;
-                }
-                else
-                {
-                    if (alpha == 1)
-                    {
-                        taps[i] = -1;
-                        scale += taps[i];
-                        continue;
-                    }
-                    x3 = (1 - alpha) * x1;
-                    x2 = (1 + alpha) * x1;
-                    num = (std::sin(x2) * (1 + alpha) * PI - std::cos(x3) * ((1 - alpha) * PI * spb) / (4 * alpha * xindx) +
-                           std::sin(x3) * spb * spb / (4 * alpha * xindx * xindx));
-                    den = -32 * PI * alpha * alpha * xindx / spb;
-                }
-                taps[i] = (float)(4 * alpha * num / den);
-                scale += taps[i];
-            }
-            for (int i = 0; i < ntaps; i++)
-                taps[i] = (float)(taps[i] * gain / scale);
-            return taps;
+            const int n = ntaps | 1, mid = n / 2;
+            const RrcPulse pulse{fs / symrate, alpha};
+            std::vector<float> h(n);
+            h[mid] = pulse.tap(0);
+            for (int k = 1; k <= mid; k++)
+                h[mid - k] = h[mid + k] = pulse.tap(-k); // evaluated on the negative side, where the reference's loop meets the value first
+            double sum = 0; // the reference adds the float taps up in index order, in double
+            for (float v : h)
+                sum += v;
+            for (float &v : h)
+                v = (float)(v * gain / sum);
+            return h;
         }
 
         // bank[(nfilt-1) - (i % nfilt)][i / nfilt] = proto[i]; returns taps per phase
@@ -97,77 +113,85 @@ namespace sdhip
             return polyphase(proto, nfilt, bank);
         }
 
-        inline double izero(double x)
-        {
-            double sum, u, halfx, temp;
-            int n;
-            sum = u = n = 1;
-            halfx = x / 2.0;
-            do
-            {
-                temp = halfx / (double)n;
-                n += 1;
-                temp *= temp;
-                u *= temp;
-                sum += u;
-            } while (u >= 1E-21 * sum);
-            return sum;
-        }
+        // ---- rational resampler prototype -----------------------------------------------------------------------
+        // Kaiser-windowed sinc low-pass at the narrower of the two Nyquist bands (design_resampler_filter_float -> low_pass(...,
+        // WIN_KAISER, beta = 7), firdes.cpp:276-301, 80-120; Kaiser window fft/window.cpp). float / double conversions sit where the
+        // reference's declarations put them: they decide the tap COUNT (a truncation) and the last bits of every tap.
 
-        // design_resampler_filter_float + low_pass (Kaiser beta 7, fractional_bw 0.4); interp/decim reduced by their gcd
+        // I0(x) by its power series sum_k ((x/2)^k / k!)^2, terms added until they vanish against the sum
+        inline double bessel_i0(double x)
+        {
+            const double h = x / 2.0;
+            double term = 1.0, total = 1.0;
+            for (int k = 1;; k++)
+            {
+                double q = h / (double)k;
+                q *= q;
+                term *= q;
+                total += term;
+                if (!(term >= 1E-21 * total))
+                    return total;
+            }
+        }
+        // w[i] = I0(beta sqrt(1 - (2i/(n-1) - 1)^2)) / I0(beta); the end points are 1 / I0(beta) by definition
+        inline std::vector<float> kaiser_window(int n, double beta)
+        {
+            const double norm = 1.0 / bessel_i0(beta), step = 1.0 / ((double)(n - 1));
+            std::vector<float> w(n, (float)norm);
+            for (int i = 1; i + 1 < n; i++)
+            {
+                const double u = 2 * i * step - 1;
+                w[i] = (float)(bessel_i0(beta * std::sqrt(1.0 - u * u)) * norm);
+            }
+            return w;
+        }
+        // length from the window's attenuation (beta / 0.1102 + 8.7 dB) and the transition width, forced odd; ideal low-pass
+        // sin(n wc) / (n pi) under the window; DC gain normalised to `gain`
+        inline std::vector<float> kaiser_lowpass(double gain, double fs, double cutoff, double width, double beta)
+        {
+            int n = (int)((beta / 0.1102 + 8.7) * fs / (22.0 * width));
+            n |= 1;
+            const std::vector<float> w = kaiser_window(n, beta);
+            const int half = (n - 1) / 2;
+            const double wc = 2 * PI * cutoff / fs;
+            std::vector<float> h(n);
+            h[half] = (float)(wc / PI * w[half]);
+            for (int m = 1; m <= half; m++)
+            {
+                h[half + m] = (float)(std::sin(m * wc) / (m * PI) * w[half + m]);
+                h[half - m] = (float)(std::sin(-m * wc) / (-m * PI) * w[half - m]);
+            }
+            double dc = h[half];
+            for (int m = 1; m <= half; m++)
+                dc += 2 * h[half + m];
+            const double k = gain / dc;
+            for (float &v : h)
+                v = (float)(v * k);
+            return h;
+        }
+        // interp / decim reduced by their gcd; pass band 0.4 of the narrower Nyquist band, transition up to that band's edge;
+        // the bank is the polyphase split of the prototype over `interp` arms
         inline int resampler_bank(unsigned &interpolation, unsigned &decimation, std::vector<float> &bank)
         {
             const unsigned g = std::gcd(interpolation, decimation);
             interpolation /= g;
             decimation /= g;
-            const float fractional_bw = 0.4f;
-            float beta = 7.0;
-            float halfband = 0.5;
-            float rate = float(interpolation) / float(decimation);
-            float trans_width, mid_transition_band;
-            if (rate >= 1.0)
+            const float passband = 0.4f, nyquist = 0.5f, beta = 7.0f;
+            const float ratio = float(interpolation) / float(decimation);
+            const float shrink = ratio >= 1.0 ? 1.0f : ratio; // decimating: everything scales with the output band
+            float width, centre;
+            if (ratio >= 1.0)
             {
-                trans_width = halfband - fractional_bw;
-                mid_transition_band = (float)(halfband - trans_width / 2.0);
+                width = nyquist - passband;
+                centre = (float)(nyquist - width / 2.0);
             }
             else
             {
-                trans_width = rate * (halfband - fractional_bw);
-                mid_transition_band = (float)(rate * halfband - trans_width / 2.0);
+                width = shrink * (nyquist - passband);
+                centre = (float)(shrink * nyquist - width / 2.0);
             }
-            double gain = interpolation, sampling_freq = interpolation, cutoff_freq = mid_transition_band, transition_width = trans_width;
-            const double att = (double)beta / 0.1102 + 8.7;
-            int ntaps = (int)(att * sampling_freq / (22.0 * transition_width));
-            if ((ntaps & 1) == 0)
-                ntaps++;
-            std::vector<float> taps(ntaps), w(ntaps);
-            {
-                const double IBeta = 1.0 / izero(beta);
-                const double inm1 = 1.0 / ((double)(ntaps - 1));
-                w[0] = (float)IBeta;
-                for (int i = 1; i < ntaps - 1; i++)
-                {
-                    const double temp = 2 * i * inm1 - 1;
-                    w[i] = (float)(izero(beta * std::sqrt(1.0 - temp * temp)) * IBeta);
-                }
-                w[ntaps - 1] = (float)IBeta;
-            }
-            const int M = (ntaps - 1) / 2;
-            const double fwT0 = 2 * PI * cutoff_freq / sampling_freq;
-            for (int n = -M; n <= M; n++)
-            {
-                if (n == 0)
-                    taps[n + M] = (float)(fwT0 / PI * w[n + M]);
-                else
-                    taps[n + M] = (float)(std::sin(n * fwT0) / (n * PI) * w[n + M]);
-            }
-            double fmax = taps[0 + M];
-            for (int n = 1; n <= M; n++)
-                fmax += 2 * taps[n + M];
-            gain /= fmax;
-            for (int i = 0; i < ntaps; i++)
-                taps[i] = (float)(taps[i] * gain);
-            return polyphase(taps, (int)interpolation, bank);
+            const std::vector<float> proto = kaiser_lowpass((double)interpolation, (double)interpolation, centre, width, beta);
+            return polyphase(proto, (int)interpolation, bank);
         }
 
         inline void costas_gains(float loop_bw, float &alpha, float &beta)

@@ -52,6 +52,48 @@ def test_struct_mirrors_match_the_header():
     assert [f for f, _ in pyref.DemodCfg._fields_] == fields("sdhip_demod_cfg")
 
 
+def test_product_filter_design_against_the_reference_tables():
+    """The PRODUCT's designers (satdump_amd/csrc/dsp_design.h, through sdhip_design of the real libsdhip.so -- host code, no device)
+    against tests/golden/taps.npz, the tables the compiled reference built (tests/golden/make_golden.py): bit for bit."""
+    import ctypes as C
+    import numpy as np
+    from satdump_amd import capi
+    L = capi.lib()
+    L.sdhip_design.restype = C.c_int64
+    L.sdhip_design.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+    d = np.load(os.path.join(ROOT, "tests", "golden", "taps.npz"))
+
+    def design(kind, params):
+        p = np.asarray(params, dtype=np.float64)
+        out = np.zeros(1 << 16, dtype=np.float32)
+        dims = np.zeros(3, dtype=np.int32)
+        n = L.sdhip_design(kind, p.ctypes.data, out.ctypes.data, len(out), dims.ctypes.data)
+        assert n > 0, capi.last_error()
+        return out[:n], dims
+
+    for key, fs, sr in (("rrc_goes", 2.7e6, 927000), ("rrc_metop", 6e6, 2333333)):
+        t, _ = design(0, [1, fs, sr, 0.5, 31])
+        assert np.array_equal(t.view(np.uint32), d[key].view(np.uint32)), key
+    t, dims = design(1, [128, 8])
+    assert list(dims[:2]) == [128, 8] and np.array_equal(t.reshape(128, 8).view(np.uint32), d["mm"].view(np.uint32))
+    t, dims = design(2, [2700000, 3000000])
+    assert list(dims[:2]) == list(d["resamp_ratio"]) and np.array_equal(t.reshape(dims[0], dims[2]).view(np.uint32), d["resamp"].view(np.uint32))
+    # the pole of the RRC formula (4 alpha k / sps = 1) and the alpha = 1 branch evaluate
+    t, _ = design(0, [1, 4.0, 1.0, 0.5, 33])
+    assert np.all(np.isfinite(t)) and abs(float(t.sum()) - 1.0) < 1e-5 and np.array_equal(t, t[::-1])
+    # and, where the compiled reference is at hand, a sweep of parameter sets against its own designers
+    from oracle import pyref
+    if pyref.ref_available():
+        R = pyref.ref()
+        for fs, sr, al, nt in [(4.0, 1.0, 0.5, 33), (4.0, 1.0, 1.0, 33), (8.0, 1.0, 0.25, 65), (30e6, 15e6, 0.35, 31), (2.5e6, 1.2e6, 0.6, 51), (6e6, 2333333, 0.2, 361)]:
+            t, _ = design(0, [1, fs, sr, al, nt])
+            assert np.array_equal(t.view(np.uint32), R.rrc_taps(fs, sr, al, nt).view(np.uint32)), (fs, sr, al, nt)
+        for ip, dc in [(2700000, 3000000), (5, 7), (7, 5), (3, 4), (99, 100), (10, 17)]:
+            t, dims = design(2, [ip, dc])
+            bank, ir, dr = R.resamp_bank(ip, dc)
+            assert [ir, dr] == list(dims[:2]) and np.array_equal(t.reshape(dims[0], dims[2]).view(np.uint32), bank.view(np.uint32)), (ip, dc)
+
+
 def test_fails_loudly_without_gpu():
     import torch
     from satdump_amd import capi
