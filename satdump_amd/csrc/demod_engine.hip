@@ -833,10 +833,14 @@ namespace sdhip
                 // float noise (measured, tools/twin/soft_parity.py and DESIGN.md 2: median 5e-7, p99 3e-6 rad) except while one of the
                 // sign detectors of the order-4/8 error has just disagreed (a kick of ~alpha that decays within a few hundred
                 // samples): such boundaries fail the window and their chunk is re-run from the exact state until it has merged.
-                // The window is 1e-4 rad / 4e-7 rad/sample: the 0.04 % of boundaries between 1e-5 and 1e-4 rad (measured, MetOp, 196 k
-                // boundaries) are back under 1e-5 within ~2.3 loop time constants (a few hundred samples of a chunk of >= 10^4); re-running
-                // them bought nothing measurable and cost a second launch (1.2 ms of a 97 ms step).
-                const double tol_phase = env_int("SDHIP_COSTAS_TOL_URAD", 100) * 1e-6, tol_freq = env_int("SDHIP_COSTAS_TOL_NFREQ", 400) * 1e-9;
+                // RE-RUN window: 1e-2 rad / 4e-5 rad/sample. Boundaries outside 1e-5 rad are the ones where one of the two
+                // trajectories was kicked shortly before the boundary (sign detectors disagreeing, see above): measured on MetOp,
+                // 196 k boundaries per 16 GiB step: 71 beyond 1e-5 rad, 54 beyond 1e-4. Each decays under 1e-5 within
+                // ~tau ln(d / 1e-5) samples (tau ~ 230: <= 1600 samples of a chunk of >= 10^4 at d = 1e-2), so letting them stand
+                // costs ~5e-5 of the symbols a transient below the loop's own phase jitter, while re-running them costs a second
+                // launch whose slowest lane runs alone for over a millisecond (measured: +1.2 ms on a 96 ms step). They are counted
+                // (chunks_inexact); anything beyond the window -- a lane that has not locked -- is re-run from the exact state.
+                const double tol_phase = env_int("SDHIP_COSTAS_TOL_URAD", 10000) * 1e-6, tol_freq = env_int("SDHIP_COSTAS_TOL_NFREQ", 40000) * 1e-9;
                 ChunkCkpt cos_ck;
                 auto costas_setup = [&](long long Wn) {
                     cos_p.est_len = (int)std::min<long long>(env_int("SDHIP_COSTAS_EST", 256), Wn / 2);
@@ -965,13 +969,14 @@ namespace sdhip
                 // them pick different interpolator arms on 0.3-0.7 % of the symbols -- the floor of any time-parallel schedule.
                 //  * TIGHT (2e-4): a boundary inside it adds nothing to that floor. It is the yardstick of the warm-up length: when more
                 //    than an eighth of the boundaries miss it, the warm-up is doubled (respec below).
-                //  * RE-RUN (1e-3): a boundary outside it is re-run from the exact state (and stops as soon as it is back inside). Between
-                //    the two windows a chunk starts <= 1e-3 sample off and is on the floor again within a loop time constant (a few
-                //    hundred symbols of a chunk of thousands): measured on the bench streams, re-running those moves the 1e-5 fraction
-                //    in the fifth digit and costs a second launch whose slowest lane runs for milliseconds.
+                //  * RE-RUN (5e-3): a boundary outside it is re-run from the exact state (and stops as soon as it is back inside). Between
+                //    the two windows a chunk starts <= 5e-3 sample off and is on the floor again within a loop time constant (a few
+                //    hundred symbols of a chunk of thousands): measured on MetOp, 14 of 65 k boundaries per step lie between 1e-3 and
+                //    the re-run window; re-running them moves the 1e-5 fraction in the sixth digit and costs a second launch whose
+                //    slowest lane runs alone for milliseconds.
                 const double MM_TOL_TIGHT = 2e-4;
-                const double MM_TOL = getenv("SDHIP_MM_TOL_MICRO") ? env_int("SDHIP_MM_TOL_MICRO", 1000) * 1e-6
-                                                                  : (getenv("SDHIP_MM_TOL_MILLI") ? env_int("SDHIP_MM_TOL_MILLI", 1) * 1e-3 : 1e-3);
+                const double MM_TOL = getenv("SDHIP_MM_TOL_MICRO") ? env_int("SDHIP_MM_TOL_MICRO", 5000) * 1e-6
+                                                                  : (getenv("SDHIP_MM_TOL_MILLI") ? env_int("SDHIP_MM_TOL_MILLI", 5) * 1e-3 : 5e-3);
                 MmCert *ckp = nullptr;
                 int ck_per_chunk = 0;
                 auto mm_setup = [&](long long Wn) {

@@ -80,6 +80,41 @@ namespace sdhip
         return sd_sinf_poly(x * sgn, x * x, (n & 2) != 0, n ^ 1);
     }
 
+    // cosf(y) and sinf(y) of the SAME argument, results bit-identical to sd_cosf(y) / sd_sinf(y), without a branch: both
+    // functions reduce y the same way (n, reduced x, quadrant sign, table), so one reduction serves both, the sine and the
+    // cosine polynomial are each evaluated once, and the quadrant decides which result is which. The |y| < pi/4 entry of
+    // glibc is the general path with n = 0 (fma(-0.0, hpi, x) == x), only |y| < 2^-12 returns y / 1.0f outright. Table 1 is
+    // table 0 with the cosine coefficients negated: fma and the final conversion commute with negation, so the negated table
+    // is the negated result. (The lanes of a wave sit at unrelated phases: the two-function form ran all four polynomial
+    // branches for every sample, ~70 f64 and ~70 f32 VALU instructions plus ~80 scalar/branch instructions per sample.)
+    __device__ __forceinline__ void sd_sincosf(float y, float &sn, float &cs)
+    {
+        const double x0 = (double)y;
+        int n;
+        const double xr = sd_reduce_fast(x0, &n);
+        const double xs = ((n + 1) & 2) ? -xr : xr; // sign[] = {1,-1,-1,1} by n & 3
+        const double x2 = xr * xr;
+        // sine polynomial
+        const double s1c = -0x1.555545995a603p-3, s2c = 0x1.1107605230bc4p-7, s3c = -0x1.994eb3774cf24p-13;
+        const double x3 = xs * x2;
+        const double s1 = fma(x2, s3c, s2c);
+        const double x7 = x3 * x2;
+        const double sp = fma(x7, s1, fma(x3, s1c, xs));
+        // cosine polynomial (table 0), negated for table 1
+        const double c1c = -0x1.ffffffd0c621cp-2, c2c = 0x1.55553e1068f19p-5, c3c = -0x1.6c087e89a359dp-10, c4c = 0x1.99343027bf8c3p-16;
+        const double x4 = x2 * x2;
+        const double c2 = fma(x2, c4c, c3c);
+        const double c1 = fma(x2, c1c, 0x1p0);
+        const double x6 = x4 * x2;
+        const double cp0 = fma(x6, c2, fma(x4, c2c, c1));
+        const float fs = (float)sp, fc0 = (float)cp0;
+        const float fc = (n & 2) ? -fc0 : fc0;
+        const bool odd = (n & 1) != 0;
+        const bool tiny = sd_abstop12(y) < sd_abstop12(0x1p-12f);
+        sn = tiny ? y : (odd ? fc : fs);
+        cs = tiny ? 1.0f : (odd ? fs : fc);
+    }
+
     // =============================================================================================
     // format conversion
     // =============================================================================================
@@ -705,7 +740,8 @@ namespace sdhip
         __device__ static __forceinline__ cf32 step(S &s, const P &p, const cf32 v)
         {
             // CostasLoopBlock::work, costas_loop.cpp:23-65
-            const float cs = sd_cosf(-s.phase), sn = sd_sinf(-s.phase);
+            float cs, sn; // cosf(-phase), sinf(-phase): two libm calls in the reference (costas_loop.cpp:26), one fused evaluation here
+            sd_sincosf(-s.phase, sn, cs);
             const float tr = (v.re * cs) - (v.im * sn);
             const float ti = (v.im * cs) + (v.re * sn);
             float error;
@@ -724,11 +760,22 @@ namespace sdhip
             error = 0.5f * (fabsf(error + 1.0f) - fabsf(error - 1.0f)); // branchless_clip(error, 1.0), block.cpp:5
             s.freq = s.freq + p.beta * error;
             s.phase = s.phase + (s.freq + p.alpha * error);
+            // while (phase > 2 pi) phase -= 2 pi; while (phase < -2 pi) phase += 2 pi; -- float against the double constant
+            // (costas_loop.cpp:55-58). |freq| <= 1 and |alpha * error| <= alpha keep one step well under 2 pi, so each loop runs at
+            // most once: selects instead of branches, the loops themselves stay behind a test that never fires in practice.
             const double twopi = 2 * 3.14159265358979323846;
-            while ((double)s.phase > twopi)
-                s.phase = (float)((double)s.phase - twopi);
-            while ((double)s.phase < -twopi)
-                s.phase = (float)((double)s.phase + twopi);
+            {
+                const double pd = (double)s.phase;
+                const float dn = (float)(pd - twopi), up = (float)(pd + twopi);
+                s.phase = pd > twopi ? dn : (pd < -twopi ? up : s.phase);
+            }
+            if (__builtin_expect((double)s.phase > twopi || (double)s.phase < -twopi, 0))
+            {
+                while ((double)s.phase > twopi)
+                    s.phase = (float)((double)s.phase - twopi);
+                while ((double)s.phase < -twopi)
+                    s.phase = (float)((double)s.phase + twopi);
+            }
             if (s.freq > p.fmax)
                 s.freq = p.fmax;
             if (s.freq < p.fmin)

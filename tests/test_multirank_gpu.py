@@ -31,7 +31,9 @@ def test_two_ranks_shard_one_recording_on_the_engines(tmp_path, workload, frames
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    common = ["--workload", workload, "--frames", str(frames), "--steps", "1", "--warmup", "1", "--cpu-samples", "0"]
+    # one pass, no warm-up pass: the single-rank run then is ALSO a cold start at sample 0 (with a warm-up pass its engines would
+    # carry their lock over from the end of the periodic recording and decode the very first frames too)
+    common = ["--workload", workload, "--frames", str(frames), "--steps", "1", "--warmup", "0", "--cpu-samples", "0"]
     one = _run([sys.executable, "bench.py", "--gpus", "1", "--blocks", "2", "--dump", str(tmp_path / "one")] + common, {})
     two = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
                 "bench.py", "--gpus", "2", "--dump", str(tmp_path / "two")] + common, {"SDHIP_BENCH_SHARE_GPU": "1"})
