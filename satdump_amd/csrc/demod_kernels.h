@@ -41,12 +41,25 @@ namespace sdhip
     // ---- format conversion (baseband_interface.h:172-199) + iq_swap --------------------------------
     void launch_convert(const void *in, int fmt, int iq_swap, long long n, cf32 *out, hipStream_t st);
 
-    // ---- DC block -- not speculated yet: sequential single lane (correct_iq.cpp:27-31) ---------------
+    // ---- DC block (correct_iq.cpp:27-31): acc = acc * (1 - alpha) + x * alpha; y = x - acc, alpha = 1e-4 ------------
     struct DcState
     {
         float acc_re, acc_im;
     };
+    // one sequential lane: exact mode and the unit op (bit for bit the reference)
     void launch_dcblock_seq(const cf32 *x, cf32 *y, long long n, DcState *state, hipStream_t st);
+    // chunk-parallel: the recurrence is linear, so the accumulator at every chunk start follows from an affine scan evaluated
+    // in double (launch_dc_partial: per chunk B_k = sum beta^(len-1-i) alpha x_i; the host chains acc_{k+1} = beta^len acc_k +
+    // B_k over the K chunks); a lane per chunk then runs the reference's float recurrence from that start value
+    // (launch_dcblock). The float trajectory wanders ~2e-6 |acc| (rms) around the exact-arithmetic one (two roundings of
+    // 3e-8 |acc| per step, remembered for 1/alpha steps), so a boundary is certified within 1e-5 |acc|, not bit for bit.
+    struct DcParams
+    {
+        const DcState *starts; // accumulator at the start of every chunk
+    };
+    void launch_dc_partial(const cf32 *x, const ChunkGeom &g, double *partial /* 2 doubles per chunk */, hipStream_t st);
+    void launch_dcblock(const cf32 *x, cf32 *y, const ChunkGeom &g, const DcParams &p, const DcState *start0, DcState *spec, DcState *endst, const int *redo,
+                        int nredo, hipStream_t st);
 
     // ---- rational resampler (rational_resampler.cpp:43-64), fully parallel ---------------------------
     // out[m] for m in [0, nout): global output index m0+m; input index/phase follow inc=(m*decim)/interp, ctr=(m*decim)%interp

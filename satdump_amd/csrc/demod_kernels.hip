@@ -673,7 +673,7 @@ namespace sdhip
         using P = AgcParams;
         using S = AgcState;
         static constexpr int DEPTH = 4; // blocks per load group (256 bytes); two groups in flight
-        __device__ static __forceinline__ S init(const P &p) { return S{p.init_gain}; }
+        __device__ static __forceinline__ S init(const P &p, int) { return S{p.init_gain}; }
         // early exit of a re-run lane (CKPT): is state a on the trajectory that left checkpoint b? (the AGC certificate's own rule)
         __device__ static __forceinline__ bool close(const S &a, const S &b, float tol_a, float) { return fabsf(a.gain - b.gain) <= tol_a * fabsf(b.gain); }
         __device__ static __forceinline__ void prewarm(S &, const P &, const cf32 *, long long) {}
@@ -695,7 +695,7 @@ namespace sdhip
         using P = CostasParams;
         using S = CostasState;
         static constexpr int DEPTH = 2; // blocks per load group (one 128-byte line); two groups in flight
-        __device__ static __forceinline__ S init(const P &p) { return S{0.0f, p.init_freq}; }
+        __device__ static __forceinline__ S init(const P &p, int) { return S{0.0f, p.init_freq}; }
         // early exit of a re-run lane (CKPT): same frame (the engine aligns a re-run with the speculative run's frame), phase
         // compared modulo the loop's own 2 pi wrap, the Costas certificate's windows
         __device__ static __forceinline__ bool close(const S &a, const S &b, float tol_phase, float tol_freq)
@@ -781,6 +781,27 @@ namespace sdhip
             if (s.freq < p.fmin)
                 s.freq = p.fmin;
             return cf32{tr, ti};
+        }
+    };
+
+    struct DcStage
+    {
+        using P = DcParams;
+        using S = DcState;
+        static constexpr int DEPTH = 4;
+        __device__ static __forceinline__ S init(const P &p, int k) { return p.starts[k]; } // the scan's value at this chunk's start
+        __device__ static __forceinline__ bool close(const S &a, const S &b, float tol, float)
+        {
+            const float m = fmaxf(fabsf(b.acc_re), fabsf(b.acc_im));
+            return fabsf(a.acc_re - b.acc_re) <= tol * m && fabsf(a.acc_im - b.acc_im) <= tol * m;
+        }
+        __device__ static __forceinline__ void prewarm(S &, const P &, const cf32 *, long long) {}
+        __device__ static __forceinline__ cf32 step(S &s, const P &, const cf32 v)
+        { // CorrectIQBlock<complex_t>::work, correct_iq.cpp:27-31 (alpha = 1e-4f, beta = 1.0f - alpha)
+            const float alpha = 0.0001f, beta = 1.0f - 0.0001f;
+            s.acc_re = s.acc_re * beta + v.re * alpha;
+            s.acc_im = s.acc_im * beta + v.im * alpha;
+            return cf32{v.re - s.acc_re, v.im - s.acc_im};
         }
     };
 
@@ -919,7 +940,7 @@ namespace sdhip
                 s = *start0;
             else
             {
-                s = Stage::init(p);
+                s = Stage::init(p, k);
                 const long long b = chunk_begin(g, k);
                 Stage::prewarm(s, p, x, b - g.W);
                 run_range<Stage>(s, p, x, y, b - g.W, b, false);
@@ -964,6 +985,60 @@ namespace sdhip
         }
     }
 
+    // B_k = sum over the chunk of beta^(len-1-i) * alpha * x_i, in double: thread t takes the samples i = t (mod 256) -- coalesced --
+    // with the weight advanced by beta^-256 from one to the next (the exponent only spans the chunk, a few 10^4)
+    __global__ __launch_bounds__(256) void k_dc_partial(const cf32 *x, ChunkGeom g, double *partial)
+    {
+        __shared__ double sr[256], si[256];
+        const int k = (int)blockIdx.x, t = (int)threadIdx.x;
+        const long long b = chunk_begin(g, k), e = chunk_end(g, k);
+        const double beta = (double)(1.0f - 0.0001f), alpha = (double)0.0001f;
+        const double up = pow(beta, -256.0);
+        double ar = 0, ai = 0;
+        if (b + t < e)
+        {
+            double w = pow(beta, (double)(e - 1 - (b + t))) * alpha;
+            for (long long i = b + t; i < e; i += 256)
+            {
+                const cf32 v = x[i];
+                ar += w * (double)v.re;
+                ai += w * (double)v.im;
+                w *= up; // i + 256 is 256 steps closer to the chunk end
+            }
+        }
+        sr[t] = ar;
+        si[t] = ai;
+        __syncthreads();
+        for (int s2 = 128; s2 > 0; s2 >>= 1)
+        {
+            if (t < s2)
+            {
+                sr[t] += sr[t + s2];
+                si[t] += si[t + s2];
+            }
+            __syncthreads();
+        }
+        if (t == 0)
+        {
+            partial[2 * k] = sr[0];
+            partial[2 * k + 1] = si[0];
+        }
+    }
+    void launch_dc_partial(const cf32 *x, const ChunkGeom &g, double *partial, hipStream_t st)
+    {
+        ProfScope _ps("k_dc_partial", st);
+        hipLaunchKernelGGL(k_dc_partial, dim3(g.K), dim3(256), 0, st, x, g, partial);
+    }
+    void launch_dcblock(const cf32 *x, cf32 *y, const ChunkGeom &g, const DcParams &p, const DcState *start0, DcState *spec, DcState *endst, const int *redo,
+                        int nredo, hipStream_t st)
+    {
+        const int n = redo ? nredo : g.K;
+        if (n <= 0)
+            return;
+        ProfScope _ps("k_chunks<DcStage>", st);
+        hipLaunchKernelGGL((k_chunks<DcStage, false>), dim3((n + 63) / 64), dim3(64), 0, st, x, y, g, p, start0, spec, endst, redo, nredo, (DcState *)nullptr, 0, 0,
+                           0.0f, 0.0f, (unsigned long long *)nullptr);
+    }
     void launch_agc(const cf32 *x, cf32 *y, const ChunkGeom &g, const AgcParams &p, const AgcState *start0, AgcState *spec, AgcState *endst, const int *redo,
                     int nredo, hipStream_t st, const ChunkCkpt &ck)
     {
