@@ -44,8 +44,11 @@ def test_two_ranks_shard_one_recording_on_the_engines(tmp_path, workload, frames
     got = np.concatenate(parts, axis=0)
     assert meta["drops"][0] == 0 and meta["drops"][1] >= 1  # the overlap really was decoded twice
     assert two["check"]["stitched"] == len(got)
-    # same frames, same order; the sync marker is not RS protected and may differ in a bit between two decodes
-    assert got.shape == want.shape and np.array_equal(got[:, 4:], want[:, 4:])
+    # same frames, same order (the sync marker is not RS protected and may differ in a bit between two decodes). The decoders
+    # work in whole Viterbi buffers and the last rank's soft stream starts elsewhere than the single run's, so the remainder
+    # that stays undecoded at the very end of the recording differs: one frame more or less at the END, none anywhere else.
+    m = min(len(got), len(want))
+    assert abs(len(got) - len(want)) <= 1 and np.array_equal(got[:m, 4:], want[:m, 4:]), (got.shape, want.shape)
     assert len(got) >= 2 * frames - 4
     assert two["check"]["payload_matching_transmitted"] == two["check"]["cadus_last_step_all_ranks"]
     assert one["check"]["payload_matching_transmitted"] == one["check"]["cadus_last_step"]

@@ -91,10 +91,16 @@ def test_stock_ids_file_to_file_under_the_override(host, tmp_path, fmt):
     assert rep["soft"].endswith(".soft") and rep["cadu"].endswith(".cadu")
     got = np.fromfile(rep["cadu"], dtype=np.uint8).reshape(-1, 1024)
     want = _ref_cadus_of_file(orc, ocfg, ofec, xr)
-    assert got.shape == want.shape and np.array_equal(got, want)
+    soft = np.fromfile(rep["soft"], dtype=np.int8)
+    ref_soft = orc.psk_demod(ocfg, xr, want_syms=False)["soft"]
+    assert len(soft) == len(ref_soft), (len(soft), len(ref_soft))
+    assert got.shape == want.shape and np.array_equal(got, want), (got.shape, want.shape, int(np.mean(soft != ref_soft) * 1e6))
     assert len(got) >= 26
-    assert rep["decoder_stats"]["viterbi_state"] == "SYNCED" and rep["decoder_stats"]["deframer_state"] == "SYNCED"
-    assert 0.0 <= rep["decoder_stats"]["rs_avg"] <= 16 and rep["demod_stats"]["peak_snr"] > 3.0
+    # the stats keys of the modules replaced (the last buffer of a file is part stale, so the final deframer state is whatever that
+    # leaves it in -- in the reference too)
+    assert rep["decoder_stats"]["viterbi_state"] == "SYNCED" and rep["decoder_stats"]["deframer_state"] in ("NOSYNC", "SYNCING", "SYNCED")
+    assert rep["decoder_stats"]["viterbi_lock"] == 1 and 0.0 < rep["decoder_stats"]["viterbi_ber"] < 0.3
+    assert -1 <= rep["decoder_stats"]["rs_avg"] <= 16 and rep["demod_stats"]["peak_snr"] > 3.0
     soft = np.fromfile(rep["soft"], dtype=np.int8)
     assert len(soft) == len(orc.psk_demod(ocfg, xr, want_syms=False)["soft"])
 
@@ -129,16 +135,17 @@ def test_fifo_and_dsp_stream_topologies(host, tmp_path):
     inp = tmp_path / "bb.cf32"
     x.tofile(str(inp))
     ocfg = pyref.demod_cfg(samplerate=6e6, symbolrate=2333333, constellation=pyref.QPSK, pll_bw=0.003)
-    want = orc.metop_decode(orc.psk_demod(ocfg, x, want_syms=False)["soft"], ber_thr=0.28, outsync_after=10)["cadu"]
+    # When the producer is done the host waits until the FIFO is empty and stops it (pipeline_run.cpp:96-101): the decoder's pending
+    # read returns with the remainder of the stream in the head of its buffer and the previous buffer's symbols behind it, and the
+    # module decodes that once -- the same last buffer as at the end of a file.
+    want = _ref_cadus_of_file(orc, ocfg, None, x, block=16384, metop=True)
     for mode in ("fifo", "dsp_stream"):
         job = {"mode": mode, "input": str(inp), "output_hint": str(tmp_path / mode),
                "demod": {"module": "psk_demod", "parameters": METOP_DEMOD}, "decoder": {"module": "metop_ahrpt_decoder", "parameters": METOP_DEC}}
         rep = _run(host, job, tmp_path)
         assert rep["demod_class"] == "psk_demod_hip" and rep["decoder_class"] == "metop_ahrpt_decoder_hip"
         got = np.fromfile(rep["cadu"], dtype=np.uint8).reshape(-1, 1024)
-        # a FIFO consumer is stopped while its last partial buffer is still pending (pipeline_run.cpp:96-101): the tail of the
-        # stream may be missing, everything written must be the reference's frames in order
-        assert len(got) >= len(want) - 3 and np.array_equal(got, want[:len(got)]), mode
+        assert got.shape == want.shape and np.array_equal(got, want), (mode, len(got), len(want))
         assert len(got) >= 50
 
 
