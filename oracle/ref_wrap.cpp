@@ -53,6 +53,7 @@ std::shared_ptr<slog::Logger> logger = std::make_shared<slog::Logger>();
 #include "common/dsp/clock_recovery/clock_recovery_mm.h"
 #include "common/dsp/clock_recovery/clock_recovery_gardner.h"
 #include "common/dsp/resamp/rational_resampler.h"
+#include "common/dsp/resamp/smart_resampler.h"
 #include "common/dsp/window/window.h"
 #include "common/dsp/demod/delay_one_imag.h"
 
@@ -671,7 +672,7 @@ extern "C"
         bool is_bpsk = false, is_oqpsk = false, ok = true;
         std::shared_ptr<dsp::stream<complex_t>> in;
         std::shared_ptr<dsp::CorrectIQBlock<complex_t>> dc_blocker;
-        std::shared_ptr<dsp::RationalResamplerBlock<complex_t>> rresamp;
+        std::shared_ptr<dsp::SmartResamplerBlock<complex_t>> rresamp;
         std::shared_ptr<dsp::AGCBlock<complex_t>> agc;
         std::shared_ptr<dsp::FIRBlock<complex_t>> rrc;
         std::shared_ptr<dsp::CostasLoopBlock> pll;
@@ -714,29 +715,11 @@ extern "C"
                 dc_blocker = std::make_shared<dsp::CorrectIQBlock<complex_t>>(cur);
                 cur = dc_blocker->output_stream;
             }
-            // SmartResamplerBlock(input, final_samplerate, d_samplerate) (module_demod_base.cpp:204):
-            // for 1 < decim/interp < 2 it reduces to a RationalResamplerBlock (smart_resampler.cpp:15-43).
+            // SmartResamplerBlock(input, final_samplerate, d_samplerate) (module_demod_base.cpp:204): the reference's own class --
+            // power-of-two pre-decimator (power_decim.cpp, its tap tables) + rational resampler as the ratio demands
             if (resample)
             {
-                unsigned interpolation = final_samplerate, decimation = d_samplerate;
-                if (decimation > interpolation)
-                {
-                    int best_power = floor(log2(decimation / interpolation));
-                    if (best_power > 0)
-                    {
-                        ok = false; // power-of-two pre-decimator: not covered by this oracle
-                        return;
-                    }
-                    double rsamp_in = decimation, fout = interpolation, t;
-                    while (modf(rsamp_in, &t) != 0 || modf(fout, &t) != 0)
-                    {
-                        rsamp_in *= 10;
-                        fout *= 10;
-                    }
-                    rresamp = std::make_shared<dsp::RationalResamplerBlock<complex_t>>(cur, fout, rsamp_in);
-                }
-                else
-                    rresamp = std::make_shared<dsp::RationalResamplerBlock<complex_t>>(cur, interpolation, decimation);
+                rresamp = std::make_shared<dsp::SmartResamplerBlock<complex_t>>(cur, final_samplerate, d_samplerate);
                 cur = rresamp->output_stream;
             }
             agc = std::make_shared<dsp::AGCBlock<complex_t>>(cur, c->agc_rate, 1.0f, 1.0f, 65536);

@@ -3,12 +3,17 @@
 // boundary certificates of the chunk-speculative loop stages, stream-state carry, and the C ABI.
 #include "demod_kernels.h"
 #include "dsp_design.h"
+namespace sdhip
+{
+#include "power_decim_tables.inc"
+}
 #include "../../include/sdhip.h"
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
 #include <chrono>
 #include <cstring>
+#include <memory>
 #include <vector>
 
 namespace sdhip
@@ -322,6 +327,21 @@ namespace sdhip
         }
     }
 
+    // hist <- last nt samples of [hist | cur[0 .. ncur)] (one block; nt <= 1024)
+    __global__ __launch_bounds__(1024) void k_hist_slide(cf32 *hist, int nt, const cf32 *cur, long long ncur)
+    {
+        const int i = (int)threadIdx.x;
+        cf32 v{0, 0};
+        if (i < nt)
+        {
+            const long long src = (long long)i + ncur - nt; // index into cur; negative: still inside the old history
+            v = src >= 0 ? cur[src] : hist[nt + src];
+        }
+        __syncthreads();
+        if (i < nt)
+            hist[i] = v;
+    }
+
     struct DemodEngine
     {
         sdhip_demod_cfg cfg;
@@ -339,6 +359,18 @@ namespace sdhip
         AgcParams agc_p{};
         CostasParams cos_p{};
         MmParams mm_p{};
+
+        // power-of-two pre-decimator of SmartResampler (smart_resampler.cpp:15-29): chain of decimating FIRs, each with its
+        // phase (`inc` of decimating_fir.cpp:60-86) and the last ntaps samples of its input carried across calls
+        struct DecimStage
+        {
+            int decim = 1, ntaps = 0, inc = 0;
+            DevBuf<float> d_taps;
+            DevBuf<cf32> d_hist; // input[-ntaps .. -1] of the next call
+        };
+        std::vector<std::unique_ptr<DecimStage>> pd_stages;
+        int pd_decim = 1;
+        bool rational = true;
 
         // stream state
         bool started = false;
@@ -438,17 +470,51 @@ namespace sdhip
                 if (decimation > interpolation)
                 {
                     const int best_power = (int)floor(log2(decimation / interpolation));
-                    if (best_power > 0)
-                        throw HipError("input needs the power-of-two pre-decimator (samplerate >= 2x the target): not implemented in the HIP path");
                     double rsamp_in = decimation, fout = interpolation, t;
-                    while (modf(rsamp_in, &t) != 0 || modf(fout, &t) != 0)
-                    {
-                        rsamp_in *= 10;
-                        fout *= 10;
+                    if (best_power > 0)
+                    { // PowerDecimatorBlock(best_decim): the plan's decimating FIR stages, power_decim.cpp:6-31
+                        const int best_decim = std::min<int>(1 << best_power, 1 << 13);
+                        rsamp_in = (double)decimation / (double)best_decim;
+                        const PdPlan &plan = PD_PLANS[(int)log2(best_decim) - 1];
+                        for (int i = 0; i < plan.nstages; i++)
+                        {
+                            const PdSet &set = PD_SETS[plan.stages[i].set];
+                            auto st = std::make_unique<DecimStage>();
+                            st->decim = plan.stages[i].decim;
+                            st->ntaps = set.count;
+                            std::vector<float> rev(set.count);
+                            for (int j = 0; j < set.count; j++)
+                            { // taps[(ntaps - 1) - j]: reversed like every FIR of the reference, decimating_fir.cpp:30
+                                const unsigned bits = PD_TAP_BITS[set.offset + (set.count - 1 - j)];
+                                memcpy(&rev[j], &bits, 4);
+                            }
+                            st->d_taps.reserve(rev.size());
+                            SD_HIP(hipMemcpy(st->d_taps.p, rev.data(), rev.size() * sizeof(float), hipMemcpyHostToDevice));
+                            st->d_hist.reserve((size_t)set.count + 1);
+                            SD_HIP(hipMemset(st->d_hist.p, 0, ((size_t)set.count + 1) * sizeof(cf32)));
+                            pd_stages.push_back(std::move(st));
+                        }
+                        pd_decim = best_decim;
                     }
-                    interpolation = (unsigned)fout;
-                    decimation = (unsigned)rsamp_in;
+                    rational = rsamp_in != fout;
+                    if (rational)
+                    {
+                        while (modf(rsamp_in, &t) != 0 || modf(fout, &t) != 0)
+                        {
+                            rsamp_in *= 10;
+                            fout *= 10;
+                        }
+                        interpolation = (unsigned)fout;
+                        decimation = (unsigned)rsamp_in;
+                    }
                 }
+                if (!rational)
+                { // the ratio was an exact power of two: the pre-decimator is the whole resampler
+                    r_interp = r_decim = 1;
+                    r_ntaps = 0;
+                }
+                else
+                {
                 std::vector<float> bank;
                 r_interp = interpolation;
                 r_decim = decimation;
@@ -457,6 +523,7 @@ namespace sdhip
                     throw HipError("resampler filter longer than the history window");
                 d_rbank.reserve(bank.size());
                 SD_HIP(hipMemcpy(d_rbank.p, bank.data(), bank.size() * sizeof(float), hipMemcpyHostToDevice));
+                }
             }
             // AGC (module_demod_base.cpp:207)
             agc_p.rate = cfg.agc_rate;
@@ -727,9 +794,34 @@ namespace sdhip
                 std::swap(A, B);
                 SRC = A;
             }
-            // ---- rational resampler
-            if (resample)
+            // ---- SmartResampler: power-of-two pre-decimator stages (if the ratio has them), then the rational resampler
+            bool in_place_r = in_place;
+            if (resample && !pd_stages.empty())
             {
+                const cf32 *cur = SRC;
+                long long ncur = n;
+                for (auto &stp : pd_stages)
+                {
+                    DecimStage &ds = *stp;
+                    cf32 *dst = (cur == A) ? B : A;
+                    const long long nout = ncur > ds.inc ? (ncur - ds.inc + ds.decim - 1) / ds.decim : 0;
+                    launch_decim_fir(cur, ds.d_hist.p, ncur, ds.d_taps.p, ds.ntaps, ds.decim, ds.inc, dst, nout, stream);
+                    hipLaunchKernelGGL(k_hist_slide, dim3(1), dim3(1024), 0, stream, ds.d_hist.p, ds.ntaps, cur, ncur);
+                    ds.inc = (int)(ds.inc + nout * ds.decim - ncur); // decimating_fir.cpp:84
+                    cur = dst;
+                    ncur = nout;
+                }
+                if (cur != A)
+                    std::swap(A, B);
+                SRC = A;
+                in_place_r = false;
+                n = ncur;
+                if (n == 0)
+                    return 0;
+            }
+            if (resample && rational)
+            {
+                const bool in_place = in_place_r; // the rational stage reads the caller's buffer only when nothing ran in front of it
                 if (in_place)
                     SD_HIP(hipMemcpyAsync(d_hist_in.p, hist_in.data(), DEMOD_HIST * sizeof(cf32), hipMemcpyHostToDevice, stream));
                 else

@@ -95,6 +95,12 @@ namespace sdhip
     void launch_agc(const cf32 *x, cf32 *y, const ChunkGeom &g, const AgcParams &p, const AgcState *start0, AgcState *spec, AgcState *endst,
                     const int *redo, int nredo, hipStream_t st, const ChunkCkpt &ck = ChunkCkpt());
 
+    // ---- decimating FIR stage of the power-of-two pre-decimator (decimating_fir.cpp:47-89 inside power_decim.cpp:58-77) ----------
+    // y[m] = sum_j x[inc0 + m*decim - (ntaps-1) + j] * rtaps[j], j ascending (oldest sample first, mul and add rounded separately);
+    // samples at negative indices come from hist[ntaps + index] (the last ntaps samples of the previous call)
+    void launch_decim_fir(const cf32 *x, const cf32 *hist, long long nin, const float *rtaps_dev, int ntaps, int decim, int inc0, cf32 *y, long long nout,
+                          hipStream_t st);
+
     // ---- RRC FIR (fir.cpp:74-83), fully parallel; taps reversed on the host, ntaps <= 361 ----------------
     void launch_fir(const cf32 *x, cf32 *y, long long n, const float *rtaps_dev, int ntaps, hipStream_t st);
 

@@ -525,6 +525,40 @@ namespace sdhip
     // =============================================================================================
     // FIR: y[i] = sum_j x[i-(nt-1)+j] * rtaps[j], accumulated oldest sample first (volk generic order)
     // =============================================================================================
+    // =============================================================================================
+    // decimating FIR (power-of-two pre-decimator stages): thread per output, taps (<= 1024, reversed) in LDS. Wideband
+    // recordings only; the bench configurations never come here.
+    // =============================================================================================
+    __global__ __launch_bounds__(256) void k_decim_fir(const cf32 *x, const cf32 *hist, long long nin, const float *__restrict__ rtaps, int ntaps, int decim,
+                                                        int inc0, cf32 *y, long long nout)
+    {
+        __shared__ float taps[1024];
+        for (int i = (int)threadIdx.x; i < ntaps; i += 256)
+            taps[i] = rtaps[i];
+        __syncthreads();
+        const long long m = (long long)blockIdx.x * 256 + threadIdx.x;
+        if (m >= nout)
+            return;
+        const long long first = (long long)inc0 + m * decim - (ntaps - 1);
+        float re = 0.0f, im = 0.0f;
+        for (int j = 0; j < ntaps; j++)
+        {
+            const long long i = first + j;
+            const cf32 v = i >= 0 ? x[i] : hist[ntaps + i];
+            re = re + v.re * taps[j];
+            im = im + v.im * taps[j];
+        }
+        y[m] = cf32{re, im};
+    }
+    void launch_decim_fir(const cf32 *x, const cf32 *hist, long long nin, const float *rtaps_dev, int ntaps, int decim, int inc0, cf32 *y, long long nout,
+                          hipStream_t st)
+    {
+        if (nout <= 0)
+            return;
+        ProfScope _ps("k_decim_fir", st);
+        hipLaunchKernelGGL(k_decim_fir, dim3((unsigned)((nout + 255) / 256)), dim3(256), 0, st, x, hist, nin, rtaps_dev, ntaps, decim, inc0, y, nout);
+    }
+
     constexpr int FIR_MAX_TAPS = 384;
     constexpr int FIR_BLOCK = 256, FIR_PER = 4; // outputs per block = 1024 (thread t: i0 + t + 256*r)
     __global__ __launch_bounds__(FIR_BLOCK) void k_fir(const cf32 *x, cf32 *y, long long n, const float *__restrict__ rtaps, int ntaps)

@@ -774,7 +774,7 @@ namespace sdhip
                     fc.rs_fill_bytes = cfg.rs_fill_bytes;
                     fc.rs_dualbasis = cfg.rs_dualbasis;
                     fc.rs_nroots = cfg.rs_type == SDHIP_RS239 ? 16 : 32;
-                    d_rs_clean.reserve((size_t)nf * I + 8);
+                    d_rs_clean.reserve((size_t)nf * I * 33 + 64); // clean flags + 32 syndrome bytes per codeword (k_rs_screen -> k_rs)
                     launch_frames(bs, fc, d_frames.p, nf, d_fbytes.p, d_ferr.p, stream, d_rs_clean.p);
                     h_dst.assign(nf, -1);
                     size_t kept = 0;
@@ -1539,7 +1539,7 @@ extern "C"
         SD_GUARD_BEGIN
         SD_HIP(hipSetDevice(device));
         DevBuf<uint8_t> clean;
-        clean.reserve((size_t)nframes * I + 8);
+        clean.reserve((size_t)nframes * I * 33 + 64);
         launch_rs_only(d_data, nframes, frame_stride, dualbasis, I, rs_type == SDHIP_RS239 ? 16 : 32, fill_bytes, d_errors, nullptr, clean.p);
         SD_HIP(hipDeviceSynchronize());
         return 0;

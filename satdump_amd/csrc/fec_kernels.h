@@ -178,7 +178,8 @@ namespace sdhip
         int pad;
     };
     // frames: nframes descriptors; out: nframes * cadu_bytes; errors: nframes * max(rs_i,1) ints (-1 = uncorrectable)
-    // clean_scratch (optional, nframes * rs_i bytes): enables the syndrome screen in front of the thread-per-codeword decoder
+    // clean_scratch (optional, 33 * nframes * rs_i + 64 bytes): enables the syndrome screen in front of the thread-per-codeword decoder
+    // (a clean flag per codeword, then the 32 syndromes of every codeword, which the decoder takes over instead of evaluating them again)
     void launch_frames(const BitStream &bs, const FrameCfg &fc, const FrameDesc *frames, int nframes, uint8_t *out, int *errors, hipStream_t st,
                        uint8_t *clean_scratch = nullptr);
     // Unit entry: RS decode of frames already in memory (sdhip_op_rs_decode).

@@ -1494,7 +1494,8 @@ namespace sdhip
     };
 
     // returns -1 on failure, else msg_length; corrects cw in place (conventional basis, byte 0 = highest order)
-    __device__ int rs_decode_thread(const RsCtx &R, unsigned char *cw, int stride)
+    // synd_pre: the codeword's syndromes as k_rs_screen left them (the same Horner evaluation, one lane per root), or nullptr
+    __device__ int rs_decode_thread(const RsCtx &R, unsigned char *cw, int stride, const unsigned char *synd_pre = nullptr)
     {
         const int md = R.nroots;
 #define CW(k) cw[(k) * stride]
@@ -1502,6 +1503,17 @@ namespace sdhip
         // equals polynomial_eval_lut over generator_root_exp, decode.c:12-28)
         unsigned char synd[32];
         bool all_zero = true;
+        if (synd_pre)
+        { // 255 x 32 dependent look-ups per thread not spent again: they were ~70 % of this function
+            const uint4 a = reinterpret_cast<const uint4 *>(synd_pre)[0], b = reinterpret_cast<const uint4 *>(synd_pre)[1];
+            const unsigned w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+            for (int i = 0; i < 32; i++)
+                synd[i] = (unsigned char)(w[i >> 2] >> (8 * (i & 3)));
+            for (int i = 0; i < md; i++)
+                if (synd[i])
+                    all_zero = false;
+        }
+        else
         for (int i = 0; i < md; i++)
         {
             const unsigned lr = (unsigned)((R.gap * (i + R.fcr)) % 255); // log of generator root i (reed-solomon.c:9-11)
@@ -1715,7 +1727,10 @@ namespace sdhip
         RsCtx R{&gf, nroots, nroots == 32 ? 112 : 120, 11};
         // count differences while correcting: snapshot first `coded` bytes is expensive in registers, so
         // recount by re-reading the input bytes after decode
-        const int res = rs_decode_thread(R, cw, RS_THREADS);
+        // scratch layout: [clean flag per codeword | 32 syndrome bytes per codeword] (k_rs_screen)
+        const long long ncw_all = (long long)nframes * I;
+        const unsigned char *synd_pre = clean ? clean + ((ncw_all + 15) / 16 * 16) + (size_t)cwid * 32 : nullptr;
+        const int res = rs_decode_thread(R, cw, RS_THREADS, synd_pre);
         if (res < 0)
         {
             errors[cwid] = -1; // data left untouched (the reference restores it, reedsolomon.cpp:78-90)
@@ -1753,6 +1768,7 @@ namespace sdhip
         __shared__ unsigned char from_dual[256];
         __shared__ unsigned char cw[RSS_CW][256];
         __shared__ int nz[RSS_CW];
+        __shared__ unsigned char sy_sh[RSS_CW][32];
         const int tid = (int)threadIdx.x;
         for (int i = tid; i < 512; i += 32 * RSS_CW)
         {
@@ -1784,6 +1800,7 @@ namespace sdhip
         }
         __syncthreads();
         const int c = tid >> 5, r = tid & 31;
+        sy_sh[c][r] = 0;
         if (r < nroots && cw0 + c < ncw)
         {
             const int fcr = nroots == 32 ? 112 : 120, gap = 11;
@@ -1795,12 +1812,19 @@ namespace sdhip
                     sy = gf.exp[gf.log[sy] + lr];
                 sy ^= cw[c][k];
             }
+            sy_sh[c][r] = (unsigned char)sy;
             if (sy)
                 nz[c] = 1;
         }
         __syncthreads();
         if (tid < RSS_CW && cw0 + tid < ncw)
             clean[cw0 + tid] = nz[tid] ? 0 : 1;
+        // the syndromes themselves, for the decoder behind the screen (32 bytes per codeword, behind the flags)
+        if (cw0 + c < ncw && (r & 3) == 0)
+        {
+            unsigned char *sp = clean + ((ncw + 15) / 16 * 16) + (size_t)(cw0 + c) * 32;
+            *reinterpret_cast<unsigned *>(sp + r) = (unsigned)sy_sh[c][r] | ((unsigned)sy_sh[c][r + 1] << 8) | ((unsigned)sy_sh[c][r + 2] << 16) | ((unsigned)sy_sh[c][r + 3] << 24);
+        }
     }
 
     void launch_rs_only(uint8_t *data, int nframes, int frame_stride, int dualbasis, int I, int nroots, int fill_bytes, int *errors, hipStream_t st, uint8_t *clean_scratch)
