@@ -87,6 +87,8 @@ extern "C"
         float clock_omega_relative_limit; /* default 0.005 */
         float costas_max_offset_hz;       /* "costas_max_offset" in Hz; <=0 -> 1.0 rad/sample */
         int buffer_size;                  /* "buffer_size"; <=0 -> reference default (module_demod_base.cpp:22-25) */
+        int post_costas_dc;               /* "post_costas_dc", default 0: a CorrectIQ DC block between the Costas loop and the clock recovery
+                                             (module_psk_demod.cpp:36-38, 127-134) */
         /* engine knobs (ours; no reference equivalent) */
         int exact;     /* 1: one sequential lane per stream, bit-for-bit the reference schedule (slow; parity tests) */
         int chunk_len; /* speculative chunk length in (resampled) samples; <=0 -> auto */

@@ -676,6 +676,7 @@ extern "C"
         std::shared_ptr<dsp::AGCBlock<complex_t>> agc;
         std::shared_ptr<dsp::FIRBlock<complex_t>> rrc;
         std::shared_ptr<dsp::CostasLoopBlock> pll;
+        std::shared_ptr<dsp::CorrectIQBlock<complex_t>> post_pll_dc;
         std::shared_ptr<dsp::DelayOneImagBlock> delay;
         std::shared_ptr<dsp::MMClockRecoveryBlock<complex_t>> rec;
         explicit RefDemodChain(const sdhip_demod_cfg *c)
@@ -730,10 +731,12 @@ extern "C"
                 costas_max_offset = dsp::hz_to_rad(c->costas_max_offset_hz, final_samplerate);
             unsigned order = is_bpsk ? 2 : (c->constellation == SDHIP_8PSK ? 8 : 4);
             pll = std::make_shared<dsp::CostasLoopBlock>(rrc->output_stream, c->pll_bw, order, costas_max_offset);
+            if (c->post_costas_dc) // module_psk_demod.cpp:127-134
+                post_pll_dc = std::make_shared<dsp::CorrectIQBlock<complex_t>>(pll->output_stream);
             if (is_oqpsk)
-                delay = std::make_shared<dsp::DelayOneImagBlock>(pll->output_stream);
-            rec = std::make_shared<dsp::MMClockRecoveryBlock<complex_t>>(is_oqpsk ? delay->output_stream : pll->output_stream, final_sps, c->clock_gain_omega, c->clock_mu,
-                                                                               c->clock_gain_mu, c->clock_omega_relative_limit);
+                delay = std::make_shared<dsp::DelayOneImagBlock>(c->post_costas_dc ? post_pll_dc->output_stream : pll->output_stream);
+            rec = std::make_shared<dsp::MMClockRecoveryBlock<complex_t>>(is_oqpsk ? delay->output_stream : (c->post_costas_dc ? post_pll_dc->output_stream : pll->output_stream),
+                                                                               final_sps, c->clock_gain_omega, c->clock_mu, c->clock_gain_mu, c->clock_omega_relative_limit);
         }
     };
 
@@ -761,6 +764,7 @@ extern "C"
         auto &agc = ch.agc;
         auto &rrc = ch.rrc;
         auto &pll = ch.pll;
+        auto &post_pll_dc = ch.post_pll_dc;
         auto &delay = ch.delay;
         auto &rec = ch.rec;
 
@@ -789,6 +793,7 @@ extern "C"
             agc->work();
             rrc->work();
             pll->work();
+            if (post_pll_dc) post_pll_dc->work();
             if (delay) delay->work();
             rec->work();
             int dat_size = rec->output_stream->read();
@@ -857,6 +862,7 @@ extern "C"
         ch.agc->start(), nthreads++;
         ch.rrc->start(), nthreads++;
         ch.pll->start(), nthreads++;
+        if (ch.post_pll_dc) ch.post_pll_dc->start(), nthreads++;
         if (ch.delay) ch.delay->start(), nthreads++;
         ch.rec->start(), nthreads++;
         std::atomic<bool> module_run{true};
@@ -920,6 +926,7 @@ extern "C"
         ch.agc->stop();
         ch.rrc->stop();
         ch.pll->stop();
+        if (ch.post_pll_dc) ch.post_pll_dc->stop();
         if (ch.delay) ch.delay->stop();
         ch.rec->stop();
         ch.rec->output_stream->stopReader();

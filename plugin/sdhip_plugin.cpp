@@ -108,11 +108,11 @@ namespace sdhip_plugin
             // custom_samplerate overrides the resample decision (module_demod_base.cpp:73-74): not a field of the C ABI
             if (parameters.count("custom_samplerate") > 0)
                 throw satdump_exception("psk_demod_hip: custom_samplerate is not on the HIP path, use psk_demod");
-            // carrier-tracking front-end and post-Costas DC block (module_psk_demod.cpp:36-40, 93-113, 127-128): CPU module only
+            // carrier-tracking front-end (module_psk_demod.cpp:39-40, 93-113; one pipeline file, ODIN): CPU module only
             if (parameters.count("has_carrier") > 0 && parameters["has_carrier"].get<bool>())
                 throw satdump_exception("psk_demod_hip: has_carrier is not on the HIP path, use psk_demod");
-            if (parameters.count("post_costas_dc") > 0 && parameters["post_costas_dc"].get<bool>())
-                throw satdump_exception("psk_demod_hip: post_costas_dc is not on the HIP path, use psk_demod");
+            b = false;
+            opt(parameters, "post_costas_dc", b), cfg.post_costas_dc = b; // module_psk_demod.cpp:36-38
             if (parameters.count("constellation") > 0)
                 cfg.constellation = constellation_of(parameters["constellation"].get<std::string>(), true);
             else

@@ -378,7 +378,7 @@ namespace sdhip
         AgcState agc_s{1.0f};
         CostasState cos_s{0.0f, 0.0f};
         MmState mm_s{};
-        DcState dc_s{0, 0};
+        DcState dc_s{0, 0}, dc2_s{0, 0}; // dc_block in front / post_costas_dc behind the Costas loop
         std::vector<cf32> hist_in, hist_agc, hist_cos; // DEMOD_HIST samples each (history in front of stage inputs)
 
         // device
@@ -708,6 +708,51 @@ namespace sdhip
             return *h_vout.p;
         }
 
+        // Chunk-parallel DC block (see demod_kernels.h): affine scan in double for the accumulator at every chunk start, then the
+        // reference's float recurrence per chunk, certified against the previous chunk's end within 1e-5 |acc|. in -> out,
+        // `carried` = the accumulator across calls.
+        void dc_block_chunked(const cf32 *in, cf32 *out, long long n, DcState &carried)
+        {
+            const int L = pick_L(n, ST_AGC);
+            const ChunkGeom g = make_geom(n, L, 0);
+            d_dc_partial.reserve(2 * (size_t)g.K);
+            d_dc_spec.reserve(g.K);
+            d_dc_end.reserve(g.K);
+            d_dc_starts.reserve(g.K);
+            launch_dc_partial(in, g, d_dc_partial.p, stream);
+            std::vector<double> part(2 * (size_t)g.K);
+            SD_HIP(hipMemcpyAsync(part.data(), d_dc_partial.p, part.size() * sizeof(double), hipMemcpyDeviceToHost, stream));
+            SD_HIP(hipStreamSynchronize(stream));
+            std::vector<DcState> starts((size_t)g.K);
+            const double beta = (double)(1.0f - 0.0001f);
+            double sr = carried.acc_re, si = carried.acc_im;
+            for (int k = 0; k < g.K; k++)
+            {
+                starts[k] = DcState{(float)sr, (float)si};
+                const double a = std::pow(beta, (double)(chunk_end(g, k) - chunk_begin(g, k)));
+                sr = a * sr + part[2 * (size_t)k];
+                si = a * si + part[2 * (size_t)k + 1];
+            }
+            starts[0] = carried; // chunk 0 starts from the carried state itself
+            SD_HIP(hipMemcpyAsync(d_dc_starts.p, starts.data(), starts.size() * sizeof(DcState), hipMemcpyHostToDevice, stream));
+            SD_HIP(hipMemcpyAsync(d_dc.p, &carried, sizeof(carried), hipMemcpyHostToDevice, stream));
+            const DcParams dp{d_dc_starts.p};
+            launch_dcblock(in, out, g, dp, d_dc.p, d_dc_spec.p, d_dc_end.p, nullptr, 0, stream);
+            const float dc_tol = 1e-5f;
+            verify_fix(
+                "dc", g.K,
+                [&](VerdictOut *vo, int *fails, int force) {
+                    hipLaunchKernelGGL(k_dc_verdict, dim3((g.K + 255) / 256), dim3(256), 0, stream, g.K, d_dc_spec.p, d_dc_end.p, dc_tol, vo, fails, force);
+                },
+                [&](const int *list, int nr) {
+                    hipLaunchKernelGGL(k_spec_from_prev<DcState>, dim3((nr + 255) / 256), dim3(256), 0, stream, list, nr, d_dc_spec.p, d_dc_end.p);
+                },
+                [&](const int *redo, int nr) { launch_dcblock(in, out, g, dp, d_dc.p, d_dc_spec.p, d_dc_end.p, redo, nr, stream); });
+            stats.chunks += g.K;
+            SD_HIP(hipMemcpyAsync(&carried, d_dc_end.p + (g.K - 1), sizeof(carried), hipMemcpyDeviceToHost, stream));
+            SD_HIP(hipStreamSynchronize(stream));
+        }
+
         // Process n input samples resident on the device. Outputs go to d_soft / d_syms (device).
         int64_t process(const void *d_in, size_t n_in, int fmt, int8_t *d_soft, size_t soft_cap, float *d_syms, size_t syms_cap)
         {
@@ -751,46 +796,7 @@ namespace sdhip
             }
             else if (cfg.dc_block)
             {
-                // chunk-parallel DC block (see demod_kernels.h): affine scan in double for the accumulator at every chunk start,
-                // then the reference's float recurrence per chunk, certified against the previous chunk's end within 1e-5 |acc|
-                const int L = pick_L(n, ST_AGC);
-                const ChunkGeom g = make_geom(n, L, 0);
-                d_dc_partial.reserve(2 * (size_t)g.K);
-                d_dc_spec.reserve(g.K);
-                d_dc_end.reserve(g.K);
-                d_dc_starts.reserve(g.K);
-                launch_dc_partial(A, g, d_dc_partial.p, stream);
-                std::vector<double> part(2 * (size_t)g.K);
-                SD_HIP(hipMemcpyAsync(part.data(), d_dc_partial.p, part.size() * sizeof(double), hipMemcpyDeviceToHost, stream));
-                SD_HIP(hipStreamSynchronize(stream));
-                std::vector<DcState> starts((size_t)g.K);
-                const double beta = (double)(1.0f - 0.0001f);
-                double sr = dc_s.acc_re, si = dc_s.acc_im;
-                for (int k = 0; k < g.K; k++)
-                {
-                    starts[k] = DcState{(float)sr, (float)si};
-                    const double a = std::pow(beta, (double)(chunk_end(g, k) - chunk_begin(g, k)));
-                    sr = a * sr + part[2 * (size_t)k];
-                    si = a * si + part[2 * (size_t)k + 1];
-                }
-                starts[0] = dc_s; // chunk 0 starts from the carried state itself
-                SD_HIP(hipMemcpyAsync(d_dc_starts.p, starts.data(), starts.size() * sizeof(DcState), hipMemcpyHostToDevice, stream));
-                SD_HIP(hipMemcpyAsync(d_dc.p, &dc_s, sizeof(dc_s), hipMemcpyHostToDevice, stream));
-                const DcParams dp{d_dc_starts.p};
-                launch_dcblock(A, B, g, dp, d_dc.p, d_dc_spec.p, d_dc_end.p, nullptr, 0, stream);
-                const float dc_tol = 1e-5f;
-                verify_fix(
-                    "dc", g.K,
-                    [&](VerdictOut *vo, int *fails, int force) {
-                        hipLaunchKernelGGL(k_dc_verdict, dim3((g.K + 255) / 256), dim3(256), 0, stream, g.K, d_dc_spec.p, d_dc_end.p, dc_tol, vo, fails, force);
-                    },
-                    [&](const int *list, int nr) {
-                        hipLaunchKernelGGL(k_spec_from_prev<DcState>, dim3((nr + 255) / 256), dim3(256), 0, stream, list, nr, d_dc_spec.p, d_dc_end.p);
-                    },
-                    [&](const int *redo, int nr) { launch_dcblock(A, B, g, dp, d_dc.p, d_dc_spec.p, d_dc_end.p, redo, nr, stream); });
-                stats.chunks += g.K;
-                SD_HIP(hipMemcpyAsync(&dc_s, d_dc_end.p + (g.K - 1), sizeof(dc_s), hipMemcpyDeviceToHost, stream));
-                SD_HIP(hipStreamSynchronize(stream));
+                dc_block_chunked(A, B, n, dc_s);
                 std::swap(A, B);
                 SRC = A;
             }
@@ -1086,6 +1092,24 @@ namespace sdhip
                 stats.freq_hz = (float)(((double)cos_s.freq / (2.0 * design::PI)) * (double)final_samplerate);
                 std::swap(A, B);
             }
+            // ---- post_costas_dc (module_psk_demod.cpp:127-134): the DC block sees ONE coherent stream, so the per-chunk frames of the
+            // Costas stage are turned back first (exact quarter / half turns); the clock recovery then reads un-rotated samples
+            const int *mm_rot = d_rot.p;
+            if (cfg.post_costas_dc)
+            {
+                launch_derotate(A, n, cg, d_rot.p, order, stream);
+                if (cfg.exact)
+                {
+                    SD_HIP(hipMemcpyAsync(d_dc.p, &dc2_s, sizeof(dc2_s), hipMemcpyHostToDevice, stream));
+                    launch_dcblock_seq(A, B, n, d_dc.p, stream);
+                    SD_HIP(hipMemcpyAsync(&dc2_s, d_dc.p, sizeof(dc2_s), hipMemcpyDeviceToHost, stream));
+                    SD_HIP(hipStreamSynchronize(stream));
+                }
+                else
+                    dc_block_chunked(A, B, n, dc2_s);
+                std::swap(A, B);
+                mm_rot = nullptr;
+            }
             tick("costas");
             // ---- M&M + quantiser
             int64_t nsoft = 0;
@@ -1137,7 +1161,7 @@ namespace sdhip
                     const long long span0 = std::min<long long>(n, (long long)L + Wn);
                     mm_p.cap = (int)(span0 / std::max(0.5, omin - 0.01)) + 16;
                     mm_p.cg = cg;
-                    mm_p.rot = d_rot.p;
+                    mm_p.rot = mm_rot;
                     symbuf.reserve((size_t)g.K * mm_p.cap);
                     d_counts.reserve(2 * (size_t)g.K);
                     d_offsets.reserve(g.K);
@@ -1232,7 +1256,7 @@ namespace sdhip
                     throw HipError("soft output buffer too small");
                 launch_quantize(symbuf.p, d_seg.p, d_offsets.p, g.K, mm_p.cap, is_bpsk ? 1 : 0, d_soft, (long long)soft_cap, d_syms, (long long)syms_cap, stream);
                 // history for the next call: last DEMOD_HIST de-rotated Costas outputs
-                launch_tail_copy(A, n, DEMOD_HIST, cg, d_rot.p, order, d_hist.p, stream);
+                launch_tail_copy(A, n, DEMOD_HIST, cg, mm_rot, order, d_hist.p, stream);
                 SD_HIP(hipMemcpyAsync(hist_cos.data(), d_hist.p, DEMOD_HIST * sizeof(cf32), hipMemcpyDeviceToHost, stream));
                 SD_HIP(hipStreamSynchronize(stream));
                 stats.symbols_out += tot;

@@ -164,5 +164,6 @@ namespace sdhip
     void launch_quantize(const cf32 *sym_scratch, const int *seg, const long long *offsets, int K, int cap, int bpsk, int8_t *soft, long long soft_cap,
                          float *syms, long long syms_cap, hipStream_t st);
     // rotated copy of the last `cnt` Costas outputs (history for the next call), incl. the per-chunk rotation
+    void launch_derotate(cf32 *x, long long n, const ChunkGeom &cg, const int *rot, int order, hipStream_t st);
     void launch_tail_copy(const cf32 *x, long long n, int cnt, const ChunkGeom &cg, const int *rot, int order, cf32 *out, hipStream_t st);
 } // namespace sdhip

@@ -1638,6 +1638,18 @@ namespace sdhip
             v = rot_apply(v, rot[costas_chunk_of(cg, i)], order);
         out[j] = v;
     }
+    // x[i] *= exp(+j rot[chunk of i] unit): the Costas chunks' frames turned back into the stream's (exact for order 2 / 4)
+    __global__ __launch_bounds__(256) void k_derotate(cf32 *x, long long n, ChunkGeom cg, const int *rot, int order)
+    {
+        const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+        if (i < n)
+            x[i] = rot_apply(x[i], rot[costas_chunk_of(cg, i)], order);
+    }
+    void launch_derotate(cf32 *x, long long n, const ChunkGeom &cg, const int *rot, int order, hipStream_t st)
+    {
+        ProfScope _ps("k_derotate", st);
+        hipLaunchKernelGGL(k_derotate, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, n, cg, rot, order);
+    }
     void launch_tail_copy(const cf32 *x, long long n, int cnt, const ChunkGeom &cg, const int *rot, int order, cf32 *out, hipStream_t st)
     {
         ProfScope _ps("k_tail_copy", st);

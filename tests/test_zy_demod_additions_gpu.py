@@ -72,3 +72,27 @@ def test_power_of_two_predecimator(torch_cuda, capi, orc, samplerate, symbolrate
     assert np.array_equal(soft, want["soft"])
     soft2, syms2, st2 = _run_demod(torch_cuda, capi, dict(constellation="bpsk", **kw), x, chunk_len=4096)
     assert len(soft2) == len(want["soft"]) and np.mean(soft2 != want["soft"]) < 0.02
+
+
+@pytest.mark.parametrize("case", ["goes", "npp"])
+def test_post_costas_dc(torch_cuda, capi, orc, case):
+    """psk_demod's post_costas_dc option (module_psk_demod.cpp:36-38, 127-134; NOAA / Psyche / Stereo pipelines): a DC block between
+    the Costas loop and the clock recovery. Exact mode bit-identical over ragged calls; chunk-parallel mode (Costas chunks turned
+    back into one frame in front of the DC block) same symbol count, >= 98.5 % of the symbols within 1e-5, CADUs identical."""
+    from tests import test_demod_gpu as G
+    spec, plain, x, ocfg, kw, fec, ofec = G._case(case)
+    ocfg.post_costas_dc = 1
+    want = orc.psk_demod(ocfg, x)
+    n = len(x)
+    soft, syms, st = _run_demod(torch_cuda, capi, dict(kw, post_costas_dc=1), x[:300000], chunks=[0, 1000, 77777, 300000], exact=1)
+    w3 = orc.psk_demod(ocfg, x[:300000])
+    assert np.array_equal(syms.view(np.uint32), w3["syms"].view(np.uint32)) and np.array_equal(soft, w3["soft"])
+    soft, syms, st = _run_demod(torch_cuda, capi, dict(kw, post_costas_dc=1), x, chunks=[0, n // 2 + 3, n], chunk_len=8192)
+    assert len(syms) == len(want["syms"])
+    err = np.abs(syms - want["syms"]) / np.sqrt(np.mean(np.abs(want["syms"]) ** 2))
+    assert np.mean(err > 1e-5) < 0.015, float(np.mean(err > 1e-5))
+    dec = capi.FecDecoder(capi.fec_cfg(**fec))
+    dec.push(soft)
+    got = dec.pull()
+    wantc = orc.concat_decode(ofec, want["soft"])["cadu"]
+    assert got.shape == wantc.shape and np.array_equal(got, wantc) and len(got) >= 20
