@@ -12,6 +12,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <functional>
 #include <map>
 #include <mutex>
 #include <vector>
@@ -324,6 +325,9 @@ namespace sdhip
         DevBuf<uint32_t> d_hits;
         DevBuf<int> d_count;
         DevBuf<uint8_t> d_packed, d_rs_clean;
+        DevBuf<uint32_t> d_win;
+        PinBuf<uint32_t> h_win;
+        unsigned long long stats_full_fetches = 0; // deframer walks that needed the whole packed stream on the host
         DevBuf<FrameDesc> d_frames;
         DevBuf<uint8_t> d_fbytes;
         DevBuf<int> d_ferr;
@@ -556,7 +560,31 @@ namespace sdhip
             return (uint32_t)((v << (24 + sh)) >> 32);
         }
 
-        WalkResult walk(const DeframerState &in, const uint8_t *bytes, int64_t base_abs, int64_t total_rel, const std::vector<uint32_t> &hits, int nblk) const
+        // Where the FSM gets its 32-bit windows from. A locked deframer only ever looks at p0 + k * CADU (one word per frame):
+        // those words were gathered on the device and are all that crossed PCIe (a few 100 KB instead of the whole packed stream,
+        // 100 MB per 65536-block batch). Any other position -- the bit-by-bit slide after a failed check, a re-lock on another
+        // alignment -- makes fetch_full() bring the whole stream over once, and the walk carries on from it.
+        struct WindowSource
+        {
+            const uint32_t *words = nullptr; // gathered windows
+            int64_t p0 = 0;                  // stream-relative position of words[0]
+            int step = 1, K = 0;
+            const uint8_t *bytes = nullptr;  // whole packed stream, once fetched
+            std::function<const uint8_t *()> fetch_full;
+            uint32_t at(int64_t p)
+            {
+                if (!bytes)
+                {
+                    const int64_t d = p - p0;
+                    if (d >= 0 && d % step == 0 && d / step < K)
+                        return words[d / step];
+                    bytes = fetch_full();
+                }
+                return window_at(bytes, p);
+            }
+        };
+
+        WalkResult walk(const DeframerState &in, WindowSource &src, int64_t base_abs, int64_t total_rel, const std::vector<uint32_t> &hits, int nblk) const
         {
             // bytes: NRZ-M decoded logical stream of this call, relative index r <-> absolute base_abs + r
             WalkResult R;
@@ -612,7 +640,7 @@ namespace sdhip
                 }
                 else
                 {
-                    const uint32_t w = window_at(bytes, p - base_abs);
+                    const uint32_t w = src.at(p - base_abs);
                     const int dist = __builtin_popcount(w ^ (s.inv ? ASMI : ASM));
                     if (s.state == 6)
                     {
@@ -696,9 +724,16 @@ namespace sdhip
                 d_packed.reserve(pbytes);
                 h_packed.reserve(pbytes);
                 launch_pack_stream(bs, d_packed.p, total, stream);
+                // the windows a locked FSM will ask for: one per frame from its next check position on
+                const int64_t gp0 = def.next_check - base_abs;
+                const int gK = (int)std::min<int64_t>(std::max<int64_t>(0, (total - gp0) / cfg.cadu_size + 2), 1 << 24);
+                d_win.reserve((size_t)gK + 1);
+                h_win.reserve((size_t)gK + 1);
+                launch_window_gather(d_packed.p, total, gp0, cfg.cadu_size, gK, d_win.p, stream);
                 int count = 0;
                 SD_HIP(hipMemcpyAsync(&count, d_count.p, sizeof(int), hipMemcpyDeviceToHost, stream));
-                SD_HIP(hipMemcpyAsync(h_packed.p, d_packed.p, pbytes - 8, hipMemcpyDeviceToHost, stream));
+                if (gK > 0)
+                    SD_HIP(hipMemcpyAsync(h_win.p, d_win.p, (size_t)gK * 4, hipMemcpyDeviceToHost, stream));
                 SD_HIP(hipStreamSynchronize(stream));
                 if (count > hits_cap)
                     throw HipError("ASM hit list overflow");
@@ -710,9 +745,20 @@ namespace sdhip
                         h += (uint32_t)(from << 1);
                     std::sort(hits.begin(), hits.end());
                 }
-                memset(h_packed.p + pbytes - 8, 0, 8);
                 tick("search+pack");
-                WalkResult W = walk(def, h_packed.p, base_abs, total, hits, n_eff);
+                WindowSource src;
+                src.words = h_win.p;
+                src.p0 = gp0;
+                src.step = cfg.cadu_size;
+                src.K = gK;
+                src.fetch_full = [&]() -> const uint8_t * {
+                    SD_HIP(hipMemcpyAsync(h_packed.p, d_packed.p, pbytes - 8, hipMemcpyDeviceToHost, stream));
+                    SD_HIP(hipStreamSynchronize(stream));
+                    memset(h_packed.p + pbytes - 8, 0, 8);
+                    stats_full_fetches++;
+                    return h_packed.p;
+                };
+                WalkResult W = walk(def, src, base_abs, total, hits, n_eff);
                 tick("walk");
 
                 if (cfg.decoder == SDHIP_DEC_METOP_AHRPT)
@@ -754,6 +800,12 @@ namespace sdhip
                     collect->done_blk.resize(nf);
                     for (int f = 0; f < nf; f++)
                         collect->done_blk[f] = (base_abs + W.frames[f].pos + (cfg.cadu_size - 32) - 1) / F;
+                }
+                if (nf > 1 && cfg.rs_i != 0 && cfg.rs_fill_bytes == -1)
+                { // frames the reference's deframer returned from ONE work() call (one Viterbi buffer): see k_rs_overrun
+                    auto call_of = [&](int f) { return (base_abs + W.frames[f].pos + (cfg.cadu_size - 32) - 1) / F; };
+                    for (int f = 0; f + 1 < nf; f++)
+                        W.frames[f].pad = call_of(f) == call_of(f + 1) ? 1 : 0;
                 }
                 if (nf > 0)
                 {

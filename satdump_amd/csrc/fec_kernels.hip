@@ -1373,6 +1373,34 @@ namespace sdhip
         out[i * 4 + 2] = (unsigned char)(w >> 8);
         out[i * 4 + 3] = (unsigned char)(w);
     }
+    // words[k] = the 32 bits ending at stream bit p0 + k * step of the packed stream (the window the deframer FSM compares
+    // with the ASM at an expected frame position); positions outside [31, total) yield 0
+    __global__ __launch_bounds__(256) void k_window_gather(const unsigned char *__restrict__ packed, long long total_bits, long long p0, int step, int K,
+                                                            unsigned *words)
+    {
+        const int k = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+        if (k >= K)
+            return;
+        const long long p = p0 + (long long)k * step;
+        unsigned w = 0;
+        if (p >= 31 && p < total_bits)
+        {
+            const long long s0 = p - 31, byte = s0 >> 3;
+            const int sh = (int)(s0 & 7);
+            unsigned long long v = 0;
+            for (int i = 0; i < 5; i++)
+                v = (v << 8) | packed[byte + i];
+            w = (unsigned)((v << (24 + sh)) >> 32);
+        }
+        words[k] = w;
+    }
+    void launch_window_gather(const uint8_t *packed, int64_t total_bits, int64_t p0, int step, int K, uint32_t *words, hipStream_t st)
+    {
+        if (K <= 0)
+            return;
+        ProfScope _ps("k_window_gather", st);
+        hipLaunchKernelGGL(k_window_gather, dim3((K + 255) / 256), dim3(256), 0, st, packed, (long long)total_bits, (long long)p0, step, K, words);
+    }
     void launch_pack_stream(const BitStream &bs, uint8_t *out_bytes, int64_t total_bits, hipStream_t st)
     {
         const int64_t n = (total_bits + 31) / 32;
@@ -1886,6 +1914,24 @@ namespace sdhip
             frames[i] ^= tabs->pn[(k - derand_start) % 255];
     }
 
+    // rs_fill_bytes = -1 (the concatenated decoder's default): ReedSolomon's de/interleave loops run to 255 - (-1) = 256 bytes
+    // (reedsolomon.cpp:145-156), one past its 255-byte buffer -- into odata[0], the next member -- and one codeblock byte past the
+    // frame: byte b of the NEXT frame in the deframer's output buffer is read into odata[0], a successful decode then leaves the
+    // first corrected message byte there (conventional basis), and interleave writes it back. When the deframer returned two
+    // frames from one call (CADUs shorter than half a Viterbi buffer: the 2048 / 2072-bit pipelines) that next frame is real:
+    // its first rs_i bytes -- sync marker bytes, rs_i <= 4 -- come out as those values. FrameDesc::pad marks a frame whose
+    // successor came from the same call.
+    __global__ __launch_bounds__(256) void k_rs_overrun(unsigned char *out, const FrameDesc *frames, int nframes, int cadu_bytes, int I, int dualbasis,
+                                                         const int *errors, const GfTables *tabs)
+    {
+        const int idx = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+        const int f = idx >> 2, b = idx & 3;
+        if (f + 1 >= nframes || b >= I || !frames[f].pad || errors[(size_t)f * I + b] < 0)
+            return;
+        const unsigned v = out[(size_t)f * cadu_bytes + 4 + b];
+        out[(size_t)(f + 1) * cadu_bytes + b] = dualbasis ? tabs->from_dual[v] : (unsigned char)v;
+    }
+
     void launch_frames(const BitStream &bs, const FrameCfg &fc, const FrameDesc *frames, int nframes, uint8_t *out, int *errors, hipStream_t st, uint8_t *clean_scratch)
     {
         if (nframes <= 0)
@@ -1897,6 +1943,12 @@ namespace sdhip
         }
         if (fc.rs_i != 0)
             launch_rs_only(out + 4, nframes, fc.cadu_bytes, fc.rs_dualbasis, fc.rs_i, fc.rs_nroots, fc.rs_fill_bytes, errors, st, clean_scratch);
+        if (fc.rs_i != 0 && fc.rs_fill_bytes == -1 && nframes > 1)
+        {
+            ProfScope _ps("k_rs_overrun", st);
+            hipLaunchKernelGGL(k_rs_overrun, dim3((unsigned)((nframes * 4 + 255) / 256)), dim3(256), 0, st, out, frames, nframes, fc.cadu_bytes, fc.rs_i, fc.rs_dualbasis,
+                               errors, tabs);
+        }
         if (fc.derand && fc.derand_after_rs)
         {
             const long long n = (long long)nframes * fc.cadu_bytes;

@@ -127,6 +127,31 @@ def test_concat_decoder_bpsk(torch_cuda, capi, orc, sigma, usecheck):
         assert util.frame_ids(got, plain)[:6] == [0, 1, 2, 3, 4, 5]
 
 
+@pytest.mark.parametrize("rs_i,usecheck", [(1, 0), (1, 1), (2, 0)])
+def test_short_cadus_and_the_fill_bytes_overrun(torch_cuda, capi, orc, rs_i, usecheck):
+    """CADUs shorter than half a Viterbi buffer (the 2048 / 2072-bit pipelines): the reference's deframer returns two frames from
+    one call, and with rs_fill_bytes = -1 (the module's default) ReedSolomon's interleave loop runs one byte past every codeblock
+    (reedsolomon.cpp:145-156): the first rs_i bytes of the NEXT frame come out as the first corrected message byte of each
+    codeword. Found by tools/twin/fec_fuzz2.py (seed 8); the output must match byte for byte, sync-marker bytes included."""
+    rng = np.random.default_rng(5 + rs_i)
+    cadus = synth.make_cadus(24, seed=77 + rs_i, rs_i=rs_i)
+    for f in range(len(cadus)):
+        for p in rng.choice(cadus.shape[1] - 4, int(rng.choice([0, 0, 3, 12, 40])), replace=False):
+            cadus[f, 4 + p] ^= int(rng.integers(1, 256))
+    sp = synth.SynthSpec(constellation="bpsk", samplerate=3e6, symbolrate=1e6, nrzm=True, seed=9)
+    soft = synth.soft_from_symbols(synth.frames_to_symbols(cadus, sp), sp, sigma=15.0, seed=4)
+    soft = np.concatenate([soft, rng.integers(-127, 128, 8192).astype(np.int8)])
+    soft = soft[: len(soft) // 8192 * 8192]
+    cs = cadus.shape[1] * 8
+    assert cs < 4096 or rs_i > 1
+    want = orc.concat_decode(pyref.fec_cfg(constellation=pyref.BPSK, nrzm=1, rs_usecheck=usecheck, cadu_size=cs, rs_i=rs_i), soft)
+    cfg = capi.fec_cfg(constellation="bpsk", nrzm=1, rs_i=rs_i, rs_type=capi.RS223, rs_usecheck=usecheck, cadu_size=cs)
+    got, ber, state, st = _run_dev(torch_cuda, capi, cfg, soft)
+    assert got.shape == want["cadu"].shape and np.array_equal(got, want["cadu"]) and len(got) >= 12
+    if rs_i == 1:  # the overrun is visible: some frame's first byte is not the sync marker's
+        assert np.any(got[:, 0] != 0x1A)
+
+
 @pytest.mark.parametrize("const,sigma,rot", [("qpsk", 30, 1), ("qpsk", 70, 0), ("oqpsk", 40, 1), ("qpsk", 120, 1)])
 def test_concat_decoder_qpsk(torch_cuda, capi, orc, const, sigma, rot):
     """JPSS-HRD-like (BASELINE config 4 in miniature): QPSK r=1/2 + NRZ-M + RS, with a 90 degree rotated stream."""
