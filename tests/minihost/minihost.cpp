@@ -229,8 +229,9 @@ int main(int argc, char **argv)
                     if (!m1->input_stream->swap(got))
                         break;
                 }
-                // let the demodulator take the last buffer, then end the stream like a stopped source does
-                std::this_thread::sleep_for(std::chrono::milliseconds(200));
+                // an empty hand-off: swap() only returns once the reader has flushed the previous buffer (buffer.h:49-106), i.e. once
+                // the demodulator has taken the last real one -- then end the stream like a stopped source does
+                m1->input_stream->swap(0);
                 m1->input_active = false;
                 m1->input_stream->stopWriter();
                 m1->input_stream->stopReader();
