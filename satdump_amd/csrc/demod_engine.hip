@@ -388,7 +388,7 @@ namespace sdhip
         DevBuf<CostasState> d_cos_spec, d_cos_end, d_cos_start;
         DevBuf<MmState> d_mm_spec, d_mm_end, d_mm_start;
         DevBuf<MmCert> d_mm_spec_c, d_mm_end_c; // what the host certificate reads (16 B per chunk instead of the 72-byte state)
-        DevBuf<MmCert> d_mm_ck;                 // experimental: per-chunk checkpoints for the early exit of re-run lanes (SDHIP_MM_CKPT)
+        DevBuf<MmCkpt> d_mm_ck;                 // per-chunk checkpoints for the early exit of re-run lanes
         DevBuf<AgcState> d_agc_ck;              // ... of the AGC and Costas lanes (SDHIP_CKPT)
         DevBuf<CostasState> d_cos_ck;
         const bool use_ckpt = env_int("SDHIP_CKPT", 1) != 0; // early exit of re-run lanes (checkpoints); SDHIP_CKPT=0: a re-run lane runs its whole chunk
@@ -900,7 +900,7 @@ namespace sdhip
                 ChunkCkpt agc_ck;
                 if (use_ckpt)
                 {
-                    agc_ck.len = 512;
+                    agc_ck.len = 2048;
                     agc_ck.per_chunk = L / agc_ck.len + 1;
                     d_agc_ck.reserve((size_t)g.K * agc_ck.per_chunk);
                     agc_ck.ck = d_agc_ck.p;
@@ -1007,7 +1007,7 @@ namespace sdhip
                     d_cos_end.reserve(cg.K);
                     if (use_ckpt)
                     {
-                        cos_ck.len = 512;
+                        cos_ck.len = 2048;
                         cos_ck.per_chunk = L / cos_ck.len + 1;
                         d_cos_ck.reserve((size_t)cg.K * cos_ck.per_chunk);
                         cos_ck.ck = d_cos_ck.p;
@@ -1153,7 +1153,7 @@ namespace sdhip
                 const double MM_TOL_TIGHT = 2e-4;
                 const double MM_TOL = getenv("SDHIP_MM_TOL_MICRO") ? env_int("SDHIP_MM_TOL_MICRO", 5000) * 1e-6
                                                                   : (getenv("SDHIP_MM_TOL_MILLI") ? env_int("SDHIP_MM_TOL_MILLI", 5) * 1e-3 : 5e-3);
-                MmCert *ckp = nullptr;
+                MmCkpt *ckp = nullptr;
                 int ck_per_chunk = 0;
                 auto mm_setup = [&](long long Wn) {
                     g = make_geom(n, L, (int)Wn);
@@ -1172,7 +1172,7 @@ namespace sdhip
                     d_skip.reserve(g.K);
                     d_extra.reserve(g.K);
                     d_seg.reserve(2 * (size_t)g.K);
-                    ck_per_chunk = mm_p.cap / MM_CKPT_SYMS + 1;
+                    ck_per_chunk = L / MM_CK_SAMPLES + 2;
                     if (use_ckpt || env_int("SDHIP_MM_CKPT", 0))
                     { // checkpoints for the early exit of re-run lanes, k_mm<true>
                         d_mm_ck.reserve((size_t)g.K * ck_per_chunk);

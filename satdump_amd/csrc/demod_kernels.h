@@ -146,12 +146,18 @@ namespace sdhip
         float mu, omega;
         long long inc;
     };
+    struct MmCkpt // checkpoint of a clock-recovery lane: its state when the block ending at a multiple of MM_CK_SAMPLES has been fed
+    {
+        float mu, omega;
+        long long inc;
+        int cnt, pad;
+    };
     // counts: 2 ints per chunk = {symbols emitted inside the chunk, extra symbols computed past its end (0..2, stored right after)}
     // spec_c / end_c: compact copies of spec / endst for the host
     void launch_mm(const cf32 *x, cf32 *sym_scratch, int *counts, const ChunkGeom &g, const MmParams &p, const MmState *start0, MmState *spec, MmState *endst,
-                   MmCert *spec_c, MmCert *end_c, const int *redo, int nredo, hipStream_t st, MmCert *ck = nullptr, int ck_per_chunk = 0,
+                   MmCert *spec_c, MmCert *end_c, const int *redo, int nredo, hipStream_t st, MmCkpt *ck = nullptr, int ck_per_chunk = 0,
                    float ck_tol = 0.0f); // ck: optional per-chunk checkpoint rows (experimental early exit of re-run lanes, see k_mm)
-    constexpr int MM_CKPT_SYMS = 64;      // symbols between checkpoints (= MM_CK_SYMS of the kernel)
+    constexpr int MM_CK_SAMPLES = 1024;   // input samples between the checkpoints of a clock-recovery lane
     // ---- Gardner clock recovery (clock_recovery_gardner.cpp:33-124), sequential lane; x must have >= 32 samples of history in front
     struct GardnerParams
     {

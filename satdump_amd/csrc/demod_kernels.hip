@@ -891,8 +891,17 @@ namespace sdhip
     // Groups of Stage::DEPTH blocks, double buffered: all loads of group j+1 (DEPTH * 64 contiguous bytes of this lane's stream,
     // whole 128-byte lines when DEPTH is even and the range starts on a 16-sample boundary) are issued together before group
     // j is consumed, instead of one 64-byte block at a time.
-    template <class Stage>
-    __device__ __forceinline__ void run_range(typename Stage::S &s, const typename Stage::P &p, const cf32 *x, cf32 *y, long long i0, long long i1, bool write)
+    // HOOK: hook(i) is called whenever the lane has just finished the samples in front of i and (i - hb) is a multiple of hstep
+    // (a power of two, a multiple of the group size; i0 and hb are multiples of 64): the checkpoints of k_chunks. It returns
+    // true to stop the lane there. The test rides on the group loop -- a mask and a compare per 16 / 32 samples -- so that the
+    // main launch keeps its double-buffered stream instead of restarting it for every piece.
+    struct NoHook
+    {
+        __device__ __forceinline__ bool operator()(long long) const { return false; }
+    };
+    template <class Stage, bool HOOK = false, class Hook = NoHook>
+    __device__ __forceinline__ void run_range(typename Stage::S &s, const typename Stage::P &p, const cf32 *x, cf32 *y, long long i0, long long i1, bool write,
+                                              long long hb = 0, int hstep = 0, Hook hook = Hook())
     {
         constexpr int D = Stage::DEPTH;
         long long i = i0;
@@ -919,6 +928,9 @@ namespace sdhip
                 }
                 group_run<Stage, D>(s, p, qa, y, i, write);
                 i += 8 * D;
+                if constexpr (HOOK)
+                    if ((((i - hb) & (long long)(hstep - 1)) == 0) && i < i1 && hook(i))
+                        return;
                 if (!more_b)
                     break;
                 const bool more_a = i + 16 * D <= i1;
@@ -930,6 +942,9 @@ namespace sdhip
                 }
                 group_run<Stage, D>(s, p, qb, y, i, write);
                 i += 8 * D;
+                if constexpr (HOOK)
+                    if ((((i - hb) & (long long)(hstep - 1)) == 0) && i < i1 && hook(i))
+                        return;
                 if (!more_a)
                     break;
             }
@@ -942,11 +957,10 @@ namespace sdhip
         }
     }
 
-    // CKPT (experimental, SDHIP_CKPT=1, validated on the host twin only): the chunk is run in pieces of ck_len samples and the
-    // state after every piece is left in ck[k][*]. A re-run lane compares itself with the checkpoint at the same sample index
-    // and stops as soon as Stage::close() holds: from there on the output and the end state of the earlier run stand, under the
-    // rule that accepts a chunk boundary. A lane that does not merge overwrites the checkpoints (they always describe the
-    // trajectory whose samples are in y).
+    // CKPT: every ck_len samples of its chunk a lane leaves its state in ck[k][*]. A re-run lane compares itself with the
+    // checkpoint at the same sample index and stops as soon as Stage::close() holds: from there on the output and the end state
+    // of the earlier run stand, under the rule that accepts a chunk boundary. A lane that does not merge overwrites the
+    // checkpoints (they always describe the trajectory whose samples are in y).
     template <class Stage, bool CKPT>
     __global__ __launch_bounds__(64) void k_chunks(const cf32 *x, cf32 *y, ChunkGeom g, typename Stage::P p, const typename Stage::S *start0,
                                                    typename Stage::S *spec, typename Stage::S *endst, const int *redo, int nredo, typename Stage::S *ck,
@@ -989,31 +1003,30 @@ namespace sdhip
         }
         else
         {
+            // checkpoint j = the state after the samples in front of b + (j + 1) * ck_len. The main launch leaves them behind; a
+            // re-run lane compares itself with the one at the same position and stops as soon as Stage::close() holds.
             bool merged = false;
-            int j = 0;
-            for (long long pos = b; pos < e;)
-            {
-                const long long nxt = pos + ck_len < e ? pos + ck_len : e;
-                run_range<Stage>(s, p, x, y, pos, nxt, true);
-                pos = nxt;
-                if (pos < e && j < ck_per_chunk)
+            int jmax = 0;
+            typename Stage::S *cks = ck + (size_t)k * ck_per_chunk;
+            run_range<Stage, true>(s, p, x, y, b, e, true, b, ck_len, [&](long long i) -> bool {
+                const int j = (int)((i - b) / ck_len) - 1;
+                if (j < 0 || j >= ck_per_chunk)
+                    return false;
+                jmax = j + 1;
+                if (redo && Stage::close(s, cks[j], tol_a, tol_b))
                 {
-                    typename Stage::S *c = ck + (size_t)k * ck_per_chunk + j;
-                    if (redo && Stage::close(s, *c, tol_a, tol_b))
-                    {
-                        merged = true;
-                        break;
-                    }
-                    *c = s;
-                    j++;
+                    merged = true;
+                    return true;
                 }
-            }
+                cks[j] = s;
+                return false;
+            });
             if (!merged)
                 endst[k] = s;
             if (redo && ck_work)
             { // statistics of the experiment: re-run lanes, pieces they ran, pieces a full re-run would have run
                 atomicAdd(ck_work, 1ull);
-                atomicAdd(ck_work + 1, (unsigned long long)(j + 1));
+                atomicAdd(ck_work + 1, (unsigned long long)(jmax + 1));
                 atomicAdd(ck_work + 2, (unsigned long long)((e - b + ck_len - 1) / ck_len));
             }
         }
@@ -1304,19 +1317,19 @@ namespace sdhip
         return out;
     }
 
-    // CKPT (experimental, SDHIP_MM_CKPT=1, not yet validated on the GPU -- DESIGN.md 6b): every MM_CK_SYMS symbols of its chunk a
-    // lane leaves a checkpoint {mu, omega, inc} of the state that is about to produce that symbol. A re-run lane (exact start
-    // state) compares itself with the checkpoint of the same symbol index and stops as soon as it is inside the boundary
-    // tolerance: from there on the speculative output, count and end state of the chunk stand under the very rule that accepts a
+    // CKPT: whenever the block ending at a multiple of MM_CK_SAMPLES samples into its chunk has been fed, a lane leaves a
+    // checkpoint {mu, omega, inc, symbols so far}. A re-run lane (exact start state) compares itself with the checkpoint at the
+    // same position and stops as soon as it has produced the same number of symbols and is inside the boundary tolerance in
+    // time: from there on the speculative output, count and end state of the chunk stand under the very rule that accepts a
     // chunk boundary. A lane that does not merge overwrites the checkpoints, so they always describe the trajectory whose
-    // symbols are in the scratch rows.
-    constexpr int MM_CK_SYMS = 64;
+    // symbols are in the scratch rows. (The test sits in the block loop, not in the symbol loop: a checkpoint per symbol count
+    // cost the main launch 12 % -- measured, MetOp: 14.8 against 13.2 ms.)
     // SPLIT (experimental, SDHIP_MM_SPLIT=1, same results bit for bit -- checked on the host twin; not yet measured): the symbol loop
     // as three plain loops, one per phase, each bounded by a single sample-index test, instead of one loop that re-evaluates the
     // warm-up / chunk / look-ahead bookkeeping (~45 of its ~200 instructions) on every symbol. The lane is issue-bound.
     template <bool CKPT, bool SPLIT>
     __global__ __launch_bounds__(64) void k_mm(const cf32 *x, cf32 *sym, int *counts, ChunkGeom g, MmParams p, const MmState *start0, MmState *spec,
-                                               MmState *endst, MmCert *spec_c, MmCert *end_c, const int *redo, int nredo, MmCert *ck, int ck_per_chunk,
+                                               MmState *endst, MmCert *spec_c, MmCert *end_c, const int *redo, int nredo, MmCkpt *ck, int ck_per_chunk,
                                                float ck_tol)
     {
         __shared__ cf32 rings[MM_RING * MM_RING_STRIDE];
@@ -1374,6 +1387,27 @@ namespace sdhip
                 const Blk8 cur = q[d];
                 q[d] = blk_load(x, f.next + 8 * MM_DEPTH); // at most 8*MM_DEPTH + 8 samples past the lane's last window
                 mm_feed_put(f, p, cur);
+                if constexpr (CKPT)
+                { // one test per 8-sample block, outside the symbol loop: a checkpoint every MM_CK_SAMPLES samples of the chunk
+                    const long long rel = f.next - b;
+                    if (phase == 1 && rel > 0 && (rel & (MM_CK_SAMPLES - 1)) == 0 && f.next < e)
+                    {
+                        const int j = (int)(rel / MM_CK_SAMPLES) - 1;
+                        if (j < ck_per_chunk)
+                        {
+                            MmCkpt *c = ck + (size_t)k * ck_per_chunk + j;
+                            if (redo)
+                            {
+                                const MmCkpt o = *c;
+                                const double dt = (double)(s.inc - o.inc) + ((double)s.mu - (double)o.mu);
+                                if (cnt == o.cnt && fabs(dt) < (double)ck_tol && fabsf(s.omega - o.omega) < 1e-3f * fabsf(o.omega))
+                                    merged = done = true;
+                            }
+                            if (!merged)
+                                *c = MmCkpt{s.mu, s.omega, s.inc, cnt, 0};
+                        }
+                    }
+                }
                 if constexpr (SPLIT && !CKPT)
                 {
                     while (!done && s.inc < f.next)
@@ -1444,36 +1478,12 @@ namespace sdhip
                         counts[2 * k] = cnt;
                         endst[k] = s;
                         end_c[k] = MmCert{s.mu, s.omega, s.inc};
-                        if constexpr (CKPT)
-                        { // the slot behind this run's last checkpoint may hold one of an earlier call: it must never match
-                            // (slots 0 .. (cnt-1)/64 - 1 were written: a checkpoint exists for every symbol index 64 m < cnt)
-                            const int nxt = cnt > 0 ? (cnt - 1) / MM_CK_SYMS : 0;
-                            if (nxt < ck_per_chunk)
-                                ck[(size_t)k * ck_per_chunk + nxt] = MmCert{0.0f, 0.0f, -(1ll << 60)};
-                        }
                         phase = 2;
                         if (k + 1 >= g.K)
                             done = true;
                     }
                     if (phase == 2 && (nx >= 2 || s.inc >= g.n))
                         done = true;
-                    if constexpr (CKPT)
-                    {
-                        if (!done && phase == 1 && cnt > 0 && (cnt & (MM_CK_SYMS - 1)) == 0 && cnt / MM_CK_SYMS <= ck_per_chunk)
-                        {
-                            MmCert *c = ck + (size_t)k * ck_per_chunk + (cnt / MM_CK_SYMS - 1);
-                            if (redo)
-                            {
-                                const MmCert o = *c;
-                                const double dt = (double)(s.inc - o.inc) + ((double)s.mu - (double)o.mu);
-                                if (fabs(dt) < (double)ck_tol && fabsf(s.omega - o.omega) < 1e-3f * fabsf(o.omega))
-                                    merged = done = true;
-
-                            }
-                            if (!merged)
-                                *c = MmCert{s.mu, s.omega, s.inc};
-                        }
-                    }
                     if (!done)
                     {
                         // warm-up gear shift: the first fast_syms symbols of a warm-up run with the timing gain raised and the
@@ -1499,7 +1509,7 @@ namespace sdhip
             counts[2 * k + 1] = nx;
     }
     void launch_mm(const cf32 *x, cf32 *sym_scratch, int *counts, const ChunkGeom &g, const MmParams &p, const MmState *start0, MmState *spec, MmState *endst,
-                   MmCert *spec_c, MmCert *end_c, const int *redo, int nredo, hipStream_t st, MmCert *ck, int ck_per_chunk, float ck_tol)
+                   MmCert *spec_c, MmCert *end_c, const int *redo, int nredo, hipStream_t st, MmCkpt *ck, int ck_per_chunk, float ck_tol)
     {
         const int n = redo ? nredo : g.K;
         if (n <= 0)
@@ -1512,10 +1522,10 @@ namespace sdhip
                                nredo, ck, ck_per_chunk, ck_tol);
         else if (split)
             hipLaunchKernelGGL((k_mm<false, true>), dim3((n + 63) / 64), dim3(64), 0, st, x, sym_scratch, counts, g, p, start0, spec, endst, spec_c, end_c, redo,
-                               nredo, (MmCert *)nullptr, 0, 0.0f);
+                               nredo, (MmCkpt *)nullptr, 0, 0.0f);
         else
             hipLaunchKernelGGL((k_mm<false, false>), dim3((n + 63) / 64), dim3(64), 0, st, x, sym_scratch, counts, g, p, start0, spec, endst, spec_c, end_c, redo,
-                               nredo, (MmCert *)nullptr, 0, 0.0f);
+                               nredo, (MmCkpt *)nullptr, 0, 0.0f);
     }
 
     // =============================================================================================
