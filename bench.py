@@ -415,9 +415,10 @@ def main():
                 want.add(bytes(p))
                 want_payload.add(bytes(p[4:]))
         ok = sum(1 for g in got if bytes(g) in want)
-        ok_payload = sum(1 for g in got if bytes(g[4:]) in want_payload)  # the 4-byte ASM is not RS protected: channel errors stay in it
+        bad_at = [i for i, g in enumerate(got) if bytes(g[4:]) not in want_payload]
+        ok_payload = len(got) - len(bad_at)  # the 4-byte ASM is not RS protected: channel errors stay in it
         check = {"cadus_last_step": int(last_nf), "cadus_matching_transmitted": int(ok), "payload_matching_transmitted": int(ok_payload),
-                 "transmitted": int(frames * bpr)}
+                 "transmitted": int(frames * bpr), "not_matching_at": bad_at[:6] + (["..."] + bad_at[-3:] if len(bad_at) > 9 else bad_at[6:9])}
         if world > 1:
             c = torch.tensor([float(last_nf), float(ok), float(ok_payload)], dtype=torch.float64, device=coll_dev)
             dist.all_reduce(c)

@@ -222,7 +222,7 @@ namespace sdhip
         int nphases = 1, n_swap = 1;
         int st_synced = 12;
         double ber_mult = 2.5;
-        int max_batch = 65536; // blocks per Viterbi launch (decision scratch: 8 B per trellis step, ~2.2 GB at F = 4096)
+        int max_batch = getenv("SDHIP_FEC_BATCH") ? std::max(1, atoi(getenv("SDHIP_FEC_BATCH"))) : 65536; // blocks per Viterbi launch (decision scratch: 8 B per trellis step, ~2.2 GB at F = 4096)
 
         // Viterbi FSM (viterbi_1_2.h:25-31)
         int vstate = 0, v_iq_swap = 0, v_phase = 0, v_shift = 0, v_invalid = 0;
@@ -758,6 +758,8 @@ namespace sdhip
                     stats_full_fetches++;
                     return h_packed.p;
                 };
+                if (getenv("SDHIP_WINDOW_GATHER") && atoi(getenv("SDHIP_WINDOW_GATHER")) == 0)
+                    src.bytes = src.fetch_full(); // A/B switch: the whole stream on the host, as before the gather
                 WalkResult W = walk(def, src, base_abs, total, hits, n_eff);
                 tick("walk");
 
