@@ -167,14 +167,16 @@ def cpu_baseline(wl, x_host):
                               f"{len(th['cadu'])} CADUs in {th['seconds']:.2f} s"})
     else:
         res.update({"value": single["value"], "cores": 1, "sample": f"first {n} samples of rank 0's stream, one thread"})
-    # all cores: one instance per core, each on its own slice
-    per = max(1_000_000, min(n // 4, 400_000_000 // max(1, ncores)))
-    k = min(ncores, max(1, n // per))
-    if k > 1:
-        outs = [None] * k
+    # all cores: one independent reference instance per host core, each on its own 2 M-sample window of the sample (the windows
+    # are spread evenly over it and overlap when there are more cores than sample / 2 M: a throughput figure, instance i has
+    # nothing to do with instance j)
+    per = min(n, 2_000_000)
+    k = ncores
+    if k > 1 and per >= 500_000:
+        starts = [(i * (n - per)) // max(1, k - 1) for i in range(k)]
 
         def work(i):
-            outs[i] = ref_decode(orc, wl, x_host[i * per:(i + 1) * per], want_syms=False)[1]
+            ref_decode(orc, wl, x_host[starts[i]:starts[i] + per], want_syms=False)
 
         ths = [threading.Thread(target=work, args=(i,)) for i in range(k)]
         t0 = time.perf_counter()
