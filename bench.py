@@ -401,10 +401,13 @@ def main():
     if not args.no_check:
         got = d_cadu[:last_nf].cpu().numpy()
         want, want_payload = set(), set()
+        order = {}
         for b in range(rank * bpr, (rank + 1) * bpr):
             plain = rec.plain_cadus(b)
             want |= {bytes(p) for p in plain}
             want_payload |= {bytes(p[4:]) for p in plain}
+            for i, p in enumerate(plain):
+                order[bytes(p[4:20])] = (b - rank * bpr) * frames + i
         if args.dump:
             np.save(f"{args.dump}.rank{rank}.npy", got)
         if world > 1:
@@ -418,9 +421,15 @@ def main():
                 want_payload.add(bytes(p[4:]))
         ok = sum(1 for g in got if bytes(g) in want)
         bad_at = [i for i, g in enumerate(got) if bytes(g[4:]) not in want_payload]
+        # where the output leaves the transmitted order: (position in the output, id before, id after); the stream is periodic, so
+        # id + 1 modulo the frame count is "no gap"
+        ids = [order.get(bytes(g[4:20]), -1) for g in got]
+        nfr = frames * bpr
+        gaps = [(i, ids[i - 1], ids[i]) for i in range(1, len(ids)) if ids[i] >= 0 and ids[i - 1] >= 0 and ids[i] != (ids[i - 1] + 1) % nfr]
         ok_payload = len(got) - len(bad_at)  # the 4-byte ASM is not RS protected: channel errors stay in it
         check = {"cadus_last_step": int(last_nf), "cadus_matching_transmitted": int(ok), "payload_matching_transmitted": int(ok_payload),
-                 "transmitted": int(frames * bpr), "not_matching_at": bad_at[:6] + (["..."] + bad_at[-3:] if len(bad_at) > 9 else bad_at[6:9])}
+                 "transmitted": int(frames * bpr), "not_matching_at": bad_at[:6] + (["..."] + bad_at[-3:] if len(bad_at) > 9 else bad_at[6:9]),
+                 "first_id": ids[0] if ids else None, "order_breaks": gaps[:8]}
         if world > 1:
             c = torch.tensor([float(last_nf), float(ok), float(ok_payload)], dtype=torch.float64, device=coll_dev)
             dist.all_reduce(c)

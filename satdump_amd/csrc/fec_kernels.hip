@@ -999,12 +999,23 @@ namespace sdhip
                                                        unsigned char *dst)
     {
         const SymFetch f{c, blk, n_in};
+        // An odd count: the last depunctured symbol is carried to the next call, and ViterbiSlidingBuffer::add copies only the even
+        // part (viterbi_punc.cpp:108-118, viterbi_buffer.h:26-30): the buffer slot behind it keeps what it held -- cc_decoder reads
+        // a few symbols past the block, so that slot is visible to the chainback's end state. Scatter, take the carry, put the old
+        // byte back.
+        unsigned char old = 0;
+        if ((total & 1) && threadIdx.x == 0)
+            old = dst[total - 1];
+        __syncthreads();
         if (lead && threadIdx.x == 0)
             dst[0] = *carry;
         punc_scatter(pat, f, n_in, pos0, lead, dst);
         __syncthreads();
         if ((total & 1) && threadIdx.x == 0)
+        {
             *carry = dst[total - 1];
+            dst[total - 1] = old;
+        }
     }
     void launch_punc_static(const VitCfg &c, const int8_t *blk, const PuncPat &pat, int shift, int n_in, unsigned char *out, hipStream_t st)
     {

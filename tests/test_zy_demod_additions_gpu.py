@@ -4,6 +4,7 @@ import numpy as np
 import pytest
 
 from oracle import pyref
+from satdump_amd import synth
 from tests.test_demod_gpu import _run_demod, capi, orc, torch_cuda  # noqa: F401  (fixtures)
 
 pytestmark = pytest.mark.gpu
@@ -96,3 +97,32 @@ def test_post_costas_dc(torch_cuda, capi, orc, case):
     got = dec.pull()
     wantc = orc.concat_decode(ofec, want["soft"])["cadu"]
     assert got.shape == wantc.shape and np.array_equal(got, wantc) and len(got) >= 20
+
+
+@pytest.mark.parametrize("workload,frames", [("metop_ahrpt", 2100), ("npp_hrd", 2000)])
+def test_three_passes_through_stateful_handles_equal_the_reference_on_the_tiled_recording(torch_cuda, capi, orc, workload, frames):
+    """What bench.py times at N=1: ONE pair of handles, the periodic recording passed through it step after step (engine state,
+    histories, pending FEC buffers, Costas frame all carry over the call boundary). Three passes of a 29-33 M-sample recording
+    against the reference run once over the recording tiled three times: the CADU lists must be identical byte for byte -- frames
+    around every call boundary included, and, for MetOp (no RS check), the frames RS cannot correct as well."""
+    import bench
+    wl = bench.WORKLOADS[workload]
+    rec = synth.Recording(synth.SynthSpec(**wl["spec"]), frames, blocks=1)
+    x = rec.synth_range(0, rec.n_samples, device="cuda")
+    n = x.numel()
+    dem = capi.PskDemod(capi.demod_cfg(**wl["demod"]))
+    fec = capi.FecDecoder(capi.fec_cfg(**wl["fec"]))
+    d_soft = torch_cuda.empty(2 * n + 64, dtype=torch_cuda.int8, device="cuda")
+    d_cadu = torch_cuda.empty((frames + 64, 1024), dtype=torch_cuda.uint8, device="cuda")
+    outs, nsoft = [], 0
+    for _ in range(3):
+        ns = dem.process_dev(x.data_ptr(), n, capi.FMT_CF32, d_soft.data_ptr(), 2 * n + 64)
+        nf = fec.process_dev(d_soft.data_ptr(), ns, d_cadu.data_ptr(), frames + 64)
+        outs.append(d_cadu[:nf].cpu().numpy().copy())
+        nsoft += ns
+    got = np.concatenate(outs)
+    xh = x.cpu().numpy()
+    r, refc, _, _ = bench.ref_decode(orc, wl, np.concatenate([xh, xh, xh]), want_syms=False)
+    assert nsoft == len(r["soft"])
+    assert got.shape == refc.shape and np.array_equal(got, refc)
+    assert len(outs[1]) >= frames - 1 and len(outs[2]) >= frames - 1
