@@ -584,7 +584,25 @@ namespace sdhip
             }
         };
 
-        WalkResult walk(const DeframerState &in, WindowSource &src, int64_t base_abs, int64_t total_rel, const std::vector<uint32_t> &hits, int nblk) const
+        // The exact-ASM hit list is only consulted while the FSM is in NOSYNC (a stream start, a loss of lock): it is searched
+        // for, copied and sorted on first use -- a locked decoder never pays for it.
+        struct HitSource
+        {
+            std::function<void(std::vector<uint32_t> &)> produce;
+            std::vector<uint32_t> hits;
+            bool have = false;
+            const std::vector<uint32_t> &get()
+            {
+                if (!have)
+                {
+                    produce(hits);
+                    have = true;
+                }
+                return hits;
+            }
+        };
+
+        WalkResult walk(const DeframerState &in, WindowSource &src, int64_t base_abs, int64_t total_rel, HitSource &hs, int nblk) const
         {
             // bytes: NRZ-M decoded logical stream of this call, relative index r <-> absolute base_abs + r
             WalkResult R;
@@ -623,6 +641,7 @@ namespace sdhip
                 {
                     // exact ASM / ~ASM, bit by bit (bpsk_ccsds_deframer.cpp:49-67): jump to the next GPU-found hit
                     const int64_t prel = p - base_abs;
+                    const std::vector<uint32_t> &hits = hs.get();
                     while (hit_ptr < hits.size() && (int64_t)(hits[hit_ptr] >> 1) < prel)
                         hit_ptr++;
                     if (hit_ptr >= hits.size())
@@ -715,11 +734,7 @@ namespace sdhip
                 const int64_t base_abs = abs_bits - carry_bits;
                 // exact hits are only needed from the first position the FSM may evaluate
                 const int hits_cap = (int)std::min<int64_t>(total / 64 + 1024, 1 << 26);
-                d_hits.reserve(hits_cap);
-                h_hits.reserve(hits_cap);
-                SD_HIP(hipMemsetAsync(d_count.p, 0, sizeof(int), stream));
                 int64_t from = std::max<int64_t>(def.next_check - base_abs, 32);
-                launch_sync_search(bs, from, cfg.asm_sync, d_hits.p, hits_cap, d_count.p, stream);
                 const size_t pbytes = (size_t)((total + 31) / 32) * 4 + 8;
                 d_packed.reserve(pbytes);
                 h_packed.reserve(pbytes);
@@ -730,21 +745,28 @@ namespace sdhip
                 d_win.reserve((size_t)gK + 1);
                 h_win.reserve((size_t)gK + 1);
                 launch_window_gather(d_packed.p, total, gp0, cfg.cadu_size, gK, d_win.p, stream);
-                int count = 0;
-                SD_HIP(hipMemcpyAsync(&count, d_count.p, sizeof(int), hipMemcpyDeviceToHost, stream));
                 if (gK > 0)
                     SD_HIP(hipMemcpyAsync(h_win.p, d_win.p, (size_t)gK * 4, hipMemcpyDeviceToHost, stream));
                 SD_HIP(hipStreamSynchronize(stream));
-                if (count > hits_cap)
-                    throw HipError("ASM hit list overflow");
-                std::vector<uint32_t> hits(count);
-                if (count)
-                {
-                    SD_HIP(hipMemcpy(hits.data(), d_hits.p, (size_t)count * 4, hipMemcpyDeviceToHost));
-                    for (auto &h : hits)
-                        h += (uint32_t)(from << 1);
-                    std::sort(hits.begin(), hits.end());
-                }
+                HitSource hs;
+                hs.produce = [&](std::vector<uint32_t> &hits) {
+                    d_hits.reserve(hits_cap);
+                    SD_HIP(hipMemsetAsync(d_count.p, 0, sizeof(int), stream));
+                    launch_sync_search(bs, from, cfg.asm_sync, d_hits.p, hits_cap, d_count.p, stream);
+                    int count = 0;
+                    SD_HIP(hipMemcpyAsync(&count, d_count.p, sizeof(int), hipMemcpyDeviceToHost, stream));
+                    SD_HIP(hipStreamSynchronize(stream));
+                    if (count > hits_cap)
+                        throw HipError("ASM hit list overflow");
+                    hits.resize(count);
+                    if (count)
+                    {
+                        SD_HIP(hipMemcpy(hits.data(), d_hits.p, (size_t)count * 4, hipMemcpyDeviceToHost));
+                        for (auto &h : hits)
+                            h += (uint32_t)(from << 1);
+                        std::sort(hits.begin(), hits.end());
+                    }
+                };
                 tick("search+pack");
                 WindowSource src;
                 src.words = h_win.p;
@@ -760,7 +782,7 @@ namespace sdhip
                 };
                 if (getenv("SDHIP_WINDOW_GATHER") && atoi(getenv("SDHIP_WINDOW_GATHER")) == 0)
                     src.bytes = src.fetch_full(); // A/B switch: the whole stream on the host, as before the gather
-                WalkResult W = walk(def, src, base_abs, total, hits, n_eff);
+                WalkResult W = walk(def, src, base_abs, total, hs, n_eff);
                 tick("walk");
 
                 if (cfg.decoder == SDHIP_DEC_METOP_AHRPT)
