@@ -89,6 +89,11 @@ extern "C"
         int buffer_size;                  /* "buffer_size"; <=0 -> reference default (module_demod_base.cpp:22-25) */
         int post_costas_dc;               /* "post_costas_dc", default 0: a CorrectIQ DC block between the Costas loop and the clock recovery
                                              (module_psk_demod.cpp:36-38, 127-134) */
+        int has_carrier;                  /* "has_carrier", default 0: BPSK on a residual carrier -- a carrier-tracking PLL and a DC block between the
+                                             RRC filter and the Costas loop (module_psk_demod.cpp:39-40, 93-113; pll_carrier_tracking.cpp:23-66).
+                                             BPSK only; the Costas frequency limit then defaults to 0.2 rad/sample instead of 1.0 */
+        float carrier_pll_bw;             /* "carrier_pll_bw" (mandatory with has_carrier) */
+        float carrier_pll_max_offset;     /* "carrier_pll_max_offset", default 3.14 rad/sample */
         /* engine knobs (ours; no reference equivalent) */
         int exact;     /* 1: one sequential lane per stream, bit-for-bit the reference schedule (slow; parity tests) */
         int chunk_len; /* speculative chunk length in (resampled) samples; <=0 -> auto */

@@ -50,6 +50,8 @@ std::shared_ptr<slog::Logger> logger = std::make_shared<slog::Logger>();
 #include "common/dsp/filter/fir.h"
 #include "common/dsp/filter/firdes.h"
 #include "common/dsp/pll/costas_loop.h"
+#include "common/dsp/pll/pll_carrier_tracking.h"
+#include "common/dsp/utils/fast_trig.h"
 #include "common/dsp/clock_recovery/clock_recovery_mm.h"
 #include "common/dsp/clock_recovery/clock_recovery_gardner.h"
 #include "common/dsp/resamp/rational_resampler.h"
@@ -599,6 +601,7 @@ extern "C"
         std::shared_ptr<dsp::CorrectIQBlock<complex_t>> dc;
         std::shared_ptr<dsp::DelayOneImagBlock> dly;
         std::shared_ptr<dsp::GardnerClockRecoveryBlock<complex_t>> gar;
+        std::shared_ptr<dsp::PLLCarrierTrackingBlock> cpll;
         switch (kind)
         {
         case 0: // AGC(rate, ref, gain, max_gain)
@@ -635,6 +638,10 @@ extern "C"
             gar->sample = gar->zc_sample = gar->last_sample = complex_t(0, 0); // uninitialised members in the reference
             outs = gar->output_stream;
             break;
+        case 8: // PLLCarrierTracking(loop_bw, max, min)
+            cpll = std::make_shared<dsp::PLLCarrierTrackingBlock>(in, p[0], p[1], p[2]);
+            outs = cpll->output_stream;
+            break;
         default:
             return -1;
         }
@@ -652,6 +659,7 @@ extern "C"
             if (dc) dc->work();
             if (dly) dly->work();
             if (gar) gar->work();
+            if (cpll) cpll->work();
             int k = outs->read();
             if (k > 0)
             {
@@ -675,6 +683,8 @@ extern "C"
         std::shared_ptr<dsp::SmartResamplerBlock<complex_t>> rresamp;
         std::shared_ptr<dsp::AGCBlock<complex_t>> agc;
         std::shared_ptr<dsp::FIRBlock<complex_t>> rrc;
+        std::shared_ptr<dsp::PLLCarrierTrackingBlock> carrier_pll;
+        std::shared_ptr<dsp::CorrectIQBlock<complex_t>> carrier_dc;
         std::shared_ptr<dsp::CostasLoopBlock> pll;
         std::shared_ptr<dsp::CorrectIQBlock<complex_t>> post_pll_dc;
         std::shared_ptr<dsp::DelayOneImagBlock> delay;
@@ -726,11 +736,21 @@ extern "C"
             agc = std::make_shared<dsp::AGCBlock<complex_t>>(cur, c->agc_rate, 1.0f, 1.0f, 65536);
             // --- PSKDemodModule::init (module_psk_demod.cpp:86-136)
             rrc = std::make_shared<dsp::FIRBlock<complex_t>>(agc->output_stream, dsp::firdes::root_raised_cosine(1, final_samplerate, d_symbolrate, c->rrc_alpha, c->rrc_taps));
-            float costas_max_offset = 1.0;
+            if (c->has_carrier) // module_psk_demod.cpp:93-113
+            {
+                if (!is_bpsk)
+                {
+                    ok = false;
+                    return;
+                }
+                carrier_pll = std::make_shared<dsp::PLLCarrierTrackingBlock>(rrc->output_stream, c->carrier_pll_bw, c->carrier_pll_max_offset, -c->carrier_pll_max_offset);
+                carrier_dc = std::make_shared<dsp::CorrectIQBlock<complex_t>>(carrier_pll->output_stream);
+            }
+            float costas_max_offset = c->has_carrier ? 0.2 : 1.0;
             if (c->costas_max_offset_hz > 0)
                 costas_max_offset = dsp::hz_to_rad(c->costas_max_offset_hz, final_samplerate);
             unsigned order = is_bpsk ? 2 : (c->constellation == SDHIP_8PSK ? 8 : 4);
-            pll = std::make_shared<dsp::CostasLoopBlock>(rrc->output_stream, c->pll_bw, order, costas_max_offset);
+            pll = std::make_shared<dsp::CostasLoopBlock>(c->has_carrier ? carrier_dc->output_stream : rrc->output_stream, c->pll_bw, order, costas_max_offset);
             if (c->post_costas_dc) // module_psk_demod.cpp:127-134
                 post_pll_dc = std::make_shared<dsp::CorrectIQBlock<complex_t>>(pll->output_stream);
             if (is_oqpsk)
@@ -763,6 +783,8 @@ extern "C"
         auto &rresamp = ch.rresamp;
         auto &agc = ch.agc;
         auto &rrc = ch.rrc;
+        auto &carrier_pll = ch.carrier_pll;
+        auto &carrier_dc = ch.carrier_dc;
         auto &pll = ch.pll;
         auto &post_pll_dc = ch.post_pll_dc;
         auto &delay = ch.delay;
@@ -792,6 +814,7 @@ extern "C"
             if (rresamp) rresamp->work();
             agc->work();
             rrc->work();
+            if (carrier_pll) carrier_pll->work(), carrier_dc->work();
             pll->work();
             if (post_pll_dc) post_pll_dc->work();
             if (delay) delay->work();
@@ -861,6 +884,7 @@ extern "C"
         if (ch.rresamp) ch.rresamp->start(), nthreads++;
         ch.agc->start(), nthreads++;
         ch.rrc->start(), nthreads++;
+        if (ch.carrier_pll) ch.carrier_pll->start(), ch.carrier_dc->start(), nthreads += 2;
         ch.pll->start(), nthreads++;
         if (ch.post_pll_dc) ch.post_pll_dc->start(), nthreads++;
         if (ch.delay) ch.delay->start(), nthreads++;
@@ -925,6 +949,7 @@ extern "C"
         if (ch.rresamp) ch.rresamp->stop();
         ch.agc->stop();
         ch.rrc->stop();
+        if (ch.carrier_pll) ch.carrier_pll->stop(), ch.carrier_dc->stop();
         ch.pll->stop();
         if (ch.post_pll_dc) ch.post_pll_dc->stop();
         if (ch.delay) ch.delay->stop();

@@ -108,9 +108,17 @@ namespace sdhip_plugin
             // custom_samplerate overrides the resample decision (module_demod_base.cpp:73-74): not a field of the C ABI
             if (parameters.count("custom_samplerate") > 0)
                 throw satdump_exception("psk_demod_hip: custom_samplerate is not on the HIP path, use psk_demod");
-            // carrier-tracking front-end (module_psk_demod.cpp:39-40, 93-113; one pipeline file, ODIN): CPU module only
-            if (parameters.count("has_carrier") > 0 && parameters["has_carrier"].get<bool>())
-                throw satdump_exception("psk_demod_hip: has_carrier is not on the HIP path, use psk_demod");
+            // carrier-tracking front-end (module_psk_demod.cpp:39-40, 93-113; the ODIN pipeline)
+            b = false;
+            opt(parameters, "has_carrier", b), cfg.has_carrier = b;
+            if (cfg.has_carrier)
+            {
+                if (parameters.count("carrier_pll_bw") > 0)
+                    cfg.carrier_pll_bw = parameters["carrier_pll_bw"].get<float>();
+                else
+                    throw satdump_exception("Carrier PLL Bw parameter must be present!");
+                opt(parameters, "carrier_pll_max_offset", cfg.carrier_pll_max_offset);
+            }
             b = false;
             opt(parameters, "post_costas_dc", b), cfg.post_costas_dc = b; // module_psk_demod.cpp:36-38
             if (parameters.count("constellation") > 0)

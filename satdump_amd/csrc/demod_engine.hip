@@ -379,6 +379,13 @@ namespace sdhip
         CostasState cos_s{0.0f, 0.0f};
         MmState mm_s{};
         DcState dc_s{0, 0}, dc2_s{0, 0}; // dc_block in front / post_costas_dc behind the Costas loop
+        // has_carrier: carrier-tracking PLL + its DC block between the RRC filter and the Costas loop
+        PllParams cpll_p{};
+        CostasState cpll_s{0.0f, 0.0f};
+        DcState dcc_s{0, 0};
+        long long w_cpll_learned = 0;
+        DevBuf<float> d_atan;
+        DevBuf<CostasState> d_cpll_spec, d_cpll_end, d_cpll_start, d_cpll_ck;
         std::vector<cf32> hist_in, hist_agc, hist_cos; // DEMOD_HIST samples each (history in front of stage inputs)
 
         // device
@@ -541,8 +548,24 @@ namespace sdhip
                 rrev[j] = rrc[rrc.size() - 1 - j]; // FIRBlock reverses its taps, fir.cpp:30
             d_rrc.reserve(rrev.size());
             SD_HIP(hipMemcpy(d_rrc.p, rrev.data(), rrev.size() * sizeof(float), hipMemcpyHostToDevice));
+            // carrier-tracking PLL (module_psk_demod.cpp:93-113, pll_carrier_tracking.cpp:8-21)
+            if (cfg.has_carrier)
+            {
+                if (!is_bpsk)
+                    throw HipError("For carrier mode, constellation must be BPSK!");
+                if (!(cfg.carrier_pll_bw > 0))
+                    throw HipError("Carrier PLL Bw parameter must be present!");
+                design::costas_gains(cfg.carrier_pll_bw, cpll_p.alpha, cpll_p.beta); // same damping / denominator expression
+                cpll_p.fmax = cfg.carrier_pll_max_offset;
+                cpll_p.fmin = -cfg.carrier_pll_max_offset;
+                const std::vector<float> at = design::atan_table();
+                d_atan.reserve(at.size());
+                SD_HIP(hipMemcpy(d_atan.p, at.data(), at.size() * sizeof(float), hipMemcpyHostToDevice));
+                cpll_p.atan_tab = d_atan.p;
+                d_cpll_start.reserve(1);
+            }
             // Costas (module_psk_demod.cpp:116-125)
-            float costas_max_offset = 1.0f;
+            float costas_max_offset = cfg.has_carrier ? 0.2f : 1.0f; // "the offset in frequency should already be resolved on AM subcarriers"
             if (cfg.costas_max_offset_hz > 0)
                 costas_max_offset = (float)(2.0 * design::PI * ((double)cfg.costas_max_offset_hz / (double)final_samplerate));
             order = is_bpsk ? 2 : (cfg.constellation == SDHIP_8PSK ? 8 : 4);
@@ -706,6 +729,93 @@ namespace sdhip
                 fprintf(stderr, "[sdhip] %-6s chunks %d  re-run %u in %u round(s)  accepted-by-tolerance %d  let through unlocked %d\n", stage, K, reruns, rounds,
                         h_vout.p->inexact, h_vout.p->forced);
             return *h_vout.p;
+        }
+
+        // has_carrier front-end: the carrier-tracking PLL as a speculative chunk stage (one stable point per turn: no frame to
+        // correct, the Costas verdict kernel with a 2 pi "rotation unit"), in -> out. The loop is linear while its detector
+        // (arg(x) - phase, wrapped) stays off the wrap, so two trajectories on the same samples contract like exp(-1.414 bw t)
+        // down to float noise; the windows are the Costas stage's.
+        void carrier_pll_chunked(const cf32 *in, cf32 *out, long long n)
+        {
+            if (!started)
+            { // start frequency of the warm-ups: lag-1 autocorrelation of the filtered signal (carrier and data both turn at it)
+                const long long m = std::min<long long>(n, 1 << 20);
+                ProfScope _ps("k_freq_est", stream);
+                hipLaunchKernelGGL(k_freq_est, dim3(64), dim3(256), 0, stream, in, m, 1, 2, 0, d_partial.p);
+                double part[256];
+                SD_HIP(hipMemcpyAsync(part, d_partial.p, sizeof(part), hipMemcpyDeviceToHost, stream));
+                SD_HIP(hipStreamSynchronize(stream));
+                double sr = 0, si = 0;
+                for (int i = 0; i < 64; i++)
+                    sr += part[4 * i], si += part[4 * i + 1];
+                cpll_p.init_freq = std::min(std::max((float)std::atan2(si, sr), cpll_p.fmin), cpll_p.fmax);
+            }
+            else
+                cpll_p.init_freq = cpll_s.freq;
+            const long long w_cap = 1 << 20;
+            long long W = cfg.warmup > 0 ? cfg.warmup : (long long)std::max(512.0, 24.0 / (1.414 * std::max(1e-5f, cfg.carrier_pll_bw)));
+            W = std::max(W, w_cpll_learned);
+            W = (std::min<long long>(W, w_cap) + 255) / 256 * 256;
+            const int L = pick_L(n, ST_COSTAS);
+            const double tol_phase = env_int("SDHIP_COSTAS_TOL_URAD", 10000) * 1e-6, tol_freq = env_int("SDHIP_COSTAS_TOL_NFREQ", 40000) * 1e-9;
+            ChunkGeom g;
+            ChunkCkpt ck;
+            auto setup = [&](long long Wn) {
+                g = make_geom(n, L, (int)Wn);
+                d_cpll_spec.reserve(g.K);
+                d_cpll_end.reserve(g.K);
+                d_dm.reserve(g.K);
+                if (use_ckpt)
+                {
+                    ck.len = 2048;
+                    ck.per_chunk = L / ck.len + 1;
+                    d_cpll_ck.reserve((size_t)g.K * ck.per_chunk);
+                    ck.ck = d_cpll_ck.p;
+                    ck.tol_a = (float)tol_phase;
+                    ck.tol_b = (float)tol_freq;
+                }
+            };
+            setup(W);
+            SD_HIP(hipMemcpyAsync(d_cpll_start.p, &cpll_s, sizeof(cpll_s), hipMemcpyHostToDevice, stream));
+            launch_pll(in, out, g, cpll_p, d_cpll_start.p, d_cpll_spec.p, d_cpll_end.p, nullptr, 0, stream, ck);
+            verify_fix(
+                "cpll", g.K,
+                [&](VerdictOut *vo, int *fails, int force) {
+                    hipLaunchKernelGGL(k_costas_verdict, dim3((g.K + 255) / 256), dim3(256), 0, stream, g.K, d_cpll_spec.p, d_cpll_end.p, 2.0 * design::PI, 1, tol_phase,
+                                       tol_freq, d_dm.p, vo, fails, force);
+                },
+                [&](const int *list, int nr) {
+                    // a re-run starts from the predecessor's end state as it is: with one stable point per turn the earlier run's
+                    // checkpoints are in the same frame (the early-exit test compares modulo 2 pi)
+                    hipLaunchKernelGGL(k_spec_from_prev<CostasState>, dim3((nr + 255) / 256), dim3(256), 0, stream, list, nr, d_cpll_spec.p, d_cpll_end.p);
+                },
+                [&](const int *redo, int nr) { launch_pll(in, out, g, cpll_p, d_cpll_start.p, d_cpll_spec.p, d_cpll_end.p, redo, nr, stream, ck); },
+                [&](int) {
+                    // many warm-ups missed: the start frequency was off (take the median of the lanes' end frequencies) or the
+                    // warm-up is too short for this loop bandwidth (double it; the stream keeps the longer one)
+                    std::vector<CostasState> es((size_t)g.K);
+                    SD_HIP(hipMemcpyAsync(es.data(), d_cpll_end.p, es.size() * sizeof(CostasState), hipMemcpyDeviceToHost, stream));
+                    SD_HIP(hipStreamSynchronize(stream));
+                    std::vector<float> fr(es.size());
+                    for (size_t i = 0; i < es.size(); i++)
+                        fr[i] = es[i].freq;
+                    std::nth_element(fr.begin(), fr.begin() + fr.size() / 2, fr.end());
+                    const float med = fr[fr.size() / 2];
+                    if (std::fabs(med - cpll_p.init_freq) > 0.05f * cfg.carrier_pll_bw)
+                        cpll_p.init_freq = med;
+                    else if (cfg.warmup <= 0 && 2 * (long long)g.W <= w_cap)
+                    {
+                        w_cpll_learned = 2 * (long long)g.W;
+                        setup(w_cpll_learned);
+                    }
+                    else
+                        return false;
+                    launch_pll(in, out, g, cpll_p, d_cpll_start.p, d_cpll_spec.p, d_cpll_end.p, nullptr, 0, stream, ck);
+                    return true;
+                });
+            stats.chunks += g.K;
+            SD_HIP(hipMemcpyAsync(&cpll_s, d_cpll_end.p + (g.K - 1), sizeof(cpll_s), hipMemcpyDeviceToHost, stream));
+            SD_HIP(hipStreamSynchronize(stream));
         }
 
         // Chunk-parallel DC block (see demod_kernels.h): affine scan in double for the accumulator at every chunk start, then the
@@ -937,6 +1047,23 @@ namespace sdhip
             std::swap(A, B);
 
             tick("fir");
+            // ---- has_carrier (module_psk_demod.cpp:93-113): carrier PLL, then the DC block that takes the carrier line out
+            if (cfg.has_carrier)
+            {
+                carrier_pll_chunked(A, B, n);
+                std::swap(A, B);
+                if (cfg.exact)
+                {
+                    SD_HIP(hipMemcpyAsync(d_dc.p, &dcc_s, sizeof(dcc_s), hipMemcpyHostToDevice, stream));
+                    launch_dcblock_seq(A, B, n, d_dc.p, stream);
+                    SD_HIP(hipMemcpyAsync(&dcc_s, d_dc.p, sizeof(dcc_s), hipMemcpyDeviceToHost, stream));
+                    SD_HIP(hipStreamSynchronize(stream));
+                }
+                else
+                    dc_block_chunked(A, B, n, dcc_s);
+                std::swap(A, B);
+                tick("carrier");
+            }
             // ---- Costas (speculative, symmetry-corrected)
             ChunkGeom cg;
             {
@@ -1359,6 +1486,7 @@ extern "C"
         c->clock_mu = 0.5f;
         c->clock_gain_mu = (float)8.7e-3;
         c->clock_omega_relative_limit = 0.005f;
+        c->carrier_pll_max_offset = 3.14f; // module_psk_demod.cpp:104
     }
     void *sdhip_demod_create(const sdhip_demod_cfg *cfg)
     {
@@ -1556,6 +1684,26 @@ extern "C"
             long long c = 0;
             SD_HIP(hipMemcpy(&c, cnt.p, sizeof(c), hipMemcpyDeviceToHost));
             nout = c;
+        }
+        else if (kind == 8)
+        { // PLLCarrierTrackingBlock(loop_bw, max, min), pll_carrier_tracking.cpp:8-66
+            if (out_cap < n)
+                throw HipError("output too small");
+            PllParams p{};
+            design::costas_gains(params[0], p.alpha, p.beta);
+            p.fmax = params[1];
+            p.fmin = params[2];
+            const std::vector<float> at = design::atan_table();
+            DevBuf<float> dt;
+            dt.reserve(at.size());
+            SD_HIP(hipMemcpy(dt.p, at.data(), at.size() * sizeof(float), hipMemcpyHostToDevice));
+            p.atan_tab = dt.p;
+            CostasState s0{0, 0};
+            DevBuf<CostasState> st;
+            st.reserve(3);
+            SD_HIP(hipMemcpy(st.p, &s0, sizeof(s0), hipMemcpyHostToDevice));
+            launch_pll(X, Y, g, p, st.p, st.p + 1, st.p + 2, nullptr, 0, nullptr);
+            SD_HIP(hipDeviceSynchronize()); // dt / st go out of scope below
         }
         else
             throw HipError("unknown block kind");

@@ -119,6 +119,17 @@ namespace sdhip
     void launch_costas(const cf32 *x, cf32 *y, const ChunkGeom &g, const CostasParams &p, const CostasState *start0, CostasState *spec, CostasState *endst,
                        const int *redo, int nredo, hipStream_t st, const ChunkCkpt &ck = ChunkCkpt());
 
+    // ---- carrier-tracking PLL (has_carrier, pll_carrier_tracking.cpp:23-66): same state layout and chunk scheme as the Costas loop,
+    // one stable point per turn (no frame ambiguity)
+    struct PllParams
+    {
+        float alpha, beta, fmin, fmax;
+        float init_freq;       // warm-up start frequency
+        const float *atan_tab; // device: 257 arctangents of i / 255 (design::atan_table)
+    };
+    void launch_pll(const cf32 *x, cf32 *y, const ChunkGeom &g, const PllParams &p, const CostasState *start0, CostasState *spec, CostasState *endst,
+                    const int *redo, int nredo, hipStream_t st, const ChunkCkpt &ck = ChunkCkpt());
+
     // ---- M&M clock recovery + quantiser ------------------------------------------------------------------
     struct MmParams
     {

@@ -818,6 +818,88 @@ namespace sdhip
         }
     };
 
+    // ---- carrier-tracking PLL of psk_demod's has_carrier mode (PLLCarrierTrackingBlock::work, pll_carrier_tracking.cpp:23-66) ----------
+    // Phase detector = the table-driven arctangent of GNU Radio (fast_trig.cpp:60-153: y/x folded into 0..1, 255 intervals, linear
+    // interpolation, the octant put back), VCO = two polynomials evaluated in double (fast_trig.cpp:157-180). Written here as
+    // selects over the octant instead of the reference's nest of branches; every float / double rounding sits where the reference's
+    // declarations put it.
+    __device__ __forceinline__ float sd_fast_atan2f(float y, float x, const float *__restrict__ tab)
+    {
+        const float ya = fabsf(y), xa = fabsf(x);
+        if (!(ya > 0.0f || xa > 0.0f))
+            return 0.0f;
+        const bool flat = ya < xa;              // ratio taken the way that keeps it <= 1 (ties: x/y, like the reference)
+        const float z = flat ? ya / xa : xa / ya;
+        float base = z;                          // below the table's resolution the angle is its own tangent
+        if (!((double)z < 0.003921569))
+        {
+            const float al = z * 255.0f;
+            const int idx = ((int)al) & 0xff;
+            const float lo = tab[idx], hi = tab[idx + 1];
+            base = lo + (hi - lo) * (al - (float)idx);
+        }
+        const float pi = (float)3.14159265358979323846, half = (float)1.57079632679489661923;
+        if (xa > ya) // within 45 degrees of the x axis
+            return x >= 0.0f ? (y >= 0.0f ? base : -base) : (y >= 0.0f ? pi - base : base - pi);
+        // within 45 degrees of the y axis
+        return y >= 0.0f ? (x >= 0.0f ? half - base : half + base) : (x >= 0.0f ? -half + base : -half - base);
+    }
+    __device__ __forceinline__ float sd_fast_cos(float x)
+    {
+        const float x2 = x * x, x4 = x2 * x2, x8 = x4 * x4;
+        return (float)((-2.7236370439787708e-7 * x2 + 2.4799852696610628e-5) * x8 + (-1.3888885054799695e-3 * x2 + 4.1666666636943683e-2) * x4 +
+                       (-4.9999999999963024e-1 * x2 + 1.0000000000000000e+0));
+    }
+    __device__ __forceinline__ float sd_fast_sin(float x)
+    {
+        const float x2 = x * x, x4 = x2 * x2;
+        return (float)(((2.7181216275479732e-6 * x2 - 1.9839312269456257e-4) * x4 + (8.3333293048425631e-3 * x2 - 1.6666666640797048e-1)) * x2 * x + x);
+    }
+    // float value wrapped into [-pi, pi] the reference's way: compared and stepped in double, stored back as float each step
+    __device__ __forceinline__ float sd_wrap_pi(float v)
+    {
+        const double pi = 3.14159265358979323846, twopi = 2 * 3.14159265358979323846;
+        while ((double)v < -pi)
+            v = (float)((double)v + twopi);
+        while ((double)v > pi)
+            v = (float)((double)v - twopi);
+        return v;
+    }
+    struct PllStage
+    {
+        using P = PllParams;
+        using S = CostasState;
+        static constexpr int DEPTH = 2;
+        __device__ static __forceinline__ S init(const P &p, int) { return S{0.0f, p.init_freq}; }
+        __device__ static __forceinline__ bool close(const S &a, const S &b, float tol_phase, float tol_freq)
+        {
+            const float twopi = 6.28318530717958647692f;
+            float d = a.phase - b.phase;
+            d -= twopi * rintf(d / twopi);
+            return fabsf(d) < tol_phase && fabsf(a.freq - b.freq) < tol_freq;
+        }
+        // a warm-up starts ON the carrier: the loop's phase detector is arg(x) - phase, so arg of the first sample is the start
+        // phase with zero error (speculation only -- the boundary certificate decides)
+        __device__ static __forceinline__ void prewarm(S &s, const P &p, const cf32 *x, long long i0)
+        {
+            const cf32 v = x[i0];
+            s.phase = sd_fast_atan2f(v.im, v.re, p.atan_tab);
+        }
+        __device__ static __forceinline__ cf32 step(S &s, const P &p, const cf32 v)
+        {
+            const float vr = sd_fast_cos(s.phase), vi = -sd_fast_sin(s.phase);
+            const cf32 o{(v.re * vr) - (v.im * vi), (v.im * vr) + (v.re * vi)};
+            const float pe = sd_wrap_pi(sd_fast_atan2f(v.im, v.re, p.atan_tab) - s.phase);
+            s.freq = s.freq + p.beta * pe;
+            if (s.freq > p.fmax)
+                s.freq = p.fmax;
+            else if (s.freq < p.fmin)
+                s.freq = p.fmin;
+            s.phase = sd_wrap_pi(s.phase + s.freq + p.alpha * pe);
+            return o;
+        }
+    };
+
     struct DcStage
     {
         using P = DcParams;
@@ -1112,6 +1194,21 @@ namespace sdhip
                                (CostasState *)ck.ck, ck.per_chunk, ck.len, ck.tol_a, ck.tol_b, ck.work);
         else
             hipLaunchKernelGGL((k_chunks<CostasStage, false>), dim3((n + 63) / 64), dim3(64), 0, st, x, y, g, p, start0, spec, endst, redo, nredo,
+                               (CostasState *)nullptr, 0, 0, 0.0f, 0.0f, (unsigned long long *)nullptr);
+    }
+
+    void launch_pll(const cf32 *x, cf32 *y, const ChunkGeom &g, const PllParams &p, const CostasState *start0, CostasState *spec, CostasState *endst,
+                    const int *redo, int nredo, hipStream_t st, const ChunkCkpt &ck)
+    {
+        const int n = redo ? nredo : g.K;
+        if (n <= 0)
+            return;
+        ProfScope _ps("k_chunks<PllStage>", st);
+        if (ck.ck)
+            hipLaunchKernelGGL((k_chunks<PllStage, true>), dim3((n + 63) / 64), dim3(64), 0, st, x, y, g, p, start0, spec, endst, redo, nredo, (CostasState *)ck.ck,
+                               ck.per_chunk, ck.len, ck.tol_a, ck.tol_b, ck.work);
+        else
+            hipLaunchKernelGGL((k_chunks<PllStage, false>), dim3((n + 63) / 64), dim3(64), 0, st, x, y, g, p, start0, spec, endst, redo, nredo,
                                (CostasState *)nullptr, 0, 0, 0.0f, 0.0f, (unsigned long long *)nullptr);
     }
 

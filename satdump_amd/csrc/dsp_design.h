@@ -7,7 +7,10 @@
 //   polyphase layout      src-core/common/dsp/resamp/polyphase_bank.cpp:6-39
 //   Costas alpha/beta     src-core/common/dsp/pll/costas_loop.cpp:5-12
 #pragma once
+#include <algorithm>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <numeric>
 #include <vector>
 
@@ -192,6 +195,21 @@ namespace sdhip
             }
             const std::vector<float> proto = kaiser_lowpass((double)interpolation, (double)interpolation, centre, width, beta);
             return polyphase(proto, (int)interpolation, bank);
+        }
+
+        // the arctangent table of the carrier PLL's phase detector (fast_trig.cpp:16-59): atan(i / 255) as the seven-significant-digit
+        // decimal literals of the reference's source, read as float; entry 256 repeats entry 255 (the interpolation's upper neighbour
+        // at ratio 1)
+        inline std::vector<float> atan_table()
+        {
+            std::vector<float> t(257);
+            for (int i = 0; i < 257; i++)
+            {
+                char txt[32];
+                snprintf(txt, sizeof(txt), "%.6e", std::atan((double)std::min(i, 255) / 255.0));
+                t[i] = strtof(txt, nullptr);
+            }
+            return t;
         }
 
         inline void costas_gains(float loop_bw, float &alpha, float &beta)

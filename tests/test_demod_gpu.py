@@ -42,16 +42,20 @@ def _dev(torch, a):
 
 BLOCKS = [(0, [1e-2, 1, 1, 65536]), (1, [6e6, 2333333, 0.5, 31]), (2, [0.003, 4, 1.0]), (2, [0.02, 2, 1.0]), (2, [0.003, 8, 1.0]),
           (3, [2.5714, (8.7e-3) ** 2 / 4, 0.5, 8.7e-3, 0.005]), (4, [2700000, 3000000]), (5, [0.0]),
-          (7, [2.5714, (8.7e-3) ** 2 / 4, 0.5, 8.7e-3, 0.005]), (7, [2.0, (8.7e-3) ** 2 / 4, 0.5, 8.7e-3, 0.005])]
+          (7, [2.5714, (8.7e-3) ** 2 / 4, 0.5, 8.7e-3, 0.005]), (7, [2.0, (8.7e-3) ** 2 / 4, 0.5, 8.7e-3, 0.005]),
+          (8, [0.002, 3.14, -3.14]), (8, [0.05, 0.25, -0.25])]
 
 
 @pytest.mark.parametrize("kind,params", BLOCKS)
 def test_single_blocks_bit_exact(torch_cuda, capi, orc, kind, params):
     """Each kernel body == the reference block (agc.cpp, fir.cpp, costas_loop.cpp, clock_recovery_mm.cpp,
-    rational_resampler.cpp), bit for bit, on a noisy QPSK-like input."""
+    rational_resampler.cpp, pll_carrier_tracking.cpp + fast_trig.cpp), bit for bit, on a noisy QPSK-like input."""
     rng = np.random.default_rng(kind + 11)
     n = 60000
     x = ((rng.standard_normal(n) + 1j * rng.standard_normal(n)) * 0.3).astype(np.complex64)
+    if kind == 8:  # carrier PLL: half of the stream noise alone (every octant, both wraps, the rate limit), half a carrier it locks to
+        x[n // 2:] += (0.9 * np.exp(1j * (0.013 * np.arange(n - n // 2) + 1.0))).astype(np.complex64)
+        x[7] = 0  # arctangent of (0, 0)
     want = orc.block(kind, params, x)
     d_x = _dev(torch_cuda, x.view(np.float32))
     d_y = torch_cuda.zeros(2 * (n + 64), dtype=torch_cuda.float32, device="cuda")

@@ -114,3 +114,4 @@ test_dc_block_in_front_of_the_resampler = G2.test_dc_block_in_front_of_the_resam
 test_dc_block_chunk_parallel = G2.test_dc_block_chunk_parallel
 test_power_of_two_predecimator = G2.test_power_of_two_predecimator
 test_post_costas_dc = G2.test_post_costas_dc
+test_has_carrier = G2.test_has_carrier

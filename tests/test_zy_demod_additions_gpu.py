@@ -99,6 +99,53 @@ def test_post_costas_dc(torch_cuda, capi, orc, case):
     assert got.shape == wantc.shape and np.array_equal(got, wantc) and len(got) >= 20
 
 
+def _carrier_case(nframes=24, carrier=0.9, cfo_hz=3000.0):
+    """BPSK with a residual carrier in quadrature (an AM-subcarrier style downlink, the has_carrier pipelines): the GOES test stream
+    built without frequency offset, the carrier line added, then both turned by the offset."""
+    import dataclasses
+    from tests import util
+    spec, cadus, plain, syms = util.goes_case(nframes=nframes)
+    spec0 = dataclasses.replace(spec, cfo_hz=0.0, phase0=0.0)
+    x0, _ = synth.modulate(syms, spec0)
+    t = np.arange(len(x0), dtype=np.float64)
+    rot = np.exp(1j * (2 * np.pi * cfo_hz / spec.samplerate * t + 0.4))
+    x = ((x0.astype(np.complex128) + 1j * carrier * spec.amplitude) * rot).astype(np.complex64)
+    kw = dict(samplerate=3e6, symbolrate=927000, rrc_alpha=0.5, pll_bw=0.006, max_sps=3.0, has_carrier=1, carrier_pll_bw=0.002)
+    return x, kw
+
+
+def test_has_carrier(torch_cuda, capi, orc):
+    """psk_demod's has_carrier mode (module_psk_demod.cpp:39-40, 93-113; the ODIN pipeline): carrier-tracking PLL
+    (pll_carrier_tracking.cpp, the table-driven arctangent and the polynomial sine / cosine of fast_trig.cpp) and a DC block between
+    the RRC filter and the Costas loop, whose frequency limit drops to 0.2. Exact mode bit-identical to the reference over ragged
+    calls; chunk-parallel mode (PLL and DC block as speculative chunk stages) same symbol count, >= 98.5 % of the float symbols
+    within 1e-5, CADUs identical; a non-BPSK constellation is refused like the reference refuses it."""
+    x, kw = _carrier_case()
+    ocfg = pyref.demod_cfg(constellation=pyref.BPSK, **kw)
+    want = orc.psk_demod(ocfg, x)
+    assert len(want["syms"]) > 100000
+    ofec = pyref.fec_cfg(constellation=pyref.BPSK, nrzm=1, rs_usecheck=1)
+    wantc = orc.concat_decode(ofec, want["soft"])["cadu"]
+    assert len(wantc) >= 18  # the reference itself decodes the stream: the carrier loop locked
+    w3 = orc.psk_demod(ocfg, x[:300000])
+    soft, syms, st = _run_demod(torch_cuda, capi, dict(kw, constellation="bpsk"), x[:300000], chunks=[0, 1000, 77777, 300000], exact=1)
+    assert np.array_equal(syms.view(np.uint32), w3["syms"].view(np.uint32)) and np.array_equal(soft, w3["soft"])
+    n = len(x)
+    soft, syms, st = _run_demod(torch_cuda, capi, dict(kw, constellation="bpsk"), x, chunks=[0, n // 2 + 3, n], chunk_len=8192)
+    assert st.chunks >= 5 * (int(0.9 * (n - n // 2 - 3)) // 8192 - 1)  # last call, 9/10-resampled: agc, pll, dc, costas, mm all chunked
+    assert len(syms) == len(want["syms"])
+    err = np.abs(syms - want["syms"]) / np.sqrt(np.mean(np.abs(want["syms"]) ** 2))
+    assert np.mean(err > 1e-5) < 0.015, float(np.mean(err > 1e-5))
+    dec = capi.FecDecoder(capi.fec_cfg(constellation="bpsk", nrzm=1, rs_i=4, rs_type=1, rs_usecheck=1))
+    dec.push(soft)
+    got = dec.pull()
+    assert got.shape == wantc.shape and np.array_equal(got, wantc)
+    with pytest.raises(capi.SdhipError):
+        capi.PskDemod(capi.demod_cfg(**dict(kw, constellation="qpsk")))
+    with pytest.raises(capi.SdhipError):
+        capi.PskDemod(capi.demod_cfg(**dict(kw, constellation="bpsk", carrier_pll_bw=0.0)))
+
+
 @pytest.mark.parametrize("workload,frames", [("metop_ahrpt", 2100), ("npp_hrd", 2000)])
 def test_three_passes_through_stateful_handles_equal_the_reference_on_the_tiled_recording(torch_cuda, capi, orc, workload, frames):
     """What bench.py times at N=1: ONE pair of handles, the periodic recording passed through it step after step (engine state,
