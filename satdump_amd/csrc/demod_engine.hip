@@ -576,6 +576,9 @@ namespace sdhip
             cos_p.fmax = costas_max_offset;
             cos_p.order = order;
             cos_p.init_freq = 0.0f;
+            // one loop step moves the phase by at most fmax + beta + alpha: the kernel's phase wrap relies on that being under one turn
+            if (!(costas_max_offset + cos_p.alpha + cos_p.beta < 6.0f))
+                throw HipError("costas_max_offset / pll_bw too large for the HIP path (one loop step could exceed a full turn)");
             // M&M (module_psk_demod.cpp:134, clock_recovery_mm.cpp:10-27)
             std::vector<float> mmb;
             const int mmt = design::mm_bank(128, 8, mmb);

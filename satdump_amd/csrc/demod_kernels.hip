@@ -724,6 +724,9 @@ namespace sdhip
         }
     };
 
+    // ORDER (2 / 4 / 8) is a template argument: the detector's form is fixed at compile time, so the per-sample loop carries no
+    // test of it and none of the other detectors' code.
+    template <int ORDER>
     struct CostasStage
     {
         using P = CostasParams;
@@ -779,36 +782,31 @@ namespace sdhip
             const float tr = (v.re * cs) - (v.im * sn);
             const float ti = (v.im * cs) + (v.re * sn);
             float error;
-            if (p.order == 2)
+            if constexpr (ORDER == 2)
                 error = tr * ti;
-            else if (p.order == 4)
+            else if constexpr (ORDER == 4)
                 error = (tr > 0.0f ? 1.0f : -1.0f) * ti - (ti > 0.0f ? 1.0f : -1.0f) * tr;
             else
             {
                 const float K = sqrtf(2.0f) - 1.0f; // (sqrtf(2.0) - 1)
-                if (fabsf(tr) >= fabsf(ti))
-                    error = ((tr > 0.0f ? 1.0f : -1.0f) * ti - (ti > 0.0f ? 1.0f : -1.0f) * tr * K);
-                else
-                    error = ((tr > 0.0f ? 1.0f : -1.0f) * ti * K - (ti > 0.0f ? 1.0f : -1.0f) * tr);
+                const float st = tr > 0.0f ? 1.0f : -1.0f, su = ti > 0.0f ? 1.0f : -1.0f;
+                const float ea = st * ti - su * tr * K, eb = st * ti * K - su * tr;
+                error = fabsf(tr) >= fabsf(ti) ? ea : eb;
             }
             error = 0.5f * (fabsf(error + 1.0f) - fabsf(error - 1.0f)); // branchless_clip(error, 1.0), block.cpp:5
             s.freq = s.freq + p.beta * error;
             s.phase = s.phase + (s.freq + p.alpha * error);
-            // while (phase > 2 pi) phase -= 2 pi; while (phase < -2 pi) phase += 2 pi; -- float against the double constant
-            // (costas_loop.cpp:55-58). |freq| <= 1 and |alpha * error| <= alpha keep one step well under 2 pi, so each loop runs at
-            // most once: selects instead of branches, the loops themselves stay behind a test that never fires in practice.
+            // while (phase > 2 pi) phase -= 2 pi; while (phase < -2 pi) phase += 2 pi; -- the float compared with the double constant,
+            // the step taken in double and rounded back (costas_loop.cpp:55-58). The phase was inside [-2 pi, 2 pi] before this step
+            // and one step moves it by at most fmax + beta + alpha, which the engine requires to be under 2 pi (DemodEngine ctor): each
+            // loop runs at most once, so they are two selects. "float > 2 pi (double)" is "float >= (float)(2 pi)": the float next
+            // above the double constant is its own rounding, 6.2831854820251465.
             const double twopi = 2 * 3.14159265358979323846;
             {
+                const float twopi_f = 6.28318548202514648f;
                 const double pd = (double)s.phase;
                 const float dn = (float)(pd - twopi), up = (float)(pd + twopi);
-                s.phase = pd > twopi ? dn : (pd < -twopi ? up : s.phase);
-            }
-            if (__builtin_expect((double)s.phase > twopi || (double)s.phase < -twopi, 0))
-            {
-                while ((double)s.phase > twopi)
-                    s.phase = (float)((double)s.phase - twopi);
-                while ((double)s.phase < -twopi)
-                    s.phase = (float)((double)s.phase + twopi);
+                s.phase = s.phase >= twopi_f ? dn : (s.phase <= -twopi_f ? up : s.phase);
             }
             if (s.freq > p.fmax)
                 s.freq = p.fmax;
@@ -1189,14 +1187,22 @@ namespace sdhip
         if (n <= 0)
             return;
         ProfScope _ps("k_chunks<CostasStage>", st);
-        if (ck.ck)
-            hipLaunchKernelGGL((k_chunks<CostasStage, true>), dim3((n + 63) / 64), dim3(64), 0, st, x, y, g, p, start0, spec, endst, redo, nredo,
-                               (CostasState *)ck.ck, ck.per_chunk, ck.len, ck.tol_a, ck.tol_b, ck.work);
+        auto go = [&](auto stage) {
+            using St = decltype(stage);
+            if (ck.ck)
+                hipLaunchKernelGGL((k_chunks<St, true>), dim3((n + 63) / 64), dim3(64), 0, st, x, y, g, p, start0, spec, endst, redo, nredo, (CostasState *)ck.ck,
+                                   ck.per_chunk, ck.len, ck.tol_a, ck.tol_b, ck.work);
+            else
+                hipLaunchKernelGGL((k_chunks<St, false>), dim3((n + 63) / 64), dim3(64), 0, st, x, y, g, p, start0, spec, endst, redo, nredo,
+                                   (CostasState *)nullptr, 0, 0, 0.0f, 0.0f, (unsigned long long *)nullptr);
+        };
+        if (p.order == 2)
+            go(CostasStage<2>{});
+        else if (p.order == 4)
+            go(CostasStage<4>{});
         else
-            hipLaunchKernelGGL((k_chunks<CostasStage, false>), dim3((n + 63) / 64), dim3(64), 0, st, x, y, g, p, start0, spec, endst, redo, nredo,
-                               (CostasState *)nullptr, 0, 0, 0.0f, 0.0f, (unsigned long long *)nullptr);
+            go(CostasStage<8>{});
     }
-
     void launch_pll(const cf32 *x, cf32 *y, const ChunkGeom &g, const PllParams &p, const CostasState *start0, CostasState *spec, CostasState *endst,
                     const int *redo, int nredo, hipStream_t st, const ChunkCkpt &ck)
     {

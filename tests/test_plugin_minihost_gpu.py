@@ -155,3 +155,32 @@ def test_uncovered_parameters_stay_on_the_cpu_module(host, tmp_path):
            "decoder": {"module": "ccsds_conv_concat_decoder", "parameters": dict(GOES_DEC, cadu_size=8191)}}
     rep = _run(host, job, tmp_path)
     assert rep["demod_class"] == "cpu:psk_demod" and rep["decoder_class"] == "cpu:ccsds_conv_concat_decoder"
+
+
+def test_has_carrier_pipeline_parameters_through_the_plugin(host, tmp_path):
+    """The ODIN pipeline's demodulator parameters (`has_carrier`, `carrier_pll_bw`; resources/pipelines/ODIN.json) stay on the HIP
+    module under the override, and its .soft is what the reference demodulates from the same file (int8, <= 1 LSB on <= 0.5 %)."""
+    from tests.test_zy_demod_additions_gpu import _carrier_case
+    orc = pyref.best()
+    x, kw = _carrier_case(nframes=30)
+    inp = tmp_path / "bb.cf32"
+    x.tofile(str(inp))
+    params = {"samplerate": 3000000, "symbolrate": 927000, "constellation": "bpsk", "rrc_alpha": 0.5, "pll_bw": kw["pll_bw"], "max_sps": 3.0,
+              "has_carrier": True, "carrier_pll_bw": kw["carrier_pll_bw"]}
+    job = {"mode": "file", "input": str(inp), "output_hint": str(tmp_path / "odin"),
+           "demod": {"module": "psk_demod", "parameters": params}, "decoder": {"module": "ccsds_conv_concat_decoder", "parameters": GOES_DEC}}
+    rep = _run(host, job, tmp_path)
+    assert rep["demod_class"] == "psk_demod_hip"
+    soft = np.fromfile(rep["soft"], dtype=np.int8)
+    ocfg = pyref.demod_cfg(constellation=pyref.BPSK, **kw)
+    ref_soft = orc.psk_demod(ocfg, x, want_syms=False)["soft"]
+    assert len(soft) == len(ref_soft)
+    d = np.abs(soft.astype(np.int16) - ref_soft.astype(np.int16))
+    assert d.max() <= 1 and np.mean(d != 0) < 0.005, (int(d.max()), float(np.mean(d != 0)))
+    got = np.fromfile(rep["cadu"], dtype=np.uint8).reshape(-1, 1024)
+    want = _ref_cadus_of_file(orc, ocfg, pyref.fec_cfg(constellation=pyref.BPSK, nrzm=1, rs_usecheck=1), x)
+    assert got.shape == want.shape and np.array_equal(got, want) and len(got) >= 24
+    # a non-BPSK constellation with has_carrier is refused by the reference module's init(); under the override the HIP probe
+    # fails and the CPU module is kept, which then raises its own error at init
+    job2 = dict(job, instantiate_only=True, demod={"module": "psk_demod", "parameters": dict(params, constellation="qpsk")})
+    assert _run(host, job2, tmp_path)["demod_class"] == "cpu:psk_demod"
