@@ -71,6 +71,8 @@ def algorithmic_bytes(wl, n_in, n_rs, nsym, nsoft, cadu_bytes_out, in_bytes_per_
         "k_resample_byoffset": n_in * 8 + n_rs * 8,
         "k_resample_period": n_in * 8 + n_rs * 8,
         "k_chunks<AgcStage>": n_rs * 16,
+        "k_chunks<AgcFirStage>": n_rs * 16,  # AGC and the RRC filter in one pass: the AGC samples never reach memory
+        "k_chunks<PllStage>": n_rs * 16,
         "k_fir": n_rs * 16,
         "k_fir_window": n_rs * 16,
         "k_chunks<CostasStage>": n_rs * 16,

@@ -164,6 +164,21 @@ namespace sdhip
         else
             verdict_fail(vo, fails, k, force);
     }
+    // AGC + FIR stage: the boundary gain and the gain 32 samples in front of it (AgcFirState::lag[3]) -- both bit-equal means the
+    // filter window behind the warm-up holds the predecessor's samples bit for bit
+    __global__ void k_agcfir_verdict(int K, const AgcFirState *spec, const AgcFirState *endst, VerdictOut *vo, int *fails, int force)
+    {
+        const int k = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+        if (k < 1 || k >= K)
+            return;
+        const float a = spec[k].gain, b = endst[k - 1].gain, a3 = spec[k].lag[3], b3 = endst[k - 1].lag[3];
+        if (__float_as_uint(a) == __float_as_uint(b) && __float_as_uint(a3) == __float_as_uint(b3))
+            return;
+        if (fabsf(a - b) <= 1e-6f * fabsf(b) && fabsf(a3 - b3) <= 1e-6f * fabsf(b3))
+            atomicAdd(&vo->inexact, 1);
+        else
+            verdict_fail(vo, fails, k, force);
+    }
     __global__ void k_dc_verdict(int K, const DcState *spec, const DcState *endst, float tol, VerdictOut *vo, int *fails, int force)
     {
         const int k = (int)(blockIdx.x * blockDim.x + threadIdx.x);
@@ -379,6 +394,10 @@ namespace sdhip
         CostasState cos_s{0.0f, 0.0f};
         MmState mm_s{};
         DcState dc_s{0, 0}, dc2_s{0, 0}; // dc_block in front / post_costas_dc behind the Costas loop
+        // AGC and the RRC filter as one stage (AgcFirStage): the filter window travels with the lane state, on the device
+        bool fuse_agc_fir = false;
+        AgcFirParams af_p{};
+        DevBuf<AgcFirState> d_af_spec, d_af_end, d_af_start;
         // has_carrier: carrier-tracking PLL + its DC block between the RRC filter and the Costas loop
         PllParams cpll_p{};
         CostasState cpll_s{0.0f, 0.0f};
@@ -548,6 +567,20 @@ namespace sdhip
                 rrev[j] = rrc[rrc.size() - 1 - j]; // FIRBlock reverses its taps, fir.cpp:30
             d_rrc.reserve(rrev.size());
             SD_HIP(hipMemcpy(d_rrc.p, rrev.data(), rrev.size() * sizeof(float), hipMemcpyHostToDevice));
+            // the 31-tap filter every pipeline of the path uses rides on the AGC lanes (SDHIP_FUSE_AGC_FIR=0: two kernels, A/B switch)
+            fuse_agc_fir = rrc_ntaps == AGCFIR_NT && env_int("SDHIP_FUSE_AGC_FIR", 1) != 0;
+            if (fuse_agc_fir)
+            {
+                af_p.agc = agc_p;
+                for (int j = 0; j < AGCFIR_NT; j++)
+                    af_p.taps[j] = rrev[j];
+                AgcFirState s0{};
+                s0.gain = 1.0f;
+                for (float &l : s0.lag)
+                    l = 1.0f;
+                d_af_start.reserve(1);
+                SD_HIP(hipMemcpy(d_af_start.p, &s0, sizeof(s0), hipMemcpyHostToDevice));
+            }
             // carrier-tracking PLL (module_psk_demod.cpp:93-113, pll_carrier_tracking.cpp:8-21)
             if (cfg.has_carrier)
             {
@@ -1007,6 +1040,31 @@ namespace sdhip
                 const int L = pick_L(n, ST_AGC);
                 const ChunkGeom g = make_geom(n, L, (int)W);
                 stats.chunks += g.K;
+                if (fuse_agc_fir)
+                {
+                    // AGC + RRC filter in one pass: in -> B holds the FILTERED samples; the lane state (gain, last 30 AGC outputs)
+                    // stays on the device from call to call
+                    af_p.agc = agc_p;
+                    d_af_spec.reserve(g.K);
+                    d_af_end.reserve(g.K);
+                    launch_agc_fir(AIN, B, g, af_p, d_af_start.p, d_af_spec.p, d_af_end.p, nullptr, 0, stream);
+                    const int vb = (g.K + 255) / 256;
+                    verify_fix(
+                        "agc+fir", g.K,
+                        [&](VerdictOut *vo, int *fails, int force) {
+                            hipLaunchKernelGGL(k_agcfir_verdict, dim3(vb), dim3(256), 0, stream, g.K, d_af_spec.p, d_af_end.p, vo, fails, force);
+                        },
+                        [&](const int *list, int nr) {
+                            hipLaunchKernelGGL(k_spec_from_prev<AgcFirState>, dim3((nr + 255) / 256), dim3(256), 0, stream, list, nr, d_af_spec.p, d_af_end.p);
+                        },
+                        [&](const int *redo, int nr) { launch_agc_fir(AIN, B, g, af_p, d_af_start.p, d_af_spec.p, d_af_end.p, redo, nr, stream); });
+                    SD_HIP(hipMemcpyAsync(d_af_start.p, d_af_end.p + (g.K - 1), sizeof(AgcFirState), hipMemcpyDeviceToDevice, stream));
+                    SD_HIP(hipMemcpyAsync(&agc_s, d_af_end.p + (g.K - 1), sizeof(agc_s), hipMemcpyDeviceToHost, stream)); // the gain is the state's first member
+                    SD_HIP(hipStreamSynchronize(stream));
+                    std::swap(A, B);
+                }
+                else
+                {
                 d_agc_spec.reserve(g.K);
                 d_agc_end.reserve(g.K);
                 SD_HIP(hipMemcpyAsync(d_agc_start.p, &agc_s, sizeof(agc_s), hipMemcpyHostToDevice, stream));
@@ -1041,13 +1099,17 @@ namespace sdhip
                 SD_HIP(hipMemcpyAsync(&agc_s, d_agc_end.p + (g.K - 1), sizeof(agc_s), hipMemcpyDeviceToHost, stream));
                 SD_HIP(hipStreamSynchronize(stream));
                 std::swap(A, B);
+                }
             }
             tick("agc");
-            // ---- RRC FIR (parallel, exact)
-            put_hist(A, hist_agc);
-            launch_fir(A, B, n, d_rrc.p, rrc_ntaps, stream);
-            get_hist(A, n, hist_agc);
-            std::swap(A, B);
+            // ---- RRC FIR (parallel, exact) -- unless it rode on the AGC lanes
+            if (!fuse_agc_fir)
+            {
+                put_hist(A, hist_agc);
+                launch_fir(A, B, n, d_rrc.p, rrc_ntaps, stream);
+                get_hist(A, n, hist_agc);
+                std::swap(A, B);
+            }
 
             tick("fir");
             // ---- has_carrier (module_psk_demod.cpp:93-113): carrier PLL, then the DC block that takes the carrier line out

@@ -95,6 +95,22 @@ namespace sdhip
     void launch_agc(const cf32 *x, cf32 *y, const ChunkGeom &g, const AgcParams &p, const AgcState *start0, AgcState *spec, AgcState *endst,
                     const int *redo, int nredo, hipStream_t st, const ChunkCkpt &ck = ChunkCkpt());
 
+    // ---- AGC + 31-tap RRC FIR as one lane-per-chunk stage (see AgcFirStage): the lane filters the AGC samples it produces ----------
+    constexpr int AGCFIR_NT = 31;
+    struct AgcFirParams
+    {
+        AgcParams agc;
+        float taps[AGCFIR_NT + 1]; // reversed taps as launch_fir takes them (FIRBlock order, fir.cpp:30); kernel argument: scalar registers
+    };
+    struct AgcFirState
+    {
+        float gain;
+        float lag[4];                 // gain at the end of each of the last four 8-sample blocks (lag[3]: 32 samples ago)
+        float w[2 * (AGCFIR_NT - 1)]; // the last NT - 1 AGC outputs (re, im), oldest first
+    };
+    void launch_agc_fir(const cf32 *x, cf32 *y, const ChunkGeom &g, const AgcFirParams &p, const AgcFirState *start0, AgcFirState *spec, AgcFirState *endst,
+                        const int *redo, int nredo, hipStream_t st);
+
     // ---- decimating FIR stage of the power-of-two pre-decimator (decimating_fir.cpp:47-89 inside power_decim.cpp:58-77) ----------
     // y[m] = sum_j x[inc0 + m*decim - (ntaps-1) + j] * rtaps[j], j ascending (oldest sample first, mul and add rounded separately);
     // samples at negative indices come from hist[ntaps + index] (the last ntaps samples of the previous call)

@@ -702,11 +702,17 @@ namespace sdhip
     // chunk-speculative driver
     // =============================================================================================
     // Stage concept:  State init(P);  void step(State&, P, x, y, i, bool write)
-    struct AgcStage
+    // one 64-byte block of a lane's stream: 8 samples = 4 x float4
+    struct Blk8
+    {
+        float4 a, b, c, d;
+    };
+    template <int D>
+    struct AgcStageT
     {
         using P = AgcParams;
         using S = AgcState;
-        static constexpr int DEPTH = 4; // blocks per load group (256 bytes); two groups in flight
+        static constexpr int DEPTH = D; // blocks per load group (D * 64 bytes); two groups in flight
         __device__ static __forceinline__ S init(const P &p, int) { return S{p.init_gain}; }
         // early exit of a re-run lane (CKPT): is state a on the trajectory that left checkpoint b? (the AGC certificate's own rule)
         __device__ static __forceinline__ bool close(const S &a, const S &b, float tol_a, float) { return fabsf(a.gain - b.gain) <= tol_a * fabsf(b.gain); }
@@ -724,14 +730,136 @@ namespace sdhip
         }
     };
 
+    using AgcStage = AgcStageT<4>;
+
+    // ---- AGC and the 31-tap RRC filter behind it as ONE lane-per-chunk stage ------------------------------------------------------
+    // The filter is feed-forward, but run as its own kernel it costs a full write + read of the stream (16 B per sample of the 60 the
+    // whole demodulator moves) while the AGC lanes -- one wave per SIMD, bound by their chunk-strided HBM reads -- leave the VALU
+    // idle. Here the lane that produces the AGC samples of a chunk also filters them: its state carries the last NT - 1 AGC outputs,
+    // every 8-sample block appends 8 new ones and emits the 8 filter outputs that end on them (same products, same ascending-tap
+    // accumulation as k_fir / k_fir_window: bit for bit the same floats). The AGC output itself never goes to memory.
+    // Certificate: the window of a warm-up equals the predecessor's iff the two gain trajectories had merged >= NT - 1 samples in
+    // front of the boundary, so the state also remembers the gain four blocks (32 samples) ago and the verdict compares both.
+    // a wave-uniform float copied into a vector register: keeps a table of loop-invariant scalars out of the scalar register file
+    // (31 tap pairs there spill; packed-FP32 operands take a vector register's low half for both lanes, a scalar pair they do not)
+    __device__ __forceinline__ float sd_to_vgpr(float v)
+    {
+        float r;
+        asm("v_mov_b32 %0, %1" : "=v"(r) : "s"(v));
+        return r;
+    }
+    struct AgcFirStage
+    {
+        using P = AgcFirParams;
+        using S = AgcFirState;
+        static constexpr int DEPTH = 4;
+        static constexpr int NT = AGCFIR_NT;
+        __device__ static __forceinline__ S init(const P &p, int)
+        {
+            S s;
+            s.gain = p.agc.init_gain;
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+                s.lag[i] = p.agc.init_gain;
+#pragma unroll
+            for (int i = 0; i < 2 * (NT - 1); i++)
+                s.w[i] = 0.0f;
+            return s;
+        }
+        __device__ static __forceinline__ bool close(const S &a, const S &b, float tol_a, float) { return fabsf(a.gain - b.gain) <= tol_a * fabsf(b.gain); }
+        __device__ static __forceinline__ void prewarm(S &, const P &, const cf32 *, long long) {}
+        __device__ static __forceinline__ v2f agc(S &s, const P &p, float re, float im)
+        {
+            AgcState a{s.gain};
+            const cf32 o = AgcStageT<4>::step(a, p.agc, cf32{re, im});
+            s.gain = a.gain;
+            return v2f{o.re, o.im};
+        }
+        __device__ static __forceinline__ Blk8 block(S &s, const P &p, const Blk8 &c, bool write)
+        {
+            v2f loc[NT - 1 + 8];
+#pragma unroll
+            for (int i = 0; i < NT - 1; i++)
+                loc[i] = v2f{s.w[2 * i], s.w[2 * i + 1]};
+            const float g_in = s.gain;
+            loc[NT - 1 + 0] = agc(s, p, c.a.x, c.a.y);
+            loc[NT - 1 + 1] = agc(s, p, c.a.z, c.a.w);
+            loc[NT - 1 + 2] = agc(s, p, c.b.x, c.b.y);
+            loc[NT - 1 + 3] = agc(s, p, c.b.z, c.b.w);
+            loc[NT - 1 + 4] = agc(s, p, c.c.x, c.c.y);
+            loc[NT - 1 + 5] = agc(s, p, c.c.z, c.c.w);
+            loc[NT - 1 + 6] = agc(s, p, c.d.x, c.d.y);
+            loc[NT - 1 + 7] = agc(s, p, c.d.z, c.d.w);
+            Blk8 o{};
+            if (write)
+            {
+                v2f acc[8];
+#pragma unroll
+                for (int r = 0; r < 8; r++)
+                    acc[r] = v2f{0.0f, 0.0f};
+#pragma unroll
+                for (int j = 0; j < NT; j++)
+                {
+                    const float tv = sd_to_vgpr(p.taps[j]);
+                    const v2f tt{tv, tv};
+                    v2f prod[8]; // the eight products first, then the eight sums: independent neighbours for the VALU pipeline
+#pragma unroll
+                    for (int r = 0; r < 8; r++)
+                        prod[r] = loc[r + j] * tt;
+#pragma unroll
+                    for (int r = 0; r < 8; r++)
+                        acc[r] = acc[r] + prod[r];
+                }
+                o = Blk8{make_float4(acc[0].x, acc[0].y, acc[1].x, acc[1].y), make_float4(acc[2].x, acc[2].y, acc[3].x, acc[3].y),
+                         make_float4(acc[4].x, acc[4].y, acc[5].x, acc[5].y), make_float4(acc[6].x, acc[6].y, acc[7].x, acc[7].y)};
+            }
+#pragma unroll
+            for (int i = 0; i < NT - 1; i++)
+            {
+                s.w[2 * i] = loc[i + 8].x;
+                s.w[2 * i + 1] = loc[i + 8].y;
+            }
+            s.lag[3] = s.lag[2];
+            s.lag[2] = s.lag[1];
+            s.lag[1] = s.lag[0];
+            s.lag[0] = g_in; // gain at the end of the previous block; lag[3] = the gain 32 samples in front of the end of this one
+            return o;
+        }
+        // one sample at a time (ragged tail of a call): same arithmetic, the window moves by one
+        __device__ static __forceinline__ cf32 step(S &s, const P &p, const cf32 v)
+        {
+            const v2f a = agc(s, p, v.re, v.im);
+            v2f acc{0.0f, 0.0f};
+#pragma unroll
+            for (int j = 0; j < NT - 1; j++)
+            {
+                const v2f prod = v2f{s.w[2 * j], s.w[2 * j + 1]} * v2f{p.taps[j], p.taps[j]};
+                acc = acc + prod;
+            }
+            {
+                const v2f prod = a * v2f{p.taps[NT - 1], p.taps[NT - 1]};
+                acc = acc + prod;
+            }
+#pragma unroll
+            for (int i = 0; i < NT - 2; i++)
+            {
+                s.w[2 * i] = s.w[2 * i + 2];
+                s.w[2 * i + 1] = s.w[2 * i + 3];
+            }
+            s.w[2 * (NT - 2)] = a.x;
+            s.w[2 * (NT - 2) + 1] = a.y;
+            return cf32{acc.x, acc.y};
+        }
+    };
+
     // ORDER (2 / 4 / 8) is a template argument: the detector's form is fixed at compile time, so the per-sample loop carries no
     // test of it and none of the other detectors' code.
-    template <int ORDER>
+    template <int ORDER, int D = 2>
     struct CostasStage
     {
         using P = CostasParams;
         using S = CostasState;
-        static constexpr int DEPTH = 2; // blocks per load group (one 128-byte line); two groups in flight
+        static constexpr int DEPTH = D; // blocks per load group (2: one 128-byte line); two groups in flight
         __device__ static __forceinline__ S init(const P &p, int) { return S{0.0f, p.init_freq}; }
         // early exit of a re-run lane (CKPT): same frame (the engine aligns a re-run with the speculative run's frame), phase
         // compared modulo the loop's own 2 pi wrap, the Costas certificate's windows
@@ -924,29 +1052,40 @@ namespace sdhip
     // issued as soon as block j has been consumed, so the ~1.3 us latency of these chunk-strided HBM reads stays off the
     // dependent recurrence (one lane per chunk means few waves per SIMD: nothing else would hide it).
     // x + 8*m must be 16-byte aligned (stage buffers are).
-    struct Blk8
-    {
-        float4 a, b, c, d;
-    };
     __device__ __forceinline__ Blk8 blk_load(const cf32 *x, long long i)
     {
         const float4 *xp = reinterpret_cast<const float4 *>(x + i);
         return Blk8{xp[0], xp[1], xp[2], xp[3]};
     }
     // run one block, results returned (stored later, a whole load group's worth at a time: 128/256 contiguous bytes per lane)
-    template <class Stage>
-    __device__ __forceinline__ Blk8 blk_step(typename Stage::S &s, const typename Stage::P &p, const Blk8 &c)
+    // a stage that defines block() works on a whole 8-sample block at a time (its state holds more than a sample's worth of
+    // history, e.g. a filter window); `write` tells it whether the block's output is wanted at all (warm-up blocks: not)
+    template <class Stage, class = void>
+    struct stage_is_blockwise : std::false_type
     {
-        const cf32 a0 = Stage::step(s, p, cf32{c.a.x, c.a.y});
-        const cf32 a1 = Stage::step(s, p, cf32{c.a.z, c.a.w});
-        const cf32 a2 = Stage::step(s, p, cf32{c.b.x, c.b.y});
-        const cf32 a3 = Stage::step(s, p, cf32{c.b.z, c.b.w});
-        const cf32 a4 = Stage::step(s, p, cf32{c.c.x, c.c.y});
-        const cf32 a5 = Stage::step(s, p, cf32{c.c.z, c.c.w});
-        const cf32 a6 = Stage::step(s, p, cf32{c.d.x, c.d.y});
-        const cf32 a7 = Stage::step(s, p, cf32{c.d.z, c.d.w});
-        return Blk8{make_float4(a0.re, a0.im, a1.re, a1.im), make_float4(a2.re, a2.im, a3.re, a3.im), make_float4(a4.re, a4.im, a5.re, a5.im),
-                    make_float4(a6.re, a6.im, a7.re, a7.im)};
+    };
+    template <class Stage>
+    struct stage_is_blockwise<Stage, std::void_t<decltype(&Stage::block)>> : std::true_type
+    {
+    };
+    template <class Stage>
+    __device__ __forceinline__ Blk8 blk_step(typename Stage::S &s, const typename Stage::P &p, const Blk8 &c, bool write)
+    {
+        if constexpr (stage_is_blockwise<Stage>::value)
+            return Stage::block(s, p, c, write);
+        else
+        {
+            const cf32 a0 = Stage::step(s, p, cf32{c.a.x, c.a.y});
+            const cf32 a1 = Stage::step(s, p, cf32{c.a.z, c.a.w});
+            const cf32 a2 = Stage::step(s, p, cf32{c.b.x, c.b.y});
+            const cf32 a3 = Stage::step(s, p, cf32{c.b.z, c.b.w});
+            const cf32 a4 = Stage::step(s, p, cf32{c.c.x, c.c.y});
+            const cf32 a5 = Stage::step(s, p, cf32{c.c.z, c.c.w});
+            const cf32 a6 = Stage::step(s, p, cf32{c.d.x, c.d.y});
+            const cf32 a7 = Stage::step(s, p, cf32{c.d.z, c.d.w});
+            return Blk8{make_float4(a0.re, a0.im, a1.re, a1.im), make_float4(a2.re, a2.im, a3.re, a3.im), make_float4(a4.re, a4.im, a5.re, a5.im),
+                        make_float4(a6.re, a6.im, a7.re, a7.im)};
+        }
     }
     template <class Stage, int D>
     __device__ __forceinline__ void group_run(typename Stage::S &s, const typename Stage::P &p, const Blk8 (&q)[D], cf32 *y, long long i, bool write)
@@ -954,7 +1093,7 @@ namespace sdhip
         Blk8 o[D];
 #pragma unroll
         for (int d = 0; d < D; d++)
-            o[d] = blk_step<Stage>(s, p, q[d]);
+            o[d] = blk_step<Stage>(s, p, q[d], write);
         if (write)
         {
             float4 *yp = reinterpret_cast<float4 *>(y + i);
@@ -1173,12 +1312,35 @@ namespace sdhip
         if (n <= 0)
             return;
         ProfScope _ps("k_chunks<AgcStage>", st);
-        if (ck.ck)
-            hipLaunchKernelGGL((k_chunks<AgcStage, true>), dim3((n + 63) / 64), dim3(64), 0, st, x, y, g, p, start0, spec, endst, redo, nredo, (AgcState *)ck.ck,
-                               ck.per_chunk, ck.len, ck.tol_a, ck.tol_b, ck.work);
+        static const int depth = [] {
+            const char *e = getenv("SDHIP_AGC_DEPTH"); // experiment: bytes per lane per load group = 64 * depth
+            return e ? atoi(e) : 4;
+        }();
+        auto go = [&](auto stage) {
+            using St = decltype(stage);
+            if (ck.ck)
+                hipLaunchKernelGGL((k_chunks<St, true>), dim3((n + 63) / 64), dim3(64), 0, st, x, y, g, p, start0, spec, endst, redo, nredo, (AgcState *)ck.ck,
+                                   ck.per_chunk, ck.len, ck.tol_a, ck.tol_b, ck.work);
+            else
+                hipLaunchKernelGGL((k_chunks<St, false>), dim3((n + 63) / 64), dim3(64), 0, st, x, y, g, p, start0, spec, endst, redo, nredo, (AgcState *)nullptr,
+                                   0, 0, 0.0f, 0.0f, (unsigned long long *)nullptr);
+        };
+        if (depth == 8)
+            go(AgcStageT<8>{});
+        else if (depth == 2)
+            go(AgcStageT<2>{});
         else
-            hipLaunchKernelGGL((k_chunks<AgcStage, false>), dim3((n + 63) / 64), dim3(64), 0, st, x, y, g, p, start0, spec, endst, redo, nredo, (AgcState *)nullptr, 0,
-                               0, 0.0f, 0.0f, (unsigned long long *)nullptr);
+            go(AgcStageT<4>{});
+    }
+    void launch_agc_fir(const cf32 *x, cf32 *y, const ChunkGeom &g, const AgcFirParams &p, const AgcFirState *start0, AgcFirState *spec, AgcFirState *endst,
+                        const int *redo, int nredo, hipStream_t st)
+    {
+        const int n = redo ? nredo : g.K;
+        if (n <= 0)
+            return;
+        ProfScope _ps("k_chunks<AgcFirStage>", st);
+        hipLaunchKernelGGL((k_chunks<AgcFirStage, false>), dim3((n + 63) / 64), dim3(64), 0, st, x, y, g, p, start0, spec, endst, redo, nredo, (AgcFirState *)nullptr,
+                           0, 0, 0.0f, 0.0f, (unsigned long long *)nullptr);
     }
     void launch_costas(const cf32 *x, cf32 *y, const ChunkGeom &g, const CostasParams &p, const CostasState *start0, CostasState *spec, CostasState *endst,
                        const int *redo, int nredo, hipStream_t st, const ChunkCkpt &ck)
@@ -1196,8 +1358,16 @@ namespace sdhip
                 hipLaunchKernelGGL((k_chunks<St, false>), dim3((n + 63) / 64), dim3(64), 0, st, x, y, g, p, start0, spec, endst, redo, nredo,
                                    (CostasState *)nullptr, 0, 0, 0.0f, 0.0f, (unsigned long long *)nullptr);
         };
+        static const int depth = [] {
+            const char *e = getenv("SDHIP_COSTAS_DEPTH"); // experiment
+            return e ? atoi(e) : 2;
+        }();
         if (p.order == 2)
             go(CostasStage<2>{});
+        else if (p.order == 4 && depth == 4)
+            go(CostasStage<4, 4>{});
+        else if (p.order == 4 && depth == 8)
+            go(CostasStage<4, 8>{});
         else if (p.order == 4)
             go(CostasStage<4>{});
         else

@@ -28,6 +28,8 @@ def build(force: bool = False) -> str:
         src = re.sub(r'__attribute__\(\(amdgpu_waves_per_eu\([^)]*\)\)\)', "", src)
         # constants pinned into registers with v_mov / s_mov: plain assignments here
         src = re.sub(r'asm volatile\("[sv]_mov_b32 %0, (0x[0-9a-fA-F]+)" : "=[sv]"\(([^;]+?)\)\);', r"\2 = \1;", src)
+        # a scalar copied into a vector register (sd_to_vgpr): a plain copy here
+        src = re.sub(r'asm\("v_mov_b32 %0, %1" : "=v"\((\w+)\) : "s"\((\w+)\)\);', r"\1 = \2;", src)
         dst = os.path.join(OUT, f.replace(".hip", "_emu.cpp"))
         open(dst, "w").write(src)
         gen.append(dst)
