@@ -1313,6 +1313,9 @@ namespace sdhip
                 // phase in, ~16/gain_mu symbols at the loop's own gains settle it onto the sequential trajectory
                 // (|dt| p99 < 0.03 sample at GOES' 7 dB, far less for the QPSK configs); 36/gain_mu without the fast gear
                 const double gmu = std::max(1e-4f, cfg.clock_gain_mu);
+                // nobody asked for the float symbols: the clock recovery stores the int8 soft symbols itself (SDHIP_MM_Q8=0: A/B switch)
+                mm_p.q8 = (d_syms == nullptr && env_int("SDHIP_MM_Q8", 1) != 0) ? 1 : 0;
+                mm_p.q8_bpsk = is_bpsk ? 1 : 0;
                 mm_p.fast_mult = (float)env_int("SDHIP_MM_FAST_MULT", 8);
                 mm_p.fast_syms = mm_p.fast_mult > 1.0f ? (int)env_int("SDHIP_MM_FAST_SYMS", (long long)(2.75 / gmu)) : 0;
                 // a re-run costs one lane the whole chunk, so long chunks (large batches) keep the conservative warm-up: it is a
@@ -1351,7 +1354,7 @@ namespace sdhip
                     g = make_geom(n, L, (int)Wn);
                     const double omin = (double)mm_p.omega_mid - (double)mm_p.omega_limit;
                     const long long span0 = std::min<long long>(n, (long long)L + Wn);
-                    mm_p.cap = (int)(span0 / std::max(0.5, omin - 0.01)) + 16;
+                    mm_p.cap = ((int)(span0 / std::max(0.5, omin - 0.01)) + 16 + 1) & ~1; // even: int8 rows start on a dword
                     mm_p.cg = cg;
                     mm_p.rot = mm_rot;
                     symbuf.reserve((size_t)g.K * mm_p.cap);
@@ -1446,7 +1449,10 @@ namespace sdhip
                 const long long need_soft = is_bpsk ? tot : 2 * tot;
                 if ((size_t)need_soft > soft_cap)
                     throw HipError("soft output buffer too small");
-                launch_quantize(symbuf.p, d_seg.p, d_offsets.p, g.K, mm_p.cap, is_bpsk ? 1 : 0, d_soft, (long long)soft_cap, d_syms, (long long)syms_cap, stream);
+                if (mm_p.q8)
+                    launch_compact8(symbuf.p, d_seg.p, d_offsets.p, g.K, mm_p.cap, is_bpsk ? 1 : 0, d_soft, (long long)soft_cap, stream);
+                else
+                    launch_quantize(symbuf.p, d_seg.p, d_offsets.p, g.K, mm_p.cap, is_bpsk ? 1 : 0, d_soft, (long long)soft_cap, d_syms, (long long)syms_cap, stream);
                 // history for the next call: last DEMOD_HIST de-rotated Costas outputs
                 launch_tail_copy(A, n, DEMOD_HIST, cg, mm_rot, order, d_hist.p, stream);
                 SD_HIP(hipMemcpyAsync(hist_cos.data(), d_hist.p, DEMOD_HIST * sizeof(cf32), hipMemcpyDeviceToHost, stream));

@@ -160,6 +160,7 @@ namespace sdhip
         int cap; // output capacity per chunk (symbols)
         int fast_syms;   // warm-up gear shift: symbols run with mu_gain * fast_mult and the omega term frozen
         float fast_mult;
+        int q8, q8_bpsk; // q8: the symbols are stored as the module's int8 soft symbols (2 bytes per symbol row entry) instead of floats
     };
     struct MmState
     {
@@ -196,6 +197,9 @@ namespace sdhip
     // [first, first+count) of its scratch row go to offsets[k]
     void launch_quantize(const cf32 *sym_scratch, const int *seg, const long long *offsets, int K, int cap, int bpsk, int8_t *soft, long long soft_cap,
                          float *syms, long long syms_cap, hipStream_t st);
+    // the same compaction for scratch rows written by launch_mm with MmParams::q8 (sym_scratch then holds 2-byte entries)
+    void launch_compact8(const cf32 *sym_scratch, const int *seg, const long long *offsets, int K, int cap, int bpsk, int8_t *soft, long long soft_cap,
+                         hipStream_t st);
     // rotated copy of the last `cnt` Costas outputs (history for the next call), incl. the per-chunk rotation
     void launch_derotate(cf32 *x, long long n, const ChunkGeom &cg, const int *rot, int order, hipStream_t st);
     void launch_tail_copy(const cf32 *x, long long n, int cnt, const ChunkGeom &cg, const int *rot, int order, cf32 *out, hipStream_t st);

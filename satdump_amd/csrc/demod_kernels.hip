@@ -1600,7 +1600,16 @@ namespace sdhip
     // SPLIT (experimental, SDHIP_MM_SPLIT=1, same results bit for bit -- checked on the host twin; not yet measured): the symbol loop
     // as three plain loops, one per phase, each bounded by a single sample-index test, instead of one loop that re-evaluates the
     // warm-up / chunk / look-ahead bookkeeping (~45 of its ~200 instructions) on every symbol. The lane is issue-bound.
-    template <bool CKPT, bool SPLIT>
+        // quantiser, module_psk_demod.cpp:199-213 + clamp module_demod_base.h:106-113
+    __device__ __forceinline__ signed char sd_clamp8(float x)
+    {
+        if (x < -128.0f)
+            return -127;
+        if (x > 127.0f)
+            return 127;
+        return (signed char)(int)x;
+    }
+template <bool CKPT, bool SPLIT, bool Q8 = false>
     __global__ __launch_bounds__(64) void k_mm(const cf32 *x, cf32 *sym, int *counts, ChunkGeom g, MmParams p, const MmState *start0, MmState *spec,
                                                MmState *endst, MmCert *spec_c, MmCert *end_c, const int *redo, int nredo, MmCkpt *ck, int ck_per_chunk,
                                                float ck_tol)
@@ -1645,7 +1654,35 @@ namespace sdhip
         // chunk's own trajectory starts one symbol later than this one ends (timing within tolerance, boundary sample
         // index on the other side of the mu wrap), the host hands these to the stream instead of re-running anything.
         const long long b = chunk_begin(g, k), e = chunk_end(g, k);
+        // Q8: the symbols leave as the module's int8 soft symbols (x100, x50 for BPSK, clamped: module_psk_demod.cpp:199-213) -- two
+        // bytes per symbol in the scratch row instead of eight; the float symbols are only stored when a caller asks for them
         cf32 *o = sym + (size_t)k * p.cap;
+        short *o8 = reinterpret_cast<short *>(sym) + (size_t)k * p.cap;
+        // (pairs of symbols leave as one aligned dword store: 2-byte stores scattered over the lanes' rows cost more than the 8-byte
+        // float stores did; a lane's symbols get consecutive indices from 0, an unpaired last one is flushed behind the loop)
+        unsigned pend = 0;
+        int pend_at = -1;
+        auto put = [&](int at, const cf32 v) {
+            if constexpr (Q8)
+            {
+                const float sc = p.q8_bpsk ? 50.0f : 100.0f;
+                const unsigned cur = (unsigned)(unsigned char)sd_clamp8(v.re * sc) | ((unsigned)(unsigned char)sd_clamp8(v.im * sc) << 8);
+                if ((at & 1) && pend_at == at - 1)
+                {
+                    *reinterpret_cast<unsigned *>(o8 + at - 1) = pend | (cur << 16);
+                    pend_at = -1;
+                }
+                else if (at & 1)
+                    o8[at] = (short)cur;
+                else
+                {
+                    pend = cur;
+                    pend_at = at;
+                }
+            }
+            else
+                o[at] = v;
+        };
         int phase = warm ? 0 : 1, cnt = 0, nx = 0, wsym = 0;
         bool done = false, merged = false;
         Blk8 q[MM_DEPTH];
@@ -1719,7 +1756,7 @@ namespace sdhip
                             {
                                 const cf32 v = mm_iter(s, p, f.ring, bank, p.omega_gain, p.mu_gain);
                                 if (cnt < p.cap)
-                                    o[cnt] = v;
+                                    put(cnt, v);
                                 cnt++;
                             } while (s.inc < lim);
                         }
@@ -1732,7 +1769,7 @@ namespace sdhip
                             }
                             const cf32 v = mm_iter(s, p, f.ring, bank, p.omega_gain, p.mu_gain);
                             if (cnt + nx < p.cap)
-                                o[cnt + nx] = v;
+                                put(cnt + nx, v);
                             nx++;
                         }
                     }
@@ -1768,7 +1805,7 @@ namespace sdhip
                         if (phase != 0)
                         {
                             if (cnt + nx < p.cap)
-                                o[cnt + nx] = v;
+                                put(cnt + nx, v);
                             if (phase == 1)
                                 cnt++;
                             else
@@ -1778,6 +1815,9 @@ namespace sdhip
                 }
             }
         }
+        if constexpr (Q8)
+            if (pend_at >= 0)
+                o8[pend_at] = (short)pend;
         if (!merged) // a merged re-run leaves the chunk's count, look-ahead and end state as the speculative run wrote them
             counts[2 * k + 1] = nx;
     }
@@ -1790,9 +1830,15 @@ namespace sdhip
         ProfScope _ps("k_mm", st);
         const char *split_env = getenv("SDHIP_MM_SPLIT");
         const bool split = split_env && split_env[0] == '1';
-        if (ck)
+        if (ck && p.q8)
+            hipLaunchKernelGGL((k_mm<true, false, true>), dim3((n + 63) / 64), dim3(64), 0, st, x, sym_scratch, counts, g, p, start0, spec, endst, spec_c, end_c,
+                               redo, nredo, ck, ck_per_chunk, ck_tol);
+        else if (ck)
             hipLaunchKernelGGL((k_mm<true, false>), dim3((n + 63) / 64), dim3(64), 0, st, x, sym_scratch, counts, g, p, start0, spec, endst, spec_c, end_c, redo,
                                nredo, ck, ck_per_chunk, ck_tol);
+        else if (p.q8)
+            hipLaunchKernelGGL((k_mm<false, false, true>), dim3((n + 63) / 64), dim3(64), 0, st, x, sym_scratch, counts, g, p, start0, spec, endst, spec_c, end_c,
+                               redo, nredo, (MmCkpt *)nullptr, 0, 0.0f);
         else if (split)
             hipLaunchKernelGGL((k_mm<false, true>), dim3((n + 63) / 64), dim3(64), 0, st, x, sym_scratch, counts, g, p, start0, spec, endst, spec_c, end_c, redo,
                                nredo, (MmCkpt *)nullptr, 0, 0.0f);
@@ -1862,15 +1908,6 @@ namespace sdhip
         hipLaunchKernelGGL(k_gardner_seq, dim3(1), dim3(64), 0, st, x, n, p, out, out_cap, count);
     }
 
-    // quantiser, module_psk_demod.cpp:199-213 + clamp module_demod_base.h:106-113
-    __device__ __forceinline__ signed char sd_clamp8(float x)
-    {
-        if (x < -128.0f)
-            return -127;
-        if (x > 127.0f)
-            return 127;
-        return (signed char)(int)x;
-    }
     __global__ __launch_bounds__(256) void k_quantize(const cf32 *sym, const int *seg, const long long *offsets, int K, int cap, int bpsk, int8_t *soft,
                                                       long long soft_cap, float *syms, long long syms_cap)
     {
@@ -1900,6 +1937,37 @@ namespace sdhip
                 soft[2 * o + 1] = sd_clamp8(v.im * 100.0f);
             }
         }
+    }
+    // compaction of the int8 scratch rows k_mm<.., Q8> leaves (two bytes per symbol): BPSK keeps the first byte of each pair
+    __global__ __launch_bounds__(256) void k_compact8(const short *sym8, const int *seg, const long long *offsets, int K, int cap, int bpsk, int8_t *soft,
+                                                      long long soft_cap)
+    {
+        const int k = (int)blockIdx.x;
+        if (k >= K)
+            return;
+        const int cnt = seg[2 * k + 1];
+        const long long off = offsets[k];
+        const short *s = sym8 + (size_t)k * cap + seg[2 * k];
+        for (int j = (int)threadIdx.x; j < cnt; j += (int)blockDim.x)
+        {
+            const unsigned v = (unsigned short)s[j];
+            const long long o = off + j;
+            if (bpsk)
+            {
+                if (o < soft_cap)
+                    soft[o] = (int8_t)(v & 0xffu);
+            }
+            else if (2 * o + 1 < soft_cap)
+                *reinterpret_cast<short *>(soft + 2 * o) = (short)v;
+        }
+    }
+    void launch_compact8(const cf32 *sym_scratch, const int *seg, const long long *offsets, int K, int cap, int bpsk, int8_t *soft, long long soft_cap,
+                         hipStream_t st)
+    {
+        if (K <= 0)
+            return;
+        ProfScope _ps("k_compact8", st);
+        hipLaunchKernelGGL(k_compact8, dim3(K), dim3(256), 0, st, reinterpret_cast<const short *>(sym_scratch), seg, offsets, K, cap, bpsk, soft, soft_cap);
     }
     void launch_quantize(const cf32 *sym_scratch, const int *seg, const long long *offsets, int K, int cap, int bpsk, int8_t *soft, long long soft_cap,
                          float *syms, long long syms_cap, hipStream_t st)

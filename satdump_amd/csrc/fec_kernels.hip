@@ -675,6 +675,73 @@ namespace sdhip
         const SymFetch f{c, reinterpret_cast<const int8_t *>(stage) + a - lo, c.B}; // f.blk[i] = byte i of block j for lo <= i < hi
         const bool have_prev = first_block + j > 0;
         unsigned v[8];
+        // Fast path (rate 1/2, the thread's eight steps wholly inside this block's staged bytes): the 16 or 18 soft bytes -- eight I/Q
+        // pairs, nine when the BPSK shift makes a step straddle two pairs -- come out of LDS as six dwords realigned to the first
+        // pair, and rotation / swap / offset-binary conversion (SymFetch::u_at) run on registers. The generic path below issues four
+        // byte reads per step and carries every mode's code.
+        {
+            const int rt = gi * 8;
+            const int j0 = c.shift + 2 * (rt - VIT2_WARM), jb = j0 & ~1, odd = c.shift & 1;
+            if (c.mode == 0 && rt >= VIT2_WARM && rt + 8 <= VIT2_WARM + nsteps && jb >= lo && jb + 16 + 2 * odd <= hi)
+            {
+                const int ob = jb - lo + a;
+                const unsigned *w32 = reinterpret_cast<const unsigned *>(stage) + (ob >> 2);
+                const unsigned sh = 8u * (unsigned)(ob & 3);
+                unsigned w[6], d[5];
+#pragma unroll
+                for (int i = 0; i < 6; i++)
+                    w[i] = w32[i];
+#pragma unroll
+                for (int i = 0; i < 5; i++)
+                    d[i] = (unsigned)(((((unsigned long long)w[i + 1]) << 32) | w[i]) >> sh);
+                const bool swap = (c.pre_swap != 0) != (c.iq_swap != 0); // two swaps cancel
+                unsigned ua[9], ub[9];
+#pragma unroll
+                for (int pi = 0; pi < 9; pi++)
+                {
+                    const unsigned word = d[pi >> 1] >> (16 * (pi & 1));
+                    int av = (int)(signed char)(word & 0xffu), bv = (int)(signed char)((word >> 8) & 0xffu);
+                    av = av == -128 ? -127 : av;
+                    bv = bv == -128 ? -127 : bv;
+                    if (swap)
+                    {
+                        const int t = av;
+                        av = bv;
+                        bv = t;
+                    }
+                    if (c.phase == 1)
+                    {
+                        const int t = av;
+                        av = bv;
+                        bv = -t;
+                    }
+                    else if (c.phase == 2)
+                    {
+                        av = -av;
+                        bv = -bv;
+                    }
+                    else if (c.phase == 3)
+                    {
+                        const int t = av;
+                        av = -bv;
+                        bv = t;
+                    }
+                    unsigned x = (unsigned)(av + 127) & 255u, y = (unsigned)(bv + 127) & 255u;
+                    ua[pi] = x == 128u ? 127u : x;
+                    ub[pi] = y == 128u ? 127u : y;
+                }
+#pragma unroll
+                for (int q = 0; q < 8; q++)
+                    v[q] = odd ? (ub[q] | (ua[q + 1] << 8)) : (ua[q] | (ub[q] << 8));
+                uint4 o;
+                o.x = v[0] | (v[1] << 16);
+                o.y = v[2] | (v[3] << 16);
+                o.z = v[4] | (v[5] << 16);
+                o.w = v[6] | (v[7] << 16);
+                *reinterpret_cast<uint4 *>(symu + (size_t)j * SU + (size_t)gi * 8) = o;
+                return;
+            }
+        }
 #pragma unroll
         for (int q = 0; q < 8; q++)
         {

@@ -99,6 +99,29 @@ def test_post_costas_dc(torch_cuda, capi, orc, case):
     assert got.shape == wantc.shape and np.array_equal(got, wantc) and len(got) >= 20
 
 
+@pytest.mark.parametrize("case", ["goes", "metop"])
+def test_int8_symbols_straight_from_the_clock_recovery(torch_cuda, capi, orc, case):
+    """When the caller does not ask for the float symbols the clock-recovery kernel stores the module's int8 soft symbols itself
+    (two bytes per symbol through the per-chunk scratch instead of eight, no float round trip): the .soft bytes must be the very
+    bytes the float path quantises, over several ragged calls, in exact and in chunk-parallel mode."""
+    from tests import test_demod_gpu as G
+    spec, plain, x, ocfg, kw, fec, ofec = G._case(case)
+    x = x[:700000]
+    n = len(x)
+    d_x = G._dev(torch_cuda, x.view(np.float32))
+    for extra in (dict(exact=1), dict(chunk_len=8192)):
+        bounds = [0, 1000, n // 3 + 5, n]
+        soft_f, _, _ = _run_demod(torch_cuda, capi, kw, x, chunks=bounds, **extra)
+        dem = capi.PskDemod(capi.demod_cfg(**kw, **extra))
+        parts = []
+        for a, b in zip(bounds[:-1], bounds[1:]):
+            d_soft = torch_cuda.zeros(2 * (b - a) + 64, dtype=torch_cuda.int8, device="cuda")
+            ns = dem.process_dev(d_x.data_ptr() + 8 * a, b - a, capi.FMT_CF32, d_soft.data_ptr(), 2 * (b - a) + 64)  # no float symbols wanted
+            parts.append(d_soft[:ns].cpu().numpy())
+        soft_q = np.concatenate(parts)
+        assert len(soft_q) == len(soft_f) > 100000 and np.array_equal(soft_q, soft_f), extra
+
+
 def _carrier_case(nframes=24, carrier=0.9, cfo_hz=3000.0):
     """BPSK with a residual carrier in quadrature (an AM-subcarrier style downlink, the has_carrier pipelines): the GOES test stream
     built without frequency offset, the carrier line added, then both turned by the offset."""
