@@ -560,10 +560,12 @@ namespace sdhip
             return (uint32_t)((v << (24 + sh)) >> 32);
         }
 
-        // Where the FSM gets its 32-bit windows from. A locked deframer only ever looks at p0 + k * CADU (one word per frame):
-        // those words were gathered on the device and are all that crossed PCIe (a few 100 KB instead of the whole packed stream,
-        // 100 MB per 65536-block batch). Any other position -- the bit-by-bit slide after a failed check, a re-lock on another
-        // alignment -- makes fetch_full() bring the whole stream over once, and the walk carries on from it.
+        // Where the FSM gets its 32-bit windows from. A locked deframer only ever looks at p0 + k * CADU, and a SYNCING one whose
+        // check fails looks one and two bits further on before it gives up (three failures -> NOSYNC, which works from the exact-hit
+        // list): WIN_OFFS words per frame position were gathered on the device and are all that crossed PCIe (~1 MB instead of the
+        // whole packed stream, 67-100 MB per 65536-block batch -- which is what a single bad frame marker used to cost: 7 ms of a
+        // MetOp step, whose uncorrectable frames are passed on). Any other position -- a re-lock on another alignment -- makes
+        // fetch_full() bring the whole stream over once, and the walk carries on from it.
         struct WindowSource
         {
             const uint32_t *words = nullptr; // gathered windows
@@ -576,8 +578,8 @@ namespace sdhip
                 if (!bytes)
                 {
                     const int64_t d = p - p0;
-                    if (d >= 0 && d % step == 0 && d / step < K)
-                        return words[d / step];
+                    if (d >= 0 && d % step < WIN_OFFS && d / step < K)
+                        return words[(d / step) * WIN_OFFS + d % step];
                     bytes = fetch_full();
                 }
                 return window_at(bytes, p);
@@ -742,11 +744,11 @@ namespace sdhip
                 // the windows a locked FSM will ask for: one per frame from its next check position on
                 const int64_t gp0 = def.next_check - base_abs;
                 const int gK = (int)std::min<int64_t>(std::max<int64_t>(0, (total - gp0) / cfg.cadu_size + 2), 1 << 24);
-                d_win.reserve((size_t)gK + 1);
-                h_win.reserve((size_t)gK + 1);
+                d_win.reserve((size_t)gK * WIN_OFFS + 1);
+                h_win.reserve((size_t)gK * WIN_OFFS + 1);
                 launch_window_gather(d_packed.p, total, gp0, cfg.cadu_size, gK, d_win.p, stream);
                 if (gK > 0)
-                    SD_HIP(hipMemcpyAsync(h_win.p, d_win.p, (size_t)gK * 4, hipMemcpyDeviceToHost, stream));
+                    SD_HIP(hipMemcpyAsync(h_win.p, d_win.p, (size_t)gK * WIN_OFFS * 4, hipMemcpyDeviceToHost, stream));
                 SD_HIP(hipStreamSynchronize(stream));
                 HitSource hs;
                 hs.produce = [&](std::vector<uint32_t> &hits) {

@@ -163,6 +163,7 @@ namespace sdhip
     // Copy the (NRZ-M decoded) logical stream [0,total) to a packed MSB-first byte buffer.
     void launch_pack_stream(const BitStream &bs, uint8_t *out_bytes, int64_t total_bits, hipStream_t st);
     // 32-bit windows of the packed stream at p0 + k * step, k < K (what a locked deframer looks at: one word per frame)
+    constexpr int WIN_OFFS = 3; // windows gathered per expected frame position: the position itself and the next two bits
     void launch_window_gather(const uint8_t *packed, int64_t total_bits, int64_t p0, int step, int K, uint32_t *words, hipStream_t st);
 
     // Frame extraction + derandomiser + Reed-Solomon (module_ccsds_conv_concat_decoder.cpp:173-195).

@@ -1506,26 +1506,33 @@ namespace sdhip
         out[i * 4 + 2] = (unsigned char)(w >> 8);
         out[i * 4 + 3] = (unsigned char)(w);
     }
-    // words[k] = the 32 bits ending at stream bit p0 + k * step of the packed stream (the window the deframer FSM compares
-    // with the ASM at an expected frame position); positions outside [31, total) yield 0
+    // words[k * WIN_OFFS + o] = the 32 bits ending at stream bit p0 + k * step + o of the packed stream, o = 0 .. WIN_OFFS - 1: the
+    // window the deframer FSM compares with the ASM at an expected frame position, and the ones it looks at one and two bits
+    // further on when that comparison fails while it is still SYNCING (bpsk_ccsds_deframer.cpp:68-87: three failures in a row
+    // before it drops to NOSYNC); positions outside [31, total) yield 0
     __global__ __launch_bounds__(256) void k_window_gather(const unsigned char *__restrict__ packed, long long total_bits, long long p0, int step, int K,
                                                             unsigned *words)
     {
         const int k = (int)(blockIdx.x * blockDim.x + threadIdx.x);
         if (k >= K)
             return;
-        const long long p = p0 + (long long)k * step;
-        unsigned w = 0;
-        if (p >= 31 && p < total_bits)
+        const long long pk = p0 + (long long)k * step;
+#pragma unroll
+        for (int o = 0; o < WIN_OFFS; o++)
         {
-            const long long s0 = p - 31, byte = s0 >> 3;
-            const int sh = (int)(s0 & 7);
-            unsigned long long v = 0;
-            for (int i = 0; i < 5; i++)
-                v = (v << 8) | packed[byte + i];
-            w = (unsigned)((v << (24 + sh)) >> 32);
+            const long long p = pk + o;
+            unsigned w = 0;
+            if (p >= 31 && p < total_bits)
+            {
+                const long long s0 = p - 31, byte = s0 >> 3;
+                const int sh = (int)(s0 & 7);
+                unsigned long long v = 0;
+                for (int i = 0; i < 5; i++)
+                    v = (v << 8) | packed[byte + i];
+                w = (unsigned)((v << (24 + sh)) >> 32);
+            }
+            words[(size_t)k * WIN_OFFS + o] = w;
         }
-        words[k] = w;
     }
     void launch_window_gather(const uint8_t *packed, int64_t total_bits, int64_t p0, int step, int K, uint32_t *words, hipStream_t st)
     {
