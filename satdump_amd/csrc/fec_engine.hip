@@ -852,7 +852,7 @@ namespace sdhip
                     fc.rs_fill_bytes = cfg.rs_fill_bytes;
                     fc.rs_dualbasis = cfg.rs_dualbasis;
                     fc.rs_nroots = cfg.rs_type == SDHIP_RS239 ? 16 : 32;
-                    d_rs_clean.reserve((size_t)nf * I * 33 + 64); // clean flags + 32 syndrome bytes per codeword (k_rs_screen -> k_rs)
+                    d_rs_clean.reserve(rs_scratch_bytes((long long)nf * I)); // clean flags, syndromes, dirty list (k_rs_screen -> k_rs)
                     launch_frames(bs, fc, d_frames.p, nf, d_fbytes.p, d_ferr.p, stream, d_rs_clean.p);
                     h_dst.assign(nf, -1);
                     size_t kept = 0;
@@ -1617,7 +1617,7 @@ extern "C"
         SD_GUARD_BEGIN
         SD_HIP(hipSetDevice(device));
         DevBuf<uint8_t> clean;
-        clean.reserve((size_t)nframes * I * 33 + 64);
+        clean.reserve(rs_scratch_bytes((long long)nframes * I));
         launch_rs_only(d_data, nframes, frame_stride, dualbasis, I, rs_type == SDHIP_RS239 ? 16 : 32, fill_bytes, d_errors, nullptr, clean.p);
         SD_HIP(hipDeviceSynchronize());
         return 0;

@@ -181,8 +181,11 @@ namespace sdhip
         int pad;
     };
     // frames: nframes descriptors; out: nframes * cadu_bytes; errors: nframes * max(rs_i,1) ints (-1 = uncorrectable)
-    // clean_scratch (optional, 33 * nframes * rs_i + 64 bytes): enables the syndrome screen in front of the thread-per-codeword decoder
-    // (a clean flag per codeword, then the 32 syndromes of every codeword, which the decoder takes over instead of evaluating them again)
+    // clean_scratch (optional, rs_scratch_bytes(nframes * rs_i) bytes): enables the syndrome screen in front of the thread-per-codeword
+    // decoder (a clean flag per codeword, then the 32 syndromes of every codeword, which the decoder takes over instead of evaluating
+    // them again, then the count and the ids of the codewords with a non-zero syndrome: the decoder runs over that compacted list)
+    inline size_t rs_scratch_list_offset(long long ncw) { return (size_t)((ncw + 15) / 16 * 16) + (size_t)ncw * 32; }
+    inline size_t rs_scratch_bytes(long long ncw) { return rs_scratch_list_offset(ncw) + 4 * (size_t)(ncw + 1) + 64; }
     void launch_frames(const BitStream &bs, const FrameCfg &fc, const FrameDesc *frames, int nframes, uint8_t *out, int *errors, hipStream_t st,
                        uint8_t *clean_scratch = nullptr);
     // Unit entry: RS decode of frames already in memory (sdhip_op_rs_decode).

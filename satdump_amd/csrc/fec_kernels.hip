@@ -1850,9 +1850,14 @@ namespace sdhip
     // One thread per codeword. Frames live in global memory; codeword b of frame f is bytes data[f*stride + ii*I + b].
     // Reproduces ReedSolomon::decode (reedsolomon.cpp:63-116) incl. fill_bytes handling and the error count.
     constexpr int RS_THREADS = 64;
+    // dirty != nullptr: thread i decodes codeword dirty[1 + i] of the dirty[0] the screen found with a non-zero syndrome (a
+    // compacted list: with one codeword in five dirty, a thread per codeword leaves four lanes in five of every wave idle through the
+    // whole Berlekamp-Massey / Chien / Forney sequence)
     __global__ __launch_bounds__(RS_THREADS) void k_rs(unsigned char *data, int nframes, int frame_stride, int dualbasis, int I, int nroots, int fill_bytes,
-                                                        int *errors, const GfTables *tabs, const unsigned char *__restrict__ clean)
+                                                        int *errors, const GfTables *tabs, const unsigned char *__restrict__ clean, const int *__restrict__ dirty)
     {
+        if (dirty && (long long)blockIdx.x * RS_THREADS >= (long long)dirty[0])
+            return;
         __shared__ GfLds gf;
         __shared__ unsigned char dual[512]; // to_dual | from_dual
         __shared__ unsigned char cwbuf[256 * RS_THREADS];
@@ -1868,7 +1873,13 @@ namespace sdhip
         }
         __syncthreads();
         const int tid = (int)threadIdx.x;
-        const long long cwid = (long long)blockIdx.x * RS_THREADS + tid;
+        long long cwid = (long long)blockIdx.x * RS_THREADS + tid;
+        if (dirty)
+        {
+            if (cwid >= (long long)dirty[0])
+                return;
+            cwid = dirty[1 + cwid];
+        }
         if (cwid >= (long long)nframes * I)
             return;
         if (clean && clean[cwid])
@@ -1930,7 +1941,7 @@ namespace sdhip
     // look-ups per thread before it can tell) has nothing left to do.
     constexpr int RSS_CW = 8;
     __global__ __launch_bounds__(32 * RSS_CW) void k_rs_screen(const unsigned char *__restrict__ data, int nframes, int frame_stride, int dualbasis, int I, int nroots,
-                                                                int fill_bytes, unsigned char *clean, const GfTables *tabs)
+                                                                int fill_bytes, unsigned char *clean, const GfTables *tabs, int *errors, int *dirty)
     {
         __shared__ GfLds gf;
         __shared__ unsigned char from_dual[256];
@@ -1986,7 +1997,16 @@ namespace sdhip
         }
         __syncthreads();
         if (tid < RSS_CW && cw0 + tid < ncw)
+        {
             clean[cw0 + tid] = nz[tid] ? 0 : 1;
+            if (dirty)
+            { // clean: no errors, nothing more to do; dirty: onto the decoder's list
+                if (nz[tid])
+                    dirty[1 + atomicAdd(dirty, 1)] = (int)(cw0 + tid);
+                else
+                    errors[cw0 + tid] = 0;
+            }
+        }
         // the syndromes themselves, for the decoder behind the screen (32 bytes per codeword, behind the flags)
         if (cw0 + c < ncw && (r & 3) == 0)
         {
@@ -2001,15 +2021,19 @@ namespace sdhip
         if (n <= 0)
             return;
         const GfTables *tabs = tables_for_current_device();
+        int *dirty = nullptr;
         if (clean_scratch)
         {
+            // scratch: [clean flag per codeword | 32 syndrome bytes per codeword | dirty count, dirty codeword ids]
+            dirty = reinterpret_cast<int *>(clean_scratch + rs_scratch_list_offset(n));
+            SD_HIP(hipMemsetAsync(dirty, 0, sizeof(int), st));
             ProfScope _ps("k_rs_screen", st);
             hipLaunchKernelGGL(k_rs_screen, dim3((unsigned)((n + RSS_CW - 1) / RSS_CW)), dim3(32 * RSS_CW), 0, st, data, nframes, frame_stride, dualbasis, I, nroots, fill_bytes,
-                               clean_scratch, tabs);
+                               clean_scratch, tabs, errors, dirty);
         }
         ProfScope _ps("k_rs", st);
         hipLaunchKernelGGL(k_rs, dim3((unsigned)((n + RS_THREADS - 1) / RS_THREADS)), dim3(RS_THREADS), 0, st, data, nframes, frame_stride, dualbasis, I, nroots,
-                           fill_bytes, errors, tabs, clean_scratch);
+                           fill_bytes, errors, tabs, clean_scratch, dirty);
     }
 
     // ---- frame extraction + derandomiser -----------------------------------------------------------
