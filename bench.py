@@ -76,7 +76,7 @@ def algorithmic_bytes(wl, n_in, n_rs, nsym, nsoft, cadu_bytes_out, in_bytes_per_
         "k_fir": n_rs * 16,
         "k_fir_window": n_rs * 16,
         "k_chunks<CostasStage>": n_rs * 16,
-        "k_mm": n_rs * 8 + nsym * 2,  # the timed steps ask for no float symbols: the kernel stores the int8 pair of every symbol
+        "k_mm": n_rs * 8 + nsym * 8,
         "k_quantize": nsym * (8 + q),
         "k_compact8": nsym * (2 + q),
         "k_vit_decode": nsoft + nsoft * wl["conv_rate"] / 8.0,

@@ -1313,8 +1313,10 @@ namespace sdhip
                 // phase in, ~16/gain_mu symbols at the loop's own gains settle it onto the sequential trajectory
                 // (|dt| p99 < 0.03 sample at GOES' 7 dB, far less for the QPSK configs); 36/gain_mu without the fast gear
                 const double gmu = std::max(1e-4f, cfg.clock_gain_mu);
-                // nobody asked for the float symbols: the clock recovery stores the int8 soft symbols itself (SDHIP_MM_Q8=0: A/B switch)
-                mm_p.q8 = (d_syms == nullptr && env_int("SDHIP_MM_Q8", 1) != 0) ? 1 : 0;
+                // SDHIP_MM_Q8=1 (experiment): when nobody asks for the float symbols the clock recovery stores the int8 soft symbols
+                // itself. Measured on MetOp: the compaction behind it drops from 2.7 to 1.5 ms, but the ~15 extra VALU instructions per
+                // symbol cost the issue-bound k_mm 1.3 - 2.2 ms (unpaired / dword-paired stores): off by default.
+                mm_p.q8 = (d_syms == nullptr && env_int("SDHIP_MM_Q8", 0) != 0) ? 1 : 0;
                 mm_p.q8_bpsk = is_bpsk ? 1 : 0;
                 mm_p.fast_mult = (float)env_int("SDHIP_MM_FAST_MULT", 8);
                 mm_p.fast_syms = mm_p.fast_mult > 1.0f ? (int)env_int("SDHIP_MM_FAST_SYMS", (long long)(2.75 / gmu)) : 0;

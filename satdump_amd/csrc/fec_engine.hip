@@ -780,11 +780,17 @@ namespace sdhip
                     SD_HIP(hipStreamSynchronize(stream));
                     memset(h_packed.p + pbytes - 8, 0, 8);
                     stats_full_fetches++;
+                    if (tdbg)
+                        fprintf(stderr, "[sdhip] fec     . deframer asked for a window off the gathered grid: whole packed stream fetched (%zu bytes)\n", pbytes);
                     return h_packed.p;
                 };
                 if (getenv("SDHIP_WINDOW_GATHER") && atoi(getenv("SDHIP_WINDOW_GATHER")) == 0)
                     src.bytes = src.fetch_full(); // A/B switch: the whole stream on the host, as before the gather
+                const int st_in = def.state;
                 WalkResult W = walk(def, src, base_abs, total, hs, n_eff);
+                if (tdbg)
+                    fprintf(stderr, "[sdhip] fec     . walk: state %d -> %d, %zu frames, exact-hit list %s (%zu hits), first window at %lld, %d windows x %d\n", st_in, W.st.state,
+                            W.frames.size(), hs.have ? "used" : "not needed", hs.hits.size(), (long long)gp0, gK, WIN_OFFS);
                 tick("walk");
 
                 if (cfg.decoder == SDHIP_DEC_METOP_AHRPT)

@@ -614,18 +614,18 @@ namespace sdhip
     constexpr int V2P_LDS = 2 * V2P_STEPS + 64;  // staged bytes: rate 1/2 needs 2 per step (+ shift, + alignment slack)
     __global__ __launch_bounds__(256) void k_vit2_prep(VitCfg c, const int8_t *__restrict__ soft, long long first_block, int nblk, unsigned short *symu, int SU)
     {
-        // thread = 8 consecutive steps of one row (one 16-byte store); 1-D grid: block index = j * tiles + tile (grid.y is
-        // limited to 65535 blocks)
+        // thread = 8 consecutive steps of one row (one 16-byte store); one thread block per row, looping over its tiles of 2048 steps
+        // (a block per tile -- 700 k blocks of 4 KB each on a MetOp batch -- was bound by the rate blocks can be dispatched at)
         __shared__ __attribute__((aligned(16))) unsigned char stage[V2P_LDS];
         const int groups = SU / 8, tiles = (groups + 255) / 256;
-        const int j = (int)(blockIdx.x / tiles);
-        const int tile = (int)(blockIdx.x % tiles);
-        const int gi = tile * (int)blockDim.x + (int)threadIdx.x;
+        const int j = (int)blockIdx.x;
         if (j >= nblk)
             return;
         const TailErasure erasure;
         const int nsteps = c.F + 6;
         const int8_t *cur = soft + (first_block + j) * (long long)c.B;
+        auto do_tile = [&](const int tile) {
+        const int gi = tile * (int)blockDim.x + (int)threadIdx.x;
         // steps of block j this tile covers, and the byte range SymFetch will touch for them
         const int r0 = tile * V2P_STEPS, r1 = r0 + V2P_STEPS;
         int t0 = r0 - VIT2_WARM, t1 = r1 - VIT2_WARM;
@@ -762,6 +762,12 @@ namespace sdhip
         o.z = v[4] | (v[5] << 16);
         o.w = v[6] | (v[7] << 16);
         *reinterpret_cast<uint4 *>(symu + (size_t)j * SU + (size_t)gi * 8) = o;
+        };
+        for (int tile = 0; tile < tiles; tile++)
+        {
+            do_tile(tile);
+            __syncthreads(); // the next tile's staging overwrites the bytes this one read
+        }
     }
 
     // ---- forward pass: one lane per (block, segment)
@@ -965,7 +971,7 @@ namespace sdhip
         const int wpb = vit_words_per_block(F);
         {
             ProfScope _ps("k_vit2_prep", st);
-            hipLaunchKernelGGL(k_vit2_prep, dim3((unsigned)(((SU / 8 + 255) / 256) * (long long)nblk)), dim3(256), 0, st, cfg, soft, (long long)first_block, nblk, w.symu.p, SU);
+            hipLaunchKernelGGL(k_vit2_prep, dim3((unsigned)nblk), dim3(256), 0, st, cfg, soft, (long long)first_block, nblk, w.symu.p, SU);
         }
         {
             ProfScope _ps("k_vit2_acs", st);

@@ -425,7 +425,9 @@ class Recording:
         # frames per whole puncture / symbol period: MetOp's 3/4 pattern consumes 6 mother-code bits per 3 information bits and
         # a frame is 8192 bits, so symbol boundaries and frame boundaries only coincide every 3 frames
         self.group = 1 if spec.conv == "1/2" else 3
-        coded_bits = self.group * (2 * bits if spec.conv == "1/2" else bits * 4 // 3)
+        # (the 4/3 of the punctured code applies to the whole group: 3 frames = 24576 bits -> 32768 code bits; frame by frame it
+        # does not divide)
+        coded_bits = self.group * 2 * bits if spec.conv == "1/2" else self.group * bits * 4 // 3
         self.syms_per_group = coded_bits if spec.constellation == "bpsk" else coded_bits // 2
         if self.P % self.group:
             raise ValueError(f"frames_per_block must be a multiple of {self.group}")

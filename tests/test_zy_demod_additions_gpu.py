@@ -100,11 +100,13 @@ def test_post_costas_dc(torch_cuda, capi, orc, case):
 
 
 @pytest.mark.parametrize("case", ["goes", "metop"])
-def test_int8_symbols_straight_from_the_clock_recovery(torch_cuda, capi, orc, case):
-    """When the caller does not ask for the float symbols the clock-recovery kernel stores the module's int8 soft symbols itself
-    (two bytes per symbol through the per-chunk scratch instead of eight, no float round trip): the .soft bytes must be the very
-    bytes the float path quantises, over several ragged calls, in exact and in chunk-parallel mode."""
+def test_int8_symbols_straight_from_the_clock_recovery(torch_cuda, capi, orc, case, monkeypatch):
+    """SDHIP_MM_Q8=1 (an experiment that stays off by default, see DemodEngine): when the caller does not ask for the float symbols
+    the clock-recovery kernel stores the module's int8 soft symbols itself (two bytes per symbol through the per-chunk scratch
+    instead of eight, no float round trip): the .soft bytes must be the very bytes the float path quantises, over several ragged
+    calls, in exact and in chunk-parallel mode."""
     from tests import test_demod_gpu as G
+    monkeypatch.setenv("SDHIP_MM_Q8", "1")
     spec, plain, x, ocfg, kw, fec, ofec = G._case(case)
     x = x[:700000]
     n = len(x)
