@@ -678,10 +678,13 @@ namespace sdhip
             return (v && *v) ? atoll(v) : dflt;
         }
         // Chunk length of one speculative stage: one lane per chunk, `lanes` lanes wanted. Measured (tools/sweep.sh, sweep_wl.sh,
-        // DESIGN.md 5): the M&M lane is issue-bound (a wave alone on a SIMD runs ~2x faster per sample than two sharing one) and
-        // the AGC lane HBM-bound with a long warm-up, so both want ONE wave per SIMD (1024 SIMDs x 64 lanes, a little less so
-        // that no SIMD gets two) and the longest chunks that allows; the Costas lane is latency-bound (sincos chain) and gains
-        // from two to three waves per SIMD. Chunks stay long enough (2048) that the warm-up overlap does not dominate.
+        // tools/gpu_p.sh, tools/ubench/lane_layout.hip): a lane streams its chunk in 64-byte blocks, and what the memory
+        // system delivers for that pattern depends on how many lanes there are and how much each asks for at a time -- 65 k lanes
+        // with 256 bytes per load group reach 4.5 TB/s (read + write) in a bare copy loop, 196 k lanes with 128 bytes 3.6. So every
+        // stage runs ONE wave per SIMD (1024 SIMDs x 64 lanes, a little less so that no SIMD gets two) with 256-byte load groups
+        // and the longest chunks that allows -- which also keeps the warm-up a small part of the chunk. (The Costas stage ran
+        // three waves per SIMD with 128-byte groups while it was issue-bound on the two-call sincos: 14.0 -> 12.5 ms on MetOp.)
+        // Chunks stay long enough (2048) that the warm-up overlap does not dominate.
         // SDHIP_LANES_AGC / _COSTAS / _MM override the targets (experiments only).
         enum StageKind { ST_AGC = 0, ST_COSTAS = 1, ST_MM = 2 };
         int pick_L(long long n, StageKind st) const
@@ -696,7 +699,7 @@ namespace sdhip
             if (getenv(lnames[st]))
                 return (int)((env_int(lnames[st], 8192) + 7) / 8 * 8);
             static const char *names[3] = {"SDHIP_LANES_AGC", "SDHIP_LANES_COSTAS", "SDHIP_LANES_MM"};
-            static const long long dflt[3] = {65280, 196608, 65280};
+            static const long long dflt[3] = {65280, 65280, 65280};
             static const long long min_len[3] = {2048, 2048, 2048};
             const long long lanes = std::max<long long>(64, env_int(names[st], dflt[st]));
             long long L = (n + lanes - 1) / lanes;

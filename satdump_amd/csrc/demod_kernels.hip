@@ -854,7 +854,7 @@ namespace sdhip
 
     // ORDER (2 / 4 / 8) is a template argument: the detector's form is fixed at compile time, so the per-sample loop carries no
     // test of it and none of the other detectors' code.
-    template <int ORDER, int D = 2>
+    template <int ORDER, int D = 4>
     struct CostasStage
     {
         using P = CostasParams;
@@ -1359,19 +1359,19 @@ namespace sdhip
                                    (CostasState *)nullptr, 0, 0, 0.0f, 0.0f, (unsigned long long *)nullptr);
         };
         static const int depth = [] {
-            const char *e = getenv("SDHIP_COSTAS_DEPTH"); // experiment
-            return e ? atoi(e) : 2;
+            const char *e = getenv("SDHIP_COSTAS_DEPTH"); // experiment: 64-byte blocks per load group (2, 4, 8)
+            return e ? atoi(e) : 4;
         }();
         if (p.order == 2)
-            go(CostasStage<2>{});
-        else if (p.order == 4 && depth == 4)
-            go(CostasStage<4, 4>{});
+            depth == 2 ? go(CostasStage<2, 2>{}) : go(CostasStage<2, 4>{});
+        else if (p.order == 4 && depth == 2)
+            go(CostasStage<4, 2>{});
         else if (p.order == 4 && depth == 8)
             go(CostasStage<4, 8>{});
         else if (p.order == 4)
-            go(CostasStage<4>{});
+            go(CostasStage<4, 4>{});
         else
-            go(CostasStage<8>{});
+            depth == 2 ? go(CostasStage<8, 2>{}) : go(CostasStage<8, 4>{});
     }
     void launch_pll(const cf32 *x, cf32 *y, const ChunkGeom &g, const PllParams &p, const CostasState *start0, CostasState *spec, CostasState *endst,
                     const int *redo, int nredo, hipStream_t st, const ChunkCkpt &ck)
