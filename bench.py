@@ -114,7 +114,7 @@ def pmc_traffic(workload, kernel):
     hdr, rows = rows[0], rows[1:]
     for r in rows:
         if r and r[0].split("<")[0] == kernel.split("<")[0] and (("<" not in kernel) or kernel.split("<")[1].split(">")[0].split(",")[0] in r[0]):
-            return float(r[hdr.index("traffic_bytes_per_dispatch")]), name
+            return float(r[-1]), name  # traffic_bytes_per_dispatch is the last column (kernel names carry commas: count from the right)
     return None, name
 
 
