@@ -1917,6 +1917,61 @@ template <bool CKPT, bool SPLIT, bool Q8 = false>
         const int cnt = seg[2 * k + 1];
         const long long off = offsets[k];
         const cf32 *s = sym + (size_t)k * cap + seg[2 * k];
+        const uintptr_t oaddr = reinterpret_cast<uintptr_t>(soft) + (uintptr_t)(bpsk ? off : 2 * off); // where this row's bytes go
+        if (!syms && off + cnt <= (bpsk ? soft_cap : soft_cap / 2) && (bpsk || (oaddr & 1) == 0))
+        {
+            // the usual case (nobody asked for the float symbols, the row fits): four symbols per thread and ONE aligned store of
+            // their 4 (BPSK) / 8 (QPSK) bytes instead of a byte store per soft symbol; the row's first few symbols, up to the
+            // next 4- / 8-byte boundary of the output, and its last few go one by one
+            const int to_boundary = bpsk ? (int)((4 - (oaddr & 3)) & 3) : (int)(((8 - (oaddr & 7)) & 7) / 2);
+            const int head = to_boundary < cnt ? to_boundary : cnt;
+            const int groups = (cnt - head) / 4;
+            const float sc = bpsk ? 50.0f : 100.0f;
+            auto one = [&](int j) {
+                const cf32 v = s[j];
+                const long long o = off + j;
+                if (bpsk)
+                    soft[o] = sd_clamp8(v.re * sc);
+                else
+                {
+                    soft[2 * o] = sd_clamp8(v.re * sc);
+                    soft[2 * o + 1] = sd_clamp8(v.im * sc);
+                }
+            };
+            if ((int)threadIdx.x < head)
+                one((int)threadIdx.x);
+            for (int g = (int)threadIdx.x; g < groups; g += (int)blockDim.x)
+            {
+                const int j = head + 4 * g;
+                unsigned lo = 0, hi = 0;
+#pragma unroll
+                for (int q = 0; q < 4; q++)
+                {
+                    const cf32 v = s[j + q];
+                    const unsigned a = (unsigned)(unsigned char)sd_clamp8(v.re * sc);
+                    if (bpsk)
+                        lo |= a << (8 * q);
+                    else
+                    {
+                        const unsigned b = (unsigned)(unsigned char)sd_clamp8(v.im * sc);
+                        const unsigned pr = a | (b << 8);
+                        if (q < 2)
+                            lo |= pr << (16 * q);
+                        else
+                            hi |= pr << (16 * (q - 2));
+                    }
+                }
+                const long long o = off + j;
+                if (bpsk)
+                    *reinterpret_cast<unsigned *>(soft + o) = lo;
+                else
+                    *reinterpret_cast<unsigned long long *>(soft + 2 * o) = (unsigned long long)lo | ((unsigned long long)hi << 32);
+            }
+            const int tail0 = head + 4 * groups;
+            if ((int)threadIdx.x < cnt - tail0)
+                one(tail0 + (int)threadIdx.x);
+            return;
+        }
         for (int j = (int)threadIdx.x; j < cnt; j += (int)blockDim.x)
         {
             const cf32 v = s[j];

@@ -742,6 +742,99 @@ namespace sdhip
                 return;
             }
         }
+        // The same for MetOp's rate 3/4 (SymFetch::pair, mode 1): three steps consume four soft bytes (one full pair, then one symbol
+        // of the next pair with the other erased, then its partner), so eight steps touch the 12 or 16 bytes of three or four groups.
+        // Which of the three positions a thread's first step has decides the whole pattern: three compile-time variants.
+        {
+            const int rt = gi * 8, t0s = rt - VIT2_WARM;
+            if (c.mode == 1 && rt >= VIT2_WARM && rt + 8 <= VIT2_WARM + nsteps)
+            {
+                const int m0 = t0s / 3, r0 = t0s - 3 * m0, jb = 4 * m0;
+                if (jb >= lo && 4 * ((t0s + 7) / 3) + 4 <= hi)
+                {
+                    const int ob = jb - lo + a;
+                    const unsigned *w32 = reinterpret_cast<const unsigned *>(stage) + (ob >> 2);
+                    const unsigned sh = 8u * (unsigned)(ob & 3);
+                    unsigned w[5], d[4];
+#pragma unroll
+                    for (int i = 0; i < 5; i++)
+                        w[i] = w32[i];
+#pragma unroll
+                    for (int i = 0; i < 4; i++)
+                        d[i] = (unsigned)(((((unsigned long long)w[i + 1]) << 32) | w[i]) >> sh);
+                    const bool swap = (c.pre_swap != 0) != (c.iq_swap != 0);
+                    unsigned ua[8], ub[8]; // pair 2g = bytes (4g, 4g + 1), pair 2g + 1 = bytes (4g + 2, 4g + 3) of group g
+#pragma unroll
+                    for (int pi = 0; pi < 8; pi++)
+                    {
+                        const unsigned word = d[pi >> 1] >> (16 * (pi & 1));
+                        int av = (int)(signed char)(word & 0xffu), bv = (int)(signed char)((word >> 8) & 0xffu);
+                        av = av == -128 ? -127 : av;
+                        bv = bv == -128 ? -127 : bv;
+                        if (swap)
+                        {
+                            const int t = av;
+                            av = bv;
+                            bv = t;
+                        }
+                        if (c.phase == 1)
+                        {
+                            const int t = av;
+                            av = bv;
+                            bv = -t;
+                        }
+                        else if (c.phase == 2)
+                        {
+                            av = -av;
+                            bv = -bv;
+                        }
+                        else if (c.phase == 3)
+                        {
+                            const int t = av;
+                            av = -bv;
+                            bv = t;
+                        }
+                        unsigned x = (unsigned)(av + 127) & 255u, y = (unsigned)(bv + 127) & 255u;
+                        ua[pi] = x == 128u ? 127u : x;
+                        ub[pi] = y == 128u ? 127u : y;
+                    }
+                    const bool sh0 = c.shift == 0;
+                    auto emit = [&](auto r0c) {
+                        constexpr int R0 = decltype(r0c)::value;
+#pragma unroll
+                        for (int q = 0; q < 8; q++)
+                        {
+                            const int mm = (R0 + q) / 3, r = (R0 + q) % 3;
+                            unsigned s0, s1;
+                            if (sh0)
+                            {
+                                s0 = r == 0 ? ua[2 * mm] : (r == 1 ? 128u : ua[2 * mm + 1]);
+                                s1 = r == 0 ? ub[2 * mm] : (r == 1 ? ub[2 * mm + 1] : 128u);
+                            }
+                            else
+                            {
+                                s0 = r == 0 ? 128u : (r == 1 ? ua[2 * mm] : ua[2 * mm + 1]);
+                                s1 = r == 0 ? ub[2 * mm] : (r == 1 ? 128u : ub[2 * mm + 1]);
+                            }
+                            v[q] = s0 | (s1 << 8);
+                        }
+                    };
+                    if (r0 == 0)
+                        emit(std::integral_constant<int, 0>{});
+                    else if (r0 == 1)
+                        emit(std::integral_constant<int, 1>{});
+                    else
+                        emit(std::integral_constant<int, 2>{});
+                    uint4 o;
+                    o.x = v[0] | (v[1] << 16);
+                    o.y = v[2] | (v[3] << 16);
+                    o.z = v[4] | (v[5] << 16);
+                    o.w = v[6] | (v[7] << 16);
+                    *reinterpret_cast<uint4 *>(symu + (size_t)j * SU + (size_t)gi * 8) = o;
+                    return;
+                }
+            }
+        }
 #pragma unroll
         for (int q = 0; q < 8; q++)
         {

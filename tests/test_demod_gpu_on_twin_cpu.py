@@ -115,4 +115,4 @@ test_dc_block_chunk_parallel = G2.test_dc_block_chunk_parallel
 test_power_of_two_predecimator = G2.test_power_of_two_predecimator
 test_post_costas_dc = G2.test_post_costas_dc
 test_has_carrier = G2.test_has_carrier
-test_int8_symbols_straight_from_the_clock_recovery = G2.test_int8_symbols_straight_from_the_clock_recovery
+test_soft_symbols_without_the_float_symbols = G2.test_soft_symbols_without_the_float_symbols

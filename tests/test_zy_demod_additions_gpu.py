@@ -99,14 +99,16 @@ def test_post_costas_dc(torch_cuda, capi, orc, case):
     assert got.shape == wantc.shape and np.array_equal(got, wantc) and len(got) >= 20
 
 
+@pytest.mark.parametrize("q8", ["0", "1"])
 @pytest.mark.parametrize("case", ["goes", "metop"])
-def test_int8_symbols_straight_from_the_clock_recovery(torch_cuda, capi, orc, case, monkeypatch):
-    """SDHIP_MM_Q8=1 (an experiment that stays off by default, see DemodEngine): when the caller does not ask for the float symbols
-    the clock-recovery kernel stores the module's int8 soft symbols itself (two bytes per symbol through the per-chunk scratch
-    instead of eight, no float round trip): the .soft bytes must be the very bytes the float path quantises, over several ragged
-    calls, in exact and in chunk-parallel mode."""
+def test_soft_symbols_without_the_float_symbols(torch_cuda, capi, orc, case, q8, monkeypatch):
+    """A caller that does not ask for the float symbols (the plugin, bench.py's timed steps) gets its .soft bytes from the
+    quantiser's vectorised path (four symbols, one aligned store) -- and, with SDHIP_MM_Q8=1 (an experiment that stays off by
+    default, see DemodEngine), from the clock-recovery kernel itself, two bytes per symbol through the per-chunk scratch. Either way
+    they must be the very bytes the path with float symbols produces, over several ragged calls (rows start at every output
+    alignment), in exact and in chunk-parallel mode."""
     from tests import test_demod_gpu as G
-    monkeypatch.setenv("SDHIP_MM_Q8", "1")
+    monkeypatch.setenv("SDHIP_MM_Q8", q8)
     spec, plain, x, ocfg, kw, fec, ofec = G._case(case)
     x = x[:700000]
     n = len(x)
