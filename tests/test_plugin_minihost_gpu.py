@@ -132,6 +132,11 @@ def test_fifo_and_dsp_stream_topologies(host, tmp_path):
     orc = pyref.best()
     spec, cadus, plain, syms = util.metop_case(nframes=60)
     x, _ = synth.modulate(syms, spec)
+    # 60 frames demodulate to exactly 40 decoder buffers -- and for a stream that ends ON a buffer boundary the reference's own
+    # loop is a race: whether the previous buffer is decoded once more depends on whether the decoder is already waiting in its next
+    # read when the host stops the FIFO (pipeline_run.cpp:96-101). Cut the stream so that it ends inside a buffer: then the last
+    # read is pending when the FIFO runs empty, whatever the timing.
+    x = x[:-4001]
     inp = tmp_path / "bb.cf32"
     x.tofile(str(inp))
     ocfg = pyref.demod_cfg(samplerate=6e6, symbolrate=2333333, constellation=pyref.QPSK, pll_bw=0.003)
@@ -139,6 +144,7 @@ def test_fifo_and_dsp_stream_topologies(host, tmp_path):
     # read returns with the remainder of the stream in the head of its buffer and the previous buffer's symbols behind it, and the
     # module decodes that once -- the same last buffer as at the end of a file.
     want = _ref_cadus_of_file(orc, ocfg, None, x, block=16384, metop=True)
+    assert len(orc.psk_demod(ocfg, x, want_syms=False)["soft"]) % 16384 > 64
     for mode in ("fifo", "dsp_stream"):
         job = {"mode": mode, "input": str(inp), "output_hint": str(tmp_path / mode),
                "demod": {"module": "psk_demod", "parameters": METOP_DEMOD}, "decoder": {"module": "metop_ahrpt_decoder", "parameters": METOP_DEC}}
@@ -146,7 +152,7 @@ def test_fifo_and_dsp_stream_topologies(host, tmp_path):
         assert rep["demod_class"] == "psk_demod_hip" and rep["decoder_class"] == "metop_ahrpt_decoder_hip"
         got = np.fromfile(rep["cadu"], dtype=np.uint8).reshape(-1, 1024)
         assert got.shape == want.shape and np.array_equal(got, want), (mode, len(got), len(want))
-        assert len(got) >= 50
+        assert len(got) >= 48
 
 
 def test_uncovered_parameters_stay_on_the_cpu_module(host, tmp_path):
