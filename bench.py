@@ -459,6 +459,10 @@ def main():
         for k, v in kernels.items():
             if k in algo and v["ms_per_step"] > 0:
                 v["algo_GBps"] = round(algo[k] / (v["ms_per_step"] * 1e-3) / 1e9, 2)
+                # measured HBM traffic over algorithmic bytes, per step (PMC passes of these very sources, else absent)
+                tr, _src = pmc_traffic(args.workload, k)
+                if tr and algo[k] > 0:
+                    v["traffic_over_algorithmic"] = round(tr * v["launches_per_step"] / algo[k], 3)
         dom = max(prof.items(), key=lambda kv: kv[1][0])[0] if prof else None
         roof = None
         if dom is not None:
