@@ -1088,6 +1088,317 @@ namespace sdhip
             SD_HIP(hipStreamSynchronize(stream));
             return one;
         }
+        // ------------------------------------------------------------------ a SYNCED run of punctured blocks in one go
+        // The reference feeds a sliding buffer call by call: depuncture the call's symbols to its end, decode a block whenever more
+        // than B symbols are in it, drop them, re-encode for the BER, run the lock FSM (viterbi_punc.cpp:103-142,
+        // viterbi_buffer.h). The symbol STREAM that passes through the buffer is just the concatenation of what the calls
+        // depuncture; the bookkeeping (pattern position, the odd symbol held back so the count stays even, when a block is due, how
+        // many symbols lie behind it at that moment) is integer arithmetic on the pattern. So a run of calls is planned on the host
+        // (sim), depunctured by ONE launch into a linear buffer, its windows -- B symbols apart, each read 12 symbols into the next
+        // -- decoded as one batch by the rate 1/2 engine's own kernels (overlapping blocks: VitCfg::stride) with the start states
+        // chained on the device and certified, their BERs computed in one launch, and the lock FSM then walks the calls. What the
+        // buffer holds behind its fill level (left-overs the decoder can see when fewer than 12 symbols lie behind a block) is tracked
+        // as a short interval list and written back at the end of the run, so the call-by-call path can take over at any call: it
+        // does for the lock search, and for the rare call whose block would read into those left-overs.
+        struct SlideIv
+        {
+            int s, e;      // positions [s, e) of the sliding buffer
+            int kind;      // 0: what the buffer held at the start of the run (from position off); 1: stream symbols lin[off ..]; 2: 128
+            long long off;
+        };
+        struct PuncWindow
+        {
+            long long lin_off; // first symbol of the window in the linear stream
+            int block;         // call (0-based in the run) during which the reference decodes it
+        };
+        struct PuncPlan
+        {
+            int nblk = 0;
+            std::vector<PuncDesc> desc;
+            std::vector<PuncWindow> win;
+            std::vector<SlideIv> map;
+            long long lin_len = 0;
+            int first_lead = 0;                                        // the first call starts with the carried symbol
+            int is_first = 0, got_extra = 0, changing_shift = 0, in_buffer = 0; // depuncturer / buffer state behind the run
+        };
+        static void iv_set(std::vector<SlideIv> &m, int a, int b, int kind, long long off, int cap)
+        {
+            b = std::min(b, cap);
+            if (a >= b)
+                return;
+            std::vector<SlideIv> o;
+            for (const SlideIv &v : m)
+            {
+                if (v.e <= a || v.s >= b)
+                {
+                    o.push_back(v);
+                    continue;
+                }
+                if (v.s < a)
+                    o.push_back(SlideIv{v.s, a, v.kind, v.off});
+                if (v.e > b)
+                    o.push_back(SlideIv{b, v.e, v.kind, v.off + (v.kind == 2 ? 0 : b - v.s)});
+            }
+            o.push_back(SlideIv{a, b, kind, off});
+            std::sort(o.begin(), o.end(), [](const SlideIv &x, const SlideIv &y) { return x.s < y.s; });
+            m.swap(o);
+        }
+        // ViterbiSlidingBuffer::del(n): [n, n + rest) moves to the front, everything from `rest` on stays as it was
+        static void iv_del(std::vector<SlideIv> &m, int n, int rest, int cap)
+        {
+            std::vector<SlideIv> o;
+            for (const SlideIv &v : m)
+            { // the moved part
+                const int a = std::max(v.s, n), b = std::min(v.e, n + rest);
+                if (a < b)
+                    o.push_back(SlideIv{a - n, b - n, v.kind, v.off + (v.kind == 2 ? 0 : a - v.s)});
+            }
+            for (const SlideIv &v : m)
+            { // what stays
+                const int a = std::max(v.s, rest), b = std::min(v.e, cap);
+                if (a < b)
+                    o.push_back(SlideIv{a, b, v.kind, v.off + (v.kind == 2 ? 0 : a - v.s)});
+            }
+            std::sort(o.begin(), o.end(), [](const SlideIv &x, const SlideIv &y) { return x.s < y.s; });
+            m.swap(o);
+        }
+        // plan up to nmax calls from the current state; stops in front of a call whose block would be decoded with fewer than 12
+        // symbols behind it
+        PuncPlan punc_sim(int nmax) const
+        {
+            const Punc &P = punc;
+            const int cap = B * 4 + 64;
+            PuncPlan pl;
+            pl.map.push_back(SlideIv{0, cap, 0, 0});
+            int is_first = P.is_first, got_extra = P.got_extra, cshift = P.changing_shift, in_buffer = P.in_buffer;
+            long long consumed = 0, lin_len = in_buffer;
+            for (int b = 0; b < nmax; b++)
+            {
+                // state in front of this call, in case the run has to stop here
+                const PuncPlan keep = pl;
+                const int k_first = is_first, k_extra = got_extra, k_shift = cshift, k_inb = in_buffer;
+                const long long k_cons = consumed, k_len = lin_len;
+                const int lead = (is_first || got_extra) ? 1 : 0;
+                if (b == 0 && lead)
+                {
+                    pl.first_lead = 1;
+                    lin_len += 1; // the carried symbol is not in the buffer yet: it goes in front of this call's symbols
+                }
+                is_first = 0;
+                got_extra = 0;
+                cshift %= P.pat.n;
+                const int cnt = punc_count(P.pat, cshift, B);
+                pl.desc.push_back(PuncDesc{cshift, lin_len});
+                lin_len += cnt;
+                cshift += B;
+                int sz = lead + cnt;
+                if (sz & 1)
+                {
+                    sz--;
+                    got_extra = 1;
+                }
+                iv_set(pl.map, in_buffer, in_buffer + sz, 1, consumed + in_buffer, cap);
+                in_buffer += sz;
+                bool rare = false;
+                while (in_buffer > B)
+                {
+                    if (in_buffer - B < 12)
+                    {
+                        rare = true;
+                        break;
+                    }
+                    pl.win.push_back(PuncWindow{consumed, b});
+                    const int rest = in_buffer - B;
+                    iv_del(pl.map, B, rest, cap);
+                    iv_set(pl.map, rest, rest + 100, 2, 0, cap);
+                    consumed += B;
+                    in_buffer = rest;
+                }
+                if (rare)
+                { // leave this call to the call-by-call path
+                    pl = keep;
+                    is_first = k_first;
+                    got_extra = k_extra;
+                    cshift = k_shift;
+                    in_buffer = k_inb;
+                    consumed = k_cons;
+                    lin_len = k_len;
+                    break;
+                }
+                pl.nblk = b + 1;
+            }
+            pl.lin_len = lin_len;
+            pl.is_first = is_first;
+            pl.got_extra = got_extra;
+            pl.changing_shift = cshift;
+            pl.in_buffer = in_buffer;
+            // positions of the map are in buffer coordinates at the END of the run; stream offsets are absolute in lin
+            return pl;
+        }
+        bool punc_batched = true;
+        DevBuf<uint8_t> d_punc_lin;
+        DevBuf<PuncDesc> d_punc_desc;
+        int punc_run(const int8_t *d_soft, int64_t b0, int nmax, VitCfg rot, int &nout)
+        {
+            const int TEST = 2048;
+            Punc &P = punc;
+            const int cap = B * 4 + 64;
+            PuncPlan pl = punc_sim(nmax);
+            if (pl.nblk == 0)
+                return 0;
+            const int M = (int)pl.win.size();
+            // ---- the stream: [what the buffer holds | the carried symbol | the calls' symbols]
+            d_punc_lin.reserve((size_t)pl.lin_len + 256);
+            if (P.in_buffer > 0)
+                SD_HIP(hipMemcpyAsync(d_punc_lin.p, P.d_slide.p, (size_t)P.in_buffer, hipMemcpyDeviceToDevice, stream));
+            if (pl.first_lead)
+                SD_HIP(hipMemcpyAsync(d_punc_lin.p + P.in_buffer, P.d_carry.p, 1, hipMemcpyDeviceToDevice, stream));
+            SD_HIP(hipMemsetAsync(d_punc_lin.p + pl.lin_len, 128, 256, stream));
+            d_punc_desc.reserve(pl.desc.size());
+            SD_HIP(hipMemcpyAsync(d_punc_desc.p, pl.desc.data(), pl.desc.size() * sizeof(PuncDesc), hipMemcpyHostToDevice, stream));
+            rot.iq_swap = P.iq_swap;
+            rot.phase = P.phase;
+            launch_punc_batch(rot, d_soft, b0, pl.nblk, B, P.pat, d_punc_desc.p, d_punc_lin.p, stream);
+            // ---- the windows, as one batch of overlapping blocks
+            std::vector<VitBlockIO> io((size_t)std::max(M, 1));
+            if (M > 0)
+            {
+                VitCfg v{};
+                v.mode = 2;
+                v.F = F;
+                v.B = 2 * (F + 6);
+                v.stride = B;
+                v.nber = P.test_bit_len / 2;
+                v.nenc = TEST;
+                const int8_t *lin = (const int8_t *)d_punc_lin.p; // window m starts at lin + m * B: block index m of stride B
+                d_io.reserve(M);
+                h_io.reserve(M);
+                for (int j = 0; j < M; j++)
+                {
+                    h_io.p[j] = VitBlockIO{};
+                    h_io.p[j].start_in = -1;
+                }
+                h_io.p[0].start_in = P.dec_first ? -2 : P.dec_start;
+                SD_HIP(hipMemcpyAsync(d_io.p, h_io.p, (size_t)M * sizeof(VitBlockIO), hipMemcpyHostToDevice, stream));
+                uint32_t *vb = d_vbits.p + (size_t)nout * wpb;
+                const bool v2 = use_vit2 && vit2_supported(v);
+                if (!v2)
+                    d_dec.reserve((size_t)M * dstride);
+                if (v2)
+                    launch_vit_decode2(v, lin, 0, M, d_io.p, vb, vit2, stream);
+                else
+                    launch_vit_decode(v, lin, 0, M, d_io.p, d_dec.p, vb, stream);
+                SD_HIP(hipMemcpyAsync(h_io.p, d_io.p, (size_t)M * sizeof(VitBlockIO), hipMemcpyDeviceToHost, stream));
+                SD_HIP(hipStreamSynchronize(stream));
+                for (unsigned rounds = 0;; rounds++)
+                { // certificates, as in process_blocks: segment certificate of the lane-per-segment kernel, start-state chain
+                    redo_list.clear();
+                    for (int j = 0; j < M; j++)
+                    {
+                        if (j > 0 && h_io.p[j].start_used != h_io.p[j - 1].ret_state)
+                        {
+                            h_io.p[j].start_in = h_io.p[j - 1].ret_state;
+                            redo_list.push_back(j);
+                            stats.vit_respec++;
+                        }
+                        else if (h_io.p[j].tb_fallback == 2)
+                        {
+                            h_io.p[j].start_in = h_io.p[j].start_used;
+                            redo_list.push_back(j);
+                            stats.tb_respec++;
+                        }
+                    }
+                    if (redo_list.empty())
+                        break;
+                    if (rounds > (unsigned)M + 2)
+                        throw HipError("viterbi start-state chain does not converge");
+                    const int nr = (int)redo_list.size();
+                    d_redo.reserve(nr);
+                    d_dec.reserve((size_t)nr * dstride);
+                    SD_HIP(hipMemcpyAsync(d_redo.p, redo_list.data(), (size_t)nr * sizeof(int), hipMemcpyHostToDevice, stream));
+                    SD_HIP(hipMemcpyAsync(d_io.p, h_io.p, (size_t)M * sizeof(VitBlockIO), hipMemcpyHostToDevice, stream));
+                    launch_vit_decode(v, lin, 0, nr, d_io.p, d_dec.p, vb, stream, d_redo.p);
+                    SD_HIP(hipMemcpyAsync(h_io.p, d_io.p, (size_t)M * sizeof(VitBlockIO), hipMemcpyDeviceToHost, stream));
+                    SD_HIP(hipStreamSynchronize(stream));
+                }
+                std::vector<int> rets((size_t)M);
+                for (int j = 0; j < M; j++)
+                    rets[j] = h_io.p[j].ret_state;
+                launch_vit_ber(v, lin, 0, M, vb, P.enc_state, d_io.p, stream);
+                SD_HIP(hipMemcpyAsync(h_io.p, d_io.p, (size_t)M * sizeof(VitBlockIO), hipMemcpyDeviceToHost, stream));
+                SD_HIP(hipStreamSynchronize(stream));
+                for (int j = 0; j < M; j++)
+                {
+                    io[j] = h_io.p[j];
+                    io[j].ret_state = rets[j];
+                }
+            }
+            // ---- the lock FSM, call by call (viterbi_punc.cpp:126-141)
+            int used = pl.nblk, wi = 0, wused = 0;
+            for (int b = 0; b < pl.nblk; b++)
+            {
+                while (wi < M && pl.win[wi].block == b)
+                {
+                    P.ber = ((float)io[wi].ber_err / (float)io[wi].ber_tot) * 5;
+                    wi++;
+                }
+                wused = wi;
+                if (P.ber > cfg.viterbi_ber_thresold)
+                {
+                    P.invalid++;
+                    if ((float)P.invalid > (float)cfg.viterbi_outsync_after)
+                        P.state = 0;
+                }
+                else
+                    P.invalid = 0;
+                tap_ber.push_back(punc_ber());
+                tap_state.push_back(P.state);
+                stats.blocks++;
+                if (P.state == 0)
+                {
+                    used = b + 1;
+                    break;
+                }
+            }
+            if (used < pl.nblk)
+            { // lock lost inside the run: the state behind call `used - 1` is what counts (P's scalars: the FSM ones are already there)
+                const float ber = P.ber;
+                const int st = P.state, inv = P.invalid;
+                // punc_sim reads the depuncturer / buffer scalars only, which this function has not touched yet
+                pl = punc_sim(used);
+                P.ber = ber;
+                P.state = st;
+                P.invalid = inv;
+            }
+            if (wused > 0)
+            {
+                P.dec_first = 0;
+                P.dec_start = io[wused - 1].ret_state;
+                P.enc_state = (unsigned)io[wused - 1].pad;
+            }
+            nout += wused;
+            // ---- hand the buffer back: contents by the interval list, the carried symbol, the scalars
+            SD_HIP(hipMemcpyAsync(P.d_tmp.p, P.d_slide.p, (size_t)cap, hipMemcpyDeviceToDevice, stream));
+            for (const SlideIv &v : pl.map)
+            {
+                const size_t n = (size_t)(v.e - v.s);
+                if (v.kind == 1)
+                    SD_HIP(hipMemcpyAsync(P.d_slide.p + v.s, d_punc_lin.p + v.off, n, hipMemcpyDeviceToDevice, stream));
+                else if (v.kind == 2)
+                    SD_HIP(hipMemsetAsync(P.d_slide.p + v.s, 128, n, stream));
+                else if (v.off != v.s)
+                    SD_HIP(hipMemcpyAsync(P.d_slide.p + v.s, P.d_tmp.p + v.off, n, hipMemcpyDeviceToDevice, stream));
+            }
+            if (pl.got_extra)
+                SD_HIP(hipMemcpyAsync(P.d_carry.p, d_punc_lin.p + pl.lin_len - 1, 1, hipMemcpyDeviceToDevice, stream));
+            P.is_first = pl.is_first;
+            P.got_extra = pl.got_extra;
+            P.changing_shift = pl.changing_shift;
+            P.in_buffer = pl.in_buffer;
+            SD_HIP(hipStreamSynchronize(stream));
+            return used;
+        }
+
         void process_blocks_punctured(const int8_t *d_soft, int64_t nblocks, uint8_t *d_out, size_t out_cap_frames, size_t &out_written)
         {
             const int TEST = 2048; // TEST_BITS_LENGTH, viterbi_punc.h:4
@@ -1116,7 +1427,8 @@ namespace sdhip
                 const int64_t batch = std::min<int64_t>(nblocks - pos, 4096);
                 d_vbits.reserve((size_t)(2 * batch + 2) * wpb + 4);
                 int nout = 0;
-                for (int64_t b = pos; b < pos + batch; b++)
+                // one input block the reference's way, call by call: the lock search, and the SYNCED blocks punc_run() leaves alone
+                auto seq_block = [&](int64_t b)
                 {
                     const int8_t *blk = d_soft + b * (int64_t)B;
                     if (P.state == 0)
@@ -1207,6 +1519,20 @@ namespace sdhip
                     tap_ber.push_back(punc_ber());
                     tap_state.push_back(P.state);
                     stats.blocks++;
+                };
+                for (int64_t b = pos; b < pos + batch;)
+                {
+                    if (P.state == 1 && punc_batched)
+                    {
+                        const int used = punc_run(d_soft, b, (int)(pos + batch - b), rot, nout);
+                        if (used > 0)
+                        {
+                            b += used;
+                            continue;
+                        }
+                    }
+                    seq_block(b);
+                    b++;
                 }
                 if (nout > 0)
                     deframe_and_emit(nout, d_out, out_cap_frames, out_written);

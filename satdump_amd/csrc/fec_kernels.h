@@ -17,7 +17,11 @@ namespace sdhip
         int iq_swap;  // d_iq_swap
         int phase;    // d_phase (0,1,2,3 = 0/90/180/270 deg)
         int shift;    // d_shift
+        int stride;   // soft bytes from one block to the next; 0 = B. Smaller than B: overlapping blocks -- the windows of a
+                      // sliding buffer (generic punctured rates: a decoder block reads its B symbols plus 12 of the next one)
+        int nenc;     // bits the BER re-encoder runs per block (its register carries over from there); 0 = nber
     };
+    __host__ __device__ inline long long vit_stride(const VitCfg &c) { return c.stride > 0 ? c.stride : c.B; }
 
     constexpr int VIT_PREPASS = 192;  // steps of the previous block replayed to speculate a start state
     constexpr int VIT_TB_OVERLAP = 96; // extra traceback steps of a speculative traceback segment
@@ -123,6 +127,16 @@ namespace sdhip
     void launch_punc_static(const VitCfg &c, const int8_t *blk, const PuncPat &pat, int shift, int n_in, unsigned char *out, hipStream_t st);
     void launch_punc_cont(const VitCfg &c, const int8_t *blk, int n_in, const PuncPat &pat, int pos0, int lead, int total, unsigned char *carry,
                           unsigned char *dst, hipStream_t st);
+    // a run of calls in one launch: input block first_block + b (n_in symbols each) starts at pattern position desc[b].pos0 and its
+    // depunctured symbols go to lin + desc[b].off -- the plain concatenation (no carry / odd-count handling: that only decides WHEN a
+    // symbol becomes visible to the sliding buffer, which the host keeps track of)
+    struct PuncDesc
+    {
+        int pos0;
+        long long off;
+    };
+    void launch_punc_batch(const VitCfg &c, const int8_t *soft, long long first_block, int nblk, int n_in, const PuncPat &pat, const PuncDesc *desc, unsigned char *lin,
+                           hipStream_t st);
 
     inline int vit_words_per_block(int F)
     {

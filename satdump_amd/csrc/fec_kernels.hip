@@ -302,7 +302,7 @@ namespace sdhip
         {
             // speculate: replay the tail of the previous block from neutral metrics, take the state 6 steps
             // before its end state (== CCDecoder::work's chained start state when survivor paths have merged)
-            SymFetch pf{c, soft + (first_block + j - 1) * (long long)c.B, c.B};
+            SymFetch pf{c, soft + (first_block + j - 1) * vit_stride(c), c.B};
             const int P = VIT_PREPASS < F ? VIT_PREPASS : F;
             const int t0 = F - P, n = P + 6;
             SinkLds sk{pre_ballots[wave]};
@@ -320,7 +320,7 @@ namespace sdhip
         }
 
         // ---- forward pass over the block ------------------------------------------------------------
-        SymFetch f{c, soft + (first_block + j) * (long long)c.B, c.B};
+        SymFetch f{c, soft + (first_block + j) * vit_stride(c), c.B};
         unsigned long long *dec = decisions + (size_t)slot * dstride;
         unsigned X = (start == -2) ? 31u : ((lane == start) ? 0u : 63u); // init_viterbi(_unbiased), cc_decoder.cpp:159-190
         {
@@ -623,7 +623,7 @@ namespace sdhip
             return;
         const TailErasure erasure;
         const int nsteps = c.F + 6;
-        const int8_t *cur = soft + (first_block + j) * (long long)c.B;
+        const int8_t *cur = soft + (first_block + j) * vit_stride(c);
         auto do_tile = [&](const int tile) {
         const int gi = tile * (int)blockDim.x + (int)threadIdx.x;
         // steps of block j this tile covers, and the byte range SymFetch will touch for them
@@ -671,7 +671,7 @@ namespace sdhip
         __syncthreads();
         if (gi >= groups)
             return;
-        const SymFetch pf{c, soft + (first_block + j - 1) * (long long)c.B, c.B};
+        const SymFetch pf{c, soft + (first_block + j - 1) * vit_stride(c), c.B};
         const SymFetch f{c, reinterpret_cast<const int8_t *>(stage) + a - lo, c.B}; // f.blk[i] = byte i of block j for lo <= i < hi
         const bool have_prev = first_block + j > 0;
         unsigned v[8];
@@ -1107,10 +1107,10 @@ namespace sdhip
         const int j = (int)blockIdx.x * 4 + wave;
         if (j >= nblk)
             return;
-        const int nber = c.nber;
+        const int nber = c.nber, nenc = c.nenc > 0 ? c.nenc : c.nber;
         const unsigned *vb = vbits + (size_t)j * wpb;
         const unsigned *vprev = (j > 0) ? vbits + (size_t)(j - 1) * wpb : nullptr;
-        SymFetch f{c, soft + (first_block + j) * (long long)c.B, c.B};
+        SymFetch f{c, soft + (first_block + j) * vit_stride(c), c.B};
         const TailErasure erasure;
         const int per = (nber + 63) / 64;
         unsigned err = 0, tot = 0;
@@ -1128,7 +1128,7 @@ namespace sdhip
                 if (n >= 0)
                     bit = getbit(vb, n);
                 else if (vprev)
-                    bit = getbit(vprev, nber + n);
+                    bit = getbit(vprev, nenc + n); // the previous block's encoder stopped behind its nenc-th bit
                 else
                     bit = (enc_state_in >> (-n - 1)) & 1u;
                 stw |= bit << d;
@@ -1155,7 +1155,7 @@ namespace sdhip
             io[j].ber_tot = (int)tot;
             unsigned e = 0; // encoder register after this block: last 6 encoded bits, newest at bit 0
             for (int d = 0; d < 6; d++)
-                e |= getbit(vb, nber - 1 - d) << d;
+                e |= getbit(vb, nenc - 1 - d) << d;
             io[j].pad = (int)e;
         }
     }
@@ -1172,8 +1172,9 @@ namespace sdhip
 
     // =============================================================================================
     // Generic punctured rates (conv_rate 2/3 .. 7/8): viterbi::puncturing::Depunc23/34/56/78, depunc.h:21-430.
-    // First cut: one call (8192 symbols) per launch, blocks decoded one after the other -- this mode is one pipeline step of 76
-    // and is built for coverage, not speed (the decoder behind it is the batch engine's own kernel).
+    // The lock search and the call-by-call path (k_punc_static / k_punc_cont: one call of 8192 symbols per launch) follow the
+    // reference step by step; a SYNCED run of calls is depunctured by ONE launch (k_punc_batch) and decoded as a batch of
+    // overlapping blocks by the rate 1/2 engine's own kernels (FecEngine::punc_run).
     // =============================================================================================
     // Output index of input i is a closed form of the pattern: j = i + pos0 inputs from a period start, q = j / n whole periods of
     // P = n + popcount(two) outputs, plus what positions pos0 .. (j % n) - 1 of the current period emit. One block, a thread per
@@ -1238,6 +1239,21 @@ namespace sdhip
             dst[total - 1] = old;
         }
     }
+    __global__ __launch_bounds__(256) void k_punc_batch(VitCfg c, const int8_t *soft, long long first_block, int n_in, PuncPat pat, const PuncDesc *desc,
+                                                        unsigned char *lin)
+    {
+        const int b = (int)blockIdx.x;
+        const SymFetch f{c, soft + (first_block + b) * (long long)n_in, n_in};
+        punc_scatter(pat, f, n_in, desc[b].pos0, 0, lin + desc[b].off);
+    }
+    void launch_punc_batch(const VitCfg &c, const int8_t *soft, long long first_block, int nblk, int n_in, const PuncPat &pat, const PuncDesc *desc, unsigned char *lin,
+                           hipStream_t st)
+    {
+        if (nblk <= 0)
+            return;
+        ProfScope _ps("k_punc_batch", st);
+        hipLaunchKernelGGL(k_punc_batch, dim3((unsigned)nblk), dim3(256), 0, st, c, soft, first_block, n_in, pat, desc, lin);
+    }
     void launch_punc_static(const VitCfg &c, const int8_t *blk, const PuncPat &pat, int shift, int n_in, unsigned char *out, hipStream_t st)
     {
         ProfScope _ps("k_punc_static", st);
@@ -1276,7 +1292,7 @@ namespace sdhip
         if (lane < 16)
             tailb[lane] = S->tail[lane];
         __syncthreads();
-        const int8_t *blk = soft + block * (long long)c.B;
+        const int8_t *blk = soft + block * vit_stride(c);
         int cand = 0;
         const int nsw = (c.mode == 0) ? n_swap : 1;
         const int nph = (c.mode == 0) ? nphases : 2;
