@@ -1377,6 +1377,9 @@ namespace sdhip
                 P.enc_state = (unsigned)io[wused - 1].pad;
             }
             nout += wused;
+            if (getenv("SDHIP_DEBUG"))
+                fprintf(stderr, "[sdhip] punctured run: %d call(s) planned, %d used, %d block(s) decoded as one batch, lock %s\n", pl.nblk, used, wused,
+                        P.state ? "kept" : "lost");
             // ---- hand the buffer back: contents by the interval list, the carried symbol, the scalars
             SD_HIP(hipMemcpyAsync(P.d_tmp.p, P.d_slide.p, (size_t)cap, hipMemcpyDeviceToDevice, stream));
             for (const SlideIv &v : pl.map)
