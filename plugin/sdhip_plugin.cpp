@@ -634,9 +634,9 @@ namespace sdhip_plugin
                 }
                 else if (e.id == "ccsds_conv_concat_decoder")
                 {
-                    // punctured rates (conv_rate != "1/2", viterbi_punc.cpp) stay on the CPU module under the OVERRIDE until the HIP
-                    // path for them (sequential first cut, validated on the host twin) has been through the GPU suite; the explicit
-                    // ccsds_conv_concat_decoder_hip module takes them. Padded frames stay on the CPU module.
+                    // punctured rates (conv_rate != "1/2", viterbi_punc.cpp): the HIP path is green on the GPU (tests/test_zz_punctured_gpu.py)
+                    // and the explicit ccsds_conv_concat_decoder_hip module takes them; the OVERRIDE still leaves them with the CPU module
+                    // until a pipeline-level run of such a pipeline (tests/minihost) exists. Padded frames stay on the CPU module.
                     auto cpu = e.inst;
                     e.inst = [cpu](std::string in, std::string out, nlohmann::json p) -> std::shared_ptr<ProcessingModule> {
                         const std::string conv = p.count("conv_rate") > 0 ? p["conv_rate"].get<std::string>() : "1/2";
