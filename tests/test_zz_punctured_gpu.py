@@ -1,8 +1,10 @@
 """conv_rate != "1/2" of ccsds_conv_concat_decoder (viterbi::Viterbi_Depunc + Depunc23/34/56/78, SURVEY.md 8 row a13') through the C ABI
 against the oracle (which is pinned to the compiled reference, tests/test_oracle_vs_ref.py). CADUs, per-block BER and lock state
 bit-identical, incl. a loss of lock with re-lock at a stale puncture phase, NRZ-M, the OQPSK IQ-swap search and ragged pushes.
-The file sorts last on purpose: this path was written after the round's GPU budget was spent and has so far been validated on the
-host twin only (tests/test_fec_gpu_on_twin_cpu.py collects these tests too)."""
+A SYNCED run of calls goes through FecEngine::punc_run (one depuncture launch, one batch of overlapping decoder blocks, one BER
+launch; the lock FSM walks the calls afterwards), the lock search and everything around a loss of lock through the call-by-call
+path -- the hand-overs between the two are what the loss-of-lock cases exercise. tests/test_fec_gpu_on_twin_cpu.py collects these
+tests too (SDHIP_TWIN_FULL=1: minutes on the host twin)."""
 import numpy as np
 import pytest
 
