@@ -144,17 +144,39 @@ def main():
     gp = np.array([2.5714, (8.7e-3) ** 2 / 4, 0.5, 8.7e-3, 0.005], dtype=np.float32)
     out["gardner"] = dict(cs16=cs16, params=gp, syms=ref.block(7, gp, xin))
 
+    # ---- psk_demod's has_carrier chain (carrier PLL + DC block in front of the Costas loop) and the carrier PLL block alone
+    from tests.test_zy_demod_additions_gpu import _carrier_case
+    x, kw = _carrier_case(nframes=6)
+    cs16 = synth.to_cs16(x[:120000])
+    xin = (cs16.astype(np.float32) * np.float32(1.0 / 32767.0)).view(np.complex64)
+    r = ref.psk_demod(pyref.demod_cfg(constellation=pyref.BPSK, **kw), xin)
+    pp = np.array([0.002, 3.14, -3.14], dtype=np.float32)
+    out["demod_carrier"] = dict(cs16=cs16, soft=r["soft"], syms=r["syms"], pll_params=pp, pll_out=ref.block(8, pp, xin[:40000]))
+
     # ---- filter designs
     bank, ir, dr = ref.resamp_bank(2700000, 3000000)
     out["taps"] = dict(rrc_goes=ref.rrc_taps(2.7e6, 927000, 0.5, 31), rrc_metop=ref.rrc_taps(6e6, 2333333, 0.5, 31), mm=ref.mm_bank(128, 8),
                        resamp=bank, resamp_ratio=np.array([ir, dr], dtype=np.int32))
 
+    # `make_golden.py name ...` rewrites only the named fixtures (and their INDEX lines): an .npz is a zip with time stamps, so
+    # rewriting an unchanged fixture would still change its bytes
+    only = set(sys.argv[1:])
+    old_lines = {}
+    ipath = os.path.join(HERE, "INDEX.txt")
+    if only and os.path.exists(ipath):
+        for ln in open(ipath).read().splitlines():
+            if ln and not ln.startswith("#"):
+                old_lines[ln.split(".npz")[0]] = ln
     index = []
     for name, d in out.items():
         path = os.path.join(HERE, name + ".npz")
+        if only and name not in only:
+            if name in old_lines:
+                index.append(old_lines[name])
+            continue
         np.savez_compressed(path, **d)
         index.append(f"{name}.npz  {os.path.getsize(path):8d} B  " + " ".join(f"{k}:{sha(v)[:12]}" for k, v in sorted(d.items())))
-    with open(os.path.join(HERE, "INDEX.txt"), "w") as f:
+    with open(ipath, "w") as f:
         f.write("# produced by tests/golden/make_golden.py from oracle/_ref (the reference's own code); key:sha256[:12]\n" + "\n".join(index) + "\n")
     print("\n".join(index))
 

@@ -69,6 +69,18 @@ def test_demod_golden(port, name, cfg):
     assert np.array_equal(r["syms"].view(np.uint32), d["syms"].view(np.uint32))  # float symbols bit for bit
 
 
+def test_demod_carrier_golden(port):
+    """psk_demod's has_carrier chain and the carrier PLL block alone (pll_carrier_tracking.cpp, fast_trig.cpp), cs16 fixture."""
+    from tests.test_zy_demod_additions_gpu import _carrier_case
+    d = load("demod_carrier")
+    x = (d["cs16"].astype(np.float32) * np.float32(1.0 / 32767.0)).view(np.complex64)
+    _, kw = _carrier_case(nframes=1)
+    r = port.psk_demod(pyref.demod_cfg(constellation=pyref.BPSK, **kw), x)
+    assert np.array_equal(r["soft"], d["soft"]) and np.array_equal(r["syms"].view(np.uint32), d["syms"].view(np.uint32))
+    got = port.block(8, d["pll_params"], x[:40000])
+    assert np.array_equal(got.view(np.uint32), d["pll_out"].view(np.uint32))
+
+
 def test_taps_golden(port):
     d = load("taps")
     assert np.array_equal(port.rrc_taps(2.7e6, 927000, 0.5, 31).view(np.uint32), d["rrc_goes"].view(np.uint32))

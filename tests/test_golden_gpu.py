@@ -106,6 +106,24 @@ def test_demod_golden_exact_cs16(torch_cuda, capi, name, kw):
     assert np.array_equal(d_syms[: 2 * nsym].cpu().numpy().view(np.uint32), d["syms"].view(np.uint32).reshape(-1))
 
 
+def test_demod_carrier_golden_exact_cs16(torch_cuda, capi):
+    """psk_demod with has_carrier (carrier-tracking PLL + DC block in front of the Costas loop), cs16 fixture, exact mode: int8 soft
+    symbols AND float symbols bit-identical to the reference's."""
+    from tests.test_zy_demod_additions_gpu import _carrier_case
+    d = load("demod_carrier")
+    cs16 = d["cs16"]
+    n = len(cs16) // 2
+    _, kw = _carrier_case(nframes=1)
+    dem = capi.PskDemod(capi.demod_cfg(constellation="bpsk", exact=1, **kw))
+    d_x = _dev(torch_cuda, cs16)
+    d_soft = torch_cuda.zeros(2 * n + 64, dtype=torch_cuda.int8, device="cuda")
+    d_syms = torch_cuda.zeros(2 * (n + 64), dtype=torch_cuda.float32, device="cuda")
+    ns = dem.process_dev(d_x.data_ptr(), n, capi.FMT_CS16, d_soft.data_ptr(), 2 * n + 64, d_syms.data_ptr(), n + 64)
+    assert ns == len(d["soft"]) and np.array_equal(d_soft[:ns].cpu().numpy(), d["soft"])
+    nsym = len(d["syms"])
+    assert np.array_equal(d_syms[: 2 * nsym].cpu().numpy().view(np.uint32), d["syms"].view(np.uint32).reshape(-1))
+
+
 @pytest.mark.parametrize("name", ["bpsk_nrzm", "qpsk_diff_swap", "qpsk_90deg"])
 def test_simple_decoder_golden(torch_cuda, capi, name):
     from tests import util

@@ -116,13 +116,17 @@ def test_taps_port_equals_ref(ref, port):
 
 BLOCKS = [(0, [1e-2, 1, 1, 65536]), (1, [6e6, 2333333, 0.5, 31]), (2, [0.003, 4, 1.0]), (2, [0.02, 2, 1.0]), (2, [0.003, 8, 1.0]),
           (3, [2.5714, (8.7e-3) ** 2 / 4, 0.5, 8.7e-3, 0.005]), (4, [2700000, 3000000]), (5, [0]), (6, [0]),
-          (7, [2.5714, (8.7e-3) ** 2 / 4, 0.5, 8.7e-3, 0.005]), (7, [2.0, (8.7e-3) ** 2 / 4, 0.5, 8.7e-3, 0.005])]
+          (7, [2.5714, (8.7e-3) ** 2 / 4, 0.5, 8.7e-3, 0.005]), (7, [2.0, (8.7e-3) ** 2 / 4, 0.5, 8.7e-3, 0.005]),
+          (8, [0.002, 3.14, -3.14]), (8, [0.05, 0.25, -0.25])]  # carrier-tracking PLL (pll_carrier_tracking.cpp, fast_trig.cpp)
 
 
 @pytest.mark.parametrize("kind,params", BLOCKS)
 def test_dsp_blocks_port_equals_ref(ref, port, kind, params):
     rng = np.random.default_rng(kind + 1)
     x = ((rng.standard_normal(120000) + 1j * rng.standard_normal(120000)) * 0.3).astype(np.complex64)
+    if kind == 8:  # half noise alone (every octant of the arctangent, both wraps, the rate limit), half a carrier the loop locks to
+        x[60000:] += (0.9 * np.exp(1j * (0.013 * np.arange(60000) + 1.0))).astype(np.complex64)
+        x[7] = 0
     for chunk in (30000, 8193):
         a = ref.block(kind, params, x, chunk=chunk)
         b = port.block(kind, params, x, chunk=chunk)
@@ -146,6 +150,22 @@ def test_psk_demod_port_equals_ref(ref, port, case):
     assert a["buffer_size"] == b["buffer_size"] and a["final_sps"] == b["final_sps"]
     assert np.array_equal(a["soft"], b["soft"])
     assert np.array_equal(a["syms"].view(np.uint32), b["syms"].view(np.uint32))
+
+
+def test_psk_demod_has_carrier_port_equals_ref(ref, port):
+    """psk_demod's has_carrier chain (carrier PLL + DC block between the RRC filter and the Costas loop, Costas limit 0.2;
+    module_psk_demod.cpp:93-125): restatement == compiled reference, bit for bit, and both refuse a non-BPSK constellation."""
+    from tests.test_zy_demod_additions_gpu import _carrier_case
+    x, kw = _carrier_case(nframes=12)
+    cfg = pyref.demod_cfg(constellation=pyref.BPSK, **kw)
+    a = ref.psk_demod(cfg, x)
+    b = port.psk_demod(cfg, x)
+    assert len(a["soft"]) > 100000 and np.array_equal(a["soft"], b["soft"])
+    assert np.array_equal(a["syms"].view(np.uint32), b["syms"].view(np.uint32))
+    bad = pyref.demod_cfg(constellation=pyref.QPSK, **kw)
+    for orc in (ref, port):
+        with pytest.raises(RuntimeError):
+            orc.psk_demod(bad, x[:50000])
 
 
 def test_sincos_restatement_matches_host_libm(port):
