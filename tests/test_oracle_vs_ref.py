@@ -152,6 +152,20 @@ def test_psk_demod_port_equals_ref(ref, port, case):
     assert np.array_equal(a["syms"].view(np.uint32), b["syms"].view(np.uint32))
 
 
+@pytest.mark.parametrize("opt", ["post_costas_dc", "dc_block"])
+def test_psk_demod_dc_options_port_equals_ref(ref, port, opt):
+    """The two DC-block options of psk_demod (in front of the chain: module_demod_base.cpp; behind the Costas loop:
+    module_psk_demod.cpp:36-38, 127-134): restatement == compiled reference on a stream with a DC offset."""
+    spec, cadus, plain, syms = util.metop_case(nframes=12)
+    x, _ = synth.modulate(syms, spec)
+    x = (x + np.complex64(0.05 - 0.02j)).astype(np.complex64)
+    cfg = pyref.demod_cfg()
+    setattr(cfg, opt, 1)
+    a = ref.psk_demod(cfg, x)
+    b = port.psk_demod(cfg, x)
+    assert np.array_equal(a["soft"], b["soft"]) and np.array_equal(a["syms"].view(np.uint32), b["syms"].view(np.uint32))
+
+
 def test_psk_demod_has_carrier_port_equals_ref(ref, port):
     """psk_demod's has_carrier chain (carrier PLL + DC block between the RRC filter and the Costas loop, Costas limit 0.2;
     module_psk_demod.cpp:93-125): restatement == compiled reference, bit for bit, and both refuse a non-BPSK constellation."""
