@@ -152,6 +152,22 @@ def test_psk_demod_port_equals_ref(ref, port, case):
     assert np.array_equal(a["syms"].view(np.uint32), b["syms"].view(np.uint32))
 
 
+@pytest.mark.parametrize("samplerate,symbolrate,what", [(6e6, 927000, "decimate by 2, then 9/10"), (12e6, 1000000, "decimate by 4 alone"),
+                                                        (33e6, 927000, "decimate by 8, then rational"), (70e6, 665400, "decimate by 32, then rational")])
+def test_psk_demod_predecimator_port_equals_ref(ref, port, samplerate, symbolrate, what):
+    """SmartResampler's power-of-two pre-decimator (smart_resampler.cpp:8-61, power_decim.cpp, decimating_fir.cpp:47-89, the plans'
+    constant tap sets) in the restatement == the compiled reference's own SmartResamplerBlock, bit for bit."""
+    spec = synth.SynthSpec(constellation="bpsk", samplerate=samplerate, symbolrate=symbolrate, conv="1/2", nrzm=True, esn0_db=9.0, amplitude=0.4,
+                           cfo_hz=2000.0, seed=11)
+    x, _ = synth.modulate(synth.frames_to_symbols(synth.make_cadus(3, seed=11), spec), spec)
+    x = x[:400000]
+    cfg = pyref.demod_cfg(constellation=pyref.BPSK, samplerate=samplerate, symbolrate=symbolrate, rrc_alpha=0.5, pll_bw=0.02, max_sps=3.0)
+    a = ref.psk_demod(cfg, x)
+    b = port.psk_demod(cfg, x)
+    assert a["final_sps"] == b["final_sps"] and a["buffer_size"] == b["buffer_size"] and len(a["syms"]) > 1000, what
+    assert np.array_equal(a["soft"], b["soft"]) and np.array_equal(a["syms"].view(np.uint32), b["syms"].view(np.uint32)), what
+
+
 @pytest.mark.parametrize("opt", ["post_costas_dc", "dc_block"])
 def test_psk_demod_dc_options_port_equals_ref(ref, port, opt):
     """The two DC-block options of psk_demod (in front of the chain: module_demod_base.cpp; behind the Costas loop:
