@@ -303,18 +303,24 @@ class Ref(_Lib):
         nsym = n if cfg.constellation == BPSK else n // 2
         return {"soft": soft[:n], "syms": None if syms is None else syms[:nsym], "buffer_size": bs.value, "final_sps": sps.value}
 
-    def pipeline_threaded(self, dcfg: DemodCfg, fcfg: FecCfg, decoder: int, iq: np.ndarray):
+    def pipeline_threaded(self, dcfg: DemodCfg, fcfg: FecCfg, decoder: int, iq: np.ndarray, keep_soft: bool = False):
         """psk_demod + decoder in the reference's own run-time topology (a thread per DSP block, module thread, decoder
-        thread; oracle/ref_wrap.cpp sdref_pipeline_threaded). Compiled reference only. -> dict(cadu, seconds, threads, nsoft)"""
+        thread; oracle/ref_wrap.cpp sdref_pipeline_threaded). Compiled reference only. -> dict(cadu, seconds, threads, nsoft
+        [, soft: the int8 soft symbols the module thread wrote]). Same arithmetic as the sequential entries; what is still inside
+        the block hand-offs when the source ends is dropped, like the reference's modules do at EOF."""
         x = np.ascontiguousarray(iq, dtype=np.complex64)
         cap = len(x) // 2048 + 64
         out = np.zeros((cap, 1024), dtype=np.uint8)
+        soft = np.empty(2 * len(x) + 64, dtype=np.int8) if keep_soft else None
         sec, thr, nsoft = C.c_double(0), C.c_int(0), C.c_int64(0)
         fn = self.lib.sdref_pipeline_threaded
         fn.restype = C.c_int64
-        fn.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
-        n = fn(C.byref(dcfg), C.byref(fcfg), decoder, _p(x), len(x), _p(out), cap, C.byref(sec), C.byref(thr), C.byref(nsoft))
+        fn.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        n = fn(C.byref(dcfg), C.byref(fcfg), decoder, _p(x), len(x), _p(out), cap, C.byref(sec), C.byref(thr), C.byref(nsoft), _p(soft) if keep_soft else None)
         if n < 0:
             raise RuntimeError(f"sdref_pipeline_threaded failed: {n}")
-        return {"cadu": out[:min(n, cap)], "seconds": sec.value, "threads": thr.value, "nsoft": nsoft.value}
+        r = {"cadu": out[:min(n, cap)], "seconds": sec.value, "threads": thr.value, "nsoft": nsoft.value}
+        if keep_soft:
+            r["soft"] = soft[:nsoft.value]
+        return r
 

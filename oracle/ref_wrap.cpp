@@ -862,14 +862,23 @@ extern "C"
     // that carried work (blocks + source + module + decoder). The tail of the stream that is still inside the block
     // hand-offs when the source ends is dropped by stop(), as in the reference: throughput, not parity, is what
     // this entry is for.
+    // soft_keep (optional, 2 * n + 64 bytes): the soft symbols the module thread wrote, for the caller's parity checks.
     int64_t sdref_pipeline_threaded(const sdhip_demod_cfg *c, const sdhip_fec_cfg *f, int decoder, const float *iq, int64_t n, uint8_t *cadu_out,
-                                    int64_t cadu_cap_frames, double *seconds, int *threads, int64_t *nsoft_out)
+                                    int64_t cadu_cap_frames, double *seconds, int *threads, int64_t *nsoft_out, int8_t *soft_keep)
     {
         RefDemodChain ch(c);
         if (!ch.ok)
             return -2;
         const bool is_bpsk = ch.is_bpsk;
-        std::vector<int8_t> soft((size_t)(2 * n + 64));
+        std::vector<int8_t> soft_own(soft_keep ? 0 : (size_t)(2 * n + 64));
+        struct SoftView
+        {
+            int8_t *p;
+            size_t n;
+            int8_t &operator[](size_t i) { return p[i]; }
+            int8_t *data() { return p; }
+            size_t size() const { return n; }
+        } soft{soft_keep ? soft_keep : soft_own.data(), (size_t)(2 * n + 64)};
         SoftFeed feed;
         auto clampf = [](float x) -> int8_t {
             if (x < -128.0)

@@ -71,10 +71,17 @@ def overlap_drop(tail_prev: np.ndarray, head: np.ndarray) -> int:
     return j
 
 
+def edge_frames(overlap_samples: int, samples_per_frame: float, margin: int = 16) -> int:
+    """Boundary frames a rank must contribute to stitch_plan: every frame that can lie inside the lock-in overlap, plus a margin."""
+    return max(64, int(np.ceil(overlap_samples / max(1.0, samples_per_frame))) + margin)
+
+
 def stitch_plan(heads, tails, counts, edge: int = 64):
     """Frames to drop at the head of every rank's CADU list, from the boundary frames alone: heads[r] / tails[r] = the first / last
     (up to `edge`) frames rank r decoded, counts[r] = how many it decoded. The running tail of the stitched stream is kept so that
-    a rank that decoded fewer than `edge` frames does not hide its predecessor's."""
+    a rank that decoded fewer than `edge` frames does not hide its predecessor's.
+    `edge` must cover the overlap (edge_frames()): two ranks that share MORE than `edge` frames cannot be told from two that share
+    none by looking at `edge` boundary frames -- that case raises instead of emitting the shared frames twice."""
     drops = [0] * len(counts)
     run = np.zeros((0, 0), dtype=np.uint8)
     for r in range(len(counts)):
@@ -85,6 +92,13 @@ def stitch_plan(heads, tails, counts, edge: int = 64):
             continue
         if run.size:
             drops[r] = overlap_drop(run, h)
+            if len(h) >= edge and c > len(h):
+                hk = h[:, 4:] if h.shape[1] > 8 else h
+                rk = run[:, 4:] if run.shape[1] > 8 else run
+                # every boundary frame of this rank repeats the predecessor, or the predecessor's oldest kept frame shows up inside
+                # this rank's head: the overlap reaches beyond the `edge` frames that were exchanged
+                if drops[r] >= len(h) or (drops[r] == 0 and len(rk) and (hk == rk[0][None, :]).all(axis=1).any()):
+                    raise ValueError(f"rank {r}: the overlap with its predecessor exceeds the {edge} boundary frames exchanged (use edge_frames())")
         if c - drops[r] >= len(t) or not run.size:
             kept_tail = t if c - drops[r] >= len(t) else t[len(t) - (c - drops[r]):]
             run = kept_tail[-edge:] if c - drops[r] >= edge or not run.size else np.concatenate([run, kept_tail], axis=0)[-edge:]
@@ -100,7 +114,7 @@ def stitch_cadus(per_rank_frames):
     for f in fr:
         if f.ndim != 2:
             raise ValueError("frames must be [n, cadu_bytes]")
-    edge = 64
+    edge = max([64] + [len(f) for f in fr])  # the full lists are at hand: any overlap size is found
     drops = stitch_plan([f[:edge] for f in fr], [f[-edge:] if len(f) else f for f in fr], [len(f) for f in fr], edge)
     parts = [f[d:] for f, d in zip(fr, drops) if len(f) - d > 0]
     if not parts:

@@ -116,3 +116,15 @@ test_power_of_two_predecimator = G2.test_power_of_two_predecimator
 test_post_costas_dc = G2.test_post_costas_dc
 test_has_carrier = G2.test_has_carrier
 test_soft_symbols_without_the_float_symbols = G2.test_soft_symbols_without_the_float_symbols
+
+
+
+@pytest.mark.parametrize("case,esn0,max_diff", [("metop", 5.5, 0.005), ("npp", 3.0, 0.005)])
+def test_margin_sweep_cadu_identity(torch_cuda, capi, orc, case, esn0, max_diff):
+    """Two points of tests/test_demod_gpu.py::test_margin_sweep_cadu_identity on the twin (the demodulator half; the decoder behind it is
+    the oracle's here): chunk-parallel soft symbols at an SNR where RS loses ~10 % / ~3 % of the frames still decode to the reference's list."""
+    G.test_margin_sweep_cadu_identity(torch_cuda, capi, orc, case, esn0, max_diff, n=420)
+
+
+def test_margin_sweep_below_loop_threshold(torch_cuda, capi, orc):
+    G.test_margin_sweep_below_loop_threshold(torch_cuda, capi, orc, 2.5, n=420)

@@ -142,3 +142,23 @@ def test_recordings_tile_seamlessly(workload, frames):
     at = good.index(frames - 1)
     assert good[at + 1:at + 4] == [0, 1, 2], good[at - 2:at + 5]
     assert len(good) >= 2 * frames - 12  # what is lost is lost while the loops lock at the very start
+
+
+
+def test_stitch_with_an_overlap_larger_than_the_exchanged_edge():
+    """two neighbouring ranks that share more frames than the boundary exchange carries. stitch_cadus (full lists at
+    hand) stitches any overlap; stitch_plan with a fixed edge refuses instead of emitting the shared frames twice; edge_frames()
+    sizes the exchange from the lock-in overlap."""
+    from satdump_amd import shard
+    rng = np.random.default_rng(7)
+    F = rng.integers(0, 256, (400, 64), dtype=np.uint8)
+    for ov in (0, 1, 50, 64, 65, 100, 250):
+        a, b = F[:200 + ov // 2], F[200 - (ov - ov // 2):]
+        out = shard.stitch_cadus([a, b])
+        assert out.shape == F.shape and np.array_equal(out, F), ov
+    a, b = F[:300], F[200:]
+    with pytest.raises(ValueError):
+        shard.stitch_plan([a[:64], b[:64]], [a[-64:], b[-64:]], [len(a), len(b)], 64)
+    e = shard.edge_frames(100 * 5000, 5000.0)
+    assert e >= 116
+    assert shard.stitch_plan([a[:e], b[:e]], [a[-e:], b[-e:]], [len(a), len(b)], e) == [0, 100]

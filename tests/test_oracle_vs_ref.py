@@ -244,3 +244,29 @@ def test_punctured_concat_decoder_port_equals_ref(ref, port, rate, const, sigma,
     ids = [i for i in util.frame_ids(a["cadu"], plain) if i >= 0]
     if not gap:  # ... and delivers the transmitted frames (behind a noise gap the reference keeps its stale puncture phase: BER*5 stays
         assert len(ids) >= 10  # under the threshold on noise, so what it delivers there is whatever it delivers -- parity only)
+
+
+
+@pytest.mark.parametrize("case", ["metop", "goes"])
+def test_threaded_pipeline_equals_the_sequential_entries(ref, case):
+    """sdref_pipeline_threaded (the reference's blocks on their own threads, the topology of pipeline_run.cpp:72-104 -- what bench.py
+    and the full-size GPU tests decode whole recordings with) produces the sequential entries' soft symbols and CADUs, up to the tail
+    its stop() drops at EOF."""
+    from tests import util
+    from satdump_amd import synth
+    if case == "metop":
+        spec, cadus, plain, syms = util.metop_case(nframes=120)
+        d = pyref.demod_cfg(samplerate=6e6, symbolrate=2333333, constellation=pyref.QPSK, rrc_alpha=0.5, pll_bw=0.003)
+        f = pyref.fec_cfg(viterbi_ber_thresold=0.28, viterbi_outsync_after=10)
+    else:
+        spec, cadus, plain, syms = util.goes_case(nframes=60)
+        d = pyref.demod_cfg(samplerate=3e6, symbolrate=927000, constellation=pyref.BPSK, pll_bw=0.02, max_sps=3.0)
+        f = pyref.fec_cfg(constellation=pyref.BPSK, nrzm=1, rs_usecheck=1)
+    x, _ = synth.modulate(syms, spec)
+    seq = ref.psk_demod(d, x, want_syms=False)["soft"]
+    seqc = (ref.metop_decode(seq, ber_thr=0.28, outsync_after=10) if case == "metop" else ref.concat_decode(f, seq))["cadu"]
+    th = ref.pipeline_threaded(d, f, 1 if case == "metop" else 0, x, keep_soft=True)
+    m = min(len(seq), len(th["soft"]))
+    assert m >= len(seq) - 2 * 8192 * 4 and np.array_equal(seq[:m], th["soft"][:m])
+    k = min(len(seqc), len(th["cadu"]))
+    assert k >= len(seqc) - 2 and k > 20 and np.array_equal(seqc[:k], th["cadu"][:k])
