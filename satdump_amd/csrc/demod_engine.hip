@@ -223,6 +223,72 @@ namespace sdhip
         }
         dm[k] = d_out;
     }
+    // Fused AGC + filter + Costas stage: one verdict per boundary = the AGC + filter rule (gain and the gain 32 samples earlier, bit-equal
+    // or within 1e-6) AND the Costas rule (bit-equal, or inside the windows on one of the loop's stable points: dm = the frame change).
+    __global__ void k_afc_verdict(int K, const AfcState *spec, const AfcState *endst, double rot_unit, int rot_mod, double tol_phase, double tol_freq, int *dm,
+                                  VerdictOut *vo, int *fails, int force)
+    {
+        const int k = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+        if (k >= K)
+            return;
+        int d_out = 0;
+        if (k >= 1)
+        {
+            const float ga = spec[k].af.gain, gb = endst[k - 1].af.gain, la = spec[k].af.lag[3], lb = endst[k - 1].af.lag[3];
+            const CostasState a = spec[k].cos, b = endst[k - 1].cos;
+            const bool agc_same = __float_as_uint(ga) == __float_as_uint(gb) && __float_as_uint(la) == __float_as_uint(lb);
+            const bool agc_ok = agc_same || (fabsf(ga - gb) <= 1e-6f * fabsf(gb) && fabsf(la - lb) <= 1e-6f * fabsf(lb));
+            const bool cos_same = __float_as_uint(a.phase) == __float_as_uint(b.phase) && __float_as_uint(a.freq) == __float_as_uint(b.freq);
+            bool ok = agc_ok;
+            if (ok && !cos_same)
+            {
+                const double dphi = (double)a.phase - (double)b.phase;
+                const long long d = llround(dphi / rot_unit);
+                const double resid = dphi - (double)d * rot_unit;
+                ok = fabs(resid) < tol_phase && fabs((double)a.freq - (double)b.freq) < tol_freq;
+                if (ok)
+                {
+                    d_out = (int)(((d % rot_mod) + rot_mod) % rot_mod);
+                    if (d_out != 0)
+                        atomicAdd(&vo->rotated, 1);
+                }
+            }
+            if (!ok)
+                verdict_fail(vo, fails, k, force); // re-run continues in the previous chunk's frame: dm = 0
+            else if (!(agc_same && cos_same))
+                atomicAdd(&vo->inexact, 1);
+        }
+        dm[k] = d_out;
+    }
+    // start state of a re-run lane: the predecessor's exact end state; with checkpoints its carrier phase is expressed in the frame the
+    // chunk's earlier run locked on (see k_costas_spec_aligned), so that the re-run can merge with that run's checkpoints
+    __global__ void k_afc_spec_fix(const int *list, int n, AfcState *spec, const AfcState *endst, double rot_unit, int align)
+    {
+        const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+        if (i >= n)
+            return;
+        const int k = list[i];
+        AfcState ns = endst[k - 1];
+        if (align)
+        {
+            const CostasState a = spec[k].cos, b = ns.cos;
+            const long long d = llround(((double)a.phase - (double)b.phase) / rot_unit);
+            double ph = (double)b.phase + (double)d * rot_unit;
+            const double twopi = 2 * 3.14159265358979323846;
+            while (ph > twopi)
+                ph -= twopi;
+            while (ph < -twopi)
+                ph += twopi;
+            ns.cos.phase = (float)ph;
+        }
+        spec[k] = ns;
+    }
+    __global__ void k_afc_gather_freq(int K, const AfcState *endst, float *out)
+    {
+        const int k = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+        if (k < K)
+            out[k] = endst[k].cos.freq;
+    }
     // symbol hand-off at an M&M boundary (see DemodEngine::process): skip[k] symbols dropped at the head of chunk k, extra[k-1]
     // look-ahead symbols of chunk k-1 appended
     __global__ void k_mm_verdict(int K, const MmCert *spec, const MmCert *endst, const int *counts, double tol, double tol_tight, int *skip, int *extra,
@@ -398,6 +464,11 @@ namespace sdhip
         bool fuse_agc_fir = false;
         AgcFirParams af_p{};
         DevBuf<AgcFirState> d_af_spec, d_af_end, d_af_start;
+        // ... and the Costas loop on the same lanes (k_afc): SDHIP_FUSE_COSTAS=0 keeps it a stage of its own (A/B switch)
+        bool fuse_afc = false;
+        DevBuf<AfcState> d_afc_spec, d_afc_end, d_afc_start;
+        DevBuf<AfcCkpt> d_afc_ck;
+        DevBuf<float> d_afc_freq, d_fe_tmp;
         // has_carrier: carrier-tracking PLL + its DC block between the RRC filter and the Costas loop
         PllParams cpll_p{};
         CostasState cpll_s{0.0f, 0.0f};
@@ -580,6 +651,15 @@ namespace sdhip
                     l = 1.0f;
                 d_af_start.reserve(1);
                 SD_HIP(hipMemcpy(d_af_start.p, &s0, sizeof(s0), hipMemcpyHostToDevice));
+                fuse_afc = !cfg.has_carrier && env_int("SDHIP_FUSE_COSTAS", 1) != 0;
+                if (fuse_afc)
+                {
+                    AfcState a0{};
+                    a0.af = s0;
+                    a0.cos = CostasState{0.0f, 0.0f};
+                    d_afc_start.reserve(1);
+                    SD_HIP(hipMemcpy(d_afc_start.p, &a0, sizeof(a0), hipMemcpyHostToDevice));
+                }
             }
             // carrier-tracking PLL (module_psk_demod.cpp:93-113, pll_carrier_tracking.cpp:8-21)
             if (cfg.has_carrier)
@@ -902,6 +982,173 @@ namespace sdhip
             SD_HIP(hipStreamSynchronize(stream));
         }
 
+        // AGC + RRC filter + Costas loop as ONE speculative lane stage (k_afc), in -> out (the Costas output in per-chunk frames; cg =
+        // its chunk geometry, d_rot the frames, as the clock recovery expects them from the stand-alone Costas stage).
+        // Warm-up of a lane = the AGC's (24 gain / rate samples, AGC alone) followed by the Costas loop's (24 loop time constants, all
+        // three stages); boundary certificate = both stages' rules (k_afc_verdict); re-runs start from the exact predecessor state and
+        // stop at the first checkpoint at which they are back on the speculative run's trajectory.
+        void afc_chunked(const cf32 *in, cf32 *out, long long n, ChunkGeom &cg)
+        {
+            // ---- AGC part of the warm-up (see the stand-alone AGC stage below for the reasoning)
+            float g_est = agc_s.gain;
+            if (!started)
+            {
+                const long long m = std::min<long long>(n, 1 << 16);
+                ProfScope _ps("k_mean_abs", stream);
+                hipLaunchKernelGGL(k_mean_abs, dim3(64), dim3(256), 0, stream, in, m, d_partial.p);
+                double part[64];
+                SD_HIP(hipMemcpyAsync(part, d_partial.p, sizeof(part), hipMemcpyDeviceToHost, stream));
+                SD_HIP(hipStreamSynchronize(stream));
+                double sm = 0;
+                for (double v : part)
+                    sm += v;
+                const double mean = sm / (double)m;
+                if (mean > 1e-12)
+                    g_est = (float)std::min(65536.0, 1.0 / mean);
+            }
+            const double tau = std::max(1.0f, g_est) / std::max(1e-6f, cfg.agc_rate);
+            long long Wa = cfg.warmup > 0 ? cfg.warmup : (long long)(24.0 * tau);
+            Wa = env_int("SDHIP_W_AGC", Wa);
+            Wa = std::min<long long>(std::max<long long>(Wa, 1024), 1 << 22);
+            Wa = (Wa + 255) / 256 * 256;
+            agc_p.init_gain = g_est;
+            af_p.agc = agc_p;
+            // ---- start frequency of the carrier loop's warm-ups: this stream's tracked frequency; on the very first call the M-th power
+            // estimate (k_freq_est) over the first samples, which the stage's input must be filtered for: a plain FIR pass over that prefix
+            if (!started)
+            {
+                const int classic = order > 4 ? 1 : 0;
+                const long long m = std::min<long long>(n - 64, classic ? 1 << 18 : 1 << 20);
+                cos_p.init_freq = 0.0f;
+                if (m > 4096)
+                {
+                    d_fe_tmp.reserve(2 * (size_t)m + 64);
+                    cf32 *tmp = reinterpret_cast<cf32 *>(d_fe_tmp.p);
+                    launch_fir(in + 64, tmp, m, d_rrc.p, rrc_ntaps, stream); // window [64 - 30, ...) lies inside the call's samples
+                    const int lag = (int)std::min(16.0, std::max(2.0, std::floor(2.0 * final_sps + 0.5)));
+                    ProfScope _ps("k_freq_est", stream);
+                    hipLaunchKernelGGL(k_freq_est, dim3(64), dim3(256), 0, stream, tmp, m, order, lag, classic, d_partial.p);
+                    double part[256];
+                    SD_HIP(hipMemcpyAsync(part, d_partial.p, sizeof(part), hipMemcpyDeviceToHost, stream));
+                    SD_HIP(hipStreamSynchronize(stream));
+                    double sr = 0, si = 0, lr = 0, li = 0;
+                    for (int i = 0; i < 64; i++)
+                    {
+                        sr += part[4 * i];
+                        si += part[4 * i + 1];
+                        lr += part[4 * i + 2];
+                        li += part[4 * i + 3];
+                    }
+                    const double coarse = std::atan2(si, sr) / order;
+                    double fine = coarse;
+                    if (!classic && m > 4 * lag && (lr != 0 || li != 0))
+                    {
+                        const double step = 2.0 * design::PI / ((double)order * lag);
+                        const double base = std::atan2(li, lr) / ((double)order * lag);
+                        fine = base + step * std::floor((coarse - base) / step + 0.5);
+                    }
+                    if (getenv("SDHIP_DEBUG"))
+                        fprintf(stderr, "[sdhip] costas start frequency: lag-1 %.6f, lag-%d %.6f rad/sample (%lld samples)\n", coarse, lag, fine, m);
+                    cos_p.init_freq = std::min(std::max((float)fine, cos_p.fmin), cos_p.fmax);
+                }
+            }
+            else
+                cos_p.init_freq = cos_s.freq;
+            const long long w_cos_cap = 1 << 20;
+            const double taus = (double)env_int("SDHIP_COSTAS_TAUS", 24);
+            long long W = cfg.warmup > 0 ? cfg.warmup : (long long)std::max(512.0, taus / (1.414 * std::max(1e-5f, cfg.pll_bw)));
+            W = std::max(W, w_cos_learned);
+            W = env_int("SDHIP_W_COSTAS", W);
+            W = (std::min<long long>(W, w_cos_cap) + 255) / 256 * 256;
+            const long long lanes = std::max<long long>(64, env_int("SDHIP_LANES_AFC", 65280));
+            int L = pick_L(n, ST_COSTAS);
+            if (!cfg.exact && cfg.chunk_len <= 0 && !getenv("SDHIP_CHUNK") && !getenv("SDHIP_CHUNK_COSTAS") && !getenv("SDHIP_LANES_COSTAS"))
+                L = (int)std::min<long long>(std::max<long long>(((n + lanes - 1) / lanes + 63) / 64 * 64, 2048), 1 << 20);
+            L = (int)(((long long)L + 63) / 64 * 64); // chunk starts on whole load groups (the lane finds its chunk start on a group boundary)
+            const double tol_phase = env_int("SDHIP_COSTAS_TOL_URAD", 10000) * 1e-6, tol_freq = env_int("SDHIP_COSTAS_TOL_NFREQ", 40000) * 1e-9;
+            AfcParams ap;
+            AfcCkptCfg ck;
+            auto setup = [&](long long Wn) {
+                cos_p.est_len = (int)(std::min<long long>(env_int("SDHIP_COSTAS_EST", 256), Wn / 2) / 32 * 32);
+                cg = make_geom(n, L, (int)Wn);
+                ap.af = af_p;
+                ap.cos = cos_p;
+                ap.w_agc = (int)Wa;
+                d_afc_spec.reserve(cg.K);
+                d_afc_end.reserve(cg.K);
+                ck.len = 2048;
+                ck.tol_phase = (float)tol_phase;
+                ck.tol_freq = (float)tol_freq;
+                if (use_ckpt && !cfg.exact)
+                {
+                    ck.per_chunk = L / ck.len + 1;
+                    d_afc_ck.reserve((size_t)cg.K * ck.per_chunk);
+                    ck.ck = d_afc_ck.p;
+                }
+                d_rot.reserve(cg.K);
+                d_dm.reserve(cg.K);
+            };
+            setup(W);
+            // the carried start state lives on the device (filter window); its carrier part is the host's copy (kept in the stream's frame)
+            SD_HIP(hipMemcpyAsync(&d_afc_start.p->cos, &cos_s, sizeof(cos_s), hipMemcpyHostToDevice, stream));
+            launch_afc(in, out, cg, ap, d_afc_start.p, d_afc_spec.p, d_afc_end.p, nullptr, 0, stream, ck);
+            verify_fix(
+                "afc", cg.K,
+                [&](VerdictOut *vo, int *fails, int force) {
+                    hipLaunchKernelGGL(k_afc_verdict, dim3((cg.K + 255) / 256), dim3(256), 0, stream, cg.K, d_afc_spec.p, d_afc_end.p, rot_unit, rot_mod, tol_phase, tol_freq,
+                                       d_dm.p, vo, fails, force);
+                },
+                [&](const int *list, int nr) {
+                    hipLaunchKernelGGL(k_afc_spec_fix, dim3((nr + 255) / 256), dim3(256), 0, stream, list, nr, d_afc_spec.p, d_afc_end.p, rot_unit, use_ckpt ? 1 : 0);
+                },
+                [&](const int *redo, int nr) { launch_afc(in, out, cg, ap, d_afc_start.p, d_afc_spec.p, d_afc_end.p, redo, nr, stream, ck); },
+                [&](int) {
+                    // many warm-ups missed: start frequency off (take the median of the lanes' end frequencies) or warm-up too short for
+                    // this signal's loop dynamics (double it; the stream keeps the longer one) -- see the stand-alone Costas stage
+                    std::vector<float> fr((size_t)cg.K);
+                    d_afc_freq.reserve(cg.K);
+                    hipLaunchKernelGGL(k_afc_gather_freq, dim3((cg.K + 255) / 256), dim3(256), 0, stream, cg.K, d_afc_end.p, d_afc_freq.p);
+                    SD_HIP(hipMemcpyAsync(fr.data(), d_afc_freq.p, fr.size() * sizeof(float), hipMemcpyDeviceToHost, stream));
+                    SD_HIP(hipStreamSynchronize(stream));
+                    std::nth_element(fr.begin(), fr.begin() + fr.size() / 2, fr.end());
+                    const float med = fr[fr.size() / 2];
+                    if (std::fabs(med - cos_p.init_freq) > 0.05f * cfg.pll_bw)
+                        cos_p.init_freq = med;
+                    else if (cfg.warmup <= 0 && !getenv("SDHIP_W_COSTAS") && 2 * (long long)cg.W <= w_cos_cap)
+                        w_cos_learned = 2 * (long long)cg.W;
+                    else
+                        return false;
+                    setup(std::max<long long>(cg.W, w_cos_learned));
+                    launch_afc(in, out, cg, ap, d_afc_start.p, d_afc_spec.p, d_afc_end.p, nullptr, 0, stream, ck);
+                    return true;
+                });
+            stats.chunks += 2 * (unsigned)cg.K; // the chunks of two loop stages
+            {
+                const int nt = (cg.K + 1023) / 1024;
+                d_tile_sums.reserve(nt);
+                hipLaunchKernelGGL(k_chunk_scan_sums, dim3(nt), dim3(1024), 0, stream, cg.K, 0, d_dm.p, nullptr, nullptr, nullptr, 0, d_tile_sums.p, nullptr);
+                hipLaunchKernelGGL(k_chunk_scan_apply, dim3(nt), dim3(1024), 0, stream, cg.K, 0, d_dm.p, rot_mod, d_rot.p, nullptr, nullptr, nullptr, d_tile_sums.p,
+                                   nullptr, nullptr, nullptr);
+            }
+            int rot_last = 0;
+            SD_HIP(hipMemcpyAsync(d_afc_start.p, d_afc_end.p + (cg.K - 1), sizeof(AfcState), hipMemcpyDeviceToDevice, stream));
+            SD_HIP(hipMemcpyAsync(&agc_s, &d_afc_end.p[cg.K - 1].af.gain, sizeof(agc_s), hipMemcpyDeviceToHost, stream));
+            SD_HIP(hipMemcpyAsync(&cos_s, &d_afc_end.p[cg.K - 1].cos, sizeof(cos_s), hipMemcpyDeviceToHost, stream));
+            SD_HIP(hipMemcpyAsync(&rot_last, d_rot.p + (cg.K - 1), sizeof(int), hipMemcpyDeviceToHost, stream));
+            SD_HIP(hipStreamSynchronize(stream));
+            // carry the loop state re-expressed in the stream's frame (rot 0), so that the next call starts unrotated
+            if (rot_last != 0)
+            {
+                double ph = (double)cos_s.phase - rot_last * rot_unit;
+                while (ph > 2 * design::PI)
+                    ph -= 2 * design::PI;
+                while (ph < -2 * design::PI)
+                    ph += 2 * design::PI;
+                cos_s.phase = (float)ph;
+            }
+            stats.freq_hz = (float)(((double)cos_s.freq / (2.0 * design::PI)) * (double)final_samplerate);
+        }
+
         // Process n input samples resident on the device. Outputs go to d_soft / d_syms (device).
         int64_t process(const void *d_in, size_t n_in, int fmt, int8_t *d_soft, size_t soft_cap, float *d_syms, size_t syms_cap)
         {
@@ -1011,7 +1258,16 @@ namespace sdhip
             }
             tick("resample");
 
+            ChunkGeom cg;
+            if (fuse_afc)
+            {
+                const cf32 *AIN = (in_place && !resample) ? SRC : A; // the lanes never load outside [chunk begin - warm-up, chunk end)
+                afc_chunked(AIN, B, n, cg);
+                std::swap(A, B);
+                tick("agc+fir+costas");
+            }
             // ---- AGC (speculative)
+            if (!fuse_afc)
             {
                 const cf32 *AIN = (in_place && !resample) ? SRC : A; // k_chunks never loads outside [chunk begin - W, chunk end)
                 // warm-up length ~ 24 time constants of the loop (tau = gain / rate samples), gain estimated from mean |x|
@@ -1133,7 +1389,7 @@ namespace sdhip
                 tick("carrier");
             }
             // ---- Costas (speculative, symmetry-corrected)
-            ChunkGeom cg;
+            if (!fuse_afc)
             {
                 if (!started)
                 {

@@ -135,6 +135,37 @@ namespace sdhip
     void launch_costas(const cf32 *x, cf32 *y, const ChunkGeom &g, const CostasParams &p, const CostasState *start0, CostasState *spec, CostasState *endst,
                        const int *redo, int nredo, hipStream_t st, const ChunkCkpt &ck = ChunkCkpt());
 
+    // ---- AGC + RRC filter + Costas loop as ONE lane-per-chunk stage (see k_afc) -----------------------------------------------------
+    // The lane that produces the filtered samples of a chunk also runs the carrier loop over them: the filter output never goes to
+    // memory (16 B per sample of HBM traffic less), and the loop's dependent chain (sincos in double, ~30 operations deep per sample)
+    // runs interleaved with the filter's independent multiply-adds of the following blocks instead of alone on its SIMD.
+    // Chunk geometry = the Costas stage's (g.W = the Costas warm-up): the clock recovery behind it keeps indexing rot[] by it. A lane
+    // starts w_agc + g.W samples in front of its chunk: AGC alone over the first w_agc samples (its window fills on the way), then AGC
+    // + filter + a feed-forward start-phase estimate over est_len samples, then all three stages without stores up to the chunk start.
+    struct AfcParams
+    {
+        AgcFirParams af;
+        CostasParams cos;
+        int w_agc; // samples of AGC-only warm-up in front of the Costas warm-up (multiple of 64)
+    };
+    struct AfcState
+    {
+        AgcFirState af;
+        CostasState cos;
+    };
+    struct AfcCkpt // what a re-run lane compares itself with (AgcFirStage's and CostasStage's own early-exit rules)
+    {
+        float gain, lag3, phase, freq;
+    };
+    struct AfcCkptCfg
+    {
+        AfcCkpt *ck = nullptr;
+        int per_chunk = 0, len = 0;
+        float tol_phase = 0, tol_freq = 0;
+    };
+    void launch_afc(const cf32 *x, cf32 *y, const ChunkGeom &g, const AfcParams &p, const AfcState *start0, AfcState *spec, AfcState *endst, const int *redo,
+                    int nredo, hipStream_t st, const AfcCkptCfg &ck);
+
     // ---- carrier-tracking PLL (has_carrier, pll_carrier_tracking.cpp:23-66): same state layout and chunk scheme as the Costas loop,
     // one stable point per turn (no frame ambiguity)
     struct PllParams

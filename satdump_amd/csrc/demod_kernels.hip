@@ -800,8 +800,9 @@ namespace sdhip
 #pragma unroll
                 for (int j = 0; j < NT; j++)
                 {
-                    const float tv = sd_to_vgpr(p.taps[j]);
-                    const v2f tt{tv, tv};
+                    // two taps share one 64-bit register pair; the packed multiply takes either half for both of its lanes (op_sel)
+                    const v2f tp{sd_to_vgpr(p.taps[j & ~1]), sd_to_vgpr(p.taps[j | 1])};
+                    const v2f tt = (j & 1) ? __builtin_shufflevector(tp, tp, 1, 1) : __builtin_shufflevector(tp, tp, 0, 0);
                     v2f prod[8]; // the eight products first, then the eight sums: independent neighbours for the VALU pipeline
 #pragma unroll
                     for (int r = 0; r < 8; r++)
@@ -1176,6 +1177,71 @@ namespace sdhip
         }
     }
 
+    // Variant for stages whose block is large and register-hungry (the fused AGC + filter + Costas block: ~1600 instructions, a 38-sample
+    // window and 31 taps in registers). run_range keeps two statically named register queues and with them two copies of a four-block
+    // group -- ~100 KB of loop, more than the 64 KB instruction cache two CUs share, and 128 registers of queue. Here: ONE group body and
+    // ONE four-block queue that is refilled in halves -- slots 0,1 (the next group's first 128 bytes) as soon as block 1 has been consumed,
+    // slots 2,3 after block 3 -- so a load has two to three blocks of compute (~3 us) to land; every block's output is stored as soon as
+    // it exists. Output is stored from sample index `write_from` on (a whole number of groups away from i0): warm-up and chunk are one
+    // loop. hook: as run_range's.
+    template <class Stage>
+    __device__ __forceinline__ void blk_store(cf32 *y, long long i, const Blk8 &o)
+    {
+        float4 *yp = reinterpret_cast<float4 *>(y + i);
+        yp[0] = o.a;
+        yp[1] = o.b;
+        yp[2] = o.c;
+        yp[3] = o.d;
+    }
+    template <class Stage, class Hook>
+    __device__ __forceinline__ void run_range1(typename Stage::S &s, const typename Stage::P &p, const cf32 *x, cf32 *y, long long i0, long long i1,
+                                               long long write_from, long long hb, int hstep, Hook hook)
+    {
+        static_assert(Stage::DEPTH == 4, "four-block groups");
+        long long i = i0;
+        for (; i < i1 && (i & 7); i++)
+        {
+            const cf32 o = Stage::step(s, p, x[i]);
+            if (i >= write_from)
+                y[i] = o;
+        }
+        if (i + 32 <= i1)
+        {
+            Blk8 q[4];
+#pragma unroll
+            for (int d = 0; d < 4; d++)
+                q[d] = blk_load(x, i + 8 * d);
+            for (;;)
+            {
+                const bool more = i + 64 <= i1;
+                const bool wr = i >= write_from;
+#pragma unroll
+                for (int d = 0; d < 4; d++)
+                {
+                    const Blk8 o = blk_step<Stage>(s, p, q[d], wr);
+                    if (wr)
+                        blk_store<Stage>(y, i + 8 * d, o);
+                    if ((d & 1) && more)
+                    {
+                        q[d - 1] = blk_load(x, i + 32 + 8 * (d - 1));
+                        q[d] = blk_load(x, i + 32 + 8 * d);
+                    }
+                }
+                i += 32;
+                if ((((i - hb) & (long long)(hstep - 1)) == 0) && i < i1 && hook(i))
+                    return;
+                if (!more)
+                    break;
+            }
+        }
+        for (; i < i1; i++)
+        {
+            const cf32 o = Stage::step(s, p, x[i]);
+            if (i >= write_from)
+                y[i] = o;
+        }
+    }
+
     // CKPT: every ck_len samples of its chunk a lane leaves its state in ck[k][*]. A re-run lane compares itself with the
     // checkpoint at the same sample index and stops as soon as Stage::close() holds: from there on the output and the end state
     // of the earlier run stand, under the rule that accepts a chunk boundary. A lane that does not merge overwrites the
@@ -1249,6 +1315,212 @@ namespace sdhip
                 atomicAdd(ck_work + 2, (unsigned long long)((e - b + ck_len - 1) / ck_len));
             }
         }
+    }
+
+    // =============================================================================================
+    // AGC + RRC filter + Costas loop in one lane (demod_kernels.h: AfcParams). Three views of the same lane state for run_range:
+    //   AfcAgcOnly : AGC recurrence, the filter window filled on the way, nothing else (first part of a warm-up)
+    //   AfcEst<M>  : AGC + filter, the filtered samples raised to the M-th power and summed against the start frequency
+    //                (CostasStage::prewarm's estimate, taken on the fly: the filtered samples exist nowhere in memory)
+    //   AfcFull<O> : AGC + filter + Costas
+    // Arithmetic per stage = AgcFirStage / CostasStage, operation for operation (exact mode: bit for bit the reference).
+    // =============================================================================================
+    struct AfcAgcOnly
+    {
+        using P = AfcParams;
+        using S = AfcState;
+        static constexpr int DEPTH = 4;
+        __device__ static __forceinline__ Blk8 block(S &s, const P &p, const Blk8 &c, bool) { return AgcFirStage::block(s.af, p.af, c, false); }
+        __device__ static __forceinline__ cf32 step(S &s, const P &p, const cf32 v) { return AgcFirStage::step(s.af, p.af, v); }
+    };
+    struct AfcEstState
+    {
+        AfcState s;
+        float cr, ci, ar, ai, rc, rs; // exp(-j M f n) by recurrence, the running sum, the recurrence's step
+    };
+    template <int M>
+    struct AfcEst
+    {
+        using P = AfcParams;
+        using S = AfcEstState;
+        static constexpr int DEPTH = 4;
+        __device__ static __forceinline__ void acc(S &e, float re, float im)
+        {
+            float zr = re * re - im * im, zi = 2.0f * re * im; // x^2
+            if constexpr (M == 4)
+            {
+                const float tr = zr * zr - zi * zi, ti = 2.0f * zr * zi;
+                zr = tr;
+                zi = ti;
+            }
+            e.ar += zr * e.cr - zi * e.ci;
+            e.ai += zr * e.ci + zi * e.cr;
+            const float nr = e.cr * e.rc - e.ci * e.rs, ni = e.cr * e.rs + e.ci * e.rc;
+            e.cr = nr;
+            e.ci = ni;
+        }
+        __device__ static __forceinline__ Blk8 block(S &e, const P &p, const Blk8 &c, bool)
+        {
+            const Blk8 f = AgcFirStage::block(e.s.af, p.af, c, true);
+            acc(e, f.a.x, f.a.y);
+            acc(e, f.a.z, f.a.w);
+            acc(e, f.b.x, f.b.y);
+            acc(e, f.b.z, f.b.w);
+            acc(e, f.c.x, f.c.y);
+            acc(e, f.c.z, f.c.w);
+            acc(e, f.d.x, f.d.y);
+            acc(e, f.d.z, f.d.w);
+            return f;
+        }
+        __device__ static __forceinline__ cf32 step(S &e, const P &p, const cf32 v)
+        {
+            const cf32 f = AgcFirStage::step(e.s.af, p.af, v);
+            acc(e, f.re, f.im);
+            return f;
+        }
+    };
+    template <int ORDER>
+    struct AfcFull
+    {
+        using P = AfcParams;
+        using S = AfcState;
+        using Cos = CostasStage<ORDER, 4>;
+        static constexpr int DEPTH = 4;
+        __device__ static __forceinline__ Blk8 block(S &s, const P &p, const Blk8 &c, bool)
+        {
+            const Blk8 f = AgcFirStage::block(s.af, p.af, c, true);
+            const cf32 a0 = Cos::step(s.cos, p.cos, cf32{f.a.x, f.a.y});
+            const cf32 a1 = Cos::step(s.cos, p.cos, cf32{f.a.z, f.a.w});
+            const cf32 a2 = Cos::step(s.cos, p.cos, cf32{f.b.x, f.b.y});
+            const cf32 a3 = Cos::step(s.cos, p.cos, cf32{f.b.z, f.b.w});
+            const cf32 a4 = Cos::step(s.cos, p.cos, cf32{f.c.x, f.c.y});
+            const cf32 a5 = Cos::step(s.cos, p.cos, cf32{f.c.z, f.c.w});
+            const cf32 a6 = Cos::step(s.cos, p.cos, cf32{f.d.x, f.d.y});
+            const cf32 a7 = Cos::step(s.cos, p.cos, cf32{f.d.z, f.d.w});
+            return Blk8{make_float4(a0.re, a0.im, a1.re, a1.im), make_float4(a2.re, a2.im, a3.re, a3.im), make_float4(a4.re, a4.im, a5.re, a5.im),
+                        make_float4(a6.re, a6.im, a7.re, a7.im)};
+        }
+        __device__ static __forceinline__ cf32 step(S &s, const P &p, const cf32 v) { return Cos::step(s.cos, p.cos, AgcFirStage::step(s.af, p.af, v)); }
+    };
+    __device__ __forceinline__ float sd_wrap_2pi(double ph)
+    { // into the loop's own range [-2 pi, 2 pi] (costas_loop.cpp:55-58 keeps it there)
+        const double twopi = 2 * 3.14159265358979323846;
+        while (ph > twopi)
+            ph -= twopi;
+        while (ph < -twopi)
+            ph += twopi;
+        return (float)ph;
+    }
+    // Checkpoints (ck != nullptr): every ck_len samples of its chunk a lane leaves {gain, gain 32 samples ago, phase, freq}; a re-run lane
+    // (exact start state) stops at the first checkpoint at which its AGC has merged with the earlier run's (the AGC certificate's rule)
+    // and its carrier loop is inside the Costas windows in the earlier run's frame: from there on the earlier output and end state stand.
+    // Warm-up tail and chunk are ONE loop over AfcFull (stores begin at the chunk start, where the state is also left in spec[k]).
+    template <int ORDER>
+    __global__ __launch_bounds__(64) void k_afc(const cf32 *x, cf32 *y, ChunkGeom g, AfcParams p, const AfcState *start0, AfcState *spec, AfcState *endst,
+                                                const int *redo, int nredo, AfcCkpt *ck, int ck_per_chunk, int ck_len, float tol_phase, float tol_freq)
+    {
+        const int idx = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+        int k;
+        AfcState s;
+        bool leave_spec = false;
+        long long i0;
+        if (redo)
+        {
+            if (idx >= nredo)
+                return;
+            k = redo[idx];
+            s = spec[k]; // the engine put the exact boundary state here before this launch (see k_chunks)
+            i0 = chunk_begin(g, k);
+        }
+        else
+        {
+            k = idx;
+            if (k >= g.K)
+                return;
+            i0 = 0;
+            s = *start0; // chunk 0, and chunks whose warm-up would reach in front of the call: from the stream's true state
+            const long long b = chunk_begin(g, k);
+            const long long w0 = b - g.W - p.w_agc;
+            if (k > 0)
+                leave_spec = true;
+            if (k > 0 && w0 > 0)
+            {
+                const auto nohook = [](long long) { return false; };
+                const long long never = 1ll << 62;
+                s.af = AgcFirStage::init(p.af, k);
+                s.cos = CostasState{0.0f, p.cos.init_freq};
+                run_range1<AfcAgcOnly>(s, p, x, y, w0, b - g.W, never, 0, 1 << 30, nohook);
+                i0 = b - g.W;
+                if (p.cos.est_len > 0 && ORDER <= 4)
+                {
+                    constexpr int M = ORDER <= 2 ? 2 : 4;
+                    AfcEstState e;
+                    e.s = s;
+                    __sincosf(-(float)M * s.cos.freq, &e.rs, &e.rc);
+                    e.cr = 1.0f;
+                    e.ci = 0.0f;
+                    e.ar = 0.0f;
+                    e.ai = 0.0f;
+                    run_range1<AfcEst<M>>(e, p, x, y, i0, i0 + p.cos.est_len, never, 0, 1 << 30, nohook);
+                    s = e.s;
+                    // BPSK symbols sit on the real axis (x^2 -> +1), QPSK symbols on the diagonals (x^4 -> -1); the sum's angle is M
+                    // times the carrier phase at the first sample of the window, the loop takes over est_len samples later
+                    const float ang = (M == 4) ? atan2f(-e.ai, -e.ar) : atan2f(e.ai, e.ar);
+                    s.cos.phase = sd_wrap_2pi((double)(ang / (float)M) + (double)s.cos.freq * (double)p.cos.est_len);
+                    i0 += p.cos.est_len;
+                }
+            }
+        }
+        const long long b = chunk_begin(g, k), e = chunk_end(g, k);
+        bool merged = false;
+        AfcCkpt *cks = ck ? ck + (size_t)k * ck_per_chunk : nullptr;
+        run_range1<AfcFull<ORDER>>(s, p, x, y, i0, e, b, b, ck_len, [&](long long i) -> bool {
+            if (i < b)
+                return false;
+            if (i == b)
+            {
+                if (leave_spec)
+                    spec[k] = s;
+                return false;
+            }
+            const int j = (int)((i - b) / ck_len) - 1;
+            if (!cks || j >= ck_per_chunk)
+                return false;
+            if (redo)
+            {
+                const AfcCkpt o = cks[j];
+                if (__float_as_uint(o.gain) == __float_as_uint(s.af.gain) && __float_as_uint(o.lag3) == __float_as_uint(s.af.lag[3]) &&
+                    CostasStage<ORDER, 4>::close(s.cos, CostasState{o.phase, o.freq}, tol_phase, tol_freq))
+                {
+                    merged = true;
+                    return true;
+                }
+            }
+            cks[j] = AfcCkpt{s.af.gain, s.af.lag[3], s.cos.phase, s.cos.freq};
+            return false;
+        });
+        if (!merged)
+            endst[k] = s;
+    }
+    void launch_afc(const cf32 *x, cf32 *y, const ChunkGeom &g, const AfcParams &p, const AfcState *start0, AfcState *spec, AfcState *endst, const int *redo,
+                    int nredo, hipStream_t st, const AfcCkptCfg &ck)
+    {
+        const int n = redo ? nredo : g.K;
+        if (n <= 0)
+            return;
+        ProfScope _ps("k_afc", st);
+        auto go = [&](auto order) {
+            constexpr int O = decltype(order)::value;
+            // ck_len is also the spacing at which the lane looks for the chunk start (spec snapshot): always a power of two >= 32
+            hipLaunchKernelGGL((k_afc<O>), dim3((n + 63) / 64), dim3(64), 0, st, x, y, g, p, start0, spec, endst, redo, nredo, ck.ck, ck.per_chunk,
+                               ck.len > 0 ? ck.len : 2048, ck.tol_phase, ck.tol_freq);
+        };
+        if (p.cos.order == 2)
+            go(std::integral_constant<int, 2>{});
+        else if (p.cos.order == 4)
+            go(std::integral_constant<int, 4>{});
+        else
+            go(std::integral_constant<int, 8>{});
     }
 
     // B_k = sum over the chunk of beta^(len-1-i) * alpha * x_i, in double: thread t takes the samples i = t (mod 256) -- coalesced --
