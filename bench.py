@@ -78,6 +78,7 @@ def algorithmic_bytes(wl, n_in, n_rs, nsym, nsoft, cadu_bytes_out, in_bytes_per_
         "k_fir": n_rs * 16,
         "k_fir_window": n_rs * 16,
         "k_chunks<CostasStage>": n_rs * 16,
+        "k_afc": n_rs * 16,  # AGC + RRC filter + Costas loop in one pass: neither the AGC nor the filtered samples reach memory
         "k_mm": n_rs * 8 + nsym * 8,
         "k_quantize": nsym * (8 + q),
         "k_compact8": nsym * (2 + q),

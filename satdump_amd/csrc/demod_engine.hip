@@ -1055,12 +1055,17 @@ namespace sdhip
             else
                 cos_p.init_freq = cos_s.freq;
             const long long w_cos_cap = 1 << 20;
-            const double taus = (double)env_int("SDHIP_COSTAS_TAUS", 24);
+            // 16 loop time constants: the lane starts next to a stable point (feed-forward phase estimate over est_len samples) at the
+            // stream's own frequency, so it is at the float floor of two trajectories well before the 24 the stand-alone stage allows
+            // (measured, MetOp 17 GB, profiles/r03_a_ab_metop.txt: soft parity 0.99617 at 16 against 0.99612 at 24; 0.99591 at 12)
+            const double taus = (double)env_int("SDHIP_COSTAS_TAUS", 16);
             long long W = cfg.warmup > 0 ? cfg.warmup : (long long)std::max(512.0, taus / (1.414 * std::max(1e-5f, cfg.pll_bw)));
             W = std::max(W, w_cos_learned);
             W = env_int("SDHIP_W_COSTAS", W);
             W = (std::min<long long>(W, w_cos_cap) + 255) / 256 * 256;
-            const long long lanes = std::max<long long>(64, env_int("SDHIP_LANES_AFC", 65280));
+            // two waves per SIMD: the stage is bound by its dependent chains (AGC sqrt, sincos in double), not by its loads -- measured
+            // (MetOp, profiles/r03_a_ab_metop.txt): 26.4 ms with 65 280 lanes, 21.3 with 98 304, 19.5 with 130 560 (226 VGPRs: two waves fit)
+            const long long lanes = std::max<long long>(64, env_int("SDHIP_LANES_AFC", 130560));
             int L = pick_L(n, ST_COSTAS);
             if (!cfg.exact && cfg.chunk_len <= 0 && !getenv("SDHIP_CHUNK") && !getenv("SDHIP_CHUNK_COSTAS") && !getenv("SDHIP_LANES_COSTAS"))
                 L = (int)std::min<long long>(std::max<long long>(((n + lanes - 1) / lanes + 63) / 64 * 64, 2048), 1 << 20);

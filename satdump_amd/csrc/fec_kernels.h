@@ -58,7 +58,10 @@ namespace sdhip
     // A block whose certificate fails comes back with io[j].tb_fallback == 2 and must be decoded again with
     // launch_vit_decode(start_in = io[j].start_used).
     constexpr int VIT2_SEG = 512;   // trellis steps per lane
-    constexpr int VIT2_WARM = 200;  // warm-up steps (multiple of 8)
+#ifndef SDHIP_VIT2_WARM
+#define SDHIP_VIT2_WARM 200
+#endif
+    constexpr int VIT2_WARM = SDHIP_VIT2_WARM;  // warm-up steps (multiple of 8)
     struct Vit2Work
     {
         DevBuf<uint16_t> symu;      // per block: [VIT2_WARM prologue | F+6 steps | pad] unsigned symbol pairs (s0 | s1 << 8)

@@ -34,7 +34,7 @@ def build(force: bool = False) -> str:
         open(dst, "w").write(src)
         gen.append(dst)
     cmd = [CLANG, "-x", "c++", "-std=c++17", "-O1", "-g", "-ffp-contract=off", "-fPIC", "-shared", "-Wno-unknown-attributes", "-D__HIPCC__", "-DSDHIP_HOST_TWIN", "-Wno-unused-value",
-           "-I", HERE, "-I", CSRC, "-I", os.path.join(ROOT, "include"), "-o", LIB] + gen + [os.path.join(HERE, "emu_runtime.cpp"), "-lm"]
+           "-I", HERE, "-I", CSRC, "-I", os.path.join(ROOT, "include"), "-o", LIB] + os.environ.get("EMU_DEFS", "").split() + gen + [os.path.join(HERE, "emu_runtime.cpp"), "-lm"]
     subprocess.run(cmd, check=True)
     return LIB
 
