@@ -237,6 +237,38 @@ extern "C"
     void sdhip_pool_enable(int on);
     void sdhip_pool_trim(void);
 
+    /* ---- DVB-S2 LDPC soft decoder (BASELINE configs[4]) ---------------------------------------------------
+       Replaces dvbs2::BBFrameLDPC (plugins/dvb_support/codings/dvb-s2/bbframe_ldpc.{h,cpp}; decoder = ldpc/layered_decoder.hh with
+       OffsetMinSumAlgorithm<SIMD<int8_t, W>, NormalUpdate, 2>, ldpc/algorithms.hh:207-279) as DVBS2DemodModule::process_s2 calls it
+       (plugins/dvb_support/dvbs2/module_dvbs2_demod.cpp:246-257): int8 soft bits in (positive = bit 0), the same soft bits updated in
+       place out, bit for bit the reference's. */
+    typedef struct sdhip_ldpc_cfg
+    {
+        int framesize; /* dvbs2_framesize_t: 0 FECFRAME_NORMAL (64800), 1 FECFRAME_SHORT (16200) */
+        int rate;      /* dvbs2_code_rate_t: 0 C1_4, 1 C1_3, 2 C2_5, 3 C1_2, 4 C3_5, 5 C2_3, 6 C3_4, 7 C4_5, 8 C5_6, 9 C7_8 (no LDPC table: error),
+                          10 C8_9, 11 C9_10 (common/codings/dvb-s2/dvbs2.h:9-23) */
+        int batch;     /* dvbs2::simd_type::SIZE of the reference build being replaced: frames per BBFrameLDPC::decode call that share ONE
+                          early exit (16 with -msse4.1 -- plugins/dvb_support/CMakeLists.txt:25-38 -- 1 for the generic build) */
+        int device;
+    } sdhip_ldpc_cfg;
+    typedef struct sdhip_ldpc_info
+    {
+        int code_len, data_len;      /* LDPCInterface::code_len / data_len (BBFrameLDPC::dataSize) */
+        int layers;                  /* q = (N - K) / 360 */
+        int links_total;             /* edges of the Tanner graph */
+        int max_phases;              /* > 1: some layer holds checks that share a data bit and is run in that many dependent steps */
+        int layers_with_shared_bits;
+        uint64_t msg_bytes_per_frame; /* check-to-bit message state kept in HBM per frame */
+    } sdhip_ldpc_info;
+    void *sdhip_ldpc_create(const sdhip_ldpc_cfg *cfg); /* NULL on error (unknown rate / size: the reference's ctor would leave ldpc unset) */
+    void sdhip_ldpc_destroy(void *h);
+    int sdhip_ldpc_get_info(void *h, sdhip_ldpc_info *out);
+    /* nframes (a multiple of batch) frames of code_len int8 each, consecutive, decoded in place; trials[b] for batch b = what
+       BBFrameLDPC::decode returns for that call: the update passes it ran, or -1 if the batch did not converge within max_trials
+       (bbframe_ldpc.cpp:114-124). Returns the number of trial launches - 1 (>= 0), < 0 on error. _dev: pointers on cfg->device. */
+    int sdhip_ldpc_decode_dev(void *h, int8_t *d_frames, int nframes, int max_trials, int *d_trials);
+    int sdhip_ldpc_decode(void *h, int8_t *frames, int nframes, int max_trials, int *trials);
+
     /* ---- misc ------------------------------------------------------------------------ */
     const char *sdhip_last_error(void);
     const char *sdhip_version(void);

@@ -324,3 +324,41 @@ class Ref(_Lib):
             r["soft"] = soft[:nsoft.value]
         return r
 
+
+
+# ---------------------------------------------------------------- DVB-S2 FEC (oracle/ref_wrap_dvbs2.cpp: the reference's BBFrameLDPC / BBFrameBCH)
+S2_RATES = {"1/4": 0, "1/3": 1, "2/5": 2, "1/2": 3, "3/5": 4, "2/3": 5, "3/4": 6, "4/5": 7, "5/6": 8, "7/8": 9, "8/9": 10, "9/10": 11}
+
+
+class Dvbs2Ref:
+    """The compiled reference DVB-S2 FEC classes. sse=False: SIMD<int8_t, 1> build (one frame per decode call); sse=True: the -msse4.1
+    build SatDump ships on x86 (16 frames per call, one early exit)."""
+
+    def __init__(self, sse: bool = False):
+        path = os.path.join(_HERE, "_ref", "libsdref_dvbs2_sse.so" if sse else "libsdref_dvbs2.so")
+        self.lib = C.CDLL(path)
+        self.batch = self.lib.sdref_ldpc_batch()
+
+    @staticmethod
+    def available(sse: bool = False) -> bool:
+        return os.path.exists(os.path.join(_HERE, "_ref", "libsdref_dvbs2_sse.so" if sse else "libsdref_dvbs2.so"))
+
+    def dims(self, framesize, rate):
+        n, k = C.c_int(), C.c_int()
+        self.lib.sdref_ldpc_dims(framesize, rate, C.byref(n), C.byref(k))
+        return n.value, k.value
+
+    def ldpc_encode(self, framesize, rate, data_bytes: np.ndarray) -> np.ndarray:
+        """data_bytes [nframes, K/8] -> packed code words [nframes, N/8] (BBFrameLDPC::encode)."""
+        n, k = self.dims(framesize, rate)
+        fr = np.zeros((len(data_bytes), n // 8), dtype=np.uint8)
+        fr[:, :k // 8] = data_bytes
+        self.lib.sdref_ldpc_encode(framesize, rate, _p(fr), len(fr))
+        return fr
+
+    def ldpc_decode(self, framesize, rate, soft: np.ndarray, max_trials=25):
+        """soft int8 [nframes, N], nframes a multiple of self.batch -> (decoded soft bits, trials per batch)."""
+        s = np.ascontiguousarray(soft, dtype=np.int8).copy()
+        tr = np.zeros(len(s) // self.batch, dtype=np.int32)
+        self.lib.sdref_ldpc_decode(framesize, rate, _p(s), len(s) // self.batch, int(max_trials), _p(tr))
+        return s, tr

@@ -60,6 +60,19 @@ class FecStats(C.Structure):
     ]
 
 
+class LdpcCfg(C.Structure):
+    _fields_ = [("framesize", C.c_int), ("rate", C.c_int), ("batch", C.c_int), ("device", C.c_int)]
+
+
+class LdpcInfo(C.Structure):
+    _fields_ = [("code_len", C.c_int), ("data_len", C.c_int), ("layers", C.c_int), ("links_total", C.c_int), ("max_phases", C.c_int),
+                ("layers_with_shared_bits", C.c_int), ("msg_bytes_per_frame", C.c_uint64)]
+
+
+# dvbs2_code_rate_t (common/codings/dvb-s2/dvbs2.h:9-23)
+S2_RATES = {"1/4": 0, "1/3": 1, "2/5": 2, "1/2": 3, "3/5": 4, "2/3": 5, "3/4": 6, "4/5": 7, "5/6": 8, "7/8": 9, "8/9": 10, "9/10": 11}
+
+
 class SdhipError(RuntimeError):
     pass
 
@@ -106,6 +119,13 @@ def lib():
             L.sdhip_demod_get_stats.argtypes = [C.c_void_p, C.POINTER(DemodStats)]
             L.sdhip_op_block.restype = C.c_int64
             L.sdhip_op_block.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+        if hasattr(L, "sdhip_ldpc_create"):
+            L.sdhip_ldpc_create.restype = C.c_void_p
+            L.sdhip_ldpc_create.argtypes = [C.POINTER(LdpcCfg)]
+            L.sdhip_ldpc_destroy.argtypes = [C.c_void_p]
+            L.sdhip_ldpc_get_info.argtypes = [C.c_void_p, C.POINTER(LdpcInfo)]
+            L.sdhip_ldpc_decode_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+            L.sdhip_ldpc_decode.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         L.sdhip_prof_enable.argtypes = [C.c_int]
         L.sdhip_pool_enable.argtypes = [C.c_int]
         L.sdhip_prof_get.argtypes = [C.c_int, C.c_char_p, C.c_size_t, C.POINTER(C.c_double), C.POINTER(C.c_longlong)]
@@ -256,3 +276,43 @@ class PskDemod:
         st = DemodStats()
         lib().sdhip_demod_get_stats(self.h, C.byref(st))
         return st
+
+
+class LdpcDecoder:
+    """dvbs2::BBFrameLDPC's decode on the GPU (include/sdhip.h, sdhip_ldpc_*): framesize 0 normal / 1 short, rate a key of S2_RATES or
+    the enum value, batch = frames per reference decode call (its SIMD width)."""
+
+    def __init__(self, framesize=0, rate="2/3", batch=1, device=0):
+        cfg = LdpcCfg(int(framesize), S2_RATES[rate] if isinstance(rate, str) else int(rate), int(batch), int(device))
+        self.batch = int(batch)
+        self.h = lib().sdhip_ldpc_create(C.byref(cfg))
+        if not self.h:
+            raise SdhipError(lib().sdhip_last_error().decode())
+        self.info = LdpcInfo()
+        lib().sdhip_ldpc_get_info(self.h, C.byref(self.info))
+
+    def close(self):
+        if self.h:
+            lib().sdhip_ldpc_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def decode(self, frames: np.ndarray, max_trials: int = 25):
+        """frames: int8 [nframes, code_len] (host), decoded in place -> trials per batch (update passes run, -1 = not converged)."""
+        assert frames.dtype == np.int8 and frames.flags.c_contiguous and frames.shape[1] == self.info.code_len
+        tr = np.zeros(frames.shape[0] // self.batch, dtype=np.int32)
+        r = lib().sdhip_ldpc_decode(self.h, frames.ctypes.data_as(C.c_void_p), frames.shape[0], max_trials, tr.ctypes.data_as(C.c_void_p))
+        if r < 0:
+            raise SdhipError(lib().sdhip_last_error().decode())
+        return tr
+
+    def decode_dev(self, d_frames_ptr: int, nframes: int, max_trials: int, d_trials_ptr: int) -> int:
+        r = lib().sdhip_ldpc_decode_dev(self.h, d_frames_ptr, nframes, max_trials, d_trials_ptr)
+        if r < 0:
+            raise SdhipError(lib().sdhip_last_error().decode())
+        return r

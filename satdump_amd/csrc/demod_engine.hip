@@ -1055,10 +1055,12 @@ namespace sdhip
             else
                 cos_p.init_freq = cos_s.freq;
             const long long w_cos_cap = 1 << 20;
-            // 16 loop time constants: the lane starts next to a stable point (feed-forward phase estimate over est_len samples) at the
-            // stream's own frequency, so it is at the float floor of two trajectories well before the 24 the stand-alone stage allows
-            // (measured, MetOp 17 GB, profiles/r03_a_ab_metop.txt: soft parity 0.99617 at 16 against 0.99612 at 24; 0.99591 at 12)
-            const double taus = (double)env_int("SDHIP_COSTAS_TAUS", 16);
+            // 20 loop time constants: the lane starts next to a stable point (feed-forward phase estimate over est_len samples) at the
+            // stream's own frequency, so it reaches the float floor of two trajectories sooner than the 24 the stand-alone stage allows.
+            // Measured: MetOp 17 GB on the GPU (profiles/r03_a_ab_metop.txt) soft parity 0.99617 at 16 against 0.99612 at 24, 0.99591 at 12;
+            // on the host twin with 8192-sample chunks (three times the boundaries) NPP's pll_bw 0.002 loses 0.27 % of the symbols at 16
+            // and nothing at 20 (0.00393 against 0.00389 beyond 1e-5).
+            const double taus = (double)env_int("SDHIP_COSTAS_TAUS", 20);
             long long W = cfg.warmup > 0 ? cfg.warmup : (long long)std::max(512.0, taus / (1.414 * std::max(1e-5f, cfg.pll_bw)));
             W = std::max(W, w_cos_learned);
             W = env_int("SDHIP_W_COSTAS", W);

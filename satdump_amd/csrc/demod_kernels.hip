@@ -1751,6 +1751,8 @@ namespace sdhip
         long long next; // first sample index not yet in the ring (multiple of 8)
         long long cend; // first sample index of the NEXT Costas chunk (rotation changes there; multiple of 8)
         int ck;         // Costas chunk of block `next`
+        int rot_nx;     // rot[ck + 1], loaded when the lane entered chunk ck: the load is long back when the lane gets there (a load issued AT
+                        // the crossing stalled the whole wave for a memory round trip, once per lane and Costas chunk)
         float rc, rs;   // its rotation exp(+j*rot*unit) as (cos, sin): exactly 0 / +-1 for quarter and half turns
         float prev_im;  // OQPSK: imaginary part of sample next-1 (after rotation)
     };
@@ -1763,7 +1765,8 @@ namespace sdhip
         {
             f.ck++;
             f.cend += p.cg.L;
-            mm_rot_cs(p.rot[f.ck], p.order, f.rc, f.rs);
+            mm_rot_cs(f.rot_nx, p.order, f.rc, f.rs);
+            f.rot_nx = p.rot[f.ck + 1 < p.cg.K ? f.ck + 1 : f.ck];
         }
         const bool dorot = p.rot && i >= 0; // history (negative indices) was rotated by the previous call
         float re[8] = {c.a.x, c.a.z, c.b.x, c.b.z, c.c.x, c.c.z, c.d.x, c.d.z};
@@ -1793,6 +1796,7 @@ namespace sdhip
         first = (first >= 0 ? first : first - 7) / 8 * 8; // floor to a multiple of 8 (also for negative indices)
         f.next = first;
         f.ck = 0;
+        f.rot_nx = 0;
         f.rc = 1.0f;
         f.rs = 0.0f;
         f.cend = 0;
@@ -1800,6 +1804,7 @@ namespace sdhip
         {
             f.ck = first >= 0 ? costas_chunk_of(p.cg, first) : 0;
             mm_rot_cs(p.rot[f.ck], p.order, f.rc, f.rs);
+            f.rot_nx = p.rot[f.ck + 1 < p.cg.K ? f.ck + 1 : f.ck];
             f.cend = chunk_end(p.cg, f.ck);
         }
         f.prev_im = 0.0f;
@@ -1830,14 +1835,16 @@ namespace sdhip
         const float4 t1 = *reinterpret_cast<const float4 *>(bank + imu * 8 + 4);
         const float t[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
         const int base = (int)((s.inc - 7) & (MM_RING - 1));
-        float re = 0.0f, im = 0.0f;
+        // (re, im) of a sample as one packed pair: v_pk_mul_f32 / v_pk_add_f32, each half rounded like the scalar operation
+        v2f acc{0.0f, 0.0f};
 #pragma unroll
         for (int k = 0; k < 8; k++)
         {
             const cf32 v = ring[((base + k) & (MM_RING - 1)) * MM_RING_STRIDE];
-            re = re + v.re * t[k];
-            im = im + v.im * t[k];
+            const v2f prod = v2f{v.re, v.im} * v2f{t[k], t[k]};
+            acc = acc + prod;
         }
+        const float re = acc.x, im = acc.y;
         s.p_0T.re = re;
         s.p_0T.im = im;
         s.c_0T.re = re > 0.0f ? 1.0f : 0.0f;

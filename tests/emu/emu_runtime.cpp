@@ -85,6 +85,18 @@ void __syncthreads()
     while (bgen == g)
         yield();
 }
+int __syncthreads_or(int pred)
+{ // block-wide OR: contributions, barrier, everybody reads, barrier, everybody clears, barrier (nobody runs ahead into the next call)
+    static int acc = 0;
+    if (pred)
+        acc = 1;
+    __syncthreads();
+    const int r = acc;
+    __syncthreads();
+    acc = 0;
+    __syncthreads();
+    return r;
+}
 unsigned long long emu_wave_xchg(unsigned long long v, int src_lane)
 {
     const int w = current / 64;

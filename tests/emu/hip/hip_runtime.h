@@ -241,6 +241,14 @@ inline T atomicAdd(T *p, T v)
     return o;
 }
 template <class T>
+inline T atomicOr(T *p, T v)
+{
+    const T o = *p;
+    *p = o | v;
+    return o;
+}
+int __syncthreads_or(int pred); // emu_runtime.cpp
+template <class T>
 inline T atomicExch(T *p, T v)
 {
     const T o = *p;

@@ -1,0 +1,121 @@
+"""GPU parity tests of the DVB-S2 LDPC decoder (sdhip_ldpc_*, satdump_amd/csrc/dvbs2_ldpc.hip) against the reference's own BBFrameLDPC
+compiled in place (oracle/_ref/libsdref_dvbs2*.so, oracle/ref_wrap_dvbs2.cpp). Integer work: the decoded soft bits and the trial counts
+must be IDENTICAL -- converged or not, and in the 16-frames-per-call grouping of the reference's SSE4.1 build (one early exit per call)."""
+import numpy as np
+import pytest
+
+from oracle import pyref
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def capi():
+    from satdump_amd import capi as c
+    c.lib()
+    return c
+
+
+def _ref(sse):
+    if not pyref.Dvbs2Ref.available(sse):
+        pytest.skip("oracle/_ref/libsdref_dvbs2*.so not built (needs /root/reference at build time)")
+    return pyref.Dvbs2Ref(sse=sse)
+
+
+def make_frames(ref, fs, rate_code, nframes, amp, sigma, seed):
+    """LDPC code words of random data (tests/dvbs2_util.py: the accumulator encoder of the standard, from the same address tables),
+    BPSK-mapped like the soft demapper's output (bit 1 -> negative), plus noise, clipped to int8."""
+    from tests import dvbs2_util
+    n, k = ref.dims(fs, rate_code)
+    rng = np.random.default_rng(seed)
+    bits = dvbs2_util.encode(fs, rate_code, rng.integers(0, 2, (nframes, k), dtype=np.uint8))
+    assert bits.shape[1] == n
+    soft = np.where(bits > 0, -1.0, 1.0) * amp + rng.standard_normal(bits.shape) * sigma
+    return np.clip(np.rint(soft), -127, 127).astype(np.int8), bits, k
+
+
+def run_case(capi, ref, fs, rate, nframes, amp, sigma, trials, seed=1):
+    rc = capi.S2_RATES[rate]
+    nframes = (nframes + ref.batch - 1) // ref.batch * ref.batch
+    soft, bits, k = make_frames(ref, fs, rc, nframes, amp, sigma, seed)
+    want, wt = ref.ldpc_decode(fs, rc, soft, trials)
+    dec = capi.LdpcDecoder(framesize=fs, rate=rate, batch=ref.batch)
+    got = soft.copy()
+    gt = dec.decode(got, trials)
+    assert np.array_equal(gt, wt), (gt.tolist(), wt.tolist())
+    assert np.array_equal(got, want)
+    return got, gt, bits, k, dec
+
+
+NORMAL = ["1/4", "1/3", "2/5", "1/2", "3/5", "2/3", "3/4", "4/5", "5/6", "8/9", "9/10"]
+SHORT = ["1/4", "1/3", "2/5", "1/2", "3/5", "2/3", "3/4", "4/5", "5/6", "8/9"]
+# noise (for unit amplitude 20) at which each rate needs a handful of iterations
+SIGMA = {"1/4": 26, "1/3": 23, "2/5": 21, "1/2": 18, "3/5": 15, "2/3": 13.5, "3/4": 12, "4/5": 11, "5/6": 10, "8/9": 8, "9/10": 7.5}
+
+
+@pytest.mark.parametrize("fs,rate", [(0, r) for r in NORMAL] + [(1, r) for r in SHORT])
+def test_every_code_bit_exact(capi, fs, rate):
+    """All 21 tables of the standard (annex B normal, annex C short): clean frames (0 update passes), frames near the waterfall
+    (some converge, some do not) and hopeless ones (-1) -- soft bits and trial counts identical to the reference's."""
+    ref = _ref(False)
+    got, gt, bits, k, dec = run_case(capi, ref, fs, rate, 3, 20, SIGMA[rate] * (1.0 if fs == 0 else 0.9), 12)
+    assert dec.info.code_len == (64800 if fs == 0 else 16200) and dec.info.data_len == k
+    run_case(capi, ref, fs, rate, 1, 60, 1.0, 5, seed=2)   # clean: converged before the first update
+    run_case(capi, ref, fs, rate, 1, 5, 30.0, 3, seed=3)   # noise: never converges
+    conv = gt >= 0
+    if conv.any():
+        assert np.array_equal((got[conv][:, :k] < 0).astype(np.uint8), bits[conv][:, :k]), "a converged frame does not carry the transmitted data"
+
+
+@pytest.mark.parametrize("fs,rate", [(0, "2/3"), (0, "3/4"), (1, "1/2"), (1, "8/9")])
+def test_sse_batches_share_one_early_exit(capi, fs, rate):
+    """The reference's x86 build decodes 16 frames per call and stops when ALL of them have converged (layered_decoder.hh:160,
+    algorithms.hh:264-271): frames that are done keep being updated. batch = 16 reproduces that bit for bit; mixed batches (a noisy
+    frame among clean ones) are what distinguishes it from batch = 1."""
+    ref = _ref(True)
+    assert ref.batch == 16
+    rc = capi.S2_RATES[rate]
+    soft, bits, k = make_frames(ref, fs, rc, 32, 20, SIGMA[rate] * (1.0 if fs == 0 else 0.9), 5)
+    clean, _, _ = make_frames(ref, fs, rc, 32, 60, 1.0, 5)
+    soft[3:16] = clean[3:16]  # first batch: three noisy frames among clean ones
+    want, wt = ref.ldpc_decode(fs, rc, soft, 15)
+    dec = capi.LdpcDecoder(framesize=fs, rate=rate, batch=16)
+    got = soft.copy()
+    gt = dec.decode(got, 15)
+    assert np.array_equal(gt, wt) and np.array_equal(got, want)
+    one = capi.LdpcDecoder(framesize=fs, rate=rate, batch=1)
+    solo = soft.copy()
+    one.decode(solo, 15)
+    if wt[0] > 0:
+        assert not np.array_equal(solo[3:16], got[3:16]), "clean frames of a mixed batch should have been updated along with the noisy ones"
+
+
+def test_device_entry_and_many_frames(capi):
+    """sdhip_ldpc_decode_dev on frames resident in HBM, a few hundred frames (more workgroups than CUs), normal 2/3 (BASELINE configs[4]'s
+    MODCOD 13): identical to the reference on a sample of them, every converged frame carries its data (size-independent property)."""
+    import torch
+    ref = _ref(False)
+    rc = capi.S2_RATES["2/3"]
+    n, k = ref.dims(0, rc)
+    nf = 600
+    soft, bits, _ = make_frames(ref, 0, rc, nf, 20, 13.0, 7)
+    d = torch.from_numpy(soft).cuda()
+    d_tr = torch.zeros(nf, dtype=torch.int32, device="cuda")
+    dec = capi.LdpcDecoder(framesize=0, rate="2/3", batch=1)
+    dec.decode_dev(d.data_ptr(), nf, 20, d_tr.data_ptr())
+    got, tr = d.cpu().numpy(), d_tr.cpu().numpy()
+    want, wt = ref.ldpc_decode(0, rc, soft[:24], 20)
+    assert np.array_equal(tr[:24], wt) and np.array_equal(got[:24], want)
+    conv = tr >= 0
+    assert conv.mean() > 0.9
+    assert np.array_equal((got[conv][:, :k] < 0).astype(np.uint8), bits[conv][:, :k])
+
+
+def test_errors(capi):
+    with pytest.raises(capi.SdhipError):
+        capi.LdpcDecoder(framesize=0, rate="7/8")   # no LDPC table (bbframe_ldpc.cpp:30-69 has no case for it)
+    with pytest.raises(capi.SdhipError):
+        capi.LdpcDecoder(framesize=1, rate="9/10")
+    dec = capi.LdpcDecoder(framesize=1, rate="1/2", batch=16)
+    with pytest.raises(capi.SdhipError):
+        dec.decode(np.zeros((3, 16200), dtype=np.int8))  # not a whole number of batches

@@ -1,0 +1,79 @@
+"""tests/test_dvbs2_gpu.py's parity cases against the HOST TWIN of dvbs2_ldpc.hip (tests/emu) -- a subset sized for the CPU suite --
+plus what needs no device: the generated tables are what the generator makes of the reference's header, and the oracle itself
+round-trips (its encoder's code words decode to themselves)."""
+import importlib.util
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from oracle import pyref
+from tests import test_dvbs2_gpu as G
+from tests.emu import build as emu_build
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def capi():
+    if not os.path.exists(emu_build.CLANG):
+        pytest.skip("no host clang++ to build the twin with")
+    lib = emu_build.build()
+    spec = importlib.util.spec_from_file_location("capi_host_twin4", os.path.join(ROOT, "satdump_amd", "capi.py"))
+    m = importlib.util.module_from_spec(spec)
+    old = os.environ.get("SDHIP_LIB")
+    os.environ["SDHIP_LIB"] = lib
+    os.environ["SDHIP_TESTING_TWIN"] = "1"
+    try:
+        spec.loader.exec_module(m)
+        m.lib()
+    finally:
+        del os.environ["SDHIP_TESTING_TWIN"]
+        if old is None:
+            del os.environ["SDHIP_LIB"]
+        else:
+            os.environ["SDHIP_LIB"] = old
+    return m
+
+
+@pytest.mark.parametrize("fs,rate", [(0, "2/3"), (0, "9/10"), (0, "1/4"), (1, "1/2"), (1, "3/5"), (1, "8/9")])
+def test_codes_bit_exact_on_the_twin(capi, fs, rate):
+    ref = G._ref(False)
+    G.run_case(capi, ref, fs, rate, 2, 20, G.SIGMA[rate] * (1.0 if fs == 0 else 0.9), 8)
+    G.run_case(capi, ref, fs, rate, 1, 60, 1.0, 5, seed=2)
+
+
+def test_sse_batch_on_the_twin(capi):
+    ref = G._ref(True)
+    rc = capi.S2_RATES["1/2"]
+    soft, bits, k = G.make_frames(ref, 1, rc, 16, 20, 16.0, 5)
+    clean, _, _ = G.make_frames(ref, 1, rc, 16, 60, 1.0, 5)
+    soft[2:] = clean[2:]
+    want, wt = ref.ldpc_decode(1, rc, soft, 10)
+    dec = capi.LdpcDecoder(framesize=1, rate="1/2", batch=16)
+    got = soft.copy()
+    gt = dec.decode(got, 10)
+    assert np.array_equal(gt, wt) and np.array_equal(got, want)
+
+
+test_errors = G.test_errors
+
+
+def test_generated_tables_are_the_generators_output():
+    if not os.path.isdir("/root/reference/plugins/dvb_support"):
+        pytest.skip("reference tree not present")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen_dvbs2_tables.py")], capture_output=True, text=True, check=True).stdout
+    assert out == open(os.path.join(ROOT, "satdump_amd", "csrc", "dvbs2_tables.inc")).read()
+
+
+@pytest.mark.parametrize("sse", [False, True])
+def test_oracle_round_trip(sse):
+    """The checker checks out: a code word of every table (tests/dvbs2_util.py) is a fixed point of the reference's decoder (0 update
+    passes), in both builds -- which also pins the generated tables and the test encoder against the reference's graph."""
+    ref = G._ref(sse)
+    for fs, rate in [(0, r) for r in (0, 1, 2, 3, 4, 5, 6, 7, 8, 10, 11)] + [(1, r) for r in (0, 1, 2, 3, 4, 5, 6, 7, 8, 10)]:
+        soft, bits, k = G.make_frames(ref, fs, rate, ref.batch, 40, 0.0, 3)
+        out, tr = ref.ldpc_decode(fs, rate, soft, 5)
+        assert tr.tolist() == [0] and np.array_equal(out, soft)
