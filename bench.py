@@ -167,7 +167,7 @@ def cpu_baseline(wl, x_host, n_prefix):
     single = {"value": round(n_prefix / (t_dem + t_fec) / 1e6, 3), "cores": 1, "demod_s": round(t_dem, 2), "fec_s": round(t_fec, 2),
               "sample": f"first {n_prefix} samples"}
     res = {"unit": "Msamples/s", "kind": kind, "host_cores": ncores, "single_thread": single,
-           "volk": "generic-order shim (oracle/ref_shim), gcc -O2, no libvolk on the box: a pessimistic baseline (a tuned libvolk would be faster)"}
+           "volk": "generic-order shim (ref_shim/), gcc -O2, no libvolk on the box: a pessimistic baseline (a tuned libvolk would be faster)"}
     full = {"cadu": cadus, "soft": r["soft"], "samples": n_prefix}
     if kind == "reference":
         ocfg, ofec, metop = ref_cfgs(wl)

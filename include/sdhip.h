@@ -269,6 +269,26 @@ extern "C"
     int sdhip_ldpc_decode_dev(void *h, int8_t *d_frames, int nframes, int max_trials, int *d_trials);
     int sdhip_ldpc_decode(void *h, int8_t *frames, int nframes, int max_trials, int *trials);
 
+    /* ---- DVB-S2 BCH outer decoder + hard-decision repack (same path) --------------------------------------------------------------
+       Replaces dvbs2::BBFrameBCH::decode (plugins/dvb_support/codings/dvb-s2/bbframe_bch.cpp:412-440 -> bch/
+       bose_chaudhuri_hocquenghem_decoder.hh, bch/reed_solomon_error_correction.hh) and the repack in front of it
+       (plugins/dvb_support/dvbs2/module_dvbs2_demod.cpp:262-266). */
+    typedef struct sdhip_bch_cfg
+    {
+        int framesize; /* as sdhip_ldpc_cfg */
+        int rate;
+        int device;
+    } sdhip_bch_cfg;
+    void *sdhip_bch_create(const sdhip_bch_cfg *cfg);
+    void sdhip_bch_destroy(void *h);
+    int sdhip_bch_dims(void *h, int *kbch, int *nbch); /* BBFrameBCH::dataSize() and the frame length (= the LDPC code's data_len) */
+    /* nframes packed frames (nbch / 8 bytes each, `stride` bytes apart), corrected in place; corrections[f] = BBFrameBCH::decode's return
+       value: bits corrected, 0 for a clean frame, -1 when the decoder gives up. _dev: pointers on cfg->device. */
+    int sdhip_bch_decode_dev(void *h, uint8_t *d_frames, int nframes, int stride, int *d_corrections);
+    int sdhip_bch_decode(void *h, uint8_t *frames, int nframes, int stride, int *corrections);
+    /* bit i of a frame = (soft[i] < 0), MSB first, for the first nbch soft bits of every LDPC frame (8-byte aligned, soft_stride apart) */
+    int sdhip_s2_pack_dev(void *h, const int8_t *d_soft, int soft_stride, int nframes, uint8_t *d_out, int out_stride);
+
     /* ---- misc ------------------------------------------------------------------------ */
     const char *sdhip_last_error(void);
     const char *sdhip_version(void);

@@ -362,3 +362,20 @@ class Dvbs2Ref:
         tr = np.zeros(len(s) // self.batch, dtype=np.int32)
         self.lib.sdref_ldpc_decode(framesize, rate, _p(s), len(s) // self.batch, int(max_trials), _p(tr))
         return s, tr
+
+    def bch_kbch(self, framesize, rate):
+        k = C.c_int()
+        self.lib.sdref_bch_dims(framesize, rate, C.byref(k))
+        return k.value
+
+    def bch_encode(self, framesize, rate, frames: np.ndarray) -> np.ndarray:
+        """frames uint8 [nframes, stride]: the first kbch / 8 bytes hold the data, BBFrameBCH::encode writes the parity behind them."""
+        f = np.ascontiguousarray(frames, dtype=np.uint8).copy()
+        self.lib.sdref_bch_encode(framesize, rate, _p(f), len(f), f.shape[1])
+        return f
+
+    def bch_decode(self, framesize, rate, frames: np.ndarray):
+        f = np.ascontiguousarray(frames, dtype=np.uint8).copy()
+        corr = np.zeros(len(f), dtype=np.int32)
+        self.lib.sdref_bch_decode(framesize, rate, _p(f), len(f), f.shape[1], _p(corr))
+        return f, corr

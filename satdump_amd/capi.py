@@ -64,6 +64,10 @@ class LdpcCfg(C.Structure):
     _fields_ = [("framesize", C.c_int), ("rate", C.c_int), ("batch", C.c_int), ("device", C.c_int)]
 
 
+class BchCfg(C.Structure):
+    _fields_ = [("framesize", C.c_int), ("rate", C.c_int), ("device", C.c_int)]
+
+
 class LdpcInfo(C.Structure):
     _fields_ = [("code_len", C.c_int), ("data_len", C.c_int), ("layers", C.c_int), ("links_total", C.c_int), ("max_phases", C.c_int),
                 ("layers_with_shared_bits", C.c_int), ("msg_bytes_per_frame", C.c_uint64)]
@@ -126,6 +130,14 @@ def lib():
             L.sdhip_ldpc_get_info.argtypes = [C.c_void_p, C.POINTER(LdpcInfo)]
             L.sdhip_ldpc_decode_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
             L.sdhip_ldpc_decode.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        if hasattr(L, "sdhip_bch_create"):
+            L.sdhip_bch_create.restype = C.c_void_p
+            L.sdhip_bch_create.argtypes = [C.POINTER(BchCfg)]
+            L.sdhip_bch_destroy.argtypes = [C.c_void_p]
+            L.sdhip_bch_dims.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+            L.sdhip_bch_decode_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+            L.sdhip_bch_decode.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+            L.sdhip_s2_pack_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int]
         L.sdhip_prof_enable.argtypes = [C.c_int]
         L.sdhip_pool_enable.argtypes = [C.c_int]
         L.sdhip_prof_get.argtypes = [C.c_int, C.c_char_p, C.c_size_t, C.POINTER(C.c_double), C.POINTER(C.c_longlong)]
@@ -316,3 +328,44 @@ class LdpcDecoder:
         if r < 0:
             raise SdhipError(lib().sdhip_last_error().decode())
         return r
+
+
+class BchDecoder:
+    """dvbs2::BBFrameBCH::decode on the GPU (include/sdhip.h, sdhip_bch_*)."""
+
+    def __init__(self, framesize=0, rate="2/3", device=0):
+        cfg = BchCfg(int(framesize), S2_RATES[rate] if isinstance(rate, str) else int(rate), int(device))
+        self.h = lib().sdhip_bch_create(C.byref(cfg))
+        if not self.h:
+            raise SdhipError(lib().sdhip_last_error().decode())
+        k, n = C.c_int(), C.c_int()
+        lib().sdhip_bch_dims(self.h, C.byref(k), C.byref(n))
+        self.kbch, self.nbch = k.value, n.value
+
+    def close(self):
+        if self.h:
+            lib().sdhip_bch_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def decode(self, frames: np.ndarray):
+        """frames uint8 [nframes, stride >= nbch / 8] (host), corrected in place -> corrections per frame."""
+        assert frames.dtype == np.uint8 and frames.flags.c_contiguous
+        corr = np.zeros(frames.shape[0], dtype=np.int32)
+        r = lib().sdhip_bch_decode(self.h, frames.ctypes.data_as(C.c_void_p), frames.shape[0], frames.shape[1], corr.ctypes.data_as(C.c_void_p))
+        if r < 0:
+            raise SdhipError(lib().sdhip_last_error().decode())
+        return corr
+
+    def decode_dev(self, d_frames_ptr, nframes, stride, d_corr_ptr):
+        if lib().sdhip_bch_decode_dev(self.h, d_frames_ptr, nframes, stride, d_corr_ptr) < 0:
+            raise SdhipError(lib().sdhip_last_error().decode())
+
+    def pack_dev(self, d_soft_ptr, soft_stride, nframes, d_out_ptr, out_stride):
+        if lib().sdhip_s2_pack_dev(self.h, d_soft_ptr, soft_stride, nframes, d_out_ptr, out_stride) < 0:
+            raise SdhipError(lib().sdhip_last_error().decode())

@@ -576,6 +576,8 @@ namespace sdhip
                         for (int i = 0; i < plan.nstages; i++)
                         {
                             const PdSet &set = PD_SETS[plan.stages[i].set];
+                            if (set.count > 1024) // k_decim_fir stages its taps in 1024 floats of LDS, k_hist_slide runs 1024 threads
+                                throw HipError("power-of-two decimator stage longer than 1024 taps");
                             auto st = std::make_unique<DecimStage>();
                             st->decim = plan.stages[i].decim;
                             st->ntaps = set.count;

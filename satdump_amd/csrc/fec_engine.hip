@@ -52,13 +52,33 @@ namespace sdhip
     {
         if (!p)
             return;
+        bool park;
         {
             std::lock_guard<std::mutex> lk(g_pool_mu);
-            if (g_pool_on)
+            park = g_pool_on;
+        }
+        if (park)
+        {
+            // hipFree waits for the device before it releases a block; a parked block must give the same guarantee, or the next
+            // owner (another handle, another stream) could be handed memory that kernels queued by the previous one still read
+            // (a DevBuf that grows in the middle of a pass releases its old block while the pass is in flight)
+            int cur = 0, own = 0;
+            (void)hipGetDevice(&cur);
             {
-                g_pool_dev.insert({{g_dev_of[p], bytes}, p});
-                return;
+                std::lock_guard<std::mutex> lk(g_pool_mu);
+                own = g_dev_of[p];
             }
+            if (own != cur)
+                (void)hipSetDevice(own);
+            (void)hipDeviceSynchronize();
+            if (own != cur)
+                (void)hipSetDevice(cur);
+            std::lock_guard<std::mutex> lk(g_pool_mu);
+            g_pool_dev.insert({{own, bytes}, p});
+            return;
+        }
+        {
+            std::lock_guard<std::mutex> lk(g_pool_mu);
             g_dev_of.erase(p);
         }
         (void)hipFree(p);

@@ -11,6 +11,11 @@ pytestmark = pytest.mark.gpu
 
 @pytest.fixture(scope="module")
 def capi():
+    # torch first: its bundled HIP runtime must be the one that initialises the device (loading libsdhip.so first and torch.cuda later
+    # left torch with "No HIP GPUs are available" on the GPU box)
+    import torch
+    assert torch.cuda.is_available()
+    torch.zeros(1, device="cuda")
     from satdump_amd import capi as c
     c.lib()
     return c
@@ -109,6 +114,77 @@ def test_device_entry_and_many_frames(capi):
     conv = tr >= 0
     assert conv.mean() > 0.9
     assert np.array_equal((got[conv][:, :k] < 0).astype(np.uint8), bits[conv][:, :k])
+
+
+def bch_case(capi, ref, fs, rate, errs, seed=3):
+    """Random BCH code words (the reference's encoder) with errs[i] bit errors in frame i, through both decoders."""
+    rc = capi.S2_RATES[rate]
+    dec = capi.BchDecoder(framesize=fs, rate=rate)
+    assert dec.kbch == ref.bch_kbch(fs, rc)
+    rng = np.random.default_rng(seed)
+    fr = np.zeros((len(errs), dec.nbch // 8), dtype=np.uint8)
+    fr[:, :dec.kbch // 8] = rng.integers(0, 256, (len(errs), dec.kbch // 8), dtype=np.uint8)
+    cw = ref.bch_encode(fs, rc, fr)
+    rx = cw.copy()
+    for i, e in enumerate(errs):
+        for p in rng.choice(dec.nbch, e, replace=False):
+            rx[i, p // 8] ^= 1 << (7 - p % 8)
+    want, wc = ref.bch_decode(fs, rc, rx)
+    got = rx.copy()
+    gc = dec.decode(got)
+    assert np.array_equal(gc, wc), (gc.tolist(), wc.tolist())
+    assert np.array_equal(got, want)
+    return cw, got, gc, dec
+
+
+@pytest.mark.parametrize("fs,rate", [(0, r) for r in NORMAL] + [(1, r) for r in SHORT])
+def test_bch_every_code_bit_exact(capi, fs, rate):
+    """BBFrameBCH::decode for every frame size / rate (t = 12 / 10 / 8 over GF(2^16), t = 12 over GF(2^14)): clean frames, 1 .. t errors
+    (degree 1 and 2 locators take the closed-form finders, the rest the Chien search), and t + 1 .. many errors, where the decoder gives
+    up (-1, frame untouched) or miscorrects -- corrected bytes and return values identical to the reference's."""
+    ref = _ref(False)
+    errs = [0, 1, 2, 3, 4, 7, 8, 9, 10, 11, 12, 13, 16, 30, 200]
+    cw, got, gc, dec = bch_case(capi, ref, fs, rate, errs)
+    t = {0: {"2/3": 10, "5/6": 10, "8/9": 8, "9/10": 8}.get(rate, 12), 1: 12}[fs]
+    for i, e in enumerate(errs):
+        if e <= t:
+            assert gc[i] == e and np.array_equal(got[i], cw[i])
+
+
+def test_ldpc_pack_bch_chain_on_device(capi):
+    """The FEC tail of DVBS2DemodModule::process_s2 on frames resident in HBM: LDPC decode -> hard-decision repack -> BCH decode
+    (module_dvbs2_demod.cpp:254-270), against the same three steps of the reference; normal 2/3 (MODCOD 13 of BASELINE configs[4])."""
+    import torch
+    from tests import dvbs2_util
+    ref = _ref(False)
+    fs, rate, rc = 0, "2/3", 5
+    n, k = ref.dims(fs, rc)
+    bch = capi.BchDecoder(framesize=fs, rate=rate)
+    assert bch.nbch == k
+    nf = 24
+    rng = np.random.default_rng(11)
+    bb = np.zeros((nf, k // 8), dtype=np.uint8)
+    bb[:, :bch.kbch // 8] = rng.integers(0, 256, (nf, bch.kbch // 8), dtype=np.uint8)
+    bb = ref.bch_encode(fs, rc, bb)                                     # BBFRAME + BCH parity = the LDPC data bits
+    cw = dvbs2_util.encode(fs, rc, np.unpackbits(bb, axis=1))
+    soft = np.clip(np.rint(np.where(cw > 0, -1.0, 1.0) * 20 + rng.standard_normal(cw.shape) * 14.0), -127, 127).astype(np.int8)
+    # reference chain
+    rsoft, rtr = ref.ldpc_decode(fs, rc, soft, 20)
+    rpack = np.packbits((rsoft[:, :k] < 0).astype(np.uint8), axis=1)
+    rout, rcorr = ref.bch_decode(fs, rc, rpack)
+    # device chain
+    d_soft = torch.from_numpy(soft.copy()).cuda()
+    d_tr = torch.zeros(nf, dtype=torch.int32, device="cuda")
+    d_pack = torch.zeros((nf, k // 8), dtype=torch.uint8, device="cuda")
+    d_corr = torch.zeros(nf, dtype=torch.int32, device="cuda")
+    ldpc = capi.LdpcDecoder(framesize=fs, rate=rate, batch=1)
+    ldpc.decode_dev(d_soft.data_ptr(), nf, 20, d_tr.data_ptr())
+    bch.pack_dev(d_soft.data_ptr(), n, nf, d_pack.data_ptr(), k // 8)
+    bch.decode_dev(d_pack.data_ptr(), nf, k // 8, d_corr.data_ptr())
+    assert np.array_equal(d_tr.cpu().numpy(), rtr)
+    assert np.array_equal(d_pack.cpu().numpy(), rout) and np.array_equal(d_corr.cpu().numpy(), rcorr)
+    good = rcorr >= 0
+    assert good.mean() > 0.5 and np.array_equal(rout[good][:, :bch.kbch // 8], bb[good][:, :bch.kbch // 8])
 
 
 def test_errors(capi):

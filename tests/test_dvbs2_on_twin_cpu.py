@@ -58,6 +58,11 @@ def test_sse_batch_on_the_twin(capi):
     assert np.array_equal(gt, wt) and np.array_equal(got, want)
 
 
+@pytest.mark.parametrize("fs,rate", [(0, "2/3"), (0, "1/2"), (0, "9/10"), (1, "1/4"), (1, "8/9")])
+def test_bch_bit_exact_on_the_twin(capi, fs, rate):
+    G.bch_case(capi, G._ref(False), fs, rate, [0, 1, 2, 3, 5, 8, 10, 12, 13, 14, 20, 40])
+
+
 test_errors = G.test_errors
 
 
