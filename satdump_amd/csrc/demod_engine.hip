@@ -1077,6 +1077,9 @@ namespace sdhip
             const double tol_phase = env_int("SDHIP_COSTAS_TOL_URAD", 10000) * 1e-6, tol_freq = env_int("SDHIP_COSTAS_TOL_NFREQ", 40000) * 1e-9;
             AfcParams ap;
             AfcCkptCfg ck;
+            // chunk-parallel mode: the stage's fast arithmetic (demod_kernels.hip, sd_sincosf_fast) -- inside the 1e-5 contract that mode is
+            // held to; exact mode rounds every operation where the reference does. SDHIP_FAST_MATH=0: the exact arithmetic in both (A/B)
+            const bool afc_fast = !cfg.exact && env_int("SDHIP_FAST_MATH", 1) != 0;
             auto setup = [&](long long Wn) {
                 cos_p.est_len = (int)(std::min<long long>(env_int("SDHIP_COSTAS_EST", 256), Wn / 2) / 32 * 32);
                 cg = make_geom(n, L, (int)Wn);
@@ -1100,7 +1103,7 @@ namespace sdhip
             setup(W);
             // the carried start state lives on the device (filter window); its carrier part is the host's copy (kept in the stream's frame)
             SD_HIP(hipMemcpyAsync(&d_afc_start.p->cos, &cos_s, sizeof(cos_s), hipMemcpyHostToDevice, stream));
-            launch_afc(in, out, cg, ap, d_afc_start.p, d_afc_spec.p, d_afc_end.p, nullptr, 0, stream, ck);
+            launch_afc(in, out, cg, ap, d_afc_start.p, d_afc_spec.p, d_afc_end.p, nullptr, 0, stream, ck, afc_fast);
             verify_fix(
                 "afc", cg.K,
                 [&](VerdictOut *vo, int *fails, int force) {
@@ -1110,7 +1113,7 @@ namespace sdhip
                 [&](const int *list, int nr) {
                     hipLaunchKernelGGL(k_afc_spec_fix, dim3((nr + 255) / 256), dim3(256), 0, stream, list, nr, d_afc_spec.p, d_afc_end.p, rot_unit, use_ckpt ? 1 : 0);
                 },
-                [&](const int *redo, int nr) { launch_afc(in, out, cg, ap, d_afc_start.p, d_afc_spec.p, d_afc_end.p, redo, nr, stream, ck); },
+                [&](const int *redo, int nr) { launch_afc(in, out, cg, ap, d_afc_start.p, d_afc_spec.p, d_afc_end.p, redo, nr, stream, ck, afc_fast); },
                 [&](int) {
                     // many warm-ups missed: start frequency off (take the median of the lanes' end frequencies) or warm-up too short for
                     // this signal's loop dynamics (double it; the stream keeps the longer one) -- see the stand-alone Costas stage
@@ -1128,7 +1131,7 @@ namespace sdhip
                     else
                         return false;
                     setup(std::max<long long>(cg.W, w_cos_learned));
-                    launch_afc(in, out, cg, ap, d_afc_start.p, d_afc_spec.p, d_afc_end.p, nullptr, 0, stream, ck);
+                    launch_afc(in, out, cg, ap, d_afc_start.p, d_afc_spec.p, d_afc_end.p, nullptr, 0, stream, ck, afc_fast);
                     return true;
                 });
             stats.chunks += 2 * (unsigned)cg.K; // the chunks of two loop stages
@@ -1586,6 +1589,7 @@ namespace sdhip
                 // symbol cost the issue-bound k_mm 1.3 - 2.2 ms (unpaired / dword-paired stores): off by default.
                 mm_p.q8 = (d_syms == nullptr && env_int("SDHIP_MM_Q8", 0) != 0) ? 1 : 0;
                 mm_p.q8_bpsk = is_bpsk ? 1 : 0;
+                mm_p.fast = (!cfg.exact && env_int("SDHIP_FAST_MATH", 1) != 0) ? 1 : 0;
                 mm_p.fast_mult = (float)env_int("SDHIP_MM_FAST_MULT", 8);
                 mm_p.fast_syms = mm_p.fast_mult > 1.0f ? (int)env_int("SDHIP_MM_FAST_SYMS", (long long)(2.75 / gmu)) : 0;
                 // a re-run costs one lane the whole chunk, so long chunks (large batches) keep the conservative warm-up: it is a

@@ -163,8 +163,10 @@ namespace sdhip
         int per_chunk = 0, len = 0;
         float tol_phase = 0, tol_freq = 0;
     };
+    // fast: the chunk-parallel mode's arithmetic (float sine / cosine, hardware square root, fused multiply-adds: see sd_sincosf_fast); false =
+    // every float operation rounded where the reference's is (exact mode)
     void launch_afc(const cf32 *x, cf32 *y, const ChunkGeom &g, const AfcParams &p, const AfcState *start0, AfcState *spec, AfcState *endst, const int *redo,
-                    int nredo, hipStream_t st, const AfcCkptCfg &ck);
+                    int nredo, hipStream_t st, const AfcCkptCfg &ck, bool fast);
 
     // ---- carrier-tracking PLL (has_carrier, pll_carrier_tracking.cpp:23-66): same state layout and chunk scheme as the Costas loop,
     // one stable point per turn (no frame ambiguity)
@@ -192,6 +194,7 @@ namespace sdhip
         int fast_syms;   // warm-up gear shift: symbols run with mu_gain * fast_mult and the omega term frozen
         float fast_mult;
         int q8, q8_bpsk; // q8: the symbols are stored as the module's int8 soft symbols (2 bytes per symbol row entry) instead of floats
+        int fast;        // chunk-parallel mode's arithmetic: fused multiply-adds in the interpolator (exact mode: 0)
     };
     struct MmState
     {

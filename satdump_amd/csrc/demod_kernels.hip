@@ -115,6 +115,36 @@ namespace sdhip
         cs = tiny ? 1.0f : (odd ? fs : fc);
     }
 
+    // ---- FAST arithmetic of the chunk-parallel mode (k_afc<ORDER, true>) ------------------------------------------------------------------
+    // The chunk-parallel mode is held to the 1e-5 soft-symbol contract, not to bit identity (no time-parallel schedule of these loops can
+    // be: DESIGN.md 2), and its float operations need not round where the reference's do. Float sine / cosine with <= 6e-8 absolute error
+    // (Cody-Waite reduction by pi/2 with a fused multiply-add, Taylor polynomials of degree 9 / 8 on [-pi/4, pi/4]: truncation 1.8e-9 /
+    // 2.4e-8) instead of glibc's double-precision evaluation, the hardware square root (1 ulp) instead of the correctly rounded one, fused
+    // multiply-adds in the matched filter: ~60 of the fused stage's ~170 VALU instructions per sample. exact = 1 keeps every rounding.
+    __device__ __forceinline__ void sd_sincosf_fast(float y, float &sn, float &cs)
+    {
+        const float k = rintf(y * 0.63661977236758134308f); // |y| <= 2 pi: |k| <= 4
+        float r = fmaf(-k, 1.57079637050628662109375f, y);  // pi/2 rounded to float; k times it is exact inside the fused operation
+        r = fmaf(-k, -4.37113900018624283e-8f, r);          // pi/2 - (float)(pi/2)
+        const float r2 = r * r;
+        const float sp = fmaf(r2, fmaf(r2, fmaf(r2, 2.75573192239858906526e-6f, -1.98412698412698412698e-4f), 8.33333333333333333333e-3f), -1.66666666666666666667e-1f);
+        const float s = fmaf(r * r2, sp, r);
+        const float cp = fmaf(r2, fmaf(r2, fmaf(r2, 2.48015873015873015873e-5f, -1.38888888888888888889e-3f), 4.16666666666666666667e-2f), -0.5f);
+        const float c = fmaf(r2, cp, 1.0f);
+        const int q = (int)k & 3;
+        const float a = (q & 1) ? c : s, b = (q & 1) ? s : c; // sin takes (s, c, -s, -c), cos takes (c, -s, -c, s) by quadrant
+        sn = (q & 2) ? -a : a;
+        cs = ((q + 1) & 2) ? -b : b;
+    }
+    __device__ __forceinline__ float sd_sqrt_fast(float x)
+    {
+#ifdef SDHIP_HOST_TWIN
+        return sqrtf(x);
+#else
+        return __builtin_amdgcn_sqrtf(x); // v_sqrt_f32, 1 ulp
+#endif
+    }
+
     // =============================================================================================
     // format conversion
     // =============================================================================================
@@ -717,12 +747,18 @@ namespace sdhip
         // early exit of a re-run lane (CKPT): is state a on the trajectory that left checkpoint b? (the AGC certificate's own rule)
         __device__ static __forceinline__ bool close(const S &a, const S &b, float tol_a, float) { return fabsf(a.gain - b.gain) <= tol_a * fabsf(b.gain); }
         __device__ static __forceinline__ void prewarm(S &, const P &, const cf32 *, long long) {}
-        __device__ static __forceinline__ cf32 step(S &s, const P &p, const cf32 v)
+        __device__ static __forceinline__ cf32 step(S &s, const P &p, const cf32 v) { return step_t<false>(s, p, v); }
+        template <bool FAST>
+        __device__ static __forceinline__ cf32 step_t(S &s, const P &p, const cf32 v)
         {
             // AGCBlock<complex_t>::work, agc.cpp:25-39
             const float ore = v.re * s.gain;
             const float oim = v.im * s.gain;
-            const float mag = sqrtf(ore * ore + oim * oim) /* correctly rounded (default -fhip-fp32-correctly-rounded-divide-sqrt); __fsqrt_rn is the native approximation */;
+            float mag;
+            if constexpr (FAST)
+                mag = sd_sqrt_fast(fmaf(ore, ore, oim * oim));
+            else
+                mag = sqrtf(ore * ore + oim * oim) /* correctly rounded (default -fhip-fp32-correctly-rounded-divide-sqrt); __fsqrt_rn is the native approximation */;
             s.gain = s.gain + p.rate * (p.reference - mag);
             if (p.max_gain > 0.0f && s.gain > p.max_gain)
                 s.gain = p.max_gain;
@@ -748,7 +784,8 @@ namespace sdhip
         asm("v_mov_b32 %0, %1" : "=v"(r) : "s"(v));
         return r;
     }
-    struct AgcFirStage
+    template <bool FAST>
+    struct AgcFirStageT
     {
         using P = AgcFirParams;
         using S = AgcFirState;
@@ -771,7 +808,7 @@ namespace sdhip
         __device__ static __forceinline__ v2f agc(S &s, const P &p, float re, float im)
         {
             AgcState a{s.gain};
-            const cf32 o = AgcStageT<4>::step(a, p.agc, cf32{re, im});
+            const cf32 o = AgcStageT<4>::template step_t<FAST>(a, p.agc, cf32{re, im});
             s.gain = a.gain;
             return v2f{o.re, o.im};
         }
@@ -803,13 +840,22 @@ namespace sdhip
                     // two taps share one 64-bit register pair; the packed multiply takes either half for both of its lanes (op_sel)
                     const v2f tp{sd_to_vgpr(p.taps[j & ~1]), sd_to_vgpr(p.taps[j | 1])};
                     const v2f tt = (j & 1) ? __builtin_shufflevector(tp, tp, 1, 1) : __builtin_shufflevector(tp, tp, 0, 0);
-                    v2f prod[8]; // the eight products first, then the eight sums: independent neighbours for the VALU pipeline
+                    if constexpr (FAST)
+                    {
 #pragma unroll
-                    for (int r = 0; r < 8; r++)
-                        prod[r] = loc[r + j] * tt;
+                        for (int r = 0; r < 8; r++)
+                            acc[r] = __builtin_elementwise_fma(loc[r + j], tt, acc[r]); // v_pk_fma_f32
+                    }
+                    else
+                    {
+                        v2f prod[8]; // the eight products first, then the eight sums: independent neighbours for the VALU pipeline
 #pragma unroll
-                    for (int r = 0; r < 8; r++)
-                        acc[r] = acc[r] + prod[r];
+                        for (int r = 0; r < 8; r++)
+                            prod[r] = loc[r + j] * tt;
+#pragma unroll
+                        for (int r = 0; r < 8; r++)
+                            acc[r] = acc[r] + prod[r];
+                    }
                 }
                 o = Blk8{make_float4(acc[0].x, acc[0].y, acc[1].x, acc[1].y), make_float4(acc[2].x, acc[2].y, acc[3].x, acc[3].y),
                          make_float4(acc[4].x, acc[4].y, acc[5].x, acc[5].y), make_float4(acc[6].x, acc[6].y, acc[7].x, acc[7].y)};
@@ -852,10 +898,11 @@ namespace sdhip
             return cf32{acc.x, acc.y};
         }
     };
+    using AgcFirStage = AgcFirStageT<false>;
 
     // ORDER (2 / 4 / 8) is a template argument: the detector's form is fixed at compile time, so the per-sample loop carries no
     // test of it and none of the other detectors' code.
-    template <int ORDER, int D = 4>
+    template <int ORDER, int D = 4, bool FAST = false>
     struct CostasStage
     {
         using P = CostasParams;
@@ -907,7 +954,10 @@ namespace sdhip
         {
             // CostasLoopBlock::work, costas_loop.cpp:23-65
             float cs, sn; // cosf(-phase), sinf(-phase): two libm calls in the reference (costas_loop.cpp:26), one fused evaluation here
-            sd_sincosf(-s.phase, sn, cs);
+            if constexpr (FAST)
+                sd_sincosf_fast(-s.phase, sn, cs);
+            else
+                sd_sincosf(-s.phase, sn, cs);
             const float tr = (v.re * cs) - (v.im * sn);
             const float ti = (v.im * cs) + (v.re * sn);
             float error;
@@ -932,15 +982,13 @@ namespace sdhip
             // above the double constant is its own rounding, 6.2831854820251465.
             const double twopi = 2 * 3.14159265358979323846;
             {
+                // ONE double addition of -2 pi, 0 or +2 pi: adding 0.0 and rounding back returns the float itself
                 const float twopi_f = 6.28318548202514648f;
-                const double pd = (double)s.phase;
-                const float dn = (float)(pd - twopi), up = (float)(pd + twopi);
-                s.phase = s.phase >= twopi_f ? dn : (s.phase <= -twopi_f ? up : s.phase);
+                const double step = s.phase >= twopi_f ? -twopi : (s.phase <= -twopi_f ? twopi : 0.0);
+                s.phase = (float)((double)s.phase + step);
             }
-            if (s.freq > p.fmax)
-                s.freq = p.fmax;
-            if (s.freq < p.fmin)
-                s.freq = p.fmin;
+            // if (freq > fmax) freq = fmax; if (freq < fmin) freq = fmin; (fmin <= fmax: v_min / v_max)
+            s.freq = __builtin_fmaxf(__builtin_fminf(s.freq, p.fmax), p.fmin);
             return cf32{tr, ti};
         }
     };
@@ -1325,20 +1373,21 @@ namespace sdhip
     //   AfcFull<O> : AGC + filter + Costas
     // Arithmetic per stage = AgcFirStage / CostasStage, operation for operation (exact mode: bit for bit the reference).
     // =============================================================================================
+    template <bool FAST>
     struct AfcAgcOnly
     {
         using P = AfcParams;
         using S = AfcState;
         static constexpr int DEPTH = 4;
-        __device__ static __forceinline__ Blk8 block(S &s, const P &p, const Blk8 &c, bool) { return AgcFirStage::block(s.af, p.af, c, false); }
-        __device__ static __forceinline__ cf32 step(S &s, const P &p, const cf32 v) { return AgcFirStage::step(s.af, p.af, v); }
+        __device__ static __forceinline__ Blk8 block(S &s, const P &p, const Blk8 &c, bool) { return AgcFirStageT<FAST>::block(s.af, p.af, c, false); }
+        __device__ static __forceinline__ cf32 step(S &s, const P &p, const cf32 v) { return AgcFirStageT<FAST>::step(s.af, p.af, v); }
     };
     struct AfcEstState
     {
         AfcState s;
         float cr, ci, ar, ai, rc, rs; // exp(-j M f n) by recurrence, the running sum, the recurrence's step
     };
-    template <int M>
+    template <int M, bool FAST>
     struct AfcEst
     {
         using P = AfcParams;
@@ -1361,7 +1410,7 @@ namespace sdhip
         }
         __device__ static __forceinline__ Blk8 block(S &e, const P &p, const Blk8 &c, bool)
         {
-            const Blk8 f = AgcFirStage::block(e.s.af, p.af, c, true);
+            const Blk8 f = AgcFirStageT<FAST>::block(e.s.af, p.af, c, true);
             acc(e, f.a.x, f.a.y);
             acc(e, f.a.z, f.a.w);
             acc(e, f.b.x, f.b.y);
@@ -1374,21 +1423,21 @@ namespace sdhip
         }
         __device__ static __forceinline__ cf32 step(S &e, const P &p, const cf32 v)
         {
-            const cf32 f = AgcFirStage::step(e.s.af, p.af, v);
+            const cf32 f = AgcFirStageT<FAST>::step(e.s.af, p.af, v);
             acc(e, f.re, f.im);
             return f;
         }
     };
-    template <int ORDER>
+    template <int ORDER, bool FAST>
     struct AfcFull
     {
         using P = AfcParams;
         using S = AfcState;
-        using Cos = CostasStage<ORDER, 4>;
+        using Cos = CostasStage<ORDER, 4, FAST>;
         static constexpr int DEPTH = 4;
         __device__ static __forceinline__ Blk8 block(S &s, const P &p, const Blk8 &c, bool)
         {
-            const Blk8 f = AgcFirStage::block(s.af, p.af, c, true);
+            const Blk8 f = AgcFirStageT<FAST>::block(s.af, p.af, c, true);
             const cf32 a0 = Cos::step(s.cos, p.cos, cf32{f.a.x, f.a.y});
             const cf32 a1 = Cos::step(s.cos, p.cos, cf32{f.a.z, f.a.w});
             const cf32 a2 = Cos::step(s.cos, p.cos, cf32{f.b.x, f.b.y});
@@ -1400,7 +1449,7 @@ namespace sdhip
             return Blk8{make_float4(a0.re, a0.im, a1.re, a1.im), make_float4(a2.re, a2.im, a3.re, a3.im), make_float4(a4.re, a4.im, a5.re, a5.im),
                         make_float4(a6.re, a6.im, a7.re, a7.im)};
         }
-        __device__ static __forceinline__ cf32 step(S &s, const P &p, const cf32 v) { return Cos::step(s.cos, p.cos, AgcFirStage::step(s.af, p.af, v)); }
+        __device__ static __forceinline__ cf32 step(S &s, const P &p, const cf32 v) { return Cos::step(s.cos, p.cos, AgcFirStageT<FAST>::step(s.af, p.af, v)); }
     };
     __device__ __forceinline__ float sd_wrap_2pi(double ph)
     { // into the loop's own range [-2 pi, 2 pi] (costas_loop.cpp:55-58 keeps it there)
@@ -1415,7 +1464,7 @@ namespace sdhip
     // (exact start state) stops at the first checkpoint at which its AGC has merged with the earlier run's (the AGC certificate's rule)
     // and its carrier loop is inside the Costas windows in the earlier run's frame: from there on the earlier output and end state stand.
     // Warm-up tail and chunk are ONE loop over AfcFull (stores begin at the chunk start, where the state is also left in spec[k]).
-    template <int ORDER>
+    template <int ORDER, bool FAST>
     __global__ __launch_bounds__(64) void k_afc(const cf32 *x, cf32 *y, ChunkGeom g, AfcParams p, const AfcState *start0, AfcState *spec, AfcState *endst,
                                                 const int *redo, int nredo, AfcCkpt *ck, int ck_per_chunk, int ck_len, float tol_phase, float tol_freq)
     {
@@ -1449,7 +1498,7 @@ namespace sdhip
                 const long long never = 1ll << 62;
                 s.af = AgcFirStage::init(p.af, k);
                 s.cos = CostasState{0.0f, p.cos.init_freq};
-                run_range1<AfcAgcOnly>(s, p, x, y, w0, b - g.W, never, 0, 1 << 30, nohook);
+                run_range1<AfcAgcOnly<FAST>>(s, p, x, y, w0, b - g.W, never, 0, 1 << 30, nohook);
                 i0 = b - g.W;
                 if (p.cos.est_len > 0 && ORDER <= 4)
                 {
@@ -1461,7 +1510,7 @@ namespace sdhip
                     e.ci = 0.0f;
                     e.ar = 0.0f;
                     e.ai = 0.0f;
-                    run_range1<AfcEst<M>>(e, p, x, y, i0, i0 + p.cos.est_len, never, 0, 1 << 30, nohook);
+                    run_range1<AfcEst<M, FAST>>(e, p, x, y, i0, i0 + p.cos.est_len, never, 0, 1 << 30, nohook);
                     s = e.s;
                     // BPSK symbols sit on the real axis (x^2 -> +1), QPSK symbols on the diagonals (x^4 -> -1); the sum's angle is M
                     // times the carrier phase at the first sample of the window, the loop takes over est_len samples later
@@ -1474,7 +1523,7 @@ namespace sdhip
         const long long b = chunk_begin(g, k), e = chunk_end(g, k);
         bool merged = false;
         AfcCkpt *cks = ck ? ck + (size_t)k * ck_per_chunk : nullptr;
-        run_range1<AfcFull<ORDER>>(s, p, x, y, i0, e, b, b, ck_len, [&](long long i) -> bool {
+        run_range1<AfcFull<ORDER, FAST>>(s, p, x, y, i0, e, b, b, ck_len, [&](long long i) -> bool {
             if (i < b)
                 return false;
             if (i == b)
@@ -1503,24 +1552,31 @@ namespace sdhip
             endst[k] = s;
     }
     void launch_afc(const cf32 *x, cf32 *y, const ChunkGeom &g, const AfcParams &p, const AfcState *start0, AfcState *spec, AfcState *endst, const int *redo,
-                    int nredo, hipStream_t st, const AfcCkptCfg &ck)
+                    int nredo, hipStream_t st, const AfcCkptCfg &ck, bool fast)
     {
         const int n = redo ? nredo : g.K;
         if (n <= 0)
             return;
         ProfScope _ps("k_afc", st);
-        auto go = [&](auto order) {
+        auto go = [&](auto order, auto fm) {
             constexpr int O = decltype(order)::value;
+            constexpr bool F = decltype(fm)::value;
             // ck_len is also the spacing at which the lane looks for the chunk start (spec snapshot): always a power of two >= 32
-            hipLaunchKernelGGL((k_afc<O>), dim3((n + 63) / 64), dim3(64), 0, st, x, y, g, p, start0, spec, endst, redo, nredo, ck.ck, ck.per_chunk,
+            hipLaunchKernelGGL((k_afc<O, F>), dim3((n + 63) / 64), dim3(64), 0, st, x, y, g, p, start0, spec, endst, redo, nredo, ck.ck, ck.per_chunk,
                                ck.len > 0 ? ck.len : 2048, ck.tol_phase, ck.tol_freq);
         };
-        if (p.cos.order == 2)
-            go(std::integral_constant<int, 2>{});
-        else if (p.cos.order == 4)
-            go(std::integral_constant<int, 4>{});
+        auto by_order = [&](auto fm) {
+            if (p.cos.order == 2)
+                go(std::integral_constant<int, 2>{}, fm);
+            else if (p.cos.order == 4)
+                go(std::integral_constant<int, 4>{}, fm);
+            else
+                go(std::integral_constant<int, 8>{}, fm);
+        };
+        if (fast)
+            by_order(std::true_type{});
         else
-            go(std::integral_constant<int, 8>{});
+            by_order(std::false_type{});
     }
 
     // B_k = sum over the chunk of beta^(len-1-i) * alpha * x_i, in double: thread t takes the samples i = t (mod 256) -- coalesced --
@@ -1820,6 +1876,7 @@ namespace sdhip
 
     // one iteration of MMClockRecoveryBlock<complex_t>::work's loop body, clock_recovery_mm.cpp:54-120; the window
     // [inc-7, inc] must be in the ring
+    template <bool FAST = false>
     __device__ __forceinline__ cf32 mm_iter(MmState &s, const MmParams &p, const cf32 *ring, const float *bank, const float omega_gain, const float mu_gain)
     {
         s.p_2T = s.p_1T;
@@ -1841,8 +1898,13 @@ namespace sdhip
         for (int k = 0; k < 8; k++)
         {
             const cf32 v = ring[((base + k) & (MM_RING - 1)) * MM_RING_STRIDE];
-            const v2f prod = v2f{v.re, v.im} * v2f{t[k], t[k]};
-            acc = acc + prod;
+            if constexpr (FAST)
+                acc = __builtin_elementwise_fma(v2f{v.re, v.im}, v2f{t[k], t[k]}, acc); // chunk-parallel mode's arithmetic (see sd_sincosf_fast)
+            else
+            {
+                const v2f prod = v2f{v.re, v.im} * v2f{t[k], t[k]};
+                acc = acc + prod;
+            }
         }
         const float re = acc.x, im = acc.y;
         s.p_0T.re = re;
@@ -1888,7 +1950,7 @@ namespace sdhip
             return 127;
         return (signed char)(int)x;
     }
-template <bool CKPT, bool SPLIT, bool Q8 = false>
+template <bool CKPT, bool SPLIT, bool Q8 = false, bool FAST = false>
     __global__ __launch_bounds__(64) void k_mm(const cf32 *x, cf32 *sym, int *counts, ChunkGeom g, MmParams p, const MmState *start0, MmState *spec,
                                                MmState *endst, MmCert *spec_c, MmCert *end_c, const int *redo, int nredo, MmCkpt *ck, int ck_per_chunk,
                                                float ck_tol)
@@ -2080,7 +2142,7 @@ template <bool CKPT, bool SPLIT, bool Q8 = false>
                         // trajectory settles onto the sequential one; only speculation -- the boundary certificate decides
                         const bool fast = phase == 0 && wsym < p.fast_syms;
                         wsym++;
-                        const cf32 v = mm_iter(s, p, f.ring, bank, fast ? 0.0f : p.omega_gain, fast ? p.mu_gain * p.fast_mult : p.mu_gain);
+                        const cf32 v = mm_iter<FAST>(s, p, f.ring, bank, fast ? 0.0f : p.omega_gain, fast ? p.mu_gain * p.fast_mult : p.mu_gain);
                         if (phase != 0)
                         {
                             if (cnt + nx < p.cap)
@@ -2111,6 +2173,9 @@ template <bool CKPT, bool SPLIT, bool Q8 = false>
         const bool split = split_env && split_env[0] == '1';
         if (ck && p.q8)
             hipLaunchKernelGGL((k_mm<true, false, true>), dim3((n + 63) / 64), dim3(64), 0, st, x, sym_scratch, counts, g, p, start0, spec, endst, spec_c, end_c,
+                               redo, nredo, ck, ck_per_chunk, ck_tol);
+        else if (ck && p.fast)
+            hipLaunchKernelGGL((k_mm<true, false, false, true>), dim3((n + 63) / 64), dim3(64), 0, st, x, sym_scratch, counts, g, p, start0, spec, endst, spec_c, end_c,
                                redo, nredo, ck, ck_per_chunk, ck_tol);
         else if (ck)
             hipLaunchKernelGGL((k_mm<true, false>), dim3((n + 63) / 64), dim3(64), 0, st, x, sym_scratch, counts, g, p, start0, spec, endst, spec_c, end_c, redo,
