@@ -99,6 +99,8 @@ extern "C"
         int chunk_len; /* speculative chunk length in (resampled) samples; <=0 -> auto */
         int warmup;    /* warm-up overlap per chunk in samples; <=0 -> auto */
         int device;    /* HIP device ordinal */
+        double freq_shift; /* "freq_shift" (Hz; a long in the reference, module_demod_base.cpp:36-37): dsp::FreqShiftBlock between the DC block
+                              and the resampler (module_demod_base.cpp:122-123, freq_shift.cpp:18-46). 0 = none */
     } sdhip_demod_cfg;
 
     typedef struct sdhip_demod_stats

@@ -47,6 +47,7 @@ std::shared_ptr<slog::Logger> logger = std::make_shared<slog::Logger>();
 #include "common/dsp/block.h"
 #include "common/dsp/utils/agc.h"
 #include "common/dsp/utils/correct_iq.h"
+#include "common/dsp/utils/freq_shift.h"
 #include "common/dsp/filter/fir.h"
 #include "common/dsp/filter/firdes.h"
 #include "common/dsp/pll/costas_loop.h"
@@ -680,6 +681,7 @@ extern "C"
         bool is_bpsk = false, is_oqpsk = false, ok = true;
         std::shared_ptr<dsp::stream<complex_t>> in;
         std::shared_ptr<dsp::CorrectIQBlock<complex_t>> dc_blocker;
+        std::shared_ptr<dsp::FreqShiftBlock> freq_shift;
         std::shared_ptr<dsp::SmartResamplerBlock<complex_t>> rresamp;
         std::shared_ptr<dsp::AGCBlock<complex_t>> agc;
         std::shared_ptr<dsp::FIRBlock<complex_t>> rrc;
@@ -725,6 +727,11 @@ extern "C"
             {
                 dc_blocker = std::make_shared<dsp::CorrectIQBlock<complex_t>>(cur);
                 cur = dc_blocker->output_stream;
+            }
+            if (c->freq_shift != 0) // module_demod_base.cpp:122-123 (d_frequency_shift is a long)
+            {
+                freq_shift = std::make_shared<dsp::FreqShiftBlock>(cur, d_samplerate, (double)(long)c->freq_shift);
+                cur = freq_shift->output_stream;
             }
             // SmartResamplerBlock(input, final_samplerate, d_samplerate) (module_demod_base.cpp:204): the reference's own class --
             // power-of-two pre-decimator (power_decim.cpp, its tap tables) + rational resampler as the ratio demands
@@ -780,6 +787,7 @@ extern "C"
             *final_sps_out = ch.final_sps;
         auto &in = ch.in;
         auto &dc_blocker = ch.dc_blocker;
+        auto &freq_shift = ch.freq_shift;
         auto &rresamp = ch.rresamp;
         auto &agc = ch.agc;
         auto &rrc = ch.rrc;
@@ -811,6 +819,7 @@ extern "C"
                 memcpy(in->writeBuf, iq + 2 * pos, (size_t)m * sizeof(complex_t));
             in->swap(m);
             if (dc_blocker) dc_blocker->work();
+            if (freq_shift) freq_shift->work();
             if (rresamp) rresamp->work();
             agc->work();
             rrc->work();
@@ -890,6 +899,7 @@ extern "C"
         int nthreads = 3; // source (caller) + module thread + decoder thread
         const auto t0 = std::chrono::steady_clock::now();
         if (ch.dc_blocker) ch.dc_blocker->start(), nthreads++;
+        if (ch.freq_shift) ch.freq_shift->start(), nthreads++;
         if (ch.rresamp) ch.rresamp->start(), nthreads++;
         ch.agc->start(), nthreads++;
         ch.rrc->start(), nthreads++;
@@ -955,6 +965,7 @@ extern "C"
         }
         module_run.store(false);
         if (ch.dc_blocker) ch.dc_blocker->stop();
+        if (ch.freq_shift) ch.freq_shift->stop();
         if (ch.rresamp) ch.rresamp->stop();
         ch.agc->stop();
         ch.rrc->stop();

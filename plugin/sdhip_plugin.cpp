@@ -103,8 +103,8 @@ namespace sdhip_plugin
             opt(parameters, "iq_swap", b), cfg.iq_swap = b;
             opt(parameters, "min_sps", cfg.min_sps);
             opt(parameters, "max_sps", cfg.max_sps);
-            if (parameters.count("freq_shift") > 0 && parameters["freq_shift"].get<long>() != 0)
-                throw satdump_exception("psk_demod_hip: freq_shift is not on the HIP path, use psk_demod");
+            if (parameters.count("freq_shift") > 0) // module_demod_base.cpp:36-37 (a long)
+                cfg.freq_shift = (double)parameters["freq_shift"].get<long>();
             // custom_samplerate overrides the resample decision (module_demod_base.cpp:73-74): not a field of the C ABI
             if (parameters.count("custom_samplerate") > 0)
                 throw satdump_exception("psk_demod_hip: custom_samplerate is not on the HIP path, use psk_demod");
@@ -634,14 +634,12 @@ namespace sdhip_plugin
                 }
                 else if (e.id == "ccsds_conv_concat_decoder")
                 {
-                    // punctured rates (conv_rate != "1/2", viterbi_punc.cpp): the HIP path is green on the GPU (tests/test_zz_punctured_gpu.py)
-                    // and the explicit ccsds_conv_concat_decoder_hip module takes them; the OVERRIDE still leaves them with the CPU module
-                    // until a pipeline-level run of such a pipeline (tests/minihost) exists. Padded frames stay on the CPU module.
+                    // punctured rates (conv_rate != "1/2", viterbi_punc.cpp) included: tests/test_plugin_minihost_gpu.py runs such a pipeline
+                    // step through this very override. Padded frames (cadu_size % 8 != 0) stay on the CPU module.
                     auto cpu = e.inst;
                     e.inst = [cpu](std::string in, std::string out, nlohmann::json p) -> std::shared_ptr<ProcessingModule> {
-                        const std::string conv = p.count("conv_rate") > 0 ? p["conv_rate"].get<std::string>() : "1/2";
                         const bool padded = p.count("cadu_size") > 0 && p["cadu_size"].get<int>() % 8 != 0;
-                        if (conv != "1/2" || padded)
+                        if (padded)
                             return cpu(in, out, p);
                         return CCSDSConvConcatDecoderHipModule::getInstance(in, out, p);
                     };

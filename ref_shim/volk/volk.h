@@ -76,3 +76,28 @@ static inline volk_func_desc volk_8u_x4_conv_k7_r2_8u_get_func_desc()
     return volk_func_desc{names, nullptr, nullptr, 1};
 }
 static inline void volk_8u_x4_conv_k7_r2_8u_manual(unsigned char *, unsigned char *, unsigned char *, unsigned char *, unsigned, unsigned, unsigned char *, const char *) { abort(); }
+
+// volk_32fc_s32fc_x2_rotator2_32fc, VOLK >= 3.1 (kernels/volk/volk_32fc_s32fc_x2_rotator2_32fc.h, _generic): out = in * phase, phase *= inc
+// per sample, the phase renormalised every ROTATOR_RELOAD = 512 samples and once more at the end of every call that had a remainder.
+// VOLK is a system library outside the reference tree; this is its published generic kernel, float complex products
+// in the plain four-multiply form, hypotf from libm. (VOLK's SIMD variants order the products differently: the oracle pins the generic one.)
+static inline void volk_32fc_s32fc_x2_rotator2_32fc(lv_32fc_t *out, const lv_32fc_t *in, const lv_32fc_t *phase_inc, lv_32fc_t *phase, unsigned int num_points)
+{
+    unsigned int i = 0;
+    for (i = 0; i < num_points / 512; ++i)
+    {
+        for (int j = 0; j < 512; ++j)
+        {
+            *out++ = *in++ * (*phase);
+            (*phase) *= *phase_inc;
+        }
+        (*phase) /= hypotf(phase->real(), phase->imag());
+    }
+    for (i = 0; i < num_points % 512; ++i)
+    {
+        *out++ = *in++ * (*phase);
+        (*phase) *= *phase_inc;
+    }
+    if (i)
+        (*phase) /= hypotf(phase->real(), phase->imag());
+}

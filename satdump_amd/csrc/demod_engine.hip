@@ -460,6 +460,13 @@ namespace sdhip
         CostasState cos_s{0.0f, 0.0f};
         MmState mm_s{};
         DcState dc_s{0, 0}, dc2_s{0, 0}; // dc_block in front / post_costas_dc behind the Costas loop
+        // freq_shift (dsp::FreqShiftBlock): the rotator's phase increment as the reference rounds it, the phase (exact mode), the stream position
+        float rot_dre = 1.0f, rot_dim = 0.0f;
+        RotState rot_s{1.0f, 0.0f};
+        long long rot_abs = 0;
+        unsigned long long rot_fix = 0;
+        float rot_mag_eps = 0.0f;
+        DevBuf<RotState> d_rot_state;
         // AGC and the RRC filter as one stage (AgcFirStage): the filter window travels with the lane state, on the device
         bool fuse_agc_fir = false;
         AgcFirParams af_p{};
@@ -723,6 +730,18 @@ namespace sdhip
             d_mm_start.reserve(1);
             d_dc.reserve(1);
             d_partial.reserve(1024);
+            if (cfg.freq_shift != 0)
+            { // FreqShiftBlock::set_freq (freq_shift.cpp:37-43): phase_delta = (cos, sin)(hz_to_rad(shift, samplerate)) computed in double, stored as floats
+                const double w = 2.0 * design::PI * ((double)(long)cfg.freq_shift / (double)d_samplerate);
+                rot_dre = (float)std::cos(w);
+                rot_dim = (float)std::sin(w);
+                // closed form of the chunk-parallel mode: the increment's own angle in 2^-64 turns, its magnitude excess per step
+                const double ang = std::atan2((double)rot_dim, (double)rot_dre) / (2.0 * design::PI);
+                const long double turns = (long double)(ang < 0 ? ang + 1.0 : ang) * 18446744073709551616.0L;
+                rot_fix = (unsigned long long)turns;
+                rot_mag_eps = (float)(std::sqrt((double)rot_dre * rot_dre + (double)rot_dim * rot_dim) - 1.0);
+                d_rot_state.reserve(1);
+            }
             stats.final_sps = final_sps;
             stats.final_samplerate = final_samplerate;
             stats.buffer_size = d_buffer_size;
@@ -1188,7 +1207,7 @@ namespace sdhip
 
             // ---- stage 0: format conversion (+ iq_swap). cf32 without swap is already the stage format: the first stage reads
             // the caller's buffer in place (16-byte aligned pointers only: the lanes move float4 blocks).
-            const bool in_place = fmt == SDHIP_FMT_CF32 && !cfg.iq_swap && !cfg.dc_block && (reinterpret_cast<uintptr_t>(d_in) & 15) == 0;
+            const bool in_place = fmt == SDHIP_FMT_CF32 && !cfg.iq_swap && !cfg.dc_block && cfg.freq_shift == 0 && (reinterpret_cast<uintptr_t>(d_in) & 15) == 0;
             const cf32 *SRC = A;
             if (in_place)
                 SRC = reinterpret_cast<const cf32 *>(d_in);
@@ -1207,6 +1226,26 @@ namespace sdhip
                 dc_block_chunked(A, B, n, dc_s);
                 std::swap(A, B);
                 SRC = A;
+            }
+            // ---- freq_shift (module_demod_base.cpp:122-123): the rotator, between the DC block and the resampler. The reference calls it once
+            // per source buffer (the file source is built with the module's final d_buffer_size, module_demod_base.cpp:111; file_source.cpp:29)
+            // and the kernel renormalises per call: the stream position carries across calls.
+            if (cfg.freq_shift != 0)
+            {
+                const int src_buf = d_buffer_size;
+                if (cfg.exact)
+                {
+                    SD_HIP(hipMemcpyAsync(d_rot_state.p, &rot_s, sizeof(rot_s), hipMemcpyHostToDevice, stream));
+                    launch_rotator_seq(A, B, n, d_rot_state.p, rot_dre, rot_dim, src_buf, (int)(rot_abs % src_buf), stream);
+                    SD_HIP(hipMemcpyAsync(&rot_s, d_rot_state.p, sizeof(rot_s), hipMemcpyDeviceToHost, stream));
+                    SD_HIP(hipStreamSynchronize(stream));
+                }
+                else
+                    launch_rotator_par(A, B, n, rot_abs, rot_fix, rot_mag_eps, src_buf, stream);
+                rot_abs += n;
+                std::swap(A, B);
+                SRC = A;
+                tick("freq_shift");
             }
             // ---- SmartResampler: power-of-two pre-decimator stages (if the ratio has them), then the rational resampler
             bool in_place_r = in_place;

@@ -41,6 +41,21 @@ namespace sdhip
     // ---- format conversion (baseband_interface.h:172-199) + iq_swap --------------------------------
     void launch_convert(const void *in, int fmt, int iq_swap, long long n, cf32 *out, hipStream_t st);
 
+    // ---- frequency shift (dsp::FreqShiftBlock, freq_shift.cpp:18-46 -> VOLK's rotator2: out = in * phase, phase *= phase_delta per sample,
+    // the phase renormalised every 512 samples of a call and at the end of every call; the reference calls it once per source buffer) ----
+    struct RotState
+    {
+        float re, im; // the rotator's phase
+    };
+    // exact: one sequential lane, the generic kernel's float operations in its order, `calls` of buf_len samples (pos0 = samples of the
+    // current call already consumed by earlier launches)
+    void launch_rotator_seq(const cf32 *x, cf32 *y, long long n, RotState *state, float dre, float dim, int buf_len, int pos0, hipStream_t st);
+    // chunk-parallel mode: closed form, one thread per sample. Phase = (absolute sample index) * f in 64-bit fixed-point turns (exact,
+    // no drift), magnitude = the sawtooth |phase_delta|^(position inside the 512-sample run) the reference's renormalisation leaves
+    // (up to 3e-5: it must be there for the 1e-5 contract); what the reference's float recurrence adds on top is a slowly varying phase
+    // offset, which the carrier loop behind it tracks out.
+    void launch_rotator_par(const cf32 *x, cf32 *y, long long n, long long abs0, unsigned long long f_fix, float mag_eps, int buf_len, hipStream_t st);
+
     // ---- DC block (correct_iq.cpp:27-31): acc = acc * (1 - alpha) + x * alpha; y = x - acc, alpha = 1e-4 ------------
     struct DcState
     {

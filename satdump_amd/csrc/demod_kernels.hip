@@ -231,6 +231,70 @@ namespace sdhip
     }
 
     // =============================================================================================
+    // frequency shift (demod_kernels.h)
+    // =============================================================================================
+    __global__ void k_rotator_seq(const cf32 *x, cf32 *y, long long n, RotState *state, float dre, float dim, int buf_len, int pos0)
+    {
+        if (threadIdx.x != 0 || blockIdx.x != 0)
+            return;
+        float pr = state->re, pi = state->im;
+        auto renorm = [&]() { // phase /= hypotf(re, im): glibc's hypotf takes the root in double and narrows
+            const float h = (float)sqrt((double)pr * (double)pr + (double)pi * (double)pi);
+            pr = pr / h;
+            pi = pi / h;
+        };
+        int pos = pos0; // samples of the current call consumed so far
+        for (long long i = 0; i < n; i++)
+        {
+            const float xr = x[i].re, xi = x[i].im;
+            y[i].re = xr * pr - xi * pi;
+            y[i].im = xr * pi + xi * pr;
+            const float nr = pr * dre - pi * dim, ni = pr * dim + pi * dre;
+            pr = nr;
+            pi = ni;
+            pos++;
+            if (pos == buf_len)
+            { // end of a call: a 512-sample run that just completed has been renormalised by the run loop, a remainder by the tail rule
+                renorm();
+                pos = 0;
+            }
+            else if ((pos & 511) == 0)
+                renorm();
+        }
+        state->re = pr;
+        state->im = pi;
+    }
+    void launch_rotator_seq(const cf32 *x, cf32 *y, long long n, RotState *state, float dre, float dim, int buf_len, int pos0, hipStream_t st)
+    {
+        ProfScope _ps("k_rotator_seq", st);
+        hipLaunchKernelGGL(k_rotator_seq, dim3(1), dim3(64), 0, st, x, y, n, state, dre, dim, buf_len, pos0);
+    }
+    __global__ __launch_bounds__(256) void k_rotator_par(const cf32 *x, cf32 *y, long long n, long long abs0, unsigned long long f_fix, float mag_eps, int buf_len)
+    {
+        const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+        if (i >= n)
+            return;
+        const unsigned long long a = (unsigned long long)(abs0 + i);
+        const unsigned long long turns = a * f_fix;                                       // phase in 2^-64 turns, exact modulo one turn
+        const float ang = (float)(int)(unsigned)(turns >> 32) * 1.46291807926715968105e-9f; // * 2 pi / 2^32: [-pi, pi)
+        float sn, cs;
+        sd_sincosf_fast(ang, sn, cs);
+        const int run = (int)(a % (unsigned long long)buf_len) & 511; // steps since the last renormalisation
+        const float m = 1.0f + (float)run * mag_eps;
+        cs *= m;
+        sn *= m;
+        const cf32 v = x[i];
+        y[i] = cf32{v.re * cs - v.im * sn, v.re * sn + v.im * cs};
+    }
+    void launch_rotator_par(const cf32 *x, cf32 *y, long long n, long long abs0, unsigned long long f_fix, float mag_eps, int buf_len, hipStream_t st)
+    {
+        if (n <= 0)
+            return;
+        ProfScope _ps("k_rotator_par", st);
+        hipLaunchKernelGGL(k_rotator_par, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, y, n, abs0, f_fix, mag_eps, buf_len);
+    }
+
+    // =============================================================================================
     // rational resampler: output m uses inputs [inc-(nt-1), inc] with phase ctr (sequential-order dot product)
     // =============================================================================================
     typedef float v2f __attribute__((ext_vector_type(2))); // (re, im) pair: mul / add map to v_pk_mul_f32 / v_pk_add_f32

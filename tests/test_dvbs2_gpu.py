@@ -97,7 +97,7 @@ def test_sse_batches_share_one_early_exit(capi, fs, rate):
 
 def test_device_entry_and_many_frames(capi):
     """sdhip_ldpc_decode_dev on frames resident in HBM, a few hundred frames (more workgroups than CUs), normal 2/3 (BASELINE configs[4]'s
-    MODCOD 13): identical to the reference on a sample of them, every converged frame carries its data (size-independent property)."""
+    MODCOD 13): identical to the reference on all of them, and (size-independent property) the converged frames carry their data."""
     import torch
     ref = _ref(False)
     rc = capi.S2_RATES["2/3"]
@@ -109,11 +109,14 @@ def test_device_entry_and_many_frames(capi):
     dec = capi.LdpcDecoder(framesize=0, rate="2/3", batch=1)
     dec.decode_dev(d.data_ptr(), nf, 20, d_tr.data_ptr())
     got, tr = d.cpu().numpy(), d_tr.cpu().numpy()
-    want, wt = ref.ldpc_decode(0, rc, soft[:24], 20)
-    assert np.array_equal(tr[:24], wt) and np.array_equal(got[:24], want)
+    want, wt = ref.ldpc_decode(0, rc, soft, 20)  # ~10 s of one host core
+    assert np.array_equal(tr, wt) and np.array_equal(got, want)
     conv = tr >= 0
     assert conv.mean() > 0.9
-    assert np.array_equal((got[conv][:, :k] < 0).astype(np.uint8), bits[conv][:, :k])
+    # (a frame can "converge" onto a neighbouring code word -- here one of 600 ends two data bits off, in the reference too: that is what
+    # the BCH outer code behind the decoder is for)
+    right = [np.array_equal(got[i, :k] < 0, bits[i, :k] > 0) for i in np.flatnonzero(conv)]
+    assert np.mean(right) > 0.99
 
 
 def bch_case(capi, ref, fs, rate, errs, seed=3):

@@ -190,3 +190,26 @@ def test_has_carrier_pipeline_parameters_through_the_plugin(host, tmp_path):
     # fails and the CPU module is kept, which then raises its own error at init
     job2 = dict(job, instantiate_only=True, demod={"module": "psk_demod", "parameters": dict(params, constellation="qpsk")})
     assert _run(host, job2, tmp_path)["demod_class"] == "cpu:psk_demod"
+
+
+@pytest.mark.parametrize("rate,code", [("3/4", 2), ("7/8", 4)])
+def test_punctured_conv_rate_through_the_override(host, tmp_path, rate, code):
+    """A pipeline step with conv_rate != 1/2 (Viterbi_Depunc, module_ccsds_conv_concat_decoder.cpp:93-119) under SDHIP_OVERRIDE=1: the stock
+    id `ccsds_conv_concat_decoder` now resolves to the HIP module for it too and writes what the reference decodes
+    from the same .soft file, EOF behaviour included."""
+    orc = pyref.best()
+    soft, plain = util.punctured_case(code, nframes=24, sigma=18.0, seed=3)
+    inp = tmp_path / "in.soft"
+    soft.tofile(str(inp))
+    params = {"constellation": "bpsk", "cadu_size": 8192, "viterbi_ber_thresold": 0.3, "viterbi_outsync_after": 20, "derandomize": True, "nrzm": False, "rs_i": 4,
+              "rs_type": "rs223", "rs_usecheck": True, "conv_rate": rate}
+    job = {"mode": "file", "input": str(inp), "output_hint": str(tmp_path / "punc"), "demod": {"module": "ccsds_conv_concat_decoder", "parameters": params}}
+    rep = _run(host, job, tmp_path)
+    assert rep["demod_class"] == "ccsds_conv_concat_decoder_hip"
+    got = np.fromfile(rep["soft"], dtype=np.uint8).reshape(-1, 1024)  # minihost reports the first module's output under "soft"
+    nfull, rem = divmod(len(soft), 8192)
+    prev = soft[(nfull - 1) * 8192:nfull * 8192]
+    ext = np.concatenate([soft[:nfull * 8192], soft[nfull * 8192:], prev[rem:]])
+    want = orc.concat_decode(pyref.fec_cfg(constellation=pyref.BPSK, nrzm=0, rs_usecheck=1, conv_rate=code), ext)["cadu"]
+    assert got.shape == want.shape and np.array_equal(got, want), (got.shape, want.shape)
+    assert len(got) >= 20
