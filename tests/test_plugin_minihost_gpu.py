@@ -213,3 +213,25 @@ def test_punctured_conv_rate_through_the_override(host, tmp_path, rate, code):
     want = orc.concat_decode(pyref.fec_cfg(constellation=pyref.BPSK, nrzm=0, rs_usecheck=1, conv_rate=code), ext)["cadu"]
     assert got.shape == want.shape and np.array_equal(got, want), (got.shape, want.shape)
     assert len(got) >= 20
+
+
+def test_freq_shift_through_the_override(host, tmp_path):
+    """A baseband file recorded 100 kHz off, `freq_shift` in the stock psk_demod's parameters under SDHIP_OVERRIDE=1: the HIP module keeps the
+    run (it used to hand every freq_shift pipeline back to the CPU module) and the CADUs are the reference's."""
+    orc = pyref.best()
+    if not pyref.ref_available():
+        pytest.skip("needs the compiled reference (its FreqShiftBlock)")
+    x, ocfg, ofec, plain = _goes(30)
+    shift = 100000
+    x = (x * np.exp(-2j * np.pi * shift / 3e6 * np.arange(len(x)))).astype(np.complex64)
+    inp = tmp_path / "bb.cf32"
+    x.tofile(str(inp))
+    job = {"mode": "file", "input": str(inp), "output_hint": str(tmp_path / "fs"),
+           "demod": {"module": "psk_demod", "parameters": dict(GOES_DEMOD, baseband_format="cf32", freq_shift=shift)},
+           "decoder": {"module": "ccsds_conv_concat_decoder", "parameters": GOES_DEC}}
+    rep = _run(host, job, tmp_path)
+    assert rep["demod_class"] == "psk_demod_hip"
+    ocfg.freq_shift = float(shift)
+    got = np.fromfile(rep["cadu"], dtype=np.uint8).reshape(-1, 1024)
+    want = _ref_cadus_of_file(pyref.ref(), ocfg, ofec, x)
+    assert got.shape == want.shape and np.array_equal(got, want) and len(got) >= 26
