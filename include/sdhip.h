@@ -205,6 +205,10 @@ extern "C"
     /* viterbi::CCDecoder::work chained over nblocks (cc_decoder.cpp:295-302). d_syms: per block
        2*(frame_bits+6) unsigned soft symbols (device). d_out: frame_bits bytes/block, one bit per byte. */
     int sdhip_op_ccdecoder(int device, int frame_bits, const uint8_t *d_syms, int nblocks, uint8_t *d_out);
+    /* viterbi::Viterbi27::work over nframes consecutive calls of one decoder (src-core/common/codings/viterbi/viterbi27.cpp:31-66; the
+       decoder of the Meteor LRPT / Inmarsat plugin modules): d_soft = nframes x 2*frame_bits int8 soft symbols, d_out = nframes x
+       frame_bits/8 bytes, ber_out (host, may be NULL) = Viterbi27::ber() after each call. CCSDS polys {79, 109} only; soft input only. */
+    int sdhip_op_viterbi27(int device, int frame_bits, int ber_test_size, const int8_t *d_soft, int nframes, uint8_t *d_out, float *ber_out);
     /* reedsolomon::ReedSolomon::decode_interlaved over nframes (reedsolomon.cpp:53-116). d_data points at
        the first codeblock byte of frame 0 (cadu+4); errors: nframes*I ints (device). fill_bytes as in the reference. */
     int sdhip_op_rs_decode(int device, uint8_t *d_data, int nframes, int frame_stride, int dualbasis, int I, int rs_type, int fill_bytes, int *d_errors);

@@ -303,6 +303,15 @@ class Ref(_Lib):
         nsym = n if cfg.constellation == BPSK else n // 2
         return {"soft": soft[:n], "syms": None if syms is None else syms[:nsym], "buffer_size": bs.value, "final_sps": sps.value}
 
+    def viterbi27(self, frame_bits: int, soft: np.ndarray, ber_test_size: int = 1024):
+        """viterbi::Viterbi27::work over consecutive frames of 2 * frame_bits soft symbols -> (bytes [nframes, frame_bits / 8], ber per call)."""
+        s = np.ascontiguousarray(soft, dtype=np.int8)
+        nf = len(s) // (2 * frame_bits)
+        out = np.zeros((nf, frame_bits // 8), dtype=np.uint8)
+        ber = np.zeros(nf, dtype=np.float32)
+        self.lib.sdref_viterbi27(C.c_int(frame_bits), C.c_int(ber_test_size), _p(s), C.c_int(nf), _p(out), _p(ber))
+        return out, ber
+
     def pipeline_threaded(self, dcfg: DemodCfg, fcfg: FecCfg, decoder: int, iq: np.ndarray, keep_soft: bool = False):
         """psk_demod + decoder in the reference's own run-time topology (a thread per DSP block, module thread, decoder
         thread; oracle/ref_wrap.cpp sdref_pipeline_threaded). Compiled reference only. -> dict(cadu, seconds, threads, nsoft

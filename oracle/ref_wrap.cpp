@@ -46,6 +46,7 @@ std::shared_ptr<slog::Logger> logger = std::make_shared<slog::Logger>();
 
 #include "common/dsp/block.h"
 #include "common/dsp/utils/agc.h"
+#include "common/codings/viterbi/viterbi27.h"
 #include "common/dsp/utils/correct_iq.h"
 #include "common/dsp/utils/freq_shift.h"
 #include "common/dsp/filter/fir.h"
@@ -123,6 +124,19 @@ extern "C"
     {
         viterbi::CCEncoder enc(nbits, 7, 2, {79, 109});
         enc.work((uint8_t *)bits, out);
+    }
+
+    // Viterbi27::work over nframes consecutive calls of one decoder (viterbi27.cpp:31-66), CCSDS polys
+    void sdref_viterbi27(int frame_bits, int ber_test_size, const int8_t *soft, int nframes, uint8_t *out, float *ber)
+    {
+        viterbi::Viterbi27 *v = zero_new<viterbi::Viterbi27>(frame_bits, viterbi::CCSDS_R2_K7_POLYS, ber_test_size);
+        for (int f = 0; f < nframes; f++)
+        {
+            v->work((int8_t *)soft + (size_t)f * 2 * frame_bits, out + (size_t)f * (frame_bits / 8));
+            if (ber)
+                ber[f] = v->ber();
+        }
+        zero_delete(v);
     }
 
     void sdref_derand(uint8_t *data, int len) { derand_ccsds(data, len); }

@@ -109,6 +109,8 @@ def lib():
         L.sdhip_fec_cfg_default.argtypes = [C.POINTER(FecCfg)]
         L.sdhip_op_ccdecoder.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
         L.sdhip_op_rs_decode.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        if hasattr(L, "sdhip_op_viterbi27"):
+            L.sdhip_op_viterbi27.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         if hasattr(L, "sdhip_demod_create"):
             L.sdhip_demod_create.restype = C.c_void_p
             L.sdhip_demod_create.argtypes = [C.POINTER(DemodCfg)]

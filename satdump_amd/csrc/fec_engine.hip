@@ -194,6 +194,16 @@ namespace sdhip
         out[i] = (unsigned char)((vbits[(size_t)j * wpb + (n >> 5)] >> (31 - (n & 31))) & 1u);
     }
 
+    // decoded bits of a block, packed MSB first 32 per word, as the bytes Viterbi27::work's repack loop writes (viterbi27.cpp:43-55)
+    __global__ void k_words_to_bytes(const unsigned *vbits, int wpb, int bytes_per_blk, int nblk, unsigned char *out)
+    {
+        const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+        if (i >= (long long)nblk * bytes_per_blk)
+            return;
+        const int j = (int)(i / bytes_per_blk), b = (int)(i % bytes_per_blk);
+        out[i] = (unsigned char)((vbits[(size_t)j * wpb + (b >> 2)] >> (24 - 8 * (b & 3))) & 0xFFu);
+    }
+
     // raw (pre NRZ-M) bits [from, from + nbits) of a logical stream -> new carry buffer (word aligned at its start)
     __global__ void k_make_carry(BitStream bs, long long from, int nwords, unsigned *out)
     {
@@ -1915,6 +1925,71 @@ extern "C"
         if (blk_state)
             memcpy(blk_state, e->tap_state.data(), n * sizeof(int));
         return (int64_t)e->tap_ber.size();
+    }
+
+    // viterbi::Viterbi27::work over nframes consecutive calls (viterbi27.cpp:31-66: signed_soft_to_unsigned, CCDecoder::work with the 12
+    // erasure symbols hard_buffer keeps behind the frame, MSB-first repack, re-encode BER x 4 over ber_test_size symbols), CCSDS polys
+    int sdhip_op_viterbi27(int device, int frame_bits, int ber_test_size, const int8_t *d_soft, int nframes, uint8_t *d_out, float *ber_out)
+    {
+        SD_GUARD_BEGIN
+        SD_HIP(hipSetDevice(device));
+        if (frame_bits < 64 || frame_bits % 32 || ber_test_size < 2 || ber_test_size % 2 || ber_test_size > 2 * frame_bits)
+            throw HipError("viterbi27: frame_bits must be a multiple of 32 and ber_test_size even, <= 2 * frame_bits");
+        if (nframes <= 0)
+            return 0;
+        VitCfg vc{};
+        vc.mode = 0; // signed soft symbols, no rotation: utils.cpp:3-12
+        vc.F = frame_bits;
+        vc.B = 2 * frame_bits;
+        vc.nber = ber_test_size / 2;
+        vc.nenc = ber_test_size / 2;
+        const int wpb = vit_words_per_block(frame_bits);
+        const int dstride = (frame_bits + 6 + 63) / 64 * 64;
+        DevBuf<VitBlockIO> d_io;
+        DevBuf<uint64_t> d_dec;
+        DevBuf<uint32_t> d_vb;
+        d_io.reserve(nframes);
+        d_vb.reserve((size_t)nframes * wpb + 4);
+        std::vector<VitBlockIO> io(nframes);
+        for (int j = 0; j < nframes; j++)
+            io[j].start_in = -1;
+        io[0].start_in = -2;
+        SD_HIP(hipMemcpy(d_io.p, io.data(), io.size() * sizeof(VitBlockIO), hipMemcpyHostToDevice));
+        Vit2Work vit2;
+        const bool v2 = vit2_supported(vc) && !(getenv("SDHIP_VIT2") && atoi(getenv("SDHIP_VIT2")) == 0);
+        if (v2)
+            launch_vit_decode2(vc, d_soft, 0, nframes, d_io.p, d_vb.p, vit2, nullptr);
+        else
+        {
+            d_dec.reserve((size_t)nframes * dstride);
+            launch_vit_decode(vc, d_soft, 0, nframes, d_io.p, d_dec.p, d_vb.p, nullptr);
+        }
+        SD_HIP(hipMemcpy(io.data(), d_io.p, io.size() * sizeof(VitBlockIO), hipMemcpyDeviceToHost));
+        d_dec.reserve((size_t)dstride);
+        auto redo = [&](int j, int start) {
+            VitBlockIO one{};
+            one.start_in = start;
+            SD_HIP(hipMemcpy(d_io.p + j, &one, sizeof(one), hipMemcpyHostToDevice));
+            launch_vit_decode(vc, d_soft, j, 1, d_io.p + j, d_dec.p, d_vb.p + (size_t)j * wpb, nullptr);
+            SD_HIP(hipMemcpy(&io[j], d_io.p + j, sizeof(one), hipMemcpyDeviceToHost));
+        };
+        for (int j = 0; j < nframes; j++)
+        {
+            if (io[j].tb_fallback == 2)
+                redo(j, io[j].start_used);
+            if (j > 0 && io[j].start_used != io[j - 1].ret_state)
+                redo(j, io[j - 1].ret_state);
+        }
+        launch_vit_ber(vc, d_soft, 0, nframes, d_vb.p, 0u, d_io.p, nullptr);
+        const long long nbytes = (long long)nframes * (frame_bits / 8);
+        hipLaunchKernelGGL(k_words_to_bytes, dim3((unsigned)((nbytes + 255) / 256)), dim3(256), 0, nullptr, d_vb.p, wpb, frame_bits / 8, nframes, d_out);
+        SD_HIP(hipMemcpy(io.data(), d_io.p, io.size() * sizeof(VitBlockIO), hipMemcpyDeviceToHost));
+        if (ber_out)
+            for (int j = 0; j < nframes; j++)
+                ber_out[j] = ((float)io[j].ber_err / (float)ber_test_size) * 4.0f;
+        SD_HIP(hipDeviceSynchronize());
+        return 0;
+        SD_GUARD_END(-1)
     }
 
     int sdhip_op_ccdecoder(int device, int frame_bits, const uint8_t *d_syms, int nblocks, uint8_t *d_out)

@@ -243,3 +243,27 @@ def test_simple_psk_decoder(torch_cuda, capi, orc, name, sigma, usecheck):
     for a, b in zip(bounds[:-1], bounds[1:]):
         dec.push(soft[a:b])
     assert np.array_equal(dec.pull(), want["cadu"])
+
+
+@pytest.mark.parametrize("sigma", [15.0, 40.0, 70.0])
+def test_viterbi27(torch_cuda, capi, orc, sigma):
+    """viterbi::Viterbi27 (viterbi27.cpp: the decoder of the Meteor LRPT / Inmarsat plugin modules = CCDecoder on 2 F soft symbols with an
+    erasure tail + MSB-first repack + re-encode BER x 4) as sdhip_op_viterbi27: six chained calls, clean / noisy / hopeless input with
+    erased symbols in it -- decoded bytes and the per-call ber() bit-identical to the reference's."""
+    import ctypes as C
+    from oracle import pyref
+    if not pyref.ref_available():
+        pytest.skip("needs the compiled reference (viterbi27.cpp)")
+    F, nf = 8192, 6
+    rng = np.random.default_rng(5)
+    tx = synth.conv_encode(rng.integers(0, 2, nf * F, dtype=np.uint8))
+    soft = np.clip(np.rint((tx.astype(float) * 2 - 1) * 60 + rng.standard_normal(len(tx)) * sigma), -127, 127).astype(np.int8)
+    soft[5] = 0
+    soft[100:140] = 0
+    want, wber = pyref.ref().viterbi27(F, soft, 1024)
+    d_soft = torch_cuda.from_numpy(soft).cuda()
+    d_out = torch_cuda.zeros((nf, F // 8), dtype=torch_cuda.uint8, device="cuda")
+    ber = np.zeros(nf, dtype=np.float32)
+    rc = capi.lib().sdhip_op_viterbi27(0, F, 1024, C.c_void_p(d_soft.data_ptr()), nf, C.c_void_p(d_out.data_ptr()), ber.ctypes.data_as(C.c_void_p))
+    assert rc == 0, capi.lib().sdhip_last_error()
+    assert np.array_equal(d_out.cpu().numpy(), want) and np.array_equal(ber, wber)
