@@ -835,10 +835,14 @@ namespace sdhip
             // failing boundaries needs up to r rounds. Short runs (a glitch, a fade) are resolved exactly; where failures persist
             // beyond max_rounds the signal is not locked at all (noise before / after a pass) and the remaining boundaries are
             // let through (VerdictOut::forced): K rounds on pure noise would mean K launches of one lane each.
+            // A short run that outlasts max_rounds -- the handful of chunks whose warm-ups straddle a level or frequency step of the signal
+            // (the fused stage's warm-up spans several short chunks) -- is still resolved exactly, up to 4 x max_rounds: what marks the
+            // unlocked case is that MANY boundaries keep failing.
             const unsigned max_rounds = (unsigned)env_int("SDHIP_MAX_ROUNDS", 4);
+            int last_nf = 1 << 30;
             for (;;)
             {
-                const int force = rounds >= max_rounds ? 1 : 0;
+                const int force = (rounds >= max_rounds && (last_nf > std::max(8, K / 64) || rounds >= 4 * max_rounds)) ? 1 : 0;
                 SD_HIP(hipMemsetAsync(d_vout.p, 0, sizeof(VerdictOut), stream));
                 verdict(d_vout.p, d_fails.p, force);
                 SD_HIP(hipMemcpyAsync(h_vout.p, d_vout.p, sizeof(VerdictOut), hipMemcpyDeviceToHost, stream));
@@ -856,6 +860,7 @@ namespace sdhip
                 }
                 if (nf == 0)
                     break;
+                last_nf = nf;
                 ++rounds;
                 reruns += (unsigned)nf;
                 specfix(d_fails.p, nf);
@@ -1039,13 +1044,20 @@ namespace sdhip
             if (!started)
             {
                 const int classic = order > 4 ? 1 : 0;
-                const long long m = std::min<long long>(n - 64, classic ? 1 << 18 : 1 << 20);
+                const long long m = std::min<long long>(n, classic ? 1 << 18 : 1 << 20);
                 cos_p.init_freq = 0.0f;
                 if (m > 4096)
                 {
-                    d_fe_tmp.reserve(2 * (size_t)m + 64);
+                    // the estimator wants what the stand-alone Costas stage would see: level-normalised, matched-filtered samples (on the raw
+                    // samples a level step in the stream lets the strong part outvote the rest and the unambiguous lag-1 value goes wrong --
+                    // found by tests/test_demod_emu_cpu.py's amplitude_step scenario). The AGC + filter stage over the prefix, its chunks
+                    // speculative and unverified: this only seeds the warm-ups' start frequency.
+                    d_fe_tmp.reserve(2 * ((size_t)m + 64) + 64);
                     cf32 *tmp = reinterpret_cast<cf32 *>(d_fe_tmp.p);
-                    launch_fir(in + 64, tmp, m, d_rrc.p, rrc_ntaps, stream); // window [64 - 30, ...) lies inside the call's samples
+                    const ChunkGeom fg = make_geom(m, pick_L(m, ST_AGC), (int)Wa);
+                    d_af_spec.reserve(fg.K);
+                    d_af_end.reserve(fg.K);
+                    launch_agc_fir(in, tmp, fg, af_p, d_af_start.p, d_af_spec.p, d_af_end.p, nullptr, 0, stream);
                     const int lag = (int)std::min(16.0, std::max(2.0, std::floor(2.0 * final_sps + 0.5)));
                     ProfScope _ps("k_freq_est", stream);
                     hipLaunchKernelGGL(k_freq_est, dim3(64), dim3(256), 0, stream, tmp, m, order, lag, classic, d_partial.p);
@@ -1083,6 +1095,7 @@ namespace sdhip
             // and nothing at 20 (0.00393 against 0.00389 beyond 1e-5).
             const double taus = (double)env_int("SDHIP_COSTAS_TAUS", 20);
             long long W = cfg.warmup > 0 ? cfg.warmup : (long long)std::max(512.0, taus / (1.414 * std::max(1e-5f, cfg.pll_bw)));
+            const long long w_first = (W + 255) / 256 * 256;
             W = std::max(W, w_cos_learned);
             W = env_int("SDHIP_W_COSTAS", W);
             W = (std::min<long long>(W, w_cos_cap) + 255) / 256 * 256;
@@ -1145,8 +1158,9 @@ namespace sdhip
                     const float med = fr[fr.size() / 2];
                     if (std::fabs(med - cos_p.init_freq) > 0.05f * cfg.pll_bw)
                         cos_p.init_freq = med;
-                    else if (cfg.warmup <= 0 && !getenv("SDHIP_W_COSTAS") && 2 * (long long)cg.W <= w_cos_cap)
-                        w_cos_learned = 2 * (long long)cg.W;
+                    else if (cfg.warmup <= 0 && !getenv("SDHIP_W_COSTAS") && 2 * (long long)cg.W <= std::min(w_cos_cap, 4 * w_first))
+                        w_cos_learned = 2 * (long long)cg.W; // (at most twice: a stream that still misses is not locked -- noise -- and every
+                                                             // further doubling would only multiply the work of lanes that cannot merge)
                     else
                         return false;
                     setup(std::max<long long>(cg.W, w_cos_learned));

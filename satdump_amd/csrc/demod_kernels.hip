@@ -2235,7 +2235,10 @@ template <bool CKPT, bool SPLIT, bool Q8 = false, bool FAST = false>
         ProfScope _ps("k_mm", st);
         const char *split_env = getenv("SDHIP_MM_SPLIT");
         const bool split = split_env && split_env[0] == '1';
-        if (ck && p.q8)
+        if (ck && p.q8 && p.fast)
+            hipLaunchKernelGGL((k_mm<true, false, true, true>), dim3((n + 63) / 64), dim3(64), 0, st, x, sym_scratch, counts, g, p, start0, spec, endst, spec_c, end_c,
+                               redo, nredo, ck, ck_per_chunk, ck_tol);
+        else if (ck && p.q8)
             hipLaunchKernelGGL((k_mm<true, false, true>), dim3((n + 63) / 64), dim3(64), 0, st, x, sym_scratch, counts, g, p, start0, spec, endst, spec_c, end_c,
                                redo, nredo, ck, ck_per_chunk, ck_tol);
         else if (ck && p.fast)

@@ -36,65 +36,98 @@ namespace sdhip
 
     __device__ __forceinline__ int q8(int v) { return v < -128 ? -128 : (v > 127 ? 127 : v); }
 
-    // one check node: OffsetMinSumAlgorithm::finalp + update + the add back, layered_decoder.hh:53-77
+    // one check node: OffsetMinSumAlgorithm::finalp + update + the add back, layered_decoder.hh:53-77. Split in three so that a layer
+    // whose checks run in dependent phases (shared data bits) pays the HBM latency of the message words and the L2 latency of the bit
+    // addresses ONCE, before its first phase, not once per phase: load (every thread of the layer at once) / update (the phase's
+    // threads: LDS and registers only) / store.
     template <int DQ>
-    __device__ __forceinline__ void ldpc_check(const LdpcDev &g, signed char *llr, unsigned *bnl_f, int i, int j)
+    struct LdpcCheck
     {
-        const int cnt = g.cnc[i];
-        const int deg = cnt + 2 - ((i | j) == 0 ? 1 : 0);
-        unsigned bw[DQ];
-#pragma unroll
-        for (int w = 0; w < DQ; w++)
-            bw[w] = 4 * w < deg ? bnl_f[((size_t)i * DQ + w) * g.M + j] : 0u;
-        const int par0 = g.K + g.M * i + j;
-        const int par1 = i ? g.K + g.M * (i - 1) + j : g.K + (g.q - 1) * g.M + j - 1;
-        auto node = [&](int d) -> int { return d < cnt ? (int)g.pos[((size_t)i * g.CNL + d) * g.M + j] : (d == cnt ? par0 : par1); };
-        int min0 = 255, min1 = 255;
-        unsigned signs = 0;
-#pragma unroll
-        for (int w = 0; w < DQ; w++)
-#pragma unroll
-            for (int b = 0; b < 4; b++)
-            {
-                const int d = 4 * w + b;
-                if (d < deg)
-                {
-                    const int inp = q8((int)llr[node(d)] - (int)(signed char)(bw[w] >> (8 * b)));
-                    int mag = inp < -127 ? 127 : (inp < 0 ? -inp : inp); // vqabs
-                    mag = mag > 0 ? mag - 1 : 0;                          // unsigned saturating - beta, beta = nearbyint(0.5 * 2) = 1
-                    // mins[1] = min(mins[1], max(mins[0], mag)); mins[0] = min(mins[0], mag) (the first two: min / max of the pair)
-                    const int hi = mag > min0 ? mag : min0;
-                    min1 = hi < min1 ? hi : min1;
-                    min0 = mag < min0 ? mag : min0;
-                    signs ^= (unsigned)inp;
-                }
-            }
-#pragma unroll
-        for (int w = 0; w < DQ; w++)
+        unsigned bw[DQ];         // check-to-bit messages, four per dword
+        unsigned nd[2 * DQ];     // node indices of the links, two per dword
+        int deg;
+        __device__ __forceinline__ void load(const LdpcDev &g, const unsigned *bnl_f, int i, int j)
         {
-            unsigned nw = 0;
+            const int cnt = g.cnc[i];
+            deg = cnt + 2 - ((i | j) == 0 ? 1 : 0);
+            const int par0 = g.K + g.M * i + j;
+            const int par1 = i ? g.K + g.M * (i - 1) + j : g.K + (g.q - 1) * g.M + j - 1;
 #pragma unroll
-            for (int b = 0; b < 4; b++)
+            for (int w = 0; w < DQ; w++)
+                bw[w] = 4 * w < deg ? bnl_f[((size_t)i * DQ + w) * g.M + j] : 0u;
+#pragma unroll
+            for (int h = 0; h < 2 * DQ; h++)
             {
-                const int d = 4 * w + b;
-                if (d < deg)
+                unsigned v = 0;
+#pragma unroll
+                for (int b = 0; b < 2; b++)
                 {
-                    const int nd = node(d);
-                    const int inp = q8((int)llr[nd] - (int)(signed char)(bw[w] >> (8 * b)));
-                    int mag = inp < -127 ? 127 : (inp < 0 ? -inp : inp);
-                    mag = mag > 0 ? mag - 1 : 0;
-                    const int other = mag == min0 ? min1 : min0;
-                    const bool neg = ((signs ^ (unsigned)inp) & 0x80u) != 0; // sign(other, (signs ^ link) | 127)
-                    int out = neg ? -other : other;
-                    out = out < -32 ? -32 : (out > 31 ? 31 : out); // update(): clamp to [-32, 31]
-                    llr[nd] = (signed char)q8(inp + out);
-                    nw |= ((unsigned)out & 0xFFu) << (8 * b);
+                    const int d = 2 * h + b;
+                    if (d < deg)
+                    {
+                        const int n = d < cnt ? (int)g.pos[((size_t)i * g.CNL + d) * g.M + j] : (d == cnt ? par0 : par1);
+                        v |= (unsigned)n << (16 * b);
+                    }
                 }
+                nd[h] = v;
             }
-            if (4 * w < deg)
-                bnl_f[((size_t)i * DQ + w) * g.M + j] = nw;
         }
-    }
+        __device__ __forceinline__ int node(int d) const { return (int)((nd[d >> 1] >> (16 * (d & 1))) & 0xFFFFu); }
+        __device__ __forceinline__ void update(signed char *llr)
+        {
+            int min0 = 255, min1 = 255;
+            unsigned signs = 0;
+#pragma unroll
+            for (int w = 0; w < DQ; w++)
+#pragma unroll
+                for (int b = 0; b < 4; b++)
+                {
+                    const int d = 4 * w + b;
+                    if (d < deg)
+                    {
+                        const int inp = q8((int)llr[node(d)] - (int)(signed char)(bw[w] >> (8 * b)));
+                        int mag = inp < -127 ? 127 : (inp < 0 ? -inp : inp); // vqabs
+                        mag = mag > 0 ? mag - 1 : 0;                          // unsigned saturating - beta, beta = nearbyint(0.5 * 2) = 1
+                        // mins[1] = min(mins[1], max(mins[0], mag)); mins[0] = min(mins[0], mag) (the first two: min / max of the pair)
+                        const int hi = mag > min0 ? mag : min0;
+                        min1 = hi < min1 ? hi : min1;
+                        min0 = mag < min0 ? mag : min0;
+                        signs ^= (unsigned)inp;
+                    }
+                }
+#pragma unroll
+            for (int w = 0; w < DQ; w++)
+            {
+                unsigned nw = 0;
+#pragma unroll
+                for (int b = 0; b < 4; b++)
+                {
+                    const int d = 4 * w + b;
+                    if (d < deg)
+                    {
+                        const int n = node(d);
+                        const int inp = q8((int)llr[n] - (int)(signed char)(bw[w] >> (8 * b)));
+                        int mag = inp < -127 ? 127 : (inp < 0 ? -inp : inp);
+                        mag = mag > 0 ? mag - 1 : 0;
+                        const int other = mag == min0 ? min1 : min0;
+                        const bool neg = ((signs ^ (unsigned)inp) & 0x80u) != 0; // sign(other, (signs ^ link) | 127)
+                        int out = neg ? -other : other;
+                        out = out < -32 ? -32 : (out > 31 ? 31 : out); // update(): clamp to [-32, 31]
+                        llr[n] = (signed char)q8(inp + out);
+                        nw |= ((unsigned)out & 0xFFu) << (8 * b);
+                    }
+                }
+                bw[w] = nw;
+            }
+        }
+        __device__ __forceinline__ void store(const LdpcDev &g, unsigned *bnl_f, int i, int j) const
+        {
+#pragma unroll
+            for (int w = 0; w < DQ; w++)
+                if (4 * w < deg)
+                    bnl_f[((size_t)i * DQ + w) * g.M + j] = bw[w];
+        }
+    };
     // parity of one check (LDPCDecoder::bad, layered_decoder.hh:29-47): bad unless every connected LLR is nonzero and an even number negative
     __device__ __forceinline__ bool ldpc_check_bad(const LdpcDev &g, const signed char *llr, int i, int j)
     {
@@ -153,12 +186,17 @@ namespace sdhip
             {
                 const int nph = g.nph[i];
                 const int my = tid < g.M ? (int)g.phase[i * g.M + tid] : -1;
+                LdpcCheck<DQ> ck;
+                if (my >= 0)
+                    ck.load(g, bnl_f, i, tid);
                 for (int ph = 0; ph < nph; ph++)
                 {
                     if (my == ph)
-                        ldpc_check<DQ>(g, llr, bnl_f, i, tid);
+                        ck.update(llr);
                     __syncthreads();
                 }
+                if (my >= 0)
+                    ck.store(g, bnl_f, i, tid);
             }
         }
         bool bad = false;

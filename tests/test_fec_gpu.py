@@ -74,6 +74,23 @@ def test_ccdecoder_bit_exact(torch_cuda, capi, orc, F, nb, kind):
     assert np.array_equal(got, want)
 
 
+@pytest.mark.parametrize("seg", [1024, 2048])
+@pytest.mark.parametrize("kind", ["noisy", "noise"])
+def test_ccdecoder_long_segments(torch_cuda, capi, orc, seg, kind, monkeypatch):
+    """The lane-per-segment decoder with 1024 / 2048 trellis steps per lane (what large batches pick: launch_vit_decode2), forced here on
+    a small batch through SDHIP_VIT2_SEG: bit-identical to CCDecoder::work like the 512-step default."""
+    monkeypatch.setenv("SDHIP_VIT2_SEG", str(seg))
+    F, nb = 12288, 5
+    rng = np.random.default_rng(seg)
+    syms = _symbols(rng, F, nb, kind)
+    want = orc.ccdecoder(F, syms)
+    d_syms = _dev(torch_cuda, syms)
+    d_out = torch_cuda.zeros(nb * F, dtype=torch_cuda.uint8, device="cuda")
+    rc = capi.lib().sdhip_op_ccdecoder(0, F, C.c_void_p(d_syms.data_ptr()), nb, C.c_void_p(d_out.data_ptr()))
+    assert rc == 0, capi.last_error()
+    assert np.array_equal(d_out.cpu().numpy(), want)
+
+
 @pytest.mark.parametrize("fill", [-1, 0])
 def test_rs_decode_bit_exact(torch_cuda, capi, orc, fill):
     """k_rs == ReedSolomon::decode_interlaved incl. the >t failure / miscorrection boundary (decode.c:32-145)."""
