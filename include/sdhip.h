@@ -292,6 +292,8 @@ extern "C"
        value: bits corrected, 0 for a clean frame, -1 when the decoder gives up. _dev: pointers on cfg->device. */
     int sdhip_bch_decode_dev(void *h, uint8_t *d_frames, int nframes, int stride, int *d_corrections);
     int sdhip_bch_decode(void *h, uint8_t *frames, int nframes, int stride, int *corrections);
+    /* dvbs2::BBFrameDescrambler::work (bbframe_descramble.cpp:133-139) on the first kbch / 8 bytes of every frame, in place (device) */
+    int sdhip_bb_descramble_dev(void *h, uint8_t *d_frames, int nframes, int stride);
     /* bit i of a frame = (soft[i] < 0), MSB first, for the first nbch soft bits of every LDPC frame (8-byte aligned, soft_stride apart) */
     int sdhip_s2_pack_dev(void *h, const int8_t *d_soft, int soft_stride, int nframes, uint8_t *d_out, int out_stride);
 

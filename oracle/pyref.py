@@ -388,3 +388,8 @@ class Dvbs2Ref:
         corr = np.zeros(len(f), dtype=np.int32)
         self.lib.sdref_bch_decode(framesize, rate, _p(f), len(f), f.shape[1], _p(corr))
         return f, corr
+
+    def bb_descramble(self, framesize, rate, frames: np.ndarray) -> np.ndarray:
+        f = np.ascontiguousarray(frames, dtype=np.uint8).copy()
+        self.lib.sdref_bb_descramble(framesize, rate, _p(f), len(f), f.shape[1])
+        return f

@@ -5,6 +5,7 @@
 // (-msse4.1, what plugins/dvb_support/CMakeLists.txt:25-38 builds on x86: SIMD<int8_t, 16>, 16 frames per call with ONE early exit).
 #include "codings/dvb-s2/bbframe_ldpc.h"
 #include "codings/dvb-s2/bbframe_bch.h"
+#include "codings/dvb-s2/bbframe_descramble.h"
 #include <cstring>
 #include <vector>
 
@@ -42,6 +43,13 @@ extern "C"
         return 0;
     }
 
+    int sdref_bb_descramble(int framesize, int rate, uint8_t *frames, int nframes, int stride)
+    {
+        dvbs2::BBFrameDescrambler d((dvbs2::dvbs2_framesize_t)framesize, (dvbs2::dvbs2_code_rate_t)rate);
+        for (int f = 0; f < nframes; f++)
+            d.work(frames + (size_t)f * stride);
+        return 0;
+    }
     int sdref_bch_dims(int framesize, int rate, int *kbch)
     {
         dvbs2::BBFrameBCH b((dvbs2::dvbs2_framesize_t)framesize, (dvbs2::dvbs2_code_rate_t)rate);

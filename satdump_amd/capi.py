@@ -140,6 +140,7 @@ def lib():
             L.sdhip_bch_decode_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
             L.sdhip_bch_decode.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
             L.sdhip_s2_pack_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int]
+            L.sdhip_bb_descramble_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
         L.sdhip_prof_enable.argtypes = [C.c_int]
         L.sdhip_pool_enable.argtypes = [C.c_int]
         L.sdhip_prof_get.argtypes = [C.c_int, C.c_char_p, C.c_size_t, C.POINTER(C.c_double), C.POINTER(C.c_longlong)]
@@ -366,6 +367,10 @@ class BchDecoder:
 
     def decode_dev(self, d_frames_ptr, nframes, stride, d_corr_ptr):
         if lib().sdhip_bch_decode_dev(self.h, d_frames_ptr, nframes, stride, d_corr_ptr) < 0:
+            raise SdhipError(lib().sdhip_last_error().decode())
+
+    def descramble_dev(self, d_frames_ptr, nframes, stride):
+        if lib().sdhip_bb_descramble_dev(self.h, d_frames_ptr, nframes, stride) < 0:
             raise SdhipError(lib().sdhip_last_error().decode())
 
     def pack_dev(self, d_soft_ptr, soft_stride, nframes, d_out_ptr, out_stride):

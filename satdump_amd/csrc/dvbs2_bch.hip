@@ -312,13 +312,22 @@ namespace sdhip
         out[(size_t)f * out_stride + b] = (unsigned char)r;
     }
 
+    // dvbs2::BBFrameDescrambler::work (bbframe_descramble.cpp:117-139): the first kbch / 8 bytes of a frame XOR the PRBS 1 + x^14 + x^15
+    // started from 0x4A80 (the sequence is built on the host like init() builds it)
+    __global__ __launch_bounds__(256) void k_bb_descramble(unsigned char *frames, int stride, int nbytes, int nframes, const unsigned char *seq)
+    {
+        const int f = (int)blockIdx.y, b = (int)(blockIdx.x * 256 + threadIdx.x);
+        if (f < nframes && b < nbytes)
+            frames[(size_t)f * stride + b] ^= seq[b];
+    }
+
     struct BchEngine
     {
         sdhip_bch_cfg cfg;
         hipStream_t stream = nullptr;
         BchDev g{};
         DevBuf<unsigned short> d_log, d_exp, d_imap;
-        DevBuf<unsigned char> d_frames;
+        DevBuf<unsigned char> d_frames, d_prbs;
         DevBuf<int> d_corr;
         explicit BchEngine(const sdhip_bch_cfg &c) : cfg(c)
         {
@@ -388,6 +397,29 @@ namespace sdhip
             g.LOG = d_log.p;
             g.EXP = d_exp.p;
             g.IMAP = d_imap.p;
+            // BBFrameDescrambler::init, bbframe_descramble.cpp:117-131
+            std::vector<unsigned char> seq(64800 / 8, 0);
+            int sr = 0x4A80;
+            for (int i = 0; i < 64800; i++)
+            {
+                const int b = (sr ^ (sr >> 1)) & 1;
+                seq[i / 8] |= (unsigned char)(b << (7 - (i % 8)));
+                sr >>= 1;
+                if (b)
+                    sr |= 0x4000;
+            }
+            d_prbs.reserve(seq.size());
+            SD_HIP(hipMemcpy(d_prbs.p, seq.data(), seq.size(), hipMemcpyHostToDevice));
+        }
+        int descramble_dev(unsigned char *d_fr, int nframes, int stride)
+        {
+            SD_HIP(hipSetDevice(cfg.device));
+            if (nframes <= 0)
+                return 0;
+            ProfScope _ps("k_bb_descramble", stream);
+            hipLaunchKernelGGL(k_bb_descramble, dim3((unsigned)((g.kbch / 8 + 255) / 256), (unsigned)nframes), dim3(256), 0, stream, d_fr, stride, g.kbch / 8, nframes, d_prbs.p);
+            SD_HIP(hipStreamSynchronize(stream));
+            return 0;
         }
         ~BchEngine()
         {
@@ -475,6 +507,12 @@ extern "C"
     {
         SD_GUARD_BEGIN
         return static_cast<BchEngine *>(h)->decode_host(frames, nframes, stride, corrections);
+        SD_GUARD_END(-1)
+    }
+    int sdhip_bb_descramble_dev(void *h, uint8_t *d_frames, int nframes, int stride)
+    {
+        SD_GUARD_BEGIN
+        return static_cast<BchEngine *>(h)->descramble_dev(d_frames, nframes, stride);
         SD_GUARD_END(-1)
     }
     int sdhip_s2_pack_dev(void *h, const int8_t *d_soft, int soft_stride, int nframes, uint8_t *d_out, int out_stride)

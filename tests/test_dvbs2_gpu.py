@@ -156,7 +156,7 @@ def test_bch_every_code_bit_exact(capi, fs, rate):
 
 def test_ldpc_pack_bch_chain_on_device(capi):
     """The FEC tail of DVBS2DemodModule::process_s2 on frames resident in HBM: LDPC decode -> hard-decision repack -> BCH decode
-    (module_dvbs2_demod.cpp:254-270), against the same three steps of the reference; normal 2/3 (MODCOD 13 of BASELINE configs[4])."""
+    -> BB descrambler (module_dvbs2_demod.cpp:254-273), against the same four steps of the reference; normal 2/3 (MODCOD 13 of BASELINE configs[4])."""
     import torch
     from tests import dvbs2_util
     ref = _ref(False)
@@ -175,6 +175,7 @@ def test_ldpc_pack_bch_chain_on_device(capi):
     rsoft, rtr = ref.ldpc_decode(fs, rc, soft, 20)
     rpack = np.packbits((rsoft[:, :k] < 0).astype(np.uint8), axis=1)
     rout, rcorr = ref.bch_decode(fs, rc, rpack)
+    rdes = ref.bb_descramble(fs, rc, rout)
     # device chain
     d_soft = torch.from_numpy(soft.copy()).cuda()
     d_tr = torch.zeros(nf, dtype=torch.int32, device="cuda")
@@ -186,6 +187,8 @@ def test_ldpc_pack_bch_chain_on_device(capi):
     bch.decode_dev(d_pack.data_ptr(), nf, k // 8, d_corr.data_ptr())
     assert np.array_equal(d_tr.cpu().numpy(), rtr)
     assert np.array_equal(d_pack.cpu().numpy(), rout) and np.array_equal(d_corr.cpu().numpy(), rcorr)
+    bch.descramble_dev(d_pack.data_ptr(), nf, k // 8)  # BBFrameDescrambler::work, the last step of process_s2 (module_dvbs2_demod.cpp:273)
+    assert np.array_equal(d_pack.cpu().numpy(), rdes)
     good = rcorr >= 0
     assert good.mean() > 0.5 and np.array_equal(rout[good][:, :bch.kbch // 8], bb[good][:, :bch.kbch // 8])
 

@@ -63,6 +63,19 @@ def test_bch_bit_exact_on_the_twin(capi, fs, rate):
     G.bch_case(capi, G._ref(False), fs, rate, [0, 1, 2, 3, 5, 8, 10, 12, 13, 14, 20, 40])
 
 
+@pytest.mark.parametrize("fs,rate", [(0, "2/3"), (1, "1/2")])
+def test_bb_descrambler_on_the_twin(capi, fs, rate):
+    """sdhip_bb_descramble_dev == BBFrameDescrambler::work (the twin's "device" pointers are host pointers)."""
+    ref = G._ref(False)
+    rc = capi.S2_RATES[rate]
+    dec = capi.BchDecoder(framesize=fs, rate=rate)
+    fr = np.random.default_rng(2).integers(0, 256, (5, dec.nbch // 8 + 3), dtype=np.uint8)
+    want = ref.bb_descramble(fs, rc, fr)
+    got = fr.copy()
+    dec.descramble_dev(got.ctypes.data, len(got), got.shape[1])
+    assert np.array_equal(got, want) and not np.array_equal(got, fr) and np.array_equal(got[:, dec.kbch // 8:], fr[:, dec.kbch // 8:])
+
+
 test_errors = G.test_errors
 
 
