@@ -198,7 +198,7 @@ def test_punctured_conv_rate_through_the_override(host, tmp_path, rate, code):
     id `ccsds_conv_concat_decoder` now resolves to the HIP module for it too and writes what the reference decodes
     from the same .soft file, EOF behaviour included."""
     orc = pyref.best()
-    soft, plain = util.punctured_case(code, nframes=24, sigma=18.0, seed=3)
+    soft, plain = util.punctured_case(code, nframes=24, sigma=32.0 * {2: 0.85, 4: 0.45}[code], seed=3)
     inp = tmp_path / "in.soft"
     soft.tofile(str(inp))
     params = {"constellation": "bpsk", "cadu_size": 8192, "viterbi_ber_thresold": 0.3, "viterbi_outsync_after": 20, "derandomize": True, "nrzm": False, "rs_i": 4,
@@ -210,7 +210,7 @@ def test_punctured_conv_rate_through_the_override(host, tmp_path, rate, code):
     nfull, rem = divmod(len(soft), 8192)
     prev = soft[(nfull - 1) * 8192:nfull * 8192]
     ext = np.concatenate([soft[:nfull * 8192], soft[nfull * 8192:], prev[rem:]])
-    want = orc.concat_decode(pyref.fec_cfg(constellation=pyref.BPSK, nrzm=0, rs_usecheck=1, conv_rate=code), ext)["cadu"]
+    want = orc.concat_decode_punc(pyref.fec_cfg(constellation=pyref.BPSK, nrzm=0, rs_usecheck=1), code, ext)["cadu"]
     assert got.shape == want.shape and np.array_equal(got, want), (got.shape, want.shape)
     assert len(got) >= 20
 
