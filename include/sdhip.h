@@ -292,6 +292,9 @@ extern "C"
        value: bits corrected, 0 for a clean frame, -1 when the decoder gives up. _dev: pointers on cfg->device. */
     int sdhip_bch_decode_dev(void *h, uint8_t *d_frames, int nframes, int stride, int *d_corrections);
     int sdhip_bch_decode(void *h, uint8_t *frames, int nframes, int stride, int *corrections);
+    /* dvbs2::S2Deinterleaver::deinterleave (codings/dvb-s2/s2_deinterleaver.cpp:92-145) over nframes frames of 64800 / 16200 soft bits:
+       constellation = dvbs2_constellation_t (0 QPSK, 1 8PSK, 2 16APSK, 3 32APSK), d_in != d_out (device pointers) */
+    int sdhip_s2_deinterleave_dev(int device, int constellation, int framesize, int rate, const int8_t *d_in, int8_t *d_out, int nframes);
     /* dvbs2::BBFrameDescrambler::work (bbframe_descramble.cpp:133-139) on the first kbch / 8 bytes of every frame, in place (device) */
     int sdhip_bb_descramble_dev(void *h, uint8_t *d_frames, int nframes, int stride);
     /* bit i of a frame = (soft[i] < 0), MSB first, for the first nbch soft bits of every LDPC frame (8-byte aligned, soft_stride apart) */

@@ -393,3 +393,9 @@ class Dvbs2Ref:
         f = np.ascontiguousarray(frames, dtype=np.uint8).copy()
         self.lib.sdref_bb_descramble(framesize, rate, _p(f), len(f), f.shape[1])
         return f
+
+    def s2_deinterleave(self, constellation, framesize, rate, soft: np.ndarray) -> np.ndarray:
+        a = np.ascontiguousarray(soft, dtype=np.int8)
+        out = np.zeros_like(a)
+        self.lib.sdref_s2_deinterleave(constellation, framesize, rate, _p(a), _p(out), len(a))
+        return out

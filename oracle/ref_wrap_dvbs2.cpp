@@ -6,6 +6,7 @@
 #include "codings/dvb-s2/bbframe_ldpc.h"
 #include "codings/dvb-s2/bbframe_bch.h"
 #include "codings/dvb-s2/bbframe_descramble.h"
+#include "codings/dvb-s2/s2_deinterleaver.h"
 #include <cstring>
 #include <vector>
 
@@ -43,6 +44,14 @@ extern "C"
         return 0;
     }
 
+    int sdref_s2_deinterleave(int constellation, int framesize, int rate, int8_t *in, int8_t *out, int nframes)
+    {
+        dvbs2::S2Deinterleaver d((dvbs2::dvbs2_constellation_t)constellation, (dvbs2::dvbs2_framesize_t)framesize, (dvbs2::dvbs2_code_rate_t)rate);
+        const int n = framesize == 0 ? 64800 : 16200;
+        for (int f = 0; f < nframes; f++)
+            d.deinterleave(in + (size_t)f * n, out + (size_t)f * n);
+        return 0;
+    }
     int sdref_bb_descramble(int framesize, int rate, uint8_t *frames, int nframes, int stride)
     {
         dvbs2::BBFrameDescrambler d((dvbs2::dvbs2_framesize_t)framesize, (dvbs2::dvbs2_code_rate_t)rate);

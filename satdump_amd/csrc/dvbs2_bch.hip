@@ -321,6 +321,27 @@ namespace sdhip
             frames[(size_t)f * stride + b] ^= seq[b];
     }
 
+    // dvbs2::S2Deinterleaver::deinterleave (codings/dvb-s2/s2_deinterleaver.cpp:24-145): the demapper's soft bits symbol by symbol ->
+    // the code word's bit order. QPSK: the two bits of a symbol swapped; 8PSK / 16APSK / 32APSK: bit c of symbol j goes to column c (rows =
+    // frame / bits per symbol), 8PSK rate 3/5 with the columns in reverse order. Thread per output byte.
+    __global__ __launch_bounds__(256) void k_s2_deinterleave(const signed char *in, signed char *out, int frame_len, int mod_bits, int reversed, int nframes)
+    {
+        const int f = (int)blockIdx.y, o = (int)(blockIdx.x * 256 + threadIdx.x);
+        if (f >= nframes || o >= frame_len)
+            return;
+        const signed char *fi = in + (size_t)f * frame_len;
+        int src;
+        if (mod_bits == 2)
+            src = o ^ 1;
+        else
+        {
+            const int rows = frame_len / mod_bits, col = o / rows, j = o - col * rows;
+            const int c = reversed ? mod_bits - 1 - col : col; // which bit of the symbol this column holds
+            src = j * mod_bits + c;
+        }
+        out[(size_t)f * frame_len + o] = fi[src];
+    }
+
     struct BchEngine
     {
         sdhip_bch_cfg cfg;
@@ -507,6 +528,25 @@ extern "C"
     {
         SD_GUARD_BEGIN
         return static_cast<BchEngine *>(h)->decode_host(frames, nframes, stride, corrections);
+        SD_GUARD_END(-1)
+    }
+    int sdhip_s2_deinterleave_dev(int device, int constellation, int framesize, int rate, const int8_t *d_in, int8_t *d_out, int nframes)
+    {
+        SD_GUARD_BEGIN
+        if (constellation < 0 || constellation > 3 || (framesize != 0 && framesize != 1))
+            throw HipError("dvbs2 deinterleaver: unknown constellation / frame size");
+        if (nframes <= 0)
+            return 0;
+        SD_HIP(hipSetDevice(device));
+        const int frame_len = framesize == 0 ? 64800 : 16200, mod_bits = constellation + 2;
+        const int reversed = (constellation == 1 && rate == 4) ? 1 : 0; // MOD_8PSK with C3_5, s2_deinterleaver.cpp:45-50
+        {
+            ProfScope _ps("k_s2_deinterleave", nullptr);
+            hipLaunchKernelGGL(k_s2_deinterleave, dim3((unsigned)((frame_len + 255) / 256), (unsigned)nframes), dim3(256), 0, nullptr, reinterpret_cast<const signed char *>(d_in),
+                               reinterpret_cast<signed char *>(d_out), frame_len, mod_bits, reversed, nframes);
+        }
+        SD_HIP(hipDeviceSynchronize());
+        return 0;
         SD_GUARD_END(-1)
     }
     int sdhip_bb_descramble_dev(void *h, uint8_t *d_frames, int nframes, int stride)

@@ -193,6 +193,22 @@ def test_ldpc_pack_bch_chain_on_device(capi):
     assert good.mean() > 0.5 and np.array_equal(rout[good][:, :bch.kbch // 8], bb[good][:, :bch.kbch // 8])
 
 
+@pytest.mark.parametrize("const,fs,rate", [(0, 0, 5), (1, 0, 5), (1, 0, 4), (1, 1, 4), (2, 0, 6), (2, 1, 6), (3, 0, 7), (3, 1, 7)])
+def test_s2_deinterleaver(capi, const, fs, rate):
+    """dvbs2::S2Deinterleaver::deinterleave (the step between the soft demapper and the LDPC decoder, dvbs2_bb_to_soft.cpp:63): QPSK pair
+    swap, 8PSK / 16APSK / 32APSK column de-interleaving, 8PSK rate 3/5 with its reversed column order -- identical bytes."""
+    import ctypes as C
+    import torch
+    ref = _ref(False)
+    n = 64800 if fs == 0 else 16200
+    x = np.random.default_rng(const + rate).integers(-128, 128, (5, n), dtype=np.int8)
+    want = ref.s2_deinterleave(const, fs, rate, x)
+    d_in = torch.from_numpy(x).cuda()
+    d_out = torch.zeros_like(d_in)
+    rc = capi.lib().sdhip_s2_deinterleave_dev(0, const, fs, rate, C.c_void_p(d_in.data_ptr()), C.c_void_p(d_out.data_ptr()), 5)
+    assert rc == 0 and np.array_equal(d_out.cpu().numpy(), want)
+
+
 def test_errors(capi):
     with pytest.raises(capi.SdhipError):
         capi.LdpcDecoder(framesize=0, rate="7/8")   # no LDPC table (bbframe_ldpc.cpp:30-69 has no case for it)

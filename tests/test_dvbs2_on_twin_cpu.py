@@ -76,6 +76,19 @@ def test_bb_descrambler_on_the_twin(capi, fs, rate):
     assert np.array_equal(got, want) and not np.array_equal(got, fr) and np.array_equal(got[:, dec.kbch // 8:], fr[:, dec.kbch // 8:])
 
 
+@pytest.mark.parametrize("const,fs,rate", [(0, 0, 5), (1, 0, 5), (1, 0, 4), (1, 1, 4), (2, 0, 6), (3, 1, 7)])
+def test_s2_deinterleaver_on_the_twin(capi, const, fs, rate):
+    """sdhip_s2_deinterleave_dev == S2Deinterleaver::deinterleave for QPSK / 8PSK (incl. the reversed columns of rate 3/5) / 16APSK / 32APSK."""
+    import ctypes as C
+    ref = G._ref(False)
+    n = 64800 if fs == 0 else 16200
+    x = np.random.default_rng(const + rate).integers(-128, 128, (3, n), dtype=np.int8)
+    want = ref.s2_deinterleave(const, fs, rate, x)
+    got = np.zeros_like(x)
+    rc = capi.lib().sdhip_s2_deinterleave_dev(0, const, fs, rate, x.ctypes.data_as(C.c_void_p), got.ctypes.data_as(C.c_void_p), 3)
+    assert rc == 0 and np.array_equal(got, want)
+
+
 test_errors = G.test_errors
 
 
