@@ -138,6 +138,50 @@ extern "C"
     int64_t sdhip_demod_process_dev(void *h, const void *d_iq, size_t nsamples, int fmt, int8_t *d_soft, size_t soft_cap, float *d_syms, size_t syms_cap, int final);
     int sdhip_demod_get_stats(void *h, sdhip_demod_stats *st);
 
+    /* ---- ndsp: the reference's new block API -------------------------
+       satdump::ndsp::PSKDemodHierBlock (src-core/dsp/hier/psk_demod.h:22-249, psk_demod.cpp:8-14): RRC FIR -> AGC (reference 0.6) ->
+       M&M clock recovery -> Costas loop at ONE sample per symbol, complex symbols out; no resampler, no quantiser. The fields are the
+       block's set_cfg() keys; the defaults (sdhip_ndsp_psk_cfg_default) are the member blocks' own:
+       rrc.h:17-21, agc.h:14-17, clock_recovery_mm.h:17-23, costas.h:14-16. */
+    typedef struct sdhip_ndsp_psk_cfg
+    {
+        int device;
+        int constellation;      /* "constellation": SDHIP_BPSK / SDHIP_QPSK (psk_demod.h:205-214; the block logs TODOREWORK for oqpsk) */
+        double samplerate;      /* "samplerate" (default 6e6) */
+        double symbolrate;      /* "symbolrate" (default 2e6) */
+        double rrc_gain;        /* "rrc_gain" 1 */
+        double rrc_alpha;       /* "rrc_alpha" 0.35 */
+        int rrc_ntaps;          /* "rrc_ntaps" 31 */
+        float agc_rate;         /* "agc_rate" 1e-4 */
+        float agc_reference;    /* "agc_reference" 0.6 (set by the hier block's constructor) */
+        float agc_gain;         /* "agc_gain" 1 */
+        float agc_max_gain;     /* "agc_max_gain" 65536 */
+        float rec_omega;        /* "rec_omega": 0 = samplerate / symbolrate (what setting either rate does, psk_demod.h:224) */
+        float rec_omegaGain;    /* "rec_omegaGain" pow(8.7e-3, 2) / 4 */
+        float rec_mu;           /* "rec_mu" 0.5 */
+        float rec_muGain;       /* "rec_muGain" 8.7e-3 */
+        float rec_omegaLimit;   /* "rec_omegaLimit" 0.005 */
+        int rec_nfilt;          /* "rec_nfilt" 128 (the only bank shape the HIP path carries; anything else is refused) */
+        int rec_ntaps;          /* "rec_ntaps" 8 (likewise) */
+        float pll_loop_bw;      /* "pll_loop_bw" 0.004 */
+        float pll_freq_limit;   /* "pll_freq_limit" 1.0 */
+        int exact;              /* 1 = one sequential lane per loop, the reference's float operations in its order (bit-exact symbols) */
+        int chunk_len;          /* 0 = automatic */
+        int warmup;             /* 0 = automatic */
+    } sdhip_ndsp_psk_cfg;
+    void sdhip_ndsp_psk_cfg_default(sdhip_ndsp_psk_cfg *c);
+    void *sdhip_ndsp_psk_demod_create(const sdhip_ndsp_psk_cfg *cfg);
+    void sdhip_ndsp_psk_demod_destroy(void *h);
+    /* One DSPBuffer's worth of work() of the whole hier block: nsamples complex floats (device) in, the symbols it produces (complex
+       floats, device, capacity out_cap symbols) out. Returns the symbols written, <0 on error. The stream state (filter history with the
+       FIR block's ntaps-sample latency, gain, clock and loop state) carries across calls, so the output does not depend on how the
+       stream is cut into buffers -- as in the reference. */
+    int64_t sdhip_ndsp_psk_demod_work_dev(void *h, const float *d_in, size_t nsamples, float *d_out, size_t out_cap);
+    /* the same through host buffers */
+    int64_t sdhip_ndsp_psk_demod_work(void *h, const float *in, size_t nsamples, float *out, size_t out_cap);
+    /* get_cfg("pll_freq") (rad_to_hz(freq, symbolrate), psk_demod.h:170) and the chunk statistics of the last call */
+    int sdhip_ndsp_psk_demod_get_stats(void *h, sdhip_demod_stats *st);
+
     /* ---- ccsds_conv_concat_decoder / metop_ahrpt_decoder ------------------------------ */
     typedef struct sdhip_fec_cfg
     {
@@ -216,7 +260,10 @@ extern "C"
        kind 0 AGC(rate,ref,gain,max) agc.cpp:25-39 | 1 RRC FIR(fs,symrate,alpha,ntaps) fir.cpp:74-83 |
        2 Costas(bw,order,limit) costas_loop.cpp:23-65 | 3 MM(omega,gw,mu,gmu,lim) clock_recovery_mm.cpp:52-121 |
        4 rational resampler(interp,decim) rational_resampler.cpp:43-64 | 5 DC block correct_iq.cpp:18-35 |
-       7 Gardner(omega,gw,mu,gmu,lim) clock_recovery_gardner.cpp:33-124. Returns output sample count. */
+       7 Gardner(omega,gw,mu,gmu,lim) clock_recovery_gardner.cpp:33-124 | 8 carrier PLL(bw,max,min) pll_carrier_tracking.cpp:8-66 |
+       9 ndsp Costas(bw,order,limit) dsp/pll/costas.cpp:12-61 (branched clip). The other ndsp blocks compute what kinds 0, 1 and 3 do
+       (dsp/agc/agc.cpp:22-39, dsp/filter/fir.cpp:62-133 minus its ntaps-sample latency, dsp/clock_recovery/clock_recovery_mm.cpp:66-183).
+       Returns output sample count. */
     int64_t sdhip_op_block(int device, int kind, const float *params, const float *d_in, size_t n, float *d_out, size_t out_cap);
 
     /* The coefficient tables the modules' blocks are constructed with, designed on the host exactly as the reference designs them

@@ -399,3 +399,27 @@ class Dvbs2Ref:
         out = np.zeros_like(a)
         self.lib.sdref_s2_deinterleave(constellation, framesize, rate, _p(a), _p(out), len(a))
         return out
+
+
+# ---------------------------------------------------------------- ndsp (oracle/ref_wrap_ndsp.cpp: the reference's new block API)
+class NdspRef:
+    """The compiled reference ndsp blocks, each run on its own thread through DSPStream FIFOs exactly as the reference runs them.
+    block ids: agc_cc, rrc_fir_cc, costas_cc, clock_recovery_mm_cc, psk_demod_cc (the hier block: RRC -> AGC -> M&M -> Costas)."""
+
+    def __init__(self):
+        self.lib = C.CDLL(os.path.join(_HERE, "_ref", "libsdref_ndsp.so"))
+        self.lib.sdref_ndsp_run.restype = C.c_longlong
+        self.lib.sdref_ndsp_run.argtypes = [C.c_char_p, C.c_char_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_size_t]
+
+    @staticmethod
+    def available() -> bool:
+        return os.path.exists(os.path.join(_HERE, "_ref", "libsdref_ndsp.so"))
+
+    def run(self, block_id: str, cfg: dict, x: np.ndarray, buf: int = 8192) -> np.ndarray:
+        import json
+        x = np.ascontiguousarray(x, dtype=np.complex64)
+        out = np.zeros(len(x) + 64, dtype=np.complex64)
+        n = self.lib.sdref_ndsp_run(block_id.encode(), json.dumps(cfg).encode(), _p(x), len(x), int(buf), _p(out), len(out))
+        if n < 0:
+            raise RuntimeError(f"sdref_ndsp_run({block_id}) -> {n}")
+        return out[:n].copy()

@@ -17,6 +17,10 @@
 #include "pipeline/modules/base/filestream_to_filestream.h"
 
 #include "../include/sdhip.h"
+#include "sdhip_ndsp_block.h"
+#ifdef SDHIP_WITH_FLOWGRAPH // defined by the CMake fragment of INTEGRATION.md: the flowgraph registry pulls the GUI node classes in
+#include "dsp/flowgraph/dsp_flowgraph_register.h"
+#endif
 
 #include <algorithm>
 #include <cmath>
@@ -599,7 +603,23 @@ namespace sdhip_plugin
         {
             satdump::eventBus->register_handler<RegisterModulesEvent>(registerModulesHandler);
             satdump::eventBus->register_handler<satdump::SatDumpStartedEvent>(startedHandler);
+#ifdef SDHIP_WITH_FLOWGRAPH
+            satdump::eventBus->register_handler<satdump::ndsp::flowgraph::RegisterNodesEvent>(registerNodesHandler);
+#endif
         }
+#ifdef SDHIP_WITH_FLOWGRAPH
+        // dsp_flowgraph_register.cpp:438 fires this after the stock nodes: what registerNodeSimple<T>() does (dsp_flowgraph_register.h:23-28),
+        // on the event's registry. SDHIP_OVERRIDE=1 also re-points the stock "psk_demod_cc" node at the HIP block.
+        static void registerNodesHandler(const satdump::ndsp::flowgraph::RegisterNodesEvent &evt)
+        {
+            using namespace satdump::ndsp::flowgraph;
+            auto make = [](const Flowgraph *f) { return std::make_shared<NodeInternal>(f, std::make_shared<PSKDemodHipBlock>()); };
+            evt.r.insert({PSKDemodHipBlock().d_id, {"Modem/PSK Demod (MI355X)", make}});
+            const char *ov = getenv("SDHIP_OVERRIDE");
+            if (ov && std::string(ov) == "1" && sdhip_device_count() > 0 && evt.r.count("psk_demod_cc"))
+                evt.r.at("psk_demod_cc").func = make;
+        }
+#endif
         static void registerModulesHandler(const RegisterModulesEvent &evt)
         {
             REGISTER_MODULE_EXTERNAL(evt.modules_registry, PSKDemodHipModule);
@@ -663,3 +683,11 @@ namespace sdhip_plugin
 } // namespace sdhip_plugin
 
 PLUGIN_LOADER(sdhip_plugin::SdhipSupport)
+
+// what a host without the flowgraph registry (tests/minihost) instantiates the ndsp block with
+extern "C" satdump::ndsp::Block *sdhip_plugin_make_ndsp_block(const char *id)
+{
+    if (std::string(id) == "psk_demod_hip_cc" || std::string(id) == "psk_demod_cc")
+        return new sdhip_plugin::PSKDemodHipBlock();
+    return nullptr;
+}

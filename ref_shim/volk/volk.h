@@ -45,6 +45,19 @@ static inline void volk_32f_x2_dot_prod_32f(float *r, const float *in, const flo
     *r = s;
 }
 #define volk_32f_x2_dot_prod_32f_a volk_32f_x2_dot_prod_32f
+/* complex taps (the ndsp FIR block's third instantiation, dsp/filter/fir.cpp:122): VOLK's generic kernel, one complex MAC per point */
+static inline void volk_32fc_x2_dot_prod_32fc(lv_32fc_t *r, const lv_32fc_t *in, const lv_32fc_t *t, unsigned n)
+{
+    const float *a = (const float *)in, *b = (const float *)t;
+    float re = 0, im = 0;
+    for (unsigned i = 0; i < n; i++)
+    {
+        re += a[2 * i] * b[2 * i] - a[2 * i + 1] * b[2 * i + 1];
+        im += a[2 * i] * b[2 * i + 1] + a[2 * i + 1] * b[2 * i];
+    }
+    *r = lv_32fc_t(re, im);
+}
+#define volk_32fc_x2_dot_prod_32fc_a volk_32fc_x2_dot_prod_32fc
 static inline void volk_16i_s32f_convert_32f_u(float *o, const int16_t *in, float s, unsigned n)
 {
     const float is = 1.0f / s;

@@ -77,6 +77,16 @@ class LdpcInfo(C.Structure):
 S2_RATES = {"1/4": 0, "1/3": 1, "2/5": 2, "1/2": 3, "3/5": 4, "2/3": 5, "3/4": 6, "4/5": 7, "5/6": 8, "7/8": 9, "8/9": 10, "9/10": 11}
 
 
+class NdspPskCfg(C.Structure):
+    """sdhip_ndsp_psk_cfg (include/sdhip.h): the set_cfg() keys of satdump::ndsp::PSKDemodHierBlock."""
+    _fields_ = [("device", C.c_int), ("constellation", C.c_int), ("samplerate", C.c_double), ("symbolrate", C.c_double),
+                ("rrc_gain", C.c_double), ("rrc_alpha", C.c_double), ("rrc_ntaps", C.c_int),
+                ("agc_rate", C.c_float), ("agc_reference", C.c_float), ("agc_gain", C.c_float), ("agc_max_gain", C.c_float),
+                ("rec_omega", C.c_float), ("rec_omegaGain", C.c_float), ("rec_mu", C.c_float), ("rec_muGain", C.c_float), ("rec_omegaLimit", C.c_float),
+                ("rec_nfilt", C.c_int), ("rec_ntaps", C.c_int), ("pll_loop_bw", C.c_float), ("pll_freq_limit", C.c_float),
+                ("exact", C.c_int), ("chunk_len", C.c_int), ("warmup", C.c_int)]
+
+
 class SdhipError(RuntimeError):
     pass
 
@@ -125,6 +135,16 @@ def lib():
             L.sdhip_demod_get_stats.argtypes = [C.c_void_p, C.POINTER(DemodStats)]
             L.sdhip_op_block.restype = C.c_int64
             L.sdhip_op_block.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+        if hasattr(L, "sdhip_ndsp_psk_demod_create"):
+            L.sdhip_ndsp_psk_cfg_default.argtypes = [C.POINTER(NdspPskCfg)]
+            L.sdhip_ndsp_psk_demod_create.restype = C.c_void_p
+            L.sdhip_ndsp_psk_demod_create.argtypes = [C.POINTER(NdspPskCfg)]
+            L.sdhip_ndsp_psk_demod_destroy.argtypes = [C.c_void_p]
+            L.sdhip_ndsp_psk_demod_work_dev.restype = C.c_int64
+            L.sdhip_ndsp_psk_demod_work_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+            L.sdhip_ndsp_psk_demod_work.restype = C.c_int64
+            L.sdhip_ndsp_psk_demod_work.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+            L.sdhip_ndsp_psk_demod_get_stats.argtypes = [C.c_void_p, C.POINTER(DemodStats)]
         if hasattr(L, "sdhip_ldpc_create"):
             L.sdhip_ldpc_create.restype = C.c_void_p
             L.sdhip_ldpc_create.argtypes = [C.POINTER(LdpcCfg)]

@@ -423,9 +423,22 @@ namespace sdhip
             hist[i] = v;
     }
 
+    // the ndsp PSK demodulator (satdump::ndsp::PSKDemodHierBlock, dsp/hier/psk_demod.h) runs on the same engine: same loop kernels,
+    // other stage order (RRC -> AGC -> M&M -> Costas at one sample per symbol), no resampler, no quantiser; what the legacy
+    // module's configuration cannot say rides here
+    struct NdspExt
+    {
+        bool on = false;
+        double samplerate = 0, symbolrate = 0, rrc_gain = 1, rrc_alpha = 0.35; // doubles in RRC_Block (dsp/filter/rrc.h:17-21)
+        float agc_reference = 1.0f, agc_gain = 1.0f, agc_max_gain = 65536.0f, rec_omega = 0.0f, pll_freq_limit = 1.0f;
+    };
+
     struct DemodEngine
     {
         sdhip_demod_cfg cfg;
+        NdspExt nd;
+        long long fir_drop = 0; // ndsp FIRBlock latency: the first ntaps outputs of the stream do not exist there (dsp/filter/fir.cpp:80-83)
+        DevBuf<cf32> symtmp;    // ndsp: the clock recovery's symbols, input of the symbol-rate Costas loop
         hipStream_t stream = nullptr;
         // derived exactly like BaseDemodModule::initb / PSKDemodModule::init
         int d_buffer_size = 0;
@@ -526,8 +539,10 @@ namespace sdhip
 
         static int fmt_bytes(int fmt) { return (fmt == SDHIP_FMT_CF32 || fmt == SDHIP_FMT_CS32) ? 8 : (fmt == SDHIP_FMT_CS16 ? 4 : 2); }
 
-        explicit DemodEngine(const sdhip_demod_cfg &c) : cfg(c)
+        explicit DemodEngine(const sdhip_demod_cfg &c, const NdspExt *ne = nullptr) : cfg(c)
         {
+            if (ne)
+                nd = *ne;
             SD_HIP(hipSetDevice(cfg.device));
             SD_HIP(hipStreamCreate(&stream));
             if (cfg.samplerate <= 0)
@@ -564,6 +579,13 @@ namespace sdhip
             if (d_buffer_size > 8192 * 20)
                 d_buffer_size = 8192 * 20;
             final_sps = final_samplerate / (float)d_symbolrate;
+            if (nd.on)
+            { // no resampler in the hier block; rec_blk "omega" = samplerate / symbolrate, a double narrowed to the block's float (psk_demod.h:224)
+                if (resample)
+                    throw HipError("ndsp chain: unexpected resample decision");
+                final_samplerate = (float)nd.samplerate;
+                final_sps = nd.rec_omega > 0 ? nd.rec_omega : (float)(nd.samplerate / nd.symbolrate);
+            }
             if (input_sps < 1.0)
                 throw HipError("Your sampling rate is too low!");
 
@@ -633,12 +655,14 @@ namespace sdhip
             }
             // AGC (module_demod_base.cpp:207)
             agc_p.rate = cfg.agc_rate;
-            agc_p.reference = 1.0f;
-            agc_p.max_gain = 65536.0f;
-            agc_p.init_gain = 1.0f;
-            agc_s.gain = 1.0f;
+            agc_p.reference = nd.on ? nd.agc_reference : 1.0f;
+            agc_p.max_gain = nd.on ? nd.agc_max_gain : 65536.0f;
+            agc_p.init_gain = nd.on ? nd.agc_gain : 1.0f;
+            agc_s.gain = agc_p.init_gain;
             // RRC (module_psk_demod.cpp:91)
-            std::vector<float> rrc = design::rrc(1, final_samplerate, d_symbolrate, cfg.rrc_alpha, cfg.rrc_taps);
+            // ndsp: RRC_Block::set_cfg designs from its double members (dsp/filter/rrc.h:62-66)
+            std::vector<float> rrc = nd.on ? design::rrc(nd.rrc_gain, nd.samplerate, nd.symbolrate, nd.rrc_alpha, cfg.rrc_taps)
+                                           : design::rrc(1, final_samplerate, d_symbolrate, cfg.rrc_alpha, cfg.rrc_taps);
             rrc_ntaps = (int)rrc.size();
             if (rrc_ntaps > DEMOD_HIST || rrc_ntaps > 384)
                 throw HipError("rrc_taps too large for the HIP path");
@@ -648,7 +672,8 @@ namespace sdhip
             d_rrc.reserve(rrev.size());
             SD_HIP(hipMemcpy(d_rrc.p, rrev.data(), rrev.size() * sizeof(float), hipMemcpyHostToDevice));
             // the 31-tap filter every pipeline of the path uses rides on the AGC lanes (SDHIP_FUSE_AGC_FIR=0: two kernels, A/B switch)
-            fuse_agc_fir = rrc_ntaps == AGCFIR_NT && env_int("SDHIP_FUSE_AGC_FIR", 1) != 0;
+            fuse_agc_fir = rrc_ntaps == AGCFIR_NT && env_int("SDHIP_FUSE_AGC_FIR", 1) != 0 && !nd.on; // ndsp filters BEFORE the AGC
+            fir_drop = nd.on ? rrc_ntaps : 0;
             if (fuse_agc_fir)
             {
                 af_p.agc = agc_p;
@@ -694,8 +719,11 @@ namespace sdhip
             rot_mod = order;
             rot_unit = 2.0 * design::PI / order;
             design::costas_gains(cfg.pll_bw, cos_p.alpha, cos_p.beta);
+            if (nd.on)
+                costas_max_offset = nd.pll_freq_limit; // CostasBlock "freq_limit", rad/sample (dsp/pll/costas.h:16, 33-34)
             cos_p.fmin = -costas_max_offset;
             cos_p.fmax = costas_max_offset;
+            cos_p.clip_branched = nd.on ? 1 : 0;
             cos_p.order = order;
             cos_p.init_freq = 0.0f;
             // one loop step moves the phase by at most fmax + beta + alpha: the kernel's phase wrap relies on that being under one turn
@@ -1030,7 +1058,7 @@ namespace sdhip
                     sm += v;
                 const double mean = sm / (double)m;
                 if (mean > 1e-12)
-                    g_est = (float)std::min(65536.0, 1.0 / mean);
+                    g_est = (float)std::min((double)(agc_p.max_gain > 0 ? agc_p.max_gain : 65536.0f), (double)agc_p.reference / mean);
             }
             const double tau = std::max(1.0f, g_est) / std::max(1e-6f, cfg.agc_rate);
             long long Wa = cfg.warmup > 0 ? cfg.warmup : (long long)(24.0 * tau);
@@ -1195,6 +1223,423 @@ namespace sdhip
         }
 
         // Process n input samples resident on the device. Outputs go to d_soft / d_syms (device).
+        // ---- AGC (speculative): AIN -> OUT (with the RRC filter on the same lanes when fuse_agc_fir)
+        void agc_stage(const cf32 *AIN, cf32 *OUT, long long n)
+        {
+            // warm-up length ~ 24 time constants of the loop (tau = gain / rate samples), gain estimated from mean |x|
+            float g_est = agc_s.gain;
+            if (!started)
+            {
+                const long long m = std::min<long long>(n, 1 << 16);
+                ProfScope _ps("k_mean_abs", stream);
+                hipLaunchKernelGGL(k_mean_abs, dim3(64), dim3(256), 0, stream, AIN, m, d_partial.p);
+                double part[64];
+                SD_HIP(hipMemcpyAsync(part, d_partial.p, sizeof(part), hipMemcpyDeviceToHost, stream));
+                SD_HIP(hipStreamSynchronize(stream));
+                double s = 0;
+                for (double v : part)
+                    s += v;
+                const double mean = s / (double)m;
+                if (mean > 1e-12)
+                    g_est = (float)std::min((double)(agc_p.max_gain > 0 ? agc_p.max_gain : 65536.0f), (double)agc_p.reference / mean);
+            }
+            // tau = gain / rate samples; 24 tau of warm-up from the mean-based gain merge bit for bit with the previous chunk's
+            // trajectory (13 tau would do within the 1e-6 tolerance; measured: the lane kernels are bound by their strided
+            // HBM traffic, not by the chain -- a parallel-scan start value that cut W to 6 tau bought nothing net)
+            const double tau = std::max(1.0f, g_est) / std::max(1e-6f, cfg.agc_rate);
+            long long W = cfg.warmup > 0 ? cfg.warmup : (long long)(24.0 * tau);
+            W = env_int("SDHIP_W_AGC", W);
+            W = std::min<long long>(std::max<long long>(W, 1024), 1 << 22);
+            W = (W + 255) / 256 * 256;
+            agc_p.init_gain = g_est;
+            int L = pick_L(n, ST_AGC);
+            // a slow loop (the ndsp block's default rate 1e-4: 24 tau ~ 4e5 samples) on many short chunks would run K lanes over W + L
+            // samples each -- a hundred times the stream through L2 / HBM for no gain in wall time, which is (W + L) sequential steps
+            // either way: keep the chunk at least half the warm-up (work <= 3 n, still thousands of lanes on a bench-sized call)
+            if (!cfg.exact && cfg.chunk_len <= 0 && !getenv("SDHIP_CHUNK") && !getenv("SDHIP_CHUNK_AGC"))
+                L = (int)std::min<long long>(std::max<long long>(L, (W / 2 + 63) / 64 * 64), 1 << 22);
+            const ChunkGeom g = make_geom(n, L, (int)W);
+            stats.chunks += g.K;
+            if (fuse_agc_fir)
+            {
+                // AGC + RRC filter in one pass: in -> OUT holds the FILTERED samples; the lane state (gain, last 30 AGC outputs)
+                // stays on the device from call to call
+                af_p.agc = agc_p;
+                d_af_spec.reserve(g.K);
+                d_af_end.reserve(g.K);
+                launch_agc_fir(AIN, OUT, g, af_p, d_af_start.p, d_af_spec.p, d_af_end.p, nullptr, 0, stream);
+                const int vb = (g.K + 255) / 256;
+                verify_fix(
+                    "agc+fir", g.K,
+                    [&](VerdictOut *vo, int *fails, int force) {
+                        hipLaunchKernelGGL(k_agcfir_verdict, dim3(vb), dim3(256), 0, stream, g.K, d_af_spec.p, d_af_end.p, vo, fails, force);
+                    },
+                    [&](const int *list, int nr) {
+                        hipLaunchKernelGGL(k_spec_from_prev<AgcFirState>, dim3((nr + 255) / 256), dim3(256), 0, stream, list, nr, d_af_spec.p, d_af_end.p);
+                    },
+                    [&](const int *redo, int nr) { launch_agc_fir(AIN, OUT, g, af_p, d_af_start.p, d_af_spec.p, d_af_end.p, redo, nr, stream); });
+                SD_HIP(hipMemcpyAsync(d_af_start.p, d_af_end.p + (g.K - 1), sizeof(AgcFirState), hipMemcpyDeviceToDevice, stream));
+                SD_HIP(hipMemcpyAsync(&agc_s, d_af_end.p + (g.K - 1), sizeof(agc_s), hipMemcpyDeviceToHost, stream)); // the gain is the state's first member
+                SD_HIP(hipStreamSynchronize(stream));
+            }
+            else
+            {
+            d_agc_spec.reserve(g.K);
+            d_agc_end.reserve(g.K);
+            SD_HIP(hipMemcpyAsync(d_agc_start.p, &agc_s, sizeof(agc_s), hipMemcpyHostToDevice, stream));
+            ChunkCkpt agc_ck;
+            if (use_ckpt)
+            {
+                agc_ck.len = 2048;
+                agc_ck.per_chunk = L / agc_ck.len + 1;
+                d_agc_ck.reserve((size_t)g.K * agc_ck.per_chunk);
+                agc_ck.ck = d_agc_ck.p;
+                agc_ck.tol_a = 1e-6f;
+                if (getenv("SDHIP_DEBUG"))
+                {
+                    d_ck_work.reserve(6);
+                    SD_HIP(hipMemsetAsync(d_ck_work.p, 0, 6 * sizeof(unsigned long long), stream));
+                    agc_ck.work = d_ck_work.p;
+                }
+            }
+            launch_agc(AIN, OUT, g, agc_p, d_agc_start.p, d_agc_spec.p, d_agc_end.p, nullptr, 0, stream, agc_ck);
+            const int vb = (g.K + 255) / 256;
+            verify_fix(
+                "agc", g.K,
+                [&](VerdictOut *vo, int *fails, int force) {
+                    hipLaunchKernelGGL(k_agc_verdict, dim3(vb), dim3(256), 0, stream, g.K, d_agc_spec.p, d_agc_end.p, vo, fails, force);
+                },
+                [&](const int *list, int nr) {
+                    hipLaunchKernelGGL(k_spec_from_prev<AgcState>, dim3((nr + 255) / 256), dim3(256), 0, stream, list, nr, d_agc_spec.p, d_agc_end.p);
+                },
+                [&](const int *redo, int nr) { launch_agc(AIN, OUT, g, agc_p, d_agc_start.p, d_agc_spec.p, d_agc_end.p, redo, nr, stream, agc_ck); });
+            if (agc_ck.work)
+                ck_report("agc", 0);
+            SD_HIP(hipMemcpyAsync(&agc_s, d_agc_end.p + (g.K - 1), sizeof(agc_s), hipMemcpyDeviceToHost, stream));
+            SD_HIP(hipStreamSynchronize(stream));
+            }
+        }
+
+        // ---- Costas (speculative, symmetry-corrected): A -> B; cg = the chunk geometry, d_rot the frame of every chunk
+        // (sps: samples per symbol of the stage input -- the lag of the start-frequency estimate; rate_hz: its sample rate, for the stats)
+        void costas_stage(const cf32 *A, cf32 *B, long long n, ChunkGeom &cg, double sps, double rate_hz)
+        {
+            if (!started)
+            {
+                // carrier frequency for the warm-up start state: arg(sum z[n+L] conj(z[n])) / (order L), z = x^order, L ~ two
+                // symbols, on the branch next to the (unambiguous, coarse) lag-1 value -- see k_freq_est
+                const int classic = order > 4 ? 1 : 0;
+                const long long m = std::min<long long>(n, classic ? 1 << 18 : 1 << 20);
+                const int lag = (int)std::min(16.0, std::max(2.0, std::floor(2.0 * sps + 0.5)));
+                ProfScope _ps("k_freq_est", stream);
+                hipLaunchKernelGGL(k_freq_est, dim3(64), dim3(256), 0, stream, A, m, order, lag, classic, d_partial.p);
+                double part[256];
+                SD_HIP(hipMemcpyAsync(part, d_partial.p, sizeof(part), hipMemcpyDeviceToHost, stream));
+                SD_HIP(hipStreamSynchronize(stream));
+                double sr = 0, si = 0, lr = 0, li = 0;
+                for (int i = 0; i < 64; i++)
+                {
+                    sr += part[4 * i];
+                    si += part[4 * i + 1];
+                    lr += part[4 * i + 2];
+                    li += part[4 * i + 3];
+                }
+                const double coarse = std::atan2(si, sr) / order;
+                double fine = coarse;
+                if (!classic && m > 4 * lag && (lr != 0 || li != 0))
+                {
+                    const double step = 2.0 * design::PI / ((double)order * lag); // spacing of the lag-L branches
+                    const double base = std::atan2(li, lr) / ((double)order * lag);
+                    fine = base + step * std::floor((coarse - base) / step + 0.5);
+                }
+                if (getenv("SDHIP_DEBUG"))
+                    fprintf(stderr, "[sdhip] costas start frequency: lag-1 %.6f, lag-%d %.6f rad/sample (%lld samples)\n", coarse, lag, fine, m);
+                float f = (float)fine;
+                f = std::min(std::max(f, cos_p.fmin), cos_p.fmax);
+                cos_p.init_freq = f;
+            }
+            else
+                cos_p.init_freq = cos_s.freq;
+            // both loop modes decay like exp(-zeta*wn*t) with zeta*wn ~ 1.414*pll_bw per sample (unit detector gain after
+            // the AGC): 24 time constants from a phase error of up to pi/order bring the warm-up to the float floor of two
+            // trajectories of this loop on the same samples. A stream that needed more (first judgement failed widely, see
+            // the respec hook below) keeps the longer warm-up for its later calls.
+            const long long w_cos_cap = 1 << 20;
+            long long W = cfg.warmup > 0 ? cfg.warmup : (long long)std::max(512.0, 24.0 / (1.414 * std::max(1e-5f, cfg.pll_bw)));
+            W = std::max(W, w_cos_learned);
+            W = env_int("SDHIP_W_COSTAS", W);
+            W = (std::min<long long>(W, w_cos_cap) + 255) / 256 * 256;
+            const int L = pick_L(n, ST_COSTAS);
+            // Acceptance window of a Costas boundary = the soft-symbol parity target (1e-5 relative): a phase offset of d rad
+            // is a relative symbol error of d. Two trajectories of this loop on the same samples contract onto each other down to
+            // float noise (measured, tools/twin/soft_parity.py and DESIGN.md 2: median 5e-7, p99 3e-6 rad) except while one of the
+            // sign detectors of the order-4/8 error has just disagreed (a kick of ~alpha that decays within a few hundred
+            // samples): such boundaries fail the window and their chunk is re-run from the exact state until it has merged.
+            // RE-RUN window: 1e-2 rad / 4e-5 rad/sample. Boundaries outside 1e-5 rad are the ones where one of the two
+            // trajectories was kicked shortly before the boundary (sign detectors disagreeing, see above): measured on MetOp,
+            // 196 k boundaries per 16 GiB step: 71 beyond 1e-5 rad, 54 beyond 1e-4. Each decays under 1e-5 within
+            // ~tau ln(d / 1e-5) samples (tau ~ 230: <= 1600 samples of a chunk of >= 10^4 at d = 1e-2), so letting them stand
+            // costs ~5e-5 of the symbols a transient below the loop's own phase jitter, while re-running them costs a second
+            // launch whose slowest lane runs alone for over a millisecond (measured: +1.2 ms on a 96 ms step). They are counted
+            // (chunks_inexact); anything beyond the window -- a lane that has not locked -- is re-run from the exact state.
+            const double tol_phase = env_int("SDHIP_COSTAS_TOL_URAD", 10000) * 1e-6, tol_freq = env_int("SDHIP_COSTAS_TOL_NFREQ", 40000) * 1e-9;
+            ChunkCkpt cos_ck;
+            auto costas_setup = [&](long long Wn) {
+                cos_p.est_len = (int)std::min<long long>(env_int("SDHIP_COSTAS_EST", 256), Wn / 2);
+                cg = make_geom(n, L, (int)Wn);
+                d_cos_spec.reserve(cg.K);
+                d_cos_end.reserve(cg.K);
+                if (use_ckpt)
+                {
+                    cos_ck.len = 2048;
+                    cos_ck.per_chunk = L / cos_ck.len + 1;
+                    d_cos_ck.reserve((size_t)cg.K * cos_ck.per_chunk);
+                    cos_ck.ck = d_cos_ck.p;
+                    cos_ck.tol_a = (float)tol_phase;
+                    cos_ck.tol_b = (float)tol_freq;
+                    if (getenv("SDHIP_DEBUG"))
+                    {
+                        d_ck_work.reserve(6);
+                        cos_ck.work = d_ck_work.p + 3;
+                    }
+                }
+                d_rot.reserve(cg.K);
+                d_dm.reserve(cg.K);
+            };
+            costas_setup(W);
+            SD_HIP(hipMemcpyAsync(d_cos_start.p, &cos_s, sizeof(cos_s), hipMemcpyHostToDevice, stream));
+            launch_costas(A, B, cg, cos_p, d_cos_start.p, d_cos_spec.p, d_cos_end.p, nullptr, 0, stream, cos_ck);
+            verify_fix(
+                "costas", cg.K,
+                [&](VerdictOut *vo, int *fails, int force) {
+                    hipLaunchKernelGGL(k_costas_verdict, dim3((cg.K + 255) / 256), dim3(256), 0, stream, cg.K, d_cos_spec.p, d_cos_end.p, rot_unit, rot_mod, tol_phase, tol_freq,
+                                       d_dm.p, vo, fails, force);
+                },
+                [&](const int *list, int nr) {
+                    if (use_ckpt)
+                        hipLaunchKernelGGL(k_costas_spec_aligned, dim3((nr + 255) / 256), dim3(256), 0, stream, list, nr, d_cos_spec.p, d_cos_end.p, rot_unit);
+                    else
+                        hipLaunchKernelGGL(k_spec_from_prev<CostasState>, dim3((nr + 255) / 256), dim3(256), 0, stream, list, nr, d_cos_spec.p, d_cos_end.p);
+                },
+                [&](const int *redo, int nr) { launch_costas(A, B, cg, cos_p, d_cos_start.p, d_cos_spec.p, d_cos_end.p, redo, nr, stream, cos_ck); },
+                [&](int) {
+                    // Many warm-ups missed. (a) The start frequency was off (the M-th-power estimate is weak for order 8 and at low
+                    // SNR; a call may also begin in noise with the carried loop state meaningless): every lane has meanwhile run a
+                    // real loop over W + L samples, and the median of their end frequencies is a far better start value. (b) The
+                    // warm-up is too short for this signal's loop dynamics: double it (the stream keeps the longer one).
+                    std::vector<CostasState> es((size_t)cg.K);
+                    SD_HIP(hipMemcpyAsync(es.data(), d_cos_end.p, es.size() * sizeof(CostasState), hipMemcpyDeviceToHost, stream));
+                    SD_HIP(hipStreamSynchronize(stream));
+                    std::vector<float> fr(es.size());
+                    for (size_t i = 0; i < es.size(); i++)
+                        fr[i] = es[i].freq;
+                    std::nth_element(fr.begin(), fr.begin() + fr.size() / 2, fr.end());
+                    const float med = fr[fr.size() / 2];
+                    if (std::fabs(med - cos_p.init_freq) > 0.05f * cfg.pll_bw)
+                        cos_p.init_freq = med;
+                    else if (cfg.warmup <= 0 && !getenv("SDHIP_W_COSTAS") && 2 * (long long)cg.W <= w_cos_cap)
+                    {
+                        w_cos_learned = 2 * (long long)cg.W;
+                        costas_setup(w_cos_learned);
+                    }
+                    else
+                        return false;
+                    launch_costas(A, B, cg, cos_p, d_cos_start.p, d_cos_spec.p, d_cos_end.p, nullptr, 0, stream, cos_ck);
+                    return true;
+                });
+            stats.chunks += cg.K;
+            if (cos_ck.work)
+                ck_report("costas", 1);
+            // rot[k] = frame of chunk k relative to the stream's (prefix sum of the per-boundary turns)
+            {
+                const int nt = (cg.K + 1023) / 1024;
+                d_tile_sums.reserve(nt);
+                hipLaunchKernelGGL(k_chunk_scan_sums, dim3(nt), dim3(1024), 0, stream, cg.K, 0, d_dm.p, nullptr, nullptr, nullptr, 0, d_tile_sums.p, nullptr);
+                hipLaunchKernelGGL(k_chunk_scan_apply, dim3(nt), dim3(1024), 0, stream, cg.K, 0, d_dm.p, rot_mod, d_rot.p, nullptr, nullptr, nullptr, d_tile_sums.p,
+                                   nullptr, nullptr, nullptr);
+            }
+            int rot_last = 0;
+            SD_HIP(hipMemcpyAsync(&cos_s, d_cos_end.p + (cg.K - 1), sizeof(cos_s), hipMemcpyDeviceToHost, stream));
+            SD_HIP(hipMemcpyAsync(&rot_last, d_rot.p + (cg.K - 1), sizeof(int), hipMemcpyDeviceToHost, stream));
+            SD_HIP(hipStreamSynchronize(stream));
+            // chunk k's phase = true phase + rot[k]*unit; carry the loop state in the frame of the last chunk,
+            // re-expressed in the stream's frame (rot 0) so the next call starts unrotated
+            if (rot_last != 0)
+            {
+                double ph = (double)cos_s.phase - rot_last * rot_unit;
+                while (ph > 2 * design::PI)
+                    ph -= 2 * design::PI;
+                while (ph < -2 * design::PI)
+                    ph += 2 * design::PI;
+                cos_s.phase = (float)ph;
+            }
+            stats.freq_hz = (float)(((double)cos_s.freq / (2.0 * design::PI)) * rate_hz);
+        }
+
+        // ---- M&M + quantiser: A (history in front) -> d_soft / d_syms; returns the soft symbols written (last_symbols: the symbols)
+        long long last_symbols = 0;
+        int64_t mm_stage(cf32 *A, long long n, const ChunkGeom &cg, const int *mm_rot, int8_t *d_soft, size_t soft_cap, float *d_syms, size_t syms_cap,
+                         std::vector<cf32> &hist)
+        {
+            put_hist(A, hist);
+            // timing loop: ~2/(Kd*gain_mu) symbols per time constant with a detector gain Kd well below 1 at low Es/N0
+            // (measured: ~700 symbols at 7 dB BPSK with the default gains)
+            // gear-shifted warm-up (tools/mm_gear_study.py): ~2.75/gain_mu symbols at 8x the timing gain (rate term frozen) pull the
+            // phase in, ~16/gain_mu symbols at the loop's own gains settle it onto the sequential trajectory
+            // (|dt| p99 < 0.03 sample at GOES' 7 dB, far less for the QPSK configs); 36/gain_mu without the fast gear
+            const double gmu = std::max(1e-4f, cfg.clock_gain_mu);
+            // SDHIP_MM_Q8=1 (experiment): when nobody asks for the float symbols the clock recovery stores the int8 soft symbols
+            // itself. Measured on MetOp: the compaction behind it drops from 2.7 to 1.5 ms, but the ~15 extra VALU instructions per
+            // symbol cost the issue-bound k_mm 1.3 - 2.2 ms (unpaired / dword-paired stores): off by default.
+            mm_p.q8 = (d_syms == nullptr && env_int("SDHIP_MM_Q8", 0) != 0) ? 1 : 0;
+            mm_p.q8_bpsk = is_bpsk ? 1 : 0;
+            mm_p.fast = (!cfg.exact && env_int("SDHIP_FAST_MATH", 1) != 0) ? 1 : 0;
+            mm_p.fast_mult = (float)env_int("SDHIP_MM_FAST_MULT", 8);
+            mm_p.fast_syms = mm_p.fast_mult > 1.0f ? (int)env_int("SDHIP_MM_FAST_SYMS", (long long)(2.75 / gmu)) : 0;
+            // a re-run costs one lane the whole chunk, so long chunks (large batches) keep the conservative warm-up: it is a
+            // small fraction of L there anyway
+            const int L = pick_L(n, ST_MM);
+            const double w_full = 36.0 / gmu * final_sps;
+            const double w_gear = mm_p.fast_syms > 0 ? (mm_p.fast_syms + 16.0 / gmu) * final_sps : w_full;
+            // Warm-up length. The timing loop's contraction rate depends on the detector gain, i.e. on the signal (measured time
+            // constants: ~360 symbols for MetOp QPSK at 10 dB, ~870 for GOES BPSK at 7 dB; tools/twin/soft_parity.py),
+            // and the chunk's symbols only agree with the sequential reference's once the warm-up has brought the lane within
+            // ~1e-4 sample of its trajectory. So the first guess (gear-shifted ~19/gain_mu symbols) is checked against the tight
+            // hand-off window below, and if more than an eighth of the boundaries miss it the stage is launched again with twice
+            // the warm-up (up to 64 loop constants 1/gain_mu); the stream keeps what it learned for its later calls.
+            const long long w_mm_cap = (long long)(64.0 / gmu * final_sps);
+            long long W = cfg.warmup > 0 ? cfg.warmup : (long long)std::min(w_full, std::max(w_gear, 0.5 * L));
+            W = std::max(W, w_mm_learned);
+            W = env_int("SDHIP_W_MM", W);
+            W = (W + 255) / 256 * 256;
+            ChunkGeom g;
+            // Hand-off windows of an M&M boundary, in samples of timing. Two trajectories of this loop on the same samples
+            // hover 3e-5 ... 3e-4 sample apart (the feedback is piecewise constant in mu through the arm index), which makes
+            // them pick different interpolator arms on 0.3-0.7 % of the symbols -- the floor of any time-parallel schedule.
+            //  * TIGHT (2e-4): a boundary inside it adds nothing to that floor. It is the yardstick of the warm-up length: when more
+            //    than an eighth of the boundaries miss it, the warm-up is doubled (respec below).
+            //  * RE-RUN (5e-3): a boundary outside it is re-run from the exact state (and stops as soon as it is back inside). Between
+            //    the two windows a chunk starts <= 5e-3 sample off and is on the floor again within a loop time constant (a few
+            //    hundred symbols of a chunk of thousands): measured on MetOp, 14 of 65 k boundaries per step lie between 1e-3 and
+            //    the re-run window; re-running them moves the 1e-5 fraction in the sixth digit and costs a second launch whose
+            //    slowest lane runs alone for milliseconds.
+            const double MM_TOL_TIGHT = 2e-4;
+            const double MM_TOL = getenv("SDHIP_MM_TOL_MICRO") ? env_int("SDHIP_MM_TOL_MICRO", 5000) * 1e-6
+                                                              : (getenv("SDHIP_MM_TOL_MILLI") ? env_int("SDHIP_MM_TOL_MILLI", 5) * 1e-3 : 5e-3);
+            MmCkpt *ckp = nullptr;
+            int ck_per_chunk = 0;
+            auto mm_setup = [&](long long Wn) {
+                g = make_geom(n, L, (int)Wn);
+                const double omin = (double)mm_p.omega_mid - (double)mm_p.omega_limit;
+                const long long span0 = std::min<long long>(n, (long long)L + Wn);
+                mm_p.cap = ((int)(span0 / std::max(0.5, omin - 0.01)) + 16 + 1) & ~1; // even: int8 rows start on a dword
+                mm_p.cg = cg;
+                mm_p.rot = mm_rot;
+                symbuf.reserve((size_t)g.K * mm_p.cap);
+                d_counts.reserve(2 * (size_t)g.K);
+                d_offsets.reserve(g.K);
+                d_mm_spec.reserve(g.K);
+                d_mm_end.reserve(g.K);
+                d_mm_spec_c.reserve(g.K);
+                d_mm_end_c.reserve(g.K);
+                d_skip.reserve(g.K);
+                d_extra.reserve(g.K);
+                d_seg.reserve(2 * (size_t)g.K);
+                ck_per_chunk = L / MM_CK_SAMPLES + 2;
+                if (use_ckpt || env_int("SDHIP_MM_CKPT", 0))
+                { // checkpoints for the early exit of re-run lanes, k_mm<true>
+                    d_mm_ck.reserve((size_t)g.K * ck_per_chunk);
+                    ckp = d_mm_ck.p;
+                }
+            };
+            mm_setup(W);
+            SD_HIP(hipMemcpyAsync(d_mm_start.p, &mm_s, sizeof(mm_s), hipMemcpyHostToDevice, stream));
+            launch_mm(A, symbuf.p, d_counts.p, g, mm_p, d_mm_start.p, d_mm_spec.p, d_mm_end.p, d_mm_spec_c.p, d_mm_end_c.p, nullptr, 0, stream, ckp, ck_per_chunk,
+                      (float)MM_TOL);
+            // Symbol hand-off at chunk boundaries. The M&M loop never re-merges bit for bit: its feedback is piecewise
+            // constant through the 128-arm interpolator index rint(mu*128) (clock_recovery_mm.cpp:66), so independent
+            // trajectories hover a fraction of an arm apart (tools/merge_study.py). What is certified is CONSISTENCY in
+            // time: t = inc + mu of the first symbol of chunk k (from its own warm-up) against the next-symbol time chunk
+            // k-1 ended with. Equal within MM_TOL samples: chunk k stands. Exactly one or two symbol periods apart (the
+            // boundary fell between the two trajectories' sample indices, mu wrapping on opposite sides): the symbol(s) are
+            // taken from chunk k-1's look-ahead, or skipped at the head of chunk k. Anything else: re-run from the exact state.
+            // (k_mm_verdict; the compaction segments and offsets are a prefix sum on the device, k_chunk_scan.)
+            verify_fix(
+                "mm", g.K,
+                [&](VerdictOut *vo, int *fails, int force) {
+                    hipLaunchKernelGGL(k_mm_verdict, dim3((g.K + 255) / 256), dim3(256), 0, stream, g.K, d_mm_spec_c.p, d_mm_end_c.p, d_counts.p, MM_TOL, std::min(MM_TOL, MM_TOL_TIGHT),
+                                       d_skip.p, d_extra.p, vo, fails, force);
+                },
+                [&](const int *list, int nr) {
+                    if (getenv("SDHIP_DEBUG"))
+                    { // first few rejected boundaries of the round
+                        int idx[4];
+                        const int m = std::min(nr, 4);
+                        SD_HIP(hipMemcpy(idx, list, m * sizeof(int), hipMemcpyDeviceToHost));
+                        for (int q = 0; q < m; q++)
+                        {
+                            MmCert a, b;
+                            SD_HIP(hipMemcpy(&a, d_mm_spec_c.p + idx[q], sizeof(a), hipMemcpyDeviceToHost));
+                            SD_HIP(hipMemcpy(&b, d_mm_end_c.p + idx[q] - 1, sizeof(b), hipMemcpyDeviceToHost));
+                            const double d = (double)(a.inc - b.inc) + ((double)a.mu - (double)b.mu);
+                            fprintf(stderr, "[sdhip] mm boundary %d rejected: dt %.5f samples = %.3f symbols, omega %.6f vs %.6f\n", idx[q], d, d / b.omega, a.omega, b.omega);
+                        }
+                    }
+                    hipLaunchKernelGGL(k_spec_from_prev<MmCert>, dim3((nr + 255) / 256), dim3(256), 0, stream, list, nr, d_mm_spec_c.p, d_mm_end_c.p);
+                    hipLaunchKernelGGL(k_spec_from_prev<MmState>, dim3((nr + 255) / 256), dim3(256), 0, stream, list, nr, d_mm_spec.p, d_mm_end.p);
+                },
+                [&](const int *redo, int nr) {
+                    launch_mm(A, symbuf.p, d_counts.p, g, mm_p, d_mm_start.p, d_mm_spec.p, d_mm_end.p, d_mm_spec_c.p, d_mm_end_c.p, redo, nr, stream, ckp,
+                              ck_per_chunk, (float)MM_TOL);
+                },
+                [&](int nf) {
+                    const long long wn = (std::min<long long>(2 * (long long)g.W, w_mm_cap) + 255) / 256 * 256;
+                    if (cfg.warmup > 0 || getenv("SDHIP_W_MM") || wn <= (long long)g.W)
+                        return false;
+                    w_mm_learned = wn;
+                    if (getenv("SDHIP_DEBUG"))
+                        fprintf(stderr, "[sdhip] mm     %d of %d boundaries outside the hand-off window: warm-up %d -> %lld samples\n", nf, g.K, g.W, w_mm_learned);
+                    mm_setup(w_mm_learned);
+                    launch_mm(A, symbuf.p, d_counts.p, g, mm_p, d_mm_start.p, d_mm_spec.p, d_mm_end.p, d_mm_spec_c.p, d_mm_end_c.p, nullptr, 0, stream, ckp,
+                              ck_per_chunk, (float)MM_TOL);
+                    return true;
+                });
+            stats.chunks += g.K;
+            // compaction segments + offsets + total
+            SD_HIP(hipMemsetAsync(d_vout.p, 0, sizeof(VerdictOut), stream));
+            {
+                const int nt = (g.K + 1023) / 1024;
+                d_tile_sums.reserve(nt);
+                hipLaunchKernelGGL(k_chunk_scan_sums, dim3(nt), dim3(1024), 0, stream, g.K, 1, nullptr, d_counts.p, d_skip.p, d_extra.p, mm_p.cap, d_tile_sums.p,
+                                   d_vout.p);
+                hipLaunchKernelGGL(k_chunk_scan_apply, dim3(nt), dim3(1024), 0, stream, g.K, 1, nullptr, 1, nullptr, d_counts.p, d_skip.p, d_extra.p, d_tile_sums.p,
+                                   d_seg.p, d_offsets.p, d_vout.p);
+            }
+            SD_HIP(hipMemcpyAsync(h_vout.p, d_vout.p, sizeof(VerdictOut), hipMemcpyDeviceToHost, stream));
+            SD_HIP(hipMemcpyAsync(&mm_s, d_mm_end.p + (g.K - 1), sizeof(mm_s), hipMemcpyDeviceToHost, stream));
+            SD_HIP(hipStreamSynchronize(stream));
+            mm_s.inc -= n; // clock_recovery_mm.cpp:123-126
+            if (mm_s.inc < 0)
+                mm_s.inc = 0;
+            if (h_vout.p->overflow)
+                throw HipError("symbol scratch overflow");
+            const long long tot = h_vout.p->total;
+            const long long need_soft = is_bpsk ? tot : 2 * tot;
+            if ((size_t)need_soft > soft_cap)
+                throw HipError("soft output buffer too small");
+            if (mm_p.q8)
+                launch_compact8(symbuf.p, d_seg.p, d_offsets.p, g.K, mm_p.cap, is_bpsk ? 1 : 0, d_soft, (long long)soft_cap, stream);
+            else
+                launch_quantize(symbuf.p, d_seg.p, d_offsets.p, g.K, mm_p.cap, is_bpsk ? 1 : 0, d_soft, (long long)soft_cap, d_syms, (long long)syms_cap, stream);
+            // history for the next call: last DEMOD_HIST de-rotated Costas outputs
+            launch_tail_copy(A, n, DEMOD_HIST, cg, mm_rot, order, d_hist.p, stream);
+            SD_HIP(hipMemcpyAsync(hist.data(), d_hist.p, DEMOD_HIST * sizeof(cf32), hipMemcpyDeviceToHost, stream));
+            SD_HIP(hipStreamSynchronize(stream));
+            stats.symbols_out += tot;
+            last_symbols = tot;
+            return need_soft;
+        }
+
         int64_t process(const void *d_in, size_t n_in, int fmt, int8_t *d_soft, size_t soft_cap, float *d_syms, size_t syms_cap)
         {
             SD_HIP(hipSetDevice(cfg.device));
@@ -1335,95 +1780,8 @@ namespace sdhip
             if (!fuse_afc)
             {
                 const cf32 *AIN = (in_place && !resample) ? SRC : A; // k_chunks never loads outside [chunk begin - W, chunk end)
-                // warm-up length ~ 24 time constants of the loop (tau = gain / rate samples), gain estimated from mean |x|
-                float g_est = agc_s.gain;
-                if (!started)
-                {
-                    const long long m = std::min<long long>(n, 1 << 16);
-                    ProfScope _ps("k_mean_abs", stream);
-                    hipLaunchKernelGGL(k_mean_abs, dim3(64), dim3(256), 0, stream, AIN, m, d_partial.p);
-                    double part[64];
-                    SD_HIP(hipMemcpyAsync(part, d_partial.p, sizeof(part), hipMemcpyDeviceToHost, stream));
-                    SD_HIP(hipStreamSynchronize(stream));
-                    double s = 0;
-                    for (double v : part)
-                        s += v;
-                    const double mean = s / (double)m;
-                    if (mean > 1e-12)
-                        g_est = (float)std::min(65536.0, 1.0 / mean);
-                }
-                // tau = gain / rate samples; 24 tau of warm-up from the mean-based gain merge bit for bit with the previous chunk's
-                // trajectory (13 tau would do within the 1e-6 tolerance; measured: the lane kernels are bound by their strided
-                // HBM traffic, not by the chain -- a parallel-scan start value that cut W to 6 tau bought nothing net)
-                const double tau = std::max(1.0f, g_est) / std::max(1e-6f, cfg.agc_rate);
-                long long W = cfg.warmup > 0 ? cfg.warmup : (long long)(24.0 * tau);
-                W = env_int("SDHIP_W_AGC", W);
-                W = std::min<long long>(std::max<long long>(W, 1024), 1 << 22);
-                W = (W + 255) / 256 * 256;
-                agc_p.init_gain = g_est;
-                const int L = pick_L(n, ST_AGC);
-                const ChunkGeom g = make_geom(n, L, (int)W);
-                stats.chunks += g.K;
-                if (fuse_agc_fir)
-                {
-                    // AGC + RRC filter in one pass: in -> B holds the FILTERED samples; the lane state (gain, last 30 AGC outputs)
-                    // stays on the device from call to call
-                    af_p.agc = agc_p;
-                    d_af_spec.reserve(g.K);
-                    d_af_end.reserve(g.K);
-                    launch_agc_fir(AIN, B, g, af_p, d_af_start.p, d_af_spec.p, d_af_end.p, nullptr, 0, stream);
-                    const int vb = (g.K + 255) / 256;
-                    verify_fix(
-                        "agc+fir", g.K,
-                        [&](VerdictOut *vo, int *fails, int force) {
-                            hipLaunchKernelGGL(k_agcfir_verdict, dim3(vb), dim3(256), 0, stream, g.K, d_af_spec.p, d_af_end.p, vo, fails, force);
-                        },
-                        [&](const int *list, int nr) {
-                            hipLaunchKernelGGL(k_spec_from_prev<AgcFirState>, dim3((nr + 255) / 256), dim3(256), 0, stream, list, nr, d_af_spec.p, d_af_end.p);
-                        },
-                        [&](const int *redo, int nr) { launch_agc_fir(AIN, B, g, af_p, d_af_start.p, d_af_spec.p, d_af_end.p, redo, nr, stream); });
-                    SD_HIP(hipMemcpyAsync(d_af_start.p, d_af_end.p + (g.K - 1), sizeof(AgcFirState), hipMemcpyDeviceToDevice, stream));
-                    SD_HIP(hipMemcpyAsync(&agc_s, d_af_end.p + (g.K - 1), sizeof(agc_s), hipMemcpyDeviceToHost, stream)); // the gain is the state's first member
-                    SD_HIP(hipStreamSynchronize(stream));
-                    std::swap(A, B);
-                }
-                else
-                {
-                d_agc_spec.reserve(g.K);
-                d_agc_end.reserve(g.K);
-                SD_HIP(hipMemcpyAsync(d_agc_start.p, &agc_s, sizeof(agc_s), hipMemcpyHostToDevice, stream));
-                ChunkCkpt agc_ck;
-                if (use_ckpt)
-                {
-                    agc_ck.len = 2048;
-                    agc_ck.per_chunk = L / agc_ck.len + 1;
-                    d_agc_ck.reserve((size_t)g.K * agc_ck.per_chunk);
-                    agc_ck.ck = d_agc_ck.p;
-                    agc_ck.tol_a = 1e-6f;
-                    if (getenv("SDHIP_DEBUG"))
-                    {
-                        d_ck_work.reserve(6);
-                        SD_HIP(hipMemsetAsync(d_ck_work.p, 0, 6 * sizeof(unsigned long long), stream));
-                        agc_ck.work = d_ck_work.p;
-                    }
-                }
-                launch_agc(AIN, B, g, agc_p, d_agc_start.p, d_agc_spec.p, d_agc_end.p, nullptr, 0, stream, agc_ck);
-                const int vb = (g.K + 255) / 256;
-                verify_fix(
-                    "agc", g.K,
-                    [&](VerdictOut *vo, int *fails, int force) {
-                        hipLaunchKernelGGL(k_agc_verdict, dim3(vb), dim3(256), 0, stream, g.K, d_agc_spec.p, d_agc_end.p, vo, fails, force);
-                    },
-                    [&](const int *list, int nr) {
-                        hipLaunchKernelGGL(k_spec_from_prev<AgcState>, dim3((nr + 255) / 256), dim3(256), 0, stream, list, nr, d_agc_spec.p, d_agc_end.p);
-                    },
-                    [&](const int *redo, int nr) { launch_agc(AIN, B, g, agc_p, d_agc_start.p, d_agc_spec.p, d_agc_end.p, redo, nr, stream, agc_ck); });
-                if (agc_ck.work)
-                    ck_report("agc", 0);
-                SD_HIP(hipMemcpyAsync(&agc_s, d_agc_end.p + (g.K - 1), sizeof(agc_s), hipMemcpyDeviceToHost, stream));
-                SD_HIP(hipStreamSynchronize(stream));
+                agc_stage(AIN, B, n);
                 std::swap(A, B);
-                }
             }
             tick("agc");
             // ---- RRC FIR (parallel, exact) -- unless it rode on the AGC lanes
@@ -1456,156 +1814,7 @@ namespace sdhip
             // ---- Costas (speculative, symmetry-corrected)
             if (!fuse_afc)
             {
-                if (!started)
-                {
-                    // carrier frequency for the warm-up start state: arg(sum z[n+L] conj(z[n])) / (order L), z = x^order, L ~ two
-                    // symbols, on the branch next to the (unambiguous, coarse) lag-1 value -- see k_freq_est
-                    const int classic = order > 4 ? 1 : 0;
-                    const long long m = std::min<long long>(n, classic ? 1 << 18 : 1 << 20);
-                    const int lag = (int)std::min(16.0, std::max(2.0, std::floor(2.0 * final_sps + 0.5)));
-                    ProfScope _ps("k_freq_est", stream);
-                    hipLaunchKernelGGL(k_freq_est, dim3(64), dim3(256), 0, stream, A, m, order, lag, classic, d_partial.p);
-                    double part[256];
-                    SD_HIP(hipMemcpyAsync(part, d_partial.p, sizeof(part), hipMemcpyDeviceToHost, stream));
-                    SD_HIP(hipStreamSynchronize(stream));
-                    double sr = 0, si = 0, lr = 0, li = 0;
-                    for (int i = 0; i < 64; i++)
-                    {
-                        sr += part[4 * i];
-                        si += part[4 * i + 1];
-                        lr += part[4 * i + 2];
-                        li += part[4 * i + 3];
-                    }
-                    const double coarse = std::atan2(si, sr) / order;
-                    double fine = coarse;
-                    if (!classic && m > 4 * lag && (lr != 0 || li != 0))
-                    {
-                        const double step = 2.0 * design::PI / ((double)order * lag); // spacing of the lag-L branches
-                        const double base = std::atan2(li, lr) / ((double)order * lag);
-                        fine = base + step * std::floor((coarse - base) / step + 0.5);
-                    }
-                    if (getenv("SDHIP_DEBUG"))
-                        fprintf(stderr, "[sdhip] costas start frequency: lag-1 %.6f, lag-%d %.6f rad/sample (%lld samples)\n", coarse, lag, fine, m);
-                    float f = (float)fine;
-                    f = std::min(std::max(f, cos_p.fmin), cos_p.fmax);
-                    cos_p.init_freq = f;
-                }
-                else
-                    cos_p.init_freq = cos_s.freq;
-                // both loop modes decay like exp(-zeta*wn*t) with zeta*wn ~ 1.414*pll_bw per sample (unit detector gain after
-                // the AGC): 24 time constants from a phase error of up to pi/order bring the warm-up to the float floor of two
-                // trajectories of this loop on the same samples. A stream that needed more (first judgement failed widely, see
-                // the respec hook below) keeps the longer warm-up for its later calls.
-                const long long w_cos_cap = 1 << 20;
-                long long W = cfg.warmup > 0 ? cfg.warmup : (long long)std::max(512.0, 24.0 / (1.414 * std::max(1e-5f, cfg.pll_bw)));
-                W = std::max(W, w_cos_learned);
-                W = env_int("SDHIP_W_COSTAS", W);
-                W = (std::min<long long>(W, w_cos_cap) + 255) / 256 * 256;
-                const int L = pick_L(n, ST_COSTAS);
-                // Acceptance window of a Costas boundary = the soft-symbol parity target (1e-5 relative): a phase offset of d rad
-                // is a relative symbol error of d. Two trajectories of this loop on the same samples contract onto each other down to
-                // float noise (measured, tools/twin/soft_parity.py and DESIGN.md 2: median 5e-7, p99 3e-6 rad) except while one of the
-                // sign detectors of the order-4/8 error has just disagreed (a kick of ~alpha that decays within a few hundred
-                // samples): such boundaries fail the window and their chunk is re-run from the exact state until it has merged.
-                // RE-RUN window: 1e-2 rad / 4e-5 rad/sample. Boundaries outside 1e-5 rad are the ones where one of the two
-                // trajectories was kicked shortly before the boundary (sign detectors disagreeing, see above): measured on MetOp,
-                // 196 k boundaries per 16 GiB step: 71 beyond 1e-5 rad, 54 beyond 1e-4. Each decays under 1e-5 within
-                // ~tau ln(d / 1e-5) samples (tau ~ 230: <= 1600 samples of a chunk of >= 10^4 at d = 1e-2), so letting them stand
-                // costs ~5e-5 of the symbols a transient below the loop's own phase jitter, while re-running them costs a second
-                // launch whose slowest lane runs alone for over a millisecond (measured: +1.2 ms on a 96 ms step). They are counted
-                // (chunks_inexact); anything beyond the window -- a lane that has not locked -- is re-run from the exact state.
-                const double tol_phase = env_int("SDHIP_COSTAS_TOL_URAD", 10000) * 1e-6, tol_freq = env_int("SDHIP_COSTAS_TOL_NFREQ", 40000) * 1e-9;
-                ChunkCkpt cos_ck;
-                auto costas_setup = [&](long long Wn) {
-                    cos_p.est_len = (int)std::min<long long>(env_int("SDHIP_COSTAS_EST", 256), Wn / 2);
-                    cg = make_geom(n, L, (int)Wn);
-                    d_cos_spec.reserve(cg.K);
-                    d_cos_end.reserve(cg.K);
-                    if (use_ckpt)
-                    {
-                        cos_ck.len = 2048;
-                        cos_ck.per_chunk = L / cos_ck.len + 1;
-                        d_cos_ck.reserve((size_t)cg.K * cos_ck.per_chunk);
-                        cos_ck.ck = d_cos_ck.p;
-                        cos_ck.tol_a = (float)tol_phase;
-                        cos_ck.tol_b = (float)tol_freq;
-                        if (getenv("SDHIP_DEBUG"))
-                        {
-                            d_ck_work.reserve(6);
-                            cos_ck.work = d_ck_work.p + 3;
-                        }
-                    }
-                    d_rot.reserve(cg.K);
-                    d_dm.reserve(cg.K);
-                };
-                costas_setup(W);
-                SD_HIP(hipMemcpyAsync(d_cos_start.p, &cos_s, sizeof(cos_s), hipMemcpyHostToDevice, stream));
-                launch_costas(A, B, cg, cos_p, d_cos_start.p, d_cos_spec.p, d_cos_end.p, nullptr, 0, stream, cos_ck);
-                verify_fix(
-                    "costas", cg.K,
-                    [&](VerdictOut *vo, int *fails, int force) {
-                        hipLaunchKernelGGL(k_costas_verdict, dim3((cg.K + 255) / 256), dim3(256), 0, stream, cg.K, d_cos_spec.p, d_cos_end.p, rot_unit, rot_mod, tol_phase, tol_freq,
-                                           d_dm.p, vo, fails, force);
-                    },
-                    [&](const int *list, int nr) {
-                        if (use_ckpt)
-                            hipLaunchKernelGGL(k_costas_spec_aligned, dim3((nr + 255) / 256), dim3(256), 0, stream, list, nr, d_cos_spec.p, d_cos_end.p, rot_unit);
-                        else
-                            hipLaunchKernelGGL(k_spec_from_prev<CostasState>, dim3((nr + 255) / 256), dim3(256), 0, stream, list, nr, d_cos_spec.p, d_cos_end.p);
-                    },
-                    [&](const int *redo, int nr) { launch_costas(A, B, cg, cos_p, d_cos_start.p, d_cos_spec.p, d_cos_end.p, redo, nr, stream, cos_ck); },
-                    [&](int) {
-                        // Many warm-ups missed. (a) The start frequency was off (the M-th-power estimate is weak for order 8 and at low
-                        // SNR; a call may also begin in noise with the carried loop state meaningless): every lane has meanwhile run a
-                        // real loop over W + L samples, and the median of their end frequencies is a far better start value. (b) The
-                        // warm-up is too short for this signal's loop dynamics: double it (the stream keeps the longer one).
-                        std::vector<CostasState> es((size_t)cg.K);
-                        SD_HIP(hipMemcpyAsync(es.data(), d_cos_end.p, es.size() * sizeof(CostasState), hipMemcpyDeviceToHost, stream));
-                        SD_HIP(hipStreamSynchronize(stream));
-                        std::vector<float> fr(es.size());
-                        for (size_t i = 0; i < es.size(); i++)
-                            fr[i] = es[i].freq;
-                        std::nth_element(fr.begin(), fr.begin() + fr.size() / 2, fr.end());
-                        const float med = fr[fr.size() / 2];
-                        if (std::fabs(med - cos_p.init_freq) > 0.05f * cfg.pll_bw)
-                            cos_p.init_freq = med;
-                        else if (cfg.warmup <= 0 && !getenv("SDHIP_W_COSTAS") && 2 * (long long)cg.W <= w_cos_cap)
-                        {
-                            w_cos_learned = 2 * (long long)cg.W;
-                            costas_setup(w_cos_learned);
-                        }
-                        else
-                            return false;
-                        launch_costas(A, B, cg, cos_p, d_cos_start.p, d_cos_spec.p, d_cos_end.p, nullptr, 0, stream, cos_ck);
-                        return true;
-                    });
-                stats.chunks += cg.K;
-                if (cos_ck.work)
-                    ck_report("costas", 1);
-                // rot[k] = frame of chunk k relative to the stream's (prefix sum of the per-boundary turns)
-                {
-                    const int nt = (cg.K + 1023) / 1024;
-                    d_tile_sums.reserve(nt);
-                    hipLaunchKernelGGL(k_chunk_scan_sums, dim3(nt), dim3(1024), 0, stream, cg.K, 0, d_dm.p, nullptr, nullptr, nullptr, 0, d_tile_sums.p, nullptr);
-                    hipLaunchKernelGGL(k_chunk_scan_apply, dim3(nt), dim3(1024), 0, stream, cg.K, 0, d_dm.p, rot_mod, d_rot.p, nullptr, nullptr, nullptr, d_tile_sums.p,
-                                       nullptr, nullptr, nullptr);
-                }
-                int rot_last = 0;
-                SD_HIP(hipMemcpyAsync(&cos_s, d_cos_end.p + (cg.K - 1), sizeof(cos_s), hipMemcpyDeviceToHost, stream));
-                SD_HIP(hipMemcpyAsync(&rot_last, d_rot.p + (cg.K - 1), sizeof(int), hipMemcpyDeviceToHost, stream));
-                SD_HIP(hipStreamSynchronize(stream));
-                // chunk k's phase = true phase + rot[k]*unit; carry the loop state in the frame of the last chunk,
-                // re-expressed in the stream's frame (rot 0) so the next call starts unrotated
-                if (rot_last != 0)
-                {
-                    double ph = (double)cos_s.phase - rot_last * rot_unit;
-                    while (ph > 2 * design::PI)
-                        ph -= 2 * design::PI;
-                    while (ph < -2 * design::PI)
-                        ph += 2 * design::PI;
-                    cos_s.phase = (float)ph;
-                }
-                stats.freq_hz = (float)(((double)cos_s.freq / (2.0 * design::PI)) * (double)final_samplerate);
+                costas_stage(A, B, n, cg, final_sps, (double)final_samplerate);
                 std::swap(A, B);
             }
             // ---- post_costas_dc (module_psk_demod.cpp:127-134): the DC block sees ONE coherent stream, so the per-chunk frames of the
@@ -1628,168 +1837,73 @@ namespace sdhip
             }
             tick("costas");
             // ---- M&M + quantiser
-            int64_t nsoft = 0;
-            {
-                put_hist(A, hist_cos);
-                // timing loop: ~2/(Kd*gain_mu) symbols per time constant with a detector gain Kd well below 1 at low Es/N0
-                // (measured: ~700 symbols at 7 dB BPSK with the default gains)
-                // gear-shifted warm-up (tools/mm_gear_study.py): ~2.75/gain_mu symbols at 8x the timing gain (rate term frozen) pull the
-                // phase in, ~16/gain_mu symbols at the loop's own gains settle it onto the sequential trajectory
-                // (|dt| p99 < 0.03 sample at GOES' 7 dB, far less for the QPSK configs); 36/gain_mu without the fast gear
-                const double gmu = std::max(1e-4f, cfg.clock_gain_mu);
-                // SDHIP_MM_Q8=1 (experiment): when nobody asks for the float symbols the clock recovery stores the int8 soft symbols
-                // itself. Measured on MetOp: the compaction behind it drops from 2.7 to 1.5 ms, but the ~15 extra VALU instructions per
-                // symbol cost the issue-bound k_mm 1.3 - 2.2 ms (unpaired / dword-paired stores): off by default.
-                mm_p.q8 = (d_syms == nullptr && env_int("SDHIP_MM_Q8", 0) != 0) ? 1 : 0;
-                mm_p.q8_bpsk = is_bpsk ? 1 : 0;
-                mm_p.fast = (!cfg.exact && env_int("SDHIP_FAST_MATH", 1) != 0) ? 1 : 0;
-                mm_p.fast_mult = (float)env_int("SDHIP_MM_FAST_MULT", 8);
-                mm_p.fast_syms = mm_p.fast_mult > 1.0f ? (int)env_int("SDHIP_MM_FAST_SYMS", (long long)(2.75 / gmu)) : 0;
-                // a re-run costs one lane the whole chunk, so long chunks (large batches) keep the conservative warm-up: it is a
-                // small fraction of L there anyway
-                const int L = pick_L(n, ST_MM);
-                const double w_full = 36.0 / gmu * final_sps;
-                const double w_gear = mm_p.fast_syms > 0 ? (mm_p.fast_syms + 16.0 / gmu) * final_sps : w_full;
-                // Warm-up length. The timing loop's contraction rate depends on the detector gain, i.e. on the signal (measured time
-                // constants: ~360 symbols for MetOp QPSK at 10 dB, ~870 for GOES BPSK at 7 dB; tools/twin/soft_parity.py),
-                // and the chunk's symbols only agree with the sequential reference's once the warm-up has brought the lane within
-                // ~1e-4 sample of its trajectory. So the first guess (gear-shifted ~19/gain_mu symbols) is checked against the tight
-                // hand-off window below, and if more than an eighth of the boundaries miss it the stage is launched again with twice
-                // the warm-up (up to 64 loop constants 1/gain_mu); the stream keeps what it learned for its later calls.
-                const long long w_mm_cap = (long long)(64.0 / gmu * final_sps);
-                long long W = cfg.warmup > 0 ? cfg.warmup : (long long)std::min(w_full, std::max(w_gear, 0.5 * L));
-                W = std::max(W, w_mm_learned);
-                W = env_int("SDHIP_W_MM", W);
-                W = (W + 255) / 256 * 256;
-                ChunkGeom g;
-                // Hand-off windows of an M&M boundary, in samples of timing. Two trajectories of this loop on the same samples
-                // hover 3e-5 ... 3e-4 sample apart (the feedback is piecewise constant in mu through the arm index), which makes
-                // them pick different interpolator arms on 0.3-0.7 % of the symbols -- the floor of any time-parallel schedule.
-                //  * TIGHT (2e-4): a boundary inside it adds nothing to that floor. It is the yardstick of the warm-up length: when more
-                //    than an eighth of the boundaries miss it, the warm-up is doubled (respec below).
-                //  * RE-RUN (5e-3): a boundary outside it is re-run from the exact state (and stops as soon as it is back inside). Between
-                //    the two windows a chunk starts <= 5e-3 sample off and is on the floor again within a loop time constant (a few
-                //    hundred symbols of a chunk of thousands): measured on MetOp, 14 of 65 k boundaries per step lie between 1e-3 and
-                //    the re-run window; re-running them moves the 1e-5 fraction in the sixth digit and costs a second launch whose
-                //    slowest lane runs alone for milliseconds.
-                const double MM_TOL_TIGHT = 2e-4;
-                const double MM_TOL = getenv("SDHIP_MM_TOL_MICRO") ? env_int("SDHIP_MM_TOL_MICRO", 5000) * 1e-6
-                                                                  : (getenv("SDHIP_MM_TOL_MILLI") ? env_int("SDHIP_MM_TOL_MILLI", 5) * 1e-3 : 5e-3);
-                MmCkpt *ckp = nullptr;
-                int ck_per_chunk = 0;
-                auto mm_setup = [&](long long Wn) {
-                    g = make_geom(n, L, (int)Wn);
-                    const double omin = (double)mm_p.omega_mid - (double)mm_p.omega_limit;
-                    const long long span0 = std::min<long long>(n, (long long)L + Wn);
-                    mm_p.cap = ((int)(span0 / std::max(0.5, omin - 0.01)) + 16 + 1) & ~1; // even: int8 rows start on a dword
-                    mm_p.cg = cg;
-                    mm_p.rot = mm_rot;
-                    symbuf.reserve((size_t)g.K * mm_p.cap);
-                    d_counts.reserve(2 * (size_t)g.K);
-                    d_offsets.reserve(g.K);
-                    d_mm_spec.reserve(g.K);
-                    d_mm_end.reserve(g.K);
-                    d_mm_spec_c.reserve(g.K);
-                    d_mm_end_c.reserve(g.K);
-                    d_skip.reserve(g.K);
-                    d_extra.reserve(g.K);
-                    d_seg.reserve(2 * (size_t)g.K);
-                    ck_per_chunk = L / MM_CK_SAMPLES + 2;
-                    if (use_ckpt || env_int("SDHIP_MM_CKPT", 0))
-                    { // checkpoints for the early exit of re-run lanes, k_mm<true>
-                        d_mm_ck.reserve((size_t)g.K * ck_per_chunk);
-                        ckp = d_mm_ck.p;
-                    }
-                };
-                mm_setup(W);
-                SD_HIP(hipMemcpyAsync(d_mm_start.p, &mm_s, sizeof(mm_s), hipMemcpyHostToDevice, stream));
-                launch_mm(A, symbuf.p, d_counts.p, g, mm_p, d_mm_start.p, d_mm_spec.p, d_mm_end.p, d_mm_spec_c.p, d_mm_end_c.p, nullptr, 0, stream, ckp, ck_per_chunk,
-                          (float)MM_TOL);
-                // Symbol hand-off at chunk boundaries. The M&M loop never re-merges bit for bit: its feedback is piecewise
-                // constant through the 128-arm interpolator index rint(mu*128) (clock_recovery_mm.cpp:66), so independent
-                // trajectories hover a fraction of an arm apart (tools/merge_study.py). What is certified is CONSISTENCY in
-                // time: t = inc + mu of the first symbol of chunk k (from its own warm-up) against the next-symbol time chunk
-                // k-1 ended with. Equal within MM_TOL samples: chunk k stands. Exactly one or two symbol periods apart (the
-                // boundary fell between the two trajectories' sample indices, mu wrapping on opposite sides): the symbol(s) are
-                // taken from chunk k-1's look-ahead, or skipped at the head of chunk k. Anything else: re-run from the exact state.
-                // (k_mm_verdict; the compaction segments and offsets are a prefix sum on the device, k_chunk_scan.)
-                verify_fix(
-                    "mm", g.K,
-                    [&](VerdictOut *vo, int *fails, int force) {
-                        hipLaunchKernelGGL(k_mm_verdict, dim3((g.K + 255) / 256), dim3(256), 0, stream, g.K, d_mm_spec_c.p, d_mm_end_c.p, d_counts.p, MM_TOL, std::min(MM_TOL, MM_TOL_TIGHT),
-                                           d_skip.p, d_extra.p, vo, fails, force);
-                    },
-                    [&](const int *list, int nr) {
-                        if (getenv("SDHIP_DEBUG"))
-                        { // first few rejected boundaries of the round
-                            int idx[4];
-                            const int m = std::min(nr, 4);
-                            SD_HIP(hipMemcpy(idx, list, m * sizeof(int), hipMemcpyDeviceToHost));
-                            for (int q = 0; q < m; q++)
-                            {
-                                MmCert a, b;
-                                SD_HIP(hipMemcpy(&a, d_mm_spec_c.p + idx[q], sizeof(a), hipMemcpyDeviceToHost));
-                                SD_HIP(hipMemcpy(&b, d_mm_end_c.p + idx[q] - 1, sizeof(b), hipMemcpyDeviceToHost));
-                                const double d = (double)(a.inc - b.inc) + ((double)a.mu - (double)b.mu);
-                                fprintf(stderr, "[sdhip] mm boundary %d rejected: dt %.5f samples = %.3f symbols, omega %.6f vs %.6f\n", idx[q], d, d / b.omega, a.omega, b.omega);
-                            }
-                        }
-                        hipLaunchKernelGGL(k_spec_from_prev<MmCert>, dim3((nr + 255) / 256), dim3(256), 0, stream, list, nr, d_mm_spec_c.p, d_mm_end_c.p);
-                        hipLaunchKernelGGL(k_spec_from_prev<MmState>, dim3((nr + 255) / 256), dim3(256), 0, stream, list, nr, d_mm_spec.p, d_mm_end.p);
-                    },
-                    [&](const int *redo, int nr) {
-                        launch_mm(A, symbuf.p, d_counts.p, g, mm_p, d_mm_start.p, d_mm_spec.p, d_mm_end.p, d_mm_spec_c.p, d_mm_end_c.p, redo, nr, stream, ckp,
-                                  ck_per_chunk, (float)MM_TOL);
-                    },
-                    [&](int nf) {
-                        const long long wn = (std::min<long long>(2 * (long long)g.W, w_mm_cap) + 255) / 256 * 256;
-                        if (cfg.warmup > 0 || getenv("SDHIP_W_MM") || wn <= (long long)g.W)
-                            return false;
-                        w_mm_learned = wn;
-                        if (getenv("SDHIP_DEBUG"))
-                            fprintf(stderr, "[sdhip] mm     %d of %d boundaries outside the hand-off window: warm-up %d -> %lld samples\n", nf, g.K, g.W, w_mm_learned);
-                        mm_setup(w_mm_learned);
-                        launch_mm(A, symbuf.p, d_counts.p, g, mm_p, d_mm_start.p, d_mm_spec.p, d_mm_end.p, d_mm_spec_c.p, d_mm_end_c.p, nullptr, 0, stream, ckp,
-                                  ck_per_chunk, (float)MM_TOL);
-                        return true;
-                    });
-                stats.chunks += g.K;
-                // compaction segments + offsets + total
-                SD_HIP(hipMemsetAsync(d_vout.p, 0, sizeof(VerdictOut), stream));
-                {
-                    const int nt = (g.K + 1023) / 1024;
-                    d_tile_sums.reserve(nt);
-                    hipLaunchKernelGGL(k_chunk_scan_sums, dim3(nt), dim3(1024), 0, stream, g.K, 1, nullptr, d_counts.p, d_skip.p, d_extra.p, mm_p.cap, d_tile_sums.p,
-                                       d_vout.p);
-                    hipLaunchKernelGGL(k_chunk_scan_apply, dim3(nt), dim3(1024), 0, stream, g.K, 1, nullptr, 1, nullptr, d_counts.p, d_skip.p, d_extra.p, d_tile_sums.p,
-                                       d_seg.p, d_offsets.p, d_vout.p);
-                }
-                SD_HIP(hipMemcpyAsync(h_vout.p, d_vout.p, sizeof(VerdictOut), hipMemcpyDeviceToHost, stream));
-                SD_HIP(hipMemcpyAsync(&mm_s, d_mm_end.p + (g.K - 1), sizeof(mm_s), hipMemcpyDeviceToHost, stream));
-                SD_HIP(hipStreamSynchronize(stream));
-                mm_s.inc -= n; // clock_recovery_mm.cpp:123-126
-                if (mm_s.inc < 0)
-                    mm_s.inc = 0;
-                if (h_vout.p->overflow)
-                    throw HipError("symbol scratch overflow");
-                const long long tot = h_vout.p->total;
-                const long long need_soft = is_bpsk ? tot : 2 * tot;
-                if ((size_t)need_soft > soft_cap)
-                    throw HipError("soft output buffer too small");
-                if (mm_p.q8)
-                    launch_compact8(symbuf.p, d_seg.p, d_offsets.p, g.K, mm_p.cap, is_bpsk ? 1 : 0, d_soft, (long long)soft_cap, stream);
-                else
-                    launch_quantize(symbuf.p, d_seg.p, d_offsets.p, g.K, mm_p.cap, is_bpsk ? 1 : 0, d_soft, (long long)soft_cap, d_syms, (long long)syms_cap, stream);
-                // history for the next call: last DEMOD_HIST de-rotated Costas outputs
-                launch_tail_copy(A, n, DEMOD_HIST, cg, mm_rot, order, d_hist.p, stream);
-                SD_HIP(hipMemcpyAsync(hist_cos.data(), d_hist.p, DEMOD_HIST * sizeof(cf32), hipMemcpyDeviceToHost, stream));
-                SD_HIP(hipStreamSynchronize(stream));
-                stats.symbols_out += tot;
-                nsoft = need_soft;
-            }
+            const int64_t nsoft = mm_stage(A, n, cg, mm_rot, d_soft, soft_cap, d_syms, syms_cap, hist_cos);
             tick("mm+quant");
             started = true;
             return nsoft;
+        }
+
+        // ---- ndsp: PSKDemodHierBlock's chain (dsp/hier/psk_demod.h:60-66: agc <- rrc, rec <- agc, pll <- rec). d_in: n complex floats,
+        // d_out: the symbols (complex floats). Same lane-per-chunk stages as process(); the Costas loop runs over the clock recovery's
+        // SYMBOLS and its per-chunk frames are turned back on its output (exact quarter / half turns).
+        int64_t process_ndsp(const float *d_in, size_t n_in, float *d_out, size_t out_cap)
+        {
+            SD_HIP(hipSetDevice(cfg.device));
+            stats.chunks = stats.chunks_fixed = stats.chunks_rotated = stats.chunks_inexact = stats.chunks_forced = 0;
+            if (n_in == 0)
+                return 0;
+            long long n = (long long)n_in;
+            const size_t need = (size_t)n + 2 * DEMOD_HIST + 64;
+            bufA.reserve(need);
+            bufB.reserve(need);
+            cf32 *A = bufA.p + DEMOD_HIST, *B = bufB.p + DEMOD_HIST;
+            stats.samples_in += n;
+            // ---- RRC FIR (FIRBlock::process, dsp/filter/fir.cpp:62-133): same dot products as the legacy block's (the aligned kernel call
+            // only puts zero taps in front), but the block holds ntaps samples back: output i is the window starting at input i + 1, and
+            // the first call returns ntaps samples fewer. In stream terms: the legacy filter's output without its first ntaps samples.
+            SD_HIP(hipMemcpyAsync(A, d_in, (size_t)n * sizeof(cf32), hipMemcpyDeviceToDevice, stream));
+            put_hist(A, hist_in);
+            launch_fir(A, B, n, d_rrc.p, rrc_ntaps, stream);
+            get_hist(A, n, hist_in);
+            std::swap(A, B);
+            if (fir_drop > 0)
+            {
+                const long long d = std::min<long long>(fir_drop, n);
+                fir_drop -= d;
+                n -= d;
+                if (n == 0)
+                    return 0;
+                SD_HIP(hipMemcpyAsync(B, A + d, (size_t)n * sizeof(cf32), hipMemcpyDeviceToDevice, stream));
+                std::swap(A, B);
+            }
+            // ---- AGC (AGCBlock::process, dsp/agc/agc.cpp:22-39), reference 0.6 from the hier block's constructor
+            agc_stage(A, B, n);
+            std::swap(A, B);
+            // ---- M&M (MMClockRecoveryBlock::work, dsp/clock_recovery/clock_recovery_mm.cpp:66-183): symbols as floats into symtmp
+            const double omin = (double)mm_p.omega_mid - (double)mm_p.omega_limit;
+            const size_t symcap = (size_t)((double)n / std::max(0.5, omin - 0.01)) + 64;
+            symtmp.reserve(symcap + 2 * DEMOD_HIST + 64);
+            d_soft_tmp.reserve(2 * symcap);
+            cf32 *S = symtmp.p + DEMOD_HIST;
+            const ChunkGeom one = make_geom(n, 1 << 30, 0);
+            mm_stage(A, n, one, nullptr, d_soft_tmp.p, 2 * symcap, reinterpret_cast<float *>(S), symcap, hist_cos);
+            const long long nsym = last_symbols;
+            if (nsym == 0)
+            {
+                started = true;
+                return 0;
+            }
+            if ((size_t)nsym > out_cap)
+                throw HipError("symbol output buffer too small");
+            // ---- Costas loop over the symbols (CostasBlock::process, dsp/pll/costas.cpp:12-61), frames turned back
+            cf32 *O = B; // the free stage buffer (nsym <= n)
+            ChunkGeom cg;
+            costas_stage(S, O, nsym, cg, 1.0, nd.symbolrate);
+            launch_derotate(O, nsym, cg, d_rot.p, order, stream);
+            SD_HIP(hipMemcpyAsync(d_out, O, (size_t)nsym * sizeof(cf32), hipMemcpyDeviceToDevice, stream));
+            SD_HIP(hipStreamSynchronize(stream));
+            started = true;
+            return nsym;
         }
 
         // ---- host path
@@ -1918,6 +2032,100 @@ extern "C"
         return ((DemodEngine *)h)->process(d_iq, nsamples, fmt, d_soft, soft_cap, d_syms, syms_cap);
         SD_GUARD_END(-1)
     }
+    // ---- ndsp PSK demodulator (PSKDemodHierBlock) on the same engine
+    void sdhip_ndsp_psk_cfg_default(sdhip_ndsp_psk_cfg *c)
+    {
+        memset(c, 0, sizeof(*c));
+        c->constellation = SDHIP_BPSK; // psk_demod.h:34-37
+        c->samplerate = 6e6;
+        c->symbolrate = 2e6;
+        c->rrc_gain = 1; // rrc.h:17-21
+        c->rrc_alpha = 0.35;
+        c->rrc_ntaps = 31;
+        c->agc_rate = 1e-4f; // agc.h:14-17, reference from psk_demod.cpp:13
+        c->agc_reference = 0.6f;
+        c->agc_gain = 1.0f;
+        c->agc_max_gain = 65536.0f;
+        c->rec_omega = 0.0f;
+        c->rec_omegaGain = (float)(pow(8.7e-3, 2) / 4.0); // clock_recovery_mm.h:17-23
+        c->rec_mu = 0.5f;
+        c->rec_muGain = (float)8.7e-3;
+        c->rec_omegaLimit = (float)0.005;
+        c->rec_nfilt = 128;
+        c->rec_ntaps = 8;
+        c->pll_loop_bw = (float)0.004; // costas.h:14-16
+        c->pll_freq_limit = 1.0f;
+    }
+    void *sdhip_ndsp_psk_demod_create(const sdhip_ndsp_psk_cfg *c)
+    {
+        SD_GUARD_BEGIN
+        if (c->constellation != SDHIP_BPSK && c->constellation != SDHIP_QPSK)
+            throw HipError("ndsp psk_demod: constellation must be bpsk or qpsk"); // set_cfg returns RES_ERR for anything else, psk_demod.h:205-214
+        if (c->rec_nfilt != 128 || c->rec_ntaps != 8)
+            throw HipError("ndsp psk_demod: the HIP path carries the 128 x 8 interpolator bank only");
+        if (!(c->samplerate > 0) || !(c->symbolrate > 0))
+            throw HipError("ndsp psk_demod: samplerate and symbolrate must be set");
+        sdhip_demod_cfg d;
+        sdhip_demod_cfg_default(&d);
+        d.device = c->device;
+        d.constellation = c->constellation;
+        d.samplerate = (decltype(d.samplerate))c->samplerate;
+        d.symbolrate = (decltype(d.symbolrate))c->symbolrate;
+        d.min_sps = 1.0f; // never resample: the hier block has no resampler
+        d.max_sps = 3.0e38f;
+        d.rrc_alpha = (float)c->rrc_alpha;
+        d.rrc_taps = c->rrc_ntaps;
+        d.agc_rate = c->agc_rate;
+        d.pll_bw = c->pll_loop_bw;
+        d.clock_gain_omega = c->rec_omegaGain;
+        d.clock_mu = c->rec_mu;
+        d.clock_gain_mu = c->rec_muGain;
+        d.clock_omega_relative_limit = c->rec_omegaLimit;
+        d.exact = c->exact;
+        d.chunk_len = c->chunk_len;
+        d.warmup = c->warmup;
+        NdspExt e;
+        e.on = true;
+        e.samplerate = c->samplerate;
+        e.symbolrate = c->symbolrate;
+        e.rrc_gain = c->rrc_gain;
+        e.rrc_alpha = c->rrc_alpha;
+        e.agc_reference = c->agc_reference;
+        e.agc_gain = c->agc_gain;
+        e.agc_max_gain = c->agc_max_gain;
+        e.rec_omega = c->rec_omega;
+        e.pll_freq_limit = c->pll_freq_limit;
+        return new DemodEngine(d, &e);
+        SD_GUARD_END(nullptr)
+    }
+    void sdhip_ndsp_psk_demod_destroy(void *h) { delete (DemodEngine *)h; }
+    int64_t sdhip_ndsp_psk_demod_work_dev(void *h, const float *d_in, size_t nsamples, float *d_out, size_t out_cap)
+    {
+        SD_GUARD_BEGIN
+        DemodEngine *e = (DemodEngine *)h;
+        if (!e->nd.on)
+            throw HipError("not an ndsp demodulator handle");
+        return e->process_ndsp(d_in, nsamples, d_out, out_cap);
+        SD_GUARD_END(-1)
+    }
+    int64_t sdhip_ndsp_psk_demod_work(void *h, const float *in, size_t nsamples, float *out, size_t out_cap)
+    {
+        SD_GUARD_BEGIN
+        DemodEngine *e = (DemodEngine *)h;
+        if (!e->nd.on)
+            throw HipError("not an ndsp demodulator handle");
+        SD_HIP(hipSetDevice(e->cfg.device));
+        DevBuf<float> din, dout;
+        din.reserve(2 * nsamples + 32);
+        dout.reserve(2 * out_cap + 32);
+        SD_HIP(hipMemcpy(din.p, in, 2 * nsamples * sizeof(float), hipMemcpyHostToDevice));
+        const int64_t r = e->process_ndsp(din.p, nsamples, dout.p, out_cap);
+        if (r > 0)
+            SD_HIP(hipMemcpy(out, dout.p, 2 * (size_t)r * sizeof(float), hipMemcpyDeviceToHost));
+        return r;
+        SD_GUARD_END(-1)
+    }
+    int sdhip_ndsp_psk_demod_get_stats(void *h, sdhip_demod_stats *st) { return sdhip_demod_get_stats(h, st); }
     int sdhip_demod_get_stats(void *h, sdhip_demod_stats *st)
     {
         *st = ((DemodEngine *)h)->stats;
@@ -1997,9 +2205,10 @@ extern "C"
             SD_HIP(hipMemcpy(dt.p, r.data(), r.size() * sizeof(float), hipMemcpyHostToDevice));
             launch_fir(X, Y, nn, dt.p, (int)r.size(), nullptr);
         }
-        else if (kind == 2)
-        {
+        else if (kind == 2 || kind == 9)
+        { // 9: the ndsp CostasBlock (dsp/pll/costas.cpp:12-61) -- the legacy loop with dsp::branched_clip on the error
             CostasParams p{};
+            p.clip_branched = kind == 9 ? 1 : 0;
             design::costas_gains(params[0], p.alpha, p.beta);
             p.order = (int)params[1];
             p.fmin = -params[2];

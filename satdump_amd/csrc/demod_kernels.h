@@ -142,6 +142,7 @@ namespace sdhip
         int order;
         float init_freq; // warm-up start frequency
         int est_len;     // samples of the feed-forward start-phase estimate of a warm-up (0 = start at phase 0)
+        int clip_branched; // 1: the ndsp CostasBlock's dsp::branched_clip (dsp/pll/costas.cpp:42) instead of the legacy block's branchless_clip
     };
     struct CostasState
     {

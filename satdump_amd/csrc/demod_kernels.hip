@@ -966,7 +966,7 @@ namespace sdhip
 
     // ORDER (2 / 4 / 8) is a template argument: the detector's form is fixed at compile time, so the per-sample loop carries no
     // test of it and none of the other detectors' code.
-    template <int ORDER, int D = 4, bool FAST = false>
+    template <int ORDER, int D = 4, bool FAST = false, bool BCLIP = false>
     struct CostasStage
     {
         using P = CostasParams;
@@ -1036,7 +1036,10 @@ namespace sdhip
                 const float ea = st * ti - su * tr * K, eb = st * ti * K - su * tr;
                 error = fabsf(tr) >= fabsf(ti) ? ea : eb;
             }
-            error = 0.5f * (fabsf(error + 1.0f) - fabsf(error - 1.0f)); // branchless_clip(error, 1.0), block.cpp:5
+            if constexpr (BCLIP)
+                error = error < -1.0f ? -1.0f : (error > 1.0f ? 1.0f : error); // dsp::branched_clip(error, 1.0), block.cpp:7-15 (ndsp CostasBlock)
+            else
+                error = 0.5f * (fabsf(error + 1.0f) - fabsf(error - 1.0f)); // branchless_clip(error, 1.0), block.cpp:5
             s.freq = s.freq + p.beta * error;
             s.phase = s.phase + (s.freq + p.alpha * error);
             // while (phase > 2 pi) phase -= 2 pi; while (phase < -2 pi) phase += 2 pi; -- the float compared with the double constant,
@@ -1754,7 +1757,16 @@ namespace sdhip
             const char *e = getenv("SDHIP_COSTAS_DEPTH"); // experiment: 64-byte blocks per load group (2, 4, 8)
             return e ? atoi(e) : 4;
         }();
-        if (p.order == 2)
+        if (p.clip_branched)
+        { // the ndsp block's clip (one load-group depth: this is the symbol-rate loop of the hier block)
+            if (p.order == 2)
+                go(CostasStage<2, 4, false, true>{});
+            else if (p.order == 4)
+                go(CostasStage<4, 4, false, true>{});
+            else
+                go(CostasStage<8, 4, false, true>{});
+        }
+        else if (p.order == 2)
             depth == 2 ? go(CostasStage<2, 2>{}) : go(CostasStage<2, 4>{});
         else if (p.order == 4 && depth == 2)
             go(CostasStage<4, 2>{});

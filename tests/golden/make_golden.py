@@ -16,6 +16,7 @@ Fixtures (np.savez_compressed):
   simple_*.npz    CCSDSSimplePSKDecoderModule loop: int8 soft -> CADUs + RS error counts (three slicer modes)
   punct_*.npz     concatenated decoder with conv_rate 3/4 and 7/8 (Viterbi_Depunc): int8 soft -> CADUs, per-block BER/state
   gardner.npz     GardnerClockRecoveryBlock on stored cs16 samples
+  ndsp_psk_*.npz  ndsp PSKDemodHierBlock (RRC -> AGC -> M&M -> Costas), stored cs16 samples -> complex symbols
   taps.npz        RRC / M&M interpolator bank / rational-resampler bank
 """
 import hashlib
@@ -152,6 +153,15 @@ def main():
     r = ref.psk_demod(pyref.demod_cfg(constellation=pyref.BPSK, **kw), xin)
     pp = np.array([0.002, 3.14, -3.14], dtype=np.float32)
     out["demod_carrier"] = dict(cs16=cs16, soft=r["soft"], syms=r["syms"], pll_params=pp, pll_out=ref.block(8, pp, xin[:40000]))
+
+    # ---- ndsp PSK demodulator hier block (src-core/dsp/hier/psk_demod.h), the reference's own threads and FIFOs: stored cs16 -> symbols
+    from tests.test_ndsp_gpu import _signal
+    nd = pyref.NdspRef()
+    for const, sr, symr in (("qpsk", 6e6, 2.33e6), ("bpsk", 6e6, 2e6)):
+        cs16 = synth.to_cs16(_signal(const, 12000, sr, symr)[:30000])
+        xin = (cs16.astype(np.float32) * np.float32(1.0 / 32767.0)).view(np.complex64)
+        out[f"ndsp_psk_{const}"] = dict(cs16=cs16, samplerate=np.float64(sr), symbolrate=np.float64(symr),
+                                        syms=nd.run("psk_demod_cc", {"constellation": const, "samplerate": sr, "symbolrate": symr}, xin))
 
     # ---- filter designs
     bank, ir, dr = ref.resamp_bank(2700000, 3000000)

@@ -18,11 +18,13 @@
 #include "logger.h"
 #include "pipeline/module.h"
 #include "pipeline/modules/base/filestream_to_filestream.h"
+#include "dsp/block.h"
 
 #include <dlfcn.h>
 #include <filesystem>
 #include <fstream>
 #include <iostream>
+#include <cstring>
 #include <thread>
 
 std::shared_ptr<slog::Logger> logger = std::make_shared<slog::Logger>();
@@ -147,6 +149,82 @@ int main(int argc, char **argv)
         for (auto &m : modules_registry)
             std::cout << " " << m.id;
         std::cout << std::endl;
+        return 0;
+    }
+    if (cmd == "ndsp" && argc >= 5)
+    { // the ndsp block of the plugin between two DSPStream FIFOs, fed and drained like a flowgraph would (src-core/dsp/block.h: set_input /
+      // get_output / start / stop; terminator propagation as in block_simple.h:31-37): cf32 file in, cf32 symbol file out
+        using namespace satdump::ndsp;
+        nlohmann::ordered_json job;
+        {
+            std::ifstream f(argv[4]);
+            f >> job;
+        }
+        try
+        {
+            auto make = reinterpret_cast<Block *(*)(const char *)>(dlsym(dyn, "sdhip_plugin_make_ndsp_block"));
+            if (!make)
+                return fail("plugin has no sdhip_plugin_make_ndsp_block()");
+            std::unique_ptr<Block> blk(make(job["block"].get<std::string>().c_str()));
+            if (!blk)
+                return fail("unknown ndsp block");
+            nlohmann::json report;
+            report["block"] = blk->d_id;
+            nlohmann::json res = nlohmann::json::object();
+            for (auto &kv : job["cfg"].items())
+                res[kv.key()] = (int)blk->set_cfg(kv.key(), nlohmann::json(kv.value()));
+            report["set_cfg"] = res;
+            std::vector<float> in;
+            {
+                std::ifstream f(job["input"].get<std::string>(), std::ios::binary | std::ios::ate);
+                in.resize((size_t)f.tellg() / sizeof(float));
+                f.seekg(0);
+                f.read((char *)in.data(), (std::streamsize)in.size() * sizeof(float));
+            }
+            const size_t n = in.size() / 2, buf = job.value("buffer", 8192);
+            BlockIO src{"in", DSP_SAMPLE_TYPE_CF32};
+            src.fifo = std::make_shared<DSPStream>(4);
+            blk->set_input(src, 0);
+            BlockIO dst = blk->get_output(0, 4);
+            blk->start();
+            std::thread feeder(
+                [&]()
+                {
+                    for (size_t o = 0; o < n; o += buf)
+                    {
+                        const size_t m = std::min(buf, n - o);
+                        DSPBuffer b = src.fifo->newBufferSamples((uint32_t)buf, sizeof(complex_t));
+                        memcpy(b.getSamples<complex_t>(), in.data() + 2 * o, m * sizeof(complex_t));
+                        b.size = (uint32_t)m;
+                        src.fifo->wait_enqueue(b);
+                    }
+                    src.fifo->wait_enqueue(src.fifo->newBufferTerminator());
+                });
+            std::ofstream out(job["output"].get<std::string>(), std::ios::binary);
+            size_t got = 0;
+            for (;;)
+            {
+                DSPBuffer b = dst.fifo->wait_dequeue();
+                if (b.isTerminator())
+                {
+                    dst.fifo->free(b);
+                    break;
+                }
+                out.write((const char *)b.getSamples<complex_t>(), (std::streamsize)b.size * sizeof(complex_t));
+                got += b.size;
+                dst.fifo->free(b);
+            }
+            feeder.join();
+            report["pll_freq"] = blk->get_cfg("pll_freq");
+            report["cfg_list"] = blk->get_cfg_list();
+            blk->stop();
+            report["symbols"] = got;
+            std::cout << report.dump() << std::endl;
+        }
+        catch (const std::exception &e)
+        {
+            return fail(std::string("exception: ") + e.what());
+        }
         return 0;
     }
     if (cmd != "run" || argc < 5)

@@ -64,3 +64,14 @@ def test_override_without_a_device_leaves_the_cpu_modules(host, tmp_path):
     jp.write_text(json.dumps(job))
     p = _run(host, "run", str(jp))
     assert p.returncode != 0 and "PLL BW parameter must be present!" in p.stderr
+
+
+def test_ndsp_block_through_the_plugin_on_the_twin(host, tmp_path):
+    """tests/test_plugin_minihost_gpu.py::test_ndsp_block_through_the_plugin with the host twin of the engine (tests/emu) as the C-ABI
+    library: the ndsp::Block subclass of the plugin, its FIFO/terminator handling and set_cfg() mapping are exercised in the CPU suite."""
+    from oracle import pyref
+    from tests import test_plugin_minihost_gpu as G
+    from tests.emu import build as emu_build
+    if not pyref.NdspRef.available() or not os.path.exists(emu_build.CLANG):
+        pytest.skip("needs the compiled reference ndsp blocks and a host clang++")
+    G.check_ndsp_block_through_the_plugin(host, emu_build.build(), tmp_path)

@@ -235,3 +235,42 @@ def test_freq_shift_through_the_override(host, tmp_path):
     got = np.fromfile(rep["cadu"], dtype=np.uint8).reshape(-1, 1024)
     want = _ref_cadus_of_file(pyref.ref(), ocfg, ofec, x)
     assert got.shape == want.shape and np.array_equal(got, want) and len(got) >= 26
+
+
+def _run_ndsp(host, lib, job, tmp_path):
+    jp = tmp_path / "ndsp_job.json"
+    jp.write_text(json.dumps(job))
+    p = subprocess.run([host, lib, PLUGIN, "ndsp", str(jp)], capture_output=True, text=True, env=dict(os.environ), timeout=600)
+    assert p.returncode == 0, p.stdout[-1000:] + p.stderr[-3000:]
+    return json.loads(p.stdout.strip().splitlines()[-1])
+
+
+def check_ndsp_block_through_the_plugin(host, lib, tmp_path):
+    """plugin/sdhip_ndsp_block.h -- PSKDemodHipBlock, a satdump::ndsp::Block -- instantiated from the plugin, configured through set_cfg()
+    with the reference hier block's keys, linked between two DSPStream FIFOs and run on its own thread by Block::start(): the symbol
+    file it writes is what the reference's PSKDemodHierBlock (its four member blocks, threads and FIFOs) produces from the same samples,
+    bit for bit with "exact", same count and within the chunk-parallel contract without."""
+    from tests.test_ndsp_gpu import _signal
+    nd = pyref.NdspRef()
+    x = _signal("qpsk", 70000, 6e6, 2.33e6)
+    inp = tmp_path / "bb.cf32"
+    x.tofile(str(inp))
+    cfg = {"constellation": "qpsk", "samplerate": 6e6, "symbolrate": 2.33e6}  # module_demod_ndsp.cpp:22-24
+    want = nd.run("psk_demod_cc", cfg, x)
+    rep = _run_ndsp(host, lib, {"block": "psk_demod_cc", "cfg": dict(cfg, exact=True, no_such_key=1), "input": str(inp), "output": str(tmp_path / "e.cf32"), "buffer": 8192}, tmp_path)
+    assert rep["block"] == "psk_demod_hip_cc" and rep["symbols"] == len(want)
+    assert rep["set_cfg"]["constellation"] == 0 and rep["set_cfg"]["no_such_key"] == 3  # RES_OK / RES_ERR (block.h:258-264)
+    got = np.fromfile(str(tmp_path / "e.cf32"), dtype=np.complex64)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    assert abs(rep["pll_freq"] - 9000.0) < 400.0 and "pll_freq" in rep["cfg_list"]
+    rep = _run_ndsp(host, lib, {"block": "psk_demod_hip_cc", "cfg": cfg, "input": str(inp), "output": str(tmp_path / "c.cf32"), "buffer": 50000}, tmp_path)
+    got = np.fromfile(str(tmp_path / "c.cf32"), dtype=np.complex64)
+    assert rep["symbols"] == len(want) == len(got)
+    err = np.abs(got - want)[40000:] / np.sqrt(np.mean(np.abs(want) ** 2))
+    assert np.median(err) < 1e-5 and np.mean(err > 1e-3) < 0.03
+
+
+def test_ndsp_block_through_the_plugin(host, tmp_path):
+    if not pyref.NdspRef.available():
+        pytest.skip("needs the compiled reference ndsp blocks")
+    check_ndsp_block_through_the_plugin(host, LIB, tmp_path)
