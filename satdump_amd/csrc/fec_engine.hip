@@ -739,6 +739,10 @@ namespace sdhip
         // d_soft: device pointer to block 0 of the contiguous region; [blk0, blk0 + n) were decoded into d_vbits.
         // Returns the number of blocks actually consumed by the deframer (may be < n for the MetOp watchdog).
         // collect != nullptr: do not emit; report the frames (left in d_fbytes) and where the reference would have returned them
+        // punctured decoders: the reference call (viterbi.work + ONE deframer.work, module_ccsds_conv_concat_decoder.cpp:93-119) during which each
+        // decoded window of the pending batch came out -- one or two windows per call there, so "frames returned by one deframer call" is
+        // not "frames ending in one window" 
+        std::vector<int64_t> punc_win_call;
         int deframe_and_emit(int n, uint8_t *d_out, size_t out_cap_frames, size_t &out_written, FrameBatch *collect = nullptr)
         {
             const bool tdbg = getenv("SDHIP_DEBUG") != nullptr;
@@ -864,8 +868,15 @@ namespace sdhip
                         collect->done_blk[f] = (base_abs + W.frames[f].pos + (cfg.cadu_size - 32) - 1) / F;
                 }
                 if (nf > 1 && cfg.rs_i != 0 && cfg.rs_fill_bytes == -1)
-                { // frames the reference's deframer returned from ONE work() call (one Viterbi buffer): see k_rs_overrun
-                    auto call_of = [&](int f) { return (base_abs + W.frames[f].pos + (cfg.cadu_size - 32) - 1) / F; };
+                { // frames the reference's deframer returned from ONE work() call (one Viterbi buffer; one or two on the punctured path): see k_rs_overrun
+                    const bool by_call = punc.rate != 0 && (int)punc_win_call.size() >= n_eff;
+                    auto call_of = [&](int f) {
+                        const int64_t blk = (base_abs + W.frames[f].pos + (cfg.cadu_size - 32) - 1) / F;
+                        if (!by_call)
+                            return blk;
+                        const int64_t w = blk - abs_bits / F; // window of this batch the frame's last bit lies in
+                        return (w >= 0 && w < (int64_t)punc_win_call.size()) ? punc_win_call[(size_t)w] : -1 - blk;
+                    };
                     for (int f = 0; f + 1 < nf; f++)
                         W.frames[f].pad = call_of(f) == call_of(f + 1) ? 1 : 0;
                 }
@@ -1406,6 +1417,8 @@ namespace sdhip
                 P.dec_start = io[wused - 1].ret_state;
                 P.enc_state = (unsigned)io[wused - 1].pad;
             }
+            for (int j = 0; j < wused; j++)
+                punc_win_call.push_back(b0 + pl.win[j].block);
             nout += wused;
             if (getenv("SDHIP_DEBUG"))
                 fprintf(stderr, "[sdhip] punctured run: %d call(s) planned, %d used, %d block(s) decoded as one batch, lock %s\n", pl.nblk, used, wused,
@@ -1460,6 +1473,7 @@ namespace sdhip
                 const int64_t batch = std::min<int64_t>(nblocks - pos, 4096);
                 d_vbits.reserve((size_t)(2 * batch + 2) * wpb + 4);
                 int nout = 0;
+                punc_win_call.clear();
                 // one input block the reference's way, call by call: the lock search, and the SYNCED blocks punc_run() leaves alone
                 auto seq_block = [&](int64_t b)
                 {
@@ -1532,6 +1546,7 @@ namespace sdhip
                             for (int d = 0; d < 6; d++)
                                 e |= ((w[0] >> d) & 1u) << d; // bit TEST-1-d sits at position d of the word that ends at bit TEST-1
                             P.enc_state = e;
+                            punc_win_call.push_back(b);
                             nout++;
                             // ViterbiSlidingBuffer::del(B), viterbi_buffer.h:32-37
                             const int rest = P.in_buffer - B;

@@ -32,7 +32,8 @@ def port():
 # The FEC half of the host twin emulates every wave collective with 128 fiber switches: the tests that spend their time in the
 # wave-per-block Viterbi kernel take minutes there. The CPU suite runs the quick ones; SDHIP_TWIN_FULL=1 runs all 75 (~30 min).
 _TWIN_SLOW = ("test_punctured_concat_decoder", "test_concat_decoder_", "test_metop_decoder", "test_metop_golden", "test_ccdecoder_golden", "test_concat_golden[concat_qpsk",
-              "-12288-4]", "-4096-9]", "-5116-3]", "[clean-640", "[noise-640", "[saturated-640", "test_viterbi27[70", "test_ccdecoder_long_segments[noise", "test_ccdecoder_long_segments[noisy-2048")
+              "-12288-4]", "-4096-9]", "-5116-3]", "[clean-640", "[noise-640", "[saturated-640", "test_viterbi27[70", "test_ccdecoder_long_segments[noise", "test_ccdecoder_long_segments[noisy-2048",
+              "fill_bytes_overrun[4-1]", "fill_bytes_overrun[2-2]")
 
 
 def pytest_collection_modifyitems(config, items):
