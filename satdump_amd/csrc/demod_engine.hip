@@ -1247,11 +1247,15 @@ namespace sdhip
             // trajectory (13 tau would do within the 1e-6 tolerance; measured: the lane kernels are bound by their strided
             // HBM traffic, not by the chain -- a parallel-scan start value that cut W to 6 tau bought nothing net)
             const double tau = std::max(1.0f, g_est) / std::max(1e-6f, cfg.agc_rate);
-            long long W = cfg.warmup > 0 ? cfg.warmup : (long long)(24.0 * tau);
+            // (the ndsp chain: 14 -- inside the certificate's 1e-6 from a start value within tens of percent; at the block's rate 1e-4 the
+            // warm-up IS the stage's time, (W + L) sequential steps per lane. SDHIP_AGC_TAUS overrides.)
+            const double taus = (double)env_int("SDHIP_AGC_TAUS", nd.on ? 14 : 24);
+            long long W = cfg.warmup > 0 ? cfg.warmup : (long long)(taus * tau);
             W = env_int("SDHIP_W_AGC", W);
             W = std::min<long long>(std::max<long long>(W, 1024), 1 << 22);
             W = (W + 255) / 256 * 256;
             agc_p.init_gain = g_est;
+            agc_p.fast = (nd.on && !cfg.exact && env_int("SDHIP_FAST_MATH", 1) != 0) ? 1 : 0;
             int L = pick_L(n, ST_AGC);
             // a slow loop (the ndsp block's default rate 1e-4: 24 tau ~ 4e5 samples) on many short chunks would run K lanes over W + L
             // samples each -- a hundred times the stream through L2 / HBM for no gain in wall time, which is (W + L) sequential steps

@@ -92,6 +92,7 @@ namespace sdhip
     struct AgcParams
     {
         float rate, reference, max_gain, init_gain;
+        int fast; // 1: chunk-parallel mode's arithmetic (sd_sqrt_fast, fma) in the stand-alone stage too
     };
     struct AgcState
     {

@@ -801,7 +801,7 @@ namespace sdhip
     {
         float4 a, b, c, d;
     };
-    template <int D>
+    template <int D, bool FASTQ = false>
     struct AgcStageT
     {
         using P = AgcParams;
@@ -811,7 +811,7 @@ namespace sdhip
         // early exit of a re-run lane (CKPT): is state a on the trajectory that left checkpoint b? (the AGC certificate's own rule)
         __device__ static __forceinline__ bool close(const S &a, const S &b, float tol_a, float) { return fabsf(a.gain - b.gain) <= tol_a * fabsf(b.gain); }
         __device__ static __forceinline__ void prewarm(S &, const P &, const cf32 *, long long) {}
-        __device__ static __forceinline__ cf32 step(S &s, const P &p, const cf32 v) { return step_t<false>(s, p, v); }
+        __device__ static __forceinline__ cf32 step(S &s, const P &p, const cf32 v) { return step_t<FASTQ>(s, p, v); }
         template <bool FAST>
         __device__ static __forceinline__ cf32 step_t(S &s, const P &p, const cf32 v)
         {
@@ -1720,7 +1720,9 @@ namespace sdhip
                 hipLaunchKernelGGL((k_chunks<St, false>), dim3((n + 63) / 64), dim3(64), 0, st, x, y, g, p, start0, spec, endst, redo, nredo, (AgcState *)nullptr,
                                    0, 0, 0.0f, 0.0f, (unsigned long long *)nullptr);
         };
-        if (depth == 8)
+        if (p.fast) // chunk-parallel mode's arithmetic (hardware square root, one fma): the serial chain per sample is what a slow loop's
+            (getenv("SDHIP_AGC_DEPTH") && depth != 8) ? go(AgcStageT<4, true>{}) : go(AgcStageT<8, true>{}); // (measured: 28.7 -> 25.0 ms with 8 blocks per group) long warm-up costs (the ndsp block's rate 1e-4: 6e5 sequential steps per lane)
+        else if (depth == 8)
             go(AgcStageT<8>{});
         else if (depth == 2)
             go(AgcStageT<2>{});
