@@ -6,6 +6,7 @@
 // precision with the same polynomial and reduction, so that a single sequential lane reproduces the
 // reference bit for bit (tests/test_demod_gpu.py, exact mode).
 #include "demod_kernels.h"
+#include <optional>
 
 namespace sdhip
 {
@@ -1625,6 +1626,9 @@ namespace sdhip
         if (n <= 0)
             return;
         ProfScope _ps("k_afc", st);
+        std::optional<ProfScope> _pr;
+        if (redo)
+            _pr.emplace("k_afc (re-run launches, included in k_afc)", st);
         auto go = [&](auto order, auto fm) {
             constexpr int O = decltype(order)::value;
             constexpr bool F = decltype(fm)::value;
@@ -2247,6 +2251,9 @@ template <bool CKPT, bool SPLIT, bool Q8 = false, bool FAST = false>
         if (n <= 0)
             return;
         ProfScope _ps("k_mm", st);
+        std::optional<ProfScope> _pr; // the re-run launches (a few lanes, each alone on its SIMD) are part of k_mm's time; listed on their own as well
+        if (redo)
+            _pr.emplace("k_mm (re-run launches, included in k_mm)", st);
         const char *split_env = getenv("SDHIP_MM_SPLIT");
         const bool split = split_env && split_env[0] == '1';
         if (ck && p.q8 && p.fast)

@@ -81,7 +81,7 @@ def main():
         dt = (time.perf_counter() - t0) / args.steps
         capi.prof_enable(False)
         prof = capi.prof_get()
-        top = {k.replace("k_chunks<", "").replace("Stage>", ""): round(v[0] / args.steps, 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])[:9]}
+        top = {k.replace("k_chunks<", "").replace("Stage>", ""): round(v[0] / args.steps, 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])[:14]}
         st = dem.stats()
         print(json.dumps({"cfg": cfg or "(defaults)", "ms_per_step": round(dt * 1e3, 3), "cadus": int(nf), "first_pass": {"fixed": st0.chunks_fixed, "inexact": st0.chunks_inexact, "forced": st0.chunks_forced},
                           "steady": {"chunks": st.chunks, "fixed": st.chunks_fixed}, "parity": par, "kernels_ms": top}), flush=True)
