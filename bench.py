@@ -20,7 +20,9 @@ sdhip_prof_*), "cpu_baseline" (the compiled reference oracle/_ref in its own thr
 N=1 only), "cadu_parity" (the first pass of fresh handles over the FULL-SIZE stream against that reference run: every CADU the
 reference produced, the RS-uncorrectable ones included, must be byte-identical -- hard failure otherwise), "soft_parity" (int8
 soft symbols over the same span, float symbols over the first --cpu-samples samples), "cadu_per_s", "kernels" (per-kernel
-ms/step), and "other_workloads": the same measurement, compact, for the other two single-GPU workloads (--others 0 to skip).
+ms/step), "other_workloads": the same measurement, compact, for the other two single-GPU workloads (--others 0 to skip), and
+"next_rows": the rows SURVEY.md 8 marks "next" that have a measurement of their own -- the ndsp PSK demodulator chain
+(tools/bench_ndsp.py) and the DVB-S2 FEC tail (tools/bench_dvbs2.py) -- as those tools report them (--next-rows 0 to skip).
 """
 from __future__ import annotations
 
@@ -229,6 +231,7 @@ def main():
     ap.add_argument("--parity-samples", type=int, default=-1,
                     help="samples the reference (its thread-per-block topology) decodes for cadu_parity / the int8 soft parity / cpu_baseline.value "
                          "(-1 = the whole stream, the default: full-stream CADU identity)")
+    ap.add_argument("--next-rows", type=int, default=1, help="N=1: also run tools/bench_ndsp.py and tools/bench_dvbs2.py, under next_rows (0 = skip)")
     ap.add_argument("--others", type=int, default=1, help="N=1: also measure the other two single-GPU workloads, compact, under other_workloads (0 = skip)")
     ap.add_argument("--others-parity-samples", type=int, default=400_000_000, help="reference span of the other workloads' parity legs")
     ap.add_argument("--chunk-len", type=int, default=0)
@@ -283,6 +286,20 @@ def main():
             others[name] = c
             failed = failed or bool(o.get("cadu_parity") is not None and not o["cadu_parity"]["byte_identical"])
         out["other_workloads"] = others
+    if rank == 0 and world == 1 and args.next_rows and not args.exact and not args.frames and not args.dump:
+        # the rows SURVEY.md 8 marks "next", each measured by its own tool (same HIP-event + reference-on-the-host method), compact: the ndsp
+        # PSK demodulator chain (f-1) and the DVB-S2 FEC tail (f-2). A failure here is recorded, it never takes the driver line down.
+        nxt = {}
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        for key, mod, argv in (("ndsp_psk_demod", "bench_ndsp", ["--steps", "4", "--warmup", "1", "--cpu-samples", "12000000"]),
+                               ("dvbs2_fec", "bench_dvbs2", ["--rate", "2/3", "--sigma", "13"])):
+            try:
+                torch.cuda.empty_cache()
+                m = __import__(mod)
+                nxt[key] = m.run(m.parse(argv))
+            except Exception as e:  # noqa: BLE001
+                nxt[key] = {"error": f"{type(e).__name__}: {e}"}
+        out["next_rows"] = nxt
     if rank == 0:
         print(json.dumps(out), flush=True)
         if failed:

@@ -1560,6 +1560,9 @@ namespace sdhip
                 }
             };
             mm_setup(W);
+            if (getenv("SDHIP_PRINT_ADDR")) // experiment: the M&M launch time against where its buffers lie
+                fprintf(stderr, "[sdhip] mm buffers: in %p  symbols %p (%zu B, row %d B)  K %d L %d W %d\n", (const void *)A, (void *)symbuf.p, symbuf.cap * sizeof(cf32),
+                        mm_p.cap * 8, g.K, g.L, g.W);
             SD_HIP(hipMemcpyAsync(d_mm_start.p, &mm_s, sizeof(mm_s), hipMemcpyHostToDevice, stream));
             launch_mm(A, symbuf.p, d_counts.p, g, mm_p, d_mm_start.p, d_mm_spec.p, d_mm_end.p, d_mm_spec_c.p, d_mm_end_c.p, nullptr, 0, stream, ckp, ck_per_chunk,
                       (float)MM_TOL);

@@ -15,7 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def main():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--framesize", type=int, default=0)
     ap.add_argument("--rate", default="2/3")
@@ -25,7 +25,10 @@ def main():
     ap.add_argument("--batch", type=int, default=16)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--cpu-frames", type=int, default=64)
-    args = ap.parse_args()
+    return ap.parse_args(argv)
+
+
+def run(args) -> dict:
     import torch
     torch.zeros(1, device="cuda")
     from oracle import pyref
@@ -95,7 +98,11 @@ def main():
                                "sample": f"first {m} frames, BBFrameLDPC::decode, SIMD width {ref.batch}"}
         if ref.batch == args.batch:
             out["parity_sample"] = {"frames": m, "soft_bits_identical": bool(np.array_equal(work[:m].cpu().numpy(), want)), "trials_identical": bool(np.array_equal(tr[:m // ref.batch], wt))}
-    print(json.dumps(out), flush=True)
+    return out
+
+
+def main():
+    print(json.dumps(run(parse())), flush=True)
 
 
 if __name__ == "__main__":

@@ -16,7 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def main():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--samples", type=int, default=1 << 30)
     ap.add_argument("--constellation", default="qpsk")
@@ -25,7 +25,10 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--cpu-samples", type=int, default=24_000_000)
-    args = ap.parse_args()
+    return ap.parse_args(argv)
+
+
+def run(args) -> dict:
     import torch
     torch.zeros(1, device="cuda")
     from oracle import pyref
@@ -95,15 +98,21 @@ def main():
     capi.prof_enable(False)
     kern = {k: round(v[0] / args.steps, 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])[:8]}
     L.sdhip_ndsp_psk_demod_get_stats(h, C.byref(st))
-    print(json.dumps({
+    res = {
         "metric": "ndsp psk_demod_cc complex samples/s, samples resident in HBM", "value": round(n / dt / 1e6, 1), "unit": "Msamples/s", "ms_per_step": round(dt * 1e3, 3),
         "config": {"workload": f"{args.constellation} {args.samplerate / 1e6:g} Msps / {args.symbolrate / 1e6:g} Msym/s, Es/N0 12 dB, {cfo:.0f} Hz offset, {n} samples per call, "
                                "block defaults (rrc 0.35 / 31 taps, agc 1e-4 / 0.6, M&M 8.7e-3, loop_bw 0.004)"},
         "symbols_per_call": int(ns), "steady_chunks": {"chunks": st.chunks, "re_run": st.chunks_fixed}, "first_call_chunks": first, "kernels_ms_per_step": kern,
         "parity_vs_reference_first_call": parity, "pll_freq_hz": round(float(st.freq_hz), 1),
         "cpu_reference": {"value": round(ncpu / t_cpu / 1e6, 2), "unit": "Msamples/s", "threads": 6, "kind": "reference",
-                          "sample": f"first {ncpu} samples, the hier block's own topology: rrc, agc, rec, pll, splitter, snr estimator threads + feeder"}}))
+                          "sample": f"first {ncpu} samples, the hier block's own topology: rrc, agc, rec, pll, splitter, snr estimator threads + feeder"}}
     L.sdhip_ndsp_psk_demod_destroy(h)
+    del d_x, d_y
+    return res
+
+
+def main():
+    print(json.dumps(run(parse())), flush=True)
 
 
 if __name__ == "__main__":
