@@ -339,6 +339,19 @@ extern "C"
        value: bits corrected, 0 for a clean frame, -1 when the decoder gives up. _dev: pointers on cfg->device. */
     int sdhip_bch_decode_dev(void *h, uint8_t *d_frames, int nframes, int stride, int *d_corrections);
     int sdhip_bch_decode(void *h, uint8_t *frames, int nframes, int stride, int *corrections);
+        /* dvbs2::S2BBToSoft::work (plugins/dvb_support/dvbs2/dvbs2_bb_to_soft.cpp:18-69) on nframes PL-synchronised, phase-recovered PLFRAMEs as
+       S2PLLBlock hands them over (dvbs2_pll.cpp:31-49): d_plframes = nframes x frame_stride complex floats (device), each [90 header symbols |
+       frame_slot_count x 90 symbols ...]. modcod / shortframes / pilots: the module's parameters (module_dvbs2_demod.cpp:55-63; the MODCOD
+       table of codings/dvb-s2/modcod_to_cfg.h:19-151 decides modulation, slots and code rate; 32APSK -- no demapper table in the reference --
+       and unknown MODCODs are refused with the reference's messages). lut_bits (HOST): the soft-demapper table constellation_t::make_lut
+       (lut_resolution) built, [x][y][bit] int8 (module_dvbs2_demod.cpp:123-124: resolution 256) -- data the caller owns, cached on the
+       device until it changes. Per frame: PLS decode (d_pls[f] = MODCOD << 2 | SHORTFRAMES << 1 | PILOTS as decoded from the header,
+       dvbs2_bb_to_soft.cpp:27-51; may be NULL), PL descrambling, table lookup, the pilots branch as the block has it, de-interleaver.
+       d_soft: nframes x 64800 (16200) soft bits, the LDPC decoder's input. Returns the soft bits per frame, <0 on error. */
+    int sdhip_s2_bb_to_soft_dev(int device, int modcod, int shortframes, int pilots, const float *d_plframes, int frame_stride, int nframes, const int8_t *lut_bits,
+                                int lut_resolution, int8_t *d_soft, int *d_pls);
+    /* get_dvbs2_cfg's answer for a MODCOD: bits per symbol, slots per frame, dvbs2_code_rate_t, dvbs2_constellation_t */
+    int sdhip_s2_cfg(int modcod, int shortframes, int *bits, int *slots, int *rate, int *constellation);
     /* dvbs2::S2Deinterleaver::deinterleave (codings/dvb-s2/s2_deinterleaver.cpp:92-145) over nframes frames of 64800 / 16200 soft bits:
        constellation = dvbs2_constellation_t (0 QPSK, 1 8PSK, 2 16APSK, 3 32APSK), d_in != d_out (device pointers) */
     int sdhip_s2_deinterleave_dev(int device, int constellation, int framesize, int rate, const int8_t *d_in, int8_t *d_out, int nframes);

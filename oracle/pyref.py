@@ -423,3 +423,39 @@ class NdspRef:
         if n < 0:
             raise RuntimeError(f"sdref_ndsp_run({block_id}) -> {n}")
         return out[:n].copy()
+
+
+class S2FrontRef:
+    """dvbs2::S2BBToSoft and the objects DVBS2DemodModule::init builds around it (oracle/ref_wrap_dvbs2_demap.cpp, in libsdref_dvbs2.so)."""
+
+    def __init__(self):
+        self.lib = C.CDLL(os.path.join(_HERE, "_ref", "libsdref_dvbs2.so"))
+
+    @staticmethod
+    def available() -> bool:
+        p = os.path.join(_HERE, "_ref", "libsdref_dvbs2.so")
+        return os.path.exists(p) and hasattr(C.CDLL(p), "sdref_s2_bb_to_soft")
+
+    def cfg(self, modcod, shortframes, pilots):
+        o = (C.c_int * 4)()
+        if self.lib.sdref_s2_cfg(int(modcod), int(shortframes), int(pilots), o) != 0:
+            raise ValueError("unsupported modcod")
+        return dict(slots=o[0], constellation=o[1], rate=o[2], bits=o[3])
+
+    def lut(self, modcod, shortframes, resolution=256) -> np.ndarray:
+        bits = self.cfg(modcod, shortframes, 0)["bits"]
+        out = np.zeros((resolution, resolution, bits), dtype=np.int8)
+        self.lib.sdref_s2_lut(int(modcod), int(shortframes), int(resolution), _p(out))
+        return out
+
+    def bb_to_soft(self, modcod, shortframes, pilots, frames: np.ndarray):
+        """frames complex64 [nframes, stride] -> (soft int8 [nframes, slots*90*bits], pls int32 [nframes])."""
+        f = np.ascontiguousarray(frames, dtype=np.complex64)
+        c = self.cfg(modcod, shortframes, pilots)
+        n = c["slots"] * 90 * c["bits"]
+        out = np.zeros((len(f), n), dtype=np.int8)
+        pls = np.zeros(len(f), dtype=np.int32)
+        r = self.lib.sdref_s2_bb_to_soft(int(modcod), int(shortframes), int(pilots), _p(f), f.shape[1], len(f), _p(out), _p(pls))
+        if r != n:
+            raise RuntimeError(f"sdref_s2_bb_to_soft -> {r}")
+        return out, pls

@@ -1,0 +1,75 @@
+// oracle/ref_wrap_dvbs2_demap.cpp -- TEST INFRASTRUCTURE ONLY: the reference's DVB-S2 PLFRAME -> soft bits stage, dvbs2::S2BBToSoft
+// (plugins/dvb_support/dvbs2/dvbs2_bb_to_soft.{h,cpp}: PLS decode, PL descrambling, LUT soft demapping, the de-interleaver), driven frame by
+// frame through its own dsp::stream input / output, and the objects DVBS2DemodModule::init builds around it (module_dvbs2_demod.cpp:85-126:
+// get_dvbs2_cfg, constellation_t + make_lut(256), S2Deinterleaver). Compiled with -fno-access-control: work() is private, and the block's
+// scratch buffer (`new int8_t[64800]`, never initialised by the reference) is zeroed so that the positions its pilots branch never
+// writes are defined.
+#include "dvbs2/dvbs2_bb_to_soft.h"
+#include "codings/dvb-s2/modcod_to_cfg.h"
+#include <cstring>
+
+extern "C"
+{
+    // -> {frame_slot_count, constellation (dvbs2_constellation_t), coderate, bits per symbol}
+    int sdref_s2_cfg(int modcod, int shortframes, int pilots, int *out4)
+    {
+        try
+        {
+            auto cfg = dvbs2::get_dvbs2_cfg(modcod, shortframes, pilots);
+            dsp::constellation_t c(cfg.constel_obj_type, cfg.g1, cfg.g2);
+            out4[0] = cfg.frame_slot_count;
+            out4[1] = (int)cfg.constellation;
+            out4[2] = (int)cfg.coderate;
+            out4[3] = c.getBitsCnt();
+            return 0;
+        }
+        catch (std::exception &)
+        {
+            return -1;
+        }
+    }
+
+    // the soft-demapper table constellation_t::make_lut(resolution) builds: out[x][y][bit]
+    int sdref_s2_lut(int modcod, int shortframes, int resolution, int8_t *out)
+    {
+        auto cfg = dvbs2::get_dvbs2_cfg(modcod, shortframes, false);
+        dsp::constellation_t c(cfg.constel_obj_type, cfg.g1, cfg.g2);
+        c.make_lut(resolution);
+        const int bits = c.getBitsCnt();
+        for (int x = 0; x < resolution; x++)
+            for (int y = 0; y < resolution; y++)
+                for (int b = 0; b < bits; b++)
+                    out[((size_t)x * resolution + y) * bits + b] = c.lut[x][y].bits[b];
+        return bits;
+    }
+
+    // frames: nframes x frame_stride complex floats (what S2PLLBlock hands over: 90 header symbols, then the slots). out: nframes x
+    // frame_slot_count * 90 * bits soft bits; pls[f] = {best_header} as S2BBToSoft::work decodes it.
+    int sdref_s2_bb_to_soft(int modcod, int shortframes, int pilots, const float *frames, int frame_stride, int nframes, int8_t *out, int *pls)
+    {
+        auto cfg = dvbs2::get_dvbs2_cfg(modcod, shortframes, pilots);
+        auto in = std::make_shared<dsp::stream<complex_t>>();
+        dvbs2::S2BBToSoft blk(in);
+        memset(blk.soft_slots_buffer, 0, 64800);
+        blk.pilots = pilots;
+        blk.constellation = std::make_shared<dsp::constellation_t>(cfg.constel_obj_type, cfg.g1, cfg.g2);
+        blk.constellation->make_lut(256);
+        blk.frame_slot_count = cfg.frame_slot_count;
+        blk.deinterleaver = std::make_shared<dvbs2::S2Deinterleaver>(cfg.constellation, cfg.framesize, cfg.coderate);
+        const int nout = cfg.frame_slot_count * 90 * blk.constellation->getBitsCnt();
+        for (int f = 0; f < nframes; f++)
+        {
+            memcpy(in->writeBuf, frames + (size_t)f * frame_stride * 2, (size_t)frame_stride * sizeof(complex_t));
+            in->swap(frame_stride);
+            blk.work();
+            const int got = blk.output_stream->read();
+            if (got != nout)
+                return -2;
+            memcpy(out + (size_t)f * nout, blk.output_stream->readBuf, nout);
+            blk.output_stream->flush();
+            if (pls)
+                pls[f] = (blk.detect_modcod << 2) | (blk.detect_shortframes ? 2 : 0) | (blk.detect_pilots ? 1 : 0);
+        }
+        return nout;
+    }
+}

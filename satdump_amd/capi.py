@@ -162,6 +162,9 @@ def lib():
             L.sdhip_s2_pack_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int]
             L.sdhip_bb_descramble_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
             L.sdhip_s2_deinterleave_dev.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
+        if hasattr(L, "sdhip_s2_bb_to_soft_dev"):
+            L.sdhip_s2_bb_to_soft_dev.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+            L.sdhip_s2_cfg.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.sdhip_prof_enable.argtypes = [C.c_int]
         L.sdhip_pool_enable.argtypes = [C.c_int]
         L.sdhip_prof_get.argtypes = [C.c_int, C.c_char_p, C.c_size_t, C.POINTER(C.c_double), C.POINTER(C.c_longlong)]

@@ -1,0 +1,277 @@
+// dvbs2_demap.hip -- the PLFRAME -> soft bits stage of the DVB-S2 demodulator on gfx950:
+// dvbs2::S2BBToSoft::work (plugins/dvb_support/dvbs2/dvbs2_bb_to_soft.cpp:18-69) on a batch of PL-synchronised, phase-recovered frames
+// as S2PLLBlock writes them (dvbs2_pll.cpp:31-49: 90 header symbols, then frame_slot_count slots of 90 symbols):
+//   * PLS decode: the 64 header symbols behind the SOF, turned by -pi/4, sliced, compared with the 128 PLS code words over their low 60 bits
+//     (dvbs2_bb_to_soft.h:29-41 -- checkSyncMarker starts at bit 59), first minimum wins                                   -> k_s2_pls
+//   * PL descrambling: the Gold sequence n = 0 restarted at every frame (s2_scrambling.cpp:10-36), a turn by a multiple of 90 degrees --
+//     exact component swaps and negations (s2_scrambling.cpp:45-70)
+//   * soft demapping through the constellation's table (constellation_t::demod_soft_lut, constellation.cpp:324-352): index
+//     (int)((double)re / 1.5 * res + res / 2) clamped to the table, `bits` int8 per symbol. The TABLE is an input: the caller hands over what
+//     constellation_t::make_lut(256) built on the host (module_dvbs2_demod.cpp:123-124) -- its entries come out of expf / logf / hypotf of
+//     the host's libm and are data here, not arithmetic to be re-derived. 32APSK has no table in the reference (it evaluates the
+//     exponentials per sample): refused.
+//   * the block's pilots branch as it is (dvbs2_bb_to_soft.cpp:57-63): every 1476 symbols the write position falls back by 36, the loop still
+//     runs over frame_slot_count * 90 input symbols; later symbols overwrite earlier ones, positions behind the last write keep the
+//     scratch buffer's previous contents (never initialised in the reference: zero here)                                  -> k_s2_demap
+//   * the de-interleaver (s2_deinterleaver.cpp) on the result: sdhip_s2_deinterleave_dev's kernel
+// All byte / index work apart from one double division per component: HBM-bound (8 B in, `bits` B out per symbol), a thread per OUTPUT symbol.
+#include "../../include/sdhip.h"
+#include "common.h"
+
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+namespace sdhip
+{
+    // ---- host tables
+    // PLS code words (ETSI EN 302 307-1 5.5.2.4; dvbs2/s2_defs.h:40-86): (7, 64) code from the 6 x 32 generator, each bit doubled / paired with its
+    // complement by the pilots bit, scrambled
+    static void s2_pls_codewords(unsigned long long *cw)
+    {
+        static const unsigned G[6] = {0x55555555u, 0x33333333u, 0x0f0f0f0fu, 0x00ff00ffu, 0x0000ffffu, 0xffffffffu};
+        for (int index = 0; index < 128; index++)
+        {
+            unsigned y = 0;
+            for (int row = 0; row < 6; row++)
+                if ((index >> (6 - row)) & 1)
+                    y ^= G[row];
+            unsigned long long code = 0;
+            for (int bit = 31; bit >= 0; bit--)
+            {
+                const unsigned long long yi = (y >> bit) & 1;
+                code = (code << 2) | (yi << 1) | ((index & 1) ? (yi ^ 1) : yi);
+            }
+            cw[index] = code ^ 0x719d83c953422dfaull;
+        }
+    }
+    // PL scrambling sequence Rn (two bits per symbol), Gold code number 0 (s2_scrambling.cpp:10-36): x^18 + x^7 + 1 and x^18 + x^10 + x^7 + x^5 + 1
+    static void s2_gold_rn(std::vector<unsigned char> &rn, int count)
+    {
+        auto lx = [](unsigned X) { const unsigned bit = ((X >> 7) ^ X) & 1u; return ((bit << 18) | X) >> 1; };
+        auto ly = [](unsigned Y) { const unsigned bit = ((Y >> 10) ^ (Y >> 7) ^ (Y >> 5) ^ Y) & 1u; return ((bit << 18) | Y) >> 1; };
+        std::vector<unsigned char> z(2 * 131072);
+        unsigned x = 0x00001u, y = 0x3ffffu;
+        for (int i = 0; i < 2 * 131072; i++)
+        {
+            z[i] = (unsigned char)((x ^ y) & 1u);
+            x = lx(x);
+            y = ly(y);
+        }
+        rn.resize(count);
+        for (int i = 0; i < count; i++)
+            rn[i] = (unsigned char)(z[i] | (z[i + 131072] << 1));
+    }
+    // get_dvbs2_cfg (codings/dvb-s2/modcod_to_cfg.h:19-151): MODCOD -> modulation (bits per symbol), slots per frame, code rate (dvbs2_code_rate_t)
+    struct S2Cfg
+    {
+        int bits, slots, rate, constellation;
+    };
+    static S2Cfg s2_cfg_of(int modcod, int shortframes)
+    {
+        static const int qpsk[11] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 10, 11};                  // 1/4 1/3 2/5 1/2 3/5 2/3 3/4 4/5 5/6 8/9 9/10
+        static const int psk8[6] = {4, 5, 6, 8, 10, 11}, apsk16[6] = {5, 6, 7, 8, 10, 11}; // 3/5 2/3 3/4 5/6 8/9 9/10 | 2/3 3/4 4/5 5/6 8/9 9/10
+        if (modcod >= 1 && modcod < 12)
+            return S2Cfg{2, shortframes ? 90 : 360, qpsk[modcod - 1], 0};
+        if (modcod >= 12 && modcod < 18)
+            return S2Cfg{3, shortframes ? 60 : 240, psk8[modcod - 12], 1};
+        if (modcod >= 18 && modcod < 24)
+            return S2Cfg{4, shortframes ? 45 : 180, apsk16[modcod - 18], 2};
+        if (modcod >= 24 && modcod < 29)
+            throw HipError("dvbs2 bb_to_soft: 32APSK has no demapper table in the reference (constellation.cpp:326, 354-357): not on the HIP path");
+        throw HipError(modcod <= 0 ? "MODCOD cannot be <= 0!" : "MODCOD not (yet?) supported!"); // modcod_to_cfg.h:26, 146
+    }
+
+    // ---- kernels
+    __global__ __launch_bounds__(64) void k_s2_pls(const float2 *__restrict__ frames, int frame_stride, int nframes, const unsigned long long *__restrict__ cw, int *pls)
+    {
+        const int f = (int)blockIdx.x, y = (int)threadIdx.x;
+        if (f >= nframes)
+            return;
+        const float2 v = frames[(size_t)f * frame_stride + 26 + y];
+        // input * complex_t(cos(-M_PI / 4), sin(-M_PI / 4)) -- the doubles narrowed to complex_t's floats -- real part: re * c - im * s
+        const float c = (float)0.70710678118654757, s = (float)-0.70710678118654746;
+        const bool value = (v.x * c - v.y * s) > 0.0f;
+        const unsigned long long hdr = __ballot(!value); // lane y -> bit y; the reference shifts bit y = 0 in first: MSB first
+        if (y == 0)
+        {
+            const unsigned long long plheader = ((unsigned long long)__brev((unsigned)hdr) << 32) | (unsigned long long)__brev((unsigned)(hdr >> 32));
+            int best = 0, diffs = 64;
+            for (int k = 0; k < 128; k++)
+            {
+                const int d = __popcll((cw[k] ^ plheader) & 0x0FFFFFFFFFFFFFFFull); // checkSyncMarker: bits 59 .. 0
+                if (d < diffs)
+                {
+                    best = k;
+                    diffs = d;
+                }
+            }
+            pls[f] = best;
+        }
+    }
+
+    // one thread per output symbol position j of a frame; nsym = frame_slot_count * 90 input symbols are looked at
+    template <int BITS>
+    __global__ __launch_bounds__(256) void k_s2_demap(const float2 *__restrict__ frames, int frame_stride, int nframes, int nsym, int pilots,
+                                                      const unsigned char *__restrict__ rn, const signed char *__restrict__ lut, int res, signed char *__restrict__ out)
+    {
+        const int j = (int)(blockIdx.x * blockDim.x + threadIdx.x), f = (int)blockIdx.y;
+        if (j >= nsym || f >= nframes)
+            return;
+        // which input symbol i lands on position j LAST: i - 36 * (i / 1476) = j (pilots), i = j otherwise
+        int i = j;
+        if (pilots)
+        {
+            const int s = j / 1440;
+            i = j + 36 * s; // segment s writes [1440 s, 1440 s + 1476)
+            if (i >= nsym)
+            { // ... unless the loop ends first: then the tail of segment s - 1 (its last 36 symbols), if any
+                i = (s > 0 && j - 1440 * (s - 1) < 1476) ? j + 36 * (s - 1) : -1;
+                if (i >= nsym)
+                    i = -1;
+            }
+        }
+        signed char *o = out + ((size_t)f * nsym + j) * BITS;
+        if (i < 0)
+        { // never written by the reference (scratch buffer contents): zero
+#pragma unroll
+            for (int b = 0; b < BITS; b++)
+                o[b] = 0;
+            return;
+        }
+        const float2 p = frames[(size_t)f * frame_stride + 90 + i];
+        float re = p.x, im = p.y;
+        switch (rn[i])
+        { // S2Scrambling::descramble, s2_scrambling.cpp:45-70
+        case 3:
+            re = -p.y;
+            im = p.x;
+            break;
+        case 2:
+            re = -p.x;
+            im = -p.y;
+            break;
+        case 1:
+            re = p.y;
+            im = -p.x;
+            break;
+        default:
+            break;
+        }
+        // int x = (sample.real / 1.5) * lut_resolution + lut_resolution / 2: double arithmetic, truncation, clamp (constellation.cpp:328-341)
+        int x = (int)(((double)re / 1.5) * (double)res + (double)(res / 2));
+        int y = (int)(((double)im / 1.5) * (double)res + (double)(res / 2));
+        x = x < 0 ? 0 : (x >= res ? res - 1 : x);
+        y = y < 0 ? 0 : (y >= res ? res - 1 : y);
+        const signed char *l = lut + ((size_t)x * res + y) * BITS;
+#pragma unroll
+        for (int b = 0; b < BITS; b++)
+            o[b] = l[b];
+    }
+
+    struct S2DemapCache
+    {
+        DevBuf<unsigned long long> d_cw;
+        DevBuf<unsigned char> d_rn;
+        DevBuf<signed char> d_lut, d_slots;
+        int rn_count = 0;
+        std::vector<signed char> lut_host;
+        int device = -1;
+    };
+} // namespace sdhip
+
+using namespace sdhip;
+
+#define SD_GUARD_BEGIN try {
+#define SD_GUARD_END(ret)           \
+    }                               \
+    catch (const std::exception &e) \
+    {                               \
+        sdhip::set_error(e.what()); \
+        return ret;                 \
+    }
+
+extern "C"
+{
+    int sdhip_s2_bb_to_soft_dev(int device, int modcod, int shortframes, int pilots, const float *d_plframes, int frame_stride, int nframes, const int8_t *lut_bits,
+                                int lut_resolution, int8_t *d_soft, int *d_pls)
+    {
+        SD_GUARD_BEGIN
+        const S2Cfg c = s2_cfg_of(modcod, shortframes ? 1 : 0);
+        const int nsym = c.slots * 90;
+        if (frame_stride < 90 + nsym)
+            throw HipError("dvbs2 bb_to_soft: frame_stride shorter than header + slots");
+        if (!lut_bits || lut_resolution < 2 || lut_resolution > 4096)
+            throw HipError("dvbs2 bb_to_soft: the demapper table (constellation_t::make_lut) must be handed over");
+        if (nframes <= 0)
+            return 0;
+        SD_HIP(hipSetDevice(device));
+        static thread_local S2DemapCache T; // tables of the calling thread's last configuration
+        if (T.device != device)
+        { // tables live on one device
+            T.d_cw.release();
+            T.d_rn.release();
+            T.d_lut.release();
+            T.d_slots.release();
+            T.rn_count = 0;
+            T.lut_host.clear();
+            T.device = device;
+        }
+        if (!T.d_cw.p)
+        {
+            unsigned long long cw[128];
+            s2_pls_codewords(cw);
+            T.d_cw.reserve(128);
+            SD_HIP(hipMemcpy(T.d_cw.p, cw, sizeof(cw), hipMemcpyHostToDevice));
+        }
+        if (T.rn_count < nsym)
+        {
+            std::vector<unsigned char> rn;
+            s2_gold_rn(rn, 33000); // a normal QPSK frame has 32 400 data symbols (+ pilots): the longest there is
+            T.d_rn.reserve(rn.size());
+            SD_HIP(hipMemcpy(T.d_rn.p, rn.data(), rn.size(), hipMemcpyHostToDevice));
+            T.rn_count = (int)rn.size();
+        }
+        const size_t lut_bytes = (size_t)lut_resolution * lut_resolution * c.bits;
+        if (T.lut_host.size() != lut_bytes || memcmp(T.lut_host.data(), lut_bits, lut_bytes) != 0)
+        {
+            T.lut_host.assign(reinterpret_cast<const signed char *>(lut_bits), reinterpret_cast<const signed char *>(lut_bits) + lut_bytes);
+            T.d_lut.reserve(lut_bytes);
+            SD_HIP(hipMemcpy(T.d_lut.p, lut_bits, lut_bytes, hipMemcpyHostToDevice));
+        }
+        const size_t frame_soft = (size_t)nsym * c.bits;
+        T.d_slots.reserve((size_t)nframes * frame_soft);
+        const float2 *fr = reinterpret_cast<const float2 *>(d_plframes);
+        if (d_pls)
+        {
+            ProfScope _ps("k_s2_pls", nullptr);
+            hipLaunchKernelGGL(k_s2_pls, dim3((unsigned)nframes), dim3(64), 0, nullptr, fr, frame_stride, nframes, T.d_cw.p, d_pls);
+        }
+        {
+            ProfScope _ps("k_s2_demap", nullptr);
+            const dim3 grid((unsigned)((nsym + 255) / 256), (unsigned)nframes);
+            if (c.bits == 2)
+                hipLaunchKernelGGL(k_s2_demap<2>, grid, dim3(256), 0, nullptr, fr, frame_stride, nframes, nsym, pilots ? 1 : 0, T.d_rn.p, T.d_lut.p, lut_resolution, T.d_slots.p);
+            else if (c.bits == 3)
+                hipLaunchKernelGGL(k_s2_demap<3>, grid, dim3(256), 0, nullptr, fr, frame_stride, nframes, nsym, pilots ? 1 : 0, T.d_rn.p, T.d_lut.p, lut_resolution, T.d_slots.p);
+            else
+                hipLaunchKernelGGL(k_s2_demap<4>, grid, dim3(256), 0, nullptr, fr, frame_stride, nframes, nsym, pilots ? 1 : 0, T.d_rn.p, T.d_lut.p, lut_resolution, T.d_slots.p);
+        }
+        // the de-interleaver (S2Deinterleaver::deinterleave, dvbs2_bb_to_soft.cpp:66): frame_slot_count * 90 * bits = 64800 / 16200 soft bits per frame
+        if (sdhip_s2_deinterleave_dev(device, c.constellation, shortframes ? 1 : 0, c.rate, reinterpret_cast<const int8_t *>(T.d_slots.p), d_soft, nframes) != 0)
+            return -1;
+        return (int)frame_soft;
+        SD_GUARD_END(-1)
+    }
+    int sdhip_s2_cfg(int modcod, int shortframes, int *bits, int *slots, int *rate, int *constellation)
+    {
+        SD_GUARD_BEGIN
+        const S2Cfg c = s2_cfg_of(modcod, shortframes ? 1 : 0);
+        *bits = c.bits;
+        *slots = c.slots;
+        *rate = c.rate;
+        *constellation = c.constellation;
+        return 0;
+        SD_GUARD_END(-1)
+    }
+}

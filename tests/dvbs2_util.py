@@ -62,3 +62,45 @@ def encode(framesize, rate_code, data_bits):
         np.bitwise_xor.at(acc[f], rows, data_bits[f, bits])
     par = np.bitwise_xor.accumulate(acc, axis=1)
     return np.concatenate([data_bits, par], axis=1)
+
+
+# ---- PLFRAMEs for the soft demapper stage (dvbs2::S2BBToSoft)
+def pls_codewords() -> np.ndarray:
+    """The 128 PLS code words of ETSI EN 302 307-1 5.5.2.4 (index = MODCOD << 2 | short << 1 | pilots): (32, 6) generator, every bit sent
+    twice (pilots bit: the second copy complemented), scrambled with the standard's 64-bit sequence."""
+    G = [0x55555555, 0x33333333, 0x0f0f0f0f, 0x00ff00ff, 0x0000ffff, 0xffffffff]
+    out = np.zeros(128, dtype=np.uint64)
+    for index in range(128):
+        y = 0
+        for row in range(6):
+            if (index >> (6 - row)) & 1:
+                y ^= G[row]
+        code = 0
+        for bit in range(31, -1, -1):
+            yi = (y >> bit) & 1
+            code = (code << 2) | (yi << 1) | ((yi ^ 1) if (index & 1) else yi)
+        out[index] = code ^ 0x719d83c953422dfa
+    return out
+
+
+def plframes(slots: int, pls_index: int, nframes: int, seed: int, flips: int = 3, stride_pad: int = 40):
+    """nframes synthetic PL-synchronised frames [90 header symbols | slots * 90 symbols | padding] as complex64 [nframes, stride]:
+    the PLS field carries code word `pls_index` the way S2BBToSoft slices it (symbol = exp(j pi/4) * (+1: bit 0, -1: bit 1), dvbs2_bb_to_soft.cpp:30-34)
+    with `flips` symbols inverted and a little noise; the data symbols are scattered over and beyond the demapper table's +-0.75 range,
+    exact zeros and table-edge values included."""
+    rng = np.random.default_rng(seed)
+    stride = 90 + slots * 90 + stride_pad
+    fr = ((rng.uniform(-1.0, 1.0, (nframes, stride)) + 1j * rng.uniform(-1.0, 1.0, (nframes, stride)))).astype(np.complex64)
+    fr[:, 90 + 5] = 0
+    fr[:, 90 + 6] = 0.75 + 0.75j
+    fr[:, 90 + 7] = -0.75 - 0.7499999j
+    fr[:, 90 + 8] = 3.0 - 9.0j
+    cw = int(pls_codewords()[pls_index])
+    for f in range(nframes):
+        bits = np.array([(cw >> (63 - y)) & 1 for y in range(64)])
+        inv = rng.choice(64, flips, replace=False)
+        bits[inv] ^= 1
+        sym = np.exp(1j * np.pi / 4) * np.where(bits == 1, -1.0, 1.0) * rng.uniform(0.5, 1.2, 64)
+        sym = sym + 0.05 * (rng.standard_normal(64) + 1j * rng.standard_normal(64))
+        fr[f, 26:90] = sym.astype(np.complex64)
+    return fr

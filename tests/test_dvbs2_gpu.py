@@ -209,6 +209,61 @@ def test_s2_deinterleaver(capi, const, fs, rate):
     assert rc == 0 and np.array_equal(d_out.cpu().numpy(), want)
 
 
+BB2SOFT = [(6, 0, 0), (4, 1, 0), (13, 0, 0), (12, 1, 0), (20, 0, 0), (23, 1, 0), (6, 0, 1), (13, 1, 1), (18, 0, 1)]
+
+
+def check_bb_to_soft(capi, to_dev, from_dev, zeros_dev, modcod, short, pilots, nframes=4):
+    """sdhip_s2_bb_to_soft_dev == dvbs2::S2BBToSoft::work frame by frame (the reference block driven through its own dsp::stream input and
+    output, oracle/ref_wrap_dvbs2_demap.cpp): decoded PLS index, PL descrambling, table demapping, pilots branch, de-interleaver -- identical
+    soft bits. The demapper table is the reference's own (constellation_t::make_lut(256)), handed over as the binding's caller would."""
+    import ctypes as C
+    from tests import dvbs2_util
+    if not pyref.S2FrontRef.available():
+        pytest.skip("oracle/_ref/libsdref_dvbs2.so without the front-end entries (rebuild with the reference tree)")
+    ref = pyref.S2FrontRef()
+    c = ref.cfg(modcod, short, pilots)
+    pls_index = (modcod << 2) | (short << 1) | pilots
+    fr = dvbs2_util.plframes(c["slots"], pls_index, nframes, seed=modcod + 7 * short + pilots)
+    want, wpls = ref.bb_to_soft(modcod, short, pilots, fr)
+    assert np.all(wpls == pls_index)  # three inverted header symbols are inside the code's distance
+    lut = ref.lut(modcod, short)
+    d_fr = to_dev(fr.view(np.float32))
+    nsoft = c["slots"] * 90 * c["bits"]
+    d_soft = zeros_dev(nframes * nsoft, np.int8)
+    d_pls = zeros_dev(nframes, np.int32)
+    rc = capi.lib().sdhip_s2_bb_to_soft_dev(0, modcod, short, pilots, C.c_void_p(d_fr[1]), fr.shape[1], nframes, lut.ctypes.data_as(C.c_void_p), 256,
+                                            C.c_void_p(d_soft[1]), C.c_void_p(d_pls[1]))
+    assert rc == nsoft, capi.last_error()
+    got = from_dev(d_soft).reshape(nframes, nsoft)
+    assert np.array_equal(from_dev(d_pls), wpls)
+    assert np.array_equal(got, want)
+    assert nsoft == (16200 if short else 64800) and np.count_nonzero(got) > 0.9 * got.size * (0.9 if pilots else 1.0)
+
+
+@pytest.mark.parametrize("modcod,short,pilots", BB2SOFT)
+def test_bb_to_soft(capi, modcod, short, pilots):
+    import torch
+
+    def to_dev(a):
+        t = torch.from_numpy(np.ascontiguousarray(a)).cuda()
+        return (t, t.data_ptr())
+
+    def zeros_dev(n, dt):
+        t = torch.zeros(n, dtype={np.int8: torch.int8, np.int32: torch.int32}[dt], device="cuda")
+        return (t, t.data_ptr())
+
+    check_bb_to_soft(capi, to_dev, lambda d: d[0].cpu().numpy(), zeros_dev, modcod, short, pilots)
+
+
+def test_bb_to_soft_refusals(capi):
+    """32APSK (no demapper table in the reference) and MODCODs outside the table come back as errors with the reference's wording."""
+    import ctypes as C
+    lut = np.zeros((256, 256, 5), dtype=np.int8)
+    for modcod, msg in ((24, "32APSK"), (0, "MODCOD cannot be <= 0!"), (29, "MODCOD not (yet?) supported!")):
+        rc = capi.lib().sdhip_s2_bb_to_soft_dev(0, modcod, 0, 0, None, 40000, 1, lut.ctypes.data_as(C.c_void_p), 256, None, None)
+        assert rc < 0 and msg in capi.last_error()
+
+
 def test_errors(capi):
     with pytest.raises(capi.SdhipError):
         capi.LdpcDecoder(framesize=0, rate="7/8")   # no LDPC table (bbframe_ldpc.cpp:30-69 has no case for it)

@@ -89,6 +89,20 @@ def test_s2_deinterleaver_on_the_twin(capi, const, fs, rate):
     assert rc == 0 and np.array_equal(got, want)
 
 
+@pytest.mark.parametrize("modcod,short,pilots", [(6, 0, 0), (13, 1, 0), (20, 0, 0), (6, 1, 1), (13, 0, 1)])
+def test_bb_to_soft_on_the_twin(capi, modcod, short, pilots):
+    def to_dev(a):
+        a = np.ascontiguousarray(a)
+        return (a, a.ctypes.data)
+
+    def zeros_dev(n, dt):
+        a = np.zeros(n, dtype=dt)
+        return (a, a.ctypes.data)
+
+    G.check_bb_to_soft(capi, to_dev, lambda d: d[0], zeros_dev, modcod, short, pilots, nframes=3)
+
+
+test_bb_to_soft_refusals = G.test_bb_to_soft_refusals
 test_errors = G.test_errors
 
 
