@@ -833,7 +833,11 @@ namespace sdhip
             // the shorter chunk pays more warm-up (10.6 k samples on 21.9 k instead of 32.9 k); parity 99.592 % against 99.614 %
             static const long long dflt[3] = {65280, 65280, 98304};
             static const long long min_len[3] = {2048, 2048, 2048};
-            const long long lanes = std::max<long long>(64, env_int(names[st], dflt[st]));
+            long long lanes = std::max<long long>(64, env_int(names[st], dflt[st]));
+            // ... on batches long enough for it: below ~16 k samples per lane (GOES' 268 M-sample step: 4 k) the extra lanes only add warm-up
+            // (measured, profiles/r03_p_bench.json: GOES k_mm 7.1 -> 7.8 ms with them)
+            if (st == ST_MM && !getenv(names[st]) && (n + 65279) / 65280 < 16384)
+                lanes = 65280;
             long long L = (n + lanes - 1) / lanes;
             L = (L + 63) / 64 * 64;
             return (int)std::min<long long>(std::max<long long>(L, min_len[st]), 1 << 20);

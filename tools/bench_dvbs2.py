@@ -25,6 +25,8 @@ def parse(argv=None):
     ap.add_argument("--batch", type=int, default=16)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--cpu-frames", type=int, default=64)
+    ap.add_argument("--front", type=int, default=1, help="1: the frames enter as QPSK PLFRAMEs through sdhip_s2_bb_to_soft_dev (needs oracle/_ref for the demapper table)")
+    ap.add_argument("--esn0", type=float, default=4.2, help="Es/N0 of the PLFRAMEs, dB")
     return ap.parse_args(argv)
 
 
@@ -54,8 +56,43 @@ def run(args) -> dict:
     d_pack = torch.zeros((nf, k // 8), dtype=torch.uint8, device="cuda")
     d_corr = torch.zeros(nf, dtype=torch.int32, device="cuda")
 
+    # --front 1 (default where the compiled reference is there to hand over its demapper table): the frames enter as PL-synchronised QPSK
+    # PLFRAMEs -- header with the PLS code word, the code word's bit pairs on I / Q (bit 0 -> +), PL-scrambled, complex noise -- and
+    # sdhip_s2_bb_to_soft_dev (PLS decode, descrambling, table demapping, de-interleaver) produces the decoder's input in every step
+    front = None
+    import ctypes as C
+    QPSK_MODCOD = {"1/4": 1, "1/3": 2, "2/5": 3, "1/2": 4, "3/5": 5, "2/3": 6, "3/4": 7, "4/5": 8, "5/6": 9, "8/9": 10, "9/10": 11}
+    if args.front and pyref.S2FrontRef.available() and args.rate in QPSK_MODCOD:
+        modcod = QPSK_MODCOD[args.rate]
+        fref = pyref.S2FrontRef()
+        lut = fref.lut(modcod, args.framesize)
+        nsym = n // 2
+        x, y, z = 1, 0x3ffff, np.zeros(2 * 131072, dtype=np.uint8)
+        for i in range(2 * 131072):  # Gold sequence n = 0 (ETSI EN 302 307-1 5.5.4)
+            z[i] = (x ^ y) & 1
+            x = ((((x >> 7) ^ x) & 1) << 18 | x) >> 1
+            y = ((((y >> 10) ^ (y >> 7) ^ (y >> 5) ^ y) & 1) << 18 | y) >> 1
+        rn = (z[:nsym] | (z[131072:131072 + nsym] << 1)).astype(np.int64)
+        a = 2.0 / 3.0 / np.sqrt(2.0)  # the table's nominal point: sample * const_amp (3) = (sqrt 2, sqrt 2)
+        sym = ((1.0 - 2.0 * cw[:, 0::2]) + 1j * (1.0 - 2.0 * cw[:, 1::2])) * a * np.exp(1j * np.pi / 2 * rn)[None, :]
+        stride = 90 + nsym + 6
+        base_fr = np.zeros((base, stride), dtype=np.complex64)
+        base_fr[:, 90:90 + nsym] = sym
+        pcw = int(dvbs2_util.pls_codewords()[(modcod << 2) | (args.framesize << 1)])
+        base_fr[:, 26:90] = np.exp(1j * np.pi / 4) * np.where(np.array([(pcw >> (63 - q)) & 1 for q in range(64)]) == 1, -1.0, 1.0)
+        sig = a * np.sqrt(2.0) * 10 ** (-args.esn0 / 20.0) / np.sqrt(2.0)  # per component, Es = 2 a^2
+        d_base = torch.from_numpy(base_fr.view(np.float32)).cuda()
+        d_fr = d_base[torch.arange(nf, device="cuda") % base] + sig * torch.randn((nf, 2 * stride), device="cuda", generator=g)
+        d_pls = torch.zeros(nf, dtype=torch.int32, device="cuda")
+        front = dict(modcod=modcod, stride=stride, nsym=nsym)
+
     def step():
-        work.copy_(soft)
+        if front:
+            r = capi.lib().sdhip_s2_bb_to_soft_dev(0, front["modcod"], args.framesize, 0, C.c_void_p(d_fr.data_ptr()), front["stride"], nf, lut.ctypes.data_as(C.c_void_p), 256,
+                                                   C.c_void_p(work.data_ptr()), C.c_void_p(d_pls.data_ptr()))
+            assert r == n, capi.last_error()
+        else:
+            work.copy_(soft)
         launches = ldpc.decode_dev(work.data_ptr(), nf, args.trials, d_tr.data_ptr())
         bch.pack_dev(work.data_ptr(), n, nf, d_pack.data_ptr(), k // 8)
         bch.decode_dev(d_pack.data_ptr(), nf, k // 8, d_corr.data_ptr())
@@ -78,8 +115,11 @@ def run(args) -> dict:
     upd = float(np.where(tr >= 0, tr, args.trials).mean())  # update passes per frame (a batch runs until all of it has converged)
     ms_ldpc = prof.get("k_ldpc_trial", (0.0, 0))[0] / args.steps
     algo = nf * upd * (2 * ldpc.info.msg_bytes_per_frame + 2 * n) + nf * (launches + 1 - upd) * n  # update passes + parity-check-only passes
-    out = {"metric": "DVB-S2 FEC frames/s (LDPC + repack + BCH), soft bits resident in HBM", "value": round(nf / dt, 1), "unit": "frames/s", "coded_Mbit_per_s": round(nf * n / dt / 1e6, 1),
-           "config": {"workload": f"{'normal' if args.framesize == 0 else 'short'} FECFRAME rate {args.rate}, {nf} frames per step, noise sigma {args.sigma} on +-20, max {args.trials} trials, "
+    out = {"metric": ("DVB-S2 PLFRAME -> BBFRAME frames/s (soft demapper stage + LDPC + repack + BCH), frames resident in HBM" if front else
+                      "DVB-S2 FEC frames/s (LDPC + repack + BCH), soft bits resident in HBM"), "value": round(nf / dt, 1), "unit": "frames/s", "coded_Mbit_per_s": round(nf * n / dt / 1e6, 1),
+           "config": {"workload": f"{'normal' if args.framesize == 0 else 'short'} FECFRAME rate {args.rate}, {nf} frames per step, "
+                                  + (f"QPSK PLFRAMEs at Es/N0 {args.esn0} dB, PLS decoded = {int(d_pls[0])} on every frame: {bool((d_pls == d_pls[0]).all())}, " if front else f"noise sigma {args.sigma} on +-20, ")
+                                  + f"max {args.trials} trials, "
                                   f"batch {args.batch} (the reference's SIMD width)"},
            "ms_per_step": round(dt * 1e3, 3), "trial_launches": int(launches) + 1, "update_passes_per_frame": round(upd, 2),
            "frames_converged": float((tr >= 0).mean()), "frames_bch_ok": float((corr >= 0).mean()), "bbframes_match_transmitted": bool(ok),
@@ -90,6 +130,9 @@ def run(args) -> dict:
                         "frac": round(algo / (ms_ldpc * 1e-3) / 1e9 / 8000.0, 4) if ms_ldpc else None, "traffic": None}}
     if args.cpu_frames > 0:
         m = args.cpu_frames // ref.batch * ref.batch
+        if front:  # the decoder's input is what the demapper stage produced
+            capi.lib().sdhip_s2_bb_to_soft_dev(0, front["modcod"], args.framesize, 0, C.c_void_p(d_fr.data_ptr()), front["stride"], m, lut.ctypes.data_as(C.c_void_p), 256,
+                                               C.c_void_p(soft.data_ptr()), None)
         sh = soft[:m].cpu().numpy()
         t1 = time.perf_counter()
         want, wt = ref.ldpc_decode(args.framesize, rc, sh, args.trials)
