@@ -26,7 +26,7 @@ def parse(argv=None):
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--cpu-frames", type=int, default=64)
     ap.add_argument("--front", type=int, default=1, help="1: the frames enter as QPSK PLFRAMEs through sdhip_s2_bb_to_soft_dev (needs oracle/_ref for the demapper table)")
-    ap.add_argument("--esn0", type=float, default=4.2, help="Es/N0 of the PLFRAMEs, dB")
+    ap.add_argument("--esn0", type=float, default=8.0, help="Es/N0 of the PLFRAMEs, dB")
     return ap.parse_args(argv)
 
 
