@@ -16,6 +16,7 @@ Fixtures (np.savez_compressed):
   simple_*.npz    CCSDSSimplePSKDecoderModule loop: int8 soft -> CADUs + RS error counts (three slicer modes)
   punct_*.npz     concatenated decoder with conv_rate 3/4 and 7/8 (Viterbi_Depunc): int8 soft -> CADUs, per-block BER/state
   gardner.npz     GardnerClockRecoveryBlock on stored cs16 samples
+  s2_bb_to_soft.npz  DVB-S2 S2BBToSoft (PLS decode, PL descrambling, table demapping, de-interleaver) on stored short QPSK PLFRAMEs
   ndsp_psk_*.npz  ndsp PSKDemodHierBlock (RRC -> AGC -> M&M -> Costas), stored cs16 samples -> complex symbols
   taps.npz        RRC / M&M interpolator bank / rational-resampler bank
 """
@@ -162,6 +163,15 @@ def main():
         xin = (cs16.astype(np.float32) * np.float32(1.0 / 32767.0)).view(np.complex64)
         out[f"ndsp_psk_{const}"] = dict(cs16=cs16, samplerate=np.float64(sr), symbolrate=np.float64(symr),
                                         syms=nd.run("psk_demod_cc", {"constellation": const, "samplerate": sr, "symbolrate": symr}, xin))
+
+    # ---- DVB-S2 PLFRAME -> soft bits stage (dvbs2::S2BBToSoft driven through its own streams, oracle/ref_wrap_dvbs2_demap.cpp): short QPSK
+    # frames (MODCOD 4), stored samples + the demapper table the reference builds -> PLS index and the LDPC decoder's input
+    from tests import dvbs2_util
+    fr_ref = pyref.S2FrontRef()
+    c4 = fr_ref.cfg(4, 1, 0)
+    frames = dvbs2_util.plframes(c4["slots"], (4 << 2) | 2, 2, seed=11, stride_pad=6)
+    soft4, pls4 = fr_ref.bb_to_soft(4, 1, 0, frames)
+    out["s2_bb_to_soft"] = dict(frames=frames, modcod=np.int32(4), shortframes=np.int32(1), pilots=np.int32(0), lut=fr_ref.lut(4, 1), soft=soft4, pls=pls4)
 
     # ---- filter designs
     bank, ir, dr = ref.resamp_bank(2700000, 3000000)

@@ -255,6 +255,37 @@ def test_bb_to_soft(capi, modcod, short, pilots):
     check_bb_to_soft(capi, to_dev, lambda d: d[0].cpu().numpy(), zeros_dev, modcod, short, pilots)
 
 
+def check_bb_to_soft_golden(capi, to_dev, from_dev, zeros_dev):
+    """The committed fixture tests/golden/s2_bb_to_soft.npz (written by make_golden.py from the compiled reference): stored PLFRAMEs and the
+    reference's demapper table -> its PLS indices and soft bits, byte for byte. Needs no reference build at run time."""
+    import ctypes as C
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "s2_bb_to_soft.npz"))
+    fr, lut = g["frames"], np.ascontiguousarray(g["lut"])
+    nframes, nsoft = g["soft"].shape
+    d_fr = to_dev(fr.view(np.float32))
+    d_soft = zeros_dev(nframes * nsoft, np.int8)
+    d_pls = zeros_dev(nframes, np.int32)
+    rc = capi.lib().sdhip_s2_bb_to_soft_dev(0, int(g["modcod"]), int(g["shortframes"]), int(g["pilots"]), C.c_void_p(d_fr[1]), fr.shape[1], nframes,
+                                            lut.ctypes.data_as(C.c_void_p), lut.shape[0], C.c_void_p(d_soft[1]), C.c_void_p(d_pls[1]))
+    assert rc == nsoft, capi.last_error()
+    assert np.array_equal(from_dev(d_pls), g["pls"]) and np.array_equal(from_dev(d_soft).reshape(nframes, nsoft), g["soft"])
+
+
+def test_bb_to_soft_golden(capi):
+    import torch
+
+    def to_dev(a):
+        t = torch.from_numpy(np.ascontiguousarray(a)).cuda()
+        return (t, t.data_ptr())
+
+    def zeros_dev(n, dt):
+        t = torch.zeros(n, dtype={np.int8: torch.int8, np.int32: torch.int32}[dt], device="cuda")
+        return (t, t.data_ptr())
+
+    check_bb_to_soft_golden(capi, to_dev, lambda d: d[0].cpu().numpy(), zeros_dev)
+
+
 def test_bb_to_soft_refusals(capi):
     """32APSK (no demapper table in the reference) and MODCODs outside the table come back as errors with the reference's wording."""
     import ctypes as C

@@ -102,6 +102,18 @@ def test_bb_to_soft_on_the_twin(capi, modcod, short, pilots):
     G.check_bb_to_soft(capi, to_dev, lambda d: d[0], zeros_dev, modcod, short, pilots, nframes=3)
 
 
+def test_bb_to_soft_golden_on_the_twin(capi):
+    def to_dev(a):
+        a = np.ascontiguousarray(a)
+        return (a, a.ctypes.data)
+
+    def zeros_dev(n, dt):
+        a = np.zeros(n, dtype=dt)
+        return (a, a.ctypes.data)
+
+    G.check_bb_to_soft_golden(capi, to_dev, lambda d: d[0], zeros_dev)
+
+
 test_bb_to_soft_refusals = G.test_bb_to_soft_refusals
 test_errors = G.test_errors
 
