@@ -350,6 +350,15 @@ extern "C"
        d_soft: nframes x 64800 (16200) soft bits, the LDPC decoder's input. Returns the soft bits per frame, <0 on error. */
     int sdhip_s2_bb_to_soft_dev(int device, int modcod, int shortframes, int pilots, const float *d_plframes, int frame_stride, int nframes, const int8_t *lut_bits,
                                 int lut_resolution, int8_t *d_soft, int *d_pls);
+    /* dvbs2::S2PLSyncBlock::work2 (plugins/dvb_support/dvbs2/dvbs2_pl_sync.cpp:52-125) over a batch of clock-recovered symbols (device, complex
+       floats): the block's ring buffer is [d_syms, d_syms + nsyms). Per frame: the differential SOF + PLS correlation at every offset of a
+       raw_frame_size window ((slot_number + 1) * 90 symbols, + 36 per pilot block as the constructor counts them), the first offset above
+       `thresold` (the block's public member, 0.6) or else the best one, re-alignment by that offset; d_frames gets raw_frame_size symbols per
+       frame at frame_stride complex floats. Frames are emitted while the input holds a frame's window plus its re-alignment symbols;
+       *consumed = symbols taken out of the ring (the caller keeps the rest in front of the next call's symbols, as the ring buffer does);
+       best_pos_out (HOST, may be NULL): the offset each frame was found at (0 in lock). Returns the frames written, <0 on error. */
+    int64_t sdhip_s2_pl_sync_dev(int device, int slot_number, int pilots, float thresold, const float *d_syms, size_t nsyms, float *d_frames, int frame_stride,
+                                 size_t max_frames, size_t *consumed, int *best_pos_out);
     /* get_dvbs2_cfg's answer for a MODCOD: bits per symbol, slots per frame, dvbs2_code_rate_t, dvbs2_constellation_t */
     int sdhip_s2_cfg(int modcod, int shortframes, int *bits, int *slots, int *rate, int *constellation);
     /* dvbs2::S2Deinterleaver::deinterleave (codings/dvb-s2/s2_deinterleaver.cpp:92-145) over nframes frames of 64800 / 16200 soft bits:

@@ -459,3 +459,20 @@ class S2FrontRef:
         if r != n:
             raise RuntimeError(f"sdref_s2_bb_to_soft -> {r}")
         return out, pls
+
+
+def s2_pl_sync_ref(slot_number, pilots, thresold, syms: np.ndarray, max_frames: int = 4096):
+    """dvbs2::S2PLSyncBlock::work2 over a symbol stream (oracle/ref_wrap_dvbs2_demap.cpp): (frames complex64 [nf, raw], consumed int32 [nf], raw)."""
+    lib = C.CDLL(os.path.join(_HERE, "_ref", "libsdref_dvbs2.so"))
+    x = np.ascontiguousarray(syms, dtype=np.complex64)
+    raw = C.c_int(0)
+    cap = max_frames
+    out = np.zeros((cap, (slot_number + 1) * 90 + 36 * 64), dtype=np.complex64)
+    cons = np.zeros(cap, dtype=np.int32)
+    flat = np.zeros(cap * ((slot_number + 1) * 90 + 36 * 64), dtype=np.complex64)
+    lib.sdref_s2_pl_sync.argtypes = [C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_longlong, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    nf = lib.sdref_s2_pl_sync(int(slot_number), int(pilots), float(thresold), _p(x), len(x), _p(flat), cap, _p(cons), C.byref(raw))
+    if nf < 0:
+        raise RuntimeError(f"sdref_s2_pl_sync -> {nf}")
+    r = raw.value
+    return flat[: nf * r].reshape(nf, r).copy(), cons[:nf].copy(), r

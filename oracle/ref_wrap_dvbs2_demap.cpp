@@ -5,6 +5,7 @@
 // scratch buffer (`new int8_t[64800]`, never initialised by the reference) is zeroed so that the positions its pilots branch never
 // writes are defined.
 #include "dvbs2/dvbs2_bb_to_soft.h"
+#include "dvbs2/dvbs2_pl_sync.h"
 #include "codings/dvb-s2/modcod_to_cfg.h"
 #include <cstring>
 
@@ -41,6 +42,48 @@ extern "C"
                 for (int b = 0; b < bits; b++)
                     out[((size_t)x * resolution + y) * bits + b] = c.lut[x][y].bits[b];
         return bits;
+    }
+
+    // dvbs2::S2PLSyncBlock (dvbs2_pl_sync.{h,cpp}): the symbols go into the block's ring buffer, work2() is called for as long as the ring holds
+    // two frames' worth (it reads one frame, then up to one more frame's worth to re-align). frames_out: nframes x raw_frame_size complex
+    // floats; consumed_out[k] = symbols frame k took out of the ring (raw_frame_size + its best_pos). Returns the frames written.
+    int sdref_s2_pl_sync(int slot_number, int pilots, float thresold, const float *syms, long long nsyms, float *frames_out, int max_frames, int *consumed_out, int *raw_frame_size)
+    {
+        auto in = std::make_shared<dsp::stream<complex_t>>();
+        dvbs2::S2PLSyncBlock blk(in, slot_number, pilots);
+        blk.thresold = thresold;
+        const int raw = blk.raw_frame_size;
+        *raw_frame_size = raw;
+        const complex_t *s = (const complex_t *)syms;
+        long long fed = 0;
+        int nf = 0;
+        for (;;)
+        {
+            const int w = (int)std::min<long long>(nsyms - fed, std::min<long long>(blk.ring_buffer.getWritable(), 1 << 20));
+            if (w > 0)
+            {
+                blk.ring_buffer.write((complex_t *)s + fed, w);
+                fed += w;
+            }
+            if (blk.ring_buffer.getReadable() < 2 * raw)
+            {
+                if (fed >= nsyms)
+                    break;
+                continue;
+            }
+            if (nf >= max_frames)
+                break;
+            const int before = blk.ring_buffer.getReadable();
+            blk.work2();
+            const int got = blk.output_stream->read();
+            if (got != raw)
+                return -2;
+            memcpy(frames_out + (size_t)nf * raw * 2, blk.output_stream->readBuf, (size_t)raw * sizeof(complex_t));
+            blk.output_stream->flush();
+            consumed_out[nf] = before - blk.ring_buffer.getReadable();
+            nf++;
+        }
+        return nf;
     }
 
     // frames: nframes x frame_stride complex floats (what S2PLLBlock hands over: 90 header symbols, then the slots). out: nframes x

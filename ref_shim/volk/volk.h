@@ -58,6 +58,29 @@ static inline void volk_32fc_x2_dot_prod_32fc(lv_32fc_t *r, const lv_32fc_t *in,
     *r = lv_32fc_t(re, im);
 }
 #define volk_32fc_x2_dot_prod_32fc_a volk_32fc_x2_dot_prod_32fc
+/* element-wise complex kernels (dvbs2_pl_sync.cpp:77-78): VOLK's generic forms */
+static inline void volk_32fc_conjugate_32fc(lv_32fc_t *out, const lv_32fc_t *in, unsigned n)
+{
+    const float *a = (const float *)in;
+    float *o = (float *)out;
+    for (unsigned i = 0; i < n; i++)
+    {
+        o[2 * i] = a[2 * i];
+        o[2 * i + 1] = -a[2 * i + 1];
+    }
+}
+static inline void volk_32fc_x2_multiply_32fc(lv_32fc_t *out, const lv_32fc_t *x, const lv_32fc_t *y, unsigned n)
+{
+    const float *a = (const float *)x, *b = (const float *)y;
+    float *o = (float *)out;
+    for (unsigned i = 0; i < n; i++)
+    {
+        const float re = a[2 * i] * b[2 * i] - a[2 * i + 1] * b[2 * i + 1];
+        const float im = a[2 * i] * b[2 * i + 1] + a[2 * i + 1] * b[2 * i];
+        o[2 * i] = re;
+        o[2 * i + 1] = im;
+    }
+}
 static inline void volk_16i_s32f_convert_32f_u(float *o, const int16_t *in, float s, unsigned n)
 {
     const float is = 1.0f / s;

@@ -18,6 +18,7 @@
 #include "../../include/sdhip.h"
 #include "common.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 #include <vector>
@@ -169,6 +170,127 @@ namespace sdhip
             o[b] = l[b];
     }
 
+    // ---- PL synchroniser: dvbs2::S2PLSyncBlock::work2 (plugins/dvb_support/dvbs2/dvbs2_pl_sync.cpp:52-125) ----------------------------------------
+    // One frame's search: for every offset ss of a raw_frame_size window, the differential correlation of the 90 header symbols (conjugate
+    // of the previous symbol times the symbol: VOLK's generic conjugate / multiply, the float operations in their order) against the SOF and
+    // the PLS scrambling pattern (correlate_sof_diff / correlate_plscode_diff, :127-154), the better of the pilots-off / pilots-on sums scaled
+    // by 1 / 57, its magnitude as a double. The block walks ss upwards, keeps the running maximum among the offsets with d.imag > 0 and stops
+    // at the first one above `thresold`: = the FIRST qualifying offset above the threshold if there is one (everything in front of it is below
+    // it), else the first occurrence of the maximum (> 0), else 0. A block of 256 threads per speculated frame, a thread per offset.
+    struct PlsRes
+    {
+        int best_pos;
+    };
+    __device__ __forceinline__ void s2_hdr_corr(const float2 *w, double &difference, bool &qual)
+    {
+        const unsigned dsof = 0x18d2e82u ^ (0x18d2e82u >> 1);
+        const unsigned long long dscr = 0x719d83c953422dfaull ^ (0x719d83c953422dfaull >> 1);
+        float sr = 0.0f, si = 0.0f, pr = 0.0f, pi = 0.0f; // csof, cplsc
+        float2 prev = w[0];
+        // plheader_symbols[0] = 0 * corr[ss]: adds (or subtracts) a zero to csof -- nothing
+        for (int i = 1; i < 90; i++)
+        {
+            const float2 cur = w[i];
+            // conj(prev) * cur: (a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re) with a = (prev.x, -prev.y)
+            const float nre = -prev.y;
+            const float dre = prev.x * cur.x - nre * cur.y;
+            const float dim = prev.x * cur.y + nre * cur.x;
+            if (i < 26)
+            {
+                if (((dsof >> (25 - i)) ^ (unsigned)i) & 1u)
+                {
+                    sr += dre;
+                    si += dim;
+                }
+                else
+                {
+                    sr -= dre;
+                    si -= dim;
+                }
+            }
+            else
+            {
+                const int k = i - 26; // diffs index within the PLS field: odd ones only
+                if (k & 1)
+                {
+                    if ((dscr >> (63 - k)) & 1ull)
+                    {
+                        pr -= dre;
+                        pi -= dim;
+                    }
+                    else
+                    {
+                        pr += dre;
+                        pi += dim;
+                    }
+                }
+            }
+            prev = cur;
+        }
+        const float c0r = sr + pr, c0i = si + pi, c1r = sr - pr, c1i = si - pi;
+        const float n0 = sqrtf(c0r * c0r + c0i * c0i), n1 = sqrtf(c1r * c1r + c1i * c1i);
+        const float cr = n0 > n1 ? c0r : c1r, ci = n0 > n1 ? c0i : c1i;
+        const float sc = 1.0f / (float)(26 - 1 + 64 / 2);
+        const float dr = cr * sc, di = ci * sc;
+        difference = (double)sqrtf(dr * dr + di * di);
+        qual = di > 0.0f;
+    }
+    __global__ __launch_bounds__(256) void k_s2_plsync_search(const float2 *__restrict__ syms, long long base, int raw, int nframes, float thresold, int *best_pos)
+    {
+        const int f = (int)blockIdx.x;
+        if (f >= nframes)
+            return;
+        const float2 *win = syms + base + (long long)f * raw;
+        const int nss = raw - 90;
+        int first_over = 0x7fffffff, arg = 0x7fffffff;
+        double best = 0.0;
+        for (int ss = (int)threadIdx.x; ss < nss; ss += 256)
+        {
+            double d;
+            bool q;
+            s2_hdr_corr(win + ss, d, q);
+            if (!q)
+                continue;
+            if (d > (double)thresold && ss < first_over)
+                first_over = ss;
+            if (d > best) // this thread's offsets ascend: strict > keeps the first occurrence
+            {
+                best = d;
+                arg = ss;
+            }
+        }
+        __shared__ int s_first[256], s_arg[256];
+        __shared__ double s_best[256];
+        s_first[threadIdx.x] = first_over;
+        s_arg[threadIdx.x] = arg;
+        s_best[threadIdx.x] = best;
+        __syncthreads();
+        for (int st = 128; st > 0; st >>= 1)
+        {
+            if ((int)threadIdx.x < st)
+            {
+                const int o = (int)threadIdx.x + st;
+                if (s_first[o] < s_first[threadIdx.x])
+                    s_first[threadIdx.x] = s_first[o];
+                if (s_best[o] > s_best[threadIdx.x] || (s_best[o] == s_best[threadIdx.x] && s_arg[o] < s_arg[threadIdx.x]))
+                {
+                    s_best[threadIdx.x] = s_best[o];
+                    s_arg[threadIdx.x] = s_arg[o];
+                }
+            }
+            __syncthreads();
+        }
+        if (threadIdx.x == 0)
+            best_pos[f] = s_first[0] != 0x7fffffff ? s_first[0] : (s_best[0] > 0.0 ? s_arg[0] : 0);
+    }
+    // frame k of the output = raw symbols from starts[k]
+    __global__ __launch_bounds__(256) void k_s2_plsync_emit(const float2 *__restrict__ syms, const long long *__restrict__ starts, int raw, int nframes, float2 *out, int stride)
+    {
+        const int f = (int)blockIdx.y, i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+        if (f < nframes && i < raw)
+            out[(size_t)f * stride + i] = syms[starts[f] + i];
+    }
+
     struct S2DemapCache
     {
         DevBuf<unsigned long long> d_cw;
@@ -261,6 +383,98 @@ extern "C"
         if (sdhip_s2_deinterleave_dev(device, c.constellation, shortframes ? 1 : 0, c.rate, reinterpret_cast<const int8_t *>(T.d_slots.p), d_soft, nframes) != 0)
             return -1;
         return (int)frame_soft;
+        SD_GUARD_END(-1)
+    }
+    int64_t sdhip_s2_pl_sync_dev(int device, int slot_number, int pilots, float thresold, const float *d_syms, size_t nsyms, float *d_frames, int frame_stride,
+                                 size_t max_frames, size_t *consumed, int *best_pos_out)
+    {
+        SD_GUARD_BEGIN
+        if (slot_number <= 0 || slot_number > 360)
+            throw HipError("dvbs2 pl_sync: slot_number out of range");
+        // S2PLSyncBlock's constructor, dvbs2_pl_sync.cpp:12-30
+        int raw = (slot_number + 1) * 90;
+        if (pilots)
+        {
+            int raw_size = (raw - 90) / 90, pilot_cnt = 1;
+            raw_size -= 16;
+            while (raw_size > 16)
+            {
+                raw_size -= 16;
+                pilot_cnt++;
+            }
+            raw += pilot_cnt * 36;
+        }
+        if (frame_stride < raw)
+            throw HipError("dvbs2 pl_sync: frame_stride shorter than the raw frame");
+        if (consumed)
+            *consumed = 0;
+        SD_HIP(hipSetDevice(device));
+        const float2 *sy = reinterpret_cast<const float2 *>(d_syms);
+        // Speculate-and-certify over the frame chain: frame k's window starts where frame k-1's ended (raw + its best_pos further). In lock every
+        // best_pos is 0, so the windows of a whole batch are known in advance: search them all in one launch, accept the run of zeros and the first
+        // frame behind it, continue from there. After a miss the next launch speculates on fewer frames (a stream of noise costs a launch per
+        // frame either way).
+        std::vector<long long> starts;
+        std::vector<int> bps;
+        DevBuf<int> d_bp;
+        std::vector<int> h_bp;
+        long long pos = 0; // read position of the block's ring buffer
+        size_t spec = 64;
+        while (starts.size() < max_frames)
+        {
+            const long long avail = (long long)nsyms - pos;
+            long long can = avail / raw; // frames whose WINDOW is there
+            if (can <= 0)
+                break;
+            const size_t nspec = (size_t)std::min<long long>(std::min<long long>(can, (long long)spec), (long long)(max_frames - starts.size()));
+            d_bp.reserve(nspec);
+            h_bp.resize(nspec);
+            {
+                ProfScope _ps("k_s2_plsync_search", nullptr);
+                hipLaunchKernelGGL(k_s2_plsync_search, dim3((unsigned)nspec), dim3(256), 0, nullptr, sy, pos, raw, (int)nspec, thresold, d_bp.p);
+            }
+            SD_HIP(hipMemcpy(h_bp.data(), d_bp.p, nspec * sizeof(int), hipMemcpyDeviceToHost));
+            size_t k = 0;
+            bool stop = false;
+            for (; k < nspec; k++)
+            {
+                const int bp = h_bp[k];
+                // work2 reads the frame, then best_pos more symbols to re-align (:112-118): both must be there
+                if (pos + raw + bp > (long long)nsyms)
+                {
+                    stop = true;
+                    break;
+                }
+                starts.push_back(pos + bp);
+                bps.push_back(bp);
+                pos += raw + bp;
+                if (bp != 0)
+                {
+                    k++;
+                    break; // the windows behind this frame were speculated at the wrong place
+                }
+            }
+            if (stop)
+                break;
+            spec = (k == nspec) ? std::min<size_t>(spec * 2, 4096) : 8;
+        }
+        const size_t nf = starts.size();
+        if (nf > 0)
+        {
+            DevBuf<long long> d_st;
+            d_st.reserve(nf);
+            SD_HIP(hipMemcpy(d_st.p, starts.data(), nf * sizeof(long long), hipMemcpyHostToDevice));
+            ProfScope _ps("k_s2_plsync_emit", nullptr);
+            hipLaunchKernelGGL(k_s2_plsync_emit, dim3((unsigned)((raw + 255) / 256), (unsigned)nf), dim3(256), 0, nullptr, sy, d_st.p, raw, (int)nf,
+                               reinterpret_cast<float2 *>(d_frames), frame_stride);
+            SD_HIP(hipDeviceSynchronize());
+        }
+        if (consumed)
+            *consumed = (size_t)pos;
+        if (best_pos_out)
+            for (size_t k = 0; k < nf; k++)
+                best_pos_out[k] = bps[k];
+        return (int64_t)nf;
         SD_GUARD_END(-1)
     }
     int sdhip_s2_cfg(int modcod, int shortframes, int *bits, int *slots, int *rate, int *constellation)

@@ -104,3 +104,43 @@ def plframes(slots: int, pls_index: int, nframes: int, seed: int, flips: int = 3
         sym = sym + 0.05 * (rng.standard_normal(64) + 1j * rng.standard_normal(64))
         fr[f, 26:90] = sym.astype(np.complex64)
     return fr
+
+
+def sof_symbols() -> np.ndarray:
+    """The 26 pi/2-BPSK symbols of the start-of-frame field 0x18D2E82 (ETSI EN 302 307-1 5.5.2.1; dvbs2/s2_defs.h:16-36)."""
+    value = 0x18d2e82
+    s = np.arange(26)
+    bit = (value >> (25 - s)) & 1
+    angle = bit * 2 + (s & 1)
+    return np.exp(1j * (np.pi / 4 + 2 * np.pi * angle / 4))
+
+
+def pls_symbols(index: int) -> np.ndarray:
+    """The 64 pi/2-BPSK symbols of PLS code word `index` (dvbs2/s2_defs.h:74-80)."""
+    cw = int(pls_codewords()[index])
+    i = np.arange(64)
+    yi = np.array([(cw >> (63 - k)) & 1 for k in range(64)])
+    nyi = yi ^ (i & 1)
+    return ((1 - 2 * nyi) + 1j * (1 - 2 * yi)) / np.sqrt(2.0)
+
+
+def pl_stream(raw_frame_size: int, pls_index: int, nframes: int, seed: int, lead: int = 1234, glitches=(), esn0_db: float = 12.0, cfo: float = 0.002,
+              amplitude: float = 0.6):
+    """A clock-recovered symbol stream for the PL synchroniser: `lead` noise symbols, then `nframes` PLFRAMEs of raw_frame_size symbols back to
+    back (true SOF + PLS header, random QPSK data), with `glitches` = {frame index: extra symbols inserted in front of that frame} (a slip the
+    synchroniser has to find again), a slow rotation (cfo, rad / symbol) and noise. complex64."""
+    rng = np.random.default_rng(seed)
+    hdr = np.concatenate([sof_symbols(), pls_symbols(pls_index)])
+    parts = [(rng.standard_normal(lead) + 1j * rng.standard_normal(lead)) * 0.5]
+    g = dict(glitches)
+    for f in range(nframes):
+        if f in g:
+            parts.append(np.exp(1j * np.pi / 4 * (2 * rng.integers(0, 4, g[f]) + 1)))
+        data = np.exp(1j * np.pi / 4 * (2 * rng.integers(0, 4, raw_frame_size - 90) + 1))
+        parts.append(np.concatenate([hdr, data]))
+    x = np.concatenate(parts)
+    n = len(x)
+    x = x * np.exp(1j * (cfo * np.arange(n) + 0.7))
+    sigma = np.sqrt(1.0 / (2.0 * 10 ** (esn0_db / 10)))
+    x = (x + sigma * (rng.standard_normal(n) + 1j * rng.standard_normal(n))) * amplitude
+    return x.astype(np.complex64)

@@ -255,6 +255,67 @@ def test_bb_to_soft(capi, modcod, short, pilots):
     check_bb_to_soft(capi, to_dev, lambda d: d[0].cpu().numpy(), zeros_dev, modcod, short, pilots)
 
 
+PLSYNC = [(90, 0, "slips"), (60, 1, "slips"), (45, 0, "locked"), (90, 0, "noise"), (360, 0, "slips")]
+
+
+def check_pl_sync(capi, to_dev, from_dev, zeros_dev, slots, pilots, kind):
+    """sdhip_s2_pl_sync_dev == dvbs2::S2PLSyncBlock::work2 frame by frame (the reference block fed through its own ring buffer): a stream that starts
+    in noise, frames back to back, symbols slipped in front of two of them; a stream already in lock; noise alone (every frame re-aligns somewhere).
+    Same frames, same number of symbols taken per frame. (The reference driver only calls work2 while its ring holds two frames' worth, the
+    entry point emits while a frame and its re-alignment symbols are there: it may deliver one or two frames more at the end of the input.)"""
+    import ctypes as C
+    from tests import dvbs2_util
+    if not pyref.S2FrontRef.available() or not hasattr(C.CDLL(pyref.os.path.join(pyref._HERE, "_ref", "libsdref_dvbs2.so")), "sdref_s2_pl_sync"):
+        pytest.skip("oracle/_ref/libsdref_dvbs2.so without the PL sync entry (rebuild with the reference tree)")
+    probe = np.zeros(8, dtype=np.complex64)
+    _, _, raw = pyref.s2_pl_sync_ref(slots, pilots, 0.6, probe, max_frames=1)
+    nfr = 10 if slots < 360 else 5
+    if kind == "slips":
+        x = dvbs2_util.pl_stream(raw, (6 << 2) | pilots, nfr, seed=slots + pilots, lead=1234, glitches={3: 17, 6: raw // 2 + 5})
+    elif kind == "locked":
+        x = dvbs2_util.pl_stream(raw, (20 << 2) | 2, nfr, seed=9, lead=0)
+    else:
+        rng = np.random.default_rng(4)
+        x = ((rng.standard_normal(nfr * raw) + 1j * rng.standard_normal(nfr * raw)) * 0.4).astype(np.complex64)
+    want, wcons, _ = pyref.s2_pl_sync_ref(slots, pilots, 0.6, x)
+    assert len(want) >= (3 if kind == "noise" else nfr - 3)  # in noise every frame re-aligns by up to a frame: about half as many come out
+    d_x = to_dev(x.view(np.float32))
+    cap = len(x) // raw + 2
+    stride = raw + 6
+    d_fr = zeros_dev(cap * stride * 2, np.float32)
+    consumed = C.c_size_t(0)
+    bp = np.full(cap, -1, dtype=np.int32)
+    nf = capi.lib().sdhip_s2_pl_sync_dev(0, slots, pilots, 0.6, C.c_void_p(d_x[1]), len(x), C.c_void_p(d_fr[1]), stride, cap, C.byref(consumed), bp.ctypes.data_as(C.c_void_p))
+    assert nf >= len(want), (nf, len(want), capi.last_error())
+    got = from_dev(d_fr).view(np.complex64).reshape(cap, stride)[:nf, :raw]
+    assert np.array_equal(bp[:len(want)] + raw, wcons), (bp[:nf].tolist(), (wcons - raw).tolist())
+    assert np.array_equal(got[:len(want)].view(np.uint32), want.view(np.uint32))
+    assert consumed.value == int(np.sum(bp[:nf] + raw)) and consumed.value <= len(x)
+    if kind == "locked":
+        assert np.all(bp[:nf] == 0)
+    if kind == "slips":
+        assert bp[0] == 1234 and bp[3] == 17 and bp[6] == raw // 2 + 5 and np.count_nonzero(bp[:nf]) == 3
+    # max_frames is honoured and the call is restartable where it stopped
+    d_fr2 = zeros_dev(cap * stride * 2, np.float32)
+    nf2 = capi.lib().sdhip_s2_pl_sync_dev(0, slots, pilots, 0.6, C.c_void_p(d_x[1]), len(x), C.c_void_p(d_fr2[1]), stride, 2, C.byref(consumed), None)
+    assert nf2 == 2 and consumed.value == int(np.sum(bp[:2] + raw))
+
+
+@pytest.mark.parametrize("slots,pilots,kind", PLSYNC)
+def test_pl_sync(capi, slots, pilots, kind):
+    import torch
+
+    def to_dev(a):
+        t = torch.from_numpy(np.ascontiguousarray(a)).cuda()
+        return (t, t.data_ptr())
+
+    def zeros_dev(n, dt):
+        t = torch.zeros(n, dtype={np.int8: torch.int8, np.int32: torch.int32, np.float32: torch.float32}[dt], device="cuda")
+        return (t, t.data_ptr())
+
+    check_pl_sync(capi, to_dev, lambda d: d[0].cpu().numpy(), zeros_dev, slots, pilots, kind)
+
+
 def check_bb_to_soft_golden(capi, to_dev, from_dev, zeros_dev):
     """The committed fixture tests/golden/s2_bb_to_soft.npz (written by make_golden.py from the compiled reference): stored PLFRAMEs and the
     reference's demapper table -> its PLS indices and soft bits, byte for byte. Needs no reference build at run time."""

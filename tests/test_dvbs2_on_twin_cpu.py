@@ -102,6 +102,19 @@ def test_bb_to_soft_on_the_twin(capi, modcod, short, pilots):
     G.check_bb_to_soft(capi, to_dev, lambda d: d[0], zeros_dev, modcod, short, pilots, nframes=3)
 
 
+@pytest.mark.parametrize("slots,pilots,kind", [(90, 0, "slips"), (60, 1, "slips"), (45, 0, "locked"), (90, 0, "noise")])
+def test_pl_sync_on_the_twin(capi, slots, pilots, kind):
+    def to_dev(a):
+        a = np.ascontiguousarray(a)
+        return (a, a.ctypes.data)
+
+    def zeros_dev(n, dt):
+        a = np.zeros(n, dtype=dt)
+        return (a, a.ctypes.data)
+
+    G.check_pl_sync(capi, to_dev, lambda d: d[0], zeros_dev, slots, pilots, kind)
+
+
 def test_bb_to_soft_golden_on_the_twin(capi):
     def to_dev(a):
         a = np.ascontiguousarray(a)
