@@ -359,6 +359,19 @@ extern "C"
        best_pos_out (HOST, may be NULL): the offset each frame was found at (0 in lock). Returns the frames written, <0 on error. */
     int64_t sdhip_s2_pl_sync_dev(int device, int slot_number, int pilots, float thresold, const float *d_syms, size_t nsyms, float *d_frames, int frame_stride,
                                  size_t max_frames, size_t *consumed, int *best_pos_out);
+    /* dvbs2::S2PLLBlock::work (plugins/dvb_support/dvbs2/dvbs2_pll.cpp:20-66) over nframes synchronised frames (device, frame_stride complex floats
+       each, as sdhip_s2_pl_sync_dev writes them): the frame PLL, one sequential loop over every symbol with its state carried across frames and
+       calls -- state2 (HOST, in / out) = {phase, freq}, both 0 for a new stream. Header symbols: phase error against the known SOF / PLS
+       symbols of the CONFIGURED modcod / shortframes / pilots (pls_code, module_dvbs2_demod.cpp:117), output as the block's "45 degree BPSK";
+       behind the header: the demapper table's phase_error entries -- lut_phase_error (HOST): constellation_t::make_lut(lut_resolution)'s
+       [x][y].phase_error floats, the caller's data like sdhip_s2_bb_to_soft_dev's bits. With pilots the block walks (slots + 1) * 90 + 36
+       symbols (it counts one pilot block, dvbs2_pll.h:33-47) and leaves the rest of the frame unwritten: d_frames_out gets exactly what the
+       block writes. Exact arithmetic only (glibc's sinf / cosf / atan2f restated), one lane: the loop is a serial chain. Returns the symbols
+       walked per frame, <0 on error. */
+    int sdhip_s2_pll_dev(int device, int modcod, int shortframes, int pilots, float loop_bw, const float *d_frames_in, float *d_frames_out, int frame_stride, int nframes,
+                         const float *lut_phase_error, int lut_resolution, float *state2);
+    /* unit entry: d_out[i] = atan2f(d_y[i], d_x[i]) as the frame PLL evaluates it (glibc 2.35's float code restated) */
+    int sdhip_op_atan2f(int device, const float *d_y, const float *d_x, int n, float *d_out);
     /* get_dvbs2_cfg's answer for a MODCOD: bits per symbol, slots per frame, dvbs2_code_rate_t, dvbs2_constellation_t */
     int sdhip_s2_cfg(int modcod, int shortframes, int *bits, int *slots, int *rate, int *constellation);
     /* dvbs2::S2Deinterleaver::deinterleave (codings/dvb-s2/s2_deinterleaver.cpp:92-145) over nframes frames of 64800 / 16200 soft bits:

@@ -476,3 +476,24 @@ def s2_pl_sync_ref(slot_number, pilots, thresold, syms: np.ndarray, max_frames: 
         raise RuntimeError(f"sdref_s2_pl_sync -> {nf}")
     r = raw.value
     return flat[: nf * r].reshape(nf, r).copy(), cons[:nf].copy(), r
+
+
+def s2_pll_ref(modcod, shortframes, pilots, loop_bw, frames: np.ndarray):
+    """dvbs2::S2PLLBlock over synchronised frames (oracle/ref_wrap_dvbs2_demap.cpp): (frames out complex64 -- only the first `walked` symbols of each
+    row are the block's --, walked, (phase, freq))."""
+    lib = C.CDLL(os.path.join(_HERE, "_ref", "libsdref_dvbs2.so"))
+    f = np.ascontiguousarray(frames, dtype=np.complex64)
+    out = np.zeros_like(f)
+    st = np.zeros(2, dtype=np.float32)
+    lib.sdref_s2_pll.argtypes = [C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    w = lib.sdref_s2_pll(int(modcod), int(shortframes), int(pilots), float(loop_bw), _p(f), f.shape[1], len(f), _p(out), _p(st))
+    if w < 0:
+        raise RuntimeError(f"sdref_s2_pll -> {w}")
+    return out, w, st
+
+
+def s2_lut_phase_ref(modcod, shortframes, resolution=256) -> np.ndarray:
+    lib = C.CDLL(os.path.join(_HERE, "_ref", "libsdref_dvbs2.so"))
+    out = np.zeros((resolution, resolution), dtype=np.float32)
+    lib.sdref_s2_lut_phase(int(modcod), int(shortframes), int(resolution), _p(out))
+    return out

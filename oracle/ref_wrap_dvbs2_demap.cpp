@@ -6,6 +6,7 @@
 // writes are defined.
 #include "dvbs2/dvbs2_bb_to_soft.h"
 #include "dvbs2/dvbs2_pl_sync.h"
+#include "dvbs2/dvbs2_pll.h"
 #include "codings/dvb-s2/modcod_to_cfg.h"
 #include <cstring>
 
@@ -42,6 +43,57 @@ extern "C"
                 for (int b = 0; b < bits; b++)
                     out[((size_t)x * resolution + y) * bits + b] = c.lut[x][y].bits[b];
         return bits;
+    }
+
+    // the host libm's atan2f, element-wise (what complex_t::arg() calls): the yardstick of the device restatement
+    int sdref_atan2f(const float *y, const float *x, int n, float *out)
+    {
+        for (int i = 0; i < n; i++)
+            out[i] = atan2f(y[i], x[i]);
+        return 0;
+    }
+
+    // the demapper table's phase errors: constellation_t::make_lut(resolution)'s [x][y].phase_error
+    int sdref_s2_lut_phase(int modcod, int shortframes, int resolution, float *out)
+    {
+        auto cfg = dvbs2::get_dvbs2_cfg(modcod, shortframes, false);
+        dsp::constellation_t c(cfg.constel_obj_type, cfg.g1, cfg.g2);
+        c.make_lut(resolution);
+        for (int x = 0; x < resolution; x++)
+            for (int y = 0; y < resolution; y++)
+                out[(size_t)x * resolution + y] = c.lut[x][y].phase_error;
+        return 0;
+    }
+
+    // dvbs2::S2PLLBlock (dvbs2_pll.{h,cpp}) as DVBS2DemodModule::init sets it up (module_dvbs2_demod.cpp:111-118), one work() per frame through its
+    // own streams. frames: nframes x frame_stride complex floats in, the same layout out (only the symbols the block writes are copied:
+    // the return value per frame). state_out = {phase, freq} behind the last frame.
+    int sdref_s2_pll(int modcod, int shortframes, int pilots, float loop_bw, const float *frames, int frame_stride, int nframes, float *out, float *state_out)
+    {
+        auto cfg = dvbs2::get_dvbs2_cfg(modcod, shortframes, pilots);
+        auto in = std::make_shared<dsp::stream<complex_t>>();
+        dvbs2::S2PLLBlock blk(in, loop_bw);
+        blk.pilots = pilots;
+        blk.constellation = std::make_shared<dsp::constellation_t>(cfg.constel_obj_type, cfg.g1, cfg.g2);
+        blk.constellation->make_lut(256);
+        blk.frame_slot_count = cfg.frame_slot_count;
+        blk.pls_code = modcod << 2 | shortframes << 1 | pilots;
+        blk.update();
+        const int walked = (cfg.frame_slot_count + 1) * 90 + blk.pilot_cnt * 36;
+        for (int f = 0; f < nframes; f++)
+        {
+            memcpy(in->writeBuf, frames + (size_t)f * frame_stride * 2, (size_t)frame_stride * sizeof(complex_t));
+            in->swap(frame_stride);
+            blk.work();
+            const int got = blk.output_stream->read();
+            if (got != frame_stride)
+                return -2;
+            memcpy(out + (size_t)f * frame_stride * 2, blk.output_stream->readBuf, (size_t)walked * sizeof(complex_t));
+            blk.output_stream->flush();
+        }
+        state_out[0] = blk.phase;
+        state_out[1] = blk.freq;
+        return walked;
     }
 
     // dvbs2::S2PLSyncBlock (dvbs2_pl_sync.{h,cpp}): the symbols go into the block's ring buffer, work2() is called for as long as the ring holds

@@ -165,6 +165,8 @@ def lib():
         if hasattr(L, "sdhip_s2_bb_to_soft_dev"):
             L.sdhip_s2_bb_to_soft_dev.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
             L.sdhip_s2_cfg.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+            L.sdhip_s2_pll_dev.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+            L.sdhip_op_atan2f.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
             L.sdhip_s2_pl_sync_dev.restype = C.c_int64
             L.sdhip_s2_pl_sync_dev.argtypes = [C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int, C.c_size_t, C.c_void_p, C.c_void_p]
         L.sdhip_prof_enable.argtypes = [C.c_int]

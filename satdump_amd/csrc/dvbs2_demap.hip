@@ -291,6 +291,199 @@ namespace sdhip
             out[(size_t)f * stride + i] = syms[starts[f] + i];
     }
 
+    // ---- frame PLL: dvbs2::S2PLLBlock::work (plugins/dvb_support/dvbs2/dvbs2_pll.cpp:20-66) -----------------------------------------------------
+    // A second-order loop over EVERY symbol of the synchronised frames, its state carried from frame to frame: rotate by (cosf(-phase),
+    // sinf(-phase)); phase error = arg(symbol * conj(known symbol)) on the 90 header symbols (SOF, then the PLS code word of the configured
+    // MODCOD), the demapper table's phase_error entry on everything behind; header symbols leave as "proper 45 degree BPSK". One sequential
+    // lane, every float operation where the reference has it: glibc 2.35's sinf / cosf (the evaluation demod_kernels.hip carries, copied
+    // below) and its atan2f / atanf (fdlibm's float code -- this restatement equals the host libm's results on 6e7 random arguments,
+    // special values included: tests/test_dvbs2_pll_math_cpu.py). With pilots the block counts ONE pilot block (update(), dvbs2_pll.h:33-47:
+    // it divides the slot count by 90 where the symbol count is meant) and leaves the rest of the frame untouched: so does this.
+    __device__ __forceinline__ unsigned s2_abstop12(float x) { return (__float_as_uint(x) >> 20) & 0x7ffu; }
+    __device__ __forceinline__ void s2_sincosf(float y, float &sn, float &cs)
+    { // = sdhip::sd_sincosf (demod_kernels.hip): sinf(y), cosf(y) of glibc, one reduction
+        const double x0 = (double)y;
+        const double hpi_inv = 0x1.45F306DC9C883p+23, hpi = 0x1.921FB54442D18p0;
+        const double r = x0 * hpi_inv;
+        const int n = ((int)r + 0x800000) >> 24;
+        const double xr = fma(-(double)n, hpi, x0);
+        const double xs = ((n + 1) & 2) ? -xr : xr;
+        const double x2 = xr * xr;
+        const double s1c = -0x1.555545995a603p-3, s2c = 0x1.1107605230bc4p-7, s3c = -0x1.994eb3774cf24p-13;
+        const double x3 = xs * x2;
+        const double s1 = fma(x2, s3c, s2c);
+        const double x7 = x3 * x2;
+        const double sp = fma(x7, s1, fma(x3, s1c, xs));
+        const double c1c = -0x1.ffffffd0c621cp-2, c2c = 0x1.55553e1068f19p-5, c3c = -0x1.6c087e89a359dp-10, c4c = 0x1.99343027bf8c3p-16;
+        const double x4 = x2 * x2;
+        const double c2 = fma(x2, c4c, c3c);
+        const double c1 = fma(x2, c1c, 0x1p0);
+        const double x6 = x4 * x2;
+        const double cp0 = fma(x6, c2, fma(x4, c2c, c1));
+        const float fs = (float)sp, fc0 = (float)cp0;
+        const float fc = (n & 2) ? -fc0 : fc0;
+        const bool odd = (n & 1) != 0;
+        const bool tiny = s2_abstop12(y) < s2_abstop12(0x1p-12f);
+        sn = tiny ? y : (odd ? fc : fs);
+        cs = tiny ? 1.0f : (odd ? fs : fc);
+    }
+    __device__ __forceinline__ float s2_atanf(float x)
+    { // glibc 2.35 sysdeps/ieee754/flt-32/s_atanf.c (fdlibm): argument reduction to one of four intervals, odd polynomial of degree 11 in x^2
+        const float atanhi[4] = {4.6364760399e-01f, 7.8539812565e-01f, 9.8279368877e-01f, 1.5707962513e+00f};
+        const float atanlo[4] = {5.0121582440e-09f, 3.7748947079e-08f, 3.4473217170e-08f, 7.5497894159e-08f};
+        const float aT[11] = {3.3333334327e-01f, -2.0000000298e-01f, 1.4285714924e-01f, -1.1111110449e-01f, 9.0908870101e-02f, -7.6918758452e-02f,
+                              6.6610731184e-02f, -5.8335702866e-02f, 4.9768779427e-02f, -3.6531571299e-02f, 1.6285819933e-02f};
+        const int hx = (int)__float_as_uint(x), ix = hx & 0x7fffffff;
+        int id;
+        if (ix >= 0x4c000000)
+        {
+            if (ix > 0x7f800000)
+                return x + x;
+            return hx > 0 ? atanhi[3] + atanlo[3] : -atanhi[3] - atanlo[3];
+        }
+        if (ix < 0x3ee00000)
+        {
+            if (ix < 0x31000000)
+                return x; // (huge + x > one: raises inexact, returns x)
+            id = -1;
+        }
+        else
+        {
+            x = fabsf(x);
+            if (ix < 0x3f980000)
+            {
+                if (ix < 0x3f300000)
+                {
+                    id = 0;
+                    x = (2.0f * x - 1.0f) / (2.0f + x);
+                }
+                else
+                {
+                    id = 1;
+                    x = (x - 1.0f) / (x + 1.0f);
+                }
+            }
+            else if (ix < 0x401c0000)
+            {
+                id = 2;
+                x = (x - 1.5f) / (1.0f + 1.5f * x);
+            }
+            else
+            {
+                id = 3;
+                x = -1.0f / x;
+            }
+        }
+        const float z = x * x, w = z * z;
+        const float s1 = z * (aT[0] + w * (aT[2] + w * (aT[4] + w * (aT[6] + w * (aT[8] + w * aT[10])))));
+        const float s2 = w * (aT[1] + w * (aT[3] + w * (aT[5] + w * (aT[7] + w * aT[9]))));
+        if (id < 0)
+            return x - x * (s1 + s2);
+        const float r = atanhi[id] - ((x * (s1 + s2) - atanlo[id]) - x);
+        return hx < 0 ? -r : r;
+    }
+    __device__ __forceinline__ float s2_atan2f(float y, float x)
+    { // glibc 2.35 sysdeps/ieee754/flt-32/e_atan2f.c (fdlibm)
+        const float tiny = 1.0e-30f, pi_o_4 = 7.8539818525e-01f, pi_o_2 = 1.5707963705e+00f, pi = 3.1415927410e+00f, pi_lo = -8.7422776573e-08f;
+        const int hx = (int)__float_as_uint(x), ix = hx & 0x7fffffff, hy = (int)__float_as_uint(y), iy = hy & 0x7fffffff;
+        if (ix > 0x7f800000 || iy > 0x7f800000)
+            return x + y;
+        if (hx == 0x3f800000)
+            return s2_atanf(y);
+        const int m = ((hy >> 31) & 1) | ((hx >> 30) & 2);
+        if (iy == 0)
+            return m < 2 ? y : (m == 2 ? pi + tiny : -pi - tiny);
+        if (ix == 0)
+            return hy < 0 ? -pi_o_2 - tiny : pi_o_2 + tiny;
+        if (ix == 0x7f800000)
+        {
+            if (iy == 0x7f800000)
+                return m == 0 ? pi_o_4 + tiny : (m == 1 ? -pi_o_4 - tiny : (m == 2 ? 3.0f * pi_o_4 + tiny : -3.0f * pi_o_4 - tiny));
+            return m == 0 ? 0.0f : (m == 1 ? -0.0f : (m == 2 ? pi + tiny : -pi - tiny));
+        }
+        if (iy == 0x7f800000)
+            return hy < 0 ? -pi_o_2 - tiny : pi_o_2 + tiny;
+        const int k = (iy - ix) >> 23;
+        float z;
+        if (k > 60)
+            z = pi_o_2 + 0.5f * pi_lo;
+        else if (hx < 0 && k < -60)
+            z = 0.0f;
+        else
+            z = s2_atanf(fabsf(y / x));
+        if (m == 0)
+            return z;
+        if (m == 1)
+            return __uint_as_float(__float_as_uint(z) ^ 0x80000000u);
+        if (m == 2)
+            return pi - (z - pi_lo);
+        return (z - pi_lo) - pi;
+    }
+    // unit test hook of the two functions above (host twin and GPU): out[i] = atan2f(y[i], x[i])
+    __global__ void k_s2_atan2f(const float *y, const float *x, int n, float *out)
+    {
+        const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+        if (i < n)
+            out[i] = s2_atan2f(y[i], x[i]);
+    }
+    struct S2PllState
+    {
+        float phase, freq;
+    };
+    __global__ __launch_bounds__(64) void k_s2_pll_seq(const float2 *__restrict__ in, float2 *__restrict__ out, int stride, int nframes, int per_frame, float alpha, float beta,
+                                                       const float2 *__restrict__ hdr /* 90 known header symbols */, const float *__restrict__ lut_err, int res,
+                                                       S2PllState *state)
+    {
+        if (blockIdx.x != 0 || threadIdx.x != 0)
+            return;
+        float phase = state->phase, freq = state->freq;
+        for (int f = 0; f < nframes; f++)
+        {
+            const float2 *x = in + (size_t)f * stride;
+            float2 *o = out + (size_t)f * stride;
+            for (int i = 0; i < per_frame; i++)
+            {
+                float sn, cs;
+                s2_sincosf(-phase, sn, cs);
+                const float2 v = x[i];
+                const float tr = (v.x * cs) - (v.y * sn);
+                const float ti = (v.y * cs) + (v.x * sn);
+                float error;
+                if (i >= 90)
+                { // constellation->demod_soft_lut(tmp_val, nullptr, &error), constellation.cpp:324-352
+                    int ix = (int)(((double)tr / 1.5) * (double)res + (double)(res / 2));
+                    int iy = (int)(((double)ti / 1.5) * (double)res + (double)(res / 2));
+                    ix = ix < 0 ? 0 : (ix >= res ? res - 1 : ix);
+                    iy = iy < 0 ? 0 : (iy >= res ? res - 1 : iy);
+                    error = lut_err[(size_t)ix * res + iy];
+                    o[i] = make_float2(tr, ti);
+                }
+                else
+                { // (tmp_val * known.conj()).arg(): (a.re * b.re - a.im * b.im, a.im * b.re + a.re * b.im) with b = (k.x, -k.y)
+                    const float2 k = hdr[i];
+                    const float nb = -k.y;
+                    const float pr = (tr * k.x) - (ti * nb);
+                    const float pim = (ti * k.x) + (tr * nb);
+                    error = s2_atan2f(pim, pr);
+                    o[i] = (i & 1) ? make_float2(-tr, ti) : make_float2(ti, tr);
+                }
+                freq = freq + beta * error;
+                phase = phase + (freq + alpha * error);
+                // while (phase > 2 pi) phase -= 2 pi; while (phase < -2 pi) phase += 2 pi: float compared with the double constant, the step in double
+                while ((double)phase > 2.0 * 3.14159265358979323846)
+                    phase = (float)((double)phase - 2.0 * 3.14159265358979323846);
+                while ((double)phase < -2.0 * 3.14159265358979323846)
+                    phase = (float)((double)phase + 2.0 * 3.14159265358979323846);
+                if (freq > 1.0f)
+                    freq = 1.0f;
+                if (freq < -1.0f)
+                    freq = -1.0f;
+            }
+        }
+        state->phase = phase;
+        state->freq = freq;
+    }
+
     struct S2DemapCache
     {
         DevBuf<unsigned long long> d_cw;
@@ -475,6 +668,84 @@ extern "C"
             for (size_t k = 0; k < nf; k++)
                 best_pos_out[k] = bps[k];
         return (int64_t)nf;
+        SD_GUARD_END(-1)
+    }
+    int sdhip_s2_pll_dev(int device, int modcod, int shortframes, int pilots, float loop_bw, const float *d_frames_in, float *d_frames_out, int frame_stride, int nframes,
+                         const float *lut_phase_error, int lut_resolution, float *state2)
+    {
+        SD_GUARD_BEGIN
+        const S2Cfg c = s2_cfg_of(modcod, shortframes ? 1 : 0);
+        if (!lut_phase_error || lut_resolution < 2 || lut_resolution > 4096 || !state2)
+            throw HipError("dvbs2 pll: the demapper table's phase errors and the loop state must be handed over");
+        // S2PLLBlock::update(), dvbs2_pll.h:33-47 (frame_slot_count is the SLOT count: the loop below it never runs, one pilot block is counted)
+        int pilot_cnt = 0;
+        if (pilots)
+        {
+            int raw_size = (c.slots - 90) / 90;
+            pilot_cnt = 1;
+            raw_size -= 16;
+            while (raw_size > 16)
+            {
+                raw_size -= 16;
+                pilot_cnt++;
+            }
+        }
+        const int per_frame = (c.slots + 1) * 90 + pilot_cnt * 36;
+        if (frame_stride < per_frame)
+            throw HipError("dvbs2 pll: frame_stride shorter than the symbols the loop walks");
+        if (nframes <= 0)
+            return 0;
+        SD_HIP(hipSetDevice(device));
+        // loop gains, dvbs2_pll.cpp:8-12 (the Costas block's expression)
+        const float damping = sqrtf(2.0f) / 2.0f;
+        const float denom = (float)(1.0 + 2.0 * damping * loop_bw + loop_bw * loop_bw);
+        const float alpha = (4 * damping * loop_bw) / denom, beta = (4 * loop_bw * loop_bw) / denom;
+        // known header: s2_sof / s2_plscodes symbols (dvbs2/s2_defs.h:16-36, 74-80), computed with the host's cosf / sinf / sqrtf like the reference's tables
+        float2 hdr[90];
+        for (int s = 0; s < 26; s++)
+        {
+            const bool bit = (0x18d2e82u >> (25 - s)) & 1u;
+            const int angle = bit * 2 + (s & 1);
+            hdr[s].x = 1 * cosf(M_PI / 4 + 2 * M_PI * angle / 4);
+            hdr[s].y = 1 * sinf(M_PI / 4 + 2 * M_PI * angle / 4);
+        }
+        unsigned long long cw[128];
+        s2_pls_codewords(cw);
+        const unsigned long long code = cw[(modcod << 2) | ((shortframes ? 1 : 0) << 1) | (pilots ? 1 : 0)];
+        for (int i = 0; i < 64; i++)
+        {
+            const int yi = (int)((code >> (63 - i)) & 1ull), nyi = yi ^ (i & 1);
+            hdr[26 + i].x = 1 * (1 - 2 * nyi) / sqrtf(2);
+            hdr[26 + i].y = 1 * (1 - 2 * yi) / sqrtf(2);
+        }
+        DevBuf<float2> d_hdr;
+        DevBuf<float> d_lut;
+        DevBuf<S2PllState> d_st;
+        d_hdr.reserve(90);
+        d_lut.reserve((size_t)lut_resolution * lut_resolution);
+        d_st.reserve(1);
+        SD_HIP(hipMemcpy(d_hdr.p, hdr, sizeof(hdr), hipMemcpyHostToDevice));
+        SD_HIP(hipMemcpy(d_lut.p, lut_phase_error, (size_t)lut_resolution * lut_resolution * sizeof(float), hipMemcpyHostToDevice));
+        S2PllState st{state2[0], state2[1]};
+        SD_HIP(hipMemcpy(d_st.p, &st, sizeof(st), hipMemcpyHostToDevice));
+        {
+            ProfScope _ps("k_s2_pll_seq", nullptr);
+            hipLaunchKernelGGL(k_s2_pll_seq, dim3(1), dim3(64), 0, nullptr, reinterpret_cast<const float2 *>(d_frames_in), reinterpret_cast<float2 *>(d_frames_out), frame_stride,
+                               nframes, per_frame, alpha, beta, d_hdr.p, d_lut.p, lut_resolution, d_st.p);
+        }
+        SD_HIP(hipMemcpy(&st, d_st.p, sizeof(st), hipMemcpyDeviceToHost));
+        state2[0] = st.phase;
+        state2[1] = st.freq;
+        return per_frame;
+        SD_GUARD_END(-1)
+    }
+    int sdhip_op_atan2f(int device, const float *d_y, const float *d_x, int n, float *d_out)
+    {
+        SD_GUARD_BEGIN
+        SD_HIP(hipSetDevice(device));
+        hipLaunchKernelGGL(k_s2_atan2f, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, nullptr, d_y, d_x, n, d_out);
+        SD_HIP(hipDeviceSynchronize());
+        return 0;
         SD_GUARD_END(-1)
     }
     int sdhip_s2_cfg(int modcod, int shortframes, int *bits, int *slots, int *rate, int *constellation)

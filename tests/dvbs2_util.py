@@ -144,3 +144,30 @@ def pl_stream(raw_frame_size: int, pls_index: int, nframes: int, seed: int, lead
     sigma = np.sqrt(1.0 / (2.0 * 10 ** (esn0_db / 10)))
     x = (x + sigma * (rng.standard_normal(n) + 1j * rng.standard_normal(n))) * amplitude
     return x.astype(np.complex64)
+
+
+def pl_stream_from_bits(codewords: np.ndarray, raw_frame_size: int, pls_index: int, seed: int, lead: int = 0, cfo: float = 0.0, esn0_db: float = 10.0):
+    """QPSK PLFRAMEs carrying the given code words (bit pairs on I / Q, bit 0 -> +; PL-scrambled with the Gold sequence n = 0), true header,
+    back to back behind `lead` noise symbols, with a rotation and noise; amplitude = the demapper table's nominal point (|s| = 2/3)."""
+    rng = np.random.default_rng(seed)
+    nsym = codewords.shape[1] // 2
+    assert raw_frame_size == 90 + nsym
+    x, y = 1, 0x3ffff
+    z = np.zeros(2 * 131072, dtype=np.uint8)
+    for i in range(2 * 131072):
+        z[i] = (x ^ y) & 1
+        x = ((((x >> 7) ^ x) & 1) << 18 | x) >> 1
+        y = ((((y >> 10) ^ (y >> 7) ^ (y >> 5) ^ y) & 1) << 18 | y) >> 1
+    rn = (z[:nsym] | (z[131072:131072 + nsym] << 1)).astype(np.int64)
+    hdr = np.concatenate([sof_symbols(), pls_symbols(pls_index)])
+    parts = [(rng.standard_normal(lead) + 1j * rng.standard_normal(lead)) * 0.7]
+    for cw in codewords:
+        sym = ((1.0 - 2.0 * cw[0::2]) + 1j * (1.0 - 2.0 * cw[1::2])) / np.sqrt(2.0) * np.exp(1j * np.pi / 2 * rn)
+        parts.append(np.concatenate([hdr, sym]))
+    parts.append((rng.standard_normal(2 * raw_frame_size) + 1j * rng.standard_normal(2 * raw_frame_size)) * 0.7)  # so that the last frame's window is there
+    s = np.concatenate(parts)
+    n = len(s)
+    s = s * np.exp(1j * (cfo * np.arange(n) + 0.4))
+    sigma = np.sqrt(1.0 / (2.0 * 10 ** (esn0_db / 10)))
+    s = (s + sigma * (rng.standard_normal(n) + 1j * rng.standard_normal(n))) * (2.0 / 3.0)
+    return s.astype(np.complex64)

@@ -316,6 +316,159 @@ def test_pl_sync(capi, slots, pilots, kind):
     check_pl_sync(capi, to_dev, lambda d: d[0].cpu().numpy(), zeros_dev, slots, pilots, kind)
 
 
+def _dvbs2_ref_lib():
+    import ctypes as C
+    p = pyref.os.path.join(pyref._HERE, "_ref", "libsdref_dvbs2.so")
+    if not pyref.os.path.exists(p) or not hasattr(C.CDLL(p), "sdref_s2_pll"):
+        pytest.skip("oracle/_ref/libsdref_dvbs2.so without the PLL entries (rebuild with the reference tree)")
+    return C.CDLL(p)
+
+
+def check_atan2f(capi, to_dev, from_dev, zeros_dev):
+    """The device restatement of glibc's atan2f / atanf (what complex_t::arg() calls in the frame PLL) == the host libm's atan2f, bit for bit:
+    signal-like arguments, every quadrant, tiny / huge ratios, zeros, infinities, the x == 1 shortcut."""
+    import ctypes as C
+    lib = _dvbs2_ref_lib()
+    rng = np.random.default_rng(12)
+    n = 400000
+    y = rng.standard_normal(n).astype(np.float32)
+    x = rng.standard_normal(n).astype(np.float32)
+    y[:50000] *= np.float32(1e-6)
+    x[50000:100000] *= np.float32(1e-7)
+    bits = rng.integers(0, 2 ** 32, 100000, dtype=np.uint64).astype(np.uint32)
+    y[100000:200000] = bits.view(np.float32)
+    x[150000:250000] = rng.integers(0, 2 ** 32, 100000, dtype=np.uint64).astype(np.uint32).view(np.float32)
+    sp = np.array([0.0, -0.0, 1.0, -1.0, np.inf, -np.inf, 1e-30, -1e30, 0.4375, 0.6875, 1.1875, 2.4375, 3.4e38], dtype=np.float32)
+    k = len(sp)
+    y[-k * k:] = np.repeat(sp, k)
+    x[-k * k:] = np.tile(sp, k)
+    ok = ~(np.isnan(x) | np.isnan(y))
+    want = np.zeros(n, dtype=np.float32)
+    lib.sdref_atan2f(y.ctypes.data_as(C.c_void_p), x.ctypes.data_as(C.c_void_p), n, want.ctypes.data_as(C.c_void_p))
+    d_y, d_x, d_o = to_dev(y), to_dev(x), zeros_dev(n, np.float32)
+    assert capi.lib().sdhip_op_atan2f(0, C.c_void_p(d_y[1]), C.c_void_p(d_x[1]), n, C.c_void_p(d_o[1])) == 0
+    got = from_dev(d_o)
+    assert np.array_equal(got[ok].view(np.uint32), want[ok].view(np.uint32))
+
+
+def check_pll(capi, to_dev, from_dev, zeros_dev, modcod, short, pilots, nfr=5):
+    """sdhip_s2_pll_dev == dvbs2::S2PLLBlock::work frame by frame (the reference block set up as the module sets it up, driven through its own
+    streams): every symbol the block writes and the loop state behind the last frame, bit for bit -- in one call and in two (state carried by
+    the caller)."""
+    import ctypes as C
+    from tests import dvbs2_util
+    _dvbs2_ref_lib()
+    ref = pyref.S2FrontRef()
+    c = ref.cfg(modcod, short, pilots)
+    probe = np.zeros(8, dtype=np.complex64)
+    _, _, raw = pyref.s2_pl_sync_ref(c["slots"], pilots, 0.6, probe, max_frames=1)
+    x = dvbs2_util.pl_stream(raw, (modcod << 2) | (short << 1) | pilots, nfr + 2, seed=modcod, lead=0, cfo=0.0004)
+    fr, _, _ = pyref.s2_pl_sync_ref(c["slots"], pilots, 0.6, x)
+    fr = fr[:nfr]
+    want, walked, wst = pyref.s2_pll_ref(modcod, short, pilots, 0.002, fr)
+    lut = pyref.s2_lut_phase_ref(modcod, short)
+    d_in = to_dev(fr.view(np.float32))
+    for cuts in ([0, nfr], [0, 2, nfr]):
+        d_out = zeros_dev(fr.size * 2, np.float32)
+        st = np.zeros(2, dtype=np.float32)
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            off = a * fr.shape[1] * 8
+            rc = capi.lib().sdhip_s2_pll_dev(0, modcod, short, pilots, 0.002, C.c_void_p(d_in[1] + off), C.c_void_p(d_out[1] + off), fr.shape[1], b - a,
+                                             lut.ctypes.data_as(C.c_void_p), 256, st.ctypes.data_as(C.c_void_p))
+            assert rc == walked, capi.last_error()
+        got = from_dev(d_out).view(np.complex64).reshape(fr.shape)
+        assert np.array_equal(got[:, :walked].view(np.uint32), want[:, :walked].view(np.uint32))
+        assert np.array_equal(st.view(np.uint32), wst.view(np.uint32))
+    assert abs(float(wst[1]) - 0.0004) < 1e-4  # the loop sits on the stream's offset
+    assert walked == (c["slots"] + 1) * 90 + (36 if pilots else 0)
+
+
+def _torch_helpers():
+    import torch
+
+    def to_dev(a):
+        t = torch.from_numpy(np.ascontiguousarray(a)).cuda()
+        return (t, t.data_ptr())
+
+    def zeros_dev(n, dt):
+        t = torch.zeros(n, dtype={np.int8: torch.int8, np.int32: torch.int32, np.float32: torch.float32, np.uint8: torch.uint8}[dt], device="cuda")
+        return (t, t.data_ptr())
+
+    return to_dev, (lambda d: d[0].cpu().numpy()), zeros_dev
+
+
+def test_atan2f(capi):
+    check_atan2f(capi, *_torch_helpers())
+
+
+@pytest.mark.parametrize("modcod,short,pilots", [(4, 1, 0), (13, 1, 0), (20, 1, 0), (6, 1, 1)])
+def test_pll(capi, modcod, short, pilots):
+    check_pll(capi, *_torch_helpers(), modcod, short, pilots)
+
+
+def check_symbols_to_bbframes(capi, to_dev, from_dev, zeros_dev, nfr=4):
+    """The DVB-S2 receive chain behind the clock recovery on the device, entry by entry -- PL synchroniser, frame PLL, soft demapper stage, LDPC,
+    repack, BCH, BB descrambler -- against the reference's own classes chained the same way (DVBS2DemodModule's blocks and process_s2):
+    short QPSK 1/2 frames carrying BCH + LDPC encoded random BBFRAMEs, a leading stretch of noise, a carrier offset: identical BBFRAMEs, and
+    they are the transmitted ones."""
+    import ctypes as C
+    from tests import dvbs2_util
+    _dvbs2_ref_lib()
+    modcod, short, rate = 4, 1, "1/2"
+    rc_ = capi.S2_RATES[rate]
+    front, fec = pyref.S2FrontRef(), pyref.Dvbs2Ref(False)
+    c = front.cfg(modcod, short, 0)
+    n, k = fec.dims(short, rc_)
+    kb = fec.bch_kbch(short, rc_)
+    rng = np.random.default_rng(21)
+    bb = np.zeros((nfr, k // 8), dtype=np.uint8)
+    bb[:, :kb // 8] = rng.integers(0, 256, (nfr, kb // 8), dtype=np.uint8)
+    scr = fec.bb_descramble(short, rc_, bb.copy())           # the BB scrambler is its own inverse
+    cw = dvbs2_util.encode(short, rc_, np.unpackbits(fec.bch_encode(short, rc_, scr.copy()), axis=1))
+    raw = (c["slots"] + 1) * 90
+    x = dvbs2_util.pl_stream_from_bits(cw, raw, (modcod << 2) | (short << 1), seed=5, lead=777, cfo=0.0003, esn0_db=9.0)
+    # ---- reference chain
+    fr, _, _ = pyref.s2_pl_sync_ref(c["slots"], 0, 0.6, x)
+    rp, walked, _ = pyref.s2_pll_ref(modcod, short, 0, 0.002, fr)
+    soft, _ = front.bb_to_soft(modcod, short, 0, rp)
+    dec, _tr = fec.ldpc_decode(short, rc_, soft.copy(), 25)
+    packed = np.packbits((dec < 0).astype(np.uint8), axis=1)[:, :k // 8]
+    wfix, wcorr = fec.bch_decode(short, rc_, packed.copy())
+    want = fec.bb_descramble(short, rc_, wfix.copy())
+    assert len(want) >= nfr - 1 and np.array_equal(want[:nfr - 1, :kb // 8], bb[:len(want)][:nfr - 1, :kb // 8])
+    # ---- device chain
+    L = capi.lib()
+    d_x = to_dev(x.view(np.float32))
+    cap = nfr + 2
+    stride = raw + 6
+    d_fr, d_pl = zeros_dev(cap * stride * 2, np.float32), zeros_dev(cap * stride * 2, np.float32)
+    consumed = C.c_size_t(0)
+    nf = L.sdhip_s2_pl_sync_dev(0, c["slots"], 0, 0.6, C.c_void_p(d_x[1]), len(x), C.c_void_p(d_fr[1]), stride, cap, C.byref(consumed), None)
+    assert nf >= len(want)
+    nf = len(want)
+    st = np.zeros(2, dtype=np.float32)
+    lutp, lutb = pyref.s2_lut_phase_ref(modcod, short), front.lut(modcod, short)
+    assert L.sdhip_s2_pll_dev(0, modcod, short, 0, 0.002, C.c_void_p(d_fr[1]), C.c_void_p(d_pl[1]), stride, nf, lutp.ctypes.data_as(C.c_void_p), 256,
+                              st.ctypes.data_as(C.c_void_p)) == walked
+    d_soft = zeros_dev(nf * n, np.int8)
+    assert L.sdhip_s2_bb_to_soft_dev(0, modcod, short, 0, C.c_void_p(d_pl[1]), stride, nf, lutb.ctypes.data_as(C.c_void_p), 256, C.c_void_p(d_soft[1]), None) == n
+    ldpc = capi.LdpcDecoder(framesize=short, rate=rate, batch=1)
+    bch = capi.BchDecoder(framesize=short, rate=rate)
+    d_tr = zeros_dev(nf, np.int32)
+    ldpc.decode_dev(d_soft[1], nf, 25, d_tr[1])
+    d_pack = zeros_dev(nf * (k // 8), np.uint8)
+    d_corr = zeros_dev(nf, np.int32)
+    bch.pack_dev(d_soft[1], n, nf, d_pack[1], k // 8)
+    bch.decode_dev(d_pack[1], nf, k // 8, d_corr[1])
+    bch.descramble_dev(d_pack[1], nf, k // 8)
+    got = from_dev(d_pack).reshape(nf, k // 8)
+    assert np.array_equal(from_dev(d_corr), wcorr) and np.array_equal(got, want)
+
+
+def test_symbols_to_bbframes(capi):
+    check_symbols_to_bbframes(capi, *_torch_helpers())
+
+
 def check_bb_to_soft_golden(capi, to_dev, from_dev, zeros_dev):
     """The committed fixture tests/golden/s2_bb_to_soft.npz (written by make_golden.py from the compiled reference): stored PLFRAMEs and the
     reference's demapper table -> its PLS indices and soft bits, byte for byte. Needs no reference build at run time."""

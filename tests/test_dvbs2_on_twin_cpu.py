@@ -115,6 +115,31 @@ def test_pl_sync_on_the_twin(capi, slots, pilots, kind):
     G.check_pl_sync(capi, to_dev, lambda d: d[0], zeros_dev, slots, pilots, kind)
 
 
+def _np_helpers():
+    def to_dev(a):
+        a = np.ascontiguousarray(a)
+        return (a, a.ctypes.data)
+
+    def zeros_dev(n, dt):
+        a = np.zeros(n, dtype=dt)
+        return (a, a.ctypes.data)
+
+    return to_dev, (lambda d: d[0]), zeros_dev
+
+
+def test_atan2f_on_the_twin(capi):
+    G.check_atan2f(capi, *_np_helpers())
+
+
+@pytest.mark.parametrize("modcod,short,pilots", [(4, 1, 0), (13, 1, 0), (6, 1, 1)])
+def test_pll_on_the_twin(capi, modcod, short, pilots):
+    G.check_pll(capi, *_np_helpers(), modcod, short, pilots, nfr=3)
+
+
+def test_symbols_to_bbframes_on_the_twin(capi):
+    G.check_symbols_to_bbframes(capi, *_np_helpers(), nfr=3)
+
+
 def test_bb_to_soft_golden_on_the_twin(capi):
     def to_dev(a):
         a = np.ascontiguousarray(a)
