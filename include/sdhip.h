@@ -138,6 +138,13 @@ extern "C"
     int64_t sdhip_demod_process_dev(void *h, const void *d_iq, size_t nsamples, int fmt, int8_t *d_soft, size_t soft_cap, float *d_syms, size_t syms_cap, int final);
     int sdhip_demod_get_stats(void *h, sdhip_demod_stats *st);
 
+    /* The DVB-S2 demodulator's front end (plugins/dvb_support/dvbs2/module_dvbs2_demod.cpp:98-105 on BaseDemodModule: resampler, AGC, RRC filter,
+       M&M clock recovery -- psk_demod's stages without its Costas loop; carrier recovery follows per frame, sdhip_s2_pl_sync_dev /
+       sdhip_s2_pll_dev). Same configuration struct (constellation only selects the clock recovery's OQPSK handling: pass SDHIP_QPSK; pll_bw
+       is unused), same handle functions: sdhip_demod_process_dev with d_syms != NULL delivers the clock-recovered symbols (the int8 soft
+       output is a by-product). Destroy with sdhip_demod_destroy. */
+    void *sdhip_dvbs2_front_create(const sdhip_demod_cfg *cfg);
+
     /* ---- ndsp: the reference's new block API -------------------------
        satdump::ndsp::PSKDemodHierBlock (src-core/dsp/hier/psk_demod.h:22-249, psk_demod.cpp:8-14): RRC FIR -> AGC (reference 0.6) ->
        M&M clock recovery -> Costas loop at ONE sample per symbol, complex symbols out; no resampler, no quantiser. The fields are the

@@ -135,6 +135,9 @@ def lib():
             L.sdhip_demod_get_stats.argtypes = [C.c_void_p, C.POINTER(DemodStats)]
             L.sdhip_op_block.restype = C.c_int64
             L.sdhip_op_block.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+        if hasattr(L, "sdhip_dvbs2_front_create"):
+            L.sdhip_dvbs2_front_create.restype = C.c_void_p
+            L.sdhip_dvbs2_front_create.argtypes = [C.POINTER(DemodCfg)]
         if hasattr(L, "sdhip_ndsp_psk_demod_create"):
             L.sdhip_ndsp_psk_cfg_default.argtypes = [C.POINTER(NdspPskCfg)]
             L.sdhip_ndsp_psk_demod_create.restype = C.c_void_p
@@ -279,11 +282,11 @@ class FecDecoder:
 
 
 class PskDemod:
-    """psk_demod on one GPU stream."""
+    """psk_demod on one GPU stream. front_only=True: the DVB-S2 demodulator's front end (no Costas loop; take the symbols, sdhip_dvbs2_front_create)."""
 
-    def __init__(self, cfg: DemodCfg):
+    def __init__(self, cfg: DemodCfg, front_only: bool = False):
         self.cfg = cfg
-        self.h = lib().sdhip_demod_create(C.byref(cfg))
+        self.h = (lib().sdhip_dvbs2_front_create if front_only else lib().sdhip_demod_create)(C.byref(cfg))
         if not self.h:
             raise SdhipError(f"sdhip_demod_create failed: {last_error()}")
 

@@ -431,6 +431,10 @@ namespace sdhip
         bool on = false;
         double samplerate = 0, symbolrate = 0, rrc_gain = 1, rrc_alpha = 0.35; // doubles in RRC_Block (dsp/filter/rrc.h:17-21)
         float agc_reference = 1.0f, agc_gain = 1.0f, agc_max_gain = 65536.0f, rec_omega = 0.0f, pll_freq_limit = 1.0f;
+        // the DVB-S2 demodulator's front (plugins/dvb_support/dvbs2/module_dvbs2_demod.cpp:98-105): BaseDemodModule's stages, the RRC filter and the
+        // clock recovery like psk_demod's -- and NO Costas loop: carrier recovery happens per frame behind the PL synchroniser (sdhip_s2_pll_dev).
+        // The legacy stage order, the symbols leave as floats.
+        bool skip_costas = false;
     };
 
     struct DemodEngine
@@ -685,7 +689,7 @@ namespace sdhip
                     l = 1.0f;
                 d_af_start.reserve(1);
                 SD_HIP(hipMemcpy(d_af_start.p, &s0, sizeof(s0), hipMemcpyHostToDevice));
-                fuse_afc = !cfg.has_carrier && env_int("SDHIP_FUSE_COSTAS", 1) != 0;
+                fuse_afc = !cfg.has_carrier && env_int("SDHIP_FUSE_COSTAS", 1) != 0 && !nd.skip_costas;
                 if (fuse_afc)
                 {
                     AfcState a0{};
@@ -1826,14 +1830,16 @@ namespace sdhip
                 tick("carrier");
             }
             // ---- Costas (speculative, symmetry-corrected)
-            if (!fuse_afc)
+            if (!fuse_afc && !nd.skip_costas)
             {
                 costas_stage(A, B, n, cg, final_sps, (double)final_samplerate);
                 std::swap(A, B);
             }
             // ---- post_costas_dc (module_psk_demod.cpp:127-134): the DC block sees ONE coherent stream, so the per-chunk frames of the
             // Costas stage are turned back first (exact quarter / half turns); the clock recovery then reads un-rotated samples
-            const int *mm_rot = d_rot.p;
+            const int *mm_rot = nd.skip_costas ? nullptr : d_rot.p; // no Costas stage: no per-chunk frames to undo
+            if (nd.skip_costas)
+                cg = make_geom(n, 1 << 30, 0);
             if (cfg.post_costas_dc)
             {
                 launch_derotate(A, n, cg, d_rot.p, order, stream);
@@ -2113,6 +2119,17 @@ extern "C"
         SD_GUARD_END(nullptr)
     }
     void sdhip_ndsp_psk_demod_destroy(void *h) { delete (DemodEngine *)h; }
+    // DVB-S2 demodulator front: a psk_demod handle without the Costas loop (use sdhip_demod_process_dev with d_syms for the symbols)
+    void *sdhip_dvbs2_front_create(const sdhip_demod_cfg *cfg)
+    {
+        SD_GUARD_BEGIN
+        if (cfg->has_carrier || cfg->post_costas_dc)
+            throw HipError("dvbs2 front: has_carrier / post_costas_dc belong to psk_demod's carrier loop");
+        NdspExt e;
+        e.skip_costas = true;
+        return new DemodEngine(*cfg, &e);
+        SD_GUARD_END(nullptr)
+    }
     int64_t sdhip_ndsp_psk_demod_work_dev(void *h, const float *d_in, size_t nsamples, float *d_out, size_t out_cap)
     {
         SD_GUARD_BEGIN

@@ -406,7 +406,7 @@ def test_pll(capi, modcod, short, pilots):
     check_pll(capi, *_torch_helpers(), modcod, short, pilots)
 
 
-def check_symbols_to_bbframes(capi, to_dev, from_dev, zeros_dev, nfr=4):
+def check_symbols_to_bbframes(capi, to_dev, from_dev, zeros_dev, nfr=4, via_baseband=None):
     """The DVB-S2 receive chain behind the clock recovery on the device, entry by entry -- PL synchroniser, frame PLL, soft demapper stage, LDPC,
     repack, BCH, BB descrambler -- against the reference's own classes chained the same way (DVBS2DemodModule's blocks and process_s2):
     short QPSK 1/2 frames carrying BCH + LDPC encoded random BBFRAMEs, a leading stretch of noise, a carrier offset: identical BBFRAMEs, and
@@ -426,16 +426,39 @@ def check_symbols_to_bbframes(capi, to_dev, from_dev, zeros_dev, nfr=4):
     scr = fec.bb_descramble(short, rc_, bb.copy())           # the BB scrambler is its own inverse
     cw = dvbs2_util.encode(short, rc_, np.unpackbits(fec.bch_encode(short, rc_, scr.copy()), axis=1))
     raw = (c["slots"] + 1) * 90
-    x = dvbs2_util.pl_stream_from_bits(cw, raw, (modcod << 2) | (short << 1), seed=5, lead=777, cfo=0.0003, esn0_db=9.0)
+    x = dvbs2_util.pl_stream_from_bits(cw, raw, (modcod << 2) | (short << 1), seed=5, lead=0 if via_baseband else 777, cfo=0.0003, esn0_db=9.0)
+    xref = x
+    if via_baseband:
+        # the clean symbol stream is pulse-shaped to 2.5 samples per symbol with a timing offset, a carrier offset and noise (synth.modulate); the
+        # reference recovers the symbols with its AGC, RRC filter and M&M blocks, the device with the front-end handle (via_baseband = "exact":
+        # the same symbols bit for bit; "chunk": the chunk-parallel schedule's)
+        from satdump_amd import synth
+        clean = dvbs2_util.pl_stream_from_bits(cw, raw, (modcod << 2) | (short << 1), seed=5, lead=0, cfo=0.0, esn0_db=80.0) * 1.5
+        spec = synth.SynthSpec(constellation="qpsk", samplerate=2.5e6, symbolrate=1e6, rrc_alpha=0.35, amplitude=0.5, cfo_hz=60.0, esn0_db=7.0, seed=3, timing_offset=0.3)
+        bbx, _ = synth.modulate(clean.astype(np.complex128), spec)
+        orc = pyref.best()
+        xref = orc.block(3, [2.5, (8.7e-3) ** 2 / 4, 0.5, 8.7e-3, 0.005], orc.block(1, [2.5e6, 1e6, 0.35, 31], orc.block(0, [1e-3, 1.0, 1.0, 65536.0], bbx)))
+        dem = capi.PskDemod(capi.demod_cfg(samplerate=2.5e6, symbolrate=1e6, constellation="qpsk", rrc_alpha=0.35, rrc_taps=31, agc_rate=1e-3, pll_bw=0.005,
+                                           exact=1 if via_baseband == "exact" else 0, chunk_len=0 if via_baseband == "exact" else 8192), front_only=True)
+        d_bb = to_dev(bbx.view(np.float32))
+        d_so, d_sy = zeros_dev(2 * len(bbx) + 64, np.int8), zeros_dev(2 * (len(bbx) + 64), np.float32)
+        ns = dem.process_dev(d_bb[1], len(bbx), capi.FMT_CF32, d_so[1], 2 * len(bbx) + 64, d_sy[1], len(bbx) + 64)
+        x = from_dev(d_sy)[: 2 * (ns // 2)].view(np.complex64).copy()
+        if via_baseband == "exact":
+            assert len(x) == len(xref) and np.array_equal(x.view(np.uint32), xref.view(np.uint32))
     # ---- reference chain
-    fr, _, _ = pyref.s2_pl_sync_ref(c["slots"], 0, 0.6, x)
+    fr, _, _ = pyref.s2_pl_sync_ref(c["slots"], 0, 0.6, xref)
     rp, walked, _ = pyref.s2_pll_ref(modcod, short, 0, 0.002, fr)
     soft, _ = front.bb_to_soft(modcod, short, 0, rp)
     dec, _tr = fec.ldpc_decode(short, rc_, soft.copy(), 25)
     packed = np.packbits((dec < 0).astype(np.uint8), axis=1)[:, :k // 8]
     wfix, wcorr = fec.bch_decode(short, rc_, packed.copy())
     want = fec.bb_descramble(short, rc_, wfix.copy())
-    assert len(want) >= nfr - 1 and np.array_equal(want[:nfr - 1, :kb // 8], bb[:len(want)][:nfr - 1, :kb // 8])
+    # what the reference delivers: transmitted frames, in order (from baseband the first ones are lost to the AGC / clock loop's acquisition)
+    sent = {bytes(r[:kb // 8]): i for i, r in enumerate(bb)}
+    hits = [sent.get(bytes(r[:kb // 8]), -1) for r in want]
+    found = [h for h in hits if h >= 0]
+    assert found == sorted(found) and len(found) >= (3 if via_baseband else nfr - 1), hits
     # ---- device chain
     L = capi.lib()
     d_x = to_dev(x.view(np.float32))
@@ -444,8 +467,9 @@ def check_symbols_to_bbframes(capi, to_dev, from_dev, zeros_dev, nfr=4):
     d_fr, d_pl = zeros_dev(cap * stride * 2, np.float32), zeros_dev(cap * stride * 2, np.float32)
     consumed = C.c_size_t(0)
     nf = L.sdhip_s2_pl_sync_dev(0, c["slots"], 0, 0.6, C.c_void_p(d_x[1]), len(x), C.c_void_p(d_fr[1]), stride, cap, C.byref(consumed), None)
-    assert nf >= len(want)
-    nf = len(want)
+    if via_baseband != "chunk":
+        assert nf >= len(want)
+        nf = len(want)
     st = np.zeros(2, dtype=np.float32)
     lutp, lutb = pyref.s2_lut_phase_ref(modcod, short), front.lut(modcod, short)
     assert L.sdhip_s2_pll_dev(0, modcod, short, 0, 0.002, C.c_void_p(d_fr[1]), C.c_void_p(d_pl[1]), stride, nf, lutp.ctypes.data_as(C.c_void_p), 256,
@@ -462,11 +486,25 @@ def check_symbols_to_bbframes(capi, to_dev, from_dev, zeros_dev, nfr=4):
     bch.decode_dev(d_pack[1], nf, k // 8, d_corr[1])
     bch.descramble_dev(d_pack[1], nf, k // 8)
     got = from_dev(d_pack).reshape(nf, k // 8)
-    assert np.array_equal(from_dev(d_corr), wcorr) and np.array_equal(got, want)
+    if via_baseband == "chunk":
+        # other float symbols (inside the clock recovery's floor; its rare symbol slips need not fall where the sequential loop's do): the
+        # contract here is the decoders' output -- transmitted frames, in order, about as many as the reference recovers
+        ghits = [sent.get(bytes(r[:kb // 8]), -1) for r in got]
+        gfound = [h for h in ghits if h >= 0]
+        assert gfound == sorted(gfound) and len(gfound) >= 3 and len(gfound) >= len(found) - 2, (ghits, hits)
+    else:
+        assert np.array_equal(from_dev(d_corr), wcorr) and np.array_equal(got, want)
 
 
 def test_symbols_to_bbframes(capi):
     check_symbols_to_bbframes(capi, *_torch_helpers())
+
+
+@pytest.mark.parametrize("front", ["exact", "chunk"])
+def test_baseband_to_bbframes(capi, front):
+    """The whole DVB-S2 receive path on the device, baseband samples in, BBFRAMEs out: front end (AGC, RRC filter, clock recovery), PL synchroniser,
+    frame PLL, soft demapper stage, LDPC, BCH, BB descrambler -- against the reference's blocks and classes chained the same way."""
+    check_symbols_to_bbframes(capi, *_torch_helpers(), nfr=10, via_baseband=front)
 
 
 def check_bb_to_soft_golden(capi, to_dev, from_dev, zeros_dev):

@@ -140,6 +140,11 @@ def test_symbols_to_bbframes_on_the_twin(capi):
     G.check_symbols_to_bbframes(capi, *_np_helpers(), nfr=3)
 
 
+@pytest.mark.parametrize("front", ["exact", "chunk"])
+def test_baseband_to_bbframes_on_the_twin(capi, front):
+    G.check_symbols_to_bbframes(capi, *_np_helpers(), nfr=10, via_baseband=front)
+
+
 def test_bb_to_soft_golden_on_the_twin(capi):
     def to_dev(a):
         a = np.ascontiguousarray(a)
