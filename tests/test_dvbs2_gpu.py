@@ -294,7 +294,8 @@ def check_pl_sync(capi, to_dev, from_dev, zeros_dev, slots, pilots, kind):
     if kind == "locked":
         assert np.all(bp[:nf] == 0)
     if kind == "slips":
-        assert bp[0] == 1234 and bp[3] == 17 and bp[6] == raw // 2 + 5 and np.count_nonzero(bp[:nf]) == 3
+        slips = {f: v for f, v in {0: 1234, 3: 17, 6: raw // 2 + 5}.items() if f < nf}  # (the 5-frame normal-FECFRAME case ends before the third)
+        assert all(bp[f] == v for f, v in slips.items()) and np.count_nonzero(bp[:nf]) == len(slips)
     # max_frames is honoured and the call is restartable where it stopped
     d_fr2 = zeros_dev(cap * stride * 2, np.float32)
     nf2 = capi.lib().sdhip_s2_pl_sync_dev(0, slots, pilots, 0.6, C.c_void_p(d_x[1]), len(x), C.c_void_p(d_fr2[1]), stride, 2, C.byref(consumed), None)
