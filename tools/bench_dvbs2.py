@@ -26,6 +26,7 @@ def parse(argv=None):
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--cpu-frames", type=int, default=64)
     ap.add_argument("--front", type=int, default=1, help="1: the frames enter as QPSK PLFRAMEs through sdhip_s2_bb_to_soft_dev (needs oracle/_ref for the demapper table)")
+    ap.add_argument("--sync-frames", type=int, default=128, help="frames the PL synchroniser and the frame PLL are timed on (0 = skip)")
     ap.add_argument("--esn0", type=float, default=8.0, help="Es/N0 of the PLFRAMEs, dB")
     return ap.parse_args(argv)
 
@@ -128,6 +129,38 @@ def run(args) -> dict:
            "kernels_ms": {k2: round(v[0] / args.steps, 3) for k2, v in prof.items()},
            "roofline": {"bound": "hbm", "kernel": "k_ldpc_trial", "achieved": round(algo / (ms_ldpc * 1e-3) / 1e9, 1) if ms_ldpc else None, "peak": 8000.0, "unit": "GB/s",
                         "frac": round(algo / (ms_ldpc * 1e-3) / 1e9 / 8000.0, 4) if ms_ldpc else None, "traffic": None}}
+    if front and args.sync_frames > 0:
+        # the two synchronisation stages in front of the demapper, timed on their own (the frame PLL is one serial lane: it would hide everything else
+        # in the step above): PL synchroniser over the frames laid back to back, frame PLL over what it emits
+        ns_ = min(nf, args.sync_frames)
+        rawlen = 90 + front["nsym"]
+        # on-air headers for these stages (SOF + PLS as pi/2-BPSK at the data symbols' amplitude; the frames of the step above carry the header the
+        # way the PLL leaves it, which is what the demapper stage reads)
+        hdr_air = (np.concatenate([dvbs2_util.sof_symbols(), dvbs2_util.pls_symbols((front["modcod"] << 2) | (args.framesize << 1))]) * a * np.sqrt(2.0)).astype(np.complex64)
+        d_true = d_fr.view(nf, front["stride"], 2)[:ns_, :rawlen, :].clone()
+        d_true[:, :90, :] = torch.from_numpy(hdr_air.view(np.float32).reshape(90, 2)).cuda()[None, :, :] + sig * torch.randn((ns_, 90, 2), device="cuda", generator=g)
+        d_stream = d_true.contiguous().view(-1)
+        d_sf = torch.zeros(ns_ * front["stride"] * 2, dtype=torch.float32, device="cuda")
+        d_pf = torch.zeros_like(d_sf)
+        consumed = C.c_size_t(0)
+        bp = np.zeros(ns_, dtype=np.int32)
+        slots = front["nsym"] // 90
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        nfs = capi.lib().sdhip_s2_pl_sync_dev(0, slots, 0, 0.6, C.c_void_p(d_stream.data_ptr()), ns_ * rawlen, C.c_void_p(d_sf.data_ptr()), front["stride"], ns_, C.byref(consumed),
+                                              bp.ctypes.data_as(C.c_void_p))
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        lutp = pyref.s2_lut_phase_ref(front["modcod"], args.framesize)
+        st2 = np.zeros(2, dtype=np.float32)
+        walked = capi.lib().sdhip_s2_pll_dev(0, front["modcod"], args.framesize, 0, 0.002, C.c_void_p(d_sf.data_ptr()), C.c_void_p(d_pf.data_ptr()), front["stride"], int(nfs),
+                                             lutp.ctypes.data_as(C.c_void_p), 256, st2.ctypes.data_as(C.c_void_p))
+        torch.cuda.synchronize()
+        t3 = time.perf_counter()
+        out["sync_stages"] = {"frames": int(nfs), "symbols": int(nfs) * rawlen, "pl_sync_ms": round((t2 - t1) * 1e3, 3), "pl_sync_Msym_per_s": round(int(nfs) * rawlen / (t2 - t1) / 1e6, 1),
+                              "frames_found_at_offset_0": int(np.count_nonzero(bp[:nfs] == 0)), "pll_ms": round((t3 - t2) * 1e3, 3),
+                              "pll_Msym_per_s": round(int(nfs) * walked / (t3 - t2) / 1e6, 2), "pll_state": [float(st2[0]), float(st2[1])],
+                              "note": "host wall clock around each call (uploads of the 90 known header symbols and the 256 KB phase-error table included); the frame PLL is one sequential lane"}
     if args.cpu_frames > 0:
         m = args.cpu_frames // ref.batch * ref.batch
         if front:  # the decoder's input is what the demapper stage produced
