@@ -508,6 +508,63 @@ def test_baseband_to_bbframes(capi, front):
     check_symbols_to_bbframes(capi, *_torch_helpers(), nfr=10, via_baseband=front)
 
 
+def check_dvbs2_demod_mirror(capi, make_mem):
+    """satdump_amd.dvbs2.DVBS2Demod -- the module's parameter keys, baseband in, BBFRAMEs out, carry-over between calls -- against the reference's
+    blocks and classes chained the same way: identical BBFRAMEs in exact mode, whether the samples arrive in one call or in five ragged ones;
+    the module's error messages for missing parameters; the frequency feedback refused."""
+    from satdump_amd import dvbs2, synth
+    from tests import dvbs2_util
+    _dvbs2_ref_lib()
+    modcod, short, rc_ = 4, 1, 3
+    front, fec = pyref.S2FrontRef(), pyref.Dvbs2Ref(False)
+    c = front.cfg(modcod, short, 0)
+    n, k = fec.dims(short, rc_)
+    kb = fec.bch_kbch(short, rc_)
+    nfr = 10
+    rng = np.random.default_rng(21)
+    bb = np.zeros((nfr, k // 8), dtype=np.uint8)
+    bb[:, :kb // 8] = rng.integers(0, 256, (nfr, kb // 8), dtype=np.uint8)
+    cw = dvbs2_util.encode(short, rc_, np.unpackbits(fec.bch_encode(short, rc_, fec.bb_descramble(short, rc_, bb.copy())), axis=1))
+    raw = (c["slots"] + 1) * 90
+    clean = dvbs2_util.pl_stream_from_bits(cw, raw, (modcod << 2) | (short << 1), seed=5, lead=0, cfo=0.0, esn0_db=80.0) * 1.5
+    spec = synth.SynthSpec(constellation="qpsk", samplerate=2.5e6, symbolrate=1e6, rrc_alpha=0.35, amplitude=0.5, cfo_hz=60.0, esn0_db=7.0, seed=3, timing_offset=0.3)
+    bbx, _ = synth.modulate(clean.astype(np.complex128), spec)
+    params = {"samplerate": 2.5e6, "symbolrate": 1e6, "rrc_alpha": 0.35, "pll_bw": 0.002, "modcod": modcod, "shortframes": True, "agc_rate": 1e-3,
+              "clock_alpha": 8.7e-3, "freq_prop_factor": 0.0, "ldpc_trials": 25}
+    # ---- the reference chain
+    orc = pyref.best()
+    xref = orc.block(3, [2.5, (8.7e-3) ** 2 / 4, 0.5, 8.7e-3, 0.005], orc.block(1, [2.5e6, 1e6, 0.35, 31], orc.block(0, [1e-3, 1.0, 1.0, 65536.0], bbx)))
+    fr, _, _ = pyref.s2_pl_sync_ref(c["slots"], 0, 0.6, xref)
+    rp, _, _ = pyref.s2_pll_ref(modcod, short, 0, 0.002, fr)
+    soft, _ = front.bb_to_soft(modcod, short, 0, rp)
+    dec, _ = fec.ldpc_decode(short, rc_, soft.copy(), 25)
+    wfix, _ = fec.bch_decode(short, rc_, np.packbits((dec < 0).astype(np.uint8), axis=1)[:, :k // 8].copy())
+    want = fec.bb_descramble(short, rc_, wfix.copy())[:, :kb // 8]
+    sent = {bytes(r[:kb // 8]): i for i, r in enumerate(bb)}
+    assert sum(bytes(r) in sent for r in want) >= 3
+    # ---- the mirror, one call and five ragged calls
+    lut_b, lut_p = front.lut(modcod, short), pyref.s2_lut_phase_ref(modcod, short)
+    for cuts in ([0, len(bbx)], [0, 5000, 5001, 77777, 150000, len(bbx)]):
+        dem = dvbs2.DVBS2Demod(params, lut_b, lut_p, mem=make_mem(), capi=capi, exact=True)
+        assert dem.bbframe_bytes == kb // 8
+        got = np.concatenate([dem.process(bbx[a:b]) for a, b in zip(cuts[:-1], cuts[1:])])
+        assert len(got) >= len(want) - 1 and np.array_equal(got[:len(want)], want[:len(got)])
+        assert dem.stats["pls"] is not None and dem.stats["frames"] == len(got)
+    for missing, msg in (("rrc_alpha", "RRC Alpha parameter must be present!"), ("pll_bw", "PLL BW parameter must be present!"), ("modcod", "MODCOD parameter must be present!")):
+        with pytest.raises(ValueError, match=msg.replace("!", ".")):
+            dvbs2.DVBS2Demod({k2: v for k2, v in params.items() if k2 != missing}, lut_b, lut_p, mem=make_mem(), capi=capi)
+    with pytest.raises(NotImplementedError):
+        dvbs2.DVBS2Demod(dict(params, freq_prop_factor=0.01), lut_b, lut_p, mem=make_mem(), capi=capi)
+    with pytest.raises(ValueError, match="32APSK"):
+        dvbs2.DVBS2Demod(dict(params, modcod=25), lut_b, lut_p, mem=make_mem(), capi=capi)
+
+
+
+def test_dvbs2_demod_mirror(capi):
+    from satdump_amd import dvbs2
+    check_dvbs2_demod_mirror(capi, dvbs2.TorchMem)
+
+
 def check_bb_to_soft_golden(capi, to_dev, from_dev, zeros_dev):
     """The committed fixture tests/golden/s2_bb_to_soft.npz (written by make_golden.py from the compiled reference): stored PLFRAMEs and the
     reference's demapper table -> its PLS indices and soft bits, byte for byte. Needs no reference build at run time."""

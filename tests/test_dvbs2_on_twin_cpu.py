@@ -145,6 +145,30 @@ def test_baseband_to_bbframes_on_the_twin(capi, front):
     G.check_symbols_to_bbframes(capi, *_np_helpers(), nfr=10, via_baseband=front)
 
 
+class _NumpyMem:
+    """satdump_amd.dvbs2's memory adapter on host arrays (the twin's 'device' pointers are host pointers)."""
+
+    @staticmethod
+    def alloc(n, dtype):
+        return np.zeros(int(n), dtype=dtype)
+
+    @staticmethod
+    def from_host(a):
+        return np.ascontiguousarray(a).copy()
+
+    @staticmethod
+    def ptr(h):
+        return h.ctypes.data
+
+    @staticmethod
+    def to_host(h, n=None):
+        return (h if n is None else h[:n]).copy()
+
+
+def test_dvbs2_demod_mirror_on_the_twin(capi):
+    G.check_dvbs2_demod_mirror(capi, _NumpyMem)
+
+
 def test_bb_to_soft_golden_on_the_twin(capi):
     def to_dev(a):
         a = np.ascontiguousarray(a)
