@@ -1,3 +1,6 @@
+"""What of bench.py's contract can be checked without a GPU: its next_rows tools import, the committed PMC profile belongs to the sources in the tree
+(otherwise the driver line would carry traffic = null), the workload table and the algorithmic-byte figures of the dominant kernels."""
+import os
 
 
 def test_next_row_tools_import_and_parse():
@@ -17,3 +20,25 @@ def test_next_row_tools_import_and_parse():
         assert callable(nd.run) and callable(s2.run)
     finally:
         sys.path.remove(tools)
+
+
+def test_committed_pmc_profile_belongs_to_the_sources_in_the_tree():
+    """bench.py quotes roofline.traffic only from a PMC profile stamped with the hash of the kernel sources the library is built from: the newest
+    committed profiles/r*_metop_pmc.csv must carry satdump_amd.build.source_hash(), and yield a figure for the dominant lane kernels."""
+    import bench
+    from satdump_amd import build
+    for k in ("k_afc", "k_mm", "k_vit2_acs", "k_quantize"):
+        traffic, src = bench.pmc_traffic("metop_ahrpt", k)
+        assert traffic and traffic > 1e9 and "stale" not in src, (k, traffic, src)
+    with open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", src)) as f:
+        assert f"# source_hash: {build.source_hash()}" in f.read()
+
+
+def test_bench_workloads_and_algorithmic_bytes():
+    """The three single-GPU workloads of BASELINE.json are there; the dominant kernels' algorithmic bytes are what DESIGN.md 4 states (16 B per resampled
+    sample for the fused AGC + filter + Costas stage, 8 B in + 8 B per symbol out for the clock recovery)."""
+    import bench
+    assert set(bench.WORKLOADS) == {"goes_hrit", "metop_ahrpt", "npp_hrd"}
+    wl = bench.WORKLOADS["metop_ahrpt"]
+    a = bench.algorithmic_bytes(wl, 1000, 1000, 400, 800, 1024, 8)
+    assert a["k_afc"] == 16000 and a["k_mm"] == 1000 * 8 + 400 * 8 and a["k_quantize"] == 400 * (8 + wl["soft_per_sym"])
