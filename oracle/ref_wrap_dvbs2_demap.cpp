@@ -68,7 +68,14 @@ extern "C"
     // dvbs2::S2PLLBlock (dvbs2_pll.{h,cpp}) as DVBS2DemodModule::init sets it up (module_dvbs2_demod.cpp:111-118), one work() per frame through its
     // own streams. frames: nframes x frame_stride complex floats in, the same layout out (only the symbols the block writes are copied:
     // the return value per frame). state_out = {phase, freq} behind the last frame.
+    int sdref_s2_pll_from(int modcod, int shortframes, int pilots, float loop_bw, const float *frames, int frame_stride, int nframes, float *out, float *state_io);
     int sdref_s2_pll(int modcod, int shortframes, int pilots, float loop_bw, const float *frames, int frame_stride, int nframes, float *out, float *state_out)
+    {
+        state_out[0] = state_out[1] = 0.0f;
+        return sdref_s2_pll_from(modcod, shortframes, pilots, loop_bw, frames, frame_stride, nframes, out, state_out);
+    }
+    // the same with the loop state set beforehand (state_io = {phase, freq} in and out): what a study of frame-parallel schedules needs
+    int sdref_s2_pll_from(int modcod, int shortframes, int pilots, float loop_bw, const float *frames, int frame_stride, int nframes, float *out, float *state_io)
     {
         auto cfg = dvbs2::get_dvbs2_cfg(modcod, shortframes, pilots);
         auto in = std::make_shared<dsp::stream<complex_t>>();
@@ -79,6 +86,9 @@ extern "C"
         blk.frame_slot_count = cfg.frame_slot_count;
         blk.pls_code = modcod << 2 | shortframes << 1 | pilots;
         blk.update();
+        blk.phase = state_io[0];
+        blk.freq = state_io[1];
+        float *state_out = state_io;
         const int walked = (cfg.frame_slot_count + 1) * 90 + blk.pilot_cnt * 36;
         for (int f = 0; f < nframes; f++)
         {
