@@ -377,6 +377,16 @@ extern "C"
        walked per frame, <0 on error. */
     int sdhip_s2_pll_dev(int device, int modcod, int shortframes, int pilots, float loop_bw, const float *d_frames_in, float *d_frames_out, int frame_stride, int nframes,
                          const float *lut_phase_error, int lut_resolution, float *state2);
+    /* The same loop with its FRAME-PARALLEL schedule (round 4). mode 1 = sdhip_s2_pll_dev (the serial lane, exact). mode 0 / 2: the chain of loop steps
+       over the batch is cut into lanes; a lane starts a warm-up in front of its range from a data-aided estimate (phase from the 90 known header
+       symbols of its frame, frequency from two consecutive headers -- the carried loop frequency only picks the 2 pi / frame branch), and the
+       chain is certified lane by lane against the predecessors' end states; lanes that miss are re-run from the exact predecessor state. mode 2 =
+       a new stream: the first frames (65 536 symbols) are walked by the serial lane until the loop frequency is there; mode 0 = the caller vouches
+       that state2 is a locked loop's. What it promises: NOT the serial loop's symbols to 1e-5 -- the loop's detector is a 256 x 256 table, two
+       trajectories on the same symbols stay ~1e-2 (8PSK, 10 dB) ... 2e-4 (QPSK, 8 dB) of a symbol apart for good -- but the decoders' output, the
+       same BBFRAMEs. stats4 (HOST, may be NULL) = {lanes, lanes re-run, boundaries forced after the round limit, frames walked serially}. */
+    int sdhip_s2_pll_frames_dev(int device, int modcod, int shortframes, int pilots, float loop_bw, const float *d_frames_in, float *d_frames_out, int frame_stride, int nframes,
+                                const float *lut_phase_error, int lut_resolution, float *state2, int mode, unsigned *stats4);
     /* unit entry: d_out[i] = atan2f(d_y[i], d_x[i]) as the frame PLL evaluates it (glibc 2.35's float code restated) */
     int sdhip_op_atan2f(int device, const float *d_y, const float *d_x, int n, float *d_out);
     /* get_dvbs2_cfg's answer for a MODCOD: bits per symbol, slots per frame, dvbs2_code_rate_t, dvbs2_constellation_t */
@@ -388,6 +398,59 @@ extern "C"
     int sdhip_bb_descramble_dev(void *h, uint8_t *d_frames, int nframes, int stride);
     /* bit i of a frame = (soft[i] < 0), MSB first, for the first nbch soft bits of every LDPC frame (8-byte aligned, soft_stride apart) */
     int sdhip_s2_pack_dev(void *h, const int8_t *d_soft, int soft_stride, int nframes, uint8_t *d_out, int out_stride);
+
+    /* ---- the DVB-S2 demodulator as a module-shaped handle (BASELINE configs[4]) -------------------------------------------------------------------
+       Replaces satdump::pipeline::dvb::DVBS2DemodModule (plugins/dvb_support/dvbs2/module_dvbs2_demod.{h,cpp}: constructor :13-83, init :85-137,
+       process :141-222, process_s2 :239-293, getModuleStats :224-237): baseband samples in, BBFRAME bytes out (bch_decoder->dataSize() / 8 bytes per
+       frame: what the module writes to its .bbframe file / output fifo). The fields are the module's JSON keys; `front` carries BaseDemodModule's and
+       the RRC / clock recovery keys (its pll_bw = the module's "pll_bw", the FRAME PLL's loop bandwidth; constellation is ignored; exact = 1 selects the
+       serial schedules everywhere: bit for bit the reference's blocks chained the way the module chains them, freq_prop_factor = 0 only). */
+    typedef struct sdhip_dvbs2_cfg
+    {
+        sdhip_demod_cfg front;        /* "samplerate", "symbolrate", "rrc_alpha", "rrc_taps", "pll_bw", "agc_rate", "dc_block", "iq_swap", "buffer_size", "clock_*" ... */
+        float freq_prop_factor;       /* "freq_prop_factor", default 0.01: share of the PLL's frequency handed to the rotator in front of the PL
+                                         synchroniser per frame (module_dvbs2_demod.cpp:204-206). Applied at call boundaries in closed form -- see
+                                         dvbs2_engine.hip's header: the reference's own feedback runs on thread timing */
+        int modcod;                   /* "modcod" (mandatory) */
+        int shortframes;              /* "shortframes" */
+        int pilots;                   /* "pilots" */
+        float sof_thresold;           /* "sof_thresold" (sic), default 0.6 */
+        int ldpc_trials;              /* "ldpc_trials", default 10 */
+        int ldpc_batch;               /* dvbs2::simd_type::SIZE of the build being replaced: frames per BBFrameLDPC::decode call sharing one early exit
+                                         (16 with SSE4.1, 1 generic); frames wait in the handle until a group is full, as in process_s2 */
+        const int8_t *lut_bits;       /* HOST: constellation_t::make_lut(lut_resolution)'s soft bits [x][y][bit] (module_dvbs2_demod.cpp:123-124) */
+        const float *lut_phase_error; /* HOST: the same table's phase errors [x][y] (:114-115); both are copied at create */
+        int lut_resolution;           /* 256 */
+    } sdhip_dvbs2_cfg;
+    typedef struct sdhip_dvbs2_stats
+    {
+        uint64_t samples_in;   /* baseband samples consumed */
+        uint64_t plframes;     /* frames the PL synchroniser emitted */
+        uint64_t bbframes;     /* BBFRAMEs written */
+        float snr, peak_snr;   /* "snr", "peak_snr": M2M4 estimate over the last frame's slots */
+        float freq_hz;         /* "freq": rad_to_hz(current_freq / final_sps, final_samplerate) -- the rotator's share, as in the module */
+        float pll_freq;        /* S2PLLBlock::getFreq() behind the last frame, rad / symbol */
+        float ldpc_trials;     /* "ldpc_trials" of the last decoder group (max trials when it did not converge) */
+        float bch_corrections; /* "bch_corrections" of the last frame */
+        int detected_modcod, detected_shortframes, detected_pilots; /* S2BBToSoft's PLS decode of the last frame (-1 before the first) */
+        uint32_t pll_lanes, pll_rerun, pll_forced, pll_serial_frames; /* the frame PLL's schedule, summed over the calls: lanes, lanes re-run from the
+                                                                         exact predecessor state, boundaries let through unlocked, frames walked serially */
+    } sdhip_dvbs2_stats;
+    void sdhip_dvbs2_cfg_default(sdhip_dvbs2_cfg *cfg);
+    void *sdhip_dvbs2_demod_create(const sdhip_dvbs2_cfg *cfg); /* NULL on error; the messages are the module's / get_dvbs2_cfg's */
+    void sdhip_dvbs2_demod_destroy(void *h);
+    int sdhip_dvbs2_demod_bbframe_bytes(void *h);
+    /* Host-buffer path (what the pipeline module calls): append samples; whole batches are processed as they fill, flush processes the rest. */
+    int sdhip_dvbs2_demod_push(void *h, const void *iq, size_t nsamples, int fmt);
+    int sdhip_dvbs2_demod_flush(void *h);
+    /* Pop up to cap_frames BBFRAMEs (bbframe_bytes each). Returns the frame count. */
+    int64_t sdhip_dvbs2_demod_pull(void *h, uint8_t *bbframes, size_t cap_frames);
+    /* Device-resident path: nsamples baseband samples already in HBM -> the BBFRAMEs this call completes, written to d_bbframes (device).
+       Returns the frame count, <0 on error. Stream state carries across calls. */
+    int64_t sdhip_dvbs2_demod_process_dev(void *h, const void *d_iq, size_t nsamples, int fmt, uint8_t *d_bbframes, size_t cap_frames);
+    /* The same behind the clock recovery: nsyms clock-recovered symbols (complex floats, device) enter at the rotator / PL synchroniser. */
+    int64_t sdhip_dvbs2_demod_symbols_dev(void *h, const float *d_syms, size_t nsyms, uint8_t *d_bbframes, size_t cap_frames);
+    int sdhip_dvbs2_demod_get_stats(void *h, sdhip_dvbs2_stats *st);
 
     /* ---- misc ------------------------------------------------------------------------ */
     const char *sdhip_last_error(void);

@@ -73,6 +73,18 @@ class LdpcInfo(C.Structure):
                 ("layers_with_shared_bits", C.c_int), ("msg_bytes_per_frame", C.c_uint64)]
 
 
+class Dvbs2Cfg(C.Structure):
+    """sdhip_dvbs2_cfg (include/sdhip.h): DVBS2DemodModule's JSON keys."""
+    _fields_ = [("front", DemodCfg), ("freq_prop_factor", C.c_float), ("modcod", C.c_int), ("shortframes", C.c_int), ("pilots", C.c_int), ("sof_thresold", C.c_float),
+                ("ldpc_trials", C.c_int), ("ldpc_batch", C.c_int), ("lut_bits", C.c_void_p), ("lut_phase_error", C.c_void_p), ("lut_resolution", C.c_int)]
+
+
+class Dvbs2Stats(C.Structure):
+    _fields_ = [("samples_in", C.c_uint64), ("plframes", C.c_uint64), ("bbframes", C.c_uint64), ("snr", C.c_float), ("peak_snr", C.c_float), ("freq_hz", C.c_float),
+                ("pll_freq", C.c_float), ("ldpc_trials", C.c_float), ("bch_corrections", C.c_float), ("detected_modcod", C.c_int), ("detected_shortframes", C.c_int),
+                ("detected_pilots", C.c_int), ("pll_lanes", C.c_uint32), ("pll_rerun", C.c_uint32), ("pll_forced", C.c_uint32), ("pll_serial_frames", C.c_uint32)]
+
+
 # dvbs2_code_rate_t (common/codings/dvb-s2/dvbs2.h:9-23)
 S2_RATES = {"1/4": 0, "1/3": 1, "2/5": 2, "1/2": 3, "3/5": 4, "2/3": 5, "3/4": 6, "4/5": 7, "5/6": 8, "7/8": 9, "8/9": 10, "9/10": 11}
 
@@ -172,6 +184,24 @@ def lib():
             L.sdhip_op_atan2f.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
             L.sdhip_s2_pl_sync_dev.restype = C.c_int64
             L.sdhip_s2_pl_sync_dev.argtypes = [C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int, C.c_size_t, C.c_void_p, C.c_void_p]
+        if hasattr(L, "sdhip_s2_pll_frames_dev"):
+            L.sdhip_s2_pll_frames_dev.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
+                                                  C.c_void_p]
+        if hasattr(L, "sdhip_dvbs2_demod_create"):
+            L.sdhip_dvbs2_cfg_default.argtypes = [C.POINTER(Dvbs2Cfg)]
+            L.sdhip_dvbs2_demod_create.restype = C.c_void_p
+            L.sdhip_dvbs2_demod_create.argtypes = [C.POINTER(Dvbs2Cfg)]
+            L.sdhip_dvbs2_demod_destroy.argtypes = [C.c_void_p]
+            L.sdhip_dvbs2_demod_bbframe_bytes.argtypes = [C.c_void_p]
+            L.sdhip_dvbs2_demod_push.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+            L.sdhip_dvbs2_demod_flush.argtypes = [C.c_void_p]
+            L.sdhip_dvbs2_demod_pull.restype = C.c_int64
+            L.sdhip_dvbs2_demod_pull.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+            L.sdhip_dvbs2_demod_process_dev.restype = C.c_int64
+            L.sdhip_dvbs2_demod_process_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_size_t]
+            L.sdhip_dvbs2_demod_symbols_dev.restype = C.c_int64
+            L.sdhip_dvbs2_demod_symbols_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+            L.sdhip_dvbs2_demod_get_stats.argtypes = [C.c_void_p, C.POINTER(Dvbs2Stats)]
         L.sdhip_prof_enable.argtypes = [C.c_int]
         L.sdhip_pool_enable.argtypes = [C.c_int]
         L.sdhip_prof_get.argtypes = [C.c_int, C.c_char_p, C.c_size_t, C.POINTER(C.c_double), C.POINTER(C.c_longlong)]

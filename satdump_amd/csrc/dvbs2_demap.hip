@@ -17,8 +17,10 @@
 // All byte / index work apart from one double division per component: HBM-bound (8 B in, `bits` B out per symbol), a thread per OUTPUT symbol.
 #include "../../include/sdhip.h"
 #include "common.h"
+#include "dvbs2_stages.h"
 
 #include <algorithm>
+#include <mutex>
 #include <cmath>
 #include <cstring>
 #include <vector>
@@ -64,11 +66,7 @@ namespace sdhip
             rn[i] = (unsigned char)(z[i] | (z[i + 131072] << 1));
     }
     // get_dvbs2_cfg (codings/dvb-s2/modcod_to_cfg.h:19-151): MODCOD -> modulation (bits per symbol), slots per frame, code rate (dvbs2_code_rate_t)
-    struct S2Cfg
-    {
-        int bits, slots, rate, constellation;
-    };
-    static S2Cfg s2_cfg_of(int modcod, int shortframes)
+    S2Cfg s2_cfg_of(int modcod, int shortframes)
     {
         static const int qpsk[11] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 10, 11};                  // 1/4 1/3 2/5 1/2 3/5 2/3 3/4 4/5 5/6 8/9 9/10
         static const int psk8[6] = {4, 5, 6, 8, 10, 11}, apsk16[6] = {5, 6, 7, 8, 10, 11}; // 3/5 2/3 3/4 5/6 8/9 9/10 | 2/3 3/4 4/5 5/6 8/9 9/10
@@ -426,13 +424,54 @@ namespace sdhip
         if (i < n)
             out[i] = s2_atan2f(y[i], x[i]);
     }
-    struct S2PllState
+    struct S2PllCtx
     {
-        float phase, freq;
+        float alpha, beta;
+        const float2 *hdr;    // 90 known header symbols
+        const float *lut_err; // the demapper table's phase errors
+        int res;
     };
-    __global__ __launch_bounds__(64) void k_s2_pll_seq(const float2 *__restrict__ in, float2 *__restrict__ out, int stride, int nframes, int per_frame, float alpha, float beta,
-                                                       const float2 *__restrict__ hdr /* 90 known header symbols */, const float *__restrict__ lut_err, int res,
-                                                       S2PllState *state)
+    // one step of S2PLLBlock::work's loop (dvbs2_pll.cpp:31-62) on symbol i of a frame: every float operation where the reference has it
+    __device__ __forceinline__ float2 s2_pll_step(const S2PllCtx &c, int i, const float2 v, float &phase, float &freq)
+    {
+        float sn, cs;
+        s2_sincosf(-phase, sn, cs);
+        const float tr = (v.x * cs) - (v.y * sn);
+        const float ti = (v.y * cs) + (v.x * sn);
+        float error;
+        float2 o;
+        if (i >= 90)
+        { // constellation->demod_soft_lut(tmp_val, nullptr, &error), constellation.cpp:324-352
+            int ix = (int)(((double)tr / 1.5) * (double)c.res + (double)(c.res / 2));
+            int iy = (int)(((double)ti / 1.5) * (double)c.res + (double)(c.res / 2));
+            ix = ix < 0 ? 0 : (ix >= c.res ? c.res - 1 : ix);
+            iy = iy < 0 ? 0 : (iy >= c.res ? c.res - 1 : iy);
+            error = c.lut_err[(size_t)ix * c.res + iy];
+            o = make_float2(tr, ti);
+        }
+        else
+        { // (tmp_val * known.conj()).arg(): (a.re * b.re - a.im * b.im, a.im * b.re + a.re * b.im) with b = (k.x, -k.y)
+            const float2 k = c.hdr[i];
+            const float nb = -k.y;
+            const float pr = (tr * k.x) - (ti * nb);
+            const float pim = (ti * k.x) + (tr * nb);
+            error = s2_atan2f(pim, pr);
+            o = (i & 1) ? make_float2(-tr, ti) : make_float2(ti, tr);
+        }
+        freq = freq + c.beta * error;
+        phase = phase + (freq + c.alpha * error);
+        // while (phase > 2 pi) phase -= 2 pi; while (phase < -2 pi) phase += 2 pi: float compared with the double constant, the step in double
+        while ((double)phase > 2.0 * 3.14159265358979323846)
+            phase = (float)((double)phase - 2.0 * 3.14159265358979323846);
+        while ((double)phase < -2.0 * 3.14159265358979323846)
+            phase = (float)((double)phase + 2.0 * 3.14159265358979323846);
+        if (freq > 1.0f)
+            freq = 1.0f;
+        if (freq < -1.0f)
+            freq = -1.0f;
+        return o;
+    }
+    __global__ __launch_bounds__(64) void k_s2_pll_seq(const float2 *__restrict__ in, float2 *__restrict__ out, int stride, int nframes, int per_frame, S2PllCtx c, S2PllState *state)
     {
         if (blockIdx.x != 0 || threadIdx.x != 0)
             return;
@@ -442,46 +481,342 @@ namespace sdhip
             const float2 *x = in + (size_t)f * stride;
             float2 *o = out + (size_t)f * stride;
             for (int i = 0; i < per_frame; i++)
-            {
-                float sn, cs;
-                s2_sincosf(-phase, sn, cs);
-                const float2 v = x[i];
-                const float tr = (v.x * cs) - (v.y * sn);
-                const float ti = (v.y * cs) + (v.x * sn);
-                float error;
-                if (i >= 90)
-                { // constellation->demod_soft_lut(tmp_val, nullptr, &error), constellation.cpp:324-352
-                    int ix = (int)(((double)tr / 1.5) * (double)res + (double)(res / 2));
-                    int iy = (int)(((double)ti / 1.5) * (double)res + (double)(res / 2));
-                    ix = ix < 0 ? 0 : (ix >= res ? res - 1 : ix);
-                    iy = iy < 0 ? 0 : (iy >= res ? res - 1 : iy);
-                    error = lut_err[(size_t)ix * res + iy];
-                    o[i] = make_float2(tr, ti);
-                }
-                else
-                { // (tmp_val * known.conj()).arg(): (a.re * b.re - a.im * b.im, a.im * b.re + a.re * b.im) with b = (k.x, -k.y)
-                    const float2 k = hdr[i];
-                    const float nb = -k.y;
-                    const float pr = (tr * k.x) - (ti * nb);
-                    const float pim = (ti * k.x) + (tr * nb);
-                    error = s2_atan2f(pim, pr);
-                    o[i] = (i & 1) ? make_float2(-tr, ti) : make_float2(ti, tr);
-                }
-                freq = freq + beta * error;
-                phase = phase + (freq + alpha * error);
-                // while (phase > 2 pi) phase -= 2 pi; while (phase < -2 pi) phase += 2 pi: float compared with the double constant, the step in double
-                while ((double)phase > 2.0 * 3.14159265358979323846)
-                    phase = (float)((double)phase - 2.0 * 3.14159265358979323846);
-                while ((double)phase < -2.0 * 3.14159265358979323846)
-                    phase = (float)((double)phase + 2.0 * 3.14159265358979323846);
-                if (freq > 1.0f)
-                    freq = 1.0f;
-                if (freq < -1.0f)
-                    freq = -1.0f;
-            }
+                o[i] = s2_pll_step(c, i, x[i], phase, freq);
         }
         state->phase = phase;
         state->freq = freq;
+    }
+
+    // ---- the frame-parallel schedule of the same loop (round 4) ---------------------------------------------------------------------
+    // The loop's steps over a batch of frames form ONE chain g = f * per_frame + i. It is cut into lanes of L steps; a lane starts W steps in
+    // front of its range (on the previous frame's tail where it has to) from a DATA-AIDED estimate -- every frame begins with 90 known symbols:
+    // z_f = sum conj(known) * received is the loop's phase at the header's centre, consecutive headers give the frequency (the carried loop
+    // frequency only picks the 2 pi / per_frame branch) -- walks the warm-up without storing, leaves the state it reaches its range with
+    // (`start`), then its range with stores, and leaves its end state. Lane 0 continues the carried state exactly. The host certifies the
+    // chain: start[l] against end[l - 1] (phase modulo the turn, frequency), re-runs the lanes that miss from their predecessor's exact end state.
+    // What this can promise is NOT symbols within 1e-5 of the serial loop's: the detector is a 256 x 256 table (piecewise-constant feedback), two
+    // trajectories of the loop on the same symbols hover ~1e-2 (8PSK, 10 dB) ... 2e-4 (QPSK, 8 dB) of a symbol apart for good
+    // (tools/s2_pll_frame_study.py) -- the contract is the decoders' output: the same BBFRAMEs.
+    __global__ __launch_bounds__(64) void k_s2_hdr_est(const float2 *__restrict__ in, int stride, int nframes, const float2 *__restrict__ hdr, double2 *__restrict__ z)
+    {
+        const int f = (int)blockIdx.x, t = (int)threadIdx.x;
+        if (f >= nframes)
+            return;
+        double re = 0.0, im = 0.0;
+        for (int i = t; i < 90; i += 64)
+        {
+            const float2 v = in[(size_t)f * stride + i], k = hdr[i];
+            re += (double)v.x * k.x + (double)v.y * k.y; // received * conj(known)
+            im += (double)v.y * k.x - (double)v.x * k.y;
+        }
+        for (int o = 32; o > 0; o >>= 1)
+        {
+            re += __shfl_xor(re, o);
+            im += __shfl_xor(im, o);
+        }
+        if (t == 0)
+            z[f] = make_double2(re, im);
+    }
+    struct S2PllLane
+    {
+        long long g0, g1;  // the lane's range of chain steps
+        int warm;          // steps walked in front of g0 (0: the lane continues `from` exactly)
+        int from;          // >= 0: start from end[from]; -1: from the carried state; -2: from the estimate
+    };
+    __global__ __launch_bounds__(64) void k_s2_pll_lanes(const float2 *__restrict__ in, float2 *__restrict__ out, int stride, int per_frame, S2PllCtx c,
+                                                         const S2PllLane *__restrict__ lanes, const int *__restrict__ list, int nlist, const double2 *__restrict__ z, int nframes,
+                                                         float freq_hint, const S2PllState *__restrict__ carried, S2PllState *__restrict__ start, S2PllState *__restrict__ end)
+    {
+        const int k = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+        if (k >= nlist)
+            return;
+        const int l = list ? list[k] : k;
+        const S2PllLane ln = lanes[l];
+        float phase, freq;
+        long long g = ln.g0 - ln.warm;
+        if (ln.from >= 0)
+        {
+            phase = end[ln.from].phase;
+            freq = end[ln.from].freq;
+        }
+        else if (ln.from == -1)
+        {
+            phase = carried->phase;
+            freq = carried->freq;
+        }
+        else
+        { // estimate at step g from the header of the frame g0 lies in (and its neighbour's)
+            const int F = (int)(ln.g0 / per_frame);
+            const int A = F > 0 ? F - 1 : 0, B = F > 0 ? F : (nframes > 1 ? 1 : 0);
+            double fr = (double)freq_hint;
+            if (B != A)
+            {
+                const double2 za = z[A], zb = z[B];
+                const double d = atan2(zb.y * za.x - zb.x * za.y, zb.x * za.x + zb.y * za.y); // arg(zb * conj(za))
+                const double turns = rint((fr * (double)per_frame - d) / (2.0 * 3.14159265358979323846));
+                fr = (d + 2.0 * 3.14159265358979323846 * turns) / (double)per_frame;
+            }
+            const double2 zf = z[F];
+            double ph = atan2(zf.y, zf.x) + fr * ((double)(g - (long long)F * per_frame) - 44.5);
+            ph -= 2.0 * 3.14159265358979323846 * rint(ph / (2.0 * 3.14159265358979323846));
+            phase = (float)ph;
+            freq = (float)fr;
+        }
+        int f = (int)(g / per_frame), i = (int)(g - (long long)f * per_frame);
+        const float2 *x = in + (size_t)f * stride;
+        for (; g < ln.g0; g++)
+        { // warm-up: the loop runs, nothing is stored
+            (void)s2_pll_step(c, i, x[i], phase, freq);
+            if (++i == per_frame)
+            {
+                i = 0;
+                f++;
+                x = in + (size_t)f * stride;
+            }
+        }
+        start[l].phase = phase;
+        start[l].freq = freq;
+        float2 *o = out + (size_t)f * stride;
+        for (; g < ln.g1; g++)
+        {
+            o[i] = s2_pll_step(c, i, x[i], phase, freq);
+            if (++i == per_frame)
+            {
+                i = 0;
+                f++;
+                x = in + (size_t)f * stride;
+                o = out + (size_t)f * stride;
+            }
+        }
+        end[l].phase = phase;
+        end[l].freq = freq;
+    }
+
+    // ---- host side of the frame PLL ----------------------------------------------------------------------------------------------------------
+    int s2_raw_frame_size(int slot_number, int pilots)
+    { // S2PLSyncBlock's constructor, dvbs2_pl_sync.cpp:12-30
+        int raw = (slot_number + 1) * 90;
+        if (pilots)
+        {
+            int raw_size = (raw - 90) / 90, pilot_cnt = 1;
+            raw_size -= 16;
+            while (raw_size > 16)
+            {
+                raw_size -= 16;
+                pilot_cnt++;
+            }
+            raw += pilot_cnt * 36;
+        }
+        return raw;
+    }
+    int s2_pll_walked(int slots, int pilots)
+    { // S2PLLBlock::update(), dvbs2_pll.h:33-47 (frame_slot_count is the SLOT count: the loop below it never runs, one pilot block is counted)
+        int pilot_cnt = 0;
+        if (pilots)
+        {
+            int raw_size = (slots - 90) / 90;
+            pilot_cnt = 1;
+            raw_size -= 16;
+            while (raw_size > 16)
+            {
+                raw_size -= 16;
+                pilot_cnt++;
+            }
+        }
+        return (slots + 1) * 90 + pilot_cnt * 36;
+    }
+    static long env_long(const char *name, long dflt)
+    {
+        const char *v = getenv(name);
+        return (v && *v) ? atol(v) : dflt;
+    }
+    struct S2PllImpl
+    {
+        int device = 0, per_frame = 0;
+        S2PllCtx ctx{};
+        DevBuf<float2> d_hdr;
+        DevBuf<float> d_lut;
+        DevBuf<S2PllState> d_state, d_start, d_end;
+        DevBuf<double2> d_z;
+        DevBuf<S2PllLane> d_lanes;
+        DevBuf<int> d_list;
+        std::vector<S2PllLane> lanes;
+        std::vector<S2PllState> h_start, h_end;
+        std::vector<int> list;
+    };
+    S2Pll::S2Pll(int device, int modcod, int shortframes, int pilots, float loop_bw, const float *lut_phase_error, int lut_resolution, bool exact_) : exact(exact_), im(new S2PllImpl)
+    {
+        const S2Cfg c = s2_cfg_of(modcod, shortframes ? 1 : 0);
+        if (!lut_phase_error || lut_resolution < 2 || lut_resolution > 4096)
+            throw HipError("dvbs2 pll: the demapper table's phase errors and the loop state must be handed over");
+        state = S2PllState{0.0f, 0.0f};
+        im->device = device;
+        im->per_frame = s2_pll_walked(c.slots, pilots);
+        SD_HIP(hipSetDevice(device));
+        // loop gains, dvbs2_pll.cpp:8-12 (the Costas block's expression)
+        const float damping = sqrtf(2.0f) / 2.0f;
+        const float denom = (float)(1.0 + 2.0 * damping * loop_bw + loop_bw * loop_bw);
+        im->ctx.alpha = (4 * damping * loop_bw) / denom;
+        im->ctx.beta = (4 * loop_bw * loop_bw) / denom;
+        // known header: s2_sof / s2_plscodes symbols (dvbs2/s2_defs.h:16-36, 74-80), computed with the host's cosf / sinf / sqrtf like the reference's tables
+        float2 hdr[90];
+        for (int s = 0; s < 26; s++)
+        {
+            const bool bit = (0x18d2e82u >> (25 - s)) & 1u;
+            const int angle = bit * 2 + (s & 1);
+            hdr[s].x = 1 * cosf(M_PI / 4 + 2 * M_PI * angle / 4);
+            hdr[s].y = 1 * sinf(M_PI / 4 + 2 * M_PI * angle / 4);
+        }
+        unsigned long long cw[128];
+        s2_pls_codewords(cw);
+        const unsigned long long code = cw[(modcod << 2) | ((shortframes ? 1 : 0) << 1) | (pilots ? 1 : 0)];
+        for (int i = 0; i < 64; i++)
+        {
+            const int yi = (int)((code >> (63 - i)) & 1ull), nyi = yi ^ (i & 1);
+            hdr[26 + i].x = 1 * (1 - 2 * nyi) / sqrtf(2);
+            hdr[26 + i].y = 1 * (1 - 2 * yi) / sqrtf(2);
+        }
+        im->d_hdr.reserve(90);
+        im->d_lut.reserve((size_t)lut_resolution * lut_resolution);
+        im->d_state.reserve(1);
+        SD_HIP(hipMemcpy(im->d_hdr.p, hdr, sizeof(hdr), hipMemcpyHostToDevice));
+        SD_HIP(hipMemcpy(im->d_lut.p, lut_phase_error, (size_t)lut_resolution * lut_resolution * sizeof(float), hipMemcpyHostToDevice));
+        im->ctx.hdr = im->d_hdr.p;
+        im->ctx.lut_err = im->d_lut.p;
+        im->ctx.res = lut_resolution;
+    }
+    S2Pll::~S2Pll() = default;
+    int S2Pll::per_frame() const { return im->per_frame; }
+    void S2Pll::add_frequency(float df) { state.freq += df; }
+    static bool s2_state_close(const S2PllState &a, const S2PllState &b, double tol_p, double tol_f)
+    {
+        double d = (double)a.phase - (double)b.phase;
+        d -= 2.0 * M_PI * rint(d / (2.0 * M_PI));
+        return fabs(d) < tol_p && fabs((double)a.freq - (double)b.freq) < tol_f;
+    }
+    void S2Pll::run(const float *d_in, float *d_out, int stride, int nframes, hipStream_t st)
+    {
+        S2PllImpl &m = *im;
+        stats = S2PllStats{};
+        if (nframes <= 0)
+            return;
+        if (stride < m.per_frame)
+            throw HipError("dvbs2 pll: frame_stride shorter than the symbols the loop walks");
+        SD_HIP(hipSetDevice(m.device));
+        const float2 *in = reinterpret_cast<const float2 *>(d_in);
+        float2 *out = reinterpret_cast<float2 *>(d_out);
+        auto serial = [&](int f0, int nf)
+        {
+            SD_HIP(hipMemcpyAsync(m.d_state.p, &state, sizeof(state), hipMemcpyHostToDevice, st));
+            {
+                ProfScope _ps("k_s2_pll_seq", st);
+                hipLaunchKernelGGL(k_s2_pll_seq, dim3(1), dim3(64), 0, st, in + (size_t)f0 * stride, out + (size_t)f0 * stride, stride, nf, m.per_frame, m.ctx, m.d_state.p);
+            }
+            SD_HIP(hipMemcpyAsync(&state, m.d_state.p, sizeof(state), hipMemcpyDeviceToHost, st));
+            SD_HIP(hipStreamSynchronize(st));
+            stats.serial_frames += (unsigned)nf;
+        };
+        if (exact)
+        {
+            serial(0, nframes);
+            return;
+        }
+        int f0 = 0;
+        if (!have_hint)
+        { // a new stream: the loop acquires on its own (the estimates need its frequency to pick their 2 pi / per_frame branch)
+            const long acq_syms = env_long("SDHIP_S2PLL_ACQ", 65536);
+            const int acq = (int)std::min<long>(nframes, std::max<long>(2, (acq_syms + m.per_frame - 1) / m.per_frame));
+            serial(0, acq);
+            f0 = acq;
+            have_hint = true;
+            if (f0 >= nframes)
+                return;
+        }
+        const int nf = nframes - f0;
+        in += (size_t)f0 * stride;
+        out += (size_t)f0 * stride;
+        const long long total = (long long)nf * m.per_frame;
+        const long W = std::max<long>(0, env_long("SDHIP_S2PLL_W", 2048));
+        long L = env_long("SDHIP_S2PLL_L", 0);
+        if (L <= 0)
+            L = std::max<long long>(4096, (total + 4095) / 4096);
+        L = std::max<long>(L, std::max<long>(W, 64));
+        const double tol_p = (double)env_long("SDHIP_S2PLL_TOL_MRAD", 80) * 1e-3, tol_f = (double)env_long("SDHIP_S2PLL_TOL_UFREQ", 100) * 1e-6;
+        const int max_rounds = (int)env_long("SDHIP_S2PLL_ROUNDS", 4);
+        m.lanes.clear();
+        for (long long g = 0; g < total; g += L)
+        {
+            S2PllLane ln;
+            ln.g0 = g;
+            ln.g1 = std::min<long long>(total, g + L);
+            ln.warm = g == 0 ? 0 : (int)std::min<long long>(W, g);
+            ln.from = g == 0 ? -1 : -2;
+            m.lanes.push_back(ln);
+        }
+        const int nl = (int)m.lanes.size();
+        stats.lanes = (unsigned)nl;
+        m.d_lanes.reserve(nl);
+        m.d_start.reserve(nl);
+        m.d_end.reserve(nl);
+        m.d_z.reserve(nf);
+        m.d_list.reserve(nl);
+        SD_HIP(hipMemcpyAsync(m.d_lanes.p, m.lanes.data(), nl * sizeof(S2PllLane), hipMemcpyHostToDevice, st));
+        SD_HIP(hipMemcpyAsync(m.d_state.p, &state, sizeof(state), hipMemcpyHostToDevice, st));
+        {
+            ProfScope _ps("k_s2_hdr_est", st);
+            hipLaunchKernelGGL(k_s2_hdr_est, dim3((unsigned)nf), dim3(64), 0, st, in, stride, nf, m.ctx.hdr, m.d_z.p);
+        }
+        {
+            ProfScope _ps("k_s2_pll_lanes", st);
+            hipLaunchKernelGGL(k_s2_pll_lanes, dim3((unsigned)((nl + 63) / 64)), dim3(64), 0, st, in, out, stride, m.per_frame, m.ctx, m.d_lanes.p, (const int *)nullptr, nl, m.d_z.p, nf,
+                               state.freq, m.d_state.p, m.d_start.p, m.d_end.p);
+        }
+        m.h_start.resize(nl);
+        m.h_end.resize(nl);
+        auto fetch = [&]()
+        {
+            SD_HIP(hipMemcpyAsync(m.h_start.data(), m.d_start.p, nl * sizeof(S2PllState), hipMemcpyDeviceToHost, st));
+            SD_HIP(hipMemcpyAsync(m.h_end.data(), m.d_end.p, nl * sizeof(S2PllState), hipMemcpyDeviceToHost, st));
+            SD_HIP(hipStreamSynchronize(st));
+        };
+        fetch();
+        // certify the chain: a lane's start state (behind its warm-up) against its predecessor's end state. Lanes that miss are re-run from the
+        // predecessor's EXACT end state -- only the heads of runs of missing lanes can be (their predecessor is settled); after max_rounds the rest is
+        // re-run once from whatever their predecessors ended with and let through (a stream the loop is not locked on: noise)
+        for (int round = 0;; round++)
+        {
+            m.list.clear();
+            std::vector<char> bad(nl, 0);
+            for (int l = 1; l < nl; l++)
+                bad[l] = !s2_state_close(m.h_start[l], m.h_end[l - 1], tol_p, tol_f);
+            const bool last = round >= max_rounds;
+            for (int l = 1; l < nl; l++)
+                if (bad[l] && (last || !bad[l - 1]))
+                    m.list.push_back(l);
+            if (m.list.empty())
+                break;
+            for (int l : m.list)
+            {
+                m.lanes[l].warm = 0;
+                m.lanes[l].from = l - 1;
+            }
+            SD_HIP(hipMemcpyAsync(m.d_lanes.p, m.lanes.data(), nl * sizeof(S2PllLane), hipMemcpyHostToDevice, st));
+            SD_HIP(hipMemcpyAsync(m.d_list.p, m.list.data(), m.list.size() * sizeof(int), hipMemcpyHostToDevice, st));
+            {
+                ProfScope _ps("k_s2_pll_lanes", st);
+                hipLaunchKernelGGL(k_s2_pll_lanes, dim3((unsigned)((m.list.size() + 63) / 64)), dim3(64), 0, st, in, out, stride, m.per_frame, m.ctx, m.d_lanes.p, m.d_list.p,
+                                   (int)m.list.size(), m.d_z.p, nf, state.freq, m.d_state.p, m.d_start.p, m.d_end.p);
+            }
+            if (last)
+            {
+                stats.forced += (unsigned)m.list.size();
+                fetch();
+                break;
+            }
+            stats.rerun += (unsigned)m.list.size();
+            fetch();
+        }
+        state = m.h_end[nl - 1];
     }
 
     struct S2DemapCache
@@ -521,17 +856,21 @@ extern "C"
         if (nframes <= 0)
             return 0;
         SD_HIP(hipSetDevice(device));
-        static thread_local S2DemapCache T; // tables of the calling thread's last configuration
-        if (T.device != device)
-        { // tables live on one device
-            T.d_cw.release();
-            T.d_rn.release();
-            T.d_lut.release();
-            T.d_slots.release();
-            T.rn_count = 0;
-            T.lut_host.clear();
-            T.device = device;
+        // the stage's tables, one set per device, shared by every caller (the call is serialised: the scratch rows are part of the set); never
+        // destroyed at exit -- their device buffers would be freed behind the HIP runtime's own teardown
+        static std::mutex mu;
+        static std::vector<S2DemapCache *> caches;
+        std::lock_guard<std::mutex> lk(mu);
+        if (device < 0 || device > 1023)
+            throw HipError("dvbs2 bb_to_soft: device ordinal out of range");
+        if ((int)caches.size() <= device)
+            caches.resize(device + 1, nullptr);
+        if (!caches[device])
+        {
+            caches[device] = new S2DemapCache;
+            caches[device]->device = device;
         }
+        S2DemapCache &T = *caches[device];
         if (!T.d_cw.p)
         {
             unsigned long long cw[128];
@@ -584,19 +923,7 @@ extern "C"
         SD_GUARD_BEGIN
         if (slot_number <= 0 || slot_number > 360)
             throw HipError("dvbs2 pl_sync: slot_number out of range");
-        // S2PLSyncBlock's constructor, dvbs2_pl_sync.cpp:12-30
-        int raw = (slot_number + 1) * 90;
-        if (pilots)
-        {
-            int raw_size = (raw - 90) / 90, pilot_cnt = 1;
-            raw_size -= 16;
-            while (raw_size > 16)
-            {
-                raw_size -= 16;
-                pilot_cnt++;
-            }
-            raw += pilot_cnt * 36;
-        }
+        const int raw = s2_raw_frame_size(slot_number, pilots);
         if (frame_stride < raw)
             throw HipError("dvbs2 pl_sync: frame_stride shorter than the raw frame");
         if (consumed)
@@ -673,70 +1000,53 @@ extern "C"
     int sdhip_s2_pll_dev(int device, int modcod, int shortframes, int pilots, float loop_bw, const float *d_frames_in, float *d_frames_out, int frame_stride, int nframes,
                          const float *lut_phase_error, int lut_resolution, float *state2)
     {
+        return sdhip_s2_pll_frames_dev(device, modcod, shortframes, pilots, loop_bw, d_frames_in, d_frames_out, frame_stride, nframes, lut_phase_error, lut_resolution, state2, 1, nullptr);
+    }
+    int sdhip_s2_pll_frames_dev(int device, int modcod, int shortframes, int pilots, float loop_bw, const float *d_frames_in, float *d_frames_out, int frame_stride, int nframes,
+                                const float *lut_phase_error, int lut_resolution, float *state2, int mode, unsigned *stats4)
+    {
         SD_GUARD_BEGIN
-        const S2Cfg c = s2_cfg_of(modcod, shortframes ? 1 : 0);
-        if (!lut_phase_error || lut_resolution < 2 || lut_resolution > 4096 || !state2)
+        if (!state2)
             throw HipError("dvbs2 pll: the demapper table's phase errors and the loop state must be handed over");
-        // S2PLLBlock::update(), dvbs2_pll.h:33-47 (frame_slot_count is the SLOT count: the loop below it never runs, one pilot block is counted)
-        int pilot_cnt = 0;
-        if (pilots)
+        // the table is the caller's data: keep the last runner per calling thread while configuration and table stay the same (a stream of calls
+        // with carried state then uploads nothing); an engine handle (sdhip_dvbs2_demod_create) owns its own
+        struct Key
         {
-            int raw_size = (c.slots - 90) / 90;
-            pilot_cnt = 1;
-            raw_size -= 16;
-            while (raw_size > 16)
-            {
-                raw_size -= 16;
-                pilot_cnt++;
-            }
-        }
-        const int per_frame = (c.slots + 1) * 90 + pilot_cnt * 36;
-        if (frame_stride < per_frame)
-            throw HipError("dvbs2 pll: frame_stride shorter than the symbols the loop walks");
-        if (nframes <= 0)
-            return 0;
-        SD_HIP(hipSetDevice(device));
-        // loop gains, dvbs2_pll.cpp:8-12 (the Costas block's expression)
-        const float damping = sqrtf(2.0f) / 2.0f;
-        const float denom = (float)(1.0 + 2.0 * damping * loop_bw + loop_bw * loop_bw);
-        const float alpha = (4 * damping * loop_bw) / denom, beta = (4 * loop_bw * loop_bw) / denom;
-        // known header: s2_sof / s2_plscodes symbols (dvbs2/s2_defs.h:16-36, 74-80), computed with the host's cosf / sinf / sqrtf like the reference's tables
-        float2 hdr[90];
-        for (int s = 0; s < 26; s++)
+            int device, modcod, sf, pilots, res, exact;
+            float bw;
+            std::vector<float> lut;
+        };
+        static std::mutex mu;
+        static S2Pll *runner = nullptr; // never destroyed at exit: its device buffers would be freed behind the HIP runtime's own teardown
+        static Key key;
+        std::lock_guard<std::mutex> lk(mu);
+        const size_t nl = (lut_phase_error && lut_resolution >= 2 && lut_resolution <= 4096) ? (size_t)lut_resolution * lut_resolution : 0;
+        const bool same = runner && key.device == device && key.modcod == modcod && key.sf == (shortframes ? 1 : 0) && key.pilots == (pilots ? 1 : 0) && key.res == lut_resolution &&
+                          key.bw == loop_bw && key.lut.size() == nl && nl && memcmp(key.lut.data(), lut_phase_error, nl * sizeof(float)) == 0;
+        if (!same)
         {
-            const bool bit = (0x18d2e82u >> (25 - s)) & 1u;
-            const int angle = bit * 2 + (s & 1);
-            hdr[s].x = 1 * cosf(M_PI / 4 + 2 * M_PI * angle / 4);
-            hdr[s].y = 1 * sinf(M_PI / 4 + 2 * M_PI * angle / 4);
+            delete runner;
+            runner = nullptr;
+            runner = new S2Pll(device, modcod, shortframes, pilots, loop_bw, lut_phase_error, lut_resolution, true);
+            key = Key{device, modcod, shortframes ? 1 : 0, pilots ? 1 : 0, lut_resolution, 1, loop_bw, std::vector<float>(lut_phase_error, lut_phase_error + nl)};
         }
-        unsigned long long cw[128];
-        s2_pls_codewords(cw);
-        const unsigned long long code = cw[(modcod << 2) | ((shortframes ? 1 : 0) << 1) | (pilots ? 1 : 0)];
-        for (int i = 0; i < 64; i++)
+        runner->exact = mode == 1;
+        runner->state = S2PllState{state2[0], state2[1]};
+        // mode 0: the frame-parallel schedule with the caller vouching that state2 is a locked loop's (any call but a stream's first); mode 2: the
+        // same on a new stream (the first frames are walked serially)
+        runner->have_hint = mode == 0;
+        if (nframes > 0)
+            runner->run(d_frames_in, d_frames_out, frame_stride, nframes, nullptr);
+        state2[0] = runner->state.phase;
+        state2[1] = runner->state.freq;
+        if (stats4)
         {
-            const int yi = (int)((code >> (63 - i)) & 1ull), nyi = yi ^ (i & 1);
-            hdr[26 + i].x = 1 * (1 - 2 * nyi) / sqrtf(2);
-            hdr[26 + i].y = 1 * (1 - 2 * yi) / sqrtf(2);
+            stats4[0] = runner->stats.lanes;
+            stats4[1] = runner->stats.rerun;
+            stats4[2] = runner->stats.forced;
+            stats4[3] = runner->stats.serial_frames;
         }
-        DevBuf<float2> d_hdr;
-        DevBuf<float> d_lut;
-        DevBuf<S2PllState> d_st;
-        d_hdr.reserve(90);
-        d_lut.reserve((size_t)lut_resolution * lut_resolution);
-        d_st.reserve(1);
-        SD_HIP(hipMemcpy(d_hdr.p, hdr, sizeof(hdr), hipMemcpyHostToDevice));
-        SD_HIP(hipMemcpy(d_lut.p, lut_phase_error, (size_t)lut_resolution * lut_resolution * sizeof(float), hipMemcpyHostToDevice));
-        S2PllState st{state2[0], state2[1]};
-        SD_HIP(hipMemcpy(d_st.p, &st, sizeof(st), hipMemcpyHostToDevice));
-        {
-            ProfScope _ps("k_s2_pll_seq", nullptr);
-            hipLaunchKernelGGL(k_s2_pll_seq, dim3(1), dim3(64), 0, nullptr, reinterpret_cast<const float2 *>(d_frames_in), reinterpret_cast<float2 *>(d_frames_out), frame_stride,
-                               nframes, per_frame, alpha, beta, d_hdr.p, d_lut.p, lut_resolution, d_st.p);
-        }
-        SD_HIP(hipMemcpy(&st, d_st.p, sizeof(st), hipMemcpyDeviceToHost));
-        state2[0] = st.phase;
-        state2[1] = st.freq;
-        return per_frame;
+        return runner->per_frame();
         SD_GUARD_END(-1)
     }
     int sdhip_op_atan2f(int device, const float *d_y, const float *d_x, int n, float *d_out)

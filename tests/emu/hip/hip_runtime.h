@@ -44,6 +44,8 @@ struct alignas(16) int4 { int x, y, z, w; };
 struct alignas(16) uint4 { unsigned x, y, z, w; };
 inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
 inline float2 make_float2(float x, float y) { return float2{x, y}; }
+struct double2 { double x, y; };
+inline double2 make_double2(double x, double y) { return double2{x, y}; }
 
 typedef int hipError_t;
 constexpr hipError_t hipSuccess = 0;
@@ -159,6 +161,14 @@ unsigned long long emu_ballot(int pred);
 inline int emu_lane() { return (int)((threadIdx.x + blockDim.x * (threadIdx.y + blockDim.y * threadIdx.z)) & 63u); }
 inline unsigned long long __ballot(int pred) { return emu_ballot(pred); }
 inline int __shfl_xor(int v, int mask) { return (int)(unsigned)emu_wave_xchg((unsigned)v, emu_lane() ^ mask); }
+inline double __shfl_xor(double v, int mask)
+{
+    unsigned long long u;
+    memcpy(&u, &v, 8);
+    u = emu_wave_xchg(u, emu_lane() ^ mask);
+    memcpy(&v, &u, 8);
+    return v;
+}
 inline int __shfl_down(int v, int d) { return (int)(unsigned)emu_wave_xchg((unsigned)v, emu_lane() + d < 64 ? emu_lane() + d : emu_lane()); }
 inline int __shfl(int v, int lane) { return (int)(unsigned)emu_wave_xchg((unsigned)v, lane & 63); }
 inline int emu_readlane(int v, int lane) { return (int)(unsigned)emu_wave_xchg((unsigned)v, lane & 63); }
