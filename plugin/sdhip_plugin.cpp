@@ -4,6 +4,8 @@
 //   psk_demod_hip                  <- PSKDemodModule              (src-core/pipeline/modules/demod/module_psk_demod.{h,cpp})
 //   ccsds_conv_concat_decoder_hip  <- CCSDSConvConcatDecoderModule (src-core/pipeline/modules/ccsds/module_ccsds_conv_concat_decoder.{h,cpp})
 //   metop_ahrpt_decoder_hip        <- MetOpAHRPTDecoderModule      (plugins/noaa_metop_support/metop/module_metop_ahrpt_decoder.{h,cpp})
+//   ccsds_simple_psk_decoder_hip   <- CCSDSSimplePSKDecoderModule  (src-core/pipeline/modules/ccsds/module_ccsds_simple_psk_decoder.{h,cpp})
+//   dvbs2_demod_hip                <- DVBS2DemodModule             (plugins/dvb_support/dvbs2/module_dvbs2_demod.{h,cpp})
 // during RegisterModulesEvent (src-core/pipeline/module.h:213-216) and, when SDHIP_OVERRIDE=1 is set, re-points the
 // reference ids themselves at these classes from a SatDumpStartedEvent handler (src-core/core/plugin.h:21-23; the
 // registry lookup is first-match, src-core/pipeline/module.cpp:129-135), so existing pipelines run unchanged.
@@ -15,6 +17,9 @@
 #include "logger.h"
 #include "pipeline/module.h"
 #include "pipeline/modules/base/filestream_to_filestream.h"
+
+#include "common/dsp/demod/constellation.h"  // the DVB-S2 module's demapper table is built by the reference's own class (libsatdump_core)
+#include "codings/dvb-s2/modcod_to_cfg.h"    // plugins/dvb_support (header only): get_dvbs2_cfg
 
 #include "../include/sdhip.h"
 #include "sdhip_ndsp_block.h"
@@ -52,6 +57,44 @@ namespace sdhip_plugin
     {
         if (p.count(key) > 0)
             dst = p[key].get<T>();
+    }
+
+    static int baseband_fmt_of(const std::string &baseband_format, const char *who)
+    {
+        if (baseband_format == "cf32" || baseband_format == "f32")
+            return SDHIP_FMT_CF32;
+        if (baseband_format == "cs16" || baseband_format == "s16")
+            return SDHIP_FMT_CS16;
+        if (baseband_format == "cs8" || baseband_format == "s8")
+            return SDHIP_FMT_CS8;
+        if (baseband_format == "cu8" || baseband_format == "u8")
+            return SDHIP_FMT_CU8;
+        if (baseband_format == "cs32" || baseband_format == "s32")
+            return SDHIP_FMT_CS32;
+        throw satdump_exception(std::string(who) + ": baseband_format " + baseband_format + " is not on the HIP path (cf32, cs32, cs16, cs8, cu8)");
+    }
+    // BaseDemodModule's constructor (module_demod_base.cpp:12-57) into the C ABI's struct
+    static void parse_base_demod(const nlohmann::json &parameters, sdhip_demod_cfg &cfg, const char *who)
+    {
+        if (parameters.count("samplerate") > 0)
+            cfg.samplerate = parameters["samplerate"].get<long>();
+        else
+            throw satdump_exception("Samplerate parameter must be present!");
+        opt(parameters, "buffer_size", cfg.buffer_size);
+        if (parameters.count("symbolrate") > 0)
+            cfg.symbolrate = parameters["symbolrate"].get<long>();
+        opt(parameters, "agc_rate", cfg.agc_rate);
+        bool b = false;
+        opt(parameters, "dc_block", b), cfg.dc_block = b;
+        b = false;
+        opt(parameters, "iq_swap", b), cfg.iq_swap = b;
+        opt(parameters, "min_sps", cfg.min_sps);
+        opt(parameters, "max_sps", cfg.max_sps);
+        if (parameters.count("freq_shift") > 0) // module_demod_base.cpp:36-37 (a long)
+            cfg.freq_shift = (double)parameters["freq_shift"].get<long>();
+        // custom_samplerate overrides the resample decision (module_demod_base.cpp:73-74): not a field of the C ABI
+        if (parameters.count("custom_samplerate") > 0)
+            throw satdump_exception(std::string(who) + ": custom_samplerate is not on the HIP path");
     }
 
     // ------------------------------------------------------------------------------------------------ psk_demod
@@ -93,25 +136,8 @@ namespace sdhip_plugin
         {
             sdhip_demod_cfg_default(&cfg);
             // BaseDemodModule ctor (module_demod_base.cpp:12-57) + PSKDemodModule ctor (module_psk_demod.cpp:12-84)
-            if (parameters.count("samplerate") > 0)
-                cfg.samplerate = parameters["samplerate"].get<long>();
-            else
-                throw satdump_exception("Samplerate parameter must be present!");
-            opt(parameters, "buffer_size", cfg.buffer_size);
-            if (parameters.count("symbolrate") > 0)
-                cfg.symbolrate = parameters["symbolrate"].get<long>();
-            opt(parameters, "agc_rate", cfg.agc_rate);
+            parse_base_demod(parameters, cfg, "psk_demod_hip");
             bool b = false;
-            opt(parameters, "dc_block", b), cfg.dc_block = b;
-            b = false;
-            opt(parameters, "iq_swap", b), cfg.iq_swap = b;
-            opt(parameters, "min_sps", cfg.min_sps);
-            opt(parameters, "max_sps", cfg.max_sps);
-            if (parameters.count("freq_shift") > 0) // module_demod_base.cpp:36-37 (a long)
-                cfg.freq_shift = (double)parameters["freq_shift"].get<long>();
-            // custom_samplerate overrides the resample decision (module_demod_base.cpp:73-74): not a field of the C ABI
-            if (parameters.count("custom_samplerate") > 0)
-                throw satdump_exception("psk_demod_hip: custom_samplerate is not on the HIP path, use psk_demod");
             // carrier-tracking front-end (module_psk_demod.cpp:39-40, 93-113; the ODIN pipeline)
             b = false;
             opt(parameters, "has_carrier", b), cfg.has_carrier = b;
@@ -155,18 +181,7 @@ namespace sdhip_plugin
             // engine knobs of the HIP path (no reference equivalent)
             opt(parameters, "hip_device", cfg.device);
             opt(parameters, "hip_exact", cfg.exact);
-            if (baseband_format == "cf32" || baseband_format == "f32")
-                fmt = SDHIP_FMT_CF32;
-            else if (baseband_format == "cs16" || baseband_format == "s16")
-                fmt = SDHIP_FMT_CS16;
-            else if (baseband_format == "cs8" || baseband_format == "s8")
-                fmt = SDHIP_FMT_CS8;
-            else if (baseband_format == "cu8" || baseband_format == "u8")
-                fmt = SDHIP_FMT_CU8;
-            else if (baseband_format == "cs32" || baseband_format == "s32")
-                fmt = SDHIP_FMT_CS32;
-            else
-                throw satdump_exception("psk_demod_hip: baseband_format " + baseband_format + " is not on the HIP path (cf32, cs32, cs16, cs8, cu8)");
+            fmt = baseband_fmt_of(baseband_format, "psk_demod_hip");
         }
         ~PSKDemodHipModule()
         {
@@ -594,6 +609,243 @@ namespace sdhip_plugin
         }
     };
 
+    // ------------------------------------------------------------------------------------------------ dvbs2_demod
+    // DVBS2DemodModule (plugins/dvb_support/dvbs2/module_dvbs2_demod.{h,cpp}) on the handle of include/sdhip.h (sdhip_dvbs2_demod_*): same JSON
+    // keys, defaults and exceptions, baseband file / dsp::stream in, .bbframe file / fifo out, the same statistics keys. What the module builds on the
+    // host with the reference's own class stays the reference's: the demapper table (constellation_t::make_lut(256), module_dvbs2_demod.cpp:
+    // 114-115, 123-124) is built here with that class and handed to the engine as data.
+    class DVBS2DemodHipModule : public ProcessingModule
+    {
+        sdhip_dvbs2_cfg cfg;
+        void *h = nullptr;
+        std::string baseband_format = "cf32";
+        int fmt = SDHIP_FMT_CF32;
+        std::vector<int8_t> lut_bits;
+        std::vector<float> lut_phase;
+        std::atomic<uint64_t> filesize{0}, progress{0};
+        std::atomic<float> display_freq{0}, snr{0}, peak_snr{0}, ldpc_trials{0}, bch_corrections{0};
+        std::atomic<int> detected_modcod{-1};
+        std::atomic<bool> should_stop{false};
+        std::ofstream data_out;
+
+        void build_lut()
+        {
+            auto c = dvbs2::get_dvbs2_cfg(cfg.modcod, cfg.shortframes, cfg.pilots); // throws for MODCOD <= 0 / unsupported, as in init()
+            dsp::constellation_t constellation(c.constel_obj_type, c.g1, c.g2);
+            const int bits = constellation.getBitsCnt(), res = 256;
+            if (bits == 5)
+                throw satdump_exception("dvbs2_demod_hip: 32APSK has no demapper table in the reference (it evaluates the exponentials per sample): not on the HIP path");
+            constellation.make_lut(res);
+            lut_bits.assign((size_t)res * res * bits, 0);
+            lut_phase.assign((size_t)res * res, 0.0f);
+            for (int x = 0; x < res; x++)
+                for (int y = 0; y < res; y++)
+                { // the table's cell (x, y) read back through its public lookup, at the cell's centre (constellation.cpp:324-352)
+                    const complex_t centre((float)((x - res / 2 + 0.5) / res * 1.5), (float)((y - res / 2 + 0.5) / res * 1.5));
+                    constellation.demod_soft_lut(centre, &lut_bits[((size_t)x * res + y) * bits], &lut_phase[(size_t)x * res + y]);
+                }
+            cfg.lut_bits = lut_bits.data();
+            cfg.lut_phase_error = lut_phase.data();
+            cfg.lut_resolution = res;
+        }
+
+    public:
+        DVBS2DemodHipModule(std::string input_file, std::string output_file_hint, nlohmann::json parameters)
+            : ProcessingModule(input_file, output_file_hint, parameters)
+        {
+            sdhip_dvbs2_cfg_default(&cfg);
+            parse_base_demod(parameters, cfg.front, "dvbs2_demod_hip");
+            // DVBS2DemodModule ctor, module_dvbs2_demod.cpp:13-83
+            if (parameters.count("rrc_alpha") > 0)
+                cfg.front.rrc_alpha = parameters["rrc_alpha"].get<float>();
+            else
+                throw satdump_exception("RRC Alpha parameter must be present!");
+            opt(parameters, "rrc_taps", cfg.front.rrc_taps);
+            if (parameters.count("pll_bw") > 0)
+                cfg.front.pll_bw = parameters["pll_bw"].get<float>();
+            else
+                throw satdump_exception("PLL BW parameter must be present!");
+            opt(parameters, "freq_prop_factor", cfg.freq_prop_factor);
+            if (parameters.count("clock_alpha") > 0)
+            {
+                const float clock_alpha = parameters["clock_alpha"].get<float>();
+                cfg.front.clock_gain_omega = pow(clock_alpha, 2) / 4.0;
+                cfg.front.clock_gain_mu = clock_alpha;
+            }
+            opt(parameters, "clock_gain_omega", cfg.front.clock_gain_omega);
+            opt(parameters, "clock_mu", cfg.front.clock_mu);
+            opt(parameters, "clock_gain_mu", cfg.front.clock_gain_mu);
+            opt(parameters, "clock_omega_relative_limit", cfg.front.clock_omega_relative_limit);
+            if (parameters.count("modcod") > 0)
+                cfg.modcod = parameters["modcod"].get<int>();
+            else
+                throw satdump_exception("MODCOD parameter must be present!");
+            bool b = false;
+            opt(parameters, "shortframes", b), cfg.shortframes = b;
+            b = false;
+            opt(parameters, "pilots", b), cfg.pilots = b;
+            opt(parameters, "sof_thresold", cfg.sof_thresold);
+            opt(parameters, "ldpc_trials", cfg.ldpc_trials);
+            // "mt_bch" moves the BCH decoder to a thread of its own in the reference (module_dvbs2_demod.cpp:66-67, 295-325): same output, nothing to do here
+            opt(parameters, "baseband_format", baseband_format);
+            fmt = baseband_fmt_of(baseband_format, "dvbs2_demod_hip");
+            // engine knobs of the HIP path (no reference equivalent). hip_ldpc_batch = dvbs2::simd_type::SIZE of the build being replaced (frames per
+            // BBFrameLDPC::decode call sharing one early exit; the x86-64 build of plugins/dvb_support has SSE4.1: 16): frames wait for a full group
+            // and a trailing partial group is never decoded, exactly as in process_s2
+            cfg.ldpc_batch = 16;
+            opt(parameters, "hip_ldpc_batch", cfg.ldpc_batch);
+            opt(parameters, "hip_device", cfg.front.device);
+            opt(parameters, "hip_exact", cfg.front.exact);
+        }
+        ~DVBS2DemodHipModule()
+        {
+            if (h)
+                sdhip_dvbs2_demod_destroy(h);
+        }
+        static bool covers(const std::string &input_file, const std::string &output_file_hint, const nlohmann::json &parameters, std::string &why)
+        {
+            if (parameters.count("enable_doppler") > 0 && parameters["enable_doppler"].get<bool>())
+            {
+                why = "enable_doppler";
+                return false;
+            }
+            try
+            {
+                DVBS2DemodHipModule probe(input_file, output_file_hint, parameters);
+                probe.build_lut();
+                void *e = sdhip_dvbs2_demod_create(&probe.cfg);
+                if (!e)
+                {
+                    why = sdhip_last_error();
+                    return false;
+                }
+                sdhip_dvbs2_demod_destroy(e);
+                return true;
+            }
+            catch (const std::exception &ex)
+            {
+                why = ex.what();
+                return false;
+            }
+        }
+        std::vector<ModuleDataType> getInputTypes() { return {DATA_FILE, DATA_DSP_STREAM}; }
+        std::vector<ModuleDataType> getOutputTypes() { return {DATA_FILE, DATA_STREAM}; }
+        void init()
+        {
+            build_lut();
+            h = sdhip_dvbs2_demod_create(&cfg);
+            if (!h)
+                throw satdump_exception(std::string("dvbs2_demod_hip: ") + sdhip_last_error());
+            logger->info("Output bbframe bits : %d", sdhip_dvbs2_demod_bbframe_bytes(h) * 8);
+        }
+        void stop() { should_stop = true; }
+        void drain(std::vector<uint8_t> &buf)
+        {
+            const size_t fb = (size_t)sdhip_dvbs2_demod_bbframe_bytes(h);
+            for (;;)
+            {
+                const int64_t n = sdhip_dvbs2_demod_pull(h, buf.data(), buf.size() / fb);
+                if (n < 0)
+                    throw satdump_exception(std::string("dvbs2_demod_hip: ") + sdhip_last_error());
+                if (n == 0)
+                    break;
+                if (output_data_type == DATA_FILE)
+                    data_out.write((char *)buf.data(), n * fb);
+                else
+                    output_fifo->write(buf.data(), n * fb);
+            }
+            sdhip_dvbs2_stats st;
+            sdhip_dvbs2_demod_get_stats(h, &st);
+            display_freq = st.freq_hz;
+            snr = st.snr;
+            peak_snr = st.peak_snr;
+            ldpc_trials = st.ldpc_trials;
+            bch_corrections = st.bch_corrections;
+            detected_modcod = st.detected_modcod;
+        }
+        void process()
+        {
+            if (output_data_type == DATA_FILE)
+            {
+                data_out = std::ofstream(d_output_file_hint + ".bbframe", std::ios::binary);
+                d_output_file = d_output_file_hint + ".bbframe";
+            }
+            logger->info("MODCOD : %d", cfg.modcod);
+            logger->info("Using input baseband " + d_input_file);
+            logger->info("Demodulating to " + d_output_file_hint + ".bbframe (MI355X path)");
+            std::vector<uint8_t> out((size_t)sdhip_dvbs2_demod_bbframe_bytes(h) * 512);
+            static const int bps[5] = {8, 4, 2, 2, 8};
+            if (input_data_type == DATA_FILE)
+            {
+                std::ifstream in(d_input_file, std::ios::binary);
+                in.seekg(0, std::ios::end);
+                filesize = (uint64_t)in.tellg();
+                in.seekg(0, std::ios::beg);
+                const size_t samples_per_read = 1 << 22;
+                std::vector<char> raw(samples_per_read * bps[fmt]);
+                while (!should_stop && in)
+                {
+                    in.read(raw.data(), raw.size());
+                    const size_t got = (size_t)in.gcount() / bps[fmt];
+                    if (got == 0)
+                        break;
+                    if (sdhip_dvbs2_demod_push(h, raw.data(), got, fmt) < 0)
+                        throw satdump_exception(std::string("dvbs2_demod_hip: ") + sdhip_last_error());
+                    progress = progress + got * bps[fmt];
+                    drain(out);
+                }
+            }
+            else
+            { // live input: process what has arrived every eighth of a second of samples (see psk_demod_hip)
+                const size_t flush_every = std::max<size_t>(8192, (size_t)(cfg.front.samplerate / 8.0));
+                size_t since_flush = 0;
+                while (!should_stop && input_active.load())
+                {
+                    const int n = input_stream->read();
+                    if (n <= 0)
+                        continue;
+                    const int rc = sdhip_dvbs2_demod_push(h, input_stream->readBuf, (size_t)n, SDHIP_FMT_CF32);
+                    input_stream->flush();
+                    if (rc < 0)
+                        throw satdump_exception(std::string("dvbs2_demod_hip: ") + sdhip_last_error());
+                    since_flush += (size_t)n;
+                    if (since_flush >= flush_every)
+                    {
+                        if (sdhip_dvbs2_demod_flush(h) < 0)
+                            throw satdump_exception(std::string("dvbs2_demod_hip: ") + sdhip_last_error());
+                        since_flush = 0;
+                    }
+                    drain(out);
+                }
+            }
+            if (sdhip_dvbs2_demod_flush(h) < 0)
+                throw satdump_exception(std::string("dvbs2_demod_hip: ") + sdhip_last_error());
+            drain(out);
+            if (output_data_type == DATA_FILE)
+                data_out.close();
+            logger->info("Demodulation finished");
+        }
+        void drawUI(bool) {}
+        nlohmann::json getModuleStats()
+        { // module_dvbs2_demod.cpp:224-237
+            nlohmann::json v;
+            v["progress"] = filesize ? ((double)progress / (double)filesize) : 0.0;
+            v["snr"] = snr.load();
+            v["peak_snr"] = peak_snr.load();
+            v["freq"] = display_freq.load();
+            v["ldpc_trials"] = ldpc_trials.load();
+            v["bch_corrections"] = bch_corrections.load();
+            return v;
+        }
+        static std::string getID() { return "dvbs2_demod_hip"; }
+        virtual std::string getIDM() { return getID(); }
+        static nlohmann::json getParams() { return {}; }
+        static std::shared_ptr<ProcessingModule> getInstance(std::string input_file, std::string output_file_hint, nlohmann::json parameters)
+        {
+            return std::make_shared<DVBS2DemodHipModule>(input_file, output_file_hint, parameters);
+        }
+    };
+
     // ------------------------------------------------------------------------------------------------ plugin
     class SdhipSupport : public satdump::Plugin
     {
@@ -626,6 +878,7 @@ namespace sdhip_plugin
             REGISTER_MODULE_EXTERNAL(evt.modules_registry, CCSDSConvConcatDecoderHipModule);
             REGISTER_MODULE_EXTERNAL(evt.modules_registry, MetOpAHRPTDecoderHipModule);
             REGISTER_MODULE_EXTERNAL(evt.modules_registry, CCSDSSimplePSKDecoderHipModule);
+            REGISTER_MODULE_EXTERNAL(evt.modules_registry, DVBS2DemodHipModule);
         }
         static void startedHandler(const satdump::SatDumpStartedEvent &)
         {
@@ -666,6 +919,20 @@ namespace sdhip_plugin
                 }
                 else if (e.id == "metop_ahrpt_decoder")
                     e.inst = MetOpAHRPTDecoderHipModule::getInstance;
+                else if (e.id == "dvbs2_demod")
+                { // plugins/dvb_support's module (registered by that plugin: the ordering caveat of metop_ahrpt_decoder applies). 32APSK, Doppler and
+                  // custom_samplerate stay on the CPU module
+                    auto cpu = e.inst;
+                    e.inst = [cpu](std::string in, std::string out, nlohmann::json p) -> std::shared_ptr<ProcessingModule> {
+                        std::string why;
+                        if (!DVBS2DemodHipModule::covers(in, out, p, why))
+                        {
+                            logger->info("sdhip_support: dvbs2_demod stays on the CPU module for this run (" + why + ")");
+                            return cpu(in, out, p);
+                        }
+                        return DVBS2DemodHipModule::getInstance(in, out, p);
+                    };
+                }
                 else if (e.id == "ccsds_simple_psk_decoder")
                 {
                     // hard_symbols input (soft_reader.h:49-58) stays on the CPU module

@@ -43,10 +43,12 @@ namespace sdhip
     }
     // M2M4SNREstimator::update over a frame's slots (src-core/common/dsp/utils/snr_estimator.cpp:16-31): y <- alpha |x|^2 + beta y per symbol is an
     // exponential window; its value behind the frame = sum alpha beta^(N - 1 - i) |x_i|^k (+ beta^N times the value in front, 4e-10 of it for a normal
-    // frame: dropped). One block, double accumulation: a display statistic, float noise apart the reference's.
-    __global__ __launch_bounds__(256) void k_s2_m2m4(const float2 *x, int n, double alpha, double *out2)
+    // frame: dropped). A block per frame, double accumulation: a display statistic, float noise apart the reference's.
+    __global__ __launch_bounds__(256) void k_s2_m2m4(const float2 *frames, int stride, int n, double alpha, double *out2)
     {
         __shared__ double s1[256], s2[256];
+        const float2 *x = frames + (size_t)blockIdx.x * stride + 90;
+        out2 += 2 * blockIdx.x;
         double a1 = 0.0, a2 = 0.0;
         const double lb = log1p(-alpha);
         for (int i = (int)threadIdx.x; i < n; i += 256)
@@ -103,6 +105,7 @@ namespace sdhip
         DevBuf<int> d_pls, d_tr, d_corr;
         DevBuf<unsigned char> d_pack, d_bb;
         DevBuf<double> d_m2m4;
+        std::vector<double> h_m2m4;
         PinBuf<unsigned char> h_bb, h_in;
         size_t pend_size = 0;
         int pend_fmt = 0;
@@ -148,7 +151,6 @@ namespace sdhip
             int nb = 0;
             sdhip_bch_dims(bch, &kbch, &nb);
             pll.reset(new S2Pll(device, c.modcod, c.shortframes ? 1 : 0, c.pilots ? 1 : 0, c.front.pll_bw, c.lut_phase_error, c.lut_resolution, c.front.exact != 0));
-            d_m2m4.reserve(2);
             st.detected_modcod = -1;
         }
         ~Dvbs2Engine()
@@ -214,17 +216,21 @@ namespace sdhip
             st.pll_rerun += pll->stats.rerun;
             st.pll_forced += pll->stats.forced;
             st.pll_serial_frames += pll->stats.serial_frames;
-            // the module's statistics over the last frame (module_dvbs2_demod.cpp:183-198)
+            // the module's statistics (module_dvbs2_demod.cpp:183-198): the estimate behind every frame, the last one and the peak
             {
-                hipLaunchKernelGGL(k_s2_m2m4, dim3(1), dim3(256), 0, nullptr, pl.p + (size_t)(nf - 1) * raw + 90, mc.slots * 90, 0.001, d_m2m4.p);
-                double m[2];
-                SD_HIP(hipMemcpy(m, d_m2m4.p, sizeof(m), hipMemcpyDeviceToHost));
-                const float y1 = (float)m[0], y2 = (float)m[1];
-                const float y1_2 = y1 * y1;
-                const float sig = sqrtf(2 * y1_2 - y2), noise = y1 - sqrtf(2 * y1_2 - y2);
-                const float snr = std::max<float>(0, (float)(10.0 * log10(sig / noise)));
-                st.snr = std::isfinite(snr) ? snr : 0.0f;
-                peak_snr = std::max(peak_snr, st.snr);
+                d_m2m4.reserve(2 * (size_t)nf);
+                hipLaunchKernelGGL(k_s2_m2m4, dim3((unsigned)nf), dim3(256), 0, nullptr, pl.p, raw, mc.slots * 90, 0.001, d_m2m4.p);
+                h_m2m4.resize(2 * (size_t)nf);
+                SD_HIP(hipMemcpy(h_m2m4.data(), d_m2m4.p, h_m2m4.size() * sizeof(double), hipMemcpyDeviceToHost));
+                for (int64_t f = 0; f < nf; f++)
+                {
+                    const float y1 = (float)h_m2m4[2 * f], y2 = (float)h_m2m4[2 * f + 1];
+                    const float y1_2 = y1 * y1;
+                    const float sig = sqrtf(2 * y1_2 - y2), noise = y1 - sqrtf(2 * y1_2 - y2);
+                    const float snr = std::max<float>(0, (float)(10.0 * log10(sig / noise)));
+                    st.snr = std::isfinite(snr) ? snr : 0.0f;
+                    peak_snr = std::max(peak_snr, st.snr);
+                }
                 st.peak_snr = peak_snr;
             }
             // ---- soft demapper stage, behind the frames that wait for a full decoder group

@@ -35,7 +35,7 @@ def test_plugin_loads_and_registers_its_modules(host):
     assert p.returncode == 0, p.stderr
     ids = p.stdout.split()
     assert ids[0] == "sdhip_support"
-    for m in ("psk_demod_hip", "ccsds_conv_concat_decoder_hip", "metop_ahrpt_decoder_hip", "ccsds_simple_psk_decoder_hip"):
+    for m in ("psk_demod_hip", "ccsds_conv_concat_decoder_hip", "metop_ahrpt_decoder_hip", "ccsds_simple_psk_decoder_hip", "dvbs2_demod_hip"):
         assert m in ids[1:]
     # new ids are appended behind the core modules, the stock ids stay first (first-match lookup, module.cpp:123-129)
     assert ids.index("psk_demod") < ids.index("psk_demod_hip")
@@ -75,3 +75,14 @@ def test_ndsp_block_through_the_plugin_on_the_twin(host, tmp_path):
     if not pyref.NdspRef.available() or not os.path.exists(emu_build.CLANG):
         pytest.skip("needs the compiled reference ndsp blocks and a host clang++")
     G.check_ndsp_block_through_the_plugin(host, emu_build.build(), tmp_path)
+
+
+def test_dvbs2_module_through_the_plugin_on_the_twin(host, tmp_path):
+    """tests/test_plugin_minihost_gpu.py::test_dvbs2_module_through_the_plugin with the host twin as the C-ABI library: DVBS2DemodHipModule's
+    parameter parsing, table hand-over, file plumbing and statistics run in the CPU suite (short 8PSK 3/5 frames)."""
+    from oracle import pyref
+    from tests import test_plugin_minihost_gpu as G
+    from tests.emu import build as emu_build
+    if not (pyref.Dvbs2Ref.available(False) and pyref.S2FrontRef.available()) or not os.path.exists(emu_build.CLANG):
+        pytest.skip("needs the compiled reference DVB-S2 classes and a host clang++")
+    G.check_dvbs2_module_through_the_plugin(host, emu_build.build(), tmp_path)

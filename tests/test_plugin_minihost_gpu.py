@@ -274,3 +274,83 @@ def test_ndsp_block_through_the_plugin(host, tmp_path):
     if not pyref.NdspRef.available():
         pytest.skip("needs the compiled reference ndsp blocks")
     check_ndsp_block_through_the_plugin(host, LIB, tmp_path)
+
+
+def check_dvbs2_module_through_the_plugin(host, lib, tmp_path, modcod=12, short=1, nfr=16, acq=3 * 5490):
+    """BASELINE configs[4]'s module through the drop-in boundary: the stock id `dvbs2_demod`, re-pointed by the plugin under SDHIP_OVERRIDE=1 at
+    DVBS2DemodHipModule (plugin/sdhip_plugin.cpp), reads a baseband file of 8PSK PLFRAMEs and writes a .bbframe file -- against the reference's
+    blocks and classes chained the way DVBS2DemodModule chains them (module_dvbs2_demod.cpp:98-137, 239-293). The demapper table is built by the
+    plugin with the reference's own constellation_t (compiled into the host where it lies). hip_exact: the file is the reference's, byte for
+    byte over the frames of the signal; default schedules (chunk-parallel front end, frame-parallel PLL): the same frames (the parallel
+    schedules' contract is the decoders' output). cs16 input, the module's mandatory-key messages, 32APSK staying on the CPU module."""
+    from tests.test_dvbs2_gpu import _s2_baseband, _s2_reference_chain
+    bbx, bb = _s2_baseband(modcod, short, nfr, 10.0)
+    kb = bb.shape[1]
+    sent = {bytes(r): i for i, r in enumerate(bb)}
+    orc = pyref.best()
+    xref = orc.block(3, [2.0, (1.7e-3) ** 2 / 4, 0.5, 1.7e-3, 0.005], orc.block(1, [2e6, 1e6, 0.2, 31], orc.block(0, [1e-2, 1.0, 1.0, 65536.0], bbx)))
+    want, _, _, _, _, _ = _s2_reference_chain(modcod, short, xref, trials=10)
+    whits = [sent.get(bytes(r), -1) for r in want]
+    assert sum(h >= 0 for h in whits) >= nfr - 4
+    inp = tmp_path / "dvbs2.cf32"
+    bbx.tofile(str(inp))
+    params = {"samplerate": 2000000, "symbolrate": 1000000, "rrc_alpha": 0.2, "pll_bw": 0.002, "modcod": modcod, "shortframes": bool(short), "freq_prop_factor": 0.0,
+              "hip_ldpc_batch": 1}
+
+    def run(extra, name, env=None):
+        job = {"mode": "file", "input": str(inp), "output_hint": str(tmp_path / name), "demod": {"module": "dvbs2_demod", "parameters": dict(params, **extra)}}
+        jp = tmp_path / (name + ".json")
+        jp.write_text(json.dumps(job))
+        e = dict(os.environ, SDHIP_OVERRIDE="1", SDHIP_S2PLL_ACQ=str(acq))
+        e.update(env or {})
+        p = subprocess.run([host, lib, PLUGIN, "run", str(jp)], capture_output=True, text=True, env=e, timeout=900)
+        return p, (json.loads(p.stdout.strip().splitlines()[-1]) if p.returncode == 0 else None)
+
+    p, rep = run({"hip_exact": 1}, "exact")
+    assert p.returncode == 0, p.stdout[-1000:] + p.stderr[-3000:]
+    assert rep["demod_class"] == "dvbs2_demod_hip" and rep["soft"].endswith(".bbframe")
+    got = np.fromfile(rep["soft"], dtype=np.uint8).reshape(-1, kb)
+    # (the oracle's driver of S2PLSyncBlock waits for two frames' worth of symbols before every work2() call, the block itself -- and the engine --
+    # for one frame plus its re-alignment: at the end of a stream the engine may emit one more frame of the trailing noise)
+    assert len(want) <= len(got) <= len(want) + 1
+    good = np.array([h >= 0 for h in whits])
+    assert np.array_equal(got[:len(want)][good], want[good])
+    assert set(rep["demod_stats"]) == {"progress", "snr", "peak_snr", "freq", "ldpc_trials", "bch_corrections"} and rep["demod_stats"]["progress"] == 1.0  # module_dvbs2_demod.cpp:224-237
+    # the default schedules, and the same through cs16 samples
+    p, rep = run({}, "par")
+    assert p.returncode == 0, p.stdout[-1000:] + p.stderr[-3000:]
+    got = np.fromfile(rep["soft"], dtype=np.uint8).reshape(-1, kb)
+    ghits = [sent.get(bytes(r), -1) for r in got]
+    gfound = [h for h in ghits if h >= 0]
+    assert gfound == sorted(gfound) and set(gfound) >= set(h for h in whits if h >= 0) - {min(h for h in whits if h >= 0)}, (ghits, whits)
+    assert rep["demod_stats"]["peak_snr"] > 5.0
+    cs = synth.to_cs16(bbx)
+    (tmp_path / "dvbs2.cs16").write_bytes(cs.tobytes())
+    job_in = str(tmp_path / "dvbs2.cs16")
+    job = {"mode": "file", "input": job_in, "output_hint": str(tmp_path / "c16"), "demod": {"module": "dvbs2_demod", "parameters": dict(params, baseband_format="cs16")}}
+    (tmp_path / "c16.json").write_text(json.dumps(job))
+    p = subprocess.run([host, lib, PLUGIN, "run", str(tmp_path / "c16.json")], capture_output=True, text=True, env=dict(os.environ, SDHIP_OVERRIDE="1", SDHIP_S2PLL_ACQ=str(acq)), timeout=900)
+    assert p.returncode == 0, p.stdout[-1000:] + p.stderr[-3000:]
+    got16 = np.fromfile(json.loads(p.stdout.strip().splitlines()[-1])["soft"], dtype=np.uint8).reshape(-1, kb)
+    assert sum(bytes(r) in sent for r in got16) >= len(gfound) - 1
+    # the groups of the reference's SSE4.1 build (16 frames per decode call): a trailing partial group is never written, as in process_s2
+    p, rep = run({"hip_ldpc_batch": 16}, "b16")
+    assert p.returncode == 0 and os.path.getsize(rep["soft"]) == (len(got) // 16) * 16 * kb
+    # the module's own messages; what the HIP path does not carry stays with the CPU module
+    bad = dict(params)
+    del bad["modcod"]
+    job = {"mode": "file", "input": str(inp), "output_hint": str(tmp_path / "x"), "instantiate_only": True, "demod": {"module": "dvbs2_demod_hip", "parameters": bad}}
+    (tmp_path / "bad.json").write_text(json.dumps(job))
+    p = subprocess.run([host, lib, PLUGIN, "run", str(tmp_path / "bad.json")], capture_output=True, text=True, env=dict(os.environ), timeout=120)
+    assert p.returncode != 0 and "MODCOD parameter must be present!" in p.stderr
+    job["demod"] = {"module": "dvbs2_demod", "parameters": dict(params, modcod=25)}
+    (tmp_path / "apsk.json").write_text(json.dumps(job))
+    p = subprocess.run([host, lib, PLUGIN, "run", str(tmp_path / "apsk.json")], capture_output=True, text=True, env=dict(os.environ, SDHIP_OVERRIDE="1"), timeout=120)
+    assert p.returncode == 0 and json.loads(p.stdout.strip().splitlines()[-1])["demod_class"] == "cpu:dvbs2_demod"
+
+
+def test_dvbs2_module_through_the_plugin(host, tmp_path):
+    from oracle import pyref as _p
+    if not (_p.Dvbs2Ref.available(False) and _p.S2FrontRef.available()):
+        pytest.skip("needs the compiled reference DVB-S2 classes")
+    check_dvbs2_module_through_the_plugin(host, LIB, tmp_path, modcod=13, short=0, nfr=10, acq=2 * 21690)

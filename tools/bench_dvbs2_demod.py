@@ -1,0 +1,175 @@
+#!/usr/bin/env python3
+"""BASELINE.json configs[4] on one MI355X: DVB-S2 8PSK (MODCOD 13 = rate 2/3, normal FECFRAMEs, roll-off 0.2) at 45 Msym/s, two samples per symbol,
+BASEBAND samples resident in HBM -> BBFRAMEs, through the module-shaped handle (sdhip_dvbs2_demod_*: front end, PL synchroniser, frame-parallel
+PLL, soft demapper stage, LDPC in the reference build's 16-frame groups, BCH, BB descrambler). One step = one pass over `--frames` PLFRAMEs of
+a periodic recording (so that consecutive steps continue ONE stream: loop states, the synchroniser's ring and the decoder groups carry over).
+Reported: Msym/s, Msamples/s, frames/s; per-kernel HIP-event times; the dominant kernel against its HBM roofline; every BBFRAME of the first
+timed step checked against the transmitted ones; the reference's blocks and classes chained the way the module chains them on a bounded sample
+of the same samples -- its BBFRAMEs must be ours (parity) and its rate on the host is the cpu_baseline (one thread: the chain run block after
+block).   usage: tools/bench_dvbs2_demod.py [--frames 512] [--steps 3] [--esn0 10] [--cpu-frames 24]"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+MODCOD, SYMRATE, SPS, ALPHA, LOOP_BW = 13, 45e6, 2, 0.2, 0.002
+
+
+def parse(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--frames", type=int, default=512, help="PLFRAMEs per step (a multiple of --base)")
+    ap.add_argument("--base", type=int, default=32, help="distinct BBFRAMEs of the periodic recording")
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--esn0", type=float, default=10.0)
+    ap.add_argument("--trials", type=int, default=10)
+    ap.add_argument("--batch", type=int, default=16, help="frames per LDPC decode call of the reference build being replaced (SSE4.1: 16)")
+    ap.add_argument("--freq-prop", type=float, default=0.0, help="the module's freq_prop_factor (default 0: what the reference chain beside it can be run with)")
+    ap.add_argument("--cpu-frames", type=int, default=24, help="frames' worth of samples the reference chain decodes on the host (0 = skip)")
+    ap.add_argument("--exact", type=int, default=0)
+    return ap.parse_args(argv)
+
+
+def run(args) -> dict:
+    import torch
+    torch.zeros(1, device="cuda")
+    from satdump_amd import capi, dvbs2, synth, synth_dvbs2 as sd
+    c = sd.modcod_cfg(MODCOD, 0)
+    raw = 90 + c["slots"] * 90
+    base = args.base
+    nfr = max(base, args.frames // base * base)
+    bb = sd.bbframes_random(0, c["rate"], base, seed=5)
+    t0 = time.perf_counter()
+    syms = sd.plframes(MODCOD, 0, bb).reshape(-1)
+    t_gen = time.perf_counter() - t0
+    spec = synth.SynthSpec(constellation="qpsk", samplerate=SYMRATE * SPS, symbolrate=SYMRATE, rrc_alpha=ALPHA, amplitude=0.5, cfo_hz=0.0, esn0_db=args.esn0, seed=5,
+                           timing_offset=0.3)
+    d_clean, _ = synth.modulate_torch(syms, dataclass_noiseless(spec), torch.device("cuda"), periodic=True)
+    nb = d_clean.numel()
+    reps = nfr // base
+    g = torch.Generator(device="cuda").manual_seed(11)
+    sigma = float(np.sqrt(SPS / (2.0 * 10 ** (args.esn0 / 10)))) * spec.amplitude
+    d_x = torch.view_as_real(d_clean).repeat(reps, 1).contiguous()
+    d_x += sigma * torch.randn(d_x.shape, device="cuda", generator=g)
+    n = nb * reps
+    del d_clean
+    # the demapper table: data the module builds on the host with the reference's constellation_t. On the GPU box the compiled reference class is the
+    # prebuilt checker library; the bench only takes the TABLE from it (what the plugin takes from libsatdump_core)
+    from oracle import pyref
+    fref = pyref.S2FrontRef()
+    lut_b, lut_p = fref.lut(MODCOD, 0), pyref.s2_lut_phase_ref(MODCOD, 0)
+    params = {"samplerate": SYMRATE * SPS, "symbolrate": SYMRATE, "rrc_alpha": ALPHA, "pll_bw": LOOP_BW, "modcod": MODCOD, "freq_prop_factor": args.freq_prop,
+              "ldpc_trials": args.trials}
+    dem = dvbs2.DVBS2Demod(params, lut_b, lut_p, mem=dvbs2.TorchMem("cuda"), exact=bool(args.exact), batch=args.batch)
+    fb = dem.bbframe_bytes
+    cap = nfr + 64
+    d_out = torch.zeros(cap * fb, dtype=torch.uint8, device="cuda")
+    sent = {bytes(r): i for i, r in enumerate(bb)}
+    firsts = []
+    for _ in range(args.warmup):
+        k = dem.process_dev(d_x.data_ptr(), n, capi.FMT_CF32, d_out.data_ptr(), cap)
+        firsts.append(d_out[:k * fb].cpu().numpy().reshape(k, fb).copy())
+    st0 = dem.stats
+    torch.cuda.synchronize()
+    capi.prof_reset()
+    capi.prof_enable(True)
+    outs = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        k = dem.process_dev(d_x.data_ptr(), n, capi.FMT_CF32, d_out.data_ptr(), cap)
+        outs.append(k)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / args.steps
+    capi.prof_enable(False)
+    prof = capi.prof_get()
+    st = dem.stats
+    got = d_out[:outs[-1] * fb].cpu().numpy().reshape(outs[-1], fb)
+    hits = [sent.get(bytes(r), -1) for r in got]
+    ok = [h for h in hits if h >= 0]
+    in_order = all((b - a) % base == 1 for a, b in zip(ok[:-1], ok[1:])) and len(ok) == len(hits)
+    kern = {k2: round(v[0] / args.steps, 3) for k2, v in sorted(prof.items(), key=lambda kv: -kv[1][0])}
+    nsym = nfr * raw
+    out = {"metric": "DVB-S2 8PSK baseband -> BBFRAMEs: Msym/s of the configured symbol rate's stream through the whole demodulator module, baseband resident in HBM",
+           "value": round(nsym / dt / 1e6, 1), "unit": "Msym/s", "Msamples_per_s": round(n / dt / 1e6, 1), "frames_per_s": round(sum(outs) / args.steps / dt, 1),
+           "realtime_factor_at_45_Msym_per_s": round(nsym / dt / SYMRATE, 2), "ms_per_step": round(dt * 1e3, 3), "steps": args.steps, "dtype": "f32 + int8",
+           "config": {"workload": f"BASELINE configs[4]: MODCOD {MODCOD} (8PSK 2/3), normal FECFRAMEs, roll-off {ALPHA}, {SPS} samples per symbol ({SYMRATE * SPS / 1e6:.0f} Msps for "
+                                  f"{SYMRATE / 1e6:.0f} Msym/s), Es/N0 {args.esn0} dB, {nfr} PLFRAMEs = {n} cf32 samples ({n * 8 / 1e6:.0f} MB) per step, periodic recording of {base} "
+                                  f"distinct BBFRAMEs with fresh noise on every repetition, no carrier offset (see tests/test_dvbs2_gpu.py::_s2_baseband), freq_prop_factor "
+                                  f"{args.freq_prop}, max {args.trials} LDPC trials in groups of {args.batch}, "
+                                  + ("serial schedules (exact)" if args.exact else "chunk-parallel front end + frame-parallel PLL")},
+           "bbframes_per_step": outs, "all_bbframes_are_transmitted_ones_in_order": bool(in_order), "frames_not_matching": len(hits) - len(ok),
+           "stats": {k2: (round(v, 6) if isinstance(v, float) else v) for k2, v in st.items() if k2 not in ("frames", "pls", "freq")},
+           "pll_schedule_per_step": {"lanes": (st["pll_lanes"] - st0["pll_lanes"]) // args.steps, "rerun": (st["pll_rerun"] - st0["pll_rerun"]) / args.steps,
+                                     "forced": st["pll_forced"] - st0["pll_forced"], "serial_frames_at_stream_start": st0["pll_serial_frames"]},
+           "kernels_ms": kern, "synthesis_s": round(t_gen, 1)}
+    # ---- roofline of the dominant kernel. Algorithmic bytes per step: front-end lane stages 8 B in + 8 B out per sample (k_afc* is not used here: the
+    # DVB-S2 front end has no Costas stage: k_chunks<AgcFir> + k_mm); k_ldpc_trial: 2 x the check-to-bit messages + 2 x the LLRs per frame and update pass
+    dom = next(iter(kern)) if kern else None
+    ldpc = capi.LdpcDecoder(framesize=0, rate="2/3", batch=args.batch)
+    upd = float(st["ldpc_trials"])
+    algo = {"k_ldpc_trial": sum(outs) / args.steps * max(upd, 1.0) * (2 * ldpc.info.msg_bytes_per_frame + 2 * 64800),
+            "k_mm": n * 8 + nsym * 8, "k_chunks_AgcFirStage": n * 16, "k_s2_pll_lanes": nsym * 16, "k_s2_demap": nsym * 11, "k_s2_plsync_search": nsym * 8}
+    if dom:
+        key = next((k2 for k2 in algo if dom.startswith(k2)), None)
+        if key and kern[dom] > 0:
+            ach = algo[key] / (kern[dom] * 1e-3) / 1e9
+            out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": round(ach, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 4), "traffic": None,
+                               "algorithmic_bytes_per_step": int(algo[key]), "note": "ldpc update passes per frame taken from the last group's trial count" if key == "k_ldpc_trial" else ""}
+    whole = (n * 8 + sum(outs) / args.steps * fb) / dt / 1e9
+    out["whole_path"] = {"algorithmic_GB_per_s": round(whole, 1), "frac_of_hbm_peak": round(whole / 8000.0, 4), "note": "8 B per baseband sample in + the BBFRAME bytes out"}
+    # ---- the reference beside it: its blocks and classes chained the way the module chains them, on the first cpu-frames frames' worth of samples
+    if args.cpu_frames > 0:
+        m = min(n, args.cpu_frames * raw * SPS)
+        xs = torch.view_as_complex(d_x[:m]).cpu().numpy()
+        orc = pyref.best()
+        fec = pyref.Dvbs2Ref(pyref.Dvbs2Ref.available(True) and args.batch == 16)
+        rc = c["rate"]
+        nl, kl = fec.dims(0, rc)
+        kb = fec.bch_kbch(0, rc)
+        t1 = time.perf_counter()
+        xr = orc.block(3, [float(SPS), (1.7e-3) ** 2 / 4, 0.5, 1.7e-3, 0.005], orc.block(1, [SYMRATE * SPS, SYMRATE, ALPHA, 31], orc.block(0, [1e-2, 1.0, 1.0, 65536.0], xs)))
+        t2 = time.perf_counter()
+        fr, _, _ = pyref.s2_pl_sync_ref(c["slots"], 0, 0.6, xr)
+        rp, _, _ = pyref.s2_pll_ref(MODCOD, 0, 0, LOOP_BW, fr)
+        soft, _ = fref.bb_to_soft(MODCOD, 0, 0, rp)
+        nfull = len(soft) // fec.batch * fec.batch
+        t3 = time.perf_counter()
+        dec, tr = fec.ldpc_decode(0, rc, soft[:nfull].copy(), args.trials)
+        t4 = time.perf_counter()
+        fix, _ = fec.bch_decode(0, rc, np.packbits((dec < 0).astype(np.uint8), axis=1)[:, :kl // 8].copy())
+        want = fec.bb_descramble(0, rc, fix.copy())[:, :kb // 8]
+        t5 = time.perf_counter()
+        whits = [sent.get(bytes(r), -1) for r in want]
+        first = firsts[0] if firsts else got
+        fhits = [sent.get(bytes(r), -1) for r in first[:len(want) + 4]]
+        common = [h for h in whits if h >= 0 and h in fhits]
+        same = all(np.array_equal(want[whits.index(h)], first[fhits.index(h)]) for h in common)
+        out["cpu_baseline"] = {"value": round(len(xr) / (t5 - t1) / 1e6, 3), "unit": "Msym/s", "cores": 1, "kind": "reference",
+                               "sample": f"the first {m} samples ({args.cpu_frames} frames' worth): AGC, RRC filter, M&M, S2PLSyncBlock, S2PLLBlock, S2BBToSoft, BBFrameLDPC (SIMD width {fec.batch}), "
+                                         "BBFrameBCH, BB descrambler, one after the other on one thread",
+                               "stage_seconds": {"front_end": round(t2 - t1, 3), "sync_pll_demap": round(t3 - t2, 3), "ldpc": round(t4 - t3, 3), "bch_descramble": round(t5 - t4, 3)},
+                               "ldpc_trials": [int(v) for v in tr[:8]]}
+        out["parity_sample"] = {"reference_frames": int(len(want)), "reference_frames_that_are_transmitted_ones": int(sum(h >= 0 for h in whits)),
+                                "frames_both_deliver": len(common), "byte_identical": bool(same and len(common) >= max(1, sum(h >= 0 for h in whits) - 2))}
+    return out
+
+
+def dataclass_noiseless(spec):
+    """the same SynthSpec with the noise switched off (it is added per repetition on the device instead)"""
+    import dataclasses
+    return dataclasses.replace(spec, esn0_db=200.0)
+
+
+def main():
+    print(json.dumps(run(parse())), flush=True)
+
+
+if __name__ == "__main__":
+    main()
