@@ -433,8 +433,9 @@ extern "C"
         float ldpc_trials;     /* "ldpc_trials" of the last decoder group (max trials when it did not converge) */
         float bch_corrections; /* "bch_corrections" of the last frame */
         int detected_modcod, detected_shortframes, detected_pilots; /* S2BBToSoft's PLS decode of the last frame (-1 before the first) */
-        uint32_t pll_lanes, pll_rerun, pll_forced, pll_serial_frames; /* the frame PLL's schedule, summed over the calls: lanes, lanes re-run from the
-                                                                         exact predecessor state, boundaries let through unlocked, frames walked serially */
+        uint32_t pll_lanes, pll_rerun, pll_forced, pll_serial_frames, pll_branch_tries; /* the frame PLL's schedule, summed over the calls: lanes, lanes re-run from the
+                                                                         exact predecessor state, boundaries let through unlocked, frames walked serially, whole-batch
+                                                                         launches spent on the estimates' frequency branch */
     } sdhip_dvbs2_stats;
     void sdhip_dvbs2_cfg_default(sdhip_dvbs2_cfg *cfg);
     void *sdhip_dvbs2_demod_create(const sdhip_dvbs2_cfg *cfg); /* NULL on error; the messages are the module's / get_dvbs2_cfg's */

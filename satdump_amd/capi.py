@@ -82,7 +82,7 @@ class Dvbs2Cfg(C.Structure):
 class Dvbs2Stats(C.Structure):
     _fields_ = [("samples_in", C.c_uint64), ("plframes", C.c_uint64), ("bbframes", C.c_uint64), ("snr", C.c_float), ("peak_snr", C.c_float), ("freq_hz", C.c_float),
                 ("pll_freq", C.c_float), ("ldpc_trials", C.c_float), ("bch_corrections", C.c_float), ("detected_modcod", C.c_int), ("detected_shortframes", C.c_int),
-                ("detected_pilots", C.c_int), ("pll_lanes", C.c_uint32), ("pll_rerun", C.c_uint32), ("pll_forced", C.c_uint32), ("pll_serial_frames", C.c_uint32)]
+                ("detected_pilots", C.c_int), ("pll_lanes", C.c_uint32), ("pll_rerun", C.c_uint32), ("pll_forced", C.c_uint32), ("pll_serial_frames", C.c_uint32), ("pll_branch_tries", C.c_uint32)]
 
 
 # dvbs2_code_rate_t (common/codings/dvb-s2/dvbs2.h:9-23)

@@ -8,6 +8,7 @@ namespace sdhip
 #include "power_decim_tables.inc"
 }
 #include "../../include/sdhip.h"
+#include "host_pipe.h"
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
@@ -530,12 +531,12 @@ namespace sdhip
         DevBuf<int8_t> d_soft_tmp;
         DevBuf<uint8_t> d_in_tmp;
 
-        // host path
-        static constexpr size_t HOST_BATCH = (size_t)64u << 20; // samples per shipped batch
-        PinBuf<uint8_t> h_in;
+        // host path (host_pipe.h): two pinned staging buffers filled by the copy pool, shipped and processed by a worker thread while the caller fills
+        // the other one; results queue up for pull()
+        static constexpr size_t HOST_BATCH = (size_t)32u << 20; // samples per shipped batch
+        std::unique_ptr<HostPipe> pipe;
         PinBuf<int8_t> h_out;
-        size_t pend_size = 0; // bytes gathered in h_in
-        int pend_fmt = 0;
+        std::mutex out_mu;
         std::vector<int8_t> out_queue;
         size_t out_read = 0;
 
@@ -782,6 +783,7 @@ namespace sdhip
         }
         ~DemodEngine()
         {
+            pipe.reset(); // the host path's worker thread ends before the stream and the buffers it uses go
             if (stream)
                 (void)hipStreamDestroy(stream);
         }
@@ -1927,58 +1929,41 @@ namespace sdhip
         }
 
         // ---- host path
+        // one staged batch, on the pipe's worker thread: H2D, the stages, D2H of the soft symbols
+        void ship(const uint8_t *pinned, size_t bytes, int fmt)
+        {
+            const size_t ns = bytes / fmt_bytes(fmt);
+            if (ns == 0)
+                return;
+            SD_HIP(hipSetDevice(cfg.device));
+            d_in_tmp.reserve(bytes);
+            SD_HIP(hipMemcpyAsync(d_in_tmp.p, pinned, bytes, hipMemcpyHostToDevice, stream));
+            const size_t cap = 2 * ns + 64;
+            d_soft_tmp.reserve(cap);
+            const int64_t n = process(d_in_tmp.p, ns, fmt, d_soft_tmp.p, cap, nullptr, 0);
+            h_out.reserve((size_t)n + 1);
+            SD_HIP(hipMemcpyAsync(h_out.p, d_soft_tmp.p, (size_t)n, hipMemcpyDeviceToHost, stream));
+            SD_HIP(hipStreamSynchronize(stream));
+            std::lock_guard<std::mutex> lk(out_mu);
+            out_queue.insert(out_queue.end(), h_out.p, h_out.p + n);
+        }
         int push_host(const void *iq, size_t nsamples, int fmt)
         {
-            if (pend_size != 0 && fmt != pend_fmt)
-                throw HipError("baseband format changed mid-stream");
-            pend_fmt = fmt;
-            // samples are gathered in a PINNED staging buffer (one copy on the host, H2D at PCIe rate) and shipped in batches
-            // of HOST_BATCH samples: large enough to fill the lanes, small enough for a live stream's latency
+            if (!pipe)
+                pipe.reset(new HostPipe([this](const uint8_t *p, size_t b, int f) { ship(p, b, f); }));
             const size_t bps = (size_t)fmt_bytes(fmt);
-            const uint8_t *src = (const uint8_t *)iq;
-            size_t left = nsamples;
-            while (left)
-            {
-                const size_t have = pend_size / bps;
-                const size_t take = std::min(left, HOST_BATCH - have);
-                if (pend_size + take * bps > h_in.cap)
-                { // grow the staging buffer, keeping what is gathered (PinBuf::reserve does not preserve content)
-                    PinBuf<uint8_t> bigger;
-                    bigger.reserve(std::min(HOST_BATCH * bps, std::max<size_t>(2 * (pend_size + take * bps), (size_t)1 << 22)));
-                    if (pend_size)
-                        memcpy(bigger.p, h_in.p, pend_size);
-                    std::swap(bigger.p, h_in.p);
-                    std::swap(bigger.cap, h_in.cap);
-                }
-                memcpy(h_in.p + pend_size, src, take * bps);
-                pend_size += take * bps;
-                src += take * bps;
-                left -= take;
-                if (pend_size / bps >= HOST_BATCH)
-                    flush_host();
-            }
+            pipe->push(iq, nsamples * bps, fmt, HOST_BATCH * bps);
             return 0;
         }
         int flush_host()
         {
-            const size_t ns = pend_size / fmt_bytes(pend_fmt);
-            if (ns == 0)
-                return 0;
-            SD_HIP(hipSetDevice(cfg.device));
-            d_in_tmp.reserve(pend_size);
-            SD_HIP(hipMemcpyAsync(d_in_tmp.p, h_in.p, pend_size, hipMemcpyHostToDevice, stream));
-            const size_t cap = 2 * ns + 64;
-            d_soft_tmp.reserve(cap);
-            const int64_t n = process(d_in_tmp.p, ns, pend_fmt, d_soft_tmp.p, cap, nullptr, 0);
-            h_out.reserve((size_t)n + 1);
-            SD_HIP(hipMemcpyAsync(h_out.p, d_soft_tmp.p, (size_t)n, hipMemcpyDeviceToHost, stream));
-            SD_HIP(hipStreamSynchronize(stream));
-            out_queue.insert(out_queue.end(), h_out.p, h_out.p + n);
-            pend_size = 0;
+            if (pipe)
+                pipe->flush();
             return 0;
         }
         int64_t pull(int8_t *soft, size_t cap)
         {
+            std::lock_guard<std::mutex> lk(out_mu);
             const size_t avail = out_queue.size() - out_read;
             const size_t take = std::min(avail, cap);
             memcpy(soft, out_queue.data() + out_read, take);

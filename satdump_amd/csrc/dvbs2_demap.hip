@@ -471,17 +471,24 @@ namespace sdhip
             freq = -1.0f;
         return o;
     }
-    __global__ __launch_bounds__(64) void k_s2_pll_seq(const float2 *__restrict__ in, float2 *__restrict__ out, int stride, int nframes, int per_frame, S2PllCtx c, S2PllState *state)
+    // trace (may be null): the loop frequency every 1024 steps (what a new stream's acquisition leaves for the estimates' branch, S2Pll::run)
+    __global__ __launch_bounds__(64) void k_s2_pll_seq(const float2 *__restrict__ in, float2 *__restrict__ out, int stride, int nframes, int per_frame, S2PllCtx c, S2PllState *state,
+                                                       float *__restrict__ trace)
     {
         if (blockIdx.x != 0 || threadIdx.x != 0)
             return;
         float phase = state->phase, freq = state->freq;
+        long long g = 0;
         for (int f = 0; f < nframes; f++)
         {
             const float2 *x = in + (size_t)f * stride;
             float2 *o = out + (size_t)f * stride;
-            for (int i = 0; i < per_frame; i++)
+            for (int i = 0; i < per_frame; i++, g++)
+            {
                 o[i] = s2_pll_step(c, i, x[i], phase, freq);
+                if (trace && (g & 1023) == 1023)
+                    trace[g >> 10] = freq;
+            }
         }
         state->phase = phase;
         state->freq = freq;
@@ -640,6 +647,9 @@ namespace sdhip
         DevBuf<double2> d_z;
         DevBuf<S2PllLane> d_lanes;
         DevBuf<int> d_list;
+        DevBuf<float> d_trace;
+        double freq_hint = 0.0; // the loop frequency the estimates pick their branch with: a MEAN (the loop's own frequency state wanders by ~1e-4 rad / symbol
+                                // at 10 dB, half the 2 pi / 21 690 branch spacing of normal 8PSK frames)
         std::vector<S2PllLane> lanes;
         std::vector<S2PllState> h_start, h_end;
         std::vector<int> list;
@@ -687,7 +697,12 @@ namespace sdhip
     }
     S2Pll::~S2Pll() = default;
     int S2Pll::per_frame() const { return im->per_frame; }
-    void S2Pll::add_frequency(float df) { state.freq += df; }
+    void S2Pll::set_hint(double f) { im->freq_hint = f; }
+    void S2Pll::add_frequency(float df)
+    {
+        state.freq += df;
+        im->freq_hint += (double)df;
+    }
     static bool s2_state_close(const S2PllState &a, const S2PllState &b, double tol_p, double tol_f)
     {
         double d = (double)a.phase - (double)b.phase;
@@ -705,20 +720,36 @@ namespace sdhip
         SD_HIP(hipSetDevice(m.device));
         const float2 *in = reinterpret_cast<const float2 *>(d_in);
         float2 *out = reinterpret_cast<float2 *>(d_out);
-        auto serial = [&](int f0, int nf)
+        auto serial = [&](int f0, int nf, bool trace)
         {
             SD_HIP(hipMemcpyAsync(m.d_state.p, &state, sizeof(state), hipMemcpyHostToDevice, st));
+            const size_t ntr = trace ? (size_t)(((long long)nf * m.per_frame) >> 10) : 0;
+            if (ntr)
+                m.d_trace.reserve(ntr);
             {
                 ProfScope _ps("k_s2_pll_seq", st);
-                hipLaunchKernelGGL(k_s2_pll_seq, dim3(1), dim3(64), 0, st, in + (size_t)f0 * stride, out + (size_t)f0 * stride, stride, nf, m.per_frame, m.ctx, m.d_state.p);
+                hipLaunchKernelGGL(k_s2_pll_seq, dim3(1), dim3(64), 0, st, in + (size_t)f0 * stride, out + (size_t)f0 * stride, stride, nf, m.per_frame, m.ctx, m.d_state.p,
+                                   ntr ? m.d_trace.p : (float *)nullptr);
             }
             SD_HIP(hipMemcpyAsync(&state, m.d_state.p, sizeof(state), hipMemcpyDeviceToHost, st));
             SD_HIP(hipStreamSynchronize(st));
             stats.serial_frames += (unsigned)nf;
+            if (ntr)
+            { // mean loop frequency over the second half of the stretch
+                std::vector<float> tr(ntr);
+                SD_HIP(hipMemcpy(tr.data(), m.d_trace.p, ntr * sizeof(float), hipMemcpyDeviceToHost));
+                double a = 0.0;
+                const size_t h0 = ntr / 2;
+                for (size_t i = h0; i < ntr; i++)
+                    a += tr[i];
+                m.freq_hint = a / (double)(ntr - h0);
+            }
+            else
+                m.freq_hint = state.freq;
         };
         if (exact)
         {
-            serial(0, nframes);
+            serial(0, nframes, false);
             return;
         }
         int f0 = 0;
@@ -726,7 +757,7 @@ namespace sdhip
         { // a new stream: the loop acquires on its own (the estimates need its frequency to pick their 2 pi / per_frame branch)
             const long acq_syms = env_long("SDHIP_S2PLL_ACQ", 65536);
             const int acq = (int)std::min<long>(nframes, std::max<long>(2, (acq_syms + m.per_frame - 1) / m.per_frame));
-            serial(0, acq);
+            serial(0, acq, true);
             f0 = acq;
             have_hint = true;
             if (f0 >= nframes)
@@ -741,8 +772,8 @@ namespace sdhip
         if (L <= 0)
             L = std::max<long long>(4096, (total + 4095) / 4096);
         L = std::max<long>(L, std::max<long>(W, 64));
-        const double tol_p = (double)env_long("SDHIP_S2PLL_TOL_MRAD", 80) * 1e-3, tol_f = (double)env_long("SDHIP_S2PLL_TOL_UFREQ", 100) * 1e-6;
-        const int max_rounds = (int)env_long("SDHIP_S2PLL_ROUNDS", 4);
+        const double tol_p = (double)env_long("SDHIP_S2PLL_TOL_MRAD", 100) * 1e-3, tol_f = (double)env_long("SDHIP_S2PLL_TOL_UFREQ", 250) * 1e-6;
+        const int max_rounds = (int)env_long("SDHIP_S2PLL_ROUNDS", 6);
         m.lanes.clear();
         for (long long g = 0; g < total; g += L)
         {
@@ -766,11 +797,6 @@ namespace sdhip
             ProfScope _ps("k_s2_hdr_est", st);
             hipLaunchKernelGGL(k_s2_hdr_est, dim3((unsigned)nf), dim3(64), 0, st, in, stride, nf, m.ctx.hdr, m.d_z.p);
         }
-        {
-            ProfScope _ps("k_s2_pll_lanes", st);
-            hipLaunchKernelGGL(k_s2_pll_lanes, dim3((unsigned)((nl + 63) / 64)), dim3(64), 0, st, in, out, stride, m.per_frame, m.ctx, m.d_lanes.p, (const int *)nullptr, nl, m.d_z.p, nf,
-                               state.freq, m.d_state.p, m.d_start.p, m.d_end.p);
-        }
         m.h_start.resize(nl);
         m.h_end.resize(nl);
         auto fetch = [&]()
@@ -779,7 +805,50 @@ namespace sdhip
             SD_HIP(hipMemcpyAsync(m.h_end.data(), m.d_end.p, nl * sizeof(S2PllState), hipMemcpyDeviceToHost, st));
             SD_HIP(hipStreamSynchronize(st));
         };
+        auto count_bad = [&]()
+        {
+            int nb = 0;
+            for (int l = 1; l < nl; l++)
+                nb += !s2_state_close(m.h_start[l], m.h_end[l - 1], tol_p, tol_f);
+            return nb;
+        };
+        auto launch_all = [&](double hint)
+        {
+            ProfScope _ps("k_s2_pll_lanes", st);
+            hipLaunchKernelGGL(k_s2_pll_lanes, dim3((unsigned)((nl + 63) / 64)), dim3(64), 0, st, in, out, stride, m.per_frame, m.ctx, m.d_lanes.p, (const int *)nullptr, nl, m.d_z.p, nf,
+                               (float)hint, m.d_state.p, m.d_start.p, m.d_end.p);
+        };
+        launch_all(m.freq_hint);
         fetch();
+        // The estimates' frequency comes from two headers modulo 2 pi / per_frame; the hint picks the branch. When a quarter of the chain misses, the
+        // hint was on the wrong side of a branch boundary (a new stream whose acquisition stretch was short, a frequency step): try its neighbours
+        // and keep the branch the chain agrees with.
+        if (nl >= 8 && count_bad() > nl / 4)
+        {
+            const double sp = 2.0 * M_PI / (double)m.per_frame;
+            const int bad0 = count_bad();
+            int best = bad0;
+            double best_hint = m.freq_hint;
+            for (int j : {+1, -1, +2, -2})
+            {
+                launch_all(m.freq_hint + j * sp);
+                fetch();
+                const int nb = count_bad();
+                stats.branch_tries++;
+                if (nb < best)
+                {
+                    best = nb;
+                    best_hint = m.freq_hint + j * sp;
+                }
+                if (nb <= nl / 16)
+                    break;
+            }
+            if (getenv("SDHIP_DEBUG"))
+                fprintf(stderr, "[sdhip] s2 pll: %d of %d lanes missed with the hint %.3e rad/symbol; branch search -> %.3e (%d miss)\n", bad0, nl, m.freq_hint, best_hint, best);
+            m.freq_hint = best_hint;
+            launch_all(m.freq_hint); // (the last candidate tried is not always the one kept)
+            fetch();
+        }
         // certify the chain: a lane's start state (behind its warm-up) against its predecessor's end state. Lanes that miss are re-run from the
         // predecessor's EXACT end state -- only the heads of runs of missing lanes can be (their predecessor is settled); after max_rounds the rest is
         // re-run once from whatever their predecessors ended with and let through (a stream the loop is not locked on: noise)
@@ -789,6 +858,15 @@ namespace sdhip
             std::vector<char> bad(nl, 0);
             for (int l = 1; l < nl; l++)
                 bad[l] = !s2_state_close(m.h_start[l], m.h_end[l - 1], tol_p, tol_f);
+            if (getenv("SDHIP_DEBUG"))
+                for (int l = 1; l < nl; l++)
+                    if (bad[l])
+                    {
+                        double d = (double)m.h_start[l].phase - (double)m.h_end[l - 1].phase;
+                        d -= 2.0 * M_PI * rint(d / (2.0 * M_PI));
+                        fprintf(stderr, "[sdhip] s2 pll round %d lane %d (step %lld): start - predecessor's end = %+.4f rad, %+.3e rad/symbol (freq %.3e)\n", round, l, m.lanes[l].g0, d,
+                                (double)m.h_start[l].freq - (double)m.h_end[l - 1].freq, (double)m.h_end[l - 1].freq);
+                    }
             const bool last = round >= max_rounds;
             for (int l = 1; l < nl; l++)
                 if (bad[l] && (last || !bad[l - 1]))
@@ -805,7 +883,7 @@ namespace sdhip
             {
                 ProfScope _ps("k_s2_pll_lanes", st);
                 hipLaunchKernelGGL(k_s2_pll_lanes, dim3((unsigned)((m.list.size() + 63) / 64)), dim3(64), 0, st, in, out, stride, m.per_frame, m.ctx, m.d_lanes.p, m.d_list.p,
-                                   (int)m.list.size(), m.d_z.p, nf, state.freq, m.d_state.p, m.d_start.p, m.d_end.p);
+                                   (int)m.list.size(), m.d_z.p, nf, (float)m.freq_hint, m.d_state.p, m.d_start.p, m.d_end.p);
             }
             if (last)
             {
@@ -817,6 +895,11 @@ namespace sdhip
             fetch();
         }
         state = m.h_end[nl - 1];
+        // the next call's hint: the mean loop frequency over the lanes' end states
+        double a = 0.0;
+        for (int l = 0; l < nl; l++)
+            a += m.h_end[l].freq;
+        m.freq_hint = a / (double)nl;
     }
 
     struct S2DemapCache
@@ -921,6 +1004,18 @@ extern "C"
                                  size_t max_frames, size_t *consumed, int *best_pos_out)
     {
         SD_GUARD_BEGIN
+        size_t spec = 64;
+        return s2_pl_sync_run(device, slot_number, pilots, thresold, d_syms, nsyms, d_frames, frame_stride, max_frames, consumed, best_pos_out, &spec);
+        SD_GUARD_END(-1)
+    }
+}
+namespace sdhip
+{
+    // spec_io: how many frame windows the next launch speculates on, carried by a caller with a stream (the engine): a stream in lock searches all
+    // the windows of a call in ONE launch
+    int64_t s2_pl_sync_run(int device, int slot_number, int pilots, float thresold, const float *d_syms, size_t nsyms, float *d_frames, int frame_stride, size_t max_frames,
+                           size_t *consumed, int *best_pos_out, size_t *spec_io)
+    {
         if (slot_number <= 0 || slot_number > 360)
             throw HipError("dvbs2 pl_sync: slot_number out of range");
         const int raw = s2_raw_frame_size(slot_number, pilots);
@@ -939,7 +1034,7 @@ extern "C"
         DevBuf<int> d_bp;
         std::vector<int> h_bp;
         long long pos = 0; // read position of the block's ring buffer
-        size_t spec = 64;
+        size_t spec = std::max<size_t>(8, *spec_io);
         while (starts.size() < max_frames)
         {
             const long long avail = (long long)nsyms - pos;
@@ -976,8 +1071,9 @@ extern "C"
             }
             if (stop)
                 break;
-            spec = (k == nspec) ? std::min<size_t>(spec * 2, 4096) : 8;
+            spec = (k == nspec) ? std::min<size_t>(spec * 2, 65536) : 8;
         }
+        *spec_io = spec;
         const size_t nf = starts.size();
         if (nf > 0)
         {
@@ -995,8 +1091,10 @@ extern "C"
             for (size_t k = 0; k < nf; k++)
                 best_pos_out[k] = bps[k];
         return (int64_t)nf;
-        SD_GUARD_END(-1)
     }
+} // namespace sdhip
+extern "C"
+{
     int sdhip_s2_pll_dev(int device, int modcod, int shortframes, int pilots, float loop_bw, const float *d_frames_in, float *d_frames_out, int frame_stride, int nframes,
                          const float *lut_phase_error, int lut_resolution, float *state2)
     {
@@ -1035,6 +1133,8 @@ extern "C"
         // mode 0: the frame-parallel schedule with the caller vouching that state2 is a locked loop's (any call but a stream's first); mode 2: the
         // same on a new stream (the first frames are walked serially)
         runner->have_hint = mode == 0;
+        if (mode == 0)
+            runner->set_hint(state2[1]);
         if (nframes > 0)
             runner->run(d_frames_in, d_frames_out, frame_stride, nframes, nullptr);
         state2[0] = runner->state.phase;

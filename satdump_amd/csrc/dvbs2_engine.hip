@@ -20,6 +20,7 @@
 #include "../../include/sdhip.h"
 #include "common.h"
 #include "dvbs2_stages.h"
+#include "host_pipe.h"
 
 #include <algorithm>
 #include <cmath>
@@ -95,7 +96,7 @@ namespace sdhip
         std::vector<int8_t> lut_bits;
         // carry-over
         DevBuf<float2> ring, ring2;
-        size_t ring_len = 0;
+        size_t ring_len = 0, pl_spec = 64;
         DevBuf<int8_t> soft, soft2;
         size_t pend_frames = 0;
         double rot_phase = 0.0, current_freq = 0.0;
@@ -106,9 +107,7 @@ namespace sdhip
         DevBuf<unsigned char> d_pack, d_bb;
         DevBuf<double> d_m2m4;
         std::vector<double> h_m2m4;
-        PinBuf<unsigned char> h_bb, h_in;
-        size_t pend_size = 0;
-        int pend_fmt = 0;
+        PinBuf<unsigned char> h_bb;
         std::vector<unsigned char> out_queue;
         size_t out_read = 0;
         sdhip_dvbs2_stats st{};
@@ -155,6 +154,7 @@ namespace sdhip
         }
         ~Dvbs2Engine()
         {
+            pipe.reset(); // the host path's worker thread first
             if (front)
                 sdhip_demod_destroy(front);
             if (ldpc)
@@ -193,10 +193,8 @@ namespace sdhip
             fr.reserve(cap_frames * raw);
             pl.reserve(cap_frames * raw);
             size_t consumed = 0;
-            const int64_t nf = sdhip_s2_pl_sync_dev(device, mc.slots, cfg.pilots ? 1 : 0, cfg.sof_thresold, reinterpret_cast<const float *>(ring.p), ring_len,
-                                                    reinterpret_cast<float *>(fr.p), raw, cap_frames, &consumed, nullptr);
-            if (nf < 0)
-                throw HipError(sdhip_last_error());
+            const int64_t nf = s2_pl_sync_run(device, mc.slots, cfg.pilots ? 1 : 0, cfg.sof_thresold, reinterpret_cast<const float *>(ring.p), ring_len,
+                                              reinterpret_cast<float *>(fr.p), raw, cap_frames, &consumed, nullptr, &pl_spec);
             if (consumed)
             {
                 const size_t left = ring_len - consumed;
@@ -216,6 +214,7 @@ namespace sdhip
             st.pll_rerun += pll->stats.rerun;
             st.pll_forced += pll->stats.forced;
             st.pll_serial_frames += pll->stats.serial_frames;
+            st.pll_branch_tries += pll->stats.branch_tries;
             // the module's statistics (module_dvbs2_demod.cpp:183-198): the estimate behind every frame, the last one and the peak
             {
                 d_m2m4.reserve(2 * (size_t)nf);
@@ -329,6 +328,7 @@ namespace sdhip
             const size_t nb = nframes * (size_t)bbframe_bytes();
             h_bb.reserve(nb);
             SD_HIP(hipMemcpy(h_bb.p, d_bb.p, nb, hipMemcpyDeviceToHost));
+            std::lock_guard<std::mutex> lk(out_mu);
             out_queue.insert(out_queue.end(), h_bb.p, h_bb.p + nb);
         }
         static size_t fmt_bytes(int fmt)
@@ -345,49 +345,35 @@ namespace sdhip
             }
         }
         DevBuf<unsigned char> d_in_tmp;
+        std::unique_ptr<HostPipe> pipe;
+        std::mutex out_mu;
+        // one staged batch on the pipe's worker thread
+        void ship(const uint8_t *pinned, size_t bytes, int fmt)
+        {
+            const size_t ns = bytes / fmt_bytes(fmt);
+            if (ns == 0)
+                return;
+            SD_HIP(hipSetDevice(device));
+            d_in_tmp.reserve(bytes);
+            SD_HIP(hipMemcpy(d_in_tmp.p, pinned, bytes, hipMemcpyHostToDevice));
+            deliver_host(feed_baseband(d_in_tmp.p, ns, fmt));
+        }
         int flush_host()
         {
-            const size_t bps = fmt_bytes(pend_fmt), ns = pend_size / bps;
-            if (ns == 0)
-                return 0;
-            SD_HIP(hipSetDevice(device));
-            d_in_tmp.reserve(pend_size);
-            SD_HIP(hipMemcpy(d_in_tmp.p, h_in.p, pend_size, hipMemcpyHostToDevice));
-            pend_size = 0;
-            deliver_host(feed_baseband(d_in_tmp.p, ns, pend_fmt));
+            if (pipe)
+                pipe->flush();
             return 0;
         }
         int push_host(const void *iq, size_t nsamples, int fmt)
         {
-            if (pend_size != 0 && fmt != pend_fmt)
-                throw HipError("baseband format changed mid-stream");
-            pend_fmt = fmt;
-            const size_t bps = fmt_bytes(fmt);
-            const uint8_t *src = (const uint8_t *)iq;
-            size_t left = nsamples;
-            while (left)
-            {
-                const size_t have = pend_size / bps, take = std::min(left, HOST_BATCH - have);
-                if (pend_size + take * bps > h_in.cap)
-                {
-                    PinBuf<unsigned char> bigger;
-                    bigger.reserve(std::min(HOST_BATCH * bps, std::max<size_t>(2 * (pend_size + take * bps), (size_t)1 << 22)));
-                    if (pend_size)
-                        memcpy(bigger.p, h_in.p, pend_size);
-                    std::swap(bigger.p, h_in.p);
-                    std::swap(bigger.cap, h_in.cap);
-                }
-                memcpy(h_in.p + pend_size, src, take * bps);
-                pend_size += take * bps;
-                src += take * bps;
-                left -= take;
-                if (pend_size / bps >= HOST_BATCH)
-                    flush_host();
-            }
+            if (!pipe)
+                pipe.reset(new HostPipe([this](const uint8_t *p, size_t b, int f) { ship(p, b, f); }));
+            pipe->push(iq, nsamples * fmt_bytes(fmt), fmt, HOST_BATCH * fmt_bytes(fmt));
             return 0;
         }
         int64_t pull(uint8_t *out, size_t cap_frames)
         {
+            std::lock_guard<std::mutex> lk(out_mu);
             const size_t fb = (size_t)bbframe_bytes();
             const size_t avail = (out_queue.size() - out_read) / fb, take = std::min(avail, cap_frames);
             memcpy(out, out_queue.data() + out_read, take * fb);

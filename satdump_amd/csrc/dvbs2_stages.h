@@ -19,6 +19,10 @@ namespace sdhip
     // S2PLLBlock::update (dvbs2_pll.h:33-47): symbols of a frame the loop walks
     int s2_pll_walked(int slots, int pilots);
 
+    // sdhip_s2_pl_sync_dev with the speculation width carried by the caller (dvbs2_demap.hip)
+    int64_t s2_pl_sync_run(int device, int slot_number, int pilots, float thresold, const float *d_syms, size_t nsyms, float *d_frames, int frame_stride, size_t max_frames,
+                           size_t *consumed, int *best_pos_out, size_t *spec_io);
+
     struct S2PllState
     {
         float phase, freq;
@@ -29,6 +33,7 @@ namespace sdhip
         unsigned rerun = 0;   // lanes re-run from their predecessor's exact end state (certificate missed)
         unsigned forced = 0;  // boundaries let through after the round limit (the loop was not locked there)
         unsigned serial_frames = 0; // frames walked by the serial lane (exact mode, acquisition)
+        unsigned branch_tries = 0;  // whole-batch launches spent on the estimates' frequency branch (a quarter of the chain missed)
     };
     struct S2PllImpl;
     // One stream's frame PLL. exact: the serial lane only (bit for bit the reference's loop). Otherwise the frame-parallel schedule (dvbs2_demap.hip):
@@ -44,6 +49,7 @@ namespace sdhip
         S2PllStats stats;
         bool exact;
         bool have_hint = false; // the carried frequency is a locked loop's
+        void set_hint(double freq);   // the loop frequency the estimates pick their branch with (a caller that vouches for a locked state)
         void add_frequency(float df); // the engine's frequency hand-over (freq_prop_factor): the loop's frequency state moves by df
       private:
         std::unique_ptr<S2PllImpl> im;

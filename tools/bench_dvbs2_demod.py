@@ -24,7 +24,7 @@ MODCOD, SYMRATE, SPS, ALPHA, LOOP_BW = 13, 45e6, 2, 0.2, 0.002
 
 def parse(argv=None):
     ap = argparse.ArgumentParser()
-    ap.add_argument("--frames", type=int, default=512, help="PLFRAMEs per step (a multiple of --base)")
+    ap.add_argument("--frames", type=int, default=2048, help="PLFRAMEs per step (a multiple of --base)")
     ap.add_argument("--base", type=int, default=32, help="distinct BBFRAMEs of the periodic recording")
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
@@ -32,7 +32,7 @@ def parse(argv=None):
     ap.add_argument("--trials", type=int, default=10)
     ap.add_argument("--batch", type=int, default=16, help="frames per LDPC decode call of the reference build being replaced (SSE4.1: 16)")
     ap.add_argument("--freq-prop", type=float, default=0.0, help="the module's freq_prop_factor (default 0: what the reference chain beside it can be run with)")
-    ap.add_argument("--cpu-frames", type=int, default=24, help="frames' worth of samples the reference chain decodes on the host (0 = skip)")
+    ap.add_argument("--cpu-frames", type=int, default=64, help="frames' worth of samples the reference chain decodes on the host (0 = skip)")
     ap.add_argument("--exact", type=int, default=0)
     return ap.parse_args(argv)
 
@@ -148,16 +148,19 @@ def run(args) -> dict:
         t5 = time.perf_counter()
         whits = [sent.get(bytes(r), -1) for r in want]
         first = firsts[0] if firsts else got
-        fhits = [sent.get(bytes(r), -1) for r in first[:len(want) + 4]]
-        common = [h for h in whits if h >= 0 and h in fhits]
-        same = all(np.array_equal(want[whits.index(h)], first[fhits.index(h)]) for h in common)
+        # the reference's k-th frame is the stream's k-th PLFRAME (both PL synchronisers emit the same frames; tests/test_dvbs2_gpu.py): compare position by
+        # position where the reference's frame is a transmitted one -- its cold-started loop needs some frames to settle, the lanes' header estimates do not
+        fhits = [sent.get(bytes(r), -1) for r in first[:len(want)]]
+        common = [k for k in range(min(len(want), len(first))) if whits[k] >= 0]
+        same = all(np.array_equal(want[k], first[k]) for k in common)
         out["cpu_baseline"] = {"value": round(len(xr) / (t5 - t1) / 1e6, 3), "unit": "Msym/s", "cores": 1, "kind": "reference",
                                "sample": f"the first {m} samples ({args.cpu_frames} frames' worth): AGC, RRC filter, M&M, S2PLSyncBlock, S2PLLBlock, S2BBToSoft, BBFrameLDPC (SIMD width {fec.batch}), "
                                          "BBFrameBCH, BB descrambler, one after the other on one thread",
                                "stage_seconds": {"front_end": round(t2 - t1, 3), "sync_pll_demap": round(t3 - t2, 3), "ldpc": round(t4 - t3, 3), "bch_descramble": round(t5 - t4, 3)},
                                "ldpc_trials": [int(v) for v in tr[:8]]}
         out["parity_sample"] = {"reference_frames": int(len(want)), "reference_frames_that_are_transmitted_ones": int(sum(h >= 0 for h in whits)),
-                                "frames_both_deliver": len(common), "byte_identical": bool(same and len(common) >= max(1, sum(h >= 0 for h in whits) - 2))}
+                                "reference_hits": whits, "our_hits_on_the_same_positions": fhits,
+                                "frames_compared": len(common), "byte_identical": bool(same and len(common) >= 1)}
     return out
 
 
