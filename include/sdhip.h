@@ -325,7 +325,8 @@ extern "C"
     int sdhip_ldpc_get_info(void *h, sdhip_ldpc_info *out);
     /* nframes (a multiple of batch) frames of code_len int8 each, consecutive, decoded in place; trials[b] for batch b = what
        BBFrameLDPC::decode returns for that call: the update passes it ran, or -1 if the batch did not converge within max_trials
-       (bbframe_ldpc.cpp:114-124). Returns the number of trial launches - 1 (>= 0), < 0 on error. _dev: pointers on cfg->device. */
+       (bbframe_ldpc.cpp:114-124). Returns the number of trial launches - 1 (>= 0), < 0 on error. _dev: pointers on cfg->device, d_frames 4-byte
+       aligned (refused otherwise: the kernel moves the frames as 32-bit words). */
     int sdhip_ldpc_decode_dev(void *h, int8_t *d_frames, int nframes, int max_trials, int *d_trials);
     int sdhip_ldpc_decode(void *h, int8_t *frames, int nframes, int max_trials, int *trials);
 

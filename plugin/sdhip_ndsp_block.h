@@ -148,9 +148,15 @@ namespace sdhip_plugin
                 cfg.constellation = v == "bpsk" ? SDHIP_BPSK : SDHIP_QPSK;
             }
             else if (key == "samplerate")
+            {
                 cfg.samplerate = v;
+                cfg.rec_omega = 0; // setting either rate forces the clock recovery's omega back to samplerate / symbolrate (psk_demod.h:224)
+            }
             else if (key == "symbolrate")
+            {
                 cfg.symbolrate = v;
+                cfg.rec_omega = 0;
+            }
             else if (key == "advanced")
             {
                 advanced_mode = v;
@@ -180,7 +186,11 @@ namespace sdhip_plugin
             SDHIP_SET(pll_freq_limit)
 #undef SDHIP_SET
             else return RES_ERR; // psk_demod.h:250-253
-            needs_reinit = true; // applied at the next buffer, like MMClockRecoveryBlock / FIRBlock do (clock_recovery_mm.cpp:78-82)
+            // Applied at the next buffer, like MMClockRecoveryBlock / FIRBlock do (clock_recovery_mm.cpp:78-82) -- but as a re-creation of the WHOLE
+            // engine: filter history, gain, clock and loop state start over and the filter's ntaps-sample latency is paid again, where the reference
+            // re-initialises only the member block whose key was touched (and changes the Costas order live). A flowgraph configures its blocks
+            // before start(); a key changed in mid-stream costs this block a re-acquisition the reference's would not have.
+            needs_reinit = true;
             return RES_OK;
         }
     };

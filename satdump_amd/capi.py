@@ -339,10 +339,14 @@ class PskDemod:
     def flush(self):
         _check(lib().sdhip_demod_flush(self.h), "sdhip_demod_flush")
 
-    def pull(self, cap: int = 1 << 26) -> np.ndarray:
-        out = np.zeros(cap, dtype=np.int8)
-        n = _check(lib().sdhip_demod_pull(self.h, out.ctypes.data_as(C.c_void_p), cap), "sdhip_demod_pull")
-        return out[:n].copy()
+    def pull(self, cap: int = 1 << 26, out: np.ndarray | None = None) -> np.ndarray:
+        """Up to cap soft bytes; with `out` (an int8 array the caller owns) nothing is allocated and a view of it is returned."""
+        if out is None:
+            out = np.empty(cap, dtype=np.int8)
+            n = _check(lib().sdhip_demod_pull(self.h, out.ctypes.data_as(C.c_void_p), cap), "sdhip_demod_pull")
+            return out[:n].copy()
+        n = _check(lib().sdhip_demod_pull(self.h, out.ctypes.data_as(C.c_void_p), min(cap, out.size)), "sdhip_demod_pull")
+        return out[:n]
 
     def process_dev(self, iq_ptr: int, nsamples: int, fmt: int, soft_ptr: int, soft_cap: int, syms_ptr: int = 0, syms_cap: int = 0, final: bool = True) -> int:
         return _check(lib().sdhip_demod_process_dev(self.h, C.c_void_p(iq_ptr), nsamples, fmt, C.c_void_p(soft_ptr), soft_cap,

@@ -12,6 +12,7 @@ namespace sdhip
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
+#include <deque>
 #include <chrono>
 #include <cstring>
 #include <memory>
@@ -537,8 +538,13 @@ namespace sdhip
         std::unique_ptr<HostPipe> pipe;
         PinBuf<int8_t> h_out;
         std::mutex out_mu;
-        std::vector<int8_t> out_queue;
-        size_t out_read = 0;
+        struct OutChunk
+        {
+            std::unique_ptr<int8_t[]> p;
+            size_t n;
+        };
+        std::deque<OutChunk> out_queue; // one chunk per shipped batch (no reallocation of what is queued), oldest first
+        size_t out_read = 0;           // bytes of the front chunk already pulled
 
         sdhip_demod_stats stats{};
 
@@ -1944,8 +1950,10 @@ namespace sdhip
             h_out.reserve((size_t)n + 1);
             SD_HIP(hipMemcpyAsync(h_out.p, d_soft_tmp.p, (size_t)n, hipMemcpyDeviceToHost, stream));
             SD_HIP(hipStreamSynchronize(stream));
+            OutChunk c{std::unique_ptr<int8_t[]>(new int8_t[(size_t)n + 1]), (size_t)n};
+            CopyPool::get().copy(c.p.get(), h_out.p, (size_t)n);
             std::lock_guard<std::mutex> lk(out_mu);
-            out_queue.insert(out_queue.end(), h_out.p, h_out.p + n);
+            out_queue.push_back(std::move(c));
         }
         int push_host(const void *iq, size_t nsamples, int fmt)
         {
@@ -1963,17 +1971,30 @@ namespace sdhip
         }
         int64_t pull(int8_t *soft, size_t cap)
         {
-            std::lock_guard<std::mutex> lk(out_mu);
-            const size_t avail = out_queue.size() - out_read;
-            const size_t take = std::min(avail, cap);
-            memcpy(soft, out_queue.data() + out_read, take);
-            out_read += take;
-            if (out_read == out_queue.size())
+            size_t done = 0;
+            while (done < cap)
             {
-                out_queue.clear();
-                out_read = 0;
+                const int8_t *src;
+                size_t take;
+                {
+                    std::lock_guard<std::mutex> lk(out_mu);
+                    if (out_queue.empty())
+                        break;
+                    const OutChunk &c = out_queue.front();
+                    take = std::min(c.n - out_read, cap - done);
+                    src = c.p.get() + out_read; // the front chunk stays where it is while this (single) consumer copies out of it
+                }
+                CopyPool::get().copy(soft + done, src, take);
+                done += take;
+                std::lock_guard<std::mutex> lk(out_mu);
+                out_read += take;
+                if (out_read == out_queue.front().n)
+                {
+                    out_queue.pop_front();
+                    out_read = 0;
+                }
             }
-            return (int64_t)take;
+            return (int64_t)done;
         }
     };
 } // namespace sdhip
@@ -2070,6 +2091,12 @@ extern "C"
             throw HipError("ndsp psk_demod: the HIP path carries the 128 x 8 interpolator bank only");
         if (!(c->samplerate > 0) || !(c->symbolrate > 0))
             throw HipError("ndsp psk_demod: samplerate and symbolrate must be set");
+        // the stage buffers hold one symbol per input sample at most: an omega below one sample per symbol (the advanced "rec_omega" key; 0 = samplerate /
+        // symbolrate) would have the clock recovery write more symbols than samples came in
+        if (c->rec_omega != 0.0f && !(c->rec_omega * (1.0f - fabsf(c->rec_omegaLimit)) >= 1.0f))
+            throw HipError("ndsp psk_demod: rec_omega (with rec_omegaLimit) must stay at or above one sample per symbol");
+        if (c->rec_omega == 0.0f && !(c->samplerate / c->symbolrate * (1.0 - fabs((double)c->rec_omegaLimit)) >= 1.0))
+            throw HipError("ndsp psk_demod: samplerate / symbolrate (with rec_omegaLimit) must stay at or above one sample per symbol");
         sdhip_demod_cfg d;
         sdhip_demod_cfg_default(&d);
         d.device = c->device;

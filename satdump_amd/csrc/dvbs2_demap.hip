@@ -769,8 +769,8 @@ namespace sdhip
         const long long total = (long long)nf * m.per_frame;
         const long W = std::max<long>(0, env_long("SDHIP_S2PLL_W", 2048));
         long L = env_long("SDHIP_S2PLL_L", 0);
-        if (L <= 0)
-            L = std::max<long long>(4096, (total + 4095) / 4096);
+        if (L <= 0) // up to 16 384 lanes (256 waves: a wave per CU) of at least 2048 steps: the lanes' serial walk is the stage's time, re-run rounds cost one more each
+            L = std::max<long long>(2048, (total + 16383) / 16384);
         L = std::max<long>(L, std::max<long>(W, 64));
         const double tol_p = (double)env_long("SDHIP_S2PLL_TOL_MRAD", 100) * 1e-3, tol_f = (double)env_long("SDHIP_S2PLL_TOL_UFREQ", 250) * 1e-6;
         const int max_rounds = (int)env_long("SDHIP_S2PLL_ROUNDS", 6);

@@ -443,6 +443,8 @@ extern "C"
     int sdhip_ldpc_decode_dev(void *h, int8_t *d_frames, int nframes, int max_trials, int *d_trials)
     {
         SD_GUARD_BEGIN
+        if (reinterpret_cast<uintptr_t>(d_frames) & 3u) // the kernel moves the frames as 32-bit words (code_len is a multiple of 4)
+            throw HipError("dvbs2 ldpc: d_frames must be 4-byte aligned");
         return static_cast<LdpcEngine *>(h)->decode_dev(reinterpret_cast<signed char *>(d_frames), nframes, max_trials, d_trials);
         SD_GUARD_END(-1)
     }

@@ -20,7 +20,7 @@ namespace sdhip
     class CopyPool
     {
         std::vector<std::thread> th;
-        std::mutex mu;
+        std::mutex mu, call_mu; // call_mu: one copy() at a time (the caller's staging copy and the worker's result copy may meet)
         std::condition_variable cv_go, cv_done;
         struct Job
         {
@@ -81,6 +81,7 @@ namespace sdhip
                 memcpy(dst, src, bytes);
                 return;
             }
+            std::lock_guard<std::mutex> one(call_mu);
             std::unique_lock<std::mutex> lk(mu);
             const size_t per = ((bytes + n - 1) / n + 4095) & ~(size_t)4095;
             for (int i = 0; i < n; i++)

@@ -30,6 +30,8 @@ def test_committed_pmc_profile_belongs_to_the_sources_in_the_tree():
     import bench
     from satdump_amd import build
     traffic, src = bench.pmc_traffic("metop_ahrpt", "k_afc")
+    if src and "stale" in src and os.environ.get("SDHIP_FINAL") == "1":
+        pytest.fail("SDHIP_FINAL=1 (the round's closing check): the committed PMC profile is of other kernel sources (" + src + ")")
     if src and "stale" in src:
         pytest.skip("the committed PMC profile is of other kernel sources (" + src + "): take the two --pmc passes again before the round ends")
     for k in ("k_afc", "k_mm", "k_vit2_acs", "k_quantize"):
