@@ -399,7 +399,13 @@ def run_workload(args, workload, n_steps, n_warmup, parity_samples, ctx):
     if world == 1:
         def step():
             ns = dem.process_dev(x.data_ptr(), n_in, capi.FMT_CF32, d_soft.data_ptr(), soft_cap)
-            nf = fec.process_dev(d_soft.data_ptr(), ns, d_cadu.data_ptr(), cap_frames)
+            # where this rank's soft stream continues its predecessor's (a few KB of boundary symbols exchanged), and from there the byte its decoder starts at:
+            # on the single stream's Viterbi block grid -- the N lists then stitch into the single stream's list, whole frames (shard.hip)
+            lag, turn, agree, before, found = shard.align_ranks(lambda nb: d_soft[ns - nb:ns].cpu().numpy(), lambda nb: d_soft[:nb].cpu().numpy(), ns, q_soft, plan, rank, world,
+                                                                all_gather_np)
+            start = shard.fec_start(before, lag, q_soft, lock_block, lock_fec, int(lock_demod / sps_nom) * q_soft) if rank and found else 0
+            state["align"] = {"lag_symbols": lag, "quarter_turns": turn, "agreement": round(agree, 4), "found": bool(found), "decoder_starts_at_soft_byte": start}
+            nf = fec.process_dev(d_soft.data_ptr() + start, ns - start, d_cadu.data_ptr(), cap_frames)
             return ns, nf
     else:
         # one cold start per step: fresh handles, their device blocks recycled through the library's pool
@@ -407,6 +413,15 @@ def run_workload(args, workload, n_steps, n_warmup, parity_samples, ctx):
         # boundary frames each rank contributes to the stitch: every frame that can lie in the lock-in overlap, plus a margin
         EDGE = shard.edge_frames(overlap, rec.samples_per_block / frames)
         state = {}
+        q_soft = wl["soft_per_sym"]
+        sps_nom = wl["spec"]["samplerate"] / wl["spec"]["symbolrate"]
+        lock_demod, lock_fec, lock_block = shard.lockin_parts(wl["demod"], wl["fec"])
+
+        def all_gather_np(a):
+            t = torch.from_numpy(np.ascontiguousarray(a)).to(coll_dev)
+            outv = [torch.empty_like(t) for _ in range(world)]
+            dist.all_gather(outv, t)
+            return [o.cpu().numpy() for o in outv]
 
         def step():
             nonlocal dem, fec
@@ -415,7 +430,13 @@ def run_workload(args, workload, n_steps, n_warmup, parity_samples, ctx):
             dem = capi.PskDemod(capi.demod_cfg(**dcfg_kw))
             fec = capi.FecDecoder(capi.fec_cfg(**fcfg_kw))
             ns = dem.process_dev(x.data_ptr(), n_in, capi.FMT_CF32, d_soft.data_ptr(), soft_cap)
-            nf = fec.process_dev(d_soft.data_ptr(), ns, d_cadu.data_ptr(), cap_frames)
+            # where this rank's soft stream continues its predecessor's (a few KB of boundary symbols exchanged), and from there the byte its decoder starts at:
+            # on the single stream's Viterbi block grid -- the N lists then stitch into the single stream's list, whole frames (shard.hip)
+            lag, turn, agree, before, found = shard.align_ranks(lambda nb: d_soft[ns - nb:ns].cpu().numpy(), lambda nb: d_soft[:nb].cpu().numpy(), ns, q_soft, plan, rank, world,
+                                                                all_gather_np)
+            start = shard.fec_start(before, lag, q_soft, lock_block, lock_fec, int(lock_demod / sps_nom) * q_soft) if rank and found else 0
+            state["align"] = {"lag_symbols": lag, "quarter_turns": turn, "agreement": round(agree, 4), "found": bool(found), "decoder_starts_at_soft_byte": start}
+            nf = fec.process_dev(d_soft.data_ptr() + start, ns - start, d_cadu.data_ptr(), cap_frames)
             # stitch on the host from the boundary frames only (the CADU lists themselves stay with their ranks, like the
             # per-module output files of the reference): [count | first EDGE frames | last EDGE frames] per rank
             edge = torch.zeros((2 * EDGE + 1, cadu_bytes), dtype=torch.uint8, device=device)
@@ -431,7 +452,7 @@ def run_workload(args, workload, n_steps, n_warmup, parity_samples, ctx):
                 counts = [int.from_bytes(bytes(a[0, :8]), "little") for a in hv]
                 heads = [a[1:1 + min(EDGE, c)] for a, c in zip(hv, counts)]
                 tails = [a[1 + EDGE:1 + EDGE + min(EDGE, c)] for a, c in zip(hv, counts)]
-                state["drops"] = shard.stitch_plan(heads, tails, counts, EDGE)
+                state["drops"] = shard.stitch_plan(heads, tails, counts, EDGE, whole_frames=True)
                 state["counts"] = counts
             return ns, nf
 
@@ -531,7 +552,7 @@ def run_workload(args, workload, n_steps, n_warmup, parity_samples, ctx):
                 stitched_total = int(sum(counts) - sum(drops))
                 check = {"cadus_last_step_all_ranks": int(c[0].item()), "cadus_matching_transmitted": int(c[1].item()),
                          "payload_matching_transmitted": int(c[2].item()), "transmitted": int(frames * blocks),
-                         "stitched": stitched_total, "dropped_as_decoded_twice": [int(d) for d in drops]}
+                         "stitched": stitched_total, "dropped_as_decoded_twice": [int(d) for d in drops], "rank0_alignment": state.get("align")}
                 if args.dump:
                     with open(args.dump + ".json", "w") as fh:
                         json.dump({"drops": [int(d) for d in drops], "counts": [int(c) for c in counts]}, fh)
@@ -665,7 +686,8 @@ def run_workload(args, workload, n_steps, n_warmup, parity_samples, ctx):
             sharding = "one continuous stream on one GPU"
         else:
             sharding = (f"ONE recording of {rec.n_samples} samples cut into {world} contiguous chunks, one per GPU, each read from {overlap} samples early "
-                        f"(lock-in overlap), cold start per step, per-rank CADU lists stitched on the host from the boundary frames; no data-path collective")
+                        f"(lock-in overlap), cold start per step, every rank's decoder started on the single stream's Viterbi block grid (found from a few KB of boundary symbols: "
+                        f"sdhip_shard_align), per-rank CADU lists stitched on the host from the boundary frames compared whole; no data-path collective")
         out = {
             "metric": "Msamples/s IQ through PSK demod -> Viterbi -> RS (HBM-resident cf32)",
             "value": round(samples_all / dt_all / 1e6, 3), "unit": "Msamples/s", "n_gpus": world, "steps": steps, "warmup": n_warmup,

@@ -454,6 +454,37 @@ extern "C"
     int64_t sdhip_dvbs2_demod_symbols_dev(void *h, const float *d_syms, size_t nsyms, uint8_t *d_bbframes, size_t cap_frames);
     int sdhip_dvbs2_demod_get_stats(void *h, sdhip_dvbs2_stats *st);
 
+    /* ---- stream-parallel sharding of one recording over several devices / ranks (shard.hip) ------------------------------------------
+       Host logic only. The reference runs ONE stream (a thread per module, src-core/pipeline/pipeline_run.cpp:72-104); cutting a recording in time is what
+       N devices add, and these entry points are what makes the N chunks end in the single stream's CADU list: plan the sample ranges, find where a
+       chunk's soft stream continues its predecessor's (so that its decoder starts on the single stream's Viterbi block grid), drop the frames two
+       neighbours both decoded. bench.py --gpus N (torch.distributed, one process per GPU) and the plugin's "hip_devices" key use them. */
+    typedef struct sdhip_shard_range
+    {
+        uint64_t read_start; /* first sample the chunk reads (own_start - overlap, clipped at 0) */
+        uint64_t own_start;  /* first sample of the chunk's own range */
+        uint64_t stop;       /* one past its last sample */
+    } sdhip_shard_range;
+    /* samples a chunk reads in front of its own range: the lock-in times of the stages from the modules' loop constants (shard.hip) */
+    uint64_t sdhip_shard_overlap(const sdhip_demod_cfg *demod, const sdhip_fec_cfg *fec);
+    /* its parts: out3 = {samples until a cold-started demodulator is locked, soft bytes a cold-started decoder needs in front of the first frame that counts,
+       the decoder's block in soft bytes} */
+    int sdhip_shard_lockin(const sdhip_demod_cfg *demod, const sdhip_fec_cfg *fec, uint64_t *out3);
+    /* n_samples cut into `world` contiguous ranges whose boundaries are multiples of `align` samples */
+    int sdhip_shard_plan(uint64_t n_samples, int world, uint64_t overlap, int align, sdhip_shard_range *out);
+    /* prev_tail: the predecessor's LAST n_prev soft bytes; head: this chunk's first n_head soft bytes (both int8 as psk_demod writes them, q = 1 byte per
+       symbol for BPSK, 2 otherwise). Both chunks demodulated the overlap's samples: finds *lag_symbols = the index in `head` of the symbol that follows the
+       predecessor's last one, and *turn = the quarter turns (0..3; 0 / 2 for BPSK) this chunk's constellation is rotated by against the predecessor's,
+       searching lags within `radius` symbols of `expect` (radius <= 0: everywhere). *agreement = fraction of equal hard decisions at the best lag (the two
+       demodulators saw the same noise: ~1 at the right lag, ~0.5 elsewhere). Returns 0, 1 if no lag reaches 0.9, <0 on error. */
+    int sdhip_shard_align(const int8_t *prev_tail, size_t n_prev, const int8_t *head, size_t n_head, int q, int64_t expect, int64_t radius, int64_t *lag_symbols, int *turn,
+                          float *agreement);
+    /* drops_out[r] = frames to drop at the head of chunk r's frame list, from boundary frames alone: heads[r] / tails[r] = its first n_heads[r] / last
+       n_tails[r] frames (at most `edge` each), counts[r] = how many it decoded. whole_frames != 0: frames are compared whole (decoders on the common block
+       grid); 0: behind the 4-byte sync marker. An overlap of more than `edge` frames is an error, not a silent duplicate. */
+    int sdhip_shard_stitch(const uint8_t *const *heads, const size_t *n_heads, const uint8_t *const *tails, const size_t *n_tails, const uint64_t *counts, int world, int frame_bytes,
+                           size_t edge, int whole_frames, uint64_t *drops_out);
+
     /* ---- misc ------------------------------------------------------------------------ */
     const char *sdhip_last_error(void);
     const char *sdhip_version(void);

@@ -31,6 +31,7 @@
 #include <cmath>
 #include <cstring>
 #include <fstream>
+#include <thread>
 #include <vector>
 
 namespace sdhip_plugin
@@ -104,6 +105,7 @@ namespace sdhip_plugin
         void *h = nullptr;
         std::string baseband_format = "cf32";
         int fmt = SDHIP_FMT_CF32;
+        std::vector<int> devices; // "hip_devices": a baseband FILE is cut in time over these devices (process_sharded)
         std::atomic<uint64_t> filesize{0}, progress{0};
         std::atomic<float> display_freq{0}, snr{0}, peak_snr{0};
         std::atomic<bool> should_stop{false};
@@ -181,6 +183,8 @@ namespace sdhip_plugin
             // engine knobs of the HIP path (no reference equivalent)
             opt(parameters, "hip_device", cfg.device);
             opt(parameters, "hip_exact", cfg.exact);
+            if (parameters.count("hip_devices") > 0) // e.g. [0, 1, 2, 3, 4, 5, 6, 7]: one recording over the GPUs of a node
+                devices = parameters["hip_devices"].get<std::vector<int>>();
             fmt = baseband_fmt_of(baseband_format, "psk_demod_hip");
         }
         ~PSKDemodHipModule()
@@ -247,6 +251,161 @@ namespace sdhip_plugin
             display_freq = st.freq_hz;
         }
 
+        // ---- one baseband FILE over several devices (the C ABI's sdhip_shard_*). The recording is cut into contiguous ranges, one per device,
+        // each read from `overlap` samples early; a thread per device demodulates its range with its own handle (cold start: AGC, Costas and clock loops
+        // lock inside the overlap); then chunk r's soft stream is cut where it CONTINUES chunk r-1's (both demodulated the overlap's samples:
+        // sdhip_shard_align finds the symbol lag and the quarter turns the two carrier loops locked apart) and turned back onto chunk 0's constellation.
+        // The .soft file written is ONE symbol stream, symbol for symbol the single device's (values: another trajectory of the same loops on the same
+        // samples, +-1 LSB on ~0.1 % of the symbols), so the decoder behind it delivers the single stream's CADUs.
+        static void turn_soft(int8_t *s, size_t n, int q, int turns)
+        {
+            auto neg = [](int8_t v) { return (int8_t)(v == -128 ? 127 : -v); };
+            turns &= 3;
+            if (turns == 0)
+                return;
+            if (q == 1)
+            {
+                if (turns == 2)
+                    for (size_t i = 0; i < n; i++)
+                        s[i] = neg(s[i]);
+                return;
+            }
+            for (size_t i = 0; i + 1 < n; i += 2)
+            {
+                const int8_t a = s[i], b = s[i + 1];
+                if (turns == 1)
+                    s[i] = neg(b), s[i + 1] = a;
+                else if (turns == 2)
+                    s[i] = neg(a), s[i + 1] = neg(b);
+                else
+                    s[i] = b, s[i + 1] = neg(a);
+            }
+        }
+        void process_sharded()
+        {
+            static const int bps[5] = {8, 4, 2, 2, 8};
+            const int N = (int)devices.size(), q = cfg.constellation == SDHIP_BPSK ? 1 : 2;
+            std::ifstream probe(d_input_file, std::ios::binary | std::ios::ate);
+            filesize = (uint64_t)probe.tellg();
+            const uint64_t n_samples = filesize / bps[fmt];
+            // overlap: the demodulator's lock-in plus the window the alignment looks at
+            sdhip_fec_cfg fdummy;
+            sdhip_fec_cfg_default(&fdummy);
+            uint64_t lock[3];
+            if (sdhip_shard_lockin(&cfg, &fdummy, lock) != 0)
+                throw satdump_exception(std::string("psk_demod_hip: ") + sdhip_last_error());
+            const double sps = cfg.samplerate / cfg.symbolrate;
+            const int64_t T = 2048, R = 8192;
+            const uint64_t overlap = (lock[0] + (uint64_t)((T + R + 1024) * sps) + 7) / 8 * 8;
+            std::vector<sdhip_shard_range> plan(N);
+            if (sdhip_shard_plan(n_samples, N, overlap, 8, plan.data()) != 0)
+                throw satdump_exception(std::string("psk_demod_hip: ") + sdhip_last_error());
+            std::vector<std::vector<int8_t>> soft(N);
+            std::vector<std::string> errs(N);
+            std::vector<std::thread> th;
+            // SDHIP_PLUGIN_SERIAL_CHUNKS=1: one chunk after the other (the test suite's host twin of the library runs one kernel at a time)
+            const char *ser = getenv("SDHIP_PLUGIN_SERIAL_CHUNKS");
+            const bool serial_chunks = ser && std::string(ser) == "1";
+            for (int r = 0; r < N; r++)
+            {
+                th.emplace_back(
+                    [&, r]()
+                    {
+                        try
+                        {
+                            sdhip_demod_cfg c = cfg;
+                            c.device = devices[r];
+                            void *e = sdhip_demod_create(&c);
+                            if (!e)
+                                throw std::runtime_error(sdhip_last_error());
+                            std::ifstream in(d_input_file, std::ios::binary);
+                            in.seekg((std::streamoff)(plan[r].read_start * bps[fmt]));
+                            uint64_t left = plan[r].stop - plan[r].read_start;
+                            const size_t piece = 1 << 22;
+                            std::vector<char> raw(piece * bps[fmt]);
+                            std::vector<int8_t> buf(1 << 24);
+                            soft[r].reserve((size_t)((double)left / sps * q * 1.02) + 4096);
+                            auto drain = [&]() {
+                                for (;;)
+                                {
+                                    const int64_t n = sdhip_demod_pull(e, buf.data(), buf.size());
+                                    if (n < 0)
+                                        throw std::runtime_error(sdhip_last_error());
+                                    if (n == 0)
+                                        break;
+                                    soft[r].insert(soft[r].end(), buf.begin(), buf.begin() + n);
+                                }
+                            };
+                            while (left && !should_stop)
+                            {
+                                const size_t want = (size_t)std::min<uint64_t>(left, piece);
+                                in.read(raw.data(), want * bps[fmt]);
+                                const size_t got = (size_t)in.gcount() / bps[fmt];
+                                if (got == 0)
+                                    break;
+                                if (sdhip_demod_push(e, raw.data(), got, fmt) < 0)
+                                    throw std::runtime_error(sdhip_last_error());
+                                left -= got;
+                                progress = progress + (uint64_t)(got * bps[fmt] * (double)(plan[r].stop - plan[r].own_start) / (double)(plan[r].stop - plan[r].read_start));
+                                drain();
+                            }
+                            if (sdhip_demod_flush(e) < 0)
+                                throw std::runtime_error(sdhip_last_error());
+                            drain();
+                            if (r == N - 1)
+                            {
+                                sdhip_demod_stats st;
+                                sdhip_demod_get_stats(e, &st);
+                                display_freq = st.freq_hz;
+                            }
+                            sdhip_demod_destroy(e);
+                        }
+                        catch (const std::exception &ex)
+                        {
+                            errs[r] = ex.what();
+                        }
+                    });
+                if (serial_chunks)
+                    th.back().join();
+            }
+            for (auto &t : th)
+                if (t.joinable())
+                    t.join();
+            for (int r = 0; r < N; r++)
+                if (!errs[r].empty())
+                    throw satdump_exception("psk_demod_hip (device " + std::to_string(devices[r]) + "): " + errs[r]);
+            int cum_turn = 0;
+            for (int r = 0; r < N; r++)
+            {
+                size_t from = 0;
+                if (r > 0)
+                {
+                    const size_t nprev = std::min<size_t>(soft[r - 1].size(), (size_t)T * q) / q * q;
+                    const int64_t nsym = (int64_t)(soft[r].size() / q);
+                    const int64_t expect = (int64_t)((double)nsym * (double)(plan[r].own_start - plan[r].read_start) / (double)(plan[r].stop - plan[r].read_start));
+                    int64_t lag = 0;
+                    int turn = 0;
+                    float agree = 0;
+                    // (chunk r-1 has been turned onto chunk 0's constellation already: the turn found is chunk r's against chunk 0)
+                    const int rc = sdhip_shard_align(soft[r - 1].data() + soft[r - 1].size() - nprev, nprev, soft[r].data(), soft[r].size(), q, expect, R, &lag, &turn, &agree);
+                    if (rc != 0)
+                        throw satdump_exception("psk_demod_hip: chunk " + std::to_string(r) + " does not continue its predecessor (agreement " + std::to_string(agree) +
+                                                "): the signal was not locked across the cut -- run the recording on one device");
+                    cum_turn = turn;
+                    from = (size_t)lag * q;
+                    logger->info("psk_demod_hip: device %d continues at its symbol %lld, %d quarter turn(s) from the first chunk (agreement %.4f)", devices[r], (long long)lag, turn, agree);
+                }
+                // a chunk's own soft symbols turn onto chunk 0's constellation: multiples of a quarter turn are exact on int8 (swaps / negations)
+                turn_soft(soft[r].data() + from, soft[r].size() - from, q, cum_turn); // sdhip_shard_align's turn = what takes this chunk onto the predecessor's constellation
+                if (output_data_type == DATA_FILE)
+                    data_out.write((char *)soft[r].data() + from, soft[r].size() - from);
+                else
+                    output_fifo->write((uint8_t *)soft[r].data() + from, soft[r].size() - from);
+                snr_update(soft[r].data() + from, std::min<size_t>(soft[r].size() - from, (size_t)1 << 22));
+            }
+            progress = filesize.load();
+        }
+
         void process()
         {
             if (output_data_type == DATA_FILE)
@@ -256,6 +415,14 @@ namespace sdhip_plugin
             }
             logger->info("Using input baseband " + d_input_file);
             logger->info("Demodulating to " + d_output_file_hint + ".soft (MI355X path)");
+            if (devices.size() > 1 && input_data_type == DATA_FILE)
+            {
+                process_sharded();
+                if (output_data_type == DATA_FILE)
+                    data_out.close();
+                logger->info("Demodulation finished (%d devices)", (int)devices.size());
+                return;
+            }
             std::vector<int8_t> out(1 << 24);
             static const int bps[5] = {8, 4, 2, 2, 8}; // bytes per complex sample, indexed by SDHIP_FMT_* (cf32, cs16, cs8, cu8, cs32)
             if (input_data_type == DATA_FILE)

@@ -1,6 +1,6 @@
 """N>1 path on CPU: world_size-2 gloo processes run the sharding plan of satdump_amd/shard.py on ONE synthetic recording
-(every rank synthesises its own range of it, as bench.py does), each rank decoding its chunk with the ORACLE standing in for the
-GPU engines (test infrastructure: there is no GPU here and the product has no CPU path; tests/test_multirank_gpu.py is the
+(every rank synthesises its own range of it, as bench.py does), each rank demodulating its chunk, aligning its soft stream with its predecessor's (shard.align_ranks -> sdhip_shard_align) and decoding from the single
+stream's Viterbi block grid, with the ORACLE standing in for the GPU engines (test infrastructure: there is no GPU here and the product has no CPU path; tests/test_multirank_gpu.py is the
 same run on the engines), rank 0 stitches from the boundary frames. The stitched CADU list must equal what the sequential
 reference decodes from the whole recording (minus the frames lost while the very first rank locks, which the sequential
 run loses too), and the timing/counter reduction must be max / sum over ranks."""
@@ -52,11 +52,18 @@ SPEC = dict(constellation="qpsk", samplerate=30e6, symbolrate=15e6, conv="1/2", 
 FRAMES = 48
 
 
-def _decode(x):
+def _demod(x):
     from oracle import pyref
-    orc = pyref.best()
-    soft = orc.psk_demod(pyref.demod_cfg(samplerate=30e6, symbolrate=15e6, constellation=pyref.QPSK, pll_bw=0.002), x, want_syms=False)["soft"]
-    return orc.concat_decode(pyref.fec_cfg(constellation=pyref.QPSK, nrzm=1, rs_usecheck=1), soft)["cadu"]
+    return pyref.best().psk_demod(pyref.demod_cfg(samplerate=30e6, symbolrate=15e6, constellation=pyref.QPSK, pll_bw=0.002), x, want_syms=False)["soft"]
+
+
+def _fec(soft):
+    from oracle import pyref
+    return pyref.best().concat_decode(pyref.fec_cfg(constellation=pyref.QPSK, nrzm=1, rs_usecheck=1), soft)["cadu"]
+
+
+def _decode(x):
+    return _fec(_demod(x))
 
 
 def _worker(rank, world, port, out_dir):
@@ -67,7 +74,21 @@ def _worker(rank, world, port, out_dir):
     # every rank synthesises ITS range of the one recording (a pure function of the absolute sample index)
     rec = synth.Recording(synth.SynthSpec(**SPEC), FRAMES, blocks=world)
     me = shard.plan_chunks(rec.n_samples, world, shard.lockin_overlap(DEMOD, FEC))[rank]
-    cadu = _decode(rec.synth_range(me["read_start"], me["stop"]))
+    soft = _demod(rec.synth_range(me["read_start"], me["stop"]))
+
+    def all_gather(a):
+        t = torch.from_numpy(np.ascontiguousarray(a))
+        out = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(out, t)
+        return [o.numpy() for o in out]
+    # where this rank's soft stream continues its predecessor's, and from there the byte its decoder starts at: on the single stream's Viterbi block grid
+    q = 2
+    demod_lock, fec_lock, block = shard.lockin_parts(DEMOD, FEC)
+    lag, turn, agree, before, found = shard.align_ranks(lambda nb: soft[len(soft) - nb:], lambda nb: soft[:nb], len(soft), q, me, rank, world, all_gather)
+    assert found and agree > 0.99, (rank, lag, agree)
+    start = shard.fec_start(before, lag, q, block, fec_lock, int(demod_lock / 2.0) * q) if rank else 0
+    assert rank == 0 or (start > 0 and (before * q - (lag * q - start)) % block == 0)
+    cadu = _fec(soft[start:])
     # the boundary exchange bench.py does: [count | first EDGE | last EDGE] frames per rank
     EDGE = 64
     edge = torch.zeros((2 * EDGE + 1, 1024), dtype=torch.uint8)
@@ -83,9 +104,10 @@ def _worker(rank, world, port, out_dir):
     if rank == 0:
         hv = [a.numpy() for a in allv]
         counts = [int.from_bytes(bytes(a[0, :8]), "little") for a in hv]
-        drops = shard.stitch_plan([a[1:1 + min(EDGE, c)] for a, c in zip(hv, counts)], [a[1 + EDGE:1 + EDGE + min(EDGE, c)] for a, c in zip(hv, counts)], counts)
+        drops = shard.stitch_plan([a[1:1 + min(EDGE, c)] for a, c in zip(hv, counts)], [a[1 + EDGE:1 + EDGE + min(EDGE, c)] for a, c in zip(hv, counts)], counts,
+                                  whole_frames=True)
         np.save(os.path.join(out_dir, "stitched.npy"), np.concatenate([g[d:] for g, d in zip(gathered, drops)], axis=0))
-        np.save(os.path.join(out_dir, "stitched_full.npy"), shard.stitch_cadus(gathered))
+        np.save(os.path.join(out_dir, "stitched_full.npy"), shard.stitch_cadus(gathered, whole_frames=True))
         np.save(os.path.join(out_dir, "metrics.npy"), np.array([dt, ns, nf, sum(len(g) for g in gathered)] + drops))
     dist.barrier()
     dist.destroy_process_group()
@@ -103,8 +125,9 @@ def test_two_ranks_shard_one_recording(tmp_path):
     dt, ns, nf, ntot, drops = m[0], m[1], m[2], m[3], m[4:]
     assert dt == 2.0 and ns == float(rec.n_samples) and nf == ntot  # max over ranks / sums over ranks
     assert drops[0] == 0 and drops[1] >= 1  # the overlap was decoded by both ranks and stitched away
-    # identical frame list (sync marker aside: it is not RS protected)
-    assert got.shape == want.shape and np.array_equal(got[:, 4:], want[:, 4:])
+    # the single stream's frame list, WHOLE frames -- sync marker and RS parity included (round 4: every rank decodes on the single stream's Viterbi block
+    # grid, found from the boundary symbols)
+    assert got.shape == want.shape and np.array_equal(got, want)
     assert np.array_equal(np.load(str(tmp_path / "stitched_full.npy")), got)
     plain = np.concatenate([rec.plain_cadus(b) for b in range(world)])
     ids = util.frame_ids(got, plain)

@@ -44,11 +44,12 @@ def test_two_ranks_shard_one_recording_on_the_engines(tmp_path, workload, frames
     got = np.concatenate(parts, axis=0)
     assert meta["drops"][0] == 0 and meta["drops"][1] >= 1  # the overlap really was decoded twice
     assert two["check"]["stitched"] == len(got)
-    # same frames, same order (the sync marker is not RS protected and may differ in a bit between two decodes). The decoders
-    # work in whole Viterbi buffers and the last rank's soft stream starts elsewhere than the single run's, so the remainder
-    # that stays undecoded at the very end of the recording differs: one frame more or less at the END, none anywhere else.
+    # The single rank's list, WHOLE frames -- sync marker and RS parity included, MetOp (rs_usecheck off) too. Round 4: every rank finds where its soft stream
+    # continues its predecessor's (sdhip_shard_align on a few KB of boundary symbols) and starts its decoder on the single stream's Viterbi block grid, so the
+    # N decoders decode the very blocks one decoder decodes. The decoders work in whole Viterbi buffers, so the remainder that stays
+    # undecoded at the very end of the recording can differ: one frame more or less at the END, none anywhere else.
     m = min(len(got), len(want))
-    assert abs(len(got) - len(want)) <= 1 and np.array_equal(got[:m, 4:], want[:m, 4:]), (got.shape, want.shape)
+    assert abs(len(got) - len(want)) <= 1 and np.array_equal(got[:m], want[:m]), (got.shape, want.shape, np.flatnonzero((got[:m] != want[:m]).any(axis=1))[:8])
     assert len(got) >= 2 * frames - 4
     assert two["check"]["payload_matching_transmitted"] == two["check"]["cadus_last_step_all_ranks"]
     assert one["check"]["payload_matching_transmitted"] == one["check"]["cadus_last_step"]
@@ -63,17 +64,6 @@ def test_two_ranks_shard_one_recording_on_the_engines(tmp_path, workload, frames
     _, refc, _, _ = bench.ref_decode(pyref.best(), wl, x, want_syms=False)
     k = min(len(got), len(refc))
     assert abs(len(got) - len(refc)) <= 1 and k >= 2 * frames - 4
-    # What can differ, and why. Rank 0's part is the single stream's own beginning: identical to the reference byte for byte (CADU
-    # identity of the chunk-parallel engine). Rank 1's loops were started cold `overlap` samples in front of its range, so its soft
-    # symbols are those of ANOTHER trajectory of the same loops on the same samples (they agree to ~1e-6 once locked, +-1 int8 LSB on
-    # ~0.1 % of the symbols). The 4 x 223 RS DATA bytes of every frame are corrected to the transmitted ones on both sides: identical.
-    # The sync marker (4 bytes) and the 4 x 32 RS parity bytes are passed on UNcorrected by the reference (reedsolomon.cpp:53-116 copies
-    # only the data part back), so a channel bit error there survives on the side whose soft symbol was on the wrong side of zero:
-    # at these SNRs that is a rare event, bounded here at 1 % of rank 1's frames.
-    data = slice(4, 4 + 4 * 223)
-    assert np.array_equal(got[:k, data], refc[:k, data])
-    n0 = len(parts[0])
-    assert np.array_equal(got[:min(n0, k)], refc[:min(n0, k)]), "rank 0's frames are the single stream's: byte-identical incl. marker and parity"
-    diff1 = int((got[n0:k] != refc[n0:k]).any(axis=1).sum())
-    print(f"{workload}: {k} frames against the reference; rank 1's {k - n0} frames differ in marker/parity bytes on {diff1}")
-    assert diff1 <= max(1, (k - n0) // 100)
+    # whole frames against the reference too: rank 1 decodes the single stream's blocks from soft symbols that are another trajectory of the same loops on the
+    # same samples (+-1 int8 LSB on ~0.1 % of them) -- the Viterbi decoder does not see that
+    assert np.array_equal(got[:k], refc[:k]), np.flatnonzero((got[:k] != refc[:k]).any(axis=1))[:8]

@@ -86,3 +86,14 @@ def test_dvbs2_module_through_the_plugin_on_the_twin(host, tmp_path):
     if not (pyref.Dvbs2Ref.available(False) and pyref.S2FrontRef.available()) or not os.path.exists(emu_build.CLANG):
         pytest.skip("needs the compiled reference DVB-S2 classes and a host clang++")
     G.check_dvbs2_module_through_the_plugin(host, emu_build.build(), tmp_path)
+
+
+def test_hip_devices_through_the_plugin_on_the_twin(host, tmp_path):
+    """tests/test_plugin_minihost_gpu.py::test_hip_devices_through_the_plugin with the host twin as the C-ABI library (its one "device" three times):
+    the plugin's chunk threads, the alignment of the chunks' soft streams and the quarter-turn hand-over run in the CPU suite."""
+    from oracle import pyref
+    from tests import test_plugin_minihost_gpu as G
+    from tests.emu import build as emu_build
+    if not pyref.ref_available() or not os.path.exists(emu_build.CLANG):
+        pytest.skip("needs the compiled reference and a host clang++")
+    G.check_hip_devices_through_the_plugin(host, emu_build.build(), tmp_path, case="metop", nframes=60, devices=(0, 0), serial_chunks=True)

@@ -354,3 +354,51 @@ def test_dvbs2_module_through_the_plugin(host, tmp_path):
     if not (_p.Dvbs2Ref.available(False) and _p.S2FrontRef.available()):
         pytest.skip("needs the compiled reference DVB-S2 classes")
     check_dvbs2_module_through_the_plugin(host, LIB, tmp_path, modcod=13, short=0, nfr=10, acq=2 * 21690)
+
+
+def check_hip_devices_through_the_plugin(host, lib, tmp_path, case="metop", nframes=60, devices=(0, 0, 0), serial_chunks=False):
+    """`hip_devices` (round 4): ONE baseband file cut in time over several devices by the plugin's psk_demod (here the same device several times: the
+    plumbing is the point), a thread and a handle per chunk, the chunks' soft streams joined where each CONTINUES its predecessor's (sdhip_shard_align) and
+    turned onto the first chunk's constellation. The .soft file is the single stream's symbol for symbol -- the same length, the same hard decisions but for
+    a handful, values another trajectory of the same loops -- and the decoder behind it (stock id, HIP module) writes the .cadu the reference decodes from
+    the same baseband, byte for byte. MetOp: QPSK, rs_usecheck off (uncorrectable frames would show)."""
+    orc = pyref.best()
+    if case == "metop":
+        spec, cadus, plain, syms = util.metop_case(nframes=nframes)
+        dpar, fpar, metop = METOP_DEMOD, METOP_DEC, True
+        ocfg = pyref.demod_cfg(samplerate=6e6, symbolrate=2333333, constellation=pyref.QPSK, pll_bw=0.003)
+        ofec = None
+        dec_id = "metop_ahrpt_decoder"
+    else:
+        spec, cadus, plain, syms = util.goes_case(nframes=nframes)
+        dpar, fpar, metop = GOES_DEMOD, GOES_DEC, False
+        ocfg = pyref.demod_cfg(samplerate=3e6, symbolrate=927000, constellation=pyref.BPSK, pll_bw=0.02, max_sps=3.0)
+        ofec = pyref.fec_cfg(constellation=pyref.BPSK, nrzm=1, rs_usecheck=1)
+        dec_id = "ccsds_conv_concat_decoder"
+    x, _ = synth.modulate(syms, spec)
+    inp = tmp_path / "bb.cf32"
+    x.tofile(str(inp))
+    outs = {}
+    for name, extra in (("one", {}), ("many", {"hip_devices": list(devices)})):
+        job = {"mode": "file", "input": str(inp), "output_hint": str(tmp_path / name), "demod": {"module": "psk_demod", "parameters": dict(dpar, **extra)},
+               "decoder": {"module": dec_id, "parameters": fpar}}
+        jp = tmp_path / (name + ".json")
+        jp.write_text(json.dumps(job))
+        p = subprocess.run([host, lib, PLUGIN, "run", str(jp)], capture_output=True, text=True,
+                           env=dict(os.environ, SDHIP_OVERRIDE="1", SDHIP_PLUGIN_SERIAL_CHUNKS="1" if serial_chunks else "0"), timeout=900)
+        assert p.returncode == 0, p.stdout[-1000:] + p.stderr[-3000:]
+        rep = json.loads(p.stdout.strip().splitlines()[-1])
+        outs[name] = (np.fromfile(rep["soft"], dtype=np.int8), np.fromfile(rep["cadu"], dtype=np.uint8).reshape(-1, 1024))
+    s1, c1 = outs["one"]
+    sn, cn = outs["many"]
+    assert len(sn) == len(s1), (len(sn), len(s1))  # symbol for symbol the single stream
+    assert np.mean((sn < 0) != (s1 < 0)) < 2e-3 and np.mean(np.abs(sn.astype(np.int16) - s1.astype(np.int16)) > 2) < 5e-3
+    want = _ref_cadus_of_file(orc, ocfg, ofec, x, block=16384 if metop else 8192, metop=metop)
+    assert c1.shape == want.shape and np.array_equal(c1, want)
+    assert cn.shape == want.shape and np.array_equal(cn, want), (cn.shape, want.shape)
+    assert len(want) >= nframes - 8
+
+
+@pytest.mark.parametrize("case", ["metop", "goes"])
+def test_hip_devices_through_the_plugin(host, tmp_path, case):
+    check_hip_devices_through_the_plugin(host, LIB, tmp_path, case=case, nframes=120 if case == "metop" else 60)
