@@ -178,6 +178,20 @@ extern "C"
     } sdhip_ndsp_psk_cfg;
     void sdhip_ndsp_psk_cfg_default(sdhip_ndsp_psk_cfg *c);
     void *sdhip_ndsp_psk_demod_create(const sdhip_ndsp_psk_cfg *cfg);
+    /* ONE member block of that chain as a handle of its own -- the flowgraph registry's single nodes (dsp/flowgraph/dsp_flowgraph_register.cpp): the same
+       struct carries the block's keys (rrc_* + samplerate / symbolrate for the filter design; agc_*; rec_* with rec_omega or samplerate / symbolrate;
+       pll_* + constellation for the loop's order), the same work / stats / destroy functions serve it. Each is the stage the hier block runs, with its
+       state carried across work() calls, exact = 1 bit for bit the reference block (dsp/filter/fir.cpp:62-133 incl. its ntaps-sample latency,
+       dsp/agc/agc.cpp:22-39, dsp/clock_recovery/clock_recovery_mm.cpp:66-183, dsp/pll/costas.cpp:12-61). */
+    enum
+    {
+        SDHIP_NDSP_HIER = 0,    /* "psk_demod_cc" */
+        SDHIP_NDSP_RRC_FIR = 1, /* "rrc_fir_cc" */
+        SDHIP_NDSP_AGC = 2,     /* "agc_cc" */
+        SDHIP_NDSP_MM = 3,      /* "clock_recovery_mm_cc" */
+        SDHIP_NDSP_COSTAS = 4   /* "costas_cc" */
+    };
+    void *sdhip_ndsp_block_create(int kind, const sdhip_ndsp_psk_cfg *cfg);
     void sdhip_ndsp_psk_demod_destroy(void *h);
     /* One DSPBuffer's worth of work() of the whole hier block: nsamples complex floats (device) in, the symbols it produces (complex
        floats, device, capacity out_cap symbols) out. Returns the symbols written, <0 on error. The stream state (filter history with the

@@ -16,6 +16,7 @@
 #include "../include/sdhip.h"
 
 #include <string>
+#include <vector>
 
 namespace sdhip_plugin
 {
@@ -191,6 +192,217 @@ namespace sdhip_plugin
             // re-initialises only the member block whose key was touched (and changes the Costas order live). A flowgraph configures its blocks
             // before start(); a key changed in mid-stream costs this block a re-acquisition the reference's would not have.
             needs_reinit = true;
+            return RES_OK;
+        }
+    };
+    // ---- the chain's member blocks as ndsp::Block's of their own: what the flowgraph registry offers next to the hier block (dsp_flowgraph_register.cpp:
+    // "AGC/Agc CC", "Filter/RRC CC", "Clock Recovery/MM CC", "PLL/Costas"). Each takes the reference block's own keys (dsp/agc/agc.h:38-78,
+    // dsp/filter/rrc.h:34-66, dsp/clock_recovery/clock_recovery_mm.h:70-130, dsp/pll/costas.h:55-90) plus "device" / "exact", and hands every DSPBuffer
+    // to the C ABI's single-block handle (sdhip_ndsp_block_create); the block's state carries across buffers as in the reference.
+    class SingleHipBlock : public satdump::ndsp::Block
+    {
+        struct Key
+        {
+            const char *name;
+            int field; // index into the cfg (below)
+            bool integer;
+        };
+        int kind;
+        sdhip_ndsp_psk_cfg cfg;
+        void *h = nullptr;
+        bool needs_reinit = true;
+        int order = 2;
+        std::vector<Key> keys;
+        double *fd(int f)
+        {
+            switch (f)
+            {
+            case 0:
+                return &cfg.rrc_gain;
+            case 1:
+                return &cfg.samplerate;
+            case 2:
+                return &cfg.symbolrate;
+            case 3:
+                return &cfg.rrc_alpha;
+            default:
+                return nullptr;
+            }
+        }
+        float *ff(int f)
+        {
+            switch (f)
+            {
+            case 10:
+                return &cfg.agc_rate;
+            case 11:
+                return &cfg.agc_reference;
+            case 12:
+                return &cfg.agc_gain;
+            case 13:
+                return &cfg.agc_max_gain;
+            case 20:
+                return &cfg.rec_omega;
+            case 21:
+                return &cfg.rec_omegaGain;
+            case 22:
+                return &cfg.rec_mu;
+            case 23:
+                return &cfg.rec_muGain;
+            case 24:
+                return &cfg.rec_omegaLimit;
+            case 30:
+                return &cfg.pll_loop_bw;
+            case 31:
+                return &cfg.pll_freq_limit;
+            default:
+                return nullptr;
+            }
+        }
+        int *fi(int f)
+        {
+            switch (f)
+            {
+            case 4:
+                return &cfg.rrc_ntaps;
+            case 25:
+                return &cfg.rec_nfilt;
+            case 26:
+                return &cfg.rec_ntaps;
+            default:
+                return nullptr;
+            }
+        }
+        void drop()
+        {
+            if (h)
+                sdhip_ndsp_psk_demod_destroy(h);
+            h = nullptr;
+        }
+        bool work()
+        {
+            using namespace satdump::ndsp;
+            DSPBuffer iblk = inputs[0].fifo->wait_dequeue();
+            if (iblk.isTerminator())
+            {
+                if (iblk.terminatorShouldPropagate())
+                    outputs[0].fifo->wait_enqueue(outputs[0].fifo->newBufferTerminator());
+                inputs[0].fifo->free(iblk);
+                return true;
+            }
+            if (needs_reinit)
+            {
+                needs_reinit = false;
+                init();
+            }
+            DSPBuffer oblk = outputs[0].fifo->newBufferSamples(iblk.max_size, sizeof(complex_t));
+            const int64_t n = sdhip_ndsp_psk_demod_work(h, (const float *)iblk.getSamples<complex_t>(), iblk.size, (float *)oblk.getSamples<complex_t>(), iblk.max_size);
+            if (n < 0)
+            {
+                outputs[0].fifo->free(oblk);
+                inputs[0].fifo->free(iblk);
+                throw satdump_exception(std::string("sdhip: ") + sdhip_last_error());
+            }
+            oblk.size = (uint32_t)n;
+            if (n > 0)
+                outputs[0].fifo->wait_enqueue(oblk);
+            else
+                outputs[0].fifo->free(oblk);
+            inputs[0].fifo->free(iblk);
+            return false;
+        }
+
+    public:
+        static const char *id_of(int kind)
+        {
+            static const char *ids[5] = {"psk_demod_hip_cc", "rrc_fir_hip_cc", "agc_hip_cc", "clock_recovery_mm_hip_cc", "costas_hip_cc"};
+            return ids[kind];
+        }
+        explicit SingleHipBlock(int kind_) : Block(id_of(kind_), {{"in", satdump::ndsp::DSP_SAMPLE_TYPE_CF32}}, {{"out", satdump::ndsp::DSP_SAMPLE_TYPE_CF32}}), kind(kind_)
+        {
+            sdhip_ndsp_psk_cfg_default(&cfg);
+            cfg.agc_reference = 1.0f; // the blocks' own defaults (agc.h:15, clock_recovery_mm.h:17, costas.h:14-16): the hier block is what sets 0.6
+            cfg.rec_omega = 2.0f;
+            cfg.samplerate = 6e6;
+            cfg.symbolrate = 2e6;
+            if (kind == SDHIP_NDSP_RRC_FIR)
+                keys = {{"gain", 0, false}, {"samplerate", 1, false}, {"symbolrate", 2, false}, {"alpha", 3, false}, {"ntaps", 4, true}};
+            else if (kind == SDHIP_NDSP_AGC)
+                keys = {{"rate", 10, false}, {"reference", 11, false}, {"gain", 12, false}, {"max_gain", 13, false}};
+            else if (kind == SDHIP_NDSP_MM)
+                keys = {{"omega", 20, false}, {"omegaGain", 21, false}, {"mu", 22, false}, {"muGain", 23, false}, {"omegaLimit", 24, false}, {"nfilt", 25, true}, {"ntaps", 26, true}};
+            else
+                keys = {{"loop_bw", 30, false}, {"freq_limit", 31, false}};
+        }
+        ~SingleHipBlock() { drop(); }
+        void init()
+        {
+            drop();
+            h = sdhip_ndsp_block_create(kind, &cfg);
+            if (!h)
+                throw satdump_exception(std::string("sdhip: ") + sdhip_last_error());
+        }
+        nlohmann::ordered_json get_cfg_list()
+        {
+            nlohmann::ordered_json v;
+            if (kind == SDHIP_NDSP_COSTAS)
+                satdump::ndsp::add_param_simple(v, "order", "int");
+            for (auto &k : keys)
+                satdump::ndsp::add_param_simple(v, k.name, k.integer ? "int" : "float");
+            satdump::ndsp::add_param_simple(v, "device", "int");
+            satdump::ndsp::add_param_simple(v, "exact", "bool");
+            return v;
+        }
+        nlohmann::json get_cfg(std::string key)
+        {
+            if (key == "device")
+                return cfg.device;
+            if (key == "exact")
+                return cfg.exact != 0;
+            if (kind == SDHIP_NDSP_COSTAS && key == "order")
+                return order;
+            for (auto &k : keys)
+                if (key == k.name)
+                {
+                    if (double *d = fd(k.field))
+                        return *d;
+                    if (float *f = ff(k.field))
+                        return *f;
+                    return *fi(k.field);
+                }
+            throw satdump_exception(key); // the member blocks throw on unknown keys (agc.h:62)
+        }
+        cfg_res_t set_cfg(std::string key, nlohmann::json v)
+        {
+            if (key == "device")
+                cfg.device = v;
+            else if (key == "exact")
+                cfg.exact = v.get<bool>() ? 1 : 0;
+            else if (kind == SDHIP_NDSP_COSTAS && key == "order")
+            {
+                order = v;
+                if (order != 2 && order != 4 && order != 8)
+                    throw satdump_exception("costas order must be 2, 4 or 8");
+                cfg.constellation = order == 2 ? SDHIP_BPSK : (order == 4 ? SDHIP_QPSK : SDHIP_8PSK);
+            }
+            else
+            {
+                bool found = false;
+                for (auto &k : keys)
+                    if (key == k.name)
+                    {
+                        if (double *d = fd(k.field))
+                            *d = v;
+                        else if (float *f = ff(k.field))
+                            *f = v;
+                        else
+                            *fi(k.field) = v;
+                        found = true;
+                    }
+                if (!found)
+                    throw satdump_exception(key);
+            }
+            needs_reinit = true; // (one stage: re-creating the handle re-initialises exactly the block whose key was touched, as the reference does)
             return RES_OK;
         }
     };

@@ -1035,8 +1035,18 @@ namespace sdhip_plugin
             auto make = [](const Flowgraph *f) { return std::make_shared<NodeInternal>(f, std::make_shared<PSKDemodHipBlock>()); };
             evt.r.insert({PSKDemodHipBlock().d_id, {"Modem/PSK Demod (MI355X)", make}});
             const char *ov = getenv("SDHIP_OVERRIDE");
-            if (ov && std::string(ov) == "1" && sdhip_device_count() > 0 && evt.r.count("psk_demod_cc"))
+            const bool over = ov && std::string(ov) == "1" && sdhip_device_count() > 0;
+            if (over && evt.r.count("psk_demod_cc"))
                 evt.r.at("psk_demod_cc").func = make;
+            static const char *stock[5] = {"", "rrc_fir_cc", "agc_cc", "clock_recovery_mm_cc", "costas_cc"};
+            static const char *menu[5] = {"", "Filter/RRC CC (MI355X)", "AGC/Agc CC (MI355X)", "Clock Recovery/MM CC (MI355X)", "PLL/Costas (MI355X)"};
+            for (int k = SDHIP_NDSP_RRC_FIR; k <= SDHIP_NDSP_COSTAS; k++)
+            {
+                auto mk = [k](const Flowgraph *f) { return std::make_shared<NodeInternal>(f, std::make_shared<SingleHipBlock>(k)); };
+                evt.r.insert({SingleHipBlock::id_of(k), {menu[k], mk}});
+                if (over && evt.r.count(stock[k]))
+                    evt.r.at(stock[k]).func = mk;
+            }
         }
 #endif
         static void registerModulesHandler(const RegisterModulesEvent &evt)
@@ -1121,7 +1131,12 @@ PLUGIN_LOADER(sdhip_plugin::SdhipSupport)
 // what a host without the flowgraph registry (tests/minihost) instantiates the ndsp block with
 extern "C" satdump::ndsp::Block *sdhip_plugin_make_ndsp_block(const char *id)
 {
-    if (std::string(id) == "psk_demod_hip_cc" || std::string(id) == "psk_demod_cc")
+    const std::string s(id);
+    if (s == "psk_demod_hip_cc" || s == "psk_demod_cc")
         return new sdhip_plugin::PSKDemodHipBlock();
+    static const char *stock[5] = {"", "rrc_fir_cc", "agc_cc", "clock_recovery_mm_cc", "costas_cc"};
+    for (int k = SDHIP_NDSP_RRC_FIR; k <= SDHIP_NDSP_COSTAS; k++)
+        if (s == stock[k] || s == sdhip_plugin::SingleHipBlock::id_of(k))
+            return new sdhip_plugin::SingleHipBlock(k);
     return nullptr;
 }

@@ -155,6 +155,9 @@ def lib():
             L.sdhip_ndsp_psk_demod_create.restype = C.c_void_p
             L.sdhip_ndsp_psk_demod_create.argtypes = [C.POINTER(NdspPskCfg)]
             L.sdhip_ndsp_psk_demod_destroy.argtypes = [C.c_void_p]
+            if hasattr(L, "sdhip_ndsp_block_create"):
+                L.sdhip_ndsp_block_create.restype = C.c_void_p
+                L.sdhip_ndsp_block_create.argtypes = [C.c_int, C.POINTER(NdspPskCfg)]
             L.sdhip_ndsp_psk_demod_work_dev.restype = C.c_int64
             L.sdhip_ndsp_psk_demod_work_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
             L.sdhip_ndsp_psk_demod_work.restype = C.c_int64

@@ -437,6 +437,9 @@ namespace sdhip
         // clock recovery like psk_demod's -- and NO Costas loop: carrier recovery happens per frame behind the PL synchroniser (sdhip_s2_pll_dev).
         // The legacy stage order, the symbols leave as floats.
         bool skip_costas = false;
+        // ndsp: ONE member block of the chain on its own (the flowgraph's agc_cc / rrc_fir_cc / clock_recovery_mm_cc / costas_cc nodes):
+        // 0 = the whole hier block, else SDHIP_NDSP_RRC_FIR / _AGC / _MM / _COSTAS
+        int only = 0;
     };
 
     struct DemodEngine
@@ -534,7 +537,7 @@ namespace sdhip
 
         // host path (host_pipe.h): two pinned staging buffers filled by the copy pool, shipped and processed by a worker thread while the caller fills
         // the other one; results queue up for pull()
-        static constexpr size_t HOST_BATCH = (size_t)32u << 20; // samples per shipped batch
+        static constexpr size_t HOST_BATCH = (size_t)64u << 20; // samples per shipped batch
         std::unique_ptr<HostPipe> pipe;
         PinBuf<int8_t> h_out;
         std::mutex out_mu;
@@ -789,7 +792,9 @@ namespace sdhip
         }
         ~DemodEngine()
         {
-            pipe.reset(); // the host path's worker thread ends before the stream and the buffers it uses go
+            pipe.reset(); // the host path's threads end before the streams and the buffers they use go
+            if (copy_stream)
+                (void)hipStreamDestroy(copy_stream);
             if (stream)
                 (void)hipStreamDestroy(stream);
         }
@@ -1886,6 +1891,53 @@ namespace sdhip
             bufB.reserve(need);
             cf32 *A = bufA.p + DEMOD_HIST, *B = bufB.p + DEMOD_HIST;
             stats.samples_in += n;
+            if (nd.only == SDHIP_NDSP_AGC)
+            { // AGCBlock<complex_t>::process (dsp/agc/agc.cpp:22-39) on its own
+                if ((size_t)n > out_cap)
+                    throw HipError("output buffer too small");
+                SD_HIP(hipMemcpyAsync(A, d_in, (size_t)n * sizeof(cf32), hipMemcpyDeviceToDevice, stream));
+                agc_stage(A, B, n);
+                SD_HIP(hipMemcpyAsync(d_out, B, (size_t)n * sizeof(cf32), hipMemcpyDeviceToDevice, stream));
+                SD_HIP(hipStreamSynchronize(stream));
+                started = true;
+                return n;
+            }
+            if (nd.only == SDHIP_NDSP_MM)
+            { // MMClockRecoveryBlock<complex_t>::work (dsp/clock_recovery/clock_recovery_mm.cpp:66-183) on its own
+                SD_HIP(hipMemcpyAsync(A, d_in, (size_t)n * sizeof(cf32), hipMemcpyDeviceToDevice, stream));
+                const double omin1 = (double)mm_p.omega_mid - (double)mm_p.omega_limit;
+                const size_t symcap1 = (size_t)((double)n / std::max(0.5, omin1 - 0.01)) + 64;
+                if (symcap1 > out_cap + 64 && (size_t)((double)n / omin1) + 8 > out_cap)
+                    throw HipError("symbol output buffer too small");
+                symtmp.reserve(symcap1 + 2 * DEMOD_HIST + 64);
+                d_soft_tmp.reserve(2 * symcap1);
+                cf32 *S1 = symtmp.p + DEMOD_HIST;
+                const ChunkGeom one1 = make_geom(n, 1 << 30, 0);
+                mm_stage(A, n, one1, nullptr, d_soft_tmp.p, 2 * symcap1, reinterpret_cast<float *>(S1), symcap1, hist_cos);
+                const long long ns1 = last_symbols;
+                if ((size_t)ns1 > out_cap)
+                    throw HipError("symbol output buffer too small");
+                if (ns1)
+                    SD_HIP(hipMemcpyAsync(d_out, S1, (size_t)ns1 * sizeof(cf32), hipMemcpyDeviceToDevice, stream));
+                SD_HIP(hipStreamSynchronize(stream));
+                started = true;
+                return ns1;
+            }
+            if (nd.only == SDHIP_NDSP_COSTAS)
+            { // CostasBlock::process (dsp/pll/costas.cpp:12-61) on its own: the loop over whatever rate its input has
+                if ((size_t)n > out_cap)
+                    throw HipError("output buffer too small");
+                symtmp.reserve((size_t)n + 2 * DEMOD_HIST + 64);
+                cf32 *S1 = symtmp.p + DEMOD_HIST;
+                SD_HIP(hipMemcpyAsync(S1, d_in, (size_t)n * sizeof(cf32), hipMemcpyDeviceToDevice, stream));
+                ChunkGeom cg1;
+                costas_stage(S1, B, n, cg1, 1.0, nd.samplerate);
+                launch_derotate(B, n, cg1, d_rot.p, order, stream);
+                SD_HIP(hipMemcpyAsync(d_out, B, (size_t)n * sizeof(cf32), hipMemcpyDeviceToDevice, stream));
+                SD_HIP(hipStreamSynchronize(stream));
+                started = true;
+                return n;
+            }
             // ---- RRC FIR (FIRBlock::process, dsp/filter/fir.cpp:62-133): same dot products as the legacy block's (the aligned kernel call
             // only puts zero taps in front), but the block holds ntaps samples back: output i is the window starting at input i + 1, and
             // the first call returns ntaps samples fewer. In stream terms: the legacy filter's output without its first ntaps samples.
@@ -1903,6 +1955,15 @@ namespace sdhip
                     return 0;
                 SD_HIP(hipMemcpyAsync(B, A + d, (size_t)n * sizeof(cf32), hipMemcpyDeviceToDevice, stream));
                 std::swap(A, B);
+            }
+            if (nd.only == SDHIP_NDSP_RRC_FIR)
+            { // RRC_Block<FIRBlock<complex_t>> on its own
+                if ((size_t)n > out_cap)
+                    throw HipError("output buffer too small");
+                SD_HIP(hipMemcpyAsync(d_out, A, (size_t)n * sizeof(cf32), hipMemcpyDeviceToDevice, stream));
+                SD_HIP(hipStreamSynchronize(stream));
+                started = true;
+                return n;
             }
             // ---- AGC (AGCBlock::process, dsp/agc/agc.cpp:22-39), reference 0.6 from the hier block's constructor
             agc_stage(A, B, n);
@@ -1935,18 +1996,28 @@ namespace sdhip
         }
 
         // ---- host path
-        // one staged batch, on the pipe's worker thread: H2D, the stages, D2H of the soft symbols
-        void ship(const uint8_t *pinned, size_t bytes, int fmt)
+        // one staged batch: shipped into a device slot by the pipe's first thread (its own copy stream), processed by the second (the stages, D2H of the
+        // soft symbols) while the next batch is on its way
+        DevBuf<uint8_t> d_in_slot[2];
+        hipStream_t copy_stream = nullptr;
+        void ship_in(const uint8_t *pinned, size_t bytes, int /*fmt*/, int slot)
+        {
+            SD_HIP(hipSetDevice(cfg.device));
+            if (!copy_stream)
+                SD_HIP(hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking));
+            d_in_slot[slot].reserve(bytes);
+            SD_HIP(hipMemcpyAsync(d_in_slot[slot].p, pinned, bytes, hipMemcpyHostToDevice, copy_stream));
+            SD_HIP(hipStreamSynchronize(copy_stream));
+        }
+        void ship(size_t bytes, int fmt, int slot)
         {
             const size_t ns = bytes / fmt_bytes(fmt);
             if (ns == 0)
                 return;
             SD_HIP(hipSetDevice(cfg.device));
-            d_in_tmp.reserve(bytes);
-            SD_HIP(hipMemcpyAsync(d_in_tmp.p, pinned, bytes, hipMemcpyHostToDevice, stream));
             const size_t cap = 2 * ns + 64;
             d_soft_tmp.reserve(cap);
-            const int64_t n = process(d_in_tmp.p, ns, fmt, d_soft_tmp.p, cap, nullptr, 0);
+            const int64_t n = process(d_in_slot[slot].p, ns, fmt, d_soft_tmp.p, cap, nullptr, 0);
             h_out.reserve((size_t)n + 1);
             SD_HIP(hipMemcpyAsync(h_out.p, d_soft_tmp.p, (size_t)n, hipMemcpyDeviceToHost, stream));
             SD_HIP(hipStreamSynchronize(stream));
@@ -1958,7 +2029,7 @@ namespace sdhip
         int push_host(const void *iq, size_t nsamples, int fmt)
         {
             if (!pipe)
-                pipe.reset(new HostPipe([this](const uint8_t *p, size_t b, int f) { ship(p, b, f); }));
+                pipe.reset(new HostPipe([this](const uint8_t *p, size_t b, int f, int s) { ship_in(p, b, f, s); }, [this](size_t b, int f, int s) { ship(b, f, s); }));
             const size_t bps = (size_t)fmt_bytes(fmt);
             pipe->push(iq, nsamples * bps, fmt, HOST_BATCH * bps);
             return 0;
@@ -2082,11 +2153,14 @@ extern "C"
         c->pll_loop_bw = (float)0.004; // costas.h:14-16
         c->pll_freq_limit = 1.0f;
     }
-    void *sdhip_ndsp_psk_demod_create(const sdhip_ndsp_psk_cfg *c)
+    static void *ndsp_create(const sdhip_ndsp_psk_cfg *c, int kind);
+    void *sdhip_ndsp_psk_demod_create(const sdhip_ndsp_psk_cfg *c) { return ndsp_create(c, SDHIP_NDSP_HIER); }
+    static void *ndsp_create(const sdhip_ndsp_psk_cfg *c, int kind)
     {
         SD_GUARD_BEGIN
-        if (c->constellation != SDHIP_BPSK && c->constellation != SDHIP_QPSK)
-            throw HipError("ndsp psk_demod: constellation must be bpsk or qpsk"); // set_cfg returns RES_ERR for anything else, psk_demod.h:205-214
+        // the hier block: bpsk / qpsk (set_cfg returns RES_ERR for anything else, psk_demod.h:205-214); CostasBlock on its own also has order 8 (costas.h:78)
+        if (c->constellation != SDHIP_BPSK && c->constellation != SDHIP_QPSK && !(kind == SDHIP_NDSP_COSTAS && c->constellation == SDHIP_8PSK))
+            throw HipError("ndsp psk_demod: constellation must be bpsk or qpsk");
         if (c->rec_nfilt != 128 || c->rec_ntaps != 8)
             throw HipError("ndsp psk_demod: the HIP path carries the 128 x 8 interpolator bank only");
         if (!(c->samplerate > 0) || !(c->symbolrate > 0))
@@ -2127,10 +2201,23 @@ extern "C"
         e.agc_max_gain = c->agc_max_gain;
         e.rec_omega = c->rec_omega;
         e.pll_freq_limit = c->pll_freq_limit;
-        return new DemodEngine(d, &e);
+        e.only = kind;
+        DemodEngine *eng = new DemodEngine(d, &e);
+        if (kind != SDHIP_NDSP_HIER && kind != SDHIP_NDSP_RRC_FIR)
+            eng->fir_drop = 0;
+        return eng;
         SD_GUARD_END(nullptr)
     }
     void sdhip_ndsp_psk_demod_destroy(void *h) { delete (DemodEngine *)h; }
+    void *sdhip_ndsp_block_create(int kind, const sdhip_ndsp_psk_cfg *c)
+    {
+        if (kind < SDHIP_NDSP_HIER || kind > SDHIP_NDSP_COSTAS)
+        {
+            sdhip::set_error("ndsp block: unknown kind");
+            return nullptr;
+        }
+        return ndsp_create(c, kind);
+    }
     // DVB-S2 demodulator front: a psk_demod handle without the Costas loop (use sdhip_demod_process_dev with d_syms for the symbols)
     void *sdhip_dvbs2_front_create(const sdhip_demod_cfg *cfg)
     {

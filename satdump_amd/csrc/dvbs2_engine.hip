@@ -344,19 +344,23 @@ namespace sdhip
                 return 2;
             }
         }
-        DevBuf<unsigned char> d_in_tmp;
         std::unique_ptr<HostPipe> pipe;
         std::mutex out_mu;
-        // one staged batch on the pipe's worker thread
-        void ship(const uint8_t *pinned, size_t bytes, int fmt)
+        // one staged batch: shipped into a device slot by the pipe's first thread, processed by the second
+        DevBuf<unsigned char> d_in_slot[2];
+        void ship_in(const uint8_t *pinned, size_t bytes, int /*fmt*/, int slot)
+        {
+            SD_HIP(hipSetDevice(device));
+            d_in_slot[slot].reserve(bytes);
+            SD_HIP(hipMemcpy(d_in_slot[slot].p, pinned, bytes, hipMemcpyHostToDevice));
+        }
+        void ship(size_t bytes, int fmt, int slot)
         {
             const size_t ns = bytes / fmt_bytes(fmt);
             if (ns == 0)
                 return;
             SD_HIP(hipSetDevice(device));
-            d_in_tmp.reserve(bytes);
-            SD_HIP(hipMemcpy(d_in_tmp.p, pinned, bytes, hipMemcpyHostToDevice));
-            deliver_host(feed_baseband(d_in_tmp.p, ns, fmt));
+            deliver_host(feed_baseband(d_in_slot[slot].p, ns, fmt));
         }
         int flush_host()
         {
@@ -367,7 +371,7 @@ namespace sdhip
         int push_host(const void *iq, size_t nsamples, int fmt)
         {
             if (!pipe)
-                pipe.reset(new HostPipe([this](const uint8_t *p, size_t b, int f) { ship(p, b, f); }));
+                pipe.reset(new HostPipe([this](const uint8_t *p, size_t b, int f, int s) { ship_in(p, b, f, s); }, [this](size_t b, int f, int s) { ship(b, f, s); }));
             pipe->push(iq, nsamples * fmt_bytes(fmt), fmt, HOST_BATCH * fmt_bytes(fmt));
             return 0;
         }

@@ -111,54 +111,119 @@ namespace sdhip
     class HostPipe
     {
       public:
-        using Work = std::function<void(const uint8_t *pinned, size_t bytes, int fmt)>; // on the worker thread: ship, process, queue the results
+        // thread A: ship a staged batch into device slot `slot` (H2D, synchronous); thread B: process slot `slot` and queue the results. While B works on
+        // batch k, A ships batch k + 1 and the caller stages batch k + 2.
+        using Ship = std::function<void(const uint8_t *pinned, size_t bytes, int fmt, int slot)>;
+        using Compute = std::function<void(size_t bytes, int fmt, int slot)>;
 
       private:
         PinBuf<uint8_t> buf[2];
         size_t fill = 0; // bytes gathered in buf[cur]
         int cur = 0, fmt = 0;
-        bool busy[2] = {false, false};
-        std::vector<int> order; // submitted buffers, oldest first
+        bool busy[2] = {false, false};      // staging buffer handed to thread A
+        bool slot_busy[2] = {false, false}; // device slot shipped, not yet processed
+        std::vector<int> order;             // submitted staging buffers, oldest first
+        struct Job
+        {
+            size_t bytes;
+            int fmt, slot;
+        };
+        std::vector<Job> jobs; // shipped, waiting for thread B
+        bool computing = false;
         size_t sub_bytes[2] = {0, 0};
         int sub_fmt[2] = {0, 0};
+        int next_slot = 0;
         std::mutex mu;
         std::condition_variable cv;
-        std::thread worker;
+        std::thread ta, tb;
         bool quit = false;
         std::exception_ptr err;
-        Work work;
-        void loop()
+        Ship ship;
+        Compute compute;
+        void fail()
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            if (!err)
+                err = std::current_exception();
+        }
+        void loop_a()
         {
             for (;;)
             {
-                int b;
+                int b, s;
                 {
                     std::unique_lock<std::mutex> lk(mu);
                     cv.wait(lk, [&] { return quit || !order.empty(); });
                     if (order.empty())
                         return;
                     b = order.front();
+                    s = next_slot;
+                    cv.wait(lk, [&] { return quit || !slot_busy[s]; });
+                    if (slot_busy[s])
+                        return;
+                    slot_busy[s] = true;
+                    next_slot ^= 1;
                 }
+                bool ok = true;
                 try
                 {
-                    if (!err)
-                        work(buf[b].p, sub_bytes[b], sub_fmt[b]);
+                    ship(buf[b].p, sub_bytes[b], sub_fmt[b], s);
                 }
                 catch (...)
                 {
-                    std::lock_guard<std::mutex> lk(mu);
-                    err = std::current_exception();
+                    ok = false;
+                    fail();
                 }
                 {
                     std::lock_guard<std::mutex> lk(mu);
                     order.erase(order.begin());
                     busy[b] = false;
+                    if (ok)
+                        jobs.push_back(Job{sub_bytes[b], sub_fmt[b], s});
+                    else
+                        slot_busy[s] = false;
+                }
+                cv.notify_all();
+            }
+        }
+        void loop_b()
+        {
+            for (;;)
+            {
+                Job j;
+                {
+                    std::unique_lock<std::mutex> lk(mu);
+                    cv.wait(lk, [&] { return quit || !jobs.empty(); });
+                    if (jobs.empty())
+                        return;
+                    j = jobs.front();
+                    jobs.erase(jobs.begin());
+                    computing = true;
+                }
+                try
+                {
+                    bool bad;
+                    {
+                        std::lock_guard<std::mutex> lk(mu);
+                        bad = (bool)err;
+                    }
+                    if (!bad)
+                        compute(j.bytes, j.fmt, j.slot);
+                }
+                catch (...)
+                {
+                    fail();
+                }
+                {
+                    std::lock_guard<std::mutex> lk(mu);
+                    slot_busy[j.slot] = false;
+                    computing = false;
                 }
                 cv.notify_all();
             }
         }
         void submit()
-        { // buf[cur] goes to the worker, the caller moves on to the other one (waiting for it if the worker still holds it)
+        { // buf[cur] goes to the shipping thread, the caller moves on to the other one (waiting for it if it is still being shipped)
             {
                 std::lock_guard<std::mutex> lk(mu);
                 busy[cur] = true;
@@ -185,7 +250,7 @@ namespace sdhip
         }
 
       public:
-        explicit HostPipe(Work w) : work(std::move(w)) {}
+        HostPipe(Ship s, Compute c) : ship(std::move(s)), compute(std::move(c)) {}
         ~HostPipe()
         {
             {
@@ -193,8 +258,10 @@ namespace sdhip
                 quit = true;
             }
             cv.notify_all();
-            if (worker.joinable())
-                worker.join();
+            if (ta.joinable())
+                ta.join();
+            if (tb.joinable())
+                tb.join();
         }
         size_t pending_bytes() const { return fill; }
         // append `bytes` of samples in format f; a buffer is shipped when it holds batch_bytes
@@ -204,8 +271,11 @@ namespace sdhip
             if (fill != 0 && f != fmt)
                 throw HipError("baseband format changed mid-stream");
             fmt = f;
-            if (!worker.joinable())
-                worker = std::thread([this] { loop(); });
+            if (!ta.joinable())
+            {
+                ta = std::thread([this] { loop_a(); });
+                tb = std::thread([this] { loop_b(); });
+            }
             const uint8_t *s = (const uint8_t *)src;
             while (bytes)
             {
@@ -227,14 +297,14 @@ namespace sdhip
                     submit();
             }
         }
-        // ship what is gathered and wait until the worker has nothing left
+        // ship what is gathered and wait until both threads have nothing left
         void flush()
         {
             if (fill)
                 submit();
             {
                 std::unique_lock<std::mutex> lk(mu);
-                cv.wait(lk, [&] { return order.empty(); });
+                cv.wait(lk, [&] { return order.empty() && jobs.empty() && !computing; });
             }
             rethrow();
         }

@@ -118,3 +118,80 @@ class PSKDemodHierBlock:
             self._drop()
         except Exception:
             pass
+
+
+# ---- the chain's member blocks as flowgraph nodes of their own (include/sdhip.h, sdhip_ndsp_block_create)
+NDSP_HIER, NDSP_RRC_FIR, NDSP_AGC, NDSP_MM, NDSP_COSTAS = 0, 1, 2, 3, 4
+_SINGLE = {
+    # block id -> (kind, {block key: cfg field})   (the keys of dsp/agc/agc.h:38-78, dsp/filter/rrc.h:34-66, dsp/clock_recovery/clock_recovery_mm.h:70-130, dsp/pll/costas.h:55-90)
+    "agc_cc": (NDSP_AGC, {"rate": "agc_rate", "reference": "agc_reference", "gain": "agc_gain", "max_gain": "agc_max_gain"}),
+    "rrc_fir_cc": (NDSP_RRC_FIR, {"gain": "rrc_gain", "samplerate": "samplerate", "symbolrate": "symbolrate", "alpha": "rrc_alpha", "ntaps": "rrc_ntaps"}),
+    "clock_recovery_mm_cc": (NDSP_MM, {"omega": "rec_omega", "omegaGain": "rec_omegaGain", "mu": "rec_mu", "muGain": "rec_muGain", "omegaLimit": "rec_omegaLimit",
+                                       "nfilt": "rec_nfilt", "ntaps": "rec_ntaps"}),
+    "costas_cc": (NDSP_COSTAS, {"loop_bw": "pll_loop_bw", "freq_limit": "pll_freq_limit"}),
+}
+_ORDER = {2: capi.BPSK, 4: capi.QPSK, 8: capi.PSK8}
+
+
+class SingleBlock:
+    """agc_cc / rrc_fir_cc / clock_recovery_mm_cc / costas_cc: one member block of the chain with the reference block's own keys and defaults
+    (AGCBlock: reference 1.0 -- the hier block is what sets 0.6 --, MMClockRecoveryBlock: omega 2, CostasBlock: order 2), state carried across work() calls."""
+
+    def __init__(self, block_id: str, device: int = 0, exact: bool = False, capi_mod=None):
+        if block_id not in _SINGLE:
+            raise ValueError("unknown block " + block_id)
+        self.d_id = block_id
+        self._capi = capi_mod or capi
+        self._kind, self._keys = _SINGLE[block_id]
+        self._cfg = self._capi.NdspPskCfg()
+        self._capi.lib().sdhip_ndsp_psk_cfg_default(C.byref(self._cfg))
+        self._cfg.device, self._cfg.exact = device, int(exact)
+        self._cfg.agc_reference = 1.0      # agc.h:15
+        self._cfg.rec_omega = 2.0          # clock_recovery_mm.h:17
+        self._cfg.samplerate, self._cfg.symbolrate = 6e6, 2e6
+        self._h = None
+
+    def set_cfg(self, key: str, v) -> int:
+        if self._kind == NDSP_COSTAS and key == "order":
+            if int(v) not in _ORDER:
+                return RES_ERR
+            self._cfg.constellation = _ORDER[int(v)]
+        elif key in self._keys:
+            f = self._keys[key]
+            setattr(self._cfg, f, type(getattr(self._cfg, f))(v))
+        else:
+            return RES_ERR
+        self._drop()
+        return RES_OK
+
+    def _handle(self):
+        if self._h is None:
+            self._h = self._capi.lib().sdhip_ndsp_block_create(self._kind, C.byref(self._cfg))
+            if not self._h:
+                raise self._capi.SdhipError(f"sdhip_ndsp_block_create failed: {self._capi.last_error()}")
+        return self._h
+
+    def _drop(self):
+        if self._h:
+            self._capi.lib().sdhip_ndsp_psk_demod_destroy(self._h)
+            self._h = None
+
+    def work(self, samples: np.ndarray) -> np.ndarray:
+        x = np.ascontiguousarray(samples, dtype=np.complex64)
+        out = np.zeros(len(x) + 64, dtype=np.complex64)
+        n = self._capi._check(self._capi.lib().sdhip_ndsp_psk_demod_work(self._handle(), x.ctypes.data_as(C.c_void_p), len(x), out.ctypes.data_as(C.c_void_p), len(out)),
+                              "sdhip_ndsp_psk_demod_work")
+        return out[:n].copy()
+
+    def work_dev(self, d_in_ptr: int, nsamples: int, d_out_ptr: int, out_cap: int) -> int:
+        return self._capi._check(self._capi.lib().sdhip_ndsp_psk_demod_work_dev(self._handle(), C.c_void_p(d_in_ptr), nsamples, C.c_void_p(d_out_ptr), out_cap),
+                                 "sdhip_ndsp_psk_demod_work_dev")
+
+    def stop(self, stop_now: bool = False, force: bool = False):
+        self._drop()
+
+    def __del__(self):
+        try:
+            self._drop()
+        except Exception:
+            pass

@@ -112,6 +112,8 @@ inline hipError_t hipStreamCreate(hipStream_t *s)
     *s = nullptr;
     return 0;
 }
+constexpr unsigned hipStreamNonBlocking = 1;
+inline hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned) { return hipStreamCreate(s); }
 inline hipError_t hipStreamDestroy(hipStream_t) { return 0; }
 inline hipError_t hipStreamSynchronize(hipStream_t) { return 0; }
 inline hipError_t hipDeviceSynchronize() { return 0; }

@@ -216,8 +216,9 @@ int main(int argc, char **argv)
                 dst.fifo->free(b);
             }
             feeder.join();
-            report["pll_freq"] = blk->get_cfg("pll_freq");
             report["cfg_list"] = blk->get_cfg_list();
+            if (report["cfg_list"].contains("pll_freq"))
+                report["pll_freq"] = blk->get_cfg("pll_freq");
             blk->stop();
             report["symbols"] = got;
             std::cout << report.dump() << std::endl;

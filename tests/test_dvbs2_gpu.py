@@ -633,7 +633,16 @@ def check_pll_parallel(capi, to_dev, from_dev, zeros_dev, modcod, short, esn0_db
     assert (s1 == s2).mean() > 0.8  # the others a table cell or two apart (no bound on a single one: the table's clamp halves values beyond 127)
     d1, t1 = fec.ldpc_decode(short, c["rate"], s1.copy(), 25)
     d2, t2 = fec.ldpc_decode(short, c["rate"], s2.copy(), 25)
-    assert np.array_equal(d1 < 0, d2 < 0)
+    # frames both decoders converge on: the same code word. (The reference's decoder reports "not converged" on valid code words of most SHORT codes --
+    # tests/dvbs2_util.py -- and what it leaves then depends on the last soft bit: those frames are compared behind the BCH decoder, which is where the
+    # module takes its BBFRAMEs from.)
+    conv = (t1 >= 0) & (t2 >= 0)
+    assert np.array_equal((d1 < 0)[conv], (d2 < 0)[conv])
+    n, k = fec.dims(short, c["rate"])
+    b1, c1 = fec.bch_decode(short, c["rate"], np.packbits((d1 < 0).astype(np.uint8), axis=1)[:, :k // 8].copy())
+    b2, c2 = fec.bch_decode(short, c["rate"], np.packbits((d2 < 0).astype(np.uint8), axis=1)[:, :k // 8].copy())
+    okf = (c1 >= 0) & (c2 >= 0)
+    assert okf.sum() >= nfr - 1 and np.array_equal(b1[okf], b2[okf]) and np.array_equal(c1 >= 0, c2 >= 0)
 
 
 @pytest.mark.parametrize("modcod,short,esn0_db,nfr,lane_len", [(12, 1, 9.0, 16, 0), (12, 1, 9.0, 10, 1500), (6, 1, 6.0, 12, 0), (13, 0, 9.5, 6, 0)])

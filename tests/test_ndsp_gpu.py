@@ -187,3 +187,54 @@ def test_ndsp_host_mirror(torch_cuda, capi, nref):
     assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
     assert abs(blk.get_cfg("pll_freq") - 9000.0) < 400.0
     blk.stop()
+
+
+SINGLE = [
+    ("agc_cc", {"rate": 1e-4, "reference": 0.6, "gain": 1.0, "max_gain": 65536.0}),
+    ("agc_cc", {"rate": 1e-2, "gain": 3.0, "max_gain": 4.0}),
+    ("rrc_fir_cc", {"samplerate": 6e6, "symbolrate": 2333333.0, "alpha": 0.5, "ntaps": 21}),
+    ("costas_cc", {"order": 4, "loop_bw": 0.02}),
+    ("costas_cc", {"order": 8, "loop_bw": 0.003, "freq_limit": 0.01}),
+    ("clock_recovery_mm_cc", {"omega": 3.0}),
+    ("clock_recovery_mm_cc", {"omega": 2.5714, "mu": 0.25, "muGain": 0.02, "omegaGain": 1e-4, "omegaLimit": 0.01}),
+]
+
+
+def check_single_block_handles(capi, nref, block_id, cfg, to_host_run=None):
+    """The member blocks as handles of their own (sdhip_ndsp_block_create: what the plugin's single ndsp::Block classes sit on), state carried across work()
+    calls: exact mode against the reference block on its own thread and FIFOs, bit for bit, for a stream cut into ragged buffers; the default
+    chunk-parallel schedule: the same sample count, and values inside the schedule's floor (filter exact; loops: median < 1e-5 once locked)."""
+    from satdump_amd import ndsp
+    x = _signal("qpsk", 30000, esn0=10.0, seed=len(block_id) + len(cfg))
+    if block_id == "costas_cc":
+        x = x[::3].copy()  # a loop over symbols-ish samples
+    if block_id == "clock_recovery_mm_cc":
+        # the clock recovery sits behind the matched filter and the AGC (on raw samples its loop is no contraction: two trajectories never meet, and a
+        # time-parallel schedule has nothing to certify against)
+        sr = 2e6 * float(cfg.get("omega", 3.0))
+        x = _signal("qpsk", 30000, samplerate=sr, symbolrate=2e6, esn0=10.0, seed=len(block_id) + len(cfg))
+        x = nref.run("agc_cc", {"rate": 1e-3, "reference": 0.6}, nref.run("rrc_fir_cc", {"samplerate": sr, "symbolrate": 2e6, "alpha": 0.35}, x, buf=1000), buf=1000)
+    want = nref.run(block_id, cfg, x, buf=1000)
+    cuts = [0, 5, 1005, 20000, 20001, len(x)]
+    for exact in (True, False):
+        blk = ndsp.SingleBlock(block_id, exact=exact, capi_mod=capi)
+        for k2, v in cfg.items():
+            assert blk.set_cfg(k2, v) == ndsp.RES_OK
+        assert blk.set_cfg("no_such_key", 1) == ndsp.RES_ERR
+        got = np.concatenate([blk.work(x[a:b]) for a, b in zip(cuts[:-1], cuts[1:])])
+        blk.stop()
+        if block_id == "clock_recovery_mm_cc":
+            assert abs(len(got) - len(want)) <= (0 if exact else 1)
+        else:
+            assert len(got) == len(want)
+        if exact:
+            assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), block_id
+        else:
+            m = min(len(got), len(want))
+            err = np.abs(got[:m] - want[:m])[m // 2:] / np.sqrt(np.mean(np.abs(want) ** 2))
+            assert np.median(err) < 1e-5 and np.mean(err > 1e-3) < 0.05, (block_id, float(np.median(err)), float(np.mean(err > 1e-3)))
+
+
+@pytest.mark.parametrize("block_id,cfg", SINGLE)
+def test_ndsp_single_block_handles(torch_cuda, capi, nref, block_id, cfg):
+    check_single_block_handles(capi, nref, block_id, cfg)

@@ -11,3 +11,4 @@ test_ndsp_psk_demod_advanced_keys = N.test_ndsp_psk_demod_advanced_keys
 test_ndsp_psk_demod_chunk_parallel = N.test_ndsp_psk_demod_chunk_parallel
 test_ndsp_psk_demod_golden = N.test_ndsp_psk_demod_golden
 test_ndsp_host_mirror = N.test_ndsp_host_mirror
+test_ndsp_single_block_handles = N.test_ndsp_single_block_handles

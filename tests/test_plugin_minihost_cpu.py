@@ -97,3 +97,12 @@ def test_hip_devices_through_the_plugin_on_the_twin(host, tmp_path):
     if not pyref.ref_available() or not os.path.exists(emu_build.CLANG):
         pytest.skip("needs the compiled reference and a host clang++")
     G.check_hip_devices_through_the_plugin(host, emu_build.build(), tmp_path, case="metop", nframes=60, devices=(0, 0), serial_chunks=True)
+
+
+def test_ndsp_single_blocks_through_the_plugin_on_the_twin(host, tmp_path):
+    from oracle import pyref
+    from tests import test_plugin_minihost_gpu as G
+    from tests.emu import build as emu_build
+    if not pyref.NdspRef.available() or not os.path.exists(emu_build.CLANG):
+        pytest.skip("needs the compiled reference ndsp blocks and a host clang++")
+    G.check_ndsp_single_blocks_through_the_plugin(host, emu_build.build(), tmp_path)

@@ -392,7 +392,12 @@ def check_hip_devices_through_the_plugin(host, lib, tmp_path, case="metop", nfra
     s1, c1 = outs["one"]
     sn, cn = outs["many"]
     assert len(sn) == len(s1), (len(sn), len(s1))  # symbol for symbol the single stream
-    assert np.mean((sn < 0) != (s1 < 0)) < 2e-3 and np.mean(np.abs(sn.astype(np.int16) - s1.astype(np.int16)) > 2) < 5e-3
+    # ... in hard decisions; in VALUE a chunk whose carrier loop locked a quarter or half turn from the single stream's is another trajectory of the clock
+    # recovery too: the M&M detector slices to {0, 1}, not {-1, +1} (clock_recovery_mm.cpp:99-100), so its error term is not invariant under the constellation's
+    # symmetries and the timing jitter of the two locks differs by ~1e-2 sample (measured: 27 % of the int8 values differ by one LSB, 1.7 % by more than two,
+    # none by more than 8; a chunk that locks on the SAME turn agrees with the single stream on 99.9 %). The decoder does not see it: same CADUs below.
+    dsoft = np.abs(sn.astype(np.int16) - s1.astype(np.int16))
+    assert np.mean((sn < 0) != (s1 < 0)) < 1e-3 and np.mean(dsoft > 4) < 5e-3 and dsoft.max() <= 16, (float(np.mean((sn < 0) != (s1 < 0))), float(np.mean(dsoft > 4)), int(dsoft.max()))
     want = _ref_cadus_of_file(orc, ocfg, ofec, x, block=16384 if metop else 8192, metop=metop)
     assert c1.shape == want.shape and np.array_equal(c1, want)
     assert cn.shape == want.shape and np.array_equal(cn, want), (cn.shape, want.shape)
@@ -402,3 +407,32 @@ def check_hip_devices_through_the_plugin(host, lib, tmp_path, case="metop", nfra
 @pytest.mark.parametrize("case", ["metop", "goes"])
 def test_hip_devices_through_the_plugin(host, tmp_path, case):
     check_hip_devices_through_the_plugin(host, LIB, tmp_path, case=case, nframes=120 if case == "metop" else 60)
+
+
+def check_ndsp_single_blocks_through_the_plugin(host, lib, tmp_path):
+    """plugin/sdhip_ndsp_block.h -- SingleHipBlock, the chain's member blocks as satdump::ndsp::Block's of their own (agc_cc, rrc_fir_cc,
+    clock_recovery_mm_cc, costas_cc: what the flowgraph registry offers next to the hier block) -- instantiated from the plugin under the stock ids,
+    configured through set_cfg() with the reference blocks' own keys, linked between two DSPStream FIFOs and run by Block::start(): with "exact" the file
+    each writes is the reference block's output bit for bit (the reference block on its own thread and FIFOs, oracle/ref_wrap_ndsp.cpp)."""
+    from tests.test_ndsp_gpu import _signal
+    nd = pyref.NdspRef()
+    x = _signal("qpsk", 40000, 6e6, 2e6, esn0=10.0)
+    cases = [("agc_cc", {"rate": 1e-3, "reference": 0.6}, x),
+             ("rrc_fir_cc", {"samplerate": 6e6, "symbolrate": 2e6, "alpha": 0.35, "ntaps": 31}, x),
+             ("costas_cc", {"order": 4, "loop_bw": 0.01}, x[::3].copy())]
+    xm = nd.run("agc_cc", {"rate": 1e-3, "reference": 0.6}, nd.run("rrc_fir_cc", {"samplerate": 6e6, "symbolrate": 2e6, "alpha": 0.35}, x))
+    cases.append(("clock_recovery_mm_cc", {"omega": 3.0, "muGain": 0.01}, xm))
+    for bid, cfg, xin in cases:
+        inp = tmp_path / (bid + ".cf32")
+        np.ascontiguousarray(xin).tofile(str(inp))
+        want = nd.run(bid, cfg, xin)
+        rep = _run_ndsp(host, lib, {"block": bid, "cfg": dict(cfg, exact=True), "input": str(inp), "output": str(tmp_path / (bid + ".out")), "buffer": 4096}, tmp_path)
+        assert rep["block"].endswith("_hip_cc") and all(v == 0 for v in rep["set_cfg"].values()), rep
+        got = np.fromfile(str(tmp_path / (bid + ".out")), dtype=np.complex64)
+        assert len(got) == len(want) == rep["symbols"] and np.array_equal(got.view(np.uint32), want.view(np.uint32)), bid
+
+
+def test_ndsp_single_blocks_through_the_plugin(host, tmp_path):
+    if not pyref.NdspRef.available():
+        pytest.skip("needs the compiled reference ndsp blocks")
+    check_ndsp_single_blocks_through_the_plugin(host, LIB, tmp_path)
