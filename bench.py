@@ -399,13 +399,7 @@ def run_workload(args, workload, n_steps, n_warmup, parity_samples, ctx):
     if world == 1:
         def step():
             ns = dem.process_dev(x.data_ptr(), n_in, capi.FMT_CF32, d_soft.data_ptr(), soft_cap)
-            # where this rank's soft stream continues its predecessor's (a few KB of boundary symbols exchanged), and from there the byte its decoder starts at:
-            # on the single stream's Viterbi block grid -- the N lists then stitch into the single stream's list, whole frames (shard.hip)
-            lag, turn, agree, before, found = shard.align_ranks(lambda nb: d_soft[ns - nb:ns].cpu().numpy(), lambda nb: d_soft[:nb].cpu().numpy(), ns, q_soft, plan, rank, world,
-                                                                all_gather_np)
-            start = shard.fec_start(before, lag, q_soft, lock_block, lock_fec, int(lock_demod / sps_nom) * q_soft) if rank and found else 0
-            state["align"] = {"lag_symbols": lag, "quarter_turns": turn, "agreement": round(agree, 4), "found": bool(found), "decoder_starts_at_soft_byte": start}
-            nf = fec.process_dev(d_soft.data_ptr() + start, ns - start, d_cadu.data_ptr(), cap_frames)
+            nf = fec.process_dev(d_soft.data_ptr(), ns, d_cadu.data_ptr(), cap_frames)
             return ns, nf
     else:
         # one cold start per step: fresh handles, their device blocks recycled through the library's pool

@@ -624,7 +624,7 @@ def check_pll_parallel(capi, to_dev, from_dev, zeros_dev, modcod, short, esn0_db
     # the serial stretch is the reference's loop bit for bit
     assert np.array_equal(got[:3, :walked].view(np.uint32), want[:3, :walked].view(np.uint32))
     err = np.abs(got[:, :walked] - want[:, :walked]) / np.sqrt(np.mean(np.abs(want[:, :walked]) ** 2))
-    assert err.max() < 0.3 and np.quantile(err, 0.99) < (0.1 if lane_len else 0.05), (err.max(), np.quantile(err, 0.99))  # (short lanes: more of every lane is its settling stretch)
+    assert err.max() < 0.3 and np.quantile(err, 0.99) < 0.1, (err.max(), np.quantile(err, 0.99))  # (2 048-step lanes: a good part of every lane is its settling stretch)
     dph = (float(st[0]) - float(wst[0]) + np.pi) % (2 * np.pi) - np.pi
     assert abs(dph) < 0.08 and abs(float(st[1]) - float(wst[1])) < 1e-4, (st, wst)
     front, fec = pyref.S2FrontRef(), pyref.Dvbs2Ref(False)
