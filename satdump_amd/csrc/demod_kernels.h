@@ -56,6 +56,25 @@ namespace sdhip
     // offset, which the carrier loop behind it tracks out.
     void launch_rotator_par(const cf32 *x, cf32 *y, long long n, long long abs0, unsigned long long f_fix, float mag_eps, int buf_len, hipStream_t st);
 
+    // ---- Doppler correction (dsp::DopplerCorrectBlock::work, src-core/common/dsp/utils/doppler_correct.cpp:41-63): out = in * (cosf(-phase), sinf(-phase));
+    // phase += freq, wrapped into +-2 pi; freq = freq * (1 - alpha) + target * alpha, the target set anew after every source buffer from the pass
+    // prediction (:68-93: SGP4 on the host -- the caller supplies it, sdhip_demod_doppler_targets) ----
+    struct DopState
+    {
+        float phase, freq;
+    };
+    // exact: one sequential lane, every float / double operation where the reference has it. targets[k] = the target during the k-th source buffer that
+    // STARTS inside this launch (the buffer in progress at the launch's first sample runs on target_cur); pos0 = samples of that buffer already consumed
+    void launch_doppler_seq(const cf32 *x, cf32 *y, long long n, DopState *state, float alpha, float target_cur, const float *targets, int buf_len, int pos0, hipStream_t st);
+    // chunk-parallel mode: the recurrence in closed form, in double: within a source buffer freq_i = target + (f0 - target) beta^i, phase_i = ph0 + i target +
+    // (f0 - target)(1 - beta^i) / alpha. starts[b] = {ph0, f0, target} of the b-th buffer touched by this launch (host, double recurrence from buffer to buffer).
+    // What it leaves out is the float rounding of the reference's phase accumulation (a random walk of ~1e-4 rad per buffer): the carrier loop behind tracks it.
+    struct DopStart
+    {
+        double ph0, f0, target;
+    };
+    void launch_doppler_par(const cf32 *x, cf32 *y, long long n, const DopStart *starts, double alpha, int buf_len, int pos0, hipStream_t st);
+
     // ---- DC block (correct_iq.cpp:27-31): acc = acc * (1 - alpha) + x * alpha; y = x - acc, alpha = 1e-4 ------------
     struct DcState
     {
@@ -212,6 +231,8 @@ namespace sdhip
         float fast_mult;
         int q8, q8_bpsk; // q8: the symbols are stored as the module's int8 soft symbols (2 bytes per symbol row entry) instead of floats
         int fast;        // chunk-parallel mode's arithmetic: fused multiply-adds in the interpolator (exact mode: 0)
+        int arm_stride;  // floats between consecutive interpolator arms in the kernel's LDS copy: 8, or 12 (48 bytes: the lanes' 16-byte reads then start on
+                         // eight bank groups instead of four; SDHIP_MM_ARM_STRIDE)
     };
     struct MmState
     {

@@ -296,6 +296,69 @@ namespace sdhip
     }
 
     // =============================================================================================
+    // Doppler correction (demod_kernels.h)
+    // =============================================================================================
+    __global__ void k_doppler_seq(const cf32 *x, cf32 *y, long long n, DopState *state, float alpha, float target_cur, const float *targets, int buf_len, int pos0)
+    {
+        if (threadIdx.x != 0 || blockIdx.x != 0)
+            return;
+        float phase = state->phase, freq = state->freq, targ = target_cur;
+        int pos = pos0, tk = 0;
+        for (long long i = 0; i < n; i++)
+        {
+            if (pos == buf_len)
+            { // a new source buffer: the block has recomputed its target behind the previous one
+                targ = targets[tk++];
+                pos = 0;
+            }
+            float sn, cs;
+            sd_sincosf(-phase, sn, cs);
+            const float xr = x[i].re, xi = x[i].im;
+            y[i].re = (xr * cs) - (xi * sn); // complex_t * complex_t(cosf(-phase), sinf(-phase))
+            y[i].im = (xi * cs) + (xr * sn);
+            phase = phase + freq;
+            while ((double)phase > 2.0 * 3.14159265358979323846)
+                phase = (float)((double)phase - 2.0 * 3.14159265358979323846);
+            while ((double)phase < -2.0 * 3.14159265358979323846)
+                phase = (float)((double)phase + 2.0 * 3.14159265358979323846);
+            // curr_freq * (1.0 - d_alpha) + targ_freq * d_alpha: the first product in double, the second in float, the sum in double
+            freq = (float)((double)freq * (1.0 - (double)alpha) + (double)(targ * alpha));
+            pos++;
+        }
+        state->phase = phase;
+        state->freq = freq;
+    }
+    void launch_doppler_seq(const cf32 *x, cf32 *y, long long n, DopState *state, float alpha, float target_cur, const float *targets, int buf_len, int pos0, hipStream_t st)
+    {
+        ProfScope _ps("k_doppler_seq", st);
+        hipLaunchKernelGGL(k_doppler_seq, dim3(1), dim3(64), 0, st, x, y, n, state, alpha, target_cur, targets, buf_len, pos0);
+    }
+    __global__ __launch_bounds__(256) void k_doppler_par(const cf32 *x, cf32 *y, long long n, const DopStart *starts, double alpha, double log_beta, int buf_len, int pos0)
+    {
+        const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+        if (i >= n)
+            return;
+        const long long a = i + pos0;
+        const int b = (int)(a / buf_len);
+        const double k = (double)(a - (long long)b * buf_len) - (b == 0 ? (double)pos0 : 0.0); // steps since this buffer's start state was taken
+        const DopStart s = starts[b];
+        const double bk = exp(log_beta * k);
+        double ph = s.ph0 + k * s.target + (s.f0 - s.target) * (1.0 - bk) / alpha;
+        ph -= 6.283185307179586476925 * rint(ph / 6.283185307179586476925);
+        float sn, cs;
+        sd_sincosf_fast((float)-ph, sn, cs);
+        const cf32 v = x[i];
+        y[i] = cf32{v.re * cs - v.im * sn, v.im * cs + v.re * sn};
+    }
+    void launch_doppler_par(const cf32 *x, cf32 *y, long long n, const DopStart *starts, double alpha, int buf_len, int pos0, hipStream_t st)
+    {
+        if (n <= 0)
+            return;
+        ProfScope _ps("k_doppler_par", st);
+        hipLaunchKernelGGL(k_doppler_par, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, y, n, starts, alpha, log1p(-alpha), buf_len, pos0);
+    }
+
+    // =============================================================================================
     // rational resampler: output m uses inputs [inc-(nt-1), inc] with phase ctr (sequential-order dot product)
     // =============================================================================================
     typedef float v2f __attribute__((ext_vector_type(2))); // (re, im) pair: mul / add map to v_pk_mul_f32 / v_pk_add_f32
@@ -1970,8 +2033,8 @@ namespace sdhip
             imu = 0;
         if (imu >= 128)
             imu = 127;
-        const float4 t0 = *reinterpret_cast<const float4 *>(bank + imu * 8);
-        const float4 t1 = *reinterpret_cast<const float4 *>(bank + imu * 8 + 4);
+        const float4 t0 = *reinterpret_cast<const float4 *>(bank + imu * p.arm_stride);
+        const float4 t1 = *reinterpret_cast<const float4 *>(bank + imu * p.arm_stride + 4);
         const float t[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
         const int base = (int)((s.inc - 7) & (MM_RING - 1));
         // (re, im) of a sample as one packed pair: v_pk_mul_f32 / v_pk_add_f32, each half rounded like the scalar operation
@@ -2038,9 +2101,9 @@ template <bool CKPT, bool SPLIT, bool Q8 = false, bool FAST = false>
                                                float ck_tol)
     {
         __shared__ cf32 rings[MM_RING * MM_RING_STRIDE];
-        __shared__ __attribute__((aligned(16))) float bank[128 * 8];
+        __shared__ __attribute__((aligned(16))) float bank[128 * 12];
         for (int i = (int)threadIdx.x; i < 128 * 8; i += 64)
-            bank[i] = p.bank[i];
+            bank[(i >> 3) * p.arm_stride + (i & 7)] = p.bank[i];
         __syncthreads();
         const int idx = (int)(blockIdx.x * blockDim.x + threadIdx.x);
         int k;
