@@ -101,6 +101,10 @@ extern "C"
         int device;    /* HIP device ordinal */
         double freq_shift; /* "freq_shift" (Hz; a long in the reference, module_demod_base.cpp:36-37): dsp::FreqShiftBlock between the DC block
                               and the resampler (module_demod_base.cpp:122-123, freq_shift.cpp:18-46). 0 = none */
+        int doppler;         /* "enable_doppler" (module_demod_base.cpp:43-44, 125-171): dsp::DopplerCorrectBlock behind the frequency shift. The block's
+                                target frequency comes from the pass prediction (SGP4 on the satellite's TLE, doppler_correct.cpp:68-93) once per source
+                                buffer of `buffer_size` samples: host work that stays with the caller -- sdhip_demod_doppler_targets hands the targets in */
+        float doppler_alpha; /* "doppler_alpha", default 0.01: the one-pole ramp of the rotator's frequency toward the target */
     } sdhip_demod_cfg;
 
     typedef struct sdhip_demod_stats
@@ -137,6 +141,11 @@ extern "C"
        tail. Returns soft bytes written, <0 on error. Stream state carries across calls. */
     int64_t sdhip_demod_process_dev(void *h, const void *d_iq, size_t nsamples, int fmt, int8_t *d_soft, size_t soft_cap, float *d_syms, size_t syms_cap, int final);
     int sdhip_demod_get_stats(void *h, sdhip_demod_stats *st);
+    /* Doppler correction (cfg.doppler): append the rotator's target frequencies, rad / sample, for the source buffers to come. targets[k] is what
+       DopplerCorrectBlock::work computes BEHIND a buffer -- hz_to_rad(-doppler_shift, samplerate) at the time that buffer ends (doppler_correct.cpp:68-93) --
+       and is in force during the next one; the first buffer of a stream runs on target 0, as in the reference. A buffer is `buffer_size` samples
+       (sdhip_demod_get_stats tells the effective value); processing fails when a buffer starts for which no target has been handed in. */
+    int sdhip_demod_doppler_targets(void *h, const float *targets, size_t n);
 
     /* The DVB-S2 demodulator's front end (plugins/dvb_support/dvbs2/module_dvbs2_demod.cpp:98-105 on BaseDemodModule: resampler, AGC, RRC filter,
        M&M clock recovery -- psk_demod's stages without its Costas loop; carrier recovery follows per frame, sdhip_s2_pl_sync_dev /
@@ -282,7 +291,8 @@ extern "C"
        2 Costas(bw,order,limit) costas_loop.cpp:23-65 | 3 MM(omega,gw,mu,gmu,lim) clock_recovery_mm.cpp:52-121 |
        4 rational resampler(interp,decim) rational_resampler.cpp:43-64 | 5 DC block correct_iq.cpp:18-35 |
        7 Gardner(omega,gw,mu,gmu,lim) clock_recovery_gardner.cpp:33-124 | 8 carrier PLL(bw,max,min) pll_carrier_tracking.cpp:8-66 |
-       9 ndsp Costas(bw,order,limit) dsp/pll/costas.cpp:12-61 (branched clip). The other ndsp blocks compute what kinds 0, 1 and 3 do
+       9 ndsp Costas(bw,order,limit) dsp/pll/costas.cpp:12-61 (branched clip) | 10 Doppler rotator, exact (alpha, buf_len, ntargets, targets...)
+       doppler_correct.cpp:41-63 | 11 the same in the chunk-parallel mode's closed form. The other ndsp blocks compute what kinds 0, 1 and 3 do
        (dsp/agc/agc.cpp:22-39, dsp/filter/fir.cpp:62-133 minus its ntaps-sample latency, dsp/clock_recovery/clock_recovery_mm.cpp:66-183).
        Returns output sample count. */
     int64_t sdhip_op_block(int device, int kind, const float *params, const float *d_in, size_t n, float *d_out, size_t out_cap);

@@ -22,6 +22,7 @@ class DemodCfg(C.Structure):
         ("clock_gain_mu", C.c_float), ("clock_omega_relative_limit", C.c_float), ("costas_max_offset_hz", C.c_float),
         ("buffer_size", C.c_int), ("post_costas_dc", C.c_int),
         ("has_carrier", C.c_int), ("carrier_pll_bw", C.c_float), ("carrier_pll_max_offset", C.c_float), ("exact", C.c_int), ("chunk_len", C.c_int), ("warmup", C.c_int), ("device", C.c_int), ("freq_shift", C.c_double),
+        ("doppler", C.c_int), ("doppler_alpha", C.c_float),
     ]
 
 
@@ -497,3 +498,43 @@ def s2_lut_phase_ref(modcod, shortframes, resolution=256) -> np.ndarray:
     out = np.zeros((resolution, resolution), dtype=np.float32)
     lib.sdref_s2_lut_phase(int(modcod), int(shortframes), int(resolution), _p(out))
     return out
+
+
+def doppler_ref(x: np.ndarray, alpha: float, buf_len: int, targets: np.ndarray, state=(0.0, 0.0)):
+    """DopplerCorrectBlock::work's sample loop over a stream (oracle/sd_oracle.c: sdo_doppler; the plain-C restatement -- the block itself needs SatDump's TLE
+    database to construct): (rotated samples complex64, (phase, freq) behind the last sample). targets[k] = the block's target in force during buffer k + 1."""
+    lib = C.CDLL(os.path.join(_HERE, "_build", "libsdoracle.so"))
+    a = np.ascontiguousarray(x, dtype=np.complex64)
+    t = np.ascontiguousarray(targets, dtype=np.float32)
+    out = np.zeros_like(a)
+    st = np.array(state, dtype=np.float32)
+    lib.sdo_doppler.argtypes = [C.c_void_p, C.c_int64, C.c_float, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    lib.sdo_doppler(_p(a), len(a), float(alpha), int(buf_len), _p(t), len(t), _p(out), _p(st))
+    return out, st
+
+
+# a MetOp-B element set (epoch 2024-01-01; any valid-format set serves the tests: the prediction only has to be the SAME on both sides)
+TLE_TEST = ("1 38771U 12049A   24001.50000000  .00000100  00000-0  65000-4 0  9990",
+            "2 38771  98.6800  60.0000 0002000  90.0000 270.0000 14.21500000585000")
+
+
+def doppler_block_ref(x: np.ndarray, buf: int, samplerate: float, signal_frequency: float, start_time: float, alpha: float = 0.01, norad: int = 38771, tle=TLE_TEST,
+                      qth=(2.35, 48.85, 100.0)):
+    """The reference's DopplerCorrectBlock itself (oracle/ref_wrap_doppler.cpp, libsdref_doppler.so: the block + libpredict compiled in place), fed buffer by
+    buffer like BaseDemodModule feeds it from a baseband file: (corrected samples complex64, targets float32 -- targets[k] = targ_freq behind buffer k)."""
+    lib = C.CDLL(os.path.join(_HERE, "_ref", "libsdref_doppler.so"))
+    a = np.ascontiguousarray(x, dtype=np.complex64)
+    out = np.zeros_like(a)
+    nb = (len(a) + buf - 1) // buf
+    targ = np.zeros(nb + 1, dtype=np.float32)
+    lib.sdref_doppler.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_double, C.c_float, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_void_p, C.c_longlong,
+                                  C.c_int, C.c_void_p, C.c_void_p, C.c_int]
+    k = lib.sdref_doppler(tle[0].encode(), tle[1].encode(), int(norad), float(samplerate), float(alpha), float(signal_frequency), float(qth[0]), float(qth[1]), float(qth[2]),
+                          float(start_time), _p(a), len(a), int(buf), _p(out), _p(targ), len(targ))
+    if k < 0:
+        raise RuntimeError(f"sdref_doppler -> {k}")
+    return out, targ[:k]
+
+
+def doppler_block_available() -> bool:
+    return os.path.exists(os.path.join(_HERE, "_ref", "libsdref_doppler.so"))

@@ -28,6 +28,11 @@ int sdo_resamp_bank(unsigned interp, unsigned decim, float *out, int cap, int *i
 int64_t sdo_block_run(int kind, const float *p, const float *in_c, int64_t n, int chunk, float *out_c, int64_t out_cap);
 int64_t sdo_psk_demod(const sdhip_demod_cfg *c, const float *iq, int64_t n, int8_t *soft, int64_t soft_cap, float *syms, int64_t syms_cap,
                       int *buffer_size_out, float *final_sps_out);
+/* dsp::DopplerCorrectBlock::work's sample loop (src-core/common/dsp/utils/doppler_correct.cpp:41-63), restated; the target frequency the block
+   recomputes behind every source buffer (:68-93, SGP4 on a TLE from SatDump's database) is an INPUT here: targets[k] is in force during source buffer
+   k + 1, the first buffer runs on 0. state2 = {phase, freq} in / out. Pinned against the block itself, compiled in place with libpredict
+   (oracle/ref_wrap_doppler.cpp, tests/test_oracle_vs_ref.py::test_doppler_restatement_equals_the_block). */
+void sdo_doppler(const float *in_c, int64_t n, float alpha, int buf_len, const float *targets, int ntargets, float *out_c, float *state2);
 /* glibc-2.35 sinf/cosf restatement (the device code must match this bit for bit) */
 float sdo_sinf(float x);
 float sdo_cosf(float x);

@@ -18,6 +18,9 @@
 #include "pipeline/module.h"
 #include "pipeline/modules/base/filestream_to_filestream.h"
 
+#include "common/geodetic/geodetic_coordinates.h" // DEG_TO_RAD (enable_doppler)
+#include "init.h"                                  // satdump::db_keplers (enable_doppler: the satellite's TLE, as DopplerCorrectBlock's constructor asks for it)
+#include "libs/predict/predict.h"                  // SGP4 / SDP4 (libsatdump_core)
 #include "common/dsp/demod/constellation.h"  // the DVB-S2 module's demapper table is built by the reference's own class (libsatdump_core)
 #include "codings/dvb-s2/modcod_to_cfg.h"    // plugins/dvb_support (header only): get_dvbs2_cfg
 
@@ -106,6 +109,34 @@ namespace sdhip_plugin
         std::string baseband_format = "cf32";
         int fmt = SDHIP_FMT_CF32;
         std::vector<int> devices; // "hip_devices": a baseband FILE is cut in time over these devices (process_sharded)
+        // enable_doppler (module_demod_base.cpp:125-171): the rotator runs on the device, its target per source buffer is computed here exactly where and how
+        // DopplerCorrectBlock::work computes it (doppler_correct.cpp:65-93: time advanced by the buffer, SGP4 on the TLE, range rate -> Hz -> rad / sample)
+        double dop_frequency = -1, dop_start_time = -1, qth_lon = 0, qth_lat = 0, qth_alt = 0;
+        int dop_norad = -1;
+        std::vector<float> doppler_targets(uint64_t n_samples, int buffer_size)
+        {
+            auto tle = satdump::db_keplers->get_from_norad(dop_norad).value();
+            predict_orbital_elements_t *sat = predict_parse_tle(tle.line1.c_str(), tle.line2.c_str());
+            predict_observer_t *obs = predict_create_observer("Main", qth_lat * DEG_TO_RAD, qth_lon * DEG_TO_RAD, qth_alt);
+            if (obs == nullptr || sat == nullptr)
+                throw std::runtime_error("Couldn't init libpredict objects!");
+            std::vector<float> t;
+            double start_time = dop_start_time;
+            for (uint64_t o = 0; o < n_samples; o += (uint64_t)buffer_size)
+            {
+                const uint64_t nsamples = std::min<uint64_t>((uint64_t)buffer_size, n_samples - o);
+                start_time += (double)nsamples / (double)(long)cfg.samplerate;
+                struct predict_position orbit;
+                struct predict_observation pos;
+                predict_orbit(sat, &orbit, predict_to_julian_double(start_time));
+                predict_observe_orbit(obs, &orbit, &pos);
+                const double doppler_shift = (pos.range_rate * 1000.0 / 299792458.0) * dop_frequency;
+                t.push_back((float)dsp::hz_to_rad(-doppler_shift, (double)(long)cfg.samplerate));
+            }
+            predict_destroy_observer(obs);
+            predict_destroy_orbital_elements(sat);
+            return t;
+        }
         std::atomic<uint64_t> filesize{0}, progress{0};
         std::atomic<float> display_freq{0}, snr{0}, peak_snr{0};
         std::atomic<bool> should_stop{false};
@@ -186,6 +217,30 @@ namespace sdhip_plugin
             if (parameters.count("hip_devices") > 0) // e.g. [0, 1, 2, 3, 4, 5, 6, 7]: one recording over the GPUs of a node
                 devices = parameters["hip_devices"].get<std::vector<int>>();
             fmt = baseband_fmt_of(baseband_format, "psk_demod_hip");
+            bool dop = false;
+            opt(parameters, "enable_doppler", dop);
+            if (dop)
+            { // module_demod_base.cpp:43-47, 125-171
+                cfg.doppler = 1;
+                opt(parameters, "doppler_alpha", cfg.doppler_alpha);
+                if (parameters.count("satellite_frequency"))
+                    dop_frequency = parameters["satellite_frequency"].get<double>();
+                else
+                    throw satdump_exception("Satellite Frequency is required for doppler correction!");
+                if (cfg.freq_shift != 0)
+                    dop_frequency += cfg.freq_shift;
+                if (parameters.count("satellite_norad"))
+                    dop_norad = parameters["satellite_norad"].get<double>();
+                else
+                    throw satdump_exception("Satellite NORAD is required for doppler correction!");
+                // the station: the module reads SatDump's general configuration first (satdump_cfg, not reachable from a plugin's translation unit without
+                // the core's config headers: INTEGRATION.md) and lets these keys override it
+                opt(parameters, "qth_lon", qth_lon);
+                opt(parameters, "qth_lat", qth_lat);
+                opt(parameters, "qth_alt", qth_alt);
+                if (parameters.count("start_timestamp") > 0)
+                    dop_start_time = parameters["start_timestamp"].get<double>();
+            }
         }
         ~PSKDemodHipModule()
         {
@@ -196,9 +251,10 @@ namespace sdhip_plugin
         // shift / Doppler front-ends, wav/ziq/cs32 containers, ratios that need SmartResampler's power-of-two pre-decimator.)
         static bool covers(const std::string &input_file, const std::string &output_file_hint, const nlohmann::json &parameters, std::string &why)
         {
-            if (parameters.count("enable_doppler") > 0 && parameters["enable_doppler"].get<bool>())
-            {
-                why = "enable_doppler";
+            if (parameters.count("enable_doppler") > 0 && parameters["enable_doppler"].get<bool>() && parameters.count("start_timestamp") == 0)
+            { // a live stream takes the wall clock behind every buffer (doppler_correct.cpp:71-78): thread timing; a file without a timestamp has its
+              // Doppler correction switched off by the module (module_demod_base.cpp:168-172): both stay with the CPU module
+                why = "enable_doppler without start_timestamp";
                 return false;
             }
             try
@@ -425,12 +481,24 @@ namespace sdhip_plugin
             }
             std::vector<int8_t> out(1 << 24);
             static const int bps[5] = {8, 4, 2, 2, 8}; // bytes per complex sample, indexed by SDHIP_FMT_* (cf32, cs16, cs8, cu8, cs32)
+            if (cfg.doppler && (input_data_type != DATA_FILE || dop_start_time == -1 || devices.size() > 1))
+                throw satdump_exception("psk_demod_hip: enable_doppler is on the HIP path for baseband files with a start_timestamp on one device (use psk_demod otherwise)");
             if (input_data_type == DATA_FILE)
             {
                 std::ifstream in(d_input_file, std::ios::binary);
                 in.seekg(0, std::ios::end);
                 filesize = (uint64_t)in.tellg();
                 in.seekg(0, std::ios::beg);
+                if (cfg.doppler)
+                {
+                    sdhip_demod_stats st0;
+                    sdhip_demod_get_stats(h, &st0);
+                    const std::vector<float> t = doppler_targets(filesize / bps[fmt], st0.buffer_size);
+                    if (sdhip_demod_doppler_targets(h, t.data(), t.size()) < 0)
+                        throw satdump_exception(std::string("psk_demod_hip: ") + sdhip_last_error());
+                    logger->info("Doppler correction: %d source buffers of %d samples, first target %.1f Hz", (int)t.size(), st0.buffer_size,
+                                 t.empty() ? 0.0 : -dsp::rad_to_hz(t[0], (double)(long)cfg.samplerate));
+                }
                 const size_t samples_per_read = 1 << 22;
                 std::vector<char> raw(samples_per_read * bps[fmt]);
                 while (!should_stop && in)

@@ -29,6 +29,7 @@ class DemodCfg(C.Structure):
         ("clock_gain_mu", C.c_float), ("clock_omega_relative_limit", C.c_float), ("costas_max_offset_hz", C.c_float),
         ("buffer_size", C.c_int), ("post_costas_dc", C.c_int),
         ("has_carrier", C.c_int), ("carrier_pll_bw", C.c_float), ("carrier_pll_max_offset", C.c_float), ("exact", C.c_int), ("chunk_len", C.c_int), ("warmup", C.c_int), ("device", C.c_int), ("freq_shift", C.c_double),
+        ("doppler", C.c_int), ("doppler_alpha", C.c_float),
     ]
 
 
@@ -145,6 +146,8 @@ def lib():
             L.sdhip_demod_process_dev.restype = C.c_int64
             L.sdhip_demod_process_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int]
             L.sdhip_demod_get_stats.argtypes = [C.c_void_p, C.POINTER(DemodStats)]
+            if hasattr(L, "sdhip_demod_doppler_targets"):
+                L.sdhip_demod_doppler_targets.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
             L.sdhip_op_block.restype = C.c_int64
             L.sdhip_op_block.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
         if hasattr(L, "sdhip_dvbs2_front_create"):
@@ -359,6 +362,11 @@ class PskDemod:
         st = DemodStats()
         lib().sdhip_demod_get_stats(self.h, C.byref(st))
         return st
+
+    def doppler_targets(self, targets):
+        """The Doppler rotator's target frequencies (rad / sample) for the source buffers to come (sdhip_demod_doppler_targets)."""
+        t = np.ascontiguousarray(targets, dtype=np.float32)
+        _check(lib().sdhip_demod_doppler_targets(self.h, t.ctypes.data_as(C.c_void_p), len(t)), "sdhip_demod_doppler_targets")
 
 
 class LdpcDecoder:

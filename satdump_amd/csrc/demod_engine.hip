@@ -486,6 +486,16 @@ namespace sdhip
         float rot_dre = 1.0f, rot_dim = 0.0f;
         RotState rot_s{1.0f, 0.0f};
         long long rot_abs = 0;
+        // Doppler correction (dsp::DopplerCorrectBlock): rotator state, the target in force, position inside the source buffer in progress (0 .. buffer
+        // size: at the size, the next sample opens a new buffer), the targets handed in for the buffers to come
+        DopState dop_s{0.0f, 0.0f};
+        double dop_ph = 0.0, dop_f = 0.0; // the same state as the chunk-parallel mode carries it (double)
+        float dop_target = 0.0f;
+        int dop_pos = 0;
+        std::deque<float> dop_queue;
+        DevBuf<DopState> d_dop;
+        DevBuf<float> d_dop_t;
+        DevBuf<DopStart> d_dop_starts;
         unsigned long long rot_fix = 0;
         float rot_mag_eps = 0.0f;
         DevBuf<RotState> d_rot_state;
@@ -1698,7 +1708,7 @@ namespace sdhip
 
             // ---- stage 0: format conversion (+ iq_swap). cf32 without swap is already the stage format: the first stage reads
             // the caller's buffer in place (16-byte aligned pointers only: the lanes move float4 blocks).
-            const bool in_place = fmt == SDHIP_FMT_CF32 && !cfg.iq_swap && !cfg.dc_block && cfg.freq_shift == 0 && (reinterpret_cast<uintptr_t>(d_in) & 15) == 0;
+            const bool in_place = fmt == SDHIP_FMT_CF32 && !cfg.iq_swap && !cfg.dc_block && cfg.freq_shift == 0 && !cfg.doppler && (reinterpret_cast<uintptr_t>(d_in) & 15) == 0;
             const cf32 *SRC = A;
             if (in_place)
                 SRC = reinterpret_cast<const cf32 *>(d_in);
@@ -1737,6 +1747,73 @@ namespace sdhip
                 std::swap(A, B);
                 SRC = A;
                 tick("freq_shift");
+            }
+            // ---- Doppler correction (module_demod_base.cpp:125-171): behind the frequency shift, in front of the resampler
+            if (cfg.doppler)
+            {
+                const int src_buf = d_buffer_size;
+                const long long first = (long long)src_buf - dop_pos; // samples left in the buffer in progress
+                const int nstart = n > first ? (int)((n - first + src_buf - 1) / src_buf) : 0; // source buffers that START inside this call
+                if ((size_t)nstart > dop_queue.size())
+                    throw HipError("doppler: " + std::to_string(nstart) + " source buffers start in this call but only " + std::to_string(dop_queue.size()) +
+                                   " targets are queued (sdhip_demod_doppler_targets)");
+                std::vector<float> t(dop_queue.begin(), dop_queue.begin() + nstart);
+                const float alpha = cfg.doppler_alpha;
+                if (cfg.exact)
+                {
+                    d_dop.reserve(1);
+                    d_dop_t.reserve(std::max<size_t>(1, t.size()));
+                    SD_HIP(hipMemcpyAsync(d_dop.p, &dop_s, sizeof(dop_s), hipMemcpyHostToDevice, stream));
+                    if (!t.empty())
+                        SD_HIP(hipMemcpyAsync(d_dop_t.p, t.data(), t.size() * sizeof(float), hipMemcpyHostToDevice, stream));
+                    launch_doppler_seq(A, B, n, d_dop.p, alpha, dop_target, d_dop_t.p, src_buf, dop_pos, stream);
+                    SD_HIP(hipMemcpyAsync(&dop_s, d_dop.p, sizeof(dop_s), hipMemcpyDeviceToHost, stream));
+                    SD_HIP(hipStreamSynchronize(stream));
+                }
+                else
+                {
+                    // start states of the buffers touched, buffer to buffer in closed form (double)
+                    const double a = (double)alpha, lb = log1p(-a);
+                    std::vector<DopStart> st;
+                    double ph = dop_ph, f = dop_f, targ = (double)dop_target;
+                    long long left = n;
+                    long long seg = std::min<long long>(left, first);
+                    size_t tk = 0;
+                    for (;;)
+                    {
+                        if (seg == 0 && left > 0)
+                        { // the buffer in progress is used up: the next sample opens a new one
+                            targ = (double)t[tk++];
+                            seg = std::min<long long>(left, src_buf);
+                        }
+                        st.push_back(DopStart{ph, f, targ});
+                        const double bk = exp(lb * (double)seg);
+                        ph = ph + (double)seg * targ + (f - targ) * (1.0 - bk) / a;
+                        ph -= 2.0 * design::PI * rint(ph / (2.0 * design::PI));
+                        f = targ + (f - targ) * bk;
+                        left -= seg;
+                        if (left <= 0)
+                            break;
+                        seg = 0;
+                    }
+                    // the kernel indexes buffers by (i + pos0) / buf_len: an exhausted buffer in progress (first == 0) occupies index 0 with no samples
+                    if (first == 0)
+                        st.insert(st.begin(), DopStart{dop_ph, dop_f, (double)dop_target});
+                    d_dop_starts.reserve(st.size());
+                    SD_HIP(hipMemcpyAsync(d_dop_starts.p, st.data(), st.size() * sizeof(DopStart), hipMemcpyHostToDevice, stream));
+                    launch_doppler_par(A, B, n, d_dop_starts.p, a, src_buf, dop_pos, stream);
+                    SD_HIP(hipStreamSynchronize(stream)); // (st is a local)
+                    dop_ph = ph;
+                    dop_f = f;
+                }
+                for (int k = 0; k < nstart; k++)
+                    dop_queue.pop_front();
+                if (nstart)
+                    dop_target = t.back();
+                dop_pos = nstart ? (int)(n - first - (long long)(nstart - 1) * src_buf) : (int)(dop_pos + n);
+                std::swap(A, B);
+                SRC = A;
+                tick("doppler");
             }
             // ---- SmartResampler: power-of-two pre-decimator stages (if the ratio has them), then the rational resampler
             bool in_place_r = in_place;
@@ -2097,6 +2174,7 @@ extern "C"
         c->clock_gain_mu = (float)8.7e-3;
         c->clock_omega_relative_limit = 0.005f;
         c->carrier_pll_max_offset = 3.14f; // module_psk_demod.cpp:104
+        c->doppler_alpha = 0.01f;          // module_demod_base.h:61
     }
     void *sdhip_demod_create(const sdhip_demod_cfg *cfg)
     {
@@ -2257,6 +2335,17 @@ extern "C"
         SD_GUARD_END(-1)
     }
     int sdhip_ndsp_psk_demod_get_stats(void *h, sdhip_demod_stats *st) { return sdhip_demod_get_stats(h, st); }
+    int sdhip_demod_doppler_targets(void *h, const float *targets, size_t n)
+    {
+        SD_GUARD_BEGIN
+        DemodEngine *e = (DemodEngine *)h;
+        if (!e->cfg.doppler)
+            throw HipError("doppler targets handed to a handle without cfg.doppler");
+        for (size_t i = 0; i < n; i++)
+            e->dop_queue.push_back(targets[i]);
+        return 0;
+        SD_GUARD_END(-1)
+    }
     int sdhip_demod_get_stats(void *h, sdhip_demod_stats *st)
     {
         *st = ((DemodEngine *)h)->stats;

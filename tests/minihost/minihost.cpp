@@ -27,6 +27,8 @@
 #include <cstring>
 #include <thread>
 
+#include "init.h" // ref_shim/init.h: the TLE registry's one method (enable_doppler)
+
 std::shared_ptr<slog::Logger> logger = std::make_shared<slog::Logger>();
 
 // ---- what libsatdump_core provides for the headers above
@@ -41,6 +43,7 @@ namespace satdump
     uint64_t getFilesize(std::string filepath) { return std::filesystem::exists(filepath) ? (uint64_t)std::filesystem::file_size(filepath) : 0; }
     std::map<std::string, std::shared_ptr<satdump::Plugin>> loaded_plugins;
     std::shared_ptr<EventBus> eventBus = std::make_shared<EventBus>();
+    std::shared_ptr<KeplerDBHandler> db_keplers = std::make_shared<KeplerDBHandler>(); // filled from the job's "tles" (libsatdump_core: the TLE database)
     std::shared_ptr<TaskScheduler> taskScheduler;
     namespace pipeline
     {
@@ -236,6 +239,9 @@ int main(int argc, char **argv)
         std::ifstream f(argv[4]);
         f >> job;
     }
+    if (job.contains("tles"))
+        for (auto &e : job["tles"])
+            satdump::db_keplers->tles.push_back(e.get<satdump::TLE>());
     try
     {
         const std::string mode = job["mode"], input = job["input"], hint = job["output_hint"];

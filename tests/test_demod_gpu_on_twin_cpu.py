@@ -117,6 +117,7 @@ test_post_costas_dc = G2.test_post_costas_dc
 test_has_carrier = G2.test_has_carrier
 test_soft_symbols_without_the_float_symbols = G2.test_soft_symbols_without_the_float_symbols
 test_freq_shift = G2.test_freq_shift
+test_doppler = G2.test_doppler
 test_dvbs2_front_end = G2.test_dvbs2_front_end
 
 

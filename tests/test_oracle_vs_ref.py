@@ -270,3 +270,22 @@ def test_threaded_pipeline_equals_the_sequential_entries(ref, case):
     assert m >= len(seq) - 2 * 8192 * 4 and np.array_equal(seq[:m], th["soft"][:m])
     k = min(len(seqc), len(th["cadu"]))
     assert k >= len(seqc) - 2 and k > 20 and np.array_equal(seqc[:k], th["cadu"][:k])
+
+
+def test_doppler_restatement_equals_the_block():
+    """oracle/sd_oracle.c's restatement of DopplerCorrectBlock::work's sample loop (sdo_doppler) against the block itself, compiled in place with libpredict
+    (oracle/ref_wrap_doppler.cpp) and fed buffer by buffer like a baseband file feeds it: the block's own targets in, the same samples out, bit for bit -- at
+    three points of an orbit (rising, high, setting Doppler)."""
+    if not pyref.doppler_block_available():
+        pytest.skip("oracle/_ref/libsdref_doppler.so not built (needs /root/reference at build time)")
+    rng = np.random.default_rng(1)
+    n, buf = 250_000, 30000
+    x = (rng.standard_normal(n) + 1j * rng.standard_normal(n)).astype(np.complex64)
+    seen = set()
+    for st in (1704110400.0, 1704112000.0, 1704115000.0):
+        y, t = pyref.doppler_block_ref(x, buf, 6e6, 1701.3e6, st)
+        assert len(t) == (n + buf - 1) // buf and np.all(np.abs(t) < 0.1) and np.any(t != 0)
+        y2, _ = pyref.doppler_ref(x, 0.01, buf, t)
+        assert np.array_equal(y.view(np.uint32), y2.view(np.uint32))
+        seen.add(float(np.round(t[0], 6)))
+    assert len(seen) == 3

@@ -106,3 +106,12 @@ def test_ndsp_single_blocks_through_the_plugin_on_the_twin(host, tmp_path):
     if not pyref.NdspRef.available() or not os.path.exists(emu_build.CLANG):
         pytest.skip("needs the compiled reference ndsp blocks and a host clang++")
     G.check_ndsp_single_blocks_through_the_plugin(host, emu_build.build(), tmp_path)
+
+
+def test_doppler_through_the_plugin_on_the_twin(host, tmp_path):
+    from oracle import pyref
+    from tests import test_plugin_minihost_gpu as G
+    from tests.emu import build as emu_build
+    if not pyref.doppler_block_available() or not os.path.exists(emu_build.CLANG):
+        pytest.skip("needs the compiled reference Doppler block and a host clang++")
+    G.check_doppler_through_the_plugin(host, emu_build.build(), tmp_path)

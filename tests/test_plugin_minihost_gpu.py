@@ -436,3 +436,61 @@ def test_ndsp_single_blocks_through_the_plugin(host, tmp_path):
     if not pyref.NdspRef.available():
         pytest.skip("needs the compiled reference ndsp blocks")
     check_ndsp_single_blocks_through_the_plugin(host, LIB, tmp_path)
+
+
+def check_doppler_through_the_plugin(host, lib, tmp_path, nframes=40):
+    """`enable_doppler` through the drop-in boundary: the stock id `psk_demod` with satellite_frequency / satellite_norad / qth_* / start_timestamp on a
+    baseband FILE. The plugin computes the rotator's target per source buffer where and how DopplerCorrectBlock::work does (time advanced by the buffer,
+    SGP4 on the satellite's TLE from the registry, range rate -> Hz -> rad / sample: libpredict, libsatdump_core's) and hands them to the device's rotator
+    (sdhip_demod_doppler_targets). Checker: the reference's own block (compiled in place with libpredict, oracle/ref_wrap_doppler.cpp) in front of the reference
+    chain on the same file. hip_exact: the .soft file is the reference's byte for byte -- which also says the plugin's targets are the block's, float for
+    float; default schedule: same length, CADUs of the stock decoder id identical. A file without start_timestamp stays with the CPU module (the module
+    switches its correction off, a live stream takes the wall clock)."""
+    orc = pyref.best()
+    spec, cadus, plain, syms = util.metop_case(nframes=nframes)
+    x, _ = synth.modulate(syms, spec)
+    fs, f_sat, t0 = 6e6, 1701.3e6, 1704112000.0
+    ocfg = pyref.demod_cfg(samplerate=6e6, symbolrate=2333333, constellation=pyref.QPSK, pll_bw=0.003)
+    buf = orc.psk_demod(ocfg, x[:70000], want_syms=False)["buffer_size"]
+    # the pass's Doppler put ON the recording: what the block itself takes off a carrier, inverted
+    ones = np.ones(len(x), dtype=np.complex64)
+    rot, targ = pyref.doppler_block_ref(ones, buf, fs, f_sat, t0)
+    assert np.abs(targ).max() > 1e-3
+    xd = (x * np.conj(rot)).astype(np.complex64)
+    inp = tmp_path / "dop.cf32"
+    xd.tofile(str(inp))
+    y, targ2 = pyref.doppler_block_ref(xd, buf, fs, f_sat, t0)
+    assert np.array_equal(targ, targ2)
+    want = orc.psk_demod(ocfg, y, want_syms=False)["soft"]
+    wantc = orc.metop_decode(want, ber_thr=0.28, outsync_after=10)["cadu"]
+    assert len(wantc) >= nframes - 8
+    tles = [{"norad": 38771, "name": "METOP-B", "line1": pyref.TLE_TEST[0], "line2": pyref.TLE_TEST[1]}]
+    dop = {"enable_doppler": True, "satellite_frequency": f_sat, "satellite_norad": 38771, "qth_lon": 2.35, "qth_lat": 48.85, "qth_alt": 100.0, "start_timestamp": t0}
+    for name, extra in (("exact", {"hip_exact": 1}), ("par", {})):
+        job = {"mode": "file", "input": str(inp), "output_hint": str(tmp_path / name), "tles": tles,
+               "demod": {"module": "psk_demod", "parameters": dict(METOP_DEMOD, **dop, **extra)}, "decoder": {"module": "metop_ahrpt_decoder", "parameters": METOP_DEC}}
+        jp = tmp_path / (name + ".json")
+        jp.write_text(json.dumps(job))
+        p = subprocess.run([host, lib, PLUGIN, "run", str(jp)], capture_output=True, text=True, env=dict(os.environ, SDHIP_OVERRIDE="1"), timeout=900)
+        assert p.returncode == 0, p.stdout[-1000:] + p.stderr[-3000:]
+        rep = json.loads(p.stdout.strip().splitlines()[-1])
+        assert rep["demod_class"] == "psk_demod_hip"
+        soft = np.fromfile(rep["soft"], dtype=np.int8)
+        if name == "exact":
+            assert np.array_equal(soft, want)
+        else:
+            assert len(soft) == len(want)
+            got = np.fromfile(rep["cadu"], dtype=np.uint8).reshape(-1, 1024)
+            refc = _ref_cadus_of_file(orc, ocfg, None, y, block=16384, metop=True)
+            assert got.shape == refc.shape and np.array_equal(got, refc)
+    job["demod"]["parameters"] = {k2: v for k2, v in dict(METOP_DEMOD, **dop).items() if k2 != "start_timestamp"}
+    job["instantiate_only"] = True
+    (tmp_path / "nots.json").write_text(json.dumps(job))
+    p = subprocess.run([host, lib, PLUGIN, "run", str(tmp_path / "nots.json")], capture_output=True, text=True, env=dict(os.environ, SDHIP_OVERRIDE="1"), timeout=120)
+    assert p.returncode == 0 and json.loads(p.stdout.strip().splitlines()[-1])["demod_class"] == "cpu:psk_demod"
+
+
+def test_doppler_through_the_plugin(host, tmp_path):
+    if not pyref.doppler_block_available():
+        pytest.skip("needs the compiled reference Doppler block")
+    check_doppler_through_the_plugin(host, LIB, tmp_path)
