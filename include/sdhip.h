@@ -509,6 +509,39 @@ extern "C"
     int sdhip_shard_stitch(const uint8_t *const *heads, const size_t *n_heads, const uint8_t *const *tails, const size_t *n_tails, const uint64_t *counts, int world, int frame_bytes,
                            size_t edge, int whole_frames, uint64_t *drops_out);
 
+    /* ---- the first step behind the CADUs: CCSDS AOS virtual channels and M_PDU packet extraction (aos_demux.hip) -----------------
+       What every instrument decoder of the reference does first with a .cadu stream: ccsds::ccsds_aos::parseVCDU on each frame
+       (src-core/common/ccsds/ccsds_aos/vcdu.cpp:10-18), keep the frames of its virtual channel, feed them to ccsds::ccsds_aos::Demuxer::work
+       (demuxer.cpp:67-201) -- here with the CADUs and the packets' payload bytes staying in HBM. */
+    typedef struct sdhip_vcdu
+    {
+        uint8_t version;
+        uint16_t spacecraft_id;
+        uint8_t vcid;
+        uint32_t vcdu_counter;
+        uint8_t replay_flag;
+    } sdhip_vcdu; /* ccsds_aos::VCDU, vcdu.h:11-18 */
+    int sdhip_aos_parse_vcdu_dev(int device, const uint8_t *d_cadus, int cadu_bytes, int nframes, sdhip_vcdu *d_out);
+    /* the frames whose VCID is `vcid`, in order, copied to d_out (device); d_index_out (device, may be NULL) = their indices in the input. Returns the count. */
+    int64_t sdhip_aos_select_vcid_dev(int device, const uint8_t *d_cadus, int cadu_bytes, int nframes, int vcid, uint8_t *d_out, size_t cap_frames, int *d_index_out);
+    typedef struct sdhip_aos_packet
+    {
+        uint8_t header[6]; /* CCSDSHeader::raw and its fields (src-core/common/ccsds/ccsds.cpp:12-22) */
+        uint8_t version, type, secondary_header_flag, sequence_flag;
+        uint16_t apid, packet_sequence_count, packet_length;
+        uint32_t frame;          /* index (within the call) of the frame whose Demuxer::work call handed the packet out */
+        uint32_t payload_size;   /* CCSDSPacket::payload.size(): what was gathered, which a damaged stream can leave short of packet_length + 1 */
+        uint64_t payload_offset; /* of its bytes in the call's payload pool */
+    } sdhip_aos_packet;
+    /* Demuxer(mpdu_data_size, hasInsertZone, insertZoneSize, secondaryHeaderExtendsPkt), demuxer.h:35: one handle per virtual channel, its state (a packet
+       spanning frames, a header split across frames) carried across calls */
+    void *sdhip_aos_demux_create(int device, int mpdu_data_size, int has_insert_zone, int insert_zone_size, int secondary_header_extends_pkt);
+    void sdhip_aos_demux_destroy(void *h);
+    /* nframes CADUs of ONE virtual channel (device), in order -> the packets Demuxer::work hands out for them, in order: packets_out (HOST table), their payload
+       bytes gathered into d_payload (DEVICE pool, packet k at payload_offset). Returns the packet count; *payload_bytes_out = pool bytes used. */
+    int64_t sdhip_aos_demux_work_dev(void *h, const uint8_t *d_cadus, int cadu_bytes, int nframes, sdhip_aos_packet *packets_out, size_t cap_packets, uint8_t *d_payload,
+                                     size_t cap_payload, uint64_t *payload_bytes_out);
+
     /* ---- misc ------------------------------------------------------------------------ */
     const char *sdhip_last_error(void);
     const char *sdhip_version(void);

@@ -538,3 +538,37 @@ def doppler_block_ref(x: np.ndarray, buf: int, samplerate: float, signal_frequen
 
 def doppler_block_available() -> bool:
     return os.path.exists(os.path.join(_HERE, "_ref", "libsdref_doppler.so"))
+
+
+class AosRef:
+    """The reference's CCSDS AOS helpers (oracle/ref_wrap_aos.cpp, libsdref_aos.so): parseVCDU and ccsds_aos::Demuxer."""
+
+    def __init__(self):
+        self.lib = C.CDLL(os.path.join(_HERE, "_ref", "libsdref_aos.so"))
+
+    @staticmethod
+    def available() -> bool:
+        return os.path.exists(os.path.join(_HERE, "_ref", "libsdref_aos.so"))
+
+    def vcdu(self, cadus: np.ndarray) -> np.ndarray:
+        c = np.ascontiguousarray(cadus, dtype=np.uint8)
+        out = np.zeros((len(c), 5), dtype=np.uint32)
+        self.lib.sdref_aos_vcdu(_p(c), c.shape[1], len(c), _p(out))
+        return out
+
+    def demux(self, cadus: np.ndarray, mpdu_data_size=884, has_insert_zone=False, insert_zone_size=2, sec_ext=False):
+        """-> (headers uint8 [np, 6], meta uint32 [np, 6] = {frame, payload size, apid, sequence count, packet_length, sequence_flag}, payload pool uint8)."""
+        c = np.ascontiguousarray(cadus, dtype=np.uint8)
+        cap = len(c) * 140 + 16
+        hdr = np.zeros((cap, 6), dtype=np.uint8)
+        meta = np.zeros((cap, 6), dtype=np.uint32)
+        pool = np.zeros(len(c) * c.shape[1] * 2 + 4096, dtype=np.uint8)
+        used = C.c_longlong(0)
+        self.lib.sdref_aos_demux.restype = C.c_longlong
+        self.lib.sdref_aos_demux.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_longlong, C.c_void_p, C.c_longlong,
+                                             C.POINTER(C.c_longlong)]
+        n = self.lib.sdref_aos_demux(int(mpdu_data_size), int(has_insert_zone), int(insert_zone_size), int(sec_ext), _p(c), c.shape[1], len(c), _p(hdr), _p(meta), cap, _p(pool),
+                                     len(pool), C.byref(used))
+        if n < 0:
+            raise RuntimeError(f"sdref_aos_demux -> {n}")
+        return hdr[:n].copy(), meta[:n].copy(), pool[:used.value].copy()

@@ -86,6 +86,16 @@ class Dvbs2Stats(C.Structure):
                 ("detected_pilots", C.c_int), ("pll_lanes", C.c_uint32), ("pll_rerun", C.c_uint32), ("pll_forced", C.c_uint32), ("pll_serial_frames", C.c_uint32), ("pll_branch_tries", C.c_uint32)]
 
 
+class Vcdu(C.Structure):
+    _fields_ = [("version", C.c_uint8), ("spacecraft_id", C.c_uint16), ("vcid", C.c_uint8), ("vcdu_counter", C.c_uint32), ("replay_flag", C.c_uint8)]
+
+
+class AosPacket(C.Structure):
+    _fields_ = [("header", C.c_uint8 * 6), ("version", C.c_uint8), ("type", C.c_uint8), ("secondary_header_flag", C.c_uint8), ("sequence_flag", C.c_uint8),
+                ("apid", C.c_uint16), ("packet_sequence_count", C.c_uint16), ("packet_length", C.c_uint16), ("frame", C.c_uint32), ("payload_size", C.c_uint32),
+                ("payload_offset", C.c_uint64)]
+
+
 # dvbs2_code_rate_t (common/codings/dvb-s2/dvbs2.h:9-23)
 S2_RATES = {"1/4": 0, "1/3": 1, "2/5": 2, "1/2": 3, "3/5": 4, "2/3": 5, "3/4": 6, "4/5": 7, "5/6": 8, "7/8": 9, "8/9": 10, "9/10": 11}
 
@@ -208,6 +218,15 @@ def lib():
             L.sdhip_dvbs2_demod_symbols_dev.restype = C.c_int64
             L.sdhip_dvbs2_demod_symbols_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
             L.sdhip_dvbs2_demod_get_stats.argtypes = [C.c_void_p, C.POINTER(Dvbs2Stats)]
+        if hasattr(L, "sdhip_aos_demux_create"):
+            L.sdhip_aos_parse_vcdu_dev.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+            L.sdhip_aos_select_vcid_dev.restype = C.c_int64
+            L.sdhip_aos_select_vcid_dev.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]
+            L.sdhip_aos_demux_create.restype = C.c_void_p
+            L.sdhip_aos_demux_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
+            L.sdhip_aos_demux_destroy.argtypes = [C.c_void_p]
+            L.sdhip_aos_demux_work_dev.restype = C.c_int64
+            L.sdhip_aos_demux_work_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_uint64)]
         L.sdhip_prof_enable.argtypes = [C.c_int]
         L.sdhip_pool_enable.argtypes = [C.c_int]
         L.sdhip_prof_get.argtypes = [C.c_int, C.c_char_p, C.c_size_t, C.POINTER(C.c_double), C.POINTER(C.c_longlong)]
