@@ -198,7 +198,8 @@ extern "C"
         SDHIP_NDSP_RRC_FIR = 1, /* "rrc_fir_cc" */
         SDHIP_NDSP_AGC = 2,     /* "agc_cc" */
         SDHIP_NDSP_MM = 3,      /* "clock_recovery_mm_cc" */
-        SDHIP_NDSP_COSTAS = 4   /* "costas_cc" */
+        SDHIP_NDSP_COSTAS = 4,  /* "costas_cc" */
+        SDHIP_NDSP_GARDNER = 5  /* "clock_recovery_gardner_cc" (dsp/clock_recovery/clock_recovery_gardner.cpp): rec_* keys as for the M&M block */
     };
     void *sdhip_ndsp_block_create(int kind, const sdhip_ndsp_psk_cfg *cfg);
     void sdhip_ndsp_psk_demod_destroy(void *h);
@@ -291,8 +292,8 @@ extern "C"
        2 Costas(bw,order,limit) costas_loop.cpp:23-65 | 3 MM(omega,gw,mu,gmu,lim) clock_recovery_mm.cpp:52-121 |
        4 rational resampler(interp,decim) rational_resampler.cpp:43-64 | 5 DC block correct_iq.cpp:18-35 |
        7 Gardner(omega,gw,mu,gmu,lim) clock_recovery_gardner.cpp:33-124 | 8 carrier PLL(bw,max,min) pll_carrier_tracking.cpp:8-66 |
-       9 ndsp Costas(bw,order,limit) dsp/pll/costas.cpp:12-61 (branched clip) | 10 Doppler rotator, exact (alpha, buf_len, ntargets, targets...)
-       doppler_correct.cpp:41-63 | 11 the same in the chunk-parallel mode's closed form. The other ndsp blocks compute what kinds 0, 1 and 3 do
+       9 ndsp Costas(bw,order,limit) dsp/pll/costas.cpp:12-61 (branched clip) | 10 ndsp Gardner(omega,gw,mu,gmu,lim)
+       dsp/clock_recovery/clock_recovery_gardner.cpp:60-170 (kind 7 with branched clips on floats). The other ndsp blocks compute what kinds 0, 1 and 3 do
        (dsp/agc/agc.cpp:22-39, dsp/filter/fir.cpp:62-133 minus its ntaps-sample latency, dsp/clock_recovery/clock_recovery_mm.cpp:66-183).
        Returns output sample count. */
     int64_t sdhip_op_block(int device, int kind, const float *params, const float *d_in, size_t n, float *d_out, size_t out_cap);

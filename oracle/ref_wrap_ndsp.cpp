@@ -4,6 +4,7 @@
 // terminator buffer. One generic entry point: the block is chosen by its reference id, configured through the block's own set_cfg()
 // (same keys the flowgraph uses), so nothing here restates any arithmetic.
 #include "dsp/agc/agc.h"
+#include "dsp/clock_recovery/clock_recovery_gardner.h"
 #include "dsp/clock_recovery/clock_recovery_mm.h"
 #include "dsp/filter/fir.h"
 #include "dsp/filter/rrc.h"
@@ -27,6 +28,8 @@ namespace
             return std::make_unique<CostasBlock>();
         if (id == "clock_recovery_mm_cc")
             return std::make_unique<MMClockRecoveryBlock<complex_t>>();
+        if (id == "clock_recovery_gardner_cc")
+            return std::make_unique<GardnerClockRecoveryBlock<complex_t>>();
         if (id == "psk_demod_cc")
             return std::make_unique<PSKDemodHierBlock>();
         return nullptr;

@@ -315,7 +315,7 @@ namespace sdhip_plugin
     public:
         static const char *id_of(int kind)
         {
-            static const char *ids[5] = {"psk_demod_hip_cc", "rrc_fir_hip_cc", "agc_hip_cc", "clock_recovery_mm_hip_cc", "costas_hip_cc"};
+            static const char *ids[6] = {"psk_demod_hip_cc", "rrc_fir_hip_cc", "agc_hip_cc", "clock_recovery_mm_hip_cc", "costas_hip_cc", "clock_recovery_gardner_hip_cc"};
             return ids[kind];
         }
         explicit SingleHipBlock(int kind_) : Block(id_of(kind_), {{"in", satdump::ndsp::DSP_SAMPLE_TYPE_CF32}}, {{"out", satdump::ndsp::DSP_SAMPLE_TYPE_CF32}}), kind(kind_)
@@ -329,7 +329,7 @@ namespace sdhip_plugin
                 keys = {{"gain", 0, false}, {"samplerate", 1, false}, {"symbolrate", 2, false}, {"alpha", 3, false}, {"ntaps", 4, true}};
             else if (kind == SDHIP_NDSP_AGC)
                 keys = {{"rate", 10, false}, {"reference", 11, false}, {"gain", 12, false}, {"max_gain", 13, false}};
-            else if (kind == SDHIP_NDSP_MM)
+            else if (kind == SDHIP_NDSP_MM || kind == SDHIP_NDSP_GARDNER) // (clock_recovery_gardner.h:57-130: the same keys)
                 keys = {{"omega", 20, false}, {"omegaGain", 21, false}, {"mu", 22, false}, {"muGain", 23, false}, {"omegaLimit", 24, false}, {"nfilt", 25, true}, {"ntaps", 26, true}};
             else
                 keys = {{"loop_bw", 30, false}, {"freq_limit", 31, false}};

@@ -1106,9 +1106,10 @@ namespace sdhip_plugin
             const bool over = ov && std::string(ov) == "1" && sdhip_device_count() > 0;
             if (over && evt.r.count("psk_demod_cc"))
                 evt.r.at("psk_demod_cc").func = make;
-            static const char *stock[5] = {"", "rrc_fir_cc", "agc_cc", "clock_recovery_mm_cc", "costas_cc"};
-            static const char *menu[5] = {"", "Filter/RRC CC (MI355X)", "AGC/Agc CC (MI355X)", "Clock Recovery/MM CC (MI355X)", "PLL/Costas (MI355X)"};
-            for (int k = SDHIP_NDSP_RRC_FIR; k <= SDHIP_NDSP_COSTAS; k++)
+            static const char *stock[6] = {"", "rrc_fir_cc", "agc_cc", "clock_recovery_mm_cc", "costas_cc", "clock_recovery_gardner_cc"};
+            static const char *menu[6] = {"", "Filter/RRC CC (MI355X)", "AGC/Agc CC (MI355X)", "Clock Recovery/MM CC (MI355X)", "PLL/Costas (MI355X)",
+                                          "Timing/Clock Recovery Gardner CC (MI355X)"};
+            for (int k = SDHIP_NDSP_RRC_FIR; k <= SDHIP_NDSP_GARDNER; k++)
             {
                 auto mk = [k](const Flowgraph *f) { return std::make_shared<NodeInternal>(f, std::make_shared<SingleHipBlock>(k)); };
                 evt.r.insert({SingleHipBlock::id_of(k), {menu[k], mk}});
@@ -1202,8 +1203,8 @@ extern "C" satdump::ndsp::Block *sdhip_plugin_make_ndsp_block(const char *id)
     const std::string s(id);
     if (s == "psk_demod_hip_cc" || s == "psk_demod_cc")
         return new sdhip_plugin::PSKDemodHipBlock();
-    static const char *stock[5] = {"", "rrc_fir_cc", "agc_cc", "clock_recovery_mm_cc", "costas_cc"};
-    for (int k = SDHIP_NDSP_RRC_FIR; k <= SDHIP_NDSP_COSTAS; k++)
+    static const char *stock[6] = {"", "rrc_fir_cc", "agc_cc", "clock_recovery_mm_cc", "costas_cc", "clock_recovery_gardner_cc"};
+    for (int k = SDHIP_NDSP_RRC_FIR; k <= SDHIP_NDSP_GARDNER; k++)
         if (s == stock[k] || s == sdhip_plugin::SingleHipBlock::id_of(k))
             return new sdhip_plugin::SingleHipBlock(k);
     return nullptr;

@@ -768,6 +768,14 @@ namespace sdhip
             mm_p.bank = d_mmbank.p;
             mm_p.oqpsk = is_oqpsk ? 1 : 0;
             mm_p.order = order;
+            if (nd.only == SDHIP_NDSP_GARDNER)
+            { // GardnerClockRecoveryBlock<complex_t> on the clock-recovery lanes (dsp/clock_recovery/clock_recovery_gardner.cpp:33-56)
+                mm_p.loop = 1;
+                mm_p.clip_float = 1;
+                mm_p.back = (int)std::floor(((double)mm_p.omega_mid + std::fabs((double)mm_p.omega_limit)) / 2.0) + 1;
+                if (mm_p.back > MM_BACK_MAX)
+                    throw HipError("ndsp gardner: more than 32 samples per symbol are outside the window the HIP lanes carry");
+            }
             memset(&mm_s, 0, sizeof(mm_s));
             mm_s.mu = cfg.clock_mu;
             mm_s.omega = final_sps;
@@ -1538,15 +1546,19 @@ namespace sdhip
             // a re-run costs one lane the whole chunk, so long chunks (large batches) keep the conservative warm-up: it is a
             // small fraction of L there anyway
             const int L = pick_L(n, ST_MM);
-            const double w_full = 36.0 / gmu * final_sps;
-            const double w_gear = mm_p.fast_syms > 0 ? (mm_p.fast_syms + 16.0 / gmu) * final_sps : w_full;
+            // Gardner's detector is the product of two interpolated samples: its gain goes with the signal power (0.36 behind an AGC at 0.6) where the
+            // M&M detector's goes with the amplitude, so the same loop gains give a time constant ~4 times as long (measured on the twin: QPSK at 10 dB,
+            // muGain 8.7e-3: 1.5 % of the symbols beyond 1e-5 with 22 k symbols of warm-up, 36 % with 7 k)
+            const double slow = mm_p.loop == 1 ? 4.0 : 1.0;
+            const double w_full = slow * 36.0 / gmu * final_sps;
+            const double w_gear = mm_p.fast_syms > 0 ? (mm_p.fast_syms + slow * 16.0 / gmu) * final_sps : w_full;
             // Warm-up length. The timing loop's contraction rate depends on the detector gain, i.e. on the signal (measured time
             // constants: ~360 symbols for MetOp QPSK at 10 dB, ~870 for GOES BPSK at 7 dB; tools/twin/soft_parity.py),
             // and the chunk's symbols only agree with the sequential reference's once the warm-up has brought the lane within
             // ~1e-4 sample of its trajectory. So the first guess (gear-shifted ~19/gain_mu symbols) is checked against the tight
             // hand-off window below, and if more than an eighth of the boundaries miss it the stage is launched again with twice
             // the warm-up (up to 64 loop constants 1/gain_mu); the stream keeps what it learned for its later calls.
-            const long long w_mm_cap = (long long)(64.0 / gmu * final_sps);
+            const long long w_mm_cap = (long long)(slow * 64.0 / gmu * final_sps);
             long long W = cfg.warmup > 0 ? cfg.warmup : (long long)std::min(w_full, std::max(w_gear, 0.5 * L));
             W = std::max(W, w_mm_learned);
             W = env_int("SDHIP_W_MM", W);
@@ -1980,8 +1992,9 @@ namespace sdhip
                 started = true;
                 return n;
             }
-            if (nd.only == SDHIP_NDSP_MM)
-            { // MMClockRecoveryBlock<complex_t>::work (dsp/clock_recovery/clock_recovery_mm.cpp:66-183) on its own
+            if (nd.only == SDHIP_NDSP_MM || nd.only == SDHIP_NDSP_GARDNER)
+            { // MMClockRecoveryBlock<complex_t>::work (dsp/clock_recovery/clock_recovery_mm.cpp:66-183) on its own; GardnerClockRecoveryBlock<complex_t>::work
+              // (dsp/clock_recovery/clock_recovery_gardner.cpp:60-170) on the same lanes with its own iteration (mm_p.loop)
                 SD_HIP(hipMemcpyAsync(A, d_in, (size_t)n * sizeof(cf32), hipMemcpyDeviceToDevice, stream));
                 const double omin1 = (double)mm_p.omega_mid - (double)mm_p.omega_limit;
                 const size_t symcap1 = (size_t)((double)n / std::max(0.5, omin1 - 0.01)) + 64;
@@ -2290,7 +2303,7 @@ extern "C"
     void sdhip_ndsp_psk_demod_destroy(void *h) { delete (DemodEngine *)h; }
     void *sdhip_ndsp_block_create(int kind, const sdhip_ndsp_psk_cfg *c)
     {
-        if (kind < SDHIP_NDSP_HIER || kind > SDHIP_NDSP_COSTAS)
+        if (kind < SDHIP_NDSP_HIER || kind > SDHIP_NDSP_GARDNER)
         {
             sdhip::set_error("ndsp block: unknown kind");
             return nullptr;
@@ -2498,19 +2511,42 @@ extern "C"
             SD_HIP(hipMemcpy(st.p, &s0, sizeof(s0), hipMemcpyHostToDevice));
             launch_dcblock_seq(X, Y, nn, st.p, nullptr);
         }
-        else if (kind == 7)
-        { // GardnerClockRecoveryBlock(omega, omega_gain, mu, mu_gain, omega_limit), clock_recovery_gardner.cpp:10-24
+        else if (kind == 7 || kind == 10)
+        { // GardnerClockRecoveryBlock(omega, omega_gain, mu, mu_gain, omega_limit), clock_recovery_gardner.cpp:10-24; 10: the ndsp block's arithmetic
+          // (dsp/clock_recovery/clock_recovery_gardner.cpp: branched_clip on floats). One lane of the clock-recovery kernel with the Gardner iteration.
             std::vector<float> mmb;
             design::mm_bank(128, 8, mmb);
             DevBuf<float> db;
             db.reserve(mmb.size());
             SD_HIP(hipMemcpy(db.p, mmb.data(), mmb.size() * sizeof(float), hipMemcpyHostToDevice));
-            GardnerParams p{params[1], params[3], params[0], params[4] * params[0], params[2], db.p};
-            DevBuf<long long> cnt;
-            cnt.reserve(1);
-            launch_gardner_seq(X, nn, p, Y, (long long)out_cap, cnt.p, nullptr);
-            long long c = 0;
-            SD_HIP(hipMemcpy(&c, cnt.p, sizeof(c), hipMemcpyDeviceToHost));
+            MmParams p{};
+            p.omega_gain = params[1];
+            p.mu_gain = params[3];
+            p.omega_mid = params[0];
+            p.omega_limit = params[4] * params[0];
+            p.init_mu = params[2];
+            p.bank = db.p;
+            p.arm_stride = 8;
+            p.cap = (int)out_cap;
+            p.cg = g;
+            p.rot = nullptr;
+            p.order = 4;
+            p.loop = 1;
+            p.clip_float = kind == 10 ? 1 : 0;
+            p.back = (int)std::floor(((double)p.omega_mid + std::fabs((double)p.omega_limit)) / 2.0) + 1;
+            MmState s0{};
+            s0.mu = params[2];
+            s0.omega = params[0];
+            DevBuf<MmState> st;
+            st.reserve(3);
+            DevBuf<int> cnt;
+            cnt.reserve(2);
+            SD_HIP(hipMemcpy(st.p, &s0, sizeof(s0), hipMemcpyHostToDevice));
+            DevBuf<MmCert> cc;
+            cc.reserve(2);
+            launch_mm(X, Y, cnt.p, g, p, st.p, st.p + 1, st.p + 2, cc.p, cc.p + 1, nullptr, 0, nullptr);
+            int c = 0;
+            SD_HIP(hipMemcpy(&c, cnt.p, sizeof(int), hipMemcpyDeviceToHost));
             nout = c;
         }
         else if (kind == 8)

@@ -233,7 +233,14 @@ namespace sdhip
         int fast;        // chunk-parallel mode's arithmetic: fused multiply-adds in the interpolator (exact mode: 0)
         int arm_stride;  // floats between consecutive interpolator arms in the kernel's LDS copy: 8, or 12 (48 bytes: the lanes' 16-byte reads then start on
                          // eight bank groups instead of four; SDHIP_MM_ARM_STRIDE)
+        // loop: 0 = Mueller & Muller (clock_recovery_mm.cpp), 1 = Gardner (clock_recovery_gardner.cpp: a second interpolation half a symbol back, the
+        // zero-crossing sample; MmState::p_0T holds its last symbol). Same lanes, same hand-off certificate (time of the next symbol, rate).
+        // clip_float: Gardner's two clips as dsp::branched_clip on floats (the ndsp block, dsp/clock_recovery/clock_recovery_gardner.cpp:115,131) instead of
+        // the legacy block's BRANCHLESS_CLIP in double (common/dsp/clock_recovery/clock_recovery_gardner.cpp:84,96).
+        // back: samples a lane's window reaches behind inc - 7 (Gardner: floor(omega_max / 2) + 1, at most MM_BACK_MAX; M&M: 0)
+        int loop, clip_float, back;
     };
+    constexpr int MM_BACK_MAX = 17;
     struct MmState
     {
         float mu, omega;
@@ -258,13 +265,6 @@ namespace sdhip
                    MmCert *spec_c, MmCert *end_c, const int *redo, int nredo, hipStream_t st, MmCkpt *ck = nullptr, int ck_per_chunk = 0,
                    float ck_tol = 0.0f); // ck: optional per-chunk checkpoint rows (experimental early exit of re-run lanes, see k_mm)
     constexpr int MM_CK_SAMPLES = 1024;   // input samples between the checkpoints of a clock-recovery lane
-    // ---- Gardner clock recovery (clock_recovery_gardner.cpp:33-124), sequential lane; x must have >= 32 samples of history in front
-    struct GardnerParams
-    {
-        float omega_gain, mu_gain, omega_mid, omega_limit, init_mu;
-        const float *bank; // [128][8] device, same interpolator bank as the M&M loop
-    };
-    void launch_gardner_seq(const cf32 *x, long long n, const GardnerParams &p, cf32 *out, long long out_cap, long long *count, hipStream_t st);
     // compaction + quantiser (module_psk_demod.cpp:199-213): seg = 2 ints per chunk {first, count}: chunk k's symbols
     // [first, first+count) of its scratch row go to offsets[k]
     void launch_quantize(const cf32 *sym_scratch, const int *seg, const long long *offsets, int K, int cap, int bpsk, int8_t *soft, long long soft_cap,

@@ -1989,11 +1989,11 @@ namespace sdhip
         }
         f.next = i + 8;
     }
-    // start the window so that samples [inc-7, inc] can be served
+    // start the window so that samples [inc-7-back, inc] can be served
     __device__ __forceinline__ void mm_feed_init(MmFeed &f, const MmParams &p, const cf32 *x, cf32 *ring, long long inc)
     {
         f.ring = ring;
-        long long first = inc - 7;
+        long long first = inc - 7 - p.back; // Gardner: the zero-crossing window lies up to p.back samples behind the symbol's
         first = (first >= 0 ? first : first - 7) / 8 * 8; // floor to a multiple of 8 (also for negative indices)
         f.next = first;
         f.ck = 0;
@@ -2076,6 +2076,87 @@ namespace sdhip
         return out;
     }
 
+    // one iteration of GardnerClockRecoveryBlock<complex_t>::work's loop body (legacy: common/dsp/clock_recovery/clock_recovery_gardner.cpp:49-106;
+    // ndsp: dsp/clock_recovery/clock_recovery_gardner.cpp:88-138 -- the same statements, its two clips on floats): two interpolations per symbol -- the
+    // symbol itself over [inc-7, inc] and the zero crossing half a symbol back over [inc-offzc-7, inc-offzc] -- the float / double promotions where C++
+    // puts them. The window [inc-7-p.back, inc] must be in the ring; the last symbol rides in s.p_0T.
+    template <bool FAST = false>
+    __device__ __forceinline__ cf32 gardner_iter(MmState &s, const MmParams &p, const cf32 *ring, const float *bank, const float omega_gain, const float mu_gain)
+    {
+        const float muz = (float)((double)s.mu - ((double)s.omega / 2.0));
+        int offzc = (int)floor((double)s.omega / 2.0);
+        float mupos = (float)fmod((double)(muz + (float)offzc), 1.0);
+        if (mupos < 0)
+        {
+            mupos = 1 + mupos;
+            offzc += 1;
+        }
+        int imuz = (int)rint((double)(mupos * 128.0f));
+        imuz = imuz < 0 ? 0 : (imuz >= 128 ? 127 : imuz);
+        int imu = (int)rint((double)(s.mu * 128.0f));
+        imu = imu < 0 ? 0 : (imu >= 128 ? 127 : imu);
+        if (offzc > p.back) // cannot happen inside the omega limits the engine admits; keeps a wild state inside the ring
+            offzc = p.back;
+        const float4 z0 = *reinterpret_cast<const float4 *>(bank + imuz * p.arm_stride), z1 = *reinterpret_cast<const float4 *>(bank + imuz * p.arm_stride + 4);
+        const float4 t0 = *reinterpret_cast<const float4 *>(bank + imu * p.arm_stride), t1 = *reinterpret_cast<const float4 *>(bank + imu * p.arm_stride + 4);
+        const float tz[8] = {z0.x, z0.y, z0.z, z0.w, z1.x, z1.y, z1.z, z1.w};
+        const float t[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
+        const int base = (int)((s.inc - 7) & (MM_RING - 1)), basez = (int)((s.inc - offzc - 7) & (MM_RING - 1));
+        v2f az{0.0f, 0.0f}, as{0.0f, 0.0f};
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+        {
+            const cf32 v = ring[((basez + k) & (MM_RING - 1)) * MM_RING_STRIDE];
+            if constexpr (FAST)
+                az = __builtin_elementwise_fma(v2f{v.re, v.im}, v2f{tz[k], tz[k]}, az);
+            else
+            {
+                const v2f prod = v2f{v.re, v.im} * v2f{tz[k], tz[k]};
+                az = az + prod;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+        {
+            const cf32 v = ring[((base + k) & (MM_RING - 1)) * MM_RING_STRIDE];
+            if constexpr (FAST)
+                as = __builtin_elementwise_fma(v2f{v.re, v.im}, v2f{t[k], t[k]}, as);
+            else
+            {
+                const v2f prod = v2f{v.re, v.im} * v2f{t[k], t[k]};
+                as = as + prod;
+            }
+        }
+        const float zr = az.x, zi = az.y, sr = as.x, si = as.y;
+        float pe = zr * (s.p_0T.re - sr) + zi * (s.p_0T.im - si);
+        if (p.clip_float)
+            pe = pe < -1.0f ? -1.0f : (pe > 1.0f ? 1.0f : pe);
+        else
+            pe = (float)(0.5 * (fabs((double)pe + 1.0) - fabs((double)pe - 1.0)));
+        s.p_0T = cf32{sr, si};
+        s.omega = s.omega + omega_gain * pe;
+        const float d = s.omega - p.omega_mid;
+        if (p.clip_float)
+            s.omega = p.omega_mid + (d < -p.omega_limit ? -p.omega_limit : (d > p.omega_limit ? p.omega_limit : d));
+        else
+            s.omega = (float)((double)p.omega_mid + 0.5 * (double)(fabsf(d + p.omega_limit) - fabsf(d - p.omega_limit)));
+        s.mu = s.mu + s.omega + mu_gain * pe;
+        const float fl = floorf(s.mu);
+        s.inc += (long long)(int)fl;
+        s.mu = s.mu - fl;
+        if (s.inc < 0)
+            s.inc = 0;
+        return s.p_0T;
+    }
+    template <bool GARD, bool FAST>
+    __device__ __forceinline__ cf32 clock_iter(MmState &s, const MmParams &p, const cf32 *ring, const float *bank, const float omega_gain, const float mu_gain)
+    {
+        if constexpr (GARD)
+            return gardner_iter<FAST>(s, p, ring, bank, omega_gain, mu_gain);
+        else
+            return mm_iter<FAST>(s, p, ring, bank, omega_gain, mu_gain);
+    }
+
     // CKPT: whenever the block ending at a multiple of MM_CK_SAMPLES samples into its chunk has been fed, a lane leaves a
     // checkpoint {mu, omega, inc, symbols so far}. A re-run lane (exact start state) compares itself with the checkpoint at the
     // same position and stops as soon as it has produced the same number of symbols and is inside the boundary tolerance in
@@ -2095,7 +2176,7 @@ namespace sdhip
             return 127;
         return (signed char)(int)x;
     }
-template <bool CKPT, bool SPLIT, bool Q8 = false, bool FAST = false>
+template <bool CKPT, bool SPLIT, bool Q8 = false, bool FAST = false, bool GARD = false>
     __global__ __launch_bounds__(64) void k_mm(const cf32 *x, cf32 *sym, int *counts, ChunkGeom g, MmParams p, const MmState *start0, MmState *spec,
                                                MmState *endst, MmCert *spec_c, MmCert *end_c, const int *redo, int nredo, MmCkpt *ck, int ck_per_chunk,
                                                float ck_tol)
@@ -2287,7 +2368,7 @@ template <bool CKPT, bool SPLIT, bool Q8 = false, bool FAST = false>
                         // trajectory settles onto the sequential one; only speculation -- the boundary certificate decides
                         const bool fast = phase == 0 && wsym < p.fast_syms;
                         wsym++;
-                        const cf32 v = mm_iter<FAST>(s, p, f.ring, bank, fast ? 0.0f : p.omega_gain, fast ? p.mu_gain * p.fast_mult : p.mu_gain);
+                        const cf32 v = clock_iter<GARD, FAST>(s, p, f.ring, bank, fast ? 0.0f : p.omega_gain, fast ? p.mu_gain * p.fast_mult : p.mu_gain);
                         if (phase != 0)
                         {
                             if (cnt + nx < p.cap)
@@ -2319,6 +2400,24 @@ template <bool CKPT, bool SPLIT, bool Q8 = false, bool FAST = false>
             _pr.emplace("k_mm (re-run launches, included in k_mm)", st);
         const char *split_env = getenv("SDHIP_MM_SPLIT");
         const bool split = split_env && split_env[0] == '1';
+        if (p.loop == 1)
+        { // the Gardner loop on the same lanes (float symbols only)
+            if (p.back < 1 || p.back > MM_BACK_MAX || p.q8)
+                throw HipError("Gardner lanes: omega out of the window the lanes carry");
+            if (ck && p.fast)
+                hipLaunchKernelGGL((k_mm<true, false, false, true, true>), dim3((n + 63) / 64), dim3(64), 0, st, x, sym_scratch, counts, g, p, start0, spec, endst, spec_c,
+                                   end_c, redo, nredo, ck, ck_per_chunk, ck_tol);
+            else if (ck)
+                hipLaunchKernelGGL((k_mm<true, false, false, false, true>), dim3((n + 63) / 64), dim3(64), 0, st, x, sym_scratch, counts, g, p, start0, spec, endst, spec_c,
+                                   end_c, redo, nredo, ck, ck_per_chunk, ck_tol);
+            else if (p.fast)
+                hipLaunchKernelGGL((k_mm<false, false, false, true, true>), dim3((n + 63) / 64), dim3(64), 0, st, x, sym_scratch, counts, g, p, start0, spec, endst, spec_c,
+                                   end_c, redo, nredo, (MmCkpt *)nullptr, 0, 0.0f);
+            else
+                hipLaunchKernelGGL((k_mm<false, false, false, false, true>), dim3((n + 63) / 64), dim3(64), 0, st, x, sym_scratch, counts, g, p, start0, spec, endst, spec_c,
+                                   end_c, redo, nredo, (MmCkpt *)nullptr, 0, 0.0f);
+            return;
+        }
         if (ck && p.q8 && p.fast)
             hipLaunchKernelGGL((k_mm<true, false, true, true>), dim3((n + 63) / 64), dim3(64), 0, st, x, sym_scratch, counts, g, p, start0, spec, endst, spec_c, end_c,
                                redo, nredo, ck, ck_per_chunk, ck_tol);
@@ -2342,66 +2441,6 @@ template <bool CKPT, bool SPLIT, bool Q8 = false, bool FAST = false>
                                nredo, (MmCkpt *)nullptr, 0, 0.0f);
     }
 
-    // =============================================================================================
-    // Gardner clock recovery (clock_recovery_gardner.cpp:33-124): sibling of the M&M loop, used by xfsk_burst_demod, not by
-    // psk_demod. One sequential lane, the reference's float/double operations in the reference's order (the two
-    // BRANCHLESS_CLIPs and the zero-crossing phase are evaluated in double exactly where C++'s promotions put them).
-    // =============================================================================================
-    __global__ void k_gardner_seq(const cf32 *x, long long n, GardnerParams p, cf32 *out, long long out_cap, long long *count)
-    {
-        if (threadIdx.x != 0 || blockIdx.x != 0)
-            return;
-        float mu = p.init_mu, omega = p.omega_mid;
-        cf32 last{0.0f, 0.0f};
-        long long inc = 0, ouc = 0;
-        while (inc < n && ouc < out_cap)
-        {
-            const float muz = (float)((double)mu - ((double)omega / 2.0));
-            int offzc = (int)floor((double)omega / 2.0);
-            float mupos = (float)fmod((double)(muz + (float)offzc), 1.0);
-            if (mupos < 0)
-            {
-                mupos = 1 + mupos;
-                offzc += 1;
-            }
-            int imuz = (int)rint((double)(mupos * 128.0f));
-            imuz = imuz < 0 ? 0 : (imuz >= 128 ? 127 : imuz);
-            int imu = (int)rint((double)(mu * 128.0f));
-            imu = imu < 0 ? 0 : (imu >= 128 ? 127 : imu);
-            const float *tz = p.bank + imuz * 8, *t = p.bank + imu * 8;
-            const cf32 *bz = x + inc - offzc - 7, *b = x + inc - 7;
-            float zr = 0.0f, zi = 0.0f, sr = 0.0f, si = 0.0f;
-            for (int k = 0; k < 8; k++)
-            {
-                zr = zr + bz[k].re * tz[k];
-                zi = zi + bz[k].im * tz[k];
-            }
-            for (int k = 0; k < 8; k++)
-            {
-                sr = sr + b[k].re * t[k];
-                si = si + b[k].im * t[k];
-            }
-            float pe = zr * (last.re - sr) + zi * (last.im - si);
-            pe = (float)(0.5 * (fabs((double)pe + 1.0) - fabs((double)pe - 1.0)));
-            last = cf32{sr, si};
-            out[ouc++] = last;
-            omega = omega + p.omega_gain * pe;
-            const float d = omega - p.omega_mid;
-            omega = (float)((double)p.omega_mid + 0.5 * (double)(fabsf(d + p.omega_limit) - fabsf(d - p.omega_limit)));
-            mu = mu + omega + p.mu_gain * pe;
-            const float fl = floorf(mu);
-            inc += (long long)(int)fl;
-            mu = mu - fl;
-            if (inc < 0)
-                inc = 0;
-        }
-        *count = ouc;
-    }
-    void launch_gardner_seq(const cf32 *x, long long n, const GardnerParams &p, cf32 *out, long long out_cap, long long *count, hipStream_t st)
-    {
-        ProfScope _ps("k_gardner_seq", st);
-        hipLaunchKernelGGL(k_gardner_seq, dim3(1), dim3(64), 0, st, x, n, p, out, out_cap, count);
-    }
 
     __global__ __launch_bounds__(256) void k_quantize(const cf32 *sym, const int *seg, const long long *offsets, int K, int cap, int bpsk, int8_t *soft,
                                                       long long soft_cap, float *syms, long long syms_cap)

@@ -121,7 +121,7 @@ class PSKDemodHierBlock:
 
 
 # ---- the chain's member blocks as flowgraph nodes of their own (include/sdhip.h, sdhip_ndsp_block_create)
-NDSP_HIER, NDSP_RRC_FIR, NDSP_AGC, NDSP_MM, NDSP_COSTAS = 0, 1, 2, 3, 4
+NDSP_HIER, NDSP_RRC_FIR, NDSP_AGC, NDSP_MM, NDSP_COSTAS, NDSP_GARDNER = 0, 1, 2, 3, 4, 5
 _SINGLE = {
     # block id -> (kind, {block key: cfg field})   (the keys of dsp/agc/agc.h:38-78, dsp/filter/rrc.h:34-66, dsp/clock_recovery/clock_recovery_mm.h:70-130, dsp/pll/costas.h:55-90)
     "agc_cc": (NDSP_AGC, {"rate": "agc_rate", "reference": "agc_reference", "gain": "agc_gain", "max_gain": "agc_max_gain"}),
@@ -129,12 +129,15 @@ _SINGLE = {
     "clock_recovery_mm_cc": (NDSP_MM, {"omega": "rec_omega", "omegaGain": "rec_omegaGain", "mu": "rec_mu", "muGain": "rec_muGain", "omegaLimit": "rec_omegaLimit",
                                        "nfilt": "rec_nfilt", "ntaps": "rec_ntaps"}),
     "costas_cc": (NDSP_COSTAS, {"loop_bw": "pll_loop_bw", "freq_limit": "pll_freq_limit"}),
+    # dsp/clock_recovery/clock_recovery_gardner.h:15-21, 57-130: the M&M block's keys (its own default omega is 0: set it)
+    "clock_recovery_gardner_cc": (NDSP_GARDNER, {"omega": "rec_omega", "omegaGain": "rec_omegaGain", "mu": "rec_mu", "muGain": "rec_muGain", "omegaLimit": "rec_omegaLimit",
+                                                 "nfilt": "rec_nfilt", "ntaps": "rec_ntaps"}),
 }
 _ORDER = {2: capi.BPSK, 4: capi.QPSK, 8: capi.PSK8}
 
 
 class SingleBlock:
-    """agc_cc / rrc_fir_cc / clock_recovery_mm_cc / costas_cc: one member block of the chain with the reference block's own keys and defaults
+    """agc_cc / rrc_fir_cc / clock_recovery_mm_cc / costas_cc / clock_recovery_gardner_cc: one member block of the chain with the reference block's own keys and defaults
     (AGCBlock: reference 1.0 -- the hier block is what sets 0.6 --, MMClockRecoveryBlock: omega 2, CostasBlock: order 2), state carried across work() calls."""
 
     def __init__(self, block_id: str, device: int = 0, exact: bool = False, capi_mod=None):

@@ -411,7 +411,7 @@ def test_hip_devices_through_the_plugin(host, tmp_path, case):
 
 def check_ndsp_single_blocks_through_the_plugin(host, lib, tmp_path):
     """plugin/sdhip_ndsp_block.h -- SingleHipBlock, the chain's member blocks as satdump::ndsp::Block's of their own (agc_cc, rrc_fir_cc,
-    clock_recovery_mm_cc, costas_cc: what the flowgraph registry offers next to the hier block) -- instantiated from the plugin under the stock ids,
+    clock_recovery_mm_cc, costas_cc, clock_recovery_gardner_cc: what the flowgraph registry offers next to the hier block) -- instantiated from the plugin under the stock ids,
     configured through set_cfg() with the reference blocks' own keys, linked between two DSPStream FIFOs and run by Block::start(): with "exact" the file
     each writes is the reference block's output bit for bit (the reference block on its own thread and FIFOs, oracle/ref_wrap_ndsp.cpp)."""
     from tests.test_ndsp_gpu import _signal
@@ -422,6 +422,7 @@ def check_ndsp_single_blocks_through_the_plugin(host, lib, tmp_path):
              ("costas_cc", {"order": 4, "loop_bw": 0.01}, x[::3].copy())]
     xm = nd.run("agc_cc", {"rate": 1e-3, "reference": 0.6}, nd.run("rrc_fir_cc", {"samplerate": 6e6, "symbolrate": 2e6, "alpha": 0.35}, x))
     cases.append(("clock_recovery_mm_cc", {"omega": 3.0, "muGain": 0.01}, xm))
+    cases.append(("clock_recovery_gardner_cc", {"omega": 3.0, "muGain": 0.01}, xm))
     for bid, cfg, xin in cases:
         inp = tmp_path / (bid + ".cf32")
         np.ascontiguousarray(xin).tofile(str(inp))
