@@ -443,10 +443,15 @@ namespace sdhip
     //   T1 = R1 + (M, M')       = (m0, m3')      T2 = R2 + (63-M, 63-M')   = (m1, m2')    E = min(T1,T2) = (Y[2i],   Y[63-2i])
     //   T3 = R1 + (63-M, 63-M') = (m2, m1')      T4 = R2 + (M, M')         = (m3, m0')    O = min(T3,T4) = (Y[2i+1], Y[62-2i])
     // (M, M' = branch metrics of butterflies i and 31-i; their branch-table bits are complements of each other.)
-    // Values are kept DOUBLED in the 16-bit fields (mask 0x1FE = the reference's uint8 wrap, volk_k7_r2_generic_fixed.h:118-121),
-    // which frees bit 0 as a tie-break tag: decision = (a >= b) is sign(b - a - tag) with the tag on the correct side, so
-    // one v_pk_sub_i16 yields both decisions of a packed pair (low half inverted). The per-step renormalisation
-    // (subtract the minimum, :80-92) is folded into the next step's branch-metric constants.
+    // Values live in the HIGH BYTE of the 16-bit fields: a packed 16-bit add then wraps exactly like the reference's unsigned char arithmetic
+    // (volk_k7_r2_generic_fixed.h:118-121) with no masking, and the low byte is free for a TAG that does two jobs at once. Every register carries
+    // tag 1 in its low half (0 in its high half; swapped for R2), branch constants carry none, so of the two candidates of a compare-select exactly one
+    // has low byte 1: (a) on a tie of the values the untagged candidate wins the 16-bit minimum -- placed so that it is the one the reference's
+    // `decision = (m0 - m1) >= 0` picks (:123-127) --, and (b) the low byte of the minimum says which candidate won: the (inverted) decision bit
+    // comes out of the select itself, no subtraction. One v_and_or puts the tag back on a new metric; v_perm gathers the four low bytes of (E, O) and
+    // v_lshl_or shifts them into the decision words. The per-step renormalisation (subtract the minimum, :80-92) is folded into the next step's
+    // branch constants. ~12 instructions per butterfly pair (4 add, 2 min, 2 and_or, 2 running min, perm, shift-or); the doubled-value form with
+    // masks and sign extraction this replaces took 17.
     typedef unsigned short v2u16 __attribute__((ext_vector_type(2)));
     __device__ __forceinline__ v2u16 v2v(unsigned x) { return __builtin_bit_cast(v2u16, x); }
     __device__ __forceinline__ unsigned v2u(v2u16 x) { return __builtin_bit_cast(unsigned, x); }
@@ -458,45 +463,37 @@ namespace sdhip
         const v2u16 v = v2v(a);
         return v2u(__builtin_shufflevector(v, v, 1, 0));
     }
-    constexpr unsigned V2_MASK = 0x01FE01FEu; // (the tie-break tag 0x00010000 lives in V2Consts::tag)
-    // Constants that feed three-operand ops ((x & m) | y = one v_and_or_b32 / v_bitop3_b32) must live in registers: VOP3
-    // encodings take no literals on gfx9. The asm keeps the compiler from folding them back into literals.
+    constexpr unsigned V2_MASK = 0xFF00FF00u; // the metric bytes
+    constexpr unsigned V2_TAG = 0x00000001u;  // low half tagged, high half not
+    // Constants that feed three-operand ops ((x & m) | y = one v_and_or_b32) must live in registers: VOP3 encodings take no literals on
+    // gfx9 and one scalar operand at most. The asm keeps the compiler from folding them back into literals.
     struct V2Consts
     {
-        unsigned tag;     // VGPR
-        unsigned mask;    // SGPR
-        unsigned dm[8];   // SGPR: 0x80808080 >> k
+        unsigned tag;  // VGPR
+        unsigned mask; // SGPR
     };
     __device__ __forceinline__ void v2_consts(V2Consts &k)
     {
-        asm volatile("v_mov_b32 %0, 0x10000" : "=v"(k.tag));
-        asm volatile("s_mov_b32 %0, 0x1fe01fe" : "=s"(k.mask));
-        asm volatile("s_mov_b32 %0, 0x80808080" : "=s"(k.dm[0]));
-        asm volatile("s_mov_b32 %0, 0x40404040" : "=s"(k.dm[1]));
-        asm volatile("s_mov_b32 %0, 0x20202020" : "=s"(k.dm[2]));
-        asm volatile("s_mov_b32 %0, 0x10101010" : "=s"(k.dm[3]));
-        asm volatile("s_mov_b32 %0, 0x08080808" : "=s"(k.dm[4]));
-        asm volatile("s_mov_b32 %0, 0x04040404" : "=s"(k.dm[5]));
-        asm volatile("s_mov_b32 %0, 0x02020202" : "=s"(k.dm[6]));
-        asm volatile("s_mov_b32 %0, 0x01010101" : "=s"(k.dm[7]));
+        asm volatile("v_mov_b32 %0, 0x1" : "=v"(k.tag));
+        asm volatile("s_mov_b32 %0, 0xff00ff00" : "=s"(k.mask));
     }
 
     struct V2State
     {
-        unsigned R[32]; // (2*Y[r] | tag, 2*Y[63-r] | tag), not yet renormalised
-        unsigned C2;    // 2*min(Y) in both halves: true metric = ((half - C) & 0x1FE) >> 1
+        unsigned R[32]; // (Y[r] << 8 | 1, Y[63-r] << 8), not yet renormalised
+        unsigned C2;    // min(Y) << 8 in both halves: true metric = (half - C) >> 8 (mod 256)
     };
     __device__ __forceinline__ void v2_init_neutral(V2State &s)
     {
 #pragma unroll
         for (int r = 0; r < 32; r++)
-            s.R[r] = 0u;
+            s.R[r] = V2_TAG;
         s.C2 = 0u;
     }
     // init_viterbi / init_viterbi_unbiased, cc_decoder.cpp:159-190
     __device__ __forceinline__ void v2_init_start(V2State &s, int start)
     {
-        const unsigned all = (start == -2) ? 62u : 126u;
+        const unsigned all = ((start == -2) ? 31u : 63u) << 8;
 #pragma unroll
         for (int r = 0; r < 32; r++)
         {
@@ -505,17 +502,17 @@ namespace sdhip
                 lo = 0u;
             if (start == 63 - r)
                 hi = 0u;
-            s.R[r] = lo | (hi << 16);
+            s.R[r] = lo | (hi << 16) | V2_TAG;
         }
         s.C2 = 0u;
     }
-    // normalised packed metrics (for the certificate and the end state)
+    // normalised packed metrics (for the certificate and the end state): the values in the high bytes, low bytes clear
     __device__ __forceinline__ unsigned v2_norm(const V2State &s, int r) { return pk_sub(s.R[r], s.C2) & V2_MASK; }
 
     // find_endstate (cc_decoder.cpp:192-209): first state index holding the minimum metric
     __device__ __forceinline__ unsigned v2_endstate(const V2State &s)
     {
-        unsigned best = 0xFFFFu, idx = 0;
+        unsigned best = 0xFFFFFu, idx = 0;
 #pragma unroll
         for (int st = 0; st < 64; st++)
         {
@@ -547,12 +544,12 @@ namespace sdhip
     {
         const unsigned s0 = sym & 255u, s1 = (sym >> 8) & 255u;
         const unsigned a[2] = {s0, s0 ^ 255u}, c[2] = {s1, s1 ^ 255u};
-        // BFLY metric (volk_k7_r2_generic_fixed.h:110-113), doubled: class = b0*2 + b1 (Branchtab bits of the butterfly)
+        // BFLY metric (volk_k7_r2_generic_fixed.h:110-113) in the high byte: class = b0*2 + b1 (Branchtab bits of the butterfly)
         unsigned D[4];
 #pragma unroll
         for (int k = 0; k < 4; k++)
-            D[k] = ((a[k >> 1] + c[k & 1] + 1u) >> 2) & 0x7Eu;
-        const unsigned Q = pk_sub(0x007E007Eu, s.C2);
+            D[k] = ((a[k >> 1] + c[k & 1] + 1u) << 5) & 0x3F00u; // ((sum + 1) >> 3) << 8
+        const unsigned Q = pk_sub(0x3F003F00u, s.C2);
         unsigned K1[4], K2[4];
 #pragma unroll
         for (int k = 0; k < 4; k++)
@@ -570,37 +567,38 @@ namespace sdhip
             // Branchtab (cc_decoder.cpp:116-123, polys 79 / 109): b0 = parity(2i & 79) = i0^i1^i2, b1 = parity(2i & 109) = i1^i2^i4
             const int b0 = (i ^ (i >> 1) ^ (i >> 2)) & 1, b1 = ((i >> 1) ^ (i >> 2) ^ (i >> 4)) & 1;
             const int k = b0 * 2 + b1;
+            // tags: R1 = (.. | 1, .. | 0), R2 = (.. | 0, .. | 1). Low half: a tie goes to R2's candidate (m1 / m3: decision 1), high half (the mirror
+            // butterfly, candidates in the other order) to R1's: each time the reference's choice. Low byte of the minimum = 1 <=> decision 0.
             const unsigned R1 = s.R[i], R2 = pk_swap(s.R[31 - i]);
-            const unsigned T1 = pk_add(R1, K1[k]) & V2_MASK;
-            const unsigned T2 = (pk_add(R2, K2[k]) & kc.mask) | kc.tag;
-            const unsigned T3 = pk_add(R1, K2[k]) & V2_MASK;
-            const unsigned T4 = (pk_add(R2, K1[k]) & kc.mask) | kc.tag;
+            const unsigned T1 = pk_add(R1, K1[k]);
+            const unsigned T2 = pk_add(R2, K2[k]);
+            const unsigned T3 = pk_add(R1, K2[k]);
+            const unsigned T4 = pk_add(R2, K1[k]);
             const unsigned E = pk_min(T1, T2), O = pk_min(T3, T4);
-            Rn[2 * i] = E;
-            Rn[2 * i + 1] = O;
+            Rn[2 * i] = (E & kc.mask) | kc.tag;
+            Rn[2 * i + 1] = (O & kc.mask) | kc.tag;
             mnA = pk_min(mnA, E);
             mnB = pk_min(mnB, O);
             if (DEC)
             {
-                const unsigned dE = pk_sub(T1, T2), dO = pk_sub(T3, T4);
-                // bytes: [dE.lo sign, dE.hi sign, dO.lo sign, dO.hi sign] in bit 7 of each byte
-                const unsigned p = __builtin_amdgcn_perm(dO, dE, 0x07050301u);
+                // bytes: [E.lo, E.hi, O.lo, O.hi] low bytes, each 0 or 1 (= the inverted decision)
+                const unsigned p = __builtin_amdgcn_perm(O, E, 0x06040200u);
                 if (i < 8)
-                    acc0 = ((p >> (i & 7)) & kc.dm[i & 7]) | acc0;
+                    acc0 = (acc0 << 1) | p;
                 else
-                    acc1 = ((p >> (i & 7)) & kc.dm[i & 7]) | acc1;
+                    acc1 = (acc1 << 1) | p;
             }
         }
 #pragma unroll
         for (int r = 0; r < 32; r++)
             s.R[r] = Rn[r];
         const unsigned mn = pk_min(mnA, mnB);
-        const unsigned m1 = min(mn & 0xFFFFu, mn >> 16) & 0xFFFEu;
+        const unsigned m1 = min(mn & 0xFFFFu, mn >> 16) & 0xFF00u;
         s.C2 = m1 | (m1 << 16);
         if (DEC)
         {
-            w0 = acc0 ^ 0x00FF00FFu; // low-half signs are inverted decisions
-            w1 = acc1 ^ 0x00FF00FFu;
+            w0 = ~acc0;
+            w1 = ~acc1;
         }
     }
 
