@@ -543,6 +543,37 @@ extern "C"
     int64_t sdhip_aos_demux_work_dev(void *h, const uint8_t *d_cadus, int cadu_bytes, int nframes, sdhip_aos_packet *packets_out, size_t cap_packets, uint8_t *d_payload,
                                      size_t cap_payload, uint64_t *payload_bytes_out);
 
+    /* ---- "meteor_lrpt_decoder" (the Viterbi27-based plugin decoders; lrpt_decoder.hip) ------------------------------------------
+       METEORLRPTDecoderModule::process(), the classic branch (plugins/meteor_support/meteor/module_meteor_lrpt_decoder.cpp:201-262): soft symbols ->
+       frame correlator on the encoded sync word (src-core/common/codings/correlator.cpp:68-176) -> rotate_soft -> viterbi::Viterbi27 -> NRZ-M if
+       "diff_decode" -> derand_ccsds -> RS(255,223) x 4 (conventional basis) -> the CADUs whose four codewords decoded. "m2x_mode" (Viterbi1_2 +
+       deframer, optionally deinterleaved) is not this entry's: such runs stay on the CPU module. */
+    typedef struct sdhip_lrpt_cfg
+    {
+        int diff_decode; /* "diff_decode" (mandatory key of the module) */
+        int device;
+    } sdhip_lrpt_cfg;
+    typedef struct sdhip_lrpt_stats
+    {
+        uint64_t soft_in;     /* soft bytes consumed */
+        uint64_t frames_seen; /* frames the correlator placed */
+        uint64_t frames_out;  /* CADUs written */
+        float viterbi_ber;    /* "viterbi_ber": Viterbi27::ber() of the last frame */
+        int correlator_lock;  /* "correlator_lock": the last frame sat at offset 0 */
+        int cor;              /* the last frame's correlation (of 64) */
+        int rs_errors[4];     /* the last frame's per-codeword error counts (-1 = uncorrectable); "rs_avg" = their mean */
+    } sdhip_lrpt_stats;
+    void sdhip_lrpt_cfg_default(sdhip_lrpt_cfg *cfg);
+    void *sdhip_lrpt_create(const sdhip_lrpt_cfg *cfg);
+    void sdhip_lrpt_destroy(void *h);
+    /* Host-buffer path: append n soft bytes (.soft wire format); every complete frame is decoded, an incomplete one stays pending. */
+    int sdhip_lrpt_push(void *h, const int8_t *soft, size_t n);
+    /* Pop up to cap_frames CADUs (1024 bytes each). Returns the count. */
+    int64_t sdhip_lrpt_pull(void *h, uint8_t *cadu, size_t cap_frames);
+    /* Device-resident path: n more soft bytes in HBM -> CADUs in d_cadu (device). Returns the frames written, < 0 on error. */
+    int64_t sdhip_lrpt_process_dev(void *h, const int8_t *d_soft, size_t n, uint8_t *d_cadu, size_t cap_frames);
+    int sdhip_lrpt_get_stats(void *h, sdhip_lrpt_stats *st);
+
     /* ---- misc ------------------------------------------------------------------------ */
     const char *sdhip_last_error(void);
     const char *sdhip_version(void);

@@ -266,6 +266,19 @@ class Ref(_Lib):
             res["vit_bits"] = vb[:nvb.value]
         return res
 
+    def lrpt_decode(self, soft: np.ndarray, diff_decode=False):
+        """METEORLRPTDecoderModule::process(), classic branch, on the reference's own classes (ref_wrap.cpp: sdref_lrpt_decode). Compiled reference only."""
+        if not hasattr(self.lib, "sdref_lrpt_decode"):
+            raise RuntimeError("sdref_lrpt_decode needs oracle/_ref/libsdref.so")
+        s = np.ascontiguousarray(soft, dtype=np.int8)
+        cap = len(s) // 16384 + 8
+        out = np.zeros((cap, 1024), dtype=np.uint8)
+        locks = np.zeros(cap, dtype=np.int32)
+        it = C.c_int64(0)
+        self.lib.sdref_lrpt_decode.restype = C.c_int64
+        n = self.lib.sdref_lrpt_decode(C.c_int(int(bool(diff_decode))), _p(s), C.c_int64(len(s)), _p(out), C.c_int64(cap), _p(locks), C.c_int64(cap), C.byref(it))
+        return {"cadu": out[:n], "locks": locks[: it.value], "iterations": it.value}
+
     # ---- dsp
     def rrc_taps(self, fs, symrate, alpha, ntaps=31) -> np.ndarray:
         out = np.zeros(ntaps | 1, dtype=np.float32)

@@ -37,6 +37,9 @@ std::shared_ptr<slog::Logger> logger = std::make_shared<slog::Logger>();
 #include "common/codings/viterbi/viterbi_3_4.h"
 #include "common/codings/viterbi/viterbi_punc.h"
 #include "common/codings/rotation.h"
+#include "common/codings/correlator.h"
+#include "common/codings/viterbi/viterbi27.h"
+#include "common/codings/differential/nrzm.h"
 #include "common/codings/randomization.h"
 #include "common/codings/differential/nrzm.h"
 #include "common/codings/deframing/bpsk_ccsds_deframer.h"
@@ -502,6 +505,73 @@ extern "C"
         zero_delete(qpsk_diff);
         if (rs)
             zero_delete(rs);
+        return nout;
+    }
+
+    // In-memory restatement of METEORLRPTDecoderModule::process(), the classic (non m2x_mode) branch
+    // (plugins/meteor_support/meteor/module_meteor_lrpt_decoder.cpp:201-262), on the reference's own Correlator / Viterbi27 / NRZMDiff /
+    // ReedSolomon. The input behaves like the module's file: read_data copies what is left (a short read keeps the buffer's old tail),
+    // should_run() turns false once a read has hit the end. locks_out (may be NULL): `pos == 0` per iteration.
+    int64_t sdref_lrpt_decode(int diff_decode, const int8_t *soft, int64_t n, uint8_t *cadu_out, int64_t cadu_cap_frames, int *locks_out, int64_t locks_cap,
+                              int64_t *iterations_out)
+    {
+        const int FRAME_SIZE = 1024, ENCODED_FRAME_SIZE = 1024 * 8 * 2;
+        std::vector<int8_t> store(ENCODED_FRAME_SIZE + 64, 0);
+        int8_t *buffer = store.data() + 64;
+        viterbi::Viterbi27 *viterbi = zero_new<viterbi::Viterbi27>(ENCODED_FRAME_SIZE / 2, viterbi::CCSDS_R2_K7_POLYS);
+        int64_t rd = 0;
+        bool eof = false;
+        auto read_data = [&](uint8_t *dst, size_t len) {
+            const size_t have = (size_t)std::min<int64_t>((int64_t)len, n - rd);
+            memcpy(dst, soft + rd, have);
+            rd += (int64_t)have;
+            if (have < len)
+                eof = true;
+        };
+        Correlator correlator(QPSK, diff_decode ? 0xfc4ef4fd0cc2df89 : 0xfca2b63db00d9794);
+        reedsolomon::ReedSolomon rs(reedsolomon::RS223);
+        uint8_t frameBuffer[1024 + 64] = {0};
+        int errors[4] = {0, 0, 0, 0};
+        phase_t phase = PHASE_0;
+        bool swap = false;
+        int cor = 0;
+        diff::NRZMDiff diff;
+        int64_t nout = 0, it = 0;
+        while (!eof)
+        {
+            read_data((uint8_t *)buffer, ENCODED_FRAME_SIZE);
+            int pos = correlator.correlate((int8_t *)buffer, phase, swap, cor, ENCODED_FRAME_SIZE);
+            if (locks_out && it < locks_cap)
+                locks_out[it] = pos == 0;
+            it++;
+            if (pos != 0 && pos < ENCODED_FRAME_SIZE)
+            {
+                std::memmove(buffer, &buffer[pos], ENCODED_FRAME_SIZE - pos);
+                read_data((uint8_t *)&buffer[ENCODED_FRAME_SIZE - pos], pos);
+            }
+            rotate_soft(buffer, ENCODED_FRAME_SIZE, phase, swap);
+            viterbi->work((int8_t *)buffer, frameBuffer);
+            if (diff_decode)
+                diff.decode(frameBuffer, FRAME_SIZE);
+            derand_ccsds(&frameBuffer[4], FRAME_SIZE - 4);
+            if (frameBuffer[9] == 0xFF)
+                for (int i = 0; i < FRAME_SIZE; i++)
+                    frameBuffer[i] ^= 0xFF;
+            rs.decode_interlaved(&frameBuffer[4], false, 4, errors);
+            if (errors[0] >= 0 && errors[1] >= 0 && errors[2] >= 0 && errors[3] >= 0)
+            {
+                if (nout < cadu_cap_frames)
+                {
+                    const uint8_t sync[4] = {0x1d, 0xcf, 0xfc, 0x1d};
+                    memcpy(cadu_out + nout * FRAME_SIZE, sync, 4);
+                    memcpy(cadu_out + nout * FRAME_SIZE + 4, &frameBuffer[4], FRAME_SIZE - 4);
+                }
+                nout++;
+            }
+        }
+        if (iterations_out)
+            *iterations_out = it;
+        zero_delete(viterbi);
         return nout;
     }
 

@@ -96,6 +96,15 @@ class AosPacket(C.Structure):
                 ("payload_offset", C.c_uint64)]
 
 
+class LrptCfg(C.Structure):
+    _fields_ = [("diff_decode", C.c_int), ("device", C.c_int)]
+
+
+class LrptStats(C.Structure):
+    _fields_ = [("soft_in", C.c_uint64), ("frames_seen", C.c_uint64), ("frames_out", C.c_uint64), ("viterbi_ber", C.c_float), ("correlator_lock", C.c_int),
+                ("cor", C.c_int), ("rs_errors", C.c_int * 4)]
+
+
 # dvbs2_code_rate_t (common/codings/dvb-s2/dvbs2.h:9-23)
 S2_RATES = {"1/4": 0, "1/3": 1, "2/5": 2, "1/2": 3, "3/5": 4, "2/3": 5, "3/4": 6, "4/5": 7, "5/6": 8, "7/8": 9, "8/9": 10, "9/10": 11}
 
@@ -227,6 +236,17 @@ def lib():
             L.sdhip_aos_demux_destroy.argtypes = [C.c_void_p]
             L.sdhip_aos_demux_work_dev.restype = C.c_int64
             L.sdhip_aos_demux_work_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_uint64)]
+        if hasattr(L, "sdhip_lrpt_create"):
+            L.sdhip_lrpt_cfg_default.argtypes = [C.POINTER(LrptCfg)]
+            L.sdhip_lrpt_create.restype = C.c_void_p
+            L.sdhip_lrpt_create.argtypes = [C.POINTER(LrptCfg)]
+            L.sdhip_lrpt_destroy.argtypes = [C.c_void_p]
+            L.sdhip_lrpt_push.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+            L.sdhip_lrpt_pull.restype = C.c_int64
+            L.sdhip_lrpt_pull.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+            L.sdhip_lrpt_process_dev.restype = C.c_int64
+            L.sdhip_lrpt_process_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+            L.sdhip_lrpt_get_stats.argtypes = [C.c_void_p, C.POINTER(LrptStats)]
         L.sdhip_prof_enable.argtypes = [C.c_int]
         L.sdhip_pool_enable.argtypes = [C.c_int]
         L.sdhip_prof_get.argtypes = [C.c_int, C.c_char_p, C.c_size_t, C.POINTER(C.c_double), C.POINTER(C.c_longlong)]

@@ -1832,6 +1832,77 @@ using namespace sdhip;
         return ret;                      \
     }
 
+namespace sdhip
+{
+    // viterbi::Viterbi27::work over nframes consecutive calls of one decoder (viterbi27.cpp:31-66), everything on the device: frame j reads
+    // d_soft + j * 2 * frame_bits signed soft symbols, d_out gets frame_bits / 8 bytes per frame. start_in0 = -2: the decoder's first call ever
+    // (unbiased metrics), else the chained start state the previous call of this decoder returned (*ret_state). ber_err[j] = the numerator of
+    // Viterbi27::ber() after frame j (x 4 / ber_test_size). Current device, default stream, synchronous.
+    void viterbi27_frames(int frame_bits, int ber_test_size, const int8_t *d_soft, int nframes, int start_in0, uint8_t *d_out, std::vector<int> *ber_err, int *ret_state)
+    {
+        if (frame_bits < 64 || frame_bits % 32 || ber_test_size < 2 || ber_test_size % 2 || ber_test_size > 2 * frame_bits)
+            throw HipError("viterbi27: frame_bits must be a multiple of 32 and ber_test_size even, <= 2 * frame_bits");
+        if (nframes <= 0)
+            return;
+        VitCfg vc{};
+        vc.mode = 0; // signed soft symbols, no rotation: utils.cpp:3-12
+        vc.F = frame_bits;
+        vc.B = 2 * frame_bits;
+        vc.nber = ber_test_size / 2;
+        vc.nenc = ber_test_size / 2;
+        const int wpb = vit_words_per_block(frame_bits);
+        const int dstride = (frame_bits + 6 + 63) / 64 * 64;
+        DevBuf<VitBlockIO> d_io;
+        DevBuf<uint64_t> d_dec;
+        DevBuf<uint32_t> d_vb;
+        d_io.reserve(nframes);
+        d_vb.reserve((size_t)nframes * wpb + 4);
+        std::vector<VitBlockIO> io(nframes);
+        for (int j = 0; j < nframes; j++)
+            io[j].start_in = -1;
+        io[0].start_in = start_in0;
+        SD_HIP(hipMemcpy(d_io.p, io.data(), io.size() * sizeof(VitBlockIO), hipMemcpyHostToDevice));
+        Vit2Work vit2;
+        const bool v2 = vit2_supported(vc) && !(getenv("SDHIP_VIT2") && atoi(getenv("SDHIP_VIT2")) == 0);
+        if (v2)
+            launch_vit_decode2(vc, d_soft, 0, nframes, d_io.p, d_vb.p, vit2, nullptr);
+        else
+        {
+            d_dec.reserve((size_t)nframes * dstride);
+            launch_vit_decode(vc, d_soft, 0, nframes, d_io.p, d_dec.p, d_vb.p, nullptr);
+        }
+        SD_HIP(hipMemcpy(io.data(), d_io.p, io.size() * sizeof(VitBlockIO), hipMemcpyDeviceToHost));
+        d_dec.reserve((size_t)dstride);
+        auto redo = [&](int j, int start) {
+            VitBlockIO one{};
+            one.start_in = start;
+            SD_HIP(hipMemcpy(d_io.p + j, &one, sizeof(one), hipMemcpyHostToDevice));
+            launch_vit_decode(vc, d_soft, j, 1, d_io.p + j, d_dec.p, d_vb.p + (size_t)j * wpb, nullptr);
+            SD_HIP(hipMemcpy(&io[j], d_io.p + j, sizeof(one), hipMemcpyDeviceToHost));
+        };
+        for (int j = 0; j < nframes; j++)
+        {
+            if (io[j].tb_fallback == 2)
+                redo(j, io[j].start_used);
+            if (j > 0 && io[j].start_used != io[j - 1].ret_state)
+                redo(j, io[j - 1].ret_state);
+        }
+        launch_vit_ber(vc, d_soft, 0, nframes, d_vb.p, 0u, d_io.p, nullptr);
+        const long long nbytes = (long long)nframes * (frame_bits / 8);
+        hipLaunchKernelGGL(k_words_to_bytes, dim3((unsigned)((nbytes + 255) / 256)), dim3(256), 0, nullptr, d_vb.p, wpb, frame_bits / 8, nframes, d_out);
+        SD_HIP(hipMemcpy(io.data(), d_io.p, io.size() * sizeof(VitBlockIO), hipMemcpyDeviceToHost));
+        if (ber_err)
+        {
+            ber_err->resize(nframes);
+            for (int j = 0; j < nframes; j++)
+                (*ber_err)[j] = io[j].ber_err;
+        }
+        if (ret_state)
+            *ret_state = io[nframes - 1].ret_state;
+        SD_HIP(hipDeviceSynchronize());
+    }
+} // namespace sdhip
+
 extern "C"
 {
     const char *sdhip_last_error(void) { return g_last_error.c_str(); }
@@ -1948,61 +2019,14 @@ extern "C"
     {
         SD_GUARD_BEGIN
         SD_HIP(hipSetDevice(device));
-        if (frame_bits < 64 || frame_bits % 32 || ber_test_size < 2 || ber_test_size % 2 || ber_test_size > 2 * frame_bits)
-            throw HipError("viterbi27: frame_bits must be a multiple of 32 and ber_test_size even, <= 2 * frame_bits");
         if (nframes <= 0)
             return 0;
-        VitCfg vc{};
-        vc.mode = 0; // signed soft symbols, no rotation: utils.cpp:3-12
-        vc.F = frame_bits;
-        vc.B = 2 * frame_bits;
-        vc.nber = ber_test_size / 2;
-        vc.nenc = ber_test_size / 2;
-        const int wpb = vit_words_per_block(frame_bits);
-        const int dstride = (frame_bits + 6 + 63) / 64 * 64;
-        DevBuf<VitBlockIO> d_io;
-        DevBuf<uint64_t> d_dec;
-        DevBuf<uint32_t> d_vb;
-        d_io.reserve(nframes);
-        d_vb.reserve((size_t)nframes * wpb + 4);
-        std::vector<VitBlockIO> io(nframes);
-        for (int j = 0; j < nframes; j++)
-            io[j].start_in = -1;
-        io[0].start_in = -2;
-        SD_HIP(hipMemcpy(d_io.p, io.data(), io.size() * sizeof(VitBlockIO), hipMemcpyHostToDevice));
-        Vit2Work vit2;
-        const bool v2 = vit2_supported(vc) && !(getenv("SDHIP_VIT2") && atoi(getenv("SDHIP_VIT2")) == 0);
-        if (v2)
-            launch_vit_decode2(vc, d_soft, 0, nframes, d_io.p, d_vb.p, vit2, nullptr);
-        else
-        {
-            d_dec.reserve((size_t)nframes * dstride);
-            launch_vit_decode(vc, d_soft, 0, nframes, d_io.p, d_dec.p, d_vb.p, nullptr);
-        }
-        SD_HIP(hipMemcpy(io.data(), d_io.p, io.size() * sizeof(VitBlockIO), hipMemcpyDeviceToHost));
-        d_dec.reserve((size_t)dstride);
-        auto redo = [&](int j, int start) {
-            VitBlockIO one{};
-            one.start_in = start;
-            SD_HIP(hipMemcpy(d_io.p + j, &one, sizeof(one), hipMemcpyHostToDevice));
-            launch_vit_decode(vc, d_soft, j, 1, d_io.p + j, d_dec.p, d_vb.p + (size_t)j * wpb, nullptr);
-            SD_HIP(hipMemcpy(&io[j], d_io.p + j, sizeof(one), hipMemcpyDeviceToHost));
-        };
-        for (int j = 0; j < nframes; j++)
-        {
-            if (io[j].tb_fallback == 2)
-                redo(j, io[j].start_used);
-            if (j > 0 && io[j].start_used != io[j - 1].ret_state)
-                redo(j, io[j - 1].ret_state);
-        }
-        launch_vit_ber(vc, d_soft, 0, nframes, d_vb.p, 0u, d_io.p, nullptr);
-        const long long nbytes = (long long)nframes * (frame_bits / 8);
-        hipLaunchKernelGGL(k_words_to_bytes, dim3((unsigned)((nbytes + 255) / 256)), dim3(256), 0, nullptr, d_vb.p, wpb, frame_bits / 8, nframes, d_out);
-        SD_HIP(hipMemcpy(io.data(), d_io.p, io.size() * sizeof(VitBlockIO), hipMemcpyDeviceToHost));
+        std::vector<int> err;
+        int ret = -2;
+        sdhip::viterbi27_frames(frame_bits, ber_test_size, d_soft, nframes, -2, d_out, &err, &ret);
         if (ber_out)
             for (int j = 0; j < nframes; j++)
-                ber_out[j] = ((float)io[j].ber_err / (float)ber_test_size) * 4.0f;
-        SD_HIP(hipDeviceSynchronize());
+                ber_out[j] = ((float)err[j] / (float)ber_test_size) * 4.0f;
         return 0;
         SD_GUARD_END(-1)
     }

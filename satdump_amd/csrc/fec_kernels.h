@@ -1,6 +1,7 @@
 // fec_kernels.h -- launch-side declarations of the CCSDS FEC kernels (gfx950).
 #pragma once
 #include "common.h"
+#include <vector>
 
 namespace sdhip
 {
@@ -210,4 +211,6 @@ namespace sdhip
                         uint8_t *clean_scratch = nullptr);
     // Compaction: copy frames whose keep[i] != 0 to out in order. Returns nothing; count known to the host.
     void launch_compact(const uint8_t *frames, const int *dst_index, int nframes, int cadu_bytes, uint8_t *out, hipStream_t st);
+    // viterbi::Viterbi27::work over consecutive frames of one decoder (fec_engine.hip), device buffers
+    void viterbi27_frames(int frame_bits, int ber_test_size, const int8_t *d_soft, int nframes, int start_in0, uint8_t *d_out, std::vector<int> *ber_err, int *ret_state);
 } // namespace sdhip
