@@ -33,6 +33,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <filesystem>
 #include <fstream>
 #include <thread>
 #include <vector>
@@ -844,6 +845,102 @@ namespace sdhip_plugin
         }
     };
 
+    // ------------------------------------------------------------------------------------------------ meteor_lrpt_decoder
+    // METEORLRPTDecoderModule (plugins/meteor_support/meteor/module_meteor_lrpt_decoder.{h,cpp}), its classic branch, on sdhip_lrpt_*: same keys
+    // ("diff_decode" mandatory), .soft file / fifo in, .cadu out, the module's statistics keys. "m2x_mode" runs (Viterbi1_2 + deframer, optionally behind
+    // the deinterleaver) stay on the CPU module.
+    class METEORLRPTDecoderHipModule : public base::FileStreamToFileStreamModule
+    {
+        sdhip_lrpt_cfg cfg;
+        void *h = nullptr;
+        std::atomic<float> viterbi_ber{10};
+        std::atomic<int> locked{0}, rs_avg{0};
+        uint64_t file_bytes = 0, file_pos = 0;
+
+    public:
+        METEORLRPTDecoderHipModule(std::string input_file, std::string output_file_hint, nlohmann::json parameters)
+            : base::FileStreamToFileStreamModule(input_file, output_file_hint, parameters)
+        {
+            sdhip_lrpt_cfg_default(&cfg);
+            cfg.diff_decode = parameters["diff_decode"].get<bool>() ? 1 : 0; // module_meteor_lrpt_decoder.cpp:22
+            opt(parameters, "hip_device", cfg.device);
+            if (parameters.count("m2x_mode") > 0 && parameters["m2x_mode"].get<bool>())
+                throw satdump_exception("meteor_lrpt_decoder_hip: m2x_mode is the CPU module's");
+            fsfsm_file_ext = ".cadu";
+        }
+        ~METEORLRPTDecoderHipModule()
+        {
+            if (h)
+                sdhip_lrpt_destroy(h);
+        }
+        static bool covers(const nlohmann::json &p) { return !(p.count("m2x_mode") > 0 && p["m2x_mode"].get<bool>()); }
+        void init()
+        {
+            base::FileStreamToFileStreamModule::init();
+            h = sdhip_lrpt_create(&cfg);
+            if (!h)
+                throw satdump_exception(std::string("meteor_lrpt_decoder_hip: ") + sdhip_last_error());
+            if (input_data_type == DATA_FILE)
+                file_bytes = (uint64_t)std::filesystem::file_size(d_input_file);
+        }
+        void process()
+        {
+            // the module reads one encoded frame (16384 soft bytes) per iteration, plus the correlator's slide; here a file goes to the device in batches of
+            // 1024 frames' worth, a fifo frame by frame. What the module does with its last, partly stale buffer at the end of a file is not reproduced
+            // (csrc/lrpt_decoder.hip): an incomplete last frame is dropped.
+            const size_t chunk = (size_t)16384 * (input_data_type == DATA_FILE ? 1024 : 1);
+            std::vector<int8_t> soft(chunk);
+            std::vector<uint8_t> frames((size_t)1024 * 1100);
+            while (should_run())
+            {
+                // (read_data on a file reads short at the end without saying by how much: counted against the file's size)
+                size_t got = chunk;
+                if (input_data_type == DATA_FILE)
+                {
+                    got = (size_t)std::min<uint64_t>(chunk, file_bytes > file_pos ? file_bytes - file_pos : 0);
+                    file_pos += got;
+                }
+                read_data((uint8_t *)soft.data(), chunk);
+                if (got == 0)
+                    break;
+                if (sdhip_lrpt_push(h, soft.data(), got) < 0)
+                    throw satdump_exception(std::string("meteor_lrpt_decoder_hip: ") + sdhip_last_error());
+                for (;;)
+                {
+                    const int64_t n = sdhip_lrpt_pull(h, frames.data(), frames.size() / 1024);
+                    if (n < 0)
+                        throw satdump_exception(std::string("meteor_lrpt_decoder_hip: ") + sdhip_last_error());
+                    if (n == 0)
+                        break;
+                    write_data(frames.data(), (size_t)n * 1024);
+                }
+                sdhip_lrpt_stats st;
+                sdhip_lrpt_get_stats(h, &st);
+                viterbi_ber = st.viterbi_ber;
+                locked = st.correlator_lock;
+                rs_avg = (st.rs_errors[0] + st.rs_errors[1] + st.rs_errors[2] + st.rs_errors[3]) / 4;
+            }
+            cleanup();
+        }
+        void drawUI(bool) {}
+        nlohmann::json getModuleStats()
+        { // module_meteor_lrpt_decoder.cpp:268-290 (classic branch)
+            auto v = base::FileStreamToFileStreamModule::getModuleStats();
+            v["correlator_lock"] = locked.load() != 0;
+            v["viterbi_ber"] = viterbi_ber.load();
+            v["rs_avg"] = rs_avg.load();
+            v["lock_state"] = locked.load() ? "SYNCED" : "NOSYNC";
+            return v;
+        }
+        static std::string getID() { return "meteor_lrpt_decoder_hip"; }
+        virtual std::string getIDM() { return getID(); }
+        static nlohmann::json getParams() { return {}; }
+        static std::shared_ptr<ProcessingModule> getInstance(std::string input_file, std::string output_file_hint, nlohmann::json parameters)
+        {
+            return std::make_shared<METEORLRPTDecoderHipModule>(input_file, output_file_hint, parameters);
+        }
+    };
+
     // ------------------------------------------------------------------------------------------------ dvbs2_demod
     // DVBS2DemodModule (plugins/dvb_support/dvbs2/module_dvbs2_demod.{h,cpp}) on the handle of include/sdhip.h (sdhip_dvbs2_demod_*): same JSON
     // keys, defaults and exceptions, baseband file / dsp::stream in, .bbframe file / fifo out, the same statistics keys. What the module builds on the
@@ -1125,6 +1222,7 @@ namespace sdhip_plugin
             REGISTER_MODULE_EXTERNAL(evt.modules_registry, MetOpAHRPTDecoderHipModule);
             REGISTER_MODULE_EXTERNAL(evt.modules_registry, CCSDSSimplePSKDecoderHipModule);
             REGISTER_MODULE_EXTERNAL(evt.modules_registry, DVBS2DemodHipModule);
+            REGISTER_MODULE_EXTERNAL(evt.modules_registry, METEORLRPTDecoderHipModule);
         }
         static void startedHandler(const satdump::SatDumpStartedEvent &)
         {
@@ -1177,6 +1275,15 @@ namespace sdhip_plugin
                             return cpu(in, out, p);
                         }
                         return DVBS2DemodHipModule::getInstance(in, out, p);
+                    };
+                }
+                else if (e.id == "meteor_lrpt_decoder")
+                { // plugins/meteor_support's module (ordering caveat as for metop_ahrpt_decoder); its m2x_mode branch stays on the CPU module
+                    auto cpu = e.inst;
+                    e.inst = [cpu](std::string in, std::string out, nlohmann::json p) -> std::shared_ptr<ProcessingModule> {
+                        if (!METEORLRPTDecoderHipModule::covers(p))
+                            return cpu(in, out, p);
+                        return METEORLRPTDecoderHipModule::getInstance(in, out, p);
                     };
                 }
                 else if (e.id == "ccsds_simple_psk_decoder")

@@ -50,6 +50,9 @@ def test_struct_mirrors_match_the_header():
     assert [f for f, _ in pyref.FecCfg._fields_] == fields("sdhip_fec_cfg")
     assert [f for f, _ in capi.DemodCfg._fields_] == fields("sdhip_demod_cfg")
     assert [f for f, _ in pyref.DemodCfg._fields_] == fields("sdhip_demod_cfg")
+    assert [f for f, _ in capi.LrptCfg._fields_] == fields("sdhip_lrpt_cfg")
+    assert [f for f, _ in capi.LrptStats._fields_] == fields("sdhip_lrpt_stats")
+    assert [f for f, _ in capi.Dvbs2Stats._fields_] == fields("sdhip_dvbs2_stats")
 
 
 def test_product_filter_design_against_the_reference_tables():

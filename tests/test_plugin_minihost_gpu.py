@@ -439,6 +439,44 @@ def test_ndsp_single_blocks_through_the_plugin(host, tmp_path):
     check_ndsp_single_blocks_through_the_plugin(host, LIB, tmp_path)
 
 
+def check_lrpt_module_through_the_plugin(host, lib, tmp_path):
+    """SURVEY 8 f-3's plugin decoder through the drop-in boundary: the stock id `meteor_lrpt_decoder` (plugins/meteor_support), re-pointed by the plugin
+    under SDHIP_OVERRIDE=1 at METEORLRPTDecoderHipModule, reads a .soft file and writes the .cadu file the reference module's loop writes (the module's
+    loop on the reference's own Correlator / Viterbi27 / ReedSolomon: oracle/ref_wrap.cpp) -- but for the module's extra iteration on a stale buffer at
+    the end of a file (the last CADU twice). NRZ-M ("diff_decode"), garbage in front; m2x_mode stays on the CPU module; the mandatory key throws."""
+    from tests.test_lrpt_gpu import lrpt_soft
+    for name, diff in (("plain", False), ("diff", True)):
+        soft, _ = lrpt_soft(11, seed=8, diff=diff, lead=4444, sigma=20.0)
+        want = pyref.ref().lrpt_decode(soft, diff)["cadu"]
+        inp = tmp_path / (name + ".soft")
+        soft.tofile(str(inp))
+        job = {"mode": "file", "input": str(inp), "output_hint": str(tmp_path / name), "demod": {"module": "meteor_lrpt_decoder", "parameters": {"diff_decode": diff}}}
+        jp = tmp_path / (name + ".json")
+        jp.write_text(json.dumps(job))
+        p = subprocess.run([host, lib, PLUGIN, "run", str(jp)], capture_output=True, text=True, env=dict(os.environ, SDHIP_OVERRIDE="1"), timeout=900)
+        assert p.returncode == 0, p.stdout[-1000:] + p.stderr[-3000:]
+        rep = json.loads(p.stdout.strip().splitlines()[-1])
+        assert rep["demod_class"] == "meteor_lrpt_decoder_hip" and rep["soft"].endswith(".cadu")
+        got = np.fromfile(rep["soft"], dtype=np.uint8).reshape(-1, 1024)
+        assert len(got) >= 8 and len(got) <= len(want) <= len(got) + 2 and np.array_equal(got, want[: len(got)])
+        assert set(rep["demod_stats"]) >= {"correlator_lock", "viterbi_ber", "rs_avg", "lock_state"} and rep["demod_stats"]["lock_state"] == "SYNCED"
+    job = {"mode": "file", "input": str(inp), "output_hint": str(tmp_path / "m2x"), "instantiate_only": True,
+           "demod": {"module": "meteor_lrpt_decoder", "parameters": {"diff_decode": False, "m2x_mode": True, "viterbi_outsync_after": 5, "viterbi_ber_thresold": 0.2}}}
+    jp.write_text(json.dumps(job))
+    p = subprocess.run([host, lib, PLUGIN, "run", str(jp)], capture_output=True, text=True, env=dict(os.environ, SDHIP_OVERRIDE="1"), timeout=900)
+    assert p.returncode == 0 and json.loads(p.stdout.strip().splitlines()[-1])["demod_class"] == "cpu:meteor_lrpt_decoder", p.stdout[-500:] + p.stderr[-2000:]
+    job["demod"] = {"module": "meteor_lrpt_decoder_hip", "parameters": {}}
+    jp.write_text(json.dumps(job))
+    p = subprocess.run([host, lib, PLUGIN, "run", str(jp)], capture_output=True, text=True, env=dict(os.environ, SDHIP_OVERRIDE="1"), timeout=900)
+    assert p.returncode != 0
+
+
+def test_lrpt_module_through_the_plugin(host, tmp_path):
+    if not (pyref.ref_available() and hasattr(pyref.ref().lib, "sdref_lrpt_decode")):
+        pytest.skip("needs the compiled reference")
+    check_lrpt_module_through_the_plugin(host, LIB, tmp_path)
+
+
 def check_doppler_through_the_plugin(host, lib, tmp_path, nframes=40):
     """`enable_doppler` through the drop-in boundary: the stock id `psk_demod` with satellite_frequency / satellite_norad / qth_* / start_timestamp on a
     baseband FILE. The plugin computes the rotator's target per source buffer where and how DopplerCorrectBlock::work does (time advanced by the buffer,
