@@ -18,6 +18,8 @@ def test_next_row_tools_import_and_parse():
         b = s2.parse(["--rate", "2/3", "--sigma", "13"])
         assert a.samples == 1 << 30 and a.constellation == "qpsk" and b.front == 1 and b.sync_frames == 128 and b.esn0 == 8.0
         assert callable(nd.run) and callable(s2.run)
+        lr = importlib.import_module("bench_lrpt")
+        assert lr.parse([]).frames == 8192 and callable(lr.run)
     finally:
         sys.path.remove(tools)
 

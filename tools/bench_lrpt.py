@@ -1,0 +1,89 @@
+#!/usr/bin/env python3
+"""meteor_lrpt_decoder (the Viterbi27-based plugin decoders) on one MI355X, soft symbols resident in HBM: frames/s of
+sdhip_lrpt_process_dev (correlator walk -> rotate_soft -> Viterbi27 -> NRZ-M / derand -> RS x 4), per-kernel HIP-event times, the CADUs of a prefix
+against the reference module's loop on the reference's own classes (oracle/_ref), and that loop's own rate on the host.
+usage: tools/bench_lrpt.py [--frames 8192] [--steps 4] [--cpu-frames 256]"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def parse(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--frames", type=int, default=8192)
+    ap.add_argument("--steps", type=int, default=4)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--cpu-frames", type=int, default=256)
+    ap.add_argument("--sigma", type=float, default=20.0)
+    return ap.parse_args(argv)
+
+
+def run(args) -> dict:
+    import torch
+    torch.zeros(1, device="cuda")
+    from oracle import pyref
+    from satdump_amd import capi
+    from tests.test_lrpt_gpu import lrpt_soft
+
+    base = 256  # distinct frames, tiled (the decoder does not care that frames repeat)
+    soft, _ = lrpt_soft(base, seed=21, sigma=args.sigma, lead=1234)
+    lead, body = soft[:1234], soft[1234:]
+    reps = max(1, args.frames // base)
+    d_soft = torch.cat([torch.from_numpy(lead).cuda(), torch.from_numpy(body).cuda().repeat(reps)])
+    n = int(d_soft.numel())
+    nfr = reps * base
+    d_out = torch.zeros((nfr + 8) * 1024, dtype=torch.uint8, device="cuda")
+    L = capi.lib()
+    cfg = capi.LrptCfg()
+    L.sdhip_lrpt_cfg_default(C.byref(cfg))
+
+    def one():
+        h = L.sdhip_lrpt_create(C.byref(cfg))
+        assert h, capi.last_error()
+        k = L.sdhip_lrpt_process_dev(h, C.c_void_p(d_soft.data_ptr()), n, C.c_void_p(d_out.data_ptr()), nfr + 8)
+        assert k >= 0, capi.last_error()
+        L.sdhip_lrpt_destroy(h)
+        return k
+
+    for _ in range(args.warmup):
+        one()
+    capi.prof_enable(True)
+    capi.prof_reset()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ks = [one() for _ in range(args.steps)]
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / args.steps
+    kern = {k: round(v[0] / args.steps, 3) for k, v in capi.prof_get().items()}
+    capi.prof_enable(False)
+    out = {"metric": "frames_per_s", "value": round(ks[-1] / dt, 1), "unit": "CADU/s", "ms_per_step": round(dt * 1e3, 3), "steps": args.steps,
+           "config": {"workload": f"meteor_lrpt_decoder, {nfr} frames of 16384 soft bytes (r=1/2 k=7 QPSK, 1024-byte CADUs, RS(255,223) x 4), sigma {args.sigma} on +-70"},
+           "soft_MB_per_s": round(n / dt / 1e6, 1), "frames_out": int(ks[-1]), "kernels_ms": dict(sorted(kern.items(), key=lambda kv: -kv[1])[:8]), "dtype": "u8"}
+    if args.cpu_frames > 0 and pyref.ref_available():
+        m = 1234 + args.cpu_frames * 16384
+        s = d_soft[:m].cpu().numpy()
+        t1 = time.perf_counter()
+        want = pyref.ref().lrpt_decode(s, False)["cadu"]
+        t2 = time.perf_counter()
+        got = d_out[: len(want) * 1024].cpu().numpy().reshape(-1, 1024)
+        k = min(len(want), args.cpu_frames - 1)
+        out["cpu_baseline"] = {"value": round(args.cpu_frames / (t2 - t1), 1), "unit": "CADU/s", "cores": 1, "kind": "reference",
+                               "sample": f"the first {args.cpu_frames} frames: the module's loop (Correlator, rotate_soft, Viterbi27, derand_ccsds, ReedSolomon) on one thread"}
+        out["parity_sample"] = {"frames_compared": int(k), "byte_identical": bool(np.array_equal(got[:k], want[:k]))}
+    return out
+
+
+def main():
+    print(json.dumps(run(parse())), flush=True)
+
+
+if __name__ == "__main__":
+    main()
