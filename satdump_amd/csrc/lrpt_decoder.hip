@@ -306,17 +306,22 @@ namespace sdhip
             SD_HIP(hipSetDevice(cfg.device));
             stats.soft_in += n;
             const size_t total = carry + n;
-            // (grow keeping the carry)
-            if (total + 64 > stream.cap)
+            // with nothing pending the call's own buffer is the stream (no copy); else the new bytes are appended to the pending ones
+            const int8_t *base = d_in;
+            if (carry || total < (size_t)LRPT_ENC || (reinterpret_cast<uintptr_t>(d_in) & 1u)) // (the gather reads (I, Q) pairs as one 2-byte load)
             {
-                DevBuf<int8_t> bigger;
-                bigger.reserve(total + total / 2 + 64);
-                if (carry)
-                    SD_HIP(hipMemcpy(bigger.p, stream.p, carry, hipMemcpyDeviceToDevice));
-                stream.swap(bigger);
+                if (total + 64 > stream.cap)
+                { // (grow keeping the pending bytes)
+                    DevBuf<int8_t> bigger;
+                    bigger.reserve(total + total / 2 + 64);
+                    if (carry)
+                        SD_HIP(hipMemcpy(bigger.p, stream.p, carry, hipMemcpyDeviceToDevice));
+                    stream.swap(bigger);
+                }
+                if (n)
+                    SD_HIP(hipMemcpy(stream.p + carry, d_in, n, hipMemcpyDeviceToDevice));
+                base = stream.p;
             }
-            if (n)
-                SD_HIP(hipMemcpy(stream.p + carry, d_in, n, hipMemcpyDeviceToDevice));
             if (total < (size_t)LRPT_ENC)
             {
                 carry = total;
@@ -325,7 +330,7 @@ namespace sdhip
             const long long nwords = (long long)((total + 31) / 32);
             bits.reserve((size_t)nwords + 4);
             SD_HIP(hipMemsetAsync(bits.p + nwords, 0, 4 * sizeof(unsigned), nullptr));
-            hipLaunchKernelGGL(k_lrpt_hard, dim3((unsigned)((nwords + 255) / 256)), dim3(256), 0, nullptr, stream.p, (long long)total, bits.p, nwords);
+            hipLaunchKernelGGL(k_lrpt_hard, dim3((unsigned)((nwords + 255) / 256)), dim3(256), 0, nullptr, base, (long long)total, bits.p, nwords);
             const int max_frames = (int)(total / LRPT_ENC) + 1;
             d_desc.reserve(max_frames);
             {
@@ -345,7 +350,7 @@ namespace sdhip
                 d_err.reserve((size_t)nf * 4);
                 d_dst.reserve(nf);
                 const long long pairs = (long long)nf * (LRPT_ENC / 2);
-                hipLaunchKernelGGL(k_lrpt_gather, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, nullptr, stream.p, d_desc.p, nf, d_frames.p);
+                hipLaunchKernelGGL(k_lrpt_gather, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, nullptr, base, d_desc.p, nf, d_frames.p);
                 std::vector<int> ber;
                 int ret = vit_start;
                 viterbi27_frames(LRPT_ENC / 2, 1024, d_frames.p, nf, vit_start, d_raw.p, &ber, &ret); // Viterbi27(ENCODED_FRAME_SIZE / 2, polys): ber_test_size 1024
@@ -384,12 +389,20 @@ namespace sdhip
             }
             // keep what the walk did not consume
             const size_t rest = total - (size_t)consumed;
-            if (rest && consumed)
+            if (rest && (consumed || base != stream.p))
             {
-                DevBuf<int8_t> tmp;
-                tmp.reserve(rest);
-                SD_HIP(hipMemcpy(tmp.p, stream.p + consumed, rest, hipMemcpyDeviceToDevice));
-                SD_HIP(hipMemcpy(stream.p, tmp.p, rest, hipMemcpyDeviceToDevice));
+                if (base == stream.p)
+                {
+                    DevBuf<int8_t> tmp;
+                    tmp.reserve(rest);
+                    SD_HIP(hipMemcpy(tmp.p, stream.p + consumed, rest, hipMemcpyDeviceToDevice));
+                    SD_HIP(hipMemcpy(stream.p, tmp.p, rest, hipMemcpyDeviceToDevice));
+                }
+                else
+                {
+                    stream.reserve(rest + 64);
+                    SD_HIP(hipMemcpy(stream.p, base + consumed, rest, hipMemcpyDeviceToDevice));
+                }
             }
             carry = rest;
             return written;

@@ -53,6 +53,7 @@ def run(args) -> dict:
         L.sdhip_lrpt_destroy(h)
         return k
 
+    L.sdhip_pool_enable(1)  # a handle per step: its buffers come back from the pool instead of hipMalloc
     for _ in range(args.warmup):
         one()
     capi.prof_enable(True)
