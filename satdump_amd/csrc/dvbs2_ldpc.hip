@@ -32,6 +32,12 @@ namespace sdhip
         const unsigned char *cnc;   // [q] data bits per check of the layer
         const unsigned char *phase; // [q][M] phase of a check inside its layer (0 unless it shares a bit with a lower-numbered one)
         const unsigned char *nph;   // [q] phases of the layer
+        // "narrow" layers: many phases of a few checks each (chains of checks sharing bits: 90 phases of 4 checks, 52 of 7, ...). A check per thread
+        // makes every one of those phases cost a whole check's instruction stream (~400 dependent instructions on one wave); they run a LINK per
+        // lane instead: G lanes per check (G = the power of two >= its degree), minima / sign parity by row reductions.
+        int MB, G;                   // checks a layer's message block holds (>= M: a narrow layer's schedule is padded to width x phases); lanes per check
+        const unsigned char *narrow; // [q] 0 = a check per thread; else W = checks per phase of the padded schedule
+        const unsigned short *snode; // [q][MB][4 * DQ] node of link d of the check at schedule position k = phase * W + slot, 0xFFFF = no such link
     };
 
     __device__ __forceinline__ int q8(int v) { return v < -128 ? -128 : (v > 127 ? 127 : v); }
@@ -54,7 +60,7 @@ namespace sdhip
             const int par1 = i ? g.K + g.M * (i - 1) + j : g.K + (g.q - 1) * g.M + j - 1;
 #pragma unroll
             for (int w = 0; w < DQ; w++)
-                bw[w] = 4 * w < deg ? bnl_f[((size_t)i * DQ + w) * g.M + j] : 0u;
+                bw[w] = 4 * w < deg ? bnl_f[((size_t)i * DQ + w) * g.MB + j] : 0u;
 #pragma unroll
             for (int h = 0; h < 2 * DQ; h++)
             {
@@ -125,7 +131,7 @@ namespace sdhip
 #pragma unroll
             for (int w = 0; w < DQ; w++)
                 if (4 * w < deg)
-                    bnl_f[((size_t)i * DQ + w) * g.M + j] = bw[w];
+                    bnl_f[((size_t)i * DQ + w) * g.MB + j] = bw[w];
         }
     };
     // parity of one check (LDPCDecoder::bad, layered_decoder.hh:29-47): bad unless every connected LLR is nonzero and an even number negative
@@ -149,13 +155,129 @@ namespace sdhip
     }
 
     constexpr int LDPC_THREADS = 384; // 360 checks of a layer, six waves
+
+    // allreduce over the G lanes of a group (G = 4, 8, 16: DPP inside a 16-lane row; 32: one cross-row exchange on top)
+    template <int G, class Op>
+    __device__ __forceinline__ unsigned group_allreduce(unsigned v, Op op)
+    {
+        v = op(v, dpp_mov<0xB1>(v)); // quad_perm [1,0,3,2]
+        v = op(v, dpp_mov<0x4E>(v)); // quad_perm [2,3,0,1]
+        if constexpr (G >= 8)
+            v = op(v, dpp_mov<0x141>(v)); // row_half_mirror
+        if constexpr (G >= 16)
+            v = op(v, dpp_mov<0x140>(v)); // row_mirror
+        if constexpr (G >= 32)
+            v = op(v, (unsigned)__shfl_xor((int)v, 16));
+        return v;
+    }
+    // One phase of a narrow layer for this lane's link: the check node update of LdpcCheck::update with the check's links spread over the
+    // group's lanes. n = node (0xFFFF: no link), m = the link's check-to-bit message; returns the new message.
+    template <int G>
+    __device__ __forceinline__ int ldpc_link_update(signed char *llr, unsigned n, int m)
+    {
+        const bool has = n != 0xFFFFu;
+        const int inp = has ? q8((int)llr[n] - m) : 0;
+        int mag = inp < -127 ? 127 : (inp < 0 ? -inp : inp);
+        mag = mag > 0 ? mag - 1 : 0;
+        const unsigned key = has ? (unsigned)mag : 255u;
+        auto mn = [](unsigned a, unsigned b) { return a < b ? a : b; };
+        const unsigned min0 = group_allreduce<G>(key, mn);
+        // the second of the sorted magnitudes: min0 again when two links hold it
+        const unsigned long long lanes = __ballot(has && key == min0), negs = __ballot(has && inp < 0);
+        const int base = (int)(threadIdx.x & 63u) & ~(G - 1);
+        const unsigned gm = G >= 32 ? 0xFFFFFFFFu : ((1u << (G & 31)) - 1u);
+        const unsigned at_min = (unsigned)(lanes >> base) & gm, neg_bits = (unsigned)(negs >> base) & gm;
+        const unsigned next = group_allreduce<G>(key == min0 ? 255u : key, mn); // (unconditional: the lanes of a wave stay convergent)
+        const unsigned min1 = __popc(at_min) >= 2 ? min0 : next;
+        const int other = (unsigned)mag == min0 ? (int)min1 : (int)min0;
+        const bool neg = ((__popc(neg_bits) & 1) != 0) != (inp < 0); // sign of the product of the OTHER links' signs
+        int out = neg ? -other : other;
+        out = out < -32 ? -32 : (out > 31 ? 31 : out);
+        if (has)
+            llr[n] = (signed char)q8(inp + out);
+        __builtin_amdgcn_wave_barrier(); // (the next phase's reads come after every lane's write: lockstep on the hardware, a meeting point for the host twin)
+        return out;
+    }
+    // a narrow layer: lane (group, link) walks the phases; node indices and messages of the phases ahead ride in a register queue (their
+    // addresses depend on the phase alone), so that no global latency sits between two phases
+    template <int G, int DQ>
+    __device__ __forceinline__ void ldpc_narrow_layer(const LdpcDev &g, signed char *llr, unsigned *bnl_f, int i, int tid)
+    {
+        constexpr int D = 8, L = 4 * DQ;
+        const int W = g.narrow[i], nph = g.nph[i];
+        const int gid = tid / G, l = tid % G;
+        const bool mine = gid < W && l < L;
+        const bool multi = W * G > 64; // the phase's lanes span more than one wave: the phases need the workgroup's barrier
+        const unsigned short *sn = g.snode + ((size_t)i * g.MB + gid) * L + l;
+        signed char *mb = reinterpret_cast<signed char *>(bnl_f) + ((size_t)i * g.MB + gid) * L + l; // messages of a narrow layer: [position][link] bytes
+        const size_t step = (size_t)W * L;
+        unsigned nq[D];
+        int mq[D];
+#pragma unroll
+        for (int u = 0; u < D; u++)
+        {
+            nq[u] = 0xFFFFu;
+            mq[u] = 0;
+            if (mine && u < nph)
+            {
+                nq[u] = sn[(size_t)u * step];
+                mq[u] = mb[(size_t)u * step];
+            }
+        }
+        for (int base = 0; base < nph; base += D)
+        {
+#pragma unroll
+            for (int u = 0; u < D; u++)
+            {
+                const int ph = base + u;
+                if (ph < nph)
+                {
+                    const unsigned n = nq[u];
+                    const int m = mq[u];
+                    nq[u] = 0xFFFFu;
+                    if (mine && ph + D < nph)
+                    {
+                        nq[u] = sn[(size_t)(ph + D) * step];
+                        mq[u] = mb[(size_t)(ph + D) * step];
+                    }
+                    if ((tid & ~63) < W * G) // (waves without a link skip the arithmetic)
+                    {
+                        const int out = ldpc_link_update<G>(llr, n, m);
+                        if (n != 0xFFFFu)
+                            mb[(size_t)ph * step] = (signed char)out;
+                    }
+                    if (multi)
+                        __syncthreads();
+                }
+            }
+        }
+    }
     // trial t of every frame. bad_prev / bad_cur: per frame flags of trial t-1 / t; updates[f]: update passes run so far.
+    // probe (SDHIP_LDPC_PROBE=1, measurements only): shader-clock ticks workgroup 0's first lane spends in {frame in, waiting for a layer's loads, the
+    // phases, the stores, the parity check, frame out}, summed over the launches
+#ifdef SDHIP_HOST_TWIN
+    __device__ __forceinline__ long long ldpc_clock() { return 0; }
+    __device__ __forceinline__ void ldpc_wait_loads() {}
+#else
+    __device__ __forceinline__ long long ldpc_clock() { return (long long)__builtin_amdgcn_s_memtime(); }
+    __device__ __forceinline__ void ldpc_wait_loads() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+#endif
     template <int DQ>
     __global__ __launch_bounds__(LDPC_THREADS) void k_ldpc_trial(LdpcDev g, signed char *frames, unsigned *bnl, int nframes, int batch, int t, const int *bad_prev,
-                                                                 int *bad_cur, int *updates, int *any_bad)
+                                                                 int *bad_cur, int *updates, int *any_bad, long long *probe)
     {
         __shared__ signed char llr[64800];
         const int f = (int)blockIdx.x, tid = (int)threadIdx.x;
+        const bool pr = probe != nullptr && f == 0 && tid == 0;
+        long long pc[6] = {0, 0, 0, 0, 0, 0}, pt = probe ? ldpc_clock() : 0;
+        auto lap = [&](int k) {
+            if (probe)
+            {
+                const long long now = ldpc_clock();
+                pc[k] += now - pt;
+                pt = now;
+            }
+        };
         bool active = false;
         if (t > 0)
         { // while (bad(...) && --trials >= 0) update(...): the whole batch goes on while ANY of its frames is bad
@@ -178,25 +300,54 @@ namespace sdhip
             const int j = p / g.q, i = p - j * g.q;
             llr[g.K + g.M * i + j] = fr[g.K + p];
         }
-        unsigned *bnl_f = bnl + (size_t)f * g.q * DQ * g.M;
+        unsigned *bnl_f = bnl + (size_t)f * g.q * DQ * g.MB;
         __syncthreads();
+        lap(0);
         if (active)
         {
             for (int i = 0; i < g.q; i++)
             {
                 const int nph = g.nph[i];
+                if (g.narrow[i])
+                { // many phases of a few checks: a link per lane (see LdpcDev)
+                    switch (g.G)
+                    {
+                    case 4:
+                        ldpc_narrow_layer<4, DQ>(g, llr, bnl_f, i, tid);
+                        break;
+                    case 8:
+                        ldpc_narrow_layer<8, DQ>(g, llr, bnl_f, i, tid);
+                        break;
+                    case 16:
+                        ldpc_narrow_layer<16, DQ>(g, llr, bnl_f, i, tid);
+                        break;
+                    default:
+                        ldpc_narrow_layer<32, DQ>(g, llr, bnl_f, i, tid);
+                        break;
+                    }
+                    __syncthreads();
+                    lap(2);
+                    continue;
+                }
                 const int my = tid < g.M ? (int)g.phase[i * g.M + tid] : -1;
                 LdpcCheck<DQ> ck;
                 if (my >= 0)
                     ck.load(g, bnl_f, i, tid);
+                if (probe)
+                {
+                    ldpc_wait_loads();
+                    lap(1);
+                }
                 for (int ph = 0; ph < nph; ph++)
                 {
                     if (my == ph)
                         ck.update(llr);
                     __syncthreads();
                 }
+                lap(2);
                 if (my >= 0)
                     ck.store(g, bnl_f, i, tid);
+                lap(3);
             }
         }
         bool bad = false;
@@ -204,6 +355,7 @@ namespace sdhip
             for (int i = 0; i < g.q && !bad; i++)
                 bad = ldpc_check_bad(g, llr, i, tid);
         const int any = __syncthreads_or(bad ? 1 : 0);
+        lap(4);
         if (active)
         {
             for (int w = tid; w < g.K / 4; w += LDPC_THREADS)
@@ -221,6 +373,14 @@ namespace sdhip
                 updates[f] += 1;
             if (any)
                 atomicOr(any_bad, 1);
+        }
+        if (pr)
+        {
+            lap(5);
+            for (int k = 0; k < 6; k++)
+                probe[k] += pc[k];
+            probe[6] += active ? 1 : 0;
+            probe[7] += 1;
         }
     }
 
@@ -243,13 +403,16 @@ namespace sdhip
         const S2Table *tab = nullptr;
         LdpcDev g{};
         DevBuf<unsigned short> d_pos;
-        DevBuf<unsigned char> d_cnc, d_phase, d_nph;
+        DevBuf<unsigned char> d_cnc, d_phase, d_nph, d_narrow;
+        DevBuf<unsigned short> d_snode;
+        int narrow_layers = 0;
         DevBuf<unsigned> d_bnl;
         DevBuf<int> d_flags; // bad[2][nf] | updates[nf] | any
         DevBuf<signed char> d_frames;
         DevBuf<int> d_trials;
         int max_phases = 1, conflict_layers = 0;
         sdhip_ldpc_info info{};
+        DevBuf<long long> d_probe; // SDHIP_LDPC_PROBE=1 (see k_ldpc_trial)
 
         explicit LdpcEngine(const sdhip_ldpc_cfg &c) : cfg(c)
         {
@@ -313,8 +476,67 @@ namespace sdhip
                 }
                 max_phases = std::max<int>(max_phases, nph[i]);
                 conflict_layers += nph[i] > 1;
+                if (getenv("SDHIP_LDPC_DUMP") && nph[i] > 1)
+                { // the layer's dependency structure: checks per phase
+                    std::vector<int> cntp(nph[i], 0);
+                    for (int j = 0; j < M; j++)
+                        cntp[phase[(size_t)i * M + j]]++;
+                    int mx = 0, mx1 = 0;
+                    for (int p2 = 0; p2 < nph[i]; p2++)
+                    {
+                        mx = std::max(mx, cntp[p2]);
+                        if (p2)
+                            mx1 = std::max(mx1, cntp[p2]);
+                    }
+                    fprintf(stderr, "[sdhip] ldpc table %d layer %d: degree %d + 2, %d phases, phase 0 has %d checks, later phases at most %d\n", ti, i, cn[i], nph[i], cntp[0], mx1);
+                }
             }
             const int DQ = (CNL + 2 + 3) / 4;
+            // narrow layers (LdpcDev): schedule position k = phase * W + slot, W = the widest phase; a link per lane, G lanes per check
+            int G = 4;
+            while (G < CNL + 2)
+                G *= 2;
+            std::vector<unsigned char> narrow(q, 0);
+            int MB = M;
+            const bool use_narrow = !(getenv("SDHIP_LDPC_NARROW") && atoi(getenv("SDHIP_LDPC_NARROW")) == 0);
+            std::vector<std::vector<int>> per_phase_count(q);
+            for (int i = 0; i < q; i++)
+            {
+                std::vector<int> cntp(nph[i], 0);
+                for (int j = 0; j < M; j++)
+                    cntp[phase[(size_t)i * M + j]]++;
+                const int W = *std::max_element(cntp.begin(), cntp.end());
+                if (use_narrow && nph[i] >= 8 && W * G <= LDPC_THREADS && W <= 255 && G <= 32)
+                {
+                    narrow[i] = (unsigned char)W;
+                    MB = std::max(MB, (int)nph[i] * W);
+                    narrow_layers++;
+                }
+            }
+            std::vector<unsigned short> snode((size_t)q * MB * 4 * DQ, 0xFFFFu);
+            for (int i = 0; i < q; i++)
+            {
+                if (!narrow[i])
+                    continue;
+                const int W = narrow[i];
+                std::vector<int> slot(nph[i], 0);
+                for (int j = 0; j < M; j++)
+                {
+                    const int ph = phase[(size_t)i * M + j];
+                    const size_t k = (size_t)ph * W + slot[ph]++;
+                    unsigned short *e = &snode[((size_t)i * MB + k) * 4 * DQ];
+                    const int cnt = cn[i];
+                    for (int d = 0; d < cnt; d++)
+                        e[d] = pos[((size_t)i * CNL + d) * M + j];
+                    e[cnt] = (unsigned short)(K + M * i + j); // the check's own parity bit
+                    if ((i | j) != 0)                        // and its predecessor's (layered_decoder.hh:157-159; check (0, 0) has none)
+                        e[cnt + 1] = (unsigned short)(i ? K + M * (i - 1) + j : K + (q - 1) * M + j - 1);
+                }
+            }
+            d_narrow.reserve(q);
+            d_snode.reserve(snode.size());
+            SD_HIP(hipMemcpy(d_narrow.p, narrow.data(), q, hipMemcpyHostToDevice));
+            SD_HIP(hipMemcpy(d_snode.p, snode.data(), snode.size() * sizeof(unsigned short), hipMemcpyHostToDevice));
             d_pos.reserve(pos.size());
             d_cnc.reserve(q);
             d_nph.reserve(q);
@@ -323,14 +545,14 @@ namespace sdhip
             SD_HIP(hipMemcpy(d_cnc.p, cnc.data(), q, hipMemcpyHostToDevice));
             SD_HIP(hipMemcpy(d_nph.p, nph.data(), q, hipMemcpyHostToDevice));
             SD_HIP(hipMemcpy(d_phase.p, phase.data(), phase.size(), hipMemcpyHostToDevice));
-            g = LdpcDev{M, N, K, R, q, CNL, DQ, d_pos.p, d_cnc.p, d_phase.p, d_nph.p};
+            g = LdpcDev{M, N, K, R, q, CNL, DQ, d_pos.p, d_cnc.p, d_phase.p, d_nph.p, MB, G, d_narrow.p, d_snode.p};
             info.code_len = N;
             info.data_len = K;
             info.layers = q;
             info.links_total = tab->links_total;
             info.max_phases = max_phases;
             info.layers_with_shared_bits = conflict_layers;
-            info.msg_bytes_per_frame = (uint64_t)q * DQ * M * 4;
+            info.msg_bytes_per_frame = (uint64_t)q * DQ * M * 4; // (what the decoder reads and writes; the allocation is padded to MB checks per layer)
         }
         ~LdpcEngine()
         {
@@ -348,7 +570,12 @@ namespace sdhip
                 throw HipError("dvbs2 ldpc: the frame count must be a multiple of the batch");
             if (max_trials < 0)
                 max_trials = 0;
-            const size_t per = (size_t)g.q * g.DQ * g.M;
+            if (getenv("SDHIP_LDPC_PROBE") && !d_probe.p)
+            {
+                d_probe.reserve(8);
+                SD_HIP(hipMemset(d_probe.p, 0, 8 * sizeof(long long)));
+            }
+            const size_t per = (size_t)g.q * g.DQ * g.MB;
             d_bnl.reserve(per * nframes);
             d_flags.reserve(3 * (size_t)nframes + 8);
             SD_HIP(hipMemsetAsync(d_bnl.p, 0, per * nframes * sizeof(unsigned), stream)); // reset(): bnl = 0
@@ -373,6 +600,13 @@ namespace sdhip
             const int nb = nframes / cfg.batch;
             hipLaunchKernelGGL(k_ldpc_result, dim3((nb + 63) / 64), dim3(64), 0, stream, nb, cfg.batch, (ran & 1) ? bad1 : bad0, upd, d_trials_out);
             SD_HIP(hipStreamSynchronize(stream));
+            if (d_probe.p)
+            {
+                long long h[8];
+                SD_HIP(hipMemcpy(h, d_probe.p, sizeof(h), hipMemcpyDeviceToHost));
+                fprintf(stderr, "[sdhip] ldpc probe (ticks, workgroup 0, %lld launches of which %lld updating): frame in %lld, load wait %lld, phases %lld, stores %lld, parity check %lld, frame out %lld\n",
+                        h[7], h[6], h[0], h[1], h[2], h[3], h[4], h[5]);
+            }
             return ran;
         }
         void launch_trial(signed char *d_fr, int nframes, int t, const int *prev, int *cur, int *upd, int *any)
@@ -380,7 +614,7 @@ namespace sdhip
             const dim3 grid((unsigned)nframes), block(LDPC_THREADS);
 #define SD_LDPC_CASE(D)                                                                                                                      \
     case D:                                                                                                                                  \
-        hipLaunchKernelGGL((k_ldpc_trial<D>), grid, block, 0, stream, g, d_fr, d_bnl.p, nframes, cfg.batch, t, prev, cur, upd, any);          \
+        hipLaunchKernelGGL((k_ldpc_trial<D>), grid, block, 0, stream, g, d_fr, d_bnl.p, nframes, cfg.batch, t, prev, cur, upd, any, d_probe.p); \
         break;
             switch (g.DQ)
             {

@@ -205,7 +205,7 @@ inline unsigned emu_perm(unsigned s0, unsigned s1, unsigned sel)
 #define __builtin_amdgcn_readlane emu_readlane
 #define __builtin_amdgcn_update_dpp emu_update_dpp
 #define __builtin_amdgcn_perm emu_perm
-#define __builtin_amdgcn_wave_barrier() ((void)0)
+#define __builtin_amdgcn_wave_barrier() ((void)emu_ballot(1)) // the wave's lanes meet: what lockstep execution gives the hardware for free (one lane's LDS write before another lane's next read)
 #define __builtin_amdgcn_fence(...) ((void)0)
 inline void __threadfence() {}
 inline void __threadfence_block() {}
