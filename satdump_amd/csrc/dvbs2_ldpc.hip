@@ -83,8 +83,11 @@ namespace sdhip
         {
             int min0 = 255, min1 = 255;
             unsigned signs = 0;
+            unsigned iw[DQ]; // the links' inputs, four per dword: the second loop takes them from here instead of reading and subtracting again
 #pragma unroll
             for (int w = 0; w < DQ; w++)
+            {
+                iw[w] = 0;
 #pragma unroll
                 for (int b = 0; b < 4; b++)
                 {
@@ -92,6 +95,7 @@ namespace sdhip
                     if (d < deg)
                     {
                         const int inp = q8((int)llr[node(d)] - (int)(signed char)(bw[w] >> (8 * b)));
+                        iw[w] |= ((unsigned)inp & 0xFFu) << (8 * b);
                         int mag = inp < -127 ? 127 : (inp < 0 ? -inp : inp); // vqabs
                         mag = mag > 0 ? mag - 1 : 0;                          // unsigned saturating - beta, beta = nearbyint(0.5 * 2) = 1
                         // mins[1] = min(mins[1], max(mins[0], mag)); mins[0] = min(mins[0], mag) (the first two: min / max of the pair)
@@ -101,6 +105,7 @@ namespace sdhip
                         signs ^= (unsigned)inp;
                     }
                 }
+            }
 #pragma unroll
             for (int w = 0; w < DQ; w++)
             {
@@ -112,7 +117,7 @@ namespace sdhip
                     if (d < deg)
                     {
                         const int n = node(d);
-                        const int inp = q8((int)llr[n] - (int)(signed char)(bw[w] >> (8 * b)));
+                        const int inp = (int)(signed char)(iw[w] >> (8 * b));
                         int mag = inp < -127 ? 127 : (inp < 0 ? -inp : inp);
                         mag = mag > 0 ? mag - 1 : 0;
                         const int other = mag == min0 ? min1 : min0;
@@ -305,9 +310,24 @@ namespace sdhip
         lap(0);
         if (active)
         {
+            // a wide layer's message words, node indices and phases are fetched one layer AHEAD (they do not depend on the layer in between: the
+            // messages are the previous pass's), so that their HBM / L2 latency is not paid in front of every layer
+            LdpcCheck<DQ> ck, nx;
+            int my = -1, my_nx = -1;
+            auto fetch = [&](int i, LdpcCheck<DQ> &c, int &m) {
+                m = -1;
+                if (i < g.q && !g.narrow[i] && tid < g.M)
+                {
+                    m = (int)g.phase[i * g.M + tid];
+                    c.load(g, bnl_f, i, tid);
+                }
+            };
+            fetch(0, ck, my);
             for (int i = 0; i < g.q; i++)
             {
                 const int nph = g.nph[i];
+                fetch(i + 1, nx, my_nx);
+                lap(1); // (issue only: what of the loads' latency is not hidden shows up in the phases)
                 if (g.narrow[i])
                 { // many phases of a few checks: a link per lane (see LdpcDev)
                     switch (g.G)
@@ -327,33 +347,35 @@ namespace sdhip
                     }
                     __syncthreads();
                     lap(2);
-                    continue;
                 }
-                const int my = tid < g.M ? (int)g.phase[i * g.M + tid] : -1;
-                LdpcCheck<DQ> ck;
-                if (my >= 0)
-                    ck.load(g, bnl_f, i, tid);
-                if (probe)
+                else
                 {
-                    ldpc_wait_loads();
-                    lap(1);
+                    for (int ph = 0; ph < nph; ph++)
+                    {
+                        if (my == ph)
+                            ck.update(llr);
+                        __syncthreads();
+                    }
+                    lap(2);
+                    if (my >= 0)
+                        ck.store(g, bnl_f, i, tid);
+                    lap(3);
                 }
-                for (int ph = 0; ph < nph; ph++)
-                {
-                    if (my == ph)
-                        ck.update(llr);
-                    __syncthreads();
-                }
-                lap(2);
-                if (my >= 0)
-                    ck.store(g, bnl_f, i, tid);
-                lap(3);
+                ck = nx;
+                my = my_nx;
             }
         }
         bool bad = false;
         if (tid < g.M)
-            for (int i = 0; i < g.q && !bad; i++)
-                bad = ldpc_check_bad(g, llr, i, tid);
+            for (int i = 0; i < g.q && !bad; i += 4)
+            { // four layers between two looks at the result: their address loads overlap instead of waiting for each other
+                bool b4 = false;
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+                    if (i + k < g.q)
+                        b4 |= ldpc_check_bad(g, llr, i + k, tid);
+                bad = b4;
+            }
         const int any = __syncthreads_or(bad ? 1 : 0);
         lap(4);
         if (active)
