@@ -272,7 +272,19 @@ namespace sdhip
                                                                  int *bad_cur, int *updates, int *any_bad, long long *probe)
     {
         __shared__ signed char llr[64800];
+        // the per-layer bytes (data bits per check, phases, narrow width) in LDS: read in front of every layer, they each cost an L2 round trip
+        // on the critical path when they come from memory
+        __shared__ unsigned char s_layer[3][256];
         const int f = (int)blockIdx.x, tid = (int)threadIdx.x;
+        if (tid < g.q)
+        {
+            s_layer[0][tid] = g.cnc[tid];
+            s_layer[1][tid] = g.nph[tid];
+            s_layer[2][tid] = g.narrow[tid];
+        }
+        g.cnc = s_layer[0];
+        g.nph = s_layer[1];
+        g.narrow = s_layer[2];
         const bool pr = probe != nullptr && f == 0 && tid == 0;
         long long pc[6] = {0, 0, 0, 0, 0, 0}, pt = probe ? ldpc_clock() : 0;
         auto lap = [&](int k) {
@@ -322,12 +334,8 @@ namespace sdhip
                     c.load(g, bnl_f, i, tid);
                 }
             };
-            fetch(0, ck, my);
-            for (int i = 0; i < g.q; i++)
-            {
+            auto layer = [&](int i, LdpcCheck<DQ> &c, int m) {
                 const int nph = g.nph[i];
-                fetch(i + 1, nx, my_nx);
-                lap(1); // (issue only: what of the loads' latency is not hidden shows up in the phases)
                 if (g.narrow[i])
                 { // many phases of a few checks: a link per lane (see LdpcDev)
                     switch (g.G)
@@ -352,30 +360,35 @@ namespace sdhip
                 {
                     for (int ph = 0; ph < nph; ph++)
                     {
-                        if (my == ph)
-                            ck.update(llr);
+                        if (m == ph)
+                            c.update(llr);
                         __syncthreads();
                     }
                     lap(2);
-                    if (my >= 0)
-                        ck.store(g, bnl_f, i, tid);
+                    if (m >= 0)
+                        c.store(g, bnl_f, i, tid);
                     lap(3);
                 }
-                ck = nx;
-                my = my_nx;
+            };
+            // (two register sets taking turns: copying one into the other would wait for its loads)
+            fetch(0, ck, my);
+            for (int i = 0; i < g.q; i += 2)
+            {
+                fetch(i + 1, nx, my_nx);
+                lap(1); // (issue only: what of the loads' latency is not hidden shows up in the phases)
+                layer(i, ck, my);
+                if (i + 1 < g.q)
+                {
+                    fetch(i + 2, ck, my);
+                    lap(1);
+                    layer(i + 1, nx, my_nx);
+                }
             }
         }
         bool bad = false;
         if (tid < g.M)
-            for (int i = 0; i < g.q && !bad; i += 4)
-            { // four layers between two looks at the result: their address loads overlap instead of waiting for each other
-                bool b4 = false;
-#pragma unroll
-                for (int k = 0; k < 4; k++)
-                    if (i + k < g.q)
-                        b4 |= ldpc_check_bad(g, llr, i + k, tid);
-                bad = b4;
-            }
+            for (int i = 0; i < g.q && !bad; i++)
+                bad = ldpc_check_bad(g, llr, i, tid);
         const int any = __syncthreads_or(bad ? 1 : 0);
         lap(4);
         if (active)
@@ -472,6 +485,8 @@ namespace sdhip
             }
             if (bit != K)
                 throw HipError("dvbs2 ldpc: table inconsistent (bit count)");
+            if (q > 256)
+                throw HipError("dvbs2 ldpc: more layers than the kernel's per-layer table holds");
             std::vector<unsigned char> cnc(q), nph(q, 1), phase((size_t)q * M, 0);
             std::vector<unsigned short> pos((size_t)q * CNL * M, 0);
             for (int i = 0; i < q; i++)
