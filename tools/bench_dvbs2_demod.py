@@ -33,6 +33,7 @@ def parse(argv=None):
     ap.add_argument("--batch", type=int, default=16, help="frames per LDPC decode call of the reference build being replaced (SSE4.1: 16)")
     ap.add_argument("--freq-prop", type=float, default=0.0, help="the module's freq_prop_factor (default 0: what the reference chain beside it can be run with)")
     ap.add_argument("--cpu-frames", type=int, default=64, help="frames' worth of samples the reference chain decodes on the host (0 = skip)")
+    ap.add_argument("--cpu-procs", type=int, default=-1, help="all-cores leg: that many processes run the reference chain at once (-1 = one per core up to 128, 0 = skip)")
     ap.add_argument("--exact", type=int, default=0)
     return ap.parse_args(argv)
 
@@ -128,24 +129,8 @@ def run(args) -> dict:
     if args.cpu_frames > 0:
         m = min(n, args.cpu_frames * raw * SPS)
         xs = torch.view_as_complex(d_x[:m]).cpu().numpy()
-        orc = pyref.best()
-        fec = pyref.Dvbs2Ref(pyref.Dvbs2Ref.available(True) and args.batch == 16)
-        rc = c["rate"]
-        nl, kl = fec.dims(0, rc)
-        kb = fec.bch_kbch(0, rc)
-        t1 = time.perf_counter()
-        xr = orc.block(3, [float(SPS), (1.7e-3) ** 2 / 4, 0.5, 1.7e-3, 0.005], orc.block(1, [SYMRATE * SPS, SYMRATE, ALPHA, 31], orc.block(0, [1e-2, 1.0, 1.0, 65536.0], xs)))
-        t2 = time.perf_counter()
-        fr, _, _ = pyref.s2_pl_sync_ref(c["slots"], 0, 0.6, xr)
-        rp, _, _ = pyref.s2_pll_ref(MODCOD, 0, 0, LOOP_BW, fr)
-        soft, _ = fref.bb_to_soft(MODCOD, 0, 0, rp)
-        nfull = len(soft) // fec.batch * fec.batch
-        t3 = time.perf_counter()
-        dec, tr = fec.ldpc_decode(0, rc, soft[:nfull].copy(), args.trials)
-        t4 = time.perf_counter()
-        fix, _ = fec.bch_decode(0, rc, np.packbits((dec < 0).astype(np.uint8), axis=1)[:, :kl // 8].copy())
-        want = fec.bb_descramble(0, rc, fix.copy())[:, :kb // 8]
-        t5 = time.perf_counter()
+        import dvbs2_cpu_chain as cc
+        want, nxr, stage, tr, fbatch = cc.chain(xs, MODCOD, SYMRATE, SPS, ALPHA, LOOP_BW, args.trials, args.batch)
         whits = [sent.get(bytes(r), -1) for r in want]
         first = firsts[0] if firsts else got
         # the reference's k-th frame is the stream's k-th PLFRAME (both PL synchronisers emit the same frames; tests/test_dvbs2_gpu.py): compare position by
@@ -153,11 +138,28 @@ def run(args) -> dict:
         fhits = [sent.get(bytes(r), -1) for r in first[:len(want)]]
         common = [k for k in range(min(len(want), len(first))) if whits[k] >= 0]
         same = all(np.array_equal(want[k], first[k]) for k in common)
-        out["cpu_baseline"] = {"value": round(len(xr) / (t5 - t1) / 1e6, 3), "unit": "Msym/s", "cores": 1, "kind": "reference",
-                               "sample": f"the first {m} samples ({args.cpu_frames} frames' worth): AGC, RRC filter, M&M, S2PLSyncBlock, S2PLLBlock, S2BBToSoft, BBFrameLDPC (SIMD width {fec.batch}), "
+        out["cpu_baseline"] = {"value": round(nxr / stage["total"] / 1e6, 3), "unit": "Msym/s", "cores": 1, "kind": "reference",
+                               "sample": f"the first {m} samples ({args.cpu_frames} frames' worth): AGC, RRC filter, M&M, S2PLSyncBlock, S2PLLBlock, S2BBToSoft, BBFrameLDPC (SIMD width {fbatch}), "
                                          "BBFrameBCH, BB descrambler, one after the other on one thread",
-                               "stage_seconds": {"front_end": round(t2 - t1, 3), "sync_pll_demap": round(t3 - t2, 3), "ldpc": round(t4 - t3, 3), "bch_descramble": round(t5 - t4, 3)},
-                               "ldpc_trials": [int(v) for v in tr[:8]]}
+                               "stage_seconds": {k: v for k, v in stage.items() if k != "total"}, "ldpc_trials": [int(v) for v in tr[:8]]}
+        if args.cpu_procs != 0:
+            # the same chain in P independent processes at once (an instance per core: what the host does flat out), on the same sample
+            import subprocess
+            import tempfile
+            P = args.cpu_procs if args.cpu_procs > 0 else max(1, min(os.cpu_count() or 1, 128))
+            with tempfile.TemporaryDirectory() as td:
+                f = os.path.join(td, "x.npy")
+                np.save(f, xs)
+                cmd = [sys.executable, os.path.join(ROOT, "tools", "dvbs2_cpu_chain.py"), f, str(MODCOD), str(SYMRATE), str(SPS), str(ALPHA), str(LOOP_BW), str(args.trials), str(args.batch)]
+                tw = time.perf_counter()
+                procs = [subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True) for _ in range(P)]
+                outs_p = [p.communicate()[0] for p in procs]
+                wall = time.perf_counter() - tw
+            good = [o.split() for o in outs_p if o.strip()]
+            if good:
+                out["cpu_baseline"]["all_cores"] = {"value": round(sum(float(g[1]) for g in good) / wall / 1e6, 2), "unit": "Msym/s", "cores": len(good), "host_cores": os.cpu_count(),
+                                                    "sample": f"{len(good)} independent processes x the same {m} samples in {wall:.1f} s wall (process start-up included)",
+                                                    "slowest_chain_s": round(max(float(g[0]) for g in good), 2)}
         out["parity_sample"] = {"reference_frames": int(len(want)), "reference_frames_that_are_transmitted_ones": int(sum(h >= 0 for h in whits)),
                                 "reference_hits": whits, "our_hits_on_the_same_positions": fhits,
                                 "frames_compared": len(common), "byte_identical": bool(same and len(common) >= 1)}
