@@ -28,7 +28,8 @@ namespace sdhip
     struct LdpcDev
     {
         int M, N, K, R, q, CNL, DQ;
-        const unsigned short *pos;  // [q][CNL][M] data bit of check (layer, check) slot c
+        const unsigned *ndp;        // [q][2 * DQ][M] the nodes of links 2h (low half) and 2h + 1 (high half) of check (layer, check): its data bits in bit
+                                    // order, then its own parity bit, then its predecessor's; 0xFFFF = no such link
         const unsigned char *cnc;   // [q] data bits per check of the layer
         const unsigned char *phase; // [q][M] phase of a check inside its layer (0 unless it shares a bit with a lower-numbered one)
         const unsigned char *nph;   // [q] phases of the layer
@@ -56,27 +57,12 @@ namespace sdhip
         {
             const int cnt = g.cnc[i];
             deg = cnt + 2 - ((i | j) == 0 ? 1 : 0);
-            const int par0 = g.K + g.M * i + j;
-            const int par1 = i ? g.K + g.M * (i - 1) + j : g.K + (g.q - 1) * g.M + j - 1;
 #pragma unroll
             for (int w = 0; w < DQ; w++)
                 bw[w] = 4 * w < deg ? bnl_f[((size_t)i * DQ + w) * g.MB + j] : 0u;
 #pragma unroll
             for (int h = 0; h < 2 * DQ; h++)
-            {
-                unsigned v = 0;
-#pragma unroll
-                for (int b = 0; b < 2; b++)
-                {
-                    const int d = 2 * h + b;
-                    if (d < deg)
-                    {
-                        const int n = d < cnt ? (int)g.pos[((size_t)i * g.CNL + d) * g.M + j] : (d == cnt ? par0 : par1);
-                        v |= (unsigned)n << (16 * b);
-                    }
-                }
-                nd[h] = v;
-            }
+                nd[h] = g.ndp[((size_t)i * 2 * DQ + h) * g.M + j];
         }
         __device__ __forceinline__ int node(int d) const { return (int)((nd[d >> 1] >> (16 * (d & 1))) & 0xFFFFu); }
         __device__ __forceinline__ void update(signed char *llr)
@@ -149,13 +135,16 @@ namespace sdhip
             zero |= v == 0;
             neg ^= v < 0 ? 1 : 0;
         };
-        take(llr[g.K + g.M * i + j]);
-        if (i)
-            take(llr[g.K + g.M * (i - 1) + j]);
-        else if (j)
-            take(llr[g.K + (g.q - 1) * g.M + j - 1]);
-        for (int c = 0; c < cnt; c++)
-            take(llr[g.pos[((size_t)i * g.CNL + c) * g.M + j]]);
+        const int nh = (cnt + 2 + 1) >> 1;
+        for (int h = 0; h < nh; h++)
+        {
+            const unsigned w = g.ndp[((size_t)i * 2 * g.DQ + h) * g.M + j];
+            const unsigned n0 = w & 0xFFFFu, n1 = w >> 16;
+            if (n0 != 0xFFFFu)
+                take(llr[n0]);
+            if (n1 != 0xFFFFu)
+                take(llr[n1]);
+        }
         return zero || neg;
     }
 
@@ -437,7 +426,7 @@ namespace sdhip
         hipStream_t stream = nullptr;
         const S2Table *tab = nullptr;
         LdpcDev g{};
-        DevBuf<unsigned short> d_pos;
+        DevBuf<unsigned> d_ndp;
         DevBuf<unsigned char> d_cnc, d_phase, d_nph, d_narrow;
         DevBuf<unsigned short> d_snode;
         int narrow_layers = 0;
@@ -570,19 +559,34 @@ namespace sdhip
                         e[cnt + 1] = (unsigned short)(i ? K + M * (i - 1) + j : K + (q - 1) * M + j - 1);
                 }
             }
+            std::vector<unsigned> ndp((size_t)q * 2 * DQ * M, 0xFFFFFFFFu);
+            for (int i = 0; i < q; i++)
+                for (int j = 0; j < M; j++)
+                {
+                    const int cnt = cn[i];
+                    auto put = [&](int d, unsigned n) {
+                        unsigned &w = ndp[((size_t)i * 2 * DQ + (d >> 1)) * M + j];
+                        w = (d & 1) ? ((w & 0x0000FFFFu) | (n << 16)) : ((w & 0xFFFF0000u) | n);
+                    };
+                    for (int d = 0; d < cnt; d++)
+                        put(d, pos[((size_t)i * CNL + d) * M + j]);
+                    put(cnt, (unsigned)(K + M * i + j));
+                    if ((i | j) != 0)
+                        put(cnt + 1, (unsigned)(i ? K + M * (i - 1) + j : K + (q - 1) * M + j - 1));
+                }
+            d_ndp.reserve(ndp.size());
+            SD_HIP(hipMemcpy(d_ndp.p, ndp.data(), ndp.size() * sizeof(unsigned), hipMemcpyHostToDevice));
             d_narrow.reserve(q);
             d_snode.reserve(snode.size());
             SD_HIP(hipMemcpy(d_narrow.p, narrow.data(), q, hipMemcpyHostToDevice));
             SD_HIP(hipMemcpy(d_snode.p, snode.data(), snode.size() * sizeof(unsigned short), hipMemcpyHostToDevice));
-            d_pos.reserve(pos.size());
             d_cnc.reserve(q);
             d_nph.reserve(q);
             d_phase.reserve(phase.size());
-            SD_HIP(hipMemcpy(d_pos.p, pos.data(), pos.size() * sizeof(unsigned short), hipMemcpyHostToDevice));
             SD_HIP(hipMemcpy(d_cnc.p, cnc.data(), q, hipMemcpyHostToDevice));
             SD_HIP(hipMemcpy(d_nph.p, nph.data(), q, hipMemcpyHostToDevice));
             SD_HIP(hipMemcpy(d_phase.p, phase.data(), phase.size(), hipMemcpyHostToDevice));
-            g = LdpcDev{M, N, K, R, q, CNL, DQ, d_pos.p, d_cnc.p, d_phase.p, d_nph.p, MB, G, d_narrow.p, d_snode.p};
+            g = LdpcDev{M, N, K, R, q, CNL, DQ, d_ndp.p, d_cnc.p, d_phase.p, d_nph.p, MB, G, d_narrow.p, d_snode.p};
             info.code_len = N;
             info.data_len = K;
             info.layers = q;

@@ -142,7 +142,7 @@ def test_symbols_to_bbframes_on_the_twin(capi):
 
 @pytest.mark.parametrize("front", ["exact", "chunk"])
 def test_baseband_to_bbframes_on_the_twin(capi, front):
-    G.check_symbols_to_bbframes(capi, *_np_helpers(), nfr=10, via_baseband=front)
+    G.check_symbols_to_bbframes(capi, *_np_helpers(), nfr=7, via_baseband=front)
 
 
 class _NumpyMem:
@@ -175,17 +175,17 @@ def test_pll_parallel_on_the_twin(capi, modcod, short, esn0_db, nfr, lane_len):
 
 
 def test_dvbs2_engine_parallel_on_the_twin(capi):
-    st = G.check_dvbs2_engine(capi, _NumpyMem, modcod=12, short=1, nfr=16, esn0_db=10.0, acq=3 * 5490)
+    st = G.check_dvbs2_engine(capi, _NumpyMem, modcod=12, short=1, nfr=10, esn0_db=10.0, acq=3 * 5490)
     assert st["pll_serial_frames"] == 3
 
 
 def test_dvbs2_engine_ragged_calls_on_the_twin(capi):
-    G.check_dvbs2_engine(capi, _NumpyMem, modcod=12, short=1, nfr=16, esn0_db=10.0, cuts=[0, 40001, 40002, 123457, 16 * 5490 * 2 + 3 * 5490 * 2], acq=3 * 5490)
+    G.check_dvbs2_engine(capi, _NumpyMem, modcod=12, short=1, nfr=10, esn0_db=10.0, cuts=[0, 40001, 40002, 83457, 10 * 5490 * 2 + 3 * 5490 * 2], acq=3 * 5490)
 
 
 def test_dvbs2_engine_freq_prop_on_the_twin(capi):
-    G.check_dvbs2_engine(capi, _NumpyMem, modcod=4, short=1, nfr=30, esn0_db=7.0, freq_prop=0.05, acq=3 * 8190, cfo_hz=50.0,
-                         cuts=[0] + [8190 * 2 * 5 * k for k in range(1, 7)] + [33 * 8190 * 2])
+    G.check_dvbs2_engine(capi, _NumpyMem, modcod=4, short=1, nfr=20, esn0_db=7.0, freq_prop=0.08, acq=3 * 8190, cfo_hz=50.0,
+                         cuts=[0] + [8190 * 2 * 5 * k for k in range(1, 5)] + [23 * 8190 * 2])
 
 
 def test_bb_to_soft_golden_on_the_twin(capi):

@@ -85,7 +85,7 @@ def test_dvbs2_module_through_the_plugin_on_the_twin(host, tmp_path):
     from tests.emu import build as emu_build
     if not (pyref.Dvbs2Ref.available(False) and pyref.S2FrontRef.available()) or not os.path.exists(emu_build.CLANG):
         pytest.skip("needs the compiled reference DVB-S2 classes and a host clang++")
-    G.check_dvbs2_module_through_the_plugin(host, emu_build.build(), tmp_path)
+    G.check_dvbs2_module_through_the_plugin(host, emu_build.build(), tmp_path, nfr=10, extra_legs=False)
 
 
 def test_hip_devices_through_the_plugin_on_the_twin(host, tmp_path):

@@ -276,7 +276,7 @@ def test_ndsp_block_through_the_plugin(host, tmp_path):
     check_ndsp_block_through_the_plugin(host, LIB, tmp_path)
 
 
-def check_dvbs2_module_through_the_plugin(host, lib, tmp_path, modcod=12, short=1, nfr=16, acq=3 * 5490):
+def check_dvbs2_module_through_the_plugin(host, lib, tmp_path, modcod=12, short=1, nfr=16, acq=3 * 5490, extra_legs=True):
     """BASELINE configs[4]'s module through the drop-in boundary: the stock id `dvbs2_demod`, re-pointed by the plugin under SDHIP_OVERRIDE=1 at
     DVBS2DemodHipModule (plugin/sdhip_plugin.cpp), reads a baseband file of 8PSK PLFRAMEs and writes a .bbframe file -- against the reference's
     blocks and classes chained the way DVBS2DemodModule chains them (module_dvbs2_demod.cpp:98-137, 239-293). The demapper table is built by the
@@ -324,18 +324,19 @@ def check_dvbs2_module_through_the_plugin(host, lib, tmp_path, modcod=12, short=
     gfound = [h for h in ghits if h >= 0]
     assert gfound == sorted(gfound) and set(gfound) >= set(h for h in whits if h >= 0) - {min(h for h in whits if h >= 0)}, (ghits, whits)
     assert rep["demod_stats"]["peak_snr"] > 5.0
-    cs = synth.to_cs16(bbx)
-    (tmp_path / "dvbs2.cs16").write_bytes(cs.tobytes())
-    job_in = str(tmp_path / "dvbs2.cs16")
-    job = {"mode": "file", "input": job_in, "output_hint": str(tmp_path / "c16"), "demod": {"module": "dvbs2_demod", "parameters": dict(params, baseband_format="cs16")}}
-    (tmp_path / "c16.json").write_text(json.dumps(job))
-    p = subprocess.run([host, lib, PLUGIN, "run", str(tmp_path / "c16.json")], capture_output=True, text=True, env=dict(os.environ, SDHIP_OVERRIDE="1", SDHIP_S2PLL_ACQ=str(acq)), timeout=900)
-    assert p.returncode == 0, p.stdout[-1000:] + p.stderr[-3000:]
-    got16 = np.fromfile(json.loads(p.stdout.strip().splitlines()[-1])["soft"], dtype=np.uint8).reshape(-1, kb)
-    assert sum(bytes(r) in sent for r in got16) >= len(gfound) - 1
-    # the groups of the reference's SSE4.1 build (16 frames per decode call): a trailing partial group is never written, as in process_s2
-    p, rep = run({"hip_ldpc_batch": 16}, "b16")
-    assert p.returncode == 0 and os.path.getsize(rep["soft"]) == (len(got) // 16) * 16 * kb
+    if extra_legs:  # (the host twin runs the first two legs only: each is a minute of emulated kernels)
+        cs = synth.to_cs16(bbx)
+        (tmp_path / "dvbs2.cs16").write_bytes(cs.tobytes())
+        job_in = str(tmp_path / "dvbs2.cs16")
+        job = {"mode": "file", "input": job_in, "output_hint": str(tmp_path / "c16"), "demod": {"module": "dvbs2_demod", "parameters": dict(params, baseband_format="cs16")}}
+        (tmp_path / "c16.json").write_text(json.dumps(job))
+        p = subprocess.run([host, lib, PLUGIN, "run", str(tmp_path / "c16.json")], capture_output=True, text=True, env=dict(os.environ, SDHIP_OVERRIDE="1", SDHIP_S2PLL_ACQ=str(acq)), timeout=900)
+        assert p.returncode == 0, p.stdout[-1000:] + p.stderr[-3000:]
+        got16 = np.fromfile(json.loads(p.stdout.strip().splitlines()[-1])["soft"], dtype=np.uint8).reshape(-1, kb)
+        assert sum(bytes(r) in sent for r in got16) >= len(gfound) - 1
+        # the groups of the reference's SSE4.1 build (16 frames per decode call): a trailing partial group is never written, as in process_s2
+        p, rep = run({"hip_ldpc_batch": 16}, "b16")
+        assert p.returncode == 0 and os.path.getsize(rep["soft"]) == (len(got) // 16) * 16 * kb
     # the module's own messages; what the HIP path does not carry stays with the CPU module
     bad = dict(params)
     del bad["modcod"]
