@@ -55,8 +55,11 @@ extern "C"
     {
         SDHIP_DEC_CONV_CONCAT = 0, /* ccsds_conv_concat_decoder: Viterbi1_2 r=1/2 */
         SDHIP_DEC_METOP_AHRPT = 1, /* metop_ahrpt_decoder: Viterbi3_4 (MetOp puncture), deframer SYNCED=18, Viterbi watchdog */
-        SDHIP_DEC_SIMPLE_PSK = 2   /* ccsds_simple_psk_decoder: hard decisions (+NRZ-M / QPSK differential) -> deframer(s) -> derand -> RS
+        SDHIP_DEC_SIMPLE_PSK = 2,  /* ccsds_simple_psk_decoder: hard decisions (+NRZ-M / QPSK differential) -> deframer(s) -> derand -> RS
                                       (src-core/pipeline/modules/ccsds/module_ccsds_simple_psk_decoder.cpp:16-296) */
+        SDHIP_DEC_FENGYUN_AHRPT = 3 /* fengyun_ahrpt_decoder: a Viterbi3_4 (fymode) per QPSK rail, FengyunDiff::work2, deframer SYNCING=8 / SYNCED=16,
+                                      derand, RS223 I=4 (plugins/fengyun3_support/fengyun3/module_fengyun_ahrpt_decoder.cpp:14-126). Reads
+                                      viterbi_outsync_after, viterbi_ber_thresold, invert_second_viterbi; 16384 soft bytes per read */
     };
     enum
     {
@@ -243,6 +246,8 @@ extern "C"
         int conv_rate;
         /* engine knobs */
         int device;
+        /* fengyun_ahrpt_decoder only: "invert_second_viterbi" (module_fengyun_ahrpt_decoder.cpp:17,67) */
+        int invert_second_viterbi;
     } sdhip_fec_cfg;
 
     typedef struct sdhip_fec_stats
@@ -258,6 +263,8 @@ extern "C"
         int rs_errors[8];        /* last frame's per-codeword error counts (-1 = uncorrectable) */
         uint32_t vit_respec;     /* Viterbi blocks re-decoded because the start-state speculation failed */
         uint32_t tb_respec;      /* traceback segments re-run because the merge certificate failed */
+        float viterbi2_ber;      /* fengyun_ahrpt_decoder: "viterbi2_ber" / "viterbi2_lock" (viterbi_ber / viterbi_lock are its viterbi1_*) */
+        int viterbi2_lock;
     } sdhip_fec_stats;
 
     void sdhip_fec_cfg_default(sdhip_fec_cfg *cfg);
@@ -273,7 +280,7 @@ extern "C"
     int64_t sdhip_fec_process_dev(void *h, const int8_t *d_soft, size_t n, uint8_t *d_cadu, size_t cap_frames);
     int sdhip_fec_get_stats(void *h, sdhip_fec_stats *st);
     /* Optional per-block taps of the last process call (host arrays, may be NULL):
-       blk_ber[nblocks], blk_state[nblocks]. Returns number of blocks. */
+       blk_ber[nblocks], blk_state[nblocks]. Returns number of blocks. (fengyun_ahrpt_decoder: two entries per read, Viterbi 1 then Viterbi 2.) */
     int64_t sdhip_fec_get_block_taps(void *h, float *blk_ber, int *blk_state, size_t cap);
 
     /* ---- kernel-level entry points (unit parity tests; each replaces one reference function) ---- */

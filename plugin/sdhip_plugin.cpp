@@ -610,9 +610,12 @@ namespace sdhip_plugin
                 }
             }
         }
-        std::atomic<float> viterbi_ber{10};
-        std::atomic<int> viterbi_lock{0}, deframer_state{0}, rs_avg{0};
+        std::atomic<float> viterbi_ber{10}, viterbi2_ber{10};
+        std::atomic<int> viterbi_lock{0}, viterbi2_lock{0}, deframer_state{0}, rs_avg{0};
         bool has_viterbi = true;
+        // what the module's soft buffer holds when the next read_data() lands in it (a short last read keeps the tail): the bytes just read, unless the
+        // module works on its buffer in place
+        virtual void keep_for_next_read(const int8_t *slot, int8_t *last) { memcpy(last, slot, (size_t)block_bytes); }
 
     public:
         FecHipModuleBase(std::string input_file, std::string output_file_hint, nlohmann::json parameters)
@@ -653,7 +656,7 @@ namespace sdhip_plugin
                     int8_t *slot = soft.data() + nb * (size_t)block_bytes;
                     memcpy(slot, last.data(), (size_t)block_bytes);
                     read_soft(slot, (size_t)block_bytes);
-                    memcpy(last.data(), slot, (size_t)block_bytes);
+                    keep_for_next_read(slot, last.data());
                     nb++;
                 }
                 if (nb == 0)
@@ -673,6 +676,8 @@ namespace sdhip_plugin
                 sdhip_fec_get_stats(h, &st);
                 viterbi_ber = st.viterbi_ber;
                 viterbi_lock = st.viterbi_lock;
+                viterbi2_ber = st.viterbi2_ber;
+                viterbi2_lock = st.viterbi2_lock;
                 deframer_state = st.deframer_state;
                 rs_avg = (st.rs_errors[0] + st.rs_errors[1] + st.rs_errors[2] + st.rs_errors[3]) / 4;
             }
@@ -842,6 +847,58 @@ namespace sdhip_plugin
         static std::shared_ptr<ProcessingModule> getInstance(std::string input_file, std::string output_file_hint, nlohmann::json parameters)
         {
             return std::make_shared<MetOpAHRPTDecoderHipModule>(input_file, output_file_hint, parameters);
+        }
+    };
+
+    // ------------------------------------------------------------------------------------------------ fengyun_ahrpt_decoder
+    // FengyunAHRPTDecoderModule (plugins/fengyun3_support/fengyun3/module_fengyun_ahrpt_decoder.{h,cpp}) on the FEC handle's SDHIP_DEC_FENGYUN_AHRPT: same
+    // mandatory keys ("viterbi_outsync_after", "viterbi_ber_thresold", "invert_second_viterbi"), .soft file / fifo in, .cadu out, the module's statistics keys.
+    class FengyunAHRPTDecoderHipModule : public FecHipModuleBase
+    {
+        // the module exchanges I and Q of its buffer IN PLACE before it splits the rails (rotate_soft, :60): a short last read lands on exchanged bytes
+        void keep_for_next_read(const int8_t *slot, int8_t *last) override
+        {
+            for (int i = 0; i < block_bytes; i += 2)
+            {
+                const int8_t a = slot[i] == -128 ? -127 : slot[i], b = slot[i + 1] == -128 ? -127 : slot[i + 1];
+                last[i] = b;
+                last[i + 1] = a;
+            }
+        }
+
+    public:
+        FengyunAHRPTDecoderHipModule(std::string input_file, std::string output_file_hint, nlohmann::json parameters)
+            : FecHipModuleBase(input_file, output_file_hint, parameters)
+        {
+            cfg.decoder = SDHIP_DEC_FENGYUN_AHRPT;
+            cfg.viterbi_outsync_after = parameters["viterbi_outsync_after"].get<int>(); // module_fengyun_ahrpt_decoder.cpp:16-17
+            cfg.viterbi_ber_thresold = parameters["viterbi_ber_thresold"].get<float>();
+            cfg.invert_second_viterbi = parameters["invert_second_viterbi"].get<bool>() ? 1 : 0;
+            fsfsm_file_ext = ".cadu";
+            block_bytes = 16384;
+            cadu_bytes = 1024;
+        }
+        nlohmann::json getModuleStats()
+        { // module_fengyun_ahrpt_decoder.cpp:128-145
+            auto v = base::FileStreamToFileStreamModule::getModuleStats();
+            const int ds = deframer_state.load();
+            v["deframer_lock"] = ds == 16;
+            v["viterbi1_ber"] = viterbi_ber.load();
+            v["viterbi1_lock"] = viterbi_lock.load();
+            v["viterbi2_ber"] = viterbi2_ber.load();
+            v["viterbi2_lock"] = viterbi2_lock.load();
+            v["rs_avg"] = rs_avg.load();
+            v["viterbi1_state"] = viterbi_lock.load() == 0 ? "NOSYNC" : "SYNCED";
+            v["viterbi2_state"] = viterbi2_lock.load() == 0 ? "NOSYNC" : "SYNCED";
+            v["deframer_state"] = ds <= 2 ? "NOSYNC" : (ds == 8 ? "SYNCING" : "SYNCED");
+            return v;
+        }
+        static std::string getID() { return "fengyun_ahrpt_decoder_hip"; }
+        virtual std::string getIDM() { return getID(); }
+        static nlohmann::json getParams() { return {}; }
+        static std::shared_ptr<ProcessingModule> getInstance(std::string input_file, std::string output_file_hint, nlohmann::json parameters)
+        {
+            return std::make_shared<FengyunAHRPTDecoderHipModule>(input_file, output_file_hint, parameters);
         }
     };
 
@@ -1223,6 +1280,7 @@ namespace sdhip_plugin
             REGISTER_MODULE_EXTERNAL(evt.modules_registry, CCSDSSimplePSKDecoderHipModule);
             REGISTER_MODULE_EXTERNAL(evt.modules_registry, DVBS2DemodHipModule);
             REGISTER_MODULE_EXTERNAL(evt.modules_registry, METEORLRPTDecoderHipModule);
+            REGISTER_MODULE_EXTERNAL(evt.modules_registry, FengyunAHRPTDecoderHipModule);
         }
         static void startedHandler(const satdump::SatDumpStartedEvent &)
         {
@@ -1263,6 +1321,8 @@ namespace sdhip_plugin
                 }
                 else if (e.id == "metop_ahrpt_decoder")
                     e.inst = MetOpAHRPTDecoderHipModule::getInstance;
+                else if (e.id == "fengyun_ahrpt_decoder") // plugins/fengyun3_support's module (ordering caveat as for metop_ahrpt_decoder)
+                    e.inst = FengyunAHRPTDecoderHipModule::getInstance;
                 else if (e.id == "dvbs2_demod")
                 { // plugins/dvb_support's module (registered by that plugin: the ordering caveat of metop_ahrpt_decoder applies). 32APSK, Doppler and
                   // custom_samplerate stay on the CPU module

@@ -17,7 +17,7 @@ BPSK, BPSK_90, QPSK, OQPSK, PSK8 = 0, 1, 2, 3, 4
 RS_NONE, RS223, RS239 = 0, 1, 2
 RATE_1_2, RATE_2_3, RATE_3_4, RATE_5_6, RATE_7_8 = 0, 1, 2, 3, 4
 FMT_CF32, FMT_CS16, FMT_CS8, FMT_CU8, FMT_CS32 = 0, 1, 2, 3, 4
-DEC_CONV_CONCAT, DEC_METOP_AHRPT, DEC_SIMPLE_PSK = 0, 1, 2
+DEC_CONV_CONCAT, DEC_METOP_AHRPT, DEC_SIMPLE_PSK, DEC_FENGYUN_AHRPT = 0, 1, 2, 3
 CONSTELLATIONS = {"bpsk": BPSK, "bpsk_90": BPSK_90, "qpsk": QPSK, "oqpsk": OQPSK, "8psk": PSK8}
 
 
@@ -49,7 +49,7 @@ class FecCfg(C.Structure):
         ("derand_after_rs", C.c_int), ("derand_start", C.c_int), ("rs_i", C.c_int), ("rs_fill_bytes", C.c_int),
         ("rs_dualbasis", C.c_int), ("rs_type", C.c_int), ("rs_usecheck", C.c_int), ("asm_sync", C.c_uint32),
         ("qpsk_swap_iq", C.c_int), ("qpsk_swap_diff", C.c_int), ("oqpsk_delay", C.c_int), ("oqpsk_method2", C.c_int), ("oqpsk_method3", C.c_int),
-        ("conv_rate", C.c_int), ("device", C.c_int),
+        ("conv_rate", C.c_int), ("device", C.c_int), ("invert_second_viterbi", C.c_int),
     ]
 
 
@@ -57,7 +57,7 @@ class FecStats(C.Structure):
     _fields_ = [
         ("soft_in", C.c_uint64), ("blocks", C.c_uint64), ("bits_decoded", C.c_uint64), ("frames_deframed", C.c_uint64),
         ("frames_out", C.c_uint64), ("viterbi_ber", C.c_float), ("viterbi_lock", C.c_int), ("deframer_state", C.c_int),
-        ("rs_errors", C.c_int * 8), ("vit_respec", C.c_uint32), ("tb_respec", C.c_uint32),
+        ("rs_errors", C.c_int * 8), ("vit_respec", C.c_uint32), ("tb_respec", C.c_uint32), ("viterbi2_ber", C.c_float), ("viterbi2_lock", C.c_int),
     ]
 
 
@@ -318,7 +318,7 @@ class FecDecoder:
         self.h = lib().sdhip_fec_create(C.byref(cfg))
         if not self.h:
             raise SdhipError(f"sdhip_fec_create failed: {last_error()}")
-        self.cadu_bytes = 1024 if cfg.decoder == DEC_METOP_AHRPT else cfg.cadu_size // 8
+        self.cadu_bytes = 1024 if cfg.decoder in (DEC_METOP_AHRPT, DEC_FENGYUN_AHRPT) else cfg.cadu_size // 8
 
     def close(self):
         if self.h:

@@ -250,7 +250,7 @@ namespace sdhip
         VitCfg vc{};
         int phases[4] = {0, 0, 0, 0};
         int nphases = 1, n_swap = 1;
-        int st_synced = 12;
+        int st_synced = 12, st_syncing = 6;
         double ber_mult = 2.5;
         int max_batch = getenv("SDHIP_FEC_BATCH") ? std::max(1, atoi(getenv("SDHIP_FEC_BATCH"))) : 65536; // blocks per Viterbi launch (decision scratch: 8 B per trellis step, ~2.2 GB at F = 4096)
 
@@ -283,6 +283,30 @@ namespace sdhip
             DevBuf<uint64_t> d_dec;
             DevBuf<uint32_t> d_vb_ber;
         } punc;
+
+        // fengyun_ahrpt_decoder (plugins/fengyun3_support/fengyun3/module_fengyun_ahrpt_decoder.cpp:46-126): two Viterbi3_4 (fymode) on the two rails of the
+        // QPSK stream, FengyunDiff::work2 on their outputs, then the common deframer / derandomiser / RS tail. Host = the two lock FSMs and the module's
+        // counters call by call; device = rail split, lock searches, decodes, BER sums, the differential decoder, everything behind it.
+        struct FyRail
+        {
+            int vstate = 0, v_shift = 0, v_invalid = 0; // d_state, d_shift, d_invalid
+            float v_ber = 10, bers[2] = {10, 10};       // d_ber, d_bers[0][shift] (phase 1 is never tried in fymode: stays 10)
+            int dec_first = 1, dec_start = 0;           // cc_decoder chaining
+            VitSearchState search{};                    // cc_decoder_ber / cc_encoder_ber
+            DevBuf<VitSearchState> d_search;
+            DevBuf<VitBlockIO> d_io;
+            PinBuf<VitBlockIO> h_io;
+            DevBuf<uint32_t> d_vb; // decoded bits, packed
+            DevBuf<int8_t> d_rail; // i_soft_buffer / q_soft_buffer of the blocks of one run
+            float ber() const { return vstate == 1 ? v_ber : std::min(10.0f, std::min(bers[0], bers[1])); } // Viterbi3_4::ber(), viterbi_3_4.cpp:173-188
+        };
+        struct Fy
+        {
+            FyRail rail[2];
+            VitCfg rvc{};
+            int shift = 0, invert_branches = 0, vit_nosync_run = 0; // the module's `shift`, `invert_branches`, `viterbiNoSyncRun` (`noSyncRuns` = metop_nosync_runs)
+            unsigned x_prev = 0, y_prev = 0;                        // FengyunDiff's Xin >> 1, Yin
+        } fy;
 
         // deframer
         DeframerState def;
@@ -393,6 +417,42 @@ namespace sdhip
                 phases[1] = 1;
                 n_swap = 1;
                 st_synced = 18;
+                cfg.cadu_size = 8192;
+                cadu_bytes = 1024;
+                cfg.nrzm = 0;
+                cfg.derandomize = 1;
+                cfg.derand_after_rs = 0;
+                cfg.derand_start = 4;
+                cfg.rs_i = 4;
+                cfg.rs_fill_bytes = 0;
+                cfg.rs_dualbasis = 1;
+                cfg.rs_type = SDHIP_RS223;
+                cfg.rs_usecheck = 0;
+                cfg.asm_sync = 0x1ACFFC1D;
+            }
+            else if (cfg.decoder == SDHIP_DEC_FENGYUN_AHRPT)
+            {
+                // FengyunAHRPTDecoderModule: BUFFER_SIZE 8192 symbols = 16384 soft bytes per read, Viterbi3_4(thr, outsync, 8192, fymode) per rail,
+                // deframer STATE_SYNCING = 8 / STATE_SYNCED = 16, derand from byte 4, RS223 dual basis I=4, every frame written
+                // (module_fengyun_ahrpt_decoder.cpp:10-24,46-54,112-121)
+                B = 16384;
+                F = 12288; // bits per read handed to the deframer: 2 x 6144
+                nber = 1536;
+                ber_mult = 5;
+                vc.mode = 1;
+                fy.rvc.mode = 1;
+                fy.rvc.fy = 1;
+                fy.rvc.B = 8192;
+                fy.rvc.F = 6144;
+                fy.rvc.nber = 1536;
+                for (FyRail &r : fy.rail)
+                {
+                    memset(&r.search, 0, sizeof(r.search));
+                    r.search.ber_first = 1;
+                    r.d_search.reserve(1);
+                }
+                st_syncing = 8;
+                st_synced = 16;
                 cfg.cadu_size = 8192;
                 cadu_bytes = 1024;
                 cfg.nrzm = 0;
@@ -684,7 +744,7 @@ namespace sdhip
                     const int64_t q = base_abs + (int64_t)(hits[hit_ptr] >> 1);
                     settle_blocks(q);
                     s.inv = (int)(hits[hit_ptr] & 1u);
-                    s.state = 6;
+                    s.state = st_syncing;
                     s.good = s.invalid = 0;
                     s.pending_start = q + 1;
                     s.next_check = q + CADU;
@@ -693,7 +753,7 @@ namespace sdhip
                 {
                     const uint32_t w = src.at(p - base_abs);
                     const int dist = __builtin_popcount(w ^ (s.inv ? ASMI : ASM));
-                    if (s.state == 6)
+                    if (s.state == st_syncing)
                     {
                         if (dist < s.state)
                         {
@@ -827,9 +887,10 @@ namespace sdhip
                             W.frames.size(), hs.have ? "used" : "not needed", hs.hits.size(), (long long)gp0, gK, WIN_OFFS);
                 tick("walk");
 
-                if (cfg.decoder == SDHIP_DEC_METOP_AHRPT)
+                if (cfg.decoder == SDHIP_DEC_METOP_AHRPT || cfg.decoder == SDHIP_DEC_FENGYUN_AHRPT)
                 {
                     // watchdog, module_metop_ahrpt_decoder.cpp:59-72: 10 consecutive calls ending in NOSYNC reset the Viterbi
+                    // (module_fengyun_ahrpt_decoder.cpp:97-109: ... exchange the differential decoder's two inputs from the next call on)
                     int runs = metop_nosync_runs, cut = -1;
                     for (int j = 0; j < n_eff; j++)
                     {
@@ -976,7 +1037,9 @@ namespace sdhip
                 carry_bits = nwords * 32;
                 abs_bits = avail_end;
                 stats.bits_decoded += (uint64_t)n_eff * F;
-                if (watchdog_fired)
+                if (watchdog_fired && cfg.decoder == SDHIP_DEC_FENGYUN_AHRPT)
+                    fy.invert_branches ^= 1;
+                else if (watchdog_fired)
                     vstate = 0; // viterbi.reset()
                 tick("carry");
                 return n_eff;
@@ -1593,8 +1656,234 @@ namespace sdhip
                 stats.rs_errors[k] = last_errors[k];
         }
 
+        // ------------------------------------------------------------------ one run of SYNCED blocks through the decoder
+        // Decodes blocks [pos, pos + n) of d_soft under `vc` into d_vbits (packed) and leaves every block's control words -- start / end / chained
+        // state, BER sums, encoder register -- in h_io. Speculation (segment warm-ups, start states taken from the previous block's tail) is
+        // verified here; what fails is decoded again.
+        void vit_run(const VitCfg &vc, const int8_t *d_soft, int64_t pos, int n, int first_start_in, DevBuf<VitBlockIO> &d_io, PinBuf<VitBlockIO> &h_io,
+                     DevBuf<uint32_t> &d_vbits, unsigned enc_state_in, const std::function<void(const char *)> &tick)
+        {
+            const int wpb = vit_words_per_block(vc.F), dstride = (vc.F + 6 + 63) / 64 * 64; // of THIS decoder (the FengYun rails are not the engine's F)
+            d_io.reserve(n);
+            h_io.reserve(n);
+            if (!(use_vit2 && vit2_supported(vc)))
+                d_dec.reserve((size_t)n * dstride);
+            d_vbits.reserve((size_t)n * wpb + 4);
+            for (int j = 0; j < n; j++)
+            {
+                h_io.p[j] = VitBlockIO{};
+                h_io.p[j].start_in = -1;
+            }
+            h_io.p[0].start_in = first_start_in;
+            SD_HIP(hipMemcpyAsync(d_io.p, h_io.p, (size_t)n * sizeof(VitBlockIO), hipMemcpyHostToDevice, stream));
+            const bool v2 = use_vit2 && vit2_supported(vc);
+            if (v2)
+                launch_vit_decode2(vc, d_soft, pos, n, d_io.p, d_vbits.p, vit2, stream);
+            else
+                launch_vit_decode(vc, d_soft, pos, n, d_io.p, d_dec.p, d_vbits.p, stream);
+            SD_HIP(hipMemcpyAsync(h_io.p, d_io.p, (size_t)n * sizeof(VitBlockIO), hipMemcpyDeviceToHost, stream));
+            SD_HIP(hipStreamSynchronize(stream));
+            // Certificates, in rounds (every failing block of a round is decoded again in ONE launch of the
+            // wave-per-block kernel, which is exact within a block given its start state): (1) segment certificate of
+            // the lane-per-segment kernel failed (tb_fallback == 2) -> again from the start state it used; (2) the
+            // start-state chain (cc_decoder.cpp:295-302): start used != state the previous block's chainback returned.
+            unsigned n_cert = 0, n_chain = 0, n_rounds = 0;
+            for (;;)
+            {
+                redo_list.clear();
+                for (int j = 0; j < n; j++)
+                {
+                    if (j > 0 && h_io.p[j].start_used != h_io.p[j - 1].ret_state)
+                    {
+                        n_chain++;
+                        h_io.p[j].start_in = h_io.p[j - 1].ret_state;
+                        redo_list.push_back(j);
+                    }
+                    else if (h_io.p[j].tb_fallback == 2)
+                    {
+                        n_cert++;
+                        h_io.p[j].start_in = h_io.p[j].start_used;
+                        redo_list.push_back(j);
+                    }
+                }
+                if (redo_list.empty())
+                    break;
+                if (++n_rounds > (unsigned)n + 2)
+                    throw HipError("viterbi start-state chain does not converge");
+                const int nr = (int)redo_list.size();
+                d_redo.reserve(nr);
+                d_dec.reserve((size_t)nr * dstride);
+                SD_HIP(hipMemcpyAsync(d_redo.p, redo_list.data(), (size_t)nr * sizeof(int), hipMemcpyHostToDevice, stream));
+                SD_HIP(hipMemcpyAsync(d_io.p, h_io.p, (size_t)n * sizeof(VitBlockIO), hipMemcpyHostToDevice, stream));
+                launch_vit_decode(vc, d_soft, pos, nr, d_io.p, d_dec.p, d_vbits.p, stream, d_redo.p);
+                SD_HIP(hipMemcpyAsync(h_io.p, d_io.p, (size_t)n * sizeof(VitBlockIO), hipMemcpyDeviceToHost, stream));
+                SD_HIP(hipStreamSynchronize(stream));
+            }
+            stats.vit_respec += n_chain;
+            stats.tb_respec += n_cert;
+            unsigned n_tbfb = 0;
+            for (int j = 0; j < n; j++)
+                n_tbfb += h_io.p[j].tb_fallback;
+            stats.tb_respec += n_tbfb;
+            if (getenv("SDHIP_DEBUG"))
+                fprintf(stderr, "[sdhip] viterbi batch %d blocks (%s): segment-certificate re-decodes %u, start-state re-decodes %u in %u round(s), serial tracebacks %u\n", n,
+                        v2 ? "lane-per-segment" : "wave-per-block", n_cert, n_chain, n_rounds, n_tbfb);
+            tick("viterbi");
+            // BER estimate of every block, then the lock FSM (viterbi_1_2.cpp:101-113)
+            launch_vit_ber(vc, d_soft, pos, n, d_vbits.p, enc_state_in, d_io.p, stream);
+            SD_HIP(hipMemcpyAsync(h_io.p, d_io.p, (size_t)n * sizeof(VitBlockIO), hipMemcpyDeviceToHost, stream));
+            SD_HIP(hipStreamSynchronize(stream));
+        }
+
+        // ------------------------------------------------------------------ fengyun_ahrpt_decoder
+        // Lock search of one rail's Viterbi3_4 on block 0 of its rail buffer (viterbi_3_4.cpp:110-147, fymode: phase 0, two puncturing shifts)
+        void fy_search(FyRail &r)
+        {
+            SD_HIP(hipMemcpyAsync(r.d_search.p, &r.search, sizeof(r.search), hipMemcpyHostToDevice, stream));
+            const int ph0[1] = {0};
+            launch_vit_search(fy.rvc, r.d_rail.p, 0, 1, ph0, 1, r.d_search.p, stream);
+            SD_HIP(hipMemcpyAsync(&r.search, r.d_search.p, sizeof(r.search), hipMemcpyDeviceToHost, stream));
+            SD_HIP(hipStreamSynchronize(stream));
+            r.v_ber = 10;
+            for (int shift = 0; shift < 2; shift++)
+            {
+                const float errors = (float)r.search.err[shift], total = (float)r.search.tot[shift];
+                const float ber = (float)((errors / total) * ber_mult);
+                r.bers[shift] = ber;
+                if ((r.v_ber == 10 && ber < cfg.viterbi_ber_thresold) || (r.v_ber < 10 && ber < r.v_ber))
+                {
+                    r.v_ber = ber;
+                    r.vstate = 1;
+                    r.v_shift = shift;
+                    r.v_invalid = 0;
+                }
+            }
+        }
+
+        // The module's loop (module_fengyun_ahrpt_decoder.cpp:58-126), a run of reads at a time: while either Viterbi is searching, one read per turn
+        // (rail split, search, decode of the rail(s) that hold a lock, the counters); once both hold, a batch of reads is decoded for both rails on the
+        // assumption that both stay locked, and the two FSMs then walk the batch's BER figures in step -- the read in which either drops out ends the run.
+        void process_blocks_fengyun(const int8_t *d_soft, int64_t nblocks, uint8_t *d_out, size_t out_cap_frames, size_t &out_written)
+        {
+            const int RB = fy.rvc.B, RF = fy.rvc.F, rwpb = vit_words_per_block(RF);
+            const auto no_tick = [](const char *) {};
+            struct Snap
+            {
+                int vstate, v_invalid;
+                float v_ber;
+            };
+            std::vector<Snap> snaps[2];
+            int64_t pos = 0;
+            while (pos < nblocks)
+            {
+                const bool any_idle = fy.rail[0].vstate == 0 || fy.rail[1].vstate == 0;
+                const int n = any_idle ? 1 : (int)std::min<int64_t>(nblocks - pos, max_batch);
+                for (FyRail &r : fy.rail)
+                    r.d_rail.reserve((size_t)n * RB);
+                launch_fy_rails(d_soft, pos, n, fy.shift, cfg.invert_second_viterbi, fy.rail[0].d_rail.p, fy.rail[1].d_rail.p, stream);
+                bool dec[2];
+                for (int k = 0; k < 2; k++)
+                {
+                    FyRail &r = fy.rail[k];
+                    if (r.vstate == 0)
+                        fy_search(r);
+                    dec[k] = r.vstate == 1;
+                    if (dec[k])
+                    {
+                        VitCfg v = fy.rvc;
+                        v.shift = r.v_shift;
+                        vit_run(v, r.d_rail.p, 0, n, r.dec_first ? -2 : r.dec_start, r.d_io, r.h_io, r.d_vb, r.search.enc_state, no_tick);
+                    }
+                    snaps[k].assign(n, Snap{r.vstate, r.v_invalid, r.v_ber});
+                }
+                // the two lock FSMs over the run (viterbi_3_4.cpp:156-168), in step
+                int accepted = n;
+                for (int j = 0; j < n; j++)
+                {
+                    for (int k = 0; k < 2; k++)
+                    {
+                        FyRail &r = fy.rail[k];
+                        if (dec[k])
+                        {
+                            const float errors = (float)r.h_io.p[j].ber_err, total = (float)r.h_io.p[j].ber_tot;
+                            r.v_ber = (float)((errors / total) * ber_mult);
+                            if (r.v_ber > cfg.viterbi_ber_thresold)
+                            {
+                                r.v_invalid++;
+                                if ((float)r.v_invalid > (float)cfg.viterbi_outsync_after)
+                                    r.vstate = 0;
+                            }
+                            else
+                                r.v_invalid = 0;
+                        }
+                        snaps[k][j] = Snap{r.vstate, r.v_invalid, r.v_ber};
+                    }
+                    if (fy.rail[0].vstate == 0 || fy.rail[1].vstate == 0)
+                    {
+                        accepted = j + 1;
+                        break;
+                    }
+                }
+                int used = accepted;
+                if (dec[0] && dec[1])
+                {
+                    // v1 > 0 && v2 > 0: differential decoder over the run, then the deframer and what follows it (:93-121)
+                    d_vbits.reserve((size_t)accepted * wpb + 4);
+                    const FyRail &rx = fy.rail[fy.invert_branches ? 0 : 1], &ry = fy.rail[fy.invert_branches ? 1 : 0];
+                    launch_fy_diff(rx.d_vb.p, ry.d_vb.p, accepted, RF, rwpb, fy.x_prev, fy.y_prev, d_vbits.p, wpb, stream);
+                    used = deframe_and_emit(accepted, d_out, out_cap_frames, out_written); // < accepted: the branches were exchanged behind read used - 1
+                    if (used < accepted)
+                        for (int k = 0; k < 2; k++)
+                        {
+                            fy.rail[k].vstate = snaps[k][used - 1].vstate;
+                            fy.rail[k].v_invalid = snaps[k][used - 1].v_invalid;
+                            fy.rail[k].v_ber = snaps[k][used - 1].v_ber;
+                        }
+                    unsigned last[2];
+                    SD_HIP(hipMemcpyAsync(&last[0], rx.d_vb.p + (size_t)(used - 1) * rwpb + ((RF - 1) >> 5), 4, hipMemcpyDeviceToHost, stream));
+                    SD_HIP(hipMemcpyAsync(&last[1], ry.d_vb.p + (size_t)(used - 1) * rwpb + ((RF - 1) >> 5), 4, hipMemcpyDeviceToHost, stream));
+                    SD_HIP(hipStreamSynchronize(stream));
+                    fy.x_prev = (last[0] >> (31 - ((RF - 1) & 31))) & 1u;
+                    fy.y_prev = (last[1] >> (31 - ((RF - 1) & 31))) & 1u;
+                }
+                for (int k = 0; k < 2; k++)
+                    if (dec[k])
+                    {
+                        FyRail &r = fy.rail[k];
+                        r.dec_first = 0;
+                        r.dec_start = r.h_io.p[used - 1].ret_state;
+                        r.search.enc_state = (unsigned)r.h_io.p[used - 1].pad;
+                    }
+                for (int j = 0; j < used; j++)
+                    for (int k = 0; k < 2; k++)
+                    { // taps: two entries per read, rail 0 then rail 1
+                        const Snap &sn = snaps[k][j];
+                        tap_ber.push_back(sn.vstate == 1 ? sn.v_ber : std::min(10.0f, std::min(fy.rail[k].bers[0], fy.rail[k].bers[1])));
+                        tap_state.push_back(sn.vstate);
+                    }
+                // :80-91, after the two work() calls of a read: only the last read of a run can have left a Viterbi searching
+                if (fy.rail[0].vstate == 0 || fy.rail[1].vstate == 0)
+                {
+                    fy.vit_nosync_run++;
+                    if (fy.vit_nosync_run >= 10)
+                        fy.shift ^= 1;
+                }
+                pos += used;
+                stats.blocks += used;
+            }
+            stats.viterbi_lock = fy.rail[0].vstate;
+            stats.viterbi_ber = fy.rail[0].ber();
+            stats.viterbi2_lock = fy.rail[1].vstate;
+            stats.viterbi2_ber = fy.rail[1].ber();
+            stats.deframer_state = def.state;
+            for (int k = 0; k < 8; k++)
+                stats.rs_errors[k] = last_errors[k];
+        }
+
         void process_blocks(const int8_t *d_soft, int64_t nblocks, uint8_t *d_out, size_t out_cap_frames, size_t &out_written)
         {
+            if (cfg.decoder == SDHIP_DEC_FENGYUN_AHRPT)
+                return process_blocks_fengyun(d_soft, nblocks, d_out, out_cap_frames, out_written);
             if (cfg.decoder == SDHIP_DEC_SIMPLE_PSK)
                 return process_blocks_simple(d_soft, nblocks, d_out, out_cap_frames, out_written);
             if (punc.rate != 0)
@@ -1631,75 +1920,7 @@ namespace sdhip
                 vc.iq_swap = v_iq_swap;
                 vc.phase = v_phase;
                 vc.shift = v_shift;
-                d_io.reserve(n);
-                h_io.reserve(n);
-                if (!(use_vit2 && vit2_supported(vc)))
-                    d_dec.reserve((size_t)n * dstride);
-                d_vbits.reserve((size_t)n * wpb + 4);
-                for (int j = 0; j < n; j++)
-                {
-                    h_io.p[j] = VitBlockIO{};
-                    h_io.p[j].start_in = -1;
-                }
-                h_io.p[0].start_in = dec_first ? -2 : dec_start;
-                SD_HIP(hipMemcpyAsync(d_io.p, h_io.p, (size_t)n * sizeof(VitBlockIO), hipMemcpyHostToDevice, stream));
-                const bool v2 = use_vit2 && vit2_supported(vc);
-                if (v2)
-                    launch_vit_decode2(vc, d_soft, pos, n, d_io.p, d_vbits.p, vit2, stream);
-                else
-                    launch_vit_decode(vc, d_soft, pos, n, d_io.p, d_dec.p, d_vbits.p, stream);
-                SD_HIP(hipMemcpyAsync(h_io.p, d_io.p, (size_t)n * sizeof(VitBlockIO), hipMemcpyDeviceToHost, stream));
-                SD_HIP(hipStreamSynchronize(stream));
-                // Certificates, in rounds (every failing block of a round is decoded again in ONE launch of the
-                // wave-per-block kernel, which is exact within a block given its start state): (1) segment certificate of
-                // the lane-per-segment kernel failed (tb_fallback == 2) -> again from the start state it used; (2) the
-                // start-state chain (cc_decoder.cpp:295-302): start used != state the previous block's chainback returned.
-                unsigned n_cert = 0, n_chain = 0, n_rounds = 0;
-                for (;;)
-                {
-                    redo_list.clear();
-                    for (int j = 0; j < n; j++)
-                    {
-                        if (j > 0 && h_io.p[j].start_used != h_io.p[j - 1].ret_state)
-                        {
-                            n_chain++;
-                            h_io.p[j].start_in = h_io.p[j - 1].ret_state;
-                            redo_list.push_back(j);
-                        }
-                        else if (h_io.p[j].tb_fallback == 2)
-                        {
-                            n_cert++;
-                            h_io.p[j].start_in = h_io.p[j].start_used;
-                            redo_list.push_back(j);
-                        }
-                    }
-                    if (redo_list.empty())
-                        break;
-                    if (++n_rounds > (unsigned)n + 2)
-                        throw HipError("viterbi start-state chain does not converge");
-                    const int nr = (int)redo_list.size();
-                    d_redo.reserve(nr);
-                    d_dec.reserve((size_t)nr * dstride);
-                    SD_HIP(hipMemcpyAsync(d_redo.p, redo_list.data(), (size_t)nr * sizeof(int), hipMemcpyHostToDevice, stream));
-                    SD_HIP(hipMemcpyAsync(d_io.p, h_io.p, (size_t)n * sizeof(VitBlockIO), hipMemcpyHostToDevice, stream));
-                    launch_vit_decode(vc, d_soft, pos, nr, d_io.p, d_dec.p, d_vbits.p, stream, d_redo.p);
-                    SD_HIP(hipMemcpyAsync(h_io.p, d_io.p, (size_t)n * sizeof(VitBlockIO), hipMemcpyDeviceToHost, stream));
-                    SD_HIP(hipStreamSynchronize(stream));
-                }
-                stats.vit_respec += n_chain;
-                stats.tb_respec += n_cert;
-                unsigned n_tbfb = 0;
-                for (int j = 0; j < n; j++)
-                    n_tbfb += h_io.p[j].tb_fallback;
-                stats.tb_respec += n_tbfb;
-                if (getenv("SDHIP_DEBUG"))
-                    fprintf(stderr, "[sdhip] viterbi batch %d blocks (%s): segment-certificate re-decodes %u, start-state re-decodes %u in %u round(s), serial tracebacks %u\n", n,
-                            v2 ? "lane-per-segment" : "wave-per-block", n_cert, n_chain, n_rounds, n_tbfb);
-                tick("viterbi");
-                // BER estimate of every block, then the lock FSM (viterbi_1_2.cpp:101-113)
-                launch_vit_ber(vc, d_soft, pos, n, d_vbits.p, search.enc_state, d_io.p, stream);
-                SD_HIP(hipMemcpyAsync(h_io.p, d_io.p, (size_t)n * sizeof(VitBlockIO), hipMemcpyDeviceToHost, stream));
-                SD_HIP(hipStreamSynchronize(stream));
+                vit_run(vc, d_soft, pos, n, dec_first ? -2 : dec_start, d_io, h_io, d_vbits, search.enc_state, tick);
                 int accepted = n;
                 const size_t tap0 = tap_ber.size();
                 for (int j = 0; j < n; j++)

@@ -7,7 +7,7 @@ namespace sdhip
 {
     // How the k=7 r=1/2 decoder's symbol stream is produced from a block of soft bytes.
     //   mode 0 = viterbi::Viterbi1_2  (src-core/common/codings/viterbi/viterbi_1_2.cpp:92-98)
-    //   mode 1 = viterbi::Viterbi3_4 MetOp depuncture (viterbi_3_4.cpp:84-105,150-154)
+    //   mode 1 = viterbi::Viterbi3_4 MetOp depuncture (viterbi_3_4.cpp:84-105,150-154); with fy = 1 the FengYun one (:58-78)
     struct VitCfg
     {
         int mode;
@@ -21,6 +21,8 @@ namespace sdhip
         int stride;   // soft bytes from one block to the next; 0 = B. Smaller than B: overlapping blocks -- the windows of a
                       // sliding buffer (generic punctured rates: a decoder block reads its B symbols plus 12 of the next one)
         int nenc;     // bits the BER re-encoder runs per block (its register carries over from there); 0 = nber
+        int fy;       // mode 1 only: Viterbi3_4's fymode (viterbi_3_4.cpp:58-78,115) -- the punctured pair keeps its symbol order
+                      // (128, in[0], in[1], 128 where MetOp has 128, in[1], in[0], 128) and the lock search tries phase 0 only
     };
     __host__ __device__ inline long long vit_stride(const VitCfg &c) { return c.stride > 0 ? c.stride : c.B; }
 
@@ -92,9 +94,20 @@ namespace sdhip
         int ncand;
         int err[16], tot[16];
     };
-    // candidates: mode 0: for s in [0, n_swap) for phase in phases[] for shift in {0,1}; mode 1: phase in {0,1} x shift in {0,1}
+    // candidates: mode 0: for s in [0, n_swap) for phase in phases[] for shift in {0,1}; mode 1: phase in {0,1} x shift in {0,1} (fy: phase 0 only)
     void launch_vit_search(const VitCfg &cfg, const int8_t *soft, int64_t block, int n_swap, const int *phases, int nphases, VitSearchState *d_state,
                            hipStream_t st);
+
+    // ---- fengyun_ahrpt_decoder (plugins/fengyun3_support/fengyun3/module_fengyun_ahrpt_decoder.cpp:58-110) ----
+    // The module's rail split (:62-68): after rotate_soft(.., PHASE_0, iq_invert = true) -- -128 -> -127, I and Q exchanged -- rail 0 takes byte 0 and
+    // rail 1 byte 1 of pair i + shift (rail 1 complemented, ~x, when invert_second is set) for i in [0, 8192) of every 16384-byte block. With shift = 1
+    // the module reads pair 8192 of its 8192-pair buffer; that pair is taken as (0, 0) here.
+    void launch_fy_rails(const int8_t *soft, int64_t first_block, int nblk, int shift, int invert_second, int8_t *rail0, int8_t *rail1, hipStream_t st);
+    // FengyunDiff::work2 (fengyun3/diff.cpp:49-78) over nblk blocks of bits_per_rail decoded bits of the two rails (packed MSB first, wpb_rail words per
+    // block): x = the rail that is in1, y = in2; (x_prev, y_prev) = the pair in front of block 0. Writes 2 * bits_per_rail bits per block into out (wpb_out
+    // words per block), the stream the deframer reads.
+    void launch_fy_diff(const uint32_t *x, const uint32_t *y, int nblk, int bits_per_rail, int wpb_rail, unsigned x_prev, unsigned y_prev, uint32_t *out, int wpb_out,
+                        hipStream_t st);
 
     // ---- generic punctured rates (depunc.h): per input position of the period, one or two depunctured symbols
     struct PuncPat

@@ -102,6 +102,7 @@ namespace sdhip
             {
                 const int m = t / 3, r = t - 3 * m;
                 const int base = 4 * m;
+                const int x = c.fy ? 1 : 0; // FengYun: the punctured pair is not swapped (viterbi_3_4.cpp:63-75 against :91-102)
                 if (base >= limit) // past the depunctured data (limit is a multiple of 4)
                 {
                     s0 = tail(0);
@@ -117,11 +118,11 @@ namespace sdhip
                     else if (r == 1)
                     {
                         s0 = 128u;
-                        s1 = u_at(base + 3);
+                        s1 = u_at(base + (3 ^ x));
                     }
                     else
                     {
-                        s0 = u_at(base + 2);
+                        s0 = u_at(base + (2 ^ x));
                         s1 = 128u;
                     }
                 }
@@ -130,11 +131,11 @@ namespace sdhip
                     if (r == 0)
                     {
                         s0 = 128u;
-                        s1 = u_at(base + 1);
+                        s1 = u_at(base + (1 ^ x));
                     }
                     else if (r == 1)
                     {
-                        s0 = u_at(base);
+                        s0 = u_at(base + (0 ^ x));
                         s1 = 128u;
                     }
                     else
@@ -797,6 +798,17 @@ namespace sdhip
                         ub[pi] = y == 128u ? 127u : y;
                     }
                     const bool sh0 = c.shift == 0;
+                    if (c.fy)
+                    { // FengYun keeps the punctured pair's order: exchanging the two bytes of those pairs here gives the MetOp pattern below that
+#pragma unroll
+                        for (int pi = 0; pi < 8; pi++)
+                            if ((pi & 1) == (sh0 ? 1 : 0))
+                            {
+                                const unsigned t = ua[pi];
+                                ua[pi] = ub[pi];
+                                ub[pi] = t;
+                            }
+                    }
                     auto emit = [&](auto r0c) {
                         constexpr int R0 = decltype(r0c)::value;
 #pragma unroll
@@ -1174,6 +1186,106 @@ namespace sdhip
     }
 
     // =============================================================================================
+    // fengyun_ahrpt_decoder: the rail split in front of the two Viterbi3_4 decoders and the differential decoder behind them
+    // =============================================================================================
+    __global__ __launch_bounds__(256) void k_fy_rails(const int8_t *__restrict__ soft, long long first_block, int nblk, int shift, int invert_second, int8_t *rail0,
+                                                       int8_t *rail1)
+    { // thread = four consecutive symbols of one block: two dword loads (+ one for the shifted pair), one dword store per rail
+        const long long g = (long long)blockIdx.x * 256 + threadIdx.x;
+        if (g >= (long long)nblk * 2048)
+            return;
+        const long long j = g >> 11;
+        const int i0 = (int)(g & 2047) * 4;
+        const unsigned *w = reinterpret_cast<const unsigned *>(soft + (first_block + j) * 16384);
+        unsigned r0 = 0, r1 = 0;
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+        {
+            const int p = i0 + q + shift; // pair index inside the block
+            int a = 0, b = 0;
+            if (p < 8192)
+            {
+                const unsigned d = w[p >> 1] >> (16 * (p & 1));
+                a = (int)(signed char)(d & 0xffu);
+                b = (int)(signed char)((d >> 8) & 0xffu);
+                a = a == -128 ? -127 : a;
+                b = b == -128 ? -127 : b;
+            }
+            // iq swap: soft_buffer[2p] = b, soft_buffer[2p + 1] = a
+            const int v0 = b, v1 = invert_second ? ~a : a;
+            r0 |= ((unsigned)v0 & 0xffu) << (8 * q);
+            r1 |= ((unsigned)v1 & 0xffu) << (8 * q);
+        }
+        reinterpret_cast<unsigned *>(rail0 + j * 8192)[i0 >> 2] = r0;
+        reinterpret_cast<unsigned *>(rail1 + j * 8192)[i0 >> 2] = r1;
+    }
+    void launch_fy_rails(const int8_t *soft, int64_t first_block, int nblk, int shift, int invert_second, int8_t *rail0, int8_t *rail1, hipStream_t st)
+    {
+        if (nblk <= 0)
+            return;
+        ProfScope _ps("k_fy_rails", st);
+        const long long threads = (long long)nblk * 2048;
+        hipLaunchKernelGGL(k_fy_rails, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, soft, (long long)first_block, nblk, shift, invert_second, rail0, rail1);
+    }
+
+    __global__ __launch_bounds__(256) void k_fy_diff(const unsigned *__restrict__ x, const unsigned *__restrict__ y, int nblk, int bits_per_rail, int wpb_rail,
+                                                      unsigned x_prev, unsigned y_prev, unsigned *out, int wpb_out)
+    { // thread = one output word = 16 rail positions: half a word of each rail and the bit in front of it
+        const int wout = 2 * bits_per_rail / 32;
+        const long long g = (long long)blockIdx.x * 256 + threadIdx.x;
+        if (g >= (long long)nblk * wout)
+            return;
+        const int j = (int)(g / wout), w = (int)(g - (long long)j * wout);
+        const int k0 = 16 * w; // first rail position of this word
+        const unsigned *xb = x + (size_t)j * wpb_rail, *yb = y + (size_t)j * wpb_rail;
+        const unsigned xw = xb[k0 >> 5], yw = yb[k0 >> 5];
+        unsigned xp, yp; // the rail bits in front of position k0
+        if (k0 & 31)
+        {
+            xp = (xw >> (32 - (k0 & 31))) & 1u;
+            yp = (yw >> (32 - (k0 & 31))) & 1u;
+        }
+        else if (k0 > 0)
+        {
+            xp = xb[(k0 >> 5) - 1] & 1u;
+            yp = yb[(k0 >> 5) - 1] & 1u;
+        }
+        else if (j > 0)
+        {
+            xp = (xb - wpb_rail)[(bits_per_rail - 1) >> 5] >> (31 - ((bits_per_rail - 1) & 31)) & 1u;
+            yp = (yb - wpb_rail)[(bits_per_rail - 1) >> 5] >> (31 - ((bits_per_rail - 1) & 31)) & 1u;
+        }
+        else
+        {
+            xp = x_prev & 1u;
+            yp = y_prev & 1u;
+        }
+        unsigned o = 0;
+#pragma unroll
+        for (int q = 0; q < 16; q++)
+        {
+            const int k = k0 + q;
+            const unsigned xi = (xw >> (31 - (k & 31))) & 1u, yi = (yw >> (31 - (k & 31))) & 1u;
+            const unsigned dx = xi ^ xp, dy = yi ^ yp;
+            // diff.cpp:61-74: X != Y -> (high, low) = (dy, dx), else (dx, dy)
+            const unsigned hi = (xi ^ yi) ? dy : dx, lo = (xi ^ yi) ? dx : dy;
+            o = (o << 2) | (hi << 1) | lo;
+            xp = xi;
+            yp = yi;
+        }
+        out[(size_t)j * wpb_out + w] = o;
+    }
+    void launch_fy_diff(const uint32_t *x, const uint32_t *y, int nblk, int bits_per_rail, int wpb_rail, unsigned x_prev, unsigned y_prev, uint32_t *out, int wpb_out,
+                        hipStream_t st)
+    {
+        if (nblk <= 0)
+            return;
+        ProfScope _ps("k_fy_diff", st);
+        const long long threads = (long long)nblk * (2 * bits_per_rail / 32);
+        hipLaunchKernelGGL(k_fy_diff, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, x, y, nblk, bits_per_rail, wpb_rail, x_prev, y_prev, out, wpb_out);
+    }
+
+    // =============================================================================================
     // Generic punctured rates (conv_rate 2/3 .. 7/8): viterbi::puncturing::Depunc23/34/56/78, depunc.h:21-430.
     // The lock search and the call-by-call path (k_punc_static / k_punc_cont: one call of 8192 symbols per launch) follow the
     // reference step by step; a SYNCED run of calls is depunctured by ONE launch (k_punc_batch) and decoded as a batch of
@@ -1298,7 +1410,7 @@ namespace sdhip
         const int8_t *blk = soft + block * vit_stride(c);
         int cand = 0;
         const int nsw = (c.mode == 0) ? n_swap : 1;
-        const int nph = (c.mode == 0) ? nphases : 2;
+        const int nph = (c.mode == 0) ? nphases : (c.fy ? 1 : 2);
         for (int s = 0; s < nsw; s++)
             for (int pi = 0; pi < nph; pi++)
                 for (int shift = 0; shift < 2; shift++)

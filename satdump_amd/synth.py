@@ -183,6 +183,56 @@ def puncture_metop(coded: np.ndarray) -> np.ndarray:
     return out.reshape(-1)
 
 
+def fy3_diff_encode(dibits: np.ndarray) -> tuple[np.ndarray, np.ndarray]:
+    """Transmit-side inverse of fengyun3::FengyunDiff::work2 (plugins/fengyun3_support/fengyun3/diff.cpp:49-78): the rail bits (x, y) = (in1, in2) whose
+    decoder output is the dibit stream (hi, lo). The decoder emits (y^y', x^x') when x != y and (x^x', y^y') otherwise (x', y' = the previous pair), so from
+    a = x' ^ y' ^ hi ^ lo: a == 0 -> x = x' ^ hi, y = y' ^ lo (and x == y holds), a == 1 -> x = x' ^ lo, y = y' ^ hi. Starts from (0, 0) like the decoder."""
+    d = np.asarray(dibits, dtype=np.uint8).reshape(-1, 2)
+    x = np.empty(len(d), dtype=np.uint8)
+    y = np.empty(len(d), dtype=np.uint8)
+    xp = yp = 0
+    for i, (hi, lo) in enumerate(d.tolist()):
+        if (xp ^ yp ^ hi ^ lo) == 0:
+            xp, yp = xp ^ hi, yp ^ lo
+        else:
+            xp, yp = xp ^ lo, yp ^ hi
+        x[i] = xp
+        y[i] = yp
+    return x, y
+
+
+def fy3_ahrpt_soft(nframes: int, seed: int = 3, sigma: float = 18.0, amp: float = 70.0, invert_second: bool = True, branches_swapped: bool = False, lead: int = 0,
+                   gaps=(), noise_tail: int = 0):
+    """A FengYun-3 AHRPT .soft stream as fengyun_ahrpt_decoder reads it (module_fengyun_ahrpt_decoder.cpp:58-126): 1024-byte CADUs (RS(255,223) x 4 dual
+    basis, randomised) -> dibits -> differential encoder -> two rails, each r = 1/2 k = 7 punctured to 3/4 (c0 c1 . c1 c0 . per three bits, what
+    Viterbi3_4's fymode depuncture undoes, viterbi_3_4.cpp:58-78) -> QPSK. The module exchanges I and Q, hands byte 0 of a pair to Viterbi 1 and byte 1
+    (complemented when invert_second) to Viterbi 2, and takes Viterbi 2's bits as the differential decoder's first input -- unless `branches_swapped`, the
+    case its noSyncRuns counter resolves. lead: garbage bytes in front, gaps: (byte position, bytes removed). Returns (soft int8, plain CADUs)."""
+    cadus = make_cadus(nframes, seed=seed, rs_i=4, dualbasis=True)
+    x, y = fy3_diff_encode(np.unpackbits(cadus.reshape(-1)))
+    v1_bits, v2_bits = (x, y) if branches_swapped else (y, x)
+    rails = []
+    for bits in (v1_bits, v2_bits):
+        c = puncture(conv_encode(bits), 2).astype(np.float64) * 2.0 - 1.0
+        rails.append(c)
+    n = min(len(rails[0]), len(rails[1]))
+    rng = np.random.default_rng(seed + 100)
+    v = np.empty(2 * n)
+    v[1::2] = rails[0][:n] * amp  # byte 1 of a pair -> (after the I/Q exchange) Viterbi 1
+    v[0::2] = rails[1][:n] * amp
+    v = v + sigma * rng.standard_normal(len(v))
+    s = np.where(v < -128.0, -127, np.where(v > 127.0, 127, np.trunc(v))).astype(np.int8)
+    if invert_second:
+        s[0::2] = ~s[0::2]
+    for pos, cut in sorted(gaps, reverse=True):
+        s = np.concatenate([s[:pos], s[pos + cut:]])
+    if lead:
+        s = np.concatenate([rng.integers(-60, 60, lead).astype(np.int8), s])
+    if noise_tail:
+        s = np.concatenate([s, rng.integers(-60, 60, noise_tail).astype(np.int8)])
+    return s, make_cadus(nframes, seed=seed, rs_i=4, dualbasis=True, derand=False)
+
+
 # --------------------------------------------------------------------------- modulation
 # transmit masks over the r=1/2 coded stream (c0,c1 per bit) of the DVB-style punctured rates the reference's
 # viterbi::puncturing::Depunc23/34/56/78 undo (src-core/common/codings/viterbi/depunc.h): rate code 1 = 2/3, 2 = 3/4, 3 = 5/6, 4 = 7/8

@@ -472,6 +472,49 @@ def check_lrpt_module_through_the_plugin(host, lib, tmp_path):
     assert p.returncode != 0
 
 
+def check_fy3_module_through_the_plugin(host, lib, tmp_path):
+    """SURVEY 8 f-3's other plugin decoder through the drop-in boundary: the stock id `fengyun_ahrpt_decoder` (plugins/fengyun3_support), re-pointed by the
+    plugin under SDHIP_OVERRIDE=1 at FengyunAHRPTDecoderHipModule, reads a .soft file and writes the .cadu file the reference module's loop writes (its loop
+    on the reference's own classes: oracle/ref_wrap.cpp sdref_fy3_decode) -- the end of the file included: the module exchanges I and Q of its buffer in
+    place, so the short last read (or, on a buffer boundary, the extra iteration) works on a tail that is the previous buffer's EXCHANGED bytes. Both settings
+    of invert_second_viterbi, the module's statistics keys, a missing mandatory key."""
+    for name, inv2, nbytes in (("inv", True, None), ("plain", False, 16384 * 30), ("short", True, 16384 * 26 + 5000)):
+        soft, _ = synth.fy3_ahrpt_soft(36, seed=12, sigma=20.0, invert_second=inv2, lead=16384 + 444 * 4)
+        soft = soft[: nbytes or len(soft)]
+        nfull, rem = divmod(len(soft), 16384)
+        prev = soft[(nfull - 1) * 16384:nfull * 16384].copy()
+        prev[prev == -128] = -127
+        prev = prev.reshape(-1, 2)[:, ::-1].reshape(-1)
+        ext = np.concatenate([soft[:nfull * 16384], soft[nfull * 16384:], prev[rem:]])
+        want = pyref.ref().fy3_decode(ext, ber_thr=0.17, outsync_after=5, invert_second=inv2)["cadu"]
+        inp = tmp_path / (name + ".soft")
+        soft.tofile(str(inp))
+        job = {"mode": "file", "input": str(inp), "output_hint": str(tmp_path / name),
+               "demod": {"module": "fengyun_ahrpt_decoder", "parameters": {"viterbi_outsync_after": 5, "viterbi_ber_thresold": 0.17, "invert_second_viterbi": inv2}}}
+        jp = tmp_path / (name + ".json")
+        jp.write_text(json.dumps(job))
+        p = subprocess.run([host, lib, PLUGIN, "run", str(jp)], capture_output=True, text=True, env=dict(os.environ, SDHIP_OVERRIDE="1"), timeout=900)
+        assert p.returncode == 0, p.stdout[-1000:] + p.stderr[-3000:]
+        rep = json.loads(p.stdout.strip().splitlines()[-1])
+        assert rep["demod_class"] == "fengyun_ahrpt_decoder_hip" and rep["soft"].endswith(".cadu")
+        got = np.fromfile(rep["soft"], dtype=np.uint8).reshape(-1, 1024)
+        assert len(want) >= 30 and got.shape == want.shape and np.array_equal(got, want), name
+        st = rep["demod_stats"]
+        assert set(st) >= {"deframer_lock", "viterbi1_ber", "viterbi1_lock", "viterbi2_ber", "viterbi2_lock", "rs_avg", "viterbi1_state", "viterbi2_state", "deframer_state"}
+        assert st["viterbi1_state"] == "SYNCED" and st["viterbi2_state"] == "SYNCED" and 0.0 <= st["viterbi2_ber"] < 0.17
+    job["demod"] = {"module": "fengyun_ahrpt_decoder_hip", "parameters": {"viterbi_outsync_after": 5, "viterbi_ber_thresold": 0.17}}
+    job["instantiate_only"] = True
+    jp.write_text(json.dumps(job))
+    p = subprocess.run([host, lib, PLUGIN, "run", str(jp)], capture_output=True, text=True, env=dict(os.environ, SDHIP_OVERRIDE="1"), timeout=900)
+    assert p.returncode != 0
+
+
+def test_fy3_module_through_the_plugin(host, tmp_path):
+    if not (pyref.ref_available() and hasattr(pyref.ref().lib, "sdref_fy3_decode")):
+        pytest.skip("needs the compiled reference")
+    check_fy3_module_through_the_plugin(host, LIB, tmp_path)
+
+
 def test_lrpt_module_through_the_plugin(host, tmp_path):
     if not (pyref.ref_available() and hasattr(pyref.ref().lib, "sdref_lrpt_decode")):
         pytest.skip("needs the compiled reference")
