@@ -23,7 +23,7 @@ soft symbols over the same span, float symbols over the first --cpu-samples samp
 ms/step), "other_workloads": the same measurement, compact, for the other two single-GPU workloads (--others 0 to skip), and
 "next_rows": the rows SURVEY.md 8 marks "next" that have a measurement of their own -- the ndsp PSK demodulator chain
 (tools/bench_ndsp.py), the DVB-S2 FEC tail (tools/bench_dvbs2.py) and BASELINE configs[4] itself, 8PSK baseband -> BBFRAMEs through the module-shaped
-handle (tools/bench_dvbs2_demod.py), the Meteor LRPT decoder (tools/bench_lrpt.py) -- as those tools report them (--next-rows 0 to skip).
+handle (tools/bench_dvbs2_demod.py), the Meteor LRPT decoder (tools/bench_lrpt.py), the FengYun-3 AHRPT decoder (tools/bench_fy3.py) -- as those tools report them (--next-rows 0 to skip).
 """
 from __future__ import annotations
 
@@ -312,7 +312,8 @@ def main():
         for key, mod, argv in (("ndsp_psk_demod", "bench_ndsp", ["--steps", "4", "--warmup", "1", "--cpu-samples", "12000000"]),
                                ("dvbs2_fec", "bench_dvbs2", ["--rate", "2/3", "--sigma", "13"]),
                                ("dvbs2_demod_8psk", "bench_dvbs2_demod", []),
-                               ("meteor_lrpt_decoder", "bench_lrpt", [])):
+                               ("meteor_lrpt_decoder", "bench_lrpt", []),
+                               ("fengyun_ahrpt_decoder", "bench_fy3", [])):
             try:
                 torch.cuda.empty_cache()
                 m = __import__(mod)

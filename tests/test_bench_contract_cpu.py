@@ -20,6 +20,8 @@ def test_next_row_tools_import_and_parse():
         assert callable(nd.run) and callable(s2.run)
         lr = importlib.import_module("bench_lrpt")
         assert lr.parse([]).frames == 8192 and callable(lr.run)
+        fy = importlib.import_module("bench_fy3")
+        assert fy.parse([]).frames == 98304 and callable(fy.run)
     finally:
         sys.path.remove(tools)
 

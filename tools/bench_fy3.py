@@ -1,0 +1,87 @@
+#!/usr/bin/env python3
+"""fengyun_ahrpt_decoder (the FY-3 plugin decoder) on one MI355X, soft symbols resident in HBM: CADU/s of sdhip_fec_process_dev with
+SDHIP_DEC_FENGYUN_AHRPT (rail split -> two Viterbi3_4 fymode -> FengyunDiff::work2 -> deframer -> derand -> RS x 4), per-kernel HIP-event times, the
+CADUs of a prefix against the reference module's loop on the reference's own classes (oracle/_ref), and that loop's own rate on one host core (the
+module runs its two Viterbis on two OpenMP threads: at most twice that).
+usage: tools/bench_fy3.py [--frames 98304] [--steps 4] [--cpu-frames 768]"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def parse(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--frames", type=int, default=98304)
+    ap.add_argument("--steps", type=int, default=4)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--cpu-frames", type=int, default=768)
+    ap.add_argument("--sigma", type=float, default=20.0)
+    return ap.parse_args(argv)
+
+
+def run(args) -> dict:
+    import torch
+    torch.zeros(1, device="cuda")
+    from oracle import pyref
+    from satdump_amd import capi, synth
+
+    base = 768  # distinct frames = 512 reads of 16384 soft bytes; tiled whole (the seam is a data discontinuity the decoders ride through or re-lock on)
+    soft, _ = synth.fy3_ahrpt_soft(base, seed=21, sigma=args.sigma)
+    soft = soft[: len(soft) // 16384 * 16384]
+    reps = max(1, args.frames // base)
+    d_soft = torch.from_numpy(soft).cuda().repeat(reps)
+    n = int(d_soft.numel())
+    cap = n // 8192 + 16
+    d_out = torch.zeros(cap * 1024, dtype=torch.uint8, device="cuda")
+    cfg = capi.fec_cfg(decoder=capi.DEC_FENGYUN_AHRPT, viterbi_ber_thresold=0.17, viterbi_outsync_after=5, invert_second_viterbi=1)
+
+    def one():
+        dec = capi.FecDecoder(cfg)
+        k = dec.process_dev(d_soft.data_ptr(), n, d_out.data_ptr(), cap)
+        st = dec.stats()
+        del dec
+        return k, st
+
+    capi.lib().sdhip_pool_enable(1)  # a handle per step: its buffers come back from the pool instead of hipMalloc
+    for _ in range(args.warmup):
+        one()
+    capi.prof_enable(True)
+    capi.prof_reset()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ks = [one() for _ in range(args.steps)]
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / args.steps
+    kern = {k: round(v[0] / args.steps, 3) for k, v in capi.prof_get().items()}
+    capi.prof_enable(False)
+    k_last, st = ks[-1]
+    out = {"metric": "frames_per_s", "value": round(k_last / dt, 1), "unit": "CADU/s", "ms_per_step": round(dt * 1e3, 3), "steps": args.steps,
+           "config": {"workload": f"fengyun_ahrpt_decoder, {n // 16384} reads of 16384 soft bytes (two rails r=3/4 k=7, differential, 1024-byte CADUs, RS(255,223) x 4), sigma {args.sigma} on +-70"},
+           "soft_MB_per_s": round(n / dt / 1e6, 1), "Msym_per_s": round(n / 2 / dt / 1e6, 1), "frames_out": int(k_last), "reads": int(st.blocks),
+           "kernels_ms": dict(sorted(kern.items(), key=lambda kv: -kv[1])[:8]), "dtype": "u8"}
+    if args.cpu_frames > 0 and pyref.ref_available():
+        m = args.cpu_frames * 8192 * 4 // 3 // 16384 * 16384
+        s = d_soft[:m].cpu().numpy()
+        t1 = time.perf_counter()
+        want = pyref.ref().fy3_decode(s)["cadu"]
+        t2 = time.perf_counter()
+        got = d_out[: len(want) * 1024].cpu().numpy().reshape(-1, 1024)
+        out["cpu_baseline"] = {"value": round(len(want) / (t2 - t1), 1), "unit": "CADU/s", "cores": 1, "kind": "reference",
+                               "sample": f"the first {m // 16384} reads: the module's loop (rotate_soft, 2 x Viterbi3_4, FengyunDiff, BPSK_CCSDS_Deframer, derand_ccsds, ReedSolomon) on one thread"}
+        out["parity_sample"] = {"frames_compared": int(len(want)), "byte_identical": bool(len(want) > 0 and np.array_equal(got, want))}
+    return out
+
+
+def main():
+    print(json.dumps(run(parse())), flush=True)
+
+
+if __name__ == "__main__":
+    main()
