@@ -2391,6 +2391,10 @@ template <bool CKPT, bool SPLIT, bool Q8 = false, bool FAST = false, bool GARD =
     void launch_mm(const cf32 *x, cf32 *sym_scratch, int *counts, const ChunkGeom &g, const MmParams &p, const MmState *start0, MmState *spec, MmState *endst,
                    MmCert *spec_c, MmCert *end_c, const int *redo, int nredo, hipStream_t st, MmCkpt *ck, int ck_per_chunk, float ck_tol)
     {
+        // Dynamic LDS nobody reads, on top of the 22 KB a block (one wave) uses: with it a CU holds 6 blocks, not 7, and the 1 536 blocks of a 98 304-lane
+        // launch spread as 6 per CU -- the dispatcher otherwise packs some CUs with 7 and leaves others short, differently from one queue to the next
+        // (the 13.0 / 14.9 ms modes of this kernel). SDHIP_MM_LDS_PAD overrides (bytes).
+        const unsigned lds_pad = getenv("SDHIP_MM_LDS_PAD") ? (unsigned)atoi(getenv("SDHIP_MM_LDS_PAD")) : 0u;
         const int n = redo ? nredo : g.K;
         if (n <= 0)
             return;
@@ -2405,39 +2409,39 @@ template <bool CKPT, bool SPLIT, bool Q8 = false, bool FAST = false, bool GARD =
             if (p.back < 1 || p.back > MM_BACK_MAX || p.q8)
                 throw HipError("Gardner lanes: omega out of the window the lanes carry");
             if (ck && p.fast)
-                hipLaunchKernelGGL((k_mm<true, false, false, true, true>), dim3((n + 63) / 64), dim3(64), 0, st, x, sym_scratch, counts, g, p, start0, spec, endst, spec_c,
+                hipLaunchKernelGGL((k_mm<true, false, false, true, true>), dim3((n + 63) / 64), dim3(64), lds_pad, st, x, sym_scratch, counts, g, p, start0, spec, endst, spec_c,
                                    end_c, redo, nredo, ck, ck_per_chunk, ck_tol);
             else if (ck)
-                hipLaunchKernelGGL((k_mm<true, false, false, false, true>), dim3((n + 63) / 64), dim3(64), 0, st, x, sym_scratch, counts, g, p, start0, spec, endst, spec_c,
+                hipLaunchKernelGGL((k_mm<true, false, false, false, true>), dim3((n + 63) / 64), dim3(64), lds_pad, st, x, sym_scratch, counts, g, p, start0, spec, endst, spec_c,
                                    end_c, redo, nredo, ck, ck_per_chunk, ck_tol);
             else if (p.fast)
-                hipLaunchKernelGGL((k_mm<false, false, false, true, true>), dim3((n + 63) / 64), dim3(64), 0, st, x, sym_scratch, counts, g, p, start0, spec, endst, spec_c,
+                hipLaunchKernelGGL((k_mm<false, false, false, true, true>), dim3((n + 63) / 64), dim3(64), lds_pad, st, x, sym_scratch, counts, g, p, start0, spec, endst, spec_c,
                                    end_c, redo, nredo, (MmCkpt *)nullptr, 0, 0.0f);
             else
-                hipLaunchKernelGGL((k_mm<false, false, false, false, true>), dim3((n + 63) / 64), dim3(64), 0, st, x, sym_scratch, counts, g, p, start0, spec, endst, spec_c,
+                hipLaunchKernelGGL((k_mm<false, false, false, false, true>), dim3((n + 63) / 64), dim3(64), lds_pad, st, x, sym_scratch, counts, g, p, start0, spec, endst, spec_c,
                                    end_c, redo, nredo, (MmCkpt *)nullptr, 0, 0.0f);
             return;
         }
         if (ck && p.q8 && p.fast)
-            hipLaunchKernelGGL((k_mm<true, false, true, true>), dim3((n + 63) / 64), dim3(64), 0, st, x, sym_scratch, counts, g, p, start0, spec, endst, spec_c, end_c,
+            hipLaunchKernelGGL((k_mm<true, false, true, true>), dim3((n + 63) / 64), dim3(64), lds_pad, st, x, sym_scratch, counts, g, p, start0, spec, endst, spec_c, end_c,
                                redo, nredo, ck, ck_per_chunk, ck_tol);
         else if (ck && p.q8)
-            hipLaunchKernelGGL((k_mm<true, false, true>), dim3((n + 63) / 64), dim3(64), 0, st, x, sym_scratch, counts, g, p, start0, spec, endst, spec_c, end_c,
+            hipLaunchKernelGGL((k_mm<true, false, true>), dim3((n + 63) / 64), dim3(64), lds_pad, st, x, sym_scratch, counts, g, p, start0, spec, endst, spec_c, end_c,
                                redo, nredo, ck, ck_per_chunk, ck_tol);
         else if (ck && p.fast)
-            hipLaunchKernelGGL((k_mm<true, false, false, true>), dim3((n + 63) / 64), dim3(64), 0, st, x, sym_scratch, counts, g, p, start0, spec, endst, spec_c, end_c,
+            hipLaunchKernelGGL((k_mm<true, false, false, true>), dim3((n + 63) / 64), dim3(64), lds_pad, st, x, sym_scratch, counts, g, p, start0, spec, endst, spec_c, end_c,
                                redo, nredo, ck, ck_per_chunk, ck_tol);
         else if (ck)
-            hipLaunchKernelGGL((k_mm<true, false>), dim3((n + 63) / 64), dim3(64), 0, st, x, sym_scratch, counts, g, p, start0, spec, endst, spec_c, end_c, redo,
+            hipLaunchKernelGGL((k_mm<true, false>), dim3((n + 63) / 64), dim3(64), lds_pad, st, x, sym_scratch, counts, g, p, start0, spec, endst, spec_c, end_c, redo,
                                nredo, ck, ck_per_chunk, ck_tol);
         else if (p.q8)
-            hipLaunchKernelGGL((k_mm<false, false, true>), dim3((n + 63) / 64), dim3(64), 0, st, x, sym_scratch, counts, g, p, start0, spec, endst, spec_c, end_c,
+            hipLaunchKernelGGL((k_mm<false, false, true>), dim3((n + 63) / 64), dim3(64), lds_pad, st, x, sym_scratch, counts, g, p, start0, spec, endst, spec_c, end_c,
                                redo, nredo, (MmCkpt *)nullptr, 0, 0.0f);
         else if (split)
-            hipLaunchKernelGGL((k_mm<false, true>), dim3((n + 63) / 64), dim3(64), 0, st, x, sym_scratch, counts, g, p, start0, spec, endst, spec_c, end_c, redo,
+            hipLaunchKernelGGL((k_mm<false, true>), dim3((n + 63) / 64), dim3(64), lds_pad, st, x, sym_scratch, counts, g, p, start0, spec, endst, spec_c, end_c, redo,
                                nredo, (MmCkpt *)nullptr, 0, 0.0f);
         else
-            hipLaunchKernelGGL((k_mm<false, false>), dim3((n + 63) / 64), dim3(64), 0, st, x, sym_scratch, counts, g, p, start0, spec, endst, spec_c, end_c, redo,
+            hipLaunchKernelGGL((k_mm<false, false>), dim3((n + 63) / 64), dim3(64), lds_pad, st, x, sym_scratch, counts, g, p, start0, spec, endst, spec_c, end_c, redo,
                                nredo, (MmCkpt *)nullptr, 0, 0.0f);
     }
 

@@ -1029,6 +1029,258 @@ namespace sdhip
         exitst[u] = (int)st;
     }
 
+    // ---- the same lane-per-segment decoder with PATH HISTORIES instead of per-step decision words (k_vit2h_*) -------------------------------------
+    // The tag that breaks a tie and names the winner of a compare-select (above) does not have to be put back on the metric after every step: within a
+    // group of 8 steps, step k carries it in BIT k of the low byte -- on the branch constants (K | 1 << k for the two candidates that must lose a tie),
+    // not on the registers -- and the low byte of a surviving metric is left alone. The bits of earlier steps sit below bit k, so exactly one of two
+    // candidates has bit k set and the 16-bit minimum still resolves ties the reference's way; and after 8 steps the low byte of state s holds the 8
+    // (inverted) decisions along the path that SURVIVES in s. That byte is all a traceback needs: 8 decoded bits at a time, and the state 8 steps
+    // earlier is the bit reversal of the first six of them (each step back shifts the state right and enters the decision at bit 5, cc_decoder.cpp:
+    // 250-260). Per step this drops the two v_and_or (tag back on), the v_perm and the v_lshl_or (decision words) of every butterfly pair -- 13 -> 9
+    // instructions, + 16 v_or per step for the tagged constants, + 48 per group to gather and clear the bytes -- and the traceback makes one dependent
+    // byte fetch per 8 steps. Storage is what it was: 64 bytes per 8 steps and lane, as four uint4 planes [group][v][unit].
+    __device__ __forceinline__ void v2h_init_neutral(V2State &s)
+    {
+#pragma unroll
+        for (int r = 0; r < 32; r++)
+            s.R[r] = 0u;
+        s.C2 = 0u;
+    }
+    __device__ __forceinline__ void v2h_init_start(V2State &s, int start)
+    { // init_viterbi / init_viterbi_unbiased, cc_decoder.cpp:159-190
+        const unsigned all = ((start == -2) ? 31u : 63u) << 8;
+#pragma unroll
+        for (int r = 0; r < 32; r++)
+        {
+            unsigned lo = all, hi = all;
+            if (start == r)
+                lo = 0u;
+            if (start == 63 - r)
+                hi = 0u;
+            s.R[r] = lo | (hi << 16);
+        }
+        s.C2 = 0u;
+    }
+    // one trellis step, the KSTEP-th of its group; DEC = false: no tags (the low bytes stay as they are -- clear, in a warm-up)
+    template <int KSTEP, bool DEC>
+    __device__ __forceinline__ void v2h_step(V2State &s, unsigned sym)
+    {
+        const unsigned s0 = sym & 255u, s1 = (sym >> 8) & 255u;
+        const unsigned a[2] = {s0, s0 ^ 255u}, c[2] = {s1, s1 ^ 255u};
+        unsigned D[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            D[k] = ((a[k >> 1] + c[k & 1] + 1u) << 5) & 0x3F00u; // ((sum + 1) >> 3) << 8
+        const unsigned Q = pk_sub(0x3F003F00u, s.C2);
+        constexpr unsigned TL = DEC ? (1u << KSTEP) : 0u, TH = TL << 16;
+        // candidates (see the register map above): T1 = (m0, m3'), T2 = (m1, m2'), T3 = (m2, m1'), T4 = (m3, m0'); a tie goes to m1 / m3 / m3' / m1'
+        // (decision = (m0 - m1) >= 0 picks the second), so m0, m2 (low halves of T1, T3) and m2', m0' (high halves of T2, T4) carry the tag
+        unsigned K1a[4], K1b[4], K2a[4], K2b[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+        {
+            const unsigned PD = D[k] | (D[3 - k] << 16);
+            const unsigned K1 = pk_sub(PD, s.C2), K2 = pk_sub(Q, PD);
+            K1a[k] = K1 | TL;
+            K1b[k] = K1 | TH;
+            K2a[k] = K2 | TH;
+            K2b[k] = K2 | TL;
+        }
+        unsigned Rn[32];
+        unsigned mnA = 0xFFFFFFFFu, mnB = 0xFFFFFFFFu;
+#pragma unroll
+        for (int i = 0; i < 16; i++)
+        {
+            const int b0 = (i ^ (i >> 1) ^ (i >> 2)) & 1, b1 = ((i >> 1) ^ (i >> 2) ^ (i >> 4)) & 1;
+            const int k = b0 * 2 + b1;
+            const unsigned R1 = s.R[i], R2 = pk_swap(s.R[31 - i]);
+            const unsigned E = pk_min(pk_add(R1, K1a[k]), pk_add(R2, K2a[k]));
+            const unsigned O = pk_min(pk_add(R1, K2b[k]), pk_add(R2, K1b[k]));
+            Rn[2 * i] = E;
+            Rn[2 * i + 1] = O;
+            mnA = pk_min(mnA, E);
+            mnB = pk_min(mnB, O);
+        }
+#pragma unroll
+        for (int r = 0; r < 32; r++)
+            s.R[r] = Rn[r];
+        const unsigned mn = pk_min(mnA, mnB);
+        const unsigned m1 = min(mn & 0xFFFFu, mn >> 16) & 0xFF00u;
+        s.C2 = m1 | (m1 << 16);
+    }
+    template <bool DEC>
+    __device__ __forceinline__ void v2h_group(V2State &s, const uint4 q)
+    {
+        v2h_step<0, DEC>(s, q.x & 0xFFFFu);
+        v2h_step<1, DEC>(s, q.x >> 16);
+        v2h_step<2, DEC>(s, q.y & 0xFFFFu);
+        v2h_step<3, DEC>(s, q.y >> 16);
+        v2h_step<4, DEC>(s, q.z & 0xFFFFu);
+        v2h_step<5, DEC>(s, q.z >> 16);
+        v2h_step<6, DEC>(s, q.w & 0xFFFFu);
+        v2h_step<7, DEC>(s, q.w >> 16);
+    }
+    // the 64 history bytes of a group: dword q = states (2q, 63 - 2q, 2q + 1, 62 - 2q), byte 0 first
+    __device__ __forceinline__ void v2h_gather(const V2State &s, unsigned (&rec)[16])
+    {
+#pragma unroll
+        for (int q = 0; q < 16; q++)
+            rec[q] = __builtin_amdgcn_perm(s.R[2 * q + 1], s.R[2 * q], 0x06040200u);
+    }
+    __device__ __forceinline__ void v2h_clear(V2State &s)
+    {
+#pragma unroll
+        for (int r = 0; r < 32; r++)
+            s.R[r] &= V2_MASK;
+    }
+    __device__ __forceinline__ void v2h_where(unsigned st, unsigned &q, unsigned &byte)
+    {
+        const unsigned r = st < 32u ? st : 63u - st;
+        q = r >> 1;
+        byte = ((r & 1u) << 1) + (st < 32u ? 0u : 1u);
+    }
+    // decisions along the path that ends in state st, step k of the group at bit k (a register-resident record: once per lane)
+    __device__ __forceinline__ unsigned v2h_path(const unsigned (&rec)[16], unsigned st)
+    {
+        unsigned q, byte, w = 0;
+        v2h_where(st, q, byte);
+#pragma unroll
+        for (int i = 0; i < 16; i++)
+            w = (q == (unsigned)i) ? rec[i] : w;
+        return ~(w >> (8u * byte)) & 255u;
+    }
+    __device__ __forceinline__ unsigned v2h_back6(unsigned six) { return __brev(six & 63u) >> 26; } // the state in front of six steps whose decisions are `six` (first step at bit 0)
+
+#ifndef V2H_WAVES
+#define V2H_WAVES 2
+#endif
+    __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(V2H_WAVES, V2H_WAVES))) void k_vit2h_acs(int F, int S, int NSEG, int nblk, const unsigned short *__restrict__ symu, int SU, VitBlockIO *io,
+                                                      uint4 *dec4, long long U64, unsigned *specx, unsigned *endx)
+    {
+        const int u = (int)(blockIdx.x * 64 + threadIdx.x);
+        if (u >= nblk * NSEG)
+            return;
+        const int j = u / NSEG, g = u - j * NSEG;
+        const uint4 *row = reinterpret_cast<const uint4 *>(symu + (size_t)j * SU + (size_t)g * S); // 8 steps per uint4
+        V2State s;
+        v2h_init_neutral(s);
+        unsigned rec[16];
+        // ---- warm-up over the VIT2_WARM steps in front of the segment: only its last group keeps histories (the chained start state, g == 0)
+        constexpr int WG = VIT2_WARM / 8;
+        uint4 q = row[0];
+        for (int grp = 0; grp < WG - 1; grp++)
+        {
+            const uint4 nq = row[grp + 1];
+            v2h_group<false>(s, q);
+            q = nq;
+        }
+        {
+            const uint4 nq = row[WG];
+            v2h_group<true>(s, q);
+            q = nq;
+        }
+        if (g == 0)
+        {
+            int start = io[j].start_in;
+            if (start == -1)
+            { // state 6 steps before the end state of the previous block (cc_decoder.cpp:250-260, 295-302): the decisions of the group's steps 7 .. 2
+                v2h_gather(s, rec);
+                start = (int)v2h_back6(v2h_path(rec, v2_endstate(s)) >> 2);
+            }
+            v2h_init_start(s, start);
+            io[j].start_used = start;
+        }
+        else
+        {
+#pragma unroll
+            for (int r = 0; r < 32; r++)
+                specx[(size_t)u * 32 + r] = v2_norm(s, r);
+            v2h_clear(s);
+        }
+        // ---- the segment itself: S steps (the last segment of a block: S + 6)
+        uint4 *d = dec4 + u;
+        for (int grp = 0; grp < S / 8; grp++)
+        {
+            const uint4 nq = row[WG + grp + 1];
+            v2h_group<true>(s, q);
+            q = nq;
+            v2h_gather(s, rec);
+            v2h_clear(s);
+#pragma unroll
+            for (int v = 0; v < 4; v++)
+                d[(size_t)(grp * 4 + v) * U64] = make_uint4(rec[4 * v], rec[4 * v + 1], rec[4 * v + 2], rec[4 * v + 3]);
+        }
+        if (g == NSEG - 1)
+        {
+            v2h_step<0, true>(s, q.x & 0xFFFFu);
+            v2h_step<1, true>(s, q.x >> 16);
+            v2h_step<2, true>(s, q.y & 0xFFFFu);
+            v2h_step<3, true>(s, q.y >> 16);
+            v2h_step<4, true>(s, q.z & 0xFFFFu);
+            v2h_step<5, true>(s, q.z >> 16);
+            v2h_gather(s, rec);
+#pragma unroll
+            for (int v = 0; v < 4; v++)
+                d[(size_t)((S / 8) * 4 + v) * U64] = make_uint4(rec[4 * v], rec[4 * v + 1], rec[4 * v + 2], rec[4 * v + 3]);
+            const unsigned endstate = v2_endstate(s);
+            io[j].end_state = (int)endstate;
+            io[j].ret_state = (int)v2h_back6(v2h_path(rec, endstate)); // chained start state for the next block: the state in front of steps F .. F+5 (cc_decoder.cpp:250-260,275)
+        }
+        else
+        {
+#pragma unroll
+            for (int r = 0; r < 32; r++)
+                endx[(size_t)u * 32 + r] = v2_norm(s, r);
+        }
+    }
+
+    // ---- traceback on the histories: one lane per (block, segment), a group of 8 steps per hop. Group G of a block = steps 8G .. 8G + 7 (the block's
+    // last one holds 6); bit n of the block is the decision of step n + 6, so output word w of the segment is steps 32w + 6 .. 32w + 37 of it.
+    __global__ __launch_bounds__(64) void k_vit2h_tb(int F, int S, int NSEG, int nblk, const VitBlockIO *io, const uint4 *__restrict__ dec4, long long U64, unsigned *vbits,
+                                                      int wpb, int *entry, int *exitst)
+    {
+        const int u = (int)(blockIdx.x * 64 + threadIdx.x);
+        if (u >= nblk * NSEG)
+            return;
+        const int j = u / NSEG, g = u - j * NSEG;
+        const int GPS = S / 8;
+        const long long ubase = (long long)j * NSEG;
+        auto path = [&](int Gb, unsigned st) -> unsigned { // decisions of group Gb along the path into st (step k at bit k)
+            int gg = Gb / GPS;
+            if (gg > NSEG - 1)
+                gg = NSEG - 1;
+            const int ql = Gb - gg * GPS;
+            unsigned q, byte;
+            v2h_where(st, q, byte);
+            const unsigned *p = reinterpret_cast<const unsigned *>(dec4 + ((size_t)(ql * 4 + (int)(q >> 2)) * U64 + ubase + gg));
+            return ~(p[q & 3u] >> (8u * byte)) & 255u;
+        };
+        const int Gtop = (g + 1) * GPS, Glow = g * GPS;
+        unsigned st;
+        if (g == NSEG - 1)
+            st = (unsigned)io[j].end_state; // the state behind step F + 5
+        else
+        {
+            st = 0u; // overlap: converge onto the survivor path
+            for (int Gb = Gtop + VIT_TB_OVERLAP / 8; Gb > Gtop; Gb--)
+                st = v2h_back6(path(Gb, st));
+        }
+        entry[u] = (int)st; // the state behind the last step of group Gtop
+        unsigned *vb = vbits + (size_t)j * wpb + (size_t)g * (S / 32);
+        unsigned long long acc = 0ull; // steps in time order from bit 63 down, the group just walked first
+        for (int Gb = Gtop; Gb >= Glow; Gb--)
+        {
+            if (Gb == Glow)
+                exitst[u] = (int)st; // the state behind the last step of group Glow = the previous segment's Gtop
+            const unsigned D = path(Gb, st);
+            acc = (acc >> 8) | ((unsigned long long)(__brev(D) >> 24) << 56);
+            const int ql = Gb - Glow;
+            if ((ql & 3) == 0 && ql < GPS)
+                vb[ql >> 2] = (unsigned)(acc >> 26);
+            st = v2h_back6(D);
+        }
+    }
+
     // ---- certificates: segment g's warm-up metrics == segment g-1's end metrics; traceback entry[g] == exit[g+1]
     __global__ __launch_bounds__(64) void k_vit2_cert(int NSEG, int nblk, const unsigned *__restrict__ specx, const unsigned *__restrict__ endx,
                                                        const int *__restrict__ entry, const int *__restrict__ exitst, VitBlockIO *io)
@@ -1081,15 +1333,30 @@ namespace sdhip
             ProfScope _ps("k_vit2_prep", st);
             hipLaunchKernelGGL(k_vit2_prep, dim3((unsigned)nblk), dim3(256), 0, st, cfg, soft, (long long)first_block, nblk, w.symu.p, SU);
         }
+        const bool hist = !(getenv("SDHIP_VIT2_HIST") && atoi(getenv("SDHIP_VIT2_HIST")) == 0); // A/B switch: 0 = per-step decision words (k_vit2_acs / k_vit2_tb)
+        if (hist)
         {
-            ProfScope _ps("k_vit2_acs", st);
-            hipLaunchKernelGGL(k_vit2_acs, dim3((unsigned)(U64 / 64)), dim3(64), 0, st, F, S, NSEG, nblk, w.symu.p, SU, io, (unsigned long long *)w.dec.p, U64,
-                               w.specx.p, w.endx.p);
+            {
+                ProfScope _ps("k_vit2_acs", st);
+                hipLaunchKernelGGL(k_vit2h_acs, dim3((unsigned)(U64 / 64)), dim3(64), 0, st, F, S, NSEG, nblk, w.symu.p, SU, io, (uint4 *)w.dec.p, U64, w.specx.p, w.endx.p);
+            }
+            {
+                ProfScope _ps("k_vit2_tb", st);
+                hipLaunchKernelGGL(k_vit2h_tb, dim3((unsigned)(U64 / 64)), dim3(64), 0, st, F, S, NSEG, nblk, io, (const uint4 *)w.dec.p, U64, vbits, wpb, w.entry.p, w.exitst.p);
+            }
         }
+        else
         {
-            ProfScope _ps("k_vit2_tb", st);
-            hipLaunchKernelGGL(k_vit2_tb, dim3((unsigned)(U64 / 64)), dim3(64), 0, st, F, S, NSEG, nblk, io, (const unsigned long long *)w.dec.p, U64, vbits, wpb,
-                               w.entry.p, w.exitst.p);
+            {
+                ProfScope _ps("k_vit2_acs", st);
+                hipLaunchKernelGGL(k_vit2_acs, dim3((unsigned)(U64 / 64)), dim3(64), 0, st, F, S, NSEG, nblk, w.symu.p, SU, io, (unsigned long long *)w.dec.p, U64,
+                                   w.specx.p, w.endx.p);
+            }
+            {
+                ProfScope _ps("k_vit2_tb", st);
+                hipLaunchKernelGGL(k_vit2_tb, dim3((unsigned)(U64 / 64)), dim3(64), 0, st, F, S, NSEG, nblk, io, (const unsigned long long *)w.dec.p, U64, vbits, wpb,
+                                   w.entry.p, w.exitst.p);
+            }
         }
         {
             ProfScope _ps("k_vit2_cert", st);

@@ -23,12 +23,15 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--cpu-samples", type=int, default=40_000_000)
     ap.add_argument("--frames", type=int, default=0)
+    ap.add_argument("--pool", type=int, default=0, help="1: the handles of consecutive configurations recycle their device blocks (sdhip_pool_enable) instead of freeing and allocating")
     ap.add_argument("configs", nargs="*", default=[""])
     args = ap.parse_args()
     import torch
     from oracle import pyref
     from satdump_amd import capi, synth
     wl = bench.WORKLOADS[args.workload]
+    if args.pool:
+        capi.pool_enable(True)
     frames = args.frames or wl["frames"]
     frames = max(wl["frames_quantum"], frames // wl["frames_quantum"] * wl["frames_quantum"])
     dev = torch.device("cuda", 0)
