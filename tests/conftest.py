@@ -12,6 +12,22 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+@pytest.hookimpl(tryfirst=True)
+def pytest_cmdline_main(config):
+    """The CPU suite (-m "not gpu") spends its time in the host twin's emulated kernels, one test at a time: 35-40 minutes serially, under ten on eight
+    workers. When pytest-xdist is there and the caller did not say otherwise (-n ..., -p no:xdist, SDHIP_NO_XDIST=1), a CPU-only run is spread over the
+    cores. GPU runs are never touched (one device, 17 GB workloads)."""
+    if os.environ.get("SDHIP_NO_XDIST") or not config.pluginmanager.hasplugin("xdist"):
+        return None
+    if getattr(config.option, "markexpr", "") != "not gpu" or getattr(config.option, "numprocesses", None) is not None:
+        return None
+    if getattr(config.option, "collectonly", False) or getattr(config.option, "usepdb", False):
+        return None
+    config.option.numprocesses = max(1, min(8, (os.cpu_count() or 2) - 1))
+    config.option.dist = "load"
+    return None
+
+
 @pytest.fixture(scope="session")
 def ref():
     from oracle import pyref

@@ -19,8 +19,19 @@ def build(force: bool = False) -> str:
     os.makedirs(OUT, exist_ok=True)
     deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, "emu_runtime.cpp"), os.path.join(HERE, "hip", "hip_runtime.h"),
                                                                   os.path.join(ROOT, "include", "sdhip.h"), os.path.abspath(__file__)]
-    if not force and os.path.exists(LIB) and all(os.path.getmtime(LIB) >= os.path.getmtime(d) for d in deps):
+    fresh = lambda: os.path.exists(LIB) and all(os.path.getmtime(LIB) >= os.path.getmtime(d) for d in deps)  # noqa: E731
+    if not force and fresh():
         return LIB
+    # several test processes (pytest-xdist workers) may arrive here at once: one builds, the others wait for it; the library appears atomically
+    import fcntl
+    with open(os.path.join(OUT, ".build.lock"), "w") as lk:
+        fcntl.flock(lk, fcntl.LOCK_EX)
+        if not force and fresh():
+            return LIB
+        return _build_locked()
+
+
+def _build_locked() -> str:
     gen = []
     for f in SOURCES:
         src = open(os.path.join(CSRC, f)).read()
@@ -34,8 +45,9 @@ def build(force: bool = False) -> str:
         open(dst, "w").write(src)
         gen.append(dst)
     cmd = [CLANG, "-x", "c++", "-std=c++17", "-O1", "-g", "-ffp-contract=off", "-fPIC", "-shared", "-Wno-unknown-attributes", "-D__HIPCC__", "-DSDHIP_HOST_TWIN", "-Wno-unused-value",
-           "-I", HERE, "-I", CSRC, "-I", os.path.join(ROOT, "include"), "-o", LIB] + os.environ.get("EMU_DEFS", "").split() + gen + [os.path.join(HERE, "emu_runtime.cpp"), "-lm"]
+           "-I", HERE, "-I", CSRC, "-I", os.path.join(ROOT, "include"), "-o", LIB + ".tmp"] + os.environ.get("EMU_DEFS", "").split() + gen + [os.path.join(HERE, "emu_runtime.cpp"), "-lm"]
     subprocess.run(cmd, check=True)
+    os.replace(LIB + ".tmp", LIB)
     return LIB
 
 
