@@ -19,6 +19,8 @@ def pytest_cmdline_main(config):
     cores. GPU runs are never touched (one device, 17 GB workloads)."""
     if os.environ.get("SDHIP_NO_XDIST") or not config.pluginmanager.hasplugin("xdist"):
         return None
+    if os.environ.get("PYTEST_XDIST_WORKER") or hasattr(config, "workerinput"):  # a worker of such a run: it must not spread itself again
+        return None
     if getattr(config.option, "markexpr", "") != "not gpu" or getattr(config.option, "numprocesses", None) is not None:
         return None
     if getattr(config.option, "collectonly", False) or getattr(config.option, "usepdb", False):

@@ -4,7 +4,7 @@
 TAG=${1:-r04_z}
 OUT=gpurun_out/$TAG; mkdir -p $OUT
 export TMPDIR=/tmp
-timeout 1500 python -m pytest tests/ -m gpu -q --durations=15 2>&1 | tail -45 | tee $OUT/pytest_gpu.txt
+timeout 900 python -m pytest tests/ -m gpu -q --durations=15 2>&1 | tail -45 | tee $OUT/pytest_gpu.txt
 echo "== the driver's command line"; timeout 1200 python bench.py > $OUT/bench.json 2> $OUT/bench.err || { echo "bench rc $?"; tail -20 $OUT/bench.err; }
 LEGS="--cpu-samples 0 --others 0 --next-rows 0 --exact-samples 0 --streamed-samples 0"
 WL=metop_ahrpt
