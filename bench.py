@@ -118,8 +118,11 @@ def pmc_traffic(workload, kernel):
         return None, f"{name} (stale: taken with kernel sources {prof_hash}, this library is {sd_build.source_hash()})"
     rows = [r for r in csv.reader(ln for ln in lines if not ln.startswith("#"))]
     hdr, rows = rows[0], rows[1:]
+    # the engine times the Viterbi lanes under the stage names k_vit2_acs / k_vit2_tb; the symbols rocprofv3 sees since round 4 are the path-history
+    # kernels k_vit2h_acs / k_vit2h_tb (the decision-word kernels keep the plain names: SDHIP_VIT2_HIST=0)
+    alias = {"k_vit2_acs": ("k_vit2_acs", "k_vit2h_acs"), "k_vit2_tb": ("k_vit2_tb", "k_vit2h_tb")}.get(kernel.split("<")[0], (kernel.split("<")[0],))
     for r in rows:
-        if r and r[0].split("<")[0] == kernel.split("<")[0] and (("<" not in kernel) or kernel.split("<")[1].split(">")[0].split(",")[0] in r[0]):
+        if r and r[0].split("<")[0] in alias and (("<" not in kernel) or kernel.split("<")[1].split(">")[0].split(",")[0] in r[0]):
             return float(r[-1]), name  # traffic_bytes_per_dispatch is the last column (kernel names carry commas: count from the right)
     return None, name
 
