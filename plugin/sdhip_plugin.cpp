@@ -68,8 +68,8 @@ namespace sdhip_plugin
     {
         if (baseband_format == "cf32" || baseband_format == "f32")
             return SDHIP_FMT_CF32;
-        if (baseband_format == "cs16" || baseband_format == "s16")
-            return SDHIP_FMT_CS16;
+        if (baseband_format == "cs16" || baseband_format == "s16" || baseband_format == "w16" || baseband_format == "wav")
+            return SDHIP_FMT_CS16; // WAV_16 is read exactly like CS_16 (baseband_interface.h:181-184); the header is skipped below
         if (baseband_format == "cs8" || baseband_format == "s8")
             return SDHIP_FMT_CS8;
         if (baseband_format == "cu8" || baseband_format == "u8")
@@ -77,6 +77,22 @@ namespace sdhip_plugin
         if (baseband_format == "cs32" || baseband_format == "s32")
             return SDHIP_FMT_CS32;
         throw satdump_exception(std::string(who) + ": baseband_format " + baseband_format + " is not on the HIP path (cf32, cs32, cs16, cs8, cu8)");
+    }
+    // The reference's BasebandReader (common/dsp/io/baseband_interface.h:80-81, 143-146) looks at the first four bytes of EVERY baseband file, whatever
+    // baseband_format says: "RIFF" -> the samples start behind a wav::WavHeader (44 bytes), "RF64" -> behind a wav::RF64Header (80 bytes); common/wav.cpp:40-48
+    // test nothing but the magic. Bytes in front of the first sample of `path`.
+    static uint64_t container_header_bytes(const std::string &path)
+    {
+        char magic[4] = {0, 0, 0, 0};
+        std::ifstream f(path, std::ios::binary);
+        f.read(magic, 4);
+        if (f.gcount() != 4)
+            return 0;
+        if (std::memcmp(magic, "RIFF", 4) == 0)
+            return 44;
+        if (std::memcmp(magic, "RF64", 4) == 0)
+            return 80;
+        return 0;
     }
     // BaseDemodModule's constructor (module_demod_base.cpp:12-57) into the C ABI's struct
     static void parse_base_demod(const nlohmann::json &parameters, sdhip_demod_cfg &cfg, const char *who)
@@ -248,8 +264,8 @@ namespace sdhip_plugin
             if (h)
                 sdhip_demod_destroy(h);
         }
-        // Can the HIP path run this parameter set? (The override keeps the CPU module for what it does not cover: frequency
-        // shift / Doppler front-ends, wav/ziq/cs32 containers, ratios that need SmartResampler's power-of-two pre-decimator.)
+        // Can the HIP path run this parameter set? (The override keeps the CPU module for what it does not cover:
+        // ziq / ziq2 containers -- they need the reference's zstd reader --; wav / RF64 headers are skipped as BasebandReader skips them.)
         static bool covers(const std::string &input_file, const std::string &output_file_hint, const nlohmann::json &parameters, std::string &why)
         {
             if (parameters.count("enable_doppler") > 0 && parameters["enable_doppler"].get<bool>() && parameters.count("start_timestamp") == 0)
@@ -344,7 +360,8 @@ namespace sdhip_plugin
             const int N = (int)devices.size(), q = cfg.constellation == SDHIP_BPSK ? 1 : 2;
             std::ifstream probe(d_input_file, std::ios::binary | std::ios::ate);
             filesize = (uint64_t)probe.tellg();
-            const uint64_t n_samples = filesize / bps[fmt];
+            const uint64_t skip = std::min<uint64_t>(container_header_bytes(d_input_file), filesize); // wav / RF64 header in front of the samples
+            const uint64_t n_samples = (filesize - skip) / bps[fmt];
             // overlap: the demodulator's lock-in plus the window the alignment looks at
             sdhip_fec_cfg fdummy;
             sdhip_fec_cfg_default(&fdummy);
@@ -376,7 +393,7 @@ namespace sdhip_plugin
                             if (!e)
                                 throw std::runtime_error(sdhip_last_error());
                             std::ifstream in(d_input_file, std::ios::binary);
-                            in.seekg((std::streamoff)(plan[r].read_start * bps[fmt]));
+                            in.seekg((std::streamoff)(skip + plan[r].read_start * bps[fmt]));
                             uint64_t left = plan[r].stop - plan[r].read_start;
                             const size_t piece = 1 << 22;
                             std::vector<char> raw(piece * bps[fmt]);
@@ -489,12 +506,14 @@ namespace sdhip_plugin
                 std::ifstream in(d_input_file, std::ios::binary);
                 in.seekg(0, std::ios::end);
                 filesize = (uint64_t)in.tellg();
-                in.seekg(0, std::ios::beg);
+                const uint64_t skip = std::min<uint64_t>(container_header_bytes(d_input_file), filesize); // wav / RF64 header in front of the samples
+                in.seekg((std::streamoff)skip, std::ios::beg);
+                progress = skip;
                 if (cfg.doppler)
                 {
                     sdhip_demod_stats st0;
                     sdhip_demod_get_stats(h, &st0);
-                    const std::vector<float> t = doppler_targets(filesize / bps[fmt], st0.buffer_size);
+                    const std::vector<float> t = doppler_targets((filesize - skip) / bps[fmt], st0.buffer_size);
                     if (sdhip_demod_doppler_targets(h, t.data(), t.size()) < 0)
                         throw satdump_exception(std::string("psk_demod_hip: ") + sdhip_last_error());
                     logger->info("Doppler correction: %d source buffers of %d samples, first target %.1f Hz", (int)t.size(), st0.buffer_size,
@@ -1169,7 +1188,9 @@ namespace sdhip_plugin
                 std::ifstream in(d_input_file, std::ios::binary);
                 in.seekg(0, std::ios::end);
                 filesize = (uint64_t)in.tellg();
-                in.seekg(0, std::ios::beg);
+                const uint64_t skip = std::min<uint64_t>(container_header_bytes(d_input_file), filesize); // wav / RF64 header in front of the samples
+                in.seekg((std::streamoff)skip, std::ios::beg);
+                progress = skip;
                 const size_t samples_per_read = 1 << 22;
                 std::vector<char> raw(samples_per_read * bps[fmt]);
                 while (!should_stop && in)

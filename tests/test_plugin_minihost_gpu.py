@@ -410,6 +410,52 @@ def test_hip_devices_through_the_plugin(host, tmp_path, case):
     check_hip_devices_through_the_plugin(host, LIB, tmp_path, case=case, nframes=120 if case == "metop" else 60)
 
 
+def check_wav_container_through_the_plugin(host, lib, tmp_path, nframes=16, sharded=True, serial_chunks=False):
+    """wav / RF64 recordings through the stock id `psk_demod` under the override. The reference's BasebandReader (common/dsp/io/baseband_interface.h:80-81,
+    143-146, 181-184; common/wav.cpp:40-48) looks at the first four bytes of EVERY baseband file: "RIFF" -> the samples start behind the 44-byte
+    wav::WavHeader, "RF64" -> behind the 80-byte wav::RF64Header, whatever baseband_format says; `w16` / `wav` is read exactly like cs16. The .soft file of
+    such a recording must be the .soft file of the bare samples, byte for byte (same samples in, deterministic engine) -- on one device and cut over
+    `hip_devices` (the chunk plan counts samples behind the header). A header in front of cf32 samples is skipped the same way."""
+    import struct
+    spec, cadus, plain, syms = util.goes_case(nframes=nframes)
+    x, _ = synth.modulate(syms, spec)
+    q = synth.to_cs16(x)
+    raw = q.tobytes()
+    riff = b"RIFF" + struct.pack("<I", 36 + len(raw)) + b"WAVEfmt " + struct.pack("<IHHIIHH", 16, 1, 2, 3000000, 12000000, 4, 16) + b"data" + struct.pack("<I", len(raw))
+    assert len(riff) == 44
+    rf64 = b"RF64" + struct.pack("<I", 0xFFFFFFFF) + b"WAVE" + b"\0" * 36 + b"fmt " + struct.pack("<IHHIIHH", 16, 1, 2, 3000000, 12000000, 4, 16) + b"data" + struct.pack("<I", 0xFFFFFFFF)
+    assert len(rf64) == 80
+    files = {"bare": (b"", raw, "cs16"), "wav": (riff, raw, "w16"), "wavfmt": (riff, raw, "wav"), "rf64": (rf64, raw, "cs16"), "barecf": (b"", x.tobytes(), "cf32"), "wavcf": (riff, x.tobytes(), "cf32")}
+    runs = [("bare", {}), ("wav", {}), ("wavfmt", {}), ("rf64", {}), ("barecf", {}), ("wavcf", {})]
+    if sharded:
+        runs += [("bare", {"hip_devices": [0, 0]}), ("wav", {"hip_devices": [0, 0]})]
+    soft = {}
+    for name, extra in runs:
+        hdr, body, fmt = files[name]
+        inp = tmp_path / (name + ".bin")
+        inp.write_bytes(hdr + body)
+        key = name + ("+devices" if extra else "")
+        job = {"mode": "file", "input": str(inp), "output_hint": str(tmp_path / key), "demod": {"module": "psk_demod", "parameters": dict(GOES_DEMOD, baseband_format=fmt, **extra)}}
+        jp = tmp_path / (key + ".json")
+        jp.write_text(json.dumps(job))
+        p = subprocess.run([host, lib, PLUGIN, "run", str(jp)], capture_output=True, text=True,
+                           env=dict(os.environ, SDHIP_OVERRIDE="1", SDHIP_PLUGIN_SERIAL_CHUNKS="1" if serial_chunks else "0"), timeout=900)
+        assert p.returncode == 0, p.stdout[-1000:] + p.stderr[-3000:]
+        rep = json.loads(p.stdout.strip().splitlines()[-1])
+        assert rep["demod_class"] == "psk_demod_hip", rep
+        soft[key] = np.fromfile(rep["soft"], dtype=np.int8)
+    assert len(soft["bare"]) > nframes * 8192 * 2 * 0.95  # r = 1/2 BPSK: 16 384 soft symbols per CADU
+    for k in ("wav", "wavfmt", "rf64"):
+        assert np.array_equal(soft[k], soft["bare"]), (k, len(soft[k]), len(soft["bare"]))
+    assert np.array_equal(soft["wavcf"], soft["barecf"])
+    if sharded:
+        assert np.array_equal(soft["wav+devices"], soft["bare+devices"]) and len(soft["bare+devices"]) == len(soft["bare"])
+
+
+def test_wav_container_through_the_plugin(host, tmp_path):
+    check_wav_container_through_the_plugin(host, LIB, tmp_path, nframes=30)
+
+
 def check_ndsp_single_blocks_through_the_plugin(host, lib, tmp_path):
     """plugin/sdhip_ndsp_block.h -- SingleHipBlock, the chain's member blocks as satdump::ndsp::Block's of their own (agc_cc, rrc_fir_cc,
     clock_recovery_mm_cc, costas_cc, clock_recovery_gardner_cc: what the flowgraph registry offers next to the hier block) -- instantiated from the plugin under the stock ids,
