@@ -19,6 +19,7 @@
 #include "pipeline/module.h"
 #include "pipeline/modules/base/filestream_to_filestream.h"
 #include "dsp/block.h"
+#include "dsp/flowgraph/dsp_flowgraph_register.h" // RegisterNodesEvent, Flowgraph::NodeInternalReg (the flowgraph-registry variant of the plugin)
 
 #include <dlfcn.h>
 #include <filesystem>
@@ -40,6 +41,26 @@ namespace ImGui
 }
 namespace satdump
 {
+    namespace widgets
+    { // node_int.h's inline upd_state() drags the options GUI's inline code in, which refers to this widget (common/widgets/double_list.cpp: ImGui): never
+      // constructed here (no node gets an options displayer), defined so that the host links
+        DoubleList::DoubleList(std::string name) : d_id(name), current_value(nullptr) {}
+        DoubleList::~DoubleList() {}
+        void DoubleList::set_list(std::vector<double> list, bool, std::string) { available_values = list; }
+        bool DoubleList::set_value(double, double) { return false; }
+    } // namespace widgets
+    namespace ndsp
+    {
+        namespace flowgraph
+        {
+            // src-core/dsp/flowgraph/node_int.cpp without its GUI side (the OptDisplayerWarper it creates and render()'s ImGui calls): what the registry entries
+            // of dsp_flowgraph_register.h:23-28 -- and the plugin's RegisterNodesEvent handler -- construct around a block
+            NodeInternal::NodeInternal(const Flowgraph *f, std::shared_ptr<ndsp::Block> b) : f((Flowgraph *)f), blk(b) {}
+            bool NodeInternal::render() { return false; }
+            nlohmann::json NodeInternal::getP() { return blk->get_cfg(); }
+            void NodeInternal::setP(nlohmann::json p) { blk->set_cfg(p); }
+        } // namespace flowgraph
+    } // namespace ndsp
     uint64_t getFilesize(std::string filepath) { return std::filesystem::exists(filepath) ? (uint64_t)std::filesystem::file_size(filepath) : 0; }
     std::map<std::string, std::shared_ptr<satdump::Plugin>> loaded_plugins;
     std::shared_ptr<EventBus> eventBus = std::make_shared<EventBus>();
@@ -168,13 +189,43 @@ int main(int argc, char **argv)
         }
         try
         {
-            auto make = reinterpret_cast<Block *(*)(const char *)>(dlsym(dyn, "sdhip_plugin_make_ndsp_block"));
-            if (!make)
-                return fail("plugin has no sdhip_plugin_make_ndsp_block()");
-            std::unique_ptr<Block> blk(make(job["block"].get<std::string>().c_str()));
+            nlohmann::json report;
+            std::shared_ptr<Block> blk;
+            if (job.value("via_registry", false))
+            { // the flowgraph's node registry (dsp_flowgraph_register.cpp: the stock nodes first, then RegisterNodesEvent :438): stand-ins under the stock
+              // ids, the plugin's handler adds its nodes (and, under SDHIP_OVERRIDE=1 with a device, re-points the stock ones); the node is then made
+              // the way Flowgraph::addNode does it -- registry entry's func(flowgraph) -- and its block run below
+                using namespace satdump::ndsp::flowgraph;
+                std::map<std::string, Flowgraph::NodeInternalReg> reg;
+                for (const char *id : {"psk_demod_cc", "rrc_fir_cc", "agc_cc", "clock_recovery_mm_cc", "costas_cc", "clock_recovery_gardner_cc"})
+                    reg.insert({id, {std::string("stock/") + id, [](const Flowgraph *) { return std::shared_ptr<NodeInternal>(); }}});
+                satdump::eventBus->fire_event<RegisterNodesEvent>({reg});
+                nlohmann::json ids = nlohmann::json::object();
+                for (auto &kv : reg)
+                    ids[kv.first] = kv.second.menuname;
+                report["registry"] = ids;
+                const std::string id = job["block"].get<std::string>();
+                if (!reg.count(id))
+                    return fail("node id not in the registry: " + id);
+                std::shared_ptr<NodeInternal> node = reg.at(id).func(nullptr);
+                if (!node)
+                {
+                    report["node"] = "stock stand-in";
+                    std::cout << report.dump() << std::endl;
+                    return 0;
+                }
+                blk = node->blk;
+                report["node_cfg"] = node->getP();
+            }
+            else
+            {
+                auto make = reinterpret_cast<Block *(*)(const char *)>(dlsym(dyn, "sdhip_plugin_make_ndsp_block"));
+                if (!make)
+                    return fail("plugin has no sdhip_plugin_make_ndsp_block()");
+                blk.reset(make(job["block"].get<std::string>().c_str()));
+            }
             if (!blk)
                 return fail("unknown ndsp block");
-            nlohmann::json report;
             report["block"] = blk->d_id;
             nlohmann::json res = nlohmann::json::object();
             for (auto &kv : job["cfg"].items())

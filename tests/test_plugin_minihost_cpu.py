@@ -143,3 +143,14 @@ def test_wav_container_through_the_plugin_on_the_twin(host, tmp_path):
     if not os.path.exists(emu_build.CLANG):
         pytest.skip("needs a host clang++")
     G.check_wav_container_through_the_plugin(host, emu_build.build(), tmp_path, nframes=10, serial_chunks=True)
+
+
+def test_flowgraph_registry_through_the_plugin_on_the_twin(host, tmp_path):
+    """tests/test_plugin_minihost_gpu.py::test_flowgraph_registry_through_the_plugin with the host twin as the C-ABI library: the plugin built with
+    -DSDHIP_WITH_FLOWGRAPH, its RegisterNodesEvent handler fired and its nodes made and run by the minihost -- in the CPU suite."""
+    from oracle import pyref
+    from tests import test_plugin_minihost_gpu as G
+    from tests.emu import build as emu_build
+    if not pyref.NdspRef.available() or not os.path.exists(emu_build.CLANG):
+        pytest.skip("needs the compiled reference ndsp blocks and a host clang++")
+    G.check_flowgraph_registry_through_the_plugin(host, emu_build.build(), tmp_path)

@@ -237,10 +237,13 @@ def test_freq_shift_through_the_override(host, tmp_path):
     assert got.shape == want.shape and np.array_equal(got, want) and len(got) >= 26
 
 
-def _run_ndsp(host, lib, job, tmp_path):
+PLUGIN_FG = os.path.join(ROOT, "plugin", "_build", "libsdhip_support_fg.so")  # built with -DSDHIP_WITH_FLOWGRAPH (plugin/Makefile)
+
+
+def _run_ndsp(host, lib, job, tmp_path, plugin=PLUGIN, env=None):
     jp = tmp_path / "ndsp_job.json"
     jp.write_text(json.dumps(job))
-    p = subprocess.run([host, lib, PLUGIN, "ndsp", str(jp)], capture_output=True, text=True, env=dict(os.environ), timeout=600)
+    p = subprocess.run([host, lib, plugin, "ndsp", str(jp)], capture_output=True, text=True, env=dict(os.environ, **(env or {})), timeout=600)
     assert p.returncode == 0, p.stdout[-1000:] + p.stderr[-3000:]
     return json.loads(p.stdout.strip().splitlines()[-1])
 
@@ -274,6 +277,54 @@ def test_ndsp_block_through_the_plugin(host, tmp_path):
     if not pyref.NdspRef.available():
         pytest.skip("needs the compiled reference ndsp blocks")
     check_ndsp_block_through_the_plugin(host, LIB, tmp_path)
+
+
+def check_flowgraph_registry_through_the_plugin(host, lib, tmp_path):
+    """The plugin's RegisterNodesEvent handler EXECUTED ("registered in the flowgraph registry"): the plugin built with -DSDHIP_WITH_FLOWGRAPH
+    (what INTEGRATION.md's CMake fragment builds inside a SatDump tree) is loaded by the minihost, which fills a node registry with stand-ins under the stock
+    ids, fires the event where dsp_flowgraph_register.cpp:438 fires it, and makes the node the way the flowgraph does -- the registry entry's func -- around
+    a NodeInternal without its GUI side. The node's block then runs between two DSPStream FIFOs: the plugin's own id gives the reference hier block's symbols
+    bit for bit (exact); under SDHIP_OVERRIDE=1 the stock ids make the HIP blocks, without it they stay what they were."""
+    from tests.test_ndsp_gpu import _signal
+    if not os.path.exists(PLUGIN_FG):
+        pytest.skip("plugin/_build/libsdhip_support_fg.so not built")
+    nd = pyref.NdspRef()
+    x = _signal("qpsk", 40000, 6e6, 2.33e6)
+    inp = tmp_path / "bb.cf32"
+    x.tofile(str(inp))
+    cfg = {"constellation": "qpsk", "samplerate": 6e6, "symbolrate": 2.33e6}
+    want = nd.run("psk_demod_cc", cfg, x)
+    job = {"block": "psk_demod_hip_cc", "via_registry": True, "cfg": dict(cfg, exact=True), "input": str(inp), "output": str(tmp_path / "r.cf32"), "buffer": 8192}
+    rep = _run_ndsp(host, lib, job, tmp_path, plugin=PLUGIN_FG)
+    reg = rep["registry"]
+    for pid in ("psk_demod_hip_cc", "rrc_fir_hip_cc", "agc_hip_cc", "clock_recovery_mm_hip_cc", "costas_hip_cc", "clock_recovery_gardner_hip_cc"):
+        assert pid in reg and reg[pid].endswith("(MI355X)"), reg
+    for sid in ("psk_demod_cc", "rrc_fir_cc", "agc_cc", "clock_recovery_mm_cc", "costas_cc", "clock_recovery_gardner_cc"):
+        assert reg[sid] == "stock/" + sid  # the entries of the stock nodes are not replaced, only (under the override) their func
+    assert rep["block"] == "psk_demod_hip_cc" and rep["symbols"] == len(want) and "constellation" in rep["node_cfg"]
+    got = np.fromfile(str(tmp_path / "r.cf32"), dtype=np.complex64)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    # a stock id: the stand-in without the override, the HIP block with it -- the same symbols as the plugin's own id
+    rep = _run_ndsp(host, lib, dict(job, block="psk_demod_cc"), tmp_path, plugin=PLUGIN_FG)
+    assert rep.get("node") == "stock stand-in"
+    rep = _run_ndsp(host, lib, dict(job, block="psk_demod_cc", output=str(tmp_path / "o.cf32")), tmp_path, plugin=PLUGIN_FG, env={"SDHIP_OVERRIDE": "1"})
+    assert rep["block"] == "psk_demod_hip_cc" and rep["symbols"] == len(want)
+    assert np.array_equal(np.fromfile(str(tmp_path / "o.cf32"), dtype=np.uint32), want.view(np.uint32))
+    # ... and a member block's stock id: the node made by the registry runs like the block made by the plugin's factory
+    ccfg = {"order": 4, "loop_bw": 0.004}
+    outs = {}
+    for name, via in (("factory", False), ("registry", True)):
+        rep = _run_ndsp(host, lib, {"block": "costas_cc", "via_registry": via, "cfg": dict(ccfg, exact=True), "input": str(inp), "output": str(tmp_path / (name + ".cf32")), "buffer": 8192},
+                        tmp_path, plugin=PLUGIN_FG, env={"SDHIP_OVERRIDE": "1"})
+        assert rep["block"] == "costas_hip_cc" and rep["symbols"] == len(x), rep
+        outs[name] = np.fromfile(str(tmp_path / (name + ".cf32")), dtype=np.uint32)
+    assert np.array_equal(outs["factory"], outs["registry"])
+
+
+def test_flowgraph_registry_through_the_plugin(host, tmp_path):
+    if not pyref.NdspRef.available():
+        pytest.skip("needs the compiled reference ndsp blocks")
+    check_flowgraph_registry_through_the_plugin(host, LIB, tmp_path)
 
 
 def check_dvbs2_module_through_the_plugin(host, lib, tmp_path, modcod=12, short=1, nfr=16, acq=3 * 5490, extra_legs=True):
