@@ -2512,6 +2512,107 @@ namespace sdhip
         }
     }
 
+    // ---- the screen for I = 4 (every CCSDS 1020- / 1024-byte CADU): the four interleaved codewords of a frame as ONE packed dword per symbol position --------
+    // Byte k of codeword b of a frame lies at frame[(k - fb) * 4 + b]: the dword at position k - fb holds symbol k of all four codewords. A lane (one generator
+    // root, as above) runs Horner on the four codewords at once: S <- S * alpha^lr ^ symbols, four GF(256) bytes per register. Multiplying a byte by a CONSTANT
+    // is linear over GF(2): x * c = Ta[x & 7] ^ Tb[(x >> 3) & 7] ^ Tc[x >> 6], three 8-entry byte tables = two registers each, looked up for four bytes at once by
+    // v_perm_b32 (selector byte 0..7 picks that byte of the register pair). 11 VALU instructions per symbol position of FOUR codewords and no table in LDS on the
+    // recurrence (k_rs_screen: log and exp look-ups per codeword and symbol, two dependent LDS reads each, bank conflicts above its LDS-active cycles). The dual
+    // basis conversion (linear too) is applied the same way while the frame is staged. Same syndromes, flags and lists as k_rs_screen, byte for byte.
+    struct Lin8
+    {
+        unsigned a0, a1, b0, b1, c0; // Ta[0..3], Ta[4..7], Tb[0..3], Tb[4..7], Tc[0..3]
+    };
+    __device__ __forceinline__ unsigned lin8_apply(const Lin8 &t, unsigned x)
+    {
+        const unsigned ia = x & 0x07070707u, ib = (x >> 3) & 0x07070707u, ic = (x >> 6) & 0x03030303u;
+        return __builtin_amdgcn_perm(t.a1, t.a0, ia) ^ __builtin_amdgcn_perm(t.b1, t.b0, ib) ^ __builtin_amdgcn_perm(0u, t.c0, ic);
+    }
+    template <class F>
+    __device__ __forceinline__ Lin8 lin8_make(F f)
+    { // f(x): the linear map's value on byte x
+        Lin8 t{0, 0, 0, 0, 0};
+        for (int i = 0; i < 4; i++)
+        {
+            t.a0 |= (unsigned)f(i) << (8 * i);
+            t.a1 |= (unsigned)f(4 + i) << (8 * i);
+            t.b0 |= (unsigned)f(i << 3) << (8 * i);
+            t.b1 |= (unsigned)f((4 + i) << 3) << (8 * i);
+            t.c0 |= (unsigned)f(i << 6) << (8 * i);
+        }
+        return t;
+    }
+    constexpr int RSS4_FR = 8; // frames per block: 32 codewords, 256 threads (frame, root)
+    __global__ __launch_bounds__(32 * RSS4_FR) void k_rs_screen4(const unsigned char *__restrict__ data, int nframes, int frame_stride, int dualbasis, int nroots, int fill_bytes,
+                                                                 unsigned char *clean, const GfTables *tabs, int *errors, int *dirty)
+    {
+        __shared__ __attribute__((aligned(16))) unsigned stage[RSS4_FR][256]; // symbol position k of the frame's four codewords (position 255: padding)
+        __shared__ __attribute__((aligned(4))) unsigned char sy_sh[RSS4_FR * 4][32];
+        const int tid = (int)threadIdx.x;
+        const long long f0 = (long long)blockIdx.x * RSS4_FR, ncw = (long long)nframes * 4, cw0 = f0 * 4;
+        const int fb = fill_bytes < 0 ? 0 : fill_bytes;
+        const Lin8 dual = lin8_make([&](int x) { return tabs->from_dual[x]; });
+        for (int idx = tid; idx < RSS4_FR * 256; idx += 32 * RSS4_FR)
+        {
+            const int fi = idx >> 8, k = idx & 255;
+            unsigned v = 0;
+            if (f0 + fi < nframes && k >= fb && k < 255)
+            {
+                v = reinterpret_cast<const unsigned *>(data + (size_t)(f0 + fi) * frame_stride)[k - fb];
+                if (dualbasis)
+                    v = lin8_apply(dual, v);
+            }
+            stage[fi][k] = v;
+        }
+        const int fi = tid >> 5, r = tid & 31;
+        unsigned S = 0;
+        __syncthreads();
+        if (r < nroots && f0 + fi < nframes)
+        {
+            const int fcr = nroots == 32 ? 112 : 120, gap = 11;
+            const unsigned lr = (unsigned)((gap * (r + fcr)) % 255); // log of generator root r (reed-solomon.c:9-11)
+            const Lin8 mul = lin8_make([&](int x) { return x ? tabs->exp[tabs->log[x] + lr] : (unsigned char)0; });
+            const uint4 *row = reinterpret_cast<const uint4 *>(stage[fi]);
+#pragma unroll 4
+            for (int k4 = 0; k4 < 64; k4++)
+            {
+                const uint4 q = row[k4];
+                S = lin8_apply(mul, S) ^ q.x;
+                S = lin8_apply(mul, S) ^ q.y;
+                S = lin8_apply(mul, S) ^ q.z;
+                if (k4 < 63)
+                    S = lin8_apply(mul, S) ^ q.w;
+            }
+        }
+#pragma unroll
+        for (int b = 0; b < 4; b++)
+            sy_sh[fi * 4 + b][r] = (unsigned char)(S >> (8 * b));
+        __syncthreads();
+        { // 32 codewords x 8 dwords of syndromes, behind the flags (the layout k_rs reads)
+            const int c = tid >> 3, d = tid & 7;
+            if (cw0 + c < ncw)
+            {
+                unsigned char *sp = clean + ((ncw + 15) / 16 * 16) + (size_t)(cw0 + c) * 32;
+                reinterpret_cast<unsigned *>(sp)[d] = reinterpret_cast<const unsigned *>(sy_sh[c])[d];
+            }
+        }
+        if (tid < RSS4_FR * 4 && cw0 + tid < ncw)
+        {
+            unsigned any = 0;
+#pragma unroll
+            for (int d = 0; d < 8; d++)
+                any |= reinterpret_cast<const unsigned *>(sy_sh[tid])[d];
+            clean[cw0 + tid] = any ? 0 : 1;
+            if (dirty)
+            { // clean: no errors, nothing more to do; dirty: onto the decoder's list
+                if (any)
+                    dirty[1 + atomicAdd(dirty, 1)] = (int)(cw0 + tid);
+                else
+                    errors[cw0 + tid] = 0;
+            }
+        }
+    }
+
     void launch_rs_only(uint8_t *data, int nframes, int frame_stride, int dualbasis, int I, int nroots, int fill_bytes, int *errors, hipStream_t st, uint8_t *clean_scratch)
     {
         const long long n = (long long)nframes * I;
@@ -2525,8 +2626,13 @@ namespace sdhip
             dirty = reinterpret_cast<int *>(clean_scratch + rs_scratch_list_offset(n));
             SD_HIP(hipMemsetAsync(dirty, 0, sizeof(int), st));
             ProfScope _ps("k_rs_screen", st);
-            hipLaunchKernelGGL(k_rs_screen, dim3((unsigned)((n + RSS_CW - 1) / RSS_CW)), dim3(32 * RSS_CW), 0, st, data, nframes, frame_stride, dualbasis, I, nroots, fill_bytes,
-                               clean_scratch, tabs, errors, dirty);
+            static const bool packed_ok = !(getenv("SDHIP_RS_SCREEN4") && atoi(getenv("SDHIP_RS_SCREEN4")) == 0);
+            if (packed_ok && I == 4 && frame_stride % 4 == 0 && (reinterpret_cast<uintptr_t>(data) & 3u) == 0)
+                hipLaunchKernelGGL(k_rs_screen4, dim3((unsigned)((nframes + RSS4_FR - 1) / RSS4_FR)), dim3(32 * RSS4_FR), 0, st, data, nframes, frame_stride, dualbasis, nroots,
+                                   fill_bytes, clean_scratch, tabs, errors, dirty);
+            else
+                hipLaunchKernelGGL(k_rs_screen, dim3((unsigned)((n + RSS_CW - 1) / RSS_CW)), dim3(32 * RSS_CW), 0, st, data, nframes, frame_stride, dualbasis, I, nroots, fill_bytes,
+                                   clean_scratch, tabs, errors, dirty);
         }
         ProfScope _ps("k_rs", st);
         hipLaunchKernelGGL(k_rs, dim3((unsigned)((n + RS_THREADS - 1) / RS_THREADS)), dim3(RS_THREADS), 0, st, data, nframes, frame_stride, dualbasis, I, nroots,
