@@ -1937,6 +1937,11 @@ namespace sdhip
     // addresses -- the lanes' windows sit at unrelated ring positions, and a lane-major layout made them collide at random
     // (SQ: bank-conflict cycles were twice the active LDS cycles)
     constexpr int MM_RING_STRIDE = 64; // cf32 units between consecutive slots of one lane
+    // Mirror region: whenever slots 0..6 are written they are written a second time at MM_RING..MM_RING+6, so an 8-tap window that starts at any slot of
+    // the ring is 8 CONSECUTIVE slots [base, base+7] -- one address per symbol and immediate offsets instead of a wrap per tap (the ring addresses were
+    // ~24 of the ~130 VALU instructions of a symbol). A window lies inside the last MM_RING samples, so the copy a reader finds behind slot 31 is the
+    // newest write of that slot, the very value the wrapped read returned.
+    constexpr int MM_MIRROR = 7;
     constexpr int MM_DEPTH = 4;
     __device__ __forceinline__ void mm_rot_cs(int q, int order, float &c, float &s)
     {
@@ -1986,6 +1991,8 @@ namespace sdhip
                 f.prev_im = t;
             }
             f.ring[(slot + j) * MM_RING_STRIDE] = v;
+            if (j < MM_MIRROR && slot == 0)
+                f.ring[(MM_RING + j) * MM_RING_STRIDE] = v;
         }
         f.next = i + 8;
     }
@@ -2042,7 +2049,7 @@ namespace sdhip
 #pragma unroll
         for (int k = 0; k < 8; k++)
         {
-            const cf32 v = ring[((base + k) & (MM_RING - 1)) * MM_RING_STRIDE];
+            const cf32 v = ring[(base + k) * MM_RING_STRIDE];
             if constexpr (FAST)
                 acc = __builtin_elementwise_fma(v2f{v.re, v.im}, v2f{t[k], t[k]}, acc); // chunk-parallel mode's arithmetic (see sd_sincosf_fast)
             else
@@ -2106,7 +2113,7 @@ namespace sdhip
 #pragma unroll
         for (int k = 0; k < 8; k++)
         {
-            const cf32 v = ring[((basez + k) & (MM_RING - 1)) * MM_RING_STRIDE];
+            const cf32 v = ring[(basez + k) * MM_RING_STRIDE];
             if constexpr (FAST)
                 az = __builtin_elementwise_fma(v2f{v.re, v.im}, v2f{tz[k], tz[k]}, az);
             else
@@ -2118,7 +2125,7 @@ namespace sdhip
 #pragma unroll
         for (int k = 0; k < 8; k++)
         {
-            const cf32 v = ring[((base + k) & (MM_RING - 1)) * MM_RING_STRIDE];
+            const cf32 v = ring[(base + k) * MM_RING_STRIDE];
             if constexpr (FAST)
                 as = __builtin_elementwise_fma(v2f{v.re, v.im}, v2f{t[k], t[k]}, as);
             else
@@ -2181,7 +2188,7 @@ template <bool CKPT, bool SPLIT, bool Q8 = false, bool FAST = false, bool GARD =
                                                MmState *endst, MmCert *spec_c, MmCert *end_c, const int *redo, int nredo, MmCkpt *ck, int ck_per_chunk,
                                                float ck_tol)
     {
-        __shared__ cf32 rings[MM_RING * MM_RING_STRIDE];
+        __shared__ cf32 rings[(MM_RING + MM_MIRROR) * MM_RING_STRIDE];
         __shared__ __attribute__((aligned(16))) float bank[128 * 12];
         for (int i = (int)threadIdx.x; i < 128 * 8; i += 64)
             bank[(i >> 3) * p.arm_stride + (i & 7)] = p.bank[i];
