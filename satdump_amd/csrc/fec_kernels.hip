@@ -611,8 +611,17 @@ namespace sdhip
     // previous block directly.
     constexpr int V2P_STEPS = 2048;              // steps per thread block (256 threads x 8)
     constexpr int V2P_LDS = 2 * V2P_STEPS + 64;  // staged bytes: rate 1/2 needs 2 per step (+ shift, + alignment slack)
-    __global__ __launch_bounds__(256) void k_vit2_prep(VitCfg c, const int8_t *__restrict__ soft, long long first_block, int nblk, unsigned short *symu, int SU)
+    // MODE / PHASE >= 0: that value of the decoder configuration at compile time (the kernel tests the run-uniform mode and phase per soft pair, nine pairs a
+    // thread: scalar compares and branches were as many as its vector instructions); -1: read from the configuration, as before -- for anything the host does
+    // not dispatch. Same code, same results.
+    template <int MODE, int PHASE>
+    __global__ __launch_bounds__(256) void k_vit2_prep(VitCfg c_in, const int8_t *__restrict__ soft, long long first_block, int nblk, unsigned short *symu, int SU)
     {
+        VitCfg c = c_in;
+        if constexpr (MODE >= 0)
+            c.mode = MODE;
+        if constexpr (PHASE >= 0)
+            c.phase = PHASE;
         // thread = 8 consecutive steps of one row (one 16-byte store); one thread block per row, looping over its tiles of 2048 steps
         // (a block per tile -- 700 k blocks of 4 KB each on a MetOp batch -- was bound by the rate blocks can be dispatched at)
         __shared__ __attribute__((aligned(16))) unsigned char stage[V2P_LDS];
@@ -1331,7 +1340,21 @@ namespace sdhip
         const int wpb = vit_words_per_block(F);
         {
             ProfScope _ps("k_vit2_prep", st);
-            hipLaunchKernelGGL(k_vit2_prep, dim3((unsigned)nblk), dim3(256), 0, st, cfg, soft, (long long)first_block, nblk, w.symu.p, SU);
+            auto go = [&](auto kern) { hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), 0, st, cfg, soft, (long long)first_block, nblk, w.symu.p, SU); };
+            static const bool templ = !(getenv("SDHIP_VIT2_PREP_TEMPL") && atoi(getenv("SDHIP_VIT2_PREP_TEMPL")) == 0);
+            const int key = (templ && (cfg.mode == 0 || cfg.mode == 1) && cfg.phase >= 0 && cfg.phase <= 3) ? cfg.mode * 4 + cfg.phase : -1;
+            switch (key)
+            {
+            case 0: go(k_vit2_prep<0, 0>); break;
+            case 1: go(k_vit2_prep<0, 1>); break;
+            case 2: go(k_vit2_prep<0, 2>); break;
+            case 3: go(k_vit2_prep<0, 3>); break;
+            case 4: go(k_vit2_prep<1, 0>); break;
+            case 5: go(k_vit2_prep<1, 1>); break;
+            case 6: go(k_vit2_prep<1, 2>); break;
+            case 7: go(k_vit2_prep<1, 3>); break;
+            default: go(k_vit2_prep<-1, -1>); break;
+            }
         }
         const bool hist = !(getenv("SDHIP_VIT2_HIST") && atoi(getenv("SDHIP_VIT2_HIST")) == 0); // A/B switch: 0 = per-step decision words (k_vit2_acs / k_vit2_tb)
         if (hist)
