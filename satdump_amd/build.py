@@ -27,13 +27,34 @@ def _newer(target: str, deps: list[str]) -> bool:
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
 
+def _compile_one(args):
+    hipcc, src, obj, verbose = args
+    cmd = [hipcc] + [f for f in HIPCC_FLAGS if f != "-shared"] + ["-c", src, "-o", obj]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd, cwd=ROOT)
+    return obj
+
+
 def build_lib(force: bool = False, verbose: bool = True) -> str:
+    """One object per translation unit (compiled side by side, only the ones whose source or a header changed), then one link."""
+    from concurrent.futures import ThreadPoolExecutor
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     srcs = [os.path.join(CSRC, s) for s in HIP_SOURCES if os.path.exists(os.path.join(CSRC, s))]
-    deps = srcs + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + [os.path.join(ROOT, "include", "sdhip.h")]
-    os.makedirs(LIBDIR, exist_ok=True)
-    if force or _newer(LIB, deps):
-        cmd = [hipcc] + HIPCC_FLAGS + srcs + ["-o", LIB]
+    hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".inc"))] + [os.path.join(ROOT, "include", "sdhip.h")]
+    objdir = os.path.join(LIBDIR, "obj")
+    os.makedirs(objdir, exist_ok=True)
+    jobs, objs = [], []
+    for s in srcs:
+        o = os.path.join(objdir, os.path.basename(s)[:-4] + ".o")
+        objs.append(o)
+        if force or _newer(o, [s] + hdrs):
+            jobs.append((hipcc, s, o, verbose))
+    if jobs:
+        with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 4)) as ex:
+            list(ex.map(_compile_one, jobs))
+    if jobs or force or _newer(LIB, objs):
+        cmd = [hipcc, "--offload-arch=gfx950", "-fPIC", "-shared"] + objs + ["-o", LIB]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd, cwd=ROOT)
