@@ -144,6 +144,11 @@ extern "C"
        tail. Returns soft bytes written, <0 on error. Stream state carries across calls. */
     int64_t sdhip_demod_process_dev(void *h, const void *d_iq, size_t nsamples, int fmt, int8_t *d_soft, size_t soft_cap, float *d_syms, size_t syms_cap, int final);
     int sdhip_demod_get_stats(void *h, sdhip_demod_stats *st);
+    /* TEST TAP (tests/test_demod_gpu.py::test_every_symbol_beyond_tolerance_is_an_arm_flip; not a product feature). mode 1: from the next call on, the chunk-parallel
+       mode's d_syms output carries, in the eight bytes of every symbol, an int64 -- the clock recovery's position on its interpolator grid for that symbol,
+       (input sample index of the call * 128 + arm), arm = the index rint(mu * 128) of clock_recovery_mm.cpp:66 -- instead of the symbol (the int8 output is then
+       meaningless). Two fresh handles on the same input follow the same trajectory, so one run gives the symbols and a second one their grid positions. mode 0: off. */
+    int sdhip_demod_set_tap(void *h, int mode);
     /* Doppler correction (cfg.doppler): append the rotator's target frequencies, rad / sample, for the source buffers to come. targets[k] is what
        DopplerCorrectBlock::work computes BEHIND a buffer -- hz_to_rad(-doppler_shift, samplerate) at the time that buffer ends (doppler_correct.cpp:68-93) --
        and is in force during the next one; the first buffer of a stream runs on target 0, as in the reference. A buffer is `buffer_size` samples

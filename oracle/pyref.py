@@ -113,6 +113,26 @@ def port():
     return _port
 
 
+def psk_demod_with_arms(cfg, iq: np.ndarray):
+    """psk_demod on the plain-C restatement with its M&M test tap on: -> (result dict, int64 grid position of every symbol's interpolation,
+    (sample index in the clock recovery's input stream * 128 + arm index rint(mu * 128), clock_recovery_mm.cpp:66)). The restatement follows the
+    reference statement by statement and its symbols are pinned bit for bit to the compiled reference's (tests/test_oracle_vs_ref.py; the caller
+    asserts it once more on its own input), so these are the reference's arms."""
+    o = port()
+    x = np.ascontiguousarray(iq, dtype=np.complex64)
+    arms = np.full(len(x) + 64, -1, dtype=np.int64)
+    o.raw.sdo_mm_set_tap.argtypes = [C.c_void_p, C.c_int64]
+    o.raw.sdo_mm_tap_count.restype = C.c_int64
+    o.raw.sdo_mm_set_tap(_p(arms), len(arms))
+    try:
+        r = o.psk_demod(cfg, x)
+        n = int(o.raw.sdo_mm_tap_count())
+    finally:
+        o.raw.sdo_mm_set_tap(None, 0)
+    assert n == len(r["syms"])
+    return r, arms[:n]
+
+
 def best():
     """Prefer the compiled reference; fall back to the restatement (e.g. if _ref was not shipped)."""
     return ref() if ref_available() else port()

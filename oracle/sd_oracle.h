@@ -26,6 +26,9 @@ int sdo_rrc_taps(double gain, double fs, double symrate, double alpha, int ntaps
 int sdo_mm_bank(int nfilt, int ntaps, float *out);
 int sdo_resamp_bank(unsigned interp, unsigned decim, float *out, int cap, int *interp_red, int *decim_red);
 int64_t sdo_block_run(int kind, const float *p, const float *in_c, int64_t n, int chunk, float *out_c, int64_t out_cap);
+/* test tap of the M&M restatement: see sd_oracle_dsp.inc */
+void sdo_mm_set_tap(int64_t *buf, int64_t cap);
+int64_t sdo_mm_tap_count(void);
 int64_t sdo_psk_demod(const sdhip_demod_cfg *c, const float *iq, int64_t n, int8_t *soft, int64_t soft_cap, float *syms, int64_t syms_cap,
                       int *buffer_size_out, float *final_sps_out);
 /* dsp::DopplerCorrectBlock::work's sample loop (src-core/common/dsp/utils/doppler_correct.cpp:41-63), restated; the target frequency the block

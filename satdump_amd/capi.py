@@ -402,6 +402,12 @@ class PskDemod:
         lib().sdhip_demod_get_stats(self.h, C.byref(st))
         return st
 
+    def set_tap(self, mode: int):
+        """Test tap (sdhip_demod_set_tap): mode 1 = d_syms carries the clock recovery's int64 grid position of every symbol instead of the symbol."""
+        L = lib()
+        L.sdhip_demod_set_tap.argtypes = [C.c_void_p, C.c_int]
+        _check(L.sdhip_demod_set_tap(self.h, int(mode)), "sdhip_demod_set_tap")
+
     def doppler_targets(self, targets):
         """The Doppler rotator's target frequencies (rad / sample) for the source buffers to come (sdhip_demod_doppler_targets)."""
         t = np.ascontiguousarray(targets, dtype=np.float32)

@@ -462,6 +462,7 @@ namespace sdhip
         AgcParams agc_p{};
         CostasParams cos_p{};
         MmParams mm_p{};
+        int tap_mode = 0; // tests only: sdhip_demod_set_tap
 
         // power-of-two pre-decimator of SmartResampler (smart_resampler.cpp:15-29): chain of decimating FIRs, each with its
         // phase (`inc` of decimating_fir.cpp:60-86) and the last ntaps samples of its input carried across calls
@@ -1539,6 +1540,7 @@ namespace sdhip
             // symbol cost the issue-bound k_mm 1.3 - 2.2 ms (unpaired / dword-paired stores): off by default.
             mm_p.q8 = (d_syms == nullptr && env_int("SDHIP_MM_Q8", 0) != 0) ? 1 : 0;
             mm_p.q8_bpsk = is_bpsk ? 1 : 0;
+            mm_p.tap = tap_mode;
             mm_p.fast = (!cfg.exact && env_int("SDHIP_FAST_MATH", 1) != 0) ? 1 : 0;
             mm_p.fast_mult = (float)env_int("SDHIP_MM_FAST_MULT", 8);
             mm_p.arm_stride = env_int("SDHIP_MM_ARM_STRIDE", 8) == 12 ? 12 : 8;
@@ -2363,6 +2365,18 @@ extern "C"
     {
         *st = ((DemodEngine *)h)->stats;
         return 0;
+    }
+    int sdhip_demod_set_tap(void *h, int mode)
+    {
+        SD_GUARD_BEGIN
+        auto *e = (DemodEngine *)h;
+        if (mode != 0 && mode != 1)
+            throw HipError("unknown tap mode");
+        if (mode && e->cfg.exact)
+            throw HipError("the arm tap exists for the chunk-parallel mode only (the exact mode IS the reference's trajectory)");
+        e->tap_mode = mode;
+        return 0;
+        SD_GUARD_END(-1)
     }
 
     // the coefficient tables the modules are built with (host only: no device involved)

@@ -239,6 +239,9 @@ namespace sdhip
         // the legacy block's BRANCHLESS_CLIP in double (common/dsp/clock_recovery/clock_recovery_gardner.cpp:84,96).
         // back: samples a lane's window reaches behind inc - 7 (Gardner: floor(omega_max / 2) + 1, at most MM_BACK_MAX; M&M: 0)
         int loop, clip_float, back;
+        // tap (tests only, sdhip_demod_set_tap): the symbol rows receive, instead of the symbol, the interpolation's position on the arm grid -- (inc * 128 + arm) as a
+        // 64-bit integer in the symbol's eight bytes -- so a test can tell the symbols two trajectories computed on the same arm from the ones a neighbouring arm gave
+        int tap;
     };
     constexpr int MM_BACK_MAX = 17;
     struct MmState

@@ -2028,8 +2028,9 @@ namespace sdhip
 
     // one iteration of MMClockRecoveryBlock<complex_t>::work's loop body, clock_recovery_mm.cpp:54-120; the window
     // [inc-7, inc] must be in the ring
-    template <bool FAST = false>
-    __device__ __forceinline__ cf32 mm_iter(MmState &s, const MmParams &p, const cf32 *ring, const float *bank, const float omega_gain, const float mu_gain)
+    template <bool FAST = false, bool TAP = false>
+    __device__ __forceinline__ cf32 mm_iter(MmState &s, const MmParams &p, const cf32 *ring, const float *bank, const float omega_gain, const float mu_gain,
+                                            long long *arm_pos = nullptr)
     {
         s.p_2T = s.p_1T;
         s.p_1T = s.p_0T;
@@ -2040,6 +2041,8 @@ namespace sdhip
             imu = 0;
         if (imu >= 128)
             imu = 127;
+        if constexpr (TAP)
+            *arm_pos = s.inc * 128 + imu;
         const float4 t0 = *reinterpret_cast<const float4 *>(bank + imu * p.arm_stride);
         const float4 t1 = *reinterpret_cast<const float4 *>(bank + imu * p.arm_stride + 4);
         const float t[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
@@ -2155,11 +2158,17 @@ namespace sdhip
             s.inc = 0;
         return s.p_0T;
     }
-    template <bool GARD, bool FAST>
+    template <bool GARD, bool FAST, bool TAP = false>
     __device__ __forceinline__ cf32 clock_iter(MmState &s, const MmParams &p, const cf32 *ring, const float *bank, const float omega_gain, const float mu_gain)
     {
         if constexpr (GARD)
             return gardner_iter<FAST>(s, p, ring, bank, omega_gain, mu_gain);
+        else if constexpr (TAP)
+        { // tests only: the symbol's eight bytes carry its position on the arm grid (MmParams::tap)
+            long long pos = 0;
+            (void)mm_iter<FAST, true>(s, p, ring, bank, omega_gain, mu_gain, &pos);
+            return cf32{__uint_as_float((unsigned)(pos & 0xffffffffll)), __uint_as_float((unsigned)((unsigned long long)pos >> 32))};
+        }
         else
             return mm_iter<FAST>(s, p, ring, bank, omega_gain, mu_gain);
     }
@@ -2183,7 +2192,7 @@ namespace sdhip
             return 127;
         return (signed char)(int)x;
     }
-template <bool CKPT, bool SPLIT, bool Q8 = false, bool FAST = false, bool GARD = false>
+template <bool CKPT, bool SPLIT, bool Q8 = false, bool FAST = false, bool GARD = false, bool TAP = false>
     __global__ __launch_bounds__(64) void k_mm(const cf32 *x, cf32 *sym, int *counts, ChunkGeom g, MmParams p, const MmState *start0, MmState *spec,
                                                MmState *endst, MmCert *spec_c, MmCert *end_c, const int *redo, int nredo, MmCkpt *ck, int ck_per_chunk,
                                                float ck_tol)
@@ -2375,7 +2384,7 @@ template <bool CKPT, bool SPLIT, bool Q8 = false, bool FAST = false, bool GARD =
                         // trajectory settles onto the sequential one; only speculation -- the boundary certificate decides
                         const bool fast = phase == 0 && wsym < p.fast_syms;
                         wsym++;
-                        const cf32 v = clock_iter<GARD, FAST>(s, p, f.ring, bank, fast ? 0.0f : p.omega_gain, fast ? p.mu_gain * p.fast_mult : p.mu_gain);
+                        const cf32 v = clock_iter<GARD, FAST, TAP>(s, p, f.ring, bank, fast ? 0.0f : p.omega_gain, fast ? p.mu_gain * p.fast_mult : p.mu_gain);
                         if (phase != 0)
                         {
                             if (cnt + nx < p.cap)
@@ -2427,6 +2436,14 @@ template <bool CKPT, bool SPLIT, bool Q8 = false, bool FAST = false, bool GARD =
             else
                 hipLaunchKernelGGL((k_mm<false, false, false, false, true>), dim3((n + 63) / 64), dim3(64), lds_pad, st, x, sym_scratch, counts, g, p, start0, spec, endst, spec_c,
                                    end_c, redo, nredo, (MmCkpt *)nullptr, 0, 0.0f);
+            return;
+        }
+        if (p.tap)
+        { // tests only (sdhip_demod_set_tap): the default instance with the arm positions in place of the symbols
+            if (!ck || !p.fast || p.q8)
+                throw HipError("the arm tap exists for the chunk-parallel mode's default kernel only");
+            hipLaunchKernelGGL((k_mm<true, false, false, true, false, true>), dim3((n + 63) / 64), dim3(64), lds_pad, st, x, sym_scratch, counts, g, p, start0, spec, endst, spec_c,
+                               end_c, redo, nredo, ck, ck_per_chunk, ck_tol);
             return;
         }
         if (ck && p.q8 && p.fast)

@@ -89,6 +89,7 @@ test_exact_mode_bit_identical = G.test_exact_mode_bit_identical
 test_exact_mode_streaming = G.test_exact_mode_streaming
 test_chunked_mode_symbols_and_cadus = G.test_chunked_mode_symbols_and_cadus
 test_chunked_mode_streaming_calls = G.test_chunked_mode_streaming_calls
+test_every_symbol_beyond_tolerance_is_an_arm_flip = G.test_every_symbol_beyond_tolerance_is_an_arm_flip
 test_cs16_input = G.test_cs16_input
 test_empty_and_tiny_calls = G.test_empty_and_tiny_calls
 test_integer_input_formats = G.test_integer_input_formats
