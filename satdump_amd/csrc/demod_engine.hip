@@ -1543,7 +1543,6 @@ namespace sdhip
             mm_p.tap = tap_mode;
             mm_p.fast = (!cfg.exact && env_int("SDHIP_FAST_MATH", 1) != 0) ? 1 : 0;
             mm_p.fast_mult = (float)env_int("SDHIP_MM_FAST_MULT", 8);
-            mm_p.arm_stride = env_int("SDHIP_MM_ARM_STRIDE", 8) == 12 ? 12 : 8;
             mm_p.fast_syms = mm_p.fast_mult > 1.0f ? (int)env_int("SDHIP_MM_FAST_SYMS", (long long)(2.75 / gmu)) : 0;
             // a re-run costs one lane the whole chunk, so long chunks (large batches) keep the conservative warm-up: it is a
             // small fraction of L there anyway
@@ -2480,7 +2479,6 @@ extern "C"
             p.omega_limit = params[4] * params[0];
             p.init_mu = params[2];
             p.bank = db.p;
-            p.arm_stride = 8;
             p.cap = (int)out_cap;
             p.cg = g;
             p.rot = nullptr;
@@ -2540,7 +2538,6 @@ extern "C"
             p.omega_limit = params[4] * params[0];
             p.init_mu = params[2];
             p.bank = db.p;
-            p.arm_stride = 8;
             p.cap = (int)out_cap;
             p.cg = g;
             p.rot = nullptr;

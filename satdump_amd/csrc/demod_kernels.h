@@ -231,8 +231,6 @@ namespace sdhip
         float fast_mult;
         int q8, q8_bpsk; // q8: the symbols are stored as the module's int8 soft symbols (2 bytes per symbol row entry) instead of floats
         int fast;        // chunk-parallel mode's arithmetic: fused multiply-adds in the interpolator (exact mode: 0)
-        int arm_stride;  // floats between consecutive interpolator arms in the kernel's LDS copy: 8, or 12 (48 bytes: the lanes' 16-byte reads then start on
-                         // eight bank groups instead of four; SDHIP_MM_ARM_STRIDE)
         // loop: 0 = Mueller & Muller (clock_recovery_mm.cpp), 1 = Gardner (clock_recovery_gardner.cpp: a second interpolation half a symbol back, the
         // zero-crossing sample; MmState::p_0T holds its last symbol). Same lanes, same hand-off certificate (time of the next symbol, rate).
         // clip_float: Gardner's two clips as dsp::branched_clip on floats (the ndsp block, dsp/clock_recovery/clock_recovery_gardner.cpp:115,131) instead of

@@ -1932,7 +1932,9 @@ namespace sdhip
     // window is now complete. The queue never shifts (a register move would have to wait for its load), so the compiler
     // can count outstanding loads exactly and the ~1.3 us HBM latency of these chunk-strided reads stays off the timing
     // recurrence; the interpolator reads samples and taps from LDS with lane-private addresses.
-    constexpr int MM_RING = 32;
+    constexpr int MM_RING = 32;    // Gardner lanes (their window reaches up to MM_BACK_MAX samples further back)
+    constexpr int MM_RING_MM = 16; // Mueller & Mueller lanes: a window [inc-7, inc] with inc in the newest block lies inside the last 16 samples; 11.5 KB of ring
+                                   // + 4 KB of interpolator arms per wave lets a CU hold eight blocks -- two waves on every SIMD (it was six: one and a half)
     // ring[slot][lane]: slot-major, so lane l of a 32-lane LDS access group always owns 8-byte bank pair l whatever slot it
     // addresses -- the lanes' windows sit at unrelated ring positions, and a lane-major layout made them collide at random
     // (SQ: bank-conflict cycles were twice the active LDS cycles)
@@ -1942,6 +1944,7 @@ namespace sdhip
     // ~24 of the ~130 VALU instructions of a symbol). A window lies inside the last MM_RING samples, so the copy a reader finds behind slot 31 is the
     // newest write of that slot, the very value the wrapped read returned.
     constexpr int MM_MIRROR = 7;
+    constexpr int MM_ARM_STRIDE = 8; // floats between interpolator arms in the LDS copy (a 48-byte stride was measured in round 4: no change)
     constexpr int MM_DEPTH = 4;
     __device__ __forceinline__ void mm_rot_cs(int q, int order, float &c, float &s)
     {
@@ -1964,6 +1967,7 @@ namespace sdhip
     };
     // move one block into the ring. Stage chunk boundaries and 0 are multiples of 8, so a block never straddles a rotation
     // change or the history/data boundary.
+    template <int RING = MM_RING>
     __device__ __forceinline__ void mm_feed_put(MmFeed &f, const MmParams &p, const Blk8 &c)
     {
         const long long i = f.next;
@@ -1977,7 +1981,7 @@ namespace sdhip
         const bool dorot = p.rot && i >= 0; // history (negative indices) was rotated by the previous call
         float re[8] = {c.a.x, c.a.z, c.b.x, c.b.z, c.c.x, c.c.z, c.d.x, c.d.z};
         float im[8] = {c.a.y, c.a.w, c.b.y, c.b.w, c.c.y, c.c.w, c.d.y, c.d.w};
-        const int slot = (int)(i & (MM_RING - 1));
+        const int slot = (int)(i & (RING - 1));
 #pragma unroll
         for (int j = 0; j < 8; j++)
         {
@@ -1992,7 +1996,7 @@ namespace sdhip
             }
             f.ring[(slot + j) * MM_RING_STRIDE] = v;
             if (j < MM_MIRROR && slot == 0)
-                f.ring[(MM_RING + j) * MM_RING_STRIDE] = v;
+                f.ring[(RING + j) * MM_RING_STRIDE] = v;
         }
         f.next = i + 8;
     }
@@ -2028,7 +2032,7 @@ namespace sdhip
 
     // one iteration of MMClockRecoveryBlock<complex_t>::work's loop body, clock_recovery_mm.cpp:54-120; the window
     // [inc-7, inc] must be in the ring
-    template <bool FAST = false, bool TAP = false>
+    template <bool FAST = false, bool TAP = false, int RING = MM_RING>
     __device__ __forceinline__ cf32 mm_iter(MmState &s, const MmParams &p, const cf32 *ring, const float *bank, const float omega_gain, const float mu_gain,
                                             long long *arm_pos = nullptr)
     {
@@ -2043,10 +2047,10 @@ namespace sdhip
             imu = 127;
         if constexpr (TAP)
             *arm_pos = s.inc * 128 + imu;
-        const float4 t0 = *reinterpret_cast<const float4 *>(bank + imu * p.arm_stride);
-        const float4 t1 = *reinterpret_cast<const float4 *>(bank + imu * p.arm_stride + 4);
+        const float4 t0 = *reinterpret_cast<const float4 *>(bank + imu * MM_ARM_STRIDE);
+        const float4 t1 = *reinterpret_cast<const float4 *>(bank + imu * MM_ARM_STRIDE + 4);
         const float t[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
-        const int base = (int)((s.inc - 7) & (MM_RING - 1));
+        const int base = (int)((s.inc - 7) & (RING - 1));
         // (re, im) of a sample as one packed pair: v_pk_mul_f32 / v_pk_add_f32, each half rounded like the scalar operation
         v2f acc{0.0f, 0.0f};
 #pragma unroll
@@ -2107,8 +2111,8 @@ namespace sdhip
         imu = imu < 0 ? 0 : (imu >= 128 ? 127 : imu);
         if (offzc > p.back) // cannot happen inside the omega limits the engine admits; keeps a wild state inside the ring
             offzc = p.back;
-        const float4 z0 = *reinterpret_cast<const float4 *>(bank + imuz * p.arm_stride), z1 = *reinterpret_cast<const float4 *>(bank + imuz * p.arm_stride + 4);
-        const float4 t0 = *reinterpret_cast<const float4 *>(bank + imu * p.arm_stride), t1 = *reinterpret_cast<const float4 *>(bank + imu * p.arm_stride + 4);
+        const float4 z0 = *reinterpret_cast<const float4 *>(bank + imuz * MM_ARM_STRIDE), z1 = *reinterpret_cast<const float4 *>(bank + imuz * MM_ARM_STRIDE + 4);
+        const float4 t0 = *reinterpret_cast<const float4 *>(bank + imu * MM_ARM_STRIDE), t1 = *reinterpret_cast<const float4 *>(bank + imu * MM_ARM_STRIDE + 4);
         const float tz[8] = {z0.x, z0.y, z0.z, z0.w, z1.x, z1.y, z1.z, z1.w};
         const float t[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
         const int base = (int)((s.inc - 7) & (MM_RING - 1)), basez = (int)((s.inc - offzc - 7) & (MM_RING - 1));
@@ -2158,7 +2162,7 @@ namespace sdhip
             s.inc = 0;
         return s.p_0T;
     }
-    template <bool GARD, bool FAST, bool TAP = false>
+    template <bool GARD, bool FAST, bool TAP = false, int RING = MM_RING>
     __device__ __forceinline__ cf32 clock_iter(MmState &s, const MmParams &p, const cf32 *ring, const float *bank, const float omega_gain, const float mu_gain)
     {
         if constexpr (GARD)
@@ -2166,11 +2170,11 @@ namespace sdhip
         else if constexpr (TAP)
         { // tests only: the symbol's eight bytes carry its position on the arm grid (MmParams::tap)
             long long pos = 0;
-            (void)mm_iter<FAST, true>(s, p, ring, bank, omega_gain, mu_gain, &pos);
+            (void)mm_iter<FAST, true, RING>(s, p, ring, bank, omega_gain, mu_gain, &pos);
             return cf32{__uint_as_float((unsigned)(pos & 0xffffffffll)), __uint_as_float((unsigned)((unsigned long long)pos >> 32))};
         }
         else
-            return mm_iter<FAST>(s, p, ring, bank, omega_gain, mu_gain);
+            return mm_iter<FAST, false, RING>(s, p, ring, bank, omega_gain, mu_gain);
     }
 
     // CKPT: whenever the block ending at a multiple of MM_CK_SAMPLES samples into its chunk has been fed, a lane leaves a
@@ -2197,10 +2201,11 @@ template <bool CKPT, bool SPLIT, bool Q8 = false, bool FAST = false, bool GARD =
                                                MmState *endst, MmCert *spec_c, MmCert *end_c, const int *redo, int nredo, MmCkpt *ck, int ck_per_chunk,
                                                float ck_tol)
     {
-        __shared__ cf32 rings[(MM_RING + MM_MIRROR) * MM_RING_STRIDE];
-        __shared__ __attribute__((aligned(16))) float bank[128 * 12];
+        constexpr int RING = GARD ? MM_RING : MM_RING_MM;
+        __shared__ cf32 rings[(RING + MM_MIRROR) * MM_RING_STRIDE];
+        __shared__ __attribute__((aligned(16))) float bank[128 * MM_ARM_STRIDE];
         for (int i = (int)threadIdx.x; i < 128 * 8; i += 64)
-            bank[(i >> 3) * p.arm_stride + (i & 7)] = p.bank[i];
+            bank[(i >> 3) * MM_ARM_STRIDE + (i & 7)] = p.bank[i];
         __syncthreads();
         const int idx = (int)(blockIdx.x * blockDim.x + threadIdx.x);
         int k;
@@ -2279,7 +2284,7 @@ template <bool CKPT, bool SPLIT, bool Q8 = false, bool FAST = false, bool GARD =
             {
                 const Blk8 cur = q[d];
                 q[d] = blk_load(x, f.next + 8 * MM_DEPTH); // at most 8*MM_DEPTH + 8 samples past the lane's last window
-                mm_feed_put(f, p, cur);
+                mm_feed_put<RING>(f, p, cur);
                 if constexpr (CKPT)
                 { // one test per 8-sample block, outside the symbol loop: a checkpoint every MM_CK_SAMPLES samples of the chunk
                     const long long rel = f.next - b;
@@ -2319,7 +2324,7 @@ template <bool CKPT, bool SPLIT, bool Q8 = false, bool FAST = false, bool GARD =
                             { // warm-up symbols: nothing stored (gear shift: see below)
                                 const bool fast = wsym < p.fast_syms;
                                 wsym++;
-                                (void)mm_iter(s, p, f.ring, bank, fast ? 0.0f : p.omega_gain, fast ? p.mu_gain * p.fast_mult : p.mu_gain);
+                                (void)mm_iter<false, false, RING>(s, p, f.ring, bank, fast ? 0.0f : p.omega_gain, fast ? p.mu_gain * p.fast_mult : p.mu_gain);
                             } while (s.inc < lim);
                         }
                         else if (phase == 1)
@@ -2337,7 +2342,7 @@ template <bool CKPT, bool SPLIT, bool Q8 = false, bool FAST = false, bool GARD =
                             const long long lim = f.next < e ? f.next : e;
                             do
                             {
-                                const cf32 v = mm_iter(s, p, f.ring, bank, p.omega_gain, p.mu_gain);
+                                const cf32 v = mm_iter<false, false, RING>(s, p, f.ring, bank, p.omega_gain, p.mu_gain);
                                 if (cnt < p.cap)
                                     put(cnt, v);
                                 cnt++;
@@ -2350,13 +2355,41 @@ template <bool CKPT, bool SPLIT, bool Q8 = false, bool FAST = false, bool GARD =
                                 done = true;
                                 break;
                             }
-                            const cf32 v = mm_iter(s, p, f.ring, bank, p.omega_gain, p.mu_gain);
+                            const cf32 v = mm_iter<false, false, RING>(s, p, f.ring, bank, p.omega_gain, p.mu_gain);
                             if (cnt + nx < p.cap)
                                 put(cnt + nx, v);
                             nx++;
                         }
                     }
                     continue;
+                }
+                if constexpr (!SPLIT)
+                {
+                    // Wave-uniform fast paths. The lanes of a wave sit at the same place relative to their chunks (chunk starts, lengths and warm-ups are the
+                    // same multiples of 8), so for all but a handful of the blocks of a chunk EVERY lane is in its warm-up for the whole block, or every lane is
+                    // inside its chunk for the whole block: then the symbol loop needs none of the per-symbol phase bookkeeping below (a third of its
+                    // instructions; the kernel is issue-bound at two waves per SIMD). Same iterations, same order, same results.
+                    const unsigned long long act = __ballot(1);
+                    if (__ballot(phase == 1 && f.next <= e && cnt + 8 < p.cap) == act)
+                    {
+                        while (s.inc < f.next)
+                        {
+                            const cf32 v = clock_iter<GARD, FAST, TAP, RING>(s, p, f.ring, bank, p.omega_gain, p.mu_gain);
+                            put(cnt, v);
+                            cnt++;
+                        }
+                        continue;
+                    }
+                    if (__ballot(phase == 0 && f.next <= b) == act)
+                    {
+                        while (s.inc < f.next)
+                        {
+                            const bool fast = wsym < p.fast_syms;
+                            wsym++;
+                            (void)clock_iter<GARD, FAST, TAP, RING>(s, p, f.ring, bank, fast ? 0.0f : p.omega_gain, fast ? p.mu_gain * p.fast_mult : p.mu_gain);
+                        }
+                        continue;
+                    }
                 }
                 while (!done && s.inc < f.next)
                 {
@@ -2384,7 +2417,7 @@ template <bool CKPT, bool SPLIT, bool Q8 = false, bool FAST = false, bool GARD =
                         // trajectory settles onto the sequential one; only speculation -- the boundary certificate decides
                         const bool fast = phase == 0 && wsym < p.fast_syms;
                         wsym++;
-                        const cf32 v = clock_iter<GARD, FAST, TAP>(s, p, f.ring, bank, fast ? 0.0f : p.omega_gain, fast ? p.mu_gain * p.fast_mult : p.mu_gain);
+                        const cf32 v = clock_iter<GARD, FAST, TAP, RING>(s, p, f.ring, bank, fast ? 0.0f : p.omega_gain, fast ? p.mu_gain * p.fast_mult : p.mu_gain);
                         if (phase != 0)
                         {
                             if (cnt + nx < p.cap)

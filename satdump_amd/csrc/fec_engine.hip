@@ -43,16 +43,7 @@ namespace sdhip
             }
         }
         void *p = nullptr;
-        // SDHIP_ALLOC_SPACER=1 (experiment, DESIGN.md 5: k_mm's launch time follows which physical memory a handle's stage buffers are backed by): a large
-        // block is allocated behind a spacer of its own size, which is released again at once
-        static const bool spacer_on = getenv("SDHIP_ALLOC_SPACER") && getenv("SDHIP_ALLOC_SPACER")[0] == '1';
-        void *sp = nullptr;
-        if (spacer_on && bytes >= ((size_t)512 << 20) && hipMalloc(&sp, bytes) != hipSuccess)
-            sp = nullptr;
-        const hipError_t e = hipMalloc(&p, bytes);
-        if (sp)
-            (void)hipFree(sp);
-        SD_HIP(e);
+        SD_HIP(hipMalloc(&p, bytes));
         std::lock_guard<std::mutex> lk(g_pool_mu);
         g_dev_of[p] = dev;
         return p;
