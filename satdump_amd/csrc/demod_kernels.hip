@@ -1372,9 +1372,109 @@ namespace sdhip
         yp[2] = o.c;
         yp[3] = o.d;
     }
-    template <class Stage, class Hook>
+    // ---- coalesced access to the lanes' streams (round 5) ---------------------------------------------------------------------------------
+    // A lane-per-chunk stage reads and writes 64 far-apart streams per wave: every 16-byte piece a lane moves is a request of its own to
+    // a cache line of its own, and all the lane stages ran at the same ~200 G such requests per second whatever their arithmetic (k_afc,
+    // k_mm, the stand-alone Costas / AGC stages: 2.9 - 3.2 TB/s of payload) -- the rate of uncoalesced requests was the roof, not VALU issue,
+    // not HBM. Here the wave moves the same bytes COOPERATIVELY: the lanes of a wave sit at the same place of their streams (same chunk
+    // length, same warm-up), so the 128 bytes every lane needs next are fetched by eight loads in which lanes 8r .. 8r+7 read the eight
+    // consecutive 16-byte pieces of stream 8j + r -- eight whole 128-byte lines per instruction instead of 64 sixteen-byte pieces of 64
+    // lines -- and are handed to their owners through an LDS transpose (region stride 144 bytes: the owners' 16-byte reads start on
+    // disjoint bank groups). Stores go the other way. Same bytes, same values, an eighth of the requests.
+    constexpr int COOP_REGION = 144;
+    constexpr int COOP_LDS_BYTES = 64 * COOP_REGION;
+    struct Coop
+    {
+        char *lw, *lr, *sw, *sr; // this lane's places in the wave's two LDS transpose buffers: load side write (as loader) / read (as owner), store side write (as owner) / read
+        long long stride;        // bytes between the streams of adjacent lanes (= chunk length * sizeof(cf32))
+        unsigned voff;           // (lane >> 3) * stride + (lane & 7) * 16: this lane's offset from "stream 8 j of the wave, byte 0 of the burst"
+    };
+    __device__ __forceinline__ Coop coop_make(char *lds, long long stride)
+    {
+        const int lane = (int)threadIdx.x & 63;
+        Coop co;
+        co.lw = lds + (lane >> 3) * COOP_REGION + (lane & 7) * 16;
+        co.lr = lds + lane * COOP_REGION;
+        co.sw = lds + COOP_LDS_BYTES + lane * COOP_REGION;
+        co.sr = lds + COOP_LDS_BYTES + (lane >> 3) * COOP_REGION + (lane & 7) * 16;
+        co.stride = stride;
+        co.voff = (unsigned)((lane >> 3) * stride + (lane & 7) * 16);
+        return co;
+    }
+    // a value every lane of the wave holds alike, as a scalar (lane 0's copy)
+    __device__ __forceinline__ int sd_uniform(int v) { return __builtin_amdgcn_readlane(v, 0); }
+    __device__ __forceinline__ long long sd_uniform(long long v)
+    {
+        const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v & 0xffffffffll), 0);
+        const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)((unsigned long long)v >> 32), 0);
+        return (long long)(((unsigned long long)hi << 32) | lo);
+    }
+    __device__ __forceinline__ void sd_wave_sync()
+    { // one lane's LDS write before another lane's read of it: lockstep on the device (the fence keeps the compiler from moving the accesses), a meeting point on the host twin
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+    }
+    struct Burst
+    {
+        float4 c0, c1, c2, c3, c4, c5, c6, c7; // piece (lane & 7) of the streams 8 j + (lane >> 3), j = 0 .. 7 (named members: an array here stayed in scratch memory)
+    };
+    // the 128 bytes at stream index i0w (LANE 0's index, a scalar; lane l's own index is i0w + l * chunk length) of every stream of the wave
+    __device__ __forceinline__ Burst coop_load(const cf32 *x, long long i0w, const Coop &co)
+    {
+        const char *sb = reinterpret_cast<const char *>(x + i0w);
+        const long long st8 = 8 * co.stride;
+        Burst b;
+        b.c0 = *reinterpret_cast<const float4 *>(sb + co.voff);
+        b.c1 = *reinterpret_cast<const float4 *>(sb + st8 + co.voff);
+        b.c2 = *reinterpret_cast<const float4 *>(sb + 2 * st8 + co.voff);
+        b.c3 = *reinterpret_cast<const float4 *>(sb + 3 * st8 + co.voff);
+        b.c4 = *reinterpret_cast<const float4 *>(sb + 4 * st8 + co.voff);
+        b.c5 = *reinterpret_cast<const float4 *>(sb + 5 * st8 + co.voff);
+        b.c6 = *reinterpret_cast<const float4 *>(sb + 6 * st8 + co.voff);
+        b.c7 = *reinterpret_cast<const float4 *>(sb + 7 * st8 + co.voff);
+        return b;
+    }
+    __device__ __forceinline__ void coop_unpack(const Burst &b, const Coop &co, Blk8 &q0, Blk8 &q1)
+    {
+        __builtin_amdgcn_sched_barrier(0); // (the transposes stay where they are written: hoisted in front of the preceding blocks' arithmetic they kept two more blocks alive)
+        *reinterpret_cast<float4 *>(co.lw + 0 * 8 * COOP_REGION) = b.c0;
+        *reinterpret_cast<float4 *>(co.lw + 1 * 8 * COOP_REGION) = b.c1;
+        *reinterpret_cast<float4 *>(co.lw + 2 * 8 * COOP_REGION) = b.c2;
+        *reinterpret_cast<float4 *>(co.lw + 3 * 8 * COOP_REGION) = b.c3;
+        *reinterpret_cast<float4 *>(co.lw + 4 * 8 * COOP_REGION) = b.c4;
+        *reinterpret_cast<float4 *>(co.lw + 5 * 8 * COOP_REGION) = b.c5;
+        *reinterpret_cast<float4 *>(co.lw + 6 * 8 * COOP_REGION) = b.c6;
+        *reinterpret_cast<float4 *>(co.lw + 7 * 8 * COOP_REGION) = b.c7;
+        sd_wave_sync();
+        const float4 *r = reinterpret_cast<const float4 *>(co.lr);
+        q0 = Blk8{r[0], r[1], r[2], r[3]};
+        q1 = Blk8{r[4], r[5], r[6], r[7]};
+        sd_wave_sync();
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    __device__ __forceinline__ void coop_store_half(const Blk8 &o, int half, const Coop &co)
+    {
+        float4 *w = reinterpret_cast<float4 *>(co.sw + half * 64);
+        w[0] = o.a;
+        w[1] = o.b;
+        w[2] = o.c;
+        w[3] = o.d;
+    }
+    // the 128 bytes every lane has put together with two coop_store_half calls go out to stream index i0w (lane 0's, as in coop_load)
+    __device__ __forceinline__ void coop_store_flush(cf32 *y, long long i0w, const Coop &co)
+    {
+        __builtin_amdgcn_sched_barrier(0);
+        sd_wave_sync();
+        char *sb = reinterpret_cast<char *>(y + i0w);
+#pragma unroll
+        for (int j = 0; j < 8; j++)
+            *reinterpret_cast<float4 *>(sb + (long long)(8 * j) * co.stride + co.voff) = *reinterpret_cast<const float4 *>(co.sr + j * 8 * COOP_REGION);
+        sd_wave_sync();
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    template <class Stage, bool COOP = false, class Hook>
     __device__ __forceinline__ void run_range1(typename Stage::S &s, const typename Stage::P &p, const cf32 *x, cf32 *y, long long i0, long long i1,
-                                               long long write_from, long long hb, int hstep, Hook hook)
+                                               long long write_from, long long hb, int hstep, Hook hook, const Coop *co = nullptr)
     {
         static_assert(Stage::DEPTH == 4, "four-block groups");
         long long i = i0;
@@ -1386,6 +1486,57 @@ namespace sdhip
         }
         if (i + 32 <= i1)
         {
+            if constexpr (COOP)
+            { // every lane of the wave is here with the same i1 - i, the same write_from - i, and nobody leaves through the hook (the caller's promise):
+              // the loop runs on scalars (position relative to the start, lane 0's stream index), the lane's own index only names the hook's position
+                const long long lim = 1ll << 30;
+                const long long wf = write_from - i, tl = i1 - i;
+                const int total = sd_uniform((int)(tl < lim ? tl : lim));
+                const int wfrom = sd_uniform((int)(wf < -lim ? -lim : (wf < lim ? wf : lim)));
+                const int hoff = sd_uniform((int)((i - hb) & (long long)(hstep - 1)));
+                const long long iw = sd_uniform(i);
+                const long long ibase = i;
+                int r = 0;
+                Burst b0 = coop_load(x, iw, *co), b1 = coop_load(x, iw + 16, *co);
+                Blk8 q[4];
+                for (;;)
+                {
+                    const bool more = r + 64 <= total;
+                    const bool wr = r >= wfrom;
+                    coop_unpack(b0, *co, q[0], q[1]);
+#pragma unroll
+                    for (int d = 0; d < 2; d++)
+                    {
+                        const Blk8 o = blk_step<Stage>(s, p, q[d], wr);
+                        if (wr)
+                            coop_store_half(o, d, *co);
+                    }
+                    if (wr)
+                        coop_store_flush(y, iw + r, *co);
+                    if (more)
+                        b0 = coop_load(x, iw + r + 32, *co);
+                    coop_unpack(b1, *co, q[2], q[3]);
+#pragma unroll
+                    for (int d = 2; d < 4; d++)
+                    {
+                        const Blk8 o = blk_step<Stage>(s, p, q[d], wr);
+                        if (wr)
+                            coop_store_half(o, d - 2, *co);
+                    }
+                    if (wr)
+                        coop_store_flush(y, iw + r + 16, *co);
+                    if (more)
+                        b1 = coop_load(x, iw + r + 48, *co);
+                    r += 32;
+                    if ((((r + hoff) & (hstep - 1)) == 0) && r < total)
+                        (void)hook(ibase + r);
+                    if (!more)
+                        break;
+                }
+                i = ibase + r;
+            }
+            else
+            {
             Blk8 q[4];
 #pragma unroll
             for (int d = 0; d < 4; d++)
@@ -1411,6 +1562,7 @@ namespace sdhip
                     return;
                 if (!more)
                     break;
+            }
             }
         }
         for (; i < i1; i++)
@@ -1596,10 +1748,17 @@ namespace sdhip
     // and its carrier loop is inside the Costas windows in the earlier run's frame: from there on the earlier output and end state stand.
     // Warm-up tail and chunk are ONE loop over AfcFull (stores begin at the chunk start, where the state is also left in spec[k]).
     template <int ORDER, bool FAST>
-    __global__ __launch_bounds__(64) void k_afc(const cf32 *x, cf32 *y, ChunkGeom g, AfcParams p, const AfcState *start0, AfcState *spec, AfcState *endst,
-                                                const int *redo, int nredo, AfcCkpt *ck, int ck_per_chunk, int ck_len, float tol_phase, float tol_freq)
+    __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_afc(const cf32 *x, cf32 *y, ChunkGeom g, AfcParams p, const AfcState *start0, AfcState *spec, AfcState *endst,
+                                                const int *redo, int nredo, AfcCkpt *ck, int ck_per_chunk, int ck_len, float tol_phase, float tol_freq, int coop_nb)
     {
+        __shared__ __attribute__((aligned(16))) char coop_lds[2 * COOP_LDS_BYTES];
         const int idx = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+        // Main launch with cooperative access (coop_nb > 0, see Coop): blocks 0 .. coop_nb-1 take the chunks 1 + 64 blk + lane -- all of them ordinary chunks, a
+        // warm-up of their own in front and the full length (the host's promise), so the 64 lanes of such a wave walk their streams in lockstep one chunk length
+        // apart --; chunk 0 (no warm-up: the stream's carried state) and the last few chunks (the very last one may be shorter) follow eight to a block on the
+        // per-lane path, so that no wave of the launch runs 64 lanes of it
+        const bool coop = !redo && coop_nb > 0 && (int)blockIdx.x < coop_nb;
+        const Coop co = coop_make(coop_lds, (long long)g.L * (long long)sizeof(cf32));
         int k;
         AfcState s;
         bool leave_spec = false;
@@ -1614,9 +1773,24 @@ namespace sdhip
         }
         else
         {
-            k = idx;
-            if (k >= g.K)
-                return;
+            if (coop_nb > 0)
+            {
+                if (coop)
+                    k = 1 + idx;
+                else
+                {
+                    const int j = ((int)blockIdx.x - coop_nb) * 8 + (int)threadIdx.x;
+                    if ((int)threadIdx.x >= 8 || j >= g.K - 64 * coop_nb)
+                        return;
+                    k = j == 0 ? 0 : 64 * coop_nb + j;
+                }
+            }
+            else
+            {
+                k = idx;
+                if (k >= g.K)
+                    return;
+            }
             i0 = 0;
             s = *start0; // chunk 0, and chunks whose warm-up would reach in front of the call: from the stream's true state
             const long long b = chunk_begin(g, k);
@@ -1629,7 +1803,10 @@ namespace sdhip
                 const long long never = 1ll << 62;
                 s.af = AgcFirStage::init(p.af, k);
                 s.cos = CostasState{0.0f, p.cos.init_freq};
-                run_range1<AfcAgcOnly<FAST>>(s, p, x, y, w0, b - g.W, never, 0, 1 << 30, nohook);
+                if (coop)
+                    run_range1<AfcAgcOnly<FAST>, true>(s, p, x, y, w0, b - g.W, never, 0, 1 << 30, nohook, &co);
+                else
+                    run_range1<AfcAgcOnly<FAST>>(s, p, x, y, w0, b - g.W, never, 0, 1 << 30, nohook);
                 i0 = b - g.W;
                 if (p.cos.est_len > 0 && ORDER <= 4)
                 {
@@ -1641,7 +1818,10 @@ namespace sdhip
                     e.ci = 0.0f;
                     e.ar = 0.0f;
                     e.ai = 0.0f;
-                    run_range1<AfcEst<M, FAST>>(e, p, x, y, i0, i0 + p.cos.est_len, never, 0, 1 << 30, nohook);
+                    if (coop)
+                        run_range1<AfcEst<M, FAST>, true>(e, p, x, y, i0, i0 + p.cos.est_len, never, 0, 1 << 30, nohook, &co);
+                    else
+                        run_range1<AfcEst<M, FAST>>(e, p, x, y, i0, i0 + p.cos.est_len, never, 0, 1 << 30, nohook);
                     s = e.s;
                     // BPSK symbols sit on the real axis (x^2 -> +1), QPSK symbols on the diagonals (x^4 -> -1); the sum's angle is M
                     // times the carrier phase at the first sample of the window, the loop takes over est_len samples later
@@ -1654,7 +1834,7 @@ namespace sdhip
         const long long b = chunk_begin(g, k), e = chunk_end(g, k);
         bool merged = false;
         AfcCkpt *cks = ck ? ck + (size_t)k * ck_per_chunk : nullptr;
-        run_range1<AfcFull<ORDER, FAST>>(s, p, x, y, i0, e, b, b, ck_len, [&](long long i) -> bool {
+        const auto hook = [&](long long i) -> bool {
             if (i < b)
                 return false;
             if (i == b)
@@ -1678,7 +1858,11 @@ namespace sdhip
             }
             cks[j] = AfcCkpt{s.af.gain, s.af.lag[3], s.cos.phase, s.cos.freq};
             return false;
-        });
+        };
+        if (coop) // (never a re-run launch: the hook stops nobody)
+            run_range1<AfcFull<ORDER, FAST>, true>(s, p, x, y, i0, e, b, b, ck_len, hook, &co);
+        else
+            run_range1<AfcFull<ORDER, FAST>>(s, p, x, y, i0, e, b, b, ck_len, hook);
         if (!merged)
             endst[k] = s;
     }
@@ -1696,8 +1880,19 @@ namespace sdhip
             constexpr int O = decltype(order)::value;
             constexpr bool F = decltype(fm)::value;
             // ck_len is also the spacing at which the lane looks for the chunk start (spec snapshot): always a power of two >= 32
-            hipLaunchKernelGGL((k_afc<O, F>), dim3((n + 63) / 64), dim3(64), 0, st, x, y, g, p, start0, spec, endst, redo, nredo, ck.ck, ck.per_chunk,
-                               ck.len > 0 ? ck.len : 2048, ck.tol_phase, ck.tol_freq);
+            // cooperative access of the wave's 64 streams (see Coop): every stage range a whole number of 128-byte bursts (chunk length, warm-ups, estimator
+            // window: multiples of 16 samples), every chunk from 1 on with its whole warm-up inside the call, and at least one full wave of ordinary chunks
+            const bool coop_env = !(getenv("SDHIP_COOP") && atoi(getenv("SDHIP_COOP")) == 0); // (read per launch: tests and tools/ab_demod.py switch it in one process)
+            int coop_nb = 0;
+            if (coop_env && !redo && g.L % 16 == 0 && g.W % 16 == 0 && p.w_agc % 16 == 0 && p.cos.est_len % 16 == 0 && (long long)g.L > (long long)p.w_agc && g.K >= 66)
+                coop_nb = (g.K - 2) / 64; // chunks 1 .. 64 coop_nb; chunk 0 and the rest (the last chunk among them) on the per-lane path
+            const int nblk = coop_nb > 0 ? coop_nb + (g.K - 64 * coop_nb + 7) / 8 : (n + 63) / 64;
+            if (!redo && coop_nb == 0 && g.K >= 66 && getenv("SDHIP_COOP_REQUIRE")) // tests: the path under test must be the one that runs
+                throw HipError("k_afc: cooperative access asked for (SDHIP_COOP_REQUIRE) but the geometry does not allow it");
+            if (getenv("SDHIP_DEBUG") && !redo)
+                fprintf(stderr, "[sdhip] k_afc: K %d L %d W %d w_agc %d est %d -> %d cooperative blocks of %d\n", g.K, g.L, g.W, p.w_agc, p.cos.est_len, coop_nb, nblk);
+            hipLaunchKernelGGL((k_afc<O, F>), dim3(nblk), dim3(64), 0, st, x, y, g, p, start0, spec, endst, redo, nredo, ck.ck, ck.per_chunk,
+                               ck.len > 0 ? ck.len : 2048, ck.tol_phase, ck.tol_freq, coop_nb);
         };
         auto by_order = [&](auto fm) {
             if (p.cos.order == 2)

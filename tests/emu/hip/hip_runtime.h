@@ -208,6 +208,7 @@ inline unsigned emu_perm(unsigned s0, unsigned s1, unsigned sel)
 #define __builtin_amdgcn_perm emu_perm
 #define __builtin_amdgcn_wave_barrier() ((void)emu_ballot(1)) // the wave's lanes meet: what lockstep execution gives the hardware for free (one lane's LDS write before another lane's next read)
 #define __builtin_amdgcn_fence(...) ((void)0)
+#define __builtin_amdgcn_sched_barrier(x) ((void)0)
 inline void __threadfence() {}
 inline void __threadfence_block() {}
 inline int __popc(unsigned v) { return __builtin_popcount(v); }

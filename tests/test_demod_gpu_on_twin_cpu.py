@@ -120,6 +120,7 @@ test_soft_symbols_without_the_float_symbols = G2.test_soft_symbols_without_the_f
 test_freq_shift = G2.test_freq_shift
 test_doppler = G2.test_doppler
 test_dvbs2_front_end = G2.test_dvbs2_front_end
+test_cooperative_lanes_equal_the_per_lane_streams = G2.test_cooperative_lanes_equal_the_per_lane_streams
 
 
 

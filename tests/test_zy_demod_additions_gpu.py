@@ -330,3 +330,25 @@ def test_doppler(torch_cuda, capi, orc, case):
     d_soft = torch_cuda.zeros(2 * n + 64, dtype=torch_cuda.int8, device="cuda")
     with pytest.raises(capi.SdhipError, match="targets"):
         dem.process_dev(d_x.data_ptr(), n, capi.FMT_CF32, d_soft.data_ptr(), 2 * n + 64)
+
+
+@pytest.mark.parametrize("case,chunk", [("goes", 8192), ("metop", 16384), ("npp", 8192)])
+def test_cooperative_lanes_equal_the_per_lane_streams(torch_cuda, capi, orc, case, chunk, monkeypatch):
+    """Round 5: the lane stages move their 64 streams cooperatively (demod_kernels.hip, Coop: eight whole 128-byte lines per load / store instruction, handed to
+    their owners through an LDS transpose) instead of 64 sixteen-byte pieces of 64 lines. Same bytes, same arithmetic: soft symbols, float symbols and chunk
+    statistics must be BIT-identical to the per-lane path (SDHIP_COOP=0), on streams long enough for whole cooperative waves (chunks 1 .. 64 m), with chunk 0 and
+    the tail on the per-lane path beside them, over two calls (state and history carried)."""
+    from tests.test_demod_gpu import _case
+    spec, plain, x, ocfg, kw, fec, ofec = _case(case)
+    need = int((75 * chunk + 12345) * (1.2 if case == "goes" else 1.0))  # (GOES: the stages run behind the 9/10 resampler)
+    x = np.tile(x, need // len(x) + 1)[:need]
+    out = {}
+    for coop in ("0", "1"):
+        monkeypatch.setenv("SDHIP_COOP", coop)
+        if coop == "1":
+            monkeypatch.setenv("SDHIP_COOP_REQUIRE", "1")  # the engine refuses to fall back silently: the first (long) call must run cooperative waves
+        out[coop] = _run_demod(torch_cuda, capi, kw, x, chunks=[0, len(x) - 50000, len(x)], chunk_len=chunk)
+    (s0, y0, st0), (s1, y1, st1) = out["0"], out["1"]
+    assert st0.chunks == st1.chunks and st0.chunks_fixed == st1.chunks_fixed and st0.chunks_inexact == st1.chunks_inexact
+    assert np.array_equal(s0, s1)
+    assert np.array_equal(y0.view(np.uint32), y1.view(np.uint32))
