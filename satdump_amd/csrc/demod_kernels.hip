@@ -2200,7 +2200,7 @@ namespace sdhip
     {
         f.ring = ring;
         long long first = inc - 7 - p.back; // Gardner: the zero-crossing window lies up to p.back samples behind the symbol's
-        first = (first >= 0 ? first : first - 7) / 8 * 8; // floor to a multiple of 8 (also for negative indices)
+        first = (first >= 0 ? first : first - 15) / 16 * 16; // floor to a multiple of 16 (also for negative indices): whole 128-byte bursts from the chunk's first block on
         f.next = first;
         f.ck = 0;
         f.rot_nx = 0;
@@ -2394,15 +2394,18 @@ namespace sdhip
 template <bool CKPT, bool SPLIT, bool Q8 = false, bool FAST = false, bool GARD = false, bool TAP = false>
     __global__ __launch_bounds__(64) void k_mm(const cf32 *x, cf32 *sym, int *counts, ChunkGeom g, MmParams p, const MmState *start0, MmState *spec,
                                                MmState *endst, MmCert *spec_c, MmCert *end_c, const int *redo, int nredo, MmCkpt *ck, int ck_per_chunk,
-                                               float ck_tol)
+                                               float ck_tol, int coop_nb)
     {
         constexpr int RING = GARD ? MM_RING : MM_RING_MM;
         __shared__ cf32 rings[(RING + MM_MIRROR) * MM_RING_STRIDE];
         __shared__ __attribute__((aligned(16))) float bank[128 * MM_ARM_STRIDE];
+        __shared__ __attribute__((aligned(16))) char coop_lds[COOP_LDS_BYTES]; // load side only: the symbols leave per lane
         for (int i = (int)threadIdx.x; i < 128 * 8; i += 64)
             bank[(i >> 3) * MM_ARM_STRIDE + (i & 7)] = p.bank[i];
         __syncthreads();
         const int idx = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+        // cooperative loads (see Coop, k_afc): blocks 0 .. coop_nb-1 of a main launch take the chunks 1 + 64 blk + lane, chunk 0 and the tail follow eight to a block
+        const bool coop = !redo && coop_nb > 0 && (int)blockIdx.x < coop_nb;
         int k;
         MmState s;
         bool warm = false;
@@ -2415,9 +2418,24 @@ template <bool CKPT, bool SPLIT, bool Q8 = false, bool FAST = false, bool GARD =
         }
         else
         {
-            k = idx;
-            if (k >= g.K)
-                return;
+            if (coop_nb > 0)
+            {
+                if (coop)
+                    k = 1 + idx;
+                else
+                {
+                    const int j = ((int)blockIdx.x - coop_nb) * 8 + (int)threadIdx.x;
+                    if ((int)threadIdx.x >= 8 || j >= g.K - 64 * coop_nb)
+                        return;
+                    k = j == 0 ? 0 : 64 * coop_nb + j;
+                }
+            }
+            else
+            {
+                k = idx;
+                if (k >= g.K)
+                    return;
+            }
             if (k == 0)
                 s = *start0;
             else
@@ -2468,17 +2486,8 @@ template <bool CKPT, bool SPLIT, bool Q8 = false, bool FAST = false, bool GARD =
         };
         int phase = warm ? 0 : 1, cnt = 0, nx = 0, wsym = 0;
         bool done = false, merged = false;
-        Blk8 q[MM_DEPTH];
-#pragma unroll
-        for (int d = 0; d < MM_DEPTH; d++)
-            q[d] = blk_load(x, f.next + 8 * d);
-        while (!done)
-        {
-#pragma unroll
-            for (int d = 0; d < MM_DEPTH; d++)
-            {
-                const Blk8 cur = q[d];
-                q[d] = blk_load(x, f.next + 8 * MM_DEPTH); // at most 8*MM_DEPTH + 8 samples past the lane's last window
+        // one 8-sample block: into the ring, then every symbol whose window is complete (the body of both loops below)
+        const auto block_body = [&](const Blk8 &cur) __attribute__((always_inline)) {
                 mm_feed_put<RING>(f, p, cur);
                 if constexpr (CKPT)
                 { // one test per 8-sample block, outside the symbol loop: a checkpoint every MM_CK_SAMPLES samples of the chunk
@@ -2556,7 +2565,7 @@ template <bool CKPT, bool SPLIT, bool Q8 = false, bool FAST = false, bool GARD =
                             nx++;
                         }
                     }
-                    continue;
+                    return;
                 }
                 if constexpr (!SPLIT)
                 {
@@ -2573,7 +2582,7 @@ template <bool CKPT, bool SPLIT, bool Q8 = false, bool FAST = false, bool GARD =
                             put(cnt, v);
                             cnt++;
                         }
-                        continue;
+                        return;
                     }
                     if (__ballot(phase == 0 && f.next <= b) == act)
                     {
@@ -2583,7 +2592,7 @@ template <bool CKPT, bool SPLIT, bool Q8 = false, bool FAST = false, bool GARD =
                             wsym++;
                             (void)clock_iter<GARD, FAST, TAP, RING>(s, p, f.ring, bank, fast ? 0.0f : p.omega_gain, fast ? p.mu_gain * p.fast_mult : p.mu_gain);
                         }
-                        continue;
+                        return;
                     }
                 }
                 while (!done && s.inc < f.next)
@@ -2624,6 +2633,44 @@ template <bool CKPT, bool SPLIT, bool Q8 = false, bool FAST = false, bool GARD =
                         }
                     }
                 }
+        };
+        if (coop)
+        { // Cooperative phase: the lanes of this wave are ordinary chunks one chunk length apart and walk in lockstep (same f.next relative to the chunk start, a
+          // multiple of 16), nobody is done before its chunk end; bursts of 16 samples while they lie in front of the chunk end, the rest on the per-lane queue below
+            const Coop co = coop_make(coop_lds, (long long)g.L * (long long)sizeof(cf32));
+            const long long span = e - f.next;
+            const int nb = sd_uniform((int)(span > 0 ? span / 16 : 0));
+            long long fw = sd_uniform(f.next);
+            if (nb > 0)
+            {
+                Burst b0 = coop_load(x, fw, co), b1 = b0;
+                if (nb > 1)
+                    b1 = coop_load(x, fw + 16, co);
+                for (int it = 0; it < nb; it++)
+                {
+                    Blk8 c0, c1;
+                    coop_unpack(b0, co, c0, c1);
+                    b0 = b1;
+                    if (it + 2 < nb)
+                        b1 = coop_load(x, fw + 32, co);
+                    fw += 16;
+                    block_body(c0);
+                    block_body(c1);
+                }
+            }
+        }
+        Blk8 q[MM_DEPTH];
+#pragma unroll
+        for (int d = 0; d < MM_DEPTH; d++)
+            q[d] = blk_load(x, f.next + 8 * d);
+        while (!done)
+        {
+#pragma unroll
+            for (int d = 0; d < MM_DEPTH; d++)
+            {
+                const Blk8 cur = q[d];
+                q[d] = blk_load(x, f.next + 8 * MM_DEPTH); // at most 8*MM_DEPTH + 8 samples past the lane's last window
+                block_body(cur);
             }
         }
         if constexpr (Q8)
@@ -2635,10 +2682,6 @@ template <bool CKPT, bool SPLIT, bool Q8 = false, bool FAST = false, bool GARD =
     void launch_mm(const cf32 *x, cf32 *sym_scratch, int *counts, const ChunkGeom &g, const MmParams &p, const MmState *start0, MmState *spec, MmState *endst,
                    MmCert *spec_c, MmCert *end_c, const int *redo, int nredo, hipStream_t st, MmCkpt *ck, int ck_per_chunk, float ck_tol)
     {
-        // Dynamic LDS nobody reads, on top of the 22 KB a block (one wave) uses: with it a CU holds 6 blocks, not 7, and the 1 536 blocks of a 98 304-lane
-        // launch spread as 6 per CU -- the dispatcher otherwise packs some CUs with 7 and leaves others short, differently from one queue to the next
-        // (the 13.0 / 14.9 ms modes of this kernel). SDHIP_MM_LDS_PAD overrides (bytes).
-        const unsigned lds_pad = getenv("SDHIP_MM_LDS_PAD") ? (unsigned)atoi(getenv("SDHIP_MM_LDS_PAD")) : 0u;
         const int n = redo ? nredo : g.K;
         if (n <= 0)
             return;
@@ -2648,53 +2691,54 @@ template <bool CKPT, bool SPLIT, bool Q8 = false, bool FAST = false, bool GARD =
             _pr.emplace("k_mm (re-run launches, included in k_mm)", st);
         const char *split_env = getenv("SDHIP_MM_SPLIT");
         const bool split = split_env && split_env[0] == '1';
+        // cooperative loads of the wave's 64 streams (see Coop): chunk length and warm-up whole 128-byte bursts, at least one full wave of ordinary chunks
+        const bool coop_env = !(getenv("SDHIP_COOP") && atoi(getenv("SDHIP_COOP")) == 0);
+        int coop_nb = 0;
+        if (coop_env && !redo && g.L % 16 == 0 && g.W % 16 == 0 && g.K >= 66)
+            coop_nb = (g.K - 2) / 64;
+        if (!redo && coop_nb == 0 && g.K >= 66 && getenv("SDHIP_COOP_REQUIRE"))
+            throw HipError("k_mm: cooperative access asked for (SDHIP_COOP_REQUIRE) but the geometry does not allow it");
+        const int nblk = coop_nb > 0 ? coop_nb + (g.K - 64 * coop_nb + 7) / 8 : (n + 63) / 64;
+        if (getenv("SDHIP_DEBUG") && !redo)
+            fprintf(stderr, "[sdhip] k_mm: K %d L %d W %d -> %d cooperative blocks of %d\n", g.K, g.L, g.W, coop_nb, nblk);
+        auto go = [&](auto kern, MmCkpt *ckp, int per, float tol) {
+            hipLaunchKernelGGL(kern, dim3(nblk), dim3(64), 0, st, x, sym_scratch, counts, g, p, start0, spec, endst, spec_c, end_c, redo, nredo, ckp, per, tol, coop_nb);
+        };
+        if (p.tap)
+        { // tests only (sdhip_demod_set_tap): the default instance with the arm positions in place of the symbols
+            if (!ck || !p.fast || p.q8 || p.loop == 1)
+                throw HipError("the arm tap exists for the chunk-parallel mode's default kernel only");
+            go(k_mm<true, false, false, true, false, true>, ck, ck_per_chunk, ck_tol);
+            return;
+        }
         if (p.loop == 1)
         { // the Gardner loop on the same lanes (float symbols only)
             if (p.back < 1 || p.back > MM_BACK_MAX || p.q8)
                 throw HipError("Gardner lanes: omega out of the window the lanes carry");
             if (ck && p.fast)
-                hipLaunchKernelGGL((k_mm<true, false, false, true, true>), dim3((n + 63) / 64), dim3(64), lds_pad, st, x, sym_scratch, counts, g, p, start0, spec, endst, spec_c,
-                                   end_c, redo, nredo, ck, ck_per_chunk, ck_tol);
+                go(k_mm<true, false, false, true, true>, ck, ck_per_chunk, ck_tol);
             else if (ck)
-                hipLaunchKernelGGL((k_mm<true, false, false, false, true>), dim3((n + 63) / 64), dim3(64), lds_pad, st, x, sym_scratch, counts, g, p, start0, spec, endst, spec_c,
-                                   end_c, redo, nredo, ck, ck_per_chunk, ck_tol);
+                go(k_mm<true, false, false, false, true>, ck, ck_per_chunk, ck_tol);
             else if (p.fast)
-                hipLaunchKernelGGL((k_mm<false, false, false, true, true>), dim3((n + 63) / 64), dim3(64), lds_pad, st, x, sym_scratch, counts, g, p, start0, spec, endst, spec_c,
-                                   end_c, redo, nredo, (MmCkpt *)nullptr, 0, 0.0f);
+                go(k_mm<false, false, false, true, true>, nullptr, 0, 0.0f);
             else
-                hipLaunchKernelGGL((k_mm<false, false, false, false, true>), dim3((n + 63) / 64), dim3(64), lds_pad, st, x, sym_scratch, counts, g, p, start0, spec, endst, spec_c,
-                                   end_c, redo, nredo, (MmCkpt *)nullptr, 0, 0.0f);
-            return;
-        }
-        if (p.tap)
-        { // tests only (sdhip_demod_set_tap): the default instance with the arm positions in place of the symbols
-            if (!ck || !p.fast || p.q8)
-                throw HipError("the arm tap exists for the chunk-parallel mode's default kernel only");
-            hipLaunchKernelGGL((k_mm<true, false, false, true, false, true>), dim3((n + 63) / 64), dim3(64), lds_pad, st, x, sym_scratch, counts, g, p, start0, spec, endst, spec_c,
-                               end_c, redo, nredo, ck, ck_per_chunk, ck_tol);
+                go(k_mm<false, false, false, false, true>, nullptr, 0, 0.0f);
             return;
         }
         if (ck && p.q8 && p.fast)
-            hipLaunchKernelGGL((k_mm<true, false, true, true>), dim3((n + 63) / 64), dim3(64), lds_pad, st, x, sym_scratch, counts, g, p, start0, spec, endst, spec_c, end_c,
-                               redo, nredo, ck, ck_per_chunk, ck_tol);
+            go(k_mm<true, false, true, true>, ck, ck_per_chunk, ck_tol);
         else if (ck && p.q8)
-            hipLaunchKernelGGL((k_mm<true, false, true>), dim3((n + 63) / 64), dim3(64), lds_pad, st, x, sym_scratch, counts, g, p, start0, spec, endst, spec_c, end_c,
-                               redo, nredo, ck, ck_per_chunk, ck_tol);
+            go(k_mm<true, false, true>, ck, ck_per_chunk, ck_tol);
         else if (ck && p.fast)
-            hipLaunchKernelGGL((k_mm<true, false, false, true>), dim3((n + 63) / 64), dim3(64), lds_pad, st, x, sym_scratch, counts, g, p, start0, spec, endst, spec_c, end_c,
-                               redo, nredo, ck, ck_per_chunk, ck_tol);
+            go(k_mm<true, false, false, true>, ck, ck_per_chunk, ck_tol);
         else if (ck)
-            hipLaunchKernelGGL((k_mm<true, false>), dim3((n + 63) / 64), dim3(64), lds_pad, st, x, sym_scratch, counts, g, p, start0, spec, endst, spec_c, end_c, redo,
-                               nredo, ck, ck_per_chunk, ck_tol);
+            go(k_mm<true, false>, ck, ck_per_chunk, ck_tol);
         else if (p.q8)
-            hipLaunchKernelGGL((k_mm<false, false, true>), dim3((n + 63) / 64), dim3(64), lds_pad, st, x, sym_scratch, counts, g, p, start0, spec, endst, spec_c, end_c,
-                               redo, nredo, (MmCkpt *)nullptr, 0, 0.0f);
+            go(k_mm<false, false, true>, nullptr, 0, 0.0f);
         else if (split)
-            hipLaunchKernelGGL((k_mm<false, true>), dim3((n + 63) / 64), dim3(64), lds_pad, st, x, sym_scratch, counts, g, p, start0, spec, endst, spec_c, end_c, redo,
-                               nredo, (MmCkpt *)nullptr, 0, 0.0f);
+            go(k_mm<false, true>, nullptr, 0, 0.0f);
         else
-            hipLaunchKernelGGL((k_mm<false, false>), dim3((n + 63) / 64), dim3(64), lds_pad, st, x, sym_scratch, counts, g, p, start0, spec, endst, spec_c, end_c, redo,
-                               nredo, (MmCkpt *)nullptr, 0, 0.0f);
+            go(k_mm<false, false>, nullptr, 0, 0.0f);
     }
 
 
