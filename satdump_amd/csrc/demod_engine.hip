@@ -864,16 +864,12 @@ namespace sdhip
             if (getenv(lnames[st]))
                 return (int)((env_int(lnames[st], 8192) + 7) / 8 * 8);
             static const char *names[3] = {"SDHIP_LANES_AGC", "SDHIP_LANES_COSTAS", "SDHIP_LANES_MM"};
-            // M&M: 98 304 lanes = one and a half waves per SIMD. Measured on MetOp (profiles/r03_i_lanes_metop.txt, r03_k_repeat_metop.txt):
-            // 65 280 lanes 15.5 ms, 81 920 13.6, 98 304 13.0, 122 880 13.2, 130 560 14.5 -- the second wave hides the lane's LDS / load latency,
-            // the shorter chunk pays more warm-up (10.6 k samples on 21.9 k instead of 32.9 k); parity 99.592 % against 99.614 %
-            static const long long dflt[3] = {65280, 65280, 98304};
+            // M&M: one wave per SIMD. Round 3 / 4 ran 98 304 lanes (one and a half waves: 13.0 ms against 15.5 at 65 280 on MetOp); since the symbol loop's
+            // wave-uniform fast paths (round 5: 185 -> 86 instructions per symbol) a lone wave per SIMD is no slower per lane than two sharing one, and the
+            // longer chunks of 65 280 lanes pay less warm-up: 11.2 ms against 13.3 (98 304) and 13.2 (130 560), parity 99.614 % against 99.592 % (profiles/r05_d_ab_metop_ahrpt.txt)
+            static const long long dflt[3] = {65280, 65280, 65280};
             static const long long min_len[3] = {2048, 2048, 2048};
             long long lanes = std::max<long long>(64, env_int(names[st], dflt[st]));
-            // ... on batches long enough for it: below ~16 k samples per lane (GOES' 268 M-sample step: 4 k) the extra lanes only add warm-up
-            // (measured, profiles/r03_p_bench.json: GOES k_mm 7.1 -> 7.8 ms with them)
-            if (st == ST_MM && !getenv(names[st]) && (n + 65279) / 65280 < 16384)
-                lanes = 65280;
             long long L = (n + lanes - 1) / lanes;
             L = (L + 63) / 64 * 64;
             return (int)std::min<long long>(std::max<long long>(L, min_len[st]), 1 << 20);

@@ -2692,7 +2692,9 @@ template <bool CKPT, bool SPLIT, bool Q8 = false, bool FAST = false, bool GARD =
         const char *split_env = getenv("SDHIP_MM_SPLIT");
         const bool split = split_env && split_env[0] == '1';
         // cooperative loads of the wave's 64 streams (see Coop): chunk length and warm-up whole 128-byte bursts, at least one full wave of ordinary chunks
-        const bool coop_env = !(getenv("SDHIP_COOP") && atoi(getenv("SDHIP_COOP")) == 0);
+        // (measured, visit D of round 5: on these lanes -- latency-bound, one wave per SIMD -- the transposes cost more than the coalescing returns: MetOp 14.6 ms
+        // with, 13.3 without at 98 304 lanes; SDHIP_COOP_MM=1 turns it on, tests run both)
+        const bool coop_env = !(getenv("SDHIP_COOP") && atoi(getenv("SDHIP_COOP")) == 0) && getenv("SDHIP_COOP_MM") && atoi(getenv("SDHIP_COOP_MM")) != 0;
         int coop_nb = 0;
         if (coop_env && !redo && g.L % 16 == 0 && g.W % 16 == 0 && g.K >= 66)
             coop_nb = (g.K - 2) / 64;

@@ -15,7 +15,7 @@
 // S2BBToSoft -- from the module's thread, while the block threads run ahead by however many buffers their FIFOs hold: its output depends on thread
 // timing. Here the hand-over happens at call boundaries, with the closed form of "once per frame, the PLL following at once": after a call that
 // produced n frames the rotator takes over the fraction 1 - (1 - factor)^n of the PLL's frequency, and the PLL's frequency state is lowered by the
-// same amount (the sum the symbols are turned by stays continuous). Deterministic, stable for any n, and it converges to the same split: the
+// same amount (the sum the symbols are turned by stays continuous -- the symbols waiting in the ring are turned on accordingly). Deterministic, stable for any n, and it converges to the same split: the
 // rotator ends up carrying the offset, the PLL a residual near zero. factor = 0 is bit-for-bit the reference with that setting (exact mode).
 #include "../../include/sdhip.h"
 #include "common.h"
@@ -264,6 +264,16 @@ namespace sdhip
                 const double d = (double)pll->state.freq * g;
                 current_freq -= d;
                 pll->add_frequency((float)-d);
+                // The symbols still in the ring (what the PL synchroniser has not consumed: up to a frame and more) were turned at the OLD rate and reach the
+                // loop in the next call: turned on by exp(-j d i) from the first of them, and the rotator's phase for the next appended symbol moved by the
+                // same -d * left, the sum every symbol is turned by is continuous through the hand-over for them too (the loop saw a +d step over
+                // the leftover and a -d step behind it)
+                if (ring_len)
+                {
+                    ProfScope _ps("k_s2_rotate", nullptr);
+                    hipLaunchKernelGGL(k_s2_rotate, dim3((unsigned)((ring_len + 255) / 256)), dim3(256), 0, nullptr, ring.p, (long long)ring_len, 0.0, -d);
+                    rot_phase = fmod(rot_phase - d * (double)ring_len, 6.283185307179586476925);
+                }
             }
             // ---- process_s2: whole decoder groups
             const size_t nfull = total / batch * batch;

@@ -667,7 +667,7 @@ def _s2_baseband(modcod, short, nfr, esn0_db, seed=3, cfo_hz=0.0, sps=2.0, alpha
     return bbx, bb
 
 
-def check_dvbs2_engine(capi, make_mem, modcod=12, short=1, nfr=16, esn0_db=10.0, freq_prop=0.0, cuts=None, acq=None, cfo_hz=0.0):
+def check_dvbs2_engine(capi, make_mem, modcod=12, short=1, nfr=16, esn0_db=10.0, freq_prop=0.0, cuts=None, acq=None, cfo_hz=0.0, min_handover=0.6):
     """The DVB-S2 demodulator handle (sdhip_dvbs2_demod_*) in its DEFAULT schedules -- chunk-parallel front end, frame-parallel PLL -- on 8PSK frames,
     baseband in, BBFRAMEs out, against the reference's blocks and classes chained the way the module chains them: the same BBFRAMEs in the same order
     (the contract of the parallel schedules: the decoders' output), all of them transmitted ones; with freq_prop_factor (the reference's feedback runs
@@ -718,7 +718,8 @@ def check_dvbs2_engine(capi, make_mem, modcod=12, short=1, nfr=16, esn0_db=10.0,
         assert good.sum() >= nfr - 5 and np.array_equal(got[k0:k0 + m][good], want[r0:r0 + m][good])
     else:
         q = seen[-2]  # behind the last call of the signal proper
-        assert -1.1 * cfo_hz < q["freq_hz"] < -0.6 * cfo_hz and abs(q["pll_freq"]) < 2 * np.pi * cfo_hz / 1e6, seen  # the rotator has taken most of the offset over
+        # the rotator has taken the offset over (most of it at the larger factors; 1 - (1 - factor)^frames of it in any case)
+        assert -1.1 * cfo_hz < q["freq_hz"] < -min_handover * cfo_hz and abs(q["pll_freq"]) < 2 * np.pi * cfo_hz / 1e6, seen
     return st
 
 
@@ -737,6 +738,15 @@ def test_dvbs2_engine_freq_prop(capi):
     from satdump_amd import dvbs2
     check_dvbs2_engine(capi, dvbs2.TorchMem, modcod=4, short=1, nfr=40, esn0_db=7.0, freq_prop=0.05, acq=3 * 8190, cfo_hz=50.0,
                        cuts=[0] + [8190 * 2 * 5 * k for k in range(1, 9)] + [43 * 8190 * 2])
+
+
+def test_dvbs2_engine_freq_prop_hand_over(capi):
+    """the symbols waiting in the PL synchroniser's ring at a hand-over are turned on at the new rate (they reached the loop with a +d / -d frequency
+    step before). A larger offset, the module's default factor 0.01, a hand-over every two frames: every frame the reference chain finds (without the feedback)
+    comes out, in order, and the rotator carries 1 - 0.99^frames of the offset."""
+    from satdump_amd import dvbs2
+    check_dvbs2_engine(capi, dvbs2.TorchMem, modcod=4, short=1, nfr=40, esn0_db=7.0, freq_prop=0.01, acq=3 * 8190, cfo_hz=120.0,
+                       cuts=[0] + [8190 * 2 * 2 * k for k in range(1, 21)] + [43 * 8190 * 2], min_handover=0.2)
 
 
 

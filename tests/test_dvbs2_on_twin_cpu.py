@@ -188,6 +188,14 @@ def test_dvbs2_engine_freq_prop_on_the_twin(capi):
                          cuts=[0] + [8190 * 2 * 5 * k for k in range(1, 5)] + [23 * 8190 * 2])
 
 
+def test_dvbs2_engine_freq_prop_hand_over_on_the_twin(capi):
+    """the symbols waiting in the PL synchroniser's ring at a hand-over are turned on at the new rate (they reached the loop with a +d / -d frequency
+    step before). A larger offset, the module's default factor, a hand-over every two frames: every frame the reference chain finds (without the feedback) comes
+    out, in order."""
+    G.check_dvbs2_engine(capi, _NumpyMem, modcod=4, short=1, nfr=20, esn0_db=7.0, freq_prop=0.01, acq=3 * 8190, cfo_hz=120.0,
+                         cuts=[0] + [8190 * 2 * 2 * k for k in range(1, 11)] + [23 * 8190 * 2], min_handover=0.1)
+
+
 def test_bb_to_soft_golden_on_the_twin(capi):
     def to_dev(a):
         a = np.ascontiguousarray(a)

@@ -345,6 +345,7 @@ def test_cooperative_lanes_equal_the_per_lane_streams(torch_cuda, capi, orc, cas
     out = {}
     for coop in ("0", "1"):
         monkeypatch.setenv("SDHIP_COOP", coop)
+        monkeypatch.setenv("SDHIP_COOP_MM", coop)  # (the clock recovery's cooperative loads are off by default: measured slower; kept, tested here)
         if coop == "1":
             monkeypatch.setenv("SDHIP_COOP_REQUIRE", "1")  # the engine refuses to fall back silently: the first (long) call must run cooperative waves
         out[coop] = _run_demod(torch_cuda, capi, kw, x, chunks=[0, len(x) - 50000, len(x)], chunk_len=chunk)
