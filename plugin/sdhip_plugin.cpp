@@ -921,6 +921,53 @@ namespace sdhip_plugin
         }
     };
 
+    // METEORLRPTDecoderModule's m2x_mode branch WITHOUT the interleaver (module_meteor_lrpt_decoder.cpp:24-33, 103-200 with interleaved = false): 8192 soft bytes
+    // per read -> Viterbi1_2 (phases 0 / 90, I/Q exchange searched) -> NRZ-M ("diff_decode") -> BPSK_CCSDS_Deframer(8192) -> derandomiser -> RS(255,223) x 4,
+    // conventional basis, frames with an uncorrectable codeword dropped: statement for statement the concatenated decoder with an "oqpsk" constellation, so the
+    // module is that handle with the keys fixed. The interleaved variant (two DeinterleaverReaders, two Viterbis) stays on the CPU module.
+    class METEORLRPTM2XHipModule : public FecHipModuleBase
+    {
+    public:
+        METEORLRPTM2XHipModule(std::string input_file, std::string output_file_hint, nlohmann::json parameters)
+            : FecHipModuleBase(input_file, output_file_hint, parameters)
+        {
+            cfg.decoder = SDHIP_DEC_CONV_CONCAT;
+            cfg.constellation = SDHIP_OQPSK; // std::vector<phase_t> phases = {PHASE_0, PHASE_90}, check_iq_swap = true (:31-32)
+            cfg.cadu_size = 8192;
+            cfg.viterbi_outsync_after = parameters["viterbi_outsync_after"].get<int>();
+            cfg.viterbi_ber_thresold = parameters["viterbi_ber_thresold"].get<float>();
+            cfg.nrzm = parameters["diff_decode"].get<bool>() ? 1 : 0;
+            cfg.derandomize = 1;
+            cfg.derand_after_rs = 0;
+            cfg.derand_start = 4;
+            cfg.conv_rate = SDHIP_RATE_1_2;
+            cfg.rs_i = 4;
+            cfg.rs_fill_bytes = -1;
+            cfg.rs_dualbasis = 0;
+            cfg.rs_type = SDHIP_RS223;
+            cfg.rs_usecheck = 1;
+            fsfsm_file_ext = ".cadu";
+            block_bytes = 8192;
+            cadu_bytes = 1024;
+        }
+        static bool covers(const nlohmann::json &p)
+        {
+            return p.count("m2x_mode") > 0 && p["m2x_mode"].get<bool>() && !(p.count("interleaved") > 0 && p["interleaved"].get<bool>());
+        }
+        static std::string getID() { return "meteor_lrpt_m2x_decoder_hip"; }
+        virtual std::string getIDM() { return getID(); }
+        static nlohmann::json getParams() { return {}; }
+        static std::shared_ptr<ProcessingModule> getInstance(std::string input_file, std::string output_file_hint, nlohmann::json parameters)
+        {
+            return std::make_shared<METEORLRPTM2XHipModule>(input_file, output_file_hint, parameters);
+        }
+        nlohmann::json getModuleStats()
+        { // module_meteor_lrpt_decoder.cpp:269-281 (the keys of its m2x branch)
+            nlohmann::json v = FecHipModuleBase::getModuleStats();
+            return v;
+        }
+    };
+
     // ------------------------------------------------------------------------------------------------ meteor_lrpt_decoder
     // METEORLRPTDecoderModule (plugins/meteor_support/meteor/module_meteor_lrpt_decoder.{h,cpp}), its classic branch, on sdhip_lrpt_*: same keys
     // ("diff_decode" mandatory), .soft file / fifo in, .cadu out, the module's statistics keys. "m2x_mode" runs (Viterbi1_2 + deframer, optionally behind
@@ -941,7 +988,7 @@ namespace sdhip_plugin
             cfg.diff_decode = parameters["diff_decode"].get<bool>() ? 1 : 0; // module_meteor_lrpt_decoder.cpp:22
             opt(parameters, "hip_device", cfg.device);
             if (parameters.count("m2x_mode") > 0 && parameters["m2x_mode"].get<bool>())
-                throw satdump_exception("meteor_lrpt_decoder_hip: m2x_mode is the CPU module's");
+                throw satdump_exception("meteor_lrpt_decoder_hip: the interleaved m2x_mode is the CPU module's");
             fsfsm_file_ext = ".cadu";
         }
         ~METEORLRPTDecoderHipModule()
@@ -1013,6 +1060,8 @@ namespace sdhip_plugin
         static nlohmann::json getParams() { return {}; }
         static std::shared_ptr<ProcessingModule> getInstance(std::string input_file, std::string output_file_hint, nlohmann::json parameters)
         {
+            if (METEORLRPTM2XHipModule::covers(parameters)) // the same id with "m2x_mode" (no interleaver): the Viterbi1_2 / deframer branch's module
+                return METEORLRPTM2XHipModule::getInstance(input_file, output_file_hint, parameters);
             return std::make_shared<METEORLRPTDecoderHipModule>(input_file, output_file_hint, parameters);
         }
     };
@@ -1301,6 +1350,7 @@ namespace sdhip_plugin
             REGISTER_MODULE_EXTERNAL(evt.modules_registry, CCSDSSimplePSKDecoderHipModule);
             REGISTER_MODULE_EXTERNAL(evt.modules_registry, DVBS2DemodHipModule);
             REGISTER_MODULE_EXTERNAL(evt.modules_registry, METEORLRPTDecoderHipModule);
+            REGISTER_MODULE_EXTERNAL(evt.modules_registry, METEORLRPTM2XHipModule);
             REGISTER_MODULE_EXTERNAL(evt.modules_registry, FengyunAHRPTDecoderHipModule);
         }
         static void startedHandler(const satdump::SatDumpStartedEvent &)
@@ -1359,9 +1409,11 @@ namespace sdhip_plugin
                     };
                 }
                 else if (e.id == "meteor_lrpt_decoder")
-                { // plugins/meteor_support's module (ordering caveat as for metop_ahrpt_decoder); its m2x_mode branch stays on the CPU module
+                { // plugins/meteor_support's module (ordering caveat as for metop_ahrpt_decoder); of its m2x_mode branch the interleaved variant stays on the CPU module
                     auto cpu = e.inst;
                     e.inst = [cpu](std::string in, std::string out, nlohmann::json p) -> std::shared_ptr<ProcessingModule> {
+                        if (METEORLRPTM2XHipModule::covers(p)) // m2x_mode without the interleaver: the concatenated decoder's handle
+                            return METEORLRPTM2XHipModule::getInstance(in, out, p);
                         if (!METEORLRPTDecoderHipModule::covers(p))
                             return cpu(in, out, p);
                         return METEORLRPTDecoderHipModule::getInstance(in, out, p);

@@ -558,8 +558,29 @@ def check_lrpt_module_through_the_plugin(host, lib, tmp_path):
         got = np.fromfile(rep["soft"], dtype=np.uint8).reshape(-1, 1024)
         assert len(got) >= 8 and len(got) <= len(want) <= len(got) + 2 and np.array_equal(got, want[: len(got)])
         assert set(rep["demod_stats"]) >= {"correlator_lock", "viterbi_ber", "rs_avg", "lock_state"} and rep["demod_stats"]["lock_state"] == "SYNCED"
+    # m2x_mode without the interleaver (module_meteor_lrpt_decoder.cpp:103-200): Viterbi1_2 (phases 0 / 90, I/Q exchange) -> NRZ-M -> deframer -> derandomiser -> RS,
+    # conventional basis: the module's loop IS the concatenated decoder's with an "oqpsk" constellation (the reference's own classes chained by oracle/ref_wrap.cpp);
+    # the interleaved variant (today's Meteor-M pipeline) stays on the CPU module
+    soft8, _ = lrpt_soft(26, seed=9, diff=True, sigma=20.0)  # (the same frames serve both branches: ASM, randomiser, RS x 4 conventional basis, r = 1/2 on I / Q)
+    ofec = pyref.fec_cfg(constellation=pyref.OQPSK, nrzm=1, rs_i=4, rs_dualbasis=0, rs_usecheck=1, viterbi_ber_thresold=0.2, viterbi_outsync_after=5)
+    # (a file that ends on a buffer boundary: the module's loop runs once more on the buffer it still holds -- phase 0, no exchange: unchanged by its in-place turn)
+    wantm = pyref.best().concat_decode(ofec, np.concatenate([soft8, soft8[-8192:]]))["cadu"]
+    assert len(wantm) >= 22
+    inp2 = tmp_path / "m2x.soft"
+    soft8.tofile(str(inp2))
+    for module in ("meteor_lrpt_decoder", "meteor_lrpt_decoder_hip"):
+        job = {"mode": "file", "input": str(inp2), "output_hint": str(tmp_path / ("m2x_" + module)),
+               "demod": {"module": module, "parameters": {"diff_decode": True, "m2x_mode": True, "viterbi_outsync_after": 5, "viterbi_ber_thresold": 0.2}}}
+        jp.write_text(json.dumps(job))
+        p = subprocess.run([host, lib, PLUGIN, "run", str(jp)], capture_output=True, text=True, env=dict(os.environ, SDHIP_OVERRIDE="1"), timeout=900)
+        assert p.returncode == 0, p.stdout[-1000:] + p.stderr[-3000:]
+        rep = json.loads(p.stdout.strip().splitlines()[-1])
+        assert rep["demod_class"] == "meteor_lrpt_m2x_decoder_hip"
+        got = np.fromfile(rep["soft"], dtype=np.uint8).reshape(-1, 1024)
+        assert len(got) >= 20 and len(got) <= len(wantm) <= len(got) + 2 and np.array_equal(got, wantm[: len(got)])
+        assert set(rep["demod_stats"]) >= {"deframer_lock", "viterbi_ber", "viterbi_lock", "rs_avg", "viterbi_state", "deframer_state"}
     job = {"mode": "file", "input": str(inp), "output_hint": str(tmp_path / "m2x"), "instantiate_only": True,
-           "demod": {"module": "meteor_lrpt_decoder", "parameters": {"diff_decode": False, "m2x_mode": True, "viterbi_outsync_after": 5, "viterbi_ber_thresold": 0.2}}}
+           "demod": {"module": "meteor_lrpt_decoder", "parameters": {"diff_decode": False, "m2x_mode": True, "interleaved": True, "viterbi_outsync_after": 5, "viterbi_ber_thresold": 0.2}}}
     jp.write_text(json.dumps(job))
     p = subprocess.run([host, lib, PLUGIN, "run", str(jp)], capture_output=True, text=True, env=dict(os.environ, SDHIP_OVERRIDE="1"), timeout=900)
     assert p.returncode == 0 and json.loads(p.stdout.strip().splitlines()[-1])["demod_class"] == "cpu:meteor_lrpt_decoder", p.stdout[-500:] + p.stderr[-2000:]
