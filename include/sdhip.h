@@ -57,9 +57,13 @@ extern "C"
         SDHIP_DEC_METOP_AHRPT = 1, /* metop_ahrpt_decoder: Viterbi3_4 (MetOp puncture), deframer SYNCED=18, Viterbi watchdog */
         SDHIP_DEC_SIMPLE_PSK = 2,  /* ccsds_simple_psk_decoder: hard decisions (+NRZ-M / QPSK differential) -> deframer(s) -> derand -> RS
                                       (src-core/pipeline/modules/ccsds/module_ccsds_simple_psk_decoder.cpp:16-296) */
-        SDHIP_DEC_FENGYUN_AHRPT = 3 /* fengyun_ahrpt_decoder: a Viterbi3_4 (fymode) per QPSK rail, FengyunDiff::work2, deframer SYNCING=8 / SYNCED=16,
+        SDHIP_DEC_FENGYUN_AHRPT = 3, /* fengyun_ahrpt_decoder: a Viterbi3_4 (fymode) per QPSK rail, FengyunDiff::work2, deframer SYNCING=8 / SYNCED=16,
                                       derand, RS223 I=4 (plugins/fengyun3_support/fengyun3/module_fengyun_ahrpt_decoder.cpp:14-126). Reads
                                       viterbi_outsync_after, viterbi_ber_thresold, invert_second_viterbi; 16384 soft bytes per read */
+        SDHIP_DEC_FENGYUN_MPT = 4, /* fengyun_mpt_decoder: the same loop on two Viterbi1_2 (rate 1/2 rails, phases 0 / 90), the second rail always complemented, each
+                                      rail's byte pairs exchanged in front of its decoder, the deframer's default thresholds, the Viterbi watchdog on decoder 1 alone
+                                      as the module writes it (plugins/fengyun3_support/fengyun3/module_fengyun_mpt_decoder.cpp:17-134). Reads viterbi_outsync_after,
+                                      viterbi_ber_thresold */
     };
     enum
     {

@@ -304,6 +304,23 @@ class Ref(_Lib):
                                       _p(ber), _p(st), _p(ferr), C.byref(shift), C.byref(inv))
         return {"cadu": out[:n], "ber": ber[:nrd], "state": st[:nrd], "frm_err": ferr[:n], "shift": shift.value, "invert_branches": inv.value}
 
+    def fy3_mpt_decode(self, soft: np.ndarray, ber_thr=0.17, outsync_after=5):
+        """FengyunMPTDecoderModule::process() on the reference's own classes (ref_wrap.cpp: sdref_fy3_mpt_decode). Compiled reference only."""
+        if not hasattr(self.lib, "sdref_fy3_mpt_decode"):
+            raise RuntimeError("sdref_fy3_mpt_decode needs oracle/_ref/libsdref.so")
+        s = np.ascontiguousarray(soft, dtype=np.int8)
+        nrd = len(s) // 16384
+        cap = nrd * 2 + 8
+        out = np.zeros((cap, 1024), dtype=np.uint8)
+        ber = np.zeros((max(nrd, 1), 2), dtype=np.float32)
+        st = np.zeros((max(nrd, 1), 2), dtype=np.int32)
+        ferr = np.zeros((cap, 4), dtype=np.int32)
+        shift, inv = C.c_int(0), C.c_int(0)
+        self.lib.sdref_fy3_mpt_decode.restype = C.c_int64
+        n = self.lib.sdref_fy3_mpt_decode(C.c_float(ber_thr), C.c_int(outsync_after), _p(s), C.c_int64(len(s)), _p(out), C.c_int64(cap), _p(ber), _p(st), _p(ferr),
+                                          C.byref(shift), C.byref(inv))
+        return {"cadu": out[:n], "ber": ber[:nrd], "state": st[:nrd], "frm_err": ferr[:n], "shift": shift.value, "invert_branches": inv.value}
+
     def lrpt_decode(self, soft: np.ndarray, diff_decode=False):
         """METEORLRPTDecoderModule::process(), classic branch, on the reference's own classes (ref_wrap.cpp: sdref_lrpt_decode). Compiled reference only."""
         if not hasattr(self.lib, "sdref_lrpt_decode"):

@@ -731,6 +731,95 @@ extern "C"
         return nout;
     }
 
+    // In-memory restatement of FengyunMPTDecoderModule::process() (plugins/fengyun3_support/fengyun3/module_fengyun_mpt_decoder.cpp:43-134) on the reference's
+    // own Viterbi1_2 (phases 0 / 90), FengyunDiff, BPSK_CCSDS_Deframer (default thresholds), derand_ccsds and ReedSolomon: the AHRPT module's loop with rate-1/2
+    // rails, the second rail always complemented, a second I/Q exchange on each rail, and its watchdog condition as written (Viterbi 1's state twice, :78).
+    int64_t sdref_fy3_mpt_decode(float ber_thr, int outsync_after, const int8_t *soft, int64_t n, uint8_t *cadu_out, int64_t cadu_cap_frames, float *blk_ber, int *blk_state,
+                                 int *frm_err, int *shift_out, int *invert_branches_out)
+    {
+        const int BUFFER_SIZE = 8192;
+        viterbi::Viterbi1_2 *viterbi1 = zero_new<viterbi::Viterbi1_2>(ber_thr, outsync_after, BUFFER_SIZE, std::vector<phase_t>{PHASE_0, PHASE_90});
+        viterbi::Viterbi1_2 *viterbi2 = zero_new<viterbi::Viterbi1_2>(ber_thr, outsync_after, BUFFER_SIZE, std::vector<phase_t>{PHASE_0, PHASE_90});
+        deframing::BPSK_CCSDS_Deframer deframer;
+        fengyun3::FengyunDiff diff;
+        reedsolomon::ReedSolomon *rs = zero_new<reedsolomon::ReedSolomon>(reedsolomon::RS223);
+        std::vector<int8_t> soft_buffer(BUFFER_SIZE * 2 + 2, 0), i_soft_buffer(BUFFER_SIZE), q_soft_buffer(BUFFER_SIZE);
+        std::vector<uint8_t> viterbi1_out(BUFFER_SIZE * 2, 0), viterbi2_out(BUFFER_SIZE * 2, 0), diff_out(BUFFER_SIZE * 20, 0), frame_buffer(1024 * 10, 0);
+        int errors[4] = {0, 0, 0, 0};
+        int shift = 0;
+        bool iq_invert = true, invert_branches = false;
+        int noSyncRuns = 0, viterbiNoSyncRun = 0;
+        int64_t nout = 0;
+        const int64_t nreads = n / (BUFFER_SIZE * 2);
+        for (int64_t b = 0; b < nreads; b++)
+        {
+            memcpy(soft_buffer.data(), soft + b * BUFFER_SIZE * 2, BUFFER_SIZE * 2);
+            rotate_soft(soft_buffer.data(), BUFFER_SIZE * 2, PHASE_0, iq_invert);
+            for (int i = 0; i < BUFFER_SIZE; i++)
+            {
+                i_soft_buffer[i] = soft_buffer[(i + shift) * 2 + 0];
+                q_soft_buffer[i] = ~soft_buffer[(i + shift) * 2 + 1];
+            }
+            rotate_soft(i_soft_buffer.data(), BUFFER_SIZE, PHASE_0, true);
+            rotate_soft(q_soft_buffer.data(), BUFFER_SIZE, PHASE_0, true);
+            const int v1 = viterbi1->work(i_soft_buffer.data(), BUFFER_SIZE, viterbi1_out.data());
+            const int v2 = viterbi2->work(q_soft_buffer.data(), BUFFER_SIZE, viterbi2_out.data());
+            const int vout = std::min(v1, v2);
+            if (blk_ber)
+            {
+                blk_ber[2 * b] = viterbi1->ber();
+                blk_ber[2 * b + 1] = viterbi2->ber();
+            }
+            if (blk_state)
+            {
+                blk_state[2 * b] = viterbi1->getState();
+                blk_state[2 * b + 1] = viterbi2->getState();
+            }
+            if (viterbi1->getState() == 0 || viterbi1->getState() == 0)
+            {
+                viterbiNoSyncRun++;
+                if (viterbiNoSyncRun >= 10)
+                    shift = shift == 0 ? 1 : 0;
+            }
+            diff.work2(invert_branches ? viterbi1_out.data() : viterbi2_out.data(), invert_branches ? viterbi2_out.data() : viterbi1_out.data(), vout, diff_out.data());
+            if (v1 > 0 && v2 > 0)
+            {
+                int frames = deframer.work(diff_out.data(), vout * 2, frame_buffer.data());
+                if (deframer.getState() == deframer.STATE_NOSYNC)
+                {
+                    noSyncRuns++;
+                    if (noSyncRuns >= 10)
+                    {
+                        invert_branches = !invert_branches;
+                        noSyncRuns = 0;
+                    }
+                }
+                else
+                    noSyncRuns = 0;
+                for (int i = 0; i < frames; i++)
+                {
+                    uint8_t *cadu = &frame_buffer[i * 1024];
+                    derand_ccsds(&cadu[4], 1024 - 4);
+                    rs->decode_interlaved(&cadu[4], true, 4, errors);
+                    if (frm_err)
+                        for (int k = 0; k < 4; k++)
+                            frm_err[nout * 4 + k] = errors[k];
+                    if (nout < cadu_cap_frames)
+                        memcpy(cadu_out + nout * 1024, cadu, 1024);
+                    nout++;
+                }
+            }
+        }
+        if (shift_out)
+            *shift_out = shift;
+        if (invert_branches_out)
+            *invert_branches_out = invert_branches ? 1 : 0;
+        zero_delete(viterbi1);
+        zero_delete(viterbi2);
+        zero_delete(rs);
+        return nout;
+    }
+
     // FengyunDiff::work2 alone (fengyun3/diff.cpp:49-78) over one call of len bit pairs, and its transmit-side inverse for the test streams: the
     // pairs (x, y) whose work2 output is the given dibit stream, found pair by pair from the decoder's own rule.
     void sdref_fy3_diff2(const uint8_t *in1, const uint8_t *in2, int len, uint8_t *out)

@@ -921,6 +921,56 @@ namespace sdhip_plugin
         }
     };
 
+    // FengyunMPTDecoderModule (plugins/fengyun3_support/fengyun3/module_fengyun_mpt_decoder.{h,cpp}) on the FEC handle's SDHIP_DEC_FENGYUN_MPT: the AHRPT module's
+    // sibling on two Viterbi1_2 (rate-1/2 rails); same mandatory keys ("viterbi_outsync_after", "viterbi_ber_thresold"), .soft in, .cadu out, its statistics keys.
+    class FengyunMPTDecoderHipModule : public FecHipModuleBase
+    {
+        // the module exchanges I and Q of its buffer IN PLACE before it splits the rails (rotate_soft, :57): a short last read lands on exchanged bytes
+        void keep_for_next_read(const int8_t *slot, int8_t *last) override
+        {
+            for (int i = 0; i < block_bytes; i += 2)
+            {
+                const int8_t a = slot[i] == -128 ? -127 : slot[i], b = slot[i + 1] == -128 ? -127 : slot[i + 1];
+                last[i] = b;
+                last[i + 1] = a;
+            }
+        }
+
+    public:
+        FengyunMPTDecoderHipModule(std::string input_file, std::string output_file_hint, nlohmann::json parameters)
+            : FecHipModuleBase(input_file, output_file_hint, parameters)
+        {
+            cfg.decoder = SDHIP_DEC_FENGYUN_MPT;
+            cfg.viterbi_outsync_after = parameters["viterbi_outsync_after"].get<int>(); // module_fengyun_mpt_decoder.cpp:18-19
+            cfg.viterbi_ber_thresold = parameters["viterbi_ber_thresold"].get<float>();
+            fsfsm_file_ext = ".cadu";
+            block_bytes = 16384;
+            cadu_bytes = 1024;
+        }
+        nlohmann::json getModuleStats()
+        { // module_fengyun_mpt_decoder.cpp:136-152
+            auto v = base::FileStreamToFileStreamModule::getModuleStats();
+            const int ds = deframer_state.load();
+            v["deframer_lock"] = ds == 12;
+            v["viterbi1_ber"] = viterbi_ber.load();
+            v["viterbi1_lock"] = viterbi_lock.load();
+            v["viterbi2_ber"] = viterbi2_ber.load();
+            v["viterbi2_lock"] = viterbi2_lock.load();
+            v["rs_avg"] = rs_avg.load();
+            v["viterbi1_state"] = viterbi_lock.load() == 0 ? "NOSYNC" : "SYNCED";
+            v["viterbi2_state"] = viterbi2_lock.load() == 0 ? "NOSYNC" : "SYNCED";
+            v["deframer_state"] = ds <= 2 ? "NOSYNC" : (ds == 6 ? "SYNCING" : "SYNCED");
+            return v;
+        }
+        static std::string getID() { return "fengyun_mpt_decoder_hip"; }
+        virtual std::string getIDM() { return getID(); }
+        static nlohmann::json getParams() { return {}; }
+        static std::shared_ptr<ProcessingModule> getInstance(std::string input_file, std::string output_file_hint, nlohmann::json parameters)
+        {
+            return std::make_shared<FengyunMPTDecoderHipModule>(input_file, output_file_hint, parameters);
+        }
+    };
+
     // METEORLRPTDecoderModule's m2x_mode branch WITHOUT the interleaver (module_meteor_lrpt_decoder.cpp:24-33, 103-200 with interleaved = false): 8192 soft bytes
     // per read -> Viterbi1_2 (phases 0 / 90, I/Q exchange searched) -> NRZ-M ("diff_decode") -> BPSK_CCSDS_Deframer(8192) -> derandomiser -> RS(255,223) x 4,
     // conventional basis, frames with an uncorrectable codeword dropped: statement for statement the concatenated decoder with an "oqpsk" constellation, so the
@@ -1352,6 +1402,7 @@ namespace sdhip_plugin
             REGISTER_MODULE_EXTERNAL(evt.modules_registry, METEORLRPTDecoderHipModule);
             REGISTER_MODULE_EXTERNAL(evt.modules_registry, METEORLRPTM2XHipModule);
             REGISTER_MODULE_EXTERNAL(evt.modules_registry, FengyunAHRPTDecoderHipModule);
+            REGISTER_MODULE_EXTERNAL(evt.modules_registry, FengyunMPTDecoderHipModule);
         }
         static void startedHandler(const satdump::SatDumpStartedEvent &)
         {
@@ -1394,6 +1445,8 @@ namespace sdhip_plugin
                     e.inst = MetOpAHRPTDecoderHipModule::getInstance;
                 else if (e.id == "fengyun_ahrpt_decoder") // plugins/fengyun3_support's module (ordering caveat as for metop_ahrpt_decoder)
                     e.inst = FengyunAHRPTDecoderHipModule::getInstance;
+                else if (e.id == "fengyun_mpt_decoder") // its sibling in the same plugin
+                    e.inst = FengyunMPTDecoderHipModule::getInstance;
                 else if (e.id == "dvbs2_demod")
                 { // plugins/dvb_support's module (registered by that plugin: the ordering caveat of metop_ahrpt_decoder applies). 32APSK, Doppler and
                   // custom_samplerate stay on the CPU module

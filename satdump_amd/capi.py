@@ -17,7 +17,7 @@ BPSK, BPSK_90, QPSK, OQPSK, PSK8 = 0, 1, 2, 3, 4
 RS_NONE, RS223, RS239 = 0, 1, 2
 RATE_1_2, RATE_2_3, RATE_3_4, RATE_5_6, RATE_7_8 = 0, 1, 2, 3, 4
 FMT_CF32, FMT_CS16, FMT_CS8, FMT_CU8, FMT_CS32 = 0, 1, 2, 3, 4
-DEC_CONV_CONCAT, DEC_METOP_AHRPT, DEC_SIMPLE_PSK, DEC_FENGYUN_AHRPT = 0, 1, 2, 3
+DEC_CONV_CONCAT, DEC_METOP_AHRPT, DEC_SIMPLE_PSK, DEC_FENGYUN_AHRPT, DEC_FENGYUN_MPT = 0, 1, 2, 3, 4
 CONSTELLATIONS = {"bpsk": BPSK, "bpsk_90": BPSK_90, "qpsk": QPSK, "oqpsk": OQPSK, "8psk": PSK8}
 
 
@@ -318,7 +318,7 @@ class FecDecoder:
         self.h = lib().sdhip_fec_create(C.byref(cfg))
         if not self.h:
             raise SdhipError(f"sdhip_fec_create failed: {last_error()}")
-        self.cadu_bytes = 1024 if cfg.decoder in (DEC_METOP_AHRPT, DEC_FENGYUN_AHRPT) else cfg.cadu_size // 8
+        self.cadu_bytes = 1024 if cfg.decoder in (DEC_METOP_AHRPT, DEC_FENGYUN_AHRPT, DEC_FENGYUN_MPT) else cfg.cadu_size // 8
 
     def close(self):
         if self.h:

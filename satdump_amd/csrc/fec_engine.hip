@@ -289,8 +289,8 @@ namespace sdhip
         // counters call by call; device = rail split, lock searches, decodes, BER sums, the differential decoder, everything behind it.
         struct FyRail
         {
-            int vstate = 0, v_shift = 0, v_invalid = 0; // d_state, d_shift, d_invalid
-            float v_ber = 10, bers[2] = {10, 10};       // d_ber, d_bers[0][shift] (phase 1 is never tried in fymode: stays 10)
+            int vstate = 0, v_shift = 0, v_invalid = 0, v_phase = 0; // d_state, d_shift, d_invalid, d_phase (MPT's Viterbi1_2 searches phases 0 / 90)
+            float v_ber = 10, bers[4] = {10, 10, 10, 10};            // d_ber, d_bers[0][phase][shift] (fymode never tries phase 1: entries 2, 3 stay 10)
             int dec_first = 1, dec_start = 0;           // cc_decoder chaining
             VitSearchState search{};                    // cc_decoder_ber / cc_encoder_ber
             DevBuf<VitSearchState> d_search;
@@ -298,12 +298,13 @@ namespace sdhip
             PinBuf<VitBlockIO> h_io;
             DevBuf<uint32_t> d_vb; // decoded bits, packed
             DevBuf<int8_t> d_rail; // i_soft_buffer / q_soft_buffer of the blocks of one run
-            float ber() const { return vstate == 1 ? v_ber : std::min(10.0f, std::min(bers[0], bers[1])); } // Viterbi3_4::ber(), viterbi_3_4.cpp:173-188
+            float ber() const { return vstate == 1 ? v_ber : std::min(std::min(10.0f, std::min(bers[0], bers[1])), std::min(bers[2], bers[3])); } // Viterbi3_4::ber(), viterbi_3_4.cpp:173-188 / Viterbi1_2::ber()
         };
         struct Fy
         {
             FyRail rail[2];
             VitCfg rvc{};
+            int mpt = 0;                                           // fengyun_mpt_decoder: rate-1/2 rails (Viterbi1_2), see the constructor
             int shift = 0, invert_branches = 0, vit_nosync_run = 0; // the module's `shift`, `invert_branches`, `viterbiNoSyncRun` (`noSyncRuns` = metop_nosync_runs)
             unsigned x_prev = 0, y_prev = 0;                        // FengyunDiff's Xin >> 1, Yin
         } fy;
@@ -453,6 +454,42 @@ namespace sdhip
                 }
                 st_syncing = 8;
                 st_synced = 16;
+                cfg.cadu_size = 8192;
+                cadu_bytes = 1024;
+                cfg.nrzm = 0;
+                cfg.derandomize = 1;
+                cfg.derand_after_rs = 0;
+                cfg.derand_start = 4;
+                cfg.rs_i = 4;
+                cfg.rs_fill_bytes = 0;
+                cfg.rs_dualbasis = 1;
+                cfg.rs_type = SDHIP_RS223;
+                cfg.rs_usecheck = 0;
+                cfg.asm_sync = 0x1ACFFC1D;
+            }
+            else if (cfg.decoder == SDHIP_DEC_FENGYUN_MPT)
+            {
+                // FengyunMPTDecoderModule (module_fengyun_mpt_decoder.cpp:17-31, 43-134): BUFFER_SIZE 8192 symbols = 16384 soft bytes per read, a
+                // Viterbi1_2(thr, outsync, 8192, {PHASE_0, PHASE_90}) per rail (4096 bits per rail and read), the deframer as it is constructed (6 / 12),
+                // derand from byte 4, RS223 dual basis I=4, every frame written
+                B = 16384;
+                F = 8192; // bits per read handed to the deframer: 2 x 4096
+                nber = 1024;
+                ber_mult = 2.5;
+                vc.mode = 0;
+                fy.mpt = 1;
+                fy.rvc.mode = 0;
+                fy.rvc.fy = 0;
+                fy.rvc.B = 8192;
+                fy.rvc.F = 4096;
+                fy.rvc.nber = 1024;
+                for (FyRail &r : fy.rail)
+                {
+                    memset(&r.search, 0, sizeof(r.search));
+                    r.search.ber_first = 1;
+                    r.d_search.reserve(1);
+                }
+                st_synced = 12;
                 cfg.cadu_size = 8192;
                 cadu_bytes = 1024;
                 cfg.nrzm = 0;
@@ -887,7 +924,7 @@ namespace sdhip
                             W.frames.size(), hs.have ? "used" : "not needed", hs.hits.size(), (long long)gp0, gK, WIN_OFFS);
                 tick("walk");
 
-                if (cfg.decoder == SDHIP_DEC_METOP_AHRPT || cfg.decoder == SDHIP_DEC_FENGYUN_AHRPT)
+                if (cfg.decoder == SDHIP_DEC_METOP_AHRPT || cfg.decoder == SDHIP_DEC_FENGYUN_AHRPT || cfg.decoder == SDHIP_DEC_FENGYUN_MPT)
                 {
                     // watchdog, module_metop_ahrpt_decoder.cpp:59-72: 10 consecutive calls ending in NOSYNC reset the Viterbi
                     // (module_fengyun_ahrpt_decoder.cpp:97-109: ... exchange the differential decoder's two inputs from the next call on)
@@ -1037,7 +1074,7 @@ namespace sdhip
                 carry_bits = nwords * 32;
                 abs_bits = avail_end;
                 stats.bits_decoded += (uint64_t)n_eff * F;
-                if (watchdog_fired && cfg.decoder == SDHIP_DEC_FENGYUN_AHRPT)
+                if (watchdog_fired && (cfg.decoder == SDHIP_DEC_FENGYUN_AHRPT || cfg.decoder == SDHIP_DEC_FENGYUN_MPT))
                     fy.invert_branches ^= 1;
                 else if (watchdog_fired)
                     vstate = 0; // viterbi.reset()
@@ -1740,24 +1777,28 @@ namespace sdhip
         void fy_search(FyRail &r)
         {
             SD_HIP(hipMemcpyAsync(r.d_search.p, &r.search, sizeof(r.search), hipMemcpyHostToDevice, stream));
-            const int ph0[1] = {0};
-            launch_vit_search(fy.rvc, r.d_rail.p, 0, 1, ph0, 1, r.d_search.p, stream);
+            const int ph[2] = {0, 1};
+            const int nph = fy.mpt ? 2 : 1; // MPT: Viterbi1_2 over {PHASE_0, PHASE_90} (viterbi_1_2.cpp:55-90); AHRPT: Viterbi3_4's fymode, phase 0 only
+            launch_vit_search(fy.rvc, r.d_rail.p, 0, 1, ph, nph, r.d_search.p, stream);
             SD_HIP(hipMemcpyAsync(&r.search, r.d_search.p, sizeof(r.search), hipMemcpyDeviceToHost, stream));
             SD_HIP(hipStreamSynchronize(stream));
             r.v_ber = 10;
-            for (int shift = 0; shift < 2; shift++)
-            {
-                const float errors = (float)r.search.err[shift], total = (float)r.search.tot[shift];
-                const float ber = (float)((errors / total) * ber_mult);
-                r.bers[shift] = ber;
-                if ((r.v_ber == 10 && ber < cfg.viterbi_ber_thresold) || (r.v_ber < 10 && ber < r.v_ber))
+            int cand = 0;
+            for (int pi = 0; pi < nph; pi++)
+                for (int shift = 0; shift < 2; shift++, cand++)
                 {
-                    r.v_ber = ber;
-                    r.vstate = 1;
-                    r.v_shift = shift;
-                    r.v_invalid = 0;
+                    const float errors = (float)r.search.err[cand], total = (float)r.search.tot[cand];
+                    const float ber = (float)((errors / total) * ber_mult);
+                    r.bers[2 * pi + shift] = ber;
+                    if ((r.v_ber == 10 && ber < cfg.viterbi_ber_thresold) || (r.v_ber < 10 && ber < r.v_ber))
+                    {
+                        r.v_ber = ber;
+                        r.vstate = 1;
+                        r.v_phase = ph[pi];
+                        r.v_shift = shift;
+                        r.v_invalid = 0;
+                    }
                 }
-            }
         }
 
         // The module's loop (module_fengyun_ahrpt_decoder.cpp:58-126), a run of reads at a time: while either Viterbi is searching, one read per turn
@@ -1780,7 +1821,7 @@ namespace sdhip
                 const int n = any_idle ? 1 : (int)std::min<int64_t>(nblocks - pos, max_batch);
                 for (FyRail &r : fy.rail)
                     r.d_rail.reserve((size_t)n * RB);
-                launch_fy_rails(d_soft, pos, n, fy.shift, cfg.invert_second_viterbi, fy.rail[0].d_rail.p, fy.rail[1].d_rail.p, stream);
+                launch_fy_rails(d_soft, pos, n, fy.shift, cfg.invert_second_viterbi, fy.rail[0].d_rail.p, fy.rail[1].d_rail.p, stream, fy.mpt);
                 bool dec[2];
                 for (int k = 0; k < 2; k++)
                 {
@@ -1792,6 +1833,8 @@ namespace sdhip
                     {
                         VitCfg v = fy.rvc;
                         v.shift = r.v_shift;
+                        if (fy.mpt)
+                            v.phase = r.v_phase;
                         vit_run(v, r.d_rail.p, 0, n, r.dec_first ? -2 : r.dec_start, r.d_io, r.h_io, r.d_vb, r.search.enc_state, no_tick);
                     }
                     snaps[k].assign(n, Snap{r.vstate, r.v_invalid, r.v_ber});
@@ -1858,11 +1901,12 @@ namespace sdhip
                     for (int k = 0; k < 2; k++)
                     { // taps: two entries per read, rail 0 then rail 1
                         const Snap &sn = snaps[k][j];
-                        tap_ber.push_back(sn.vstate == 1 ? sn.v_ber : std::min(10.0f, std::min(fy.rail[k].bers[0], fy.rail[k].bers[1])));
+                        tap_ber.push_back(sn.vstate == 1 ? sn.v_ber : std::min(std::min(10.0f, std::min(fy.rail[k].bers[0], fy.rail[k].bers[1])), std::min(fy.rail[k].bers[2], fy.rail[k].bers[3])));
                         tap_state.push_back(sn.vstate);
                     }
-                // :80-91, after the two work() calls of a read: only the last read of a run can have left a Viterbi searching
-                if (fy.rail[0].vstate == 0 || fy.rail[1].vstate == 0)
+                // :80-91, after the two work() calls of a read: only the last read of a run can have left a Viterbi searching (the MPT module tests
+                // Viterbi 1's state twice, module_fengyun_mpt_decoder.cpp:78: Viterbi 2 searching alone does not count there)
+                if (fy.rail[0].vstate == 0 || (!fy.mpt && fy.rail[1].vstate == 0))
                 {
                     fy.vit_nosync_run++;
                     if (fy.vit_nosync_run >= 10)
@@ -1882,7 +1926,7 @@ namespace sdhip
 
         void process_blocks(const int8_t *d_soft, int64_t nblocks, uint8_t *d_out, size_t out_cap_frames, size_t &out_written)
         {
-            if (cfg.decoder == SDHIP_DEC_FENGYUN_AHRPT)
+            if (cfg.decoder == SDHIP_DEC_FENGYUN_AHRPT || cfg.decoder == SDHIP_DEC_FENGYUN_MPT)
                 return process_blocks_fengyun(d_soft, nblocks, d_out, out_cap_frames, out_written);
             if (cfg.decoder == SDHIP_DEC_SIMPLE_PSK)
                 return process_blocks_simple(d_soft, nblocks, d_out, out_cap_frames, out_written);

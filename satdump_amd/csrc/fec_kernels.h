@@ -102,7 +102,9 @@ namespace sdhip
     // The module's rail split (:62-68): after rotate_soft(.., PHASE_0, iq_invert = true) -- -128 -> -127, I and Q exchanged -- rail 0 takes byte 0 and
     // rail 1 byte 1 of pair i + shift (rail 1 complemented, ~x, when invert_second is set) for i in [0, 8192) of every 16384-byte block. With shift = 1
     // the module reads pair 8192 of its 8192-pair buffer; that pair is taken as (0, 0) here.
-    void launch_fy_rails(const int8_t *soft, int64_t first_block, int nblk, int shift, int invert_second, int8_t *rail0, int8_t *rail1, hipStream_t st);
+    // mpt (fengyun_mpt_decoder, module_fengyun_mpt_decoder.cpp:62-69): rail 1 always complemented, and both rails through rotate_soft(.., PHASE_0, true) once
+    // more: -128 -> -127, then the bytes of every pair of the RAIL exchanged.
+    void launch_fy_rails(const int8_t *soft, int64_t first_block, int nblk, int shift, int invert_second, int8_t *rail0, int8_t *rail1, hipStream_t st, int mpt = 0);
     // FengyunDiff::work2 (fengyun3/diff.cpp:49-78) over nblk blocks of bits_per_rail decoded bits of the two rails (packed MSB first, wpb_rail words per
     // block): x = the rail that is in1, y = in2; (x_prev, y_prev) = the pair in front of block 0. Writes 2 * bits_per_rail bits per block into out (wpb_out
     // words per block), the stream the deframer reads.

@@ -1479,7 +1479,7 @@ namespace sdhip
     // fengyun_ahrpt_decoder: the rail split in front of the two Viterbi3_4 decoders and the differential decoder behind them
     // =============================================================================================
     __global__ __launch_bounds__(256) void k_fy_rails(const int8_t *__restrict__ soft, long long first_block, int nblk, int shift, int invert_second, int8_t *rail0,
-                                                       int8_t *rail1)
+                                                       int8_t *rail1, int mpt)
     { // thread = four consecutive symbols of one block: two dword loads (+ one for the shifted pair), one dword store per rail
         const long long g = (long long)blockIdx.x * 256 + threadIdx.x;
         if (g >= (long long)nblk * 2048)
@@ -1502,20 +1502,26 @@ namespace sdhip
                 b = b == -128 ? -127 : b;
             }
             // iq swap: soft_buffer[2p] = b, soft_buffer[2p + 1] = a
-            const int v0 = b, v1 = invert_second ? ~a : a;
-            r0 |= ((unsigned)v0 & 0xffu) << (8 * q);
-            r1 |= ((unsigned)v1 & 0xffu) << (8 * q);
+            int v0 = b, v1 = invert_second ? ~a : a;
+            int qq = q;
+            if (mpt)
+            { // the rails' own rotate_soft(.., PHASE_0, true): -128 -> -127 (~127), then the bytes of a pair exchanged (i0 is a multiple of 4: pairs (0,1), (2,3))
+                v1 = v1 == -128 ? -127 : v1;
+                qq = q ^ 1;
+            }
+            r0 |= ((unsigned)v0 & 0xffu) << (8 * qq);
+            r1 |= ((unsigned)v1 & 0xffu) << (8 * qq);
         }
         reinterpret_cast<unsigned *>(rail0 + j * 8192)[i0 >> 2] = r0;
         reinterpret_cast<unsigned *>(rail1 + j * 8192)[i0 >> 2] = r1;
     }
-    void launch_fy_rails(const int8_t *soft, int64_t first_block, int nblk, int shift, int invert_second, int8_t *rail0, int8_t *rail1, hipStream_t st)
+    void launch_fy_rails(const int8_t *soft, int64_t first_block, int nblk, int shift, int invert_second, int8_t *rail0, int8_t *rail1, hipStream_t st, int mpt)
     {
         if (nblk <= 0)
             return;
         ProfScope _ps("k_fy_rails", st);
         const long long threads = (long long)nblk * 2048;
-        hipLaunchKernelGGL(k_fy_rails, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, soft, (long long)first_block, nblk, shift, invert_second, rail0, rail1);
+        hipLaunchKernelGGL(k_fy_rails, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, soft, (long long)first_block, nblk, shift, (invert_second || mpt) ? 1 : 0, rail0, rail1, mpt);
     }
 
     __global__ __launch_bounds__(256) void k_fy_diff(const unsigned *__restrict__ x, const unsigned *__restrict__ y, int nblk, int bits_per_rail, int wpb_rail,

@@ -202,18 +202,25 @@ def fy3_diff_encode(dibits: np.ndarray) -> tuple[np.ndarray, np.ndarray]:
 
 
 def fy3_ahrpt_soft(nframes: int, seed: int = 3, sigma: float = 18.0, amp: float = 70.0, invert_second: bool = True, branches_swapped: bool = False, lead: int = 0,
-                   gaps=(), noise_tail: int = 0):
+                   gaps=(), noise_tail: int = 0, mpt: bool = False):
     """A FengYun-3 AHRPT .soft stream as fengyun_ahrpt_decoder reads it (module_fengyun_ahrpt_decoder.cpp:58-126): 1024-byte CADUs (RS(255,223) x 4 dual
     basis, randomised) -> dibits -> differential encoder -> two rails, each r = 1/2 k = 7 punctured to 3/4 (c0 c1 . c1 c0 . per three bits, what
     Viterbi3_4's fymode depuncture undoes, viterbi_3_4.cpp:58-78) -> QPSK. The module exchanges I and Q, hands byte 0 of a pair to Viterbi 1 and byte 1
     (complemented when invert_second) to Viterbi 2, and takes Viterbi 2's bits as the differential decoder's first input -- unless `branches_swapped`, the
-    case its noSyncRuns counter resolves. lead: garbage bytes in front, gaps: (byte position, bytes removed). Returns (soft int8, plain CADUs)."""
+    case its noSyncRuns counter resolves. lead: garbage bytes in front, gaps: (byte position, bytes removed). Returns (soft int8, plain CADUs).
+    mpt: the stream fengyun_mpt_decoder reads instead (module_fengyun_mpt_decoder.cpp:56-75): the rails at rate 1/2 unpunctured, every rail's byte pairs
+    exchanged (the module exchanges them back in front of its Viterbi1_2), the second rail always complemented."""
     cadus = make_cadus(nframes, seed=seed, rs_i=4, dualbasis=True)
     x, y = fy3_diff_encode(np.unpackbits(cadus.reshape(-1)))
     v1_bits, v2_bits = (x, y) if branches_swapped else (y, x)
     rails = []
+    if mpt:
+        invert_second = True
     for bits in (v1_bits, v2_bits):
-        c = puncture(conv_encode(bits), 2).astype(np.float64) * 2.0 - 1.0
+        if mpt:
+            c = conv_encode(bits).reshape(-1, 2)[:, ::-1].reshape(-1).astype(np.float64) * 2.0 - 1.0
+        else:
+            c = puncture(conv_encode(bits), 2).astype(np.float64) * 2.0 - 1.0
         rails.append(c)
     n = min(len(rails[0]), len(rails[1]))
     rng = np.random.default_rng(seed + 100)

@@ -39,8 +39,9 @@ def _torch_helpers():
     return to_dev, (lambda d: d[0].cpu().numpy()), zeros_dev
 
 
-def run_engine(capi, to_dev, to_host, zeros_dev, soft, invert_second=True, cuts=None, ber_thr=0.17, outsync_after=5):
-    cfg = capi.fec_cfg(decoder=capi.DEC_FENGYUN_AHRPT, viterbi_ber_thresold=ber_thr, viterbi_outsync_after=outsync_after, invert_second_viterbi=int(invert_second))
+def run_engine(capi, to_dev, to_host, zeros_dev, soft, invert_second=True, cuts=None, ber_thr=0.17, outsync_after=5, mpt=False):
+    cfg = capi.fec_cfg(decoder=capi.DEC_FENGYUN_MPT if mpt else capi.DEC_FENGYUN_AHRPT, viterbi_ber_thresold=ber_thr, viterbi_outsync_after=outsync_after,
+                       invert_second_viterbi=int(invert_second))
     dec = capi.FecDecoder(cfg)
     outs, bers, states = [], [], []
     cuts = cuts or [0, len(soft)]
@@ -73,9 +74,10 @@ CASES = [
 def check_decoder(capi, to_dev, to_host, zeros_dev, case, cuts=None):
     kw = dict(case)
     inv2 = kw.get("invert_second", True)
+    mpt = kw.get("mpt", False)
     soft, plain = synth.fy3_ahrpt_soft(**kw) if kw.get("nframes") else (np.random.default_rng(5).integers(-60, 60, kw["noise_tail"]).astype(np.int8), None)
-    want = pyref.ref().fy3_decode(soft, invert_second=inv2)
-    got, ber, state, st = run_engine(capi, to_dev, to_host, zeros_dev, soft, invert_second=inv2, cuts=cuts)
+    want = pyref.ref().fy3_mpt_decode(soft) if mpt else pyref.ref().fy3_decode(soft, invert_second=inv2)
+    got, ber, state, st = run_engine(capi, to_dev, to_host, zeros_dev, soft, invert_second=inv2, cuts=cuts, mpt=mpt)
     assert np.array_equal(state, want["state"])
     assert np.array_equal(ber.view(np.uint32), want["ber"].view(np.uint32))
     assert got.shape == want["cadu"].shape and np.array_equal(got, want["cadu"])
@@ -129,3 +131,44 @@ def test_fy3_long_run(capi):
     assert np.array_equal(state, want["state"]) and np.array_equal(ber.view(np.uint32), want["ber"].view(np.uint32))
     assert got.shape == want["cadu"].shape and np.array_equal(got, want["cadu"])
     assert len(got) > 500
+
+
+# fengyun_mpt_decoder (plugins/fengyun3_support/fengyun3/module_fengyun_mpt_decoder.cpp; SDHIP_DEC_FENGYUN_MPT): the same loop on two Viterbi1_2 -- rate-1/2 rails,
+# phases 0 / 90 searched, the rails' byte pairs exchanged in front of the decoders, the deframer's default thresholds, the watchdog on Viterbi 1's state alone --
+# against the module's loop on the reference's own classes (oracle/ref_wrap.cpp: sdref_fy3_mpt_decode)
+MPT_CASES = [
+    dict(nframes=24, mpt=True),
+    dict(nframes=30, sigma=30.0, mpt=True),
+    dict(nframes=30, sigma=40.0, mpt=True),                        # around the lock threshold
+    dict(nframes=48, branches_swapped=True, mpt=True),
+    dict(nframes=48, lead=16384 * 2 + 2, mpt=True),                # the other symbol of a pair first
+    dict(nframes=40, gaps=((16384 * 9 + 4 * 333, 4 * 777 + 2),), sigma=12.0, mpt=True),
+    dict(nframes=12, lead=16384 * 3, noise_tail=16384 * 4, mpt=True),
+]
+
+
+@pytest.mark.parametrize("case", MPT_CASES, ids=[str(i) for i in range(len(MPT_CASES))])
+def test_fy3_mpt_decoder(capi, case):
+    if not (pyref.ref_available() and hasattr(pyref.ref().lib, "sdref_fy3_mpt_decode")):
+        pytest.skip("needs the compiled reference")
+    check_decoder(capi, *_torch_helpers(), case)
+
+
+def check_mpt_cuts(capi, to_dev, to_host, zeros_dev, nframes=36):
+    soft, _ = synth.fy3_ahrpt_soft(nframes, seed=9, sigma=24.0, mpt=True)
+    want = pyref.ref().fy3_mpt_decode(soft)
+    n = len(soft)
+    cuts = [0, 1000, 1000, 16384 * 3 + 17, 16384 * 11, 16384 * 11 + 5, n]
+    got, ber, state, _ = run_engine(capi, to_dev, to_host, zeros_dev, soft, cuts=cuts, mpt=True)
+    assert np.array_equal(got, want["cadu"]) and len(got) >= nframes - 6
+    assert np.array_equal(state, want["state"]) and np.array_equal(ber.view(np.uint32), want["ber"].view(np.uint32))
+    dec = capi.FecDecoder(capi.fec_cfg(decoder=capi.DEC_FENGYUN_MPT, viterbi_ber_thresold=0.17, viterbi_outsync_after=5))
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        dec.push(soft[a:b])
+    assert np.array_equal(dec.pull(), want["cadu"])
+
+
+def test_fy3_mpt_cuts_and_host_path(capi):
+    if not (pyref.ref_available() and hasattr(pyref.ref().lib, "sdref_fy3_mpt_decode")):
+        pytest.skip("needs the compiled reference")
+    check_mpt_cuts(capi, *_torch_helpers())

@@ -25,3 +25,10 @@ def test_fy3_cuts_on_the_twin(capi):
     if not (pyref.ref_available() and hasattr(pyref.ref().lib, "sdref_fy3_decode")):
         pytest.skip("needs the compiled reference")
     G.check_cuts(capi, *_np_helpers())
+
+
+@pytest.mark.parametrize("case", [G.MPT_CASES[0]] if not os.environ.get("FY3_TWIN_ALL") else G.MPT_CASES)
+def test_fy3_mpt_decoder_on_the_twin(capi, case):
+    if not (pyref.ref_available() and hasattr(pyref.ref().lib, "sdref_fy3_mpt_decode")):
+        pytest.skip("needs the compiled reference")
+    G.check_decoder(capi, *_np_helpers(), case)

@@ -135,6 +135,15 @@ def test_fy3_module_through_the_plugin_on_the_twin(host, tmp_path):
     G.check_fy3_module_through_the_plugin(host, emu_build.build(), tmp_path, variants=("short",))  # the end-of-file case; all three on the GPU
 
 
+def test_fy3_mpt_module_through_the_plugin_on_the_twin(host, tmp_path):
+    from oracle import pyref
+    from tests import test_plugin_minihost_gpu as G
+    from tests.emu import build as emu_build
+    if not (pyref.ref_available() and hasattr(pyref.ref().lib, "sdref_fy3_mpt_decode")) or not os.path.exists(emu_build.CLANG):
+        pytest.skip("needs the compiled reference and a host clang++")
+    G.check_fy3_mpt_module_through_the_plugin(host, emu_build.build(), tmp_path)
+
+
 def test_wav_container_through_the_plugin_on_the_twin(host, tmp_path):
     """tests/test_plugin_minihost_gpu.py::test_wav_container_through_the_plugin with the host twin as the C-ABI library: the plugin's header detection, the
     `w16` / `wav` format names and the chunk plan behind a header run in the CPU suite."""

@@ -629,6 +629,40 @@ def check_fy3_module_through_the_plugin(host, lib, tmp_path, variants=("inv", "p
     assert p.returncode != 0
 
 
+def check_fy3_mpt_module_through_the_plugin(host, lib, tmp_path):
+    """fengyun_mpt_decoder (the AHRPT module's sibling in plugins/fengyun3_support: two Viterbi1_2 on rate-1/2 rails) through the drop-in boundary: the stock id,
+    re-pointed under SDHIP_OVERRIDE=1 at FengyunMPTDecoderHipModule, reads a .soft file and writes the .cadu file the module's loop writes (on the reference's
+    own classes: oracle/ref_wrap.cpp sdref_fy3_mpt_decode), a short last read included (it lands on the previous buffer's EXCHANGED bytes: rotate_soft works in place)."""
+    soft, _ = synth.fy3_ahrpt_soft(36, seed=14, sigma=24.0, mpt=True, lead=16384 + 444 * 4)
+    soft = soft[: 16384 * 26 + 5000]
+    nfull, rem = divmod(len(soft), 16384)
+    prev = soft[(nfull - 1) * 16384:nfull * 16384].copy()
+    prev[prev == -128] = -127
+    prev = prev.reshape(-1, 2)[:, ::-1].reshape(-1)
+    ext = np.concatenate([soft[:nfull * 16384], soft[nfull * 16384:], prev[rem:]])
+    want = pyref.ref().fy3_mpt_decode(ext, ber_thr=0.17, outsync_after=5)["cadu"]
+    inp = tmp_path / "mpt.soft"
+    soft.tofile(str(inp))
+    job = {"mode": "file", "input": str(inp), "output_hint": str(tmp_path / "mpt"),
+           "demod": {"module": "fengyun_mpt_decoder", "parameters": {"viterbi_outsync_after": 5, "viterbi_ber_thresold": 0.17}}}
+    jp = tmp_path / "mpt.json"
+    jp.write_text(json.dumps(job))
+    p = subprocess.run([host, lib, PLUGIN, "run", str(jp)], capture_output=True, text=True, env=dict(os.environ, SDHIP_OVERRIDE="1"), timeout=900)
+    assert p.returncode == 0, p.stdout[-1000:] + p.stderr[-3000:]
+    rep = json.loads(p.stdout.strip().splitlines()[-1])
+    assert rep["demod_class"] == "fengyun_mpt_decoder_hip" and rep["soft"].endswith(".cadu")
+    got = np.fromfile(rep["soft"], dtype=np.uint8).reshape(-1, 1024)
+    assert len(want) >= 20 and got.shape == want.shape and np.array_equal(got, want)
+    st = rep["demod_stats"]
+    assert set(st) >= {"deframer_lock", "viterbi1_ber", "viterbi1_lock", "viterbi2_ber", "viterbi2_lock", "rs_avg", "viterbi1_state", "viterbi2_state", "deframer_state"}
+
+
+def test_fy3_mpt_module_through_the_plugin(host, tmp_path):
+    if not (pyref.ref_available() and hasattr(pyref.ref().lib, "sdref_fy3_mpt_decode")):
+        pytest.skip("needs the compiled reference")
+    check_fy3_mpt_module_through_the_plugin(host, LIB, tmp_path)
+
+
 def test_fy3_module_through_the_plugin(host, tmp_path):
     if not (pyref.ref_available() and hasattr(pyref.ref().lib, "sdref_fy3_decode")):
         pytest.skip("needs the compiled reference")
