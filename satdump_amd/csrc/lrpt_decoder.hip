@@ -72,12 +72,12 @@ namespace sdhip
 
     // Correlator::correlate (QPSK) + the module's buffer bookkeeping, frame after frame
     __global__ __launch_bounds__(1024) void k_lrpt_chain(const unsigned *__restrict__ bits, long long n, LrptSync sync, LrptDesc *descs, int max_frames, int *count,
-                                                          long long *consumed)
+                                                          long long *consumed, long long o0, long long desc_base)
     {
         __shared__ unsigned red[16];
         __shared__ int s_p0, s_c0;
         const int tid = (int)threadIdx.x;
-        long long o = 0;
+        long long o = o0; // (start inside the bit array handed in; descriptors name positions desc_base further on: the stream's)
         int cnt = 0;
         while (o + LRPT_ENC <= n && cnt < max_frames)
         {
@@ -139,7 +139,7 @@ namespace sdhip
             if (pos != 0 && o + pos + LRPT_ENC > n)
                 break; // the slid frame is not complete yet: it stays for the next call
             if (tid == 0)
-                descs[cnt] = LrptDesc{o + pos, p % 4, (p / 4) == 0 ? 1 : 0, cor, pos == 0 ? 1 : 0};
+                descs[cnt] = LrptDesc{desc_base + o + pos, p % 4, (p / 4) == 0 ? 1 : 0, cor, pos == 0 ? 1 : 0};
             cnt++;
             o += pos + LRPT_ENC;
             __syncthreads(); // red / s_p0 are rewritten by the next frame
@@ -149,6 +149,104 @@ namespace sdhip
             *count = cnt;
             *consumed = o;
         }
+    }
+
+    // ---- the chain in parallel (round 5) -------------------------------------------------------------------------------------------------------------------
+    // While the correlator answers "offset 0" -- the in-sync case, the "> 45 at offset 0" shortcut -- frame k starts exactly 16384 bytes behind frame k-1: the
+    // chain runs along a GRID from wherever it last slid to. k_lrpt_spec takes the correlator's decision at EVERY grid position behind an origin at once (a
+    // workgroup per position: the shortcut, else the full 8160 x 8 scan with the reference's order of preference); k_lrpt_walk then follows the chain over those
+    // answers for as long as they say 0, takes the first slide (the module reads on behind it: a new origin) and stops there. In lock one round covers the call;
+    // every slide costs a round, and a stream that keeps sliding (noise) goes back to the serial kernel above after a few of them. Same descriptors either way.
+    struct LrptSpec
+    {
+        int pos, p, cor;
+    };
+    __global__ __launch_bounds__(256) void k_lrpt_spec(const unsigned *__restrict__ bits, long long n, long long origin, LrptSync sync, LrptSpec *spec, int npos)
+    {
+        __shared__ unsigned red[4];
+        __shared__ int s_p0, s_c0;
+        const int k = (int)blockIdx.x, tid = (int)threadIdx.x;
+        if (k >= npos)
+            return;
+        const long long o = origin + (long long)k * LRPT_ENC;
+        if (tid == 0)
+        {
+            const unsigned long long win = lrpt_window(bits, o);
+            int p0 = -1, c0 = 0;
+            for (int p = 0; p < 8; p++)
+            {
+                const int c = 64 - __popcll(sync.w[p] ^ win);
+                if (c > 45)
+                {
+                    p0 = p;
+                    c0 = c;
+                    break;
+                }
+            }
+            s_p0 = p0;
+            s_c0 = c0;
+        }
+        __syncthreads();
+        if (s_p0 >= 0)
+        {
+            if (tid == 0)
+                spec[k] = LrptSpec{0, s_p0, s_c0};
+            return;
+        }
+        unsigned best = 0;
+        for (int s = tid; s < LRPT_OFFSETS; s += 256)
+        {
+            const unsigned long long win = lrpt_window(bits, o + 2 * s);
+#pragma unroll
+            for (int v = 0; v < 8; v++)
+            {
+                const unsigned c = 64u - (unsigned)__popcll(sync.w[v] ^ win);
+                const unsigned key = (c << 16) | ((unsigned)(8191 - s) << 3) | (unsigned)(7 - v);
+                best = best > key ? best : key;
+            }
+        }
+        for (int d = 32; d >= 1; d >>= 1)
+        {
+            const unsigned other = (unsigned)__shfl_xor((int)best, d);
+            best = best > other ? best : other;
+        }
+        if ((tid & 63) == 0)
+            red[tid >> 6] = best;
+        __syncthreads();
+        if (tid == 0)
+        {
+            unsigned all = red[0];
+            for (int w = 1; w < 4; w++)
+                all = all > red[w] ? all : red[w];
+            spec[k] = LrptSpec{2 * (8191 - (int)((all >> 3) & 8191u)), 7 - (int)(all & 7u), (int)(all >> 16)};
+        }
+    }
+    // one thread: the module's loop over the speculated answers (k_lrpt_chain's bookkeeping). state[0] = frames so far, state[1] = 1 when the stream is used up
+    // (or the slid frame is not complete yet), consumed = where the chain stands
+    __global__ void k_lrpt_walk(const LrptSpec *__restrict__ spec, int npos, long long n, long long origin, LrptDesc *descs, int max_frames, int *state, long long *consumed)
+    {
+        int cnt = state[0];
+        long long o = origin;
+        int done = 1;
+        for (int k = 0; k < npos; k++)
+        {
+            if (!(o + LRPT_ENC <= n && cnt < max_frames))
+                break;
+            const LrptSpec sp = spec[k];
+            if (sp.pos != 0 && o + sp.pos + LRPT_ENC > n)
+                break; // the slid frame is not complete yet: it stays for the next call
+            descs[cnt] = LrptDesc{o + sp.pos, sp.p % 4, (sp.p / 4) == 0 ? 1 : 0, sp.cor, sp.pos == 0 ? 1 : 0};
+            cnt++;
+            o += sp.pos + LRPT_ENC;
+            if (sp.pos != 0)
+            { // off the grid: the next round speculates from here
+                done = (o + LRPT_ENC <= n && cnt < max_frames) ? 0 : 1;
+                break;
+            }
+        }
+        state[0] = cnt;
+        state[1] = done;
+        *consumed = o;
     }
 
     // rotate_soft(buffer, 16384, phase, swap), rotation.cpp:4-58, out of place: thread per (I, Q) pair
@@ -259,6 +357,9 @@ namespace sdhip
         DevBuf<LrptDesc> d_desc;
         DevBuf<int> d_cnt;
         DevBuf<long long> d_consumed;
+        DevBuf<LrptSpec> d_spec;
+        DevBuf<int> d_state;
+        unsigned long long stats_rounds = 0;
         DevBuf<int8_t> d_frames;
         DevBuf<unsigned char> d_raw, d_post, d_pn, d_clean;
         DevBuf<int> d_err, d_dst;
@@ -333,14 +434,52 @@ namespace sdhip
             hipLaunchKernelGGL(k_lrpt_hard, dim3((unsigned)((nwords + 255) / 256)), dim3(256), 0, nullptr, base, (long long)total, bits.p, nwords);
             const int max_frames = (int)(total / LRPT_ENC) + 1;
             d_desc.reserve(max_frames);
-            {
-                ProfScope _ps("k_lrpt_chain", nullptr);
-                hipLaunchKernelGGL(k_lrpt_chain, dim3(1), dim3(1024), 0, nullptr, bits.p, (long long)total, sync, d_desc.p, max_frames, d_cnt.p, d_consumed.p);
-            }
             int nf = 0;
             long long consumed = 0;
-            SD_HIP(hipMemcpy(&nf, d_cnt.p, sizeof(int), hipMemcpyDeviceToHost));
-            SD_HIP(hipMemcpy(&consumed, d_consumed.p, sizeof(long long), hipMemcpyDeviceToHost));
+            static const bool serial_only = getenv("SDHIP_LRPT_SERIAL") && atoi(getenv("SDHIP_LRPT_SERIAL")) != 0;
+            bool chained = false;
+            if (!serial_only)
+            { // the chain along its grid, a round per slide (k_lrpt_spec / k_lrpt_walk)
+                ProfScope _ps("k_lrpt_spec + k_lrpt_walk", nullptr);
+                d_spec.reserve(max_frames);
+                d_state.reserve(2);
+                SD_HIP(hipMemsetAsync(d_state.p, 0, 2 * sizeof(int), nullptr));
+                long long origin = 0;
+                int st[2] = {0, 0};
+                for (int round = 0; round < 6; round++)
+                {
+                    const int npos = (int)(((long long)total - origin) / LRPT_ENC);
+                    if (npos <= 0)
+                    {
+                        st[1] = 1;
+                        consumed = origin;
+                        break;
+                    }
+                    hipLaunchKernelGGL(k_lrpt_spec, dim3((unsigned)npos), dim3(256), 0, nullptr, bits.p, (long long)total, origin, sync, d_spec.p, npos);
+                    hipLaunchKernelGGL(k_lrpt_walk, dim3(1), dim3(1), 0, nullptr, d_spec.p, npos, (long long)total, origin, d_desc.p, max_frames, d_state.p, d_consumed.p);
+                    SD_HIP(hipMemcpy(st, d_state.p, sizeof(st), hipMemcpyDeviceToHost));
+                    SD_HIP(hipMemcpy(&consumed, d_consumed.p, sizeof(long long), hipMemcpyDeviceToHost));
+                    origin = consumed;
+                    if (st[1])
+                        break;
+                }
+                nf = st[0];
+                chained = st[1] != 0;
+                stats_rounds++;
+            }
+            if (!chained)
+            { // a stream that keeps sliding (or SDHIP_LRPT_SERIAL=1): the serial walk over what is left, behind the frames found so far
+                ProfScope _ps("k_lrpt_chain", nullptr);
+                long long rest_consumed = 0;
+                int rest = 0;
+                const long long wofs = consumed / 32 * 32; // (the serial kernel addresses the bit array from a word boundary: it gets the sub-array and the byte offset inside its first word)
+                hipLaunchKernelGGL(k_lrpt_chain, dim3(1), dim3(1024), 0, nullptr, bits.p + wofs / 32, (long long)total - wofs, sync, d_desc.p + nf, max_frames - nf, d_cnt.p, d_consumed.p,
+                                   consumed - wofs, wofs);
+                SD_HIP(hipMemcpy(&rest, d_cnt.p, sizeof(int), hipMemcpyDeviceToHost));
+                SD_HIP(hipMemcpy(&rest_consumed, d_consumed.p, sizeof(long long), hipMemcpyDeviceToHost));
+                nf += rest;
+                consumed = wofs + rest_consumed;
+            }
             int64_t written = 0;
             if (nf > 0)
             {
