@@ -85,6 +85,7 @@ CASES = [
     dict(nframes=16, lead=10, gaps=((5 * 16384 + 7000, 1236), (11 * 16384, 16000))),
     dict(nframes=8, sigma=60.0),     # at the edge: RS decides frame by frame
     dict(nframes=3, noise_tail=6 * 16384 + 500),
+    dict(nframes=4, noise_tail=14 * 16384 + 777, lead=5000),  # more slides than speculation rounds: the serial chain takes over behind the frames found so far
 ]
 
 
