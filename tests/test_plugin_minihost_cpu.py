@@ -163,3 +163,13 @@ def test_flowgraph_registry_through_the_plugin_on_the_twin(host, tmp_path):
     if not pyref.NdspRef.available() or not os.path.exists(emu_build.CLANG):
         pytest.skip("needs the compiled reference ndsp blocks and a host clang++")
     G.check_flowgraph_registry_through_the_plugin(host, emu_build.build(), tmp_path)
+
+
+def test_decoder_hip_devices_through_the_plugin_on_the_twin(host, tmp_path):
+    """tests/test_plugin_minihost_gpu.py::test_decoder_hip_devices_through_the_plugin on the host twin (the chunks one after the other: the twin runs one kernel at
+    a time): the concatenated decoder's case; MetOp and FengYun-3 stay with the GPU suite."""
+    from tests import test_plugin_minihost_gpu as G
+    from tests.emu import build as emu_build
+    if not os.path.exists(emu_build.CLANG):
+        pytest.skip("no host clang++ to build the twin with")
+    G.check_decoder_hip_devices_through_the_plugin(host, emu_build.build(), tmp_path, cases=("goes",), devices=(0, 0), serial_chunks=True)
