@@ -106,7 +106,7 @@ def pmc_traffic(workload, kernel):
     import csv
     import glob
     from satdump_amd import build as sd_build
-    short = {"goes_hrit": "goes", "metop_ahrpt": "metop", "npp_hrd": "npp"}[workload]
+    short = {"goes_hrit": "goes", "metop_ahrpt": "metop", "npp_hrd": "npp"}.get(workload, workload)  # (the next-row benches pass their own tag: dvbs2, dvbs2fec, lrpt, fy3, ndsp)
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_{short}_pmc.csv")))
     if not files:
         return None, None
