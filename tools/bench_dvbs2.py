@@ -128,7 +128,7 @@ def run(args) -> dict:
                      "msg_bytes_per_frame": int(ldpc.info.msg_bytes_per_frame)},
            "kernels_ms": {k2: round(v[0] / args.steps, 3) for k2, v in prof.items()},
            "roofline": {"bound": "hbm", "kernel": "k_ldpc_trial", "achieved": round(algo / (ms_ldpc * 1e-3) / 1e9, 1) if ms_ldpc else None, "peak": 8000.0, "unit": "GB/s",
-                        "frac": round(algo / (ms_ldpc * 1e-3) / 1e9 / 8000.0, 4) if ms_ldpc else None, "traffic": None}}
+                        "frac": round(algo / (ms_ldpc * 1e-3) / 1e9 / 8000.0, 4) if ms_ldpc else None, "traffic": _pmc("k_ldpc_trial")[0], "traffic_source": _pmc("k_ldpc_trial")[1]}}
     if front and args.sync_frames > 0:
         # the two synchronisation stages in front of the demapper, timed on their own (the frame PLL is one serial lane: it would hide everything else
         # in the step above): PL synchroniser over the frames laid back to back, frame PLL over what it emits
@@ -175,6 +175,12 @@ def run(args) -> dict:
         if ref.batch == args.batch:
             out["parity_sample"] = {"frames": m, "soft_bits_identical": bool(np.array_equal(work[:m].cpu().numpy(), want)), "trials_identical": bool(np.array_equal(tr[:m // ref.batch], wt))}
     return out
+
+
+def _pmc(kernel):
+    """HBM bytes per launch of `kernel` from the PMC profile of THIS bench, when one was committed for these kernel sources (bench.pmc_traffic, tag dvbs2fec)"""
+    import bench as _b
+    return _b.pmc_traffic("dvbs2fec", kernel)
 
 
 def main():

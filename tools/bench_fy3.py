@@ -66,6 +66,11 @@ def run(args) -> dict:
            "config": {"workload": f"fengyun_ahrpt_decoder, {n // 16384} reads of 16384 soft bytes (two rails r=3/4 k=7, differential, 1024-byte CADUs, RS(255,223) x 4), sigma {args.sigma} on +-70"},
            "soft_MB_per_s": round(n / dt / 1e6, 1), "Msym_per_s": round(n / 2 / dt / 1e6, 1), "frames_out": int(k_last), "reads": int(st.blocks),
            "kernels_ms": dict(sorted(kern.items(), key=lambda kv: -kv[1])[:8]), "dtype": "u8"}
+    nbits = n * 3 // 4  # decoded bits of both rails (rate 3/4 on n soft bytes)
+    steps_b = {"k_vit2_acs": n + nbits / 8, "k_vit2_tb": nbits / 8, "k_vit2_prep": 2 * n, "k_fy_rails": 2 * n, "k_vit_search": n / 64, "k_sync_search": nbits / 8, "k_rs_screen": 2 * k_last * 1020,
+               "k_vit_ber": n / 8 + nbits / 8, "k_fy_diff": nbits / 4}
+    out["roofline"] = _roofline("fy3", kern, steps_b, "soft bytes in + decoded bits out of the dominant kernel")
+    out["whole_path"] = {"algorithmic_GB_per_s": round((n + k_last * 1024) / dt / 1e9, 2), "frac_of_hbm_peak": round((n + k_last * 1024) / dt / 1e9 / 8000.0, 5)}
     if args.cpu_frames > 0 and pyref.ref_available():
         m = args.cpu_frames * 8192 * 4 // 3 // 16384 * 16384
         s = d_soft[:m].cpu().numpy()
@@ -77,6 +82,25 @@ def run(args) -> dict:
                                "sample": f"the first {m // 16384} reads: the module's loop (rotate_soft, 2 x Viterbi3_4, FengyunDiff, BPSK_CCSDS_Deframer, derand_ccsds, ReedSolomon) on one thread"}
         out["parity_sample"] = {"frames_compared": int(len(want)), "byte_identical": bool(len(want) > 0 and np.array_equal(got, want))}
     return out
+
+
+
+def _roofline(tag, kern, algo_bytes, note):
+    """the dominant kernel of the line against the HBM roof (bench.py's object): algorithmic bytes of that kernel per step / its HIP-event time per step; traffic
+    from the PMC profile of this very bench when one was committed for these kernel sources (bench.pmc_traffic)"""
+    import os, sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench as _b
+    dom = max(kern, key=kern.get) if kern else None
+    if not dom or kern[dom] <= 0:
+        return None
+    key = next((k for k in algo_bytes if dom.startswith(k)), None)
+    if key is None:
+        return {"bound": "hbm", "kernel": dom, "achieved": None, "peak": 8000.0, "unit": "GB/s", "frac": None, "traffic": None, "note": "no byte model for this kernel: " + note}
+    ach = algo_bytes[key] / (kern[dom] * 1e-3) / 1e9
+    tr, src = _b.pmc_traffic(tag, dom)
+    return {"bound": "hbm", "kernel": dom, "achieved": round(ach, 2), "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 5), "traffic": tr, "traffic_source": src,
+            "algo_bytes_per_step": int(algo_bytes[key]), "ms_per_step": kern[dom], "note": note}
 
 
 def main():

@@ -68,6 +68,12 @@ def run(args) -> dict:
     out = {"metric": "frames_per_s", "value": round(ks[-1] / dt, 1), "unit": "CADU/s", "ms_per_step": round(dt * 1e3, 3), "steps": args.steps,
            "config": {"workload": f"meteor_lrpt_decoder, {nfr} frames of 16384 soft bytes (r=1/2 k=7 QPSK, 1024-byte CADUs, RS(255,223) x 4), sigma {args.sigma} on +-70"},
            "soft_MB_per_s": round(n / dt / 1e6, 1), "frames_out": int(ks[-1]), "kernels_ms": dict(sorted(kern.items(), key=lambda kv: -kv[1])[:8]), "dtype": "u8"}
+    # algorithmic bytes per step: the Viterbi stage reads the frames' soft bytes once and writes the decoded bits (the gather in front reads / writes them once more),
+    # the correlator reads the hard bits (n / 8), RS reads and writes the frames
+    steps_b = {"k_vit2_acs": n + nfr * 1024, "k_vit2_tb": nfr * 1024, "k_vit2_prep": 2 * n, "k_lrpt_gather": 2 * n, "k_lrpt_hard": n + n / 8, "k_lrpt_spec": n / 8, "k_lrpt_chain": n / 8,
+               "k_rs": 2 * nfr * 1020, "k_vit_ber": n / 8 + nfr * 1024}
+    out["roofline"] = _roofline("lrpt", kern, steps_b, "soft bytes in + decoded bytes out of the dominant kernel")
+    out["whole_path"] = {"algorithmic_GB_per_s": round((n + ks[-1] * 1024) / dt / 1e9, 2), "frac_of_hbm_peak": round((n + ks[-1] * 1024) / dt / 1e9 / 8000.0, 5)}
     if args.cpu_frames > 0 and pyref.ref_available():
         m = 1234 + args.cpu_frames * 16384
         s = d_soft[:m].cpu().numpy()
@@ -80,6 +86,25 @@ def run(args) -> dict:
                                "sample": f"the first {args.cpu_frames} frames: the module's loop (Correlator, rotate_soft, Viterbi27, derand_ccsds, ReedSolomon) on one thread"}
         out["parity_sample"] = {"frames_compared": int(k), "byte_identical": bool(np.array_equal(got[:k], want[:k]))}
     return out
+
+
+
+def _roofline(tag, kern, algo_bytes, note):
+    """the dominant kernel of the line against the HBM roof (bench.py's object): algorithmic bytes of that kernel per step / its HIP-event time per step; traffic
+    from the PMC profile of this very bench when one was committed for these kernel sources (bench.pmc_traffic)"""
+    import os, sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench as _b
+    dom = max(kern, key=kern.get) if kern else None
+    if not dom or kern[dom] <= 0:
+        return None
+    key = next((k for k in algo_bytes if dom.startswith(k)), None)
+    if key is None:
+        return {"bound": "hbm", "kernel": dom, "achieved": None, "peak": 8000.0, "unit": "GB/s", "frac": None, "traffic": None, "note": "no byte model for this kernel: " + note}
+    ach = algo_bytes[key] / (kern[dom] * 1e-3) / 1e9
+    tr, src = _b.pmc_traffic(tag, dom)
+    return {"bound": "hbm", "kernel": dom, "achieved": round(ach, 2), "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 5), "traffic": tr, "traffic_source": src,
+            "algo_bytes_per_step": int(algo_bytes[key]), "ms_per_step": kern[dom], "note": note}
 
 
 def main():
