@@ -829,7 +829,16 @@ namespace sdhip
             const int bad0 = count_bad();
             int best = bad0;
             double best_hint = m.freq_hint;
-            for (int j : {+1, -1, +2, -2})
+            // (round 5: out to +-8 branches, nearest first -- a recording with a carrier offset of a few 1e-4 rad / symbol, which the reference's loop takes a
+            // hundred frames to pull in, leaves the two-frame acquisition stretch with a hint several branches off; each try is one launch, once per stream)
+            const int reach = (int)env_long("SDHIP_S2PLL_BRANCHES", 8);
+            std::vector<int> order;
+            for (int a = 1; a <= reach; a++)
+            {
+                order.push_back(+a);
+                order.push_back(-a);
+            }
+            for (int j : order)
             {
                 launch_all(m.freq_hint + j * sp);
                 fetch();

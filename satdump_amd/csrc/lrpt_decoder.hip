@@ -221,32 +221,53 @@ namespace sdhip
             spec[k] = LrptSpec{2 * (8191 - (int)((all >> 3) & 8191u)), 7 - (int)(all & 7u), (int)(all >> 16)};
         }
     }
-    // one thread: the module's loop over the speculated answers (k_lrpt_chain's bookkeeping). state[0] = frames so far, state[1] = 1 when the stream is used up
-    // (or the slid frame is not complete yet), consumed = where the chain stands
-    __global__ void k_lrpt_walk(const LrptSpec *__restrict__ spec, int npos, long long n, long long origin, LrptDesc *descs, int max_frames, int *state, long long *consumed)
+    // One workgroup: the module's loop over the speculated answers (k_lrpt_chain's bookkeeping). A run of "offset 0" answers is a run of frames on the grid: the
+    // first answer that is not 0 is found by the whole workgroup, the descriptors in front of it are written in parallel, thread 0 takes the slide. state[0] =
+    // frames so far, state[1] = 1 when the stream is used up (or the slid frame is not complete yet), consumed = where the chain stands
+    __global__ __launch_bounds__(1024) void k_lrpt_walk(const LrptSpec *__restrict__ spec, int npos, long long n, long long origin, LrptDesc *descs, int max_frames, int *state,
+                                                         long long *consumed)
     {
-        int cnt = state[0];
-        long long o = origin;
-        int done = 1;
-        for (int k = 0; k < npos; k++)
+        __shared__ int s_first;
+        const int tid = (int)threadIdx.x;
+        const int cnt0 = state[0];
+        long long fit = (n - origin) / LRPT_ENC; // grid positions whose frame lies inside the stream
+        int limit = npos;
+        if (fit < (long long)limit)
+            limit = (int)(fit < 0 ? 0 : fit);
+        if (max_frames - cnt0 < limit)
+            limit = max_frames - cnt0 < 0 ? 0 : max_frames - cnt0;
+        if (tid == 0)
+            s_first = limit;
+        __syncthreads();
+        for (int k = tid; k < limit; k += 1024)
+            if (spec[k].pos != 0)
+                atomicMin(&s_first, k);
+        __syncthreads();
+        const int first = s_first;
+        for (int k = tid; k < first; k += 1024)
         {
-            if (!(o + LRPT_ENC <= n && cnt < max_frames))
-                break;
             const LrptSpec sp = spec[k];
-            if (sp.pos != 0 && o + sp.pos + LRPT_ENC > n)
-                break; // the slid frame is not complete yet: it stays for the next call
-            descs[cnt] = LrptDesc{o + sp.pos, sp.p % 4, (sp.p / 4) == 0 ? 1 : 0, sp.cor, sp.pos == 0 ? 1 : 0};
-            cnt++;
-            o += sp.pos + LRPT_ENC;
-            if (sp.pos != 0)
-            { // off the grid: the next round speculates from here
-                done = (o + LRPT_ENC <= n && cnt < max_frames) ? 0 : 1;
-                break;
-            }
+            descs[cnt0 + k] = LrptDesc{origin + (long long)k * LRPT_ENC, sp.p % 4, (sp.p / 4) == 0 ? 1 : 0, sp.cor, 1};
         }
-        state[0] = cnt;
-        state[1] = done;
-        *consumed = o;
+        if (tid == 0)
+        {
+            int cnt = cnt0 + first, done = 1;
+            long long o = origin + (long long)first * LRPT_ENC;
+            if (first < limit)
+            { // the first slide: the frame behind it, then off the grid -- the next round speculates from there
+                const LrptSpec sp = spec[first];
+                if (o + sp.pos + LRPT_ENC <= n)
+                {
+                    descs[cnt] = LrptDesc{o + sp.pos, sp.p % 4, (sp.p / 4) == 0 ? 1 : 0, sp.cor, 0};
+                    cnt++;
+                    o += sp.pos + LRPT_ENC;
+                    done = (o + LRPT_ENC <= n && cnt < max_frames) ? 0 : 1;
+                } // (else: the slid frame is not complete yet -- it stays for the next call)
+            }
+            state[0] = cnt;
+            state[1] = done;
+            *consumed = o;
+        }
     }
 
     // rotate_soft(buffer, 16384, phase, swap), rotation.cpp:4-58, out of place: thread per (I, Q) pair
@@ -456,7 +477,7 @@ namespace sdhip
                         break;
                     }
                     hipLaunchKernelGGL(k_lrpt_spec, dim3((unsigned)npos), dim3(256), 0, nullptr, bits.p, (long long)total, origin, sync, d_spec.p, npos);
-                    hipLaunchKernelGGL(k_lrpt_walk, dim3(1), dim3(1), 0, nullptr, d_spec.p, npos, (long long)total, origin, d_desc.p, max_frames, d_state.p, d_consumed.p);
+                    hipLaunchKernelGGL(k_lrpt_walk, dim3(1), dim3(1024), 0, nullptr, d_spec.p, npos, (long long)total, origin, d_desc.p, max_frames, d_state.p, d_consumed.p);
                     SD_HIP(hipMemcpy(st, d_state.p, sizeof(st), hipMemcpyDeviceToHost));
                     SD_HIP(hipMemcpy(&consumed, d_consumed.p, sizeof(long long), hipMemcpyDeviceToHost));
                     origin = consumed;

@@ -277,5 +277,13 @@ inline T atomicMax(T *p, T v)
         *p = v;
     return o;
 }
+template <class T>
+inline T atomicMin(T *p, T v)
+{
+    const T o = *p;
+    if (v < o)
+        *p = v;
+    return o;
+}
 using std::max;
 using std::min;
