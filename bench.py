@@ -343,6 +343,8 @@ def main():
         sys.path.insert(0, os.path.join(ROOT, "tools"))
         for key, mod, argv in (("ndsp_psk_demod", "bench_ndsp", ["--steps", "4", "--warmup", "1", "--cpu-samples", "12000000"]),
                                ("dvbs2_fec", "bench_dvbs2", ["--rate", "2/3", "--sigma", "13"]),
+                               # (the same decoder on frames that converge after a few update passes: the early exit timed)
+                               ("dvbs2_fec_converging", "bench_dvbs2", ["--rate", "2/3", "--front", "0", "--sigma", "10.5", "--sync-frames", "0"]),
                                ("dvbs2_demod_8psk", "bench_dvbs2_demod", []),
                                ("meteor_lrpt_decoder", "bench_lrpt", []),
                                ("fengyun_ahrpt_decoder", "bench_fy3", [])):

@@ -504,8 +504,14 @@ namespace sdhip
     // What this can promise is NOT symbols within 1e-5 of the serial loop's: the detector is a 256 x 256 table (piecewise-constant feedback), two
     // trajectories of the loop on the same symbols hover ~1e-2 (8PSK, 10 dB) ... 2e-4 (QPSK, 8 dB) of a symbol apart for good
     // (tools/s2_pll_frame_study.py) -- the contract is the decoders' output: the same BBFRAMEs.
-    __global__ __launch_bounds__(64) void k_s2_hdr_est(const float2 *__restrict__ in, int stride, int nframes, const float2 *__restrict__ hdr, double2 *__restrict__ z)
+    // z[f]: the header of frame f against the known one (the loop's phase at the header's centre). a[f] (may be null): the wiped header against itself 45 symbols
+    // on, sum_{i >= 45} w_i conj(w_{i-45}), w_i = received_i conj(known_i): its angle / 45 is the carrier's rate INSIDE the header -- unambiguous to +-pi / 45 per
+    // symbol, coarse per frame (sigma ~5e-3 rad / symbol at 10 dB), and over the frames of a long call good to a few 1e-5: what picks the 2 pi / per_frame branch of
+    // the header-to-header estimate when the loop's own frequency cannot (a new stream with a carrier offset the loop has not pulled in yet)
+    __global__ __launch_bounds__(64) void k_s2_hdr_est(const float2 *__restrict__ in, int stride, int nframes, const float2 *__restrict__ hdr, double2 *__restrict__ z,
+                                                       double2 *__restrict__ a)
     {
+        __shared__ float2 w[90];
         const int f = (int)blockIdx.x, t = (int)threadIdx.x;
         if (f >= nframes)
             return;
@@ -513,16 +519,32 @@ namespace sdhip
         for (int i = t; i < 90; i += 64)
         {
             const float2 v = in[(size_t)f * stride + i], k = hdr[i];
-            re += (double)v.x * k.x + (double)v.y * k.y; // received * conj(known)
+            const float wr = v.x * k.x + v.y * k.y, wi = v.y * k.x - v.x * k.y; // received * conj(known)
+            w[i] = make_float2(wr, wi);
+            re += (double)v.x * k.x + (double)v.y * k.y;
             im += (double)v.y * k.x - (double)v.x * k.y;
+        }
+        __syncthreads();
+        double ar = 0.0, ai = 0.0;
+        if (a && t < 45)
+        {
+            const float2 p = w[t + 45], q = w[t];
+            ar = (double)p.x * q.x + (double)p.y * q.y;
+            ai = (double)p.y * q.x - (double)p.x * q.y;
         }
         for (int o = 32; o > 0; o >>= 1)
         {
             re += __shfl_xor(re, o);
             im += __shfl_xor(im, o);
+            ar += __shfl_xor(ar, o);
+            ai += __shfl_xor(ai, o);
         }
         if (t == 0)
+        {
             z[f] = make_double2(re, im);
+            if (a)
+                a[f] = make_double2(ar, ai);
+        }
     }
     struct S2PllLane
     {
@@ -644,7 +666,7 @@ namespace sdhip
         DevBuf<float2> d_hdr;
         DevBuf<float> d_lut;
         DevBuf<S2PllState> d_state, d_start, d_end;
-        DevBuf<double2> d_z;
+        DevBuf<double2> d_z, d_a;
         DevBuf<S2PllLane> d_lanes;
         DevBuf<int> d_list;
         DevBuf<float> d_trace;
@@ -795,7 +817,8 @@ namespace sdhip
         SD_HIP(hipMemcpyAsync(m.d_state.p, &state, sizeof(state), hipMemcpyHostToDevice, st));
         {
             ProfScope _ps("k_s2_hdr_est", st);
-            hipLaunchKernelGGL(k_s2_hdr_est, dim3((unsigned)nf), dim3(64), 0, st, in, stride, nf, m.ctx.hdr, m.d_z.p);
+            m.d_a.reserve(nf);
+            hipLaunchKernelGGL(k_s2_hdr_est, dim3((unsigned)nf), dim3(64), 0, st, in, stride, nf, m.ctx.hdr, m.d_z.p, m.d_a.p);
         }
         m.h_start.resize(nl);
         m.h_end.resize(nl);
@@ -829,6 +852,31 @@ namespace sdhip
             const int bad0 = count_bad();
             int best = bad0;
             double best_hint = m.freq_hint;
+            double centre = m.freq_hint;
+            if (nf >= 128)
+            { // enough headers for the rate INSIDE them to name the branch (k_s2_hdr_est's second output): search around that instead of around the loop's word
+                std::vector<double> ha(2 * (size_t)nf);
+                SD_HIP(hipMemcpyAsync(ha.data(), m.d_a.p, ha.size() * sizeof(double), hipMemcpyDeviceToHost, st));
+                SD_HIP(hipStreamSynchronize(st));
+                double sr = 0.0, si = 0.0;
+                for (int f = 0; f < nf; f++)
+                {
+                    sr += ha[2 * (size_t)f];
+                    si += ha[2 * (size_t)f + 1];
+                }
+                centre = atan2(si, sr) / 45.0;
+                if (getenv("SDHIP_DEBUG"))
+                    fprintf(stderr, "[sdhip] s2 pll: rate inside %d headers %.3e rad/symbol (the loop's hint was %.3e)\n", nf, centre, m.freq_hint);
+                launch_all(centre);
+                fetch();
+                stats.branch_tries++;
+                const int nb = count_bad();
+                if (nb < best)
+                {
+                    best = nb;
+                    best_hint = centre;
+                }
+            }
             // (round 5: out to +-8 branches, nearest first -- a recording with a carrier offset of a few 1e-4 rad / symbol, which the reference's loop takes a
             // hundred frames to pull in, leaves the two-frame acquisition stretch with a hint several branches off; each try is one launch, once per stream)
             const int reach = (int)env_long("SDHIP_S2PLL_BRANCHES", 8);
@@ -840,14 +888,16 @@ namespace sdhip
             }
             for (int j : order)
             {
-                launch_all(m.freq_hint + j * sp);
+                if (best <= nl / 16)
+                    break;
+                launch_all(centre + j * sp);
                 fetch();
                 const int nb = count_bad();
                 stats.branch_tries++;
                 if (nb < best)
                 {
                     best = nb;
-                    best_hint = m.freq_hint + j * sp;
+                    best_hint = centre + j * sp;
                 }
                 if (nb <= nl / 16)
                     break;

@@ -258,8 +258,10 @@ namespace sdhip
                 if (sdhip_demod_get_stats(front, &ds) == 0 && ds.final_sps > 0)
                     st.freq_hz = (float)((current_freq / ds.final_sps) * ds.final_samplerate / (2.0 * M_PI));
             }
-            if (cfg.freq_prop_factor != 0.0f)
-            { // the hand-over (file header)
+            if (cfg.freq_prop_factor != 0.0f && pll->stats.forced * 16 <= pll->stats.lanes)
+            { // the hand-over (file header) -- of a loop that HOLDS the stream: while its chain does not certify (acquisition, a stretch of noise: lanes let
+              // through as `forced`) its frequency state is not the stream's, and a rotator fed with it runs away and takes the recording with it (measured,
+              // visit F of round 5: -45 kHz on a +2.9 kHz offset); the reference's rotator is fed by frames that left S2BBToSoft, i.e. by a locked chain too
                 const double g = 1.0 - pow(1.0 - (double)cfg.freq_prop_factor, (double)nf);
                 const double d = (double)pll->state.freq * g;
                 current_freq -= d;
