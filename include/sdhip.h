@@ -555,7 +555,7 @@ extern "C"
     void *sdhip_aos_demux_create(int device, int mpdu_data_size, int has_insert_zone, int insert_zone_size, int secondary_header_extends_pkt);
     void sdhip_aos_demux_destroy(void *h);
     /* nframes CADUs of ONE virtual channel (device), in order -> the packets Demuxer::work hands out for them, in order: packets_out (HOST table), their payload
-       bytes gathered into d_payload (DEVICE pool, packet k at payload_offset). Returns the packet count; *payload_bytes_out = pool bytes used. */
+       bytes gathered into d_payload (DEVICE pool, packet k at payload_offset). Returns the packet count; *payload_bytes_out = pool bytes used.    After a capacity error (packet table / payload pool too small) the handle must be destroyed and created anew: the state machine has consumed the call's frames. */
     int64_t sdhip_aos_demux_work_dev(void *h, const uint8_t *d_cadus, int cadu_bytes, int nframes, sdhip_aos_packet *packets_out, size_t cap_packets, uint8_t *d_payload,
                                      size_t cap_payload, uint64_t *payload_bytes_out);
 

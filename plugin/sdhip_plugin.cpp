@@ -392,6 +392,15 @@ namespace sdhip_plugin
                             void *e = sdhip_demod_create(&c);
                             if (!e)
                                 throw std::runtime_error(sdhip_last_error());
+                            struct Guard // (a worker that throws must not leak its handle: ADVICE r4)
+                            {
+                                void *&h;
+                                ~Guard()
+                                {
+                                    if (h)
+                                        sdhip_demod_destroy(h);
+                                }
+                            } guard{e};
                             std::ifstream in(d_input_file, std::ios::binary);
                             in.seekg((std::streamoff)(skip + plan[r].read_start * bps[fmt]));
                             uint64_t left = plan[r].stop - plan[r].read_start;
@@ -420,7 +429,7 @@ namespace sdhip_plugin
                                 if (sdhip_demod_push(e, raw.data(), got, fmt) < 0)
                                     throw std::runtime_error(sdhip_last_error());
                                 left -= got;
-                                progress = progress + (uint64_t)(got * bps[fmt] * (double)(plan[r].stop - plan[r].own_start) / (double)(plan[r].stop - plan[r].read_start));
+                                progress.fetch_add((uint64_t)(got * bps[fmt] * (double)(plan[r].stop - plan[r].own_start) / (double)(plan[r].stop - plan[r].read_start))); // (N threads)
                                 drain();
                             }
                             if (sdhip_demod_flush(e) < 0)
@@ -433,6 +442,7 @@ namespace sdhip_plugin
                                 display_freq = st.freq_hz;
                             }
                             sdhip_demod_destroy(e);
+                            e = nullptr;
                         }
                         catch (const std::exception &ex)
                         {
@@ -489,6 +499,8 @@ namespace sdhip_plugin
             }
             logger->info("Using input baseband " + d_input_file);
             logger->info("Demodulating to " + d_output_file_hint + ".soft (MI355X path)");
+            if (cfg.doppler && devices.size() > 1) // (checked in front of the sharded branch: every chunk would need its own targets -- ADVICE r4)
+                throw satdump_exception("psk_demod_hip: enable_doppler is on the HIP path for baseband files with a start_timestamp on one device (use psk_demod otherwise)");
             if (devices.size() > 1 && input_data_type == DATA_FILE)
             {
                 process_sharded();

@@ -152,6 +152,7 @@ namespace sdhip
         int device, size, zone_off, sec_ext;
         // Demuxer state
         bool working = false, in_header = false;
+        bool broken = false; // a capacity error left the state machine ahead of what the caller received: the handle refuses further work
         int remaining = 0, payload_len = 0, total_len = 0, in_header_n = 0;
         unsigned char header_buf[6] = {0, 0, 0, 0, 0, 0};
         unsigned char cur_hdr[6] = {0, 0, 0, 0, 0, 0};
@@ -408,6 +409,8 @@ extern "C"
     {
         SD_GUARD_BEGIN
         AosDemux &d = *(AosDemux *)h;
+        if (d.broken) // (a capacity error comes after the state machine has consumed the call's frames -- a retry would feed them into an advanced state)
+            throw HipError("aos demux: an earlier call ran out of output capacity in mid-stream; the handle's state is behind the frames it has seen -- create a new one");
         if (cadu_bytes < d.zone_off + 2 + d.size)
             throw HipError("aos demux: the CADU is shorter than its M_PDU zone");
         d.packets.clear();
@@ -446,10 +449,11 @@ extern "C"
             }
             d.frame((unsigned)f, s, zh);
         }
-        if (d.packets.size() > cap_packets)
-            throw HipError("aos demux: packet table too small");
-        if (d.pool_used > cap_payload)
-            throw HipError("aos demux: payload pool too small");
+        if (d.packets.size() > cap_packets || d.pool_used > cap_payload)
+        {
+            d.broken = true;
+            throw HipError(d.packets.size() > cap_packets ? "aos demux: packet table too small (the handle must be created anew)" : "aos demux: payload pool too small (the handle must be created anew)");
+        }
         if (!d.cmds.empty())
         {
             d.d_cmds.reserve(d.cmds.size());

@@ -9,6 +9,8 @@ namespace sdhip
 }
 #include "../../include/sdhip.h"
 #include "host_pipe.h"
+#include <atomic>
+#include <mutex>
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
@@ -561,6 +563,21 @@ namespace sdhip
         size_t out_read = 0;           // bytes of the front chunk already pulled
 
         sdhip_demod_stats stats{};
+        // what sdhip_demod_get_stats hands out while a call is in flight on another thread (the host path's worker): the snapshot the previous call left
+        std::mutex stats_mu;
+        sdhip_demod_stats stats_pub{};
+        std::atomic<bool> stats_busy{false};
+        struct StatsScope
+        {
+            DemodEngine &e;
+            explicit StatsScope(DemodEngine &en) : e(en) { e.stats_busy = true; }
+            ~StatsScope()
+            {
+                std::lock_guard<std::mutex> lk(e.stats_mu);
+                e.stats_pub = e.stats;
+                e.stats_busy = false;
+            }
+        };
 
         static int fmt_bytes(int fmt) { return (fmt == SDHIP_FMT_CF32 || fmt == SDHIP_FMT_CS32) ? 8 : (fmt == SDHIP_FMT_CS16 ? 4 : 2); }
 
@@ -1693,6 +1710,7 @@ namespace sdhip
 
         int64_t process(const void *d_in, size_t n_in, int fmt, int8_t *d_soft, size_t soft_cap, float *d_syms, size_t syms_cap)
         {
+            StatsScope _ss(*this);
             SD_HIP(hipSetDevice(cfg.device));
             // SDHIP_DEBUG: host wall-clock of every stage incl. its certificate round trips
             const bool tdbg = getenv("SDHIP_DEBUG") != nullptr;
@@ -2358,7 +2376,9 @@ extern "C"
     }
     int sdhip_demod_get_stats(void *h, sdhip_demod_stats *st)
     {
-        *st = ((DemodEngine *)h)->stats;
+        DemodEngine *e = (DemodEngine *)h;
+        std::lock_guard<std::mutex> lk(e->stats_mu);
+        *st = e->stats_busy.load() ? e->stats_pub : e->stats;
         return 0;
     }
     int sdhip_demod_set_tap(void *h, int mode)

@@ -22,6 +22,8 @@
 #include "dvbs2_stages.h"
 #include "host_pipe.h"
 
+#include <atomic>
+#include <mutex>
 #include <algorithm>
 #include <cmath>
 #include <cstring>
@@ -111,6 +113,20 @@ namespace sdhip
         std::vector<unsigned char> out_queue;
         size_t out_read = 0;
         sdhip_dvbs2_stats st{};
+        std::mutex st_mu; // sdhip_dvbs2_demod_get_stats against the host path's worker thread: the getter sees the snapshot the last call left
+        sdhip_dvbs2_stats st_pub{};
+        std::atomic<bool> st_busy{false};
+        struct StScope
+        {
+            Dvbs2Engine &e;
+            explicit StScope(Dvbs2Engine &en) : e(en) { e.st_busy = true; }
+            ~StScope()
+            {
+                std::lock_guard<std::mutex> lk(e.st_mu);
+                e.st_pub = e.st;
+                e.st_busy = false;
+            }
+        };
         float peak_snr = 0.0f;
         static constexpr size_t HOST_BATCH = (size_t)8u << 20; // samples per shipped batch (~190 normal 8PSK frames at two samples per symbol)
 
@@ -167,6 +183,7 @@ namespace sdhip
         // clock-recovered symbols (device) -> BBFRAMEs appended to d_bb; returns the frames completed
         size_t feed_symbols(const float2 *d_syms, size_t nsym)
         {
+            StScope _ss(*this);
             SD_HIP(hipSetDevice(device));
             if (nsym)
             {
@@ -476,7 +493,9 @@ extern "C"
     int sdhip_dvbs2_demod_get_stats(void *h, sdhip_dvbs2_stats *out)
     {
         SD_GUARD_BEGIN
-        *out = ((Dvbs2Engine *)h)->st;
+        Dvbs2Engine *e = (Dvbs2Engine *)h;
+        std::lock_guard<std::mutex> lk(e->st_mu);
+        *out = e->st_busy.load() ? e->st_pub : e->st;
         return 0;
         SD_GUARD_END(-1)
     }

@@ -2103,7 +2103,8 @@ namespace sdhip
     // d_soft + j * 2 * frame_bits signed soft symbols, d_out gets frame_bits / 8 bytes per frame. start_in0 = -2: the decoder's first call ever
     // (unbiased metrics), else the chained start state the previous call of this decoder returned (*ret_state). ber_err[j] = the numerator of
     // Viterbi27::ber() after frame j (x 4 / ber_test_size). Current device, default stream, synchronous.
-    void viterbi27_frames(int frame_bits, int ber_test_size, const int8_t *d_soft, int nframes, int start_in0, uint8_t *d_out, std::vector<int> *ber_err, int *ret_state)
+    void viterbi27_frames(int frame_bits, int ber_test_size, const int8_t *d_soft, int nframes, int start_in0, uint8_t *d_out, std::vector<int> *ber_err, int *ret_state,
+                          unsigned *enc_state)
     {
         if (frame_bits < 64 || frame_bits % 32 || ber_test_size < 2 || ber_test_size % 2 || ber_test_size > 2 * frame_bits)
             throw HipError("viterbi27: frame_bits must be a multiple of 32 and ber_test_size even, <= 2 * frame_bits");
@@ -2152,7 +2153,8 @@ namespace sdhip
             if (j > 0 && io[j].start_used != io[j - 1].ret_state)
                 redo(j, io[j - 1].ret_state);
         }
-        launch_vit_ber(vc, d_soft, 0, nframes, d_vb.p, 0u, d_io.p, nullptr);
+        // (the BER re-encoder's register carries over from call to call like CCEncoder::work's d_start_state does across Viterbi27::work calls: ADVICE r4)
+        launch_vit_ber(vc, d_soft, 0, nframes, d_vb.p, enc_state ? *enc_state : 0u, d_io.p, nullptr);
         const long long nbytes = (long long)nframes * (frame_bits / 8);
         hipLaunchKernelGGL(k_words_to_bytes, dim3((unsigned)((nbytes + 255) / 256)), dim3(256), 0, nullptr, d_vb.p, wpb, frame_bits / 8, nframes, d_out);
         SD_HIP(hipMemcpy(io.data(), d_io.p, io.size() * sizeof(VitBlockIO), hipMemcpyDeviceToHost));
@@ -2164,6 +2166,8 @@ namespace sdhip
         }
         if (ret_state)
             *ret_state = io[nframes - 1].ret_state;
+        if (enc_state)
+            *enc_state = (unsigned)io[nframes - 1].pad;
         SD_HIP(hipDeviceSynchronize());
     }
 } // namespace sdhip
@@ -2288,7 +2292,7 @@ extern "C"
             return 0;
         std::vector<int> err;
         int ret = -2;
-        sdhip::viterbi27_frames(frame_bits, ber_test_size, d_soft, nframes, -2, d_out, &err, &ret);
+        sdhip::viterbi27_frames(frame_bits, ber_test_size, d_soft, nframes, -2, d_out, &err, &ret, nullptr);
         if (ber_out)
             for (int j = 0; j < nframes; j++)
                 ber_out[j] = ((float)err[j] / (float)ber_test_size) * 4.0f;

@@ -381,6 +381,7 @@ namespace sdhip
         DevBuf<LrptSpec> d_spec;
         DevBuf<int> d_state;
         unsigned long long stats_rounds = 0;
+        unsigned vit_enc = 0; // Viterbi27's BER re-encoder register, carried across calls
         DevBuf<int8_t> d_frames;
         DevBuf<unsigned char> d_raw, d_post, d_pn, d_clean;
         DevBuf<int> d_err, d_dst;
@@ -513,7 +514,7 @@ namespace sdhip
                 hipLaunchKernelGGL(k_lrpt_gather, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, nullptr, base, d_desc.p, nf, d_frames.p);
                 std::vector<int> ber;
                 int ret = vit_start;
-                viterbi27_frames(LRPT_ENC / 2, 1024, d_frames.p, nf, vit_start, d_raw.p, &ber, &ret); // Viterbi27(ENCODED_FRAME_SIZE / 2, polys): ber_test_size 1024
+                viterbi27_frames(LRPT_ENC / 2, 1024, d_frames.p, nf, vit_start, d_raw.p, &ber, &ret, &vit_enc); // Viterbi27(ENCODED_FRAME_SIZE / 2, polys): ber_test_size 1024
                 vit_start = ret;
                 const long long nb = (long long)nf * LRPT_FRAME;
                 hipLaunchKernelGGL(k_lrpt_post, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, nullptr, d_raw.p, nf, cfg.diff_decode ? 1 : 0, nrzm_last, d_pn.p, d_post.p);
