@@ -465,6 +465,7 @@ namespace sdhip
         CostasParams cos_p{};
         MmParams mm_p{};
         int tap_mode = 0; // tests only: sdhip_demod_set_tap
+        double mm_windows_tight = 0.0, mm_windows_tol = 0.0; // the clock recovery's hand-off windows when a caller sets its own (demod_set_mm_windows); 0 = the defaults
 
         // power-of-two pre-decimator of SmartResampler (smart_resampler.cpp:15-29): chain of decimating FIRs, each with its
         // phase (`inc` of decimating_fir.cpp:60-86) and the last ntaps samples of its input carried across calls
@@ -1588,9 +1589,16 @@ namespace sdhip
             //    hundred symbols of a chunk of thousands): measured on MetOp, 14 of 65 k boundaries per step lie between 1e-3 and
             //    the re-run window; re-running them moves the 1e-5 fraction in the sixth digit and costs a second launch whose
             //    slowest lane runs alone for milliseconds.
-            const double MM_TOL_TIGHT = 2e-4;
+            // The DVB-S2 front end (nd.skip_costas: sdhip_dvbs2_front_create) has its own pair of windows. Its clock recovery runs at the module's gain 1.7e-3 on a
+            // roll-off of 0.2: two trajectories of THAT loop hover ~1e-2 sample apart for good (measured, visit G of round 5: 8 500 of 43 k boundaries outside 5e-3
+            // behind 44 k samples of warm-up, dt 5e-3 .. 1.5e-2 behind 75 k), so MetOp's windows drove its adaptive warm-up to the cap -- 75 520 samples in front of
+            // 2 048-sample chunks, 97 % of the lanes' work -- for nothing its consumers see: what is promised there is the decoders' output (the same BBFRAMEs, DESIGN
+            // 4b), and a symbol taken 2e-2 sample off is 46 dB below the symbol. Windows of 2.5 / 5 interpolator arms instead.
+            // (Set by the DVB-S2 demodulator MODULE's handle on its front end, demod_set_mm_windows: the front end as a unit -- sdhip_dvbs2_front_create -- keeps MetOp's.)
+            const bool s2_front = mm_windows_tight > 0.0 && !cfg.exact;
+            const double MM_TOL_TIGHT = s2_front ? mm_windows_tight : 2e-4;
             const double MM_TOL = getenv("SDHIP_MM_TOL_MICRO") ? env_int("SDHIP_MM_TOL_MICRO", 5000) * 1e-6
-                                                              : (getenv("SDHIP_MM_TOL_MILLI") ? env_int("SDHIP_MM_TOL_MILLI", 5) * 1e-3 : 5e-3);
+                                  : (getenv("SDHIP_MM_TOL_MILLI") ? env_int("SDHIP_MM_TOL_MILLI", 5) * 1e-3 : (s2_front ? mm_windows_tol : 5e-3));
             MmCkpt *ckp = nullptr;
             int ck_per_chunk = 0;
             auto mm_setup = [&](long long Wn) {
@@ -2186,6 +2194,18 @@ using namespace sdhip;
         sdhip::set_error(e.what()); \
         return ret;                 \
     }
+
+namespace sdhip
+{
+    // internal (csrc/dvbs2_engine.hip): the clock recovery's hand-off windows of one handle, in samples -- `tight` = what the adaptive warm-up is measured against,
+    // `tol` = beyond it a boundary is re-run from the exact state
+    void demod_set_mm_windows(void *h, double tight, double tol)
+    {
+        DemodEngine *e = (DemodEngine *)h;
+        e->mm_windows_tight = tight;
+        e->mm_windows_tol = tol;
+    }
+} // namespace sdhip
 
 extern "C"
 {

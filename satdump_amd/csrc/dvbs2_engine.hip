@@ -31,6 +31,10 @@
 
 namespace sdhip
 {
+    void demod_set_mm_windows(void *h, double tight, double tol); // demod_engine.hip
+}
+namespace sdhip
+{
     // symbols turned by exp(j (phase0 + w i)): the rotator in front of the PL synchroniser
     __global__ __launch_bounds__(256) void k_s2_rotate(float2 *x, long long n, double phase0, double w)
     {
@@ -151,6 +155,17 @@ namespace sdhip
             front = sdhip_dvbs2_front_create(&f);
             if (!front)
                 throw HipError(std::string("dvbs2 demod: front end: ") + sdhip_last_error());
+            // The clock recovery's hand-off windows, scaled to THIS loop: at the module's gain 1.7e-3 on a roll-off of 0.2 two trajectories of it hover ~1e-2 sample
+            // apart for good (measured, visit G of round 5: 8 500 of 43 k boundaries outside 5e-3 behind 44 k samples of warm-up, dt 5e-3 .. 1.5e-2 behind 75 k), so
+            // psk_demod's windows (2e-4 / 5e-3: its 1e-5 symbol contract) drove the adaptive warm-up to its cap -- 75 520 samples in front of 2 048-sample chunks, 97 %
+            // of the lanes' work -- for nothing this module's consumers see: what is promised here is the decoders' output, and a symbol taken 2e-2 sample
+            // off is 46 dB below the symbol. 2.5 / 5 interpolator arms instead (SDHIP_S2_MM_TIGHT_MILLI / _TOL_MILLI; 0 = psk_demod's).
+            {
+                const char *et = getenv("SDHIP_S2_MM_TIGHT_MILLI"), *eo = getenv("SDHIP_S2_MM_TOL_MILLI");
+                const double tight = (et ? atof(et) : 20.0) * 1e-3, tol = (eo ? atof(eo) : 40.0) * 1e-3;
+                if (!c.front.exact && tight > 0.0)
+                    demod_set_mm_windows(front, tight, std::max(tol, tight));
+            }
             sdhip_ldpc_cfg lc{c.shortframes ? 1 : 0, mc.rate, batch, device};
             ldpc = sdhip_ldpc_create(&lc);
             if (!ldpc)
