@@ -249,13 +249,23 @@ def arm_grid(wl, x_prefix, ref, gpu_syms, gpu_pos):
     other = ~same & ~flip
     amp = np.abs(np.abs(gpu_syms[:n]) - np.abs(rs)) / scale
     ang = np.abs(np.angle(gpu_syms[:n] * np.conj(rs)))
+    beyond = err > 1e-5
+    nb = max(1, int(beyond.sum()))
+    steps = np.abs(step[other]) if other.any() else np.zeros(0, dtype=np.int64)
+    hist = {str(k): int((steps == k).sum()) for k in (2, 3, 4)}
+    hist[">=5"] = int((steps >= 5).sum())
     return {"symbols": int(n), "restatement_symbols_bit_identical_to_the_reference": pinned,
             "same_arm": {"frac": round(float(same.mean()), 6), "beyond_1e-5": int((err[same] > 1e-5).sum()), "max_rel": float(err[same].max()),
                          "max_amplitude_rel": float(amp[same].max()), "max_angle_rad": float(ang[same].max())},
             "one_arm_step": {"frac": round(float(flip.mean()), 6), "max_rel": float(err[flip].max()) if flip.any() else 0.0},
-            "other": int(other.sum()),
-            "what": "every symbol beyond 1e-5 is either one step of the 128-arm interpolator grid from the reference's position (the timing loop's arm flicker) "
-                    "or, on the reference's own arm, a pure phase difference <= 1e-4 rad behind a carrier-loop chunk boundary (same amplitude to 1e-5)"}
+            "other": int(other.sum()), "other_steps_hist": hist,
+            "of_the_symbols_beyond_1e-5": {"count": int(beyond.sum()), "one_arm_step": round(float((beyond & flip).sum()) / nb, 4), "same_arm": round(float((beyond & same).sum()) / nb, 4),
+                                           "two_or_more_steps": round(float((beyond & other).sum()) / nb, 4)},
+            "what": "where on the clock recovery's 128-arm grid each symbol was interpolated, both sides: symbols beyond 1e-5 are (a) ONE grid step (1/128 sample) from the "
+                    "reference's position -- the arm flicker of two trajectories of the timing loop, the bulk --, (b) on the reference's own arm behind a chunk boundary at which "
+                    "the carrier loops' hand-off differed (a phase step that decays within the loop's time constant; the larger ones where an order-4 sign detector had just "
+                    "disagreed: DESIGN.md 2), (c) a few per million two or more steps off, behind such a boundary. tests/test_demod_gpu.py::"
+                    "test_every_symbol_beyond_tolerance_is_an_arm_flip asserts (a) and bounds (b) on streams of 60 - 140 chunks, where (c) does not occur"}
 
 
 def main():

@@ -533,6 +533,8 @@ namespace sdhip
         DevBuf<CostasState> d_cos_ck;
         const bool use_ckpt = env_int("SDHIP_CKPT", 1) != 0; // early exit of re-run lanes (checkpoints); SDHIP_CKPT=0: a re-run lane runs its whole chunk
         long long w_mm_learned = 0, w_cos_learned = 0; // warm-up lengths this stream has been found to need (see the stages)
+        long long w_mm_learned_own = 0;                // ... under a caller's own hand-off windows (demod_set_mm_windows)
+        unsigned long long mm_calls = 0;               // clock-recovery stage calls of this stream so far
         DevBuf<unsigned long long> d_ck_work;   // {lanes, pieces run, pieces of full chunks} x {agc, costas}, SDHIP_DEBUG only
         void ck_report(const char *stage, int slot)
         {
@@ -1573,9 +1575,15 @@ namespace sdhip
             // ~1e-4 sample of its trajectory. So the first guess (gear-shifted ~19/gain_mu symbols) is checked against the tight
             // hand-off window below, and if more than an eighth of the boundaries miss it the stage is launched again with twice
             // the warm-up (up to 64 loop constants 1/gain_mu); the stream keeps what it learned for its later calls.
+            // A caller's own hand-off windows (demod_set_mm_windows: the DVB-S2 module, see MM_TOL_TIGHT below) hold from the stream's SECOND call on: while the
+            // loops are still pulling the signal in (the first call of a stream) lanes are only comparable to the one sequential trajectory inside the default windows
+            // -- with the wide ones the module lost the two earliest frames the reference decodes (visit I of round 5). Each pair of windows learns its own warm-up.
+            const bool s2_front = mm_windows_tight > 0.0 && !cfg.exact && mm_calls > 0;
+            mm_calls++;
+            long long &w_learned = s2_front ? w_mm_learned_own : w_mm_learned;
             const long long w_mm_cap = (long long)(slow * 64.0 / gmu * final_sps);
             long long W = cfg.warmup > 0 ? cfg.warmup : (long long)std::min(w_full, std::max(w_gear, 0.5 * L));
-            W = std::max(W, w_mm_learned);
+            W = std::max(W, w_learned);
             W = env_int("SDHIP_W_MM", W);
             W = (W + 255) / 256 * 256;
             ChunkGeom g;
@@ -1595,7 +1603,6 @@ namespace sdhip
             // 2 048-sample chunks, 97 % of the lanes' work -- for nothing its consumers see: what is promised there is the decoders' output (the same BBFRAMEs, DESIGN
             // 4b), and a symbol taken 2e-2 sample off is 46 dB below the symbol. Windows of 2.5 / 5 interpolator arms instead.
             // (Set by the DVB-S2 demodulator MODULE's handle on its front end, demod_set_mm_windows: the front end as a unit -- sdhip_dvbs2_front_create -- keeps MetOp's.)
-            const bool s2_front = mm_windows_tight > 0.0 && !cfg.exact;
             const double MM_TOL_TIGHT = s2_front ? mm_windows_tight : 2e-4;
             const double MM_TOL = getenv("SDHIP_MM_TOL_MICRO") ? env_int("SDHIP_MM_TOL_MICRO", 5000) * 1e-6
                                   : (getenv("SDHIP_MM_TOL_MILLI") ? env_int("SDHIP_MM_TOL_MILLI", 5) * 1e-3 : (s2_front ? mm_windows_tol : 5e-3));
@@ -1672,10 +1679,10 @@ namespace sdhip
                     const long long wn = (std::min<long long>(2 * (long long)g.W, w_mm_cap) + 255) / 256 * 256;
                     if (cfg.warmup > 0 || getenv("SDHIP_W_MM") || wn <= (long long)g.W)
                         return false;
-                    w_mm_learned = wn;
+                    w_learned = wn;
                     if (getenv("SDHIP_DEBUG"))
-                        fprintf(stderr, "[sdhip] mm     %d of %d boundaries outside the hand-off window: warm-up %d -> %lld samples\n", nf, g.K, g.W, w_mm_learned);
-                    mm_setup(w_mm_learned);
+                        fprintf(stderr, "[sdhip] mm     %d of %d boundaries outside the hand-off window: warm-up %d -> %lld samples\n", nf, g.K, g.W, w_learned);
+                    mm_setup(w_learned);
                     launch_mm(A, symbuf.p, d_counts.p, g, mm_p, d_mm_start.p, d_mm_spec.p, d_mm_end.p, d_mm_spec_c.p, d_mm_end_c.p, nullptr, 0, stream, ckp,
                               ck_per_chunk, (float)MM_TOL);
                     return true;
