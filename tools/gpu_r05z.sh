@@ -32,6 +32,7 @@ ks lrpt python tools/bench_lrpt.py --steps 3 --cpu-frames 0
 ks fy3 python tools/bench_fy3.py --steps 3 --cpu-frames 0
 find $OUT -name "*kernel_trace.csv" -size +5M -delete
 find $OUT -name "*counter_collection.csv" -size +5M -delete
+echo "== smoke()"; timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -3 | tee $OUT/smoke.txt
 echo "== the whole GPU suite"
 SDHIP_FINAL=1 timeout 1100 python -m pytest tests/ -m gpu -q --durations=12 2>&1 | tail -40 | tee $OUT/pytest_gpu.txt
 echo "== the driver's command line"; timeout 1300 python bench.py > $OUT/bench.json 2> $OUT/bench.err || { echo "bench rc $?"; tail -20 $OUT/bench.err; }
