@@ -33,6 +33,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <dlfcn.h>
 #include <filesystem>
 #include <fstream>
 #include <thread>
@@ -76,7 +77,7 @@ namespace sdhip_plugin
             return SDHIP_FMT_CU8;
         if (baseband_format == "cs32" || baseband_format == "s32")
             return SDHIP_FMT_CS32;
-        throw satdump_exception(std::string(who) + ": baseband_format " + baseband_format + " is not on the HIP path (cf32, cs32, cs16, cs8, cu8)");
+        throw satdump_exception(std::string(who) + ": baseband_format " + baseband_format + " is not on the HIP path (cf32, cs32, cs16, cs8, cu8, wav, ziq)");
     }
     // The reference's BasebandReader (common/dsp/io/baseband_interface.h:80-81, 143-146) looks at the first four bytes of EVERY baseband file, whatever
     // baseband_format says: "RIFF" -> the samples start behind a wav::WavHeader (44 bytes), "RF64" -> behind a wav::RF64Header (80 bytes); common/wav.cpp:40-48
@@ -94,6 +95,155 @@ namespace sdhip_plugin
             return 80;
         return 0;
     }
+    // ZIQ recordings (src-core/common/ziq.{h,cpp}; baseband_format "ziq", BasebandReader's ZIQ branch baseband_interface.h:133-136, 201-204): "ZIQ_", one byte
+    // is_compressed, one byte bits_per_sample (8 / 16 / 32), the samplerate (8 bytes), the annotation's length (8 bytes) and the annotation (ziq.cpp:12-20, 116-126);
+    // behind them int8 / int16 / float I,Q pairs scaled exactly like cs8 / cs16 / cf32 (1/127, 1/32767, raw: ziq.cpp:263-305) -- as they are, or as ONE zstd stream
+    // the writer never closes (ZSTD_e_continue only, ziq.cpp:52-63). The samples go to the device in the file's own format; only the zstd stream is undone here, by
+    // the system's libzstd.so.1 (the reference links the same library when it is built with BUILD_ZIQ), bound at run time so that the plugin builds without its headers.
+    struct ZiqHeader
+    {
+        bool valid = false, compressed = false;
+        int bits = 0;
+        uint64_t samplerate = 0, data_start = 0;
+    };
+    static ZiqHeader ziq_header_of(const std::string &path)
+    {
+        ZiqHeader z;
+        std::ifstream f(path, std::ios::binary);
+        char sig[4] = {0, 0, 0, 0}, comp = 0, bits = 0;
+        uint64_t sr = 0, alen = 0;
+        f.read(sig, 4), f.read(&comp, 1), f.read(&bits, 1), f.read((char *)&sr, 8), f.read((char *)&alen, 8);
+        if (!f || std::memcmp(sig, "ZIQ_", 4) != 0)
+            return z;
+        z.valid = true, z.compressed = comp != 0, z.bits = bits, z.samplerate = sr, z.data_start = 22 + alen;
+        return z;
+    }
+    static int ziq_fmt_of(const ZiqHeader &z, const char *who)
+    {
+        if (!z.valid)
+            throw satdump_exception(std::string(who) + ": baseband_format ziq, but the input is not a ZIQ file");
+        if (z.bits == 8)
+            return SDHIP_FMT_CS8;
+        if (z.bits == 16)
+            return SDHIP_FMT_CS16;
+        if (z.bits == 32)
+            return SDHIP_FMT_CF32;
+        throw satdump_exception(std::string(who) + ": ZIQ file with " + std::to_string(z.bits) + " bits per sample");
+    }
+    // the four entry points of zstd's streaming decompression (zstd.h: ZSTD_createDCtx, ZSTD_freeDCtx, ZSTD_decompressStream, ZSTD_isError; the two buffer structs
+    // are {pointer, size, pos} -- part of the library's stable ABI)
+    // where the samples of `path` start: behind the ZIQ header when the format says ZIQ, behind a wav / RF64 header otherwise
+    static uint64_t baseband_data_start(const std::string &path, const std::string &baseband_format)
+    {
+        return baseband_format == "ziq" ? ziq_header_of(path).data_start : container_header_bytes(path);
+    }
+    struct ZstdApi
+    {
+        struct In
+        {
+            const void *src;
+            size_t size, pos;
+        };
+        struct Out
+        {
+            void *dst;
+            size_t size, pos;
+        };
+        void *(*createDCtx)() = nullptr;
+        size_t (*freeDCtx)(void *) = nullptr;
+        size_t (*decompressStream)(void *, Out *, In *) = nullptr;
+        unsigned (*isError)(size_t) = nullptr;
+        static const ZstdApi &get()
+        {
+            static ZstdApi api = [] {
+                ZstdApi a;
+                void *lib = dlopen("libzstd.so.1", RTLD_NOW | RTLD_GLOBAL);
+                if (!lib)
+                    lib = dlopen("libzstd.so", RTLD_NOW | RTLD_GLOBAL);
+                if (lib)
+                {
+                    a.createDCtx = (void *(*)())dlsym(lib, "ZSTD_createDCtx");
+                    a.freeDCtx = (size_t(*)(void *))dlsym(lib, "ZSTD_freeDCtx");
+                    a.decompressStream = (size_t(*)(void *, Out *, In *))dlsym(lib, "ZSTD_decompressStream");
+                    a.isError = (unsigned (*)(size_t))dlsym(lib, "ZSTD_isError");
+                }
+                return a;
+            }();
+            return api;
+        }
+        bool ok() const { return createDCtx && freeDCtx && decompressStream && isError; }
+    };
+    // A baseband recording as the demodulator modules read it: the container's header skipped (wav / RF64 for every format, ZIQ when the format says so), the
+    // payload handed out in the C ABI's sample formats. read() fills `dst` unless the recording ends.
+    class BasebandFile
+    {
+        std::ifstream in;
+        void *dctx = nullptr;
+        std::vector<char> cbuf;
+        size_t cpos = 0, clen = 0;
+        bool zerr = false;
+
+    public:
+        int fmt;
+        bool compressed = false;
+        uint64_t filesize = 0, data_start = 0;
+        BasebandFile(const std::string &path, const std::string &baseband_format, int declared_fmt, const char *who) : in(path, std::ios::binary), fmt(declared_fmt)
+        {
+            in.seekg(0, std::ios::end);
+            filesize = (uint64_t)in.tellg();
+            if (baseband_format == "ziq")
+            {
+                const ZiqHeader z = ziq_header_of(path);
+                fmt = ziq_fmt_of(z, who);
+                data_start = std::min<uint64_t>(z.data_start, filesize);
+                compressed = z.compressed;
+                if (compressed)
+                {
+                    if (!ZstdApi::get().ok())
+                        throw satdump_exception(std::string(who) + ": compressed ZIQ needs libzstd.so.1, which this system does not have");
+                    dctx = ZstdApi::get().createDCtx();
+                    cbuf.resize(1 << 20);
+                }
+            }
+            else
+                data_start = std::min<uint64_t>(container_header_bytes(path), filesize);
+            in.seekg((std::streamoff)data_start, std::ios::beg);
+        }
+        ~BasebandFile()
+        {
+            if (dctx)
+                ZstdApi::get().freeDCtx(dctx);
+        }
+        BasebandFile(const BasebandFile &) = delete;
+        BasebandFile &operator=(const BasebandFile &) = delete;
+        // bytes of the FILE consumed so far (the modules' progress figure)
+        uint64_t consumed() { return in ? (uint64_t)in.tellg() - (clen - cpos) : filesize; }
+        size_t read(char *dst, size_t bytes)
+        {
+            if (!compressed)
+            {
+                in.read(dst, (std::streamsize)bytes);
+                return (size_t)in.gcount();
+            }
+            ZstdApi::Out out{dst, bytes, 0};
+            while (out.pos < out.size && !zerr)
+            {
+                if (cpos == clen)
+                {
+                    in.read(cbuf.data(), (std::streamsize)cbuf.size());
+                    clen = (size_t)in.gcount(), cpos = 0;
+                    if (clen == 0)
+                        break; // the writer leaves its stream open (no epilogue): the recording ends where the file does
+                }
+                ZstdApi::In inb{cbuf.data(), clen, cpos};
+                const size_t rc = ZstdApi::get().decompressStream(dctx, &out, &inb);
+                cpos = inb.pos;
+                if (ZstdApi::get().isError(rc))
+                    zerr = true; // a damaged stream ends the recording (the reference resets its context and goes on with whatever follows: ziq.cpp:221-225)
+            }
+            return out.pos;
+        }
+    };
     // BaseDemodModule's constructor (module_demod_base.cpp:12-57) into the C ABI's struct
     static void parse_base_demod(const nlohmann::json &parameters, sdhip_demod_cfg &cfg, const char *who)
     {
@@ -233,7 +383,7 @@ namespace sdhip_plugin
             opt(parameters, "hip_exact", cfg.exact);
             if (parameters.count("hip_devices") > 0) // e.g. [0, 1, 2, 3, 4, 5, 6, 7]: one recording over the GPUs of a node
                 devices = parameters["hip_devices"].get<std::vector<int>>();
-            fmt = baseband_fmt_of(baseband_format, "psk_demod_hip");
+            fmt = baseband_format == "ziq" ? SDHIP_FMT_CF32 /* the file's header says which (process()) */ : baseband_fmt_of(baseband_format, "psk_demod_hip");
             bool dop = false;
             opt(parameters, "enable_doppler", dop);
             if (dop)
@@ -265,7 +415,7 @@ namespace sdhip_plugin
                 sdhip_demod_destroy(h);
         }
         // Can the HIP path run this parameter set? (The override keeps the CPU module for what it does not cover:
-        // ziq / ziq2 containers -- they need the reference's zstd reader --; wav / RF64 headers are skipped as BasebandReader skips them.)
+        // ziq2 packet streams; wav / RF64 headers are skipped as BasebandReader skips them, ZIQ recordings are read by BasebandFile above.)
         static bool covers(const std::string &input_file, const std::string &output_file_hint, const nlohmann::json &parameters, std::string &why)
         {
             if (parameters.count("enable_doppler") > 0 && parameters["enable_doppler"].get<bool>() && parameters.count("start_timestamp") == 0)
@@ -277,6 +427,8 @@ namespace sdhip_plugin
             try
             {
                 PSKDemodHipModule probe(input_file, output_file_hint, parameters);
+                if (probe.baseband_format == "ziq" && std::filesystem::exists(input_file))
+                    BasebandFile probe_file(input_file, probe.baseband_format, probe.fmt, "psk_demod_hip"); // not a ZIQ file / compressed without a libzstd: throws
                 void *e = sdhip_demod_create(&probe.cfg);
                 if (!e)
                 {
@@ -360,7 +512,7 @@ namespace sdhip_plugin
             const int N = (int)devices.size(), q = cfg.constellation == SDHIP_BPSK ? 1 : 2;
             std::ifstream probe(d_input_file, std::ios::binary | std::ios::ate);
             filesize = (uint64_t)probe.tellg();
-            const uint64_t skip = std::min<uint64_t>(container_header_bytes(d_input_file), filesize); // wav / RF64 header in front of the samples
+            const uint64_t skip = std::min<uint64_t>(baseband_data_start(d_input_file, baseband_format), filesize); // wav / RF64 / ZIQ header in front of the samples
             const uint64_t n_samples = (filesize - skip) / bps[fmt];
             // overlap: the demodulator's lock-in plus the window the alignment looks at
             sdhip_fec_cfg fdummy;
@@ -501,7 +653,17 @@ namespace sdhip_plugin
             logger->info("Demodulating to " + d_output_file_hint + ".soft (MI355X path)");
             if (cfg.doppler && devices.size() > 1) // (checked in front of the sharded branch: every chunk would need its own targets -- ADVICE r4)
                 throw satdump_exception("psk_demod_hip: enable_doppler is on the HIP path for baseband files with a start_timestamp on one device (use psk_demod otherwise)");
-            if (devices.size() > 1 && input_data_type == DATA_FILE)
+            bool ziq_compressed = false;
+            if (baseband_format == "ziq" && input_data_type == DATA_FILE)
+            { // the sample format is the file's own (ziq.cpp:116-126)
+                const ZiqHeader z = ziq_header_of(d_input_file);
+                fmt = ziq_fmt_of(z, "psk_demod_hip");
+                ziq_compressed = z.compressed;
+                logger->info("ZIQ recording: %d bits per sample, %s, recorded at %llu S/s", z.bits, z.compressed ? "zstd stream" : "not compressed", (unsigned long long)z.samplerate);
+                if (ziq_compressed && devices.size() > 1)
+                    logger->warn("psk_demod_hip: a compressed ZIQ recording cannot be cut in time -- hip_devices ignored, running on device %d", cfg.device);
+            }
+            if (devices.size() > 1 && input_data_type == DATA_FILE && !ziq_compressed)
             {
                 process_sharded();
                 if (output_data_type == DATA_FILE)
@@ -511,15 +673,13 @@ namespace sdhip_plugin
             }
             std::vector<int8_t> out(1 << 24);
             static const int bps[5] = {8, 4, 2, 2, 8}; // bytes per complex sample, indexed by SDHIP_FMT_* (cf32, cs16, cs8, cu8, cs32)
-            if (cfg.doppler && (input_data_type != DATA_FILE || dop_start_time == -1 || devices.size() > 1))
-                throw satdump_exception("psk_demod_hip: enable_doppler is on the HIP path for baseband files with a start_timestamp on one device (use psk_demod otherwise)");
+            if (cfg.doppler && (input_data_type != DATA_FILE || dop_start_time == -1 || devices.size() > 1 || ziq_compressed))
+                throw satdump_exception("psk_demod_hip: enable_doppler is on the HIP path for baseband files (not zstd streams) with a start_timestamp on one device (use psk_demod otherwise)");
             if (input_data_type == DATA_FILE)
             {
-                std::ifstream in(d_input_file, std::ios::binary);
-                in.seekg(0, std::ios::end);
-                filesize = (uint64_t)in.tellg();
-                const uint64_t skip = std::min<uint64_t>(container_header_bytes(d_input_file), filesize); // wav / RF64 header in front of the samples
-                in.seekg((std::streamoff)skip, std::ios::beg);
+                BasebandFile in(d_input_file, baseband_format, fmt, "psk_demod_hip"); // wav / RF64 / ZIQ header skipped, a ZIQ zstd stream undone
+                filesize = in.filesize;
+                const uint64_t skip = in.data_start;
                 progress = skip;
                 if (cfg.doppler)
                 {
@@ -533,15 +693,14 @@ namespace sdhip_plugin
                 }
                 const size_t samples_per_read = 1 << 22;
                 std::vector<char> raw(samples_per_read * bps[fmt]);
-                while (!should_stop && in)
+                while (!should_stop)
                 {
-                    in.read(raw.data(), raw.size());
-                    const size_t got = (size_t)in.gcount() / bps[fmt];
+                    const size_t got = in.read(raw.data(), raw.size()) / bps[fmt];
                     if (got == 0)
                         break;
                     if (sdhip_demod_push(h, raw.data(), got, fmt) < 0)
                         throw satdump_exception(std::string("psk_demod_hip: ") + sdhip_last_error());
-                    progress = progress + got * bps[fmt];
+                    progress = in.consumed();
                     drain(out);
                 }
             }
@@ -1366,7 +1525,7 @@ namespace sdhip_plugin
             opt(parameters, "ldpc_trials", cfg.ldpc_trials);
             // "mt_bch" moves the BCH decoder to a thread of its own in the reference (module_dvbs2_demod.cpp:66-67, 295-325): same output, nothing to do here
             opt(parameters, "baseband_format", baseband_format);
-            fmt = baseband_fmt_of(baseband_format, "dvbs2_demod_hip");
+            fmt = baseband_format == "ziq" ? SDHIP_FMT_CF32 /* the file's header says which (process()) */ : baseband_fmt_of(baseband_format, "dvbs2_demod_hip");
             // engine knobs of the HIP path (no reference equivalent). hip_ldpc_batch = dvbs2::simd_type::SIZE of the build being replaced (frames per
             // BBFrameLDPC::decode call sharing one early exit; the x86-64 build of plugins/dvb_support has SSE4.1: 16): frames wait for a full group
             // and a trailing partial group is never decoded, exactly as in process_s2
@@ -1455,23 +1614,20 @@ namespace sdhip_plugin
             static const int bps[5] = {8, 4, 2, 2, 8};
             if (input_data_type == DATA_FILE)
             {
-                std::ifstream in(d_input_file, std::ios::binary);
-                in.seekg(0, std::ios::end);
-                filesize = (uint64_t)in.tellg();
-                const uint64_t skip = std::min<uint64_t>(container_header_bytes(d_input_file), filesize); // wav / RF64 header in front of the samples
-                in.seekg((std::streamoff)skip, std::ios::beg);
-                progress = skip;
+                BasebandFile in(d_input_file, baseband_format, fmt, "dvbs2_demod_hip"); // wav / RF64 / ZIQ header skipped, a ZIQ zstd stream undone
+                fmt = in.fmt;
+                filesize = in.filesize;
+                progress = in.data_start;
                 const size_t samples_per_read = 1 << 22;
                 std::vector<char> raw(samples_per_read * bps[fmt]);
-                while (!should_stop && in)
+                while (!should_stop)
                 {
-                    in.read(raw.data(), raw.size());
-                    const size_t got = (size_t)in.gcount() / bps[fmt];
+                    const size_t got = in.read(raw.data(), raw.size()) / bps[fmt];
                     if (got == 0)
                         break;
                     if (sdhip_dvbs2_demod_push(h, raw.data(), got, fmt) < 0)
                         throw satdump_exception(std::string("dvbs2_demod_hip: ") + sdhip_last_error());
-                    progress = progress + got * bps[fmt];
+                    progress = in.consumed();
                     drain(out);
                 }
             }

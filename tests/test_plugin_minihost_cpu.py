@@ -173,3 +173,14 @@ def test_decoder_hip_devices_through_the_plugin_on_the_twin(host, tmp_path):
     if not os.path.exists(emu_build.CLANG):
         pytest.skip("no host clang++ to build the twin with")
     G.check_decoder_hip_devices_through_the_plugin(host, emu_build.build(), tmp_path, cases=("goes",), devices=(0, 0), serial_chunks=True)
+
+
+def test_ziq_container_through_the_plugin_on_the_twin(host, tmp_path):
+    """tests/test_plugin_minihost_gpu.py::test_ziq_container_through_the_plugin with the host twin as the C-ABI library: the ZIQ header, the zstd stream undone
+    through the system's libzstd and the chunk plan behind the header run in the CPU suite."""
+    from tests import test_plugin_minihost_gpu as G
+    from tests.emu import build as emu_build
+    if not os.path.exists(emu_build.CLANG):
+        pytest.skip("needs a host clang++")
+    G.check_ziq_container_through_the_plugin(host, emu_build.build(), tmp_path, nframes=10, serial_chunks=True,
+                                             only=("bare16", "ziq16z", "bare8", "ziq8z", "bare16+devices", "ziq16+devices", "ziq16z+devices"))

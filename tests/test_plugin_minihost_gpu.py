@@ -385,6 +385,15 @@ def check_dvbs2_module_through_the_plugin(host, lib, tmp_path, modcod=12, short=
         assert p.returncode == 0, p.stdout[-1000:] + p.stderr[-3000:]
         got16 = np.fromfile(json.loads(p.stdout.strip().splitlines()[-1])["soft"], dtype=np.uint8).reshape(-1, kb)
         assert sum(bytes(r) in sent for r in got16) >= len(gfound) - 1
+        # the same cs16 samples as a compressed ZIQ recording (baseband_format "ziq": the header names the width, the zstd stream is undone by the plugin): same file out
+        import pyarrow as pa
+        (tmp_path / "dvbs2.ziq").write_bytes(ziq_header(True, 16, samplerate=int(params["samplerate"])) + pa.compress(cs.tobytes(), codec="zstd", asbytes=True))
+        job = {"mode": "file", "input": str(tmp_path / "dvbs2.ziq"), "output_hint": str(tmp_path / "zq"), "demod": {"module": "dvbs2_demod", "parameters": dict(params, baseband_format="ziq")}}
+        (tmp_path / "zq.json").write_text(json.dumps(job))
+        p = subprocess.run([host, lib, PLUGIN, "run", str(tmp_path / "zq.json")], capture_output=True, text=True, env=dict(os.environ, SDHIP_OVERRIDE="1", SDHIP_S2PLL_ACQ=str(acq)), timeout=900)
+        assert p.returncode == 0, p.stdout[-1000:] + p.stderr[-3000:]
+        gotz = np.fromfile(json.loads(p.stdout.strip().splitlines()[-1])["soft"], dtype=np.uint8).reshape(-1, kb)
+        assert np.array_equal(gotz, got16)
         # the groups of the reference's SSE4.1 build (16 frames per decode call): a trailing partial group is never written, as in process_s2
         p, rep = run({"hip_ldpc_batch": 16}, "b16")
         assert p.returncode == 0 and os.path.getsize(rep["soft"]) == (len(got) // 16) * 16 * kb
@@ -546,6 +555,81 @@ def check_wav_container_through_the_plugin(host, lib, tmp_path, nframes=16, shar
 
 def test_wav_container_through_the_plugin(host, tmp_path):
     check_wav_container_through_the_plugin(host, LIB, tmp_path, nframes=30)
+
+
+def ziq_header(compressed, bits, samplerate=3000000, annotation=b'{"frequency": 1694100000}'):
+    """the header ziq::ziq_writer's constructor writes (src-core/common/ziq.cpp:12-20)"""
+    import struct
+    return b"ZIQ_" + struct.pack("<BBQQ", 1 if compressed else 0, bits, samplerate, len(annotation)) + annotation
+
+
+def check_ziq_container_through_the_plugin(host, lib, tmp_path, nframes=16, sharded=True, serial_chunks=False, only=None):
+    """ZIQ recordings (src-core/common/ziq.{h,cpp}; `baseband_format: "ziq"`, BasebandReader's ZIQ branch common/dsp/io/baseband_interface.h:133-136, 201-204)
+    through the stock id `psk_demod` under the override: the header names the sample width (8 / 16 / 32 bits, scaled as cs8 / cs16 / cf32: ziq.cpp:263-305) and
+    whether the samples behind it are one zstd stream. The .soft file of each must be the .soft file of the bare samples in the matching raw format, byte for
+    byte -- not compressed, compressed (the plugin undoes the stream with the system's libzstd, bound at run time), cut over `hip_devices` (not compressed: the plan
+    counts samples behind the header; compressed: no seeking, one device). A stream that stops short -- the reference's writer never closes its zstd frame
+    (ZSTD_e_continue only, ziq.cpp:52-63) -- ends the recording where the file does."""
+    import pyarrow as pa
+    spec, cadus, plain, syms = util.goes_case(nframes=nframes)
+    x, _ = synth.modulate(syms, spec)
+    q16 = synth.to_cs16(x).tobytes()
+    q8 = np.clip(np.rint(x.view(np.float32) * 127.0), -127, 127).astype(np.int8).tobytes()
+    f32 = x.tobytes()
+    z = lambda b: pa.compress(b, codec="zstd", asbytes=True)
+    files = {"bare16": (b"", q16, "cs16"), "ziq16": (ziq_header(False, 16), q16, "ziq"), "ziq16z": (ziq_header(True, 16), z(q16), "ziq"),
+             "bare8": (b"", q8, "cs8"), "ziq8z": (ziq_header(True, 8, annotation=b""), z(q8), "ziq"),
+             "bare32": (b"", f32, "cf32"), "ziq32": (ziq_header(False, 32), f32, "ziq"), "ziq32z": (ziq_header(True, 32), z(f32), "ziq"),
+             "ziq16cut": (ziq_header(True, 16), z(q16)[:-4096], "ziq")}
+    runs = [(k, {}) for k in files]
+    if sharded:
+        runs += [("bare16", {"hip_devices": [0, 0]}), ("ziq16", {"hip_devices": [0, 0]}), ("ziq16z", {"hip_devices": [0, 0]})]
+    if only is not None:  # (the CPU suite's subset)
+        runs = [r for r in runs if r[0] + ("+devices" if r[1] else "") in only]
+    soft = {}
+    for name, extra in runs:
+        hdr, body, fmt = files[name]
+        inp = tmp_path / (name + ".bin")
+        inp.write_bytes(hdr + body)
+        key = name + ("+devices" if extra else "")
+        job = {"mode": "file", "input": str(inp), "output_hint": str(tmp_path / key), "demod": {"module": "psk_demod", "parameters": dict(GOES_DEMOD, baseband_format=fmt, **extra)}}
+        jp = tmp_path / (key + ".json")
+        jp.write_text(json.dumps(job))
+        p = subprocess.run([host, lib, PLUGIN, "run", str(jp)], capture_output=True, text=True,
+                           env=dict(os.environ, SDHIP_OVERRIDE="1", SDHIP_PLUGIN_SERIAL_CHUNKS="1" if serial_chunks else "0"), timeout=900)
+        assert p.returncode == 0, p.stdout[-1000:] + p.stderr[-3000:]
+        rep = json.loads(p.stdout.strip().splitlines()[-1])
+        assert rep["demod_class"] == "psk_demod_hip", rep
+        soft[key] = np.fromfile(rep["soft"], dtype=np.int8)
+    assert len(soft["bare16"]) > nframes * 8192 * 2 * 0.95  # r = 1/2 BPSK: 16 384 soft symbols per CADU
+    for k, ref in (("ziq16", "bare16"), ("ziq16z", "bare16"), ("ziq8z", "bare8"), ("ziq32", "bare32"), ("ziq32z", "bare32")):
+        if k in soft:
+            assert np.array_equal(soft[k], soft[ref]), (k, len(soft[k]), len(soft[ref]))
+    # the open-ended stream: whatever zstd blocks are whole come out -- most of the recording, the same symbols where both have them (another batch length
+    # is another chunk geometry: the float symbols agree to the engine's tolerance, an int8 may sit on the other side of a rounding step)
+    if "ziq16cut" in soft:
+        n = len(soft["ziq16cut"])
+        assert 0.5 * len(soft["bare16"]) < n <= len(soft["bare16"]), (n, len(soft["bare16"]))
+        m = n * 9 // 10
+        assert np.mean(np.abs(soft["ziq16cut"][:m].astype(np.int16) - soft["bare16"][:m].astype(np.int16)) <= 1) > 0.999
+    if "ziq16+devices" in soft:
+        assert np.array_equal(soft["ziq16+devices"], soft["bare16+devices"]) and len(soft["bare16+devices"]) == len(soft["bare16"])
+    if "ziq16z+devices" in soft:
+        assert np.array_equal(soft["ziq16z+devices"], soft["bare16"])  # no seeking in a zstd stream: hip_devices ignored (logged), one device
+    # the wrong container is refused with a message, a ziq2 packet stream stays with the CPU module
+    inp = tmp_path / "notziq.bin"
+    inp.write_bytes(q16[:1 << 20])
+    job = {"mode": "file", "input": str(inp), "output_hint": str(tmp_path / "notziq"), "instantiate_only": True,
+           "demod": {"module": "psk_demod", "parameters": dict(GOES_DEMOD, baseband_format="ziq")}}
+    jp = tmp_path / "notziq.json"
+    jp.write_text(json.dumps(job))
+    p = subprocess.run([host, lib, PLUGIN, "run", str(jp)], capture_output=True, text=True, env=dict(os.environ, SDHIP_OVERRIDE="1"), timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert json.loads(p.stdout.strip().splitlines()[-1])["demod_class"] == "cpu:psk_demod"  # covers() said no: the reference module keeps the job
+
+
+def test_ziq_container_through_the_plugin(host, tmp_path):
+    check_ziq_container_through_the_plugin(host, LIB, tmp_path, nframes=30)
 
 
 def check_ndsp_single_blocks_through_the_plugin(host, lib, tmp_path):
