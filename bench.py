@@ -67,8 +67,10 @@ WORKLOADS = {
 }
 
 
-def algorithmic_bytes(wl, n_in, n_rs, nsym, nsoft, cadu_bytes_out, in_bytes_per_sample):
-    """Per-step minimal HBM traffic of each kernel when stages are NOT fused: read + write once."""
+def algorithmic_bytes(wl, n_in, n_rs, nsym, nsoft, cadu_bytes_out, in_bytes_per_sample, q8=False):
+    """Per-step minimal HBM traffic of each kernel when stages are NOT fused: read + write once. q8: the clock recovery
+    writes the module's int8 soft symbols (two bytes per symbol in its rows, k_compact8 behind it) instead of float symbols (eight bytes,
+    k_quantize behind it) -- what it does whenever nobody asks for the float symbols, i.e. in the timed steps."""
     q = wl["soft_per_sym"]
     return {
         "k_convert": n_in * (in_bytes_per_sample + 8),
@@ -82,7 +84,7 @@ def algorithmic_bytes(wl, n_in, n_rs, nsym, nsoft, cadu_bytes_out, in_bytes_per_
         "k_fir_window": n_rs * 16,
         "k_chunks<CostasStage>": n_rs * 16,
         "k_afc": n_rs * 16,  # AGC + RRC filter + Costas loop in one pass: neither the AGC nor the filtered samples reach memory
-        "k_mm": n_rs * 8 + nsym * 8,
+        "k_mm": n_rs * 8 + nsym * (2 if q8 else 8),
         "k_quantize": nsym * (8 + q),
         "k_compact8": nsym * (2 + q),
         "k_vit_decode": nsoft + nsoft * wl["conv_rate"] / 8.0,
@@ -617,7 +619,7 @@ def run_workload(args, workload, n_steps, n_warmup, parity_samples, ctx):
         nsym = dst.symbols_out // passes
         n_rs = n_in if not dst.resample_interp else (n_in * dst.resample_interp) // dst.resample_decim
         nsoft = tot_soft // steps
-        algo = algorithmic_bytes(wl, n_in, n_rs, nsym, nsoft, (tot_frames // steps) * cadu_bytes, 8)
+        algo = algorithmic_bytes(wl, n_in, n_rs, nsym, nsoft, (tot_frames // steps) * cadu_bytes, 8, q8="k_compact8" in prof)
         kernels = {k: {"ms_per_step": round(v[0] / steps, 4), "launches_per_step": round(v[1] / steps, 2)} for k, v in prof.items()}
         for k, v in kernels.items():
             if k in algo and v["ms_per_step"] > 0:

@@ -1551,10 +1551,13 @@ namespace sdhip
             // phase in, ~16/gain_mu symbols at the loop's own gains settle it onto the sequential trajectory
             // (|dt| p99 < 0.03 sample at GOES' 7 dB, far less for the QPSK configs); 36/gain_mu without the fast gear
             const double gmu = std::max(1e-4f, cfg.clock_gain_mu);
-            // SDHIP_MM_Q8=1 (experiment): when nobody asks for the float symbols the clock recovery stores the int8 soft symbols
-            // itself. Measured on MetOp: the compaction behind it drops from 2.7 to 1.5 ms, but the ~15 extra VALU instructions per
-            // symbol cost the issue-bound k_mm 1.3 - 2.2 ms (unpaired / dword-paired stores): off by default.
-            mm_p.q8 = (d_syms == nullptr && env_int("SDHIP_MM_Q8", 0) != 0) ? 1 : 0;
+            // When nobody asks for the float symbols (the modules, bench.py's timed steps) the clock recovery stores the module's int8 soft symbols itself -- two bytes
+            // per symbol in its scratch rows instead of eight, eight symbols per 16-byte store -- and the compaction behind it moves a quarter of the bytes
+            // (k_compact8 in place of k_quantize). Round 2 had measured this slower (k_mm was bound by its instruction issue then: +1.3 - 2.2 ms for ~15 more
+            // instructions per symbol); on round 5's k_mm, which is not, it is faster (visit L: dword-paired stores and a halfword-wise compaction already level with
+            // the float rows). Same bytes either way (test_soft_symbols_without_the_float_symbols). SDHIP_MM_Q8=0: float rows + k_quantize.
+            // (The Gardner lanes and the test tap carry float symbols only.)
+            mm_p.q8 = (d_syms == nullptr && tap_mode == 0 && mm_p.loop != 1 && env_int("SDHIP_MM_Q8", 1) != 0) ? 1 : 0;
             mm_p.q8_bpsk = is_bpsk ? 1 : 0;
             mm_p.tap = tap_mode;
             mm_p.fast = (!cfg.exact && env_int("SDHIP_FAST_MATH", 1) != 0) ? 1 : 0;
@@ -1612,7 +1615,7 @@ namespace sdhip
                 g = make_geom(n, L, (int)Wn);
                 const double omin = (double)mm_p.omega_mid - (double)mm_p.omega_limit;
                 const long long span0 = std::min<long long>(n, (long long)L + Wn);
-                mm_p.cap = ((int)(span0 / std::max(0.5, omin - 0.01)) + 16 + 1) & ~1; // even: int8 rows start on a dword
+                mm_p.cap = ((int)(span0 / std::max(0.5, omin - 0.01)) + 16 + 7) & ~7; // whole groups of eight: int8 rows start on 16 bytes (k_mm<.., Q8>'s group stores)
                 mm_p.cg = cg;
                 mm_p.rot = mm_rot;
                 symbuf.reserve((size_t)g.K * mm_p.cap);

@@ -2391,6 +2391,13 @@ namespace sdhip
             return 127;
         return (signed char)(int)x;
     }
+    // the same value without branches (the symbol loop of k_mm<.., Q8>): inside [-128, 127] the conversion truncates as above, beyond 127 the clamp yields 127,
+    // below -128 the select puts -127 where the clamp left -128
+    __device__ __forceinline__ unsigned sd_clamp8_u(float x)
+    {
+        const int r = (int)fminf(fmaxf(x, -128.0f), 127.0f);
+        return (unsigned)(x < -128.0f ? -127 : r) & 0xffu;
+    }
 template <bool CKPT, bool SPLIT, bool Q8 = false, bool FAST = false, bool GARD = false, bool TAP = false>
     __global__ __launch_bounds__(64) void k_mm(const cf32 *x, cf32 *sym, int *counts, ChunkGeom g, MmParams p, const MmState *start0, MmState *spec,
                                                MmState *endst, MmCert *spec_c, MmCert *end_c, const int *redo, int nredo, MmCkpt *ck, int ck_per_chunk,
@@ -2459,26 +2466,34 @@ template <bool CKPT, bool SPLIT, bool Q8 = false, bool FAST = false, bool GARD =
         // bytes per symbol in the scratch row instead of eight; the float symbols are only stored when a caller asks for them
         cf32 *o = sym + (size_t)k * p.cap;
         short *o8 = reinterpret_cast<short *>(sym) + (size_t)k * p.cap;
-        // (pairs of symbols leave as one aligned dword store: 2-byte stores scattered over the lanes' rows cost more than the 8-byte
-        // float stores did; a lane's symbols get consecutive indices from 0, an unpaired last one is flushed behind the loop)
-        unsigned pend = 0;
-        int pend_at = -1;
+        // (eight symbols leave as ONE aligned 16-byte store: a lane's symbols get consecutive indices from 0 -- the chunk's, then its look-ahead's --, the rows start
+        // on 16-byte boundaries (the engine rounds the row length to eight symbols); the newest eight sit in a 128-bit shift register, the newest in the top
+        // halfword, and what is left of a group when the lane is done goes out halfword by halfword)
+        unsigned q0 = 0, q1 = 0, q2 = 0, q3 = 0;
+        int qn = 0, q_last = -1;
+        auto q8_flush_part = [&]() {
+            const unsigned w[4] = {q0, q1, q2, q3};
+#pragma unroll
+            for (int j = 0; j < 8; j++)
+                if (j >= 8 - qn)
+                    o8[q_last - 7 + j] = (short)((j & 1) ? (w[j >> 1] >> 16) : (w[j >> 1] & 0xffffu));
+            qn = 0;
+        };
         auto put = [&](int at, const cf32 v) {
             if constexpr (Q8)
             {
                 const float sc = p.q8_bpsk ? 50.0f : 100.0f;
-                const unsigned cur = (unsigned)(unsigned char)sd_clamp8(v.re * sc) | ((unsigned)(unsigned char)sd_clamp8(v.im * sc) << 8);
-                if ((at & 1) && pend_at == at - 1)
-                {
-                    *reinterpret_cast<unsigned *>(o8 + at - 1) = pend | (cur << 16);
-                    pend_at = -1;
-                }
-                else if (at & 1)
-                    o8[at] = (short)cur;
-                else
-                {
-                    pend = cur;
-                    pend_at = at;
+                const unsigned cur = sd_clamp8_u(v.re * sc) | (sd_clamp8_u(v.im * sc) << 8);
+                q0 = (q0 >> 16) | (q1 << 16);
+                q1 = (q1 >> 16) | (q2 << 16);
+                q2 = (q2 >> 16) | (q3 << 16);
+                q3 = (q3 >> 16) | (cur << 16);
+                qn++;
+                q_last = at;
+                if (qn == 8)
+                { // (a lane's first index is 0, so `at - 7` is a multiple of eight and the store aligned; it would be correct, only slower, from any other start)
+                    *reinterpret_cast<uint4 *>(o8 + at - 7) = uint4{q0, q1, q2, q3};
+                    qn = 0;
                 }
             }
             else
@@ -2674,8 +2689,8 @@ template <bool CKPT, bool SPLIT, bool Q8 = false, bool FAST = false, bool GARD =
             }
         }
         if constexpr (Q8)
-            if (pend_at >= 0)
-                o8[pend_at] = (short)pend;
+            if (qn > 0)
+                q8_flush_part();
         if (!merged) // a merged re-run leaves the chunk's count, look-ahead and end state as the speculative run wrote them
             counts[2 * k + 1] = nx;
     }
@@ -2829,7 +2844,41 @@ template <bool CKPT, bool SPLIT, bool Q8 = false, bool FAST = false, bool GARD =
             }
         }
     }
-    // compaction of the int8 scratch rows k_mm<.., Q8> leaves (two bytes per symbol): BPSK keeps the first byte of each pair
+    // compaction of the int8 scratch rows k_mm<.., Q8> leaves (two bytes per symbol): BPSK keeps the first byte of each pair.
+    // Eight symbols per thread and ONE aligned store of their 8 (BPSK) / 16 (QPSK) bytes: the row's halfwords come in as two aligned 16-byte loads and pass a funnel
+    // shift by the row's (block-uniform) halfword offset H against the output's alignment; the first few symbols of a row, up to the next 8-symbol boundary of the
+    // OUTPUT, and its last few go one by one.
+    template <int H>
+    __device__ __forceinline__ uint4 sd_take8(const uint4 a, const uint4 b)
+    {
+        const unsigned v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+        constexpr int t = H >> 1;
+        if constexpr ((H & 1) != 0)
+            return uint4{(v[t] >> 16) | (v[t + 1] << 16), (v[t + 1] >> 16) | (v[t + 2] << 16), (v[t + 2] >> 16) | (v[t + 3] << 16), (v[t + 3] >> 16) | (v[t + 4] << 16)};
+        else
+            return uint4{v[t], v[t + 1], v[t + 2], v[t + 3]};
+    }
+    template <int H>
+    __device__ __forceinline__ void compact8_groups(const short *s0, int groups, int bpsk, int8_t *dst)
+    { // s0: the first group's first halfword, H halfwords behind a 16-byte boundary; dst: where the first group's bytes go (8- / 16-byte aligned)
+        const uint4 *q = reinterpret_cast<const uint4 *>(s0 - H);
+        for (int g = (int)threadIdx.x; g < groups; g += (int)blockDim.x)
+        {
+            const uint4 a = q[g];
+            uint4 b = a;
+            if constexpr (H != 0)
+                b = q[g + 1];
+            const uint4 w = sd_take8<H>(a, b);
+            if (bpsk)
+            {
+                const unsigned lo = (w.x & 0xffu) | ((w.x >> 8) & 0xff00u) | ((w.y & 0xffu) << 16) | ((w.y & 0xff0000u) << 8);
+                const unsigned hi = (w.z & 0xffu) | ((w.z >> 8) & 0xff00u) | ((w.w & 0xffu) << 16) | ((w.w & 0xff0000u) << 8);
+                *reinterpret_cast<uint2 *>(dst + 8 * (size_t)g) = uint2{lo, hi};
+            }
+            else
+                *reinterpret_cast<uint4 *>(dst + 16 * (size_t)g) = w;
+        }
+    }
     __global__ __launch_bounds__(256) void k_compact8(const short *sym8, const int *seg, const long long *offsets, int K, int cap, int bpsk, int8_t *soft,
                                                       long long soft_cap)
     {
@@ -2839,8 +2888,7 @@ template <bool CKPT, bool SPLIT, bool Q8 = false, bool FAST = false, bool GARD =
         const int cnt = seg[2 * k + 1];
         const long long off = offsets[k];
         const short *s = sym8 + (size_t)k * cap + seg[2 * k];
-        for (int j = (int)threadIdx.x; j < cnt; j += (int)blockDim.x)
-        {
+        auto one = [&](int j) {
             const unsigned v = (unsigned short)s[j];
             const long long o = off + j;
             if (bpsk)
@@ -2850,7 +2898,35 @@ template <bool CKPT, bool SPLIT, bool Q8 = false, bool FAST = false, bool GARD =
             }
             else if (2 * o + 1 < soft_cap)
                 *reinterpret_cast<short *>(soft + 2 * o) = (short)v;
+        };
+        const uintptr_t oaddr = reinterpret_cast<uintptr_t>(soft) + (uintptr_t)(bpsk ? off : 2 * off); // where this row's bytes go
+        if (off + cnt > (bpsk ? soft_cap : soft_cap / 2) || (!bpsk && (oaddr & 1) != 0))
+        { // (the engine refuses a call whose symbols do not fit before it gets here; an odd output address has no aligned stores)
+            for (int j = (int)threadIdx.x; j < cnt; j += (int)blockDim.x)
+                one(j);
+            return;
         }
+        const int gb = bpsk ? 8 : 16, ob = bpsk ? 1 : 2;
+        const int to_boundary = (int)(((gb - (oaddr & (uintptr_t)(gb - 1))) & (uintptr_t)(gb - 1)) / ob);
+        const int head = to_boundary < cnt ? to_boundary : cnt;
+        const int groups = (cnt - head) / 8;
+        if ((int)threadIdx.x < head)
+            one((int)threadIdx.x);
+        const short *s0 = s + head;
+        int8_t *dst = soft + (bpsk ? off + head : 2 * (off + head));
+        switch ((int)((reinterpret_cast<uintptr_t>(s0) >> 1) & 7))
+        {
+        case 0: compact8_groups<0>(s0, groups, bpsk, dst); break;
+        case 1: compact8_groups<1>(s0, groups, bpsk, dst); break;
+        case 2: compact8_groups<2>(s0, groups, bpsk, dst); break;
+        case 3: compact8_groups<3>(s0, groups, bpsk, dst); break;
+        case 4: compact8_groups<4>(s0, groups, bpsk, dst); break;
+        case 5: compact8_groups<5>(s0, groups, bpsk, dst); break;
+        case 6: compact8_groups<6>(s0, groups, bpsk, dst); break;
+        default: compact8_groups<7>(s0, groups, bpsk, dst); break;
+        }
+        for (int j = head + 8 * groups + (int)threadIdx.x; j < cnt; j += (int)blockDim.x)
+            one(j);
     }
     void launch_compact8(const cf32 *sym_scratch, const int *seg, const long long *offsets, int K, int cap, int bpsk, int8_t *soft, long long soft_cap,
                          hipStream_t st)

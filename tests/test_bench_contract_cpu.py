@@ -38,7 +38,7 @@ def test_committed_pmc_profile_belongs_to_the_sources_in_the_tree():
         pytest.fail("SDHIP_FINAL=1 (the round's closing check): the committed PMC profile is of other kernel sources (" + src + ")")
     if src and "stale" in src:
         pytest.skip("the committed PMC profile is of other kernel sources (" + src + "): take the two --pmc passes again before the round ends")
-    for k in ("k_afc", "k_mm", "k_vit2_acs", "k_quantize"):
+    for k in ("k_afc", "k_mm", "k_vit2_acs", "k_compact8"):
         traffic, src = bench.pmc_traffic("metop_ahrpt", k)
         assert traffic and traffic > 1e9 and "stale" not in src, (k, traffic, src)
     with open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", src)) as f:
@@ -53,3 +53,5 @@ def test_bench_workloads_and_algorithmic_bytes():
     wl = bench.WORKLOADS["metop_ahrpt"]
     a = bench.algorithmic_bytes(wl, 1000, 1000, 400, 800, 1024, 8)
     assert a["k_afc"] == 16000 and a["k_mm"] == 1000 * 8 + 400 * 8 and a["k_quantize"] == 400 * (8 + wl["soft_per_sym"])
+    a = bench.algorithmic_bytes(wl, 1000, 1000, 400, 800, 1024, 8, q8=True)  # the timed steps: int8 symbols out of the clock recovery, compacted
+    assert a["k_mm"] == 1000 * 8 + 400 * 2 and a["k_compact8"] == 400 * (2 + wl["soft_per_sym"])
