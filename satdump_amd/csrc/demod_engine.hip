@@ -1556,8 +1556,9 @@ namespace sdhip
             // (k_compact8 in place of k_quantize). Round 2 had measured this slower (k_mm was bound by its instruction issue then: +1.3 - 2.2 ms for ~15 more
             // instructions per symbol); on round 5's k_mm, which is not, it is faster (visit L: dword-paired stores and a halfword-wise compaction already level with
             // the float rows). Same bytes either way (test_soft_symbols_without_the_float_symbols). SDHIP_MM_Q8=0: float rows + k_quantize.
-            // (The Gardner lanes and the test tap carry float symbols only.)
-            mm_p.q8 = (d_syms == nullptr && tap_mode == 0 && mm_p.loop != 1 && env_int("SDHIP_MM_Q8", 1) != 0) ? 1 : 0;
+            // (The Gardner lanes and the test tap carry float symbols only. BPSK keeps the float rows by default: half of an int8 pair is dropped again by the
+            // compaction, and on GOES -- five sixths of the lanes' work are warm-up, where nothing is stored -- the int8 instance measured 0.3 ms behind, visits M / N.)
+            mm_p.q8 = (d_syms == nullptr && tap_mode == 0 && mm_p.loop != 1 && env_int("SDHIP_MM_Q8", is_bpsk ? 0 : 1) != 0) ? 1 : 0;
             mm_p.q8_bpsk = is_bpsk ? 1 : 0;
             mm_p.tap = tap_mode;
             mm_p.fast = (!cfg.exact && env_int("SDHIP_FAST_MATH", 1) != 0) ? 1 : 0;
