@@ -1801,10 +1801,10 @@ namespace sdhip_plugin
                 }
                 else if (e.id == "ccsds_simple_psk_decoder")
                 {
-                    // hard_symbols input (soft_reader.h:49-58) stays on the CPU module
+                    // padded frames (cadu_size % 8 != 0) stay on the CPU module; hard_symbols input (soft_reader.h:49-58) is expanded by FecHipModuleBase::read_soft
                     auto cpu = e.inst;
                     e.inst = [cpu](std::string in, std::string out, nlohmann::json p) -> std::shared_ptr<ProcessingModule> {
-                        if ((p.count("hard_symbols") > 0 && p["hard_symbols"].get<bool>()) || (p.count("cadu_size") > 0 && p["cadu_size"].get<int>() % 8 != 0))
+                        if (p.count("cadu_size") > 0 && p["cadu_size"].get<int>() % 8 != 0)
                             return cpu(in, out, p);
                         return CCSDSSimplePSKDecoderHipModule::getInstance(in, out, p);
                     };

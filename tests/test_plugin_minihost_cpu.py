@@ -184,3 +184,14 @@ def test_ziq_container_through_the_plugin_on_the_twin(host, tmp_path):
         pytest.skip("needs a host clang++")
     G.check_ziq_container_through_the_plugin(host, emu_build.build(), tmp_path, nframes=10, serial_chunks=True,
                                              only=("bare16", "ziq16z", "bare8", "ziq8z", "bare16+devices", "ziq16+devices", "ziq16z+devices"))
+
+
+def test_hard_symbols_through_the_plugin_on_the_twin(host, tmp_path):
+    """tests/test_plugin_minihost_gpu.py::test_hard_symbols_through_the_plugin with the host twin as the C-ABI library: the plugin's packed-bit reader in front of
+    ccsds_simple_psk_decoder, in the CPU suite."""
+    from oracle import pyref
+    from tests import test_plugin_minihost_gpu as G
+    from tests.emu import build as emu_build
+    if not pyref.ref_available() or not os.path.exists(emu_build.CLANG):
+        pytest.skip("needs the compiled reference and a host clang++")
+    G.check_hard_symbols_through_the_plugin(host, emu_build.build(), tmp_path, nframes=12)

@@ -128,6 +128,43 @@ def test_soft_file_that_ends_on_a_buffer_boundary_and_one_that_does_not(host, tm
         assert got.shape == want.shape and np.array_equal(got, want), nbytes
 
 
+def check_hard_symbols_through_the_plugin(host, lib, tmp_path, nframes=16, cases=("bpsk", "qpsk_0deg")):
+    """`hard_symbols: true` (satdump::SoftSymbolReader, src-core/common/codings/soft_reader.h:17-58; of the decoders on this path only
+    ccsds_simple_psk_decoder reads through it, module_ccsds_simple_psk_decoder.cpp:123-140) through the stock id under the override: the input file holds packed
+    hard bits, MSB first; every bit becomes a soft symbol of +-70, 1024 bytes are fetched whenever the previous 8192 bits are used up -- and never before the
+    FIRST 8192 symbols, which the reference reads out of a fresh `new uint8_t[1024]` (zeros here: 8192 symbols of -70). A fetch that hits the end of the file
+    ends the module's loop: a trailing partial KiB is never decoded. The .cadu file must be what the reference's decoder makes of exactly that soft stream --
+    for a file of whole KiBs and for a ragged one, BPSK and QPSK."""
+    orc = pyref.best()
+    for name in cases:
+        ck, soft, plain = util.simple_case(name, sigma=12.0, nframes=nframes)
+        bits = (soft > 0).astype(np.uint8)
+        params = {"constellation": ck["constellation"], "cadu_size": 8192, "nrzm": bool(ck.get("nrzm", 0)), "rs_i": 4, "rs_type": "rs223", "rs_usecheck": True,
+                  "hard_symbols": True}
+        ofec = pyref.fec_cfg(decoder=2, constellation={"bpsk": pyref.BPSK, "qpsk": pyref.QPSK}[ck["constellation"]], nrzm=int(ck.get("nrzm", 0)), rs_usecheck=1)
+        whole_kib = len(bits) // 8192 * 8192
+        for cut in (whole_kib, whole_kib - 8192 + 3001 * 8):
+            packed = np.packbits(bits[:cut])  # MSB first
+            inp = tmp_path / f"{name}_{cut}.hard"
+            packed.tofile(str(inp))
+            job = {"mode": "file", "input": str(inp), "output_hint": str(tmp_path / f"{name}_{cut}"), "demod": {"module": "ccsds_simple_psk_decoder", "parameters": params}}
+            jp = tmp_path / f"{name}_{cut}.json"
+            jp.write_text(json.dumps(job))
+            p = subprocess.run([host, lib, PLUGIN, "run", str(jp)], capture_output=True, text=True, env=dict(os.environ, SDHIP_OVERRIDE="1"), timeout=900)
+            assert p.returncode == 0, p.stdout[-1000:] + p.stderr[-3000:]
+            rep = json.loads(p.stdout.strip().splitlines()[-1])
+            assert rep["demod_class"] == "ccsds_simple_psk_decoder_hip", rep
+            got = np.fromfile(rep["soft"], dtype=np.uint8).reshape(-1, 1024)  # minihost reports the first module's output under "soft"
+            whole = len(packed) // 1024 * 1024
+            stream = np.where(np.unpackbits(packed[:whole]) > 0, 70, -70).astype(np.int8)
+            want = orc.simple_decode(ofec, np.concatenate([np.full(8192, -70, dtype=np.int8), stream]))["cadu"]
+            assert len(want) >= (nframes if ck["constellation"] == "bpsk" else nframes) - 4 and got.shape == want.shape and np.array_equal(got, want), (name, cut, got.shape, want.shape)
+
+
+def test_hard_symbols_through_the_plugin(host, tmp_path):
+    check_hard_symbols_through_the_plugin(host, LIB, tmp_path)
+
+
 def test_fifo_and_dsp_stream_topologies(host, tmp_path):
     orc = pyref.best()
     spec, cadus, plain, syms = util.metop_case(nframes=60)
