@@ -14,7 +14,7 @@ when its own range begins); every step each rank starts cold (fresh handles), de
 stitches the per-rank CADU lists on the host from the boundary frames (no data-path collective); value =
 samples of the recording / max-over-ranks time, scaling "weak" (the share per GPU is fixed).
 
-Prints ONE JSON line on rank 0. Extra objects: "roofline" (dominant kernel, HIP-event timed on the launch stream via
+Prints ONE compact JSON line on rank 0 (headline(): < 4 KB, no prose) and writes the full result object to bench_detail.json. The full object's extra parts: "roofline" (dominant kernel, HIP-event timed on the launch stream via
 sdhip_prof_*), "cpu_baseline" (the compiled reference oracle/_ref in its own thread-per-block topology over the first
 --parity-samples samples of the stream -- default: ALL of it -- plus single-thread and all-cores legs on a bounded sample; rank 0 /
 N=1 only), "cadu_parity" (the first pass of fresh handles over the FULL-SIZE stream against that reference run: every CADU the
@@ -270,6 +270,78 @@ def arm_grid(wl, x_prefix, ref, gpu_syms, gpu_pos):
                     "test_every_symbol_beyond_tolerance_is_an_arm_flip asserts (a) and bounds (b) on streams of 60 - 140 chunks, where (c) does not occur"}
 
 
+HEADLINE_MAX_BYTES = 4000
+
+
+def _pick(d, keys):
+    return {k: d[k] for k in keys if d is not None and k in d} if d is not None else None
+
+
+def headline(out):
+    """The compact object bench.py prints as its LAST stdout line: the contract's keys, the roofline and cpu_baseline objects, the parity verdicts as numbers --
+    no prose, no per-kernel tables, no other workloads (those are in bench_detail.json). Kept under HEADLINE_MAX_BYTES (tests/test_bench_contract_cpu.py)."""
+    h = {k: out.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")}
+    cfg = out.get("config") or {}
+    h["config"] = {"workload": cfg.get("workload"), "mode": cfg.get("mode")}
+    if out.get("n_gpus", 1) > 1:
+        h["config"]["sharding"] = "contiguous chunks per GPU + lock-in overlap, host stitch, no data-path collective"
+    h["cadu_per_s"] = out.get("cadu_per_s")
+    h["whole_path_GBps"] = out.get("whole_path_GBps")
+    h["roofline"] = _pick(out.get("roofline"), ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "algo_bytes_per_launch", "avg_launch_ms",
+                                                "launches_per_step", "kernel_time_frac_of_step"))
+    cpu = out.get("cpu_baseline")
+    if cpu is not None:
+        c = _pick(cpu, ("value", "unit", "cores", "kind", "host_cores"))
+        c["sample"] = str(cpu.get("sample", ""))[:160]
+        c["volk"] = "generic-order shim (no libvolk on the box)"
+        if cpu.get("single_thread"):
+            c["single_thread"] = cpu["single_thread"].get("value")
+        if cpu.get("all_cores"):
+            c["all_cores"] = _pick(cpu["all_cores"], ("value", "cores"))
+        h["cpu_baseline"] = c
+    else:
+        h["cpu_baseline"] = None
+    cp = out.get("cadu_parity")
+    h["cadu_parity"] = _pick(cp, ("byte_identical", "compared", "reference_cadus", "gpu_cadus_first_pass", "whole_stream", "n_differing", "those_identical_too"))
+    sp = out.get("soft_parity")
+    if sp is not None:
+        s = _pick(sp, ("symbols_compared", "frac_within_1e-5", "max_rel", "int8_compared", "frac_int8_equal", "max_lsb"))
+        if sp.get("q8"):
+            s["q8"] = _pick(sp["q8"], ("int8_compared", "frac_int8_equal", "max_lsb"))
+        ag = sp.get("arm_grid")
+        if ag:
+            s["arm_grid"] = {"symbols": ag.get("symbols"), "other": ag.get("other"), "same_arm_beyond_1e-5": ag["same_arm"].get("beyond_1e-5"),
+                             "same_arm_max_angle_rad": ag["same_arm"].get("max_angle_rad"), "one_arm_step_frac": ag["one_arm_step"].get("frac")}
+        h["soft_parity"] = s
+    else:
+        h["soft_parity"] = None
+    h["parity_gates"] = out.get("parity_gates")
+    h["exact_mode"] = _pick(out.get("exact_mode"), ("value", "samples", "bit_identical_to_the_reference"))
+    ck = out.get("check")
+    h["check"] = _pick(ck, ("cadus_last_step", "cadus_last_step_all_ranks", "payload_matching_transmitted", "transmitted", "stitched"))
+    ks = out.get("kernels") or {}
+    h["top_kernels_ms"] = {k: v["ms_per_step"] for k, v in sorted(ks.items(), key=lambda kv: -kv[1]["ms_per_step"])[:6]}
+    ow = out.get("other_workloads") or {}
+    h["other_workloads"] = {k: {"value": v.get("value"), "ms_per_step": v.get("ms_per_step"),
+                                "cadus_identical": (v.get("cadu_parity") or {}).get("byte_identical")} for k, v in ow.items()}
+    nr = out.get("next_rows") or {}
+    h["next_rows"] = {k: ({"value": v.get("value"), "unit": v.get("unit")} if "error" not in v else {"error": str(v["error"])[:80]}) for k, v in nr.items()}
+    h["detail"] = "bench_detail.json"
+    return h
+
+
+def headline_line(out):
+    """headline(out) as one JSON line, with the optional parts dropped one by one should it ever exceed HEADLINE_MAX_BYTES."""
+    h = headline(out)
+    for drop in (None, "next_rows", "other_workloads", "top_kernels_ms", "check", "exact_mode"):
+        if drop is not None:
+            h.pop(drop, None)
+        line = json.dumps(h, separators=(",", ":"))
+        if len(line) <= HEADLINE_MAX_BYTES:
+            return line
+    return line
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -296,6 +368,7 @@ def main():
                     help="blocks of --frames CADUs the recording consists of (default: one per GPU); --gpus 1 --blocks N decodes on one GPU the very "
                          "recording that --gpus N shards")
     ap.add_argument("--dump", default="", help="write the last step's CADUs of every rank to <prefix>.rank<r>.npy (+ <prefix>.json on rank 0): tests")
+    ap.add_argument("--detail", default="", help="where the full result object goes (default: bench_detail.json beside bench.py); stdout carries the compact line only")
     ap.add_argument("--pipeline", action="store_true",
                     help="N=1: overlap the decoder of step i with the demodulator of step i+1 (two host threads, two HIP streams) like the reference's "
                          "thread-per-module pipeline; off by default: the per-kernel HIP-event times of the roofline need the kernels un-overlapped")
@@ -368,7 +441,14 @@ def main():
                 nxt[key] = {"error": f"{type(e).__name__}: {e}"}
         out["next_rows"] = nxt
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        # everything measured goes to a file; stdout carries ONE compact line (the driver keeps only the tail of stdout: round 5's 26.7 KB line did not parse)
+        detail = args.detail or os.path.join(ROOT, "bench_detail.json")
+        try:
+            with open(detail, "w") as fh:
+                json.dump(out, fh, indent=1)
+        except OSError as e:
+            print(f"bench.py: could not write {detail}: {e}", file=sys.stderr)
+        print(headline_line(out), flush=True)
         if failed:
             print("bench.py: parity failed (CADUs differ from the reference's on the same IQ, soft symbols below the workload's floor, or exact mode not bit-identical)", file=sys.stderr)
             sys.exit(3)

@@ -55,3 +55,38 @@ def test_bench_workloads_and_algorithmic_bytes():
     assert a["k_afc"] == 16000 and a["k_mm"] == 1000 * 8 + 400 * 8 and a["k_quantize"] == 400 * (8 + wl["soft_per_sym"])
     a = bench.algorithmic_bytes(wl, 1000, 1000, 400, 800, 1024, 8, q8=True)  # the timed steps: int8 symbols out of the clock recovery, compacted
     assert a["k_mm"] == 1000 * 8 + 400 * 2 and a["k_compact8"] == 400 * (2 + wl["soft_per_sym"])
+
+
+def test_headline_line_is_compact_and_complete():
+    """The driver keeps only the tail of stdout: round 5's one-line result had grown to 26.7 KB and BENCH_r05.json.parsed was null. bench.py now prints
+    headline_line(out) -- built here from a committed full result object of a real run -- and writes the rest to bench_detail.json."""
+    import glob
+    import json
+    import bench
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cans = sorted(glob.glob(os.path.join(root, "profiles", "r0*_bench.json")) + glob.glob(os.path.join(root, "profiles", "r0*_bench_detail.json")))
+    cans = [c for c in cans if os.path.getsize(c) > 8000]
+    assert cans, "no committed full result object to build the line from"
+    for can in cans[-3:]:
+        with open(can) as f:
+            out = json.load(f)
+        line = bench.headline_line(out)
+        assert "\n" not in line and len(line) < bench.HEADLINE_MAX_BYTES < 6000, (can, len(line))
+        h = json.loads(line)
+        for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline",
+                  "cpu_baseline"):
+            assert k in h, k
+        assert h["config"]["workload"] and "model" not in h["config"]
+        assert h["value"] == out["value"] and h["ms_per_step"] == out["ms_per_step"]
+        r = h["roofline"]
+        for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "algo_bytes_per_launch", "avg_launch_ms"):
+            assert k in r, k
+        assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4
+        c = h["cpu_baseline"]
+        for k in ("value", "unit", "cores", "kind", "sample"):
+            assert k in c, k
+        assert h["cadu_parity"]["byte_identical"] is True and h["soft_parity"]["frac_within_1e-5"] > 0.9
+    # a pathological object (long strings everywhere) still yields a parseable line under the limit: optional parts are dropped
+    out = dict(out, next_rows={f"row{i}": {"value": 1.0, "unit": "x" * 200} for i in range(40)})
+    line = bench.headline_line(out)
+    assert len(line) < bench.HEADLINE_MAX_BYTES and "roofline" in json.loads(line)
