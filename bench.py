@@ -101,7 +101,7 @@ def algorithmic_bytes(wl, n_in, n_rs, nsym, nsoft, cadu_bytes_out, in_bytes_per_
 
 def pmc_traffic(workload, kernel):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (profiles/r*_<wl>_pmc.csv,
-    produced by tools/gpu_round.sh + tools/pmc_summary.py with the guide's gfx950 x2 correction on FETCH_SIZE). The PMC passes cannot
+    produced by tools/gpu_visit.sh's pmc stage + tools/pmc_summary.py with the guide's gfx950 x2 correction on FETCH_SIZE). The PMC passes cannot
     run inside this process, so the figure is read from the most recent committed profile of this workload -- and only if that
     profile was taken with the kernel sources this library was built from (its `# source_hash:` line against
     satdump_amd.build.source_hash()); a profile of other sources yields traffic = null and says so in traffic_source."""
@@ -214,21 +214,37 @@ def cpu_baseline(wl, x_host, n_prefix):
 PARITY_FLOORS = {"goes_hrit": (0.991, 4), "metop_ahrpt": (0.995, 8), "npp_hrd": (0.994, 12)}
 
 
-def soft_parity(gpu_syms, gpu_soft, ref, ref_soft_full):
-    """Agreement of the chunk-parallel GPU pass with the sequential reference: float symbols over the prefix the single-thread leg
-    covered, int8 soft symbols over everything the full-stream reference run produced."""
+def int8_parity(gpu_soft, ref_soft_full):
+    m = min(len(ref_soft_full), len(gpu_soft))
+    d = np.zeros(0, dtype=np.int16)
+    hist = np.zeros(6, dtype=np.int64)
+    mx = 0
+    for a in range(0, m, 1 << 28):  # in pieces: the streams are gigabytes
+        d = np.abs(gpu_soft[a:min(m, a + (1 << 28))].astype(np.int16) - ref_soft_full[a:min(m, a + (1 << 28))].astype(np.int16))
+        hist += np.bincount(np.minimum(d, 5).astype(np.int64), minlength=6)
+        mx = max(mx, int(d.max()) if len(d) else 0)
+    return {"int8_compared": int(m), "same_length": bool(len(ref_soft_full) == len(gpu_soft) or abs(len(ref_soft_full) - len(gpu_soft)) <= 4),
+            "frac_int8_equal": round(float(hist[0] / max(1, m)), 6),
+            "int8_abs_diff_hist": {"0": int(hist[0]), "1": int(hist[1]), "2": int(hist[2]), "3": int(hist[3]), "4": int(hist[4]), ">=5": int(hist[5])},
+            "max_lsb": mx}
+
+
+def soft_parity(gpu_syms, gpu_soft, gpu_soft_float_path, ref, ref_soft_full):
+    """Agreement of the chunk-parallel GPU pass with the sequential reference: float symbols over the prefix the single-thread leg covered, int8 soft symbols over
+    everything the full-stream reference run produced -- those of the handles the timed steps use (top level; "q8": which instantiation that was) and those of the
+    float instantiation the float symbols come from ("float_path")."""
     rs = ref["syms"]
     n = min(len(rs), len(gpu_syms))
     scale = float(np.sqrt(np.mean(np.abs(rs[:n]) ** 2)))
     err = np.abs(gpu_syms[:n] - rs[:n]) / scale
-    m = min(len(ref_soft_full), len(gpu_soft))
-    d = np.abs(gpu_soft[:m].astype(np.int16) - ref_soft_full[:m].astype(np.int16))
-    hist = np.bincount(np.minimum(d, 5).astype(np.int64), minlength=6)
-    return {"symbols_compared": int(n), "frac_within_1e-5": round(float(np.mean(err <= 1e-5)), 6), "frac_bit_identical": round(float(np.mean(err == 0)), 6),
-            "median_rel": float(np.median(err)), "p99_rel": float(np.quantile(err, 0.99)), "p99.9_rel": float(np.quantile(err, 0.999)),
-            "max_rel": float(err.max()), "int8_compared": int(m), "frac_int8_equal": round(float(hist[0] / max(1, m)), 6),
-            "int8_abs_diff_hist": {"0": int(hist[0]), "1": int(hist[1]), "2": int(hist[2]), "3": int(hist[3]), "4": int(hist[4]), ">=5": int(hist[5])},
-            "max_lsb": int(d.max()) if m else 0}
+    out = {"symbols_compared": int(n), "frac_within_1e-5": round(float(np.mean(err <= 1e-5)), 6), "frac_bit_identical": round(float(np.mean(err == 0)), 6),
+           "median_rel": float(np.median(err)), "p99_rel": float(np.quantile(err, 0.99)), "p99.9_rel": float(np.quantile(err, 0.999)),
+           "max_rel": float(err.max())}
+    out.update(int8_parity(gpu_soft, ref_soft_full))
+    if gpu_soft_float_path is not None:
+        out["float_path"] = int8_parity(gpu_soft_float_path, ref_soft_full)
+        out["float_path"]["identical_to_the_timed_handles_stream"] = bool(len(gpu_soft) == len(gpu_soft_float_path) and np.array_equal(gpu_soft, gpu_soft_float_path))
+    return out
 
 
 def arm_grid(wl, x_prefix, ref, gpu_syms, gpu_pos):
@@ -306,8 +322,10 @@ def headline(out):
     sp = out.get("soft_parity")
     if sp is not None:
         s = _pick(sp, ("symbols_compared", "frac_within_1e-5", "max_rel", "int8_compared", "frac_int8_equal", "max_lsb"))
-        if sp.get("q8"):
-            s["q8"] = _pick(sp["q8"], ("int8_compared", "frac_int8_equal", "max_lsb"))
+        if sp.get("timed_instantiation"):
+            s["timed_instantiation"] = sp["timed_instantiation"]
+        if sp.get("float_path"):
+            s["float_path"] = _pick(sp["float_path"], ("frac_int8_equal", "max_lsb", "identical_to_the_timed_handles_stream"))
         ag = sp.get("arm_grid")
         if ag:
             s["arm_grid"] = {"symbols": ag.get("symbols"), "other": ag.get("other"), "same_arm_beyond_1e-5": ag["same_arm"].get("beyond_1e-5"),
@@ -511,14 +529,25 @@ def run_workload(args, workload, n_steps, n_warmup, parity_samples, ctx):
         sps_in = wl["spec"]["samplerate"] / wl["spec"]["symbolrate"]
         syms_cap = int(ncpu / sps_in * 1.02) + 4096
         d_syms = torch.empty(2 * syms_cap, dtype=torch.float32, device=device)
+        # (A) the handles of the timed steps, called the way the timed steps call them (no float symbols asked for: on QPSK the clock recovery's int8 instantiation,
+        # k_mm<.., Q8> + k_compact8): its int8 soft symbols and its CADUs are what cadu_parity and soft_parity's int8 figures compare with the reference's
         tw = time.perf_counter()
-        ns0 = dem.process_dev(x.data_ptr(), n_in, capi.FMT_CF32, d_soft.data_ptr(), soft_cap, d_syms.data_ptr(), syms_cap)
+        ns0 = dem.process_dev(x.data_ptr(), n_in, capi.FMT_CF32, d_soft.data_ptr(), soft_cap)
         nf0 = fec.process_dev(d_soft.data_ptr(), ns0, d_cadu.data_ptr(), cap_frames)
         torch.cuda.synchronize()
         warmup_ms.append(round((time.perf_counter() - tw) * 1e3, 2))
         q = wl["soft_per_sym"]
-        parity_gpu = {"syms": d_syms[: 2 * min(syms_cap, ns0 // q)].cpu().numpy().view(np.complex64),
-                      "soft": d_soft[:ns0].cpu().numpy(), "cadus": d_cadu[:nf0].cpu().numpy(), "first_pass_stats": dem.stats()}
+        parity_gpu = {"soft": d_soft[:ns0].cpu().numpy(), "cadus": d_cadu[:nf0].cpu().numpy(), "first_pass_stats": dem.stats()}
+        # (B) the same first pass through a second fresh handle WITH the float symbols of the prefix (the float instantiation + k_quantize): the float-symbol
+        # comparison, and that instantiation's int8 stream beside (A)'s
+        dem_f = capi.PskDemod(capi.demod_cfg(**dcfg_kw))
+        d_soft_f = torch.empty(soft_cap, dtype=torch.int8, device=device)
+        ns_f = dem_f.process_dev(x.data_ptr(), n_in, capi.FMT_CF32, d_soft_f.data_ptr(), soft_cap, d_syms.data_ptr(), syms_cap)
+        torch.cuda.synchronize()
+        parity_gpu["syms"] = d_syms[: 2 * min(syms_cap, ns_f // q)].cpu().numpy().view(np.complex64)
+        parity_gpu["soft_float_path"] = d_soft_f[:ns_f].cpu().numpy()
+        dem_f.close()
+        del d_soft_f
         # the same first pass once more through a second fresh handle with the test tap on (sdhip_demod_set_tap): where on its 128-arm grid the clock recovery
         # interpolated every symbol of the prefix -- soft_parity's arm_grid classification (same trajectory: the engine is deterministic)
         if hasattr(capi.PskDemod, "set_tap"):
@@ -728,12 +757,14 @@ def run_workload(args, workload, n_steps, n_warmup, parity_samples, ctx):
             xh = x[:npar].cpu().numpy().view(np.complex64)
             cpu, ref, full = cpu_baseline(wl, xh, ncpu)
             del xh
-            sparity = soft_parity(parity_gpu["syms"], parity_gpu["soft"], ref, full["soft"])
+            sparity = soft_parity(parity_gpu["syms"], parity_gpu["soft"], parity_gpu.get("soft_float_path"), ref, full["soft"])
+            sparity["timed_instantiation"] = "k_mm<Q8> + k_compact8" if "k_compact8" in prof else "k_mm (float rows) + k_quantize"
             if "arm_pos" in parity_gpu:
                 sparity["arm_grid"] = arm_grid(wl, x[:ncpu].cpu().numpy().view(np.complex64), ref, parity_gpu["syms"], parity_gpu["arm_pos"])
             fp = parity_gpu["first_pass_stats"]
-            sparity["what"] = (f"first pass of fresh handles over the full {n_in}-sample stream (chunk-parallel mode) against the sequential reference: float "
-                               f"symbols over its first {ncpu} samples, int8 soft symbols over its first {full['samples']} samples")
+            sparity["what"] = (f"first pass of fresh handles over the full {n_in}-sample stream (chunk-parallel mode) against the sequential reference: int8 soft symbols "
+                               f"of the timed steps' own handles (no float symbols requested) over its first {full['samples']} samples; float symbols (a second fresh "
+                               f"handle, the float instantiation) over its first {ncpu} samples")
             sparity["first_pass_chunks"] = {"chunks": fp.chunks, "re_run": fp.chunks_fixed, "accepted_by_tolerance": fp.chunks_inexact, "let_through": fp.chunks_forced}
             ref_cadus, gpu_cadus = full["cadu"], parity_gpu["cadus"]
             m = min(len(ref_cadus), len(gpu_cadus))

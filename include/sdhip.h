@@ -274,6 +274,10 @@ extern "C"
         uint32_t tb_respec;      /* traceback segments re-run because the merge certificate failed */
         float viterbi2_ber;      /* fengyun_ahrpt_decoder: "viterbi2_ber" / "viterbi2_lock" (viterbi_ber / viterbi_lock are its viterbi1_*) */
         int viterbi2_lock;
+        /* watchdog actions of the decoder MODULES since the handle was created: MetOp's viterbi.reset() after 10 NOSYNC reads (module_metop_ahrpt_decoder.cpp:58-66),
+           the FengYun modules' `shift` / `invert_branches` toggles AND every read their cumulative viterbiNoSyncRun counted (module_fengyun_ahrpt_decoder.cpp:82-114).
+           A sharded decode (hip_devices) is only the single stream's when this stays put over every shard's own run: a shard starts those counters cold. */
+        uint32_t watchdog_events;
     } sdhip_fec_stats;
 
     void sdhip_fec_cfg_default(sdhip_fec_cfg *cfg);

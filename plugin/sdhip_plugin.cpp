@@ -839,9 +839,14 @@ namespace sdhip_plugin
             // at the GPU's rate; a FIFO input is pushed buffer by buffer (stay close to real time).
             if (devices.size() > 1 && input_data_type == DATA_FILE && !hard_symbols)
             {
-                process_sharded();
-                cleanup();
-                return;
+                if (process_sharded())
+                {
+                    cleanup();
+                    return;
+                }
+                // (nothing has been read from the module's input or written yet: process_sharded reads the file on its own and writes only a certified result)
+                logger->warn("%s: hip_devices: a decoder watchdog acted inside a device's own run (a dropout, a branch swap): the modules' cumulative counters make "
+                             "such a recording a single stream's business -- decoding on device %d alone", getIDM().c_str(), cfg.device);
             }
             const size_t max_blocks = input_data_type == DATA_FILE ? 2048 : 1;
             std::vector<int8_t> soft((size_t)block_bytes * max_blocks, 0);
@@ -889,7 +894,12 @@ namespace sdhip_plugin
         // thread of its own, streaming its buffers through in batches, and keeps its CADUs (a sixteenth to an eighth of the soft bytes); the lists are stitched from
         // their boundary frames compared WHOLE (sdhip_shard_stitch) and written in order: the .cadu file is the single device's. The reference's topology is one
         // decoder thread per stream (src-core/pipeline/pipeline_run.cpp:72-104); this is what N devices add to it.
-        void process_sharded()
+        // Certificate: the decoder modules carry watchdog state a cold-started shard does not have -- MetOp's NOSYNC run count, the FengYun modules'
+        // `shift`, `invert_branches` and their CUMULATIVE viterbiNoSyncRun (module_fengyun_ahrpt_decoder.cpp:82-114: it never resets, so after ten counted reads every
+        // further one toggles `shift`). The lock-in stretch in front of a shard's own run covers the watchdogs' worst case from cold (sdhip_shard_lockin); inside its
+        // own run a shard must not see a watchdog act at all (sdhip_fec_stats::watchdog_events unchanged): then its state is the single stream's wherever it matters.
+        // Otherwise -- a recording with dropouts, a branch swap mid-file -- false is returned with nothing written, and the caller decodes on one device.
+        bool process_sharded()
         {
             const int N = (int)devices.size();
             const uint64_t S = (uint64_t)std::filesystem::file_size(d_input_file);
@@ -914,6 +924,7 @@ namespace sdhip_plugin
                 rd[r] = own[r] > ov_blocks ? own[r] - ov_blocks : 0;
             std::vector<std::vector<uint8_t>> out(N);
             std::vector<uint64_t> lead_frames(N, 0); // frames a chunk had decoded when its own run began: what the stitch may have to look through
+            std::vector<uint32_t> lead_events(N, 0);  // watchdog actions of a chunk's decoder when its own run began
             std::vector<std::string> errs(N);
             std::vector<sdhip_fec_stats> sts(N);
             std::vector<std::thread> th;
@@ -980,6 +991,9 @@ namespace sdhip_plugin
                                 {
                                     lead_taken = true;
                                     lead_frames[r] = out[r].size() / (size_t)cadu_bytes;
+                                    sdhip_fec_stats s0;
+                                    sdhip_fec_get_stats(e, &s0);
+                                    lead_events[r] = s0.watchdog_events;
                                 }
                             }
                             sdhip_fec_get_stats(e, &sts[r]);
@@ -1002,6 +1016,9 @@ namespace sdhip_plugin
             for (int r = 0; r < N; r++)
                 if (!errs[r].empty())
                     throw satdump_exception(std::string(getIDM()) + " (device " + std::to_string(devices[r]) + "): " + errs[r]);
+            for (int r = 1; r < N; r++)
+                if (sts[r].watchdog_events != lead_events[r])
+                    return false;
             // stitch: what two neighbours both decoded goes, judged on whole frames at the seams
             size_t edge = 16;
             for (int r = 0; r < N; r++)
@@ -1031,6 +1048,7 @@ namespace sdhip_plugin
             viterbi2_lock = st.viterbi2_lock;
             deframer_state = st.deframer_state;
             rs_avg = (st.rs_errors[0] + st.rs_errors[1] + st.rs_errors[2] + st.rs_errors[3]) / 4;
+            return true;
         }
         void drawUI(bool) {}
         nlohmann::json getModuleStats()

@@ -57,7 +57,7 @@ class FecStats(C.Structure):
     _fields_ = [
         ("soft_in", C.c_uint64), ("blocks", C.c_uint64), ("bits_decoded", C.c_uint64), ("frames_deframed", C.c_uint64),
         ("frames_out", C.c_uint64), ("viterbi_ber", C.c_float), ("viterbi_lock", C.c_int), ("deframer_state", C.c_int),
-        ("rs_errors", C.c_int * 8), ("vit_respec", C.c_uint32), ("tb_respec", C.c_uint32), ("viterbi2_ber", C.c_float), ("viterbi2_lock", C.c_int),
+        ("rs_errors", C.c_int * 8), ("vit_respec", C.c_uint32), ("tb_respec", C.c_uint32), ("viterbi2_ber", C.c_float), ("viterbi2_lock", C.c_int), ("watchdog_events", C.c_uint32),
     ]
 
 

@@ -115,6 +115,7 @@ namespace sdhip
     {
         int nfail, inexact, rotated, overflow;
         int forced, loose; // loose: accepted, but outside the stage's TIGHT window (drives the warm-up adaptation, not a re-run)
+        int wide, pad;     // wide: failed OUTSIDE the stage's wide window -- a lane that is not locked, as opposed to a hand-off a little off (carrier stages: re-run either way)
         long long total;
     };
     template <class S>
@@ -155,7 +156,7 @@ namespace sdhip
             fails[atomicAdd(&vo->nfail, 1)] = k;
     }
 
-    __global__ void k_agc_verdict(int K, const AgcState *spec, const AgcState *endst, VerdictOut *vo, int *fails, int force)
+    __global__ void k_agc_verdict(int K, const AgcState *spec, const AgcState *endst, float tol, VerdictOut *vo, int *fails, int force)
     {
         const int k = (int)(blockIdx.x * blockDim.x + threadIdx.x);
         if (k < 1 || k >= K)
@@ -163,7 +164,7 @@ namespace sdhip
         const float a = spec[k].gain, b = endst[k - 1].gain;
         if (__float_as_uint(a) == __float_as_uint(b))
             return;
-        if (fabsf(a - b) <= 1e-6f * fabsf(b))
+        if (fabsf(a - b) <= tol * fabsf(b))
             atomicAdd(&vo->inexact, 1);
         else
             verdict_fail(vo, fails, k, force);
@@ -198,7 +199,10 @@ namespace sdhip
             verdict_fail(vo, fails, k, force);
     }
     // dm[k] = quarter/half/eighth turns chunk k's frame is ahead of chunk k-1's (0 for a bit-exact or re-run boundary)
-    __global__ void k_costas_verdict(int K, const CostasState *spec, const CostasState *endst, double rot_unit, int rot_mod, double tol_phase, double tol_freq,
+    // tol_tight: the hand-off window proper (the soft-symbol contract: a phase step of d rad is a relative symbol error of d) -- outside it the chunk is re-run from
+    // the predecessor's exact state until it is back on the speculative trajectory (a checkpoint, typically the first: the step decays within ~tau ln(d / tol) samples);
+    // tol_phase: the WIDE window -- outside it the lane had not locked at all (counted in VerdictOut::wide: what the stage's warm-up adaptation goes by)
+    __global__ void k_costas_verdict(int K, const CostasState *spec, const CostasState *endst, double rot_unit, int rot_mod, double tol_phase, double tol_tight, double tol_freq,
                                      int *dm, VerdictOut *vo, int *fails, int force)
     {
         const int k = (int)(blockIdx.x * blockDim.x + threadIdx.x);
@@ -214,7 +218,8 @@ namespace sdhip
                 const double dphi = (double)a.phase - (double)b.phase;
                 const long long d = llround(dphi / rot_unit);
                 const double resid = dphi - (double)d * rot_unit;
-                if (fabs(resid) < tol_phase && fabs((double)a.freq - (double)b.freq) < tol_freq)
+                const bool in_wide = fabs(resid) < tol_phase && fabs((double)a.freq - (double)b.freq) < tol_freq;
+                if (in_wide && (fabs(resid) < tol_tight || force))
                 {
                     d_out = (int)(((d % rot_mod) + rot_mod) % rot_mod);
                     if (d_out != 0)
@@ -222,14 +227,18 @@ namespace sdhip
                     atomicAdd(&vo->inexact, 1);
                 }
                 else
+                {
+                    if (!in_wide)
+                        atomicAdd(&vo->wide, 1);
                     verdict_fail(vo, fails, k, force); // re-run continues in the previous chunk's frame: dm = 0
+                }
             }
         }
         dm[k] = d_out;
     }
     // Fused AGC + filter + Costas stage: one verdict per boundary = the AGC + filter rule (gain and the gain 32 samples earlier, bit-equal
     // or within 1e-6) AND the Costas rule (bit-equal, or inside the windows on one of the loop's stable points: dm = the frame change).
-    __global__ void k_afc_verdict(int K, const AfcState *spec, const AfcState *endst, double rot_unit, int rot_mod, double tol_phase, double tol_freq, int *dm,
+    __global__ void k_afc_verdict(int K, const AfcState *spec, const AfcState *endst, double rot_unit, int rot_mod, double tol_phase, double tol_tight, double tol_freq, int *dm,
                                   VerdictOut *vo, int *fails, int force)
     {
         const int k = (int)(blockIdx.x * blockDim.x + threadIdx.x);
@@ -243,13 +252,14 @@ namespace sdhip
             const bool agc_same = __float_as_uint(ga) == __float_as_uint(gb) && __float_as_uint(la) == __float_as_uint(lb);
             const bool agc_ok = agc_same || (fabsf(ga - gb) <= 1e-6f * fabsf(gb) && fabsf(la - lb) <= 1e-6f * fabsf(lb));
             const bool cos_same = __float_as_uint(a.phase) == __float_as_uint(b.phase) && __float_as_uint(a.freq) == __float_as_uint(b.freq);
-            bool ok = agc_ok;
+            bool ok = agc_ok, in_wide = agc_ok;
             if (ok && !cos_same)
             {
                 const double dphi = (double)a.phase - (double)b.phase;
                 const long long d = llround(dphi / rot_unit);
                 const double resid = dphi - (double)d * rot_unit;
-                ok = fabs(resid) < tol_phase && fabs((double)a.freq - (double)b.freq) < tol_freq;
+                in_wide = fabs(resid) < tol_phase && fabs((double)a.freq - (double)b.freq) < tol_freq;
+                ok = in_wide && (fabs(resid) < tol_tight || force); // (a forced boundary inside the wide window still books its frame change)
                 if (ok)
                 {
                     d_out = (int)(((d % rot_mod) + rot_mod) % rot_mod);
@@ -257,6 +267,8 @@ namespace sdhip
                         atomicAdd(&vo->rotated, 1);
                 }
             }
+            if (!ok && !in_wide)
+                atomicAdd(&vo->wide, 1);
             if (!ok)
                 verdict_fail(vo, fails, k, force); // re-run continues in the previous chunk's frame: dm = 0
             else if (!(agc_same && cos_same))
@@ -295,7 +307,7 @@ namespace sdhip
     }
     // symbol hand-off at an M&M boundary (see DemodEngine::process): skip[k] symbols dropped at the head of chunk k, extra[k-1]
     // look-ahead symbols of chunk k-1 appended
-    __global__ void k_mm_verdict(int K, const MmCert *spec, const MmCert *endst, const int *counts, double tol, double tol_tight, int *skip, int *extra,
+    __global__ void k_mm_verdict(int K, const MmCert *spec, const MmCert *endst, const int *counts, double tol, double tol_tight, float tol_omega, int *skip, int *extra,
                                  VerdictOut *vo, int *fails, int force)
     {
         const int k = (int)(blockIdx.x * blockDim.x + threadIdx.x);
@@ -316,7 +328,7 @@ namespace sdhip
             const double d = (double)(a.inc - b.inc) + ((double)a.mu - (double)b.mu);
             const double om = (double)b.omega;
             const long long r = llround(d / om);
-            if (fabs(d - (double)r * om) < tol && fabsf(a.omega - b.omega) < 1e-3f * fabsf(b.omega))
+            if (fabs(d - (double)r * om) < tol && fabsf(a.omega - b.omega) < tol_omega)
             {
                 if (fabs(d - (double)r * om) >= tol_tight)
                     atomicAdd(&vo->loose, 1);
@@ -569,16 +581,21 @@ namespace sdhip
         // what sdhip_demod_get_stats hands out while a call is in flight on another thread (the host path's worker): the snapshot the previous call left
         std::mutex stats_mu;
         sdhip_demod_stats stats_pub{};
-        std::atomic<bool> stats_busy{false};
+        int stats_busy = 0; // calls in flight (under stats_mu; a count: a nested or second process() must not clear it early -- ADVICE r5)
         struct StatsScope
         {
             DemodEngine &e;
-            explicit StatsScope(DemodEngine &en) : e(en) { e.stats_busy = true; }
+            explicit StatsScope(DemodEngine &en) : e(en)
+            { // under the lock (a getter that has seen "not busy" is copying `stats` with the lock held), and the snapshot is taken BEFORE the call touches `stats`
+                std::lock_guard<std::mutex> lk(e.stats_mu);
+                if (e.stats_busy++ == 0)
+                    e.stats_pub = e.stats;
+            }
             ~StatsScope()
             {
                 std::lock_guard<std::mutex> lk(e.stats_mu);
-                e.stats_pub = e.stats;
-                e.stats_busy = false;
+                if (--e.stats_busy == 0)
+                    e.stats_pub = e.stats;
             }
         };
 
@@ -862,8 +879,8 @@ namespace sdhip
             const char *v = getenv(name);
             return (v && *v) ? atoll(v) : dflt;
         }
-        // Chunk length of one speculative stage: one lane per chunk, `lanes` lanes wanted. Measured (tools/sweep.sh, sweep_wl.sh,
-        // tools/gpu_p.sh, tools/ubench/lane_layout.hip): a lane streams its chunk in 64-byte blocks, and what the memory
+        // Chunk length of one speculative stage: one lane per chunk, `lanes` lanes wanted. Measured (round 2's sweeps, profiles/history/r02/r02_sweeps.txt;
+        // tools/ubench/lane_layout.hip): a lane streams its chunk in 64-byte blocks, and what the memory
         // system delivers for that pattern depends on how many lanes there are and how much each asks for at a time -- 65 k lanes
         // with 256 bytes per load group reach 4.5 TB/s (read + write) in a bare copy loop, 196 k lanes with 128 bytes 3.6. So every
         // stage runs ONE wave per SIMD (1024 SIMDs x 64 lanes, a little less so that no SIMD gets two) with 256-byte load groups
@@ -886,7 +903,7 @@ namespace sdhip
             static const char *names[3] = {"SDHIP_LANES_AGC", "SDHIP_LANES_COSTAS", "SDHIP_LANES_MM"};
             // M&M: one wave per SIMD. Round 3 / 4 ran 98 304 lanes (one and a half waves: 13.0 ms against 15.5 at 65 280 on MetOp); since the symbol loop's
             // wave-uniform fast paths (round 5: 185 -> 86 instructions per symbol) a lone wave per SIMD is no slower per lane than two sharing one, and the
-            // longer chunks of 65 280 lanes pay less warm-up: 11.2 ms against 13.3 (98 304) and 13.2 (130 560), parity 99.614 % against 99.592 % (profiles/r05_d_ab_metop_ahrpt.txt)
+            // longer chunks of 65 280 lanes pay less warm-up: 11.2 ms against 13.3 (98 304) and 13.2 (130 560), parity 99.614 % against 99.592 % (profiles/history/r05/r05_d_ab_metop_ahrpt.txt)
             static const long long dflt[3] = {65280, 65280, 65280};
             static const long long min_len[3] = {2048, 2048, 2048};
             long long lanes = std::max<long long>(64, env_int(names[st], dflt[st]));
@@ -911,7 +928,7 @@ namespace sdhip
         // speculation's start values or warm-up length were off, not a few boundaries. It may re-launch the whole stage with better
         // ones (true = it did: judge again from scratch; it is then asked again if that judgement still fails as widely).
         template <class Verdict, class SpecFix, class Launch, class Respec>
-        VerdictOut verify_fix(const char *stage, const int &K, Verdict verdict, SpecFix specfix, Launch relaunch, Respec respec)
+        VerdictOut verify_fix(const char *stage, const int &K, Verdict verdict, SpecFix specfix, Launch relaunch, Respec respec, bool wide_counts = false)
         {
             int respecs = 0;
             d_vout.reserve(1);
@@ -935,10 +952,13 @@ namespace sdhip
                 SD_HIP(hipMemcpyAsync(h_vout.p, d_vout.p, sizeof(VerdictOut), hipMemcpyDeviceToHost, stream));
                 SD_HIP(hipStreamSynchronize(stream));
                 const int nf = h_vout.p->nfail;
-                if (rounds == 0 && respecs < 8 && nf + h_vout.p->loose > std::max(4, K / 8))
+                // (carrier stages: a boundary inside the wide window but outside the tight one is re-run, not a sign of a short warm-up -- their verdicts count the
+                // others in VerdictOut::wide; stages without the distinction leave it at zero and every failure counts)
+                const int nwide = wide_counts ? h_vout.p->wide : nf;
+                if (rounds == 0 && respecs < 8 && nwide + h_vout.p->loose > std::max(4, K / 8))
                 {
                     respecs++;
-                    if (respec(nf + h_vout.p->loose))
+                    if (respec(nwide + h_vout.p->loose))
                     {
                         if (getenv("SDHIP_DEBUG"))
                             fprintf(stderr, "[sdhip] %-6s %d of %d boundaries missed their (tight) window at first sight: stage re-launched\n", stage, nf + h_vout.p->loose, K);
@@ -1014,7 +1034,7 @@ namespace sdhip
                 "cpll", g.K,
                 [&](VerdictOut *vo, int *fails, int force) {
                     hipLaunchKernelGGL(k_costas_verdict, dim3((g.K + 255) / 256), dim3(256), 0, stream, g.K, d_cpll_spec.p, d_cpll_end.p, 2.0 * design::PI, 1, tol_phase,
-                                       tol_freq, d_dm.p, vo, fails, force);
+                                       tol_phase, tol_freq, d_dm.p, vo, fails, force);
                 },
                 [&](const int *list, int nr) {
                     // a re-run starts from the predecessor's end state as it is: with one stable point per turn the earlier run's
@@ -1177,7 +1197,7 @@ namespace sdhip
             const long long w_cos_cap = 1 << 20;
             // 20 loop time constants: the lane starts next to a stable point (feed-forward phase estimate over est_len samples) at the
             // stream's own frequency, so it reaches the float floor of two trajectories sooner than the 24 the stand-alone stage allows.
-            // Measured: MetOp 17 GB on the GPU (profiles/r03_a_ab_metop.txt) soft parity 0.99617 at 16 against 0.99612 at 24, 0.99591 at 12;
+            // Measured: MetOp 17 GB on the GPU (profiles/history/r03/r03_a_ab_metop.txt) soft parity 0.99617 at 16 against 0.99612 at 24, 0.99591 at 12;
             // on the host twin with 8192-sample chunks (three times the boundaries) NPP's pll_bw 0.002 loses 0.27 % of the symbols at 16
             // and nothing at 20 (0.00393 against 0.00389 beyond 1e-5).
             const double taus = (double)env_int("SDHIP_COSTAS_TAUS", 20);
@@ -1187,13 +1207,16 @@ namespace sdhip
             W = env_int("SDHIP_W_COSTAS", W);
             W = (std::min<long long>(W, w_cos_cap) + 255) / 256 * 256;
             // two waves per SIMD: the stage is bound by its dependent chains (AGC sqrt, sincos in double), not by its loads -- measured
-            // (MetOp, profiles/r03_a_ab_metop.txt): 26.4 ms with 65 280 lanes, 21.3 with 98 304, 19.5 with 130 560 (226 VGPRs: two waves fit)
+            // (MetOp, profiles/history/r03/r03_a_ab_metop.txt): 26.4 ms with 65 280 lanes, 21.3 with 98 304, 19.5 with 130 560 (226 VGPRs: two waves fit)
             const long long lanes = std::max<long long>(64, env_int("SDHIP_LANES_AFC", 130560));
             int L = pick_L(n, ST_COSTAS);
             if (!cfg.exact && cfg.chunk_len <= 0 && !getenv("SDHIP_CHUNK") && !getenv("SDHIP_CHUNK_COSTAS") && !getenv("SDHIP_LANES_COSTAS"))
                 L = (int)std::min<long long>(std::max<long long>(((n + lanes - 1) / lanes + 63) / 64 * 64, 2048), 1 << 20);
             L = (int)(((long long)L + 63) / 64 * 64); // chunk starts on whole load groups (the lane finds its chunk start on a group boundary)
             const double tol_phase = env_int("SDHIP_COSTAS_TOL_URAD", 10000) * 1e-6, tol_freq = env_int("SDHIP_COSTAS_TOL_NFREQ", 40000) * 1e-9;
+            // the hand-off window proper (round 6; see costas_stage): a boundary between it and the wide window is re-run from the exact state and stops at the first
+            // checkpoint at which it is back within it
+            const double tol_tight = std::min(tol_phase, env_int("SDHIP_COSTAS_TIGHT_URAD", 10) * 1e-6);
             AfcParams ap;
             AfcCkptCfg ck;
             // chunk-parallel mode: the stage's fast arithmetic (demod_kernels.hip, sd_sincosf_fast) -- inside the 1e-5 contract that mode is
@@ -1208,7 +1231,7 @@ namespace sdhip
                 d_afc_spec.reserve(cg.K);
                 d_afc_end.reserve(cg.K);
                 ck.len = 2048;
-                ck.tol_phase = (float)tol_phase;
+                ck.tol_phase = (float)tol_tight;
                 ck.tol_freq = (float)tol_freq;
                 if (use_ckpt && !cfg.exact)
                 {
@@ -1226,7 +1249,7 @@ namespace sdhip
             verify_fix(
                 "afc", cg.K,
                 [&](VerdictOut *vo, int *fails, int force) {
-                    hipLaunchKernelGGL(k_afc_verdict, dim3((cg.K + 255) / 256), dim3(256), 0, stream, cg.K, d_afc_spec.p, d_afc_end.p, rot_unit, rot_mod, tol_phase, tol_freq,
+                    hipLaunchKernelGGL(k_afc_verdict, dim3((cg.K + 255) / 256), dim3(256), 0, stream, cg.K, d_afc_spec.p, d_afc_end.p, rot_unit, rot_mod, tol_phase, tol_tight, tol_freq,
                                        d_dm.p, vo, fails, force);
                 },
                 [&](const int *list, int nr) {
@@ -1253,7 +1276,8 @@ namespace sdhip
                     setup(std::max<long long>(cg.W, w_cos_learned));
                     launch_afc(in, out, cg, ap, d_afc_start.p, d_afc_spec.p, d_afc_end.p, nullptr, 0, stream, ck, afc_fast);
                     return true;
-                });
+                },
+                true);
             stats.chunks += 2 * (unsigned)cg.K; // the chunks of two loop stages
             {
                 const int nt = (cg.K + 1023) / 1024;
@@ -1279,6 +1303,68 @@ namespace sdhip
                 cos_s.phase = (float)ph;
             }
             stats.freq_hz = (float)(((double)cos_s.freq / (2.0 * design::PI)) * (double)final_samplerate);
+        }
+
+        // ---- AGC with scanned start gains (see agc_stage): AIN -> OUT
+        DevBuf<double> d_agc_partial;
+        DevBuf<float> d_agc_starts;
+        bool agc_scan_stage(const cf32 *AIN, cf32 *OUT, long long n, int L, double tau)
+        {
+            const ChunkGeom g = make_geom(n, L, 0);
+            d_agc_partial.reserve(4 * (size_t)g.K);
+            d_agc_starts.reserve(g.K);
+            d_agc_spec.reserve(g.K);
+            d_agc_end.reserve(g.K);
+            launch_agc_partial(AIN, g, agc_p, d_agc_partial.p, stream);
+            std::vector<double> part(4 * (size_t)g.K);
+            SD_HIP(hipMemcpyAsync(part.data(), d_agc_partial.p, part.size() * sizeof(double), hipMemcpyDeviceToHost, stream));
+            SD_HIP(hipStreamSynchronize(stream));
+            std::vector<float> starts((size_t)g.K);
+            double gs = (double)agc_s.gain;
+            bool valid = true;
+            for (int k = 0; k < g.K; k++)
+            {
+                starts[k] = (float)gs;
+                valid = valid && part[4 * (size_t)k + 3] != 0.0 && gs == gs;
+                gs = std::fmin(part[4 * (size_t)k] * gs + part[4 * (size_t)k + 1], part[4 * (size_t)k + 2]);
+            }
+            starts[0] = agc_s.gain;
+            if (!valid)
+            { // rate |x| > 1 somewhere (the gain may have gone through zero: |gain| is not what the maps assume) or a NaN: this call runs on warm-ups
+                if (getenv("SDHIP_DEBUG"))
+                    fprintf(stderr, "[sdhip] agc    scan: a sample with rate * |x| > 1 (or a NaN) in this call: warm-up schedule instead\n");
+                return false;
+            }
+            SD_HIP(hipMemcpyAsync(d_agc_starts.p, starts.data(), starts.size() * sizeof(float), hipMemcpyHostToDevice, stream));
+            SD_HIP(hipMemcpyAsync(d_agc_start.p, &agc_s, sizeof(agc_s), hipMemcpyHostToDevice, stream));
+            AgcParams ap = agc_p;
+            ap.starts = d_agc_starts.p;
+            ChunkCkpt agc_ck;
+            const double steps = std::min((double)L, std::max(1.0, tau));
+            const float tol = (float)std::min(1e-4, std::max(1e-6, 6.0 * 3e-8 * std::sqrt(steps)));
+            if (use_ckpt)
+            {
+                agc_ck.len = 2048;
+                agc_ck.per_chunk = L / agc_ck.len + 1;
+                d_agc_ck.reserve((size_t)g.K * agc_ck.per_chunk);
+                agc_ck.ck = d_agc_ck.p;
+                agc_ck.tol_a = tol;
+            }
+            launch_agc(AIN, OUT, g, ap, d_agc_start.p, d_agc_spec.p, d_agc_end.p, nullptr, 0, stream, agc_ck);
+            const int vb = (g.K + 255) / 256;
+            verify_fix(
+                "agc-scan", g.K,
+                [&](VerdictOut *vo, int *fails, int force) {
+                    hipLaunchKernelGGL(k_agc_verdict, dim3(vb), dim3(256), 0, stream, g.K, d_agc_spec.p, d_agc_end.p, tol, vo, fails, force);
+                },
+                [&](const int *list, int nr) {
+                    hipLaunchKernelGGL(k_spec_from_prev<AgcState>, dim3((nr + 255) / 256), dim3(256), 0, stream, list, nr, d_agc_spec.p, d_agc_end.p);
+                },
+                [&](const int *redo, int nr) { launch_agc(AIN, OUT, g, ap, d_agc_start.p, d_agc_spec.p, d_agc_end.p, redo, nr, stream, agc_ck); });
+            stats.chunks += g.K;
+            SD_HIP(hipMemcpyAsync(&agc_s, d_agc_end.p + (g.K - 1), sizeof(agc_s), hipMemcpyDeviceToHost, stream));
+            SD_HIP(hipStreamSynchronize(stream));
+            return true;
         }
 
         // Process n input samples resident on the device. Outputs go to d_soft / d_syms (device).
@@ -1316,6 +1402,19 @@ namespace sdhip
             agc_p.init_gain = g_est;
             agc_p.fast = (nd.on && !cfg.exact && env_int("SDHIP_FAST_MATH", 1) != 0) ? 1 : 0;
             int L = pick_L(n, ST_AGC);
+            // ---- start gains by affine scan (round 6). A warm-up costs every lane W sequential steps; where that is a large part of the lane's work -- the ndsp
+            // block's rate 1e-4 needs 290 k samples of it, 24.8 of the chain's 53.7 ms per 2^30 samples -- the gain at every chunk start is COMPUTED instead: the
+            // recurrence is a clamped affine map of the gain whose coefficients depend on the input only (demod_kernels.h: launch_agc_partial), one pass composes
+            // the map of every chunk in double, the host chains them over the K chunks, and the lanes run their chunks with no warm-up at all. The boundary
+            // certificate then compares the scan's start value with the predecessor lane's float end state: they differ by the rounding noise the float
+            // recurrence collects over min(L, tau) steps (~3e-8 sqrt(min(L, tau) / 2) relative), so its window is six of those instead of 1e-6; a boundary
+            // outside it is re-run from the predecessor's state like any other; a call with a sample outside the scan's model (rate |x| > 1: the gain may pass through zero; a NaN) runs on warm-ups. The fused AGC + filter (+ Costas) stages of
+            // the legacy chain keep their warm-up: at rate 1e-2 it is 15 % more samples of AGC-only work in a stage bound by the Costas loop's arithmetic, less
+            // than a pass over the input for the scan would cost. SDHIP_AGC_SCAN=0/1 forces the choice.
+            const bool scan_default = !fuse_agc_fir && cfg.warmup <= 0 && !getenv("SDHIP_W_AGC") && 4 * W > (long long)L;
+            const bool use_scan = !cfg.exact && !fuse_agc_fir && env_int("SDHIP_AGC_SCAN", scan_default ? 1 : 0) != 0;
+            if (use_scan && agc_scan_stage(AIN, OUT, n, L, tau))
+                return; // (false: a sample outside the scan's model in this call -- the warm-up schedule below takes it)
             // a slow loop (the ndsp block's default rate 1e-4: 24 tau ~ 4e5 samples) on many short chunks would run K lanes over W + L
             // samples each -- a hundred times the stream through L2 / HBM for no gain in wall time, which is (W + L) sequential steps
             // either way: keep the chunk at least half the warm-up (work <= 3 n, still thousands of lanes on a bench-sized call)
@@ -1370,7 +1469,7 @@ namespace sdhip
             verify_fix(
                 "agc", g.K,
                 [&](VerdictOut *vo, int *fails, int force) {
-                    hipLaunchKernelGGL(k_agc_verdict, dim3(vb), dim3(256), 0, stream, g.K, d_agc_spec.p, d_agc_end.p, vo, fails, force);
+                    hipLaunchKernelGGL(k_agc_verdict, dim3(vb), dim3(256), 0, stream, g.K, d_agc_spec.p, d_agc_end.p, 1e-6f, vo, fails, force);
                 },
                 [&](const int *list, int nr) {
                     hipLaunchKernelGGL(k_spec_from_prev<AgcState>, dim3((nr + 255) / 256), dim3(256), 0, stream, list, nr, d_agc_spec.p, d_agc_end.p);
@@ -1446,6 +1545,12 @@ namespace sdhip
             // launch whose slowest lane runs alone for over a millisecond (measured: +1.2 ms on a 96 ms step). They are counted
             // (chunks_inexact); anything beyond the window -- a lane that has not locked -- is re-run from the exact state.
             const double tol_phase = env_int("SDHIP_COSTAS_TOL_URAD", 10000) * 1e-6, tol_freq = env_int("SDHIP_COSTAS_TOL_NFREQ", 40000) * 1e-9;
+            // Round 6: those boundaries ARE re-run now. Since the re-run lanes stop at a checkpoint (round 4) the second launch costs what 2048 samples of the
+            // slowest lane cost, not a chunk; and at bench size the kicked hand-offs were what was left on the reference's own interpolator arm beyond 1e-5
+            // (4 721 symbols of 15.6 M, max 3.6e-2 rad: VERDICT r5 weak 2). TIGHT window 1e-5 rad = the contract (SDHIP_COSTAS_TIGHT_URAD); measured on the twin
+            // (test_every_symbol_beyond_tolerance_is_an_arm_flip): same-arm symbols beyond 1e-5 57 -> 20 of 393 k (GOES), 29 -> 0 (NPP), max angle 3.3e-5 -> 1.3e-5.
+            // The wide window keeps its role: what lies outside it is an unlocked lane and counts towards the warm-up adaptation.
+            const double tol_tight = std::min(tol_phase, env_int("SDHIP_COSTAS_TIGHT_URAD", 10) * 1e-6);
             ChunkCkpt cos_ck;
             auto costas_setup = [&](long long Wn) {
                 cos_p.est_len = (int)std::min<long long>(env_int("SDHIP_COSTAS_EST", 256), Wn / 2);
@@ -1458,7 +1563,7 @@ namespace sdhip
                     cos_ck.per_chunk = L / cos_ck.len + 1;
                     d_cos_ck.reserve((size_t)cg.K * cos_ck.per_chunk);
                     cos_ck.ck = d_cos_ck.p;
-                    cos_ck.tol_a = (float)tol_phase;
+                    cos_ck.tol_a = (float)tol_tight;
                     cos_ck.tol_b = (float)tol_freq;
                     if (getenv("SDHIP_DEBUG"))
                     {
@@ -1475,7 +1580,7 @@ namespace sdhip
             verify_fix(
                 "costas", cg.K,
                 [&](VerdictOut *vo, int *fails, int force) {
-                    hipLaunchKernelGGL(k_costas_verdict, dim3((cg.K + 255) / 256), dim3(256), 0, stream, cg.K, d_cos_spec.p, d_cos_end.p, rot_unit, rot_mod, tol_phase, tol_freq,
+                    hipLaunchKernelGGL(k_costas_verdict, dim3((cg.K + 255) / 256), dim3(256), 0, stream, cg.K, d_cos_spec.p, d_cos_end.p, rot_unit, rot_mod, tol_phase, tol_tight, tol_freq,
                                        d_dm.p, vo, fails, force);
                 },
                 [&](const int *list, int nr) {
@@ -1509,7 +1614,8 @@ namespace sdhip
                         return false;
                     launch_costas(A, B, cg, cos_p, d_cos_start.p, d_cos_spec.p, d_cos_end.p, nullptr, 0, stream, cos_ck);
                     return true;
-                });
+                },
+                true);
             stats.chunks += cg.K;
             if (cos_ck.work)
                 ck_report("costas", 1);
@@ -1610,6 +1716,16 @@ namespace sdhip
             const double MM_TOL_TIGHT = s2_front ? mm_windows_tight : 2e-4;
             const double MM_TOL = getenv("SDHIP_MM_TOL_MICRO") ? env_int("SDHIP_MM_TOL_MICRO", 5000) * 1e-6
                                   : (getenv("SDHIP_MM_TOL_MILLI") ? env_int("SDHIP_MM_TOL_MILLI", 5) * 1e-3 : (s2_front ? mm_windows_tol : 5e-3));
+            // ... and the window of the loop's RATE state (round 6). The timing state alone does not make a hand-off: a lane whose timing passes through the
+            // predecessor's while its rate is still off by d (samples per symbol) is carried away again by up to ~0.74 d / (gain_mu Kd) samples before the loop
+            // (critically damped: gain_omega = gain_mu^2 / 4) pulls it back over some hundred symbols. The old window, 1e-3 of omega (2.9e-3 samples per symbol on GOES),
+            // let such lanes through: they are the runs of symbols interpolated 2 - 3 arms from the reference's position (5 812 of 12.4 M symbols on GOES at bench
+            // size; reproduced on the twin with the bench's chunk length: tools/twin/arm_probe.py). Window = what keeps that excursion inside the
+            // timing window: MM_TOL gain_mu / 2.
+            const float MM_TOL_OMEGA = getenv("SDHIP_MM_TOL_OMEGA_NANO") ? (float)(env_int("SDHIP_MM_TOL_OMEGA_NANO", 0) * 1e-9)
+                                                                          : (s2_front ? 1e-3f * final_sps // (the DVB-S2 module's own windows: what it promises are the BBFRAMEs)
+                                                                                      : (float)(MM_TOL * std::max(1e-4, (double)cfg.clock_gain_mu) * 0.5));
+            mm_p.tol_omega = MM_TOL_OMEGA;
             MmCkpt *ckp = nullptr;
             int ck_per_chunk = 0;
             auto mm_setup = [&](long long Wn) {
@@ -1655,7 +1771,7 @@ namespace sdhip
                 "mm", g.K,
                 [&](VerdictOut *vo, int *fails, int force) {
                     hipLaunchKernelGGL(k_mm_verdict, dim3((g.K + 255) / 256), dim3(256), 0, stream, g.K, d_mm_spec_c.p, d_mm_end_c.p, d_counts.p, MM_TOL, std::min(MM_TOL, MM_TOL_TIGHT),
-                                       d_skip.p, d_extra.p, vo, fails, force);
+                                       MM_TOL_OMEGA, d_skip.p, d_extra.p, vo, fails, force);
                 },
                 [&](const int *list, int nr) {
                     if (getenv("SDHIP_DEBUG"))
@@ -2409,7 +2525,7 @@ extern "C"
     {
         DemodEngine *e = (DemodEngine *)h;
         std::lock_guard<std::mutex> lk(e->stats_mu);
-        *st = e->stats_busy.load() ? e->stats_pub : e->stats;
+        *st = e->stats_busy > 0 ? e->stats_pub : e->stats;
         return 0;
     }
     int sdhip_demod_set_tap(void *h, int mode)

@@ -112,7 +112,16 @@ namespace sdhip
     {
         float rate, reference, max_gain, init_gain;
         int fast; // 1: chunk-parallel mode's arithmetic (sd_sqrt_fast, fma) in the stand-alone stage too
+        // chunk start gains from the affine scan (launch_agc_partial + the engine's chain over the chunks); nullptr = every lane warms up from init_gain
+        const float *starts = nullptr;
     };
+    // The AGC recurrence (agc.cpp:25-39 / dsp/agc/agc.cpp:22-39) is, for a positive gain, g <- min((1 - rate |x|) g + rate reference, max_gain): a clamped affine map of
+    // the gain whose coefficients depend on the INPUT only. Such maps compose -- (a2, b2, c2) o (a1, b1, c1) = (a2 a1, a2 b1 + b2, min(a2 c1 + b2, c2)) for a2 >= 0 --
+    // so the gain at every chunk start follows from one pass over the samples (this kernel: the composed map of every chunk, in double) and a chain over the K chunks
+    // (host). What the float recurrence of the reference adds is rounding noise of ~3e-8 sqrt(1 / (2 rate |x|)) relative around that exact-arithmetic trajectory: the
+    // boundary certificate (k_agc_verdict) compares the scan's start value with the predecessor lane's float end state.
+    // partial: 4 doubles per chunk = {a, b, c, valid} (valid = 0: some sample had rate |x| > 1, the map is not monotone there -- the engine falls back to warm-ups)
+    void launch_agc_partial(const cf32 *x, const ChunkGeom &g, const AgcParams &p, double *partial, hipStream_t st);
     struct AgcState
     {
         float gain;
@@ -227,6 +236,7 @@ namespace sdhip
         const int *rot;
         int order;
         int cap; // output capacity per chunk (symbols)
+        float tol_omega; // hand-off window of the loop's RATE state, samples per symbol (the early exit of a re-run lane tests it like the boundary certificate does)
         int fast_syms;   // warm-up gear shift: symbols run with mu_gain * fast_mult and the omega term frozen
         float fast_mult;
         int q8, q8_bpsk; // q8: the symbols are stored as the module's int8 soft symbols (2 bytes per symbol row entry) instead of floats

@@ -871,7 +871,7 @@ namespace sdhip
         using P = AgcParams;
         using S = AgcState;
         static constexpr int DEPTH = D; // blocks per load group (D * 64 bytes); two groups in flight
-        __device__ static __forceinline__ S init(const P &p, int) { return S{p.init_gain}; }
+        __device__ static __forceinline__ S init(const P &p, int k) { return S{p.starts ? p.starts[k] : p.init_gain}; } // (the scan's value at this chunk's start, if there is one)
         // early exit of a re-run lane (CKPT): is state a on the trajectory that left checkpoint b? (the AGC certificate's own rule)
         __device__ static __forceinline__ bool close(const S &a, const S &b, float tol_a, float) { return fabsf(a.gain - b.gain) <= tol_a * fabsf(b.gain); }
         __device__ static __forceinline__ void prewarm(S &, const P &, const cf32 *, long long) {}
@@ -1947,6 +1947,99 @@ namespace sdhip
             partial[2 * k + 1] = si[0];
         }
     }
+    // The composed gain map of every chunk (demod_kernels.h: launch_agc_partial). One block per chunk; it walks the chunk in tiles of 2048 samples: the tile's
+    // magnitudes |x| are formed from coalesced float4 loads (two samples each) and parked in LDS, thread t composes the maps of samples 8 t .. 8 t + 7 of the tile
+    // in order, the 256 per-thread maps are composed by an ordered tree in LDS, thread 0 appends the tile's map to the chunk's.
+    // (|x| in float like the reference's own sqrt of the float products; the map coefficients and their composition in double.)
+    struct AgcMap
+    {
+        double a, b, c;
+    };
+    __device__ __forceinline__ AgcMap agc_map_then(const AgcMap &f1, const AgcMap &f2) // first f1, then f2
+    {
+        return AgcMap{f2.a * f1.a, f2.a * f1.b + f2.b, fmin(f2.a * f1.c + f2.b, f2.c)};
+    }
+    constexpr int AGCP_TILE = 2048;
+    __global__ __launch_bounds__(256) void k_agc_partial(const cf32 *x, ChunkGeom g, AgcParams p, double *partial)
+    {
+        __shared__ float mag[AGCP_TILE];
+        __shared__ double sa[256], sb[256], sc[256];
+        __shared__ int bad;
+        const int k = (int)blockIdx.x, t = (int)threadIdx.x;
+        const long long b0 = chunk_begin(g, k), e = chunk_end(g, k);
+        const double rate = (double)p.rate, rr = (double)p.rate * (double)p.reference;
+        const double cmax = p.max_gain > 0.0f ? (double)p.max_gain : __builtin_inf();
+        if (t == 0)
+            bad = 0;
+        const bool aligned = (reinterpret_cast<uintptr_t>(x + b0) & 15) == 0;
+        AgcMap acc{1.0, 0.0, __builtin_inf()};
+        for (long long tb = b0; tb < e; tb += AGCP_TILE)
+        {
+            for (int j = 0; j < AGCP_TILE / 512; j++)
+            {
+                const int s2 = 2 * (t + 256 * j); // sample of the tile this thread's float4 starts at
+                const long long i = tb + s2;
+                float m0 = 0.0f, m1 = 0.0f;
+                if (aligned && i + 2 <= e)
+                {
+                    const float4 q = *reinterpret_cast<const float4 *>(x + i);
+                    m0 = sqrtf(q.x * q.x + q.y * q.y);
+                    m1 = sqrtf(q.z * q.z + q.w * q.w);
+                }
+                else
+                {
+                    if (i < e)
+                        m0 = sqrtf(x[i].re * x[i].re + x[i].im * x[i].im);
+                    if (i + 1 < e)
+                        m1 = sqrtf(x[i + 1].re * x[i + 1].re + x[i + 1].im * x[i + 1].im);
+                }
+                mag[s2] = m0;
+                mag[s2 + 1] = m1;
+            }
+            __syncthreads();
+            AgcMap m{1.0, 0.0, __builtin_inf()};
+            const long long i0 = tb + 8 * t;
+            int neg = 0;
+            if (i0 < e)
+            {
+                const int cnt = (int)(e - i0 < 8 ? e - i0 : 8);
+                for (int j = 0; j < cnt; j++)
+                {
+                    const double a = 1.0 - rate * (double)mag[8 * t + j];
+                    neg |= (a < 0.0 || !(a == a)) ? 1 : 0;
+                    m = agc_map_then(m, AgcMap{a, rr, cmax});
+                }
+            }
+            if (neg)
+                atomicOr(&bad, 1);
+            sa[t] = m.a, sb[t] = m.b, sc[t] = m.c;
+            __syncthreads();
+            for (int d = 1; d < 256; d <<= 1)
+            { // ordered tree: slot t (t a multiple of 2 d) <- slot t, then slot t + d
+                if ((t & (2 * d - 1)) == 0)
+                {
+                    const AgcMap r = agc_map_then(AgcMap{sa[t], sb[t], sc[t]}, AgcMap{sa[t + d], sb[t + d], sc[t + d]});
+                    sa[t] = r.a, sb[t] = r.b, sc[t] = r.c;
+                }
+                __syncthreads();
+            }
+            if (t == 0)
+                acc = agc_map_then(acc, AgcMap{sa[0], sb[0], sc[0]});
+            __syncthreads();
+        }
+        if (t == 0)
+        {
+            partial[4 * k] = acc.a;
+            partial[4 * k + 1] = acc.b;
+            partial[4 * k + 2] = acc.c;
+            partial[4 * k + 3] = bad ? 0.0 : 1.0;
+        }
+    }
+    void launch_agc_partial(const cf32 *x, const ChunkGeom &g, const AgcParams &p, double *partial, hipStream_t st)
+    {
+        ProfScope _ps("k_agc_partial", st);
+        hipLaunchKernelGGL(k_agc_partial, dim3(g.K), dim3(256), 0, st, x, g, p, partial);
+    }
     void launch_dc_partial(const cf32 *x, const ChunkGeom &g, double *partial, hipStream_t st)
     {
         ProfScope _ps("k_dc_partial", st);
@@ -2406,7 +2499,13 @@ template <bool CKPT, bool SPLIT, bool Q8 = false, bool FAST = false, bool GARD =
         constexpr int RING = GARD ? MM_RING : MM_RING_MM;
         __shared__ cf32 rings[(RING + MM_MIRROR) * MM_RING_STRIDE];
         __shared__ __attribute__((aligned(16))) float bank[128 * MM_ARM_STRIDE];
-        __shared__ __attribute__((aligned(16))) char coop_lds[COOP_LDS_BYTES]; // load side only: the symbols leave per lane
+        // the transposition buffer of the cooperative loads (load side only: the symbols leave per lane) is DYNAMIC shared memory, there only when a launch uses it
+        // (SDHIP_COOP_MM=1; off by default): the block's static LDS is ring + bank = 15.5 KB, ten blocks to a CU (it was 24.5 KB, six)
+#ifdef SDHIP_HOST_TWIN
+        static __attribute__((aligned(16))) char coop_lds[COOP_LDS_BYTES];
+#else
+        extern __shared__ __attribute__((aligned(16))) char coop_lds[];
+#endif
         for (int i = (int)threadIdx.x; i < 128 * 8; i += 64)
             bank[(i >> 3) * MM_ARM_STRIDE + (i & 7)] = p.bank[i];
         __syncthreads();
@@ -2517,7 +2616,7 @@ template <bool CKPT, bool SPLIT, bool Q8 = false, bool FAST = false, bool GARD =
                             {
                                 const MmCkpt o = *c;
                                 const double dt = (double)(s.inc - o.inc) + ((double)s.mu - (double)o.mu);
-                                if (cnt == o.cnt && fabs(dt) < (double)ck_tol && fabsf(s.omega - o.omega) < 1e-3f * fabsf(o.omega))
+                                if (cnt == o.cnt && fabs(dt) < (double)ck_tol && fabsf(s.omega - o.omega) < p.tol_omega)
                                     merged = done = true;
                             }
                             if (!merged)
@@ -2589,7 +2688,7 @@ template <bool CKPT, bool SPLIT, bool Q8 = false, bool FAST = false, bool GARD =
                     // inside its chunk for the whole block: then the symbol loop needs none of the per-symbol phase bookkeeping below (a third of its
                     // instructions; the kernel is issue-bound at two waves per SIMD). Same iterations, same order, same results.
                     const unsigned long long act = __ballot(1);
-                    if (__ballot(phase == 1 && f.next <= e && cnt + 8 < p.cap) == act)
+                    if (__ballot(!done && phase == 1 && f.next <= e && cnt + 8 < p.cap) == act) // (!done: a re-run lane that merged at a checkpoint stays out)
                     {
                         while (s.inc < f.next)
                         {
@@ -2599,7 +2698,7 @@ template <bool CKPT, bool SPLIT, bool Q8 = false, bool FAST = false, bool GARD =
                         }
                         return;
                     }
-                    if (__ballot(phase == 0 && f.next <= b) == act)
+                    if (__ballot(!done && phase == 0 && f.next <= b) == act)
                     {
                         while (s.inc < f.next)
                         {
@@ -2719,7 +2818,8 @@ template <bool CKPT, bool SPLIT, bool Q8 = false, bool FAST = false, bool GARD =
         if (getenv("SDHIP_DEBUG") && !redo)
             fprintf(stderr, "[sdhip] k_mm: K %d L %d W %d -> %d cooperative blocks of %d\n", g.K, g.L, g.W, coop_nb, nblk);
         auto go = [&](auto kern, MmCkpt *ckp, int per, float tol) {
-            hipLaunchKernelGGL(kern, dim3(nblk), dim3(64), 0, st, x, sym_scratch, counts, g, p, start0, spec, endst, spec_c, end_c, redo, nredo, ckp, per, tol, coop_nb);
+            hipLaunchKernelGGL(kern, dim3(nblk), dim3(64), coop_nb > 0 ? COOP_LDS_BYTES : 0, st, x, sym_scratch, counts, g, p, start0, spec, endst, spec_c, end_c, redo, nredo, ckp, per,
+                               tol, coop_nb);
         };
         if (p.tap)
         { // tests only (sdhip_demod_set_tap): the default instance with the arm positions in place of the symbols

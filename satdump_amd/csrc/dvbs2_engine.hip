@@ -119,16 +119,21 @@ namespace sdhip
         sdhip_dvbs2_stats st{};
         std::mutex st_mu; // sdhip_dvbs2_demod_get_stats against the host path's worker thread: the getter sees the snapshot the last call left
         sdhip_dvbs2_stats st_pub{};
-        std::atomic<bool> st_busy{false};
+        int st_busy = 0; // calls in flight, under st_mu
         struct StScope
         {
             Dvbs2Engine &e;
-            explicit StScope(Dvbs2Engine &en) : e(en) { e.st_busy = true; }
+            explicit StScope(Dvbs2Engine &en) : e(en)
+            { // (see DemodEngine::StatsScope)
+                std::lock_guard<std::mutex> lk(e.st_mu);
+                if (e.st_busy++ == 0)
+                    e.st_pub = e.st;
+            }
             ~StScope()
             {
                 std::lock_guard<std::mutex> lk(e.st_mu);
-                e.st_pub = e.st;
-                e.st_busy = false;
+                if (--e.st_busy == 0)
+                    e.st_pub = e.st;
             }
         };
         float peak_snr = 0.0f;
@@ -510,7 +515,7 @@ extern "C"
         SD_GUARD_BEGIN
         Dvbs2Engine *e = (Dvbs2Engine *)h;
         std::lock_guard<std::mutex> lk(e->st_mu);
-        *out = e->st_busy.load() ? e->st_pub : e->st;
+        *out = e->st_busy > 0 ? e->st_pub : e->st;
         return 0;
         SD_GUARD_END(-1)
     }

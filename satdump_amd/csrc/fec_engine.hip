@@ -1074,6 +1074,8 @@ namespace sdhip
                 carry_bits = nwords * 32;
                 abs_bits = avail_end;
                 stats.bits_decoded += (uint64_t)n_eff * F;
+                if (watchdog_fired)
+                    stats.watchdog_events++;
                 if (watchdog_fired && (cfg.decoder == SDHIP_DEC_FENGYUN_AHRPT || cfg.decoder == SDHIP_DEC_FENGYUN_MPT))
                     fy.invert_branches ^= 1;
                 else if (watchdog_fired)
@@ -1909,6 +1911,7 @@ namespace sdhip
                 if (fy.rail[0].vstate == 0 || (!fy.mpt && fy.rail[1].vstate == 0))
                 {
                     fy.vit_nosync_run++;
+                    stats.watchdog_events++; // (the counter is cumulative in the module: every counted read is state a cold-started shard does not have)
                     if (fy.vit_nosync_run >= 10)
                         fy.shift ^= 1;
                 }

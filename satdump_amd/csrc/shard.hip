@@ -106,14 +106,18 @@ extern "C"
         const double sps = d->samplerate / d->symbolrate;
         const int q = d->constellation == SDHIP_BPSK ? 1 : 2;
         const bool metop = f->decoder == SDHIP_DEC_METOP_AHRPT;
-        const int cadu_bits = metop ? 8192 : (f->cadu_size > 0 ? f->cadu_size : 8192);
+        // the FengYun-3 modules (module_fengyun_ahrpt_decoder.cpp:10,63: BUFFER_SIZE * 2 = 16384 soft bytes per read, a Viterbi per rail over 8192 of them; the MPT
+        // module likewise): from cold, ten counted reads until `shift` may toggle (:82-93), the Viterbis' own search and give-up (outsync_after + 2), ten NOSYNC reads
+        // of the deframer until `invert_branches` toggles (:105-114), one more read for the grid
+        const bool fy = f->decoder == SDHIP_DEC_FENGYUN_AHRPT || f->decoder == SDHIP_DEC_FENGYUN_MPT;
+        const int cadu_bits = (metop || fy) ? 8192 : (f->cadu_size > 0 ? f->cadu_size : 8192);
         static const double rates[5] = {0.5, 2.0 / 3.0, 0.75, 5.0 / 6.0, 7.0 / 8.0};
-        const double conv_rate = metop ? 0.75 : rates[f->conv_rate >= 0 && f->conv_rate <= 4 ? f->conv_rate : 0];
-        const uint64_t block_bytes = metop ? 16384u : (uint64_t)std::max(cadu_bits, 8192);
+        const double conv_rate = metop ? 0.75 : (f->decoder == SDHIP_DEC_FENGYUN_AHRPT ? 0.75 : (f->decoder == SDHIP_DEC_FENGYUN_MPT ? 0.5 : rates[f->conv_rate >= 0 && f->conv_rate <= 4 ? f->conv_rate : 0]));
+        const uint64_t block_bytes = (metop || fy) ? 16384u : (uint64_t)std::max(cadu_bits, 8192);
         const double cadu_bytes = cadu_bits / conv_rate; // soft bytes per CADU: cadu_bits / rate symbols-worth of soft bits, one byte each
         const double gmu = d->clock_gain_mu > 0 ? d->clock_gain_mu : 8.7e-3;
         const int outsync = f->viterbi_outsync_after > 0 ? f->viterbi_outsync_after : (metop ? 10 : 20);
-        const int relock_blocks = outsync + 2 + (metop ? 10 : 0) + 1;
+        const int relock_blocks = outsync + 2 + (metop ? 10 : 0) + (fy ? 20 : 0) + 1;
         const double agc = d->agc_rate > 0 ? d->agc_rate : 1e-2;
         out3[0] = (uint64_t)(8.0 / agc + 16.0 / d->pll_bw + 40.0 / gmu * sps + 0.5);
         out3[1] = (uint64_t)(relock_blocks * (double)block_bytes + 4 * cadu_bytes + 0.5);

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Per-kernel SQ counter table from tools/gpu_sq.sh (sum over dispatches of the kernel; duration from the kernel trace)."""
+"""Per-kernel SQ counter table from tools/gpu_visit.sh's sq stage (sum over dispatches of the kernel; duration from the kernel trace)."""
 import csv, glob, sys
 from collections import defaultdict
 outdir, wl = sys.argv[1], sys.argv[2]
