@@ -129,6 +129,15 @@ def pmc_traffic(workload, kernel):
     return None, name
 
 
+def pmc_traffic_per_step(workload, kernel, launches_per_step):
+    """pmc_traffic's bytes per DISPATCH brought to the basis the algorithmic bytes of the row tools are quoted on -- per STEP: x the kernel's launches per step
+    (the two were printed side by side). Returns (bytes per step, bytes per launch, source)."""
+    tr, src = pmc_traffic(workload, kernel)
+    if tr is None:
+        return None, None, src
+    return tr * launches_per_step, tr, src
+
+
 def ref_cfgs(wl):
     from oracle import pyref
     d, f = wl["demod"], wl["fec"]
@@ -208,10 +217,33 @@ def cpu_baseline(wl, x_host, n_prefix):
     return res, r, full
 
 
-# What the chunk-parallel mode is held to per workload (first pass of fresh handles over the full-size stream): the fraction of the float symbols
-# within 1e-5 of the reference's and the largest int8 soft-symbol difference (one interpolator step on a near-full-scale symbol). Measured round 3:
-# GOES 0.9913-0.9922 / 2, MetOp 0.9959 / 8, NPP 0.9948-0.9950 / 11 (full size). A line below these fails (exit code 3), like a CADU mismatch.
-PARITY_FLOORS = {"goes_hrit": (0.991, 4), "metop_ahrpt": (0.995, 8), "npp_hrd": (0.994, 12)}
+# What the chunk-parallel mode is held to at bench size (first pass of fresh handles over the full-size stream) -- the arm-grid contract, per workload
+# class: every CADU byte-identical (checked apart, hard); of the float symbols of the prefix: at most `other` of them interpolated two or more grid steps from the
+# reference's position (runs behind a slicer disagreement of the timing detector), at most `flip` one step off (the arm flicker), at most `same` of the symbols ON the
+# reference's arm beyond 1e-5 (runs behind a sign-detector disagreement of the carrier loop); of the int8 stream of the timed handles: at least `eq` equal, none more
+# than `lsb` apart, and the float instantiation's int8 stream the same bytes. Measured round 6 (profiles/r06_*): MetOp other 1.6e-5 / flip 3.5e-3 / same 3.3e-4 /
+# eq 0.99915 / 5 LSB; GOES 4.7e-4 / 7.4e-3 / 5.5e-4 / 0.9989 / 3; NPP 1.1e-4 / 4.2e-3 / 8.3e-4 / 0.9986 / 7. A line outside these fails (exit code 3).
+PARITY_GATES = {"goes_hrit": dict(other=1e-3, flip=0.012, same=1.2e-3, eq=0.998, lsb=6), "metop_ahrpt": dict(other=1e-4, flip=0.008, same=8e-4, eq=0.9985, lsb=10),
+                "npp_hrd": dict(other=4e-4, flip=0.008, same=1.6e-3, eq=0.998, lsb=12)}
+
+
+def parity_gates(workload, sp):
+    g = PARITY_GATES[workload]
+    ag = sp.get("arm_grid")
+    res = {"limits": g}
+    ok = sp["frac_int8_equal"] >= g["eq"] and sp["max_lsb"] <= g["lsb"]
+    res["int8"] = {"frac_equal": sp["frac_int8_equal"], "max_lsb": sp["max_lsb"]}
+    if sp.get("float_path") is not None:
+        res["float_instantiation_same_bytes"] = bool(sp["float_path"]["identical_to_the_timed_handles_stream"])
+        ok = ok and res["float_instantiation_same_bytes"]
+    if ag:
+        n = max(1, ag["symbols"])
+        res["arm_grid"] = {"other_frac": round(ag["other"] / n, 7), "one_arm_step_frac": ag["one_arm_step"]["frac"],
+                           "same_arm_beyond_1e-5_frac": round(ag["same_arm"]["beyond_1e-5"] / n, 7)}
+        ok = ok and ag["other"] / n <= g["other"] and ag["one_arm_step"]["frac"] <= g["flip"] and ag["same_arm"]["beyond_1e-5"] / n <= g["same"]
+        ok = ok and bool(ag["restatement_symbols_bit_identical_to_the_reference"])
+    res["passed"] = bool(ok)
+    return res
 
 
 def int8_parity(gpu_soft, ref_soft_full):
@@ -223,8 +255,7 @@ def int8_parity(gpu_soft, ref_soft_full):
         d = np.abs(gpu_soft[a:min(m, a + (1 << 28))].astype(np.int16) - ref_soft_full[a:min(m, a + (1 << 28))].astype(np.int16))
         hist += np.bincount(np.minimum(d, 5).astype(np.int64), minlength=6)
         mx = max(mx, int(d.max()) if len(d) else 0)
-    return {"int8_compared": int(m), "same_length": bool(len(ref_soft_full) == len(gpu_soft) or abs(len(ref_soft_full) - len(gpu_soft)) <= 4),
-            "frac_int8_equal": round(float(hist[0] / max(1, m)), 6),
+    return {"int8_compared": int(m), "frac_int8_equal": round(float(hist[0] / max(1, m)), 6),
             "int8_abs_diff_hist": {"0": int(hist[0]), "1": int(hist[1]), "2": int(hist[2]), "3": int(hist[3]), "4": int(hist[4]), ">=5": int(hist[5])},
             "max_lsb": mx}
 
@@ -300,7 +331,7 @@ def headline(out):
     cfg = out.get("config") or {}
     h["config"] = {"workload": cfg.get("workload"), "mode": cfg.get("mode")}
     if out.get("n_gpus", 1) > 1:
-        h["config"]["sharding"] = "contiguous chunks per GPU + lock-in overlap, host stitch, no data-path collective"
+        h["config"]["sharding"] = "ONE recording in contiguous chunks per GPU + lock-in overlap, host stitch, no data-path collective"
     h["cadu_per_s"] = out.get("cadu_per_s")
     h["whole_path_GBps"] = out.get("whole_path_GBps")
     h["roofline"] = _pick(out.get("roofline"), ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "algo_bytes_per_launch", "avg_launch_ms",
@@ -786,10 +817,8 @@ def run_workload(args, workload, n_steps, n_warmup, parity_samples, ctx):
         streamed = None
         gates = None
         if do_cpu:
-            # ---- gates: what the chunk-parallel mode promises for this workload, enforced -- a bench line below them is a failed line
-            floor, max_lsb = PARITY_FLOORS[workload]
-            gates = {"frac_within_1e-5_floor": floor, "max_lsb_ceiling": max_lsb,
-                     "passed": bool(sparity["frac_within_1e-5"] >= floor and sparity["max_lsb"] <= max_lsb)}
+            # ---- gates: what the chunk-parallel mode promises for this workload, enforced -- a bench line outside them is a failed line
+            gates = parity_gates(workload, sparity)
             # ---- exact mode (exact=1: every loop one sequential lane, the reference's float operations in its order): the mode that IS bit-identical,
             # timed on a prefix and checked bit for bit against the reference's soft stream
             if args.exact_samples > 0:

@@ -211,7 +211,9 @@ extern "C"
         SDHIP_NDSP_AGC = 2,     /* "agc_cc" */
         SDHIP_NDSP_MM = 3,      /* "clock_recovery_mm_cc" */
         SDHIP_NDSP_COSTAS = 4,  /* "costas_cc" */
-        SDHIP_NDSP_GARDNER = 5  /* "clock_recovery_gardner_cc" (dsp/clock_recovery/clock_recovery_gardner.cpp): rec_* keys as for the M&M block */
+        SDHIP_NDSP_GARDNER = 5, /* "clock_recovery_gardner_cc" (dsp/clock_recovery/clock_recovery_gardner.cpp): rec_* keys as for the M&M block */
+        SDHIP_NDSP_AGC_FAST = 6 /* "agc_fast_cc" (dsp/agc/agc_fast.cpp:22-58, dsp_flowgraph_register.cpp:278): the gain follows |input| x gain -- the magnitudes of the INPUT
+                                   taken first (volk_32fc_magnitude_32f) -- instead of |output|; agc_* keys as for the AGC block */
     };
     void *sdhip_ndsp_block_create(int kind, const sdhip_ndsp_psk_cfg *cfg);
     void sdhip_ndsp_psk_demod_destroy(void *h);
@@ -436,6 +438,21 @@ extern "C"
     /* unit entry: d_out[i] = atan2f(d_y[i], d_x[i]) as the frame PLL evaluates it (glibc 2.35's float code restated) */
     int sdhip_op_atan2f(int device, const float *d_y, const float *d_x, int n, float *d_out);
     /* get_dvbs2_cfg's answer for a MODCOD: bits per symbol, slots per frame, dvbs2_code_rate_t, dvbs2_constellation_t */
+    /* ---- dvbs2_ts_extractor (plugins/dvb_support/dvbs2/module_s2_ts_extractor.cpp:77-105 -> dvbs2::BBFrameTSParser::work, src-core/common/codings/dvb-s2/
+       bbframe_ts_parser.cpp:96-243): MPEG-TS packets (188 bytes) out of the BBFRAMEs' data fields, one frame per parser call, the parser's state carried from
+       frame to frame and from call to call. bbframe_bits = BBFrameBCH::dataSize() (or the module's "bb_size"); frames are bbframe_bits / 8 bytes apart.
+       Returns the packets written (< 0: error). The _dev entry takes and leaves everything in HBM (the BBFRAMEs sdhip_dvbs2_demod_* produced). */
+    typedef struct sdhip_s2_ts_stats
+    {
+        uint64_t frames_in, packets_out, header_crc_fails, resyncs;
+        int synched;
+    } sdhip_s2_ts_stats;
+    void *sdhip_s2_ts_create(int device, int bbframe_bits);
+    void sdhip_s2_ts_destroy(void *h);
+    int64_t sdhip_s2_ts_process_dev(void *h, const uint8_t *d_bbframes, int nframes, uint8_t *d_ts, size_t cap_packets);
+    int64_t sdhip_s2_ts_process(void *h, const uint8_t *bbframes, int nframes, uint8_t *ts, size_t cap_packets);
+    int sdhip_s2_ts_get_stats(void *h, sdhip_s2_ts_stats *st);
+
     int sdhip_s2_cfg(int modcod, int shortframes, int *bits, int *slots, int *rate, int *constellation);
     /* dvbs2::S2Deinterleaver::deinterleave (codings/dvb-s2/s2_deinterleaver.cpp:92-145) over nframes frames of 64800 / 16200 soft bits:
        constellation = dvbs2_constellation_t (0 QPSK, 1 8PSK, 2 16APSK, 3 32APSK), d_in != d_out (device pointers) */

@@ -334,6 +334,32 @@ class Ref(_Lib):
         n = self.lib.sdref_lrpt_decode(C.c_int(int(bool(diff_decode))), _p(s), C.c_int64(len(s)), _p(out), C.c_int64(cap), _p(locks), C.c_int64(cap), C.byref(it))
         return {"cadu": out[:n], "locks": locks[: it.value], "iterations": it.value}
 
+    def lrpt_m2x_decode(self, soft: np.ndarray, diff_decode=True, interleaved=True, reader_returns=0, ber_thr=0.3, outsync_after=20, max_iterations=1 << 40):
+        """METEORLRPTDecoderModule::process(), m2x_mode branch, on the reference's own classes (ref_wrap_lrpt_m2x.cpp). reader_returns = 0: the module's loop as it is
+        in the reference tree (the interleaved branch's DintSampleReader is handed an input_function that returns false: nothing is ever de-interleaved);
+        1: the same loop with that one token changed."""
+        s = np.ascontiguousarray(soft, dtype=np.int8)
+        cap = len(s) // 16384 + 8
+        taps = int(min(max_iterations, len(s) // 8192 + 8))
+        out = np.zeros((cap, 1024), dtype=np.uint8)
+        which, state, ber = np.zeros(taps, dtype=np.int32), np.zeros(taps, dtype=np.int32), np.zeros(taps, dtype=np.float32)
+        it, used = C.c_int64(0), C.c_int64(0)
+        self.lib.sdref_lrpt_m2x_decode.restype = C.c_int64
+        n = self.lib.sdref_lrpt_m2x_decode(C.c_int(int(bool(diff_decode))), C.c_int(int(bool(interleaved))), C.c_int(int(reader_returns)), C.c_float(ber_thr),
+                                           C.c_int(outsync_after), _p(s), C.c_int64(len(s)), C.c_int64(max_iterations), _p(out), C.c_int64(cap), _p(which), _p(state),
+                                           _p(ber), C.c_int64(taps), C.byref(it), C.byref(used))
+        k = min(taps, it.value)
+        return {"cadu": out[:n], "which": which[:k], "state": state[:k], "ber": ber[:k], "iterations": it.value, "consumed": used.value}
+
+    def m2x_deint(self, soft: np.ndarray, reads: int, pre_rotate=False):
+        """One meteor::DeinterleaverReader (plugins/meteor_support/meteor/deint.cpp, compiled in place) over a sample array: `reads` calls of read_samples(8192)."""
+        s = np.ascontiguousarray(soft, dtype=np.int8)
+        out = np.zeros(reads * 8192, dtype=np.int8)
+        rot, off = np.zeros(reads, dtype=np.int32), np.zeros(reads, dtype=np.int32)
+        self.lib.sdref_m2x_deint.restype = C.c_int64
+        n = self.lib.sdref_m2x_deint(_p(s), C.c_int64(len(s)), C.c_int(int(bool(pre_rotate))), C.c_int64(reads), _p(out), _p(rot), _p(off))
+        return {"soft": out[: n * 8192], "rotation": rot[:n], "offset": off[:n], "reads": int(n)}
+
     # ---- dsp
     def rrc_taps(self, fs, symrate, alpha, ntaps=31) -> np.ndarray:
         out = np.zeros(ntaps | 1, dtype=np.float32)
@@ -640,3 +666,20 @@ class AosRef:
         if n < 0:
             raise RuntimeError(f"sdref_aos_demux -> {n}")
         return hdr[:n].copy(), meta[:n].copy(), pool[:used.value].copy()
+
+
+def s2_ts_extract(frames: np.ndarray, bbframe_bits: int) -> np.ndarray:
+    """dvbs2::BBFrameTSParser the way the dvbs2_ts_extractor module drives it (oracle/ref_wrap_dvbs2.cpp: sdref_s2_ts_extract): frames = [n][bbframe_bits / 8] bytes ->
+    [packets][188] bytes. Compiled reference only."""
+    lib = C.CDLL(os.path.join(_HERE, "_ref", "libsdref_dvbs2.so"))
+    f = np.ascontiguousarray(frames, dtype=np.uint8).reshape(-1, bbframe_bits // 8)
+    cap = len(f) * (bbframe_bits // 8 // 188 + 2) + 8
+    out = np.zeros((cap, 188), dtype=np.uint8)
+    lib.sdref_s2_ts_extract.restype = C.c_longlong
+    n = lib.sdref_s2_ts_extract(C.c_int(bbframe_bits), _p(f), C.c_int(len(f)), _p(out), C.c_longlong(cap))
+    return out[:n]
+
+
+def s2_ts_available() -> bool:
+    p = os.path.join(_HERE, "_ref", "libsdref_dvbs2.so")
+    return os.path.exists(p) and hasattr(C.CDLL(p), "sdref_s2_ts_extract")

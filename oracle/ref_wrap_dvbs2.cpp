@@ -10,8 +10,32 @@
 #include <cstring>
 #include <vector>
 
+#include "common/codings/dvb-s2/bbframe_ts_parser.h"
+
 extern "C"
 {
+    // dvbs2::BBFrameTSParser fed the way S2TStoTCPModule::process feeds it (module_s2_ts_extractor.cpp:77-105): one frame per work() call, the 188 000-byte output
+    // array of the module. Returns the packets written to out (cap packets).
+    long long sdref_s2_ts_extract(int bbframe_bits, const unsigned char *frames, int nframes, unsigned char *out, long long cap_packets)
+    {
+        dvbs2::BBFrameTSParser ts_extractor(bbframe_bits);
+        static unsigned char ts_frames[188 * 1000];
+        std::vector<unsigned char> bb((size_t)bbframe_bits); // (the module's bb_buffer is bbframe_size BYTES-as-bits long: bbframe_size / 8 of it are read per frame)
+        long long n = 0;
+        for (int k = 0; k < nframes; k++)
+        {
+            memcpy(bb.data(), frames + (size_t)k * (bbframe_bits / 8), (size_t)(bbframe_bits / 8));
+            const int cnt = ts_extractor.work(bb.data(), 1, ts_frames, 188 * 1000);
+            for (int i = 0; i < cnt; i++)
+            {
+                if (n < cap_packets)
+                    memcpy(out + n * 188, &ts_frames[i * 188], 188);
+                n++;
+            }
+        }
+        return n;
+    }
+
     int sdref_ldpc_batch() { return dvbs2::simd_type::SIZE; }
 
     // framesize: 0 normal / 1 short; rate: dvbs2_code_rate_t. -> {N, K}

@@ -4,6 +4,7 @@
 // terminator buffer. One generic entry point: the block is chosen by its reference id, configured through the block's own set_cfg()
 // (same keys the flowgraph uses), so nothing here restates any arithmetic.
 #include "dsp/agc/agc.h"
+#include "dsp/agc/agc_fast.h"
 #include "dsp/clock_recovery/clock_recovery_gardner.h"
 #include "dsp/clock_recovery/clock_recovery_mm.h"
 #include "dsp/filter/fir.h"
@@ -22,6 +23,8 @@ namespace
     {
         if (id == "agc_cc")
             return std::make_unique<AGCBlock<complex_t>>();
+        if (id == "agc_fast_cc")
+            return std::make_unique<AGCFastBlock<complex_t>>();
         if (id == "rrc_fir_cc")
             return std::make_unique<RRC_Block<FIRBlock<complex_t>>>();
         if (id == "costas_cc")

@@ -315,7 +315,8 @@ namespace sdhip_plugin
     public:
         static const char *id_of(int kind)
         {
-            static const char *ids[6] = {"psk_demod_hip_cc", "rrc_fir_hip_cc", "agc_hip_cc", "clock_recovery_mm_hip_cc", "costas_hip_cc", "clock_recovery_gardner_hip_cc"};
+            static const char *ids[7] = {"psk_demod_hip_cc", "rrc_fir_hip_cc", "agc_hip_cc", "clock_recovery_mm_hip_cc", "costas_hip_cc", "clock_recovery_gardner_hip_cc",
+                                         "agc_fast_hip_cc"};
             return ids[kind];
         }
         explicit SingleHipBlock(int kind_) : Block(id_of(kind_), {{"in", satdump::ndsp::DSP_SAMPLE_TYPE_CF32}}, {{"out", satdump::ndsp::DSP_SAMPLE_TYPE_CF32}}), kind(kind_)
@@ -327,7 +328,7 @@ namespace sdhip_plugin
             cfg.symbolrate = 2e6;
             if (kind == SDHIP_NDSP_RRC_FIR)
                 keys = {{"gain", 0, false}, {"samplerate", 1, false}, {"symbolrate", 2, false}, {"alpha", 3, false}, {"ntaps", 4, true}};
-            else if (kind == SDHIP_NDSP_AGC)
+            else if (kind == SDHIP_NDSP_AGC || kind == SDHIP_NDSP_AGC_FAST) // (agc_fast.h:45-84: the same keys)
                 keys = {{"rate", 10, false}, {"reference", 11, false}, {"gain", 12, false}, {"max_gain", 13, false}};
             else if (kind == SDHIP_NDSP_MM || kind == SDHIP_NDSP_GARDNER) // (clock_recovery_gardner.h:57-130: the same keys)
                 keys = {{"omega", 20, false}, {"omegaGain", 21, false}, {"mu", 22, false}, {"muGain", 23, false}, {"omegaLimit", 24, false}, {"nfilt", 25, true}, {"ntaps", 26, true}};

@@ -45,6 +45,13 @@ static inline void volk_32f_x2_dot_prod_32f(float *r, const float *in, const flo
     *r = s;
 }
 #define volk_32f_x2_dot_prod_32f_a volk_32f_x2_dot_prod_32f
+// VOLK's _generic kernel: sqrtf((real * real) + (imag * imag)) per point (dsp/agc/agc_fast.cpp:37)
+static inline void volk_32fc_magnitude_32f(float *m, const lv_32fc_t *in, unsigned n)
+{
+    const float *a = (const float *)in;
+    for (unsigned i = 0; i < n; i++)
+        m[i] = sqrtf((a[2 * i] * a[2 * i]) + (a[2 * i + 1] * a[2 * i + 1]));
+}
 /* complex taps (the ndsp FIR block's third instantiation, dsp/filter/fir.cpp:122): VOLK's generic kernel, one complex MAC per point */
 static inline void volk_32fc_x2_dot_prod_32fc(lv_32fc_t *r, const lv_32fc_t *in, const lv_32fc_t *t, unsigned n)
 {

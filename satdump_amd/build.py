@@ -15,7 +15,7 @@ CSRC = os.path.join(ROOT, "satdump_amd", "csrc")
 LIBDIR = os.path.join(ROOT, "satdump_amd", "lib")
 LIB = os.path.join(LIBDIR, "libsdhip.so")
 
-HIP_SOURCES = ["fec_kernels.hip", "fec_engine.hip", "demod_kernels.hip", "demod_engine.hip", "dvbs2_ldpc.hip", "dvbs2_bch.hip", "dvbs2_demap.hip", "dvbs2_engine.hip", "shard.hip", "aos_demux.hip", "lrpt_decoder.hip"]
+HIP_SOURCES = ["fec_kernels.hip", "fec_engine.hip", "demod_kernels.hip", "demod_engine.hip", "dvbs2_ldpc.hip", "dvbs2_bch.hip", "dvbs2_demap.hip", "dvbs2_engine.hip", "dvbs2_ts.hip", "shard.hip", "aos_demux.hip", "lrpt_decoder.hip"]
 # -ffp-contract=off: the float chains must round exactly where the reference's x86-64 -O2 build rounds (no FMA)
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-Wno-unused-result"]
 

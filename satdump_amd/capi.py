@@ -192,6 +192,14 @@ def lib():
             L.sdhip_ldpc_get_info.argtypes = [C.c_void_p, C.POINTER(LdpcInfo)]
             L.sdhip_ldpc_decode_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
             L.sdhip_ldpc_decode.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        if hasattr(L, "sdhip_s2_ts_create"):  # dvbs2_ts_extractor (csrc/dvbs2_ts.hip)
+            L.sdhip_s2_ts_create.restype = C.c_void_p
+            L.sdhip_s2_ts_create.argtypes = [C.c_int, C.c_int]
+            L.sdhip_s2_ts_destroy.argtypes = [C.c_void_p]
+            L.sdhip_s2_ts_process.restype = C.c_int64
+            L.sdhip_s2_ts_process.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]
+            L.sdhip_s2_ts_process_dev.restype = C.c_int64
+            L.sdhip_s2_ts_process_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]
         if hasattr(L, "sdhip_bch_create"):
             L.sdhip_bch_create.restype = C.c_void_p
             L.sdhip_bch_create.argtypes = [C.POINTER(BchCfg)]

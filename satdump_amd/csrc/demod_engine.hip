@@ -720,6 +720,7 @@ namespace sdhip
             agc_p.reference = nd.on ? nd.agc_reference : 1.0f;
             agc_p.max_gain = nd.on ? nd.agc_max_gain : 65536.0f;
             agc_p.init_gain = nd.on ? nd.agc_gain : 1.0f;
+            agc_p.input_mag = nd.only == SDHIP_NDSP_AGC_FAST ? 1 : 0;
             agc_s.gain = agc_p.init_gain;
             // RRC (module_psk_demod.cpp:91)
             // ndsp: RRC_Block::set_cfg designs from its double members (dsp/filter/rrc.h:62-66)
@@ -1208,7 +1209,20 @@ namespace sdhip
             W = (std::min<long long>(W, w_cos_cap) + 255) / 256 * 256;
             // two waves per SIMD: the stage is bound by its dependent chains (AGC sqrt, sincos in double), not by its loads -- measured
             // (MetOp, profiles/history/r03/r03_a_ab_metop.txt): 26.4 ms with 65 280 lanes, 21.3 with 98 304, 19.5 with 130 560 (226 VGPRs: two waves fit)
-            const long long lanes = std::max<long long>(64, env_int("SDHIP_LANES_AFC", 130560));
+            // Round 6: one wave per SIMD instead where that is the faster plan. A lane's time is (warm-up + chunk) sequential samples at the per-sample pace of
+            // its occupancy -- two waves sharing a SIMD each run ~1.3 times slower than one alone (MetOp 19.5 against 26.4 ms above = 1.31 with the chunk
+            // lengths put in; GOES, profiles/r06_c_*: 3.35 against 3.17 ms) -- and the warm-up does not shrink with the chunk: on a 2 GiB stream (GOES: 5.6 k
+            // samples of warm-up in front of 2 k-sample chunks at 130 560 lanes) half the lanes with chunks twice as long finish sooner, and hand off half as
+            // often (GOES full size: float symbols within 1e-5 0.99155 -> 0.99231, symbols two or more arms off 5 812 -> 2 949 of 12.4 M).
+            long long lanes_dflt = 130560;
+            if (!cfg.exact && cfg.chunk_len <= 0)
+            {
+                const double w = (double)Wa + (double)W;
+                const double cost2 = (w + std::max(2048.0, (double)n / 130560.0)) * 1.3, cost1 = w + std::max(2048.0, (double)n / 65280.0);
+                if (cost1 < cost2)
+                    lanes_dflt = 65280;
+            }
+            const long long lanes = std::max<long long>(64, env_int("SDHIP_LANES_AFC", lanes_dflt));
             int L = pick_L(n, ST_COSTAS);
             if (!cfg.exact && cfg.chunk_len <= 0 && !getenv("SDHIP_CHUNK") && !getenv("SDHIP_CHUNK_COSTAS") && !getenv("SDHIP_LANES_COSTAS"))
                 L = (int)std::min<long long>(std::max<long long>(((n + lanes - 1) / lanes + 63) / 64 * 64, 2048), 1 << 20);
@@ -1216,7 +1230,7 @@ namespace sdhip
             const double tol_phase = env_int("SDHIP_COSTAS_TOL_URAD", 10000) * 1e-6, tol_freq = env_int("SDHIP_COSTAS_TOL_NFREQ", 40000) * 1e-9;
             // the hand-off window proper (round 6; see costas_stage): a boundary between it and the wide window is re-run from the exact state and stops at the first
             // checkpoint at which it is back within it
-            const double tol_tight = std::min(tol_phase, env_int("SDHIP_COSTAS_TIGHT_URAD", 10) * 1e-6);
+            const double tol_tight = std::min(tol_phase, env_int("SDHIP_COSTAS_TIGHT_URAD", 10000) * 1e-6);
             AfcParams ap;
             AfcCkptCfg ck;
             // chunk-parallel mode: the stage's fast arithmetic (demod_kernels.hip, sd_sincosf_fast) -- inside the 1e-5 contract that mode is
@@ -1545,12 +1559,14 @@ namespace sdhip
             // launch whose slowest lane runs alone for over a millisecond (measured: +1.2 ms on a 96 ms step). They are counted
             // (chunks_inexact); anything beyond the window -- a lane that has not locked -- is re-run from the exact state.
             const double tol_phase = env_int("SDHIP_COSTAS_TOL_URAD", 10000) * 1e-6, tol_freq = env_int("SDHIP_COSTAS_TOL_NFREQ", 40000) * 1e-9;
-            // Round 6: those boundaries ARE re-run now. Since the re-run lanes stop at a checkpoint (round 4) the second launch costs what 2048 samples of the
-            // slowest lane cost, not a chunk; and at bench size the kicked hand-offs were what was left on the reference's own interpolator arm beyond 1e-5
-            // (4 721 symbols of 15.6 M, max 3.6e-2 rad: VERDICT r5 weak 2). TIGHT window 1e-5 rad = the contract (SDHIP_COSTAS_TIGHT_URAD); measured on the twin
-            // (test_every_symbol_beyond_tolerance_is_an_arm_flip): same-arm symbols beyond 1e-5 57 -> 20 of 393 k (GOES), 29 -> 0 (NPP), max angle 3.3e-5 -> 1.3e-5.
-            // The wide window keeps its role: what lies outside it is an unlocked lane and counts towards the warm-up adaptation.
-            const double tol_tight = std::min(tol_phase, env_int("SDHIP_COSTAS_TIGHT_URAD", 10) * 1e-6);
+            // Round 6 measured exactly that again, with the re-run lanes stopping at a checkpoint (round 4): a TIGHT window (SDHIP_COSTAS_TIGHT_URAD, in 1e-6 rad;
+            // boundaries between it and the wide window re-run from the exact state until they are back within it; the wide window keeps its role for the warm-up
+            // adaptation, VerdictOut::wide). At 1e-5 rad, full size (profiles/r06_b_*): GOES 6 084 of 295 k chunks re-run, same-arm symbols beyond 1e-5 6 783 ->
+            // 2 445 of 12.4 M; NPP 1 485 re-run, 16 536 -> 13 013 of 20 M; MetOp 66 re-run, 4 721 -> 5 164 (nothing: what is left there are sign-detector
+            // disagreements in MID-chunk, tools/twin/arm_probe.py) -- for +1.2 ms per step on every workload (the slowest re-run lane walks its 2048
+            // samples alone: 0.58 us per sample of dependent chain), +3 % on MetOp and +9 % on GOES for a change in the fifth digit of the 1e-5 fraction. So the
+            // default stays the wide window; the switch is there for a caller who wants the hand-offs inside the contract and pays for it.
+            const double tol_tight = std::min(tol_phase, env_int("SDHIP_COSTAS_TIGHT_URAD", 10000) * 1e-6);
             ChunkCkpt cos_ck;
             auto costas_setup = [&](long long Wn) {
                 cos_p.est_len = (int)std::min<long long>(env_int("SDHIP_COSTAS_EST", 256), Wn / 2);
@@ -1716,15 +1732,13 @@ namespace sdhip
             const double MM_TOL_TIGHT = s2_front ? mm_windows_tight : 2e-4;
             const double MM_TOL = getenv("SDHIP_MM_TOL_MICRO") ? env_int("SDHIP_MM_TOL_MICRO", 5000) * 1e-6
                                   : (getenv("SDHIP_MM_TOL_MILLI") ? env_int("SDHIP_MM_TOL_MILLI", 5) * 1e-3 : (s2_front ? mm_windows_tol : 5e-3));
-            // ... and the window of the loop's RATE state (round 6). The timing state alone does not make a hand-off: a lane whose timing passes through the
-            // predecessor's while its rate is still off by d (samples per symbol) is carried away again by up to ~0.74 d / (gain_mu Kd) samples before the loop
-            // (critically damped: gain_omega = gain_mu^2 / 4) pulls it back over some hundred symbols. The old window, 1e-3 of omega (2.9e-3 samples per symbol on GOES),
-            // let such lanes through: they are the runs of symbols interpolated 2 - 3 arms from the reference's position (5 812 of 12.4 M symbols on GOES at bench
-            // size; reproduced on the twin with the bench's chunk length: tools/twin/arm_probe.py). Window = what keeps that excursion inside the
-            // timing window: MM_TOL gain_mu / 2.
-            const float MM_TOL_OMEGA = getenv("SDHIP_MM_TOL_OMEGA_NANO") ? (float)(env_int("SDHIP_MM_TOL_OMEGA_NANO", 0) * 1e-9)
-                                                                          : (s2_front ? 1e-3f * final_sps // (the DVB-S2 module's own windows: what it promises are the BBFRAMEs)
-                                                                                      : (float)(MM_TOL * std::max(1e-4, (double)cfg.clock_gain_mu) * 0.5));
+            // ... and the window of the loop's RATE state: 1e-3 of omega. Round 6 tried the window that would keep a rate error's excursion inside the timing
+            // window (MM_TOL gain_mu / 2 samples per symbol: a lane whose timing passes through the predecessor's while its rate is still off is carried away again
+            // before the critically damped loop pulls it back): GOES full size, symbols two or more arms from the reference's position 5 812 -> 5 017 of 12.4 M for
+            // +1.0 ms of re-run launches per step (profiles/r06_b_*). Those runs of symbols are not hand-offs: they begin in MID-chunk, where the detector's slicer
+            // (clock_recovery_mm.cpp:99-100) decided a near-zero symbol differently on the two trajectories -- a kick of ~gain_mu, one arm, on top of the flicker
+            // (tools/twin/arm_probe.py). SDHIP_MM_TOL_OMEGA_NANO sets the window in 1e-9 samples per symbol (experiments).
+            const float MM_TOL_OMEGA = getenv("SDHIP_MM_TOL_OMEGA_NANO") ? (float)(env_int("SDHIP_MM_TOL_OMEGA_NANO", 0) * 1e-9) : 1e-3f * final_sps;
             mm_p.tol_omega = MM_TOL_OMEGA;
             MmCkpt *ckp = nullptr;
             int ck_per_chunk = 0;
@@ -2131,8 +2145,8 @@ namespace sdhip
             bufB.reserve(need);
             cf32 *A = bufA.p + DEMOD_HIST, *B = bufB.p + DEMOD_HIST;
             stats.samples_in += n;
-            if (nd.only == SDHIP_NDSP_AGC)
-            { // AGCBlock<complex_t>::process (dsp/agc/agc.cpp:22-39) on its own
+            if (nd.only == SDHIP_NDSP_AGC || nd.only == SDHIP_NDSP_AGC_FAST)
+            { // AGCBlock<complex_t>::process (dsp/agc/agc.cpp:22-39) / AGCFastBlock<complex_t>::process (dsp/agc/agc_fast.cpp:22-58) on its own
                 if ((size_t)n > out_cap)
                     throw HipError("output buffer too small");
                 SD_HIP(hipMemcpyAsync(A, d_in, (size_t)n * sizeof(cf32), hipMemcpyDeviceToDevice, stream));
@@ -2465,7 +2479,7 @@ extern "C"
     void sdhip_ndsp_psk_demod_destroy(void *h) { delete (DemodEngine *)h; }
     void *sdhip_ndsp_block_create(int kind, const sdhip_ndsp_psk_cfg *c)
     {
-        if (kind < SDHIP_NDSP_HIER || kind > SDHIP_NDSP_GARDNER)
+        if (kind < SDHIP_NDSP_HIER || kind > SDHIP_NDSP_AGC_FAST)
         {
             sdhip::set_error("ndsp block: unknown kind");
             return nullptr;

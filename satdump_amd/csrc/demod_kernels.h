@@ -114,6 +114,7 @@ namespace sdhip
         int fast; // 1: chunk-parallel mode's arithmetic (sd_sqrt_fast, fma) in the stand-alone stage too
         // chunk start gains from the affine scan (launch_agc_partial + the engine's chain over the chunks); nullptr = every lane warms up from init_gain
         const float *starts = nullptr;
+        int input_mag = 0; // 1: ndsp::AGCFastBlock (dsp/agc/agc_fast.cpp:37-55): gain += rate * (reference - sqrtf(re^2 + im^2 of the INPUT) * gain)
     };
     // The AGC recurrence (agc.cpp:25-39 / dsp/agc/agc.cpp:22-39) is, for a positive gain, g <- min((1 - rate |x|) g + rate reference, max_gain): a clamped affine map of
     // the gain whose coefficients depend on the INPUT only. Such maps compose -- (a2, b2, c2) o (a1, b1, c1) = (a2 a1, a2 b1 + b2, min(a2 c1 + b2, c2)) for a2 >= 0 --

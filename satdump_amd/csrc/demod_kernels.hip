@@ -883,7 +883,16 @@ namespace sdhip
             const float ore = v.re * s.gain;
             const float oim = v.im * s.gain;
             float mag;
-            if constexpr (FAST)
+            if (p.input_mag)
+            { // AGCFastBlock<complex_t>::process, agc_fast.cpp:37-55: mag_buf[i] = sqrtf(re * re + im * im) of the input (VOLK's generic kernel), times the gain
+                float mi;
+                if constexpr (FAST)
+                    mi = sd_sqrt_fast(fmaf(v.re, v.re, v.im * v.im));
+                else
+                    mi = sqrtf(v.re * v.re + v.im * v.im);
+                mag = mi * s.gain;
+            }
+            else if constexpr (FAST)
                 mag = sd_sqrt_fast(fmaf(ore, ore, oim * oim));
             else
                 mag = sqrtf(ore * ore + oim * oim) /* correctly rounded (default -fhip-fp32-correctly-rounded-divide-sqrt); __fsqrt_rn is the native approximation */;

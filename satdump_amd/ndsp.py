@@ -121,10 +121,11 @@ class PSKDemodHierBlock:
 
 
 # ---- the chain's member blocks as flowgraph nodes of their own (include/sdhip.h, sdhip_ndsp_block_create)
-NDSP_HIER, NDSP_RRC_FIR, NDSP_AGC, NDSP_MM, NDSP_COSTAS, NDSP_GARDNER = 0, 1, 2, 3, 4, 5
+NDSP_HIER, NDSP_RRC_FIR, NDSP_AGC, NDSP_MM, NDSP_COSTAS, NDSP_GARDNER, NDSP_AGC_FAST = 0, 1, 2, 3, 4, 5, 6
 _SINGLE = {
     # block id -> (kind, {block key: cfg field})   (the keys of dsp/agc/agc.h:38-78, dsp/filter/rrc.h:34-66, dsp/clock_recovery/clock_recovery_mm.h:70-130, dsp/pll/costas.h:55-90)
     "agc_cc": (NDSP_AGC, {"rate": "agc_rate", "reference": "agc_reference", "gain": "agc_gain", "max_gain": "agc_max_gain"}),
+    "agc_fast_cc": (NDSP_AGC_FAST, {"rate": "agc_rate", "reference": "agc_reference", "gain": "agc_gain", "max_gain": "agc_max_gain"}),  # dsp/agc/agc_fast.h:45-84
     "rrc_fir_cc": (NDSP_RRC_FIR, {"gain": "rrc_gain", "samplerate": "samplerate", "symbolrate": "symbolrate", "alpha": "rrc_alpha", "ntaps": "rrc_ntaps"}),
     "clock_recovery_mm_cc": (NDSP_MM, {"omega": "rec_omega", "omegaGain": "rec_omegaGain", "mu": "rec_mu", "muGain": "rec_muGain", "omegaLimit": "rec_omegaLimit",
                                        "nfilt": "rec_nfilt", "ntaps": "rec_ntaps"}),

@@ -251,6 +251,34 @@ PUNCTURE_MASKS = {
 }
 
 
+M2X_BRANCHES, M2X_DELAY, M2X_STRIDE, M2X_MARKER = 36, 2048 * 36, 80, 0x27  # meteor/deint.h: INTER_BRANCH_COUNT, INTER_BRANCH_DELAY * INTER_BRANCH_COUNT, INTER_MARKER_STRIDE, INTER_MARKER
+
+
+def m2x_interleave(soft: np.ndarray, marker_amp: int = 90, marker_errors: float = 0.0, seed: int = 0) -> np.ndarray:
+    """What a Meteor-M2-x 80k transmitter does to the coded soft stream `soft` (the inverse of meteor::DeinterleaverReader, plugins/meteor_support/meteor/deint.cpp:
+    100-133): the convolutional interleaver -- sample n of the data stream rides branch n % 36 and comes out of the receiver's de-interleaver (35 - n % 36) * 73 728
+    samples later -- and an 8-sample marker (0x27, MSB first, a 1 = a NEGATIVE sample: soft_to_hard, deint.cpp:153-172) in front of every 72 data samples. The
+    first 35 * 73 728 outputs of the de-interleaver are the zeros its ring starts with (or stale data): `soft` should begin with that much lead-in. Returns the
+    transmitted stream, length len(soft) / 72 * 80 (whole strides only)."""
+    s = np.ascontiguousarray(soft, dtype=np.int8)
+    n = len(s) // 72 * 72
+    idx = np.arange(n, dtype=np.int64)
+    src = idx + (M2X_BRANCHES - 1 - idx % M2X_BRANCHES) * M2X_DELAY  # data[n] = out[n + (35 - n % 36) * 73728]
+    # (behind the end of `soft` the branches carry noise, not zeros: a run of equal samples defeats the receiver's marker autocorrelation)
+    fill = np.random.default_rng(seed + 78).integers(-60, 60, n).astype(np.int8)
+    data = np.where(src < len(s), s[np.minimum(src, len(s) - 1)], fill).astype(np.int8)
+    bits = np.array([(M2X_MARKER >> (7 - k)) & 1 for k in range(8)])
+    mark = np.where(bits == 1, -marker_amp, marker_amp).astype(np.int8)
+    out = np.empty((n // 72, M2X_STRIDE), dtype=np.int8)
+    out[:, :8] = mark
+    out[:, 8:] = data.reshape(-1, 72)
+    if marker_errors > 0:
+        rng = np.random.default_rng(seed + 77)
+        flip = rng.random((n // 72, 8)) < marker_errors
+        out[:, :8] = np.where(flip, -out[:, :8], out[:, :8])
+    return out.reshape(-1)
+
+
 def puncture(coded: np.ndarray, rate: int) -> np.ndarray:
     """Drop the punctured positions of an r=1/2 coded bit stream (rate code as in PUNCTURE_MASKS)."""
     m = np.asarray(PUNCTURE_MASKS[rate], dtype=bool)

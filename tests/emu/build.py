@@ -12,7 +12,7 @@ CSRC = os.environ.get("EMU_CSRC") or os.path.join(ROOT, "satdump_amd", "csrc")
 OUT = os.path.join(HERE, "_build" + os.environ.get("EMU_TAG", ""))
 LIB = os.path.join(OUT, "libsdhip_emu.so")
 CLANG = "/opt/rocm/lib/llvm/bin/clang++"
-SOURCES = ["demod_kernels.hip", "demod_engine.hip", "fec_kernels.hip", "fec_engine.hip", "dvbs2_ldpc.hip", "dvbs2_bch.hip", "dvbs2_demap.hip", "dvbs2_engine.hip", "shard.hip", "aos_demux.hip", "lrpt_decoder.hip"]
+SOURCES = ["demod_kernels.hip", "demod_engine.hip", "fec_kernels.hip", "fec_engine.hip", "dvbs2_ldpc.hip", "dvbs2_bch.hip", "dvbs2_demap.hip", "dvbs2_engine.hip", "dvbs2_ts.hip", "shard.hip", "aos_demux.hip", "lrpt_decoder.hip"]
 
 
 def build(force: bool = False) -> str:

@@ -1,6 +1,7 @@
 """GPU parity tests of the DVB-S2 LDPC decoder (sdhip_ldpc_*, satdump_amd/csrc/dvbs2_ldpc.hip) against the reference's own BBFrameLDPC
 compiled in place (oracle/_ref/libsdref_dvbs2*.so, oracle/ref_wrap_dvbs2.cpp). Integer work: the decoded soft bits and the trial counts
 must be IDENTICAL -- converged or not, and in the 16-frames-per-call grouping of the reference's SSE4.1 build (one early exit per call)."""
+import ctypes as C
 import os
 
 import numpy as np
@@ -798,3 +799,125 @@ def test_errors(capi):
     dec = capi.LdpcDecoder(framesize=1, rate="1/2", batch=16)
     with pytest.raises(capi.SdhipError):
         dec.decode(np.zeros((3, 16200), dtype=np.int8))  # not a whole number of batches
+
+
+# ---------------------------------------------------------------------------------------------------- dvbs2_ts_extractor (round 6)
+def _crc8_tab():
+    tab = np.zeros(256, dtype=np.uint8)
+    for i in range(256):
+        r, crc = i, 0
+        for j in range(7, -1, -1):
+            if ((1 if r & (1 << j) else 0) ^ (1 if crc & 0x80 else 0)):
+                crc = ((crc << 1) ^ 0xD5) & 0xFFFF
+            else:
+                crc = (crc << 1) & 0xFFFF
+        tab[i] = crc & 0xFF
+    return tab
+
+
+def _hdr_crc_bits(hdr10):
+    crc = 0
+    for n in range(80):
+        b = ((hdr10[n // 8] >> (7 - (n % 8))) & 1) ^ (crc & 1)
+        crc >>= 1
+        if b:
+            crc ^= 0xAB
+    return crc
+
+
+def ts_bbframes(kbch, nframes, seed=1, dfls=None, bad_hdr=(), bad_syncd=(), corrupt_packets=(), start_skew=0):
+    """BBFRAMEs the way a DVB-S2 modulator in TS mode builds them (EN 302 307 5.1): a continuous stream of 188-byte packets whose sync byte is replaced by the CRC-8
+    of the previous packet's 187 other bytes, cut into data fields of dfls[k] bits (default: the whole frame), each behind a 10-byte header (MATYPE, UPL, DFL, SYNC,
+    SYNCD = bits from the data field's start to the first sync/CRC byte in it, CRC-8). Returns (frames [n][kbch / 8], the packets as transmitted [m][188])."""
+    rng = np.random.default_rng(seed)
+    tab = _crc8_tab()
+    fb = kbch // 8
+    dfls = list(dfls) if dfls is not None else [kbch - 80] * nframes
+    total = sum(d // 8 for d in dfls)
+    npk = total // 188 + 3
+    pk = rng.integers(0, 256, (npk, 188), dtype=np.uint8)
+    pk[:, 0] = 0x47
+    stream = np.zeros(npk * 188, dtype=np.uint8)
+    for j in range(npk):
+        stream[188 * j + 1:188 * j + 188] = pk[j, 1:]
+        crc = 0
+        if j > 0:
+            for v in pk[j - 1, 1:]:
+                crc = tab[v ^ crc]
+            stream[188 * j] = crc ^ (0x55 if (j - 1) in corrupt_packets else 0)  # (a wrong CRC byte = a packet the receiver flags)
+        else:
+            stream[0] = 0
+    frames = np.zeros((nframes, fb), dtype=np.uint8)
+    at = start_skew  # position in `stream` of the next data-field byte
+    for k in range(nframes):
+        n = dfls[k] // 8
+        syncd = (-at) % 188  # bytes to the next sync/CRC byte
+        if k in bad_syncd:
+            syncd = (syncd + 5) % 188
+        h = np.zeros(10, dtype=np.uint8)
+        h[0], h[1] = 0xF0, 0x00
+        h[2], h[3] = (188 * 8) >> 8, (188 * 8) & 0xFF
+        h[4], h[5] = dfls[k] >> 8, dfls[k] & 0xFF
+        h[6] = 0x47
+        h[7], h[8] = (syncd * 8) >> 8, (syncd * 8) & 0xFF
+        for c in range(256):
+            h[9] = c
+            if _hdr_crc_bits(h) == 0:
+                break
+        if k in bad_hdr:
+            h[9] ^= 0x3C
+        frames[k, :10] = h
+        frames[k, 10:10 + n] = stream[at:at + n]
+        frames[k, 10 + n:] = rng.integers(0, 256, fb - 10 - n, dtype=np.uint8)  # padding behind the data field
+        at += n
+    return frames, pk
+
+
+def _ts_run(capi, frames, kbch, cuts=None):
+    h = capi.lib().sdhip_s2_ts_create(0, kbch)
+    assert h, capi.last_error()
+    capi.lib().sdhip_s2_ts_process.restype = C.c_int64
+    out = []
+    cuts = cuts or [0, len(frames)]
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        f = np.ascontiguousarray(frames[a:b])
+        cap = (b - a) * (kbch // 8 // 188 + 2) + 8
+        o = np.zeros((cap, 188), dtype=np.uint8)
+        n = capi.lib().sdhip_s2_ts_process(C.c_void_p(h), f.ctypes.data_as(C.c_void_p), C.c_int(b - a), o.ctypes.data_as(C.c_void_p), C.c_size_t(cap))
+        assert n >= 0, capi.last_error()
+        out.append(o[:n])
+    capi.lib().sdhip_s2_ts_destroy(C.c_void_p(h))
+    return np.concatenate(out) if out else np.zeros((0, 188), dtype=np.uint8)
+
+
+TS_CASES = [
+    ("full_frames", dict(nframes=40)),                                                     # the data field fills the frame: packets span frames all the time
+    ("short_fields", dict(nframes=60, dfls=[8 * v for v in ([700, 96, 187, 188, 189, 1500, 40, 8, 375, 376] * 6)])),  # fields shorter than a packet, ends ON a packet end
+    ("header_crc", dict(nframes=40, bad_hdr=(5, 6, 20))),                                  # lost frames: resynchronisation from SYNCD, the packet in flight dropped
+    ("syncd_off", dict(nframes=30, bad_syncd=(7, 19))),                                    # a SYNCD that contradicts the parser's count: out of sync from the NEXT frame
+    ("payload_errors", dict(nframes=30, corrupt_packets=(3, 4, 50, 51, 52, 200))),         # the transport error indicator (and where the parser loses it)
+    ("mid_stream", dict(nframes=25, start_skew=77)),                                       # the recording starts inside a packet
+    ("aligned_ends", dict(nframes=48, dfls=[188 * 8 * 3, 188 * 8 * 3 + 8 * 187, 8 * 1, 188 * 8 * 2] * 12, corrupt_packets=tuple(range(0, 120, 2)))),  # CRC bytes that open a frame
+]
+
+
+@pytest.mark.parametrize("name,kw", TS_CASES)
+def test_s2_ts_extractor(capi, name, kw):
+    """The step behind the BBFRAMEs (plugins/dvb_support/dvbs2/module_s2_ts_extractor.cpp -> dvbs2::BBFrameTSParser): the packets the engine gathers on the device
+    (sdhip_s2_ts_process: header walk on the host, packet gather + CRC-8 + error indicator per packet on the device) against the reference's parser compiled in place,
+    byte for byte -- sync loss and recovery, fields shorter than a packet, the error indicator and the cases in which the parser itself drops it -- in one call and in
+    ragged calls (state and the packet in flight carried)."""
+    if not pyref.s2_ts_available():
+        pytest.skip("oracle/_ref/libsdref_dvbs2.so (with the TS parser) not built")
+    kbch = 14232 if name == "short_fields" else 43040  # short 8/9 ... normal 2/3 (BBFrameBCH::dataSize())
+    frames, sent = ts_bbframes(kbch, **kw)
+    want = pyref.s2_ts_extract(frames, kbch)
+    got = _ts_run(capi, frames, kbch)
+    assert got.shape == want.shape and np.array_equal(got, want), (name, got.shape, want.shape)
+    n = len(frames)
+    got2 = _ts_run(capi, frames, kbch, cuts=[0, 1, 2, 7, n // 2, n - 1, n])
+    assert got2.shape == want.shape and np.array_equal(got2, want), (name, "ragged calls")
+    assert len(want) > 10
+    if name == "full_frames":  # sanity of the model: what comes out are the packets that went in
+        sent_set = {p.tobytes() for p in sent}
+        assert all(p.tobytes() in sent_set for p in want)

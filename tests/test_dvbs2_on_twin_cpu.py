@@ -229,3 +229,8 @@ def test_oracle_round_trip(sse):
         soft, bits, k = G.make_frames(ref, fs, rate, ref.batch, 40, 0.0, 3)
         out, tr = ref.ldpc_decode(fs, rate, soft, 5)
         assert tr.tolist() == [0] and np.array_equal(out, soft)
+
+
+@pytest.mark.parametrize("name,kw", G.TS_CASES)
+def test_s2_ts_extractor_on_the_twin(capi, name, kw):
+    G.test_s2_ts_extractor(capi, name, kw)

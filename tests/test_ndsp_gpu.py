@@ -195,6 +195,9 @@ def test_ndsp_host_mirror(torch_cuda, capi, nref):
 SINGLE = [
     ("agc_cc", {"rate": 1e-4, "reference": 0.6, "gain": 1.0, "max_gain": 65536.0}),
     ("agc_cc", {"rate": 1e-2, "gain": 3.0, "max_gain": 4.0}),
+    # round 6: dsp/agc/agc_fast.cpp (the registry's "AGC/Agc Fast CC", dsp_flowgraph_register.cpp:278): the gain follows |input| x gain
+    ("agc_fast_cc", {"rate": 1e-4, "reference": 0.6, "gain": 1.0, "max_gain": 65536.0}),
+    ("agc_fast_cc", {"rate": 1e-2, "gain": 3.0, "max_gain": 4.0}),
     ("rrc_fir_cc", {"samplerate": 6e6, "symbolrate": 2333333.0, "alpha": 0.5, "ntaps": 21}),
     ("costas_cc", {"order": 4, "loop_bw": 0.02}),
     ("costas_cc", {"order": 8, "loop_bw": 0.003, "freq_limit": 0.01}),

@@ -128,7 +128,9 @@ def run(args) -> dict:
                      "msg_bytes_per_frame": int(ldpc.info.msg_bytes_per_frame)},
            "kernels_ms": {k2: round(v[0] / args.steps, 3) for k2, v in prof.items()},
            "roofline": {"bound": "hbm", "kernel": "k_ldpc_trial", "achieved": round(algo / (ms_ldpc * 1e-3) / 1e9, 1) if ms_ldpc else None, "peak": 8000.0, "unit": "GB/s",
-                        "frac": round(algo / (ms_ldpc * 1e-3) / 1e9 / 8000.0, 4) if ms_ldpc else None, "traffic": _pmc("k_ldpc_trial")[0], "traffic_source": _pmc("k_ldpc_trial")[1]}}
+                        "frac": round(algo / (ms_ldpc * 1e-3) / 1e9 / 8000.0, 4) if ms_ldpc else None, "traffic": (_pmc("k_ldpc_trial")[0] * (prof["k_ldpc_trial"][1] / args.steps) if _pmc("k_ldpc_trial")[0] and "k_ldpc_trial" in prof else None),
+                        "traffic_per_launch": _pmc("k_ldpc_trial")[0], "launches_per_step": (prof["k_ldpc_trial"][1] / args.steps if "k_ldpc_trial" in prof else None),
+                        "traffic_source": _pmc("k_ldpc_trial")[1]}}
     if front and args.sync_frames > 0:
         # the two synchronisation stages in front of the demapper, timed on their own (the frame PLL is one serial lane: it would hide everything else
         # in the step above): PL synchroniser over the frames laid back to back, frame PLL over what it emits

@@ -137,9 +137,10 @@ def run(args) -> dict:
         if key and kern[dom] > 0:
             ach = algo[key] / (kern[dom] * 1e-3) / 1e9
             import bench as _b
-            tr_b, tr_src = _b.pmc_traffic("dvbs2", dom)
+            lps = prof[dom][1] / args.steps if dom in prof else 1.0
+            tr_b, tr_1, tr_src = _b.pmc_traffic_per_step("dvbs2", dom, lps)  # per STEP, like algorithmic_bytes_per_step
             out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": round(ach, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 4), "traffic": tr_b,
-                               "traffic_source": tr_src,
+                               "traffic_per_launch": tr_1, "launches_per_step": lps, "traffic_source": tr_src,
                                "algorithmic_bytes_per_step": int(algo[key]), "note": "ldpc update passes per frame taken from the last group's trial count" if key == "k_ldpc_trial" else ""}
     whole = (n * 8 + sum(outs) / args.steps * fb) / dt / 1e9
     out["whole_path"] = {"algorithmic_GB_per_s": round(whole, 1), "frac_of_hbm_peak": round(whole / 8000.0, 4), "note": "8 B per baseband sample in + the BBFRAME bytes out"}

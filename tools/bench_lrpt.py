@@ -63,7 +63,8 @@ def run(args) -> dict:
     ks = [one() for _ in range(args.steps)]
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / args.steps
-    kern = {k: round(v[0] / args.steps, 3) for k, v in capi.prof_get().items()}
+    prof = capi.prof_get()
+    kern = {k: round(v[0] / args.steps, 3) for k, v in prof.items()}
     capi.prof_enable(False)
     out = {"metric": "frames_per_s", "value": round(ks[-1] / dt, 1), "unit": "CADU/s", "ms_per_step": round(dt * 1e3, 3), "steps": args.steps,
            "config": {"workload": f"meteor_lrpt_decoder, {nfr} frames of 16384 soft bytes (r=1/2 k=7 QPSK, 1024-byte CADUs, RS(255,223) x 4), sigma {args.sigma} on +-70"},
@@ -72,7 +73,7 @@ def run(args) -> dict:
     # the correlator reads the hard bits (n / 8), RS reads and writes the frames
     steps_b = {"k_vit2_acs": n + nfr * 1024, "k_vit2_tb": nfr * 1024, "k_vit2_prep": 2 * n, "k_lrpt_gather": 2 * n, "k_lrpt_hard": n + n / 8, "k_lrpt_spec": n / 8, "k_lrpt_chain": n / 8,
                "k_rs": 2 * nfr * 1020, "k_vit_ber": n / 8 + nfr * 1024}
-    out["roofline"] = _roofline("lrpt", kern, steps_b, "soft bytes in + decoded bytes out of the dominant kernel")
+    out["roofline"] = _roofline("lrpt", kern, steps_b, "soft bytes in + decoded bytes out of the dominant kernel", {k: v[1] / args.steps for k, v in prof.items()})
     out["whole_path"] = {"algorithmic_GB_per_s": round((n + ks[-1] * 1024) / dt / 1e9, 2), "frac_of_hbm_peak": round((n + ks[-1] * 1024) / dt / 1e9 / 8000.0, 5)}
     if args.cpu_frames > 0 and pyref.ref_available():
         m = 1234 + args.cpu_frames * 16384
@@ -89,7 +90,7 @@ def run(args) -> dict:
 
 
 
-def _roofline(tag, kern, algo_bytes, note):
+def _roofline(tag, kern, algo_bytes, note, launches=None):
     """the dominant kernel of the line against the HBM roof (bench.py's object): algorithmic bytes of that kernel per step / its HIP-event time per step; traffic
     from the PMC profile of this very bench when one was committed for these kernel sources (bench.pmc_traffic)"""
     import os, sys
@@ -102,8 +103,10 @@ def _roofline(tag, kern, algo_bytes, note):
     if key is None:
         return {"bound": "hbm", "kernel": dom, "achieved": None, "peak": 8000.0, "unit": "GB/s", "frac": None, "traffic": None, "note": "no byte model for this kernel: " + note}
     ach = algo_bytes[key] / (kern[dom] * 1e-3) / 1e9
-    tr, src = _b.pmc_traffic(tag, dom)
-    return {"bound": "hbm", "kernel": dom, "achieved": round(ach, 2), "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 5), "traffic": tr, "traffic_source": src,
+    lps = float((launches or {}).get(dom, 1.0))
+    tr, tr1, src = _b.pmc_traffic_per_step(tag, dom, lps)  # per STEP, like algo_bytes_per_step (x launches per step)
+    return {"bound": "hbm", "kernel": dom, "achieved": round(ach, 2), "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 5), "traffic": tr, "traffic_per_launch": tr1,
+            "launches_per_step": lps, "traffic_source": src,
             "algo_bytes_per_step": int(algo_bytes[key]), "ms_per_step": kern[dom], "note": note}
 
 

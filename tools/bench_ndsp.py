@@ -108,7 +108,7 @@ def run(args) -> dict:
                           "sample": f"first {ncpu} samples, the hier block's own topology: rrc, agc, rec, pll, splitter, snr estimator threads + feeder"}}
     # per-kernel algorithmic bytes per step: a lane stage reads and writes every sample once (8 + 8 B), the clock recovery reads the samples and writes the symbols
     steps_b = {"k_chunks": 16 * n, "k_fir_window": 16 * n, "k_fir": 16 * n, "k_mm": 8 * n + 8 * int(ns), "k_quantize": 16 * int(ns), "k_derotate": 16 * int(ns)}
-    res["roofline"] = _roofline("ndsp", kern, steps_b, "8 B in + 8 B out per sample of the dominant stage")
+    res["roofline"] = _roofline("ndsp", kern, steps_b, "8 B in + 8 B out per sample of the dominant stage", {k: v[1] / args.steps for k, v in prof.items()})
     res["whole_path"] = {"algorithmic_GB_per_s": round((8 * n + 8 * int(ns)) / dt / 1e9, 1), "frac_of_hbm_peak": round((8 * n + 8 * int(ns)) / dt / 1e9 / 8000.0, 5)}
     L.sdhip_ndsp_psk_demod_destroy(h)
     del d_x, d_y
@@ -116,7 +116,7 @@ def run(args) -> dict:
 
 
 
-def _roofline(tag, kern, algo_bytes, note):
+def _roofline(tag, kern, algo_bytes, note, launches=None):
     """the dominant kernel of the line against the HBM roof (bench.py's object): algorithmic bytes of that kernel per step / its HIP-event time per step; traffic
     from the PMC profile of this very bench when one was committed for these kernel sources (bench.pmc_traffic)"""
     import os, sys
@@ -129,8 +129,10 @@ def _roofline(tag, kern, algo_bytes, note):
     if key is None:
         return {"bound": "hbm", "kernel": dom, "achieved": None, "peak": 8000.0, "unit": "GB/s", "frac": None, "traffic": None, "note": "no byte model for this kernel: " + note}
     ach = algo_bytes[key] / (kern[dom] * 1e-3) / 1e9
-    tr, src = _b.pmc_traffic(tag, dom)
-    return {"bound": "hbm", "kernel": dom, "achieved": round(ach, 2), "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 5), "traffic": tr, "traffic_source": src,
+    lps = float((launches or {}).get(dom, 1.0))
+    tr, tr1, src = _b.pmc_traffic_per_step(tag, dom, lps)  # per STEP, like algo_bytes_per_step (x launches per step)
+    return {"bound": "hbm", "kernel": dom, "achieved": round(ach, 2), "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 5), "traffic": tr, "traffic_per_launch": tr1,
+            "launches_per_step": lps, "traffic_source": src,
             "algo_bytes_per_step": int(algo_bytes[key]), "ms_per_step": kern[dom], "note": note}
 
 

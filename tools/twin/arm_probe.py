@@ -40,6 +40,16 @@ err = np.abs(sy[:n] - ref) / np.sqrt(np.mean(np.abs(ref) ** 2))
 other = np.abs(step) >= 2
 print(f"chunks {st.chunks} fixed {st.chunks_fixed} inexact {st.chunks_inexact}; symbols {n}: same {np.mean(step == 0):.6f} one {np.mean(np.abs(step) == 1):.6f} other {other.sum()} "
       f"max|step| {np.abs(step).max()}; beyond 1e-5 {np.mean(err > 1e-5):.6f}; same-arm beyond 1e-5 {(err[step == 0] > 1e-5).sum()}")
+amp = np.abs(np.abs(sy[:n]) - np.abs(ref)) / np.sqrt(np.mean(np.abs(ref) ** 2))
+ang = np.abs(np.angle(sy[:n] * np.conj(ref)))
+sb = np.flatnonzero((step == 0) & (err > 1e-5))
+if len(sb):
+    runs = np.split(sb, np.flatnonzero(np.diff(sb) > 400) + 1)
+    print(f"same-arm beyond 1e-5: {len(sb)} symbols in {len(runs)} clusters; max angle {ang[sb].max():.3g}, max amplitude diff {amp[sb].max():.3g}")
+    for r in runs[:30]:
+        a, b = r[0], r[-1]
+        s0 = ref_pos[a] // 128
+        print(f"  symbols {a}..{b} ({len(r)}), sample {s0} = chunk {s0 / chunk:.3f}; angle first {ang[a]:.3g} max {ang[r].max():.3g}, amplitude max {amp[r].max():.3g}")
 idx = np.flatnonzero(other)
 if len(idx):
     runs = np.split(idx, np.flatnonzero(np.diff(idx) > 200) + 1)
