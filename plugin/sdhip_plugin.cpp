@@ -1464,6 +1464,140 @@ namespace sdhip_plugin
         }
     };
 
+    // ------------------------------------------------------------------------------------------------ dvbs2_ts_extractor
+    // S2TStoTCPModule (plugins/dvb_support/dvbs2/module_s2_ts_extractor.{h,cpp}) on sdhip_s2_ts_* (csrc/dvbs2_ts.hip): same keys ("bb_size", or "modcod" mandatory +
+    // "shortframes" / "pilots" -> BBFrameBCH::dataSize(), :24-52, the same exception text), .bbframe file or fifo in, one BBFrameTSParser::work call per frame's
+    // worth of bytes (:77-89). The reads of the module's loop are reproduced: `while (!data_in.eof())` runs once more after the last whole frame, on a buffer the
+    // short (or empty) read has only partly overwritten -- a file that ends on a frame boundary has its last frame parsed twice. Output: the reference module never
+    // opens its data_out (:62-70: only data_in), so what it writes to a file is lost; here the packets go to <output_file_hint>.ts.
+    class S2TSExtractorHipModule : public ProcessingModule
+    {
+        int bbframe_size = 0, device = 0;
+        void *h = nullptr;
+        std::ifstream data_in;
+        std::ofstream data_out;
+        std::atomic<uint64_t> filesize{0}, progress{0}, packets{0};
+
+    public:
+        S2TSExtractorHipModule(std::string input_file, std::string output_file_hint, nlohmann::json parameters) : ProcessingModule(input_file, output_file_hint, parameters)
+        {
+            opt(parameters, "hip_device", device);
+            if (parameters.contains("bb_size"))
+                bbframe_size = parameters["bb_size"].get<int>();
+            else
+            {
+                int d_modcod = -1;
+                bool d_shortframes = false;
+                if (parameters.count("modcod") > 0)
+                    d_modcod = parameters["modcod"].get<int>();
+                else
+                    throw satdump_exception("MODCOD parameter must be present!");
+                if (parameters.count("shortframes") > 0)
+                    d_shortframes = parameters["shortframes"].get<bool>();
+                int bits = 0, slots = 0, rate = 0, constellation = 0;
+                if (sdhip_s2_cfg(d_modcod, d_shortframes ? 1 : 0, &bits, &slots, &rate, &constellation) != 0) // get_dvbs2_cfg's table and messages
+                    throw satdump_exception(sdhip_last_error());
+                sdhip_bch_cfg bc{d_shortframes ? 1 : 0, rate, device};
+                void *b = sdhip_bch_create(&bc);
+                if (!b)
+                    throw satdump_exception(std::string("dvbs2_ts_extractor_hip: ") + sdhip_last_error());
+                int kbch = 0, nbch = 0;
+                sdhip_bch_dims(b, &kbch, &nbch);
+                sdhip_bch_destroy(b);
+                bbframe_size = kbch;
+            }
+        }
+        ~S2TSExtractorHipModule()
+        {
+            if (h)
+                sdhip_s2_ts_destroy(h);
+        }
+        std::vector<ModuleDataType> getInputTypes() { return {DATA_FILE, DATA_STREAM}; }
+        std::vector<ModuleDataType> getOutputTypes() { return {DATA_FILE}; }
+        void init()
+        {
+            h = sdhip_s2_ts_create(device, bbframe_size);
+            if (!h)
+                throw satdump_exception(std::string("dvbs2_ts_extractor_hip: ") + sdhip_last_error());
+        }
+        void emit(const std::vector<uint8_t> &frames, size_t nframes, std::vector<uint8_t> &ts)
+        {
+            const size_t fb = (size_t)bbframe_size / 8;
+            ts.resize((nframes * (fb / 188 + 2) + 8) * 188);
+            const int64_t n = sdhip_s2_ts_process(h, frames.data(), (int)nframes, ts.data(), ts.size() / 188);
+            if (n < 0)
+                throw satdump_exception(std::string("dvbs2_ts_extractor_hip: ") + sdhip_last_error());
+            if (n > 0)
+            {
+                if (output_data_type == DATA_FILE)
+                    data_out.write((char *)ts.data(), (std::streamsize)n * 188);
+                else
+                    output_fifo->write(ts.data(), (size_t)n * 188);
+            }
+            packets += (uint64_t)n;
+        }
+        void process()
+        {
+            const size_t fb = (size_t)bbframe_size / 8;
+            if (output_data_type == DATA_FILE)
+            {
+                d_output_file = d_output_file_hint + ".ts";
+                data_out = std::ofstream(d_output_file, std::ios::binary);
+            }
+            logger->info("Using input bbframes " + d_input_file);
+            std::vector<uint8_t> ts;
+            if (input_data_type == DATA_FILE)
+            {
+                filesize = (uint64_t)std::filesystem::file_size(d_input_file);
+                data_in = std::ifstream(d_input_file, std::ios::binary);
+                const uint64_t nfull = filesize / fb, rem = filesize - nfull * fb;
+                const size_t batch = 2048;
+                std::vector<uint8_t> buf(fb * batch), last(fb, 0); // `last`: what the module's bb_buffer holds before a read
+                for (uint64_t k = 0; k < nfull; k += batch)
+                {
+                    const size_t nb = (size_t)std::min<uint64_t>(batch, nfull - k);
+                    data_in.read((char *)buf.data(), (std::streamsize)(nb * fb));
+                    emit(buf, nb, ts);
+                    memcpy(last.data(), buf.data() + (nb - 1) * fb, fb);
+                    progress = (k + nb) * fb;
+                }
+                // the loop's last turn (:77-89): a short read on top of the previous frame, eof only then
+                if (rem)
+                    data_in.read((char *)last.data(), (std::streamsize)rem);
+                buf.assign(last.begin(), last.end());
+                emit(buf, 1, ts);
+                progress = filesize.load();
+                data_in.close();
+            }
+            else
+            {
+                std::vector<uint8_t> buf(fb);
+                while (input_active.load())
+                {
+                    input_fifo->read(buf.data(), (int)fb);
+                    emit(buf, 1, ts);
+                }
+            }
+            if (output_data_type == DATA_FILE)
+                data_out.close();
+        }
+        void drawUI(bool) {}
+        nlohmann::json getModuleStats()
+        {
+            nlohmann::json v;
+            v["progress"] = filesize ? ((double)progress / (double)filesize) : 0.0;
+            v["ts_packets"] = packets.load();
+            return v;
+        }
+        static std::string getID() { return "dvbs2_ts_extractor_hip"; }
+        virtual std::string getIDM() { return getID(); }
+        static nlohmann::json getParams() { return {}; }
+        static std::shared_ptr<ProcessingModule> getInstance(std::string input_file, std::string output_file_hint, nlohmann::json parameters)
+        {
+            return std::make_shared<S2TSExtractorHipModule>(input_file, output_file_hint, parameters);
+        }
+    };
+
     // ------------------------------------------------------------------------------------------------ dvbs2_demod
     // DVBS2DemodModule (plugins/dvb_support/dvbs2/module_dvbs2_demod.{h,cpp}) on the handle of include/sdhip.h (sdhip_dvbs2_demod_*): same JSON
     // keys, defaults and exceptions, baseband file / dsp::stream in, .bbframe file / fifo out, the same statistics keys. What the module builds on the
@@ -1744,6 +1878,7 @@ namespace sdhip_plugin
             REGISTER_MODULE_EXTERNAL(evt.modules_registry, MetOpAHRPTDecoderHipModule);
             REGISTER_MODULE_EXTERNAL(evt.modules_registry, CCSDSSimplePSKDecoderHipModule);
             REGISTER_MODULE_EXTERNAL(evt.modules_registry, DVBS2DemodHipModule);
+            REGISTER_MODULE_EXTERNAL(evt.modules_registry, S2TSExtractorHipModule);
             REGISTER_MODULE_EXTERNAL(evt.modules_registry, METEORLRPTDecoderHipModule);
             REGISTER_MODULE_EXTERNAL(evt.modules_registry, METEORLRPTM2XHipModule);
             REGISTER_MODULE_EXTERNAL(evt.modules_registry, FengyunAHRPTDecoderHipModule);
@@ -1806,6 +1941,8 @@ namespace sdhip_plugin
                         return DVBS2DemodHipModule::getInstance(in, out, p);
                     };
                 }
+                else if (e.id == "dvbs2_ts_extractor") // plugins/dvb_support's second module: the step behind the BBFRAMEs
+                    e.inst = S2TSExtractorHipModule::getInstance;
                 else if (e.id == "meteor_lrpt_decoder")
                 { // plugins/meteor_support's module (ordering caveat as for metop_ahrpt_decoder); of its m2x_mode branch the interleaved variant stays on the CPU module
                     auto cpu = e.inst;

@@ -126,8 +126,8 @@ public:
     void drawUI(bool) {}
     static const char *name()
     {
-        static const char *n[8] = {"psk_demod", "ccsds_conv_concat_decoder", "metop_ahrpt_decoder", "ccsds_simple_psk_decoder", "dvbs2_demod", "meteor_lrpt_decoder", "fengyun_ahrpt_decoder",
-                                   "fengyun_mpt_decoder"};
+        static const char *n[9] = {"psk_demod", "ccsds_conv_concat_decoder", "metop_ahrpt_decoder", "ccsds_simple_psk_decoder", "dvbs2_demod", "meteor_lrpt_decoder", "fengyun_ahrpt_decoder",
+                                   "fengyun_mpt_decoder", "dvbs2_ts_extractor"};
         return n[WHICH];
     }
     static std::string getID() { return name(); }
@@ -169,6 +169,7 @@ int main(int argc, char **argv)
     REGISTER_MODULE(CpuStandIn<5>); // meteor_lrpt_decoder (plugins/meteor_support)
     REGISTER_MODULE(CpuStandIn<6>); // fengyun_ahrpt_decoder (plugins/fengyun3_support)
     REGISTER_MODULE(CpuStandIn<7>); // fengyun_mpt_decoder (the same plugin)
+    REGISTER_MODULE(CpuStandIn<8>); // dvbs2_ts_extractor (plugins/dvb_support)
     satdump::eventBus->fire_event<satdump::SatDumpStartedEvent>({}); // init.cpp:163
 
     const std::string cmd = argv[3];

@@ -195,3 +195,12 @@ def test_hard_symbols_through_the_plugin_on_the_twin(host, tmp_path):
     if not pyref.ref_available() or not os.path.exists(emu_build.CLANG):
         pytest.skip("needs the compiled reference and a host clang++")
     G.check_hard_symbols_through_the_plugin(host, emu_build.build(), tmp_path, nframes=12)
+
+
+def test_ts_extractor_through_the_plugin_on_the_twin(host, tmp_path):
+    from oracle import pyref
+    from tests import test_plugin_minihost_gpu as G
+    from tests.emu import build as emu_build
+    if not pyref.s2_ts_available() or not os.path.exists(emu_build.CLANG):
+        pytest.skip("needs the compiled reference TS parser and a host clang++")
+    G.check_ts_extractor_through_the_plugin(host, emu_build.build(), tmp_path)

@@ -454,6 +454,46 @@ def test_dvbs2_module_through_the_plugin(host, tmp_path):
     check_dvbs2_module_through_the_plugin(host, LIB, tmp_path, modcod=13, short=0, nfr=10, acq=2 * 21690)
 
 
+def check_ts_extractor_through_the_plugin(host, lib, tmp_path):
+    """`dvbs2_ts_extractor` (plugins/dvb_support/dvbs2/module_s2_ts_extractor.cpp; round 6) through the drop-in boundary: the stock id, re-pointed by the plugin under
+    SDHIP_OVERRIDE=1 at S2TSExtractorHipModule, reads a .bbframe file and writes the transport stream -- against dvbs2::BBFrameTSParser compiled in place, fed
+    the reads the module's loop makes (one frame per call; the loop's extra turn at the end of the file parses a last buffer the short read has only partly
+    overwritten: a file ending on a frame boundary has its last frame parsed twice). `modcod` / `shortframes` -> the frame size as the module derives it
+    (BBFrameBCH::dataSize()), `bb_size` directly; the mandatory key's message."""
+    from tests.test_dvbs2_gpu import ts_bbframes
+    for name, params, kbch, tail in (("modcod", {"modcod": 13, "shortframes": False}, 43040, 0), ("bbsize", {"bb_size": 14232}, 14232, 333)):
+        frames, _ = ts_bbframes(kbch, nframes=50, seed=4, bad_hdr=(9,), corrupt_packets=(5, 60))
+        raw = frames.tobytes() + (frames[7].tobytes()[:tail] if tail else b"")
+        inp = tmp_path / (name + ".bbframe")
+        inp.write_bytes(raw)
+        fb = kbch // 8
+        last = bytearray(frames[-1].tobytes())
+        last[:tail] = raw[len(frames) * fb:]
+        fed = np.concatenate([frames, np.frombuffer(bytes(last), dtype=np.uint8).reshape(1, fb)])
+        want = pyref.s2_ts_extract(fed, kbch)
+        job = {"mode": "file", "input": str(inp), "output_hint": str(tmp_path / name), "demod": {"module": "dvbs2_ts_extractor", "parameters": params}}
+        jp = tmp_path / (name + ".json")
+        jp.write_text(json.dumps(job))
+        p = subprocess.run([host, lib, PLUGIN, "run", str(jp)], capture_output=True, text=True, env=dict(os.environ, SDHIP_OVERRIDE="1"), timeout=600)
+        assert p.returncode == 0, p.stdout[-1000:] + p.stderr[-3000:]
+        rep = json.loads(p.stdout.strip().splitlines()[-1])
+        assert rep["demod_class"] == "dvbs2_ts_extractor_hip", rep
+        got = np.fromfile(rep["soft"], dtype=np.uint8).reshape(-1, 188)
+        assert len(want) > 100 and got.shape == want.shape and np.array_equal(got, want), (name, got.shape, want.shape)
+        assert rep["demod_stats"]["ts_packets"] == len(want)
+    job = {"mode": "file", "input": str(inp), "output_hint": str(tmp_path / "nokey"), "instantiate_only": True, "demod": {"module": "dvbs2_ts_extractor", "parameters": {}}}
+    jp = tmp_path / "nokey.json"
+    jp.write_text(json.dumps(job))
+    p = subprocess.run([host, lib, PLUGIN, "run", str(jp)], capture_output=True, text=True, env=dict(os.environ, SDHIP_OVERRIDE="1"), timeout=600)
+    assert p.returncode != 0 and "MODCOD parameter must be present!" in p.stderr
+
+
+def test_ts_extractor_through_the_plugin(host, tmp_path):
+    if not pyref.s2_ts_available():
+        pytest.skip("needs the compiled reference TS parser")
+    check_ts_extractor_through_the_plugin(host, LIB, tmp_path)
+
+
 def check_hip_devices_through_the_plugin(host, lib, tmp_path, case="metop", nframes=60, devices=(0, 0, 0), serial_chunks=False):
     """`hip_devices` (round 4): ONE baseband file cut in time over several devices by the plugin's psk_demod (here the same device several times: the
     plumbing is the point), a thread and a handle per chunk, the chunks' soft streams joined where each CONTINUES its predecessor's (sdhip_shard_align) and
