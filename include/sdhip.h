@@ -259,6 +259,12 @@ extern "C"
         int device;
         /* fengyun_ahrpt_decoder only: "invert_second_viterbi" (module_fengyun_ahrpt_decoder.cpp:17,67) */
         int invert_second_viterbi;
+        /* meteor_lrpt_decoder, "m2x_mode" + "interleaved" (module_meteor_lrpt_decoder.cpp:28-41,103-199): with decoder = SDHIP_DEC_CONV_CONCAT and constellation =
+           SDHIP_OQPSK (the module's Viterbi1_2 over {PHASE_0, PHASE_90} with the I/Q exchange searched), the input is the INTERLEAVED .soft stream: two
+           meteor::DeinterleaverReader (the stream, and the stream a quarter turn on) in front of two such Viterbis, per read the locked one's bits to the deframer.
+           Held to the module's loop with its sample reader put right (in the reference tree it reports an error after 8192 bytes and the branch decodes nothing:
+           oracle/ref_wrap_lrpt_m2x.cpp, tests/test_lrpt_m2x_reference_cpu.py). Input of any length per call; sdhip_fec_flush ends the stream. */
+        int m2x_interleaved;
     } sdhip_fec_cfg;
 
     typedef struct sdhip_fec_stats
@@ -293,6 +299,9 @@ extern "C"
     /* Device-resident path: d_soft holds n soft bytes in HBM; CADUs are written to d_cadu (device,
        capacity cap_frames frames). Returns frames written, <0 on error. */
     int64_t sdhip_fec_process_dev(void *h, const int8_t *d_soft, size_t n, uint8_t *d_cadu, size_t cap_frames);
+    /* End of the input (m2x_interleaved only; a no-op otherwise): the reads the module's loop still makes on the zero-filled rest of its FIFOs until should_run()
+       turns false. d_cadu / cap_frames as for sdhip_fec_process_dev, or NULL / 0: the frames queue up for sdhip_fec_pull. Returns the frames written / queued. */
+    int64_t sdhip_fec_flush(void *h, uint8_t *d_cadu, size_t cap_frames);
     int sdhip_fec_get_stats(void *h, sdhip_fec_stats *st);
     /* Optional per-block taps of the last process call (host arrays, may be NULL):
        blk_ber[nblocks], blk_state[nblocks]. Returns number of blocks. (fengyun_ahrpt_decoder: two entries per read, Viterbi 1 then Viterbi 2.) */

@@ -62,6 +62,9 @@ namespace
     };
 }
 
+#include <new>
+#include <cstdlib>
+
 extern "C"
 {
     // soft: the .soft file; cadu_out: cap frames of 1024 bytes. taps (may be NULL, taps_cap entries each): per iteration the Viterbi taken (1 / 2; 1 when not
@@ -75,8 +78,16 @@ extern "C"
         std::vector<int8_t> store1(ENCODED_FRAME_SIZE + INTER_MARKER_STRIDE, 0), store2(ENCODED_FRAME_SIZE + INTER_MARKER_STRIDE, 0);
         int8_t *buffer = store1.data() + INTER_MARKER_STRIDE, *buffer2 = store2.data() + INTER_MARKER_STRIDE;
         std::vector<phase_t> phases = {PHASE_0, PHASE_90};
-        auto viterbin = std::make_shared<viterbi::Viterbi1_2>(ber_thr, outsync_after, BUFFER_SIZE, phases, true);
-        auto viterbin2 = std::make_shared<viterbi::Viterbi1_2>(ber_thr, outsync_after, BUFFER_SIZE, phases, true);
+        // (on zero-filled storage: the class reads a few bytes of its ber_decoded_buffer member before it has written them, viterbi_1_2.cpp:68 -- pinned to zero
+        // as in ref_wrap.cpp's zero_new; on the module's heap they are whatever was there)
+        auto zero_vit = [&]() {
+            void *p = calloc(1, sizeof(viterbi::Viterbi1_2));
+            return std::shared_ptr<viterbi::Viterbi1_2>(new (p) viterbi::Viterbi1_2(ber_thr, outsync_after, BUFFER_SIZE, phases, true), [](viterbi::Viterbi1_2 *v) {
+                v->~Viterbi1_2();
+                free(v);
+            });
+        };
+        auto viterbin = zero_vit(), viterbin2 = zero_vit();
         auto deframer = std::make_shared<deframing::BPSK_CCSDS_Deframer>(8192);
         std::shared_ptr<meteor::DeinterleaverReader> deint1, deint2;
         if (interleaved)

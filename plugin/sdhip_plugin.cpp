@@ -1322,13 +1322,23 @@ namespace sdhip_plugin
     // METEORLRPTDecoderModule's m2x_mode branch WITHOUT the interleaver (module_meteor_lrpt_decoder.cpp:24-33, 103-200 with interleaved = false): 8192 soft bytes
     // per read -> Viterbi1_2 (phases 0 / 90, I/Q exchange searched) -> NRZ-M ("diff_decode") -> BPSK_CCSDS_Deframer(8192) -> derandomiser -> RS(255,223) x 4,
     // conventional basis, frames with an uncorrectable codeword dropped: statement for statement the concatenated decoder with an "oqpsk" constellation, so the
-    // module is that handle with the keys fixed. The interleaved variant (two DeinterleaverReaders, two Viterbis) stays on the CPU module.
+    // module is that handle with the keys fixed.
+    // "interleaved" (today's Meteor-M pipelines, resources/pipelines/Meteor-M.json:246-255; module_meteor_lrpt_decoder.cpp:103-146, deint.cpp): two
+    // meteor::DeinterleaverReader on the .soft stream and on the stream a quarter turn on, two Viterbi1_2, per read the locked one's bits to the deframer -- the
+    // same handle with sdhip_fec_cfg::m2x_interleaved (csrc/m2x_deint.h). In the reference tree this repo is built against that branch reads 8192 bytes and never
+    // decodes (its DintSampleReader takes the `false` its input_function returns as an error, :68,125-129; tests/test_lrpt_m2x_reference_cpu.py): the handle is
+    // held to the module's loop with the reader returning what it read, which is what the module is meant to do, and this module ends at the end of the input
+    // where the reference's spins. SDHIP_M2X_INTERLEAVED=0 keeps the parameter set on the CPU module.
     class METEORLRPTM2XHipModule : public FecHipModuleBase
     {
+        bool interleaved = false;
+
     public:
         METEORLRPTM2XHipModule(std::string input_file, std::string output_file_hint, nlohmann::json parameters)
             : FecHipModuleBase(input_file, output_file_hint, parameters)
         {
+            interleaved = parameters.count("interleaved") > 0 && parameters["interleaved"].get<bool>();
+            cfg.m2x_interleaved = interleaved ? 1 : 0;
             cfg.decoder = SDHIP_DEC_CONV_CONCAT;
             cfg.constellation = SDHIP_OQPSK; // std::vector<phase_t> phases = {PHASE_0, PHASE_90}, check_iq_swap = true (:31-32)
             cfg.cadu_size = 8192;
@@ -1350,7 +1360,60 @@ namespace sdhip_plugin
         }
         static bool covers(const nlohmann::json &p)
         {
-            return p.count("m2x_mode") > 0 && p["m2x_mode"].get<bool>() && !(p.count("interleaved") > 0 && p["interleaved"].get<bool>());
+            if (!(p.count("m2x_mode") > 0 && p["m2x_mode"].get<bool>()))
+                return false;
+            const char *e = getenv("SDHIP_M2X_INTERLEAVED");
+            return !(p.count("interleaved") > 0 && p["interleaved"].get<bool>()) || !(e && std::string(e) == "0");
+        }
+        void process()
+        {
+            if (!interleaved)
+                return FecHipModuleBase::process();
+            // the module's sample reader fetches 8192 bytes at a time whenever a de-interleaver asks for more than it holds (:65-72); the handle takes the stream in
+            // any cut and ends it with sdhip_fec_flush (the reads the module's loop still makes on what its FIFOs hold when the input runs dry)
+            const size_t chunk = input_data_type == DATA_FILE ? (size_t)8192 * 512 : (size_t)8192;
+            std::vector<int8_t> soft(chunk);
+            std::vector<uint8_t> frames((size_t)cadu_bytes * 4096);
+            auto drain = [&]() {
+                for (;;)
+                {
+                    const int64_t n = sdhip_fec_pull(h, frames.data(), frames.size() / cadu_bytes);
+                    if (n < 0)
+                        throw satdump_exception(std::string(getIDM()) + ": " + sdhip_last_error());
+                    if (n == 0)
+                        break;
+                    write_data(frames.data(), (size_t)n * cadu_bytes);
+                }
+                sdhip_fec_stats st;
+                sdhip_fec_get_stats(h, &st);
+                const bool second = st.viterbi2_lock > st.viterbi_lock; // the Viterbi the module shows is the one it takes (:145-162)
+                viterbi_ber = second ? st.viterbi2_ber : st.viterbi_ber;
+                viterbi_lock = second ? st.viterbi2_lock : st.viterbi_lock;
+                deframer_state = st.deframer_state;
+                rs_avg = (st.rs_errors[0] + st.rs_errors[1] + st.rs_errors[2] + st.rs_errors[3]) / 4;
+            };
+            uint64_t total = 0, left = input_data_type == DATA_FILE ? (uint64_t)std::filesystem::file_size(d_input_file) : 0;
+            while (should_run())
+            {
+                size_t n = chunk;
+                if (input_data_type == DATA_FILE)
+                { // (read_data on a file does not say how much it read: the length is the file's)
+                    n = (size_t)std::min<uint64_t>(chunk, left - total);
+                    if (n == 0)
+                        break;
+                }
+                read_data((uint8_t *)soft.data(), n);
+                total += n;
+                if (sdhip_fec_push(h, soft.data(), n) < 0)
+                    throw satdump_exception(std::string(getIDM()) + ": " + sdhip_last_error());
+                drain();
+                if (input_data_type == DATA_FILE && total >= left)
+                    break;
+            }
+            if (sdhip_fec_flush(h, nullptr, 0) < 0)
+                throw satdump_exception(std::string(getIDM()) + ": " + sdhip_last_error());
+            drain();
+            cleanup();
         }
         static std::string getID() { return "meteor_lrpt_m2x_decoder_hip"; }
         virtual std::string getIDM() { return getID(); }

@@ -49,7 +49,7 @@ class FecCfg(C.Structure):
         ("derand_after_rs", C.c_int), ("derand_start", C.c_int), ("rs_i", C.c_int), ("rs_fill_bytes", C.c_int),
         ("rs_dualbasis", C.c_int), ("rs_type", C.c_int), ("rs_usecheck", C.c_int), ("asm_sync", C.c_uint32),
         ("qpsk_swap_iq", C.c_int), ("qpsk_swap_diff", C.c_int), ("oqpsk_delay", C.c_int), ("oqpsk_method2", C.c_int), ("oqpsk_method3", C.c_int),
-        ("conv_rate", C.c_int), ("device", C.c_int), ("invert_second_viterbi", C.c_int),
+        ("conv_rate", C.c_int), ("device", C.c_int), ("invert_second_viterbi", C.c_int), ("m2x_interleaved", C.c_int),
     ]
 
 
@@ -146,6 +146,9 @@ def lib():
         L.sdhip_fec_process_dev.restype = C.c_int64
         L.sdhip_fec_process_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
         L.sdhip_fec_get_stats.argtypes = [C.c_void_p, C.POINTER(FecStats)]
+        if hasattr(L, "sdhip_fec_flush"):
+            L.sdhip_fec_flush.restype = C.c_int64
+            L.sdhip_fec_flush.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
         L.sdhip_fec_get_block_taps.restype = C.c_int64
         L.sdhip_fec_get_block_taps.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
         L.sdhip_fec_cfg_default.argtypes = [C.POINTER(FecCfg)]
@@ -350,6 +353,10 @@ class FecDecoder:
 
     def process_dev(self, soft_ptr: int, n: int, cadu_ptr: int, cap_frames: int) -> int:
         return _check(lib().sdhip_fec_process_dev(self.h, C.c_void_p(soft_ptr), n, C.c_void_p(cadu_ptr), cap_frames), "sdhip_fec_process_dev")
+
+    def flush(self, cadu_ptr: int = 0, cap_frames: int = 0) -> int:
+        """end of the input (m2x_interleaved handles: the module's last reads); frames to cadu_ptr (device) or, with 0, to the queue pull() reads"""
+        return _check(lib().sdhip_fec_flush(self.h, C.c_void_p(cadu_ptr), cap_frames), "sdhip_fec_flush")
 
     def stats(self) -> FecStats:
         st = FecStats()

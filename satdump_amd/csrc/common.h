@@ -101,6 +101,11 @@ namespace sdhip
             p = (T *)pin_alloc(want * sizeof(T));
             cap = want;
         }
+        void swap(PinBuf &o)
+        {
+            std::swap(p, o.p);
+            std::swap(cap, o.cap);
+        }
         PinBuf() = default;
         PinBuf(const PinBuf &) = delete;
         PinBuf &operator=(const PinBuf &) = delete;

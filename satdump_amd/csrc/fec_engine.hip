@@ -7,6 +7,7 @@
 //         NRZ-M, exact ASM search over every bit, frame extraction, derandomiser, Reed-Solomon.
 //   host: O(#blocks) Viterbi lock FSM (viterbi_1_2.cpp:52-117), O(#frames) deframer FSM
 //         (bpsk_ccsds_deframer.cpp:24-107) working on the packed bit stream, rs_usecheck filter.
+#include "m2x_deint.h"
 #include "fec_kernels.h"
 #include "../../include/sdhip.h"
 #include <algorithm>
@@ -594,6 +595,12 @@ namespace sdhip
             d_search.reserve(1);
             d_count.reserve(1);
             upload_carry();
+            if (cfg.m2x_interleaved)
+            {
+                if (cfg.decoder != SDHIP_DEC_CONV_CONCAT || cfg.constellation != SDHIP_OQPSK || punc.rate != 0 || cfg.cadu_size != 8192)
+                    throw HipError("m2x_interleaved: the concatenated decoder's handle with an oqpsk constellation, rate 1/2, 8192-bit CADUs (meteor_lrpt_decoder's m2x_mode)");
+                m2x_init();
+            }
             if (n_streams == 2)
             { // second deframer: same initial state
                 parked.carry_bits = 64;
@@ -2013,6 +2020,350 @@ namespace sdhip
                 stats.rs_errors[k] = last_errors[k];
         }
 
+        // ------------------------------------------------------------------ meteor_lrpt_decoder, m2x_mode + interleaved (m2x_deint.h has the front)
+        // The loop of module_meteor_lrpt_decoder.cpp:130-198 per iteration: deint1 / deint2 ->read_samples (8192 de-interleaved samples each), viterbin / viterbin2
+        // ->work on them, the second one's bits if its state is the greater, NRZ-M, deframer, derandomiser, RS. Here: the iterations the data at hand allows, at a time --
+        // the two de-interleaved rails of all of them by two gathers (after the autocorrelations have placed the reads), the Viterbis in runs (a locked one decodes its
+        // run of reads in one launch; one that is searching searches read by read: its BER decoder is chained from search to search), the selected bits of the run to the
+        // deframer in one call.
+        struct M2xRail
+        {
+            int vstate = 0, v_iq_swap = 0, v_phase = 0, v_shift = 0, v_invalid = 0;
+            float v_ber = 10, v_bers[2][4][2];
+            int dec_first = 1, dec_start = 0;
+            VitSearchState search{};
+            DevBuf<VitSearchState> d_search;
+            DevBuf<VitBlockIO> d_io;
+            PinBuf<VitBlockIO> h_io;
+            DevBuf<uint32_t> d_vb;
+            DevBuf<int8_t> d_rail;
+            float ber(int nsw, int nph, const int *ph) const
+            { // Viterbi1_2::ber(), viterbi_1_2.cpp:119-133
+                if (vstate == 1)
+                    return v_ber;
+                float b = 10;
+                for (int s2 = 0; s2 < nsw; s2++)
+                    for (int pi = 0; pi < nph; pi++)
+                        for (int o = 0; o < 2; o++)
+                            if (b > v_bers[s2][ph[pi]][o])
+                                b = v_bers[s2][ph[pi]][o];
+                return b;
+            }
+        };
+        struct M2x
+        {
+            M2xBranch br[2];
+            M2xRail rail[2];
+            DevBuf<int8_t> d_raw, d_raw2;
+            long long raw_base = 0, raw_end = 0; // absolute stream positions of d_raw[0] and of the end of what has been pushed
+            bool done = false;                    // the module's loop has ended (should_run() false)
+            DevBuf<long long> d_pos;
+            DevBuf<int> d_ns, d_res;
+            DevBuf<unsigned char> d_hard;
+            DevBuf<M2xRead> d_reads;
+            std::vector<int> which; // taps: the Viterbi taken per iteration of the last call (1 / 2)
+            long long iterations = 0;
+        } m2x;
+
+        void m2x_init()
+        {
+            m2x.br[1].second = 1;
+            for (M2xRail &r : m2x.rail)
+            {
+                memset(&r.search, 0, sizeof(r.search));
+                r.search.ber_first = 1;
+                r.d_search.reserve(1);
+                for (auto &a : r.v_bers)
+                    for (auto &b2 : a)
+                        for (float &c2 : b2)
+                            c2 = 10;
+            }
+        }
+        // append n bytes (device or host memory) to the raw stream kept on the device; bytes no gather can reach any more are dropped first
+        void m2x_append(const int8_t *src, size_t n, bool on_device)
+        {
+            // the oldest call an output of a future call can still come from: 35 x 73 728 data samples = 316 calls back
+            long long keep_from = m2x.raw_end;
+            for (const M2xBranch &b : m2x.br)
+            {
+                const long long c_old = std::max<long long>(b.hist_base, b.calls - 320);
+                const long long pk = (c_old < b.calls && !b.hist.empty()) ? b.hist[(size_t)(c_old - b.hist_base)].p - 128 : b.p_next - 128;
+                keep_from = std::min(keep_from, std::max<long long>(0, pk));
+            }
+            keep_from = std::max(keep_from, m2x.raw_base);
+            const size_t have = (size_t)(m2x.raw_end - m2x.raw_base), live = (size_t)(m2x.raw_end - keep_from);
+            if (have + n > m2x.d_raw.cap)
+            { // make room: the live part to the front of a buffer that holds it and the new bytes
+                m2x.d_raw2.reserve((live + n) * 2 + (1u << 20));
+                if (live)
+                    SD_HIP(hipMemcpyAsync(m2x.d_raw2.p, m2x.d_raw.p + (keep_from - m2x.raw_base), live, hipMemcpyDeviceToDevice, stream));
+                SD_HIP(hipStreamSynchronize(stream));
+                m2x.d_raw.swap(m2x.d_raw2);
+                m2x.raw_base = keep_from;
+            }
+            if (n)
+                SD_HIP(hipMemcpyAsync(m2x.d_raw.p + (m2x.raw_end - m2x.raw_base), src, n, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, stream));
+            SD_HIP(hipStreamSynchronize(stream));
+            m2x.raw_end += (long long)n;
+        }
+        // Viterbi1_2's lock search on read `blk` of a rail (viterbi_1_2.cpp:54-92): run_search on the rail's own state
+        void m2x_search(M2xRail &r, int64_t blk)
+        {
+            const bool dbg = getenv("SDHIP_DEBUG") != nullptr;
+            const auto t0 = std::chrono::steady_clock::now();
+            SD_HIP(hipMemcpyAsync(r.d_search.p, &r.search, sizeof(r.search), hipMemcpyHostToDevice, stream));
+            launch_vit_search(vc, r.d_rail.p, blk, n_swap, phases, nphases, r.d_search.p, stream);
+            SD_HIP(hipMemcpyAsync(&r.search, r.d_search.p, sizeof(r.search), hipMemcpyDeviceToHost, stream));
+            SD_HIP(hipStreamSynchronize(stream));
+            if (dbg)
+                fprintf(stderr, "[sdhip] m2x    search read %lld: %.1f ms\n", (long long)blk, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+            r.v_ber = 10;
+            int cand = 0;
+            for (int s2 = 0; s2 < n_swap; s2++)
+                for (int pi = 0; pi < nphases; pi++)
+                    for (int shift = 0; shift < 2; shift++, cand++)
+                    {
+                        const float errors = (float)r.search.err[cand], total = (float)r.search.tot[cand];
+                        const float ber = (float)((errors / total) * ber_mult);
+                        r.v_bers[s2][phases[pi]][shift] = ber;
+                        if ((r.v_ber == 10 && ber < cfg.viterbi_ber_thresold) || (r.v_ber < 10 && ber < r.v_ber))
+                        {
+                            r.v_ber = ber;
+                            r.v_iq_swap = s2;
+                            r.vstate = 1;
+                            r.v_phase = phases[pi];
+                            r.v_shift = shift;
+                            r.v_invalid = 0;
+                        }
+                    }
+        }
+        void m2x_decode(M2xRail &r, int64_t blk, int n)
+        {
+            VitCfg v = vc;
+            v.iq_swap = r.v_iq_swap;
+            v.phase = r.v_phase;
+            v.shift = r.v_shift;
+            const auto no_tick = [](const char *) {};
+            vit_run(v, r.d_rail.p, blk, n, r.dec_first ? -2 : r.dec_start, r.d_io, r.h_io, r.d_vb, r.search.enc_state, no_tick);
+        }
+        // the BER check behind a decoded read (viterbi_1_2.cpp:101-113)
+        void m2x_fsm(M2xRail &r, int j)
+        {
+            const float errors = (float)r.h_io.p[j].ber_err, total = (float)r.h_io.p[j].ber_tot;
+            r.v_ber = (float)((errors / total) * ber_mult);
+            if (r.v_ber > cfg.viterbi_ber_thresold)
+            {
+                r.v_invalid++;
+                if ((float)r.v_invalid > (float)cfg.viterbi_outsync_after)
+                    r.vstate = 0;
+            }
+            else
+                r.v_invalid = 0;
+        }
+        void m2x_commit(M2xRail &r, int j)
+        { // the decoder objects' chained state behind read j of the rail's current run
+            r.dec_first = 0;
+            r.dec_start = r.h_io.p[j].ret_state;
+            r.search.enc_state = (unsigned)r.h_io.p[j].pad;
+        }
+
+        // the Viterbi part of K iterations whose rails are in place; selected bits to the deframer
+        void m2x_viterbi(int K, uint8_t *d_out, size_t out_cap_frames, size_t &out_written)
+        {
+            d_vbits.reserve((size_t)K * wpb + 4);
+            int nsel = 0;
+            int64_t pos = 0;
+            while (pos < K)
+            {
+                M2xRail *R = m2x.rail;
+                bool dec[2];
+                for (int k = 0; k < 2; k++)
+                {
+                    if (R[k].vstate == 0)
+                        m2x_search(R[k], pos);
+                    dec[k] = R[k].vstate == 1;
+                }
+                // the run: while a rail is searching it is one read long for that rail's sake unless the other one can carry on (see below)
+                const int n = (int)std::min<int64_t>(K - pos, max_batch);
+                for (int k = 0; k < 2; k++)
+                    if (dec[k])
+                        m2x_decode(R[k], pos, n);
+                int used = n;
+                for (int j = 0; j < n; j++)
+                {
+                    int out_n[2] = {0, 0};
+                    bool ends = false;
+                    for (int k = 0; k < 2; k++)
+                    {
+                        if (dec[k])
+                        {
+                            out_n[k] = F;
+                            m2x_fsm(R[k], j);
+                            if (R[k].vstate == 0)
+                                ends = true; // it searches again from the next read on
+                        }
+                        else if (j > 0)
+                        { // a searching Viterbi searches every read (read pos was searched above)
+                            m2x_search(R[k], pos + j);
+                            if (R[k].vstate == 1)
+                            { // found: it decodes this very read, and the run ends behind it (from the next read on both decode in step)
+                                m2x_decode(R[k], pos + j, 1);
+                                out_n[k] = F;
+                                m2x_fsm(R[k], 0);
+                                m2x_commit(R[k], 0);
+                                ends = true;
+                            }
+                        }
+                    }
+                    // module_meteor_lrpt_decoder.cpp:145-162
+                    const int pick = R[1].vstate > R[0].vstate ? 1 : 0;
+                    tap_ber.push_back(R[pick].ber(n_swap, nphases, phases));
+                    tap_state.push_back(R[pick].vstate);
+                    m2x.which.push_back(pick + 1);
+                    if (out_n[pick] > 0)
+                    { // (a rail that found its lock at this read decoded it as block 0 of a one-read run of its own)
+                        const bool own_run = !dec[pick];
+                        SD_HIP(hipMemcpyAsync(d_vbits.p + (size_t)nsel * wpb, R[pick].d_vb.p + (size_t)(own_run ? 0 : j) * wpb, (size_t)wpb * 4, hipMemcpyDeviceToDevice, stream));
+                        nsel++;
+                    }
+                    if (ends || j == n - 1)
+                    {
+                        used = j + 1;
+                        for (int k = 0; k < 2; k++)
+                            if (dec[k])
+                                m2x_commit(R[k], j);
+                        break;
+                    }
+                }
+                pos += used;
+                stats.blocks += used;
+            }
+            if (nsel > 0)
+            {
+                SD_HIP(hipStreamSynchronize(stream));
+                deframe_and_emit(nsel, d_out, out_cap_frames, out_written);
+            }
+            stats.viterbi_lock = m2x.rail[0].vstate;
+            stats.viterbi_ber = m2x.rail[0].ber(n_swap, nphases, phases);
+            stats.viterbi2_lock = m2x.rail[1].vstate;
+            stats.viterbi2_ber = m2x.rail[1].ber(n_swap, nphases, phases);
+            stats.deframer_state = def.state;
+            for (int k = 0; k < 8; k++)
+                stats.rs_errors[k] = last_errors[k];
+        }
+
+        // as many iterations of the module's loop as the stream at hand allows (final: until should_run() turns false)
+        void m2x_run(bool final, uint8_t *d_out, size_t out_cap_frames, size_t &out_written)
+        {
+            const int max_iter = 2048;
+            const long long thr = (m2x.raw_end / 8192) * 8192; // final: the fetch that reaches past this is short -> eof (DintSampleReader::read_more, filestream read_data)
+            while (!m2x.done)
+            {
+                // ---- place the next reads of both readers on the assumption that their markers are where they are expected
+                int K = max_iter;
+                std::vector<long long> pos[2];
+                std::vector<int> ns[2];
+                for (int b = 0; b < 2; b++)
+                {
+                    long long p = m2x.br[b].p_next;
+                    int k = 0;
+                    for (; k < K; k++)
+                    {
+                        const int nsam = M2xBranch::num_samples(m2x.br[b].calls + k);
+                        if (!final && p + nsam + 48 > m2x.raw_end)
+                            break;
+                        pos[b].push_back(p);
+                        ns[b].push_back(nsam);
+                        p += nsam;
+                    }
+                    K = std::min(K, k);
+                }
+                if (K == 0)
+                    break;
+                if (getenv("SDHIP_DEBUG"))
+                    fprintf(stderr, "[sdhip] m2x    %d reads placed from call %lld (stream %lld .. %lld, final %d)\n", K, m2x.br[0].calls, m2x.raw_base, m2x.raw_end, (int)final);
+                // ---- their autocorrelations
+                std::vector<int> res[2];
+                for (int b = 0; b < 2; b++)
+                {
+                    m2x.d_pos.reserve(K);
+                    m2x.d_ns.reserve(K);
+                    m2x.d_res.reserve(2 * (size_t)K);
+                    m2x.d_hard.reserve((size_t)K * M2X_HARD_MAX);
+                    SD_HIP(hipMemcpyAsync(m2x.d_pos.p, pos[b].data(), (size_t)K * sizeof(long long), hipMemcpyHostToDevice, stream));
+                    SD_HIP(hipMemcpyAsync(m2x.d_ns.p, ns[b].data(), (size_t)K * sizeof(int), hipMemcpyHostToDevice, stream));
+                    {
+                        ProfScope _ps("k_m2x_autocorr", stream);
+                        hipLaunchKernelGGL(k_m2x_autocorr, dim3((K + 63) / 64), dim3(64), 0, stream, (const signed char *)m2x.d_raw.p, m2x.raw_base, m2x.raw_end, b, m2x.d_pos.p, m2x.d_ns.p, K,
+                                           m2x.d_hard.p, m2x.d_res.p);
+                    }
+                    res[b].resize(2 * (size_t)K);
+                    SD_HIP(hipMemcpyAsync(res[b].data(), m2x.d_res.p, res[b].size() * sizeof(int), hipMemcpyDeviceToHost, stream));
+                    SD_HIP(hipStreamSynchronize(stream));
+                }
+                // ---- the calls that stand: up to and including the first one of either reader whose marker was NOT where it was expected (what follows it moves)
+                int Kc = K;
+                for (int b = 0; b < 2; b++)
+                    for (int k = 0; k < Kc; k++)
+                        if (M2xBranch::offset_of(m2x.br[b].calls + k, res[b][2 * (size_t)k]) != 0)
+                        {
+                            Kc = k + 1;
+                            break;
+                        }
+                if (final)
+                    for (int k = 0; k < Kc; k++)
+                    { // the iteration in which a fetch comes up short is the last one
+                        long long demand = 0;
+                        for (int b = 0; b < 2; b++)
+                            demand = std::max(demand, pos[b][k] + ns[b][k] + std::max(0, M2xBranch::offset_of(m2x.br[b].calls + k, res[b][2 * (size_t)k])));
+                        if (demand > thr)
+                        {
+                            Kc = k + 1;
+                            m2x.done = true;
+                            break;
+                        }
+                    }
+                // ---- descriptors, rails
+                const long long c0 = m2x.br[0].calls; // (both readers have made the same number of calls)
+                for (int b = 0; b < 2; b++)
+                {
+                    M2xBranch &br = m2x.br[b];
+                    for (int k = 0; k < Kc; k++)
+                    {
+                        const int off = M2xBranch::offset_of(br.calls + k, res[b][2 * (size_t)k]);
+                        br.hist.push_back(M2xRead{pos[b][k], off, res[b][2 * (size_t)k + 1], ns[b][k], 0});
+                        br.rotation = res[b][2 * (size_t)k + 1];
+                        br.p_next = pos[b][k] + ns[b][k] + off;
+                    }
+                    br.calls += Kc;
+                    if (br.hist.size() > 4096)
+                    { // calls no output can come from any more
+                        const size_t drop = br.hist.size() - 1024;
+                        br.hist.erase(br.hist.begin(), br.hist.begin() + drop);
+                        br.hist_base += (long long)drop;
+                    }
+                    const long long rb = std::max<long long>(br.hist_base, c0 - 320);
+                    const int nr = (int)(br.calls - rb);
+                    m2x.d_reads.reserve(nr);
+                    SD_HIP(hipMemcpyAsync(m2x.d_reads.p, br.hist.data() + (rb - br.hist_base), (size_t)nr * sizeof(M2xRead), hipMemcpyHostToDevice, stream));
+                    m2x.rail[b].d_rail.reserve((size_t)Kc * M2X_LEN + 64);
+                    {
+                        ProfScope _ps("k_m2x_gather", stream);
+                        hipLaunchKernelGGL(k_m2x_gather, dim3((unsigned)(((size_t)Kc * M2X_LEN + 255) / 256)), dim3(256), 0, stream, (const signed char *)m2x.d_raw.p, m2x.raw_base,
+                                           m2x.raw_end, b, m2x.d_reads.p, rb, nr, c0, Kc, (signed char *)m2x.rail[b].d_rail.p);
+                    }
+                    SD_HIP(hipStreamSynchronize(stream)); // (d_reads is reused by the other reader)
+                }
+                m2x.iterations += Kc;
+                if (getenv("SDHIP_DEBUG"))
+                    fprintf(stderr, "[sdhip] m2x    %d reads stand (offsets %d / %d, rotations %d / %d); next windows at %lld / %lld\n", Kc, m2x.br[0].hist.back().off, m2x.br[1].hist.back().off,
+                            m2x.br[0].rotation, m2x.br[1].rotation, m2x.br[0].p_next, m2x.br[1].p_next);
+                m2x_viterbi(Kc, d_out, out_cap_frames, out_written);
+                if (getenv("SDHIP_DEBUG"))
+                    fprintf(stderr, "[sdhip] m2x    viterbi states %d / %d, deframer %d\n", m2x.rail[0].vstate, m2x.rail[1].vstate, def.state);
+            }
+        }
+
         // ------------------------------------------------------------------ entry points
         int64_t process_dev(const int8_t *d_soft, size_t n, uint8_t *d_out, size_t out_cap_frames)
         {
@@ -2022,6 +2373,13 @@ namespace sdhip
             size_t out_written = 0;
             size_t off = 0;
             stats.soft_in += n;
+            if (cfg.m2x_interleaved)
+            {
+                m2x.which.clear();
+                m2x_append(d_soft, n, true);
+                m2x_run(false, d_out, out_cap_frames, out_written);
+                return (int64_t)out_written;
+            }
             if (!pending.empty())
             {
                 const size_t need = (size_t)B - pending.size();
@@ -2052,9 +2410,34 @@ namespace sdhip
         }
 
         DevBuf<int8_t> d_push;
+        int64_t flush(uint8_t *d_out, size_t out_cap_frames)
+        {
+            SD_HIP(hipSetDevice(cfg.device));
+            size_t out_written = 0;
+            if (cfg.m2x_interleaved && !m2x.done)
+            {
+                tap_ber.clear();
+                tap_state.clear();
+                m2x.which.clear();
+                m2x_run(true, d_out, out_cap_frames, out_written);
+                m2x.done = true;
+            }
+            return (int64_t)out_written;
+        }
         int push_host(const int8_t *soft, size_t n)
         {
             SD_HIP(hipSetDevice(cfg.device));
+            if (cfg.m2x_interleaved)
+            {
+                stats.soft_in += n;
+                size_t out_written = 0;
+                tap_ber.clear();
+                tap_state.clear();
+                m2x.which.clear();
+                m2x_append(soft, n, false);
+                m2x_run(false, nullptr, 0, out_written);
+                return 0;
+            }
             // assemble pending + new data on the host, ship whole blocks
             const size_t old = pending.size();
             pending.insert(pending.end(), soft, soft + n);
@@ -2261,6 +2644,12 @@ extern "C"
     {
         SD_GUARD_BEGIN
         return ((FecEngine *)h)->pull(cadu, cap_frames);
+        SD_GUARD_END(-1)
+    }
+    int64_t sdhip_fec_flush(void *h, uint8_t *d_cadu, size_t cap_frames)
+    {
+        SD_GUARD_BEGIN
+        return ((FecEngine *)h)->flush(d_cadu, cap_frames);
         SD_GUARD_END(-1)
     }
     int64_t sdhip_fec_process_dev(void *h, const int8_t *d_soft, size_t n, uint8_t *d_cadu, size_t cap_frames)

@@ -882,6 +882,210 @@ namespace sdhip
         }
     }
 
+    // ---- the same symbol pairs formed in the forward pass's own loads (round 6): k_vit2_prep exists only to materialise the rotated / exchanged /
+    // depunctured stream -- 2 bytes per trellis step written and read again, 4.3 GB and 2.3 ms of a MetOp step -- and the forward pass's lanes each stream through
+    // their own segment anyway. V2Fetch gives a lane the eight pairs of row positions [rt, rt + 8) (what symu[j][rt ..] holds: rt < VIT2_WARM = the last steps of
+    // block j - 1, then steps rt - VIT2_WARM of block j, then erasures) from the soft bytes themselves: load() issues the (at most six) dword loads that contain the
+    // group's 12 .. 18 soft bytes -- one group ahead of the arithmetic, like the row loads they replace --, decode() turns them into pairs on registers: the
+    // arithmetic of k_vit2_prep's fast paths, with the depuncture phase (step mod 3) a per-lane value. A group that touches a block's tail steps, the first block's
+    // missing predecessor or the last 8 bytes of a block (the dwords loaded must lie inside it) is evaluated step by step through SymFetch::pair like the generic
+    // path of k_vit2_prep: a handful of groups per lane.
+    template <int MODE, int PHASE>
+    struct V2Fetch
+    {
+        VitCfg c;
+        const int8_t *cur, *prev; // block j, block j - 1 (nullptr: the stream starts with block j)
+        int nsteps;
+        struct Raw
+        {
+            unsigned w[6];
+            int rt, t0, sh; // row position; first step within its block; bit shift that aligns the first soft byte; sh < 0: not a fast group
+        };
+        __device__ __forceinline__ void init(const VitCfg &c_in, const int8_t *soft, long long first_block, int j)
+        {
+            c = c_in;
+            if constexpr (MODE >= 0)
+                c.mode = MODE;
+            if constexpr (PHASE >= 0)
+                c.phase = PHASE;
+            nsteps = c.F + 6;
+            cur = soft + (first_block + j) * vit_stride(c);
+            prev = (first_block + j > 0) ? cur - vit_stride(c) : nullptr;
+        }
+        __device__ __forceinline__ Raw load(int rt) const
+        { // (rt and VIT2_WARM are multiples of 8: a group lies in ONE block)
+            Raw r;
+#pragma unroll
+            for (int i = 0; i < 6; i++)
+                r.w[i] = 0u;
+            r.rt = rt;
+            r.sh = -1;
+            const int8_t *blk = rt >= VIT2_WARM ? cur : prev;
+            const int t0 = rt >= VIT2_WARM ? rt - VIT2_WARM : nsteps - VIT2_WARM + rt;
+            r.t0 = t0;
+            if (blk == nullptr || t0 < 0 || t0 + 8 > nsteps)
+                return r;
+            int jb, need;
+            if (c.mode == 0)
+            {
+                jb = (c.shift + 2 * t0) & ~1;
+                need = 16 + 2 * (c.shift & 1);
+            }
+            else if (c.mode == 1)
+            {
+                jb = 4 * (t0 / 3);
+                need = 4 * ((t0 + 7) / 3) + 4 - jb;
+            }
+            else
+                return r;
+            if (jb + need + 8 > c.B)
+                return r;
+            const int8_t *p = blk + jb;
+            const unsigned a = (unsigned)(reinterpret_cast<uintptr_t>(p) & 3u);
+            const unsigned *w32 = reinterpret_cast<const unsigned *>(p - a);
+#pragma unroll
+            for (int i = 0; i < 6; i++)
+                r.w[i] = w32[i];
+            r.sh = (int)(8u * a);
+            return r;
+        }
+        // soft pair `word` (I | Q << 8, signed bytes) -> the two unsigned symbols after rotate_soft / signed_soft_to_unsigned (SymFetch::u_at)
+        __device__ __forceinline__ void pair_u(unsigned word, bool swap, unsigned &ua, unsigned &ub) const
+        {
+            int av = (int)(signed char)(word & 0xffu), bv = (int)(signed char)((word >> 8) & 0xffu);
+            av = av == -128 ? -127 : av;
+            bv = bv == -128 ? -127 : bv;
+            if (swap)
+            {
+                const int t = av;
+                av = bv;
+                bv = t;
+            }
+            if (c.phase == 1)
+            {
+                const int t = av;
+                av = bv;
+                bv = -t;
+            }
+            else if (c.phase == 2)
+            {
+                av = -av;
+                bv = -bv;
+            }
+            else if (c.phase == 3)
+            {
+                const int t = av;
+                av = -bv;
+                bv = t;
+            }
+            const unsigned x = (unsigned)(av + 127) & 255u, y = (unsigned)(bv + 127) & 255u;
+            ua = x == 128u ? 127u : x;
+            ub = y == 128u ? 127u : y;
+        }
+        __device__ __forceinline__ uint4 decode(const Raw &r) const
+        {
+            unsigned v[8];
+            const bool swap = (c.pre_swap != 0) != (c.iq_swap != 0); // two swaps cancel
+            if (r.sh >= 0 && c.mode == 0)
+            {
+                unsigned d[5];
+#pragma unroll
+                for (int i = 0; i < 5; i++)
+                    d[i] = (unsigned)(((((unsigned long long)r.w[i + 1]) << 32) | r.w[i]) >> r.sh);
+                unsigned ua[9], ub[9];
+#pragma unroll
+                for (int pi = 0; pi < 9; pi++)
+                    pair_u(d[pi >> 1] >> (16 * (pi & 1)), swap, ua[pi], ub[pi]);
+                const bool odd = (c.shift & 1) != 0;
+#pragma unroll
+                for (int q = 0; q < 8; q++)
+                    v[q] = odd ? (ub[q] | (ua[q + 1] << 8)) : (ua[q] | (ub[q] << 8));
+            }
+            else if (r.sh >= 0)
+            { // MetOp / FengYun rate 3/4 (SymFetch::pair, mode 1): three steps consume four soft bytes; eight steps touch three or four such groups
+                unsigned d[4];
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+                    d[i] = (unsigned)(((((unsigned long long)r.w[i + 1]) << 32) | r.w[i]) >> r.sh);
+                unsigned ua[8], ub[8]; // pair 2g = bytes (4g, 4g + 1), pair 2g + 1 = bytes (4g + 2, 4g + 3) of group g
+#pragma unroll
+                for (int pi = 0; pi < 8; pi++)
+                    pair_u(d[pi >> 1] >> (16 * (pi & 1)), swap, ua[pi], ub[pi]);
+                const bool sh0 = c.shift == 0;
+                if (c.fy)
+                { // FengYun keeps the punctured pair's order: exchanging the two bytes of those pairs here gives the MetOp pattern below
+#pragma unroll
+                    for (int pi = 0; pi < 8; pi++)
+                        if ((pi & 1) == (sh0 ? 1 : 0))
+                        {
+                            const unsigned t = ua[pi];
+                            ua[pi] = ub[pi];
+                            ub[pi] = t;
+                        }
+                }
+                auto emit = [&](auto r0c) {
+                    constexpr int R0 = decltype(r0c)::value;
+#pragma unroll
+                    for (int q = 0; q < 8; q++)
+                    {
+                        const int mm = (R0 + q) / 3, rr = (R0 + q) % 3;
+                        unsigned s0, s1;
+                        if (sh0)
+                        {
+                            s0 = rr == 0 ? ua[2 * mm] : (rr == 1 ? 128u : ua[2 * mm + 1]);
+                            s1 = rr == 0 ? ub[2 * mm] : (rr == 1 ? ub[2 * mm + 1] : 128u);
+                        }
+                        else
+                        {
+                            s0 = rr == 0 ? 128u : (rr == 1 ? ua[2 * mm] : ua[2 * mm + 1]);
+                            s1 = rr == 0 ? ub[2 * mm] : (rr == 1 ? 128u : ub[2 * mm + 1]);
+                        }
+                        v[q] = s0 | (s1 << 8);
+                    }
+                };
+                const int r0 = r.t0 % 3;
+                if (r0 == 0)
+                    emit(std::integral_constant<int, 0>{});
+                else if (r0 == 1)
+                    emit(std::integral_constant<int, 1>{});
+                else
+                    emit(std::integral_constant<int, 2>{});
+            }
+            else
+            { // (a loop, not eight copies of SymFetch::pair, and no indexed array: the pairs are or-ed into the four words)
+                const SymFetch pf{c, prev, c.B}, f{c, cur, c.B};
+                const TailErasure erasure;
+                unsigned o0 = 0u, o1 = 0u, o2 = 0u, o3 = 0u;
+#pragma unroll 1
+                for (int q = 0; q < 8; q++)
+                {
+                    const int rr = r.rt + q;
+                    unsigned x = 128u | (128u << 8);
+                    if (rr < VIT2_WARM)
+                    {
+                        if (prev)
+                            x = pf.pair(nsteps - VIT2_WARM + rr, erasure);
+                    }
+                    else if (rr < VIT2_WARM + nsteps)
+                        x = f.pair(rr - VIT2_WARM, erasure);
+                    const unsigned xs = (x & 0xFFFFu) << (16 * (q & 1));
+                    const int k = q >> 1;
+                    o0 |= k == 0 ? xs : 0u;
+                    o1 |= k == 1 ? xs : 0u;
+                    o2 |= k == 2 ? xs : 0u;
+                    o3 |= k == 3 ? xs : 0u;
+                }
+                return make_uint4(o0, o1, o2, o3);
+            }
+            uint4 o;
+            o.x = v[0] | (v[1] << 16);
+            o.y = v[2] | (v[3] << 16);
+            o.z = v[4] | (v[5] << 16);
+            o.w = v[6] | (v[7] << 16);
+            return o;
+        }
+    };
+
     // ---- forward pass: one lane per (block, segment)
     template <bool DEC>
     __device__ __forceinline__ void v2_group(V2State &s, const V2Consts &kc, const uint4 q, unsigned (&w)[8][2])
@@ -1163,30 +1367,61 @@ namespace sdhip
 #ifndef V2H_WAVES
 #define V2H_WAVES 2
 #endif
-    __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(V2H_WAVES, V2H_WAVES))) void k_vit2h_acs(int F, int S, int NSEG, int nblk, const unsigned short *__restrict__ symu, int SU, VitBlockIO *io,
-                                                      uint4 *dec4, long long U64, unsigned *specx, unsigned *endx)
+    // FUSED: the symbol pairs come from the soft bytes (V2Fetch; MODE / PHASE as for k_vit2_prep); otherwise from the rows k_vit2_prep wrote
+    template <int MODE, int PHASE, bool FUSED>
+    __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(V2H_WAVES, V2H_WAVES))) void k_vit2h_acs(VitCfg c_in, const int8_t *__restrict__ soft, long long first_block, int F, int S, int NSEG, int nblk,
+                                                      const unsigned short *__restrict__ symu, int SU, VitBlockIO *io, uint4 *dec4, long long U64, unsigned *specx, unsigned *endx)
     {
         const int u = (int)(blockIdx.x * 64 + threadIdx.x);
         if (u >= nblk * NSEG)
             return;
         const int j = u / NSEG, g = u - j * NSEG;
-        const uint4 *row = reinterpret_cast<const uint4 *>(symu + (size_t)j * SU + (size_t)g * S); // 8 steps per uint4
+        const uint4 *row = FUSED ? nullptr : reinterpret_cast<const uint4 *>(symu + (size_t)j * SU + (size_t)g * S); // 8 steps per uint4
+        V2Fetch<MODE, PHASE> fx;
+        if constexpr (FUSED)
+            fx.init(c_in, soft, first_block, j);
+        typedef typename V2Fetch<MODE, PHASE>::Raw Raw;
+        const int rbase = g * S;
+        // group `grp` of the lane's row: fetched one group ahead of its use (ld), turned into pairs behind the arithmetic in between (dc)
+        auto ld = [&](int grp) -> Raw {
+            if constexpr (FUSED)
+                return fx.load(rbase + 8 * grp);
+            else
+            {
+                const uint4 t = row[grp];
+                Raw r;
+                r.w[0] = t.x;
+                r.w[1] = t.y;
+                r.w[2] = t.z;
+                r.w[3] = t.w;
+                return r;
+            }
+        };
+        auto dc = [&](const Raw &r) -> uint4 {
+            if constexpr (FUSED)
+            {
+                __builtin_amdgcn_sched_barrier(0); // (the conversion stays behind the group it was fetched across)
+                return fx.decode(r);
+            }
+            else
+                return make_uint4(r.w[0], r.w[1], r.w[2], r.w[3]);
+        };
         V2State s;
         v2h_init_neutral(s);
         unsigned rec[16];
         // ---- warm-up over the VIT2_WARM steps in front of the segment: only its last group keeps histories (the chained start state, g == 0)
         constexpr int WG = VIT2_WARM / 8;
-        uint4 q = row[0];
+        uint4 q = dc(ld(0));
         for (int grp = 0; grp < WG - 1; grp++)
         {
-            const uint4 nq = row[grp + 1];
+            const Raw nr = ld(grp + 1);
             v2h_group<false>(s, q);
-            q = nq;
+            q = dc(nr);
         }
         {
-            const uint4 nq = row[WG];
+            const Raw nr = ld(WG);
             v2h_group<true>(s, q);
-            q = nq;
+            q = dc(nr);
         }
         if (g == 0)
         {
@@ -1210,9 +1445,9 @@ namespace sdhip
         uint4 *d = dec4 + u;
         for (int grp = 0; grp < S / 8; grp++)
         {
-            const uint4 nq = row[WG + grp + 1];
+            const Raw nr = ld(WG + grp + 1);
             v2h_group<true>(s, q);
-            q = nq;
+            q = dc(nr);
             v2h_gather(s, rec);
             v2h_clear(s);
 #pragma unroll
@@ -1331,14 +1566,17 @@ namespace sdhip
         const int NSEG = F / S;
         const int SU = (VIT2_WARM + F + 6 + 8 + 7) / 8 * 8; // one spare group: the forward pass prefetches 8 steps ahead
         const long long U = (long long)nblk * NSEG, U64 = (U + 63) / 64 * 64;
-        w.symu.reserve((size_t)nblk * SU + 64);
         w.dec.reserve((size_t)(S + 8) * U64);
         w.specx.reserve((size_t)U * 32);
         w.endx.reserve((size_t)U * 32);
         w.entry.reserve((size_t)U);
         w.exitst.reserve((size_t)U);
         const int wpb = vit_words_per_block(F);
+        const bool hist = !(getenv("SDHIP_VIT2_HIST") && atoi(getenv("SDHIP_VIT2_HIST")) == 0); // A/B switch: 0 = per-step decision words (k_vit2_acs / k_vit2_tb)
+        const bool fused = hist && !(getenv("SDHIP_VIT2_FUSED") && atoi(getenv("SDHIP_VIT2_FUSED")) == 0); // A/B switch: 0 = k_vit2_prep writes the rows first
+        if (!fused)
         {
+            w.symu.reserve((size_t)nblk * SU + 64);
             ProfScope _ps("k_vit2_prep", st);
             auto go = [&](auto kern) { hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), 0, st, cfg, soft, (long long)first_block, nblk, w.symu.p, SU); };
             static const bool templ = !(getenv("SDHIP_VIT2_PREP_TEMPL") && atoi(getenv("SDHIP_VIT2_PREP_TEMPL")) == 0);
@@ -1356,12 +1594,28 @@ namespace sdhip
             default: go(k_vit2_prep<-1, -1>); break;
             }
         }
-        const bool hist = !(getenv("SDHIP_VIT2_HIST") && atoi(getenv("SDHIP_VIT2_HIST")) == 0); // A/B switch: 0 = per-step decision words (k_vit2_acs / k_vit2_tb)
         if (hist)
         {
             {
                 ProfScope _ps("k_vit2_acs", st);
-                hipLaunchKernelGGL(k_vit2h_acs, dim3((unsigned)(U64 / 64)), dim3(64), 0, st, F, S, NSEG, nblk, w.symu.p, SU, io, (uint4 *)w.dec.p, U64, w.specx.p, w.endx.p);
+                auto go = [&](auto kern) {
+                    hipLaunchKernelGGL(kern, dim3((unsigned)(U64 / 64)), dim3(64), 0, st, cfg, soft, (long long)first_block, F, S, NSEG, nblk, w.symu.p, SU, io, (uint4 *)w.dec.p, U64, w.specx.p,
+                                       w.endx.p);
+                };
+                const int key = !fused ? -2 : ((cfg.mode == 0 || cfg.mode == 1) && cfg.phase >= 0 && cfg.phase <= 3) ? cfg.mode * 4 + cfg.phase : -1;
+                switch (key)
+                {
+                case 0: go(k_vit2h_acs<0, 0, true>); break;
+                case 1: go(k_vit2h_acs<0, 1, true>); break;
+                case 2: go(k_vit2h_acs<0, 2, true>); break;
+                case 3: go(k_vit2h_acs<0, 3, true>); break;
+                case 4: go(k_vit2h_acs<1, 0, true>); break;
+                case 5: go(k_vit2h_acs<1, 1, true>); break;
+                case 6: go(k_vit2h_acs<1, 2, true>); break;
+                case 7: go(k_vit2h_acs<1, 3, true>); break;
+                case -1: go(k_vit2h_acs<-1, -1, true>); break;
+                default: go(k_vit2h_acs<-1, -1, false>); break;
+                }
             }
             {
                 ProfScope _ps("k_vit2_tb", st);

@@ -6,9 +6,45 @@
 #include "../../include/sdhip.h"
 #include <cstdio>
 #include <string>
-#include <ucontext.h>
+#include <cstdint>
+#include <cstring>
 #include <vector>
 #include <sys/mman.h>
+
+// Fiber switch. ucontext's swapcontext makes a signal-mask system call per switch, and a wave collective is 256 switches: the FEC half of the twin spent its time
+// there. This one saves what the System V x86-64 ABI calls callee-saved (rbx, rbp, r12-r15, the SSE / x87 control words) and changes stacks: a few nanoseconds.
+#if !defined(__x86_64__)
+#error "tests/emu: the fiber switch is written for x86-64 hosts"
+#endif
+extern "C" void emu_switch(void **save_sp, void *load_sp);
+asm(R"(
+    .text
+    .globl emu_switch
+    .type emu_switch,@function
+emu_switch:
+    pushq %rbp
+    pushq %rbx
+    pushq %r12
+    pushq %r13
+    pushq %r14
+    pushq %r15
+    subq $8, %rsp
+    stmxcsr (%rsp)
+    fnstcw 4(%rsp)
+    movq %rsp, (%rdi)
+    movq %rsi, %rsp
+    ldmxcsr (%rsp)
+    fldcw 4(%rsp)
+    addq $8, %rsp
+    popq %r15
+    popq %r14
+    popq %r13
+    popq %r12
+    popq %rbx
+    popq %rbp
+    ret
+    .size emu_switch,.-emu_switch
+)");
 
 emu_idx threadIdx, blockIdx;
 dim3 blockDim, gridDim;
@@ -19,12 +55,12 @@ namespace
     constexpr int MAXW = 16; // waves per block (1024 threads)
     struct Fiber
     {
-        ucontext_t ctx;
+        void *sp = nullptr;
         char *stack = nullptr;
         bool done = false;
     };
     std::vector<Fiber> fibers;
-    ucontext_t sched_ctx;
+    void *sched_sp = nullptr;
     int current = -1;
     const std::function<void()> *body = nullptr;
     // barrier state of the running block: block-wide (__syncthreads) and per wave (collectives)
@@ -35,7 +71,7 @@ namespace
     unsigned long long xchg[MAXW][64];
     unsigned long long spins = 0;
 
-    void yield() { swapcontext(&fibers[current].ctx, &sched_ctx); }
+    void yield() { emu_switch(&fibers[current].sp, sched_sp); }
     void release_if_complete(int w)
     { // called when an arrival OR an exit may have completed a rendezvous
         if (live_block > 0 && barr_arrived == live_block)
@@ -56,7 +92,19 @@ namespace
         live_block--;
         live_wave[current / 64]--;
         release_if_complete(current / 64); // threads that have left do not take part in later barriers (s_barrier semantics)
-        swapcontext(&fibers[current].ctx, &sched_ctx);
+        emu_switch(&fibers[current].sp, sched_sp);
+        abort(); // a finished fiber is never resumed
+    }
+    void fiber_prepare(Fiber &f)
+    { // the stack emu_switch pops when it first switches to the fiber: control words, six registers, fiber_main as the return address (rsp = 8 mod 16 on entry)
+        uint64_t *top = (uint64_t *)(f.stack + STACK);
+        top[-1] = 0;
+        top[-2] = (uint64_t)(uintptr_t)&fiber_main;
+        for (int i = 3; i <= 8; i++)
+            top[-i] = 0;
+        const uint32_t csr[2] = {0x1F80u, 0x037Fu};
+        memcpy(&top[-9], csr, 8);
+        f.sp = &top[-9];
     }
     void wave_sync()
     {
@@ -156,11 +204,7 @@ void emu_launch(dim3 grid, dim3 block, const std::function<void()> &thread_body)
                 {
                     Fiber &f = fibers[t];
                     f.done = false;
-                    getcontext(&f.ctx);
-                    f.ctx.uc_stack.ss_sp = f.stack;
-                    f.ctx.uc_stack.ss_size = STACK;
-                    f.ctx.uc_link = nullptr;
-                    makecontext(&f.ctx, fiber_main, 0);
+                    fiber_prepare(f);
                 }
                 while (live_block > 0)
                 { // round robin: every live fiber runs until it blocks in a rendezvous (it re-checks when resumed) or ends
@@ -171,7 +215,7 @@ void emu_launch(dim3 grid, dim3 block, const std::function<void()> &thread_body)
                         blockIdx = emu_idx{bx, by, bz};
                         threadIdx = emu_idx{t % block.x, (t / block.x) % block.y, t / (block.x * block.y)};
                         current = (int)t;
-                        swapcontext(&sched_ctx, &fibers[t].ctx);
+                        emu_switch(&sched_sp, fibers[t].sp);
                     }
                 }
             }

@@ -152,3 +152,65 @@ def test_lrpt_host_path(capi):
     capi.lib().sdhip_lrpt_destroy(h)
     got = np.concatenate(got)
     assert len(got) >= 8 and np.array_equal(got, want[: len(got)])
+
+
+# ---------------------------------------------------------------------------------------------------- m2x_mode + interleaved (round 6)
+def m2x_run_hip(capi, tx, cuts=None, diff=True, thr=0.3, outsync=20):
+    """the interleaved .soft stream through the concatenated decoder's handle with m2x_interleaved (host entries: push / flush / pull)"""
+    dec = capi.FecDecoder(capi.fec_cfg(decoder=capi.DEC_CONV_CONCAT, constellation="oqpsk", cadu_size=8192, viterbi_outsync_after=outsync, viterbi_ber_thresold=thr,
+                                       nrzm=1 if diff else 0, derandomize=1, derand_after_rs=0, derand_start=4, rs_i=4, rs_fill_bytes=-1, rs_dualbasis=0, rs_type=capi.RS223,
+                                       rs_usecheck=1, m2x_interleaved=1))
+    cuts = cuts or [0, len(tx)]
+    taps = []
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        dec.push(tx[a:b])
+        taps.append(dec.block_taps())
+    dec.flush()
+    taps.append(dec.block_taps())
+    out = dec.pull()
+    st = dec.stats()
+    dec.close()
+    return out, np.concatenate([t[0] for t in taps]), np.concatenate([t[1] for t in taps]), st
+
+
+M2X_CASES = [
+    ("clean", dict(nframes=40), None),
+    ("ragged_calls", dict(nframes=40), "cuts"),
+    ("marker_errors", dict(nframes=40, marker_errors=0.08), None),          # markers with bit errors: the autocorrelation still finds them
+    ("misaligned_start", dict(nframes=40, lead_cut=37), None),              # the recording starts 37 samples into a marker period: the first read re-aligns (offset != 0)
+    ("slip", dict(nframes=60, slip=(3_100_003, 5)), None),                  # five samples missing mid-stream: a read finds its marker early, the de-interleaver steps back
+    ("quarter_turn", dict(nframes=40, turn=1), None),                       # the constellation a quarter turn on: the SECOND reader / Viterbi pair is the one that locks
+]
+
+
+@pytest.mark.parametrize("name,kw,mode", M2X_CASES)
+def test_lrpt_m2x_interleaved(capi, name, kw, mode):
+    """meteor_lrpt_decoder, m2x_mode + interleaved (module_meteor_lrpt_decoder.cpp:103-199, deint.cpp) on the device -- two de-interleaver readers as gathers, two Viterbis,
+    the locked one's bits to the deframer -- against the module's loop on the reference's own classes WITH ITS SAMPLE READER PUT RIGHT (oracle/ref_wrap_lrpt_m2x.cpp,
+    reader_returns = 1; as it stands in the reference tree the branch decodes nothing: tests/test_lrpt_m2x_reference_cpu.py): CADUs byte for byte, and per iteration the
+    state and BER figure of the Viterbi the module takes."""
+    from tests.test_lrpt_m2x_reference_cpu import LEAD
+    if not (pyref.ref_available() and hasattr(pyref.ref().lib, "sdref_lrpt_m2x_decode")):
+        pytest.skip("oracle/_ref/libsdref.so (with the m2x wrapper) not built")
+    kw = dict(kw)
+    lead_cut, slip, turn = kw.pop("lead_cut", 0), kw.pop("slip", None), kw.pop("turn", 0)
+    me = kw.pop("marker_errors", 0.0)
+    soft, plain = lrpt_soft(kw["nframes"], seed=7, diff=True, sigma=18.0)
+    pre = np.random.default_rng(8).integers(-60, 60, LEAD).astype(np.int8)
+    tx = synth.m2x_interleave(np.concatenate([pre, soft]), marker_amp=-90, marker_errors=me, seed=7)
+    if turn:  # a receiver locked a quarter turn off: every (I, Q) pair of the stream turned
+        t = tx[: len(tx) // 2 * 2].reshape(-1, 2).astype(np.int16)
+        tx = np.stack([-t[:, 1], t[:, 0]], axis=1).reshape(-1).clip(-127, 127).astype(np.int8)
+    if lead_cut:
+        tx = tx[lead_cut:]
+    if slip:
+        tx = np.concatenate([tx[: slip[0]], tx[slip[0] + slip[1]:]])
+    want = pyref.ref().lrpt_m2x_decode(tx, diff_decode=True, interleaved=True, reader_returns=1)
+    cuts = [0, 5, 8192, 100_000, 100_001, len(tx) // 2, len(tx)] if mode == "cuts" else None
+    got, ber, state, st = m2x_run_hip(capi, tx, cuts=cuts)
+    assert len(want["cadu"]) >= kw["nframes"] - 12, len(want["cadu"])
+    assert got.shape == want["cadu"].shape and np.array_equal(got, want["cadu"]), (name, got.shape, want["cadu"].shape)
+    assert len(state) == want["iterations"] and np.array_equal(state, want["state"]), (name, len(state), want["iterations"])
+    assert np.array_equal(ber.view(np.uint32), want["ber"].view(np.uint32)), name
+    if name == "quarter_turn":
+        assert (want["which"] == 2).any()  # the reference took its second Viterbi at least once (both lock: each reader turns its stream by what its markers say)

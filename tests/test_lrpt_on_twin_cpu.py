@@ -21,3 +21,8 @@ def test_lrpt_host_path_on_the_twin(capi):
     if not (pyref.ref_available() and hasattr(pyref.ref().lib, "sdref_lrpt_decode")):
         pytest.skip("needs the compiled reference")
     G.test_lrpt_host_path(capi)
+
+
+@pytest.mark.parametrize("name,kw,mode", G.M2X_CASES)
+def test_lrpt_m2x_interleaved_on_the_twin(capi, name, kw, mode):
+    G.test_lrpt_m2x_interleaved(capi, name, kw, mode)

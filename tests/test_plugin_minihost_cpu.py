@@ -123,7 +123,7 @@ def test_lrpt_module_through_the_plugin_on_the_twin(host, tmp_path):
     from tests.emu import build as emu_build
     if not (pyref.ref_available() and hasattr(pyref.ref().lib, "sdref_lrpt_decode")) or not os.path.exists(emu_build.CLANG):
         pytest.skip("needs the compiled reference and a host clang++")
-    G.check_lrpt_module_through_the_plugin(host, emu_build.build(), tmp_path)
+    G.check_lrpt_module_through_the_plugin(host, emu_build.build(), tmp_path, interleaved_run=bool(os.environ.get("SDHIP_TWIN_FULL")))  # (the interleaved run: ~10 min on the twin)
 
 
 def test_fy3_module_through_the_plugin_on_the_twin(host, tmp_path):

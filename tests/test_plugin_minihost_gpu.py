@@ -747,7 +747,7 @@ def test_ndsp_single_blocks_through_the_plugin(host, tmp_path):
     check_ndsp_single_blocks_through_the_plugin(host, LIB, tmp_path)
 
 
-def check_lrpt_module_through_the_plugin(host, lib, tmp_path):
+def check_lrpt_module_through_the_plugin(host, lib, tmp_path, interleaved_run=True):
     """SURVEY 8 f-3's plugin decoder through the drop-in boundary: the stock id `meteor_lrpt_decoder` (plugins/meteor_support), re-pointed by the plugin
     under SDHIP_OVERRIDE=1 at METEORLRPTDecoderHipModule, reads a .soft file and writes the .cadu file the reference module's loop writes (the module's
     loop on the reference's own Correlator / Viterbi27 / ReedSolomon: oracle/ref_wrap.cpp) -- but for the module's extra iteration on a stale buffer at
@@ -789,11 +789,33 @@ def check_lrpt_module_through_the_plugin(host, lib, tmp_path):
         got = np.fromfile(rep["soft"], dtype=np.uint8).reshape(-1, 1024)
         assert len(got) >= 20 and len(got) <= len(wantm) <= len(got) + 2 and np.array_equal(got, wantm[: len(got)])
         assert set(rep["demod_stats"]) >= {"deframer_lock", "viterbi_ber", "viterbi_lock", "rs_avg", "viterbi_state", "deframer_state"}
+    # m2x_mode + interleaved (round 6; resources/pipelines/Meteor-M.json:246-255): the same module with the handle's m2x_interleaved; SDHIP_M2X_INTERLEAVED=0 leaves
+    # the parameter set with the CPU module (whose loop, in this reference tree, reads 8192 bytes and decodes nothing: tests/test_lrpt_m2x_reference_cpu.py)
     job = {"mode": "file", "input": str(inp), "output_hint": str(tmp_path / "m2x"), "instantiate_only": True,
            "demod": {"module": "meteor_lrpt_decoder", "parameters": {"diff_decode": False, "m2x_mode": True, "interleaved": True, "viterbi_outsync_after": 5, "viterbi_ber_thresold": 0.2}}}
     jp.write_text(json.dumps(job))
-    p = subprocess.run([host, lib, PLUGIN, "run", str(jp)], capture_output=True, text=True, env=dict(os.environ, SDHIP_OVERRIDE="1"), timeout=900)
+    p = subprocess.run([host, lib, PLUGIN, "run", str(jp)], capture_output=True, text=True, env=dict(os.environ, SDHIP_OVERRIDE="1", SDHIP_M2X_INTERLEAVED="0"), timeout=900)
     assert p.returncode == 0 and json.loads(p.stdout.strip().splitlines()[-1])["demod_class"] == "cpu:meteor_lrpt_decoder", p.stdout[-500:] + p.stderr[-2000:]
+    p = subprocess.run([host, lib, PLUGIN, "run", str(jp)], capture_output=True, text=True, env=dict(os.environ, SDHIP_OVERRIDE="1"), timeout=900)
+    assert p.returncode == 0 and json.loads(p.stdout.strip().splitlines()[-1])["demod_class"] == "meteor_lrpt_m2x_decoder_hip", p.stdout[-500:] + p.stderr[-2000:]
+    if interleaved_run and hasattr(pyref.ref().lib, "sdref_lrpt_m2x_decode"):
+        from satdump_amd import synth
+        from tests.test_lrpt_m2x_reference_cpu import LEAD
+        pre = np.random.default_rng(8).integers(-60, 60, LEAD).astype(np.int8)
+        tx = synth.m2x_interleave(np.concatenate([pre, soft8]), marker_amp=-90, seed=7)[23:]  # (the recording starts mid-period: the first read re-aligns)
+        wanti = pyref.ref().lrpt_m2x_decode(tx, diff_decode=True, interleaved=True, reader_returns=1, ber_thr=0.2, outsync_after=5)["cadu"]
+        assert len(wanti) >= 16
+        inp3 = tmp_path / "m2x_int.soft"
+        tx.tofile(str(inp3))
+        job = {"mode": "file", "input": str(inp3), "output_hint": str(tmp_path / "m2x_int"),
+               "demod": {"module": "meteor_lrpt_decoder", "parameters": {"diff_decode": True, "m2x_mode": True, "interleaved": True, "viterbi_outsync_after": 5, "viterbi_ber_thresold": 0.2}}}
+        jp.write_text(json.dumps(job))
+        p = subprocess.run([host, lib, PLUGIN, "run", str(jp)], capture_output=True, text=True, env=dict(os.environ, SDHIP_OVERRIDE="1"), timeout=1800)
+        assert p.returncode == 0, p.stdout[-1000:] + p.stderr[-3000:]
+        rep = json.loads(p.stdout.strip().splitlines()[-1])
+        assert rep["demod_class"] == "meteor_lrpt_m2x_decoder_hip"
+        got = np.fromfile(rep["soft"], dtype=np.uint8).reshape(-1, 1024)
+        assert got.shape == wanti.shape and np.array_equal(got, wanti)
     job["demod"] = {"module": "meteor_lrpt_decoder_hip", "parameters": {}}
     jp.write_text(json.dumps(job))
     p = subprocess.run([host, lib, PLUGIN, "run", str(jp)], capture_output=True, text=True, env=dict(os.environ, SDHIP_OVERRIDE="1"), timeout=900)
