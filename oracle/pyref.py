@@ -33,7 +33,7 @@ class FecCfg(C.Structure):
         ("derand_after_rs", C.c_int), ("derand_start", C.c_int), ("rs_i", C.c_int), ("rs_fill_bytes", C.c_int),
         ("rs_dualbasis", C.c_int), ("rs_type", C.c_int), ("rs_usecheck", C.c_int), ("asm_sync", C.c_uint32),
         ("qpsk_swap_iq", C.c_int), ("qpsk_swap_diff", C.c_int), ("oqpsk_delay", C.c_int), ("oqpsk_method2", C.c_int), ("oqpsk_method3", C.c_int),
-        ("conv_rate", C.c_int), ("device", C.c_int), ("invert_second_viterbi", C.c_int),
+        ("conv_rate", C.c_int), ("device", C.c_int), ("invert_second_viterbi", C.c_int), ("m2x_interleaved", C.c_int),
     ]
 
 

@@ -47,13 +47,11 @@ def port():
     return pyref.port()
 
 
-# The FEC half of the host twin emulates every wave collective with 128 fiber switches: the tests that spend their time in the
-# wave-per-block Viterbi kernel take minutes there. The CPU suite runs the quick ones; SDHIP_TWIN_FULL=1 runs all 75 (~30 min).
-_TWIN_SLOW = ("test_punctured_concat_decoder", "test_concat_decoder_", "test_metop_decoder", "test_metop_golden", "test_ccdecoder_golden", "test_concat_golden[concat_qpsk",
-              "-12288-4]", "-4096-9]", "-5116-3]", "[clean-640", "[noise-640", "[saturated-640", "test_viterbi27[70", "test_ccdecoder_long_segments[noise", "test_ccdecoder_long_segments[noisy-2048",
-              "fill_bytes_overrun[4-1]", "fill_bytes_overrun[2-2]",
-              # the de-interleaver's depth is 316 reads in which both Viterbis search (8 candidates x 1030 trellis steps, emulated): ~10 min a case on the twin
-              "m2x_interleaved_on_the_twin")
+# The FEC half of the host twin emulates every wave collective with 128 fiber switches. With ucontext's swapcontext (a signal-mask system call per switch) the
+# tests that spend their time in the wave-per-block Viterbi kernel took minutes and the CPU suite ran only the quick ones; since round 6 the switch is a dozen
+# instructions (tests/emu/emu_runtime.cpp) and all of them run (~80 s on seven workers). What is still skipped by default is the interleaved M2-x decoder: the
+# de-interleaver's depth is 316 reads in which both Viterbis search (8 candidates x 1030 trellis steps each, emulated) -- ~10 min a case; SDHIP_TWIN_FULL=1 runs them.
+_TWIN_SLOW = ("m2x_interleaved_on_the_twin",)
 
 
 def pytest_collection_modifyitems(config, items):
@@ -62,7 +60,5 @@ def pytest_collection_modifyitems(config, items):
         return
     skip = pytest.mark.skip(reason="minutes on the host twin (wave collectives as fiber rendezvous); SDHIP_TWIN_FULL=1 runs it")
     for it in items:
-        if "test_fec_gpu_on_twin_cpu" in it.nodeid and any(p in it.name for p in _TWIN_SLOW) and "[clean-4096" not in it.name and "[clean-12288" not in it.name:
-            it.add_marker(skip)
-        elif "m2x_interleaved_on_the_twin" in it.name:
+        if any(p in it.name for p in _TWIN_SLOW):
             it.add_marker(skip)

@@ -132,7 +132,7 @@ def test_bench_reads_committed_pmc_traffic(tmp_path, monkeypatch):
     from satdump_amd import build as sd_build
     prof = tmp_path / "profiles"
     prof.mkdir()
-    src = os.path.join(ROOT, "profiles", "r01_j_goes_pmc.csv")  # an unstamped round-1 profile
+    src = os.path.join(ROOT, "profiles", "history", "r01", "r01_j_goes_pmc.csv")  # an unstamped round-1 profile
     shutil.copy(src, prof / "r90_goes_pmc.csv")
     monkeypatch.setattr(bench, "ROOT", str(tmp_path))
     traffic, name = bench.pmc_traffic("goes_hrit", "k_mm")
