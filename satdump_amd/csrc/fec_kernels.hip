@@ -1669,41 +1669,46 @@ namespace sdhip
         const int nber = c.nber, nenc = c.nenc > 0 ? c.nenc : c.nber;
         const unsigned *vb = vbits + (size_t)j * wpb;
         const unsigned *vprev = (j > 0) ? vbits + (size_t)(j - 1) * wpb : nullptr;
-        SymFetch f{c, soft + (first_block + j) * vit_stride(c), c.B};
-        const TailErasure erasure;
-        const int per = (nber + 63) / 64;
+        // Eight bits a turn (round 6; a bit a turn with SymFetch::pair per bit made this kernel 2.1 ms of an NPP step): the received pairs of eight steps come
+        // out of V2Fetch (the forward pass's own fetch: a few dword loads and register arithmetic), the encoder's windows out of one 14-bit piece of the decoded
+        // stream -- bits i - 6 .. i + 7, MSB first --, of which step k's shift register (bit i + k - d at position d) is bits 7 - k .. 13 - k.
+        V2Fetch<-1, -1> fx;
+        fx.init(c, soft, first_block, j);
+        const int ngroups = (nber + 7) / 8;
         unsigned err = 0, tot = 0;
-        for (int q = 0; q < per; q++)
+        for (int gi = lane; gi < ngroups; gi += 64)
         {
-            const int i = lane * per + q;
-            if (i >= nber)
-                break;
-            unsigned stw = 0; // bits i, i-1, ..., i-6 at positions 0..6
+            const auto raw = fx.load(VIT2_WARM + 8 * gi);
+            const uint4 q = fx.decode(raw);
+            const unsigned qq[4] = {q.x, q.y, q.z, q.w};
+            const int i0 = 8 * gi;
+            unsigned win;
+            if (gi > 0)
+                win = peek_bits(vb, (long long)i0 - 6, 14);
+            else
+            { // the six bits in front of the block: the previous block's encoder stopped behind its nenc-th bit; in front of the first block, the carried register
+                const unsigned six = vprev ? peek_bits(vprev, (long long)nenc - 6, 6) : (enc_state_in & 63u);
+                win = (six << 8) | peek_bits(vb, 0, 8);
+            }
 #pragma unroll
-            for (int d = 0; d < 7; d++)
+            for (int k = 0; k < 8; k++)
             {
-                const int n = i - d;
-                unsigned bit;
-                if (n >= 0)
-                    bit = getbit(vb, n);
-                else if (vprev)
-                    bit = getbit(vprev, nenc + n); // the previous block's encoder stopped behind its nenc-th bit
-                else
-                    bit = (enc_state_in >> (-n - 1)) & 1u;
-                stw |= bit << d;
-            }
-            const unsigned o0 = parity32(stw & 79u), o1 = parity32(stw & 109u);
-            const unsigned pr = f.pair(i, erasure);
-            const unsigned s0 = pr & 255u, s1 = pr >> 8;
-            if (s0 != 128u)
-            {
-                tot++;
-                err += ((s0 > 127u) ? 1u : 0u) != o0;
-            }
-            if (s1 != 128u)
-            {
-                tot++;
-                err += ((s1 > 127u) ? 1u : 0u) != o1;
+                if (i0 + k >= nber)
+                    break;
+                const unsigned stw = (win >> (7 - k)) & 127u; // bits i, i-1, ..., i-6 at positions 0..6
+                const unsigned o0 = parity32(stw & 79u), o1 = parity32(stw & 109u);
+                const unsigned pr = (qq[k >> 1] >> (16 * (k & 1))) & 0xFFFFu;
+                const unsigned s0 = pr & 255u, s1 = pr >> 8;
+                if (s0 != 128u)
+                {
+                    tot++;
+                    err += ((s0 > 127u) ? 1u : 0u) != o0;
+                }
+                if (s1 != 128u)
+                {
+                    tot++;
+                    err += ((s1 > 127u) ? 1u : 0u) != o1;
+                }
             }
         }
         err = wave_sum_u32(err);
