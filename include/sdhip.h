@@ -112,6 +112,8 @@ extern "C"
                                 target frequency comes from the pass prediction (SGP4 on the satellite's TLE, doppler_correct.cpp:68-93) once per source
                                 buffer of `buffer_size` samples: host work that stays with the caller -- sdhip_demod_doppler_targets hands the targets in */
         float doppler_alpha; /* "doppler_alpha", default 0.01: the one-pole ramp of the rotator's frequency toward the target */
+        double custom_samplerate; /* "custom_samplerate" (a long in the reference, module_demod_base.cpp:73-74): the sample rate the chain works at, in place of the
+                                     one initb derives from min_sps / max_sps -- the resample DECISION stays initb's (input sps outside [min_sps, max_sps]). 0 = none */
     } sdhip_demod_cfg;
 
     typedef struct sdhip_demod_stats

@@ -22,7 +22,7 @@ class DemodCfg(C.Structure):
         ("clock_gain_mu", C.c_float), ("clock_omega_relative_limit", C.c_float), ("costas_max_offset_hz", C.c_float),
         ("buffer_size", C.c_int), ("post_costas_dc", C.c_int),
         ("has_carrier", C.c_int), ("carrier_pll_bw", C.c_float), ("carrier_pll_max_offset", C.c_float), ("exact", C.c_int), ("chunk_len", C.c_int), ("warmup", C.c_int), ("device", C.c_int), ("freq_shift", C.c_double),
-        ("doppler", C.c_int), ("doppler_alpha", C.c_float),
+        ("doppler", C.c_int), ("doppler_alpha", C.c_float), ("custom_samplerate", C.c_double),
     ]
 
 

@@ -981,7 +981,9 @@ extern "C"
             bool resample = input_sps > MAX_SPS || input_sps < MIN_SPS;
             int range = pow(10, (std::to_string(int(d_symbolrate)).size() - 1));
             float final_samplerate = d_samplerate;
-            if (MAX_SPS == MIN_SPS)
+            if (c->custom_samplerate > 0) // d_parameters.count("custom_samplerate") > 0, module_demod_base.cpp:73-74
+                final_samplerate = (long)c->custom_samplerate;
+            else if (MAX_SPS == MIN_SPS)
                 final_samplerate = d_symbolrate * MAX_SPS;
             else if (input_sps > MAX_SPS)
                 final_samplerate = resample ? (round(d_symbolrate / range) * range) * MAX_SPS : d_samplerate;

@@ -263,9 +263,8 @@ namespace sdhip_plugin
         opt(parameters, "max_sps", cfg.max_sps);
         if (parameters.count("freq_shift") > 0) // module_demod_base.cpp:36-37 (a long)
             cfg.freq_shift = (double)parameters["freq_shift"].get<long>();
-        // custom_samplerate overrides the resample decision (module_demod_base.cpp:73-74): not a field of the C ABI
-        if (parameters.count("custom_samplerate") > 0)
-            throw satdump_exception(std::string(who) + ": custom_samplerate is not on the HIP path");
+        if (parameters.count("custom_samplerate") > 0) // module_demod_base.cpp:73-74 (a long)
+            cfg.custom_samplerate = (double)parameters["custom_samplerate"].get<long>();
     }
 
     // ------------------------------------------------------------------------------------------------ psk_demod

@@ -629,7 +629,9 @@ namespace sdhip
             resample = input_sps > MAX_SPS || input_sps < MIN_SPS;
             const int range = (int)pow(10, (std::to_string(int(d_symbolrate)).size() - 1));
             final_samplerate = d_samplerate;
-            if (MAX_SPS == MIN_SPS)
+            if (cfg.custom_samplerate > 0) // "custom_samplerate", module_demod_base.cpp:73-74: the rate only -- the decision above stands
+                final_samplerate = (long)cfg.custom_samplerate;
+            else if (MAX_SPS == MIN_SPS)
                 final_samplerate = d_symbolrate * MAX_SPS;
             else if (input_sps > MAX_SPS)
                 final_samplerate = resample ? (round(d_symbolrate / range) * range) * MAX_SPS : d_samplerate;

@@ -39,6 +39,7 @@ namespace sdhip
         int MB, G;                   // checks a layer's message block holds (>= M: a narrow layer's schedule is padded to width x phases); lanes per check
         const unsigned char *narrow; // [q] 0 = a check per thread; else W = checks per phase of the padded schedule
         const unsigned short *snode; // [q][MB][4 * DQ] node of link d of the check at schedule position k = phase * W + slot, 0xFFFF = no such link
+        int packed;                  // wide layers: LdpcCheck::update_pk (two links per register half) instead of update (SDHIP_LDPC_PACKED=0: A/B)
     };
 
     __device__ __forceinline__ int q8(int v) { return v < -128 ? -128 : (v > 127 ? 127 : v); }
@@ -117,6 +118,97 @@ namespace sdhip
                 bw[w] = nw;
             }
         }
+        // The same check node on PAIRS of links (round 6): the update above spends ~35 instructions a link on byte extraction, clamps and
+        // selects; here links 2p and 2p + 1 ride in the two 16-bit halves of a register through v_pk_* arithmetic -- the int8 saturations are packed max / min,
+        // |x| is max(x, -x), "minus beta, not below zero" a saturating packed subtract, the two smallest magnitudes are tracked per half and merged once (the two
+        // smallest of a multiset do not depend on the order they are met in), "the other links' minimum" is min0 + [mag == min0] x (min1 - min0) without a compare,
+        // the sign a packed arithmetic shift, and four new messages leave through one v_perm. Same integers at every point (every quantity is an exact small
+        // integer: nothing rounds), the bits written in the same link order. ~19 instructions a link.
+        __device__ __forceinline__ void update_pk(signed char *llr)
+        {
+            typedef short s2 __attribute__((ext_vector_type(2)));
+            typedef unsigned short u2 __attribute__((ext_vector_type(2)));
+            auto S = [](unsigned x) { return __builtin_bit_cast(s2, x); };
+            auto U = [](unsigned x) { return __builtin_bit_cast(u2, x); };
+            auto RS = [](s2 x) { return __builtin_bit_cast(unsigned, x); };
+            auto RU = [](u2 x) { return __builtin_bit_cast(unsigned, x); };
+            auto sat8 = [&](s2 x) { return __builtin_elementwise_min(__builtin_elementwise_max(x, s2{-128, -128}), s2{127, 127}); };
+            constexpr int P = 2 * DQ;
+            constexpr bool KEEP = DQ <= 3; // the magnitudes kept for the second loop, or formed again there (four instructions a pair against 2 DQ registers: DQ = 4
+                                           // sits at the 168 registers that three waves per SIMD allow)
+            auto vqabs_beta = [&](unsigned iv, unsigned vmask) -> unsigned {
+                const s2 Iv = S(iv);
+                u2 G = U(RS(__builtin_elementwise_min(__builtin_elementwise_max(Iv, s2{0, 0} - Iv), s2{127, 127}))); // vqabs
+                G = __builtin_elementwise_sub_sat(G, u2{1, 1});                                                       // unsigned saturating - beta
+                return (RU(G) & vmask) | (0x00FF00FFu & ~vmask);
+            };
+            unsigned inp[P], mag[KEEP ? P : 1];
+            unsigned m0 = 0x00FF00FFu, m1 = 0x00FF00FFu, sg = 0u;
+#pragma unroll
+            for (int p = 0; p < P; p++)
+            {
+                inp[p] = 0u;
+                if constexpr (KEEP)
+                    mag[p] = 0x00FF00FFu;
+                if (2 * p < deg)
+                {
+                    const bool v1 = 2 * p + 1 < deg;
+                    const unsigned vmask = v1 ? 0xFFFFFFFFu : 0x0000FFFFu;
+                    const unsigned n0 = nd[p] & 0xFFFFu, n1 = v1 ? nd[p] >> 16 : n0;
+                    const int l0 = llr[n0], l1 = llr[n1];
+                    const unsigned L = ((unsigned)l0 & 0xFFFFu) | ((unsigned)l1 << 16);
+                    // the pair's messages, sign-extended: the bytes moved to the high byte of each half, then an arithmetic shift
+                    const unsigned mb = __builtin_amdgcn_perm(0u, bw[p >> 1], (p & 1) ? 0x030c020cu : 0x010c000cu);
+                    const s2 M = S(mb) >> 8;
+                    const s2 I = sat8(S(L) - M);
+                    const unsigned iv = RS(I) & vmask;
+                    inp[p] = iv;
+                    const unsigned gv = vqabs_beta(iv, vmask);
+                    if constexpr (KEEP)
+                        mag[p] = gv;
+                    const u2 hi = __builtin_elementwise_max(U(gv), U(m0));
+                    m1 = RU(__builtin_elementwise_min(hi, U(m1)));
+                    m0 = RU(__builtin_elementwise_min(U(gv), U(m0)));
+                    sg ^= iv;
+                }
+            }
+            const unsigned a0 = m0 & 0xFFFFu, b0 = m0 >> 16, a1 = m1 & 0xFFFFu, b1 = m1 >> 16;
+            const unsigned min0 = a0 < b0 ? a0 : b0, mx = a0 < b0 ? b0 : a0, mn1 = a1 < b1 ? a1 : b1;
+            const unsigned min1 = mx < mn1 ? mx : mn1;
+            const unsigned MIN0 = min0 | (min0 << 16), DELTA = (min1 - min0) | ((min1 - min0) << 16);
+            const unsigned SGN = (((sg ^ (sg >> 16)) & 0x80u) != 0u) ? 0xFFFFFFFFu : 0u; // the product of all the links' signs
+            unsigned olo = 0u;
+#pragma unroll
+            for (int p = 0; p < P; p++)
+            {
+                unsigned o = 0u;
+                if (2 * p < deg)
+                {
+                    const bool v1 = 2 * p + 1 < deg;
+                    const unsigned vmask = v1 ? 0xFFFFFFFFu : 0x0000FFFFu;
+                    unsigned gv;
+                    if constexpr (KEEP)
+                        gv = mag[p];
+                    else
+                        gv = vqabs_beta(inp[p], vmask);
+                    const u2 X = U(gv) - U(MIN0);                                   // >= 0: min0 is the smallest
+                    const u2 E = u2{1, 1} - __builtin_elementwise_min(X, u2{1, 1}); // [mag == min0]
+                    const s2 other = S(RU(E * U(DELTA) + U(MIN0)));
+                    const s2 NEG = S(RS(S(inp[p]) >> 15) ^ SGN);                    // -1 where the sign of the product of the OTHER links' signs is negative
+                    s2 out = (other ^ NEG) - NEG;
+                    out = __builtin_elementwise_min(__builtin_elementwise_max(out, s2{-32, -32}), s2{31, 31}); // update(): clamp to [-32, 31]
+                    const unsigned nv = RS(sat8(S(inp[p]) + out));
+                    llr[nd[p] & 0xFFFFu] = (signed char)(nv & 0xFFu);
+                    if (v1)
+                        llr[nd[p] >> 16] = (signed char)((nv >> 16) & 0xFFu);
+                    o = RS(out) & vmask;
+                }
+                if (p & 1)
+                    bw[p >> 1] = __builtin_amdgcn_perm(o, olo, 0x06040200u); // four new messages: the low bytes of the four halves
+                else
+                    olo = o;
+            }
+        }
         __device__ __forceinline__ void store(const LdpcDev &g, unsigned *bnl_f, int i, int j) const
         {
 #pragma unroll
@@ -146,6 +238,49 @@ namespace sdhip
                 take(llr[n1]);
         }
         return zero || neg;
+    }
+
+    // the parity of check j of EVERY layer (what the loop over ldpc_check_bad computes, layer by layer with a way out at the first bad one): the node words of several
+    // layers are fetched together -- a layer at a time, each one's loads waited for a memory round trip that nothing hid, q of them per trial (round 6)
+    template <int DQ>
+    __device__ __forceinline__ bool ldpc_checks_bad(const LdpcDev &g, const signed char *llr, int j)
+    {
+        constexpr int UN = DQ <= 3 ? 6 : (DQ <= 5 ? 4 : 2);
+        bool bad = false;
+        for (int i0 = 0; i0 < g.q && !bad; i0 += UN)
+        {
+            unsigned w[UN][2 * DQ];
+#pragma unroll
+            for (int u = 0; u < UN; u++)
+#pragma unroll
+                for (int h = 0; h < 2 * DQ; h++)
+                    w[u][h] = i0 + u < g.q ? g.ndp[((size_t)(i0 + u) * 2 * DQ + h) * g.M + j] : 0xFFFFFFFFu;
+#pragma unroll
+            for (int u = 0; u < UN; u++)
+            {
+                int neg = 0;
+                bool zero = false;
+#pragma unroll
+                for (int h = 0; h < 2 * DQ; h++)
+                {
+                    const unsigned n0 = w[u][h] & 0xFFFFu, n1 = w[u][h] >> 16;
+                    if (n0 != 0xFFFFu)
+                    {
+                        const int v = llr[n0];
+                        zero |= v == 0;
+                        neg ^= v < 0 ? 1 : 0;
+                    }
+                    if (n1 != 0xFFFFu)
+                    {
+                        const int v = llr[n1];
+                        zero |= v == 0;
+                        neg ^= v < 0 ? 1 : 0;
+                    }
+                }
+                bad |= zero || neg;
+            }
+        }
+        return bad;
     }
 
     constexpr int LDPC_THREADS = 384; // 360 checks of a layer, six waves
@@ -256,8 +391,14 @@ namespace sdhip
     __device__ __forceinline__ long long ldpc_clock() { return (long long)__builtin_amdgcn_s_memtime(); }
     __device__ __forceinline__ void ldpc_wait_loads() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 #endif
+    // three waves per SIMD (two workgroups of six waves on a CU, what the LDS allows) wherever the check's registers fit 168: the allocator is told so, DQ = 4 sits at the edge
     template <int DQ>
-    __global__ __launch_bounds__(LDPC_THREADS) void k_ldpc_trial(LdpcDev g, signed char *frames, unsigned *bnl, int nframes, int batch, int t, const int *bad_prev,
+    struct LdpcWaves
+    {
+        static constexpr int v = DQ <= 4 ? 3 : 2;
+    };
+    template <int DQ>
+    __global__ __launch_bounds__(LDPC_THREADS) __attribute__((amdgpu_waves_per_eu(LdpcWaves<DQ>::v, 4))) void k_ldpc_trial(LdpcDev g, signed char *frames, unsigned *bnl, int nframes, int batch, int t, const int *bad_prev,
                                                                  int *bad_cur, int *updates, int *any_bad, long long *probe)
     {
         __shared__ signed char llr[64800];
@@ -350,7 +491,12 @@ namespace sdhip
                     for (int ph = 0; ph < nph; ph++)
                     {
                         if (m == ph)
-                            c.update(llr);
+                        {
+                            if (g.packed)
+                                c.update_pk(llr);
+                            else
+                                c.update(llr);
+                        }
                         __syncthreads();
                     }
                     lap(2);
@@ -376,8 +522,13 @@ namespace sdhip
         }
         bool bad = false;
         if (tid < g.M)
-            for (int i = 0; i < g.q && !bad; i++)
-                bad = ldpc_check_bad(g, llr, i, tid);
+        {
+            if (g.packed)
+                bad = ldpc_checks_bad<DQ>(g, llr, tid);
+            else
+                for (int i = 0; i < g.q && !bad; i++)
+                    bad = ldpc_check_bad(g, llr, i, tid);
+        }
         const int any = __syncthreads_or(bad ? 1 : 0);
         lap(4);
         if (active)
@@ -586,7 +737,7 @@ namespace sdhip
             SD_HIP(hipMemcpy(d_cnc.p, cnc.data(), q, hipMemcpyHostToDevice));
             SD_HIP(hipMemcpy(d_nph.p, nph.data(), q, hipMemcpyHostToDevice));
             SD_HIP(hipMemcpy(d_phase.p, phase.data(), phase.size(), hipMemcpyHostToDevice));
-            g = LdpcDev{M, N, K, R, q, CNL, DQ, d_ndp.p, d_cnc.p, d_phase.p, d_nph.p, MB, G, d_narrow.p, d_snode.p};
+            g = LdpcDev{M, N, K, R, q, CNL, DQ, d_ndp.p, d_cnc.p, d_phase.p, d_nph.p, MB, G, d_narrow.p, d_snode.p, (getenv("SDHIP_LDPC_PACKED") && atoi(getenv("SDHIP_LDPC_PACKED")) == 0) ? 0 : 1};
             info.code_len = N;
             info.data_len = K;
             info.layers = q;

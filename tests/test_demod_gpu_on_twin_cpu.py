@@ -114,6 +114,7 @@ test_host_push_pull_path = G.test_host_push_pull_path
 test_dc_block_in_front_of_the_resampler = G2.test_dc_block_in_front_of_the_resampler
 test_dc_block_chunk_parallel = G2.test_dc_block_chunk_parallel
 test_power_of_two_predecimator = G2.test_power_of_two_predecimator
+test_custom_samplerate = G2.test_custom_samplerate
 test_post_costas_dc = G2.test_post_costas_dc
 test_has_carrier = G2.test_has_carrier
 test_soft_symbols_without_the_float_symbols = G2.test_soft_symbols_without_the_float_symbols
