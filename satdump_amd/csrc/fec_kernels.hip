@@ -949,107 +949,81 @@ namespace sdhip
             r.sh = (int)(8u * a);
             return r;
         }
-        // soft pair `word` (I | Q << 8, signed bytes) -> the two unsigned symbols after rotate_soft / signed_soft_to_unsigned (SymFetch::u_at)
-        __device__ __forceinline__ void pair_u(unsigned word, bool swap, unsigned &ua, unsigned &ub) const
+        // Four soft bytes -- two (I, Q) pairs as they lie in memory -- to the four unsigned symbols SymFetch::u_at gives, all four at once: rotate_soft's -128 -> -127,
+        // the exchange (pre_swap xor iq_swap) and the quarter turns (an exchange for the odd ones, some bytes negated), signed_soft_to_unsigned's + 127 with 128
+        // (reserved for an erasure) -> 127. Byte-parallel in a dword: "equal to a constant" is a zero-byte test ((y & 0x7f..) + 0x7f.. | y has bit 7 clear exactly in
+        // the zero bytes of y); s + 127 = (s ^ 0x80) - 1 and 127 - s = s ^ 0x7f bytewise, and the one subtraction cannot borrow across bytes (its bytes are >= 1
+        // where 1 is subtracted: s >= -127 by then). 17 instructions for four symbols; a pair at a time took ~20 for two.
+        __device__ __forceinline__ static unsigned eq80(unsigned x)
+        { // 1 in the bytes of x that are 0x80, 0 elsewhere
+            const unsigned y = x ^ 0x80808080u;
+            const unsigned z = ((y & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | y;
+            return (~z & 0x80808080u) >> 7;
+        }
+        __device__ __forceinline__ unsigned conv4(unsigned x, bool swap) const
         {
-            int av = (int)(signed char)(word & 0xffu), bv = (int)(signed char)((word >> 8) & 0xffu);
-            av = av == -128 ? -127 : av;
-            bv = bv == -128 ? -127 : bv;
-            if (swap)
-            {
-                const int t = av;
-                av = bv;
-                bv = t;
-            }
-            if (c.phase == 1)
-            {
-                const int t = av;
-                av = bv;
-                bv = -t;
-            }
-            else if (c.phase == 2)
-            {
-                av = -av;
-                bv = -bv;
-            }
-            else if (c.phase == 3)
-            {
-                const int t = av;
-                av = -bv;
-                bv = t;
-            }
-            const unsigned x = (unsigned)(av + 127) & 255u, y = (unsigned)(bv + 127) & 255u;
-            ua = x == 128u ? 127u : x;
-            ub = y == 128u ? 127u : y;
+            x |= eq80(x); // -128 -> -127
+            const bool ex = swap != ((c.phase & 1) != 0);
+            if (ex)
+                x = __builtin_amdgcn_perm(0u, x, 0x02030001u); // (a, b) -> (b, a) in both pairs
+            // bytes negated by the turn: 90 deg (a, b) -> (b, -a): the second of a pair; 180: both; 270 (a, b) -> (-b, a): the first
+            const unsigned ng = c.phase == 1 ? 0xFF00FF00u : (c.phase == 2 ? 0xFFFFFFFFu : (c.phase == 3 ? 0x00FF00FFu : 0u));
+            unsigned u = (x ^ (0x80808080u ^ ng)) - (0x01010101u & ~ng);
+            u -= eq80(u); // 128 -> 127
+            return u;
         }
         __device__ __forceinline__ uint4 decode(const Raw &r) const
         {
-            unsigned v[8];
             const bool swap = (c.pre_swap != 0) != (c.iq_swap != 0); // two swaps cancel
             if (r.sh >= 0 && c.mode == 0)
-            {
+            { // rate 1/2: the symbols of eight steps are 16 consecutive converted bytes, from the pair boundary or (BPSK's odd shift) one byte on
                 unsigned d[5];
 #pragma unroll
-                for (int i = 0; i < 5; i++)
-                    d[i] = (unsigned)(((((unsigned long long)r.w[i + 1]) << 32) | r.w[i]) >> r.sh);
-                unsigned ua[9], ub[9];
-#pragma unroll
-                for (int pi = 0; pi < 9; pi++)
-                    pair_u(d[pi >> 1] >> (16 * (pi & 1)), swap, ua[pi], ub[pi]);
-                const bool odd = (c.shift & 1) != 0;
-#pragma unroll
-                for (int q = 0; q < 8; q++)
-                    v[q] = odd ? (ub[q] | (ua[q + 1] << 8)) : (ua[q] | (ub[q] << 8));
+                for (int i = 0; i < 4; i++)
+                    d[i] = conv4((unsigned)(((((unsigned long long)r.w[i + 1]) << 32) | r.w[i]) >> r.sh), swap);
+                if (!(c.shift & 1))
+                    return make_uint4(d[0], d[1], d[2], d[3]);
+                d[4] = conv4((unsigned)(((((unsigned long long)r.w[5]) << 32) | r.w[4]) >> r.sh), swap);
+                uint4 o;
+                o.x = (d[0] >> 8) | (d[1] << 24);
+                o.y = (d[1] >> 8) | (d[2] << 24);
+                o.z = (d[2] >> 8) | (d[3] << 24);
+                o.w = (d[3] >> 8) | (d[4] << 24);
+                return o;
             }
             else if (r.sh >= 0)
-            { // MetOp / FengYun rate 3/4 (SymFetch::pair, mode 1): three steps consume four soft bytes; eight steps touch three or four such groups
-                unsigned d[4];
+            { // MetOp / FengYun rate 3/4 (SymFetch::pair, mode 1): four soft bytes (A0 B0 A1 B1) make three steps = six symbols -- shift 0: A0 B0 | E B1 | A1 E, shift 1:
+              // E B0 | A0 E | A1 B1 (E = 128, the punctured symbol; FengYun keeps the punctured pair's order: B1 and A1, resp. B0 and A0, exchanged). The four groups a
+              // lane's eight steps can touch are expanded to their 24 symbols by v_perm (the same for every lane), and the lane takes its 16 from symbol 2 x (first step mod 3) on.
+                unsigned gq[4];
 #pragma unroll
                 for (int i = 0; i < 4; i++)
-                    d[i] = (unsigned)(((((unsigned long long)r.w[i + 1]) << 32) | r.w[i]) >> r.sh);
-                unsigned ua[8], ub[8]; // pair 2g = bytes (4g, 4g + 1), pair 2g + 1 = bytes (4g + 2, 4g + 3) of group g
-#pragma unroll
-                for (int pi = 0; pi < 8; pi++)
-                    pair_u(d[pi >> 1] >> (16 * (pi & 1)), swap, ua[pi], ub[pi]);
-                const bool sh0 = c.shift == 0;
-                if (c.fy)
-                { // FengYun keeps the punctured pair's order: exchanging the two bytes of those pairs here gives the MetOp pattern below
-#pragma unroll
-                    for (int pi = 0; pi < 8; pi++)
-                        if ((pi & 1) == (sh0 ? 1 : 0))
-                        {
-                            const unsigned t = ua[pi];
-                            ua[pi] = ub[pi];
-                            ub[pi] = t;
-                        }
-                }
-                auto emit = [&](auto r0c) {
-                    constexpr int R0 = decltype(r0c)::value;
-#pragma unroll
-                    for (int q = 0; q < 8; q++)
-                    {
-                        const int mm = (R0 + q) / 3, rr = (R0 + q) % 3;
-                        unsigned s0, s1;
-                        if (sh0)
-                        {
-                            s0 = rr == 0 ? ua[2 * mm] : (rr == 1 ? 128u : ua[2 * mm + 1]);
-                            s1 = rr == 0 ? ub[2 * mm] : (rr == 1 ? ub[2 * mm + 1] : 128u);
-                        }
-                        else
-                        {
-                            s0 = rr == 0 ? 128u : (rr == 1 ? ua[2 * mm] : ua[2 * mm + 1]);
-                            s1 = rr == 0 ? ub[2 * mm] : (rr == 1 ? 128u : ub[2 * mm + 1]);
-                        }
-                        v[q] = s0 | (s1 << 8);
-                    }
-                };
+                    gq[i] = conv4((unsigned)(((((unsigned long long)r.w[i + 1]) << 32) | r.w[i]) >> r.sh), swap);
+                const bool sh0 = c.shift == 0, fy = c.fy != 0;
+                // selectors of the three dwords two groups expand to (bytes 0-3: the first group, 4-7: the second, 0x0c: zero -- the erasure is or-ed in)
+                const unsigned s0 = sh0 ? (fy ? 0x020c0100u : 0x030c0100u) : (fy ? 0x0c01000cu : 0x0c00010cu);
+                const unsigned s1 = sh0 ? (fy ? 0x05040c03u : 0x05040c02u) : (fy ? 0x040c0302u : 0x050c0302u);
+                const unsigned s2 = sh0 ? (fy ? 0x0c03020cu : 0x0c02030cu) : (fy ? 0x03020c01u : 0x03020c00u);
+                const unsigned e0 = sh0 ? 0x00800000u : 0x80000080u, e1 = sh0 ? 0x00008000u : 0x00800000u, e2 = sh0 ? 0x80000080u : 0x00008000u;
+                unsigned O[6];
+                O[0] = __builtin_amdgcn_perm(0u, gq[0], s0) | e0;
+                O[1] = __builtin_amdgcn_perm(gq[1], gq[0], s1) | e1;
+                O[2] = __builtin_amdgcn_perm(0u, gq[1], s2) | e2;
+                O[3] = __builtin_amdgcn_perm(0u, gq[2], s0) | e0;
+                O[4] = __builtin_amdgcn_perm(gq[3], gq[2], s1) | e1;
+                O[5] = __builtin_amdgcn_perm(0u, gq[3], s2) | e2;
                 const int r0 = r.t0 % 3;
-                if (r0 == 0)
-                    emit(std::integral_constant<int, 0>{});
-                else if (r0 == 1)
-                    emit(std::integral_constant<int, 1>{});
-                else
-                    emit(std::integral_constant<int, 2>{});
+                unsigned B[5];
+#pragma unroll
+                for (int k = 0; k < 5; k++)
+                    B[k] = r0 == 2 ? O[k + 1] : O[k];
+                const unsigned bs = r0 == 1 ? 16u : 0u;
+                uint4 o;
+                o.x = (unsigned)(((((unsigned long long)B[1]) << 32) | B[0]) >> bs);
+                o.y = (unsigned)(((((unsigned long long)B[2]) << 32) | B[1]) >> bs);
+                o.z = (unsigned)(((((unsigned long long)B[3]) << 32) | B[2]) >> bs);
+                o.w = (unsigned)(((((unsigned long long)B[4]) << 32) | B[3]) >> bs);
+                return o;
             }
             else
             { // (a loop, not eight copies of SymFetch::pair, and no indexed array: the pairs are or-ed into the four words)
@@ -1077,12 +1051,6 @@ namespace sdhip
                 }
                 return make_uint4(o0, o1, o2, o3);
             }
-            uint4 o;
-            o.x = v[0] | (v[1] << 16);
-            o.y = v[2] | (v[3] << 16);
-            o.z = v[4] | (v[5] << 16);
-            o.w = v[6] | (v[7] << 16);
-            return o;
         }
     };
 
