@@ -89,8 +89,13 @@ def run(args) -> dict:
     d_out = torch.zeros(cap * fb, dtype=torch.uint8, device="cuda")
     sent = {bytes(r): i for i, r in enumerate(bb)}
     firsts = []
+    call_ms = []  # wall time of the untimed calls: the FIRST call of a stream is its cold start (narrow M&M windows, the PLL's serial frames, acquisition)
     for _ in range(args.warmup):
+        torch.cuda.synchronize()
+        tc = time.perf_counter()
         k = dem.process_dev(d_x.data_ptr(), n, capi.FMT_CF32, d_out.data_ptr(), cap)
+        torch.cuda.synchronize()
+        call_ms.append(round((time.perf_counter() - tc) * 1e3, 3))
         firsts.append(d_out[:k * fb].cpu().numpy().reshape(k, fb).copy())
     st0 = dem.stats
     torch.cuda.synchronize()
@@ -124,7 +129,9 @@ def run(args) -> dict:
            "stats": {k2: (round(v, 6) if isinstance(v, float) else v) for k2, v in st.items() if k2 not in ("frames", "pls", "freq")},
            "pll_schedule_per_step": {"lanes": (st["pll_lanes"] - st0["pll_lanes"]) // args.steps, "rerun": (st["pll_rerun"] - st0["pll_rerun"]) / args.steps,
                                      "forced": st["pll_forced"] - st0["pll_forced"], "serial_frames_at_stream_start": st0["pll_serial_frames"]},
-           "kernels_ms": kern, "synthesis_s": round(t_gen, 1)}
+           "kernels_ms": kern, "synthesis_s": round(t_gen, 1),
+           "cold_start": {"untimed_calls_ms": call_ms, "note": "wall time of the calls in front of the timed ones, same input each: the first is a new stream's (allocation, acquisition, the "
+                                                               "default M&M windows, the PLL's first 65 536 symbols on the serial lane), the later ones the steady state's"}}
     # ---- roofline of the dominant kernel. Algorithmic bytes per step: front-end lane stages 8 B in + 8 B out per sample (k_afc* is not used here: the
     # DVB-S2 front end has no Costas stage: k_chunks<AgcFir> + k_mm); k_ldpc_trial: 2 x the check-to-bit messages + 2 x the LLRs per frame and update pass
     dom = next(iter(kern)) if kern else None

@@ -12,6 +12,8 @@
 #   pmc:<wl>         the two PMC passes (FETCH_SIZE, WRITE_SIZE apart, per the microarch guide) -> <wl>_pmc.csv (stamped with the kernel sources' hash)
 #   sq:<wl>          the two SQ counter passes (VALU issue, waits, LDS) of one workload -> <wl>_sq.csv (tools/sq_summary.py)
 #   row:<tool>[:args]  one of tools/bench_{ndsp,dvbs2,dvbs2_demod,lrpt,fy3}.py -> row_<tool>.json
+#   rowpmc:<tag>:<tool>[:args]    the two PMC passes of a row tool -> <tag>_pmc.csv (tag = what the tool's roofline looks up: dvbs2, dvbs2fec, lrpt, fy3, ndsp)
+#   rowstats:<tag>:<tool>[:args]  rocprofv3 --kernel-trace --stats of a row tool -> <tag>_kernel_stats.csv
 TAG=${1:?tag}; shift
 OUT=gpurun_out/$TAG; mkdir -p $OUT
 export TMPDIR=/tmp
@@ -40,6 +42,16 @@ for ST in "$@"; do
              rocprofv3 --pmc SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INST_CYCLES_VMEM GRBM_GUI_ACTIVE --kernel-trace --kernel-include-regex "sdhip" --output-format csv -d $OUT/sq2_$WL -- $B > $OUT/sq2_$WL.log 2>&1
              python tools/sq_summary.py $OUT $WL | tee $OUT/${WL}_sq.csv; find $OUT -name "*kernel_trace.csv" -size +20M -delete ;;
     row:*)   R=${ST#row:}; T=${R%%:*}; A=""; [ "$R" != "$T" ] && A=${R#*:}; python tools/bench_$T.py ${A//,/ } > $OUT/row_$T.json 2> $OUT/row_$T.err; echo rc=$?; head -c 3000 $OUT/row_$T.json; echo; tail -3 $OUT/row_$T.err ;;
+    rowpmc:*) R=${ST#rowpmc:}; TG=${R%%:*}; R2=${R#*:}; T=${R2%%:*}; A=""; [ "$R2" != "$T" ] && A=${R2#*:}
+             for c in FETCH_SIZE WRITE_SIZE; do
+               timeout 400 rocprofv3 --pmc $c --kernel-trace --kernel-include-regex "sdhip" --output-format csv -d $OUT/pmc_${c}_$TG -- python tools/bench_$T.py ${A//,/ } > $OUT/pmc_${c}_$TG.log 2>&1
+             done
+             python tools/pmc_summary.py $OUT $TG > $OUT/${TG}_pmc.csv 2>&1; head -6 $OUT/${TG}_pmc.csv
+             find $OUT -name "*kernel_trace.csv" -size +20M -delete; find $OUT -name "*counter_collection.csv" -size +20M -delete ;;
+    rowstats:*) R=${ST#rowstats:}; TG=${R%%:*}; R2=${R#*:}; T=${R2%%:*}; A=""; [ "$R2" != "$T" ] && A=${R2#*:}; CMD="python tools/bench_$T.py ${A//,/ }"
+             rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$TG -- $CMD > $OUT/prof_$TG.log 2>&1
+             f=$(find $OUT/prof_$TG -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && python tools/rocprof_summary.py $f "$CMD" > $OUT/${TG}_kernel_stats.csv && head -8 $OUT/${TG}_kernel_stats.csv
+             find $OUT -name "*kernel_trace.csv" -size +20M -delete ;;
     *) echo "unknown stage $ST" ;;
   esac
 done
