@@ -392,7 +392,8 @@ namespace sdhip
         PinBuf<VitBlockIO> h_io;
         PinBuf<uint8_t> h_packed;
         PinBuf<uint32_t> h_hits;
-        PinBuf<int> h_ferr, h_dst_pin;
+        PinBuf<int> h_ferr, h_dst_pin, h_finfo;
+        DevBuf<int> d_finfo;
         PinBuf<FrameDesc> h_frames_pin;
         std::vector<FrameDesc> h_frames;
         std::vector<int> h_dst;
@@ -1026,12 +1027,35 @@ namespace sdhip
                     launch_frames(bs, fc, d_frames.p, nf, d_fbytes.p, d_ferr.p, stream, d_rs_clean.p);
                     h_dst.assign(nf, -1);
                     size_t kept = 0;
-                    if (cfg.rs_i != 0)
+                    const bool dev_filter = d_out != nullptr && collect == nullptr && !(getenv("SDHIP_RS_FILTER_DEV") && atoi(getenv("SDHIP_RS_FILTER_DEV")) == 0);
+                    if (dev_filter)
+                    { // device-resident output: the filter and the slots on the device, nine integers back (k_rs_filter)
+                        d_dst.reserve(nf);
+                        d_finfo.reserve(16);
+                        h_finfo.reserve(16);
+                        launch_rs_filter(d_ferr.p, nf, I, cfg.rs_i, cfg.rs_usecheck, (int)out_written, d_dst.p, d_finfo.p, stream);
+                        SD_HIP(hipMemcpyAsync(h_finfo.p, d_finfo.p, 9 * sizeof(int), hipMemcpyDeviceToHost, stream));
+                        SD_HIP(hipStreamSynchronize(stream));
+                        kept = (size_t)h_finfo.p[0];
+                        for (int k = 0; k < cfg.rs_i && k < 8; k++)
+                            last_errors[k] = h_finfo.p[1 + k];
+                        if (kept)
+                        {
+                            if (out_written + kept > out_cap_frames)
+                                throw HipError("CADU output buffer too small");
+                            launch_compact(d_fbytes.p, d_dst.p, nf, cadu_bytes, d_out, stream);
+                            SD_HIP(hipStreamSynchronize(stream));
+                            out_written += kept;
+                            stats.frames_out += kept;
+                            kept = 0; // (booked)
+                        }
+                    }
+                    else if (cfg.rs_i != 0)
                     {
                         SD_HIP(hipMemcpyAsync(h_ferr.p, d_ferr.p, (size_t)nf * I * sizeof(int), hipMemcpyDeviceToHost, stream));
                         SD_HIP(hipStreamSynchronize(stream));
                     }
-                    for (int f = 0; f < nf; f++)
+                    for (int f = 0; f < nf && !dev_filter; f++)
                     {
                         bool valid = true;
                         if (cfg.rs_i != 0)

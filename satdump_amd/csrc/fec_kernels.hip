@@ -2993,6 +2993,48 @@ namespace sdhip
         for (int k = (int)threadIdx.x; k < cadu_bytes; k += (int)blockDim.x)
             o[k] = s[k];
     }
+    // The modules' frame filter (module_ccsds_conv_concat_decoder.cpp:183-196: with rs_usecheck a frame with an uncorrectable codeword is dropped) and the output slot
+    // of every kept frame, on the device: the errors of nframes x I codewords used to cross PCIe for a host loop to do this (1.5 MB and ~100 us of host time per
+    // 100 k frames, the device idle). One block: a contiguous run of frames per thread, a block scan of the counts. info[0] = frames kept, info[1 + k] = the last
+    // frame's errors[k] (the modules' rs_avg statistic).
+    __global__ __launch_bounds__(1024) void k_rs_filter(const int *__restrict__ ferr, int nframes, int I, int rs_i, int usecheck, int out_base, int *dst, int *info)
+    {
+        __shared__ int part[1024];
+        const int t = (int)threadIdx.x;
+        const int per = (nframes + 1023) / 1024;
+        const int a = t * per, b = a + per < nframes ? a + per : nframes;
+        auto keep = [&](int f) {
+            bool valid = true;
+            for (int k = 0; k < rs_i; k++)
+                valid = valid && ferr[(size_t)f * I + k] != -1;
+            return !usecheck || valid;
+        };
+        int c = 0;
+        for (int f = a; f < b; f++)
+            c += keep(f) ? 1 : 0;
+        part[t] = c;
+        __syncthreads();
+        for (int off = 1; off < 1024; off <<= 1)
+        {
+            const int v = t >= off ? part[t - off] : 0;
+            __syncthreads();
+            part[t] += v;
+            __syncthreads();
+        }
+        int slot = out_base + part[t] - c;
+        for (int f = a; f < b; f++)
+            dst[f] = keep(f) ? slot++ : -1;
+        if (t == 1023)
+            info[0] = part[1023];
+        if (t < rs_i && t < 8 && nframes > 0)
+            info[1 + t] = ferr[(size_t)(nframes - 1) * I + t];
+    }
+    void launch_rs_filter(const int *ferr, int nframes, int I, int rs_i, int usecheck, int out_base, int *dst, int *info, hipStream_t st)
+    {
+        ProfScope _ps("k_rs_filter", st);
+        hipLaunchKernelGGL(k_rs_filter, dim3(1), dim3(1024), 0, st, ferr, nframes, I, rs_i, usecheck, out_base, dst, info);
+    }
+
     void launch_compact(const uint8_t *frames, const int *dst_index, int nframes, int cadu_bytes, uint8_t *out, hipStream_t st)
     {
         if (nframes <= 0)
