@@ -14,6 +14,7 @@
 #   row:<tool>[:args]  one of tools/bench_{ndsp,dvbs2,dvbs2_demod,lrpt,fy3}.py -> row_<tool>.json
 #   rowpmc:<tag>:<tool>[:args]    the two PMC passes of a row tool -> <tag>_pmc.csv (tag = what the tool's roofline looks up: dvbs2, dvbs2fec, lrpt, fy3, ndsp)
 #   rowstats:<tag>:<tool>[:args]  rocprofv3 --kernel-trace --stats of a row tool -> <tag>_kernel_stats.csv
+#   publish          copies the visit's *_pmc.csv to profiles/<tag>_<short>_pmc.csv on the box (the closing visit: PMC first, publish, then suite + driver)
 TAG=${1:?tag}; shift
 OUT=gpurun_out/$TAG; mkdir -p $OUT
 export TMPDIR=/tmp
@@ -33,7 +34,7 @@ for ST in "$@"; do
              find $OUT -name "*kernel_trace.csv" -size +20M -delete ;;
     pmc:*)   WL=${ST#pmc:}
              for c in FETCH_SIZE WRITE_SIZE; do
-               rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/pmc_${c}_$WL -- python bench.py --workload $WL --steps 1 --warmup 1 --cpu-samples 0 --others 0 --next-rows 0 > $OUT/pmc_${c}_$WL.log 2>&1
+               timeout 400 rocprofv3 --pmc $c --kernel-trace --kernel-include-regex "sdhip" --output-format csv -d $OUT/pmc_${c}_$WL -- python bench.py --workload $WL --steps 1 --warmup 1 --cpu-samples 0 --others 0 --next-rows 0 --exact-samples 0 --streamed-samples 0 > $OUT/pmc_${c}_$WL.log 2>&1
              done
              python tools/pmc_summary.py $OUT $WL > $OUT/${WL}_pmc.csv 2>&1; head -30 $OUT/${WL}_pmc.csv
              find $OUT -name "*kernel_trace.csv" -size +20M -delete; find $OUT -name "*counter_collection.csv" -size +20M -delete ;;
@@ -52,6 +53,8 @@ for ST in "$@"; do
              rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$TG -- $CMD > $OUT/prof_$TG.log 2>&1
              f=$(find $OUT/prof_$TG -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && python tools/rocprof_summary.py $f "$CMD" > $OUT/${TG}_kernel_stats.csv && head -8 $OUT/${TG}_kernel_stats.csv
              find $OUT -name "*kernel_trace.csv" -size +20M -delete ;;
+    publish) # the PMC summaries taken so far -> profiles/<tag>_<short>_pmc.csv ON THE BOX, so that the suite / bench stages behind it quote them (locally: copy the same files)
+             for f in $OUT/*_pmc.csv; do b=$(basename $f _pmc.csv); b=${b/metop_ahrpt/metop}; b=${b/goes_hrit/goes}; b=${b/npp_hrd/npp}; cp $f profiles/${TAG}_${b}_pmc.csv; echo "profiles/${TAG}_${b}_pmc.csv"; done ;;
     *) echo "unknown stage $ST" ;;
   esac
 done
