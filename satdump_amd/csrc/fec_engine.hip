@@ -393,7 +393,7 @@ namespace sdhip
         PinBuf<uint8_t> h_packed;
         PinBuf<uint32_t> h_hits;
         PinBuf<int> h_ferr, h_dst_pin, h_finfo;
-        DevBuf<int> d_finfo;
+        DevBuf<int> d_finfo, d_fwaves;
         PinBuf<FrameDesc> h_frames_pin;
         std::vector<FrameDesc> h_frames;
         std::vector<int> h_dst;
@@ -1033,7 +1033,8 @@ namespace sdhip
                         d_dst.reserve(nf);
                         d_finfo.reserve(16);
                         h_finfo.reserve(16);
-                        launch_rs_filter(d_ferr.p, nf, I, cfg.rs_i, cfg.rs_usecheck, (int)out_written, d_dst.p, d_finfo.p, stream);
+                        d_fwaves.reserve((size_t)(nf + 255) / 256 * 4 + 4);
+                        launch_rs_filter(d_ferr.p, nf, I, cfg.rs_i, cfg.rs_usecheck, (int)out_written, d_dst.p, d_finfo.p, d_fwaves.p, stream);
                         SD_HIP(hipMemcpyAsync(h_finfo.p, d_finfo.p, 9 * sizeof(int), hipMemcpyDeviceToHost, stream));
                         SD_HIP(hipStreamSynchronize(stream));
                         kept = (size_t)h_finfo.p[0];

@@ -227,7 +227,8 @@ namespace sdhip
     // Compaction: copy frames whose keep[i] != 0 to out in order. Returns nothing; count known to the host.
     void launch_compact(const uint8_t *frames, const int *dst_index, int nframes, int cadu_bytes, uint8_t *out, hipStream_t st);
     // rs_usecheck filter + output slots on the device (fec_kernels.hip: k_rs_filter): dst[f] = out_base + (kept frames in front of f) or -1; info[0] = kept, info[1 + k] = last frame's errors[k]
-    void launch_rs_filter(const int *ferr, int nframes, int I, int rs_i, int usecheck, int out_base, int *dst, int *info, hipStream_t st);
+    // wscratch: (nframes + 255) / 256 * 4 integers (the waves' counts, then their offsets)
+    void launch_rs_filter(const int *ferr, int nframes, int I, int rs_i, int usecheck, int out_base, int *dst, int *info, int *wscratch, hipStream_t st);
     // viterbi::Viterbi27::work over consecutive frames of one decoder (fec_engine.hip), device buffers
     // enc_state (may be null): the BER re-encoder's shift register in front of frame 0 in, behind the last frame out (it carries across calls)
     void viterbi27_frames(int frame_bits, int ber_test_size, const int8_t *d_soft, int nframes, int start_in0, uint8_t *d_out, std::vector<int> *ber_err, int *ret_state,

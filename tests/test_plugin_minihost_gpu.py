@@ -194,10 +194,13 @@ def test_fifo_and_dsp_stream_topologies(host, tmp_path):
 
 def test_uncovered_parameters_stay_on_the_cpu_module(host, tmp_path):
     job = {"mode": "file", "input": str(tmp_path / "none"), "output_hint": str(tmp_path / "o"), "instantiate_only": True,
-           "demod": {"module": "psk_demod", "parameters": dict(GOES_DEMOD, custom_samplerate=2500000)},
+           # (round 6: custom_samplerate is on the HIP path now -- test_custom_samplerate; a live stream's Doppler correction, which takes the wall clock per buffer, is not)
+           "demod": {"module": "psk_demod", "parameters": dict(GOES_DEMOD, enable_doppler=True, satellite_frequency=1.6941e9, satellite_norad=41866)},
            "decoder": {"module": "ccsds_conv_concat_decoder", "parameters": dict(GOES_DEC, cadu_size=8191)}}
     rep = _run(host, job, tmp_path)
     assert rep["demod_class"] == "cpu:psk_demod" and rep["decoder_class"] == "cpu:ccsds_conv_concat_decoder"
+    job["demod"]["parameters"] = dict(GOES_DEMOD, custom_samplerate=2500000)
+    assert _run(host, job, tmp_path)["demod_class"] == "psk_demod_hip"
 
 
 def test_has_carrier_pipeline_parameters_through_the_plugin(host, tmp_path):

@@ -31,28 +31,28 @@ for ST in "$@"; do
     stats:*) WL=${ST#stats:}; CMD="python bench.py --workload $WL --steps 3 --warmup 1 --cpu-samples 0 --others 0 --next-rows 0"
              rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$WL -- $CMD > $OUT/prof_$WL.log 2>&1
              f=$(find $OUT/prof_$WL -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && python tools/rocprof_summary.py $f "$CMD" > $OUT/${WL}_kernel_stats.csv && head -14 $OUT/${WL}_kernel_stats.csv
-             find $OUT -name "*kernel_trace.csv" -size +20M -delete ;;
+             rm -rf $OUT/prof_$WL ;;
     pmc:*)   WL=${ST#pmc:}
              for c in FETCH_SIZE WRITE_SIZE; do
                timeout 400 rocprofv3 --pmc $c --kernel-trace --kernel-include-regex "sdhip" --output-format csv -d $OUT/pmc_${c}_$WL -- python bench.py --workload $WL --steps 1 --warmup 1 --cpu-samples 0 --others 0 --next-rows 0 --exact-samples 0 --streamed-samples 0 > $OUT/pmc_${c}_$WL.log 2>&1
              done
              python tools/pmc_summary.py $OUT $WL > $OUT/${WL}_pmc.csv 2>&1; head -30 $OUT/${WL}_pmc.csv
-             find $OUT -name "*kernel_trace.csv" -size +20M -delete; find $OUT -name "*counter_collection.csv" -size +20M -delete ;;
+             rm -rf $OUT/pmc_FETCH_SIZE_$WL $OUT/pmc_WRITE_SIZE_$WL ;;  # the raw traces are tens of MB: gpurun copies back at most 64 MiB
     sq:*)    WL=${ST#sq:}; B="python bench.py --workload $WL --steps 1 --warmup 1 --cpu-samples 0 --others 0 --next-rows 0"
              rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY --kernel-trace --kernel-include-regex "sdhip" --output-format csv -d $OUT/sq_$WL -- $B > $OUT/sq_$WL.log 2>&1
              rocprofv3 --pmc SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INST_CYCLES_VMEM GRBM_GUI_ACTIVE --kernel-trace --kernel-include-regex "sdhip" --output-format csv -d $OUT/sq2_$WL -- $B > $OUT/sq2_$WL.log 2>&1
-             python tools/sq_summary.py $OUT $WL | tee $OUT/${WL}_sq.csv; find $OUT -name "*kernel_trace.csv" -size +20M -delete ;;
+             python tools/sq_summary.py $OUT $WL | tee $OUT/${WL}_sq.csv; rm -rf $OUT/sq_$WL $OUT/sq2_$WL ;;
     row:*)   R=${ST#row:}; T=${R%%:*}; A=""; [ "$R" != "$T" ] && A=${R#*:}; python tools/bench_$T.py ${A//,/ } > $OUT/row_$T.json 2> $OUT/row_$T.err; echo rc=$?; head -c 3000 $OUT/row_$T.json; echo; tail -3 $OUT/row_$T.err ;;
     rowpmc:*) R=${ST#rowpmc:}; TG=${R%%:*}; R2=${R#*:}; T=${R2%%:*}; A=""; [ "$R2" != "$T" ] && A=${R2#*:}
              for c in FETCH_SIZE WRITE_SIZE; do
                timeout 400 rocprofv3 --pmc $c --kernel-trace --kernel-include-regex "sdhip" --output-format csv -d $OUT/pmc_${c}_$TG -- python tools/bench_$T.py ${A//,/ } > $OUT/pmc_${c}_$TG.log 2>&1
              done
              python tools/pmc_summary.py $OUT $TG > $OUT/${TG}_pmc.csv 2>&1; head -6 $OUT/${TG}_pmc.csv
-             find $OUT -name "*kernel_trace.csv" -size +20M -delete; find $OUT -name "*counter_collection.csv" -size +20M -delete ;;
+             rm -rf $OUT/pmc_FETCH_SIZE_$TG $OUT/pmc_WRITE_SIZE_$TG ;;
     rowstats:*) R=${ST#rowstats:}; TG=${R%%:*}; R2=${R#*:}; T=${R2%%:*}; A=""; [ "$R2" != "$T" ] && A=${R2#*:}; CMD="python tools/bench_$T.py ${A//,/ }"
              rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$TG -- $CMD > $OUT/prof_$TG.log 2>&1
              f=$(find $OUT/prof_$TG -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && python tools/rocprof_summary.py $f "$CMD" > $OUT/${TG}_kernel_stats.csv && head -8 $OUT/${TG}_kernel_stats.csv
-             find $OUT -name "*kernel_trace.csv" -size +20M -delete ;;
+             rm -rf $OUT/prof_$TG ;;
     publish) # the PMC summaries taken so far -> profiles/<tag>_<short>_pmc.csv ON THE BOX, so that the suite / bench stages behind it quote them (locally: copy the same files)
              for f in $OUT/*_pmc.csv; do b=$(basename $f _pmc.csv); b=${b/metop_ahrpt/metop}; b=${b/goes_hrit/goes}; b=${b/npp_hrd/npp}; cp $f profiles/${TAG}_${b}_pmc.csv; echo "profiles/${TAG}_${b}_pmc.csv"; done ;;
     *) echo "unknown stage $ST" ;;
