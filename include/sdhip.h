@@ -214,8 +214,14 @@ extern "C"
         SDHIP_NDSP_MM = 3,      /* "clock_recovery_mm_cc" */
         SDHIP_NDSP_COSTAS = 4,  /* "costas_cc" */
         SDHIP_NDSP_GARDNER = 5, /* "clock_recovery_gardner_cc" (dsp/clock_recovery/clock_recovery_gardner.cpp): rec_* keys as for the M&M block */
-        SDHIP_NDSP_AGC_FAST = 6 /* "agc_fast_cc" (dsp/agc/agc_fast.cpp:22-58, dsp_flowgraph_register.cpp:278): the gain follows |input| x gain -- the magnitudes of the INPUT
+        SDHIP_NDSP_AGC_FAST = 6, /* "agc_fast_cc" (dsp/agc/agc_fast.cpp:22-58, dsp_flowgraph_register.cpp:278): the gain follows |input| x gain -- the magnitudes of the INPUT
                                    taken first (volk_32fc_magnitude_32f) -- instead of |output|; agc_* keys as for the AGC block */
+        SDHIP_NDSP_COSTAS_FAST = 7, /* "costas_fast_cc" (dsp/pll/costas_fast.cpp:15-110, dsp_flowgraph_register.cpp:294): the VCO as a complex number turned by small-angle
+                                   updates, renormalised every 65th sample; pll_* keys + constellation for the order as for the Costas block. Always ONE sequential lane
+                                   (bit for bit the block whatever `exact` says): its five-float state has no chunk-parallel schedule here */
+        SDHIP_NDSP_MM_FAST = 8 /* "fast_clock_recovery_mm_cc" (dsp/clock_recovery/clock_recovery_mm_fast.cpp:66-163, dsp_flowgraph_register.cpp:306): the M&M detector on a linear
+                                   interpolation, the rate term updated every fifth symbol; rec_omega / rec_omegaGain / rec_mu / rec_muGain / rec_omegaLimit. Always one
+                                   sequential lane (the cadence counter follows the symbol count) */
     };
     void *sdhip_ndsp_block_create(int kind, const sdhip_ndsp_psk_cfg *cfg);
     void sdhip_ndsp_psk_demod_destroy(void *h);

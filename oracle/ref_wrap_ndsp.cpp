@@ -7,10 +7,12 @@
 #include "dsp/agc/agc_fast.h"
 #include "dsp/clock_recovery/clock_recovery_gardner.h"
 #include "dsp/clock_recovery/clock_recovery_mm.h"
+#include "dsp/clock_recovery/clock_recovery_mm_fast.h"
 #include "dsp/filter/fir.h"
 #include "dsp/filter/rrc.h"
 #include "dsp/hier/psk_demod.h"
 #include "dsp/pll/costas.h"
+#include "dsp/pll/costas_fast.h"
 #include <cstring>
 #include <memory>
 #include <thread>
@@ -29,6 +31,10 @@ namespace
             return std::make_unique<RRC_Block<FIRBlock<complex_t>>>();
         if (id == "costas_cc")
             return std::make_unique<CostasBlock>();
+        if (id == "costas_fast_cc")
+            return std::make_unique<CostasFastBlock>();
+        if (id == "fast_clock_recovery_mm_cc")
+            return std::make_unique<MMClockRecoveryFastBlock<complex_t>>();
         if (id == "clock_recovery_mm_cc")
             return std::make_unique<MMClockRecoveryBlock<complex_t>>();
         if (id == "clock_recovery_gardner_cc")

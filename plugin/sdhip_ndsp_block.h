@@ -315,8 +315,8 @@ namespace sdhip_plugin
     public:
         static const char *id_of(int kind)
         {
-            static const char *ids[7] = {"psk_demod_hip_cc", "rrc_fir_hip_cc", "agc_hip_cc", "clock_recovery_mm_hip_cc", "costas_hip_cc", "clock_recovery_gardner_hip_cc",
-                                         "agc_fast_hip_cc"};
+            static const char *ids[9] = {"psk_demod_hip_cc", "rrc_fir_hip_cc", "agc_hip_cc", "clock_recovery_mm_hip_cc", "costas_hip_cc", "clock_recovery_gardner_hip_cc",
+                                         "agc_fast_hip_cc", "costas_fast_hip_cc", "fast_clock_recovery_mm_hip_cc"};
             return ids[kind];
         }
         explicit SingleHipBlock(int kind_) : Block(id_of(kind_), {{"in", satdump::ndsp::DSP_SAMPLE_TYPE_CF32}}, {{"out", satdump::ndsp::DSP_SAMPLE_TYPE_CF32}}), kind(kind_)
@@ -330,6 +330,8 @@ namespace sdhip_plugin
                 keys = {{"gain", 0, false}, {"samplerate", 1, false}, {"symbolrate", 2, false}, {"alpha", 3, false}, {"ntaps", 4, true}};
             else if (kind == SDHIP_NDSP_AGC || kind == SDHIP_NDSP_AGC_FAST) // (agc_fast.h:45-84: the same keys)
                 keys = {{"rate", 10, false}, {"reference", 11, false}, {"gain", 12, false}, {"max_gain", 13, false}};
+            else if (kind == SDHIP_NDSP_MM_FAST) // (clock_recovery_mm_fast.h:59-116: the M&M block's keys without the bank's shape)
+                keys = {{"omega", 20, false}, {"omegaGain", 21, false}, {"mu", 22, false}, {"muGain", 23, false}, {"omegaLimit", 24, false}};
             else if (kind == SDHIP_NDSP_MM || kind == SDHIP_NDSP_GARDNER) // (clock_recovery_gardner.h:57-130: the same keys)
                 keys = {{"omega", 20, false}, {"omegaGain", 21, false}, {"mu", 22, false}, {"muGain", 23, false}, {"omegaLimit", 24, false}, {"nfilt", 25, true}, {"ntaps", 26, true}};
             else
@@ -346,7 +348,7 @@ namespace sdhip_plugin
         nlohmann::ordered_json get_cfg_list()
         {
             nlohmann::ordered_json v;
-            if (kind == SDHIP_NDSP_COSTAS)
+            if (kind == SDHIP_NDSP_COSTAS || kind == SDHIP_NDSP_COSTAS_FAST)
                 satdump::ndsp::add_param_simple(v, "order", "int");
             for (auto &k : keys)
                 satdump::ndsp::add_param_simple(v, k.name, k.integer ? "int" : "float");
@@ -360,7 +362,7 @@ namespace sdhip_plugin
                 return cfg.device;
             if (key == "exact")
                 return cfg.exact != 0;
-            if (kind == SDHIP_NDSP_COSTAS && key == "order")
+            if ((kind == SDHIP_NDSP_COSTAS || kind == SDHIP_NDSP_COSTAS_FAST) && key == "order")
                 return order;
             for (auto &k : keys)
                 if (key == k.name)
@@ -379,7 +381,7 @@ namespace sdhip_plugin
                 cfg.device = v;
             else if (key == "exact")
                 cfg.exact = v.get<bool>() ? 1 : 0;
-            else if (kind == SDHIP_NDSP_COSTAS && key == "order")
+            else if ((kind == SDHIP_NDSP_COSTAS || kind == SDHIP_NDSP_COSTAS_FAST) && key == "order")
             {
                 order = v;
                 if (order != 2 && order != 4 && order != 8)

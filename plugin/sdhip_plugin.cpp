@@ -1921,10 +1921,11 @@ namespace sdhip_plugin
             const bool over = ov && std::string(ov) == "1" && sdhip_device_count() > 0;
             if (over && evt.r.count("psk_demod_cc"))
                 evt.r.at("psk_demod_cc").func = make;
-            static const char *stock[7] = {"", "rrc_fir_cc", "agc_cc", "clock_recovery_mm_cc", "costas_cc", "clock_recovery_gardner_cc", "agc_fast_cc"};
-            static const char *menu[7] = {"", "Filter/RRC CC (MI355X)", "AGC/Agc CC (MI355X)", "Clock Recovery/MM CC (MI355X)", "PLL/Costas (MI355X)",
-                                          "Timing/Clock Recovery Gardner CC (MI355X)", "AGC/Agc Fast CC (MI355X)"};
-            for (int k = SDHIP_NDSP_RRC_FIR; k <= SDHIP_NDSP_AGC_FAST; k++)
+            static const char *stock[9] = {"", "rrc_fir_cc", "agc_cc", "clock_recovery_mm_cc", "costas_cc", "clock_recovery_gardner_cc", "agc_fast_cc", "costas_fast_cc", "fast_clock_recovery_mm_cc"};
+            static const char *menu[9] = {"", "Filter/RRC CC (MI355X)", "AGC/Agc CC (MI355X)", "Clock Recovery/MM CC (MI355X)", "PLL/Costas (MI355X)",
+                                          "Timing/Clock Recovery Gardner CC (MI355X)", "AGC/Agc Fast CC (MI355X)", "PLL/Costas Fast (MI355X)",
+                                          "Clock Recovery/Fast MM CC (MI355X)"};
+            for (int k = SDHIP_NDSP_RRC_FIR; k <= SDHIP_NDSP_MM_FAST; k++)
             {
                 auto mk = [k](const Flowgraph *f) { return std::make_shared<NodeInternal>(f, std::make_shared<SingleHipBlock>(k)); };
                 evt.r.insert({SingleHipBlock::id_of(k), {menu[k], mk}});
@@ -2040,8 +2041,8 @@ extern "C" satdump::ndsp::Block *sdhip_plugin_make_ndsp_block(const char *id)
     const std::string s(id);
     if (s == "psk_demod_hip_cc" || s == "psk_demod_cc")
         return new sdhip_plugin::PSKDemodHipBlock();
-    static const char *stock[7] = {"", "rrc_fir_cc", "agc_cc", "clock_recovery_mm_cc", "costas_cc", "clock_recovery_gardner_cc", "agc_fast_cc"};
-    for (int k = SDHIP_NDSP_RRC_FIR; k <= SDHIP_NDSP_AGC_FAST; k++)
+    static const char *stock[9] = {"", "rrc_fir_cc", "agc_cc", "clock_recovery_mm_cc", "costas_cc", "clock_recovery_gardner_cc", "agc_fast_cc", "costas_fast_cc", "fast_clock_recovery_mm_cc"};
+    for (int k = SDHIP_NDSP_RRC_FIR; k <= SDHIP_NDSP_MM_FAST; k++)
         if (s == stock[k] || s == sdhip_plugin::SingleHipBlock::id_of(k))
             return new sdhip_plugin::SingleHipBlock(k);
     return nullptr;

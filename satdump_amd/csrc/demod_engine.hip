@@ -538,6 +538,8 @@ namespace sdhip
         DevBuf<float> d_rrc, d_mmbank, d_rbank;
         DevBuf<AgcState> d_agc_spec, d_agc_end, d_agc_start;
         DevBuf<CostasState> d_cos_spec, d_cos_end, d_cos_start;
+        CostasFastParams cf_p{};            // SDHIP_NDSP_COSTAS_FAST: the block's parameters, its state resident on the device
+        DevBuf<CostasFastState> d_cf_state;
         DevBuf<MmState> d_mm_spec, d_mm_end, d_mm_start;
         DevBuf<MmCert> d_mm_spec_c, d_mm_end_c; // what the host certificate reads (16 B per chunk instead of the 72-byte state)
         DevBuf<MmCkpt> d_mm_ck;                 // per-chunk checkpoints for the early exit of re-run lanes
@@ -791,6 +793,21 @@ namespace sdhip
             cos_p.clip_branched = nd.on ? 1 : 0;
             cos_p.order = order;
             cos_p.init_freq = 0.0f;
+            if (nd.only == SDHIP_NDSP_COSTAS_FAST)
+            { // CostasFastBlock::init (dsp/pll/costas_fast.h:39-61): the same gains, the limits' phasors from the host's cosf / sinf
+                cf_p.alpha = cos_p.alpha;
+                cf_p.beta = cos_p.beta;
+                cf_p.fmin = -nd.pll_freq_limit;
+                cf_p.fmax = nd.pll_freq_limit;
+                cf_p.lim_min_re = cosf(cf_p.fmin);
+                cf_p.lim_min_im = sinf(cf_p.fmin);
+                cf_p.lim_max_re = cosf(cf_p.fmax);
+                cf_p.lim_max_im = sinf(cf_p.fmax);
+                cf_p.order = order;
+                const CostasFastState s0{0.0f, 1.0f, 0.0f, 1.0f, 0.0f, 0u};
+                d_cf_state.reserve(1);
+                SD_HIP(hipMemcpy(d_cf_state.p, &s0, sizeof(s0), hipMemcpyHostToDevice));
+            }
             // one loop step moves the phase by at most fmax + beta + alpha: the kernel's phase wrap relies on that being under one turn
             if (!(costas_max_offset + cos_p.alpha + cos_p.beta < 6.0f))
                 throw HipError("costas_max_offset / pll_bw too large for the HIP path (one loop step could exceed a full turn)");
@@ -817,6 +834,8 @@ namespace sdhip
                 if (mm_p.back > MM_BACK_MAX)
                     throw HipError("ndsp gardner: more than 32 samples per symbol are outside the window the HIP lanes carry");
             }
+            if (nd.only == SDHIP_NDSP_MM_FAST)
+                mm_p.loop = 2; // MMClockRecoveryFastBlock<complex_t> on one sequential lane (dsp/clock_recovery/clock_recovery_mm_fast.cpp:66-163)
             memset(&mm_s, 0, sizeof(mm_s));
             mm_s.mu = cfg.clock_mu;
             mm_s.omega = final_sps;
@@ -2158,7 +2177,24 @@ namespace sdhip
                 started = true;
                 return n;
             }
-            if (nd.only == SDHIP_NDSP_MM || nd.only == SDHIP_NDSP_GARDNER)
+            if (nd.only == SDHIP_NDSP_COSTAS_FAST)
+            { // CostasFastBlock::process (dsp/pll/costas_fast.cpp:93-106) on one sequential lane, the block's state on the device from call to call
+                if ((size_t)n > out_cap)
+                    throw HipError("output buffer too small");
+                if (n > (1ll << 30))
+                    throw HipError("costas_fast_cc: at most 2^30 samples per call");
+                SD_HIP(hipMemcpyAsync(A, d_in, (size_t)n * sizeof(cf32), hipMemcpyDeviceToDevice, stream));
+                launch_costas_fast(A, B, n, cf_p, d_cf_state.p, stream);
+                SD_HIP(hipMemcpyAsync(d_out, B, (size_t)n * sizeof(cf32), hipMemcpyDeviceToDevice, stream));
+                CostasFastState se;
+                SD_HIP(hipMemcpyAsync(&se, d_cf_state.p, sizeof(se), hipMemcpyDeviceToHost, stream));
+                SD_HIP(hipStreamSynchronize(stream));
+                stats.freq_hz = (float)(((double)se.freq / (2.0 * design::PI)) * nd.samplerate); // the block's "freq" statistic is rad / sample (costas_fast.h:80)
+                stats.chunks = 1;
+                started = true;
+                return n;
+            }
+            if (nd.only == SDHIP_NDSP_MM || nd.only == SDHIP_NDSP_GARDNER || nd.only == SDHIP_NDSP_MM_FAST)
             { // MMClockRecoveryBlock<complex_t>::work (dsp/clock_recovery/clock_recovery_mm.cpp:66-183) on its own; GardnerClockRecoveryBlock<complex_t>::work
               // (dsp/clock_recovery/clock_recovery_gardner.cpp:60-170) on the same lanes with its own iteration (mm_p.loop)
                 SD_HIP(hipMemcpyAsync(A, d_in, (size_t)n * sizeof(cf32), hipMemcpyDeviceToDevice, stream));
@@ -2429,7 +2465,7 @@ extern "C"
     {
         SD_GUARD_BEGIN
         // the hier block: bpsk / qpsk (set_cfg returns RES_ERR for anything else, psk_demod.h:205-214); CostasBlock on its own also has order 8 (costas.h:78)
-        if (c->constellation != SDHIP_BPSK && c->constellation != SDHIP_QPSK && !(kind == SDHIP_NDSP_COSTAS && c->constellation == SDHIP_8PSK))
+        if (c->constellation != SDHIP_BPSK && c->constellation != SDHIP_QPSK && !((kind == SDHIP_NDSP_COSTAS || kind == SDHIP_NDSP_COSTAS_FAST) && c->constellation == SDHIP_8PSK))
             throw HipError("ndsp psk_demod: constellation must be bpsk or qpsk");
         if (c->rec_nfilt != 128 || c->rec_ntaps != 8)
             throw HipError("ndsp psk_demod: the HIP path carries the 128 x 8 interpolator bank only");
@@ -2457,7 +2493,7 @@ extern "C"
         d.clock_mu = c->rec_mu;
         d.clock_gain_mu = c->rec_muGain;
         d.clock_omega_relative_limit = c->rec_omegaLimit;
-        d.exact = c->exact;
+        d.exact = (kind == SDHIP_NDSP_COSTAS_FAST || kind == SDHIP_NDSP_MM_FAST) ? 1 : c->exact; // the _fast loops: one sequential lane (include/sdhip.h)
         d.chunk_len = c->chunk_len;
         d.warmup = c->warmup;
         NdspExt e;
@@ -2481,7 +2517,7 @@ extern "C"
     void sdhip_ndsp_psk_demod_destroy(void *h) { delete (DemodEngine *)h; }
     void *sdhip_ndsp_block_create(int kind, const sdhip_ndsp_psk_cfg *c)
     {
-        if (kind < SDHIP_NDSP_HIER || kind > SDHIP_NDSP_AGC_FAST)
+        if (kind < SDHIP_NDSP_HIER || kind > SDHIP_NDSP_MM_FAST)
         {
             sdhip::set_error("ndsp block: unknown kind");
             return nullptr;

@@ -181,6 +181,22 @@ namespace sdhip
     void launch_costas(const cf32 *x, cf32 *y, const ChunkGeom &g, const CostasParams &p, const CostasState *start0, CostasState *spec, CostasState *endst,
                        const int *redo, int nredo, hipStream_t st, const ChunkCkpt &ck = ChunkCkpt());
 
+    // ---- ndsp::CostasFastBlock (dsp/pll/costas_fast.cpp:15-89, the registry's "costas_fast_cc", dsp_flowgraph_register.cpp:294): the VCO as a complex
+    // number turned by small-angle updates (no sine / cosine in the loop), phase and rate phasors renormalised by the bit-trick inverse square root every 65th
+    // sample. ONE sequential lane (the reference's float operations in its order: bit-exact), state resident on the device across calls.
+    struct CostasFastParams
+    {
+        float alpha, beta, fmin, fmax;
+        float lim_min_re, lim_min_im, lim_max_re, lim_max_im; // freq_limit_min_cpx / freq_limit_max_cpx (costas_fast.h:44-45)
+        int order;
+    };
+    struct CostasFastState
+    {
+        float freq, pha_re, pha_im, fre_re, fre_im;
+        unsigned ctr; // renorm_ctr
+    };
+    void launch_costas_fast(const cf32 *x, cf32 *y, long long n, const CostasFastParams &p, CostasFastState *state_dev, hipStream_t st);
+
     // ---- AGC + RRC filter + Costas loop as ONE lane-per-chunk stage (see k_afc) -----------------------------------------------------
     // The lane that produces the filtered samples of a chunk also runs the carrier loop over them: the filter output never goes to
     // memory (16 B per sample of HBM traffic less), and the loop's dependent chain (sincos in double, ~30 operations deep per sample)
@@ -247,6 +263,9 @@ namespace sdhip
         // clip_float: Gardner's two clips as dsp::branched_clip on floats (the ndsp block, dsp/clock_recovery/clock_recovery_gardner.cpp:115,131) instead of
         // the legacy block's BRANCHLESS_CLIP in double (common/dsp/clock_recovery/clock_recovery_gardner.cpp:84,96).
         // back: samples a lane's window reaches behind inc - 7 (Gardner: floor(omega_max / 2) + 1, at most MM_BACK_MAX; M&M: 0)
+        // loop 2 = ndsp::MMClockRecoveryFastBlock<complex_t> (dsp/clock_recovery/clock_recovery_mm_fast.cpp:66-163, "fast_clock_recovery_mm_cc"): the M&M detector on a
+        // LINEAR interpolation between samples inc - 7 and inc - 6 of the window, the rate term updated every fifth symbol. One sequential lane only (the cadence
+        // counter rides in MmState::upd_cnt).
         int loop, clip_float, back;
         // tap (tests only, sdhip_demod_set_tap): the symbol rows receive, instead of the symbol, the interpolation's position on the arm grid -- (inc * 128 + arm) as a
         // 64-bit integer in the symbol's eight bytes -- so a test can tell the symbols two trajectories computed on the same arm from the ones a neighbouring arm gave
@@ -258,6 +277,7 @@ namespace sdhip
         float mu, omega;
         cf32 p_2T, p_1T, p_0T, c_2T, c_1T, c_0T;
         long long inc; // position in this call's sample index space
+        unsigned upd_cnt, pad; // MmParams::loop == 2 only: omega_upd_cnt (clock_recovery_mm_fast.h:44)
     };
     // what the boundary certificate compares: the timing state (the delay lines follow from it and the data)
     struct MmCert

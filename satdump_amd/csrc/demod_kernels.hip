@@ -1215,6 +1215,81 @@ namespace sdhip
         }
     };
 
+    // ---- ndsp::CostasFastBlock::process_order<ORDER> (dsp/pll/costas_fast.cpp:15-89): one lane, the reference's float operations in its order (products and
+    // sums rounded one by one: the library is built with -ffp-contract=off). The frequency limiter hands the rate phasor the OPPOSITE limit's value
+    // (costas_fast.cpp:81-84: freq = max goes with freq_limit_min_cpx) -- kept, it is what the block does.
+    __device__ __forceinline__ float sd_fast_invsqrt(float x)
+    { // fast_math.h:9-18
+        const float y = __uint_as_float(0x5f3759dfu - (__float_as_uint(x) >> 1));
+        return y * (1.5f - ((0.5f * x) * y) * y);
+    }
+    template <int ORDER>
+    struct CostasFastStage
+    {
+        using P = CostasFastParams;
+        using S = CostasFastState;
+        static constexpr int DEPTH = 4;
+        __device__ static __forceinline__ S init(const P &, int) { return S{0.0f, 1.0f, 0.0f, 1.0f, 0.0f, 0u}; }
+        __device__ static __forceinline__ bool close(const S &, const S &, float, float) { return false; }
+        __device__ static __forceinline__ void prewarm(S &, const P &, const cf32 *, long long) {}
+        __device__ static __forceinline__ cf32 step(S &s, const P &p, const cf32 v)
+        {
+            const float tr = (v.re * s.pha_re) - (v.im * s.pha_im);
+            const float ti = (v.re * s.pha_im) + (v.im * s.pha_re);
+            float error;
+            if constexpr (ORDER == 2)
+                error = tr * ti;
+            else if constexpr (ORDER == 4)
+                error = ((tr > 0.0f ? 1.0f : -1.0f) * ti) - ((ti > 0.0f ? 1.0f : -1.0f) * tr);
+            else
+            {
+                const float K = 0.41421356f;
+                const float a = tr > 0.0f ? 1.0f : -1.0f, b = ti > 0.0f ? 1.0f : -1.0f;
+                if (fabsf(tr) >= fabsf(ti))
+                    error = (a * ti) - ((b * tr) * K);
+                else
+                    error = ((a * ti) * K) - (b * tr);
+            }
+            error = error < -1.0f ? -1.0f : (error > 1.0f ? 1.0f : error); // dsp::branched_clip(error, 1.0f)
+            s.freq = s.freq + (p.beta * error);
+            const float df = p.beta * error;
+            const float nfr = s.fre_re + (df * s.fre_im);
+            const float nfi = s.fre_im - (df * s.fre_re);
+            s.fre_re = nfr;
+            s.fre_im = nfi;
+            const float pa = p.alpha * error;
+            const float ore = s.pha_re + (pa * s.pha_im);
+            const float oim = s.pha_im - (pa * s.pha_re);
+            const float npr = (ore * s.fre_re) - (oim * s.fre_im);
+            const float npi = (ore * s.fre_im) + (oim * s.fre_re);
+            s.pha_re = npr;
+            s.pha_im = npi;
+            if (s.ctr++ >= 64u)
+            {
+                s.ctr = 0;
+                float inv = sd_fast_invsqrt((s.pha_re * s.pha_re) + (s.pha_im * s.pha_im));
+                s.pha_re *= inv;
+                s.pha_im *= inv;
+                inv = sd_fast_invsqrt((s.fre_re * s.fre_re) + (s.fre_im * s.fre_im));
+                s.fre_re *= inv;
+                s.fre_im *= inv;
+                if (s.freq > p.fmax)
+                {
+                    s.freq = p.fmax;
+                    s.fre_re = p.lim_min_re;
+                    s.fre_im = p.lim_min_im;
+                }
+                if (s.freq < p.fmin)
+                {
+                    s.freq = p.fmin;
+                    s.fre_re = p.lim_max_re;
+                    s.fre_im = p.lim_max_im;
+                }
+            }
+            return cf32{tr, ti};
+        }
+    };
+
     struct DcStage
     {
         using P = DcParams;
@@ -2143,6 +2218,28 @@ namespace sdhip
         else
             depth == 2 ? go(CostasStage<8, 2>{}) : go(CostasStage<8, 4>{});
     }
+    void launch_costas_fast(const cf32 *x, cf32 *y, long long n, const CostasFastParams &p, CostasFastState *state_dev, hipStream_t st)
+    { // one chunk = one lane over the whole call; the state is read from and written back to state_dev
+        if (n <= 0)
+            return;
+        ProfScope _ps("k_chunks<CostasFastStage>", st);
+        ChunkGeom g{};
+        g.n = n;
+        g.L = 1 << 30;
+        g.W = 0;
+        g.K = 1;
+        auto go = [&](auto stage) {
+            using St = decltype(stage);
+            hipLaunchKernelGGL((k_chunks<St, false>), dim3(1), dim3(64), 0, st, x, y, g, p, state_dev, state_dev, state_dev, (const int *)nullptr, 0, (CostasFastState *)nullptr, 0, 0, 0.0f,
+                               0.0f, (unsigned long long *)nullptr);
+        };
+        if (p.order == 2)
+            go(CostasFastStage<2>{});
+        else if (p.order == 4)
+            go(CostasFastStage<4>{});
+        else
+            go(CostasFastStage<8>{});
+    }
     void launch_pll(const cf32 *x, cf32 *y, const ChunkGeom &g, const PllParams &p, const CostasState *start0, CostasState *spec, CostasState *endst,
                     const int *redo, int nredo, hipStream_t st, const ChunkCkpt &ck)
     {
@@ -2329,7 +2426,10 @@ namespace sdhip
 
     // one iteration of MMClockRecoveryBlock<complex_t>::work's loop body, clock_recovery_mm.cpp:54-120; the window
     // [inc-7, inc] must be in the ring
-    template <bool FAST = false, bool TAP = false, int RING = MM_RING>
+    // LIN: ndsp::MMClockRecoveryFastBlock<complex_t>::work's loop body instead (dsp/clock_recovery/clock_recovery_mm_fast.cpp:96-150): the symbol is the linear
+    // interpolation buffer[inc] * (1.0 - mu) + buffer[inc + 1] * mu -- samples inc - 7 and inc - 6 of the stream, the block's buffer holding ntaps - 1 = 7 samples of
+    // history in front; (1.0 - mu) taken in double and rounded to the float complex_t::operator*(const float &) takes -- and the rate term moves on every fifth symbol
+    template <bool FAST = false, bool TAP = false, int RING = MM_RING, bool LIN = false>
     __device__ __forceinline__ cf32 mm_iter(MmState &s, const MmParams &p, const cf32 *ring, const float *bank, const float omega_gain, const float mu_gain,
                                             long long *arm_pos = nullptr)
     {
@@ -2337,6 +2437,39 @@ namespace sdhip
         s.p_1T = s.p_0T;
         s.c_2T = s.c_1T;
         s.c_1T = s.c_0T;
+        if constexpr (LIN)
+        {
+            const int b0 = (int)((s.inc - 7) & (RING - 1)), b1 = (int)((s.inc - 6) & (RING - 1));
+            const cf32 x0 = ring[b0 * MM_RING_STRIDE], x1 = ring[b1 * MM_RING_STRIDE];
+            const float w0 = (float)(1.0 - (double)s.mu);
+            const float re = (x0.re * w0) + (x1.re * s.mu), im = (x0.im * w0) + (x1.im * s.mu);
+            s.p_0T.re = re;
+            s.p_0T.im = im;
+            s.c_0T.re = re > 0.0f ? 1.0f : 0.0f;
+            s.c_0T.im = im > 0.0f ? 1.0f : 0.0f;
+            const float ur = s.p_0T.re - s.p_2T.re, ui = s.p_0T.im - s.p_2T.im;
+            const float a_re = (ur * s.c_1T.re) - (ui * (-s.c_1T.im));
+            const float vr = s.c_0T.re - s.c_2T.re, vi = s.c_0T.im - s.c_2T.im;
+            const float b_re = (vr * s.p_1T.re) - (vi * (-s.p_1T.im));
+            float pe = a_re - b_re;
+            pe = pe < -1.0f ? -1.0f : (pe > 1.0f ? 1.0f : pe);
+            const cf32 out = s.p_0T;
+            if (s.upd_cnt++ == 4u)
+            {
+                s.upd_cnt = 0;
+                s.omega = s.omega + omega_gain * pe;
+                float d = s.omega - p.omega_mid;
+                d = d < -p.omega_limit ? -p.omega_limit : (d > p.omega_limit ? p.omega_limit : d);
+                s.omega = p.omega_mid + d;
+            }
+            s.mu = (s.mu + s.omega) + mu_gain * pe;
+            const float fl = floorf(s.mu);
+            s.inc += (long long)(int)fl;
+            s.mu = s.mu - fl;
+            if (s.inc < 0)
+                s.inc = 0;
+            return out;
+        }
         int imu = (int)rintf(s.mu * 128.0f);
         if (imu < 0)
             imu = 0;
@@ -2459,10 +2592,12 @@ namespace sdhip
             s.inc = 0;
         return s.p_0T;
     }
-    template <bool GARD, bool FAST, bool TAP = false, int RING = MM_RING>
+    template <bool GARD, bool FAST, bool TAP = false, int RING = MM_RING, bool LIN = false>
     __device__ __forceinline__ cf32 clock_iter(MmState &s, const MmParams &p, const cf32 *ring, const float *bank, const float omega_gain, const float mu_gain)
     {
-        if constexpr (GARD)
+        if constexpr (LIN)
+            return mm_iter<false, false, RING, true>(s, p, ring, bank, omega_gain, mu_gain);
+        else if constexpr (GARD)
             return gardner_iter<FAST>(s, p, ring, bank, omega_gain, mu_gain);
         else if constexpr (TAP)
         { // tests only: the symbol's eight bytes carry its position on the arm grid (MmParams::tap)
@@ -2500,7 +2635,7 @@ namespace sdhip
         const int r = (int)fminf(fmaxf(x, -128.0f), 127.0f);
         return (unsigned)(x < -128.0f ? -127 : r) & 0xffu;
     }
-template <bool CKPT, bool SPLIT, bool Q8 = false, bool FAST = false, bool GARD = false, bool TAP = false>
+template <bool CKPT, bool SPLIT, bool Q8 = false, bool FAST = false, bool GARD = false, bool TAP = false, bool LIN = false>
     __global__ __launch_bounds__(64) void k_mm(const cf32 *x, cf32 *sym, int *counts, ChunkGeom g, MmParams p, const MmState *start0, MmState *spec,
                                                MmState *endst, MmCert *spec_c, MmCert *end_c, const int *redo, int nredo, MmCkpt *ck, int ck_per_chunk,
                                                float ck_tol, int coop_nb)
@@ -2560,6 +2695,8 @@ template <bool CKPT, bool SPLIT, bool Q8 = false, bool FAST = false, bool GARD =
                 s.p_2T = s.p_1T = s.p_0T = cf32{0.0f, 0.0f};
                 s.c_2T = s.c_1T = s.c_0T = cf32{0.0f, 0.0f};
                 s.inc = chunk_begin(g, k) - g.W;
+                s.upd_cnt = 0;
+                s.pad = 0;
                 warm = true;
             }
         }
@@ -2701,7 +2838,7 @@ template <bool CKPT, bool SPLIT, bool Q8 = false, bool FAST = false, bool GARD =
                     {
                         while (s.inc < f.next)
                         {
-                            const cf32 v = clock_iter<GARD, FAST, TAP, RING>(s, p, f.ring, bank, p.omega_gain, p.mu_gain);
+                            const cf32 v = clock_iter<GARD, FAST, TAP, RING, LIN>(s, p, f.ring, bank, p.omega_gain, p.mu_gain);
                             put(cnt, v);
                             cnt++;
                         }
@@ -2713,7 +2850,7 @@ template <bool CKPT, bool SPLIT, bool Q8 = false, bool FAST = false, bool GARD =
                         {
                             const bool fast = wsym < p.fast_syms;
                             wsym++;
-                            (void)clock_iter<GARD, FAST, TAP, RING>(s, p, f.ring, bank, fast ? 0.0f : p.omega_gain, fast ? p.mu_gain * p.fast_mult : p.mu_gain);
+                            (void)clock_iter<GARD, FAST, TAP, RING, LIN>(s, p, f.ring, bank, fast ? 0.0f : p.omega_gain, fast ? p.mu_gain * p.fast_mult : p.mu_gain);
                         }
                         return;
                     }
@@ -2744,7 +2881,7 @@ template <bool CKPT, bool SPLIT, bool Q8 = false, bool FAST = false, bool GARD =
                         // trajectory settles onto the sequential one; only speculation -- the boundary certificate decides
                         const bool fast = phase == 0 && wsym < p.fast_syms;
                         wsym++;
-                        const cf32 v = clock_iter<GARD, FAST, TAP, RING>(s, p, f.ring, bank, fast ? 0.0f : p.omega_gain, fast ? p.mu_gain * p.fast_mult : p.mu_gain);
+                        const cf32 v = clock_iter<GARD, FAST, TAP, RING, LIN>(s, p, f.ring, bank, fast ? 0.0f : p.omega_gain, fast ? p.mu_gain * p.fast_mult : p.mu_gain);
                         if (phase != 0)
                         {
                             if (cnt + nx < p.cap)
@@ -2835,6 +2972,13 @@ template <bool CKPT, bool SPLIT, bool Q8 = false, bool FAST = false, bool GARD =
             if (!ck || !p.fast || p.q8 || p.loop == 1)
                 throw HipError("the arm tap exists for the chunk-parallel mode's default kernel only");
             go(k_mm<true, false, false, true, false, true>, ck, ck_per_chunk, ck_tol);
+            return;
+        }
+        if (p.loop == 2)
+        { // ndsp::MMClockRecoveryFastBlock on ONE sequential lane (float symbols)
+            if (g.K != 1 || p.q8 || p.fast || redo)
+                throw HipError("fast_clock_recovery_mm_cc runs as one sequential lane");
+            go(k_mm<false, false, false, false, false, false, true>, nullptr, 0, 0.0f);
             return;
         }
         if (p.loop == 1)

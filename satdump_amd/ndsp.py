@@ -121,7 +121,7 @@ class PSKDemodHierBlock:
 
 
 # ---- the chain's member blocks as flowgraph nodes of their own (include/sdhip.h, sdhip_ndsp_block_create)
-NDSP_HIER, NDSP_RRC_FIR, NDSP_AGC, NDSP_MM, NDSP_COSTAS, NDSP_GARDNER, NDSP_AGC_FAST = 0, 1, 2, 3, 4, 5, 6
+NDSP_HIER, NDSP_RRC_FIR, NDSP_AGC, NDSP_MM, NDSP_COSTAS, NDSP_GARDNER, NDSP_AGC_FAST, NDSP_COSTAS_FAST, NDSP_MM_FAST = 0, 1, 2, 3, 4, 5, 6, 7, 8
 _SINGLE = {
     # block id -> (kind, {block key: cfg field})   (the keys of dsp/agc/agc.h:38-78, dsp/filter/rrc.h:34-66, dsp/clock_recovery/clock_recovery_mm.h:70-130, dsp/pll/costas.h:55-90)
     "agc_cc": (NDSP_AGC, {"rate": "agc_rate", "reference": "agc_reference", "gain": "agc_gain", "max_gain": "agc_max_gain"}),
@@ -133,6 +133,10 @@ _SINGLE = {
     # dsp/clock_recovery/clock_recovery_gardner.h:15-21, 57-130: the M&M block's keys (its own default omega is 0: set it)
     "clock_recovery_gardner_cc": (NDSP_GARDNER, {"omega": "rec_omega", "omegaGain": "rec_omegaGain", "mu": "rec_mu", "muGain": "rec_muGain", "omegaLimit": "rec_omegaLimit",
                                                  "nfilt": "rec_nfilt", "ntaps": "rec_ntaps"}),
+    # dsp/pll/costas_fast.h:63-104 (the Costas block's keys) and dsp/clock_recovery/clock_recovery_mm_fast.h:59-116 (the M&M block's without the bank's shape): always one
+    # sequential lane on the device, bit for bit the block
+    "costas_fast_cc": (NDSP_COSTAS_FAST, {"loop_bw": "pll_loop_bw", "freq_limit": "pll_freq_limit"}),
+    "fast_clock_recovery_mm_cc": (NDSP_MM_FAST, {"omega": "rec_omega", "omegaGain": "rec_omegaGain", "mu": "rec_mu", "muGain": "rec_muGain", "omegaLimit": "rec_omegaLimit"}),
 }
 _ORDER = {2: capi.BPSK, 4: capi.QPSK, 8: capi.PSK8}
 
@@ -156,7 +160,7 @@ class SingleBlock:
         self._h = None
 
     def set_cfg(self, key: str, v) -> int:
-        if self._kind == NDSP_COSTAS and key == "order":
+        if self._kind in (NDSP_COSTAS, NDSP_COSTAS_FAST) and key == "order":
             if int(v) not in _ORDER:
                 return RES_ERR
             self._cfg.constellation = _ORDER[int(v)]

@@ -200,7 +200,8 @@ int main(int argc, char **argv)
               // the way Flowgraph::addNode does it -- registry entry's func(flowgraph) -- and its block run below
                 using namespace satdump::ndsp::flowgraph;
                 std::map<std::string, Flowgraph::NodeInternalReg> reg;
-                for (const char *id : {"psk_demod_cc", "rrc_fir_cc", "agc_cc", "clock_recovery_mm_cc", "costas_cc", "clock_recovery_gardner_cc"})
+                for (const char *id : {"psk_demod_cc", "rrc_fir_cc", "agc_cc", "clock_recovery_mm_cc", "costas_cc", "clock_recovery_gardner_cc", "agc_fast_cc", "costas_fast_cc",
+                                       "fast_clock_recovery_mm_cc"})
                     reg.insert({id, {std::string("stock/") + id, [](const Flowgraph *) { return std::shared_ptr<NodeInternal>(); }}});
                 satdump::eventBus->fire_event<RegisterNodesEvent>({reg});
                 nlohmann::json ids = nlohmann::json::object();

@@ -337,9 +337,11 @@ def check_flowgraph_registry_through_the_plugin(host, lib, tmp_path):
     job = {"block": "psk_demod_hip_cc", "via_registry": True, "cfg": dict(cfg, exact=True), "input": str(inp), "output": str(tmp_path / "r.cf32"), "buffer": 8192}
     rep = _run_ndsp(host, lib, job, tmp_path, plugin=PLUGIN_FG)
     reg = rep["registry"]
-    for pid in ("psk_demod_hip_cc", "rrc_fir_hip_cc", "agc_hip_cc", "clock_recovery_mm_hip_cc", "costas_hip_cc", "clock_recovery_gardner_hip_cc"):
+    for pid in ("psk_demod_hip_cc", "rrc_fir_hip_cc", "agc_hip_cc", "clock_recovery_mm_hip_cc", "costas_hip_cc", "clock_recovery_gardner_hip_cc", "agc_fast_hip_cc",
+                "costas_fast_hip_cc", "fast_clock_recovery_mm_hip_cc"):
         assert pid in reg and reg[pid].endswith("(MI355X)"), reg
-    for sid in ("psk_demod_cc", "rrc_fir_cc", "agc_cc", "clock_recovery_mm_cc", "costas_cc", "clock_recovery_gardner_cc"):
+    for sid in ("psk_demod_cc", "rrc_fir_cc", "agc_cc", "clock_recovery_mm_cc", "costas_cc", "clock_recovery_gardner_cc", "agc_fast_cc", "costas_fast_cc",
+                "fast_clock_recovery_mm_cc"):
         assert reg[sid] == "stock/" + sid  # the entries of the stock nodes are not replaced, only (under the override) their func
     assert rep["block"] == "psk_demod_hip_cc" and rep["symbols"] == len(want) and "constellation" in rep["node_cfg"]
     got = np.fromfile(str(tmp_path / "r.cf32"), dtype=np.complex64)
@@ -359,6 +361,13 @@ def check_flowgraph_registry_through_the_plugin(host, lib, tmp_path):
         assert rep["block"] == "costas_hip_cc" and rep["symbols"] == len(x), rep
         outs[name] = np.fromfile(str(tmp_path / (name + ".cf32")), dtype=np.uint32)
     assert np.array_equal(outs["factory"], outs["registry"])
+    # round 6: the registry's _fast loops under their stock ids (dsp_flowgraph_register.cpp:294,306) against the reference blocks on the same samples, bit for bit
+    for bid, hid, bcfg in (("costas_fast_cc", "costas_fast_hip_cc", {"order": 4, "loop_bw": 0.004}), ("fast_clock_recovery_mm_cc", "fast_clock_recovery_mm_hip_cc", {"omega": 6e6 / 2.33e6})):
+        wantb = nd.run(bid, bcfg, x, buf=8192)
+        rep = _run_ndsp(host, lib, {"block": bid, "via_registry": True, "cfg": bcfg, "input": str(inp), "output": str(tmp_path / (bid + ".cf32")), "buffer": 8192},
+                        tmp_path, plugin=PLUGIN_FG, env={"SDHIP_OVERRIDE": "1"})
+        assert rep["block"] == hid and rep["symbols"] == len(wantb), rep
+        assert np.array_equal(np.fromfile(str(tmp_path / (bid + ".cf32")), dtype=np.uint32), wantb.view(np.uint32)), bid
 
 
 def test_flowgraph_registry_through_the_plugin(host, tmp_path):
