@@ -2493,7 +2493,7 @@ extern "C"
         d.clock_mu = c->rec_mu;
         d.clock_gain_mu = c->rec_muGain;
         d.clock_omega_relative_limit = c->rec_omegaLimit;
-        d.exact = (kind == SDHIP_NDSP_COSTAS_FAST || kind == SDHIP_NDSP_MM_FAST) ? 1 : c->exact; // the _fast loops: one sequential lane (include/sdhip.h)
+        d.exact = kind == SDHIP_NDSP_COSTAS_FAST ? 1 : c->exact; // costas_fast_cc: one sequential lane (include/sdhip.h)
         d.chunk_len = c->chunk_len;
         d.warmup = c->warmup;
         NdspExt e;

@@ -2975,10 +2975,13 @@ template <bool CKPT, bool SPLIT, bool Q8 = false, bool FAST = false, bool GARD =
             return;
         }
         if (p.loop == 2)
-        { // ndsp::MMClockRecoveryFastBlock on ONE sequential lane (float symbols)
-            if (g.K != 1 || p.q8 || p.fast || redo)
-                throw HipError("fast_clock_recovery_mm_cc runs as one sequential lane");
-            go(k_mm<false, false, false, false, false, false, true>, nullptr, 0, 0.0f);
+        { // ndsp::MMClockRecoveryFastBlock on the clock-recovery lanes (float symbols; the linear interpolation is the block's own arithmetic in either mode)
+            if (p.q8)
+                throw HipError("fast_clock_recovery_mm_cc lanes carry float symbols");
+            if (ck)
+                go(k_mm<true, false, false, false, false, false, true>, ck, ck_per_chunk, ck_tol);
+            else
+                go(k_mm<false, false, false, false, false, false, true>, nullptr, 0, 0.0f);
             return;
         }
         if (p.loop == 1)
