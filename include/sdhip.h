@@ -217,8 +217,11 @@ extern "C"
         SDHIP_NDSP_AGC_FAST = 6, /* "agc_fast_cc" (dsp/agc/agc_fast.cpp:22-58, dsp_flowgraph_register.cpp:278): the gain follows |input| x gain -- the magnitudes of the INPUT
                                    taken first (volk_32fc_magnitude_32f) -- instead of |output|; agc_* keys as for the AGC block */
         SDHIP_NDSP_COSTAS_FAST = 7, /* "costas_fast_cc" (dsp/pll/costas_fast.cpp:15-110, dsp_flowgraph_register.cpp:294): the VCO as a complex number turned by small-angle
-                                   updates, renormalised every 65th sample; pll_* keys + constellation for the order as for the Costas block. Always ONE sequential lane
-                                   (bit for bit the block whatever `exact` says): its five-float state has no chunk-parallel schedule here */
+                                   updates, renormalised every 65th sample; pll_* keys + constellation for the order as for the Costas block. exact = 1: one sequential lane.
+                                   exact = 0: lane-per-chunk with a STRICT hand-off -- a chunk stands only if its start state is bit-identical to its predecessor's end
+                                   state modulo an exact quarter / half turn, else it runs again from that state; a call whose lanes do not hand off, or whose frequency
+                                   limiter comes into play, runs as the one sequential lane -- so the samples are the block's own, float for float, in either mode
+                                   (the "freq" statistic within ~1e-6 rad / sample). SDHIP_CF_STRICT=0: the plain loop's tolerance windows instead */
         SDHIP_NDSP_MM_FAST = 8 /* "fast_clock_recovery_mm_cc" (dsp/clock_recovery/clock_recovery_mm_fast.cpp:66-163, dsp_flowgraph_register.cpp:306): the M&M detector on a linear
                                    interpolation, the rate term updated every fifth symbol; rec_omega / rec_omegaGain / rec_mu / rec_muGain / rec_omegaLimit. Always one
                                    sequential lane (the cadence counter follows the symbol count) */

@@ -539,7 +539,10 @@ namespace sdhip
         DevBuf<AgcState> d_agc_spec, d_agc_end, d_agc_start;
         DevBuf<CostasState> d_cos_spec, d_cos_end, d_cos_start;
         CostasFastParams cf_p{};            // SDHIP_NDSP_COSTAS_FAST: the block's parameters, its state resident on the device
-        DevBuf<CostasFastState> d_cf_state;
+        DevBuf<CostasFastState> d_cf_state, d_cf_spec, d_cf_end;
+        CostasFastState cf_s{0.0f, 1.0f, 0.0f, 1.0f, 0.0f, 0u, 3.0e38f}; // host copy of the block's state behind the last call
+        long long cf_total = 0;                                  // samples the block has seen (renorm_ctr follows them)
+        DevBuf<int> d_cf_redo;
         DevBuf<MmState> d_mm_spec, d_mm_end, d_mm_start;
         DevBuf<MmCert> d_mm_spec_c, d_mm_end_c; // what the host certificate reads (16 B per chunk instead of the 72-byte state)
         DevBuf<MmCkpt> d_mm_ck;                 // per-chunk checkpoints for the early exit of re-run lanes
@@ -804,7 +807,7 @@ namespace sdhip
                 cf_p.lim_max_re = cosf(cf_p.fmax);
                 cf_p.lim_max_im = sinf(cf_p.fmax);
                 cf_p.order = order;
-                const CostasFastState s0{0.0f, 1.0f, 0.0f, 1.0f, 0.0f, 0u};
+                const CostasFastState s0{0.0f, 1.0f, 0.0f, 1.0f, 0.0f, 0u, 3.0e38f};
                 d_cf_state.reserve(1);
                 SD_HIP(hipMemcpy(d_cf_state.p, &s0, sizeof(s0), hipMemcpyHostToDevice));
             }
@@ -1519,42 +1522,269 @@ namespace sdhip
 
         // ---- Costas (speculative, symmetry-corrected): A -> B; cg = the chunk geometry, d_rot the frame of every chunk
         // (sps: samples per symbol of the stage input -- the lag of the start-frequency estimate; rate_hz: its sample rate, for the stats)
+        // carrier frequency a warm-up lane starts from, estimated over the head of a stream's first call (k_freq_est)
+        float carrier_start_freq(const cf32 *A, long long n, double sps)
+        {
+            // carrier frequency for the warm-up start state: arg(sum z[n+L] conj(z[n])) / (order L), z = x^order, L ~ two
+            // symbols, on the branch next to the (unambiguous, coarse) lag-1 value -- see k_freq_est
+            const int classic = order > 4 ? 1 : 0;
+            const long long m = std::min<long long>(n, classic ? 1 << 18 : 1 << 20);
+            const int lag = (int)std::min(16.0, std::max(2.0, std::floor(2.0 * sps + 0.5)));
+            ProfScope _ps("k_freq_est", stream);
+            hipLaunchKernelGGL(k_freq_est, dim3(64), dim3(256), 0, stream, A, m, order, lag, classic, d_partial.p);
+            double part[256];
+            SD_HIP(hipMemcpyAsync(part, d_partial.p, sizeof(part), hipMemcpyDeviceToHost, stream));
+            SD_HIP(hipStreamSynchronize(stream));
+            double sr = 0, si = 0, lr = 0, li = 0;
+            for (int i = 0; i < 64; i++)
+            {
+                sr += part[4 * i];
+                si += part[4 * i + 1];
+                lr += part[4 * i + 2];
+                li += part[4 * i + 3];
+            }
+            const double coarse = std::atan2(si, sr) / order;
+            double fine = coarse;
+            if (!classic && m > 4 * lag && (lr != 0 || li != 0))
+            {
+                const double step = 2.0 * design::PI / ((double)order * lag); // spacing of the lag-L branches
+                const double base = std::atan2(li, lr) / ((double)order * lag);
+                fine = base + step * std::floor((coarse - base) / step + 0.5);
+            }
+            if (getenv("SDHIP_DEBUG"))
+                fprintf(stderr, "[sdhip] costas start frequency: lag-1 %.6f, lag-%d %.6f rad/sample (%lld samples)\n", coarse, lag, fine, m);
+            float f = (float)fine;
+            f = std::min(std::max(f, cos_p.fmin), cos_p.fmax);
+            return f;
+        }
+
+        // ---- ndsp::CostasFastBlock (dsp/pll/costas_fast.cpp), SDHIP_NDSP_COSTAS_FAST. exact: one sequential lane, bit for bit. Otherwise lane-per-chunk like the
+        // plain loop: warm-up lanes start from the carried frequency (first call: the M-th power estimate) next to a stable point, renorm_ctr follows the
+        // stream's sample count and is therefore known at every chunk start; the hand-off is judged on the HOST from the K start / end states (a few MB): the
+        // start state bit-identical to the predecessor's end state modulo an exact quarter / half turn (strict, the default: the output is then the block's own,
+        // float for float) or inside the plain loop's windows (SDHIP_CF_STRICT=0). A chunk that
+        // fails runs again from its predecessor's end state (and inherits its frame); the frames are turned back on the output (exact quarter / half turns).
+        // A call whose lanes do not hand off (a loop that is not locked: more than an eighth of the boundaries fail, or the re-runs do not settle) is run as
+        // the one sequential lane instead -- so the worst case is the block's own trajectory at twice the sequential lane's time.
+        void costas_fast_stage(const cf32 *A, cf32 *B, long long n)
+        {
+            if (n > (1ll << 30))
+                throw HipError("costas_fast_cc: at most 2^30 samples per call");
+            cf_p.ctr_base = (unsigned)(cf_total % 65);
+            cf_s.margin = 3.0e38f; // (per call)
+            auto sequential = [&]() {
+                SD_HIP(hipMemcpyAsync(d_cf_state.p, &cf_s, sizeof(cf_s), hipMemcpyHostToDevice, stream));
+                launch_costas_fast(A, B, n, cf_p, d_cf_state.p, stream);
+                SD_HIP(hipMemcpyAsync(&cf_s, d_cf_state.p, sizeof(cf_s), hipMemcpyDeviceToHost, stream));
+                SD_HIP(hipStreamSynchronize(stream));
+                stats.chunks += 1;
+            };
+            const int L = pick_L(n, ST_COSTAS);
+            long long W = cfg.warmup > 0 ? cfg.warmup : (long long)std::max(512.0, 24.0 / (1.414 * std::max(1e-5f, cfg.pll_bw)));
+            W = std::max(W, w_cos_learned); // (a stream that needed a longer warm-up keeps it)
+            W = (std::min<long long>(env_int("SDHIP_W_COSTAS", W), 1 << 20) + 255) / 256 * 256;
+            ChunkGeom g = make_geom(n, L, (int)W);
+            if (cfg.exact || g.K < 2)
+            {
+                sequential();
+                cf_total += n;
+                return;
+            }
+            cf_p.init_freq = started ? cf_s.freq : carrier_start_freq(A, n, 1.0);
+            cf_p.init_freq = std::min(std::max(cf_p.init_freq, cf_p.fmin), cf_p.fmax);
+            cf_p.est_len = (int)std::min<long long>(256, W / 2);
+            int K = g.K;
+            d_cf_spec.reserve(K);
+            d_cf_end.reserve(K);
+            d_cf_redo.reserve(K);
+            d_rot.reserve(K);
+            SD_HIP(hipMemcpyAsync(d_cf_state.p, &cf_s, sizeof(cf_s), hipMemcpyHostToDevice, stream));
+            std::vector<CostasFastState> sp((size_t)K), en((size_t)K);
+            auto first_pass = [&]() {
+                launch_costas_fast_chunks(A, B, g, cf_p, d_cf_state.p, d_cf_spec.p, d_cf_end.p, nullptr, 0, stream);
+                SD_HIP(hipMemcpyAsync(sp.data() + 1, d_cf_spec.p + 1, (size_t)(K - 1) * sizeof(CostasFastState), hipMemcpyDeviceToHost, stream));
+                SD_HIP(hipMemcpyAsync(en.data(), d_cf_end.p, (size_t)K * sizeof(CostasFastState), hipMemcpyDeviceToHost, stream));
+                SD_HIP(hipStreamSynchronize(stream));
+            };
+            first_pass();
+            const double tol_phase = env_int("SDHIP_COSTAS_TOL_URAD", 10000) * 1e-6, tol_freq = env_int("SDHIP_COSTAS_TOL_NFREQ", 40000) * 1e-9;
+            // SDHIP_CF_STRICT (default 1): a hand-off stands only when it is bit-identical -- this loop's lanes DO merge with the sequential trajectory bit for bit
+            // (no transcendental function in the recurrence; measured on the twin: every boundary behind the acquisition) --, so the whole output is the block's
+            // own, float for float, computed lane-per-chunk. 0: the plain loop's tolerance windows.
+            const bool strict = env_int("SDHIP_CF_STRICT", 1) != 0;
+            std::vector<int> turn((size_t)K, 0), redo;
+            std::vector<char> rerun((size_t)K, 0), window_ok((size_t)K, 1);
+            long long outside = 0; // boundaries outside the tolerance windows: lanes that did not reach the sequential trajectory (what the warm-up is judged by)
+            // boundary k: chunk k's start state against chunk k - 1's end state; returns whether it stands, turn[k] = its frame relative to its predecessor's
+            auto judge = [&](int k) {
+                const CostasFastState &a = sp[(size_t)k], &b = en[(size_t)k - 1];
+                const double pa = std::atan2(-(double)a.pha_im, (double)a.pha_re), pb = std::atan2(-(double)b.pha_im, (double)b.pha_re);
+                const double r = std::floor((pa - pb) / rot_unit + 0.5), res = (pa - pb) - r * rot_unit;
+                const double ma = std::hypot((double)a.pha_re, (double)a.pha_im), mb = std::hypot((double)b.pha_re, (double)b.pha_im);
+                const double fa = std::hypot((double)a.fre_re, (double)a.fre_im), fb = std::hypot((double)b.fre_re, (double)b.fre_im);
+                const double dfr = std::atan2(-(double)a.fre_im, (double)a.fre_re) - std::atan2(-(double)b.fre_im, (double)b.fre_re);
+                turn[(size_t)k] = (int)(((long long)r % rot_mod + rot_mod) % rot_mod);
+                if (getenv("SDHIP_DEBUG") && k < 5)
+                    fprintf(stderr, "[sdhip] costas_fast boundary %d: phase %.6f vs %.6f (res %.2e)  freq %.6f vs %.6f  arg(fre) diff %.2e  |pha| %.6f vs %.6f  |fre| %.6f vs %.6f  ctr %u vs %u\n", k, pa, pb,
+                            res, a.freq, b.freq, dfr, ma, mb, fa, fb, a.ctr, b.ctr);
+                const bool in_window = std::fabs(res) < tol_phase && std::fabs((double)a.freq - (double)b.freq) < tol_freq && std::fabs(dfr) < tol_freq && std::fabs(ma - mb) < 1e-4 &&
+                                       std::fabs(fa - fb) < 1e-4 && a.ctr == b.ctr;
+                window_ok[(size_t)k] = in_window ? 1 : 0;
+                if (strict)
+                { // the start state IS the predecessor's end state, a whole number of exact (quarter / half) turns on: every float of the chunk then equals the
+                  // sequential lane's (the loop's arithmetic commutes with those turns bit for bit: products and sums only change sign or place)
+                    const int q = turn[(size_t)k];
+                    if (order == 8 && (q & 1))
+                        return false;
+                    const int quarter = order == 2 ? 2 * (q & 1) : (order == 4 ? q & 3 : (q >> 1) & 3);
+                    float pr = a.pha_re, pi = a.pha_im;
+                    for (int t = 0; t < quarter; t++)
+                    {
+                        const float tr = -pi;
+                        pi = pr;
+                        pr = tr;
+                    }
+                    return pr == b.pha_re && pi == b.pha_im && a.fre_re == b.fre_re && a.fre_im == b.fre_im && a.ctr == b.ctr; // (freq: see the limiter guard below)
+                }
+                return in_window;
+            };
+            auto judge_all = [&]() {
+                redo.clear();
+                outside = 0;
+                if ((int)turn.size() < K)
+                    throw HipError("costas_fast: chunk count grew");
+                for (int k = 1; k < K; k++)
+                {
+                    if (!judge(k))
+                        redo.push_back(k);
+                    outside += window_ok[(size_t)k] ? 0 : 1;
+                }
+            };
+            judge_all();
+            // many lanes short of the sequential trajectory: the loop's gain goes with the signal's amplitude (no AGC inside the block), so the warm-up the nominal
+            // bandwidth suggests may be short -- the lanes' median end frequency as the start value, then twice the warm-up, up to three times (the stream keeps it)
+            for (int attempt = 0; attempt < 4 && outside * 8 > (long long)(K - 1); attempt++)
+            {
+                std::vector<float> fr((size_t)K);
+                for (int k = 0; k < K; k++)
+                    fr[(size_t)k] = en[(size_t)k].freq;
+                std::nth_element(fr.begin(), fr.begin() + fr.size() / 2, fr.end());
+                const float med = fr[fr.size() / 2];
+                if (attempt == 0 && std::fabs(med - cf_p.init_freq) > 0.05f * cfg.pll_bw)
+                    cf_p.init_freq = med;
+                else
+                {
+                    const long long w2 = 2 * (long long)g.W;
+                    const ChunkGeom g2 = make_geom(n, L, (int)w2);
+                    if (cfg.warmup > 0 || getenv("SDHIP_W_COSTAS") || g2.K < 2 || w2 > (1 << 20))
+                        break;
+                    g = g2;
+                    K = g.K;
+                    w_cos_learned = w2;
+                    cf_p.est_len = (int)std::min<long long>(256, w2 / 2);
+                }
+                first_pass();
+                judge_all();
+            }
+            bool give_up = outside * 8 > (long long)(K - 1);
+            int rounds = 0;
+            long long fixed = 0;
+            while (!give_up && !redo.empty())
+            {
+                if (++rounds > 16 || (rounds > 3 && (long long)redo.size() * 8 > (long long)(K - 1)))
+                {
+                    give_up = true;
+                    break;
+                }
+                for (int k : redo)
+                { // from the predecessor's end state, in the predecessor's frame
+                    sp[(size_t)k] = en[(size_t)k - 1];
+                    turn[(size_t)k] = 0;
+                    rerun[(size_t)k] = 1;
+                }
+                fixed += (long long)redo.size();
+                SD_HIP(hipMemcpyAsync(d_cf_spec.p, sp.data(), (size_t)K * sizeof(CostasFastState), hipMemcpyHostToDevice, stream));
+                SD_HIP(hipMemcpyAsync(d_cf_redo.p, redo.data(), redo.size() * sizeof(int), hipMemcpyHostToDevice, stream));
+                launch_costas_fast_chunks(A, B, g, cf_p, d_cf_state.p, d_cf_spec.p, d_cf_end.p, d_cf_redo.p, (int)redo.size(), stream);
+                SD_HIP(hipMemcpyAsync(en.data(), d_cf_end.p, (size_t)K * sizeof(CostasFastState), hipMemcpyDeviceToHost, stream));
+                SD_HIP(hipStreamSynchronize(stream));
+                std::vector<int> next;
+                for (int k : redo)
+                    if (k + 1 < K && !judge(k + 1)) // (a chunk re-run in this very round started from its predecessor's OLD end state: judged again like any other)
+                        next.push_back(k + 1);
+                redo.swap(next);
+            }
+            // The limiter guard of the strict hand-off. `freq` only accumulates beta * error: a lane that merged in (pha, fre) carries from then on the sequential
+            // lane's freq plus the offset it had at its chunk start (the sums' own rounding apart: at most half an ulp of the largest |freq| per sample, a random walk). The offsets
+            // chain over the boundaries, so chunk k's freq is off by no more than D_k = |sum of (start freq - predecessor's end freq) up to k| + samples x ulp; its
+            // limiter decisions are the sequential lane's if freq stayed further than D_k from both limits at every renormalisation it ran (margin; its warm-up's
+            // included). A chunk that cannot show that sends the call to the one sequential lane.
+            if (strict && !give_up)
+            {
+                double off = 0.0, fmaxabs = 0.0;
+                for (int k = 0; k < K; k++)
+                    fmaxabs = std::max(fmaxabs, (double)std::fabs(en[(size_t)k].freq));
+                const double ulp = std::ldexp(1.0, std::ilogb(std::max(fmaxabs, 1e-30)) - 23);
+                for (int k = 1; k < K && !give_up; k++)
+                {
+                    off += (double)sp[(size_t)k].freq - (double)en[(size_t)k - 1].freq;
+                    const double ne = (double)chunk_end(g, k);
+                    const double Dk = std::fabs(off) + std::min(ne, 16.0 * std::sqrt(ne)) * ulp + 1e-7; // (the sums' rounding walk: its worst case, or 16 standard deviations)
+                    if (!((double)en[(size_t)k].margin > Dk))
+                        give_up = true;
+                }
+                if (en[0].margin < 0.0f) // the sequential lane's own limiter acted: exact by itself, but what follows started from lanes that did not see it
+                    give_up = true;
+            }
+            if (getenv("SDHIP_DEBUG"))
+                fprintf(stderr, "[sdhip] costas_fast chunks %d L %d W %d  re-run %lld in %d round(s)%s\n", K, g.L, g.W, fixed, rounds, give_up ? "  -> one sequential lane" : "");
+            if (give_up)
+            {
+                sequential();
+                stats.chunks_forced += 1;
+                cf_total += n;
+                return;
+            }
+            // frames: rot[k] = sum of the turns up to k; the output of chunk k is out * exp(-j rot unit), the state pha * exp(-j rot unit): turned back by rot_apply
+            std::vector<int> rot((size_t)K, 0);
+            for (int k = 1; k < K; k++)
+                rot[(size_t)k] = (rot[(size_t)k - 1] + turn[(size_t)k]) % rot_mod;
+            SD_HIP(hipMemcpyAsync(d_rot.p, rot.data(), (size_t)K * sizeof(int), hipMemcpyHostToDevice, stream));
+            launch_derotate(B, n, g, d_rot.p, order, stream);
+            cf_s = en[(size_t)K - 1];
+            {
+                const double a = rot[(size_t)K - 1] * rot_unit, c = std::cos(a), sn = std::sin(a);
+                const int q = rot[(size_t)K - 1];
+                double pr = cf_s.pha_re, pi = cf_s.pha_im;
+                if (order == 2 || (order == 4) || (order == 8 && (q & 1) == 0))
+                { // exact half / quarter turns
+                    const int quarter = order == 2 ? 2 * (q & 1) : (order == 4 ? q & 3 : (q >> 1) & 3);
+                    for (int t = 0; t < quarter; t++)
+                    {
+                        const double tr = -pi;
+                        pi = pr;
+                        pr = tr;
+                    }
+                }
+                else
+                {
+                    const double tr = pr * c - pi * sn, ti = pr * sn + pi * c;
+                    pr = tr;
+                    pi = ti;
+                }
+                cf_s.pha_re = (float)pr;
+                cf_s.pha_im = (float)pi;
+            }
+            SD_HIP(hipStreamSynchronize(stream));
+            stats.chunks += K;
+            stats.chunks_fixed += fixed;
+            cf_total += n;
+        }
+
         void costas_stage(const cf32 *A, cf32 *B, long long n, ChunkGeom &cg, double sps, double rate_hz)
         {
             if (!started)
-            {
-                // carrier frequency for the warm-up start state: arg(sum z[n+L] conj(z[n])) / (order L), z = x^order, L ~ two
-                // symbols, on the branch next to the (unambiguous, coarse) lag-1 value -- see k_freq_est
-                const int classic = order > 4 ? 1 : 0;
-                const long long m = std::min<long long>(n, classic ? 1 << 18 : 1 << 20);
-                const int lag = (int)std::min(16.0, std::max(2.0, std::floor(2.0 * sps + 0.5)));
-                ProfScope _ps("k_freq_est", stream);
-                hipLaunchKernelGGL(k_freq_est, dim3(64), dim3(256), 0, stream, A, m, order, lag, classic, d_partial.p);
-                double part[256];
-                SD_HIP(hipMemcpyAsync(part, d_partial.p, sizeof(part), hipMemcpyDeviceToHost, stream));
-                SD_HIP(hipStreamSynchronize(stream));
-                double sr = 0, si = 0, lr = 0, li = 0;
-                for (int i = 0; i < 64; i++)
-                {
-                    sr += part[4 * i];
-                    si += part[4 * i + 1];
-                    lr += part[4 * i + 2];
-                    li += part[4 * i + 3];
-                }
-                const double coarse = std::atan2(si, sr) / order;
-                double fine = coarse;
-                if (!classic && m > 4 * lag && (lr != 0 || li != 0))
-                {
-                    const double step = 2.0 * design::PI / ((double)order * lag); // spacing of the lag-L branches
-                    const double base = std::atan2(li, lr) / ((double)order * lag);
-                    fine = base + step * std::floor((coarse - base) / step + 0.5);
-                }
-                if (getenv("SDHIP_DEBUG"))
-                    fprintf(stderr, "[sdhip] costas start frequency: lag-1 %.6f, lag-%d %.6f rad/sample (%lld samples)\n", coarse, lag, fine, m);
-                float f = (float)fine;
-                f = std::min(std::max(f, cos_p.fmin), cos_p.fmax);
-                cos_p.init_freq = f;
-            }
+                cos_p.init_freq = carrier_start_freq(A, n, sps);
             else
                 cos_p.init_freq = cos_s.freq;
             // both loop modes decay like exp(-zeta*wn*t) with zeta*wn ~ 1.414*pll_bw per sample (unit detector gain after
@@ -2178,19 +2408,14 @@ namespace sdhip
                 return n;
             }
             if (nd.only == SDHIP_NDSP_COSTAS_FAST)
-            { // CostasFastBlock::process (dsp/pll/costas_fast.cpp:93-106) on one sequential lane, the block's state on the device from call to call
+            { // CostasFastBlock::process (dsp/pll/costas_fast.cpp:93-106): costas_fast_stage
                 if ((size_t)n > out_cap)
                     throw HipError("output buffer too small");
-                if (n > (1ll << 30))
-                    throw HipError("costas_fast_cc: at most 2^30 samples per call");
                 SD_HIP(hipMemcpyAsync(A, d_in, (size_t)n * sizeof(cf32), hipMemcpyDeviceToDevice, stream));
-                launch_costas_fast(A, B, n, cf_p, d_cf_state.p, stream);
+                costas_fast_stage(A, B, n);
                 SD_HIP(hipMemcpyAsync(d_out, B, (size_t)n * sizeof(cf32), hipMemcpyDeviceToDevice, stream));
-                CostasFastState se;
-                SD_HIP(hipMemcpyAsync(&se, d_cf_state.p, sizeof(se), hipMemcpyDeviceToHost, stream));
                 SD_HIP(hipStreamSynchronize(stream));
-                stats.freq_hz = (float)(((double)se.freq / (2.0 * design::PI)) * nd.samplerate); // the block's "freq" statistic is rad / sample (costas_fast.h:80)
-                stats.chunks = 1;
+                stats.freq_hz = (float)(((double)cf_s.freq / (2.0 * design::PI)) * nd.samplerate); // the block's "freq" statistic is rad / sample (costas_fast.h:80)
                 started = true;
                 return n;
             }
@@ -2493,7 +2718,10 @@ extern "C"
         d.clock_mu = c->rec_mu;
         d.clock_gain_mu = c->rec_muGain;
         d.clock_omega_relative_limit = c->rec_omegaLimit;
-        d.exact = kind == SDHIP_NDSP_COSTAS_FAST ? 1 : c->exact; // costas_fast_cc: one sequential lane (include/sdhip.h)
+        // fast_clock_recovery_mm_cc runs as one sequential lane (include/sdhip.h). Measured on the twin: lanes with their own count of symbols
+        // update the rate term on another subset of the detector's outputs (every fifth symbol, clock_recovery_mm_fast.cpp:139-146) and end 0.05 - 0.2 sample
+        // from the sequential trajectory for good -- nothing a hand-off could certify without carrying all five cadences per chunk
+        d.exact = kind == SDHIP_NDSP_MM_FAST ? 1 : c->exact;
         d.chunk_len = c->chunk_len;
         d.warmup = c->warmup;
         NdspExt e;

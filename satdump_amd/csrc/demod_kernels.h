@@ -189,13 +189,25 @@ namespace sdhip
         float alpha, beta, fmin, fmax;
         float lim_min_re, lim_min_im, lim_max_re, lim_max_im; // freq_limit_min_cpx / freq_limit_max_cpx (costas_fast.h:44-45)
         int order;
+        // chunk-parallel schedule only (a warm-up lane's start): the loop frequency to start from, the samples of the feed-forward start-phase estimate,
+        // renorm_ctr at sample 0 of this call (the counter follows the stream's sample count: a lane starting at sample i carries (ctr_base + i) % 65)
+        float init_freq;
+        int est_len;
+        unsigned ctr_base;
     };
     struct CostasFastState
     {
         float freq, pha_re, pha_im, fre_re, fre_im;
         unsigned ctr; // renorm_ctr
+        // not the block's: the least distance of `freq` from its limits at the renormalisations this lane has run (negative: the limiter acted). `freq` is a pure
+        // accumulator -- it feeds nothing but the limiter's comparison --, so lanes that merge in (pha, fre) keep whatever offset in it they started with: the
+        // engine's bit-exact hand-off needs every limiter decision of a lane to be safe against that offset (DemodEngine::costas_fast_stage)
+        float margin;
     };
     void launch_costas_fast(const cf32 *x, cf32 *y, long long n, const CostasFastParams &p, CostasFastState *state_dev, hipStream_t st);
+    // the same loop lane-per-chunk (k_chunks: warm-up from init_freq / the start-phase estimate, spec[k] = state at the chunk start, endst[k] behind it; redo as for launch_costas)
+    void launch_costas_fast_chunks(const cf32 *x, cf32 *y, const ChunkGeom &g, const CostasFastParams &p, const CostasFastState *start0, CostasFastState *spec, CostasFastState *endst,
+                                   const int *redo, int nredo, hipStream_t st);
 
     // ---- AGC + RRC filter + Costas loop as ONE lane-per-chunk stage (see k_afc) -----------------------------------------------------
     // The lane that produces the filtered samples of a chunk also runs the carrier loop over them: the filter output never goes to

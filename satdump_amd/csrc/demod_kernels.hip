@@ -1229,9 +1229,29 @@ namespace sdhip
         using P = CostasFastParams;
         using S = CostasFastState;
         static constexpr int DEPTH = 4;
-        __device__ static __forceinline__ S init(const P &, int) { return S{0.0f, 1.0f, 0.0f, 1.0f, 0.0f, 0u}; }
+        // a warm-up lane (chunk-parallel schedule; speculation only -- the hand-off certificate decides): pha = exp(-j phase), fre = exp(-j freq)
+        __device__ static __forceinline__ S init(const P &p, int)
+        {
+            float sn, cs;
+            __sincosf(p.init_freq, &sn, &cs);
+            return S{p.init_freq, 1.0f, 0.0f, cs, -sn, 0u, 3.0e38f};
+        }
         __device__ static __forceinline__ bool close(const S &, const S &, float, float) { return false; }
-        __device__ static __forceinline__ void prewarm(S &, const P &, const cf32 *, long long) {}
+        __device__ static __forceinline__ void prewarm(S &s, const P &p, const cf32 *x, long long i0)
+        {
+            s.ctr = (unsigned)(((long long)p.ctr_base + i0) % 65);
+            if (p.est_len <= 0 || p.order > 4)
+                return;
+            CostasState c{0.0f, s.freq};
+            CostasParams cp{};
+            cp.order = p.order;
+            cp.est_len = p.est_len;
+            CostasStage<ORDER == 8 ? 4 : ORDER>::prewarm(c, cp, x, i0); // the M-th power estimate of the plain loop's lanes
+            float sn, cs;
+            __sincosf(c.phase, &sn, &cs);
+            s.pha_re = cs;
+            s.pha_im = -sn;
+        }
         __device__ static __forceinline__ cf32 step(S &s, const P &p, const cf32 v)
         {
             const float tr = (v.re * s.pha_re) - (v.im * s.pha_im);
@@ -1273,6 +1293,7 @@ namespace sdhip
                 inv = sd_fast_invsqrt((s.fre_re * s.fre_re) + (s.fre_im * s.fre_im));
                 s.fre_re *= inv;
                 s.fre_im *= inv;
+                s.margin = fminf(s.margin, fminf(p.fmax - s.freq, s.freq - p.fmin));
                 if (s.freq > p.fmax)
                 {
                     s.freq = p.fmax;
@@ -2240,6 +2261,25 @@ namespace sdhip
         else
             go(CostasFastStage<8>{});
     }
+    void launch_costas_fast_chunks(const cf32 *x, cf32 *y, const ChunkGeom &g, const CostasFastParams &p, const CostasFastState *start0, CostasFastState *spec, CostasFastState *endst,
+                                   const int *redo, int nredo, hipStream_t st)
+    {
+        const int n = redo ? nredo : g.K;
+        if (n <= 0)
+            return;
+        ProfScope _ps("k_chunks<CostasFastStage>", st);
+        auto go = [&](auto stage) {
+            using St = decltype(stage);
+            hipLaunchKernelGGL((k_chunks<St, false>), dim3((n + 63) / 64), dim3(64), 0, st, x, y, g, p, start0, spec, endst, redo, nredo, (CostasFastState *)nullptr, 0, 0, 0.0f, 0.0f,
+                               (unsigned long long *)nullptr);
+        };
+        if (p.order == 2)
+            go(CostasFastStage<2>{});
+        else if (p.order == 4)
+            go(CostasFastStage<4>{});
+        else
+            go(CostasFastStage<8>{});
+    }
     void launch_pll(const cf32 *x, cf32 *y, const ChunkGeom &g, const PllParams &p, const CostasState *start0, CostasState *spec, CostasState *endst,
                     const int *redo, int nredo, hipStream_t st, const ChunkCkpt &ck)
     {
@@ -2975,13 +3015,10 @@ template <bool CKPT, bool SPLIT, bool Q8 = false, bool FAST = false, bool GARD =
             return;
         }
         if (p.loop == 2)
-        { // ndsp::MMClockRecoveryFastBlock on the clock-recovery lanes (float symbols; the linear interpolation is the block's own arithmetic in either mode)
-            if (p.q8)
-                throw HipError("fast_clock_recovery_mm_cc lanes carry float symbols");
-            if (ck)
-                go(k_mm<true, false, false, false, false, false, true>, ck, ck_per_chunk, ck_tol);
-            else
-                go(k_mm<false, false, false, false, false, false, true>, nullptr, 0, 0.0f);
+        { // ndsp::MMClockRecoveryFastBlock on ONE sequential lane (float symbols): the cadence of its rate updates follows the symbol count (demod_engine.hip, ndsp_create)
+            if (g.K != 1 || p.q8 || p.fast || redo)
+                throw HipError("fast_clock_recovery_mm_cc runs as one sequential lane");
+            go(k_mm<false, false, false, false, false, false, true>, nullptr, 0, 0.0f);
             return;
         }
         if (p.loop == 1)

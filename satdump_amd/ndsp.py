@@ -133,8 +133,8 @@ _SINGLE = {
     # dsp/clock_recovery/clock_recovery_gardner.h:15-21, 57-130: the M&M block's keys (its own default omega is 0: set it)
     "clock_recovery_gardner_cc": (NDSP_GARDNER, {"omega": "rec_omega", "omegaGain": "rec_omegaGain", "mu": "rec_mu", "muGain": "rec_muGain", "omegaLimit": "rec_omegaLimit",
                                                  "nfilt": "rec_nfilt", "ntaps": "rec_ntaps"}),
-    # dsp/pll/costas_fast.h:63-104 (the Costas block's keys) and dsp/clock_recovery/clock_recovery_mm_fast.h:59-116 (the M&M block's without the bank's shape): always one
-    # sequential lane on the device, bit for bit the block
+    # dsp/pll/costas_fast.h:63-104 (the Costas block's keys) and dsp/clock_recovery/clock_recovery_mm_fast.h:59-116 (the M&M block's without the bank's shape). The clock
+    # recovery always runs as one sequential lane; the carrier loop lane-per-chunk with a bit-exact hand-off (include/sdhip.h): both bit for bit the block
     "costas_fast_cc": (NDSP_COSTAS_FAST, {"loop_bw": "pll_loop_bw", "freq_limit": "pll_freq_limit"}),
     "fast_clock_recovery_mm_cc": (NDSP_MM_FAST, {"omega": "rec_omega", "omegaGain": "rec_omegaGain", "mu": "rec_mu", "muGain": "rec_muGain", "omegaLimit": "rec_omegaLimit"}),
 }
@@ -194,6 +194,11 @@ class SingleBlock:
     def work_dev(self, d_in_ptr: int, nsamples: int, d_out_ptr: int, out_cap: int) -> int:
         return self._capi._check(self._capi.lib().sdhip_ndsp_psk_demod_work_dev(self._handle(), C.c_void_p(d_in_ptr), nsamples, C.c_void_p(d_out_ptr), out_cap),
                                  "sdhip_ndsp_psk_demod_work_dev")
+
+    def stats(self) -> capi.DemodStats:
+        st = self._capi.DemodStats()
+        self._capi.lib().sdhip_ndsp_psk_demod_get_stats(self._handle(), C.byref(st))
+        return st
 
     def stop(self, stop_now: bool = False, force: bool = False):
         self._drop()

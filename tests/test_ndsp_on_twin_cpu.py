@@ -13,3 +13,4 @@ test_ndsp_psk_demod_golden = N.test_ndsp_psk_demod_golden
 test_ndsp_host_mirror = N.test_ndsp_host_mirror
 test_ndsp_single_block_handles = N.test_ndsp_single_block_handles
 test_ndsp_agc_scan_start_gains = N.test_ndsp_agc_scan_start_gains
+test_ndsp_costas_fast_chunk_parallel = N.test_ndsp_costas_fast_chunk_parallel
