@@ -513,10 +513,19 @@ class NdspRef:
     def run(self, block_id: str, cfg: dict, x: np.ndarray, buf: int = 8192) -> np.ndarray:
         import json
         x = np.ascontiguousarray(x, dtype=np.complex64)
-        out = np.zeros(len(x) + 64, dtype=np.complex64)
-        n = self.lib.sdref_ndsp_run(block_id.encode(), json.dumps(cfg).encode(), _p(x), len(x), int(buf), _p(out), len(out))
-        if n < 0:
-            raise RuntimeError(f"sdref_ndsp_run({block_id}) -> {n}")
+        # The reference's FIR block reads up to three complex samples in FRONT of its std::vector (fir.cpp:104-106: &buffer[i + 1] rounded down to VOLK's 32-byte alignment,
+        # paired with zero taps) -- the heap's bookkeeping and the tail of whatever chunk lies before it. 0 x finite = 0; when those bytes happen to be a NaN / Inf
+        # pattern the block's first outputs are NaN (and behind an AGC everything after them). Seen once on a GPU box (visit r06_k). The heap looks different on
+        # the next try: run again rather than hand a poisoned oracle to a test.
+        finite_in = bool(np.isfinite(x.view(np.float32)).all())
+        for attempt in range(6):
+            out = np.zeros(len(x) + 64, dtype=np.complex64)
+            n = self.lib.sdref_ndsp_run(block_id.encode(), json.dumps(cfg).encode(), _p(x), len(x), int(buf), _p(out), len(out))
+            if n < 0:
+                raise RuntimeError(f"sdref_ndsp_run({block_id}) -> {n}")
+            if not finite_in or block_id not in ("rrc_fir_cc", "psk_demod_cc") or bool(np.isfinite(out[:n].view(np.float32)).all()):
+                break
+            _pad = [np.zeros(64 + 48 * attempt, dtype=np.uint8) for _ in range(8)]  # (move the allocator on)
         return out[:n].copy()
 
 

@@ -246,6 +246,15 @@ def check_single_block_handles(capi, nref, block_id, cfg, to_host_run=None):
         else:
             assert len(got) == len(want)
         if exact or block_id in SEQUENTIAL_ONLY:
+            if block_id == "rrc_fir_cc":
+                # The reference block's first outputs read in FRONT of its buffer: fir.cpp:104-106 rounds &buffer[i + 1] down to VOLK's alignment (32 bytes = 4 complex
+                # samples) and pairs what lies there with zero taps -- for i = 0 .. 2 up to three complex samples before a std::vector whose storage malloc aligns
+                # to 16 bytes, i.e. the heap's own bookkeeping. 0 x finite = 0, so it normally does not show; when those bytes happen to be a NaN / Inf pattern the
+                # reference's output is NaN there (seen once on a GPU box, visit r06_k). Where the reference is finite it must be matched bit for bit.
+                fin = np.isfinite(want[:3].view(np.float32))
+                assert np.array_equal(got[:3].view(np.uint32)[fin], want[:3].view(np.uint32)[fin]), block_id
+                assert np.array_equal(got[3:].view(np.uint32), want[3:].view(np.uint32)), block_id
+                continue
             assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), block_id
         else:
             m = min(len(got), len(want))
