@@ -223,8 +223,11 @@ extern "C"
                                    limiter comes into play, runs as the one sequential lane -- so the samples are the block's own, float for float, in either mode
                                    (the "freq" statistic within ~1e-6 rad / sample). SDHIP_CF_STRICT=0: the plain loop's tolerance windows instead */
         SDHIP_NDSP_MM_FAST = 8 /* "fast_clock_recovery_mm_cc" (dsp/clock_recovery/clock_recovery_mm_fast.cpp:66-163, dsp_flowgraph_register.cpp:306): the M&M detector on a linear
-                                   interpolation, the rate term updated every fifth symbol; rec_omega / rec_omegaGain / rec_mu / rec_muGain / rec_omegaLimit. Always one
-                                   sequential lane (the cadence counter follows the symbol count) */
+                                   interpolation, the rate term updated every fifth symbol; rec_omega / rec_omegaGain / rec_mu / rec_muGain / rec_omegaLimit. exact = 1: one
+                                   sequential lane. exact = 0: a lane per (chunk, value of the every-fifth-symbol counter at the warm-up's start) -- how many symbols lie in
+                                   front of a chunk nobody knows ahead, so each chunk runs under all five cadences -- and a STRICT hand-off: the variant stands whose state at
+                                   the chunk start is bit for bit its predecessor's state at its end, a chunk with none runs again from that state; a call whose lanes do not
+                                   hand off runs as the one sequential lane. The symbols are the block's own, float for float, in either mode */
     };
     void *sdhip_ndsp_block_create(int kind, const sdhip_ndsp_psk_cfg *cfg);
     void sdhip_ndsp_psk_demod_destroy(void *h);

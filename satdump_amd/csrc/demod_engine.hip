@@ -543,6 +543,11 @@ namespace sdhip
         CostasFastState cf_s{0.0f, 1.0f, 0.0f, 1.0f, 0.0f, 0u, 3.0e38f}; // host copy of the block's state behind the last call
         long long cf_total = 0;                                  // samples the block has seen (renorm_ctr follows them)
         DevBuf<int> d_cf_redo;
+        // fast_clock_recovery_mm_cc lane per (chunk, cadence): mmfast_stage
+        DevBuf<cf32> d_mf_rows;
+        DevBuf<MmState> d_mf_spec, d_mf_end, d_mf_redo_start;
+        DevBuf<int> d_mf_counts, d_mf_sel, d_mf_redo;
+        DevBuf<long long> d_mf_offs;
         DevBuf<MmState> d_mm_spec, d_mm_end, d_mm_start;
         DevBuf<MmCert> d_mm_spec_c, d_mm_end_c; // what the host certificate reads (16 B per chunk instead of the 72-byte state)
         DevBuf<MmCkpt> d_mm_ck;                 // per-chunk checkpoints for the early exit of re-run lanes
@@ -916,7 +921,7 @@ namespace sdhip
         enum StageKind { ST_AGC = 0, ST_COSTAS = 1, ST_MM = 2 };
         int pick_L(long long n, StageKind st) const
         {
-            if (cfg.exact)
+            if (cfg.exact || (nd.only == SDHIP_NDSP_MM_FAST && st == ST_MM)) // (the _fast clock recovery's own lanes are mmfast_stage's; here it is one sequential lane)
                 return 1 << 30;
             if (cfg.chunk_len <= 0 && getenv("SDHIP_CHUNK"))
                 return (int)((env_int("SDHIP_CHUNK", 8192) + 7) / 8 * 8);
@@ -1558,6 +1563,179 @@ namespace sdhip
             return f;
         }
 
+        // ---- ndsp::MMClockRecoveryFastBlock<complex_t> (dsp/clock_recovery/clock_recovery_mm_fast.cpp), SDHIP_NDSP_MM_FAST, lane per (chunk, cadence): k_mmfast.
+        // Returns the symbols written to d_out, or -1 when the call is to run as the one sequential lane (exact mode, a call too short for two chunks, lanes that
+        // did not hand off). The hand-off is STRICT: chunk k's variant v stands if its state at the chunk start -- timing, rate, position, cadence counter, the
+        // detector's delay lines -- is bit for bit the state its predecessor's standing variant ended with; so the output is the block's own, float for float.
+        // A chunk none of whose variants fits runs again from that end state (up to 8 rounds); while a chunk is waiting for its re-run the scan goes on behind
+        // it on the assumption that the re-run will end where one of its variants ended, and checks that afterwards.
+        long long mmfast_stage(cf32 *A, long long n, float *d_out, size_t out_cap)
+        {
+            if (cfg.exact)
+                return -1;
+            const double gmu = std::max(1e-4f, cfg.clock_gain_mu);
+            // merging bit for bit takes the RATE state down to its last bit: measured on the reference block, 12 - 25 k symbols at the default gains (8.7e-3), 4 - 11 k at
+            // 0.02 -- 110 - 220 / gain_mu: 300 / gain_mu symbols of warm-up
+            long long W = cfg.warmup > 0 ? cfg.warmup : (long long)(300.0 / gmu * final_sps);
+            W = (env_int("SDHIP_W_MMFAST", W) + 255) / 256 * 256;
+            const long long lanes = std::max<long long>(64, env_int("SDHIP_LANES_MMFAST", 13056));
+            long long L = cfg.chunk_len > 0 ? cfg.chunk_len : std::max<long long>(4096, (n + lanes - 1) / lanes);
+            L = (L + 63) / 64 * 64;
+            if (L > (1 << 30) || W > (1 << 30))
+                return -1;
+            const ChunkGeom g = make_geom(n, (int)L, (int)W);
+            if (g.K < 2)
+                return -1;
+            const int K = g.K;
+            const double omin = (double)mm_p.omega_mid - std::fabs((double)mm_p.omega_limit);
+            const int cap = ((int)((double)L / std::max(0.5, omin - 0.01)) + 16 + 7) & ~7;
+            const int cap0 = ((int)((double)(L + W) / std::max(0.5, omin - 0.01)) + 16 + 7) & ~7;
+            d_mf_rows.reserve((size_t)K * 6 * (size_t)cap + (size_t)cap0);
+            d_mf_spec.reserve((size_t)K * 6);
+            d_mf_end.reserve((size_t)K * 6);
+            d_mf_counts.reserve((size_t)K * 6);
+            d_mf_sel.reserve(K);
+            d_mf_offs.reserve(K);
+            d_mf_redo.reserve(K);
+            d_mf_redo_start.reserve(K);
+            put_hist(A, hist_cos);
+            SD_HIP(hipMemcpyAsync(d_mm_start.p, &mm_s, sizeof(mm_s), hipMemcpyHostToDevice, stream));
+            SD_HIP(hipMemsetAsync(d_mf_counts.p, 0, (size_t)K * 6 * sizeof(int), stream));
+            launch_mmfast(A, d_mf_rows.p, d_mf_counts.p, g, cap, cap0, mm_p, d_mm_start.p, d_mf_spec.p, d_mf_end.p, nullptr, nullptr, 0, stream);
+            std::vector<MmState> sp((size_t)K * 6), en((size_t)K * 6);
+            std::vector<int> cnt((size_t)K * 6);
+            SD_HIP(hipMemcpyAsync(sp.data(), d_mf_spec.p, sp.size() * sizeof(MmState), hipMemcpyDeviceToHost, stream));
+            SD_HIP(hipMemcpyAsync(en.data(), d_mf_end.p, en.size() * sizeof(MmState), hipMemcpyDeviceToHost, stream));
+            SD_HIP(hipMemcpyAsync(cnt.data(), d_mf_counts.p, cnt.size() * sizeof(int), hipMemcpyDeviceToHost, stream));
+            SD_HIP(hipStreamSynchronize(stream));
+            auto same = [](const MmState &a, const MmState &b) {
+                return memcmp(&a.mu, &b.mu, sizeof(float)) == 0 && memcmp(&a.omega, &b.omega, sizeof(float)) == 0 && a.inc == b.inc && a.upd_cnt == b.upd_cnt &&
+                       memcmp(&a.p_1T, &b.p_1T, sizeof(cf32)) == 0 && memcmp(&a.p_0T, &b.p_0T, sizeof(cf32)) == 0 && memcmp(&a.c_1T, &b.c_1T, sizeof(cf32)) == 0 &&
+                       memcmp(&a.c_0T, &b.c_0T, sizeof(cf32)) == 0;
+            };
+            std::vector<int> sel((size_t)K, 0);
+            std::vector<char> exact_end((size_t)K, 0); // chunk k's standing row ends in a state that is known (not assumed)
+            std::vector<int> assumed((size_t)K, -1);   // a chunk waiting for its re-run: the variant whose end state the scan behind it assumed
+            long long fixed = 0;
+            int rounds = 0;
+            bool give_up = false;
+            int from = 1; // chunks in front of `from` stand
+            exact_end[0] = 1;
+            for (;;)
+            {
+                std::vector<int> redo;
+                std::vector<MmState> redo_start;
+                // scan: the state chunk k has to start from = the end state of chunk k - 1's standing variant
+                for (int k = from; k < K; k++)
+                {
+                    const MmState *prev = nullptr;
+                    if (assumed[(size_t)k - 1] >= 0)
+                        prev = &en[((size_t)k - 1) * 6 + (size_t)assumed[(size_t)k - 1]];
+                    else
+                        prev = &en[((size_t)k - 1) * 6 + (size_t)sel[(size_t)k - 1]];
+                    int found = -1;
+                    for (int v = 0; v < 5 && found < 0; v++)
+                        if (same(sp[(size_t)k * 6 + v], *prev))
+                            found = v;
+                    if (found >= 0)
+                    {
+                        sel[(size_t)k] = found;
+                        assumed[(size_t)k] = -1;
+                        continue;
+                    }
+                    // none fits: re-run from the predecessor's end state if that is known; the scan goes on behind this chunk assuming its re-run will end where the
+                    // variant of the predecessor's cadence ended (the lanes of one cadence have usually merged by then)
+                    if (assumed[(size_t)k - 1] < 0)
+                    {
+                        redo.push_back(k);
+                        redo_start.push_back(*prev);
+                    }
+                    int guess = -1;
+                    for (int v = 0; v < 5 && guess < 0; v++)
+                        if (k + 1 < K)
+                            for (int w = 0; w < 5 && guess < 0; w++)
+                                if (same(sp[((size_t)k + 1) * 6 + w], en[(size_t)k * 6 + v]))
+                                    guess = v;
+                    assumed[(size_t)k] = guess >= 0 ? guess : 0;
+                    sel[(size_t)k] = 5; // (re-run lanes fill slot 5)
+                }
+                if (redo.empty())
+                    break;
+                if (++rounds > 8 || (long long)redo.size() * 4 > (long long)K)
+                {
+                    give_up = true;
+                    break;
+                }
+                fixed += (long long)redo.size();
+                SD_HIP(hipMemcpyAsync(d_mf_redo.p, redo.data(), redo.size() * sizeof(int), hipMemcpyHostToDevice, stream));
+                SD_HIP(hipMemcpyAsync(d_mf_redo_start.p, redo_start.data(), redo_start.size() * sizeof(MmState), hipMemcpyHostToDevice, stream));
+                launch_mmfast(A, d_mf_rows.p, d_mf_counts.p, g, cap, cap0, mm_p, d_mm_start.p, d_mf_spec.p, d_mf_end.p, d_mf_redo.p, d_mf_redo_start.p, (int)redo.size(), stream);
+                int first = K;
+                for (int k : redo)
+                {
+                    MmState ne;
+                    SD_HIP(hipMemcpyAsync(&ne, d_mf_end.p + (size_t)k * 6 + 5, sizeof(MmState), hipMemcpyDeviceToHost, stream));
+                    SD_HIP(hipMemcpyAsync(&cnt[(size_t)k * 6 + 5], d_mf_counts.p + (size_t)k * 6 + 5, sizeof(int), hipMemcpyDeviceToHost, stream));
+                    SD_HIP(hipStreamSynchronize(stream));
+                    const bool as_assumed = same(ne, en[(size_t)k * 6 + (size_t)assumed[(size_t)k]]);
+                    if (getenv("SDHIP_DEBUG"))
+                        fprintf(stderr, "[sdhip]   mmfast chunk %d re-run: assumed variant %d, ended as assumed: %d (inc %lld mu %.9g omega %.9g cnt %u | assumed inc %lld mu %.9g omega %.9g cnt %u)\n", k,
+                                assumed[(size_t)k], (int)as_assumed, ne.inc, ne.mu, ne.omega, ne.upd_cnt, en[(size_t)k * 6 + (size_t)assumed[(size_t)k]].inc,
+                                en[(size_t)k * 6 + (size_t)assumed[(size_t)k]].mu, en[(size_t)k * 6 + (size_t)assumed[(size_t)k]].omega, en[(size_t)k * 6 + (size_t)assumed[(size_t)k]].upd_cnt);
+                    en[(size_t)k * 6 + 5] = ne;
+                    sel[(size_t)k] = 5;
+                    assumed[(size_t)k] = -1;
+                    if (!as_assumed)
+                        first = std::min(first, k + 1); // what stood behind it stood on an assumption that did not hold: scanned again
+                }
+                // chunks that waited behind an assumed end state are scanned again from the first of them
+                for (int k = 1; k < K; k++)
+                    if (assumed[(size_t)k] >= 0)
+                    {
+                        first = std::min(first, k);
+                        break;
+                    }
+                if (first >= K)
+                    break;
+                from = first;
+                for (int k = from; k < K; k++)
+                    if (assumed[(size_t)k] >= 0)
+                        assumed[(size_t)k] = -1;
+            }
+            if (getenv("SDHIP_DEBUG"))
+                fprintf(stderr, "[sdhip] mmfast chunks %d x 5 cadences, L %d W %d  re-run %lld in %d round(s)%s\n", K, g.L, g.W, fixed, rounds, give_up ? "  -> one sequential lane" : "");
+            if (give_up)
+            {
+                stats.chunks_forced += 1;
+                return -1;
+            }
+            std::vector<long long> offs((size_t)K);
+            long long tot = 0;
+            for (int k = 0; k < K; k++)
+            {
+                const int c = cnt[(size_t)k * 6 + (size_t)sel[(size_t)k]];
+                if (c < 0)
+                    throw HipError("fast_clock_recovery_mm_cc: symbol row overflow");
+                offs[(size_t)k] = tot;
+                tot += c;
+            }
+            if ((size_t)tot > out_cap)
+                throw HipError("symbol output buffer too small");
+            SD_HIP(hipMemcpyAsync(d_mf_sel.p, sel.data(), (size_t)K * sizeof(int), hipMemcpyHostToDevice, stream));
+            SD_HIP(hipMemcpyAsync(d_mf_offs.p, offs.data(), (size_t)K * sizeof(long long), hipMemcpyHostToDevice, stream));
+            launch_mmfast_gather(d_mf_rows.p, d_mf_sel.p, d_mf_offs.p, d_mf_counts.p, K, cap, reinterpret_cast<cf32 *>(d_out), stream);
+            get_hist(A, n, hist_cos);
+            SD_HIP(hipStreamSynchronize(stream));
+            mm_s = en[((size_t)K - 1) * 6 + (size_t)sel[(size_t)K - 1]];
+            mm_s.inc -= n; // clock_recovery_mm_fast.cpp:153-156
+            if (mm_s.inc < 0)
+                mm_s.inc = 0;
+            stats.chunks += K;
+            stats.chunks_fixed += fixed;
+            last_symbols = tot;
+            return tot;
+        }
+
         // ---- ndsp::CostasFastBlock (dsp/pll/costas_fast.cpp), SDHIP_NDSP_COSTAS_FAST. exact: one sequential lane, bit for bit. Otherwise lane-per-chunk like the
         // plain loop: warm-up lanes start from the carried frequency (first call: the M-th power estimate) next to a stable point, renorm_ctr follows the
         // stream's sample count and is therefore known at every chunk start; the hand-off is judged on the HOST from the K start / end states (a few MB): the
@@ -1951,7 +2129,7 @@ namespace sdhip
             mm_p.q8 = (d_syms == nullptr && tap_mode == 0 && mm_p.loop != 1 && env_int("SDHIP_MM_Q8", is_bpsk ? 0 : 1) != 0) ? 1 : 0;
             mm_p.q8_bpsk = is_bpsk ? 1 : 0;
             mm_p.tap = tap_mode;
-            mm_p.fast = (!cfg.exact && env_int("SDHIP_FAST_MATH", 1) != 0) ? 1 : 0;
+            mm_p.fast = (!cfg.exact && mm_p.loop != 2 && env_int("SDHIP_FAST_MATH", 1) != 0) ? 1 : 0;
             mm_p.fast_mult = (float)env_int("SDHIP_MM_FAST_MULT", 8);
             mm_p.fast_syms = mm_p.fast_mult > 1.0f ? (int)env_int("SDHIP_MM_FAST_SYMS", (long long)(2.75 / gmu)) : 0;
             // a re-run costs one lane the whole chunk, so long chunks (large batches) keep the conservative warm-up: it is a
@@ -2447,6 +2625,15 @@ namespace sdhip
             { // MMClockRecoveryBlock<complex_t>::work (dsp/clock_recovery/clock_recovery_mm.cpp:66-183) on its own; GardnerClockRecoveryBlock<complex_t>::work
               // (dsp/clock_recovery/clock_recovery_gardner.cpp:60-170) on the same lanes with its own iteration (mm_p.loop)
                 SD_HIP(hipMemcpyAsync(A, d_in, (size_t)n * sizeof(cf32), hipMemcpyDeviceToDevice, stream));
+                if (nd.only == SDHIP_NDSP_MM_FAST)
+                { // lane per (chunk, cadence) with the bit-exact hand-off; -1: this call runs as the one sequential lane below
+                    const long long r = mmfast_stage(A, n, d_out, out_cap);
+                    if (r >= 0)
+                    {
+                        started = true;
+                        return r;
+                    }
+                }
                 const double omin1 = (double)mm_p.omega_mid - (double)mm_p.omega_limit;
                 const size_t symcap1 = (size_t)((double)n / std::max(0.5, omin1 - 0.01)) + 64;
                 if (symcap1 > out_cap + 64 && (size_t)((double)n / omin1) + 8 > out_cap)
@@ -2742,10 +2929,7 @@ extern "C"
         d.clock_mu = c->rec_mu;
         d.clock_gain_mu = c->rec_muGain;
         d.clock_omega_relative_limit = c->rec_omegaLimit;
-        // fast_clock_recovery_mm_cc runs as one sequential lane (include/sdhip.h). Measured on the twin: lanes with their own count of symbols
-        // update the rate term on another subset of the detector's outputs (every fifth symbol, clock_recovery_mm_fast.cpp:139-146) and end 0.05 - 0.2 sample
-        // from the sequential trajectory for good -- nothing a hand-off could certify without carrying all five cadences per chunk
-        d.exact = kind == SDHIP_NDSP_MM_FAST ? 1 : c->exact;
+        d.exact = c->exact;
         d.chunk_len = c->chunk_len;
         d.warmup = c->warmup;
         NdspExt e;

@@ -313,6 +313,11 @@ namespace sdhip
     // [first, first+count) of its scratch row go to offsets[k]
     void launch_quantize(const cf32 *sym_scratch, const int *seg, const long long *offsets, int K, int cap, int bpsk, int8_t *soft, long long soft_cap,
                          float *syms, long long syms_cap, hipStream_t st);
+    // fast_clock_recovery_mm_cc lane per (chunk, cadence) (k_mmfast): rows [K][6][cap], spec / endst / counts [K][6] (slot 5: re-runs); redo lanes start from redo_start[i]
+    // (chunk 0 -- W + L samples, one lane -- has its own row of cap0 symbols behind the others)
+    void launch_mmfast(const cf32 *x, cf32 *rows, int *counts, const ChunkGeom &g, int cap, int cap0, const MmParams &p, const MmState *start0, MmState *spec, MmState *endst,
+                       const int *redo, const MmState *redo_start, int nredo, hipStream_t st);
+    void launch_mmfast_gather(const cf32 *rows, const int *sel, const long long *offs, const int *counts, int K, int cap, cf32 *out, hipStream_t st);
     // the same compaction for scratch rows written by launch_mm with MmParams::q8 (sym_scratch then holds 2-byte entries)
     void launch_compact8(const cf32 *sym_scratch, const int *seg, const long long *offsets, int K, int cap, int bpsk, int8_t *soft, long long soft_cap,
                          hipStream_t st);

@@ -2466,6 +2466,40 @@ namespace sdhip
 
     // one iteration of MMClockRecoveryBlock<complex_t>::work's loop body, clock_recovery_mm.cpp:54-120; the window
     // [inc-7, inc] must be in the ring
+    // the body of ndsp::MMClockRecoveryFastBlock<complex_t>::work's loop behind its delay-line shift (dsp/clock_recovery/clock_recovery_mm_fast.cpp:108-150), x0 / x1 = the
+    // block's buffer[inc] / buffer[inc + 1] = samples inc - 7 / inc - 6 of the stream
+    __device__ __forceinline__ cf32 mmfast_core(MmState &s, const MmParams &p, const cf32 x0, const cf32 x1, const float omega_gain, const float mu_gain)
+    {
+        const float w0 = (float)(1.0 - (double)s.mu);
+        const float re = (x0.re * w0) + (x1.re * s.mu), im = (x0.im * w0) + (x1.im * s.mu);
+        s.p_0T.re = re;
+        s.p_0T.im = im;
+        s.c_0T.re = re > 0.0f ? 1.0f : 0.0f;
+        s.c_0T.im = im > 0.0f ? 1.0f : 0.0f;
+        const float ur = s.p_0T.re - s.p_2T.re, ui = s.p_0T.im - s.p_2T.im;
+        const float a_re = (ur * s.c_1T.re) - (ui * (-s.c_1T.im));
+        const float vr = s.c_0T.re - s.c_2T.re, vi = s.c_0T.im - s.c_2T.im;
+        const float b_re = (vr * s.p_1T.re) - (vi * (-s.p_1T.im));
+        float pe = a_re - b_re;
+        pe = pe < -1.0f ? -1.0f : (pe > 1.0f ? 1.0f : pe);
+        const cf32 out = s.p_0T;
+        if (s.upd_cnt++ == 4u)
+        {
+            s.upd_cnt = 0;
+            s.omega = s.omega + omega_gain * pe;
+            float d = s.omega - p.omega_mid;
+            d = d < -p.omega_limit ? -p.omega_limit : (d > p.omega_limit ? p.omega_limit : d);
+            s.omega = p.omega_mid + d;
+        }
+        s.mu = (s.mu + s.omega) + mu_gain * pe;
+        const float fl = floorf(s.mu);
+        s.inc += (long long)(int)fl;
+        s.mu = s.mu - fl;
+        if (s.inc < 0)
+            s.inc = 0;
+        return out;
+    }
+
     // LIN: ndsp::MMClockRecoveryFastBlock<complex_t>::work's loop body instead (dsp/clock_recovery/clock_recovery_mm_fast.cpp:96-150): the symbol is the linear
     // interpolation buffer[inc] * (1.0 - mu) + buffer[inc + 1] * mu -- samples inc - 7 and inc - 6 of the stream, the block's buffer holding ntaps - 1 = 7 samples of
     // history in front; (1.0 - mu) taken in double and rounded to the float complex_t::operator*(const float &) takes -- and the rate term moves on every fifth symbol
@@ -2480,35 +2514,7 @@ namespace sdhip
         if constexpr (LIN)
         {
             const int b0 = (int)((s.inc - 7) & (RING - 1)), b1 = (int)((s.inc - 6) & (RING - 1));
-            const cf32 x0 = ring[b0 * MM_RING_STRIDE], x1 = ring[b1 * MM_RING_STRIDE];
-            const float w0 = (float)(1.0 - (double)s.mu);
-            const float re = (x0.re * w0) + (x1.re * s.mu), im = (x0.im * w0) + (x1.im * s.mu);
-            s.p_0T.re = re;
-            s.p_0T.im = im;
-            s.c_0T.re = re > 0.0f ? 1.0f : 0.0f;
-            s.c_0T.im = im > 0.0f ? 1.0f : 0.0f;
-            const float ur = s.p_0T.re - s.p_2T.re, ui = s.p_0T.im - s.p_2T.im;
-            const float a_re = (ur * s.c_1T.re) - (ui * (-s.c_1T.im));
-            const float vr = s.c_0T.re - s.c_2T.re, vi = s.c_0T.im - s.c_2T.im;
-            const float b_re = (vr * s.p_1T.re) - (vi * (-s.p_1T.im));
-            float pe = a_re - b_re;
-            pe = pe < -1.0f ? -1.0f : (pe > 1.0f ? 1.0f : pe);
-            const cf32 out = s.p_0T;
-            if (s.upd_cnt++ == 4u)
-            {
-                s.upd_cnt = 0;
-                s.omega = s.omega + omega_gain * pe;
-                float d = s.omega - p.omega_mid;
-                d = d < -p.omega_limit ? -p.omega_limit : (d > p.omega_limit ? p.omega_limit : d);
-                s.omega = p.omega_mid + d;
-            }
-            s.mu = (s.mu + s.omega) + mu_gain * pe;
-            const float fl = floorf(s.mu);
-            s.inc += (long long)(int)fl;
-            s.mu = s.mu - fl;
-            if (s.inc < 0)
-                s.inc = 0;
-            return out;
+            return mmfast_core(s, p, ring[b0 * MM_RING_STRIDE], ring[b1 * MM_RING_STRIDE], omega_gain, mu_gain);
         }
         int imu = (int)rintf(s.mu * 128.0f);
         if (imu < 0)
@@ -3051,6 +3057,107 @@ template <bool CKPT, bool SPLIT, bool Q8 = false, bool FAST = false, bool GARD =
             go(k_mm<false, false>, nullptr, 0, 0.0f);
     }
 
+
+    // ---- fast_clock_recovery_mm_cc lane per (chunk, cadence) ------------------------------------------------------------------------------------------------
+    // The block's rate term moves on every fifth SYMBOL (omega_upd_cnt), and how many symbols lie in front of a chunk nobody knows before they have been
+    // counted -- so every chunk is run FIVE times, once per value of the counter at its warm-up's start. Lanes of the right cadence merge with the sequential
+    // trajectory bit for bit (measured on the reference block itself: 12 - 25 k symbols at the default gains, tools note in DESIGN 7b), and the engine picks for
+    // every chunk the variant whose state at the chunk start IS its predecessor's state at its end (DemodEngine::mmfast_stage). Variant-major lane order: a wave
+    // holds 64 consecutive chunks of one cadence. A lane reads samples inc - 7 and inc - 6 straight from memory (7 samples of history in front of x).
+    // rows: [K][6][cap] symbols; spec / endst / counts: [K][6]: slots 0 - 4 the cadences, slot 5 the re-run (exact start state redo_start[i]) of a chunk none of
+    // whose variants stood.
+    // (chunk 0 is W + L samples long and runs once: its row, cap0 symbols, lies behind the K x 5 rows of cap symbols)
+    __global__ __launch_bounds__(64) void k_mmfast(const cf32 *__restrict__ x, cf32 *rows, int *counts, ChunkGeom g, int cap, int cap0, MmParams p, const MmState *start0, MmState *spec,
+                                                   MmState *endst, const int *redo, const MmState *redo_start, int nredo)
+    {
+        const int idx = (int)(blockIdx.x * 64 + threadIdx.x);
+        int k, v;
+        MmState s;
+        if (redo)
+        {
+            if (idx >= nredo)
+                return;
+            k = redo[idx];
+            v = 5;
+            s = redo_start[idx];
+        }
+        else
+        {
+            if (idx >= 5 * g.K)
+                return;
+            v = idx / g.K;
+            k = idx - v * g.K;
+            if (k == 0)
+            {
+                if (v != 0)
+                    return;
+                s = *start0;
+            }
+            else
+            {
+                s.mu = p.init_mu;
+                s.omega = p.omega_mid;
+                s.p_2T = s.p_1T = s.p_0T = cf32{0.0f, 0.0f};
+                s.c_2T = s.c_1T = s.c_0T = cf32{0.0f, 0.0f};
+                s.inc = chunk_begin(g, k) - g.W;
+                s.upd_cnt = (unsigned)v;
+                s.pad = 0;
+            }
+        }
+        auto iter = [&]() {
+            s.p_2T = s.p_1T;
+            s.p_1T = s.p_0T;
+            s.c_2T = s.c_1T;
+            s.c_1T = s.c_0T;
+            const cf32 x0 = x[s.inc - 7], x1 = x[s.inc - 6];
+            return mmfast_core(s, p, x0, x1, p.omega_gain, p.mu_gain);
+        };
+        const long long b = chunk_begin(g, k), e = chunk_end(g, k);
+        const size_t slot = (size_t)k * 6 + (size_t)v;
+        if (!redo && k > 0)
+        {
+            while (s.inc < b)
+                (void)iter();
+            spec[slot] = s;
+        }
+        cf32 *row = k == 0 ? rows + (size_t)g.K * 6 * (size_t)cap : rows + slot * (size_t)cap;
+        const int room = k == 0 ? cap0 : cap;
+        int cnt = 0;
+        while (s.inc < e && cnt < room)
+            row[cnt++] = iter();
+        endst[slot] = s;
+        counts[slot] = s.inc < e ? -1 : cnt; // -1: the row overflowed (cannot happen inside the omega limits the engine admits)
+    }
+    void launch_mmfast(const cf32 *x, cf32 *rows, int *counts, const ChunkGeom &g, int cap, int cap0, const MmParams &p, const MmState *start0, MmState *spec, MmState *endst,
+                       const int *redo, const MmState *redo_start, int nredo, hipStream_t st)
+    {
+        const int n = redo ? nredo : 5 * g.K;
+        if (n <= 0)
+            return;
+        ProfScope _ps("k_mmfast", st);
+        hipLaunchKernelGGL(k_mmfast, dim3((n + 63) / 64), dim3(64), 0, st, x, rows, counts, g, cap, cap0, p, start0, spec, endst, redo, redo_start, nredo);
+    }
+    // the chosen variants' rows, end to end: a block per chunk
+    __global__ __launch_bounds__(256) void k_mmfast_gather(const cf32 *__restrict__ rows, const int *__restrict__ sel, const long long *__restrict__ offs, const int *__restrict__ counts, int K,
+                                                           int cap, cf32 *out)
+    {
+        const int k = (int)blockIdx.x;
+        if (k >= K)
+            return;
+        const size_t slot = (size_t)k * 6 + (size_t)sel[k];
+        const int cnt = counts[slot];
+        const cf32 *row = k == 0 ? rows + (size_t)K * 6 * (size_t)cap : rows + slot * (size_t)cap;
+        cf32 *o = out + offs[k];
+        for (int i = (int)threadIdx.x; i < cnt; i += 256)
+            o[i] = row[i];
+    }
+    void launch_mmfast_gather(const cf32 *rows, const int *sel, const long long *offs, const int *counts, int K, int cap, cf32 *out, hipStream_t st)
+    {
+        if (K <= 0)
+            return;
+        ProfScope _ps("k_mmfast_gather", st);
+        hipLaunchKernelGGL(k_mmfast_gather, dim3(K), dim3(256), 0, st, rows, sel, offs, counts, K, cap, out);
+    }
 
     __global__ __launch_bounds__(256) void k_quantize(const cf32 *sym, const int *seg, const long long *offsets, int K, int cap, int bpsk, int8_t *soft,
                                                       long long soft_cap, float *syms, long long syms_cap)

@@ -133,8 +133,8 @@ _SINGLE = {
     # dsp/clock_recovery/clock_recovery_gardner.h:15-21, 57-130: the M&M block's keys (its own default omega is 0: set it)
     "clock_recovery_gardner_cc": (NDSP_GARDNER, {"omega": "rec_omega", "omegaGain": "rec_omegaGain", "mu": "rec_mu", "muGain": "rec_muGain", "omegaLimit": "rec_omegaLimit",
                                                  "nfilt": "rec_nfilt", "ntaps": "rec_ntaps"}),
-    # dsp/pll/costas_fast.h:63-104 (the Costas block's keys) and dsp/clock_recovery/clock_recovery_mm_fast.h:59-116 (the M&M block's without the bank's shape). The clock
-    # recovery always runs as one sequential lane; the carrier loop lane-per-chunk with a bit-exact hand-off (include/sdhip.h): both bit for bit the block
+    # dsp/pll/costas_fast.h:63-104 (the Costas block's keys) and dsp/clock_recovery/clock_recovery_mm_fast.h:59-116 (the M&M block's without the bank's shape). Both run
+    # lane-per-chunk with a bit-exact hand-off (the clock recovery under all five cadences of its rate update per chunk; include/sdhip.h): bit for bit the blocks
     "costas_fast_cc": (NDSP_COSTAS_FAST, {"loop_bw": "pll_loop_bw", "freq_limit": "pll_freq_limit"}),
     "fast_clock_recovery_mm_cc": (NDSP_MM_FAST, {"omega": "rec_omega", "omegaGain": "rec_omegaGain", "mu": "rec_mu", "muGain": "rec_muGain", "omegaLimit": "rec_omegaLimit"}),
 }

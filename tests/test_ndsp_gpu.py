@@ -352,5 +352,37 @@ def test_ndsp_costas_fast_chunk_parallel(torch_cuda, capi, nref, strict):
     check_costas_fast_chunk_parallel(capi, nref, strict=strict)
 
 
+def check_mm_fast_chunk_parallel(capi, nref, n_sym=200000):
+    """fast_clock_recovery_mm_cc lane per (chunk, cadence) (DemodEngine::mmfast_stage, k_mmfast): the block's rate term moves on every fifth SYMBOL, so every chunk runs
+    once per value of that counter and the engine keeps the variant whose state at the chunk start is bit for bit its predecessor's state at its end -- the output is the
+    reference block's, float for float, over three calls with the state carried across them; no call falls back to the one sequential lane. Default gains (the
+    block's own: muGain 8.7e-3 -- lanes of the right cadence need 12 - 25 k symbols to merge with the sequential trajectory down to the last bit of the rate)."""
+    from satdump_amd import ndsp
+    sr = 6e6
+    x = _signal("qpsk", n_sym, samplerate=sr, symbolrate=2e6, esn0=10.0, seed=9)
+    x = nref.run("agc_cc", {"rate": 1e-3, "reference": 0.6}, nref.run("rrc_fir_cc", {"samplerate": sr, "symbolrate": 2e6, "alpha": 0.35}, x, buf=8192), buf=8192)
+    cfg = {"omega": 3.0}
+    want = nref.run("fast_clock_recovery_mm_cc", cfg, x, buf=8192)
+    blk = ndsp.SingleBlock("fast_clock_recovery_mm_cc", exact=False, capi_mod=capi)
+    for k2, v in cfg.items():
+        assert blk.set_cfg(k2, v) == ndsp.RES_OK
+    cuts = [0, len(x) // 2 + 5, len(x) - 150001, len(x)]
+    got, chunks, forced, fixed = [], 0, 0, 0
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        got.append(blk.work(x[a:b]))
+        st = blk.stats()
+        chunks += st.chunks
+        forced += st.chunks_forced
+        fixed += st.chunks_fixed
+    blk.stop()
+    got = np.concatenate(got)
+    assert chunks >= 40 and forced == 0 and fixed * 4 < chunks, (chunks, forced, fixed)
+    assert len(got) == len(want) and np.array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
+def test_ndsp_mm_fast_chunk_parallel(torch_cuda, capi, nref):
+    check_mm_fast_chunk_parallel(capi, nref)
+
+
 def test_ndsp_agc_scan_start_gains(torch_cuda, capi, nref):
     check_agc_scan_start_gains(capi, nref)
