@@ -1616,6 +1616,8 @@ namespace sdhip
             std::vector<int> sel((size_t)K, 0);
             std::vector<char> exact_end((size_t)K, 0); // chunk k's standing row ends in a state that is known (not assumed)
             std::vector<int> assumed((size_t)K, -1);   // a chunk waiting for its re-run: the variant whose end state the scan behind it assumed
+            std::vector<MmState> rr_start((size_t)K);  // the state a chunk's re-run (slot 5) started from ...
+            std::vector<char> rr_done((size_t)K, 0);   // ... once it has run: it stands for as long as the predecessor still ends in that state
             long long fixed = 0;
             int rounds = 0;
             bool give_up = false;
@@ -1643,12 +1645,20 @@ namespace sdhip
                         assumed[(size_t)k] = -1;
                         continue;
                     }
+                    if (rr_done[(size_t)k] && assumed[(size_t)k - 1] < 0 && same(rr_start[(size_t)k], *prev))
+                    { // re-run in an earlier round from exactly this state: its row and end state (slot 5) stand
+                        sel[(size_t)k] = 5;
+                        assumed[(size_t)k] = -1;
+                        continue;
+                    }
                     // none fits: re-run from the predecessor's end state if that is known; the scan goes on behind this chunk assuming its re-run will end where the
                     // variant of the predecessor's cadence ended (the lanes of one cadence have usually merged by then)
                     if (assumed[(size_t)k - 1] < 0)
                     {
                         redo.push_back(k);
                         redo_start.push_back(*prev);
+                        rr_start[(size_t)k] = *prev;
+                        rr_done[(size_t)k] = 0;
                     }
                     int guess = -1;
                     for (int v = 0; v < 5 && guess < 0; v++)
@@ -1661,7 +1671,8 @@ namespace sdhip
                 }
                 if (redo.empty())
                     break;
-                if (++rounds > 8 || (long long)redo.size() * 4 > (long long)K)
+                // (a stretch of stream on which the lanes need longer than the warm-up to merge fails as a run of neighbouring chunks: one round per chunk of it)
+                if (++rounds > 40 || (long long)redo.size() * 4 > (long long)K)
                 {
                     give_up = true;
                     break;
@@ -1677,8 +1688,9 @@ namespace sdhip
                     SD_HIP(hipMemcpyAsync(&ne, d_mf_end.p + (size_t)k * 6 + 5, sizeof(MmState), hipMemcpyDeviceToHost, stream));
                     SD_HIP(hipMemcpyAsync(&cnt[(size_t)k * 6 + 5], d_mf_counts.p + (size_t)k * 6 + 5, sizeof(int), hipMemcpyDeviceToHost, stream));
                     SD_HIP(hipStreamSynchronize(stream));
+                    rr_done[(size_t)k] = 1;
                     const bool as_assumed = same(ne, en[(size_t)k * 6 + (size_t)assumed[(size_t)k]]);
-                    if (getenv("SDHIP_DEBUG"))
+                    if (getenv("SDHIP_DEBUG") && k < 64)
                         fprintf(stderr, "[sdhip]   mmfast chunk %d re-run: assumed variant %d, ended as assumed: %d (inc %lld mu %.9g omega %.9g cnt %u | assumed inc %lld mu %.9g omega %.9g cnt %u)\n", k,
                                 assumed[(size_t)k], (int)as_assumed, ne.inc, ne.mu, ne.omega, ne.upd_cnt, en[(size_t)k * 6 + (size_t)assumed[(size_t)k]].inc,
                                 en[(size_t)k * 6 + (size_t)assumed[(size_t)k]].mu, en[(size_t)k * 6 + (size_t)assumed[(size_t)k]].omega, en[(size_t)k * 6 + (size_t)assumed[(size_t)k]].upd_cnt);

@@ -384,5 +384,27 @@ def test_ndsp_mm_fast_chunk_parallel(torch_cuda, capi, nref):
     check_mm_fast_chunk_parallel(capi, nref)
 
 
+def check_mm_fast_short_warmup(capi, nref):
+    """The same lanes behind a warm-up that is too short for some stretches of the stream (70 k samples where the default is 103 k): chunks fail in runs of neighbours, each
+    round re-runs the ones whose predecessor's end state is known (valid re-runs are kept across the rescans), and the output is still the block's own, float for float."""
+    from satdump_amd import ndsp
+    sr = 6e6
+    x = _signal("qpsk", 330000, samplerate=sr, symbolrate=2e6, esn0=10.0, seed=9)
+    x = nref.run("agc_cc", {"rate": 1e-3, "reference": 0.6}, nref.run("rrc_fir_cc", {"samplerate": sr, "symbolrate": 2e6, "alpha": 0.35}, x, buf=8192), buf=8192)
+    want = nref.run("fast_clock_recovery_mm_cc", {"omega": 3.0}, x, buf=8192)
+    blk = ndsp.SingleBlock("fast_clock_recovery_mm_cc", exact=False, capi_mod=capi)
+    assert blk.set_cfg("omega", 3.0) == ndsp.RES_OK
+    blk._cfg.warmup = 70000
+    got = blk.work(x)
+    st = blk.stats()
+    blk.stop()
+    assert st.chunks > 100 and st.chunks_fixed > 10 and st.chunks_forced == 0, (st.chunks, st.chunks_fixed, st.chunks_forced)
+    assert len(got) == len(want) and np.array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
+def test_ndsp_mm_fast_short_warmup(torch_cuda, capi, nref):
+    check_mm_fast_short_warmup(capi, nref)
+
+
 def test_ndsp_agc_scan_start_gains(torch_cuda, capi, nref):
     check_agc_scan_start_gains(capi, nref)

@@ -15,3 +15,4 @@ test_ndsp_single_block_handles = N.test_ndsp_single_block_handles
 test_ndsp_agc_scan_start_gains = N.test_ndsp_agc_scan_start_gains
 test_ndsp_costas_fast_chunk_parallel = N.test_ndsp_costas_fast_chunk_parallel
 test_ndsp_mm_fast_chunk_parallel = N.test_ndsp_mm_fast_chunk_parallel
+test_ndsp_mm_fast_short_warmup = N.test_ndsp_mm_fast_short_warmup
